@@ -1,0 +1,801 @@
+// rodio_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of rodio's per-sample DSP hot path.
+// It is the *checker* for the HIP kernels in rodio_amd/csrc and the "port"
+// CPU baseline of bench.py.  Nothing in the product path (rodio_amd/, the
+// C-ABI library) may include, link or call this file.
+//
+// The reference is Rust and cannot be compiled in this environment (no
+// cargo/rustc), so this is a restatement, not the reference itself.  It keeps
+// the reference's *structure*: a pull iterator per adapter, a virtual call
+// where rodio has `Box<dyn Source>`, std::deque where rodio has VecDeque, f32
+// arithmetic with the same parenthesisation.  Build with
+//   g++ -O2 -ffp-contract=off   (Rust never contracts a*b+c)
+// and WITHOUT -march=native so the .so runs on any x86-64 host.
+//
+// Pinned against the reference's own golden vectors by tests/test_oracle_golden.py
+// (sample_rate.rs:356-387, channels.rs:114-177, mixer.rs:208-341,
+// channel_volume.rs:135-166, math.rs:238-339).  Unpinned by the reference
+// (it has no numeric tests for them): biquad, AGC, reverb, spatial gains,
+// amplify, limiter (range tests only), sample-type conversion (dasp_sample
+// 0.11.0, an un-vendored dependency: formulas restated from the published
+// crate).  Those rows are "parity unpinned" -- see DESIGN.md.
+//
+// Citations are file:line under /root/reference.
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- Source ----
+// src/source/mod.rs:179-218 -- `trait Source: Iterator<Item = Sample>`.
+// next() returns false for rodio's `None`.
+struct Source {
+    virtual ~Source() {}
+    virtual bool next(float &out) = 0;
+    // current_span_len(): -1 encodes None.
+    virtual long current_span_len() const = 0;
+    virtual uint16_t channels() const = 0;
+    virtual uint32_t sample_rate() const = 0;
+};
+
+// A plain sample iterator (what `Vec<f32>::into_iter()` is in the reference's
+// unit tests).  Also plays benches/shared.rs:6-46 `TestSource`
+// (current_span_len = None) and src/buffer.rs:74-82 `SamplesBuffer`
+// (current_span_len = Some(len) until exhausted, then Some(0)).
+struct VecSource : Source {
+    std::vector<float> data;
+    size_t pos = 0;
+    uint16_t ch;
+    uint32_t rate;
+    long span;  // -1: None (TestSource); -2: SamplesBuffer rule; k>=0: constant Some(k)
+    VecSource(const float *d, size_t n, uint16_t c, uint32_t r, long sp)
+        : data(d, d + n), ch(c), rate(r), span(sp) {}
+    bool next(float &out) override {
+        if (pos >= data.size()) return false;
+        out = data[pos++];
+        return true;
+    }
+    long current_span_len() const override {
+        if (span == -2) return pos >= data.size() ? 0 : (long)data.size();  // buffer.rs:76-82
+        return span;
+    }
+    uint16_t channels() const override { return ch; }
+    uint32_t sample_rate() const override { return rate; }
+};
+
+// src/math.rs:23-26
+inline float lerp(float first, float second, uint32_t numerator, uint32_t denominator) {
+    return first + (second - first) * (float)numerator / (float)denominator;
+}
+
+// src/math.rs:51-56 -- Float::powf(2.0, dB * 0.05 * LOG2_10)
+constexpr float LOG2_10 = 3.32192809488736234787f;
+constexpr float LOG10_2 = 0.301029995663981195214f;
+constexpr float PI_F = 3.14159265358979323846264338327950288f;
+inline float db_to_linear(float db) { return powf(2.0f, db * 0.05f * LOG2_10); }
+// src/math.rs:86-90
+inline float linear_to_db(float lin) { return log2f(lin) * LOG10_2 * 20.0f; }
+// std::time::Duration::as_secs_f32 (src/math.rs:118-122): secs as f32 + nanos as f32 / 1e9
+inline float duration_to_float(uint64_t ns) {
+    uint64_t secs = ns / 1000000000ull;
+    uint32_t nanos = (uint32_t)(ns % 1000000000ull);
+    return (float)secs + (float)nanos / 1000000000.0f;
+}
+// src/math.rs:110-113
+inline float duration_to_coefficient(uint64_t ns, uint32_t sample_rate) {
+    return expf(-1.0f / (duration_to_float(ns) * (float)sample_rate));
+}
+
+// ------------------------------------------------- SampleRateConverter ----
+// src/conversions/sample_rate.rs:52-90 (new), :110-122 (next_input_span),
+// :131-201 (next).  `owned` says whether the converter deletes its input (the
+// Uniform iterator takes the input back out, uniform.rs:82-83).
+struct SampleRateConverter : Source {
+    Source *input;
+    bool owned;
+    uint32_t from, to;
+    uint16_t ch;
+    uint32_t out_rate;
+    std::vector<float> current_span, next_frame;
+    uint32_t current_span_pos_in_chunk = 0;
+    uint32_t next_output_span_pos_in_chunk = 0;
+    std::deque<float> output_buffer;
+
+    SampleRateConverter(Source *in, uint32_t from_rate, uint32_t to_rate, uint16_t channels,
+                        bool own = true)
+        : input(in), owned(own), ch(channels), out_rate(to_rate) {
+        if (from_rate != to_rate) {  // :58-71
+            take_frame(current_span);
+            take_frame(next_frame);
+        }
+        // :74 Ratio::new(to, from).into_raw() == divide both by gcd
+        uint32_t g = std::gcd(from_rate, to_rate);
+        from = from_rate / g;
+        to = to_rate / g;
+    }
+    ~SampleRateConverter() override {
+        if (owned) delete input;
+    }
+    void take_frame(std::vector<float> &dst) {
+        dst.clear();
+        for (uint16_t c = 0; c < ch; ++c) {
+            float v;
+            if (input->next(v)) dst.push_back(v);
+            else break;
+        }
+    }
+    void next_input_span() {  // :110-122
+        current_span_pos_in_chunk += 1;
+        std::swap(current_span, next_frame);
+        take_frame(next_frame);
+    }
+    bool next(float &out) override {
+        if (from == to) return input->next(out);  // :133-136
+        if (!output_buffer.empty()) {             // :139-141
+            out = output_buffer.front();
+            output_buffer.pop_front();
+            return true;
+        }
+        if (next_output_span_pos_in_chunk == to) {  // :146-154
+            next_output_span_pos_in_chunk = 0;
+            next_input_span();
+            while (current_span_pos_in_chunk != from) next_input_span();
+            current_span_pos_in_chunk = 0;
+        } else {  // :155-167  (u32 arithmetic, wraps like release-mode Rust)
+            uint32_t req_left_sample = (from * next_output_span_pos_in_chunk / to) % from;
+            while (current_span_pos_in_chunk != req_left_sample) next_input_span();
+        }
+        bool have = false;
+        float result = 0.f;
+        uint32_t numerator = (from * next_output_span_pos_in_chunk) % to;  // :173
+        size_t n = std::min(current_span.size(), next_frame.size());      // zip, :174-179
+        for (size_t off = 0; off < n; ++off) {
+            float sample = lerp(current_span[off], next_frame[off], numerator, to);
+            if (off == 0) {
+                result = sample;
+                have = true;
+            } else {
+                output_buffer.push_back(sample);
+            }
+        }
+        next_output_span_pos_in_chunk += 1;  // :190
+        if (have) {
+            out = result;
+            return true;
+        }
+        // :193-200 draining `current_span`
+        if (current_span.empty()) return false;
+        out = current_span[0];
+        for (size_t k = 1; k < current_span.size(); ++k) output_buffer.push_back(current_span[k]);
+        current_span.clear();
+        return true;
+    }
+    long current_span_len() const override { return -1; }
+    uint16_t channels() const override { return ch; }
+    uint32_t sample_rate() const override { return out_rate; }
+};
+
+// ------------------------------------------------ ChannelCountConverter ----
+// src/conversions/channels.rs:57-85
+struct ChannelCountConverter : Source {
+    Source *input;
+    bool owned;
+    uint16_t from, to;
+    bool have_repeat = false;
+    float sample_repeat = 0.f;
+    uint16_t next_output_sample_pos = 0;
+    ChannelCountConverter(Source *in, uint16_t f, uint16_t t, bool own = true)
+        : input(in), owned(own), from(f), to(t) {}
+    ~ChannelCountConverter() override {
+        if (owned) delete input;
+    }
+    bool next(float &out) override {
+        bool some;
+        float value = 0.f;
+        if (next_output_sample_pos == 0) {
+            some = input->next(value);
+            have_repeat = some;
+            sample_repeat = value;
+        } else if (next_output_sample_pos < from) {
+            some = input->next(value);
+        } else if (next_output_sample_pos == 1) {
+            some = have_repeat;
+            value = sample_repeat;
+        } else {
+            some = true;
+            value = 0.0f;
+        }
+        if (some) next_output_sample_pos += 1;
+        if (next_output_sample_pos == to) {
+            next_output_sample_pos = 0;
+            if (from > to) {
+                float dump;
+                for (uint16_t k = to; k < from; ++k) input->next(dump);
+            }
+        }
+        out = value;
+        return some;
+    }
+    long current_span_len() const override { return -1; }
+    uint16_t channels() const override { return to; }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// src/source/uniform.rs:148-178 (private `Take`)
+struct Take : Source {
+    Source *iter;  // never owned: Uniform takes it back
+    bool limited;
+    size_t n;
+    Take(Source *it, long span) : iter(it), limited(span >= 0), n(span >= 0 ? (size_t)span : 0) {}
+    bool next(float &out) override {
+        if (limited) {
+            if (n != 0) {
+                n -= 1;
+                return iter->next(out);
+            }
+            return false;
+        }
+        return iter->next(out);
+    }
+    long current_span_len() const override { return -1; }
+    uint16_t channels() const override { return iter->channels(); }
+    uint32_t sample_rate() const override { return iter->sample_rate(); }
+};
+
+// ------------------------------------------------ UniformSourceIterator ----
+// src/source/uniform.rs:50-97: ChannelCountConverter<SampleRateConverter<Take<I>>>
+// re-bootstrapped whenever the inner chain runs dry (i.e. every span).
+struct UniformSourceIterator : Source {
+    Source *input;  // owned
+    uint16_t target_channels;
+    uint32_t target_rate;
+    std::unique_ptr<Take> take;
+    std::unique_ptr<SampleRateConverter> src;
+    std::unique_ptr<ChannelCountConverter> ccc;
+    UniformSourceIterator(Source *in, uint16_t ch, uint32_t rate)
+        : input(in), target_channels(ch), target_rate(rate) {}
+    ~UniformSourceIterator() override { delete input; }
+    void bootstrap() {  // :50-68
+        long span = input->current_span_len();
+        if (span >= 0 && span > 32768) span = 32768;  // :56
+        uint16_t from_channels = input->channels();
+        uint32_t from_rate = input->sample_rate();
+        ccc.reset();
+        src.reset();
+        take.reset(new Take(input, span));
+        src.reset(new SampleRateConverter(take.get(), from_rate, target_rate, from_channels, false));
+        ccc.reset(new ChannelCountConverter(src.get(), from_channels, target_channels, false));
+    }
+    bool next(float &out) override {  // :78-97
+        if (ccc && ccc->next(out)) return true;
+        bootstrap();
+        return ccc->next(out);
+    }
+    long current_span_len() const override { return -1; }  // :104-106
+    uint16_t channels() const override { return target_channels; }
+    uint32_t sample_rate() const override { return target_rate; }
+};
+
+// --------------------------------------------------------------- Mixer ----
+// src/mixer.rs:120-136 (next), :175-183 (start_pending_sources),
+// :185-198 (sum_current_sources).  `add` wraps in UniformSourceIterator (:58-66).
+struct MixerSource : Source {
+    uint16_t ch;
+    uint32_t rate;
+    std::vector<Source *> current_sources, still_pending, channel_rx;
+    uint16_t current_channel = 0;
+    MixerSource(uint16_t c, uint32_t r) : ch(c), rate(r) {}
+    ~MixerSource() override {
+        for (auto *s : current_sources) delete s;
+        for (auto *s : still_pending) delete s;
+        for (auto *s : channel_rx) delete s;
+    }
+    void add(Source *s) { channel_rx.push_back(new UniformSourceIterator(s, ch, rate)); }
+    bool next(float &out) override {
+        // start_pending_sources
+        for (auto *s : channel_rx) still_pending.push_back(s);
+        channel_rx.clear();
+        if (current_channel == 0) {
+            for (auto *s : still_pending) current_sources.push_back(s);
+            still_pending.clear();
+        }
+        // sum_current_sources: ordered f32 sum + retain_mut
+        float sum = 0.0f;
+        size_t w = 0;
+        for (size_t i = 0; i < current_sources.size(); ++i) {
+            float v;
+            if (current_sources[i]->next(v)) {
+                sum += v;
+                current_sources[w++] = current_sources[i];
+            } else {
+                delete current_sources[i];
+            }
+        }
+        current_sources.resize(w);
+        current_channel += 1;
+        if (current_channel >= ch) current_channel = 0;
+        if (current_sources.empty()) return false;
+        out = sum;
+        return true;
+    }
+    long current_span_len() const override { return -1; }
+    uint16_t channels() const override { return ch; }
+    uint32_t sample_rate() const override { return rate; }
+};
+
+// ------------------------------------------------------------- Amplify ----
+// src/source/amplify.rs:64
+struct Amplify : Source {
+    Source *input;
+    float factor;
+    Amplify(Source *in, float f) : input(in), factor(f) {}
+    ~Amplify() override { delete input; }
+    bool next(float &out) override {
+        float v;
+        if (!input->next(v)) return false;
+        out = v * factor;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// ----------------------------------------------------------- BltFilter ----
+// src/source/blt.rs:502-544 (to_applier), :558-560 (apply), :397-410/:431-451/
+// :472-492 (Mono/Stereo/Multi all reduce to per-channel state indexed by
+// position mod C).  Span-change re-coefficienting (:119-141) is not restated:
+// every source used with the oracle has constant parameters.
+struct BltFilter : Source {
+    Source *input;
+    float b0, b1, b2, a1, a2;
+    std::vector<float> x1, x2, y1, y2;
+    size_t position = 0;
+    BltFilter(Source *in, bool high_pass, uint32_t freq, float q) : input(in) {
+        uint32_t fs = in->sample_rate();
+        float w0 = 2.0f * PI_F * (float)freq / (float)fs;
+        float rb0, rb1, rb2, ra0, ra1, ra2;
+        if (!high_pass) {  // :504-521
+            float alpha = sinf(w0) / (2.0f * q);
+            rb1 = 1.0f - cosf(w0);
+            rb0 = rb1 / 2.0f;
+            rb2 = rb0;
+            ra0 = 1.0f + alpha;
+            ra1 = -2.0f * cosf(w0);
+            ra2 = 1.0f - alpha;
+        } else {  // :523-542
+            float cos_w0 = cosf(w0);
+            float alpha = sinf(w0) / (2.0f * q);
+            rb0 = (1.0f + cos_w0) / 2.0f;
+            rb1 = -1.0f - cos_w0;
+            rb2 = rb0;
+            ra0 = 1.0f + alpha;
+            ra1 = -2.0f * cos_w0;
+            ra2 = 1.0f - alpha;
+        }
+        b0 = rb0 / ra0;
+        b1 = rb1 / ra0;
+        b2 = rb2 / ra0;
+        a1 = ra1 / ra0;
+        a2 = ra2 / ra0;
+        size_t n = in->channels();
+        x1.assign(n, 0.f);
+        x2.assign(n, 0.f);
+        y1.assign(n, 0.f);
+        y2.assign(n, 0.f);
+    }
+    ~BltFilter() override { delete input; }
+    bool next(float &out) override {
+        float sample;
+        if (!input->next(sample)) return false;
+        size_t c = position;
+        position = (position + 1) % x1.size();
+        // :559 left-to-right
+        float result = b0 * sample + b1 * x1[c] + b2 * x2[c] - a1 * y1[c] - a2 * y2[c];
+        y2[c] = y1[c];
+        x2[c] = x1[c];
+        y1[c] = result;
+        x1[c] = sample;
+        out = result;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// --------------------------------------------------------------- Delay ----
+// src/source/delay.rs:8-16 (remaining_samples), :68-75 (next)
+struct Delay : Source {
+    Source *input;
+    size_t remaining_samples;
+    Delay(Source *in, uint64_t ns) : input(in) {
+        unsigned __int128 s = (unsigned __int128)ns * in->channels() * in->sample_rate() /
+                              1000000000ull;
+        remaining_samples = (size_t)s;
+    }
+    ~Delay() override { delete input; }
+    bool next(float &out) override {
+        if (remaining_samples >= 1) {
+            remaining_samples -= 1;
+            out = 0.0f;
+            return true;
+        }
+        return input->next(out);
+    }
+    long current_span_len() const override {
+        long l = input->current_span_len();
+        return l < 0 ? l : l + (long)remaining_samples;
+    }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// ----------------------------------------------------------------- Mix ----
+// src/source/mix.rs:10-22 (both inputs wrapped in UniformSourceIterator at
+// input1's format), :43-53 (next)
+struct Mix : Source {
+    UniformSourceIterator *in1, *in2;
+    Mix(Source *a, Source *b) {
+        uint16_t c = a->channels();
+        uint32_t r = a->sample_rate();
+        in1 = new UniformSourceIterator(a, c, r);
+        in2 = new UniformSourceIterator(b, c, r);
+    }
+    ~Mix() override {
+        delete in1;
+        delete in2;
+    }
+    bool next(float &out) override {
+        float s1, s2;
+        bool h1 = in1->next(s1);
+        bool h2 = in2->next(s2);
+        if (h1 && h2) out = s1 + s2;
+        else if (h1) out = s1;
+        else if (h2) out = s2;
+        else return false;
+        return true;
+    }
+    long current_span_len() const override { return -1; }
+    uint16_t channels() const override { return in1->channels(); }
+    uint32_t sample_rate() const override { return in1->sample_rate(); }
+};
+
+// -------------------------------------------------------- ChannelVolume ----
+// src/source/channel_volume.rs:29-37 (new), :71-88 (next)
+struct ChannelVolume : Source {
+    Source *input;
+    std::vector<float> channel_volumes;
+    size_t current_channel;
+    bool have_sample = false;
+    float current_sample = 0.f;
+    ChannelVolume(Source *in, const float *g, size_t n)
+        : input(in), channel_volumes(g, g + n), current_channel(n) {}
+    ~ChannelVolume() override { delete input; }
+    bool next(float &out) override {
+        if (current_channel >= channel_volumes.size()) {
+            current_channel = 0;
+            have_sample = false;
+            uint16_t ic = input->channels();
+            for (uint16_t k = 0; k < ic; ++k) {
+                float s;
+                if (!input->next(s)) return false;  // `?`
+                current_sample = (have_sample ? current_sample : 0.0f /*EQUILIBRIUM*/) + s;
+                have_sample = true;
+            }
+            if (have_sample) current_sample = current_sample / (float)ic;
+        }
+        bool some = have_sample;
+        if (some) out = current_sample * channel_volumes[current_channel];
+        current_channel += 1;
+        return some;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return (uint16_t)channel_volumes.size(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// src/source/spatial.rs:19-24 (dist_sq), :48-69 (set_positions)
+inline float dist_sq(const float *a, const float *b) {
+    float s = 0.0f;  // Iterator::sum over non-negative terms
+    for (int k = 0; k < 3; ++k) s += (a[k] - b[k]) * (a[k] - b[k]);
+    return s;
+}
+void spatial_gains(const float *emitter, const float *left, const float *right, float *out) {
+    float left_dist_sq = dist_sq(left, emitter);
+    float right_dist_sq = dist_sq(right, emitter);
+    float max_diff = sqrtf(dist_sq(left, right));
+    float left_dist = sqrtf(left_dist_sq);
+    float right_dist = sqrtf(right_dist_sq);
+    float left_diff_modifier = fminf(((left_dist - right_dist) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f);
+    float right_diff_modifier = fminf(((right_dist - left_dist) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f);
+    float left_dist_modifier = fminf(1.0f / left_dist_sq, 1.0f);
+    float right_dist_modifier = fminf(1.0f / right_dist_sq, 1.0f);
+    out[0] = left_diff_modifier * left_dist_modifier;
+    out[1] = right_diff_modifier * right_dist_modifier;
+}
+
+// --------------------------------------------------------------- Limit ----
+// src/source/limit.rs:94-130 (constructor), :853-873 (process_sample),
+// :876-916 (LimitBase), :927-988 (Mono/Stereo/Multi gain coupling)
+struct Limit : Source {
+    Source *input;
+    float threshold, knee_width, inv_knee_8, attack, release;
+    std::vector<float> integrators, peaks;
+    size_t position = 0;
+    Limit(Source *in, float thr, float knee, uint64_t attack_ns, uint64_t release_ns) : input(in) {
+        uint32_t sr = in->sample_rate();
+        attack = duration_to_coefficient(attack_ns, sr);
+        release = duration_to_coefficient(release_ns, sr);
+        threshold = thr;
+        knee_width = knee;
+        inv_knee_8 = 1.0f / (8.0f * knee);
+        integrators.assign(in->channels(), 0.f);
+        peaks.assign(in->channels(), 0.f);
+    }
+    ~Limit() override { delete input; }
+    float process_sample(float sample) const {
+        float bias_db = linear_to_db(fabsf(sample) + std::numeric_limits<float>::min()) - threshold;
+        float knee_boundary_db = bias_db * 2.0f;
+        if (knee_boundary_db < -knee_width) return 0.0f;
+        if (fabsf(knee_boundary_db) <= knee_width) {
+            float x = knee_boundary_db + knee_width;
+            return x * x * inv_knee_8;
+        }
+        return bias_db;
+    }
+    bool next(float &out) override {
+        float sample;
+        if (!input->next(sample)) return false;
+        size_t c = position;
+        position = (position + 1) % integrators.size();
+        float limiter_db = process_sample(sample);
+        integrators[c] = fmaxf(limiter_db, release * integrators[c] + (1.0f - release) * limiter_db);
+        peaks[c] = attack * peaks[c] + (1.0f - attack) * integrators[c];
+        float max_peak;
+        size_t n = peaks.size();
+        if (n == 1) max_peak = peaks[0];                       // :933
+        else if (n == 2) max_peak = fmaxf(peaks[0], peaks[1]);  // :958
+        else {                                                  // :983-986 fold from 0.0
+            max_peak = 0.0f;
+            for (float p : peaks) max_peak = fmaxf(max_peak, p);
+        }
+        out = sample * db_to_linear(-max_peak);
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// ----------------------------------------------------------------- AGC ----
+// src/source/agc.rs:133-171 (CircularBuffer), :397-407 (update_peak_level),
+// :413-417 (update_rms), :421-427 (calculate_peak_gain), :433-504 (process_sample).
+// The 10 s clamp of attack/release lives in the trait method, source/mod.rs:432-433.
+struct Agc : Source {
+    static constexpr size_t RMS_WINDOW_SIZE = 8192;  // agc.rs:51
+    Source *input;
+    float target_level, floor_, absolute_max_gain, current_gain = 1.0f;
+    float attack_coeff, release_coeff, peak_level = 0.0f;
+    std::vector<float> buffer;
+    float sum = 0.0f;
+    size_t index = 0;
+    Agc(Source *in, float target, uint64_t attack_ns, uint64_t release_ns, float max_gain, float fl)
+        : input(in), target_level(target), floor_(fl), absolute_max_gain(max_gain),
+          buffer(RMS_WINDOW_SIZE, 0.0f) {
+        const uint64_t ten_s = 10000000000ull;
+        attack_ns = attack_ns < ten_s ? attack_ns : ten_s;
+        release_ns = release_ns < ten_s ? release_ns : ten_s;
+        attack_coeff = duration_to_coefficient(attack_ns, in->sample_rate());
+        release_coeff = duration_to_coefficient(release_ns, in->sample_rate());
+    }
+    ~Agc() override { delete input; }
+    bool next(float &out) override {
+        float sample;
+        if (!input->next(sample)) return false;
+        float sample_value = fabsf(sample);
+        // update_peak_level
+        float coeff = sample_value > peak_level ? 0.0f : release_coeff;
+        peak_level = peak_level * coeff + sample_value * (1.0f - coeff);
+        // update_rms
+        float squared = sample_value * sample_value;
+        float old_value = buffer[index];
+        sum = sum - old_value + squared;
+        buffer[index] = squared;
+        index = (index + 1) & (RMS_WINDOW_SIZE - 1);
+        float rms = sqrtf(sum / (float)RMS_WINDOW_SIZE);
+        float rms_gain = rms > 0.0f ? target_level / rms : absolute_max_gain;
+        float peak_gain = peak_level > 0.0f ? fminf(target_level / peak_level, absolute_max_gain)
+                                            : absolute_max_gain;
+        float desired_gain = fmaxf(fminf(rms_gain, peak_gain), floor_);
+        float attack_speed = desired_gain > current_gain ? attack_coeff : release_coeff;
+        current_gain = current_gain * attack_speed + desired_gain * (1.0f - attack_speed);
+        // f32::clamp(0.1, max)
+        if (current_gain < 0.1f) current_gain = 0.1f;
+        else if (current_gain > absolute_max_gain) current_gain = absolute_max_gain;
+        out = sample * current_gain;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// Rust `as` casts saturate and map NaN to 0.
+template <typename T>
+inline T sat_cast(float v) {
+    if (v != v) return 0;
+    const float lo = (float)std::numeric_limits<T>::min();
+    const float hi_excl = -lo;  // 2^(bits-1), exactly representable
+    if (v <= lo) return std::numeric_limits<T>::min();
+    if (v >= hi_excl) return std::numeric_limits<T>::max();
+    return (T)v;
+}
+
+}  // namespace
+
+// ================================================================ C API ====
+extern "C" {
+
+void *orc_vec_source(const float *data, size_t n, int ch, unsigned rate, long span) {
+    return new VecSource(data, n, (uint16_t)ch, rate, span);
+}
+void *orc_sample_rate_converter(void *in, unsigned from, unsigned to, int ch) {
+    return new SampleRateConverter((Source *)in, from, to, (uint16_t)ch, true);
+}
+void *orc_channel_count_converter(void *in, int from, int to) {
+    return new ChannelCountConverter((Source *)in, (uint16_t)from, (uint16_t)to, true);
+}
+void *orc_uniform(void *in, int ch, unsigned rate) {
+    return new UniformSourceIterator((Source *)in, (uint16_t)ch, rate);
+}
+void *orc_amplify(void *in, float factor) { return new Amplify((Source *)in, factor); }
+void *orc_low_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, false, freq, q); }
+void *orc_high_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, true, freq, q); }
+void *orc_delay(void *in, unsigned long long ns) { return new Delay((Source *)in, ns); }
+// source/mod.rs:628-634 -- reverb = self.mix(self.clone().amplify(a).delay(d)).  The clone of
+// a `Buffered` source (buffered.rs:97-126) replays identical samples, so the oracle
+// materialises the input once and builds both branches from it.
+void *orc_reverb(void *in, unsigned long long ns, float amplitude) {
+    Source *s = (Source *)in;
+    std::vector<float> all;
+    float v;
+    while (s->next(v)) all.push_back(v);
+    uint16_t ch = s->channels();
+    uint32_t rate = s->sample_rate();
+    delete s;
+    Source *a = new VecSource(all.data(), all.size(), ch, rate, -1);
+    Source *b = new Delay(new Amplify(new VecSource(all.data(), all.size(), ch, rate, -1), amplitude), ns);
+    return new Mix(a, b);
+}
+void *orc_channel_volume(void *in, const float *gains, int n) {
+    return new ChannelVolume((Source *)in, gains, (size_t)n);
+}
+void orc_spatial_gains(const float *emitter, const float *left, const float *right, float *out2) {
+    spatial_gains(emitter, left, right, out2);
+}
+void *orc_spatial(void *in, const float *emitter, const float *left, const float *right) {
+    float g[2];
+    spatial_gains(emitter, left, right, g);
+    return new ChannelVolume((Source *)in, g, 2);
+}
+void *orc_limit(void *in, float threshold, float knee, unsigned long long attack_ns,
+                unsigned long long release_ns) {
+    return new Limit((Source *)in, threshold, knee, attack_ns, release_ns);
+}
+void *orc_agc(void *in, float target, unsigned long long attack_ns, unsigned long long release_ns,
+              float max_gain, float floor) {
+    return new Agc((Source *)in, target, attack_ns, release_ns, max_gain, floor);
+}
+void *orc_mixer(int ch, unsigned rate) { return new MixerSource((uint16_t)ch, rate); }
+void orc_mixer_add(void *mixer, void *src) { ((MixerSource *)mixer)->add((Source *)src); }
+
+// Pull up to `max` samples; returns how many were produced before `None`.
+size_t orc_pull(void *src, float *out, size_t max) {
+    Source *s = (Source *)src;
+    size_t n = 0;
+    float v;
+    while (n < max && s->next(v)) out[n++] = v;
+    return n;
+}
+// Pull and discard (benches' `.for_each(black_box_drop)`); returns count and a checksum so the
+// loop cannot be optimised away.
+size_t orc_drain(void *src, double *checksum) {
+    Source *s = (Source *)src;
+    size_t n = 0;
+    double acc = 0.0;
+    float v;
+    while (s->next(v)) {
+        acc += v;
+        ++n;
+    }
+    if (checksum) *checksum = acc;
+    return n;
+}
+int orc_channels(void *src) { return ((Source *)src)->channels(); }
+unsigned orc_sample_rate(void *src) { return ((Source *)src)->sample_rate(); }
+void orc_free(void *src) { delete (Source *)src; }
+
+// ---- scalar helpers (src/math.rs) ----
+float orc_lerp(float a, float b, unsigned num, unsigned den) { return lerp(a, b, num, den); }
+float orc_db_to_linear(float db) { return db_to_linear(db); }
+float orc_linear_to_db(float lin) { return linear_to_db(lin); }
+float orc_duration_to_coefficient(unsigned long long ns, unsigned rate) {
+    return duration_to_coefficient(ns, rate);
+}
+// blt.rs:502-544 coefficients {b0,b1,b2,a1,a2}
+void orc_blt_coeffs(int high_pass, unsigned freq, float q, unsigned fs, float *out5) {
+    VecSource *dummy = new VecSource(nullptr, 0, 1, fs, -1);
+    BltFilter f(dummy, high_pass != 0, freq, q);
+    out5[0] = f.b0; out5[1] = f.b1; out5[2] = f.b2; out5[3] = f.a1; out5[4] = f.a2;
+}
+// delay.rs:8-16
+unsigned long long orc_delay_samples(unsigned long long ns, unsigned rate, int ch) {
+    unsigned __int128 s = (unsigned __int128)ns * (unsigned)ch * rate / 1000000000ull;
+    return (unsigned long long)s;
+}
+
+// ---- SampleTypeConverter (src/conversions/sample.rs:42-44 -> dasp_sample 0.11.0 conv.rs;
+//      crate not vendored: formulas restated from the published crate; parity unpinned) ----
+void orc_i8_to_f32(const int8_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 128.0f; }
+void orc_i16_to_f32(const int16_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 32768.0f; }
+void orc_u16_to_f32(const uint16_t *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        int16_t s = in[i] >= 32768 ? (int16_t)(in[i] - 32768) : (int16_t)((int16_t)in[i] - 32767 - 1);
+        out[i] = (float)s / 32768.0f;
+    }
+}
+void orc_u8_to_f32(const uint8_t *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        int8_t s = in[i] >= 128 ? (int8_t)(in[i] - 128) : (int8_t)((int8_t)in[i] - 127 - 1);
+        out[i] = (float)s / 128.0f;
+    }
+}
+// I24 carried in the low 24 bits of an i32 (sign-extended)
+void orc_i24_to_f32(const int32_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 8388608.0f; }
+void orc_i32_to_f32(const int32_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 2147483648.0f; }
+void orc_f32_to_i16(const float *in, int16_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sat_cast<int16_t>(in[i] * 32768.0f); }
+void orc_f32_to_i8(const float *in, int8_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sat_cast<int8_t>(in[i] * 128.0f); }
+void orc_f32_to_i32(const float *in, int32_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sat_cast<int32_t>(in[i] * 2147483648.0f); }
+void orc_f32_to_u16(const float *in, uint16_t *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        int16_t s = sat_cast<int16_t>(in[i] * 32768.0f);
+        out[i] = s < 0 ? (uint16_t)(s + 32767 + 1) : (uint16_t)((uint16_t)s + 32768);
+    }
+}
+
+// ---- the cfg-2 pipeline as one call, for the CPU baseline of bench.py:
+//   for each source: mixer.add(UniformSourceIterator::new(src, ch_out, to).low_pass(freq))
+// then drain the mixer (benches/pipeline.rs shape: `.for_each(black_box_drop)`).
+// `data` holds S sources back to back, each frames*ch samples.  Returns samples produced.
+size_t orc_pipeline_resample_lowpass_mix(const float *data, int n_sources, size_t frames, int ch,
+                                         unsigned from, unsigned to, long span, unsigned freq,
+                                         float q, float *out, size_t out_cap) {
+    MixerSource *m = new MixerSource((uint16_t)ch, to);
+    for (int s = 0; s < n_sources; ++s) {
+        Source *v = new VecSource(data + (size_t)s * frames * ch, frames * ch, (uint16_t)ch, from, span);
+        Source *u = new UniformSourceIterator(v, (uint16_t)ch, to);
+        m->add(new BltFilter(u, false, freq, q));
+    }
+    size_t n = 0;
+    float v;
+    if (out) {
+        while (n < out_cap && m->next(v)) out[n++] = v;
+    } else {
+        volatile float sink = 0.f;
+        while (m->next(v)) { sink = v; ++n; }
+        (void)sink;
+    }
+    delete m;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+"""Pins the CPU oracle against every golden vector the reference's own tests hold for the hot
+path.  Each test cites the reference test it restates
+(paths under /root/reference)."""
+import numpy as np
+import pytest
+
+
+# ---------------------------------------------------------------- resampler ----
+def test_resampler_upsample(O):
+    # src/conversions/sample_rate.rs:356-367
+    inp = [2.0, 16.0, 4.0, 18.0, 6.0, 20.0, 8.0, 22.0]
+    out = O.SampleRateConverter(O.TestSource(inp, 2, 2000), 2000, 3000, 2).collect()
+    assert len(out) == 12
+    assert np.trunc(out).tolist() == [2.0, 16.0, 3.0, 17.0, 4.0, 18.0, 6.0, 20.0, 7.0, 21.0, 8.0, 22.0]
+
+
+def test_resampler_upsample2(O):
+    # src/conversions/sample_rate.rs:369-377
+    out = O.SampleRateConverter(O.TestSource([1.0, 14.0], 1, 1000), 1000, 7000, 1).collect()
+    assert np.trunc(out).tolist() == [1.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0]
+
+
+def test_resampler_downsample(O):
+    # src/conversions/sample_rate.rs:379-387
+    inp = np.arange(17, dtype=np.float32)
+    out = O.SampleRateConverter(O.TestSource(inp, 1, 12000), 12000, 2400, 1).collect()
+    assert out.tolist() == [0.0, 5.0, 10.0, 15.0]
+
+
+@pytest.mark.parametrize("frm,to,ch", [(44100, 48000, 2), (1, 7, 3), (96000, 8000, 1), (384000, 11025, 5)])
+def test_resampler_empty(O, frm, to, ch):
+    # quickcheck `empty`, src/conversions/sample_rate.rs:254-267
+    assert len(O.SampleRateConverter(O.TestSource([], ch, frm), frm, to, ch).collect()) == 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_resampler_identity(O, seed):
+    # quickcheck `identity`, src/conversions/sample_rate.rs:270-279
+    rng = np.random.default_rng(seed)
+    ch = int(rng.integers(1, 9))
+    inp = rng.integers(-32768, 32767, size=int(rng.integers(0, 300))).astype(np.float32)
+    rate = int(rng.integers(1, 200000))
+    out = O.SampleRateConverter(O.TestSource(inp, ch, rate), rate, rate, ch).collect()
+    assert np.array_equal(out, inp)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_resampler_divide_sample_rate(O, seed):
+    # quickcheck `divide_sample_rate`, src/conversions/sample_rate.rs:283-306
+    rng = np.random.default_rng(100 + seed)
+    ch = int(rng.integers(1, 6))
+    k = int(rng.integers(1, 12))
+    to = int(rng.integers(1, 48001))
+    n = int(rng.integers(0, 400))
+    inp = rng.integers(-32768, 32767, size=n).astype(np.float32)
+    inp = inp[: ch * (len(inp) // ch)]
+    out = O.SampleRateConverter(O.TestSource(inp, ch, to * k), to * k, to, ch).collect()
+    expect = inp.reshape(-1, ch)[::k].reshape(-1)
+    assert np.array_equal(out, expect)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_resampler_multiply_sample_rate(O, seed):
+    # quickcheck `multiply_sample_rate`, src/conversions/sample_rate.rs:310-333
+    rng = np.random.default_rng(200 + seed)
+    ch = int(rng.integers(1, 6))
+    k = int(rng.integers(1, 12))
+    frm = int(rng.integers(1, 65536))
+    n = int(rng.integers(0, 300))
+    inp = rng.integers(-32768, 32767, size=n).astype(np.float32)
+    inp = inp[: ch * (len(inp) // ch)]
+    out = O.SampleRateConverter(O.TestSource(inp, ch, frm), frm, frm * k, ch).collect()
+    assert np.array_equal(out.reshape(-1, ch)[::k].reshape(-1), inp)
+
+
+def test_lerp_random(O):
+    # quickcheck `lerp_random`, src/math.rs:187-216
+    rng = np.random.default_rng(7)
+    from math import gcd
+
+    checked = 0
+    while checked < 2000:
+        a, b = (np.float32(x) for x in rng.uniform(-1, 1, 2))
+        num, den = int(rng.integers(0, 5000)), int(rng.integers(1, 5000))
+        g = gcd(num, den)
+        num, den = num // g, den // g
+        c = num / den
+        if num > 1000 or not (0.0 <= c <= 1.0):
+            continue
+        ref = float(a) * (1.0 - c) + float(b) * c
+        assert abs(float(O.lerp(a, b, num, den)) - ref) < 1e-6
+        checked += 1
+
+
+# ----------------------------------------------------------------- channels ----
+def test_channels_remove(O):
+    # src/conversions/channels.rs:114-125
+    out = O.ChannelCountConverter(O.TestSource([1, 2, 3, 4, 5, 6], 3, 1), 3, 2).collect()
+    assert out.tolist() == [1.0, 2.0, 4.0, 5.0]
+    out = O.ChannelCountConverter(O.TestSource([1, 2, 3, 4, 5, 6, 7, 8], 4, 1), 4, 1).collect()
+    assert out.tolist() == [1.0, 5.0]
+
+
+def test_channels_add(O):
+    # src/conversions/channels.rs:127-143
+    out = O.ChannelCountConverter(O.TestSource([1, 2, 3, 4], 1, 1), 1, 2).collect()
+    assert out.tolist() == [1, 1, 2, 2, 3, 3, 4, 4]
+    out = O.ChannelCountConverter(O.TestSource([1, 2], 1, 1), 1, 4).collect()
+    assert out.tolist() == [1, 1, 0, 0, 2, 2, 0, 0]
+    out = O.ChannelCountConverter(O.TestSource([1, 2, 3, 4], 2, 1), 2, 4).collect()
+    assert out.tolist() == [1, 2, 0, 0, 3, 4, 0, 0]
+
+
+def test_channels_len(O):
+    # len_more / len_less, src/conversions/channels.rs:164-177 (and the size_hint cases :146-162,
+    # restated as produced length)
+    assert len(O.ChannelCountConverter(O.TestSource([1, 2, 3, 4], 2, 1), 2, 3).collect()) == 6
+    assert len(O.ChannelCountConverter(O.TestSource([1, 2, 3, 4], 2, 1), 2, 1).collect()) == 2
+    assert len(O.ChannelCountConverter(O.TestSource([1, 2, 3], 1, 1), 1, 2).collect()) == 6
+    assert len(O.ChannelCountConverter(O.TestSource([1, 2, 3, 4, 5, 6], 3, 1), 3, 8).collect()) == 16
+    assert len(O.ChannelCountConverter(O.TestSource(range(1, 9), 4, 1), 4, 1).collect()) == 2
+
+
+# -------------------------------------------------------------------- mixer ----
+def test_mixer_basic(O):
+    # src/mixer.rs:208-230
+    m = O.Mixer(1, 48000)
+    m.add(O.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(O.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(5)] == [15.0, -5.0, 15.0, -5.0, None]
+
+
+def test_mixer_channels_conv(O):
+    # src/mixer.rs:232-258
+    m = O.Mixer(2, 48000)
+    m.add(O.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(O.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(9)] == [15.0, 15.0, -5.0, -5.0, 15.0, 15.0, -5.0, -5.0, None]
+
+
+def test_mixer_rate_conv(O):
+    # src/mixer.rs:260-285
+    m = O.Mixer(1, 96000)
+    m.add(O.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(O.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(8)] == [15.0, 5.0, -5.0, 5.0, 15.0, 5.0, -5.0, None]
+
+
+def test_mixer_start_afterwards(O):
+    # src/mixer.rs:287-318
+    m = O.Mixer(1, 48000)
+    m.add(O.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    assert m.next() == 10.0
+    assert m.next() == -10.0
+    m.add(O.SamplesBuffer(1, 48000, [5.0, 5.0, 6.0, 6.0, 7.0, 7.0, 7.0]))
+    assert m.next() == 15.0
+    assert m.next() == -5.0
+    assert m.next() == 6.0
+    assert m.next() == 6.0
+    m.add(O.SamplesBuffer(1, 48000, [2.0]))
+    assert m.next() == 9.0
+    assert m.next() == 7.0
+    assert m.next() == 7.0
+    assert m.next() is None
+
+
+def test_mixer_added_taking_phase_into_account(O):
+    # src/mixer.rs:320-341
+    m = O.Mixer(2, 48000)
+    m.add(O.SamplesBuffer(2, 48000, [10.0, -10.0, 10.0, -10.0]))
+    assert m.next() == 10.0
+    m.add(O.SamplesBuffer(2, 48000, [5.0, -5.0, 6.0, -6.0]))
+    assert m.next() == -10.0  # not yet mixed (out of phase)
+    assert m.next() == 15.0  # mixing starts
+
+
+# ------------------------------------------------------------ channel volume ----
+def test_channel_volume_mono_to_stereo(O):
+    # src/source/channel_volume.rs:135-146
+    out = O.ChannelVolume(O.TestSource([1.0, 2.0, 3.0], 1, 44100), [0.5, 0.8]).collect()
+    f = np.float32
+    assert out.tolist() == [f(1) * f(0.5), f(1) * f(0.8), f(2) * f(0.5), f(2) * f(0.8), f(3) * f(0.5), f(3) * f(0.8)]
+
+
+def test_channel_volume_stereo_to_mono(O):
+    # src/source/channel_volume.rs:148-155
+    out = O.ChannelVolume(O.TestSource([1.0, 2.0, 3.0, 4.0], 2, 44100), [1.0]).collect()
+    assert out.tolist() == [1.5, 3.5]
+
+
+def test_channel_volume_stereo_to_stereo_with_mixing(O):
+    # src/source/channel_volume.rs:157-166
+    out = O.ChannelVolume(O.TestSource([1.0, 3.0, 2.0, 4.0], 2, 44100), [0.5, 2.0]).collect()
+    assert out.tolist() == [1.0, 4.0, 1.5, 6.0]
+
+
+# ------------------------------------------------------------------ dB table ----
+DECIBELS_LINEAR_TABLE = [
+    (100.0, 100000.0), (90.0, 31623.0), (80.0, 10000.0), (70.0, 3162.0), (60.0, 1000.0), (50.0, 316.2),
+    (40.0, 100.0), (30.0, 31.62), (20.0, 10.0), (10.0, 3.162), (5.998, 1.995), (3.003, 1.413),
+    (1.002, 1.122), (0.0, 1.0), (-1.002, 0.891), (-3.003, 0.708), (-5.998, 0.501), (-10.0, 0.3162),
+    (-20.0, 0.1), (-30.0, 0.03162), (-40.0, 0.01), (-50.0, 0.003162), (-60.0, 0.001),
+    (-70.0, 0.0003162), (-80.0, 0.0001), (-90.0, 0.00003162), (-100.0, 0.00001),
+]  # src/math.rs:238-266
+
+
+def test_db_table(O):
+    # src/math.rs:268-303
+    for db, lin in DECIBELS_LINEAR_TABLE:
+        assert 0.99 < O.db_to_linear(db) / lin < 1.01
+        if abs(db) > 1e-5:
+            assert 0.99 < O.linear_to_db(lin) / db < 1.01
+
+
+def test_db_round_trip(O):
+    # src/math.rs:305-339
+    eps = float(np.finfo(np.float32).eps)
+    for db in [-60.0, -20.0, -6.0, 0.0, 6.0, 20.0, 40.0]:
+        assert abs(O.linear_to_db(O.db_to_linear(db)) - db) < 16 * eps
+    for lin in [0.001, 0.1, 1.0, 10.0, 100.0]:
+        lin32 = float(np.float32(lin))
+        assert abs((O.db_to_linear(O.linear_to_db(lin)) - lin32) / lin32) < 16 * eps
+
+
+# ------------------------------------------------------------------- limiter ----
+def test_limiter_behaviour(O):
+    # tests/limit.rs:7-155 range assertions: settled peak within +-0.1 of threshold, passthrough
+    # below threshold.  (The reference pins ranges only, not values.)
+    sr = 48000
+    t = np.arange(sr // 2, dtype=np.float64) / sr
+    sine = (np.sin(2 * np.pi * 440.0 * t) * 2.0).astype(np.float32)  # SineWave(440).amplify(2.0)
+    for thr_db, expect in [(-1.0, 0.89), (-3.0, 0.71), (-6.0, 0.50)]:
+        out = O.TestSource(sine, 1, sr).limit(threshold=thr_db, knee_width=4.0).collect()
+        peak = float(np.max(np.abs(out[-4800:])))
+        assert abs(peak - expect) < 0.1, (thr_db, peak)
+    quiet = (np.sin(2 * np.pi * 440.0 * t) * 0.2).astype(np.float32)
+    out = O.TestSource(quiet, 1, sr).limit().collect()
+    assert float(np.max(np.abs(out - quiet))) < 0.01
+
+
+# ------------------------------------------------- closed form of the resampler ----
+def closed_form_resample(x, frm, to, ch):
+    """SURVEY.md Appendix A.1 closed form -- an independent restatement used to cross-check the
+    iterator state machine (and later the kernels' index math)."""
+    from math import gcd
+
+    g = gcd(frm, to)
+    F, T = frm // g, to // g
+    x = np.asarray(x, np.float32).reshape(-1, ch)
+    if F == T:
+        return x.reshape(-1).copy()
+    N = len(x)
+    out = []
+    m = 0
+    while True:
+        i, num = (m * F) // T, (m * F) % T
+        if i <= N - 2:
+            a, b = x[i], x[i + 1]
+            out.append(a + (b - a) * np.float32(num) / np.float32(T))
+        elif i == N - 1:
+            out.append(x[i].copy())
+            break
+        else:
+            break
+        m += 1
+    return np.concatenate(out).astype(np.float32) if out else np.empty(0, np.float32)
+
+
+@pytest.mark.parametrize("frm,to,ch,n", [(44100, 48000, 2, 1000), (48000, 44100, 2, 777), (8000, 48000, 1, 50),
+                                         (44100, 40000, 2, 333), (11025, 48000, 6, 100), (48000, 8000, 3, 401),
+                                         (44100, 48000, 2, 1), (44100, 48000, 2, 2), (48000, 44100, 1, 1)])
+def test_resampler_matches_closed_form(O, frm, to, ch, n):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, n * ch).astype(np.float32)
+    out = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+    ref = closed_form_resample(x, frm, to, ch)
+    assert np.array_equal(out, ref)
