@@ -1,0 +1,198 @@
+/* rodio_hip.h -- C ABI of the MI355X (gfx950) implementation of rodio's per-sample DSP hot path.
+ *
+ * rodio has no FFI: its extension point is the Rust trait `Source: Iterator<Item = f32>`
+ * (/root/reference/src/source/mod.rs:179-218).  This header is the boundary a Rust shim
+ * (`struct GpuSource<I: Source>` / `GpuMixer`) binds with `extern "C"`:
+ * the shim pre-pulls a block of samples from the upstream iterator, hands it to one of the
+ * block functions below and serves `next()` from the returned block.  Every entry point cites
+ * the reference iterator it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - Audio is interleaved f32 (`Sample = f32`, src/common.rs:36,48; src/source/mod.rs:131-135).
+ *   - All data pointers are DEVICE pointers owned by the caller unless the name ends in _host.
+ *     Small parameter arrays (gains, coefficients) are HOST pointers and are copied by value.
+ *   - Every function enqueues on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and returns an rh_status; nothing throws or aborts.  End of stream (`None`) is
+ *     expressed through returned lengths, never through an error.
+ *   - One handle is used from one thread at a time (mirrors `Send + !Sync`).
+ *   - There is NO CPU fallback: without a usable HIP device rh_init() fails and every other
+ *     call returns RH_ERR_NOT_INITIALIZED / RH_ERR_HIP.
+ */
+#ifndef RODIO_HIP_H
+#define RODIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rh_status;
+enum {
+    RH_OK = 0,
+    RH_ERR_INVALID = 1,         /* bad argument (zero rate/channels: rodio's NonZero types) */
+    RH_ERR_HIP = 2,             /* a HIP runtime call failed; see rh_last_hip_error() */
+    RH_ERR_UNSUPPORTED = 3,     /* valid in rodio, not covered by this kernel set */
+    RH_ERR_NOMEM = 4,
+    RH_ERR_TIMEOUT = 5,         /* an in-kernel bounded wait expired (fused pipeline) */
+    RH_ERR_NOT_INITIALIZED = 6,
+    RH_ERR_CAPACITY = 7         /* output buffer too small */
+};
+
+typedef void *rh_stream; /* hipStream_t */
+
+/* ---- runtime ------------------------------------------------------------------------- */
+int32_t rh_version(void);
+const char *rh_status_string(rh_status s);
+const char *rh_last_hip_error(void);
+rh_status rh_init(int32_t device);
+rh_status rh_device_name(char *buf, size_t cap);
+rh_status rh_malloc(void **out, size_t bytes);
+rh_status rh_free(void *p);
+rh_status rh_memset(void *p, int32_t value, size_t bytes, rh_stream stream);
+rh_status rh_memcpy_h2d(void *dst, const void *src_host, size_t bytes, rh_stream stream);
+rh_status rh_memcpy_d2h(void *dst_host, const void *src, size_t bytes, rh_stream stream);
+rh_status rh_stream_create(rh_stream *out);
+rh_status rh_stream_destroy(rh_stream s);
+rh_status rh_stream_synchronize(rh_stream s);
+/* HIP-event timing on `stream` (bench.py measures the kernels on the stream they run on). */
+rh_status rh_event_create(void **out);
+rh_status rh_event_destroy(void *ev);
+rh_status rh_event_record(void *ev, rh_stream stream);
+rh_status rh_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+/* ---- SampleTypeConverter ("DataConverter") ---------------------------------------------
+ * src/conversions/sample.rs:42-44 -> dasp_sample 0.11.0 `ToSample` (Cargo.lock:317-318).
+ * Call sites: src/decoder/wav.rs:119-136, src/stream.rs:538-545 (egress).  Bit-exact. */
+rh_status rh_convert_i8_to_f32(float *dst, const int8_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_u8_to_f32(float *dst, const uint8_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_i16_to_f32(float *dst, const int16_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_u16_to_f32(float *dst, const uint16_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_i24_to_f32(float *dst, const int32_t *src, size_t n, rh_stream stream); /* I24 in i32 */
+rh_status rh_convert_i32_to_f32(float *dst, const int32_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_i8(int8_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_i16(int16_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_u16(uint16_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_i32(int32_t *dst, const float *src, size_t n, rh_stream stream);
+
+/* ---- ChannelCountConverter: src/conversions/channels.rs:57-85.  Bit-exact.
+ * dst holds frames*to_ch samples. */
+rh_status rh_channels_convert(float *dst, const float *src, size_t frames, uint32_t from_ch,
+                              uint32_t to_ch, rh_stream stream);
+
+/* ---- Amplify: src/source/amplify.rs:64 */
+rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_stream stream);
+
+/* ---- ChannelVolume / Spatial: src/source/channel_volume.rs:71-88, src/source/spatial.rs:48-69.
+ * gains_host has out_ch entries (out_ch <= 16).  dst holds frames*out_ch samples. */
+rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_t in_ch,
+                            const float *gains_host, uint32_t out_ch, rh_stream stream);
+/* Host-side: gains[2] from emitter / ear positions (spatial.rs:48-69). */
+rh_status rh_spatial_gains(const float emitter[3], const float left_ear[3],
+                           const float right_ear[3], float out_gains[2]);
+
+/* ---- reverb = Mix(x, Delay(Amplify(x))): src/source/mod.rs:628-634, delay.rs:8-16,68-75,
+ * mix.rs:43-53.  delay_samples counts INTERLEAVED samples (delay.rs:14).  dst holds
+ * n + delay_samples samples. */
+uint64_t rh_delay_samples(uint64_t delay_ns, uint32_t sample_rate, uint32_t channels);
+rh_status rh_echo_mix(float *dst, const float *src, size_t n, size_t delay_samples, float gain,
+                      rh_stream stream);
+
+/* ---- SampleRateConverter (+ UniformSourceIterator span chunking):
+ * src/conversions/sample_rate.rs:52-90,110-122,131-201, src/math.rs:23-26,
+ * src/source/uniform.rs:50-97.  span_len = 0 means current_span_len() == None; otherwise the
+ * converter restarts every min(span_len, 32768) SAMPLES like uniform.rs:56.
+ * Bit-exact with the reference's lerp (mul, IEEE divide, add; no FMA). */
+rh_status rh_resample_out_frames(uint64_t in_frames, uint32_t from_rate, uint32_t to_rate,
+                                 uint32_t channels, uint64_t span_len, uint64_t *out_frames);
+rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, uint32_t from_rate,
+                             uint32_t to_rate, uint32_t channels, uint64_t span_len,
+                             rh_stream stream);
+
+/* ---- Mixer: src/mixer.rs:58-66,120-136,175-198.  out[t] = ((0+v0[t])+v1[t])+... over the live
+ * sources in insertion order (bit-identical rounding sequence).  Source s contributes samples
+ * [start[s], start[s]+len[s]) (start = frame-aligned admission, mixer.rs:175-183).
+ * srcs_host / start_host / len_host are host arrays of n_sources entries; dst holds out_len
+ * samples = max(start+len). */
+rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host,
+                     const uint64_t *start_host, const uint64_t *len_host, uint32_t n_sources,
+                     rh_stream stream);
+
+/* ---- BltFilter (low_pass / high_pass): src/source/blt.rs:502-544,558-560,397-492.
+ * kind: 0 = low_pass, 1 = high_pass.  coeffs5 = {b0,b1,b2,a1,a2} (already divided by a0).
+ * state (optional device pointer, 4*channels floats {x1,x2,y1,y2} per channel) carries the
+ * filter across blocks; NULL = zero state, not written back.
+ * mode 0 = sequential per (source,channel) stream, same op order as blt.rs:559 (bit-exact);
+ * mode 1 = time-parallel scan (<=1e-5 abs).
+ * The batch form filters n_streams equally shaped blocks laid out back to back. */
+rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate,
+                           float out_coeffs5[5]);
+rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t channels,
+                    uint32_t n_streams, const float coeffs5_host[5], float *state, int32_t mode,
+                    rh_stream stream);
+
+/* ---- Limit: src/source/limit.rs:94-130,853-988.  state: 2*channels floats
+ * {integrator, peak} per channel (optional). */
+typedef struct rh_limit_params {
+    float threshold_db; /* LimitSettings::threshold  (default -1) */
+    float knee_width_db;/* LimitSettings::knee_width (default 4)  */
+    uint64_t attack_ns; /* default 5 ms   */
+    uint64_t release_ns;/* default 100 ms */
+} rh_limit_params;
+rh_status rh_limit(float *dst, const float *src, uint64_t frames, uint32_t channels,
+                   uint32_t sample_rate, uint32_t n_streams, const rh_limit_params *params_host,
+                   float *state, rh_stream stream);
+
+/* ---- AutomaticGainControl: src/source/agc.rs:133-171,397-504.  One state for all interleaved
+ * channels of a stream.  state (optional): rh_agc_state_floats() floats per stream. */
+typedef struct rh_agc_params {
+    float target_level;      /* default 1.0 */
+    uint64_t attack_ns;      /* default 4 s; clamped to 10 s like source/mod.rs:432-433 */
+    uint64_t release_ns;     /* default 0 */
+    float absolute_max_gain; /* default 7.0 */
+    float floor;             /* default 0.0 */
+} rh_agc_params;
+size_t rh_agc_state_floats(void);
+/* Resets n_streams states to a fresh AGC (gain 1.0, empty RMS window): agc.rs:209-236. */
+rh_status rh_agc_state_init(float *state, uint32_t n_streams, rh_stream stream);
+rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t sample_rate,
+                 uint32_t n_streams, const rh_agc_params *params_host, float *state,
+                 rh_stream stream);
+
+/* ---- fused pipeline (BASELINE config 2): for every source
+ *        mixer.add(UniformSourceIterator::new(src, ch, to_rate).low_pass(freq))
+ *      then the ordered mixer sum -- one kernel, each input byte read once.
+ * Replaces uniform.rs:78-97 + sample_rate.rs:131-201 + blt.rs:397-451 + mixer.rs:185-198. */
+typedef struct rh_rlm_config {
+    uint32_t from_rate, to_rate;
+    uint32_t channels;     /* 2 (stereo) in this round */
+    uint64_t span_len;     /* 0 = None; else chunk of min(span_len, 32768) samples */
+    int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter */
+    uint32_t filter_freq;
+    float filter_q;        /* rodio's low_pass() uses 0.5 (blt.rs:11-16) */
+    uint32_t max_sources;
+    uint64_t max_in_frames;
+    uint32_t frames_per_lane; /* 0 = auto */
+    uint32_t threads;         /* 0 = auto */
+} rh_rlm_config;
+typedef struct rh_rlm rh_rlm;
+rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg);
+rh_status rh_rlm_destroy(rh_rlm *p);
+/* srcs_host[s] = device pointer of source s ([in_frames_host[s]][channels] f32, 16-byte
+ * aligned).  All sources start at mixer time 0.  dst holds out_capacity_frames*channels
+ * samples; *out_frames = max over sources of the resampled length. */
+rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
+                             const uint64_t *in_frames_host, uint32_t n_sources);
+rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames,
+                     rh_stream stream);
+/* After a synchronise: 0 if the last run completed, RH_ERR_TIMEOUT if a bounded wait expired. */
+rh_status rh_rlm_last_status(rh_rlm *p);
+/* Launch geometry chosen by create (for the bench's roofline report). */
+rh_status rh_rlm_geometry(rh_rlm *p, uint32_t *threads, uint32_t *frames_per_lane,
+                          uint32_t *lds_bytes, uint32_t *lookback_tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RODIO_HIP_H */

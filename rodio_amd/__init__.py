@@ -1,0 +1,30 @@
+"""rodio_amd -- MI355X (gfx950) implementation of rodio's per-sample DSP hot path.
+
+The product is the C-ABI shared library `librodio_hip.so` (include/rodio_hip.h).  This Python
+package is the host-side mirror of rodio's adapter interface over that ABI, used by the parity
+tests and the benchmark; device memory comes from PyTorch-ROCm (plumbing only).
+
+Importing the package loads the HIP library and FAILS if it is missing -- there is no CPU path.
+"""
+from . import _lib
+from ._lib import LIB_PATH, RhError, lib
+from .source import (  # noqa: F401
+    ChannelCountConverter,
+    ChannelVolume,
+    GpuSource,
+    Mixer,
+    ResampleLowpassMix,
+    SampleRateConverter,
+    SampleTypeConverter,
+    SamplesBuffer,
+    SpanSource,
+    Spatial,
+    TestSource,
+    UniformSourceIterator,
+    biquad_coeffs,
+    delay_samples,
+    init,
+    spatial_gains,
+)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

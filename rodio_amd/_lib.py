@@ -1,0 +1,120 @@
+"""ctypes binding of librodio_hip.so (the C ABI declared in include/rodio_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import, and
+every compute entry point returns RH_ERR_NOT_INITIALIZED until rh_init() has found a gfx950 GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librodio_hip.so")
+
+RH_OK = 0
+STATUS_NAMES = {
+    0: "RH_OK", 1: "RH_ERR_INVALID", 2: "RH_ERR_HIP", 3: "RH_ERR_UNSUPPORTED", 4: "RH_ERR_NOMEM",
+    5: "RH_ERR_TIMEOUT", 6: "RH_ERR_NOT_INITIALIZED", 7: "RH_ERR_CAPACITY",
+}
+
+
+class RhError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: {STATUS_NAMES.get(status, status)} {detail}".strip())
+
+
+class LimitParams(C.Structure):
+    _fields_ = [("threshold_db", C.c_float), ("knee_width_db", C.c_float),
+                ("attack_ns", C.c_uint64), ("release_ns", C.c_uint64)]
+
+
+class AgcParams(C.Structure):
+    _fields_ = [("target_level", C.c_float), ("attack_ns", C.c_uint64), ("release_ns", C.c_uint64),
+                ("absolute_max_gain", C.c_float), ("floor", C.c_float)]
+
+
+class RlmConfig(C.Structure):
+    _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
+                ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
+                ("filter_q", C.c_float), ("max_sources", C.c_uint32), ("max_in_frames", C.c_uint64),
+                ("frames_per_lane", C.c_uint32), ("threads", C.c_uint32)]
+
+
+vp, sz, u32, u64, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+f32p = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes).  Everything include/rodio_hip.h declares must be listed here:
+# tests/test_abi.py checks the two against each other and against the built library.
+SIGNATURES = {
+    "rh_version": (i32, []),
+    "rh_status_string": (C.c_char_p, [i32]),
+    "rh_last_hip_error": (C.c_char_p, []),
+    "rh_init": (i32, [i32]),
+    "rh_device_name": (i32, [C.c_char_p, sz]),
+    "rh_malloc": (i32, [C.POINTER(vp), sz]),
+    "rh_free": (i32, [vp]),
+    "rh_memset": (i32, [vp, i32, sz, vp]),
+    "rh_memcpy_h2d": (i32, [vp, vp, sz, vp]),
+    "rh_memcpy_d2h": (i32, [vp, vp, sz, vp]),
+    "rh_stream_create": (i32, [C.POINTER(vp)]),
+    "rh_stream_destroy": (i32, [vp]),
+    "rh_stream_synchronize": (i32, [vp]),
+    "rh_event_create": (i32, [C.POINTER(vp)]),
+    "rh_event_destroy": (i32, [vp]),
+    "rh_event_record": (i32, [vp, vp]),
+    "rh_event_elapsed_ms": (i32, [vp, vp, f32p]),
+    "rh_convert_i8_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_u8_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_i16_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_u16_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_i24_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_i32_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_i8": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_i16": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_u16": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_i32": (i32, [vp, vp, sz, vp]),
+    "rh_channels_convert": (i32, [vp, vp, sz, u32, u32, vp]),
+    "rh_amplify": (i32, [vp, vp, sz, f32, vp]),
+    "rh_channel_volume": (i32, [vp, vp, sz, u32, f32p, u32, vp]),
+    "rh_spatial_gains": (i32, [f32p, f32p, f32p, f32p]),
+    "rh_delay_samples": (u64, [u64, u32, u32]),
+    "rh_echo_mix": (i32, [vp, vp, sz, sz, f32, vp]),
+    "rh_resample_out_frames": (i32, [u64, u32, u32, u32, u64, C.POINTER(u64)]),
+    "rh_resample_linear": (i32, [vp, vp, u64, u32, u32, u32, u64, vp]),
+    "rh_mix_sum": (i32, [vp, sz, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), u32, vp]),
+    "rh_biquad_coeffs": (i32, [i32, u32, f32, u32, f32p]),
+    "rh_biquad": (i32, [vp, vp, u64, u32, u32, f32p, vp, i32, vp]),
+    "rh_limit": (i32, [vp, vp, u64, u32, u32, u32, C.POINTER(LimitParams), vp, vp]),
+    "rh_agc_state_floats": (sz, []),
+    "rh_agc_state_init": (i32, [vp, u32, vp]),
+    "rh_agc": (i32, [vp, vp, u64, u32, u32, C.POINTER(AgcParams), vp, vp]),
+    "rh_rlm_create": (i32, [C.POINTER(vp), C.POINTER(RlmConfig)]),
+    "rh_rlm_destroy": (i32, [vp]),
+    "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
+    "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
+    "rh_rlm_last_status": (i32, [vp]),
+    "rh_rlm_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+}
+
+
+def load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python rodio_amd/build.py` (needs hipcc). "
+            "rodio_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(status: int, where: str):
+    if status != RH_OK:
+        detail = lib.rh_last_hip_error().decode(errors="replace") if status == 2 else ""
+        raise RhError(status, where, detail)

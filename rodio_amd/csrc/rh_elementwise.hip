@@ -1,0 +1,334 @@
+// rh_elementwise.hip -- the stateless, bit-exact block ops:
+//   SampleTypeConverter  (src/conversions/sample.rs:42-44 -> dasp_sample 0.11.0)
+//   ChannelCountConverter (src/conversions/channels.rs:57-85)
+//   Amplify              (src/source/amplify.rs:64)
+//   ChannelVolume        (src/source/channel_volume.rs:71-88)
+//   reverb echo-mix      (src/source/mod.rs:628-634, delay.rs:68-75, mix.rs:43-53)
+// All are HBM-bound streaming kernels: 16 B per lane per access where alignment allows,
+// grid-stride over <= 2048 workgroups of 256 threads (4 waves of 64).
+#include <cmath>
+
+#include "rh_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------ int -> f32 ----
+template <typename T>
+struct ToF32;
+template <>
+struct ToF32<int8_t> {
+    static __device__ __forceinline__ float cvt(int8_t s) { return (float)s / 128.0f; }
+};
+template <>
+struct ToF32<uint8_t> {  // u8 -> i8 (s - 128) -> f32
+    static __device__ __forceinline__ float cvt(uint8_t s) { return (float)((int)s - 128) / 128.0f; }
+};
+template <>
+struct ToF32<int16_t> {
+    static __device__ __forceinline__ float cvt(int16_t s) { return (float)s / 32768.0f; }
+};
+template <>
+struct ToF32<uint16_t> {  // u16 -> i16 (s - 32768) -> f32
+    static __device__ __forceinline__ float cvt(uint16_t s) { return (float)((int)s - 32768) / 32768.0f; }
+};
+struct I24Tag {};
+struct I32Tag {};
+
+// 16 bytes of input per lane per iteration: VEC = 16 / sizeof(T) samples, VEC/4 float4 stores.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_int_to_f32(float *__restrict__ dst, const T *__restrict__ src, size_t n) {
+    constexpr int VEC = 16 / sizeof(T);
+    const size_t nvec = n / VEC;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    for (size_t v = tid; v < nvec; v += stride) {
+        uint4 raw = src4[v];
+        T vals[VEC];
+        __builtin_memcpy(vals, &raw, 16);
+        float out[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = ToF32<T>::cvt(vals[k]);
+        float4 *d4 = reinterpret_cast<float4 *>(dst + v * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC / 4; ++k) d4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+    for (size_t i = nvec * VEC + tid; i < n; i += stride) dst[i] = ToF32<T>::cvt(src[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_int_to_f32_scalar(float *__restrict__ dst, const T *__restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = ToF32<T>::cvt(src[i]);
+}
+
+// i32-carried samples: scale = 2^23 (I24) or 2^31 (i32); float4 in, float4 out.
+__global__ __launch_bounds__(kBlock) void k_i32_to_f32(float *__restrict__ dst, const int32_t *__restrict__ src, size_t n, float scale, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t done = 0;
+    if (vec_ok) {
+        const size_t nvec = n / 4;
+        const int4 *s4 = reinterpret_cast<const int4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (size_t v = tid; v < nvec; v += stride) {
+            int4 r = s4[v];
+            d4[v] = make_float4((float)r.x / scale, (float)r.y / scale, (float)r.z / scale, (float)r.w / scale);
+        }
+        done = nvec * 4;
+    }
+    for (size_t i = done + tid; i < n; i += stride) dst[i] = (float)src[i] / scale;
+}
+
+// ------------------------------------------------------------ f32 -> int ----
+// Rust `as`: truncate toward zero, saturate, NaN -> 0.
+template <typename T>
+__device__ __forceinline__ T sat_cast(float v, float lo, float hi_excl, T tmin, T tmax) {
+    if (v != v) return (T)0;
+    if (v <= lo) return tmin;
+    if (v >= hi_excl) return tmax;
+    return (T)(int)v;
+}
+template <typename T>
+struct FromF32;
+template <>
+struct FromF32<int8_t> {
+    static __device__ __forceinline__ int8_t cvt(float s) { return sat_cast<int8_t>(s * 128.0f, -128.0f, 128.0f, (int8_t)-128, (int8_t)127); }
+};
+template <>
+struct FromF32<int16_t> {
+    static __device__ __forceinline__ int16_t cvt(float s) { return sat_cast<int16_t>(s * 32768.0f, -32768.0f, 32768.0f, (int16_t)-32768, (int16_t)32767); }
+};
+template <>
+struct FromF32<uint16_t> {  // f32 -> i16 -> u16 (s + 32768)
+    static __device__ __forceinline__ uint16_t cvt(float s) { return (uint16_t)((int)FromF32<int16_t>::cvt(s) + 32768); }
+};
+template <>
+struct FromF32<int32_t> {
+    static __device__ __forceinline__ int32_t cvt(float s) {
+        float v = s * 2147483648.0f;
+        if (v != v) return 0;
+        if (v <= -2147483648.0f) return INT32_MIN;
+        if (v >= 2147483648.0f) return INT32_MAX;
+        return (int32_t)v;
+    }
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_f32_to_int(T *__restrict__ dst, const float *__restrict__ src, size_t n, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t done = 0;
+    if (vec_ok) {  // 4 samples per lane: float4 in, 4*sizeof(T) out
+        const size_t nvec = n / 4;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        for (size_t v = tid; v < nvec; v += stride) {
+            float4 r = s4[v];
+            T o[4] = {FromF32<T>::cvt(r.x), FromF32<T>::cvt(r.y), FromF32<T>::cvt(r.z), FromF32<T>::cvt(r.w)};
+            __builtin_memcpy(dst + v * 4, o, sizeof(o));
+        }
+        done = nvec * 4;
+    }
+    for (size_t i = done + tid; i < n; i += stride) dst[i] = FromF32<T>::cvt(src[i]);
+}
+
+// ------------------------------------------------ ChannelCountConverter ----
+// One lane per OUTPUT sample (coalesced stores); channels.rs:59-70 as a pure function of
+// (frame, k): k < from -> in[k]; k == 1 -> the frame's first sample; else 0.0.
+__global__ __launch_bounds__(kBlock) void k_channels_convert(float *__restrict__ dst, const float *__restrict__ src, size_t frames, uint32_t from, uint32_t to) {
+    const size_t total = frames * to;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += stride) {
+        const size_t f = o / to;
+        const uint32_t k = (uint32_t)(o - f * to);
+        float v;
+        if (k < from) v = src[f * from + k];
+        else if (k == 1) v = src[f * from];
+        else v = 0.0f;
+        dst[o] = v;
+    }
+}
+// Stereo <-> N fast paths are not needed for correctness; the generic kernel already writes
+// coalesced and its reads hit each input line once.
+
+// --------------------------------------------------------------- Amplify ----
+__global__ __launch_bounds__(kBlock) void k_amplify(float *__restrict__ dst, const float *__restrict__ src, size_t n, float factor, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t done = 0;
+    if (vec_ok) {
+        const size_t nvec = n / 4;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (size_t v = tid; v < nvec; v += stride) {
+            float4 r = s4[v];
+            d4[v] = make_float4(r.x * factor, r.y * factor, r.z * factor, r.w * factor);
+        }
+        done = nvec * 4;
+    }
+    for (size_t i = done + tid; i < n; i += stride) dst[i] = src[i] * factor;
+}
+
+// ---------------------------------------------------------- ChannelVolume ----
+struct Gains {
+    float g[16];
+};
+// One lane per frame: ordered channel sum from EQUILIBRIUM (0.0), / C_in, x gain[k].
+__global__ __launch_bounds__(kBlock) void k_channel_volume(float *__restrict__ dst, const float *__restrict__ src, size_t frames, uint32_t in_ch, Gains gains, uint32_t out_ch) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t f = (size_t)blockIdx.x * kBlock + threadIdx.x; f < frames; f += stride) {
+        float m = 0.0f;
+        for (uint32_t c = 0; c < in_ch; ++c) m = m + src[f * in_ch + c];
+        m = m / (float)in_ch;
+        for (uint32_t k = 0; k < out_ch; ++k) dst[f * out_ch + k] = m * gains.g[k];
+    }
+}
+// Stereo in / stereo out (Spatial): one float2 load + one float2 store per lane.
+__global__ __launch_bounds__(kBlock) void k_channel_volume_2x2(float2 *__restrict__ dst, const float2 *__restrict__ src, size_t frames, float g0, float g1) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t f = (size_t)blockIdx.x * kBlock + threadIdx.x; f < frames; f += stride) {
+        float2 x = src[f];
+        float m = (0.0f + x.x) + x.y;
+        m = m / 2.0f;
+        dst[f] = make_float2(m * g0, m * g1);
+    }
+}
+
+// ------------------------------------------------------------ reverb mix ----
+// y[n] = x[n] + 0.0 (n < D); x[n] + a*x[n-D] (D <= n < L); a*x[n-D] (L <= n < L+D); when D > L
+// the gap [L, D) is Delay's zeros alone.  The second tap is 4*D bytes behind the first, i.e.
+// an L2 / Infinity-Cache hit for any realistic D, so HBM sees one read and one write.
+__global__ __launch_bounds__(kBlock) void k_echo_mix(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain) {
+    const size_t total = n + delay;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const float s2 = (i < delay) ? 0.0f : src[i - delay] * gain;  // Delay(Amplify(x))
+        dst[i] = (i < n) ? (src[i] + s2) : s2;                          // mix.rs:47-52
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+rh_status launch_int_to_f32(float *dst, const T *src, size_t n, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(dst) && aligned16(src)) {
+        hipLaunchKernelGGL(k_int_to_f32<T>, dim3(rh::grid_for(n / VEC + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
+    } else {
+        hipLaunchKernelGGL(k_int_to_f32_scalar<T>, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
+    }
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+template <typename T>
+rh_status launch_f32_to_int(T *dst, const float *src, size_t n, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    const int vec_ok = aligned16(src) && (reinterpret_cast<uintptr_t>(dst) % (4 * sizeof(T)) == 0);
+    hipLaunchKernelGGL(k_f32_to_int<T>, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rh_status rh_convert_i8_to_f32(float *dst, const int8_t *src, size_t n, rh_stream s) { return launch_int_to_f32(dst, src, n, s); }
+rh_status rh_convert_u8_to_f32(float *dst, const uint8_t *src, size_t n, rh_stream s) { return launch_int_to_f32(dst, src, n, s); }
+rh_status rh_convert_i16_to_f32(float *dst, const int16_t *src, size_t n, rh_stream s) { return launch_int_to_f32(dst, src, n, s); }
+rh_status rh_convert_u16_to_f32(float *dst, const uint16_t *src, size_t n, rh_stream s) { return launch_int_to_f32(dst, src, n, s); }
+static rh_status i32_like(float *dst, const int32_t *src, size_t n, float scale, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_i32_to_f32, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, scale, (int)(aligned16(dst) && aligned16(src)));
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+rh_status rh_convert_i24_to_f32(float *dst, const int32_t *src, size_t n, rh_stream s) { return i32_like(dst, src, n, 8388608.0f, s); }
+rh_status rh_convert_i32_to_f32(float *dst, const int32_t *src, size_t n, rh_stream s) { return i32_like(dst, src, n, 2147483648.0f, s); }
+rh_status rh_convert_f32_to_i8(int8_t *dst, const float *src, size_t n, rh_stream s) { return launch_f32_to_int(dst, src, n, s); }
+rh_status rh_convert_f32_to_i16(int16_t *dst, const float *src, size_t n, rh_stream s) { return launch_f32_to_int(dst, src, n, s); }
+rh_status rh_convert_f32_to_u16(uint16_t *dst, const float *src, size_t n, rh_stream s) { return launch_f32_to_int(dst, src, n, s); }
+rh_status rh_convert_f32_to_i32(int32_t *dst, const float *src, size_t n, rh_stream s) { return launch_f32_to_int(dst, src, n, s); }
+
+rh_status rh_channels_convert(float *dst, const float *src, size_t frames, uint32_t from_ch, uint32_t to_ch, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (from_ch == 0 || to_ch == 0 || from_ch > 65535 || to_ch > 65535) return RH_ERR_INVALID;
+    if (frames == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_channels_convert, dim3(rh::grid_for(frames * to_ch)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, from_ch, to_ch);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_amplify, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, factor, (int)(aligned16(dst) && aligned16(src)));
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_t in_ch, const float *gains_host, uint32_t out_ch, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (in_ch == 0 || out_ch == 0 || !gains_host) return RH_ERR_INVALID;
+    if (out_ch > 16) return RH_ERR_UNSUPPORTED;
+    if (frames == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    if (in_ch == 2 && out_ch == 2 && (reinterpret_cast<uintptr_t>(dst) % 8 == 0) && (reinterpret_cast<uintptr_t>(src) % 8 == 0)) {
+        hipLaunchKernelGGL(k_channel_volume_2x2, dim3(rh::grid_for(frames)), dim3(kBlock), 0, rh::as_stream(stream), reinterpret_cast<float2 *>(dst), reinterpret_cast<const float2 *>(src), frames, gains_host[0], gains_host[1]);
+    } else {
+        Gains g{};
+        for (uint32_t k = 0; k < out_ch; ++k) g.g[k] = gains_host[k];
+        hipLaunchKernelGGL(k_channel_volume, dim3(rh::grid_for(frames)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, in_ch, g, out_ch);
+    }
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+// spatial.rs:19-24 (dist_sq), :48-69 (set_positions): two gains for ChannelVolume, f32 throughout.
+static float dist_sq3(const float a[3], const float b[3]) {
+    float s = 0.0f;
+    for (int k = 0; k < 3; ++k) s += (a[k] - b[k]) * (a[k] - b[k]);
+    return s;
+}
+rh_status rh_spatial_gains(const float emitter[3], const float left_ear[3], const float right_ear[3], float out_gains[2]) {
+    if (!emitter || !left_ear || !right_ear || !out_gains) return RH_ERR_INVALID;
+    const float left_dist_sq = dist_sq3(left_ear, emitter);
+    const float right_dist_sq = dist_sq3(right_ear, emitter);
+    const float max_diff = sqrtf(dist_sq3(left_ear, right_ear));
+    const float left_dist = sqrtf(left_dist_sq);
+    const float right_dist = sqrtf(right_dist_sq);
+    const float left_diff_modifier = fminf(((left_dist - right_dist) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f);
+    const float right_diff_modifier = fminf(((right_dist - left_dist) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f);
+    const float left_dist_modifier = fminf(1.0f / left_dist_sq, 1.0f);
+    const float right_dist_modifier = fminf(1.0f / right_dist_sq, 1.0f);
+    out_gains[0] = left_diff_modifier * left_dist_modifier;
+    out_gains[1] = right_diff_modifier * right_dist_modifier;
+    return RH_OK;
+}
+
+uint64_t rh_delay_samples(uint64_t delay_ns, uint32_t sample_rate, uint32_t channels) {
+    // delay.rs:8-16: ns * channels * rate / 1e9 in u128
+    unsigned __int128 s = (unsigned __int128)delay_ns * channels * sample_rate / 1000000000ull;
+    return (uint64_t)s;
+}
+
+rh_status rh_echo_mix(float *dst, const float *src, size_t n, size_t delay_samples, float gain, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n + delay_samples == 0) return RH_OK;
+    if (!dst || (!src && n)) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_echo_mix, dim3(rh::grid_for(n + delay_samples)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// rh_recurrence.hip -- the per-stream recurrences, executed in the reference's own order:
+//   BltFilter   src/source/blt.rs:502-544 (coefficients), :558-560 (apply), :397-492 (state)
+//   Limit       src/source/limit.rs:94-130, :853-873, :903-916, :927-988
+//   AGC         src/source/agc.rs:133-171, :397-504
+//
+// "mode 0" kernels: one lane per independent stream, time-sequential, identical operation
+// order to the Rust iterators (this TU is built with -ffp-contract=off), so the biquad is
+// bit-exact and limiter/AGC differ only through log2f/exp2f/sqrtf library rounding.  Streams
+// are the only parallel axis here (S sources x C channels for the biquad, S for limiter/AGC),
+// so these kernels are latency-bound by construction; the time-parallel biquad used by the
+// headline pipeline lives in rh_pipeline.hip.
+#include <cmath>
+
+#include "rh_common.h"
+
+namespace {
+
+constexpr int kBlock = 64;  // one wave per workgroup: spread few streams over many CUs
+
+struct Biquad5 {
+    float b0, b1, b2, a1, a2;
+};
+
+__global__ __launch_bounds__(kBlock) void k_biquad_seq(float *__restrict__ dst, const float *__restrict__ src, uint64_t frames, uint32_t channels, uint32_t n_streams, Biquad5 k, float *__restrict__ state) {
+    const uint32_t id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= n_streams * channels) return;
+    const uint32_t stream = id / channels, c = id - stream * channels;
+    const float *x = src + (uint64_t)stream * frames * channels + c;
+    float *y = dst + (uint64_t)stream * frames * channels + c;
+    float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+    float *st = state ? state + (uint64_t)id * 4 : nullptr;
+    if (st) {
+        x1 = st[0];
+        x2 = st[1];
+        y1 = st[2];
+        y2 = st[3];
+    }
+    for (uint64_t n = 0; n < frames; ++n) {
+        const float xn = x[n * channels];
+        // blt.rs:559, left to right
+        const float r = k.b0 * xn + k.b1 * x1 + k.b2 * x2 - k.a1 * y1 - k.a2 * y2;
+        y2 = y1;
+        x2 = x1;
+        y1 = r;
+        x1 = xn;
+        y[n * channels] = r;
+    }
+    if (st) {
+        st[0] = x1;
+        st[1] = x2;
+        st[2] = y1;
+        st[3] = y2;
+    }
+}
+
+constexpr float LOG2_10 = 3.32192809488736234787f;
+constexpr float LOG10_2 = 0.301029995663981195214f;
+constexpr int kMaxCh = 8;
+
+struct LimitK {
+    float threshold, knee_width, inv_knee_8, attack, release;
+};
+
+__device__ __forceinline__ float limit_process_sample(float sample, const LimitK &k) {
+    // limit.rs:853-873; f32::MIN_POSITIVE = 2^-126
+    const float bias_db = log2f(fabsf(sample) + 1.17549435e-38f) * LOG10_2 * 20.0f - k.threshold;
+    const float knee_boundary_db = bias_db * 2.0f;
+    if (knee_boundary_db < -k.knee_width) return 0.0f;
+    if (fabsf(knee_boundary_db) <= k.knee_width) {
+        const float x = knee_boundary_db + k.knee_width;
+        return x * x * k.inv_knee_8;
+    }
+    return bias_db;
+}
+
+__global__ __launch_bounds__(kBlock) void k_limit_seq(float *__restrict__ dst, const float *__restrict__ src, uint64_t frames, uint32_t channels, uint32_t n_streams, LimitK k, float *__restrict__ state) {
+    const uint32_t stream = blockIdx.x * kBlock + threadIdx.x;
+    if (stream >= n_streams) return;
+    const uint64_t total = frames * channels;
+    const float *x = src + (uint64_t)stream * total;
+    float *y = dst + (uint64_t)stream * total;
+    float integ[kMaxCh], peak[kMaxCh];
+    float *st = state ? state + (uint64_t)stream * channels * 2 : nullptr;
+    for (uint32_t c = 0; c < channels; ++c) {
+        integ[c] = st ? st[2 * c] : 0.0f;
+        peak[c] = st ? st[2 * c + 1] : 0.0f;
+    }
+    uint32_t c = 0;
+    for (uint64_t n = 0; n < total; ++n) {
+        const float sample = x[n];
+        const float limiter_db = limit_process_sample(sample, k);
+        // limit.rs:909-913
+        integ[c] = fmaxf(limiter_db, k.release * integ[c] + (1.0f - k.release) * limiter_db);
+        peak[c] = k.attack * peak[c] + (1.0f - k.attack) * integ[c];
+        float max_peak;
+        if (channels == 1) max_peak = peak[0];
+        else if (channels == 2) max_peak = fmaxf(peak[0], peak[1]);
+        else {
+            max_peak = 0.0f;
+            for (uint32_t j = 0; j < channels; ++j) max_peak = fmaxf(max_peak, peak[j]);
+        }
+        // math.rs:51-56: 2^(dB * 0.05 * log2(10))
+        y[n] = sample * exp2f(-max_peak * 0.05f * LOG2_10);
+        c = (c + 1 == channels) ? 0 : c + 1;
+    }
+    if (st) {
+        for (uint32_t j = 0; j < channels; ++j) {
+            st[2 * j] = integ[j];
+            st[2 * j + 1] = peak[j];
+        }
+    }
+}
+
+constexpr uint32_t kRmsWindow = 8192;              // agc.rs:51
+constexpr size_t kAgcStateFloats = 4 + kRmsWindow;  // {sum, index(bits), peak_level, current_gain, ring[8192]}
+
+struct AgcK {
+    float target_level, attack_coeff, release_coeff, absolute_max_gain, floor;
+};
+
+__global__ __launch_bounds__(kBlock) void k_agc_seq(float *__restrict__ dst, const float *__restrict__ src, uint64_t n_samples, uint32_t n_streams, AgcK k, float *__restrict__ state, int fresh) {
+    const uint32_t stream = blockIdx.x * kBlock + threadIdx.x;
+    if (stream >= n_streams) return;
+    const float *x = src + (uint64_t)stream * n_samples;
+    float *y = dst + (uint64_t)stream * n_samples;
+    float *st = state + (uint64_t)stream * kAgcStateFloats;
+    float *ring = st + 4;
+    float sum, peak_level, current_gain;
+    uint32_t index;
+    if (fresh) {  // agc.rs:209-236: gain 1.0, peak 0.0, zeroed window
+        sum = 0.0f;
+        index = 0;
+        peak_level = 0.0f;
+        current_gain = 1.0f;
+        for (uint32_t i = 0; i < kRmsWindow; ++i) ring[i] = 0.0f;
+    } else {
+        sum = st[0];
+        index = __float_as_uint(st[1]) & (kRmsWindow - 1);
+        peak_level = st[2];
+        current_gain = st[3];
+    }
+    for (uint64_t n = 0; n < n_samples; ++n) {
+        const float sample = x[n];
+        const float sample_value = fabsf(sample);
+        // update_peak_level, agc.rs:397-407
+        const float coeff = sample_value > peak_level ? 0.0f : k.release_coeff;
+        peak_level = peak_level * coeff + sample_value * (1.0f - coeff);
+        // update_rms, agc.rs:413-417 + CircularBuffer::push :152-163
+        const float squared = sample_value * sample_value;
+        const float old_value = ring[index];
+        sum = sum - old_value + squared;
+        ring[index] = squared;
+        index = (index + 1) & (kRmsWindow - 1);
+        const float rms = sqrtf(sum / (float)kRmsWindow);
+        const float rms_gain = rms > 0.0f ? k.target_level / rms : k.absolute_max_gain;
+        const float peak_gain = peak_level > 0.0f ? fminf(k.target_level / peak_level, k.absolute_max_gain) : k.absolute_max_gain;
+        const float desired_gain = fmaxf(fminf(rms_gain, peak_gain), k.floor);
+        const float attack_speed = desired_gain > current_gain ? k.attack_coeff : k.release_coeff;
+        current_gain = current_gain * attack_speed + desired_gain * (1.0f - attack_speed);
+        current_gain = current_gain < 0.1f ? 0.1f : (current_gain > k.absolute_max_gain ? k.absolute_max_gain : current_gain);
+        y[n] = sample * current_gain;
+    }
+    st[0] = sum;
+    st[1] = __uint_as_float(index);
+    st[2] = peak_level;
+    st[3] = current_gain;
+}
+
+// Duration::as_secs_f32 then exp(-1/(t*sr)): math.rs:110-122.  Host side, f32.
+float duration_to_coefficient(uint64_t ns, uint32_t sample_rate) {
+    const uint64_t secs = ns / 1000000000ull;
+    const uint32_t nanos = (uint32_t)(ns % 1000000000ull);
+    const float t = (float)secs + (float)nanos / 1000000000.0f;
+    return expf(-1.0f / (t * (float)sample_rate));
+}
+
+}  // namespace
+
+extern "C" {
+
+rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate, float out[5]) {
+    if (!out || sample_rate == 0 || (kind != 0 && kind != 1)) return RH_ERR_INVALID;
+    const float PI_F = 3.14159265358979323846264338327950288f;
+    const float w0 = 2.0f * PI_F * (float)freq / (float)sample_rate;
+    float b0, b1, b2, a0, a1, a2;
+    if (kind == 0) {  // blt.rs:504-521
+        const float alpha = sinf(w0) / (2.0f * q);
+        b1 = 1.0f - cosf(w0);
+        b0 = b1 / 2.0f;
+        b2 = b0;
+        a0 = 1.0f + alpha;
+        a1 = -2.0f * cosf(w0);
+        a2 = 1.0f - alpha;
+    } else {  // blt.rs:523-542
+        const float cos_w0 = cosf(w0);
+        const float alpha = sinf(w0) / (2.0f * q);
+        b0 = (1.0f + cos_w0) / 2.0f;
+        b1 = -1.0f - cos_w0;
+        b2 = b0;
+        a0 = 1.0f + alpha;
+        a1 = -2.0f * cos_w0;
+        a2 = 1.0f - alpha;
+    }
+    out[0] = b0 / a0;
+    out[1] = b1 / a0;
+    out[2] = b2 / a0;
+    out[3] = a1 / a0;
+    out[4] = a2 / a0;
+    return RH_OK;
+}
+
+rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream);
+
+rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, int32_t mode, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || !coeffs5_host) return RH_ERR_INVALID;
+    if (frames == 0 || n_streams == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    if (mode == 1) return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+    if (mode != 0) return RH_ERR_INVALID;
+    const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};
+    const uint32_t lanes = n_streams * channels;
+    hipLaunchKernelGGL(k_biquad_seq, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+rh_status rh_limit(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t sample_rate, uint32_t n_streams, const rh_limit_params *p, float *state, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || sample_rate == 0 || !p) return RH_ERR_INVALID;
+    if (channels > kMaxCh) return RH_ERR_UNSUPPORTED;
+    if (frames == 0 || n_streams == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    LimitK k;
+    k.threshold = p->threshold_db;
+    k.knee_width = p->knee_width_db;
+    k.inv_knee_8 = 1.0f / (8.0f * p->knee_width_db);             // limit.rs:877
+    k.attack = duration_to_coefficient(p->attack_ns, sample_rate);  // limit.rs:96-97
+    k.release = duration_to_coefficient(p->release_ns, sample_rate);
+    hipLaunchKernelGGL(k_limit_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+size_t rh_agc_state_floats(void) { return kAgcStateFloats; }
+
+rh_status rh_agc_state_init(float *state, uint32_t n_streams, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!state) return RH_ERR_INVALID;
+    hipStream_t s = rh::as_stream(stream);
+    RH_HIP_TRY(hipMemsetAsync(state, 0, sizeof(float) * kAgcStateFloats * n_streams, s));
+    const float one = 1.0f;  // current_gain starts at 1.0
+    for (uint32_t i = 0; i < n_streams; ++i)
+        RH_HIP_TRY(hipMemcpyAsync(state + (size_t)i * kAgcStateFloats + 3, &one, sizeof(float), hipMemcpyHostToDevice, s));
+    return RH_OK;
+}
+
+rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t sample_rate, uint32_t n_streams, const rh_agc_params *p, float *state, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (sample_rate == 0 || !p) return RH_ERR_INVALID;
+    if (n_samples == 0 || n_streams == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    const uint64_t ten_s = 10000000000ull;  // source/mod.rs:432-433
+    AgcK k;
+    k.target_level = p->target_level;
+    k.attack_coeff = duration_to_coefficient(p->attack_ns < ten_s ? p->attack_ns : ten_s, sample_rate);
+    k.release_coeff = duration_to_coefficient(p->release_ns < ten_s ? p->release_ns : ten_s, sample_rate);
+    k.absolute_max_gain = p->absolute_max_gain;
+    k.floor = p->floor;
+    hipStream_t s = rh::as_stream(stream);
+    float *st = state;
+    if (!st) RH_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&st), sizeof(float) * kAgcStateFloats * n_streams, s));
+    hipLaunchKernelGGL(k_agc_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, st, state ? 0 : 1);
+    hipError_t le = hipGetLastError();
+    if (!state) (void)hipFreeAsync(st, s);
+    if (le != hipSuccess) {
+        rh::set_hip_error(le, "k_agc_seq launch");
+        return RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+
+}  // extern "C"

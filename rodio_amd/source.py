@@ -1,0 +1,381 @@
+"""Host-side mirror of rodio's `Source` adapter interface over the HIP C ABI.
+
+rodio composes per-sample pull iterators (`trait Source: Iterator<Item = f32>`,
+/root/reference/src/source/mod.rs:179-218).  Here a source is a whole block resident in HBM and
+every adapter is one (or one fused) kernel launch through librodio_hip.so; names, argument
+order and end-of-stream behaviour follow the reference so the parity tests read like rodio's
+own tests:
+
+    out = rh.SampleRateConverter(rh.TestSource(x, 2, 44100), 44100, 48000, 2).collect()
+    mixer = rh.Mixer(2, 48000); mixer.add(rh.SamplesBuffer(1, 48000, x)); mixer.next()
+
+Device memory, streams and (in bench.py) torch.distributed come from PyTorch-ROCm; no torch op
+computes audio.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AgcParams, LimitParams, RlmConfig, check, lib
+
+_torch = None
+_initialized = False
+
+
+def _t():
+    global _torch
+    if _torch is None:
+        import torch
+
+        _torch = torch
+    return _torch
+
+
+def init(device: int = 0):
+    """rh_init(): binds the library to a gfx950 device.  Raises RhError if there is none."""
+    global _initialized
+    torch = _t()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(device)
+    check(lib.rh_init(device), "rh_init")
+    _initialized = True
+
+
+def _ensure():
+    if not _initialized:
+        init(_t().cuda.current_device() if _t().cuda.is_available() else 0)
+
+
+def _stream():
+    return C.c_void_p(_t().cuda.current_stream().cuda_stream)
+
+
+def _dev_empty(n, dtype=None):
+    torch = _t()
+    return torch.empty(int(n), dtype=dtype or torch.float32, device="cuda")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+SPAN_NONE = None
+
+
+class GpuSource:
+    """A block-resident `Source`: interleaved f32 samples in HBM + (channels, sample_rate,
+    current_span_len).  Adapters return new GpuSources; `collect()` copies to the host."""
+
+    def __init__(self, samples, channels: int, sample_rate: int, span_len=None):
+        if channels <= 0 or sample_rate <= 0:
+            raise ValueError("channels and sample_rate are NonZero in rodio")
+        self.samples = samples  # torch.float32 CUDA tensor, 1-D
+        self._channels = int(channels)
+        self._sample_rate = int(sample_rate)
+        self.span_len = span_len  # None, or int (samples)
+
+    # -- Source trait ---------------------------------------------------------------------
+    def channels(self) -> int:
+        return self._channels
+
+    def sample_rate(self) -> int:
+        return self._sample_rate
+
+    def current_span_len(self):
+        return self.span_len
+
+    def __len__(self):
+        return int(self.samples.numel())
+
+    def collect(self) -> np.ndarray:
+        _t().cuda.current_stream().synchronize()
+        return self.samples.detach().cpu().numpy().copy()
+
+    # -- builder methods (src/source/mod.rs:255-731) ---------------------------------------
+    def amplify(self, factor: float) -> "GpuSource":
+        _ensure()
+        out = _dev_empty(len(self))
+        check(lib.rh_amplify(_ptr(out), _ptr(self.samples), len(self), factor, _stream()), "rh_amplify")
+        return GpuSource(out, self._channels, self._sample_rate, self.span_len)
+
+    def _blt(self, kind: int, freq: int, q: float, mode: int) -> "GpuSource":
+        _ensure()
+        co = biquad_coeffs(kind, freq, q, self._sample_rate)
+        out = _dev_empty(len(self))
+        frames = len(self) // self._channels
+        check(lib.rh_biquad(_ptr(out), _ptr(self.samples), frames, self._channels, 1,
+                            co.ctypes.data_as(_lib.f32p), None, mode, _stream()), "rh_biquad")
+        return GpuSource(out[: frames * self._channels], self._channels, self._sample_rate, self.span_len)
+
+    def low_pass(self, freq: int, q: float = 0.5, mode: int = 0) -> "GpuSource":
+        return self._blt(0, freq, q, mode)
+
+    def high_pass(self, freq: int, q: float = 0.5, mode: int = 0) -> "GpuSource":
+        return self._blt(1, freq, q, mode)
+
+    def reverb(self, duration_ns: int, amplitude: float) -> "GpuSource":
+        _ensure()
+        d = delay_samples(duration_ns, self._sample_rate, self._channels)
+        out = _dev_empty(len(self) + d)
+        check(lib.rh_echo_mix(_ptr(out), _ptr(self.samples), len(self), d, amplitude, _stream()), "rh_echo_mix")
+        return GpuSource(out, self._channels, self._sample_rate, None)
+
+    def limit(self, threshold=-1.0, knee_width=4.0, attack_ns=5_000_000, release_ns=100_000_000) -> "GpuSource":
+        _ensure()
+        p = LimitParams(threshold, knee_width, attack_ns, release_ns)
+        out = _dev_empty(len(self))
+        frames = len(self) // self._channels
+        check(lib.rh_limit(_ptr(out), _ptr(self.samples), frames, self._channels, self._sample_rate, 1,
+                           C.byref(p), None, _stream()), "rh_limit")
+        return GpuSource(out[: frames * self._channels], self._channels, self._sample_rate, self.span_len)
+
+    def automatic_gain_control(self, target_level=1.0, attack_ns=4_000_000_000, release_ns=0,
+                               absolute_max_gain=7.0, floor=0.0) -> "GpuSource":
+        _ensure()
+        p = AgcParams(target_level, attack_ns, release_ns, absolute_max_gain, floor)
+        out = _dev_empty(len(self))
+        check(lib.rh_agc(_ptr(out), _ptr(self.samples), len(self), self._sample_rate, 1, C.byref(p), None,
+                         _stream()), "rh_agc")
+        return GpuSource(out, self._channels, self._sample_rate, self.span_len)
+
+
+def _upload(samples):
+    torch = _t()
+    a = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    if a.size == 0:
+        return torch.empty(0, dtype=torch.float32, device="cuda")
+    return torch.from_numpy(a).to("cuda")
+
+
+def TestSource(samples, channels, sample_rate) -> GpuSource:
+    """benches/shared.rs:6-46: a Vec<f32> source with current_span_len() == None."""
+    return GpuSource(_upload(samples), channels, sample_rate, None)
+
+
+def SamplesBuffer(channels, sample_rate, samples) -> GpuSource:
+    """src/buffer.rs:23-140: current_span_len() == Some(len)."""
+    s = _upload(samples)
+    return GpuSource(s, channels, sample_rate, int(s.numel()))
+
+
+def SpanSource(samples, channels, sample_rate, span_len) -> GpuSource:
+    return GpuSource(_upload(samples), channels, sample_rate, int(span_len))
+
+
+# ---- conversions ---------------------------------------------------------------------------
+def SampleRateConverter(inp: GpuSource, from_rate: int, to_rate: int, channels: int, span_len=0) -> GpuSource:
+    """src/conversions/sample_rate.rs:52-57 (same argument order).  span_len applies
+    UniformSourceIterator's chunking (0 = one continuous stream)."""
+    _ensure()
+    frames = len(inp) // channels
+    m = C.c_uint64(0)
+    check(lib.rh_resample_out_frames(frames, from_rate, to_rate, channels, span_len, C.byref(m)), "rh_resample_out_frames")
+    out = _dev_empty(m.value * channels)
+    check(lib.rh_resample_linear(_ptr(out), _ptr(inp.samples), frames, from_rate, to_rate, channels, span_len,
+                                 _stream()), "rh_resample_linear")
+    return GpuSource(out, channels, to_rate, None)
+
+
+def ChannelCountConverter(inp: GpuSource, from_ch: int, to_ch: int) -> GpuSource:
+    """src/conversions/channels.rs:28."""
+    _ensure()
+    frames = len(inp) // from_ch
+    out = _dev_empty(frames * to_ch)
+    check(lib.rh_channels_convert(_ptr(out), _ptr(inp.samples), frames, from_ch, to_ch, _stream()), "rh_channels_convert")
+    return GpuSource(out, to_ch, inp.sample_rate(), inp.span_len)
+
+
+def UniformSourceIterator(inp: GpuSource, channels: int, sample_rate: int) -> GpuSource:
+    """src/source/uniform.rs:50-97: ChannelCountConverter<SampleRateConverter<Take<I>>> restarted
+    every min(current_span_len, 32768) samples."""
+    span = inp.current_span_len() or 0
+    r = SampleRateConverter(inp, inp.sample_rate(), sample_rate, inp.channels(), span)
+    return ChannelCountConverter(r, inp.channels(), channels)
+
+
+_CONV = {
+    ("i8", "f32"): ("rh_convert_i8_to_f32", np.int8, np.float32),
+    ("u8", "f32"): ("rh_convert_u8_to_f32", np.uint8, np.float32),
+    ("i16", "f32"): ("rh_convert_i16_to_f32", np.int16, np.float32),
+    ("u16", "f32"): ("rh_convert_u16_to_f32", np.uint16, np.float32),
+    ("i24", "f32"): ("rh_convert_i24_to_f32", np.int32, np.float32),
+    ("i32", "f32"): ("rh_convert_i32_to_f32", np.int32, np.float32),
+    ("f32", "i8"): ("rh_convert_f32_to_i8", np.float32, np.int8),
+    ("f32", "i16"): ("rh_convert_f32_to_i16", np.float32, np.int16),
+    ("f32", "u16"): ("rh_convert_f32_to_u16", np.float32, np.uint16),
+    ("f32", "i32"): ("rh_convert_f32_to_i32", np.float32, np.int32),
+}
+
+
+def SampleTypeConverter(samples, src: str, dst: str) -> np.ndarray:
+    """src/conversions/sample.rs:6-44 (`SampleTypeConverter<I, O>`; north_star's "DataConverter").
+    Host array in, host array out; the conversion itself runs on the GPU."""
+    _ensure()
+    torch = _t()
+    fn, st, dt = _CONV[(src, dst)]
+    a = np.ascontiguousarray(samples, dtype=st)
+    # torch has no uint16 arithmetic but can carry the bytes
+    d_in = torch.from_numpy(a.view(np.uint8).reshape(-1)).to("cuda") if a.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(a.size * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+    check(getattr(lib, fn)(_ptr(d_out), _ptr(d_in), a.size, _stream()), fn)
+    torch.cuda.current_stream().synchronize()
+    return d_out.cpu().numpy().view(dt).copy()
+
+
+# ---- effects -------------------------------------------------------------------------------
+def ChannelVolume(inp: GpuSource, gains) -> GpuSource:
+    """src/source/channel_volume.rs:29-37,71-88."""
+    _ensure()
+    g = np.ascontiguousarray(gains, dtype=np.float32)
+    frames = len(inp) // inp.channels()
+    out = _dev_empty(frames * g.size)
+    check(lib.rh_channel_volume(_ptr(out), _ptr(inp.samples), frames, inp.channels(), g.ctypes.data_as(_lib.f32p),
+                                g.size, _stream()), "rh_channel_volume")
+    return GpuSource(out, g.size, inp.sample_rate(), inp.span_len)
+
+
+def spatial_gains(emitter, left, right) -> np.ndarray:
+    e, l, r = (np.ascontiguousarray(x, dtype=np.float32) for x in (emitter, left, right))
+    out = np.zeros(2, np.float32)
+    P = _lib.f32p
+    check(lib.rh_spatial_gains(e.ctypes.data_as(P), l.ctypes.data_as(P), r.ctypes.data_as(P), out.ctypes.data_as(P)),
+          "rh_spatial_gains")
+    return out
+
+
+def Spatial(inp: GpuSource, emitter, left, right) -> GpuSource:
+    """src/source/spatial.rs:26-46."""
+    return ChannelVolume(inp, spatial_gains(emitter, left, right))
+
+
+def biquad_coeffs(kind, freq, q, fs) -> np.ndarray:
+    out = np.zeros(5, np.float32)
+    k = 1 if kind in (1, "high_pass") else 0
+    check(lib.rh_biquad_coeffs(k, freq, q, fs, out.ctypes.data_as(_lib.f32p)), "rh_biquad_coeffs")
+    return out
+
+
+def delay_samples(ns, rate, ch) -> int:
+    return int(lib.rh_delay_samples(ns, rate, ch))
+
+
+# ---- mixer ---------------------------------------------------------------------------------
+class Mixer:
+    """`let (tx, rx) = mixer::mixer(channels, rate)` as one object (src/mixer.rs:25-43).
+
+    add() converts the source with UniformSourceIterator (mixer.rs:58-66) and admits it at the
+    next frame boundary of the output position (mixer.rs:175-183); next()/pull() serve the
+    ordered sum (mixer.rs:185-198) computed by rh_mix_sum."""
+
+    def __init__(self, channels: int, sample_rate: int):
+        self._channels, self._rate = int(channels), int(sample_rate)
+        self._srcs: list[tuple[GpuSource, int]] = []
+        self._pos = 0
+        self._mixed = None
+
+    def channels(self):
+        return self._channels
+
+    def sample_rate(self):
+        return self._rate
+
+    def add(self, src: GpuSource):
+        u = UniformSourceIterator(src, self._channels, self._rate)
+        start = -(-self._pos // self._channels) * self._channels  # next frame boundary
+        self._srcs.append((u, start))
+        self._mixed = None
+
+    def _mix(self):
+        if self._mixed is None:
+            _ensure()
+            n = len(self._srcs)
+            out_len = max((st + len(u) for u, st in self._srcs), default=0)
+            out = _dev_empty(out_len)
+            if out_len:
+                ptrs = (C.c_void_p * n)(*[u.samples.data_ptr() if len(u) else None for u, _ in self._srcs])
+                starts = (C.c_uint64 * n)(*[st for _, st in self._srcs])
+                lens = (C.c_uint64 * n)(*[len(u) for u, _ in self._srcs])
+                check(lib.rh_mix_sum(_ptr(out), out_len, ptrs, starts, lens, n, _stream()), "rh_mix_sum")
+            _t().cuda.current_stream().synchronize()
+            self._mixed = out.cpu().numpy()
+        return self._mixed
+
+    def pull(self, n: int) -> np.ndarray:
+        m = self._mix()
+        out = m[self._pos: self._pos + n].copy()
+        self._pos += len(out)
+        return out
+
+    def next(self):
+        p = self.pull(1)
+        return float(p[0]) if len(p) else None
+
+    def collect(self) -> np.ndarray:
+        return self.pull(1 << 62)
+
+
+# ---- fused headline pipeline ------------------------------------------------------------------
+class ResampleLowpassMix:
+    """BASELINE config 2 as one kernel: for every source
+    `mixer.add(UniformSourceIterator::new(src, ch, to_rate).low_pass(freq))`, then the mixer sum.
+
+    Sources are device tensors ([frames, 2] or flat interleaved f32).  `span_len` = the sources'
+    current_span_len() (None/0 = continuous)."""
+
+    def __init__(self, from_rate, to_rate, channels=2, span_len=None, filter="low_pass", freq=200, q=0.5,
+                 max_sources=256, max_in_frames=1 << 20, frames_per_lane=0, threads=0):
+        _ensure()
+        kind = {"low_pass": 0, "high_pass": 1, None: -1, "none": -1}[filter]
+        self.cfg = RlmConfig(from_rate, to_rate, channels, int(span_len or 0), kind, freq, q, max_sources,
+                             max_in_frames, frames_per_lane, threads)
+        self._h = C.c_void_p()
+        check(lib.rh_rlm_create(C.byref(self._h), C.byref(self.cfg)), "rh_rlm_create")
+        self.channels = channels
+        self._keep = None
+        self.out_frames = 0
+
+    def geometry(self):
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.rh_rlm_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "rh_rlm_geometry")
+        return {"threads": a.value, "frames_per_lane": b.value, "lds_bytes": c.value, "lookback_tiles": d.value}
+
+    def set_sources(self, tensors):
+        n = len(tensors)
+        self._keep = list(tensors)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in tensors])
+        frames = (C.c_uint64 * n)(*[t.numel() // self.channels for t in tensors])
+        check(lib.rh_rlm_set_sources(self._h, ptrs, frames, n), "rh_rlm_set_sources")
+        # run() reports out_frames too; it is needed here to size the output allocation
+        mx = 0
+        for t in tensors:
+            o = C.c_uint64(0)
+            check(lib.rh_resample_out_frames(t.numel() // self.channels, self.cfg.from_rate, self.cfg.to_rate,
+                                             self.channels, self.cfg.span_len, C.byref(o)), "rh_resample_out_frames")
+            mx = max(mx, o.value)
+        self.out_frames = mx
+
+    def run(self, out=None):
+        """Enqueue one pass on the current stream; returns the mixed [out_frames*channels] tensor."""
+        if out is None:
+            out = _dev_empty(max(self.out_frames * self.channels, 4))
+        m = C.c_uint64(0)
+        check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
+        return out[: m.value * self.channels]
+
+    def check_status(self):
+        _t().cuda.current_stream().synchronize()
+        check(lib.rh_rlm_last_status(self._h), "rh_rlm_last_status")
+
+    def close(self):
+        if self._h:
+            lib.rh_rlm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,463 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Bit-exact (np.array_equal) for conversions, channel mapping, resampling, amplify, reverb,
+channel volume, sequential biquad and the ordered mixer sum; <= 1e-5 abs for limiter / AGC
+(device log2f/exp2f/sqrtf) and for the fused, time-parallel filter pipeline (BASELINE tolerance:
+"<=1e-5 abs f32 for resample/filter/mix").  Tests mirror the reference's own tests where those
+exist (cited per test) and then widen to seeded random inputs and edge cases.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def G(rh):
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    rh.init(0)
+    return rh
+
+
+def rnd(seed, n, scale=1.0):
+    return (np.random.default_rng(seed).uniform(-1, 1, n) * scale).astype(np.float32)
+
+
+# =============================================================== reference golden vectors ====
+def test_golden_resampler(G):
+    # src/conversions/sample_rate.rs:356-387
+    out = G.SampleRateConverter(G.TestSource([2.0, 16.0, 4.0, 18.0, 6.0, 20.0, 8.0, 22.0], 2, 2000), 2000, 3000, 2).collect()
+    assert len(out) == 12
+    assert np.trunc(out).tolist() == [2.0, 16.0, 3.0, 17.0, 4.0, 18.0, 6.0, 20.0, 7.0, 21.0, 8.0, 22.0]
+    out = G.SampleRateConverter(G.TestSource([1.0, 14.0], 1, 1000), 1000, 7000, 1).collect()
+    assert np.trunc(out).tolist() == [1.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0]
+    out = G.SampleRateConverter(G.TestSource(np.arange(17), 1, 12000), 12000, 2400, 1).collect()
+    assert out.tolist() == [0.0, 5.0, 10.0, 15.0]
+
+
+def test_golden_resampler_properties(G):
+    # quickcheck empty / identity / divide / multiply, sample_rate.rs:254-334
+    assert len(G.SampleRateConverter(G.TestSource([], 2, 44100), 44100, 48000, 2).collect()) == 0
+    rng = np.random.default_rng(11)
+    for _ in range(6):
+        ch, k = int(rng.integers(1, 6)), int(rng.integers(1, 12))
+        base = int(rng.integers(1, 48001))
+        x = rng.integers(-32768, 32767, size=int(rng.integers(0, 400))).astype(np.float32)
+        x = x[: ch * (len(x) // ch)]
+        assert np.array_equal(G.SampleRateConverter(G.TestSource(x, ch, base), base, base, ch).collect(), x)
+        down = G.SampleRateConverter(G.TestSource(x, ch, base * k), base * k, base, ch).collect()
+        assert np.array_equal(down, x.reshape(-1, ch)[::k].reshape(-1))
+        up = G.SampleRateConverter(G.TestSource(x, ch, base), base, base * k, ch).collect()
+        assert np.array_equal(up.reshape(-1, ch)[::k].reshape(-1), x)
+
+
+def test_golden_channels(G):
+    # src/conversions/channels.rs:114-143
+    assert G.ChannelCountConverter(G.TestSource([1, 2, 3, 4, 5, 6], 3, 1), 3, 2).collect().tolist() == [1, 2, 4, 5]
+    assert G.ChannelCountConverter(G.TestSource([1, 2, 3, 4, 5, 6, 7, 8], 4, 1), 4, 1).collect().tolist() == [1, 5]
+    assert G.ChannelCountConverter(G.TestSource([1, 2, 3, 4], 1, 1), 1, 2).collect().tolist() == [1, 1, 2, 2, 3, 3, 4, 4]
+    assert G.ChannelCountConverter(G.TestSource([1, 2], 1, 1), 1, 4).collect().tolist() == [1, 1, 0, 0, 2, 2, 0, 0]
+    assert G.ChannelCountConverter(G.TestSource([1, 2, 3, 4], 2, 1), 2, 4).collect().tolist() == [1, 2, 0, 0, 3, 4, 0, 0]
+    assert len(G.ChannelCountConverter(G.TestSource([1, 2, 3, 4], 2, 1), 2, 3).collect()) == 6
+    assert len(G.ChannelCountConverter(G.TestSource([1, 2, 3, 4], 2, 1), 2, 1).collect()) == 2
+
+
+def test_golden_mixer(G):
+    # src/mixer.rs:208-341
+    m = G.Mixer(1, 48000)
+    m.add(G.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(G.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(5)] == [15.0, -5.0, 15.0, -5.0, None]
+    m = G.Mixer(2, 48000)  # channels_conv
+    m.add(G.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(G.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(9)] == [15.0, 15.0, -5.0, -5.0, 15.0, 15.0, -5.0, -5.0, None]
+    m = G.Mixer(1, 96000)  # rate_conv
+    m.add(G.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    m.add(G.SamplesBuffer(1, 48000, [5.0, 5.0, 5.0, 5.0]))
+    assert [m.next() for _ in range(8)] == [15.0, 5.0, -5.0, 5.0, 15.0, 5.0, -5.0, None]
+    m = G.Mixer(1, 48000)  # start_afterwards
+    m.add(G.SamplesBuffer(1, 48000, [10.0, -10.0, 10.0, -10.0]))
+    assert [m.next(), m.next()] == [10.0, -10.0]
+    m.add(G.SamplesBuffer(1, 48000, [5.0, 5.0, 6.0, 6.0, 7.0, 7.0, 7.0]))
+    assert [m.next() for _ in range(4)] == [15.0, -5.0, 6.0, 6.0]
+    m.add(G.SamplesBuffer(1, 48000, [2.0]))
+    assert [m.next() for _ in range(4)] == [9.0, 7.0, 7.0, None]
+    m = G.Mixer(2, 48000)  # added_taking_phase_into_account
+    m.add(G.SamplesBuffer(2, 48000, [10.0, -10.0, 10.0, -10.0]))
+    assert m.next() == 10.0
+    m.add(G.SamplesBuffer(2, 48000, [5.0, -5.0, 6.0, -6.0]))
+    assert m.next() == -10.0
+    assert m.next() == 15.0
+
+
+def test_golden_channel_volume(G):
+    # src/source/channel_volume.rs:135-166
+    f = np.float32
+    out = G.ChannelVolume(G.TestSource([1.0, 2.0, 3.0], 1, 44100), [0.5, 0.8]).collect()
+    assert out.tolist() == [f(1) * f(0.5), f(1) * f(0.8), f(2) * f(0.5), f(2) * f(0.8), f(3) * f(0.5), f(3) * f(0.8)]
+    assert G.ChannelVolume(G.TestSource([1.0, 2.0, 3.0, 4.0], 2, 44100), [1.0]).collect().tolist() == [1.5, 3.5]
+    assert G.ChannelVolume(G.TestSource([1.0, 3.0, 2.0, 4.0], 2, 44100), [0.5, 2.0]).collect().tolist() == [1.0, 4.0, 1.5, 6.0]
+
+
+# ==================================================================== random parity ====
+@pytest.mark.parametrize("frm,to,ch,n", [
+    (44100, 48000, 2, 100003), (48000, 44100, 2, 65537), (8000, 48000, 1, 5001), (44100, 40000, 2, 33333),
+    (11025, 48000, 6, 4097), (48000, 8000, 3, 40001), (44100, 48000, 2, 1), (44100, 48000, 2, 2),
+    (44100, 48000, 1, 147), (96000, 44100, 2, 321), (44100, 48000, 5, 999),
+])
+def test_resample_bit_exact(G, O, frm, to, ch, n):
+    x = rnd(n, n * ch)
+    ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+    out = G.SampleRateConverter(G.TestSource(x, ch, frm), frm, to, ch).collect()
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("frm,to,ch,n,span", [
+    (44100, 48000, 2, 100000, 32768), (44100, 48000, 2, 16384 * 3, 32768), (44100, 48000, 2, 16384 * 3 + 1, 32768),
+    (48000, 44100, 2, 70001, 32768), (44100, 48000, 1, 5000, 300), (8000, 48000, 2, 999, 64),
+    (48000, 8000, 2, 5003, 1000), (44100, 48000, 2, 100000, 1 << 22),
+])
+def test_uniform_chunked_bit_exact(G, O, frm, to, ch, n, span):
+    # UniformSourceIterator restarts the converter every min(span,32768) samples: uniform.rs:50-97
+    x = rnd(n + 1, n * ch)
+    ref = O.UniformSourceIterator(O.SpanSource(x, ch, frm, span), ch, to).collect()
+    out = G.UniformSourceIterator(G.SpanSource(x, ch, frm, span), ch, to).collect()
+    assert np.array_equal(out, ref)
+
+
+def test_uniform_samples_buffer_with_channel_change(G, O):
+    x = rnd(5, 3 * 50000)
+    ref = O.UniformSourceIterator(O.SamplesBuffer(3, 44100, x), 2, 48000).collect()
+    out = G.UniformSourceIterator(G.SamplesBuffer(3, 44100, x), 2, 48000).collect()
+    assert np.array_equal(out, ref)
+    ref = O.UniformSourceIterator(O.SamplesBuffer(1, 22050, x[:40001]), 2, 48000).collect()
+    out = G.UniformSourceIterator(G.SamplesBuffer(1, 22050, x[:40001]), 2, 48000).collect()
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("a,b", [(6, 2), (2, 6), (1, 2), (1, 4), (2, 1), (3, 8), (8, 3), (2, 2), (5, 5)])
+def test_channels_bit_exact(G, O, a, b):
+    x = rnd(a * 10 + b, a * 10007)
+    ref = O.ChannelCountConverter(O.TestSource(x, a, 48000), a, b).collect()
+    out = G.ChannelCountConverter(G.TestSource(x, a, 48000), a, b).collect()
+    assert np.array_equal(out, ref)
+
+
+def test_sample_type_converter_exhaustive(G, O):
+    # dasp_sample 0.11.0 formulas (parity unpinned by the reference): every i16 / u16 / i8 / u8 value
+    i16 = np.arange(-32768, 32768, dtype=np.int16)
+    assert np.array_equal(G.SampleTypeConverter(i16, "i16", "f32"), O.convert("i16_to_f32", i16))
+    assert np.array_equal(G.SampleTypeConverter(i16, "i16", "f32"), i16.astype(np.float32) / np.float32(32768))
+    u16 = np.arange(0, 65536, dtype=np.uint16)
+    assert np.array_equal(G.SampleTypeConverter(u16, "u16", "f32"), O.convert("u16_to_f32", u16))
+    i8 = np.arange(-128, 128, dtype=np.int8)
+    assert np.array_equal(G.SampleTypeConverter(i8, "i8", "f32"), O.convert("i8_to_f32", i8))
+    u8 = np.arange(0, 256, dtype=np.uint8)
+    assert np.array_equal(G.SampleTypeConverter(u8, "u8", "f32"), O.convert("u8_to_f32", u8))
+    rng = np.random.default_rng(9)
+    i32 = rng.integers(-2**31, 2**31 - 1, 100003, dtype=np.int64).astype(np.int32)
+    assert np.array_equal(G.SampleTypeConverter(i32, "i32", "f32"), O.convert("i32_to_f32", i32))
+    i24 = rng.integers(-2**23, 2**23 - 1, 100003, dtype=np.int64).astype(np.int32)
+    assert np.array_equal(G.SampleTypeConverter(i24, "i24", "f32"), O.convert("i24_to_f32", i24))
+    # ragged length + unaligned tail
+    assert np.array_equal(G.SampleTypeConverter(i16[:12345], "i16", "f32"), O.convert("i16_to_f32", i16[:12345]))
+
+
+def test_sample_type_converter_egress(G, O):
+    # f32 -> device formats (src/stream.rs:538-545): saturation, truncation toward zero, NaN -> 0
+    x = np.concatenate([rnd(1, 100000, 1.5), np.float32([0, -0.0, 1, -1, 0.99999, -0.99999, 2, -2, np.nan, np.inf, -np.inf, 1e-9])])
+    for dst in ("i16", "u16", "i8", "i32"):
+        assert np.array_equal(G.SampleTypeConverter(x, "f32", dst), O.convert(f"f32_to_{dst}", x)), dst
+
+
+def test_amplify_bit_exact(G, O):
+    x = rnd(2, 100001)
+    for f in (1.2, 0.8, -0.3, 0.0):
+        assert np.array_equal(G.TestSource(x, 2, 48000).amplify(f).collect(), O.TestSource(x, 2, 48000).amplify(f).collect())
+
+
+@pytest.mark.parametrize("n,ns,amp,ch", [(100000, 682_666_667 // 16, 0.3, 2), (5000, 50_000_000, 0.7, 2),
+                                         (100, 10_000_000, 0.5, 1), (0, 1_000_000, 0.5, 2), (3001, 20_833_333, 0.3, 2)])
+def test_reverb_bit_exact(G, O, n, ns, amp, ch):
+    # source/mod.rs:628-634; the last case has an ODD delay on stereo (channel swap) -- reproduced, not fixed
+    x = rnd(n + 3, n - n % ch, 0.25)
+    ref = O.TestSource(x, ch, 48000).reverb(ns, amp).collect()
+    out = G.TestSource(x, ch, 48000).reverb(ns, amp).collect()
+    assert np.array_equal(out, ref)
+
+
+def test_reverb_delay_longer_than_source(G, O):
+    x = rnd(8, 100, 0.25)
+    ref = O.TestSource(x, 2, 48000).reverb(10_000_000, 0.3).collect()  # 960 samples of delay > 100
+    assert np.array_equal(G.TestSource(x, 2, 48000).reverb(10_000_000, 0.3).collect(), ref)
+
+
+def test_spatial_bit_exact(G, O):
+    x = rnd(4, 2 * 50001, 0.25)
+    for s in (0, 7, 63):
+        e = [0.5 + 0.01 * s, 0, 1]
+        ref = O.Spatial(O.TestSource(x, 2, 48000), e, [-1, 0, 0], [1, 0, 0]).collect()
+        out = G.Spatial(G.TestSource(x, 2, 48000), e, [-1, 0, 0], [1, 0, 0]).collect()
+        assert np.array_equal(out, ref)
+    x6 = rnd(6, 6 * 1001)
+    g = [0.5, 0.25, 1.0]
+    assert np.array_equal(G.ChannelVolume(G.TestSource(x6, 6, 48000), g).collect(), O.ChannelVolume(O.TestSource(x6, 6, 48000), g).collect())
+
+
+@pytest.mark.parametrize("kind,freq,ch,n", [("low_pass", 200, 2, 30001), ("low_pass", 1000, 1, 20000), ("high_pass", 300, 2, 25000),
+                                            ("low_pass", 200, 6, 5000)])
+def test_biquad_sequential_bit_exact(G, O, kind, freq, ch, n):
+    x = rnd(freq + ch, n * ch)
+    ref = getattr(O.TestSource(x, ch, 48000), kind)(freq).collect()
+    out = getattr(G.TestSource(x, ch, 48000), kind)(freq).collect()
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_limiter(G, O, ch):
+    sr = 48000
+    t = np.arange(sr // 4) / sr
+    x = np.repeat((np.sin(2 * np.pi * 440 * t) * 2.0).astype(np.float32), ch) * np.tile(np.linspace(0.5, 1.0, ch, dtype=np.float32), len(t))
+    for thr in (-1.0, -6.0):
+        ref = O.TestSource(x, ch, sr).limit(threshold=thr).collect()
+        out = G.TestSource(x, ch, sr).limit(threshold=thr).collect()
+        assert np.max(np.abs(out - ref)) <= TOL
+
+
+def test_agc(G, O):
+    x = rnd(21, 2 * 30000, 0.3)
+    x[20000:] *= 3.0
+    ref = O.TestSource(x, 2, 48000).automatic_gain_control().collect()
+    out = G.TestSource(x, 2, 48000).automatic_gain_control().collect()
+    assert np.max(np.abs(out - ref)) <= TOL
+    ref = O.TestSource(x, 2, 48000).automatic_gain_control(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0).collect()
+    out = G.TestSource(x, 2, 48000).automatic_gain_control(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0).collect()
+    assert np.max(np.abs(out - ref)) <= TOL
+
+
+def test_mixer_random_ordered_sum_bit_exact(G, O):
+    # full-scale sources: only the reference's own summation order reproduces these bits
+    S, n = 37, 20001
+    mo, mg = O.Mixer(2, 48000), G.Mixer(2, 48000)
+    for s in range(S):
+        x = rnd(100 + s, 2 * (n - 13 * s))
+        mo.add(O.TestSource(x, 2, 48000))
+        mg.add(G.TestSource(x, 2, 48000))
+    assert np.array_equal(mg.collect(), mo.collect())
+
+
+# ====================================================================== fused pipeline ====
+def _oracle_pipeline(O, xs, frm, to, span, filt, freq):
+    m = O.Mixer(2, to)
+    for x in xs:
+        src = O.TestSource(x, 2, frm) if not span else O.SpanSource(x, 2, frm, span)
+        u = O.UniformSourceIterator(src, 2, to)
+        if filt == "low_pass":
+            u = u.low_pass(freq)
+        elif filt == "high_pass":
+            u = u.high_pass(freq)
+        m.add(u)
+    return m.collect()
+
+
+def _gpu_pipeline(G, xs, frm, to, span, filt, freq, **kw):
+    import torch
+
+    p = G.ResampleLowpassMix(frm, to, 2, span, filt, freq, 0.5, max_sources=len(xs), max_in_frames=max(len(x) // 2 for x in xs) or 1, **kw)
+    ts = [torch.from_numpy(np.ascontiguousarray(x)).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs]
+    p.set_sources(ts)
+    out = p.run()
+    p.check_status()
+    res = out.cpu().numpy().copy()
+    geo = p.geometry()
+    p.close()
+    return res, geo
+
+
+@pytest.mark.parametrize("R,T", [(4, 128), (8, 256), (6, 384), (16, 256), (12, 512)])
+@pytest.mark.parametrize("span", [None, 32768])
+def test_fused_resample_mix_bit_exact(G, O, R, T, span):
+    # filter off: the fused kernel must reproduce resampler + ordered mixer sum bit for bit
+    S, n = 9, 40000
+    xs = [rnd(300 + s, 2 * n) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, span, None, 0)
+    out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=R, threads=T)
+    assert len(out) == len(ref)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("frm,to", [(48000, 44100), (44100, 40000), (96000, 48000), (32000, 48000)])
+def test_fused_other_ratios_bit_exact(G, O, frm, to):
+    S, n = 5, 30011
+    xs = [rnd(400 + s, 2 * n) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, frm, to, None, None, 0)
+    out, _ = _gpu_pipeline(G, xs, frm, to, None, None, 0)
+    assert np.array_equal(out, ref)
+
+
+def test_fused_ragged_lengths_bit_exact(G, O):
+    ns = [40000, 1, 0, 2, 39999, 12345, 147, 148]
+    xs = [rnd(500 + i, 2 * n) for i, n in enumerate(ns)]
+    for span in (None, 32768):
+        ref = _oracle_pipeline(O, xs, 44100, 48000, span, None, 0)
+        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=4, threads=128)
+        assert np.array_equal(out, ref)
+
+
+def _report(tag, out, ref):
+    err = float(np.max(np.abs(out - ref))) if len(ref) else 0.0
+    peak = float(np.max(np.abs(ref))) if len(ref) else 1.0
+    print(f"[{tag}] max_abs_err={err:.3e} peak={peak:.3e} rel_to_peak={err / max(peak, 1e-30):.3e}")
+    return err, peak
+
+
+@pytest.mark.parametrize("R,T", [(4, 128), (8, 256), (6, 384), (16, 256)])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("low_pass", 1000), ("high_pass", 300)])
+def test_fused_filtered_pipeline(G, O, R, T, filt, freq):
+    # BASELINE config 2 at oracle-friendly size: 16 sources x 60000 frames, amplitude 1/16
+    S, n = 16, 60000
+    xs = [rnd(600 + s, 2 * n, 1.0 / S) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, filt, freq)
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, filt, freq, frames_per_lane=R, threads=T)
+    assert len(out) == len(ref)
+    err, peak = _report(f"{filt}{freq} R{R} T{T} J{geo['lookback_tiles']}", out, ref)
+    assert err <= TOL
+    assert err <= 2e-5 * peak + 1e-7  # and not merely because the inputs were scaled down
+
+
+def test_fused_filtered_full_scale_inputs(G, O):
+    # unscaled inputs: the f32 recurrence itself moves by ~1e-6 relative between evaluation
+    # orders; tolerance is relative to the peak here
+    S, n = 4, 50000
+    xs = [rnd(700 + s, 2 * n) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 200)
+    out, _ = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 200)
+    err, peak = _report("full-scale", out, ref)
+    assert err <= 2e-5 * max(peak, 1.0)
+
+
+def test_fused_filtered_long_lookback(G, O):
+    # a 20 Hz low-pass has poles at ~0.9974: with 512-frame tiles the carry reaches back
+    # several tiles (J > 1), exercising the multi-tile gather
+    S, n = 6, 50000
+    xs = [rnd(800 + s, 2 * n, 1.0 / S) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 20)
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 20, frames_per_lane=4, threads=128)
+    assert geo["lookback_tiles"] > 1
+    err, peak = _report(f"lookback J{geo['lookback_tiles']}", out, ref)
+    assert err <= TOL and err <= 5e-5 * peak + 1e-7
+
+
+def test_fused_filtered_chunked_and_ragged(G, O):
+    ns = [50000, 16384, 16385, 1, 0, 33000, 49999]
+    xs = [rnd(900 + i, 2 * n, 0.2) for i, n in enumerate(ns)]
+    for span in (None, 32768):
+        ref = _oracle_pipeline(O, xs, 44100, 48000, span, "low_pass", 200)
+        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, "low_pass", 200, frames_per_lane=8, threads=128)
+        assert len(out) == len(ref)
+        err, _ = _report(f"ragged span={span}", out, ref)
+        assert err <= TOL
+
+
+def test_fused_matches_unfused_gpu_ops(G, O):
+    # fused kernel vs the standalone ops (resample -> sequential biquad -> ordered mix), 64 sources
+    S, n = 64, 50000
+    xs = [rnd(1000 + s, 2 * n, 1.0 / S) for s in range(S)]
+    m = G.Mixer(2, 48000)
+    for x in xs:
+        m.add(G.UniformSourceIterator(G.TestSource(x, 2, 44100), 2, 48000).low_pass(200))
+    unfused = m.collect()
+    out, _ = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 200)
+    err, _ = _report("fused vs unfused", out, unfused)
+    assert err <= TOL
+
+
+# ------------------------------------------- BASELINE config 2 at full size: properties ----
+@pytest.fixture(scope="module")
+def cfg2(G):
+    import torch
+
+    S, N = 256, 1 << 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    data = (torch.rand((S, N * 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1) * (1.0 / S)
+    return S, N, data
+
+
+def test_cfg2_full_size_head_and_tail_vs_oracle(G, O, cfg2):
+    """Full-size run (256 x 1 Mi stereo frames, 44.1->48 k, low_pass(200), mix).  The system is
+    causal and the filter's memory is ~2k frames, so the oracle can check (a) the head from a
+    prefix of every source and (b) the tail from a suffix that starts on a resampler period
+    (input frame multiple of F=147 <-> output frame multiple of T=160) with a long warm-up."""
+    import torch
+
+    S, N, data = cfg2
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=N)
+    p.set_sources([data[s] for s in range(S)])
+    out = p.run()
+    p.check_status()
+    M = p.out_frames
+    assert M == 1141308  # ceil((N-1)*160/147)+1
+    full = out.cpu().numpy()
+    # (a) head
+    n_head = 6000
+    head = data[:, : n_head * 2].cpu().numpy()
+    ref = _oracle_pipeline(O, [head[s] for s in range(S)], 44100, 48000, None, "low_pass", 200)
+    k = (len(ref) // 2 - 8) * 2  # the last oracle frames see the prefix's end-of-stream rule
+    err, peak = _report("cfg2 head", full[:k], ref[:k])
+    assert err <= TOL and err <= 2e-5 * peak + 1e-7
+    # (b) tail
+    i0 = ((N - 30000) // 147) * 147
+    m0 = i0 // 147 * 160
+    tail = data[:, i0 * 2:].cpu().numpy()
+    ref = _oracle_pipeline(O, [tail[s] for s in range(S)], 44100, 48000, None, "low_pass", 200)
+    assert m0 + len(ref) // 2 == M
+    keep = 8000 * 2  # compare the last 8000 frames (warm-up of ~24000 frames before them)
+    err, peak = _report("cfg2 tail", full[-keep:], ref[-keep:])
+    assert err <= TOL and err <= 2e-5 * peak + 1e-7
+    p.close()
+
+
+def test_cfg2_full_size_linearity_is_bit_exact(G, cfg2):
+    """Size-independent property: every stage is linear, and scaling by a power of two is exact in
+    f32, so pipeline(2x) == 2 * pipeline(x) bit for bit (any lost carry, mis-indexed tap or
+    race in the tile hand-off breaks this)."""
+    import torch
+
+    S, N, data = cfg2
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=N)
+    p.set_sources([data[s] for s in range(S)])
+    a = p.run().clone()
+    b = p.run().clone()  # same input twice: the hand-off protocol must be deterministic
+    p.check_status()
+    assert torch.equal(a, b)
+    data.mul_(2.0)
+    c = p.run().clone()
+    p.check_status()
+    data.mul_(0.5)
+    assert torch.equal(c, a * 2.0)
+    assert float(a.abs().max()) > 0
+    p.close()
+
+
+def test_cfg2_chunked_variant_matches_unchunked_away_from_seams(G, cfg2):
+    """span_len=32768 variant: 64 chunks x 17833 frames; inside a chunk the output
+    equals the continuous stream's (same taps), only the seam frames differ."""
+    S, N, data = cfg2
+    pc = G.ResampleLowpassMix(44100, 48000, 2, 32768, None, 0, 0.5, max_sources=S, max_in_frames=N)
+    pc.set_sources([data[s] for s in range(S)])
+    oc = pc.run().cpu().numpy()
+    pc.check_status()
+    assert pc.out_frames == 64 * 17833
+    pu = G.ResampleLowpassMix(44100, 48000, 2, None, None, 0, 0.5, max_sources=S, max_in_frames=N)
+    pu.set_sources([data[s] for s in range(S)])
+    ou = pu.run().cpu().numpy()
+    # chunk 0 covers output frames [0, 17833): all but its last frame coincide with the continuous stream
+    assert np.array_equal(oc[: 17832 * 2], ou[: 17832 * 2])
+    pc.close()
+    pu.close()

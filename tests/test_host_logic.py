@@ -1,0 +1,76 @@
+"""Host-side logic of the C ABI (no GPU needed) against the oracle: output-length closed form of
+the resampler incl. span chunking, biquad coefficients, spatial gains, delay length."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _out_frames(rh, n, frm, to, ch, span):
+    from rodio_amd import _lib
+
+    o = C.c_uint64(0)
+    st = _lib.lib.rh_resample_out_frames(n, frm, to, ch, span, C.byref(o))
+    return st, o.value
+
+
+RATES = [(44100, 48000), (48000, 44100), (8000, 48000), (48000, 8000), (44100, 40000), (11025, 48000),
+         (2000, 3000), (1000, 7000), (12000, 2400), (48000, 96000), (22050, 22050)]
+
+
+@pytest.mark.parametrize("frm,to", RATES)
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_out_frames_unchunked(rh, O, frm, to, ch):
+    for n in [0, 1, 2, 3, 4, 5, 17, 100, 147, 160, 161, 1000]:
+        x = np.arange(n * ch, dtype=np.float32)
+        ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+        st, m = _out_frames(rh, n, frm, to, ch, 0)
+        assert st == 0
+        assert m * ch == len(ref), (n, frm, to, ch)
+
+
+@pytest.mark.parametrize("frm,to", [(44100, 48000), (48000, 44100), (8000, 48000), (48000, 8000)])
+@pytest.mark.parametrize("span,ch", [(64, 2), (100, 2), (32768, 2), (96, 1), (10, 1), (1 << 20, 2)])
+def test_out_frames_chunked(rh, O, frm, to, span, ch):
+    # UniformSourceIterator restarts the converter every min(span, 32768) samples (uniform.rs:56)
+    for n in [0, 1, 31, 32, 33, 50, 51, 99, 100, 101, 250, 16384, 16385, 40000]:
+        x = np.arange(n * ch, dtype=np.float32)
+        ref = O.UniformSourceIterator(O.SpanSource(x, ch, frm, span), ch, to).collect()
+        st, m = _out_frames(rh, n, frm, to, ch, span)
+        assert st == 0
+        assert m * ch == len(ref), (n, frm, to, span, ch)
+
+
+def test_out_frames_rejects(rh):
+    assert _out_frames(rh, 10, 0, 48000, 2, 0)[0] == 1        # zero rate: rodio's NonZero
+    assert _out_frames(rh, 10, 44100, 48000, 0, 0)[0] == 1
+    assert _out_frames(rh, 10, 44100, 48000, 6, 32768)[0] == 3  # span that splits a frame
+    assert _out_frames(rh, 10, 4294967291, 4294967279, 1, 0)[0] == 3  # from*to overflows u32 (sample_rate.rs:45-47)
+
+
+@pytest.mark.parametrize("kind", ["low_pass", "high_pass"])
+@pytest.mark.parametrize("freq,q,fs", [(200, 0.5, 48000), (1000, 0.5, 48000), (300, 0.5, 44100), (5000, 0.7071, 96000),
+                                        (20, 0.5, 48000), (200, 2.0, 8000)])
+def test_biquad_coeffs_bit_exact(rh, O, kind, freq, q, fs):
+    assert np.array_equal(rh.biquad_coeffs(kind, freq, q, fs), O.blt_coeffs(kind, freq, q, fs))
+
+
+def test_spatial_gains_bit_exact(rh, O):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        e, l, r = rng.uniform(-3, 3, (3, 3)).astype(np.float32)
+        assert np.array_equal(rh.spatial_gains(e, l, r), O.spatial_gains(e, l, r))
+    # BASELINE config 3 geometry
+    for s in range(64):
+        e = [0.5 + 0.01 * s, 0, 1]
+        assert np.array_equal(rh.spatial_gains(e, [-1, 0, 0], [1, 0, 0]), O.spatial_gains(e, [-1, 0, 0], [1, 0, 0]))
+
+
+def test_delay_samples(rh, O):
+    # 682_666_667 ns -> 65536 samples at 48 kHz stereo; one ns less -> 65535 (odd!)
+    assert rh.delay_samples(682_666_667, 48000, 2) == 65536 == O.delay_samples(682_666_667, 48000, 2)
+    assert rh.delay_samples(682_666_666, 48000, 2) == 65535 == O.delay_samples(682_666_666, 48000, 2)
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        ns, rate, ch = int(rng.integers(0, 10**10)), int(rng.integers(1, 400000)), int(rng.integers(1, 9))
+        assert rh.delay_samples(ns, rate, ch) == O.delay_samples(ns, rate, ch)
