@@ -103,6 +103,15 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python rodio_amd/build.py` (needs hipcc). "
             "rodio_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64
+    # (same SONAME as /opt/rocm's).  If librodio_hip.so pulled in /opt/rocm's copy first, torch
+    # would later load a second runtime and one of the two would see no device.  Loading torch
+    # first makes the library bind to the runtime that is already in the process.  Hosts without
+    # torch (the Rust/C++ side) simply get /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI

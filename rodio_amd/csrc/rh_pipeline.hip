@@ -51,7 +51,7 @@ constexpr int kMaxR = 32;
 constexpr int kMaxThreads = 512;
 constexpr int kMaxLook = 64;
 constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
-constexpr int kHeaderBytes = 320;  // wagg[2][8][4] f32 (256 B) + cbuf[2][4] f32 (32 B) + misc (32 B)
+constexpr int kHeaderBytes = 640;  // wagg[2][8][4] f64 (512 B) + cbuf[2][4] f64 (64 B) + misc (64 B)
 
 struct SrcDesc {
     const float *data;
@@ -63,15 +63,19 @@ struct SrcDesc {
 // Wave-uniform tables travel in the kernel argument block (scalar registers); only the
 // per-lane tables live in memory.
 struct Uniforms {
-    float b0, b1, b2, a1, a2;
-    float scanM[6][4];            // A^(R*2^k)
-    float waveM[4];               // A^(64R)
+    // H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z), c1 = b1 - b0*a1, c2 = b2 - b0*a2: the recursive part
+    // w = y - b0*x is the state that is scanned.  w is smooth whenever the poles sit near z = 1
+    // (also for a high-pass, whose y is not), which keeps the zero-state run and the
+    // homogeneous correction of the same magnitude as w instead of cancelling large terms.
+    float b0, c1, c2, a1, a2;
+    double scanM[6][4];           // A^(R*2^k)
+    double waveM[4];              // A^(64R)
     float g1[kMaxR], g2[kMaxR];   // (A^(r+1))[0][0], [0][1]: homogeneous response inside a run
 };
 struct Tables {
-    float laneM[64][4];           // A^(R*lane)
-    float carryM[kMaxThreads][4]; // A^(R*tid)
-    float lookM[kMaxLook][4];     // A^(L*j)
+    double laneM[64][4];           // A^(R*lane)
+    double carryM[kMaxThreads][4]; // A^(R*tid)
+    double lookM[kMaxLook][4];     // A^(L*j)
 };
 
 struct Params {
@@ -144,18 +148,21 @@ __device__ __forceinline__ float div_T(float t, float Tf, float rcpT) {
 }
 
 // y = M * x for a row-major 2x2
-__device__ __forceinline__ void mat_acc(const float *M, float x1, float x2, float &y1, float &y2) {
-    y1 = fma_(M[0], x1, fma_(M[1], x2, y1));
-    y2 = fma_(M[2], x1, fma_(M[3], x2, y2));
+// The filter STATE algebra (scan, wave chain, tile carry) runs in f64: a rounding error in a
+// state is later multiplied by ||A^n|| (up to ~1/(e(1-|pole|))), so f32 there costs 10-100x the
+// reference's own error.  Samples, taps and the per-sample correction stay f32.
+__device__ __forceinline__ void mat_acc(const double *M, double x1, double x2, double &y1, double &y2) {
+    y1 = __builtin_fma(M[0], x1, __builtin_fma(M[1], x2, y1));
+    y2 = __builtin_fma(M[2], x1, __builtin_fma(M[3], x2, y2));
 }
 
 template <int R, int KV, int D, bool FILT>
 __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
     static_assert(R % 2 == 0 && R <= kMaxR, "R must be even");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *wagg = reinterpret_cast<float *>(smem);              // [2][8][4]
-    float *cbuf = reinterpret_cast<float *>(smem + 256);        // [2][4]
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + 288);  // ticket
+    double *wagg = reinterpret_cast<double *>(smem);            // [2][8][4]
+    double *cbuf = reinterpret_cast<double *>(smem + 512);      // [2][4]
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + 576);  // ticket
     unsigned char *inbuf = smem + kHeaderBytes;                 // [2][stage_bytes]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
     }
 
     const Tables *__restrict__ tb = p.tabs;
-    float lM[4], cM[4];
+    double lM[4], cM[4];
     if (FILT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -207,16 +214,16 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
             cM[q] = tb->carryM[tid][q];
         }
     }
-    const float b0 = p.u.b0, b1 = p.u.b1, b2 = p.u.b2, na1 = -p.u.a1, na2 = -p.u.a2;
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
     float2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.0f, 0.0f);
-    float Qr[D][4];  // start-of-run states (zero tile carry) of the D sources in flight
+    double Qr[D][4];  // start-of-run states (zero tile carry) of the D sources in flight
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Qr[d][q] = 0.0f;
+        for (int q = 0; q < 4; ++q) Qr[d][q] = 0.0;
 
     bool dead = false;  // a bounded wait expired: never spin again in this workgroup
     float4 pre[KV];
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
 
     const uint32_t n_iter = FILT ? S + D : S;
     for (uint32_t s = 0; s < n_iter; ++s) {
-        float Qnew[4] = {0.f, 0.f, 0.f, 0.f};
-        float P[4] = {0.f, 0.f, 0.f, 0.f};
+        double Qnew[4] = {0., 0., 0., 0.};
+        double P[4] = {0., 0., 0., 0.};
         if (s < S) {
             if (s + 1 < S) issue_loads(s + 1);
             const uint64_t Ms = p.srcs[s].out_frames;
@@ -280,12 +287,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float2 x = tap(r + 2);
-                    float2 y;  // zero-state DF-I step; the y1 term goes last (shortest chain)
-                    y.x = fma_(na1, y1.x, fma_(na2, y2.x, fma_(b2, x2.x, fma_(b1, x1.x, b0 * x.x))));
-                    y.y = fma_(na1, y1.y, fma_(na2, y2.y, fma_(b2, x2.y, fma_(b1, x1.y, b0 * x.y))));
+                    float2 y;  // zero-state step of the recursive part w; the w1 term goes last (shortest chain)
+                    y.x = fma_(na1, y1.x, fma_(na2, y2.x, fma_(c2, x2.x, c1 * x1.x)));
+                    y.y = fma_(na1, y1.y, fma_(na2, y2.y, fma_(c2, x2.y, c1 * x1.y)));
                     if (r < nvalid) {
-                        acc[r].x += y.x;
-                        acc[r].y += y.y;
+                        acc[r].x += fma_(b0, x.x, y.x);
+                        acc[r].y += fma_(b0, x.y, y.y);
                     }
                     y2 = y1;
                     y1 = y;
@@ -300,10 +307,10 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const int d = 1 << k;
-                    const float q0 = __shfl_up(P[0], d), q1 = __shfl_up(P[1], d);
-                    const float q2 = __shfl_up(P[2], d), q3 = __shfl_up(P[3], d);
+                    const double q0 = __shfl_up(P[0], d), q1 = __shfl_up(P[1], d);
+                    const double q2 = __shfl_up(P[2], d), q3 = __shfl_up(P[3], d);
                     if (lane >= d) {
-                        const float *M = p.u.scanM[k];
+                        const double *M = p.u.scanM[k];
                         mat_acc(M, q0, q1, P[0], P[1]);
                         mat_acc(M, q2, q3, P[2], P[3]);
                     }
@@ -314,8 +321,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {  // exclusive: state at the start of this lane's run
-                    const float up = __shfl_up(P[q], 1);
-                    Qnew[q] = lane ? up : 0.0f;
+                    const double up = __shfl_up(P[q], 1);
+                    Qnew[q] = lane ? up : 0.0;
                 }
             } else {
 #pragma unroll
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
         }
         // ---- wave 0: gather the tile carry of source s-D from the J previous tiles -------------
         if (FILT && wave == 0) {
-            float c[4] = {0.f, 0.f, 0.f, 0.f};
+            double c[4] = {0., 0., 0., 0.};
             if (s >= (uint32_t)D && tile > 0) {
                 const uint32_t sp = s - D;
                 const bool need = (uint32_t)lane < p.J && (uint32_t)lane < tile;
@@ -357,9 +364,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                     __builtin_amdgcn_s_sleep(4);
                 }
                 if (need && ok) {
-                    const float *M = tb->lookM[lane];
-                    mat_acc(M, __uint_as_float((uint32_t)v[0]), __uint_as_float((uint32_t)v[1]), c[0], c[1]);
-                    mat_acc(M, __uint_as_float((uint32_t)v[2]), __uint_as_float((uint32_t)v[3]), c[2], c[3]);
+                    const double *M = tb->lookM[lane];
+                    mat_acc(M, (double)__uint_as_float((uint32_t)v[0]), (double)__uint_as_float((uint32_t)v[1]), c[0], c[1]);
+                    mat_acc(M, (double)__uint_as_float((uint32_t)v[2]), (double)__uint_as_float((uint32_t)v[3]), c[2], c[3]);
                 }
                 if (p.J > 1) {
 #pragma unroll
@@ -379,19 +386,20 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
         if (FILT) {
             if (s < S) {
                 // chain the waves: state at the start of this wave (zero tile carry)
-                float Wst[4] = {0.f, 0.f, 0.f, 0.f};
-                const float *wa = wagg + (s & 1) * 32;
+                double Wst[4] = {0., 0., 0., 0.};
+                const double *wa = wagg + (s & 1) * 32;
                 for (int u = 0; u < wave; ++u) {
-                    float n0 = wa[u * 4 + 0], n1 = wa[u * 4 + 1], n2 = wa[u * 4 + 2], n3 = wa[u * 4 + 3];
+                    double n0 = wa[u * 4 + 0], n1 = wa[u * 4 + 1], n2 = wa[u * 4 + 2], n3 = wa[u * 4 + 3];
                     mat_acc(p.u.waveM, Wst[0], Wst[1], n0, n1);
                     mat_acc(p.u.waveM, Wst[2], Wst[3], n2, n3);
                     Wst[0] = n0; Wst[1] = n1; Wst[2] = n2; Wst[3] = n3;
                 }
                 if (wave == W - 1 && lane < 4) {  // publish the tile aggregate: 4 granules
-                    float e0 = wa[wave * 4 + 0], e1 = wa[wave * 4 + 1], e2 = wa[wave * 4 + 2], e3 = wa[wave * 4 + 3];
+                    double e0 = wa[wave * 4 + 0], e1 = wa[wave * 4 + 1], e2 = wa[wave * 4 + 2], e3 = wa[wave * 4 + 3];
                     mat_acc(p.u.waveM, Wst[0], Wst[1], e0, e1);
                     mat_acc(p.u.waveM, Wst[2], Wst[3], e2, e3);
-                    const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+                    // a published state is rounded to f32 once, like any output sample
+                    const float ev = (float)(lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3);
                     const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
                     __hip_atomic_store(p.gran + ((uint64_t)s * p.n_tiles + tile) * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -402,10 +410,11 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                 const uint32_t sp = s - D;
                 const uint64_t Ms = p.srcs[sp].out_frames;
                 const int nvalid = Ms > m0 ? (Ms - m0 >= (uint64_t)R ? R : (int)(Ms - m0)) : 0;
-                const float *cb = cbuf + (s & 1) * 4;
-                float S0 = Qr[0][0], S1 = Qr[0][1], S2 = Qr[0][2], S3 = Qr[0][3];
-                mat_acc(cM, cb[0], cb[1], S0, S1);
-                mat_acc(cM, cb[2], cb[3], S2, S3);
+                const double *cb = cbuf + (s & 1) * 4;
+                double D0 = Qr[0][0], D1 = Qr[0][1], D2 = Qr[0][2], D3 = Qr[0][3];
+                mat_acc(cM, cb[0], cb[1], D0, D1);
+                mat_acc(cM, cb[2], cb[3], D2, D3);
+                const float S0 = (float)D0, S1 = (float)D1, S2 = (float)D2, S3 = (float)D3;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (r < nvalid) {
@@ -451,11 +460,11 @@ M2 mpow(M2 base, uint64_t e) {
     }
     return r;
 }
-void put(float *dst, const M2 &m) {
-    dst[0] = (float)m.a;
-    dst[1] = (float)m.b;
-    dst[2] = (float)m.c;
-    dst[3] = (float)m.d;
+void put(double *dst, const M2 &m) {
+    dst[0] = m.a;
+    dst[1] = m.b;
+    dst[2] = m.c;
+    dst[3] = m.d;
 }
 double norm(const M2 &m) { return std::fabs(m.a) + std::fabs(m.b) + std::fabs(m.c) + std::fabs(m.d); }
 
@@ -597,8 +606,8 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     Uniforms &U = p->uni;
     std::memset(&U, 0, sizeof(U));
     U.b0 = p->coeffs[0];
-    U.b1 = p->coeffs[1];
-    U.b2 = p->coeffs[2];
+    U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
+    U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
     U.a1 = p->coeffs[3];
     U.a2 = p->coeffs[4];
     const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
