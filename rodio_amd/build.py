@@ -20,8 +20,10 @@ LIB = os.path.join(HERE, "librodio_hip.so")
 SOURCES = ["rh_runtime.hip", "rh_elementwise.hip", "rh_resample.hip", "rh_recurrence.hip", "rh_pipeline.hip"]
 # -ffp-contract=off: the reference's f32 expressions (lerp, biquad, mixer sum) must not be
 # fused; kernels that want an FMA spell it __builtin_fmaf.
+# -fno-slp-vectorize: hipcc's SLP pass pairs the two stereo channels into v_pk_*_f32; on gfx950
+# that costs more v_mov shuffling and VGPRs than it saves (measured: fused kernel 1.25 -> 0.89 ms).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + os.environ.get("RH_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def hipcc() -> str:

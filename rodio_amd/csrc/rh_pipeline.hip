@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "rh_common.h"
@@ -51,7 +52,7 @@ constexpr int kMaxR = 32;
 constexpr int kMaxThreads = 512;
 constexpr int kMaxLook = 64;
 constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
-constexpr int kHeaderBytes = 640;  // wagg[2][8][4] f64 (512 B) + cbuf[2][4] f64 (64 B) + misc (64 B)
+constexpr int kHeaderBytes = 320;  // wagg[2][8][4] f32 (256 B) + cbuf[2][4] f32 (32 B) + misc (32 B)
 
 struct SrcDesc {
     const float *data;
@@ -59,30 +60,40 @@ struct SrcDesc {
     uint64_t out_frames;  // M_s
 };
 
-// Host-computed (f64 -> f32) powers of the companion matrix A = [[-a1,-a2],[1,0]], row major.
-// Wave-uniform tables travel in the kernel argument block (scalar registers); only the
-// per-lane tables live in memory.
+// ---- the biquad as data -----------------------------------------------------------------------
+// H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z) with c1 = b1 - b0*a1, c2 = b2 - b0*a2.  The recursive
+// part w = y - b0*x is what is scanned along time: w is smooth whenever the poles sit near
+// z = 1 (also for a high-pass, whose y is not), so its zero-state run and its homogeneous
+// correction stay of the magnitude of w instead of cancelling large terms.
+//
+// The scan works on z = Tm * (w[n-1], w[n-2]) rather than on the companion state itself.  For
+// the double real pole p of rodio's default q = 0.5 (blt.rs:11-16) Tm = [[1,-p],[0,1]] turns the
+// companion matrix into [[p,0],[1,p]], whose powers [[p^n,0],[n p^(n-1),p^n]] multiply the SMALL
+// component z1 = w1 - p*w2 by the large entry; for complex poles rho*e^(+-j*theta),
+// Tm = [[1,-rho cos],[0,rho sin]] gives rho*Rotation(theta), a normal matrix.  In that basis
+// every table below is benign in f32; in the companion basis the same algebra needs f64 (measured:
+// 10-30x the reference's own f32 error).  All tables are powers of B = Tm A Tm^-1 computed on the
+// host in f64 and rounded once.
 struct Uniforms {
-    // H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z), c1 = b1 - b0*a1, c2 = b2 - b0*a2: the recursive part
-    // w = y - b0*x is the state that is scanned.  w is smooth whenever the poles sit near z = 1
-    // (also for a high-pass, whose y is not), which keeps the zero-state run and the
-    // homogeneous correction of the same magnitude as w instead of cancelling large terms.
     float b0, c1, c2, a1, a2;
-    double scanM[6][4];           // A^(R*2^k)
-    double waveM[4];              // A^(64R)
-    float g1[kMaxR], g2[kMaxR];   // (A^(r+1))[0][0], [0][1]: homogeneous response inside a run
+    float Tm[4];                  // (w1,w2) -> z
+    float scanM[4][4];            // B^(R*2^k), k = 0..3   (row_shr 1,2,4,8)
+    float waveM[4];               // B^(64R)
 };
-struct Tables {
-    double laneM[64][4];           // A^(R*lane)
-    double carryM[kMaxThreads][4]; // A^(R*tid)
-    double lookM[kMaxLook][4];     // A^(L*j)
+struct Tables {                    // per-lane tables (loaded once per lane)
+    float g[kMaxR][2];             // row 0 of A^(r+1) Tm^-1: homogeneous response of w inside a run
+    float bc15M[64][4];            // B^(R*((lane&15)+1))   (row_bcast:15 step)
+    float bc31M[64][4];            // B^(R*((lane&31)+1))   (row_bcast:31 step)
+    float laneM[64][4];            // B^(R*lane)
+    float carryM[kMaxThreads][4];  // B^(R*tid)
+    float lookM[kMaxLook][4];      // B^(L*j)
 };
 
 struct Params {
     const SrcDesc *srcs;
     const Tables *tabs;
     float *out;
-    unsigned long long *gran;  // [S][tiles][4]
+    unsigned long long *gran;  // [S][tiles][4] {epoch, f32 bits}
     uint32_t *ticket;
     uint32_t *status;
     uint64_t out_frames;
@@ -147,25 +158,49 @@ __device__ __forceinline__ float div_T(float t, float Tf, float rcpT) {
     return fma_(rem, rcpT, q0);
 }
 
-// y = M * x for a row-major 2x2
-// The filter STATE algebra (scan, wave chain, tile carry) runs in f64: a rounding error in a
-// state is later multiplied by ||A^n|| (up to ~1/(e(1-|pole|))), so f32 there costs 10-100x the
-// reference's own error.  Samples, taps and the per-sample correction stay f32.
-__device__ __forceinline__ void mat_acc(const double *M, double x1, double x2, double &y1, double &y2) {
-    y1 = __builtin_fma(M[0], x1, __builtin_fma(M[1], x2, y1));
-    y2 = __builtin_fma(M[2], x1, __builtin_fma(M[3], x2, y2));
+// y += M * x for a row-major 2x2
+__device__ __forceinline__ void mat_acc(const float *M, float x1, float x2, float &y1, float &y2) {
+    y1 = fma_(M[0], x1, fma_(M[1], x2, y1));
+    y2 = fma_(M[2], x1, fma_(M[3], x2, y2));
 }
+
+// Cross-lane moves on the VALU data path (DPP), no LDS round trip.  Lanes whose source is out of
+// range, or whose row is masked off, read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+constexpr int kDppRowShr = 0x110;    // row_shr:n  = 0x110 + n
+constexpr int kDppWaveShr1 = 0x138;  // wave_shr:1
+constexpr int kDppBcast15 = 0x142;   // lane 15 of each row -> the next row
+constexpr int kDppBcast31 = 0x143;   // lane 31 -> rows 2 and 3
+
+#define RH_LDS __attribute__((address_space(3)))
+typedef RH_LDS unsigned char lds_u8;
+typedef RH_LDS float lds_f32;
+typedef RH_LDS uint32_t lds_u32;
+typedef float v2f __attribute__((ext_vector_type(2)));  // native vectors: HIP's float2/float4 classes
+typedef float v4f __attribute__((ext_vector_type(4)));  // cannot be read through address-space pointers
+typedef RH_LDS v2f lds_f2;
+typedef RH_LDS v4f lds_f4;
+#define RH_GLB __attribute__((address_space(1)))
+typedef RH_GLB const float glb_cf32;  // a pointer loaded from a descriptor is generic: say it is global,
+typedef RH_GLB const v2f glb_cf2;     // or every source load is a flat_load that also blocks lgkmcnt
+typedef RH_GLB const v4f glb_cf4;
 
 template <int R, int KV, int D, bool FILT>
 __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
     static_assert(R % 2 == 0 && R <= kMaxR, "R must be even");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *wagg = reinterpret_cast<double *>(smem);            // [2][8][4]
-    double *cbuf = reinterpret_cast<double *>(smem + 512);      // [2][4]
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + 576);  // ticket
-    unsigned char *inbuf = smem + kHeaderBytes;                 // [2][stage_bytes]
+    // explicit LDS address space: a generic pointer here turns every tap into a flat_load
+    lds_u8 *const lds = (lds_u8 *)smem;
+    lds_f32 *const wagg = (lds_f32 *)lds;                // [2][8][4]
+    lds_f32 *const cbuf = (lds_f32 *)(lds + 256);        // [2][4]
+    lds_u32 *const misc = (lds_u32 *)(lds + 288);        // ticket
+    lds_u8 *const inbuf = lds + kHeaderBytes;            // [2][stage_bytes]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = blockDim.x, W = NT >> 6;
 
     if (tid == 0) misc[0] = atomicAdd(p.ticket, 1u) - p.ticket_base;
@@ -181,16 +216,19 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
     {
         uint32_t nn;
         cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, i_base, nn);
-        i_base &= ~1ull;  // 16-byte aligned float4 loads
+        i_base &= ~1ull;  // 16-byte aligned vectors
         cursor_resolve(cursor_at(m_tile0 + L - 1, p), p, i_end, nn);
         i_end += 1;
     }
     uint32_t nvec = (uint32_t)((i_end - i_base + 2) / 2);
     if (nvec > (uint32_t)(KV * NT)) nvec = KV * NT;  // host sizes KV so this never bites
 
-    // ---- per-lane tap table: LDS byte offset of frame i(m) and the lerp numerator ------------
+    // ---- per-lane tap table: LDS byte offset of frame i(m) and the lerp weight ----------------
+    // FILT: weight = num/T (the lerp becomes one FMA, <= 1.5 ulp from math.rs:25 -- far inside
+    // the 1e-5 budget of the filtered pipeline); !FILT: weight = num, divided exactly per sample
+    // so that resample+mix alone stays bit-identical to the reference.
     int offA[R + 2];
-    float numf[R + 2];
+    float wgt[R + 2];
     {
         Cursor c = cursor_at(first ? 0 : m0 - 2, p);
 #pragma unroll
@@ -200,173 +238,238 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
             uint32_t num;
             cursor_resolve(c, p, i, num);
             offA[rr] = dummy ? 0 : (int)((i - i_base) * 8);
-            numf[rr] = dummy ? 0.0f : (float)num;
+            wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
             if (!dummy) cursor_next(c, p);
         }
     }
 
     const Tables *__restrict__ tb = p.tabs;
-    double lM[4], cM[4];
+    float lM[4], cM[4], b15[4], b31[4];
+    float g1v[R], g2v[R];  // homogeneous response of a run, in VGPRs (2R scalars would not fit the SGPR file)
     if (FILT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             lM[q] = tb->laneM[lane][q];
             cM[q] = tb->carryM[tid][q];
+            b15[q] = tb->bc15M[lane][q];
+            b31[q] = tb->bc31M[lane][q];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            g1v[r] = tb->g[r][0];
+            g2v[r] = tb->g[r][1];
         }
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
-    float2 acc[R];
+    v2f acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.0f, 0.0f);
-    double Qr[D][4];  // start-of-run states (zero tile carry) of the D sources in flight
+    for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
+    float Qr[D][4];  // start-of-run states (zero tile carry) of the D sources in flight
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Qr[d][q] = 0.0;
+        for (int q = 0; q < 4; ++q) Qr[d][q] = 0.0f;
 
     bool dead = false;  // a bounded wait expired: never spin again in this workgroup
-    float4 pre[KV];
-    auto issue_loads = [&](uint32_t s) {
-        const SrcDesc sd = p.srcs[s];
+
+    // ---- staging: source frames [i_base, i_base + 2*nvec) -> LDS stage, 16 bytes per lane -------
+    // Fast path (the span lies inside the source): global_load_lds DMA, no VGPR round trip, issued
+    // a whole source ahead.  Slow path (the tile touches the end of the source): register staged,
+    // replicating the last frame, which is what makes the resampler's "last frame verbatim" rule
+    // (sample_rate.rs:193-200) fall out of the plain lerp.
+    auto stage_source = [&](const SrcDesc &sd, uint32_t stage) {
+        lds_u8 *dstb = inbuf + stage * p.stage_bytes;
+        glb_cf32 *base = (glb_cf32 *)sd.data;
+        if (i_base + 2ull * nvec <= sd.frames) {
 #pragma unroll
-        for (int k = 0; k < KV; ++k) {
-            const uint32_t j = tid + k * NT;
-            const uint64_t f = i_base + 2ull * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < nvec && sd.frames) {
-                if (f + 1 < sd.frames) {
-                    v = *reinterpret_cast<const float4 *>(sd.data + f * 2);
-                } else {  // past the end: replicate the last frame (verbatim rule, see header)
-                    const uint64_t f0 = f < sd.frames ? f : sd.frames - 1;
-                    const float2 a = *reinterpret_cast<const float2 *>(sd.data + f0 * 2);
-                    const float2 b = *reinterpret_cast<const float2 *>(sd.data + (sd.frames - 1) * 2);
-                    v = make_float4(a.x, a.y, b.x, b.y);
+            for (int k = 0; k < KV; ++k) {
+                uint32_t j = tid + k * NT;
+                j = j < nvec ? j : nvec - 1;  // surplus lanes re-fetch the last vector into unused slots
+                __builtin_amdgcn_global_load_lds(base + (i_base + 2ull * j) * 2,
+                                                 (RH_LDS void *)(dstb + (wave * 64 + k * NT) * 16), 16, 0, 0);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < KV; ++k) {
+                const uint32_t j = tid + k * NT;
+                const uint64_t f = i_base + 2ull * j;
+                if (j < nvec) {
+                    v4f v = {0.f, 0.f, 0.f, 0.f};
+                    if (sd.frames) {
+                        const uint64_t f0 = f < sd.frames ? f : sd.frames - 1;
+                        const uint64_t f1 = f + 1 < sd.frames ? f + 1 : sd.frames - 1;
+                        const v2f a = *(glb_cf2 *)(base + f0 * 2);
+                        const v2f b = *(glb_cf2 *)(base + f1 * 2);
+                        v = v4f{a.x, a.y, b.x, b.y};
+                    }
+                    *(lds_f4 *)(dstb + j * 16) = v;
                 }
             }
-            pre[k] = v;
-        }
-    };
-    auto commit_loads = [&](uint32_t s) {
-        unsigned char *dstb = inbuf + (size_t)(s & 1) * p.stage_bytes;
-#pragma unroll
-        for (int k = 0; k < KV; ++k) {
-            const uint32_t j = tid + k * NT;
-            if (j < nvec) *reinterpret_cast<float4 *>(dstb + (size_t)j * 16) = pre[k];
         }
     };
 
     const uint32_t S = p.n_sources;
+    SrcDesc sd_cur{nullptr, 0, 0}, sd_nxt{nullptr, 0, 0}, sd_nn{nullptr, 0, 0};  // descriptors of sources s, s+1, s+2
     if (S > 0) {
-        issue_loads(0);
-        commit_loads(0);
+        sd_cur = p.srcs[0];
+        if (sd_cur.out_frames > m_tile0) stage_source(sd_cur, 0);
+        if (S > 1) {
+            sd_nxt = p.srcs[1];
+            if (sd_nxt.out_frames > m_tile0) stage_source(sd_nxt, 1);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    uint64_t Ms_hist[D];  // out_frames of the D sources in flight
+#pragma unroll
+    for (int d = 0; d < D; ++d) Ms_hist[d] = 0;
 
     const uint32_t n_iter = FILT ? S + D : S;
     for (uint32_t s = 0; s < n_iter; ++s) {
-        double Qnew[4] = {0., 0., 0., 0.};
-        double P[4] = {0., 0., 0., 0.};
-        if (s < S) {
-            if (s + 1 < S) issue_loads(s + 1);
-            const uint64_t Ms = p.srcs[s].out_frames;
-            const int nvalid = Ms > m0 ? (Ms - m0 >= (uint64_t)R ? R : (int)(Ms - m0)) : 0;
-            const unsigned char *buf = inbuf + (size_t)(s & 1) * p.stage_bytes;
-            auto tap = [&](int rr) -> float2 {
-                const float2 a = *reinterpret_cast<const float2 *>(buf + offA[rr]);
-                const float2 b = *reinterpret_cast<const float2 *>(buf + offA[rr] + 8);
-                float2 x;  // math.rs:25: first + (second - first) * num / den
-                x.x = a.x + div_T((b.x - a.x) * numf[rr], p.Tf, p.rcpT);
-                x.y = a.y + div_T((b.y - a.y) * numf[rr], p.Tf, p.rcpT);
+        float Qnew[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s + 2 < S) sd_nn = p.srcs[s + 2];  // needed right after the barrier
+        const uint64_t Ms = s < S ? sd_cur.out_frames : 0;
+        const bool active = Ms > m_tile0;  // this tile still holds frames of source s
+        const uint64_t Mp = Ms_hist[0];
+        const bool pactive = FILT && s >= (uint32_t)D && Mp > m_tile0;  // source s-D is finished in this iteration
+
+        // ---- wave 0: start fetching the carry granules of source s-D (consumed after the run) --
+        unsigned long long gv[4] = {0, 0, 0, 0};
+        bool need = false;
+        const unsigned long long *gp = p.gran;
+        if (FILT && wave == 0 && pactive && tile > 0) {
+            need = (uint32_t)lane < p.J && (uint32_t)lane < tile;
+            gp = p.gran + ((uint64_t)(s - D) * p.n_tiles + (tile - 1 - (need ? lane : 0))) * 4;
+            if (need && !dead) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
+        if (active) {
+            const lds_u8 *buf = inbuf + (s & 1) * p.stage_bytes;
+            auto tap = [&](int rr) -> v2f {
+                const v2f a = *(const lds_f2 *)(buf + offA[rr]);
+                const v2f b = *(const lds_f2 *)(buf + offA[rr] + 8);
+                v2f x;
+                if (FILT) {
+                    x.x = fma_(b.x - a.x, wgt[rr], a.x);
+                    x.y = fma_(b.y - a.y, wgt[rr], a.y);
+                } else {  // math.rs:25: first + (second - first) * num / den, exactly
+                    x.x = a.x + div_T((b.x - a.x) * wgt[rr], p.Tf, p.rcpT);
+                    x.y = a.y + div_T((b.y - a.y) * wgt[rr], p.Tf, p.rcpT);
+                }
                 return x;
             };
+            // lanes past the end of the source contribute nothing (the reference's iterator ended)
+            const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
+            const bool full = Ms >= m_tile0 + L;  // uniform: no lane needs masking
             if (FILT) {
-                float2 x2 = first ? make_float2(0.f, 0.f) : tap(0);
-                float2 x1 = first ? make_float2(0.f, 0.f) : tap(1);
-                float2 y1 = make_float2(0.f, 0.f), y2 = make_float2(0.f, 0.f);
+                v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
+                v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
+                v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+                auto run = [&](auto masked) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float2 x = tap(r + 2);
-                    float2 y;  // zero-state step of the recursive part w; the w1 term goes last (shortest chain)
-                    y.x = fma_(na1, y1.x, fma_(na2, y2.x, fma_(c2, x2.x, c1 * x1.x)));
-                    y.y = fma_(na1, y1.y, fma_(na2, y2.y, fma_(c2, x2.y, c1 * x1.y)));
-                    if (r < nvalid) {
-                        acc[r].x += fma_(b0, x.x, y.x);
-                        acc[r].y += fma_(b0, x.y, y.y);
+                    for (int r = 0; r < R; ++r) {
+                        const v2f x = tap(r + 2);
+                        v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
+                        w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
+                        w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
+                        float yx = fma_(b0, x.x, w.x), yy = fma_(b0, x.y, w.y);
+                        if (decltype(masked)::value) {
+                            const bool v = r < nvalid;
+                            yx = v ? yx : 0.0f;
+                            yy = v ? yy : 0.0f;
+                        }
+                        acc[r].x += yx;
+                        acc[r].y += yy;
+                        w2 = w1;
+                        w1 = w;
+                        x2 = x1;
+                        x1 = x;
                     }
-                    y2 = y1;
-                    y1 = y;
-                    x2 = x1;
-                    x1 = x;
+                };
+                if (full) run(std::false_type{});
+                else run(std::true_type{});
+                // ---- run end state in the scan basis, then the wave64 inclusive scan ----
+                float P[4] = {0.f, 0.f, 0.f, 0.f};
+                mat_acc(p.u.Tm, w1.x, w2.x, P[0], P[1]);
+                mat_acc(p.u.Tm, w1.y, w2.y, P[2], P[3]);
+#define RH_SCAN_STEP(K, N)                                                                          \
+    {                                                                                               \
+        const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
+        const float q2 = dpp0<kDppRowShr + N, 0xf>(P[2]), q3 = dpp0<kDppRowShr + N, 0xf>(P[3]);     \
+        mat_acc(p.u.scanM[K], q0, q1, P[0], P[1]);                                                  \
+        mat_acc(p.u.scanM[K], q2, q3, P[2], P[3]);                                                  \
+    }
+                RH_SCAN_STEP(0, 1)
+                RH_SCAN_STEP(1, 2)
+                RH_SCAN_STEP(2, 4)
+                RH_SCAN_STEP(3, 8)
+#undef RH_SCAN_STEP
+                {  // rows 1 and 3 take the inclusive prefix of the row before them
+                    const float q0 = dpp0<kDppBcast15, 0xa>(P[0]), q1 = dpp0<kDppBcast15, 0xa>(P[1]);
+                    const float q2 = dpp0<kDppBcast15, 0xa>(P[2]), q3 = dpp0<kDppBcast15, 0xa>(P[3]);
+                    mat_acc(b15, q0, q1, P[0], P[1]);
+                    mat_acc(b15, q2, q3, P[2], P[3]);
                 }
-                // ---- wave64 inclusive scan of the run end states over A^(R*2^k) ----
-                P[0] = y1.x;
-                P[1] = y2.x;
-                P[2] = y1.y;
-                P[3] = y2.y;
+                {  // rows 2 and 3 take the inclusive prefix of lanes 0..31
+                    const float q0 = dpp0<kDppBcast31, 0xc>(P[0]), q1 = dpp0<kDppBcast31, 0xc>(P[1]);
+                    const float q2 = dpp0<kDppBcast31, 0xc>(P[2]), q3 = dpp0<kDppBcast31, 0xc>(P[3]);
+                    mat_acc(b31, q0, q1, P[0], P[1]);
+                    mat_acc(b31, q2, q3, P[2], P[3]);
+                }
+                if (lane == 63) *(lds_f4 *)(wagg + ((s & 1) * 8 + wave) * 4) = v4f{P[0], P[1], P[2], P[3]};
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int d = 1 << k;
-                    const double q0 = __shfl_up(P[0], d), q1 = __shfl_up(P[1], d);
-                    const double q2 = __shfl_up(P[2], d), q3 = __shfl_up(P[3], d);
-                    if (lane >= d) {
-                        const double *M = p.u.scanM[k];
-                        mat_acc(M, q0, q1, P[0], P[1]);
-                        mat_acc(M, q2, q3, P[2], P[3]);
-                    }
-                }
-                if (lane == 63) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wagg[((s & 1) * 8 + wave) * 4 + q] = P[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {  // exclusive: state at the start of this lane's run
-                    const double up = __shfl_up(P[q], 1);
-                    Qnew[q] = lane ? up : 0.0;
-                }
+                for (int q = 0; q < 4; ++q) Qnew[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
             } else {
+                auto run = [&](auto masked) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float2 x = tap(r + 2);
-                    if (r < nvalid) {
+                    for (int r = 0; r < R; ++r) {
+                        v2f x = tap(r + 2);
+                        if (decltype(masked)::value && !(r < nvalid)) continue;  // an ended source adds nothing, not even +0.0
                         acc[r].x += x.x;
                         acc[r].y += x.y;
                     }
-                }
+                };
+                if (full) run(std::false_type{});
+                else run(std::true_type{});
             }
         }
-        // ---- wave 0: gather the tile carry of source s-D from the J previous tiles -------------
+        // ---- wave 0: finish the carry of source s-D: c = sum_j B^(L*j) * aggregate(tile-1-j) ------
         if (FILT && wave == 0) {
-            double c[4] = {0., 0., 0., 0.};
-            if (s >= (uint32_t)D && tile > 0) {
-                const uint32_t sp = s - D;
-                const bool need = (uint32_t)lane < p.J && (uint32_t)lane < tile;
-                const unsigned long long *g = p.gran + ((uint64_t)sp * p.n_tiles + (tile - 1 - (need ? lane : 0))) * 4;
-                unsigned long long v[4] = {0, 0, 0, 0};
+            float c[4] = {0.f, 0.f, 0.f, 0.f};
+            if (pactive && tile > 0) {
                 bool ok = !need;
-                uint32_t spins = 0;
-                while (!dead) {
-                    if (!ok) {
-                        bool all = true;
+                if (need && !dead) {
+                    ok = true;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q] = __hip_atomic_load(g + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            all = all && ((uint32_t)(v[q] >> 32) == p.epoch);
-                        }
-                        ok = all;
-                    }
-                    if (__all(ok)) break;
+                    for (int q = 0; q < 4; ++q) ok = ok && ((uint32_t)(gv[q] >> 32) == p.epoch);
+                }
+                uint32_t spins = 0;
+                while (!dead && !__all(ok)) {  // rare: the neighbour is more than D sources behind
                     if (++spins > kSpinLimit) {
                         if (lane == 0) atomicOr(p.status, 1u);
                         dead = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(4);
+                    if (!ok) {
+                        bool all = true;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
+                        }
+                        ok = all;
+                    }
                 }
                 if (need && ok) {
-                    const double *M = tb->lookM[lane];
-                    mat_acc(M, (double)__uint_as_float((uint32_t)v[0]), (double)__uint_as_float((uint32_t)v[1]), c[0], c[1]);
-                    mat_acc(M, (double)__uint_as_float((uint32_t)v[2]), (double)__uint_as_float((uint32_t)v[3]), c[2], c[3]);
+                    const float *M = tb->lookM[lane];
+                    mat_acc(M, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
+                    mat_acc(M, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
                 }
                 if (p.J > 1) {
 #pragma unroll
@@ -376,58 +479,69 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                     }
                 }
             }
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cbuf[(s & 1) * 4 + q] = c[q];
-            }
+            if (lane == 0) *(lds_f4 *)(cbuf + (s & 1) * 4) = v4f{c[0], c[1], c[2], c[3]};
         }
-        if (s + 1 < S) commit_loads(s + 1);
+        // the DMA of source s+1 (issued a whole iteration ago) must have landed before the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // stage (s&1) is free now: start fetching source s+2 into it
+        sd_cur = sd_nxt;
+        sd_nxt = sd_nn;
+        if (s + 2 < S && sd_nxt.out_frames > m_tile0) stage_source(sd_nxt, s & 1);
         if (FILT) {
-            if (s < S) {
+            if (active) {
                 // chain the waves: state at the start of this wave (zero tile carry)
-                double Wst[4] = {0., 0., 0., 0.};
-                const double *wa = wagg + (s & 1) * 32;
+                float Wst[4] = {0.f, 0.f, 0.f, 0.f};
+                const lds_f32 *wa = wagg + (s & 1) * 32;
                 for (int u = 0; u < wave; ++u) {
-                    double n0 = wa[u * 4 + 0], n1 = wa[u * 4 + 1], n2 = wa[u * 4 + 2], n3 = wa[u * 4 + 3];
+                    const v4f n = *(const lds_f4 *)(wa + u * 4);
+                    float n0 = n.x, n1 = n.y, n2 = n.z, n3 = n.w;
                     mat_acc(p.u.waveM, Wst[0], Wst[1], n0, n1);
                     mat_acc(p.u.waveM, Wst[2], Wst[3], n2, n3);
                     Wst[0] = n0; Wst[1] = n1; Wst[2] = n2; Wst[3] = n3;
                 }
                 if (wave == W - 1 && lane < 4) {  // publish the tile aggregate: 4 granules
-                    double e0 = wa[wave * 4 + 0], e1 = wa[wave * 4 + 1], e2 = wa[wave * 4 + 2], e3 = wa[wave * 4 + 3];
+                    const v4f n = *(const lds_f4 *)(wa + wave * 4);
+                    float e0 = n.x, e1 = n.y, e2 = n.z, e3 = n.w;
                     mat_acc(p.u.waveM, Wst[0], Wst[1], e0, e1);
                     mat_acc(p.u.waveM, Wst[2], Wst[3], e2, e3);
-                    // a published state is rounded to f32 once, like any output sample
-                    const float ev = (float)(lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3);
+                    const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
                     const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
                     __hip_atomic_store(p.gran + ((uint64_t)s * p.n_tiles + tile) * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 mat_acc(lM, Wst[0], Wst[1], Qnew[0], Qnew[1]);
                 mat_acc(lM, Wst[2], Wst[3], Qnew[2], Qnew[3]);
             }
-            if (s >= (uint32_t)D) {  // finish source s-D: add the homogeneous response to its true start state
-                const uint32_t sp = s - D;
-                const uint64_t Ms = p.srcs[sp].out_frames;
-                const int nvalid = Ms > m0 ? (Ms - m0 >= (uint64_t)R ? R : (int)(Ms - m0)) : 0;
-                const double *cb = cbuf + (s & 1) * 4;
-                double D0 = Qr[0][0], D1 = Qr[0][1], D2 = Qr[0][2], D3 = Qr[0][3];
-                mat_acc(cM, cb[0], cb[1], D0, D1);
-                mat_acc(cM, cb[2], cb[3], D2, D3);
-                const float S0 = (float)D0, S1 = (float)D1, S2 = (float)D2, S3 = (float)D3;
+            if (pactive) {  // finish source s-D: homogeneous response to its true start state
+                const int nvalid = Mp >= m0 + R ? R : (Mp > m0 ? (int)(Mp - m0) : 0);
+                const bool full = Mp >= m_tile0 + L;
+                const v4f cb = *(const lds_f4 *)(cbuf + (s & 1) * 4);
+                float S0 = Qr[0][0], S1 = Qr[0][1], S2 = Qr[0][2], S3 = Qr[0][3];
+                mat_acc(cM, cb.x, cb.y, S0, S1);
+                mat_acc(cM, cb.z, cb.w, S2, S3);
+                if (!full) {  // zero the start state of lanes with no valid frame; partial lanes are masked per frame
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (r < nvalid) {
-                        const float h1 = p.u.g1[r], h2 = p.u.g2[r];
-                        acc[r].x += fma_(h1, S0, h2 * S1);
-                        acc[r].y += fma_(h1, S2, h2 * S3);
+                    for (int r = 0; r < R; ++r) {
+                        const bool v = r < nvalid;
+                        const float hx = fma_(g1v[r], S0, g2v[r] * S1), hy = fma_(g1v[r], S2, g2v[r] * S3);
+                        acc[r].x += v ? hx : 0.0f;
+                        acc[r].y += v ? hy : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r].x = fma_(g1v[r], S0, fma_(g2v[r], S1, acc[r].x));
+                        acc[r].y = fma_(g1v[r], S2, fma_(g2v[r], S3, acc[r].y));
                     }
                 }
             }
 #pragma unroll
-            for (int d = 0; d + 1 < D; ++d)
+            for (int d = 0; d + 1 < D; ++d) {
+                Ms_hist[d] = Ms_hist[d + 1];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Qr[d][q] = Qr[d + 1][q];
+            }
+            Ms_hist[D - 1] = Ms;
 #pragma unroll
             for (int q = 0; q < 4; ++q) Qr[D - 1][q] = Qnew[q];
         }
@@ -441,7 +555,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
         if (m + 1 < p.out_frames) {
             *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
         } else if (m < p.out_frames) {
-            *reinterpret_cast<float2 *>(o + r * 2) = acc[r];
+            *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
         }
     }
 }
@@ -460,13 +574,31 @@ M2 mpow(M2 base, uint64_t e) {
     }
     return r;
 }
-void put(double *dst, const M2 &m) {
-    dst[0] = m.a;
-    dst[1] = m.b;
-    dst[2] = m.c;
-    dst[3] = m.d;
+void put(float *dst, const M2 &m) {
+    dst[0] = (float)m.a;
+    dst[1] = (float)m.b;
+    dst[2] = (float)m.c;
+    dst[3] = (float)m.d;
 }
 double norm(const M2 &m) { return std::fabs(m.a) + std::fabs(m.b) + std::fabs(m.c) + std::fabs(m.d); }
+
+// Scan basis for the companion matrix of z^2 + a1 z + a2 (see the comment above Uniforms).
+void scan_basis(double a1, double a2, M2 &T, M2 &Tinv) {
+    const double disc = a1 * a1 - 4.0 * a2;
+    const double re = -0.5 * a1;
+    double mu, nu;
+    if (disc < 0.0 && std::sqrt(-disc) * 0.5 > 1e-3) {  // complex pair rho e^(+-j theta)
+        mu = re;                                          // rho cos(theta)
+        nu = std::sqrt(-disc) * 0.5;                      // rho sin(theta)
+    } else {  // real poles (or a numerically double one): peel off the smaller pole
+        const double sq = disc > 0.0 ? std::sqrt(disc) * 0.5 : 0.0;
+        const double l1 = re + sq, l2 = re - sq;
+        mu = std::fabs(l1) < std::fabs(l2) ? l1 : l2;
+        nu = 1.0;
+    }
+    T = {1.0, -mu, 0.0, nu};
+    Tinv = {1.0, mu / nu, 0.0, 1.0 / nu};
+}
 
 constexpr int kD = 2;  // sources in flight between publishing an aggregate and consuming the carry
 
@@ -600,7 +732,7 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
         return RH_ERR_UNSUPPORTED;
     }
     p->resident_per_cu = blocks_per_cu(p->kernel, p->threads, p->lds_bytes);
-    // ---- tables ------------------------------------------------------------------------------
+    // ---- tables (all powers of B = Tm A Tm^-1, f64 on the host, rounded to f32 once) --------------
     Tables *h = new Tables();
     std::memset(h, 0, sizeof(Tables));
     Uniforms &U = p->uni;
@@ -611,24 +743,32 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     U.a1 = p->coeffs[3];
     U.a2 = p->coeffs[4];
     const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
+    M2 Tm, Ti;
+    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
+    const M2 B = mul(mul(Tm, A), Ti);
+    put(U.Tm, Tm);
     const uint64_t R = bestR, L = (uint64_t)bestR * bestT;
-    for (int k = 0; k < 6; ++k) put(U.scanM[k], mpow(A, R << k));
-    put(U.waveM, mpow(A, 64 * R));
+    for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, R << k));
+    put(U.waveM, mpow(B, 64 * R));
     for (int r = 0; r < bestR; ++r) {
-        const M2 m = mpow(A, r + 1);
-        U.g1[r] = (float)m.a;
-        U.g2[r] = (float)m.b;
+        const M2 m = mul(mpow(A, r + 1), Ti);  // w[r] = row 0 of A^(r+1) applied to the companion state Ti*z
+        h->g[r][0] = (float)m.a;
+        h->g[r][1] = (float)m.b;
     }
-    for (int l = 0; l < 64; ++l) put(h->laneM[l], mpow(A, R * l));
-    for (int t = 0; t < bestT; ++t) put(h->carryM[t], mpow(A, R * t));
-    const M2 AL = mpow(A, L);
+    for (int l = 0; l < 64; ++l) {
+        put(h->laneM[l], mpow(B, R * l));
+        put(h->bc15M[l], mpow(B, R * ((l & 15) + 1)));
+        put(h->bc31M[l], mpow(B, R * ((l & 31) + 1)));
+    }
+    for (int t = 0; t < bestT; ++t) put(h->carryM[t], mpow(B, R * t));
+    const M2 BL = mpow(B, L);
     uint32_t J = 0;
     if (p->filt) {
         M2 cur{1, 0, 0, 1};
         for (int j = 0; j < kMaxLook; ++j) {
             put(h->lookM[j], cur);
             J = j + 1;
-            cur = mul(cur, AL);
+            cur = mul(cur, BL);
             if (norm(cur) < 0x1p-40) break;  // older tiles are below f32 resolution of the state
             if (j == kMaxLook - 1) {          // pole radius too close to 1 for this tile length
                 delete h;
