@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)
-    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--ring-stages", type=int, default=0)
+    ap.add_argument("--no-balance", type=int, default=0)
+    ap.add_argument("--force-general", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1 << 18)
     args = ap.parse_args()
@@ -74,7 +76,7 @@ def main():
     g.manual_seed(1234 + rank)
     data = (torch.rand((S, N * Cn), generator=g, device="cuda", dtype=torch.float32) * 2 - 1) * (1.0 / (S * world))
     pipe = rh.ResampleLowpassMix(44100, 48000, Cn, args.span or None, "low_pass", args.freq, 0.5, max_sources=S,
-                                 max_in_frames=N, frames_per_lane=args.frames_per_lane, threads=args.threads)
+                                 max_in_frames=N, frames_per_lane=args.frames_per_lane, ring_stages=args.ring_stages, no_balance=args.no_balance, force_general=args.force_general)
     pipe.set_sources([data[s] for s in range(S)])
     M = pipe.out_frames
     outs = [torch.empty(M * Cn, device="cuda", dtype=torch.float32) for _ in range(2)]
@@ -150,6 +152,13 @@ def main():
             except Exception:
                 traffic = None
         geo = pipe.geometry()
+        ph = pipe.phase_cycles()
+        if ph is not None:
+            geo["phase_cycles"] = [round(x) for x in ph]
+        lc = pipe.late_carries()
+        geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
+        if lc >> 32:
+            geo["empty_polls_per_launch"] = (lc >> 32) / max(args.steps + args.warmup, 1)
         res = {
             "metric": "Msamples/s through resample+low_pass+mix pipeline",
             "value": in_samples * world * args.steps / elapsed / 1e6,
@@ -168,7 +177,7 @@ def main():
                             + (f", span_len={args.span}" if args.span else ", span_len=None")
                             + (f"; {world} ranks, sources sharded {S}/rank, RCCL all-reduce of the mixed block" if world > 1 else ""),
                 "sources_per_gpu": S, "in_frames": N, "out_frames": M, "channels": Cn,
-                "kernel": "k_rlm_stereo", "geometry": geo,
+                "kernel": "k_rlm_wave" if pipe.geometry()["general_kernel"] else "k_rlm_fast", "geometry": geo,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

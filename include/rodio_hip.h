@@ -173,8 +173,10 @@ typedef struct rh_rlm_config {
     float filter_q;        /* rodio's low_pass() uses 0.5 (blt.rs:11-16) */
     uint32_t max_sources;
     uint64_t max_in_frames;
-    uint32_t frames_per_lane; /* 0 = auto */
-    uint32_t threads;         /* 0 = auto */
+    uint32_t frames_per_lane; /* output frames per lane of a 64-lane tile; 0 = auto */
+    uint32_t ring_stages;     /* LDS stages of the source prefetch ring (2..4); 0 = auto */
+    uint32_t no_balance;      /* diagnostics: 1 = do not pad the LDS request to even out waves per CU */
+    uint32_t force_general;   /* diagnostics/tests: 1 = use the ragged-batch kernel even for equal lengths */
 } rh_rlm_config;
 typedef struct rh_rlm rh_rlm;
 rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg);
@@ -188,9 +190,25 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
                      rh_stream stream);
 /* After a synchronise: 0 if the last run completed, RH_ERR_TIMEOUT if a bounded wait expired. */
 rh_status rh_rlm_last_status(rh_rlm *p);
+/* Diagnostics: number of (tile, source) carries since the last call that had not been published by
+ * the neighbouring tile when they were due and had to be polled (synchronises with the device). */
+rh_status rh_rlm_late_carries(rh_rlm *p, uint64_t *count);
+/* Diagnostics, only in builds with -DRH_PHASE_PROFILE (RH_ERR_UNSUPPORTED otherwise): mean shader
+ * cycles per wave spent in each phase of the source loop during the last run. */
+rh_status rh_rlm_phase_cycles(rh_rlm *p, double out8[8]);
 /* Launch geometry chosen by create (for the bench's roofline report). */
-rh_status rh_rlm_geometry(rh_rlm *p, uint32_t *threads, uint32_t *frames_per_lane,
-                          uint32_t *lds_bytes, uint32_t *lookback_tiles);
+typedef struct rh_rlm_geometry_info {
+    uint32_t threads;          /* lanes per workgroup (one wave64 = one time tile) */
+    uint32_t frames_per_lane;  /* tile = 64 * frames_per_lane output frames */
+    uint32_t ring_stages;      /* sources prefetched ahead + 1 */
+    uint32_t stage_kib;        /* KiB of LDS per stage */
+    uint32_t lds_bytes;        /* dynamic LDS per workgroup */
+    uint32_t lookback_tiles;   /* predecessor tiles whose aggregates form a tile's carry */
+    uint32_t resident_waves_per_cu;
+    uint32_t n_tiles;          /* grid of the last set_sources */
+    uint32_t general_kernel;   /* 1: ragged-batch kernel (per-source carries), 0: equal-length kernel */
+} rh_rlm_geometry_info;
+rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librodio_hip.so")
+LIB_PATH = os.environ.get("RODIO_HIP_LIB") or os.path.join(_HERE, "librodio_hip.so")  # override: diagnostic builds
 
 RH_OK = 0
 STATUS_NAMES = {
@@ -38,7 +38,12 @@ class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
                 ("filter_q", C.c_float), ("max_sources", C.c_uint32), ("max_in_frames", C.c_uint64),
-                ("frames_per_lane", C.c_uint32), ("threads", C.c_uint32)]
+                ("frames_per_lane", C.c_uint32), ("ring_stages", C.c_uint32), ("no_balance", C.c_uint32), ("force_general", C.c_uint32)]
+
+
+class RlmGeometry(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("threads", "frames_per_lane", "ring_stages", "stage_kib", "lds_bytes",
+                                           "lookback_tiles", "resident_waves_per_cu", "n_tiles", "general_kernel")]
 
 
 vp, sz, u32, u64, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
@@ -94,7 +99,9 @@ SIGNATURES = {
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_last_status": (i32, [vp]),
-    "rh_rlm_geometry": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+    "rh_rlm_geometry": (i32, [vp, C.POINTER(RlmGeometry)]),
+    "rh_rlm_late_carries": (i32, [vp, C.POINTER(u64)]),
+    "rh_rlm_phase_cycles": (i32, [vp, C.POINTER(C.c_double)]),
 }
 
 

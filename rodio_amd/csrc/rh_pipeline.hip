@@ -9,27 +9,33 @@
 //   SampleRateConverter::next    src/conversions/sample_rate.rs:131-201, src/math.rs:23-26
 //
 // Work decomposition (wave64, no MFMA -- there is no contraction here):
-//   * workgroup = one tile of L = threads*R consecutive OUTPUT frames, for ALL sources;
-//     lane = a run of R consecutive frames.  The workgroup walks the sources in insertion
-//     order and keeps the mix accumulators (R stereo frames) in registers, so the mixer sum
-//     costs no memory traffic and keeps the reference's source order.
-//   * input frames of (source, tile) are contiguous in HBM: they are fetched with 16-byte
-//     coalesced loads one source ahead (register staged) into a double-buffered LDS tile;
-//     the lerp taps are LDS reads.  HBM traffic = input once + mixed output once.
-//   * the biquad is a linear recurrence along time.  Each lane runs it over its run from a
-//     zero y-state, the end states are combined with a wave64 Kogge-Stone scan over the
-//     2x2 companion-matrix powers A^(R*2^k) (host-computed in f64), waves are chained
-//     through LDS, and tiles are chained through HBM "granules" ({epoch,value} 8-byte
-//     words written with one agent-scope relaxed store each; cdna_hip_programming.md G16
-//     form R2).  A tile needs only the zero-state aggregates of its J predecessors, where
-//     J is the number of tiles after which ||A^(L*J)|| < 2^-40 (the filter is stable, so
-//     older history is below f32 resolution): no chained inclusive prefix, hence no
-//     serial dependency along the 500+ tiles.  The correction g1[r]*S1 + g2[r]*S2
-//     (homogeneous response to the true start state S) is added D sources later, which
-//     hides the hand-off latency behind the next sources' streaming.
-//   * tiles are numbered by an atomic ticket, so a tile only ever waits for tiles that
-//     already hold a CU: progress does not depend on dispatch order or residency.
+//   * one WAVE (= one 64-lane workgroup) owns a tile of L = 64*R consecutive OUTPUT frames for
+//     ALL sources; a lane owns a run of R consecutive frames.  The wave walks the sources in
+//     insertion order and keeps the mix accumulators (R stereo frames per lane) in registers,
+//     so the mixer sum costs no memory traffic and keeps the reference's source order.
+//     Single-wave workgroups need no barrier at all: ~9 fully decoupled waves per CU.
+//   * the input frames of (source, tile) are contiguous in HBM.  They are fetched with
+//     global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a ring of NS LDS stages,
+//     NS-1 sources ahead, and retired with a counted s_waitcnt vmcnt; the lerp taps are
+//     ds_read_b64.  HBM traffic = input once + mixed output once (+ ~1% carry granules).
+//     The DMA is issued from inline asm so that hipcc neither drains it at the next load
+//     (cdna_hip_programming.md "Pipelining across barriers") nor counts it: every wait for it
+//     is placed by hand below.
+//   * the biquad is a linear recurrence along time.  Each lane runs it over its run from a zero
+//     state, the run-end states are combined with a wave64 Kogge-Stone scan (DPP, no LDS) over
+//     the 2x2 companion-matrix powers B^(R*2^k) (host-computed in f64), and tiles are chained
+//     through HBM "granules" ({epoch,value} 8-byte words, one agent-scope relaxed store each;
+//     cdna_hip_programming.md G16 form R2).  A tile needs only the zero-state aggregates of its
+//     J predecessors, where J is the number of tiles after which ||B^(L*J)|| < 2^-40 (the filter
+//     is stable, so older history is below f32 resolution): no chained inclusive prefix, hence
+//     no serial dependency along the 2000+ tiles.  The correction g1[r]*S1 + g2[r]*S2
+//     (homogeneous response to the true start state S) is added D = NS sources later, which
+//     hides the hand-off latency behind the next sources' streaming; the granules themselves
+//     are fetched by LDS-DMA too, so they ride the same counted-vmcnt pipeline.
+//   * tiles are numbered by an atomic ticket, so a tile only ever waits for tiles that already
+//     hold a wave slot: progress does not depend on dispatch order or residency.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <type_traits>
@@ -48,16 +54,18 @@ rh_status make_resample_geom(uint64_t in_frames, uint32_t from_rate, uint32_t to
 
 namespace {
 
-constexpr int kMaxR = 32;
-constexpr int kMaxThreads = 512;
-constexpr int kMaxLook = 64;
+#ifndef RH_CARRY_DEFER
+#define RH_CARRY_DEFER 2  // see DESIGN.md: slack of the tile-to-tile hand-off, in groups of 8 sources
+#endif
+constexpr int kMaxR = 16;
+constexpr int kGroupLag = RH_CARRY_DEFER;  // a source group's carries are fetched kGroupLag groups (of 8 sources) after its own
+constexpr int kMaxLook = 32;              // 2 lanes x 16 B of LDS-DMA per predecessor tile: 64 lanes
 constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
-constexpr int kHeaderBytes = 320;  // wagg[2][8][4] f32 (256 B) + cbuf[2][4] f32 (32 B) + misc (32 B)
 
-struct SrcDesc {
+struct SrcDesc {          // 16 bytes: one s_load_dwordx4
     const float *data;
-    uint64_t frames;      // N_s
-    uint64_t out_frames;  // M_s
+    uint32_t frames;      // N_s   (< 2^29)
+    uint32_t out_frames;  // M_s   (< 2^31)
 };
 
 // ---- the biquad as data -----------------------------------------------------------------------
@@ -76,17 +84,15 @@ struct SrcDesc {
 // host in f64 and rounded once.
 struct Uniforms {
     float b0, c1, c2, a1, a2;
-    float Tm[4];                  // (w1,w2) -> z
-    float scanM[4][4];            // B^(R*2^k), k = 0..3   (row_shr 1,2,4,8)
-    float waveM[4];               // B^(64R)
+    float Tm[4];          // (w1,w2) -> z
+    float scanM[4][4];    // B^(R*2^k), k = 0..3   (row_shr 1,2,4,8)
+    float g[kMaxR][2];    // row 0 of A^(r+1) Tm^-1: homogeneous response of w inside a run
 };
-struct Tables {                    // per-lane tables (loaded once per lane)
-    float g[kMaxR][2];             // row 0 of A^(r+1) Tm^-1: homogeneous response of w inside a run
-    float bc15M[64][4];            // B^(R*((lane&15)+1))   (row_bcast:15 step)
-    float bc31M[64][4];            // B^(R*((lane&31)+1))   (row_bcast:31 step)
-    float laneM[64][4];            // B^(R*lane)
-    float carryM[kMaxThreads][4];  // B^(R*tid)
-    float lookM[kMaxLook][4];      // B^(L*j)
+struct Tables {            // per-lane tables (loaded once per lane)
+    float bc15M[64][4];    // B^(R*((lane&15)+1))   (row_bcast:15 step)
+    float bc31M[64][4];    // B^(R*((lane&31)+1))   (row_bcast:31 step)
+    float laneM[64][4];    // B^(R*lane)
+    float lookM[64][4];    // B^(L*j), j < kMaxLook
 };
 
 struct Params {
@@ -102,8 +108,9 @@ struct Params {
     uint32_t F, T, qF, rF;
     float Tf, rcpT;
     uint32_t epoch, J;
-    uint32_t stage_bytes;  // bytes of one LDS input stage
     uint32_t ticket_base;  // value of *ticket when this launch starts (the counter is never reset)
+    unsigned long long *prof;  // RH_PHASE_PROFILE builds: [tiles][8] cycles per phase
+    uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
     Uniforms u;
 };
 
@@ -170,6 +177,9 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp0(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
+// v_readlane / v_readfirstlane of a float (the builtins take int: pass the bits, not the value)
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float readfirstlane_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 constexpr int kDppRowShr = 0x110;    // row_shr:n  = 0x110 + n
 constexpr int kDppWaveShr1 = 0x138;  // wave_shr:1
 constexpr int kDppBcast15 = 0x142;   // lane 15 of each row -> the next row
@@ -177,51 +187,407 @@ constexpr int kDppBcast31 = 0x143;   // lane 31 -> rows 2 and 3
 
 #define RH_LDS __attribute__((address_space(3)))
 typedef RH_LDS unsigned char lds_u8;
-typedef RH_LDS float lds_f32;
-typedef RH_LDS uint32_t lds_u32;
 typedef float v2f __attribute__((ext_vector_type(2)));  // native vectors: HIP's float2/float4 classes
 typedef float v4f __attribute__((ext_vector_type(4)));  // cannot be read through address-space pointers
+typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
 typedef RH_LDS v2f lds_f2;
 typedef RH_LDS v4f lds_f4;
+typedef RH_LDS v2u64 lds_u64x2;
 #define RH_GLB __attribute__((address_space(1)))
 typedef RH_GLB const float glb_cf32;  // a pointer loaded from a descriptor is generic: say it is global,
 typedef RH_GLB const v2f glb_cf2;     // or every source load is a flat_load that also blocks lgkmcnt
-typedef RH_GLB const v4f glb_cf4;
 
-template <int R, int KV, int D, bool FILT>
-__global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
-    static_assert(R % 2 == 0 && R <= kMaxR, "R must be even");
+// ---- hand-counted memory pipeline -------------------------------------------------------------
+// One LDS-DMA instruction: 64 lanes x 16 bytes from base + voff (per lane) land at LDS byte
+// address lds_dst + lane*16 (wave-uniform base in M0; M0 is compiler-reserved, so it is saved and
+// restored inside the statement -- cdna_hip_programming.md 5.7).  hipcc does not see the load:
+// nothing waits for it except the wait_vm<N>() calls below.
+// "s" operands must be provably wave-uniform: rebuild the 64-bit base from two readfirstlanes.
+__device__ __forceinline__ const void *uniform_ptr(const void *q) {
+    const uint64_t v = (uint64_t)(uintptr_t)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
+    const void *sbase = uniform_ptr(sbase_);
+    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+// The same with sc1 (agent scope: served by L2, never by this CU's L1): the carry granules.
+__device__ __forceinline__ void glds16_sc1(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
+    const void *sbase = uniform_ptr(sbase_);
+    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Wait until at most n*KV vector-memory operations are outstanding (n uniform, 0..NS-1).
+template <int KV, int NS>
+__device__ __forceinline__ void wait_groups(int n) {
+    if (NS > 3 && n >= 3) wait_vm<(KV * 3 < 63 ? KV * 3 : 63)>();
+    else if (NS > 2 && n == 2) wait_vm<(KV * 2 < 63 ? KV * 2 : 63)>();
+    else if (n == 1) wait_vm<KV>();
+    else wait_vm<0>();
+}
+
+#ifdef RH_PHASE_PROFILE
+#define RH_PH_DECL unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter(); const unsigned long long ph_start = ph_last;
+#define RH_PH(i) { const unsigned long long ph_now = __builtin_readcyclecounter(); ph_t[i] += ph_now - ph_last; ph_last = ph_now; }
+#else
+#define RH_PH_DECL
+#define RH_PH(i)
+#endif
+
+// =================================================================================================
+// k_rlm_fast -- the same pipeline when every source has the same length (the benchmark batch, and
+// any mixer fed equal blocks).  Everything that couples lanes and tiles is LINEAR in the lanes'
+// zero-state run-end states E_s, and all sources share the filter, so it is done once on the SUM
+// over the sources instead of once per source:
+//     sum_s scan(E_s) = scan(sum_s E_s),   sum_s carry_s = sum_j B^(L*j) * (sum_s aggregate_s(tile-1-j)).
+// Per source the wave only streams the input (LDS-DMA ring), lerps, runs the zero-state biquad over
+// its lanes' runs and mixes; Eacc += E_s costs 4 adds.  After the last source: one wave64 scan of
+// Eacc, ONE published aggregate per tile, one look-back over the J predecessor tiles (which
+// finish at about the same time -- the tiles never wait for each other inside the source loop), one
+// homogeneous correction g[r] * (start state).  Ragged batches take k_rlm_wave below instead, where a
+// source that ends inside a tile needs its own masked correction.
+// =================================================================================================
+template <int R, int KV, int NS, bool FILT>
+__global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(const Params p) {
+    static_assert(R <= kMaxR, "frames per lane");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    static_assert(KV * (NS - 1) < 64, "vmcnt range");
+    constexpr uint32_t kStage = KV * 1024;  // bytes of one LDS input stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+
+    const int lane = threadIdx.x;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    constexpr uint32_t L = 64u * R;
+    const uint32_t m_tile0 = tile * L;
+    const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
+    const bool first = (m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
+    const uint32_t Mout = (uint32_t)p.out_frames;
+    const uint32_t Ns = p.eq_frames;  // every source has Ns frames (and Mout output frames)
+
+    uint32_t i_base, nvec;
+    {
+        uint64_t ib, ie;
+        uint32_t nn;
+        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        ib &= ~1ull;  // 16-byte aligned vectors
+        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        ie += 1;
+        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
+        i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);
+        nvec = __builtin_amdgcn_readfirstlane(nv);
+    }
+    // The tile reaches past the end of the sources: lanes beyond it re-fetch the last 16-byte vector
+    // (finite data no valid output reads), and the last frame's second tap is replaced by the first
+    // (sample_rate.rs:193-200: the last frame is emitted verbatim).  Same for every source here.
+    const bool edge = i_base + 2u * nvec > Ns;
+    const uint32_t lastoff = ((Ns - 1) & ~1u) * 8u;
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = lane + k * 64;
+        j = j < nvec ? j : nvec - 1;
+        goff[k] = (i_base + 2u * j) * 8u;
+        if (edge && goff[k] > lastoff) goff[k] = lastoff;
+    }
+    int offA[R + 2];
+    float wgt[R + 2];
+    {
+        const uint32_t dthr = Ns - 1 - i_base;
+        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
+        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            const bool dummy = first && rr < 2;
+            uint64_t i;
+            uint32_t num;
+            cursor_resolve(c, p, i, num);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
+            if (edge && offA[rr] >= thr) num = 0;  // verbatim last frame (and frames past it, never stored)
+            if (edge && offA[rr] > thr) offA[rr] = thr;
+            wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
+            if (!dummy) cursor_next(c, p);
+        }
+    }
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
+    v2f E1 = {0.f, 0.f}, E2 = {0.f, 0.f};  // sum over the sources of the run-end states (w[-1], w[-2])
+
+    const uint32_t S = p.n_sources;
+    typedef __attribute__((address_space(4))) const uint64_t cu64;
+    cu64 *const desc = (cu64 *)(uintptr_t)p.srcs;  // 16-byte descriptors: the pointer is the first qword
+    auto stage_source = [&](const void *data, uint32_t stage_off) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
+    };
+    const bool live = Mout > m_tile0 && Ns > 0;  // always true for a launched tile; keeps Ns-1 honest
+    uint32_t st_cur = 0;
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d)
+        if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[2 * d], d * kStage);
+    uint64_t ptr_pref = NS - 1 < S ? desc[2 * (NS - 1)] : 0;  // fetched one iteration ahead of its use
+    RH_PH_DECL
+
+    for (uint32_t s = 0; s < S && live; ++s) {
+        {  // stage source s+NS-1 into the slot source s-1 has just left
+            uint32_t st_new = st_cur + (NS - 1) * kStage;
+            if (st_new >= NS * kStage) st_new -= NS * kStage;
+            if (s + NS - 1 < S) stage_source((const void *)(uintptr_t)ptr_pref, st_new);
+            ptr_pref = s + NS < S ? desc[2 * (uint64_t)(s + NS)] : 0;
+        }
+        RH_PH(1)
+        {  // the stage of source s has landed when at most the groups issued after it are outstanding
+            const uint32_t left = S - 1 - s;
+            wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
+        }
+        RH_PH(2)
+        v2f ta[R + 2], tb2[R + 2];
+        {
+            const lds_u8 *buf = lds + st_cur;
+#pragma unroll
+            for (int rr = 0; rr < R + 2; ++rr) {
+                ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
+                tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
+            }
+        }
+        auto tap = [&](int rr) -> v2f {
+            const v2f a = ta[rr], b = tb2[rr];
+            v2f x;
+            if (FILT) {
+                x.x = fma_(b.x - a.x, wgt[rr], a.x);
+                x.y = fma_(b.y - a.y, wgt[rr], a.y);
+            } else {  // math.rs:25: first + (second - first) * num / den, exactly
+                x.x = a.x + div_T((b.x - a.x) * wgt[rr], p.Tf, p.rcpT);
+                x.y = a.y + div_T((b.y - a.y) * wgt[rr], p.Tf, p.rcpT);
+            }
+            return x;
+        };
+        if (FILT) {
+            v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
+            v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
+            v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const v2f x = tap(r + 2);
+                v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
+                w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
+                w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
+                acc[r].x += fma_(b0, x.x, w.x);
+                acc[r].y += fma_(b0, x.y, w.y);
+                w2 = w1;
+                w1 = w;
+                x2 = x1;
+                x1 = x;
+            }
+            E1 += w1;
+            E2 += w2;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const v2f x = tap(r + 2);
+                acc[r].x += x.x;
+                acc[r].y += x.y;
+            }
+        }
+        st_cur += kStage;
+        if (st_cur >= NS * kStage) st_cur = 0;
+        RH_PH(4)
+    }
+    wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
+
+    if (FILT && live) {
+        const Tables *__restrict__ tb = p.tabs;
+        float lM[4], b15[4], b31[4], kM[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lM[q] = tb->laneM[lane][q];
+            b15[q] = tb->bc15M[lane][q];
+            b31[q] = tb->bc31M[lane][q];
+            kM[q] = tb->lookM[lane & (kMaxLook - 1)][q];
+        }
+        // ---- summed run-end states in the scan basis, then the wave64 inclusive scan ----
+        float P[4] = {0.f, 0.f, 0.f, 0.f};
+        mat_acc(p.u.Tm, E1.x, E2.x, P[0], P[1]);
+        mat_acc(p.u.Tm, E1.y, E2.y, P[2], P[3]);
+#define RH_SCAN_STEP(K, N)                                                                          \
+    {                                                                                               \
+        const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
+        const float q2 = dpp0<kDppRowShr + N, 0xf>(P[2]), q3 = dpp0<kDppRowShr + N, 0xf>(P[3]);     \
+        mat_acc(p.u.scanM[K], q0, q1, P[0], P[1]);                                                  \
+        mat_acc(p.u.scanM[K], q2, q3, P[2], P[3]);                                                  \
+    }
+        RH_SCAN_STEP(0, 1)
+        RH_SCAN_STEP(1, 2)
+        RH_SCAN_STEP(2, 4)
+        RH_SCAN_STEP(3, 8)
+#undef RH_SCAN_STEP
+        {  // rows 1 and 3 take the inclusive prefix of the row before them
+            const float q0 = dpp0<kDppBcast15, 0xa>(P[0]), q1 = dpp0<kDppBcast15, 0xa>(P[1]);
+            const float q2 = dpp0<kDppBcast15, 0xa>(P[2]), q3 = dpp0<kDppBcast15, 0xa>(P[3]);
+            mat_acc(b15, q0, q1, P[0], P[1]);
+            mat_acc(b15, q2, q3, P[2], P[3]);
+        }
+        {  // rows 2 and 3 take the inclusive prefix of lanes 0..31
+            const float q0 = dpp0<kDppBcast31, 0xc>(P[0]), q1 = dpp0<kDppBcast31, 0xc>(P[1]);
+            const float q2 = dpp0<kDppBcast31, 0xc>(P[2]), q3 = dpp0<kDppBcast31, 0xc>(P[3]);
+            mat_acc(b31, q0, q1, P[0], P[1]);
+            mat_acc(b31, q2, q3, P[2], P[3]);
+        }
+        {  // publish the tile aggregate (lane 63's inclusive prefix): 4 granules, one 32-byte store
+            const float e0 = readlane_f(P[0], 63), e1 = readlane_f(P[1], 63);
+            const float e2 = readlane_f(P[2], 63), e3 = readlane_f(P[3], 63);
+            if (lane < 4) {
+                const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+                const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
+                __hip_atomic_store(p.gran + (uint64_t)tile * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        float Q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Q[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
+        // ---- the tile carry: lane j < J polls predecessor tile-1-j (they finish about now) ----
+        const uint32_t Jc = p.J < tile ? p.J : tile;
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (Jc > 0) {
+            const bool want = (uint32_t)lane < Jc;
+            const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
+            unsigned long long gv[4] = {0, 0, 0, 0};
+            bool ok = false, dead = false;
+            uint32_t spins = 0;
+            while (true) {
+                if (want && !ok) {
+                    bool all = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
+                    }
+                    ok = all;
+                }
+                if (__all(ok || !want)) break;
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicOr(p.status, 1u);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (lane == 0 && spins) atomicAdd(p.status + 1, spins);  // statistics: polls that found nothing yet
+            if (want && ok && !dead) {
+                mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
+                mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // sum over lanes 0..31 -> uniform
+                c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 2, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 4, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 8, 0xf>(c[q]);
+                c[q] = readlane_f(c[q], 15) + readlane_f(c[q], 31);
+            }
+        }
+        // the merged homogeneous response: start state = Q + B^(R*lane) * carry
+        mat_acc(lM, c[0], c[1], Q[0], Q[1]);
+        mat_acc(lM, c[2], c[3], Q[2], Q[3]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r].x = fma_(p.u.g[r][0], Q[0], fma_(p.u.g[r][1], Q[1], acc[r].x));
+            acc[r].y = fma_(p.u.g[r][0], Q[2], fma_(p.u.g[r][1], Q[3], acc[r].y));
+        }
+    }
+#ifdef RH_PHASE_PROFILE
+    RH_PH(5)
+    if (p.prof && lane == 0) {
+        ph_t[7] = ph_start;
+        for (int i = 0; i < 8; ++i) p.prof[(uint64_t)tile * 8 + i] = ph_t[i];
+    }
+#endif
+
+    // ---- mixed output: R stereo frames per lane -----------------------------------------------------
+    float *o = p.out + (uint64_t)m0 * 2;
+    if (R % 2 == 0) {
+#pragma unroll
+        for (int r = 0; r + 1 < R; r += 2) {
+            const uint32_t m = m0 + r;
+            if (m + 1 < Mout) {
+                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+            } else if (m < Mout) {
+                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+            }
+        }
+    } else {  // odd R: a lane's run starts on an 8-byte boundary only
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+    }
+}
+
+template <int R, int KV, int NS, bool FILT>
+__global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params p) {
+    static_assert(R <= kMaxR, "frames per lane");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    static_assert(KV * (NS - 1) < 64, "vmcnt range");
+    constexpr uint32_t kStage = KV * 1024;        // bytes of one LDS input stage
+    constexpr uint32_t kPubBase = NS * kStage;    // 8 x 16 B: this tile's aggregates of the current source group
+    constexpr uint32_t kLookBase = kPubBase + 128;             // kMaxLook x 16 B: B^(L*j)
+    constexpr uint32_t kGranBase = kLookBase + kMaxLook * 16;  // NI x 1 KiB: predecessor aggregates of one source group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // explicit LDS address space: a generic pointer here turns every tap into a flat_load
     lds_u8 *const lds = (lds_u8 *)smem;
-    lds_f32 *const wagg = (lds_f32 *)lds;                // [2][8][4]
-    lds_f32 *const cbuf = (lds_f32 *)(lds + 256);        // [2][4]
-    lds_u32 *const misc = (lds_u32 *)(lds + 288);        // ticket
-    lds_u8 *const inbuf = lds + kHeaderBytes;            // [2][stage_bytes]
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;  // LDS byte address of the dynamic region
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT = blockDim.x, W = NT >> 6;
-
-    if (tid == 0) misc[0] = atomicAdd(p.ticket, 1u) - p.ticket_base;
-    __syncthreads();
-    const uint32_t tile = misc[0];
-    const uint64_t L = (uint64_t)NT * R;
-    const uint64_t m_tile0 = (uint64_t)tile * L;
-    const uint64_t m0 = m_tile0 + (uint64_t)tid * R;
+    const int lane = threadIdx.x;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    constexpr uint32_t L = 64u * R;
+    const uint32_t m_tile0 = tile * L;  // host: out_frames < 2^31
+    const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
     const bool first = (m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
+    const uint32_t Mout = (uint32_t)p.out_frames;
 
     // ---- input span of this tile (identical for every source) -------------------------------
-    uint64_t i_base, i_end;
+    uint32_t i_base, nvec;
     {
+        uint64_t ib, ie;
         uint32_t nn;
-        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, i_base, nn);
-        i_base &= ~1ull;  // 16-byte aligned vectors
-        cursor_resolve(cursor_at(m_tile0 + L - 1, p), p, i_end, nn);
-        i_end += 1;
+        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        ib &= ~1ull;  // 16-byte aligned vectors
+        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        ie += 1;
+        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
+        i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);  // host: in_frames < 2^29
+        nvec = __builtin_amdgcn_readfirstlane(nv);
     }
-    uint32_t nvec = (uint32_t)((i_end - i_base + 2) / 2);
-    if (nvec > (uint32_t)(KV * NT)) nvec = KV * NT;  // host sizes KV so this never bites
+
+    // per-lane byte offsets of the KV staging vectors inside a source (surplus lanes re-fetch the
+    // last vector into unused slots); 8*frames < 2^32
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = lane + k * 64;
+        j = j < nvec ? j : nvec - 1;
+        goff[k] = (i_base + 2u * j) * 8u;
+    }
 
     // ---- per-lane tap table: LDS byte offset of frame i(m) and the lerp weight ----------------
     // FILT: weight = num/T (the lerp becomes one FMA, <= 1.5 ulp from math.rs:25 -- far inside
@@ -237,122 +603,234 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
             uint64_t i;
             uint32_t num;
             cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)((i - i_base) * 8);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
             wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
             if (!dummy) cursor_next(c, p);
         }
     }
 
+    // ---- carry look-back geometry ----------------------------------------------------------------
+    // Aggregates travel in groups of 8 sources.  One LDS-DMA instruction fetches, for the 8 sources
+    // of a group, the aggregates of 4 predecessor tiles: lane = src*8 + pred*2 + half (16 B each);
+    // NI = ceil(J/4) instructions cover all J predecessors.  Lane l < 32 then owns the 32-byte set
+    // (src = l>>2, pred = l&3) of every instruction.
+    const uint32_t Jc = p.J < tile ? p.J : tile;  // uniform: predecessors that exist
+    const uint32_t NI = (Jc + 3) >> 2;
+    const uint32_t gsrc = lane >> 3, gpred = (lane >> 1) & 3;
+    const uint32_t gr_off0 = gsrc * p.n_tiles * 32u + (Jc - 1 - gpred) * 32u + (lane & 1) * 16u;  // instruction 0; -128 per further one
+    const uint32_t set_src = lane >> 2, set_pred = lane & 3;  // lanes < 32
+
     const Tables *__restrict__ tb = p.tabs;
-    float lM[4], cM[4], b15[4], b31[4];
-    float g1v[R], g2v[R];  // homogeneous response of a run, in VGPRs (2R scalars would not fit the SGPR file)
+    float lM[4], b15[4], b31[4];
     if (FILT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             lM[q] = tb->laneM[lane][q];
-            cM[q] = tb->carryM[tid][q];
             b15[q] = tb->bc15M[lane][q];
             b31[q] = tb->bc31M[lane][q];
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            g1v[r] = tb->g[r][0];
-            g2v[r] = tb->g[r][1];
-        }
+        if (lane < kMaxLook) *(lds_f4 *)(lds + kLookBase + lane * 16) = v4f{tb->lookM[lane][0], tb->lookM[lane][1], tb->lookM[lane][2], tb->lookM[lane][3]};
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
     v2f acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
-    float Qr[D][4];  // start-of-run states (zero tile carry) of the D sources in flight
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Qr[d][q] = 0.0f;
+    // The homogeneous corrections of all sources share g[] and laneM, so they are summed as STATES
+    // and applied once after the last source: Qacc = sum of the lanes' zero-carry start states,
+    // Cacc = this lane's share (its sets) of the summed tile carries.
+    float Qacc[4] = {0.f, 0.f, 0.f, 0.f}, Cacc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint64_t mrg = 0;      // bit k: source s-1-k was merged into Qacc
+    uint32_t pubmask = 0;  // bit (s&7): source s of the current group has an aggregate in the pub area
+    uint32_t grp_mask = 0; // merged flags (bit 7-src) of the group whose aggregates are in flight
+    uint32_t grp_first = 0;
+    uint32_t iss = 0;      // bit d: the stage of source s+d was filled by LDS-DMA (KV operations)
+    bool dead = false;     // a bounded wait expired: never spin again in this wave
 
-    bool dead = false;  // a bounded wait expired: never spin again in this workgroup
+    const uint32_t S = p.n_sources;
 
     // ---- staging: source frames [i_base, i_base + 2*nvec) -> LDS stage, 16 bytes per lane -------
-    // Fast path (the span lies inside the source): global_load_lds DMA, no VGPR round trip, issued
-    // a whole source ahead.  Slow path (the tile touches the end of the source): register staged,
-    // replicating the last frame, which is what makes the resampler's "last frame verbatim" rule
-    // (sample_rate.rs:193-200) fall out of the plain lerp.
-    auto stage_source = [&](const SrcDesc &sd, uint32_t stage) {
-        lds_u8 *dstb = inbuf + stage * p.stage_bytes;
-        glb_cf32 *base = (glb_cf32 *)sd.data;
-        if (i_base + 2ull * nvec <= sd.frames) {
+    // Always KV LDS-DMA instructions.  If the tile reaches past the end of the source, the lanes
+    // beyond it re-fetch the source's last 16-byte vector instead (an aligned 16-byte load that
+    // starts inside the source cannot leave its page): their slots then hold finite data that no
+    // valid output reads, except as the second tap of the source's last frame, which
+    // sample_rate.rs:193-200 emits verbatim -- the edge variant of the run selects the first tap there.
+    auto stage_source = [&](const void *data, uint32_t frames, uint32_t stage_off) {
+        if (i_base + 2u * nvec <= frames) {
 #pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                uint32_t j = tid + k * NT;
-                j = j < nvec ? j : nvec - 1;  // surplus lanes re-fetch the last vector into unused slots
-                __builtin_amdgcn_global_load_lds(base + (i_base + 2ull * j) * 2,
-                                                 (RH_LDS void *)(dstb + (wave * 64 + k * NT) * 16), 16, 0, 0);
-            }
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
         } else {
-#pragma unroll 1
-            for (int k = 0; k < KV; ++k) {
-                const uint32_t j = tid + k * NT;
-                const uint64_t f = i_base + 2ull * j;
-                if (j < nvec) {
-                    v4f v = {0.f, 0.f, 0.f, 0.f};
-                    if (sd.frames) {
-                        const uint64_t f0 = f < sd.frames ? f : sd.frames - 1;
-                        const uint64_t f1 = f + 1 < sd.frames ? f + 1 : sd.frames - 1;
-                        const v2f a = *(glb_cf2 *)(base + f0 * 2);
-                        const v2f b = *(glb_cf2 *)(base + f1 * 2);
-                        v = v4f{a.x, a.y, b.x, b.y};
-                    }
-                    *(lds_f4 *)(dstb + j * 16) = v;
+            const uint32_t lastoff = ((frames - 1) & ~1u) * 8u;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + stage_off + k * 1024);
+        }
+    };
+    // The descriptor table is constant for the launch: read it through the constant address space so
+    // that it is an s_load (lgkmcnt), not a vector load whose wait would drain the DMA ring.
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    cu32 *const desc = (cu32 *)(uintptr_t)p.srcs;
+    struct Desc {
+        const void *data;
+        uint32_t frames, out_frames;
+    };
+    auto load_desc = [&](uint32_t s) -> Desc {
+        Desc d{nullptr, 0, 0};
+        if (s < S) {
+            const uint64_t lo = desc[4 * (uint64_t)s], hi = desc[4 * (uint64_t)s + 1];
+            d.data = (const void *)(uintptr_t)(lo | (hi << 32));
+            d.frames = desc[4 * (uint64_t)s + 2];
+            d.out_frames = desc[4 * (uint64_t)s + 3];
+        }
+        return d;
+    };
+
+    // Sum of the lanes' carry shares (lanes < 32 hold them), as a wave-uniform value.
+    auto reduce_carry = [&](float (&c)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
+            c[q] += dpp0<kDppRowShr + 2, 0xf>(c[q]);
+            c[q] += dpp0<kDppRowShr + 4, 0xf>(c[q]);
+            c[q] += dpp0<kDppRowShr + 8, 0xf>(c[q]);
+            c[q] = readlane_f(c[q], 15) + readlane_f(c[q], 31);
+        }
+    };
+    // Poll one 32-byte aggregate per lane until it carries this launch's epoch (ordinary agent-scope
+    // loads: hipcc waits for them, which also drains the DMA ring -- this is the slow path).
+    auto poll_sets = [&](const unsigned long long *gp, bool want, unsigned long long (&gv)[4], bool &ok) {
+        uint32_t spins = 0;
+        if (lane == 0) atomicAdd(p.status + 1, 1u);  // statistics: carries that were not ready in time
+        while (!dead) {
+            if (want && !ok) {
+                bool all = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
                 }
+                ok = all;
             }
+            if (__all(ok || !want)) break;
+#ifdef RH_PHASE_PROFILE
+            if (lane == 0) atomicAdd(p.status + 2, 1u);  // statistics: polls that found nothing yet
+#endif
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicOr(p.status, 1u);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
         }
     };
 
-    const uint32_t S = p.n_sources;
-    SrcDesc sd_cur{nullptr, 0, 0}, sd_nxt{nullptr, 0, 0}, sd_nn{nullptr, 0, 0};  // descriptors of sources s, s+1, s+2
-    if (S > 0) {
-        sd_cur = p.srcs[0];
-        if (sd_cur.out_frames > m_tile0) stage_source(sd_cur, 0);
-        if (S > 1) {
-            sd_nxt = p.srcs[1];
-            if (sd_nxt.out_frames > m_tile0) stage_source(sd_nxt, 1);
+    // ---- prologue: sources 0..NS-2 into stages 0..NS-2 -------------------------------------------
+    uint32_t Ms_ring[NS], Ns_ring[NS];  // [d]: out_frames / frames of source s+d
+#pragma unroll
+    for (int d = 0; d < NS; ++d) Ms_ring[d] = Ns_ring[d] = 0;
+    uint32_t st_cur = 0;  // LDS byte offset of the stage of source s
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d) {
+        const Desc sd = load_desc(d);
+        Ms_ring[d] = sd.out_frames;
+        Ns_ring[d] = sd.frames;
+        if (sd.out_frames > m_tile0) {
+            stage_source(sd.data, sd.frames, d * kStage);
+            iss |= 1u << d;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    Desc sd_pref = load_desc(NS - 1);  // fetched one iteration ahead of its use
 
-    uint64_t Ms_hist[D];  // out_frames of the D sources in flight
-#pragma unroll
-    for (int d = 0; d < D; ++d) Ms_hist[d] = 0;
+    const uint32_t g_last = S ? (S - 1) >> 3 : 0;
+    const uint32_t n_iter = FILT ? (S ? 8 * (g_last + kGroupLag) + 3 : 0) : S;
+    RH_PH_DECL
 
-    const uint32_t n_iter = FILT ? S + D : S;
     for (uint32_t s = 0; s < n_iter; ++s) {
-        float Qnew[4] = {0.f, 0.f, 0.f, 0.f};
-        if (s + 2 < S) sd_nn = p.srcs[s + 2];  // needed right after the barrier
-        const uint64_t Ms = s < S ? sd_cur.out_frames : 0;
-        const bool active = Ms > m_tile0;  // this tile still holds frames of source s
-        const uint64_t Mp = Ms_hist[0];
-        const bool pactive = FILT && s >= (uint32_t)D && Mp > m_tile0;  // source s-D is finished in this iteration
-
-        // ---- wave 0: start fetching the carry granules of source s-D (consumed after the run) --
-        unsigned long long gv[4] = {0, 0, 0, 0};
-        bool need = false;
-        const unsigned long long *gp = p.gran;
-        if (FILT && wave == 0 && pactive && tile > 0) {
-            need = (uint32_t)lane < p.J && (uint32_t)lane < tile;
-            gp = p.gran + ((uint64_t)(s - D) * p.n_tiles + (tile - 1 - (need ? lane : 0))) * 4;
-            if (need && !dead) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (1) every 8th source: fetch the predecessor tiles' aggregates of the source group that was
+        //     completed 8*(kGroupLag-1)+1 sources ago (consumed 2 iterations from now)
+        if (FILT && (s & 7) == 0 && s >= 8 * kGroupLag) {
+            grp_first = s - 8 * kGroupLag;
+            grp_mask = (uint32_t)(mrg >> (8 * kGroupLag - 8)) & 0xffu;  // bit 7-src
+            if (Jc > 0 && grp_mask && !dead) {
+                const unsigned long long *gb = p.gran + ((uint64_t)grp_first * p.n_tiles + (tile - Jc)) * 4;
+                const bool src_on = (grp_mask >> (7 - gsrc)) & 1u;
+                for (uint32_t i = 0; i < NI; ++i)
+                    if (src_on && gpred + 4 * i < Jc) glds16_sc1(gb, gr_off0 - 128u * i, lds0 + kGranBase + 1024u * i);
             }
         }
-
+        RH_PH(0)
+        // (2) stage source s+NS-1 into the slot source s-1 has just left
+        {
+            uint32_t st_new = st_cur + (NS - 1) * kStage;
+            if (st_new >= NS * kStage) st_new -= NS * kStage;
+            Ms_ring[NS - 1] = sd_pref.out_frames;
+            Ns_ring[NS - 1] = sd_pref.frames;
+            if (s + NS - 1 < S && sd_pref.out_frames > m_tile0) {
+                stage_source(sd_pref.data, sd_pref.frames, st_new);
+                iss |= 1u << (NS - 1);
+            }
+            sd_pref = load_desc(s + NS);
+        }
+        RH_PH(1)
+        // (3) everything older than the newest (groups issued after source s) has landed: the stage
+        //     of source s, and any aggregate fetch issued 2 or more iterations ago
+        wait_groups<KV, NS>(__builtin_popcount(iss >> 1));
+        RH_PH(2)
+        // (3b) all lerp taps of source s leave for the LDS now, so that their latency overlaps the carry step
+        const uint32_t Ms = Ms_ring[0];
+        const bool active = s < S && Ms > m_tile0;  // this tile still holds frames of source s
+        v2f ta[R + 2], tb2[R + 2];
         if (active) {
-            const lds_u8 *buf = inbuf + (s & 1) * p.stage_bytes;
-            auto tap = [&](int rr) -> v2f {
-                const v2f a = *(const lds_f2 *)(buf + offA[rr]);
-                const v2f b = *(const lds_f2 *)(buf + offA[rr] + 8);
+            const lds_u8 *buf = lds + st_cur;
+#pragma unroll
+            for (int rr = 0; rr < R + 2; ++rr) {
+                ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
+                tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
+            }
+            asm volatile("" ::: "memory");  // keep the reads above the carry step
+        }
+        // (4) every 8th source: the group's tile carries join Cacc (lane l < 32: source l>>2, predecessor l&3 + 4i)
+        if (FILT && (s & 7) == 2 && s >= 8 * kGroupLag && Jc > 0 && grp_mask) {
+            const bool src_on = lane < 32 && ((grp_mask >> (7 - set_src)) & 1u);
+            for (uint32_t i = 0; i < NI; ++i) {
+                const bool want = src_on && set_pred + 4 * i < Jc;
+                unsigned long long gv[4] = {0, 0, 0, 0};
+                bool ok = false;
+                if (want && !dead) {
+                    const lds_u8 *gsl = lds + kGranBase + 1024u * i + lane * 32;
+                    const v2u64 lo = *(const lds_u64x2 *)gsl, hi = *(const lds_u64x2 *)(gsl + 16);
+                    gv[0] = lo.x; gv[1] = lo.y; gv[2] = hi.x; gv[3] = hi.y;
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && ((uint32_t)(gv[q] >> 32) == p.epoch);
+                }
+#ifndef RH_DIAG_NO_CARRY_WAIT  // diagnostic build: free-running tiles (wrong results), to price the lock-step
+                if (!dead && !__all(ok || !want)) {  // a neighbour is more than 8*(kGroupLag-1) sources behind
+                    const unsigned long long *gp = p.gran + ((uint64_t)(grp_first + (want ? set_src : 0)) * p.n_tiles + (tile - 1 - (want ? set_pred + 4 * i : 0))) * 4;
+                    poll_sets(gp, want, gv, ok);
+                }
+#endif
+                if (want && ok && !dead) {
+                    const v4f k4 = *(const lds_f4 *)(lds + kLookBase + (set_pred + 4 * i) * 16);
+                    const float kM[4] = {k4.x, k4.y, k4.z, k4.w};
+                    mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), Cacc[0], Cacc[1]);
+                    mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), Cacc[2], Cacc[3]);
+                }
+            }
+        }
+        RH_PH(3)
+
+        // (5) source s: lerp, zero-state biquad run, ordered mix
+        // frames past the end of the mix are never stored, so a source that ends with the mix needs no masking
+        const bool full = Ms >= m_tile0 + L || Ms >= Mout;
+        uint64_t merged = 0;
+        if (active) {
+            const uint32_t Ns = Ns_ring[0];
+            // edge: some lane needs masking, or the staged span reaches past the source (verbatim last frame)
+            const bool edge = !full || i_base + 2u * nvec > Ns;
+            const uint32_t dthr = Ns - 1 - i_base;  // active => i_base <= Ns-1
+            const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
+            auto tap = [&](int rr, auto edge_tag) -> v2f {
+                const v2f a = ta[rr], b = tb2[rr];
                 v2f x;
                 if (FILT) {
                     x.x = fma_(b.x - a.x, wgt[rr], a.x);
@@ -361,19 +839,23 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                     x.x = a.x + div_T((b.x - a.x) * wgt[rr], p.Tf, p.rcpT);
                     x.y = a.y + div_T((b.y - a.y) * wgt[rr], p.Tf, p.rcpT);
                 }
+                if (decltype(edge_tag)::value) {  // the source's last frame is emitted verbatim
+                    const bool last = offA[rr] >= thr;
+                    x.x = last ? a.x : x.x;
+                    x.y = last ? a.y : x.y;
+                }
                 return x;
             };
             // lanes past the end of the source contribute nothing (the reference's iterator ended)
             const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
-            const bool full = Ms >= m_tile0 + L;  // uniform: no lane needs masking
             if (FILT) {
-                v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
-                v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
                 v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
                 auto run = [&](auto masked) {
+                    v2f x2 = first ? v2f{0.f, 0.f} : tap(0, masked);
+                    v2f x1 = first ? v2f{0.f, 0.f} : tap(1, masked);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const v2f x = tap(r + 2);
+                        const v2f x = tap(r + 2, masked);
                         v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
                         w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
                         w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
@@ -391,8 +873,9 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                         x1 = x;
                     }
                 };
-                if (full) run(std::false_type{});
+                if (!edge) run(std::false_type{});
                 else run(std::true_type{});
+                RH_PH(4)
                 // ---- run end state in the scan basis, then the wave64 inclusive scan ----
                 float P[4] = {0.f, 0.f, 0.f, 0.f};
                 mat_acc(p.u.Tm, w1.x, w2.x, P[0], P[1]);
@@ -421,142 +904,118 @@ __global__ __launch_bounds__(kMaxThreads) void k_rlm_stereo(const Params p) {
                     mat_acc(b31, q0, q1, P[0], P[1]);
                     mat_acc(b31, q2, q3, P[2], P[3]);
                 }
-                if (lane == 63) *(lds_f4 *)(wagg + ((s & 1) * 8 + wave) * 4) = v4f{P[0], P[1], P[2], P[3]};
+                // the tile aggregate (lane 63's inclusive prefix) waits in LDS for the group's publication
+                if (lane == 63) *(lds_f4 *)(lds + kPubBase + (s & 7) * 16) = v4f{P[0], P[1], P[2], P[3]};
+                pubmask |= 1u << (s & 7);
+                float Qnew[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Qnew[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
+                if (full) {
+                    merged = 1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Qacc[q] += Qnew[q];
+                } else {
+                    // The source ends inside this tile while the mix goes on (at most one tile per
+                    // source): its correction is masked per frame, so it cannot join the merged
+                    // states.  Fetch its carry right now (lane j: predecessor j) and apply it exactly.
+                    float c[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (Jc > 0) {
+                        const bool want = (uint32_t)lane < Jc;
+                        unsigned long long gv[4] = {0, 0, 0, 0};
+                        bool ok = false;
+                        poll_sets(p.gran + ((uint64_t)s * p.n_tiles + (tile - 1 - (want ? lane : 0))) * 4, want, gv, ok);
+                        if (want && ok && !dead) {
+                            const v4f k4 = *(const lds_f4 *)(lds + kLookBase + lane * 16);
+                            const float kM[4] = {k4.x, k4.y, k4.z, k4.w};
+                            mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
+                            mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+                        }
+                        reduce_carry(c);
+                    }
+                    mat_acc(lM, c[0], c[1], Qnew[0], Qnew[1]);
+                    mat_acc(lM, c[2], c[3], Qnew[2], Qnew[3]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool v = r < nvalid;
+                        const float hx = fma_(p.u.g[r][0], Qnew[0], p.u.g[r][1] * Qnew[1]), hy = fma_(p.u.g[r][0], Qnew[2], p.u.g[r][1] * Qnew[3]);
+                        acc[r].x += v ? hx : 0.0f;
+                        acc[r].y += v ? hy : 0.0f;
+                    }
+                }
             } else {
                 auto run = [&](auto masked) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        v2f x = tap(r + 2);
+                        v2f x = tap(r + 2, masked);
                         if (decltype(masked)::value && !(r < nvalid)) continue;  // an ended source adds nothing, not even +0.0
                         acc[r].x += x.x;
                         acc[r].y += x.y;
                     }
                 };
-                if (full) run(std::false_type{});
+                if (!edge) run(std::false_type{});
                 else run(std::true_type{});
             }
         }
-        // ---- wave 0: finish the carry of source s-D: c = sum_j B^(L*j) * aggregate(tile-1-j) ------
-        if (FILT && wave == 0) {
-            float c[4] = {0.f, 0.f, 0.f, 0.f};
-            if (pactive && tile > 0) {
-                bool ok = !need;
-                if (need && !dead) {
-                    ok = true;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ok = ok && ((uint32_t)(gv[q] >> 32) == p.epoch);
-                }
-                uint32_t spins = 0;
-                while (!dead && !__all(ok)) {  // rare: the neighbour is more than D sources behind
-                    if (++spins > kSpinLimit) {
-                        if (lane == 0) atomicOr(p.status, 1u);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(4);
-                    if (!ok) {
-                        bool all = true;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
-                        }
-                        ok = all;
-                    }
-                }
-                if (need && ok) {
-                    const float *M = tb->lookM[lane];
-                    mat_acc(M, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
-                    mat_acc(M, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
-                }
-                if (p.J > 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) c[q] += __shfl_xor(c[q], d);
-                    }
-                }
+        // (6) the group is complete: publish this tile's aggregates, 8 sources x 4 granules in one store
+        if (FILT && s < S && ((s & 7) == 7 || s == S - 1)) {
+            if (lane < 32 && ((pubmask >> (lane >> 2)) & 1u)) {
+                const float ev = *(const RH_LDS float *)(lds + kPubBase + lane * 4);
+                const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
+                __hip_atomic_store(p.gran + ((uint64_t)((s & ~7u) + (lane >> 2)) * p.n_tiles + tile) * 4 + (lane & 3), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (lane == 0) *(lds_f4 *)(cbuf + (s & 1) * 4) = v4f{c[0], c[1], c[2], c[3]};
+            pubmask = 0;
         }
-        // the DMA of source s+1 (issued a whole iteration ago) must have landed before the barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // stage (s&1) is free now: start fetching source s+2 into it
-        sd_cur = sd_nxt;
-        sd_nxt = sd_nn;
-        if (s + 2 < S && sd_nxt.out_frames > m_tile0) stage_source(sd_nxt, s & 1);
-        if (FILT) {
-            if (active) {
-                // chain the waves: state at the start of this wave (zero tile carry)
-                float Wst[4] = {0.f, 0.f, 0.f, 0.f};
-                const lds_f32 *wa = wagg + (s & 1) * 32;
-                for (int u = 0; u < wave; ++u) {
-                    const v4f n = *(const lds_f4 *)(wa + u * 4);
-                    float n0 = n.x, n1 = n.y, n2 = n.z, n3 = n.w;
-                    mat_acc(p.u.waveM, Wst[0], Wst[1], n0, n1);
-                    mat_acc(p.u.waveM, Wst[2], Wst[3], n2, n3);
-                    Wst[0] = n0; Wst[1] = n1; Wst[2] = n2; Wst[3] = n3;
-                }
-                if (wave == W - 1 && lane < 4) {  // publish the tile aggregate: 4 granules
-                    const v4f n = *(const lds_f4 *)(wa + wave * 4);
-                    float e0 = n.x, e1 = n.y, e2 = n.z, e3 = n.w;
-                    mat_acc(p.u.waveM, Wst[0], Wst[1], e0, e1);
-                    mat_acc(p.u.waveM, Wst[2], Wst[3], e2, e3);
-                    const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
-                    const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
-                    __hip_atomic_store(p.gran + ((uint64_t)s * p.n_tiles + tile) * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                mat_acc(lM, Wst[0], Wst[1], Qnew[0], Qnew[1]);
-                mat_acc(lM, Wst[2], Wst[3], Qnew[2], Qnew[3]);
-            }
-            if (pactive) {  // finish source s-D: homogeneous response to its true start state
-                const int nvalid = Mp >= m0 + R ? R : (Mp > m0 ? (int)(Mp - m0) : 0);
-                const bool full = Mp >= m_tile0 + L;
-                const v4f cb = *(const lds_f4 *)(cbuf + (s & 1) * 4);
-                float S0 = Qr[0][0], S1 = Qr[0][1], S2 = Qr[0][2], S3 = Qr[0][3];
-                mat_acc(cM, cb.x, cb.y, S0, S1);
-                mat_acc(cM, cb.z, cb.w, S2, S3);
-                if (!full) {  // zero the start state of lanes with no valid frame; partial lanes are masked per frame
+        // rotate the rings
+        mrg = (mrg << 1) | merged;
+        iss >>= 1;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const bool v = r < nvalid;
-                        const float hx = fma_(g1v[r], S0, g2v[r] * S1), hy = fma_(g1v[r], S2, g2v[r] * S3);
-                        acc[r].x += v ? hx : 0.0f;
-                        acc[r].y += v ? hy : 0.0f;
-                    }
-                } else {
+        for (int d = 0; d + 1 < NS; ++d) {
+            Ms_ring[d] = Ms_ring[d + 1];
+            Ns_ring[d] = Ns_ring[d + 1];
+        }
+        st_cur += kStage;
+        if (st_cur >= NS * kStage) st_cur = 0;
+        RH_PH(5)
+    }
+    wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
+#ifdef RH_PHASE_PROFILE
+    if (p.prof && lane == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        ph_t[6] = ((unsigned long long)xcc << 32) | hwid;
+        ph_t[7] = ph_start;
+        for (int i = 0; i < 8; ++i) p.prof[(uint64_t)tile * 8 + i] = ph_t[i];
+    }
+#endif
+
+    if (FILT) {  // the merged homogeneous response: start state = Qacc + B^(R*lane) * (summed tile carries)
+        reduce_carry(Cacc);
+        mat_acc(lM, Cacc[0], Cacc[1], Qacc[0], Qacc[1]);
+        mat_acc(lM, Cacc[2], Cacc[3], Qacc[2], Qacc[3]);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        acc[r].x = fma_(g1v[r], S0, fma_(g2v[r], S1, acc[r].x));
-                        acc[r].y = fma_(g1v[r], S2, fma_(g2v[r], S3, acc[r].y));
-                    }
-                }
-            }
-#pragma unroll
-            for (int d = 0; d + 1 < D; ++d) {
-                Ms_hist[d] = Ms_hist[d + 1];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Qr[d][q] = Qr[d + 1][q];
-            }
-            Ms_hist[D - 1] = Ms;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Qr[D - 1][q] = Qnew[q];
+        for (int r = 0; r < R; ++r) {
+            acc[r].x = fma_(p.u.g[r][0], Qacc[0], fma_(p.u.g[r][1], Qacc[1], acc[r].x));
+            acc[r].y = fma_(p.u.g[r][0], Qacc[2], fma_(p.u.g[r][1], Qacc[3], acc[r].y));
         }
     }
 
-    // ---- mixed output: R stereo frames per lane, 16-byte stores ---------------------------------
-    float *o = p.out + m0 * 2;
+    // ---- mixed output: R stereo frames per lane -----------------------------------------------------
+    float *o = p.out + (uint64_t)m0 * 2;
+    if (R % 2 == 0) {
 #pragma unroll
-    for (int r = 0; r < R; r += 2) {
-        const uint64_t m = m0 + r;
-        if (m + 1 < p.out_frames) {
-            *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
-        } else if (m < p.out_frames) {
-            *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+        for (int r = 0; r + 1 < R; r += 2) {
+            const uint32_t m = m0 + r;
+            if (m + 1 < Mout) {
+                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+            } else if (m < Mout) {
+                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+            }
         }
+    } else {  // odd R: a lane's run starts on an 8-byte boundary only
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
     }
 }
 
@@ -600,32 +1059,69 @@ void scan_basis(double a1, double a2, M2 &T, M2 &Tinv) {
     Tinv = {1.0, mu / nu, 0.0, 1.0 / nu};
 }
 
-constexpr int kD = 2;  // sources in flight between publishing an aggregate and consuming the carry
-
 using KernelFn = void (*)(const Params);
 struct Variant {
-    int R, KV;
+    int R, KV, NS;
     KernelFn filt, plain;
 };
-#define RH_VARIANT(r, kv) Variant{r, kv, &k_rlm_stereo<r, kv, kD, true>, &k_rlm_stereo<r, kv, kD, false>}
-// KV = R/2+1 covers from <= to (upsampling, staged span <= L+7 frames); KV = R+1 covers from <= 2*to.
-const Variant kVariants[] = {
-    RH_VARIANT(4, 3),  RH_VARIANT(4, 5),  RH_VARIANT(6, 4),  RH_VARIANT(6, 7),   RH_VARIANT(8, 5),
-    RH_VARIANT(8, 9),  RH_VARIANT(12, 7), RH_VARIANT(12, 13), RH_VARIANT(16, 9), RH_VARIANT(16, 17),
+#define RH_FAST(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true>, &k_rlm_fast<r, kv, ns, false>}
+#define RH_WAVE(r, kv, ns) Variant{r, kv, ns, &k_rlm_wave<r, kv, ns, true>, &k_rlm_wave<r, kv, ns, false>}
+// KV KiB of LDS per stage must hold the input span of 64*R output frames: ~R/2 vectors per lane
+// when upsampling (from <= to), up to R+1 for from <= 2*to.  The host picks the smallest KV that fits.
+// Per R: the stage sizes for from/to <= ~0.93 (44.1->48 k), <= 1 and <= 2.
+const Variant kFast[] = {
+#ifdef RH_DEV_VARIANTS  // quick development builds
+    RH_FAST(4, 2, 2), RH_FAST(4, 2, 3), RH_FAST(5, 3, 2), RH_FAST(6, 3, 2), RH_FAST(6, 3, 3), RH_FAST(8, 4, 2), RH_FAST(8, 4, 3), RH_FAST(9, 5, 2), RH_FAST(9, 5, 3), RH_FAST(12, 6, 3),
+#else
+    RH_FAST(3, 2, 2),   RH_FAST(3, 2, 3),   RH_FAST(3, 4, 2),
+    RH_FAST(4, 2, 2),   RH_FAST(4, 2, 3),   RH_FAST(4, 3, 2),  RH_FAST(4, 3, 3),  RH_FAST(4, 5, 2),
+    RH_FAST(5, 3, 2),   RH_FAST(5, 3, 3),   RH_FAST(5, 6, 2),
+    RH_FAST(6, 3, 2),   RH_FAST(6, 3, 3),   RH_FAST(6, 4, 2),  RH_FAST(6, 4, 3),  RH_FAST(6, 7, 2),
+    RH_FAST(7, 4, 2),   RH_FAST(7, 4, 3),   RH_FAST(7, 8, 2),
+    RH_FAST(8, 4, 2),   RH_FAST(8, 4, 3),   RH_FAST(8, 4, 4),  RH_FAST(8, 5, 2),  RH_FAST(8, 5, 3),  RH_FAST(8, 9, 2),
+    RH_FAST(9, 5, 2),   RH_FAST(9, 5, 3),   RH_FAST(9, 10, 2),
+    RH_FAST(10, 5, 2),  RH_FAST(10, 5, 3),  RH_FAST(10, 6, 2), RH_FAST(10, 6, 3), RH_FAST(10, 11, 2),
+    RH_FAST(12, 6, 2),  RH_FAST(12, 6, 3),  RH_FAST(12, 7, 2), RH_FAST(12, 7, 3), RH_FAST(12, 13, 2),
+    RH_FAST(16, 8, 2),  RH_FAST(16, 8, 3),  RH_FAST(16, 9, 2), RH_FAST(16, 9, 3),
+#endif
 };
-#undef RH_VARIANT
-const void *find_kernel(int R, int KV, bool filt) {
-    for (const Variant &v : kVariants)
-        if (v.R == R && v.KV == KV) return reinterpret_cast<const void *>(filt ? v.filt : v.plain);
-    return nullptr;
+// The general kernel (ragged batches) is heavier; it ships in two tile sizes.
+const Variant kWave[] = {
+    RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
+};
+#undef RH_FAST
+#undef RH_WAVE
+template <size_t N>
+const Variant *find_variant(const Variant (&tab)[N], int R, int kv_needed, int NS) {  // smallest KV >= kv_needed
+    const Variant *best = nullptr;
+    for (const Variant &v : tab)
+        if (v.R == R && v.NS == NS && v.KV >= kv_needed && (!best || v.KV < best->KV)) best = &v;
+    return best;
 }
-// Workgroups of `threads` lanes + `lds` dynamic bytes the hardware co-schedules on one CU.
-int blocks_per_cu(const void *fn, int threads, size_t lds) {
+// Single-wave workgroups with `lds` dynamic bytes the hardware co-schedules on one CU.
+int blocks_per_cu(const void *fn, size_t lds) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess) return 0;
     return n;
 }
+// Vectors (2 frames = 16 B) per lane a stage must hold for a tile of L output frames.
+int kv_needed(uint64_t L, uint32_t F, uint32_t T) {
+    const uint64_t span = ((L + 1) * F) / T + 5;  // i(m0+L-1) - i(m0-2) + tap + even alignment
+    const uint64_t nvec = span / 2 + 2;
+    return (int)((nvec + 63) / 64);
+}
+
+// One launch plan: a kernel variant with its tables.
+struct Plan {
+    const Variant *v = nullptr;
+    const void *kernel = nullptr;
+    bool general = false;
+    uint32_t J = 0, lds_bytes = 0;
+    int resident_per_cu = 0;
+    Uniforms uni;
+    Tables *d_tabs = nullptr;
+};
 
 }  // namespace
 
@@ -635,21 +1131,135 @@ struct rh_rlm {
     uint64_t chunk_in, chunk_out;  // chunk_out == 0: unchunked
     bool filt;
     float coeffs[5];
-    int R, KV, threads;
-    const void *kernel = nullptr;
-    int resident_per_cu = 0;
-    uint32_t stage_bytes, lds_bytes, J;
-    Tables *d_tabs = nullptr;
-    Uniforms uni;
+    Plan fast, wave;        // equal-length batches / ragged batches
+    Plan *plan = nullptr;   // chosen by set_sources
+    uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
+    uint32_t eq_frames = 0;
     SrcDesc *d_srcs = nullptr;
     unsigned long long *d_gran = nullptr;
     size_t gran_words = 0;
-    uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status
+    uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status, [2] late carries, [3] empty polls
+    unsigned long long *d_prof = nullptr;
     uint32_t n_sources = 0, n_tiles = 0;
     uint64_t out_frames = 0;
     uint32_t epoch = 0;
     uint32_t ticket_base = 0;
 };
+
+namespace {
+
+// Predecessor tiles a tile of L frames has to look back at: ||B^(L*J)|| < 2^-40 (older history is
+// below f32 resolution of the state); 0 = pole radius too close to 1 for this tile length.
+uint32_t look_tiles(const M2 &B, uint64_t L) {
+    const M2 BL = mpow(B, L);
+    M2 cur = BL;
+    for (uint32_t j = 1; j <= (uint32_t)kMaxLook; ++j) {
+        if (norm(cur) < 0x1p-40) return j;
+        cur = mul(cur, BL);
+    }
+    return 0;
+}
+size_t lds_bytes_of(const Variant &v, bool general, uint32_t J) {
+    size_t n = (size_t)v.NS * v.KV * 1024;
+    if (general) n += 128 + kMaxLook * 16 + (size_t)((J + 3) / 4) * 1024;
+    return n;
+}
+
+// Geometry + tables of one plan.  One wave per tile of L = 64*R output frames; the cost of a geometry
+// is the most loaded SIMD: ceil(waves per CU / 4) waves, each issuing `per_frame` instructions per
+// frame + `per_source` per source one after the other; the issue interval falls with occupancy
+// (measured, tools/ubench/valu_rate.hip: 4.3 / 3.0 / 2.7 cycles per wave-instruction at 1 / 2 / 4
+// waves per SIMD).
+template <size_t N>
+rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, const rh::ResampleGeom &g, uint32_t want_R, uint32_t want_NS) {
+    const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
+    M2 Tm, Ti;
+    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
+    const M2 B = mul(mul(Tm, A), Ti);
+    const uint64_t M = g.out_frames ? g.out_frames : 1;
+    const int cus = rh::g_num_cus;
+    const double per_frame = 19.0, per_source = general ? 170.0 : 50.0;
+    double best = 1e300;
+    const Variant *bestV = nullptr;
+    uint32_t bestJ = 0;
+    for (int R = 1; R <= kMaxR; ++R) {
+        if (want_R && (int)want_R != R) continue;
+        const uint64_t L = 64ull * R;
+        const uint32_t Jr = p->filt ? look_tiles(B, L) : 1;
+        if (Jr == 0) continue;
+        const uint64_t tiles = (M + L - 1) / L;
+        const uint64_t per_cu = (tiles + cus - 1) / cus;
+        for (int NS = 2; NS <= 4; ++NS) {
+            if (want_NS && (int)want_NS != NS) continue;
+            const Variant *v = find_variant(tab, R, kv_needed(L, g.F, g.T), NS);
+            if (!v) continue;
+            const void *fn = reinterpret_cast<const void *>(p->filt ? v->filt : v->plain);
+            const int resident = blocks_per_cu(fn, lds_bytes_of(*v, general, Jr));
+            if (resident < 1) continue;
+            // tiles beyond the resident set only start when earlier ones finish: legal, but they
+            // run as a second pass
+            const double passes = std::ceil((double)per_cu / resident);
+            const uint64_t on_cu = std::min<uint64_t>(per_cu, resident);
+            const double w = std::ceil(on_cu / 4.0);  // waves on the most loaded SIMD
+            const double issue = 2.6 + 1.7 / std::pow(w, 1.5);
+            double cost = passes * w * (per_frame * R + per_source) * issue;
+            cost *= 1.0 + 0.01 * NS;  // among equals prefer the shallower ring (less LDS)
+            if (cost < best) {
+                best = cost;
+                bestV = v;
+                bestJ = Jr;
+            }
+        }
+    }
+    if (!bestV) return RH_ERR_UNSUPPORTED;
+    pl.v = bestV;
+    pl.general = general;
+    pl.kernel = reinterpret_cast<const void *>(p->filt ? bestV->filt : bestV->plain);
+    pl.J = p->filt ? bestJ : 0;
+    pl.lds_bytes = (uint32_t)lds_bytes_of(*bestV, general, bestJ);
+    pl.resident_per_cu = blocks_per_cu(pl.kernel, pl.lds_bytes);
+    // ---- tables (all powers of B = Tm A Tm^-1 are taken in f64 on the host and rounded to f32 once)
+    Tables *h = new Tables();
+    std::memset(h, 0, sizeof(Tables));
+    Uniforms &U = pl.uni;
+    std::memset(&U, 0, sizeof(U));
+    U.b0 = p->coeffs[0];
+    U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
+    U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
+    U.a1 = p->coeffs[3];
+    U.a2 = p->coeffs[4];
+    put(U.Tm, Tm);
+    const uint64_t R = bestV->R, L = 64ull * bestV->R;
+    for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, R << k));
+    for (int r = 0; r < bestV->R; ++r) {
+        const M2 m = mul(mpow(A, r + 1), Ti);  // w[r] = row 0 of A^(r+1) applied to the companion state Ti*z
+        U.g[r][0] = (float)m.a;
+        U.g[r][1] = (float)m.b;
+    }
+    for (int l = 0; l < 64; ++l) {
+        put(h->laneM[l], mpow(B, R * l));
+        put(h->bc15M[l], mpow(B, R * ((l & 15) + 1)));
+        put(h->bc31M[l], mpow(B, R * ((l & 31) + 1)));
+    }
+    {
+        const M2 BL = mpow(B, L);
+        M2 cur{1, 0, 0, 1};
+        for (int j = 0; j < kMaxLook; ++j) {
+            put(h->lookM[j], cur);
+            cur = mul(cur, BL);
+        }
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.d_tabs), sizeof(Tables));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
+    delete h;
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, "rh_rlm_create tables");
+        return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -658,10 +1268,12 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     if (!out || !cfg || cfg->from_rate == 0 || cfg->to_rate == 0 || cfg->channels == 0 || cfg->max_sources == 0) return RH_ERR_INVALID;
     if (cfg->channels != 2) return RH_ERR_UNSUPPORTED;
     if (cfg->from_rate == cfg->to_rate) return RH_ERR_UNSUPPORTED;  // passthrough converter: use rh_biquad + rh_mix_sum
+    if (cfg->max_in_frames >= (1ull << 29)) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets inside a source
     rh::ResampleGeom g;
     rh_status st = rh::make_resample_geom(cfg->max_in_frames, cfg->from_rate, cfg->to_rate, cfg->channels, cfg->span_len, &g);
     if (st != RH_OK) return st;
     if (g.F > 2 * g.T) return RH_ERR_UNSUPPORTED;  // staging is sized for ratios <= 2 (unfused ops cover the rest)
+    if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
     rh_rlm *p = new rh_rlm();
     p->cfg = *cfg;
     p->F = g.F;
@@ -679,126 +1291,42 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
         p->coeffs[0] = 1.f;
         p->coeffs[1] = p->coeffs[2] = p->coeffs[3] = p->coeffs[4] = 0.f;
     }
-    // ---- launch geometry: tiles of L = threads*R output frames.  All tiles advance source by
-    // source in near lock-step (they exchange carries), so the cost of a geometry is the most
-    // loaded CU: ceil(tiles / CUs) * L.  Among equals prefer ~2 workgroups per CU.
-    const uint64_t M = g.out_frames ? g.out_frames : 1;
-    const int cus = rh::g_num_cus;
-    const int Rs[] = {4, 6, 8, 12, 16};
-    double best = 1e300;
-    int bestR = 8, bestT = 256;
-    for (int R : Rs) {
-        if (cfg->frames_per_lane && (int)cfg->frames_per_lane != R) continue;
-        for (int T = 128; T <= kMaxThreads; T += 64) {
-            if (cfg->threads && (int)cfg->threads != T) continue;
-            const uint64_t L = (uint64_t)R * T;
-            const uint64_t tiles = (M + L - 1) / L;
-            const uint64_t per_cu = (tiles + cus - 1) / cus;
-            const int kv = (g.F <= g.T) ? R / 2 + 1 : R + 1;
-            const size_t lds = kHeaderBytes + 2 * (size_t)kv * T * 16;
-            if (lds > 150 * 1024) continue;
-            const void *fn = find_kernel(R, kv, p->filt);
-            if (!fn) continue;
-            // every tile should hold a CU slot at once (they advance in lock-step)
-            if ((int)per_cu > blocks_per_cu(fn, T, lds)) continue;
-            double cost = (double)per_cu * (double)L;
-            cost *= 1.0 + 0.02 * std::fabs((double)per_cu * T / 256.0 - 2.0);  // soft preference: 8 waves/CU
-            cost *= 1.0 + 0.3 / R;                                             // scan overhead ~ 1/R
-            if (cost < best) {
-                best = cost;
-                bestR = R;
-                bestT = T;
-            }
+    // two plans: equal-length batches (k_rlm_fast) and ragged ones (k_rlm_wave).  The geometry
+    // overrides of the config address the fast plan; the general plan follows them when it can.
+    st = make_plan(p, p->fast, kFast, false, g, cfg->frames_per_lane, cfg->ring_stages);
+    if (st == RH_OK) {
+        st = make_plan(p, p->wave, kWave, true, g, cfg->frames_per_lane, cfg->ring_stages);
+        if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->wave, kWave, true, g, 0, 0);
+    } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
+        st = RH_ERR_INVALID;
+    }
+    hipError_t e = hipSuccess;
+    if (st == RH_OK) {
+        e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 64);
+        if (e == hipSuccess) e = hipMemset(p->d_ctl, 0, 64);
+        if (e != hipSuccess) {
+            rh::set_hip_error(e, "rh_rlm_create");
+            st = e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
         }
     }
-    if (best == 1e300) {
-        bestR = cfg->frames_per_lane ? cfg->frames_per_lane : 8;
-        bestT = cfg->threads ? cfg->threads : 256;
-        bool okR = false;
-        for (int R : Rs) okR = okR || R == bestR;
-        if (!okR || bestT % 64 || bestT < 64 || bestT > kMaxThreads) {
-            delete p;
-            return RH_ERR_INVALID;
-        }
-    }
-    p->R = bestR;
-    p->threads = bestT;
-    p->KV = (g.F <= g.T) ? bestR / 2 + 1 : bestR + 1;
-    p->stage_bytes = (uint32_t)p->KV * bestT * 16;
-    p->lds_bytes = kHeaderBytes + 2 * p->stage_bytes;
-    p->kernel = find_kernel(p->R, p->KV, p->filt);
-    if (!p->kernel || p->lds_bytes > 159 * 1024) {
-        delete p;
-        return RH_ERR_UNSUPPORTED;
-    }
-    p->resident_per_cu = blocks_per_cu(p->kernel, p->threads, p->lds_bytes);
-    // ---- tables (all powers of B = Tm A Tm^-1, f64 on the host, rounded to f32 once) --------------
-    Tables *h = new Tables();
-    std::memset(h, 0, sizeof(Tables));
-    Uniforms &U = p->uni;
-    std::memset(&U, 0, sizeof(U));
-    U.b0 = p->coeffs[0];
-    U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
-    U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
-    U.a1 = p->coeffs[3];
-    U.a2 = p->coeffs[4];
-    const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
-    M2 Tm, Ti;
-    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
-    const M2 B = mul(mul(Tm, A), Ti);
-    put(U.Tm, Tm);
-    const uint64_t R = bestR, L = (uint64_t)bestR * bestT;
-    for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, R << k));
-    put(U.waveM, mpow(B, 64 * R));
-    for (int r = 0; r < bestR; ++r) {
-        const M2 m = mul(mpow(A, r + 1), Ti);  // w[r] = row 0 of A^(r+1) applied to the companion state Ti*z
-        h->g[r][0] = (float)m.a;
-        h->g[r][1] = (float)m.b;
-    }
-    for (int l = 0; l < 64; ++l) {
-        put(h->laneM[l], mpow(B, R * l));
-        put(h->bc15M[l], mpow(B, R * ((l & 15) + 1)));
-        put(h->bc31M[l], mpow(B, R * ((l & 31) + 1)));
-    }
-    for (int t = 0; t < bestT; ++t) put(h->carryM[t], mpow(B, R * t));
-    const M2 BL = mpow(B, L);
-    uint32_t J = 0;
-    if (p->filt) {
-        M2 cur{1, 0, 0, 1};
-        for (int j = 0; j < kMaxLook; ++j) {
-            put(h->lookM[j], cur);
-            J = j + 1;
-            cur = mul(cur, BL);
-            if (norm(cur) < 0x1p-40) break;  // older tiles are below f32 resolution of the state
-            if (j == kMaxLook - 1) {          // pole radius too close to 1 for this tile length
-                delete h;
-                delete p;
-                return RH_ERR_UNSUPPORTED;
-            }
-        }
-    }
-    p->J = J;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_tabs), sizeof(Tables));
-    if (e == hipSuccess) e = hipMemcpy(p->d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
-    delete h;
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 64);
-    if (e == hipSuccess) e = hipMemset(p->d_ctl, 0, 64);
-    if (e != hipSuccess) {
-        rh::set_hip_error(e, "rh_rlm_create");
+    if (st != RH_OK) {
         rh_rlm_destroy(p);
-        return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
+        return st;
     }
+    p->plan = &p->fast;
     *out = p;
     return RH_OK;
 }
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
-    if (p->d_tabs) (void)hipFree(p->d_tabs);
+    if (p->fast.d_tabs) (void)hipFree(p->fast.d_tabs);
+    if (p->wave.d_tabs) (void)hipFree(p->wave.d_tabs);
     if (p->d_srcs) (void)hipFree(p->d_srcs);
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_prof) (void)hipFree(p->d_prof);
     delete p;
     return RH_OK;
 }
@@ -809,20 +1337,25 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
     if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
     std::vector<SrcDesc> h(n_sources);
     uint64_t M = 0;
+    bool equal = true;
     for (uint32_t s = 0; s < n_sources; ++s) {
         if (in_frames_host[s] > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
         if (in_frames_host[s] && (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u))) return RH_ERR_INVALID;
         rh::ResampleGeom g;
         rh_status st = rh::make_resample_geom(in_frames_host[s], p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
         if (st != RH_OK) return st;
-        h[s] = SrcDesc{srcs_host[s], in_frames_host[s], g.out_frames};
+        if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
+        h[s] = SrcDesc{srcs_host[s], (uint32_t)in_frames_host[s], (uint32_t)g.out_frames};
         if (g.out_frames > M) M = g.out_frames;
+        equal = equal && in_frames_host[s] == in_frames_host[0];
     }
-    const uint64_t L = (uint64_t)p->R * p->threads;
+    // equal-length batch: the merged-state kernel; otherwise the general one
+    Plan *pl = (equal && !p->cfg.force_general) ? &p->fast : &p->wave;
+    const uint64_t L = 64ull * pl->v->R;
     const uint64_t tiles = (M + L - 1) / L;
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
     if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
-    const size_t words = (size_t)n_sources * tiles * 4;
+    const size_t words = (pl->general ? (size_t)n_sources : 1) * tiles * 4;
     if (p->filt && words > p->gran_words) {
         if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
         p->d_gran = nullptr;
@@ -830,6 +1363,25 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
         RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
         p->gran_words = words;
     }
+#ifdef RH_PHASE_PROFILE
+    if (p->d_prof) RH_HIP_TRY(hipFree(p->d_prof));
+    p->d_prof = nullptr;
+    RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_prof), (tiles + 1) * 64));
+    RH_HIP_TRY(hipMemset(p->d_prof, 0, (tiles + 1) * 64));
+#endif
+    // The most loaded CU sets the pace: pad the LDS request until the dispatcher cannot put more
+    // than ceil(tiles/CUs) waves on any CU.
+    p->launch_lds = pl->lds_bytes;
+    if (tiles > 0 && !p->cfg.no_balance) {
+        const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
+        if ((int)per_cu <= pl->resident_per_cu) {
+            uint32_t want = (uint32_t)((160u * 1024u) / per_cu) & ~511u;
+            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= 512;
+            if (want > pl->lds_bytes) p->launch_lds = want;
+        }
+    }
+    p->plan = pl;
+    p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
     p->n_sources = n_sources;
     p->n_tiles = (uint32_t)tiles;
     p->out_frames = M;
@@ -844,6 +1396,7 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     if (!dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
     if (out_capacity_frames < p->out_frames) return RH_ERR_CAPACITY;
     hipStream_t s = rh::as_stream(stream);
+    const Plan &pl = *p->plan;
     p->epoch += 1;
     if (p->epoch == 0) {  // tag wrap: old tags could alias, start over from a clean table
         if (p->d_gran) RH_HIP_TRY(hipMemsetAsync(p->d_gran, 0, p->gran_words * 8, s));
@@ -851,7 +1404,7 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     }
     Params k;
     k.srcs = p->d_srcs;
-    k.tabs = p->d_tabs;
+    k.tabs = pl.d_tabs;
     k.out = dst;
     k.gran = p->d_gran;
     k.ticket = p->d_ctl;
@@ -868,14 +1421,15 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     k.Tf = (float)p->T;
     k.rcpT = 1.0f / (float)p->T;
     k.epoch = p->epoch;
-    k.J = p->J;
-    k.stage_bytes = p->stage_bytes;
+    k.J = pl.J;
     k.ticket_base = p->ticket_base;
-    k.u = p->uni;
+    k.prof = p->d_prof;
+    k.eq_frames = p->eq_frames;
+    k.u = pl.uni;
     void *args[] = {&k};
-    hipError_t e = hipLaunchKernel(p->kernel, dim3(p->n_tiles), dim3(p->threads), args, p->lds_bytes, s);
+    hipError_t e = hipLaunchKernel(pl.kernel, dim3(p->n_tiles), dim3(64), args, p->launch_lds, s);
     if (e != hipSuccess) {
-        rh::set_hip_error(e, "k_rlm_stereo launch");
+        rh::set_hip_error(e, "k_rlm launch");
         return RH_ERR_HIP;
     }
     p->ticket_base += p->n_tiles;  // every launch takes exactly n_tiles tickets
@@ -894,12 +1448,47 @@ rh_status rh_rlm_last_status(rh_rlm *p) {
     return RH_OK;
 }
 
-rh_status rh_rlm_geometry(rh_rlm *p, uint32_t *threads, uint32_t *frames_per_lane, uint32_t *lds_bytes, uint32_t *lookback_tiles) {
-    if (!p) return RH_ERR_INVALID;
-    if (threads) *threads = p->threads;
-    if (frames_per_lane) *frames_per_lane = p->R;
-    if (lds_bytes) *lds_bytes = p->lds_bytes;
-    if (lookback_tiles) *lookback_tiles = p->J;
+rh_status rh_rlm_late_carries(rh_rlm *p, uint64_t *count) {
+    RH_REQUIRE_INIT();
+    if (!p || !count) return RH_ERR_INVALID;
+    uint32_t v[2] = {0, 0};
+    RH_HIP_TRY(hipMemcpy(v, p->d_ctl + 2, 8, hipMemcpyDeviceToHost));
+    RH_HIP_TRY(hipMemset(p->d_ctl + 2, 0, 8));
+    *count = v[0] | ((uint64_t)v[1] << 32);  // high word: empty polls (RH_PHASE_PROFILE builds)
+    return RH_OK;
+}
+
+rh_status rh_rlm_phase_cycles(rh_rlm *p, double out8[8]) {
+    RH_REQUIRE_INIT();
+    if (!p || !out8) return RH_ERR_INVALID;
+    if (!p->d_prof) return RH_ERR_UNSUPPORTED;  // not an RH_PHASE_PROFILE build
+    std::vector<unsigned long long> h((size_t)p->n_tiles * 8);
+    RH_HIP_TRY(hipMemcpy(h.data(), p->d_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    if (const char *path = getenv("RH_PROF_DUMP")) {  // raw [tiles][8] u64 for tools/prof_tiles.py
+        if (FILE *f = fopen(path, "wb")) {
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+    for (uint32_t t = 0; t < p->n_tiles; ++t)
+        for (int i = 0; i < 8; ++i) out8[i] += (double)h[(size_t)t * 8 + i];
+    for (int i = 0; i < 8; ++i) out8[i] /= p->n_tiles ? p->n_tiles : 1;
+    return RH_OK;
+}
+
+rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
+    if (!p || !info) return RH_ERR_INVALID;
+    const Plan &pl = *p->plan;
+    info->threads = 64;
+    info->frames_per_lane = (uint32_t)pl.v->R;
+    info->ring_stages = (uint32_t)pl.v->NS;
+    info->stage_kib = (uint32_t)pl.v->KV;
+    info->lds_bytes = p->launch_lds ? p->launch_lds : pl.lds_bytes;
+    info->lookback_tiles = pl.J;
+    info->resident_waves_per_cu = (uint32_t)pl.resident_per_cu;
+    info->n_tiles = p->n_tiles;
+    info->general_kernel = pl.general ? 1u : 0u;
     return RH_OK;
 }
 

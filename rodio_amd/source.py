@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AgcParams, LimitParams, RlmConfig, check, lib
+from ._lib import AgcParams, LimitParams, RlmConfig, RlmGeometry, check, lib
 
 _torch = None
 _initialized = False
@@ -326,11 +326,11 @@ class ResampleLowpassMix:
     current_span_len() (None/0 = continuous)."""
 
     def __init__(self, from_rate, to_rate, channels=2, span_len=None, filter="low_pass", freq=200, q=0.5,
-                 max_sources=256, max_in_frames=1 << 20, frames_per_lane=0, threads=0):
+                 max_sources=256, max_in_frames=1 << 20, frames_per_lane=0, ring_stages=0, no_balance=0, force_general=0):
         _ensure()
         kind = {"low_pass": 0, "high_pass": 1, None: -1, "none": -1}[filter]
         self.cfg = RlmConfig(from_rate, to_rate, channels, int(span_len or 0), kind, freq, q, max_sources,
-                             max_in_frames, frames_per_lane, threads)
+                             max_in_frames, frames_per_lane, ring_stages, no_balance, force_general)
         self._h = C.c_void_p()
         check(lib.rh_rlm_create(C.byref(self._h), C.byref(self.cfg)), "rh_rlm_create")
         self.channels = channels
@@ -338,9 +338,9 @@ class ResampleLowpassMix:
         self.out_frames = 0
 
     def geometry(self):
-        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        check(lib.rh_rlm_geometry(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "rh_rlm_geometry")
-        return {"threads": a.value, "frames_per_lane": b.value, "lds_bytes": c.value, "lookback_tiles": d.value}
+        g = RlmGeometry()
+        check(lib.rh_rlm_geometry(self._h, C.byref(g)), "rh_rlm_geometry")
+        return {n: getattr(g, n) for n, _ in RlmGeometry._fields_}
 
     def set_sources(self, tensors):
         n = len(tensors)
@@ -364,6 +364,16 @@ class ResampleLowpassMix:
         m = C.c_uint64(0)
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
+
+    def phase_cycles(self):
+        out = (C.c_double * 8)()
+        st = lib.rh_rlm_phase_cycles(self._h, out)
+        return None if st != 0 else list(out)
+
+    def late_carries(self):
+        n = C.c_uint64(0)
+        check(lib.rh_rlm_late_carries(self._h, C.byref(n)), "rh_rlm_late_carries")
+        return n.value
 
     def check_status(self):
         _t().cuda.current_stream().synchronize()

@@ -321,14 +321,21 @@ def _gpu_pipeline(G, xs, frm, to, span, filt, freq, **kw):
     return res, geo
 
 
-@pytest.mark.parametrize("R,T", [(4, 128), (8, 256), (6, 384), (16, 256), (12, 512)])
+# (frames per lane, ring stages, general kernel): k_rlm_fast is what equal-length batches take;
+# force_general runs the same batch through the ragged-batch kernel k_rlm_wave
+GEOS = [(3, 2, 0), (4, 3, 0), (5, 2, 0), (6, 3, 0), (7, 2, 0), (8, 2, 0), (8, 3, 0), (8, 4, 0), (9, 2, 0), (10, 3, 0), (12, 3, 0), (16, 3, 0),
+        (6, 2, 1), (8, 2, 1), (8, 3, 1)]
+
+
+@pytest.mark.parametrize("R,NS,general", GEOS)
 @pytest.mark.parametrize("span", [None, 32768])
-def test_fused_resample_mix_bit_exact(G, O, R, T, span):
+def test_fused_resample_mix_bit_exact(G, O, R, NS, general, span):
     # filter off: the fused kernel must reproduce resampler + ordered mixer sum bit for bit
     S, n = 9, 40000
     xs = [rnd(300 + s, 2 * n) for s in range(S)]
     ref = _oracle_pipeline(O, xs, 44100, 48000, span, None, 0)
-    out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=R, threads=T)
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=R, ring_stages=NS, force_general=general)
+    assert geo["general_kernel"] == general and geo["frames_per_lane"] == R
     assert len(out) == len(ref)
     assert np.array_equal(out, ref)
 
@@ -347,7 +354,7 @@ def test_fused_ragged_lengths_bit_exact(G, O):
     xs = [rnd(500 + i, 2 * n) for i, n in enumerate(ns)]
     for span in (None, 32768):
         ref = _oracle_pipeline(O, xs, 44100, 48000, span, None, 0)
-        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=4, threads=128)
+        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, None, 0, frames_per_lane=4)
         assert np.array_equal(out, ref)
 
 
@@ -358,16 +365,17 @@ def _report(tag, out, ref):
     return err, peak
 
 
-@pytest.mark.parametrize("R,T", [(4, 128), (8, 256), (6, 384), (16, 256)])
+@pytest.mark.parametrize("R,NS,general", GEOS)
 @pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("low_pass", 1000), ("high_pass", 300)])
-def test_fused_filtered_pipeline(G, O, R, T, filt, freq):
+def test_fused_filtered_pipeline(G, O, R, NS, general, filt, freq):
     # BASELINE config 2 at oracle-friendly size: 16 sources x 60000 frames, amplitude 1/16
     S, n = 16, 60000
     xs = [rnd(600 + s, 2 * n, 1.0 / S) for s in range(S)]
     ref = _oracle_pipeline(O, xs, 44100, 48000, None, filt, freq)
-    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, filt, freq, frames_per_lane=R, threads=T)
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, filt, freq, frames_per_lane=R, ring_stages=NS, force_general=general)
+    assert geo["general_kernel"] == general
     truth = _truth_pipeline(O, xs, 44100, 48000, None, filt, freq)
-    err, peak = _check_filtered(f"{filt}{freq} R{R} T{T} J{geo['lookback_tiles']}", out, ref, truth)
+    err, peak = _check_filtered(f"{filt}{freq} R{R} NS{NS} {'wave' if general else 'fast'} J{geo['lookback_tiles']}", out, ref, truth)
     assert err <= 2e-5 * peak + 1e-7  # and not merely because the inputs were scaled down
 
 
@@ -384,14 +392,15 @@ def test_fused_filtered_full_scale_inputs(G, O):
 
 def test_fused_filtered_long_lookback(G, O):
     # a 20 Hz low-pass has poles at ~0.9974: with 512-frame tiles the carry reaches back
-    # several tiles (J > 1), exercising the multi-tile gather
+    # dozens of tiles (J > 4), exercising the wide multi-tile gather
     S, n = 6, 50000
     xs = [rnd(800 + s, 2 * n, 1.0 / S) for s in range(S)]
     ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 20)
-    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 20, frames_per_lane=4, threads=128)
-    assert geo["lookback_tiles"] > 1
     truth = _truth_pipeline(O, xs, 44100, 48000, None, "low_pass", 20)
-    _check_filtered(f"lookback J{geo['lookback_tiles']}", out, ref, truth)
+    for general in (0, 1):
+        out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 20, frames_per_lane=8, force_general=general)
+        assert geo["lookback_tiles"] > 4 and geo["general_kernel"] == general
+        _check_filtered(f"lookback J{geo['lookback_tiles']} general={general}", out, ref, truth)
 
 
 def test_fused_filtered_chunked_and_ragged(G, O):
@@ -399,7 +408,7 @@ def test_fused_filtered_chunked_and_ragged(G, O):
     xs = [rnd(900 + i, 2 * n, 0.2) for i, n in enumerate(ns)]
     for span in (None, 32768):
         ref = _oracle_pipeline(O, xs, 44100, 48000, span, "low_pass", 200)
-        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, "low_pass", 200, frames_per_lane=8, threads=128)
+        out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, "low_pass", 200, frames_per_lane=8)
         truth = _truth_pipeline(O, xs, 44100, 48000, span, "low_pass", 200)
         _check_filtered(f"ragged span={span}", out, ref, truth)
 

@@ -9,7 +9,7 @@ rows = []
 for R in (4, 6, 8, 12, 16):
     for T in (128, 192, 256, 320, 384, 448, 512):
         cmd = [sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-               "--frames-per-lane", str(R), "--threads", str(T)] + extra
+               "--frames-per-lane", str(R), "--ring-stages", str(T)] + extra
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -1,0 +1,102 @@
+// HBM -> LDS streaming microbenchmark with the access pattern of the fused pipeline kernel:
+// one wave per workgroup owns a time tile; it walks S sources, and for each DMAs KV KiB of that
+// source (global_load_lds_dwordx4) into a ring of NS LDS stages, waits with a counted vmcnt and
+// reads the stage back with ds_read_b64.  Answers: what fraction of the HBM roofline does this
+// data path reach before any DSP work is added?   (tools only; not part of the product.)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KV, int NS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k(const float *in, float *out, uint32_t S, uint64_t src_stride_f, int flops) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * WAVES + wave;
+    const uint32_t stage_bytes = KV * 1024;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS unsigned char *)smem + wave * NS * stage_bytes;
+    const float *base = in + (uint64_t)tile * (KV * 256) + lane * 4;
+    auto issue = [&](uint32_t s) {
+        const float *g = base + (uint64_t)s * src_stride_f;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (s % NS) * stage_bytes);
+#pragma unroll
+        for (int kk = 0; kk < KV; ++kk) glds16(g + kk * 256, dst + kk * 1024);
+    };
+    for (uint32_t s = 0; s < NS - 1 && s < S; ++s) issue(s);
+    v2f acc[KV * 2];
+#pragma unroll
+    for (int q = 0; q < KV * 2; ++q) acc[q] = v2f{0.f, 0.f};
+    for (uint32_t s = 0; s < S; ++s) {
+        if (s + NS - 1 < S) { issue(s + NS - 1); wait_vm<KV *(NS - 1)>(); } else wait_vm<0>();
+        const LDS unsigned char *st = (const LDS unsigned char *)smem + wave * NS * stage_bytes + (s % NS) * stage_bytes;
+#pragma unroll
+        for (int q = 0; q < KV * 2; ++q) {
+            v2f v = *(const LDS v2f *)(st + (q * 64 + lane) * 8);
+            for (int f = 0; f < flops; ++f) v = __builtin_elementwise_fma(v, v2f{0.5f, 0.5f}, v2f{0.25f, 0.25f});
+            acc[q] += v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is re-targeted by the next DMA
+    }
+    v2f t = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KV * 2; ++q) t += acc[q];
+    out[(uint64_t)tile * 64 + lane] = t.x + t.y;
+}
+
+template <int KV, int NS, int WAVES>
+void run(const float *d_in, float *d_out, uint32_t S, uint64_t total_tiles, uint64_t src_stride_f, int flops) {
+    const uint32_t blocks = total_tiles / WAVES;
+    const size_t lds = (size_t)WAVES * NS * KV * 1024;
+    CHECK(hipFuncSetAttribute((const void *)k<KV, NS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int occ = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k<KV, NS, WAVES>, 64 * WAVES, lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k<KV, NS, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, 0, d_in, d_out, S, src_stride_f, flops);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best) best = ms;
+    }
+    const double bytes = (double)S * total_tiles * KV * 1024;
+    printf("KV=%d NS=%d waves/wg=%d flops=%d tiles=%llu (%.1f waves/CU, occ %d wg/CU, lds %zu) : %.3f ms  %.0f GB/s  (%.1f%% of 8 TB/s)\n", KV, NS, WAVES, flops,
+           (unsigned long long)total_tiles, total_tiles / 256.0, occ, lds, best, bytes / best / 1e6, bytes / best / 1e6 / 80.0);
+}
+int main() {
+    const uint32_t S = 256;
+    const uint64_t src_bytes = 8ull << 20;  // 8 MiB per source, as config 2
+    float *d_in, *d_out;
+    CHECK(hipMalloc(&d_in, S * src_bytes + (1 << 20)));
+    CHECK(hipMemset(d_in, 0, S * src_bytes + (1 << 20)));
+    CHECK(hipMalloc(&d_out, 64 << 20));
+    const uint64_t stride = src_bytes / 4;
+    for (int flops : {0, 8}) {
+        // tiles * KV KiB == 8 MiB per source
+        run<2, 2, 1>(d_in, d_out, S, 4096, stride, flops);
+        run<2, 4, 1>(d_in, d_out, S, 4096, stride, flops);
+        run<4, 2, 1>(d_in, d_out, S, 2048, stride, flops);
+        run<4, 3, 1>(d_in, d_out, S, 2048, stride, flops);
+        run<4, 4, 1>(d_in, d_out, S, 2048, stride, flops);
+        run<4, 4, 2>(d_in, d_out, S, 2048, stride, flops);
+        run<4, 4, 4>(d_in, d_out, S, 2048, stride, flops);
+        run<4, 6, 1>(d_in, d_out, S, 2048, stride, flops);
+        run<3, 4, 1>(d_in, d_out, S, 2730, stride, flops);
+        run<6, 4, 1>(d_in, d_out, S, 1365, stride, flops);
+        run<8, 3, 1>(d_in, d_out, S, 1024, stride, flops);
+        run<8, 4, 1>(d_in, d_out, S, 1024, stride, flops);
+    }
+    return 0;
+}
