@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--no-balance", type=int, default=0)
     ap.add_argument("--force-general", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=1 << 18)
+    ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
     args = ap.parse_args()
 
     import torch
@@ -55,6 +55,7 @@ def main():
 
     import rodio_amd as rh
     from rodio_amd import _lib
+    from rodio_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +101,7 @@ def main():
         if ev is not None:
             lib.rh_event_record(ev[1], stream)
         if world > 1:  # the mixer sum across the source shards: one RCCL all-reduce over xGMI,
-            works[k & 1] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)  # overlaps step k+1
+            works[k & 1] = D.all_reduce_mix(buf, async_op=True)  # rodio_amd/distributed.py; overlaps step k+1
 
     def drain():
         for i in (0, 1):
@@ -147,7 +148,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("sources") == S and tj.get("frames") == N and tj.get("span", 0) == args.span:
+                g0 = pipe.geometry()
+                same_geo = all(tj.get("geometry", {}).get(k) == g0[k] for k in ("frames_per_lane", "ring_stages")) and not g0["general_kernel"]
+                if tj.get("sources") == S and tj.get("frames") == N and tj.get("span", 0) == args.span and same_geo:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -1204,6 +1204,7 @@ rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, 
             const double issue = 2.6 + 1.7 / std::pow(w, 1.5);
             double cost = passes * w * (per_frame * R + per_source) * issue;
             cost *= 1.0 + 0.01 * NS;  // among equals prefer the shallower ring (less LDS)
+            if (general && R < 8) cost *= 1.3;  // measured: the per-source scan and hand-off want the longer runs
             if (cost < best) {
                 best = cost;
                 bestV = v;

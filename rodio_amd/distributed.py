@@ -1,0 +1,83 @@
+"""Source sharding of the mixer across the GPUs of one node.
+
+rodio's streams only meet in the mixer sum (/root/reference/src/mixer.rs:185-198); every stage
+before it touches one source.  So rank r of R owns a contiguous shard of the sources, runs the
+fused kernel on it for the same output time range, and the partial mixes are summed with ONE
+all-reduce per mixed block (RCCL over xGMI when the process group is "nccl"; gloo on CPU in the
+tests).  No other communication.  One process per GPU, torch.distributed for the collective.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def shard_range(n_sources: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of the sources rank `rank` owns: contiguous, sizes differ by at most one, the first
+    n_sources % world ranks take the extra source (insertion order is kept inside a shard)."""
+    if world <= 0 or not 0 <= rank < world or n_sources < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(n_sources, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard(items: Sequence, rank: int, world: int) -> List:
+    lo, hi = shard_range(len(items), rank, world)
+    return list(items[lo:hi])
+
+
+def all_reduce_mix(block, group=None, async_op: bool = False):
+    """Sum the ranks' partial mixes of one block in place (every rank ends up with the full mix, like
+    rodio's single MixerSource).  `block` is a contiguous f32 tensor holding the partial mix of this
+    rank for the SAME output frames on every rank.  Returns the work handle when async_op."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    return dist.all_reduce(block, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def max_out_frames(out_frames: int, group=None) -> int:
+    """Shards may hold sources of different lengths: the mixed block is as long as the longest source
+    of ANY rank, so the ranks agree on the length (and zero-pad their partial mix) before reducing."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return out_frames
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([out_frames], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+class ShardedResampleLowpassMix:
+    """`ResampleLowpassMix` over this rank's shard of the sources + the cross-rank mixer sum.
+
+    set_sources() takes ALL sources of the job (device tensors of this rank for its own shard are
+    enough: entries outside the shard may be None) and keeps shard_range(len, rank, world)."""
+
+    def __init__(self, rank: int, world: int, *args, group=None, **kw):
+        from .source import ResampleLowpassMix
+
+        self.rank, self.world, self.group = rank, world, group
+        self.pipe = ResampleLowpassMix(*args, **kw)
+        self.out_frames = 0
+
+    def set_sources(self, tensors):
+        mine = shard(tensors, self.rank, self.world)
+        self.pipe.set_sources(mine)
+        self.out_frames = max_out_frames(self.pipe.out_frames, self.group)
+
+    def run(self, out=None, async_op: bool = False):
+        """One block: local fused kernel, then the all-reduce.  Returns (mixed, work)."""
+        import torch
+
+        ch = self.pipe.channels
+        if out is None:
+            out = torch.empty(max(self.out_frames * ch, 4), device="cuda", dtype=torch.float32)
+        local = self.pipe.run(out)
+        if local.numel() < self.out_frames * ch:  # this shard's sources are shorter than another rank's
+            out[local.numel(): self.out_frames * ch].zero_()
+        mixed = out[: self.out_frames * ch]
+        return mixed, all_reduce_mix(mixed, self.group, async_op)

@@ -178,6 +178,24 @@ def test_sample_type_converter_exhaustive(G, O):
     assert np.array_equal(G.SampleTypeConverter(i16[:12345], "i16", "f32"), O.convert("i16_to_f32", i16[:12345]))
 
 
+def test_golden_music_excerpt_config5(G):
+    # BASELINE config 5 on the committed excerpt of the reference's assets/music.wav
+    # (tests/golden/make_golden.py): i16 -> f32 and ChannelCountConverter 6 -> 2, bit-exact
+    import os
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    i16 = np.load(os.path.join(gdir, "music_excerpt_i16.npy"))
+    f32 = np.load(os.path.join(gdir, "music_excerpt_f32.npy"))
+    got = G.SampleTypeConverter(i16, "i16", "f32")
+    assert got.dtype == np.float32 and np.array_equal(got, f32)
+    six = f32[: (len(f32) // 6) * 6]
+    out = G.ChannelCountConverter(G.TestSource(six, 6, 44100), 6, 2).collect()
+    assert np.array_equal(out, np.load(os.path.join(gdir, "music_excerpt_6to2.npy")))
+    # and at block scale (the excerpt tiled x1024, 32 Mi samples): same bits, size-independent
+    big = np.tile(i16, 1024)
+    assert np.array_equal(G.SampleTypeConverter(big, "i16", "f32"), np.tile(f32, 1024))
+
+
 def test_sample_type_converter_egress(G, O):
     # f32 -> device formats (src/stream.rs:538-545): saturation, truncation toward zero, NaN -> 0
     x = np.concatenate([rnd(1, 100000, 1.5), np.float32([0, -0.0, 1, -1, 0.99999, -0.99999, 2, -2, np.nan, np.inf, -np.inf, 1e-9])])

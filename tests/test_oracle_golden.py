@@ -275,3 +275,21 @@ def test_resampler_matches_closed_form(O, frm, to, ch, n):
     out = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
     ref = closed_form_resample(x, frm, to, ch)
     assert np.array_equal(out, ref)
+
+
+# ------------------------------------------ BASELINE config 5 fixtures (tests/golden) ----
+def _golden(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_golden_music_excerpt_conversions(O):
+    # tests/golden/make_golden.py: 32 768 samples of the reference's assets/music.wav, expected arrays
+    # computed from the cited formulas with numpy (sample.rs:42-44 -> dasp i16->f32; channels.rs:57-85)
+    i16 = _golden("music_excerpt_i16.npy")
+    f32 = _golden("music_excerpt_f32.npy")
+    assert np.array_equal(O.convert("i16_to_f32", i16), f32)
+    six = f32[: (len(f32) // 6) * 6]
+    out = O.ChannelCountConverter(O.TestSource(six, 6, 44100), 6, 2).collect()
+    assert np.array_equal(out, _golden("music_excerpt_6to2.npy"))

@@ -53,6 +53,40 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *in, float *out, uin
     out[(uint64_t)tile * 64 + lane] = t.x + t.y;
 }
 
+// The fused kernel's exact read pattern: tile t of source s reads nvec 16-byte vectors starting at vector
+// t*vstride (+ s*src_stride): chunks are 16-byte but not 128-byte aligned, the KV*64 - nvec surplus lanes
+// re-fetch the chunk's last vector.
+template <int KV, int NS>
+__global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t vstride, uint32_t nvec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS unsigned char *)smem;
+    uint32_t off[KV];
+#pragma unroll
+    for (int kk = 0; kk < KV; ++kk) {
+        uint32_t j = lane + kk * 64;
+        j = j < nvec ? j : nvec - 1;
+        off[kk] = ((uint64_t)tile * vstride + j) * 4;  // floats
+    }
+    auto issue = [&](uint32_t s) {
+        const float *g = in + (uint64_t)s * src_stride_f;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (s % NS) * KV * 1024);
+#pragma unroll
+        for (int kk = 0; kk < KV; ++kk) glds16(g + off[kk], dst + kk * 1024);
+    };
+    for (uint32_t s = 0; s < NS - 1 && s < S; ++s) issue(s);
+    v2f acc = {0.f, 0.f};
+    for (uint32_t s = 0; s < S; ++s) {
+        if (s + NS - 1 < S) { issue(s + NS - 1); wait_vm<KV *(NS - 1)>(); } else wait_vm<0>();
+        const LDS unsigned char *st = (const LDS unsigned char *)smem + (s % NS) * KV * 1024;
+#pragma unroll
+        for (int q = 0; q < KV * 2; ++q) acc += *(const LDS v2f *)(st + (q * 64 + lane) * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    out[(uint64_t)tile * 64 + lane] = acc.x + acc.y;
+}
+
 template <int KV, int NS, int WAVES>
 void run(const float *d_in, float *d_out, uint32_t S, uint64_t total_tiles, uint64_t src_stride_f, int flops) {
     const uint32_t blocks = total_tiles / WAVES;
@@ -75,7 +109,8 @@ void run(const float *d_in, float *d_out, uint32_t S, uint64_t total_tiles, uint
     printf("KV=%d NS=%d waves/wg=%d flops=%d tiles=%llu (%.1f waves/CU, occ %d wg/CU, lds %zu) : %.3f ms  %.0f GB/s  (%.1f%% of 8 TB/s)\n", KV, NS, WAVES, flops,
            (unsigned long long)total_tiles, total_tiles / 256.0, occ, lds, best, bytes / best / 1e6, bytes / best / 1e6 / 80.0);
 }
-int main() {
+int main(int argc, char **argv) {
+    const bool cal = argc > 1;  // calibration mode for FETCH_SIZE: one configuration, known byte count
     const uint32_t S = 256;
     const uint64_t src_bytes = 8ull << 20;  // 8 MiB per source, as config 2
     float *d_in, *d_out;
@@ -83,6 +118,21 @@ int main() {
     CHECK(hipMemset(d_in, 0, S * src_bytes + (1 << 20)));
     CHECK(hipMalloc(&d_out, 64 << 20));
     const uint64_t stride = src_bytes / 4;
+    if (cal && argv[1][0] == 'm') {  // mimic: R=10 tiles of config 2 (640 out frames -> 588 in frames = 294 vectors; 298 fetched)
+        const uint32_t vstride = 294, nvec = 298, tiles = 1784;
+        CHECK(hipFuncSetAttribute((const void *)k_mimic<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int rep = 0; rep < 4; ++rep) {
+            hipLaunchKernelGGL((k_mimic<5, 2>), dim3(tiles), dim3(64), 23040, 0, d_in, d_out, S, stride, vstride, nvec);
+            CHECK(hipDeviceSynchronize());
+        }
+        printf("known_bytes_per_launch %llu\n", (unsigned long long)S * ((unsigned long long)(tiles - 1) * vstride + nvec) * 16ull);
+        return 0;
+    }
+    if (cal) {
+        run<4, 2, 1>(d_in, d_out, S, 2048, stride, 0);
+        printf("known_bytes_per_launch %llu\n", (unsigned long long)S * 2048ull * 4096ull);
+        return 0;
+    }
     for (int flops : {0, 8}) {
         // tiles * KV KiB == 8 MiB per source
         run<2, 2, 1>(d_in, d_out, S, 4096, stride, flops);
