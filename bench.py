@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ring-stages", type=int, default=0)
     ap.add_argument("--no-balance", type=int, default=0)
     ap.add_argument("--force-general", type=int, default=0)
+    ap.add_argument("--no-autotune", action="store_true", help="keep the cost model's launch geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
     args = ap.parse_args()
@@ -80,6 +81,10 @@ def main():
                                  max_in_frames=N, frames_per_lane=args.frames_per_lane, ring_stages=args.ring_stages, no_balance=args.no_balance, force_general=args.force_general)
     pipe.set_sources([data[s] for s in range(S)])
     M = pipe.out_frames
+    tuned = None
+    if not (args.no_autotune or args.frames_per_lane or args.ring_stages):
+        tuned = pipe.autotune()  # untimed set-up, like a BLAS find step: picks the launch geometry on this GPU
+        pipe.late_carries()  # reset the diagnostics counter
     outs = [torch.empty(M * Cn, device="cuda", dtype=torch.float32) for _ in range(2)]
     works = [None, None]
     lib = _lib.lib
@@ -159,7 +164,11 @@ def main():
         if ph is not None:
             geo["phase_cycles"] = [round(x) for x in ph]
         lc = pipe.late_carries()
+        # fast kernel: polls of the end-of-kernel look-back that found a predecessor not finished yet;
+        # general kernel: (source, tile) carries that were not published in time
         geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
+        if tuned:
+            geo["autotuned"] = True
         if lc >> 32:
             geo["empty_polls_per_launch"] = (lc >> 32) / max(args.steps + args.warmup, 1)
         res = {

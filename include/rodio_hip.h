@@ -188,6 +188,11 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
                              const uint64_t *in_frames_host, uint32_t n_sources);
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames,
                      rh_stream stream);
+/* Optional: time the candidate launch geometries of the equal-length kernel on the sources that are set
+ * (a few runs each into dst, which is overwritten) and keep the fastest -- like a GEMM library's
+ * find step.  Synchronises.  Ragged batches keep the model's choice.  Reports the geometry kept. */
+rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream,
+                          uint32_t *frames_per_lane, uint32_t *ring_stages);
 /* After a synchronise: 0 if the last run completed, RH_ERR_TIMEOUT if a bounded wait expired. */
 rh_status rh_rlm_last_status(rh_rlm *p);
 /* Diagnostics: number of (tile, source) carries since the last call that had not been published by

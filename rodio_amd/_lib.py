@@ -98,6 +98,7 @@ SIGNATURES = {
     "rh_rlm_destroy": (i32, [vp]),
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
+    "rh_rlm_autotune": (i32, [vp, vp, u64, vp, C.POINTER(u32), C.POINTER(u32)]),
     "rh_rlm_last_status": (i32, [vp]),
     "rh_rlm_geometry": (i32, [vp, C.POINTER(RlmGeometry)]),
     "rh_rlm_late_carries": (i32, [vp, C.POINTER(u64)]),

@@ -57,7 +57,7 @@ namespace {
 #ifndef RH_CARRY_DEFER
 #define RH_CARRY_DEFER 2  // see DESIGN.md: slack of the tile-to-tile hand-off, in groups of 8 sources
 #endif
-constexpr int kMaxR = 16;
+constexpr int kMaxR = 20;
 constexpr int kGroupLag = RH_CARRY_DEFER;  // a source group's carries are fetched kGroupLag groups (of 8 sources) after its own
 constexpr int kMaxLook = 32;              // 2 lanes x 16 B of LDS-DMA per predecessor tile: 64 lanes
 constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         uint64_t ib, ie;
         uint32_t nn;
         cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
-        ib &= ~1ull;  // 16-byte aligned vectors
+        ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
         cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
         ie += 1;
         uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
@@ -327,6 +327,14 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         }
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+#ifdef RH_SPLIT_TAPS
+    int offB[R + 2];
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) {
+        offB[rr] = offA[rr] + 8;
+        asm volatile("" : "+v"(offB[rr]));  // opaque: two ds_read_b64 instead of one ds_read2_b64
+    }
+#endif
 
     v2f acc[R];
 #pragma unroll
@@ -341,21 +349,17 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
     };
     const bool live = Mout > m_tile0 && Ns > 0;  // always true for a launched tile; keeps Ns-1 honest
+    // The ring: NS stages, and -- because a source's taps are pulled into registers in one go -- NS
+    // sources in flight: the stage of source s is re-targeted by the DMA of source s+NS as soon as the
+    // taps of s have returned, BEFORE the arithmetic of s.
     uint32_t st_cur = 0;
 #pragma unroll
-    for (int d = 0; d < NS - 1; ++d)
+    for (int d = 0; d < NS; ++d)
         if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[2 * d], d * kStage);
-    uint64_t ptr_pref = NS - 1 < S ? desc[2 * (NS - 1)] : 0;  // fetched one iteration ahead of its use
+    uint64_t ptr_pref = NS < S ? desc[2 * NS] : 0;  // fetched one iteration ahead of its use
     RH_PH_DECL
 
     for (uint32_t s = 0; s < S && live; ++s) {
-        {  // stage source s+NS-1 into the slot source s-1 has just left
-            uint32_t st_new = st_cur + (NS - 1) * kStage;
-            if (st_new >= NS * kStage) st_new -= NS * kStage;
-            if (s + NS - 1 < S) stage_source((const void *)(uintptr_t)ptr_pref, st_new);
-            ptr_pref = s + NS < S ? desc[2 * (uint64_t)(s + NS)] : 0;
-        }
-        RH_PH(1)
         {  // the stage of source s has landed when at most the groups issued after it are outstanding
             const uint32_t left = S - 1 - s;
             wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
@@ -367,9 +371,18 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
 #pragma unroll
             for (int rr = 0; rr < R + 2; ++rr) {
                 ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
+#ifdef RH_SPLIT_TAPS
+                tb2[rr] = *(const lds_f2 *)(buf + offB[rr]);
+#else
                 tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
+#endif
             }
         }
+        // every tap is in a register: the stage is free for source s+NS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s + NS < S) stage_source((const void *)(uintptr_t)ptr_pref, st_cur);
+        ptr_pref = s + NS + 1 < S ? desc[2 * (uint64_t)(s + NS + 1)] : 0;
+        RH_PH(1)
         auto tap = [&](int rr) -> v2f {
             const v2f a = ta[rr], b = tb2[rr];
             v2f x;
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         uint64_t ib, ie;
         uint32_t nn;
         cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
-        ib &= ~1ull;  // 16-byte aligned vectors
+        ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
         cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
         ie += 1;
         uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
@@ -1082,7 +1095,10 @@ const Variant kFast[] = {
     RH_FAST(9, 5, 2),   RH_FAST(9, 5, 3),   RH_FAST(9, 10, 2),
     RH_FAST(10, 5, 2),  RH_FAST(10, 5, 3),  RH_FAST(10, 6, 2), RH_FAST(10, 6, 3), RH_FAST(10, 11, 2),
     RH_FAST(12, 6, 2),  RH_FAST(12, 6, 3),  RH_FAST(12, 7, 2), RH_FAST(12, 7, 3), RH_FAST(12, 13, 2),
+    RH_FAST(14, 7, 2),  RH_FAST(14, 8, 2),
     RH_FAST(16, 8, 2),  RH_FAST(16, 8, 3),  RH_FAST(16, 9, 2), RH_FAST(16, 9, 3),
+    RH_FAST(18, 9, 2),  RH_FAST(18, 10, 2),
+    RH_FAST(20, 10, 2), RH_FAST(20, 11, 2),
 #endif
 };
 // The general kernel (ragged batches) is heavier; it ships in two tile sizes.
@@ -1107,7 +1123,7 @@ int blocks_per_cu(const void *fn, size_t lds) {
 }
 // Vectors (2 frames = 16 B) per lane a stage must hold for a tile of L output frames.
 int kv_needed(uint64_t L, uint32_t F, uint32_t T) {
-    const uint64_t span = ((L + 1) * F) / T + 5;  // i(m0+L-1) - i(m0-2) + tap + even alignment
+    const uint64_t span = ((L + 1) * F) / T + 5 + 14;  // i(m0+L-1) - i(m0-2) + tap + alignment to a 128-byte line
     const uint64_t nvec = span / 2 + 2;
     return (int)((nvec + 63) / 64);
 }
@@ -1135,6 +1151,8 @@ struct rh_rlm {
     Plan *plan = nullptr;   // chosen by set_sources
     uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
     uint32_t eq_frames = 0;
+    bool equal = true;
+    std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
     SrcDesc *d_srcs = nullptr;
     unsigned long long *d_gran = nullptr;
     size_t gran_words = 0;
@@ -1260,6 +1278,43 @@ rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, 
     return RH_OK;
 }
 
+// Point the handle at a plan for the current batch: grid, aggregate table, LDS request.
+rh_status activate_plan(rh_rlm *p, Plan *pl) {
+    const uint64_t M = p->out_frames;
+    const uint64_t L = 64ull * pl->v->R;
+    const uint64_t tiles = (M + L - 1) / L;
+    if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
+    const size_t words = (pl->general ? (size_t)p->n_sources : 1) * tiles * 4;
+    if (p->filt && words > p->gran_words) {
+        if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
+        p->d_gran = nullptr;
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
+        RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
+        p->gran_words = words;
+    }
+#ifdef RH_PHASE_PROFILE
+    if (p->d_prof) RH_HIP_TRY(hipFree(p->d_prof));
+    p->d_prof = nullptr;
+    RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_prof), (tiles + 1) * 64));
+    RH_HIP_TRY(hipMemset(p->d_prof, 0, (tiles + 1) * 64));
+#endif
+    // The most loaded CU sets the pace: pad the LDS request until the dispatcher cannot put more
+    // than ceil(tiles/CUs) waves on any CU.
+    p->launch_lds = pl->lds_bytes;
+    if (tiles > 0 && !p->cfg.no_balance) {
+        const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
+        if ((int)per_cu <= pl->resident_per_cu) {
+            uint32_t want = (uint32_t)((160u * 1024u) / per_cu) & ~511u;
+            if (want > 64u * 1024u) want = 64u * 1024u;
+            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= 512;
+            if (want > pl->lds_bytes) p->launch_lds = want;
+        }
+    }
+    p->plan = pl;
+    p->n_tiles = (uint32_t)tiles;
+    return RH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1322,7 +1377,12 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
-    if (p->fast.d_tabs) (void)hipFree(p->fast.d_tabs);
+    bool fast_in_tried = false;
+    for (Plan &c : p->tried) {
+        fast_in_tried = fast_in_tried || c.d_tabs == p->fast.d_tabs;
+        if (c.d_tabs) (void)hipFree(c.d_tabs);
+    }
+    if (p->fast.d_tabs && !fast_in_tried) (void)hipFree(p->fast.d_tabs);
     if (p->wave.d_tabs) (void)hipFree(p->wave.d_tabs);
     if (p->d_srcs) (void)hipFree(p->d_srcs);
     if (p->d_gran) (void)hipFree(p->d_gran);
@@ -1350,43 +1410,13 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
         if (g.out_frames > M) M = g.out_frames;
         equal = equal && in_frames_host[s] == in_frames_host[0];
     }
-    // equal-length batch: the merged-state kernel; otherwise the general one
-    Plan *pl = (equal && !p->cfg.force_general) ? &p->fast : &p->wave;
-    const uint64_t L = 64ull * pl->v->R;
-    const uint64_t tiles = (M + L - 1) / L;
-    if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
     if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
-    const size_t words = (pl->general ? (size_t)n_sources : 1) * tiles * 4;
-    if (p->filt && words > p->gran_words) {
-        if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
-        p->d_gran = nullptr;
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
-        RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
-        p->gran_words = words;
-    }
-#ifdef RH_PHASE_PROFILE
-    if (p->d_prof) RH_HIP_TRY(hipFree(p->d_prof));
-    p->d_prof = nullptr;
-    RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_prof), (tiles + 1) * 64));
-    RH_HIP_TRY(hipMemset(p->d_prof, 0, (tiles + 1) * 64));
-#endif
-    // The most loaded CU sets the pace: pad the LDS request until the dispatcher cannot put more
-    // than ceil(tiles/CUs) waves on any CU.
-    p->launch_lds = pl->lds_bytes;
-    if (tiles > 0 && !p->cfg.no_balance) {
-        const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
-        if ((int)per_cu <= pl->resident_per_cu) {
-            uint32_t want = (uint32_t)((160u * 1024u) / per_cu) & ~511u;
-            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= 512;
-            if (want > pl->lds_bytes) p->launch_lds = want;
-        }
-    }
-    p->plan = pl;
+    p->equal = equal;
     p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
     p->n_sources = n_sources;
-    p->n_tiles = (uint32_t)tiles;
     p->out_frames = M;
-    return RH_OK;
+    // equal-length batch: the merged-state kernel; otherwise the general one
+    return activate_plan(p, (equal && !p->cfg.force_general) ? &p->fast : &p->wave);
 }
 
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
@@ -1434,6 +1464,73 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
         return RH_ERR_HIP;
     }
     p->ticket_base += p->n_tiles;  // every launch takes exactly n_tiles tickets
+    return RH_OK;
+}
+
+rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream, uint32_t *frames_per_lane, uint32_t *ring_stages) {
+    RH_REQUIRE_INIT();
+    if (!p || !dst) return RH_ERR_INVALID;
+    if (p->plan == &p->fast && p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
+        rh::ResampleGeom g;
+        rh_status st = rh::make_resample_geom(p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
+        if (st != RH_OK) return st;
+        hipStream_t s = rh::as_stream(stream);
+        hipEvent_t e0, e1;
+        RH_HIP_TRY(hipEventCreate(&e0));
+        RH_HIP_TRY(hipEventCreate(&e1));
+        auto time_current = [&](float &ms) -> rh_status {
+            rh_status r = rh_rlm_run(p, dst, out_capacity_frames, nullptr, stream);  // warm-up
+            if (r != RH_OK) return r;
+            ms = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                RH_HIP_TRY(hipEventRecord(e0, s));
+                r = rh_rlm_run(p, dst, out_capacity_frames, nullptr, stream);
+                if (r != RH_OK) return r;
+                RH_HIP_TRY(hipEventRecord(e1, s));
+                RH_HIP_TRY(hipEventSynchronize(e1));
+                float t = 0.f;
+                RH_HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+                if (t < ms) ms = t;
+            }
+            return RH_OK;
+        };
+        float best_ms = 0.f;
+        st = time_current(best_ms);
+        Plan best = p->fast;
+        p->tried.reserve(64);
+        {  // every table the handle ever owned is freed through `tried`
+            bool have = false;
+            for (const Plan &c : p->tried) have = have || c.d_tabs == p->fast.d_tabs;
+            if (!have) p->tried.push_back(p->fast);
+        }
+        for (int R = 2; R <= kMaxR && st == RH_OK; ++R) {
+            for (int NS = 2; NS <= 3; ++NS) {
+                if (R == best.v->R && NS == best.v->NS) continue;
+                Plan cand;
+                if (make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS) != RH_OK) continue;
+                p->tried.push_back(cand);
+                const uint64_t tiles = (p->out_frames + 64ull * R - 1) / (64ull * R);
+                const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
+                if ((int)per_cu > cand.resident_per_cu) continue;  // would run in passes: never the fastest
+                p->fast = cand;
+                if ((st = activate_plan(p, &p->fast)) != RH_OK) break;
+                float ms = 0.f;
+                if ((st = time_current(ms)) != RH_OK) break;
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = cand;
+                }
+            }
+        }
+        p->fast = best;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (st != RH_OK) return st;
+        st = activate_plan(p, &p->fast);
+        if (st != RH_OK) return st;
+    }
+    if (frames_per_lane) *frames_per_lane = (uint32_t)p->plan->v->R;
+    if (ring_stages) *ring_stages = (uint32_t)p->plan->v->NS;
     return RH_OK;
 }
 

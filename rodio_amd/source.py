@@ -365,6 +365,14 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
 
+    def autotune(self, out=None):
+        """Time the candidate geometries on the current sources and keep the fastest (synchronises)."""
+        if out is None:
+            out = _dev_empty(max(self.out_frames * self.channels, 4))
+        r, ns = C.c_uint32(0), C.c_uint32(0)
+        check(lib.rh_rlm_autotune(self._h, _ptr(out), out.numel() // self.channels, _stream(), C.byref(r), C.byref(ns)), "rh_rlm_autotune")
+        return r.value, ns.value
+
     def phase_cycles(self):
         out = (C.c_double * 8)()
         st = lib.rh_rlm_phase_cycles(self._h, out)

@@ -512,6 +512,29 @@ def test_cfg2_full_size_linearity_is_bit_exact(G, cfg2):
     p.close()
 
 
+def test_cfg2_autotune_keeps_the_result(G, cfg2):
+    """rh_rlm_autotune swaps the launch geometry (tile length, ring depth, tables): the mixed block must
+    stay within f32 re-association distance of the model geometry's, and repeat bit for bit."""
+    import torch
+
+    S, N, data = cfg2
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=N)
+    p.set_sources([data[s] for s in range(S)])
+    a = p.run().clone()
+    g0 = p.geometry()
+    r, ns = p.autotune()
+    g1 = p.geometry()
+    assert (g1["frames_per_lane"], g1["ring_stages"]) == (r, ns) and not g1["general_kernel"]
+    b = p.run().clone()
+    c = p.run().clone()
+    p.check_status()
+    assert torch.equal(b, c)
+    err = float((a - b).abs().max())
+    print(f"[autotune] {g0['frames_per_lane']},{g0['ring_stages']} -> {r},{ns}  |delta|={err:.2e} peak={float(a.abs().max()):.2e}")
+    assert err <= 1e-6
+    p.close()
+
+
 def test_cfg2_chunked_variant_matches_unchunked_away_from_seams(G, cfg2):
     """span_len=32768 variant: 64 chunks x 17833 frames; inside a chunk the output
     equals the continuous stream's (same taps), only the seam frames differ."""
