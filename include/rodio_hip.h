@@ -99,6 +99,16 @@ uint64_t rh_delay_samples(uint64_t delay_ns, uint32_t sample_rate, uint32_t chan
 rh_status rh_echo_mix(float *dst, const float *src, size_t n, size_t delay_samples, float gain,
                       rh_stream stream);
 
+/* ---- fused, batched reverb -> Spatial (BASELINE config 3): for every stream s < n_streams
+ *        Spatial(reverb(x_s, delay, gain), ...) = ChannelVolume(reverb(x_s), gains[s])
+ * Replaces source/mod.rs:628-634 + channel_volume.rs:71-88 in one pass over the input.  x_s = src +
+ * s*src_stride holds n interleaved STEREO samples; row s of dst (dst + s*dst_stride) receives
+ * 2*floor((n + delay_samples)/2) samples.  gains_dev: DEVICE array [n_streams][2] (rh_spatial_gains
+ * per stream).  Bit-exact with the two-step reference chain. */
+rh_status rh_reverb_spatial(float *dst, const float *src, size_t n, size_t delay_samples, float gain,
+                            const float *gains_dev, uint32_t n_streams, size_t src_stride,
+                            size_t dst_stride, rh_stream stream);
+
 /* ---- SampleRateConverter (+ UniformSourceIterator span chunking):
  * src/conversions/sample_rate.rs:52-90,110-122,131-201, src/math.rs:23-26,
  * src/source/uniform.rs:50-97.  span_len = 0 means current_span_len() == None; otherwise the

@@ -24,7 +24,9 @@ from .source import (  # noqa: F401
     biquad_coeffs,
     delay_samples,
     init,
+    reverb_spatial_batch,
     spatial_gains,
+    spatial_gains_batch,
 )
 
 __all__ = [n for n in dir() if not n.startswith("_")]

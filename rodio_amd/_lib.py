@@ -94,6 +94,7 @@ SIGNATURES = {
     "rh_agc_state_floats": (sz, []),
     "rh_agc_state_init": (i32, [vp, u32, vp]),
     "rh_agc": (i32, [vp, vp, u64, u32, u32, C.POINTER(AgcParams), vp, vp]),
+    "rh_reverb_spatial": (i32, [vp, vp, sz, sz, f32, vp, u32, sz, sz, vp]),
     "rh_rlm_create": (i32, [C.POINTER(vp), C.POINTER(RlmConfig)]),
     "rh_rlm_destroy": (i32, [vp]),
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),

@@ -235,6 +235,56 @@ rh_status launch_f32_to_int(T *dst, const float *src, size_t n, rh_stream stream
     return RH_OK;
 }
 
+
+// ---------------------------------------------- reverb -> Spatial, fused and batched ----
+// BASELINE config 3: for every stream  Spatial(reverb(x, D, a), emitter, ears)  in one pass:
+//   r[i] = x[i] + 0 (i < D) | x[i] + a*x[i-D] (D <= i < L) | a*x[i-D] (L <= i < L+D)      source/mod.rs:628-634
+//   m = ((0 + r[2f]) + r[2f+1]) / 2 ;  out[2f+k] = m * g[k]                               channel_volume.rs:71-88
+// x is read once from HBM (the echo tap is 4*D bytes behind: L2 / Infinity Cache), the reverb
+// intermediate never exists.  One lane = two output frames (16-byte accesses) when D % 4 == 0.
+__device__ __forceinline__ float rev_at(const float *__restrict__ x, size_t i, size_t n, size_t delay, float gain) {
+    const float s2 = (i < delay) ? 0.0f : x[i - delay] * gain;  // Delay(Amplify(x))
+    return (i < n) ? (x[i] + s2) : s2;                             // mix.rs:47-52
+}
+struct StreamGains {
+    const float *g;  // device [n_streams][2]
+};
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void k_reverb_spatial(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain,
+                                                           const float *__restrict__ gains, size_t src_stride, size_t dst_stride, size_t frames_out) {
+    const uint32_t stream = blockIdx.y;
+    const float *x = src + (size_t)stream * src_stride;
+    float *o = dst + (size_t)stream * dst_stride;
+    const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if (VEC4) {  // n % 4 == 0, delay % 4 == 0, 16-byte aligned rows
+        const size_t quads = (frames_out + 1) / 2;
+        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += stride) {
+            const size_t i = 4 * q;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (i < n) a = *reinterpret_cast<const float4 *>(x + i);
+            if (i >= delay) b = *reinterpret_cast<const float4 *>(x + i - delay);  // i - delay < n because i < n + delay
+            float r[4];
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
+                r[k] = (i < n) ? (av[k] + s2) : s2;
+            }
+            float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
+            m0 = m0 / 2.0f;
+            m1 = m1 / 2.0f;
+            *reinterpret_cast<float4 *>(o + i) = make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1);
+        }
+    } else {
+        for (size_t f = (size_t)blockIdx.x * kBlock + threadIdx.x; f < frames_out; f += stride) {
+            const float r0 = rev_at(x, 2 * f, n, delay, gain), r1 = rev_at(x, 2 * f + 1, n, delay, gain);
+            float m = (0.0f + r0) + r1;
+            m = m / 2.0f;
+            *reinterpret_cast<float2 *>(o + 2 * f) = make_float2(m * g0, m * g1);
+        }
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -320,6 +370,28 @@ uint64_t rh_delay_samples(uint64_t delay_ns, uint32_t sample_rate, uint32_t chan
     // delay.rs:8-16: ns * channels * rate / 1e9 in u128
     unsigned __int128 s = (unsigned __int128)delay_ns * channels * sample_rate / 1000000000ull;
     return (uint64_t)s;
+}
+
+rh_status rh_reverb_spatial(float *dst, const float *src, size_t n, size_t delay_samples, float gain, const float *gains_dev, uint32_t n_streams,
+                            size_t src_stride, size_t dst_stride, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n_streams == 0) return RH_OK;
+    if (n % 2 != 0) return RH_ERR_INVALID;  // stereo frames (source/mod.rs:169-178: sources end on frame boundaries)
+    const size_t frames_out = (n + delay_samples) / 2;  // an odd total leaves half a frame, which ChannelVolume drops (channel_volume.rs:76)
+    if (frames_out == 0) return RH_OK;
+    if (!dst || !src || !gains_dev) return RH_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 7u) return RH_ERR_INVALID;
+    if (n_streams > 65535u) return RH_ERR_UNSUPPORTED;
+    const bool vec4 = n % 4 == 0 && delay_samples % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0;
+    // enough workgroups for 256 CUs x 8 in total, spread over the streams
+    const size_t items = vec4 ? (frames_out + 1) / 2 : frames_out;
+    unsigned gx = rh::grid_for(items, kBlock, (256u * 8u + n_streams - 1) / n_streams);
+    const dim3 grid(gx, n_streams);
+    if (vec4) hipLaunchKernelGGL(k_reverb_spatial<true>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out);
+    else hipLaunchKernelGGL(k_reverb_spatial<false>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
 }
 
 rh_status rh_echo_mix(float *dst, const float *src, size_t n, size_t delay_samples, float gain, rh_stream stream) {

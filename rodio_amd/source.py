@@ -251,6 +251,30 @@ def Spatial(inp: GpuSource, emitter, left, right) -> GpuSource:
     return ChannelVolume(inp, spatial_gains(emitter, left, right))
 
 
+def spatial_gains_batch(emitters, left, right):
+    """Device tensor [S, 2] of Spatial gains (one rh_spatial_gains per emitter)."""
+    torch = _t()
+    gains = np.stack([spatial_gains(e, left, right) for e in emitters]).astype(np.float32)
+    return torch.from_numpy(gains).to("cuda")
+
+
+def reverb_spatial_batch(x, sample_rate, duration_ns, amplitude, emitters, left, right, out=None, gains_dev=None):
+    """BASELINE config 3 in one kernel: for every row s of the device tensor x [S, n] (interleaved stereo)
+    `Spatial(reverb(x_s, duration, amplitude), emitters[s], left, right)`.  Returns [S, n_out] on device."""
+    _ensure()
+    torch = _t()
+    S, n = x.shape
+    d = delay_samples(duration_ns, sample_rate, 2)
+    n_out = 2 * ((n + d) // 2)
+    g_dev = gains_dev if gains_dev is not None else spatial_gains_batch(emitters, left, right)
+    if out is None:
+        stride = (n_out + 3) // 4 * 4
+        out = torch.empty((S, stride), device="cuda", dtype=torch.float32)
+    check(lib.rh_reverb_spatial(_ptr(out), _ptr(x), n, d, amplitude, _ptr(g_dev), S, x.stride(0), out.stride(0), _stream()),
+          "rh_reverb_spatial")
+    return out[:, :n_out]
+
+
 def biquad_coeffs(kind, freq, q, fs) -> np.ndarray:
     out = np.zeros(5, np.float32)
     k = 1 if kind in (1, "high_pass") else 0

@@ -225,6 +225,44 @@ def test_reverb_delay_longer_than_source(G, O):
     assert np.array_equal(G.TestSource(x, 2, 48000).reverb(10_000_000, 0.3).collect(), ref)
 
 
+@pytest.mark.parametrize("n,ns", [(2 * 4096, 682_666_667 // 64), (2 * 3001, 20_833_333), (2 * 1000, 10_000_000), (2 * 777, 31_250)])
+def test_reverb_spatial_fused_batch_bit_exact(G, O, n, ns):
+    # BASELINE config 3 in miniature: 5 streams, reverb -> Spatial, one fused launch vs the oracle's
+    # two-adapter chain.  Cases: delay % 4 == 0 (vector path), an ODD delay (channel swap, half frame
+    # dropped at the end), delay > source, delay of 3 samples.
+    import torch
+
+    S = 5
+    xs = np.stack([rnd(40 + s, n, 0.25) for s in range(S)])
+    em = [[0.5 + 0.01 * s, 0, 1] for s in range(S)]
+    out = G.reverb_spatial_batch(torch.from_numpy(xs).cuda(), 48000, ns, 0.3, em, [-1, 0, 0], [1, 0, 0]).cpu().numpy()
+    for s in range(S):
+        ref = O.Spatial(O.TestSource(xs[s], 2, 48000).reverb(ns, 0.3), em[s], [-1, 0, 0], [1, 0, 0]).collect()
+        assert out.shape[1] == len(ref)
+        assert np.array_equal(out[s], ref)
+
+
+def test_reverb_spatial_config3_full_size(G, O):
+    # 64 sources x 2*2^20 samples @ 48 kHz, reverb(682 666 667 ns = 65 536 samples, 0.3), Spatial per source.
+    # Oracle on 3 of the 64 rows in full; all rows against the unfused GPU ops (themselves oracle-exact).
+    import torch
+
+    S, n = 64, 2 << 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5678)
+    x = (torch.rand((S, n), generator=g, device="cuda", dtype=torch.float32) * 2 - 1) * 0.25
+    em = [[0.5 + 0.01 * s, 0, 1] for s in range(S)]
+    out = G.reverb_spatial_batch(x, 48000, 682_666_667, 0.3, em, [-1, 0, 0], [1, 0, 0])
+    assert out.shape == (S, n + 65536)
+    for s in (0, 31, 63):
+        xs = x[s].cpu().numpy()
+        ref = O.Spatial(O.TestSource(xs, 2, 48000).reverb(682_666_667, 0.3), em[s], [-1, 0, 0], [1, 0, 0]).collect()
+        assert np.array_equal(out[s].cpu().numpy(), ref)
+    for s in range(0, S, 7):
+        two_step = G.Spatial(G.GpuSource(x[s], 2, 48000).reverb(682_666_667, 0.3), em[s], [-1, 0, 0], [1, 0, 0]).samples
+        assert torch.equal(out[s], two_step)
+
+
 def test_spatial_bit_exact(G, O):
     x = rnd(4, 2 * 50001, 0.25)
     for s in (0, 7, 63):
@@ -429,6 +467,34 @@ def test_fused_filtered_chunked_and_ragged(G, O):
         out, _ = _gpu_pipeline(G, xs, 44100, 48000, span, "low_pass", 200, frames_per_lane=8)
         truth = _truth_pipeline(O, xs, 44100, 48000, span, "low_pass", 200)
         _check_filtered(f"ragged span={span}", out, ref, truth)
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+@pytest.mark.parametrize("general", [0, 1])
+def test_fused_fewer_sources_than_ring_stages(G, O, S, general):
+    n = 20011
+    xs = [rnd(1100 + s, 2 * n, 0.5) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 200)
+    truth = _truth_pipeline(O, xs, 44100, 48000, None, "low_pass", 200)
+    for ns in (2, 3):
+        out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 200, frames_per_lane=8, ring_stages=ns, force_general=general)
+        _check_filtered(f"S={S} NS={ns} general={general}", out, ref, truth)
+    refp = _oracle_pipeline(O, xs, 44100, 48000, None, None, 0)
+    outp, _ = _gpu_pipeline(G, xs, 44100, 48000, None, None, 0, force_general=general)
+    assert np.array_equal(outp, refp)
+
+
+@pytest.mark.parametrize("general", [0, 1])
+def test_fused_more_tiles_than_resident_waves(G, O, general):
+    # 3 sources x 3 Mi frames with 256-frame tiles: ~14 000 tiles, several times what the chip holds at
+    # once, so late tiles start only when early ones have finished (ticket order keeps that safe)
+    S, n = 3, 3 << 20
+    xs = [rnd(1200 + s, 2 * n, 0.3) for s in range(S)]
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 200, frames_per_lane=(6 if general else 4), ring_stages=2, force_general=general)
+    assert geo["n_tiles"] > 256 * geo["resident_waves_per_cu"] or geo["n_tiles"] > 8000
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 200)
+    err, peak = _report(f"many tiles general={general} tiles={geo['n_tiles']}", out, ref)
+    assert err <= TOL and err <= 2e-5 * peak + 1e-7
 
 
 def test_fused_matches_unfused_gpu_ops(G, O):
