@@ -120,6 +120,32 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
                              uint32_t to_rate, uint32_t channels, uint64_t span_len,
                              rh_stream stream);
 
+/* ---- block streaming: the same two adapters when the stream arrives in blocks (what a `Source` shim
+ * does: pull a block upstream, process, serve next() from it).  The handle keeps what the reference's
+ * iterator keeps between samples; ANY split of a stream into blocks gives the bits of one pass.
+ * (rh_biquad / rh_limit / rh_agc carry their state through their `state` argument.)
+ *
+ * SampleRateConverter, continuous stream (current_span_len() == None; a spanned source is converted span
+ * by span with rh_resample_linear, uniform.rs:56-67).  process() consumes in_frames new frames and emits
+ * every output frame whose two taps have arrived; flush != 0 marks the end of the stream (rodio's None):
+ * the last input frame is then emitted verbatim (sample_rate.rs:193-200).  pending_frames() tells the
+ * caller how large dst must be. */
+typedef struct rh_resampler rh_resampler;
+rh_status rh_resampler_create(rh_resampler **out, uint32_t from_rate, uint32_t to_rate, uint32_t channels);
+rh_status rh_resampler_reset(rh_resampler *p);
+rh_status rh_resampler_destroy(rh_resampler *p);
+rh_status rh_resampler_pending_frames(rh_resampler *p, uint64_t in_frames, int32_t flush, uint64_t *out_frames);
+rh_status rh_resampler_process(rh_resampler *p, float *dst, uint64_t dst_capacity_frames, const float *src,
+                               uint64_t in_frames, int32_t flush, uint64_t *out_frames, rh_stream stream);
+/* reverb (delay_samples interleaved samples, gain): process() maps n samples to n samples; after the last
+ * block flush() emits the delay_samples samples of the delayed clone that outlive the source. */
+typedef struct rh_echo rh_echo;
+rh_status rh_echo_create(rh_echo **out, uint64_t delay_samples, float gain);
+rh_status rh_echo_reset(rh_echo *p);
+rh_status rh_echo_destroy(rh_echo *p);
+rh_status rh_echo_process(rh_echo *p, float *dst, const float *src, uint64_t n, rh_stream stream);
+rh_status rh_echo_flush(rh_echo *p, float *dst, rh_stream stream);
+
 /* ---- Mixer: src/mixer.rs:58-66,120-136,175-198.  out[t] = ((0+v0[t])+v1[t])+... over the live
  * sources in insertion order (bit-identical rounding sequence).  Source s contributes samples
  * [start[s], start[s]+len[s]) (start = frame-aligned admission, mixer.rs:175-183).

@@ -18,6 +18,8 @@ from .source import (  # noqa: F401
     SampleTypeConverter,
     SamplesBuffer,
     SpanSource,
+    StreamingResampler,
+    StreamingReverb,
     Spatial,
     TestSource,
     UniformSourceIterator,

@@ -94,6 +94,16 @@ SIGNATURES = {
     "rh_agc_state_floats": (sz, []),
     "rh_agc_state_init": (i32, [vp, u32, vp]),
     "rh_agc": (i32, [vp, vp, u64, u32, u32, C.POINTER(AgcParams), vp, vp]),
+    "rh_resampler_create": (i32, [C.POINTER(vp), u32, u32, u32]),
+    "rh_resampler_reset": (i32, [vp]),
+    "rh_resampler_destroy": (i32, [vp]),
+    "rh_resampler_pending_frames": (i32, [vp, u64, i32, C.POINTER(u64)]),
+    "rh_resampler_process": (i32, [vp, vp, u64, vp, u64, i32, C.POINTER(u64), vp]),
+    "rh_echo_create": (i32, [C.POINTER(vp), u64, f32]),
+    "rh_echo_reset": (i32, [vp]),
+    "rh_echo_destroy": (i32, [vp]),
+    "rh_echo_process": (i32, [vp, vp, vp, u64, vp]),
+    "rh_echo_flush": (i32, [vp, vp, vp]),
     "rh_reverb_spatial": (i32, [vp, vp, sz, sz, f32, vp, u32, sz, sz, vp]),
     "rh_rlm_create": (i32, [C.POINTER(vp), C.POINTER(RlmConfig)]),
     "rh_rlm_destroy": (i32, [vp]),

@@ -341,6 +341,70 @@ class Mixer:
         return self.pull(1 << 62)
 
 
+# ---- block streaming -----------------------------------------------------------------------------
+class StreamingResampler:
+    """SampleRateConverter over a stream that arrives in blocks (rh_resampler_*): feed(block) returns the
+    output frames that became computable; feed(block, flush=True) ends the stream (rodio's None)."""
+
+    def __init__(self, from_rate, to_rate, channels):
+        _ensure()
+        self._h = C.c_void_p()
+        self.channels = channels
+        check(lib.rh_resampler_create(C.byref(self._h), from_rate, to_rate, channels), "rh_resampler_create")
+
+    def feed(self, block, flush=False):
+        frames = block.numel() // self.channels
+        n = C.c_uint64(0)
+        check(lib.rh_resampler_pending_frames(self._h, frames, int(flush), C.byref(n)), "rh_resampler_pending_frames")
+        out = _dev_empty(max(n.value * self.channels, 1))
+        m = C.c_uint64(0)
+        check(lib.rh_resampler_process(self._h, _ptr(out), n.value, _ptr(block) if frames else None, frames, int(flush),
+                                       C.byref(m), _stream()), "rh_resampler_process")
+        return out[: m.value * self.channels]
+
+    def close(self):
+        if self._h:
+            lib.rh_resampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StreamingReverb:
+    """reverb(duration, amplitude) over a stream that arrives in blocks (rh_echo_*)."""
+
+    def __init__(self, duration_ns, amplitude, sample_rate, channels):
+        _ensure()
+        self.delay = delay_samples(duration_ns, sample_rate, channels)
+        self._h = C.c_void_p()
+        check(lib.rh_echo_create(C.byref(self._h), self.delay, amplitude), "rh_echo_create")
+
+    def feed(self, block):
+        out = _dev_empty(max(block.numel(), 1))
+        check(lib.rh_echo_process(self._h, _ptr(out), _ptr(block) if block.numel() else None, block.numel(), _stream()), "rh_echo_process")
+        return out[: block.numel()]
+
+    def flush(self):
+        out = _dev_empty(max(self.delay, 1))
+        check(lib.rh_echo_flush(self._h, _ptr(out), _stream()), "rh_echo_flush")
+        return out[: self.delay]
+
+    def close(self):
+        if self._h:
+            lib.rh_echo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- fused headline pipeline ------------------------------------------------------------------
 class ResampleLowpassMix:
     """BASELINE config 2 as one kernel: for every source

@@ -150,6 +150,53 @@ def test_uniform_samples_buffer_with_channel_change(G, O):
     assert e.value.status == 3  # RH_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("frm,to,ch", [(44100, 48000, 2), (48000, 44100, 2), (8000, 48000, 1), (96000, 44100, 3), (44100, 44100, 2), (1000, 7000, 1)])
+def test_streaming_resampler_block_splits_equal_one_pass(G, O, frm, to, ch):
+    # rh_resampler_*: the converter's state (position + current frame, sample_rate.rs:110-122) carried
+    # across blocks: every split of the stream gives the bits of the one-pass converter
+    import torch
+
+    rng = np.random.default_rng(frm + to + ch)
+    n = 20000
+    x = rnd(frm % 97 + ch, n * ch)
+    ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+    xd = torch.from_numpy(x).cuda()
+    for trial in range(4):
+        cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, size=[0, 1, 7, 40][trial])))
+        cuts = [0] + cuts + [n]
+        if trial == 3:
+            cuts += [n, n]  # empty blocks, also an empty flush block
+        r = G.StreamingResampler(frm, to, ch)
+        outs = []
+        for k in range(len(cuts) - 1):
+            outs.append(r.feed(xd[cuts[k] * ch: cuts[k + 1] * ch], flush=(k == len(cuts) - 2)))
+        got = torch.cat(outs).cpu().numpy()
+        assert np.array_equal(got, ref), (trial, len(got), len(ref))
+        r.close()
+    # the empty stream
+    r = G.StreamingResampler(frm, to, ch)
+    assert r.feed(xd[:0], flush=True).numel() == 0
+
+
+@pytest.mark.parametrize("n,ns,ch", [(20000, 20_833_333, 2), (20000, 682_666_667 // 16, 2), (300, 10_000_000, 2), (5000, 3_000_000, 1)])
+def test_streaming_reverb_block_splits_equal_one_pass(G, O, n, ns, ch):
+    # rh_echo_*: the delayed clone's history carried across blocks; also blocks shorter than the delay
+    import torch
+
+    rng = np.random.default_rng(n + ch)
+    x = rnd(n + 11, n - n % ch, 0.25)
+    ref = O.TestSource(x, ch, 48000).reverb(ns, 0.3).collect()
+    xd = torch.from_numpy(x).cuda()
+    for trial in range(3):
+        cuts = [0] + sorted(set(int(c) for c in rng.integers(0, len(x) + 1, size=[0, 5, 60][trial]))) + [len(x)]
+        r = G.StreamingReverb(ns, 0.3, 48000, ch)
+        outs = [r.feed(xd[cuts[k]: cuts[k + 1]]) for k in range(len(cuts) - 1)]
+        outs.append(r.flush())
+        got = torch.cat(outs).cpu().numpy()
+        assert np.array_equal(got, ref), (trial, len(got), len(ref))
+        r.close()
+
+
 @pytest.mark.parametrize("a,b", [(6, 2), (2, 6), (1, 2), (1, 4), (2, 1), (3, 8), (8, 3), (2, 2), (5, 5)])
 def test_channels_bit_exact(G, O, a, b):
     x = rnd(a * 10 + b, a * 10007)
