@@ -160,7 +160,8 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host,
  * state (optional device pointer, 4*channels floats {x1,x2,y1,y2} per channel) carries the
  * filter across blocks; NULL = zero state, not written back.
  * mode 0 = sequential per (source,channel) stream, same op order as blt.rs:559 (bit-exact);
- * mode 1 = time-parallel scan (<=1e-5 abs).
+ * mode 1 = time-parallel scan (<=1e-5 abs): stereo streams, state == NULL, frames*2 % 4 == 0
+ *          for n_streams > 1 (16-byte rows); anything else returns RH_ERR_UNSUPPORTED -- use mode 0.
  * The batch form filters n_streams equally shaped blocks laid out back to back. */
 rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate,
                            float out_coeffs5[5]);
@@ -204,7 +205,7 @@ typedef struct rh_rlm_config {
     uint32_t from_rate, to_rate;
     uint32_t channels;     /* 2 (stereo) in this round */
     uint64_t span_len;     /* 0 = None; else chunk of min(span_len, 32768) samples */
-    int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter */
+    int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter, 2 = custom_coeffs (from_rate == to_rate allowed) */
     uint32_t filter_freq;
     float filter_q;        /* rodio's low_pass() uses 0.5 (blt.rs:11-16) */
     uint32_t max_sources;
@@ -213,6 +214,7 @@ typedef struct rh_rlm_config {
     uint32_t ring_stages;     /* LDS stages of the source prefetch ring (2..4); 0 = auto */
     uint32_t no_balance;      /* diagnostics: 1 = do not pad the LDS request to even out waves per CU */
     uint32_t force_general;   /* diagnostics/tests: 1 = use the ragged-batch kernel even for equal lengths */
+    float custom_coeffs[5];   /* filter_kind 2: {b0,b1,b2,a1,a2}, already divided by a0 */
 } rh_rlm_config;
 typedef struct rh_rlm rh_rlm;
 rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg);
@@ -224,6 +226,9 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
                              const uint64_t *in_frames_host, uint32_t n_sources);
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames,
                      rh_stream stream);
+/* The same over the sources [first, first+count) only (a sub-mix; count = 1: one filtered stream). */
+rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst,
+                            uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream);
 /* Optional: time the candidate launch geometries of the equal-length kernel on the sources that are set
  * (a few runs each into dst, which is overwritten) and keep the fastest -- like a GEMM library's
  * find step.  Synchronises.  Ragged batches keep the model's choice.  Reports the geometry kept. */

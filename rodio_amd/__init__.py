@@ -23,6 +23,7 @@ from .source import (  # noqa: F401
     Spatial,
     TestSource,
     UniformSourceIterator,
+    biquad_batch,
     biquad_coeffs,
     delay_samples,
     init,

@@ -38,7 +38,7 @@ class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
                 ("filter_q", C.c_float), ("max_sources", C.c_uint32), ("max_in_frames", C.c_uint64),
-                ("frames_per_lane", C.c_uint32), ("ring_stages", C.c_uint32), ("no_balance", C.c_uint32), ("force_general", C.c_uint32)]
+                ("frames_per_lane", C.c_uint32), ("ring_stages", C.c_uint32), ("no_balance", C.c_uint32), ("force_general", C.c_uint32), ("custom_coeffs", C.c_float * 5)]
 
 
 class RlmGeometry(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "rh_rlm_destroy": (i32, [vp]),
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
+    "rh_rlm_run_subset": (i32, [vp, u32, u32, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_autotune": (i32, [vp, vp, u64, vp, C.POINTER(u32), C.POINTER(u32)]),
     "rh_rlm_last_status": (i32, [vp]),
     "rh_rlm_geometry": (i32, [vp, C.POINTER(RlmGeometry)]),

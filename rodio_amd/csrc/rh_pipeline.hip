@@ -1323,7 +1323,8 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     RH_REQUIRE_INIT();
     if (!out || !cfg || cfg->from_rate == 0 || cfg->to_rate == 0 || cfg->channels == 0 || cfg->max_sources == 0) return RH_ERR_INVALID;
     if (cfg->channels != 2) return RH_ERR_UNSUPPORTED;
-    if (cfg->from_rate == cfg->to_rate) return RH_ERR_UNSUPPORTED;  // passthrough converter: use rh_biquad + rh_mix_sum
+    // passthrough converter (sample_rate.rs:133-136): only as the time-parallel stand-alone filter (filter_kind 2)
+    if (cfg->from_rate == cfg->to_rate && cfg->filter_kind != 2) return RH_ERR_UNSUPPORTED;
     if (cfg->max_in_frames >= (1ull << 29)) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets inside a source
     rh::ResampleGeom g;
     rh_status st = rh::make_resample_geom(cfg->max_in_frames, cfg->from_rate, cfg->to_rate, cfg->channels, cfg->span_len, &g);
@@ -1337,7 +1338,14 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     p->chunk_in = g.n_chunks > 1 ? g.chunk_in : 0;
     p->chunk_out = g.n_chunks > 1 ? g.chunk_out : 0;
     p->filt = cfg->filter_kind >= 0;
-    if (p->filt) {
+    if (cfg->filter_kind == 2) {  // coefficients given ({b0,b1,b2,a1,a2}, already divided by a0)
+        for (int k = 0; k < 5; ++k) p->coeffs[k] = cfg->custom_coeffs[k];
+        const double a1 = p->coeffs[3], a2 = p->coeffs[4];  // stability triangle: the look-back needs a decaying filter
+        if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2)) {
+            delete p;
+            return RH_ERR_UNSUPPORTED;
+        }
+    } else if (p->filt) {
         st = rh_biquad_coeffs(cfg->filter_kind, cfg->filter_freq, cfg->filter_q, cfg->to_rate, p->coeffs);
         if (st != RH_OK) {
             delete p;
@@ -1420,8 +1428,14 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
 }
 
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
+    if (!p) return RH_ERR_INVALID;
+    return rh_rlm_run_subset(p, 0, p->n_sources, dst, out_capacity_frames, out_frames, stream);
+}
+
+rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
+    if (first > p->n_sources || count > p->n_sources - first) return RH_ERR_INVALID;
     if (out_frames) *out_frames = p->out_frames;
     if (p->out_frames == 0) return RH_OK;
     if (!dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
@@ -1434,7 +1448,7 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
         p->epoch = 1;
     }
     Params k;
-    k.srcs = p->d_srcs;
+    k.srcs = p->d_srcs + first;
     k.tabs = pl.d_tabs;
     k.out = dst;
     k.gran = p->d_gran;
@@ -1443,7 +1457,7 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     k.out_frames = p->out_frames;
     k.chunk_in = p->chunk_in;
     k.chunk_out = p->chunk_out;
-    k.n_sources = p->n_sources;
+    k.n_sources = count;
     k.n_tiles = p->n_tiles;
     k.F = p->F;
     k.T = p->T;
@@ -1590,10 +1604,43 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     return RH_OK;
 }
 
-// Time-parallel standalone biquad (rh_biquad mode 1): scheduled for the next round; the
-// sequential mode-0 kernel is the one shipped for the standalone op.
-rh_status rh_biquad_scan(float *, const float *, uint64_t, uint32_t, uint32_t, const float *, float *, rh_stream) {
-    return RH_ERR_UNSUPPORTED;
+// Time-parallel stand-alone biquad (rh_biquad mode 1): every stream is one launch of the equal-length
+// kernel over a single "source" with the pass-through converter (from == to: tap weight 0), i.e. the
+// per-lane zero-state runs + wave scan + tile look-back of DESIGN.md 4.2 without a mixer.  One handle is
+// cached per (coefficients, block length); like every handle it serves one thread at a time.
+rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels != 2 || state) return RH_ERR_UNSUPPORTED;  // stereo blocks from a zero state; mode 0 covers the rest
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) return RH_ERR_INVALID;
+    if ((frames * 2) % 4 != 0 && n_streams > 1) return RH_ERR_UNSUPPORTED;  // stream rows must stay 16-byte aligned
+    static rh_rlm *cache = nullptr;
+    static float cache_co[5];
+    static uint64_t cache_frames = 0;
+    static uint32_t cache_streams = 0;
+    bool same = cache && cache_frames >= frames && cache_streams >= n_streams;
+    for (int k = 0; k < 5 && same; ++k) same = cache_co[k] == coeffs5_host[k];
+    if (!same) {
+        if (cache) rh_rlm_destroy(cache);
+        cache = nullptr;
+        rh_rlm_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        cfg.from_rate = cfg.to_rate = 1;
+        cfg.channels = 2;
+        cfg.filter_kind = 2;
+        for (int k = 0; k < 5; ++k) cfg.custom_coeffs[k] = cache_co[k] = coeffs5_host[k];
+        cfg.max_sources = n_streams;
+        cfg.max_in_frames = frames;
+        rh_status st = rh_rlm_create(&cache, &cfg);
+        if (st != RH_OK) return st;
+        cache_frames = frames;
+        cache_streams = n_streams;
+    }
+    std::vector<const float *> ptrs(n_streams);
+    std::vector<uint64_t> lens(n_streams, frames);
+    for (uint32_t s = 0; s < n_streams; ++s) ptrs[s] = src + (uint64_t)s * frames * 2;
+    rh_status st = rh_rlm_set_sources(cache, ptrs.data(), lens.data(), n_streams);
+    for (uint32_t s = 0; s < n_streams && st == RH_OK; ++s) st = rh_rlm_run_subset(cache, s, 1, dst + (uint64_t)s * frames * 2, frames, nullptr, stream);
+    return st;
 }
 
 }  // extern "C"

@@ -331,6 +331,43 @@ def test_biquad_sequential_bit_exact(G, O, kind, freq, ch, n):
     assert np.array_equal(out, ref)
 
 
+
+
+@pytest.mark.parametrize("kind,freq,q", [("low_pass", 200, 0.5), ("low_pass", 1000, 0.5), ("high_pass", 300, 0.5), ("low_pass", 800, 2.0), ("high_pass", 2000, 0.7071)])
+def test_biquad_time_parallel_mode1(G, O, kind, freq, q):
+    # rh_biquad mode 1 (time-parallel scan) against the sequential reference order (mode 0 == oracle bit
+    # for bit) and the f64 recurrence: <= 1e-5 abs and no further from the truth than the f32 reference
+    import torch
+
+    S, n = 5, 100000
+    x = np.stack([rnd(70 + s, 2 * n, 0.5) for s in range(S)])
+    co = G.biquad_coeffs(kind, freq, q, 48000)
+    xd = torch.from_numpy(x).cuda()
+    seq = G.biquad_batch(xd, co, mode=0).cpu().numpy()
+    par = G.biquad_batch(xd, co, mode=1).cpu().numpy()
+    for s in (0, S - 1):
+        src = O.TestSource(x[s], 2, 48000)
+        ref = (src.low_pass_with_q(freq, q) if kind == "low_pass" else src.high_pass_with_q(freq, q)).collect() if hasattr(src, "low_pass_with_q") else None
+        if ref is not None:
+            assert np.array_equal(seq[s], ref)
+    # f64 truth of the same recurrence
+    c = co.astype(np.float64)
+    truth = np.zeros_like(x, dtype=np.float64)
+    xs = x.astype(np.float64).reshape(S, n, 2)
+    y = truth.reshape(S, n, 2)
+    x1 = np.zeros((S, 2)); x2 = np.zeros((S, 2)); y1 = np.zeros((S, 2)); y2 = np.zeros((S, 2))
+    for t in range(n):
+        r = c[0] * xs[:, t] + c[1] * x1 + c[2] * x2 - c[3] * y1 - c[4] * y2
+        y[:, t] = r
+        x2, x1, y2, y1 = x1, xs[:, t].copy(), y1, r
+    e_par = float(np.max(np.abs(par - truth)))
+    e_seq = float(np.max(np.abs(seq - truth)))
+    d = float(np.max(np.abs(par - seq)))
+    print(f"[biquad mode1 {kind}{freq} q={q}] |par-seq|={d:.3e} |par-f64|={e_par:.3e} |seq-f64|={e_seq:.3e} peak={float(np.max(np.abs(truth))):.3e}")
+    assert d <= TOL
+    assert e_par <= 2.0 * e_seq + 1e-7
+
+
 @pytest.mark.parametrize("ch", [1, 2, 3])
 def test_limiter(G, O, ch):
     sr = 48000
