@@ -66,11 +66,18 @@ def main():
             sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    rh.init(local_rank)
+    # RH_BENCH_ONE_DEVICE=1: development aid for a 1-GPU box -- every rank time-shares cuda:0 and the
+    # collective goes through gloo (RCCL refuses two ranks on one device).  Not a measurement mode.
+    one_dev = os.environ.get("RH_BENCH_ONE_DEVICE") == "1"
+    dev = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev)
+    rh.init(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     S, N, Cn = args.sources, args.frames, 2
     # synthetic 44.1 kHz stereo sources, U(-1,1) / (total sources) so |mix| <= 1
