@@ -75,6 +75,21 @@ rh_status rh_convert_f32_to_i8(int8_t *dst, const float *src, size_t n, rh_strea
 rh_status rh_convert_f32_to_i16(int16_t *dst, const float *src, size_t n, rh_stream stream);
 rh_status rh_convert_f32_to_u16(uint16_t *dst, const float *src, size_t n, rh_stream stream);
 rh_status rh_convert_f32_to_i32(int32_t *dst, const float *src, size_t n, rh_stream stream);
+/* The rest of cpal's device formats (src/stream.rs:555-568 egress, src/microphone.rs:280-291 ingress).
+ * I24 / U24 travel in 32-bit containers like cpal's (unchecked: f32 1.0 -> I24 8388608); unsigned
+ * formats go through the signed one (dasp `iN::to_uN`).  64-bit formats lose nothing that f32 has. */
+rh_status rh_convert_f32_to_u8(uint8_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_i24(int32_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_u24(int32_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_u32(uint32_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_i64(int64_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_u64(uint64_t *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_f32_to_f64(double *dst, const float *src, size_t n, rh_stream stream);
+rh_status rh_convert_u24_to_f32(float *dst, const int32_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_u32_to_f32(float *dst, const uint32_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_i64_to_f32(float *dst, const int64_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_u64_to_f32(float *dst, const uint64_t *src, size_t n, rh_stream stream);
+rh_status rh_convert_f64_to_f32(float *dst, const double *src, size_t n, rh_stream stream);
 
 /* ---- ChannelCountConverter: src/conversions/channels.rs:57-85.  Bit-exact.
  * dst holds frames*to_ch samples. */

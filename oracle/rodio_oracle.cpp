@@ -772,6 +772,29 @@ void orc_f32_to_u16(const float *in, uint16_t *out, size_t n) {
     }
 }
 
+// The rest of cpal's device formats (stream.rs:555-568, microphone.rs:280-291), dasp_sample 0.11.0 conv.rs
+// restated: unsigned goes through the signed type, I24/U24 are unchecked i32 containers.  Unpinned.
+void orc_f32_to_u8(const float *in, uint8_t *out, size_t n) { for (size_t i = 0; i < n; ++i) { int8_t s = sat_cast<int8_t>(in[i] * 128.0f); out[i] = s < 0 ? (uint8_t)(s + 127 + 1) : (uint8_t)((uint8_t)s + 128); } }
+void orc_f32_to_i24(const float *in, int32_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sat_cast<int32_t>(in[i] * 8388608.0f); }
+void orc_f32_to_u24(const float *in, int32_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (int32_t)((uint32_t)sat_cast<int32_t>(in[i] * 8388608.0f) + 8388608u); }
+void orc_f32_to_u32(const float *in, uint32_t *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { int32_t s = sat_cast<int32_t>(in[i] * 2147483648.0f); out[i] = s < 0 ? (uint32_t)(s + 2147483647 + 1) : (uint32_t)s + 2147483648u; }
+}
+void orc_f32_to_i64(const float *in, int64_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sat_cast<int64_t>(in[i] * 9223372036854775808.0f); }
+void orc_f32_to_u64(const float *in, uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { int64_t s = sat_cast<int64_t>(in[i] * 9223372036854775808.0f); out[i] = s < 0 ? (uint64_t)(s + 9223372036854775807LL + 1) : (uint64_t)s + 9223372036854775808ull; }
+}
+void orc_f32_to_f64(const float *in, double *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (double)in[i]; }
+void orc_u24_to_f32(const int32_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)(in[i] - 8388608) / 8388608.0f; }
+void orc_u32_to_f32(const uint32_t *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { uint32_t s = in[i]; int32_t v = s < 2147483648u ? (int32_t)s - 2147483647 - 1 : (int32_t)(s - 2147483648u); out[i] = (float)v / 2147483648.0f; }
+}
+void orc_i64_to_f32(const int64_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 9223372036854775808.0f; }
+void orc_u64_to_f32(const uint64_t *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { uint64_t s = in[i]; int64_t v = s < 9223372036854775808ull ? (int64_t)s - 9223372036854775807LL - 1 : (int64_t)(s - 9223372036854775808ull); out[i] = (float)v / 9223372036854775808.0f; }
+}
+void orc_f64_to_f32(const double *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i]; }
+
 // ---- the cfg-2 pipeline as one call, for the CPU baseline of bench.py:
 //   for each source: mixer.add(UniformSourceIterator::new(src, ch_out, to).low_pass(freq))
 // then drain the mixer (benches/pipeline.rs shape: `.for_each(black_box_drop)`).

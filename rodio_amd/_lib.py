@@ -79,6 +79,18 @@ SIGNATURES = {
     "rh_convert_f32_to_i16": (i32, [vp, vp, sz, vp]),
     "rh_convert_f32_to_u16": (i32, [vp, vp, sz, vp]),
     "rh_convert_f32_to_i32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_u8": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_i24": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_u24": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_u32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_i64": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_u64": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f32_to_f64": (i32, [vp, vp, sz, vp]),
+    "rh_convert_u24_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_u32_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_i64_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_u64_to_f32": (i32, [vp, vp, sz, vp]),
+    "rh_convert_f64_to_f32": (i32, [vp, vp, sz, vp]),
     "rh_channels_convert": (i32, [vp, vp, sz, u32, u32, vp]),
     "rh_amplify": (i32, [vp, vp, sz, f32, vp]),
     "rh_channel_volume": (i32, [vp, vp, sz, u32, f32p, u32, vp]),

@@ -207,6 +207,18 @@ _CONV = {
     ("f32", "i16"): ("rh_convert_f32_to_i16", np.float32, np.int16),
     ("f32", "u16"): ("rh_convert_f32_to_u16", np.float32, np.uint16),
     ("f32", "i32"): ("rh_convert_f32_to_i32", np.float32, np.int32),
+    ("f32", "u8"): ("rh_convert_f32_to_u8", np.float32, np.uint8),
+    ("f32", "i24"): ("rh_convert_f32_to_i24", np.float32, np.int32),
+    ("f32", "u24"): ("rh_convert_f32_to_u24", np.float32, np.int32),
+    ("f32", "u32"): ("rh_convert_f32_to_u32", np.float32, np.uint32),
+    ("f32", "i64"): ("rh_convert_f32_to_i64", np.float32, np.int64),
+    ("f32", "u64"): ("rh_convert_f32_to_u64", np.float32, np.uint64),
+    ("f32", "f64"): ("rh_convert_f32_to_f64", np.float32, np.float64),
+    ("u24", "f32"): ("rh_convert_u24_to_f32", np.int32, np.float32),
+    ("u32", "f32"): ("rh_convert_u32_to_f32", np.uint32, np.float32),
+    ("i64", "f32"): ("rh_convert_i64_to_f32", np.int64, np.float32),
+    ("u64", "f32"): ("rh_convert_u64_to_f32", np.uint64, np.float32),
+    ("f64", "f32"): ("rh_convert_f64_to_f32", np.float64, np.float32),
 }
 
 

@@ -243,6 +243,37 @@ def test_golden_music_excerpt_config5(G):
     assert np.array_equal(G.SampleTypeConverter(big, "i16", "f32"), np.tile(f32, 1024))
 
 
+def test_device_formats_egress_and_ingress(G, O):
+    # the rest of cpal's formats either side of the path (stream.rs:555-568,
+    # microphone.rs:280-291).  dasp_sample 0.11.0 formulas restated twice: the C++ oracle and numpy here.
+    x = np.concatenate([rnd(21, 200001, 1.5), np.float32([0, -0.0, 1, -1, 0.99999994, -0.99999994, 0.5, -0.5, 2, -2, 300, -300,
+                                                          np.nan, np.inf, -np.inf, 1e-9, -1e-9, 2.0 ** -24, -(2.0 ** -24)])])
+    for dst in ("u8", "i24", "u24", "u32", "i64", "u64", "f64"):
+        got = G.SampleTypeConverter(x, "f32", dst)
+        assert np.array_equal(got, O.convert("f32_to_" + dst, x), equal_nan=(dst == "f64")), dst
+    fin = x[np.isfinite(x)]
+    with np.errstate(invalid="ignore", over="ignore"):
+        i8 = np.clip(np.trunc(fin.astype(np.float32) * np.float32(128)), -128, 127).astype(np.int64)
+        assert np.array_equal(G.SampleTypeConverter(fin, "f32", "u8"), (i8 + 128).astype(np.uint8))
+        i32 = np.clip(np.trunc((fin * np.float32(8388608.0)).astype(np.float64)), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+        assert np.array_equal(G.SampleTypeConverter(fin, "f32", "i24"), i32.astype(np.int32))
+        assert np.array_equal(G.SampleTypeConverter(fin, "f32", "f64"), fin.astype(np.float64))
+    assert G.SampleTypeConverter(np.float32([1.0]), "f32", "i24")[0] == 8388608  # unchecked container, not clamped to 24 bits
+    rng = np.random.default_rng(23)
+    u24 = rng.integers(0, 2 ** 24, 100003, dtype=np.int64).astype(np.int32)
+    assert np.array_equal(G.SampleTypeConverter(u24, "u24", "f32"), O.convert("u24_to_f32", u24))
+    assert np.array_equal(G.SampleTypeConverter(u24, "u24", "f32"), ((u24.astype(np.int64) - 8388608).astype(np.float32) / np.float32(8388608)))
+    u32 = np.concatenate([rng.integers(0, 2 ** 32, 100003, dtype=np.uint64).astype(np.uint32), np.uint32([0, 1, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 1])])
+    assert np.array_equal(G.SampleTypeConverter(u32, "u32", "f32"), O.convert("u32_to_f32", u32))
+    i64 = np.concatenate([rng.integers(-2 ** 63, 2 ** 63 - 1, 100003, dtype=np.int64), np.int64([0, 1, -1, 2 ** 62, -2 ** 63, 2 ** 63 - 1])])
+    assert np.array_equal(G.SampleTypeConverter(i64, "i64", "f32"), O.convert("i64_to_f32", i64))
+    u64 = i64.view(np.uint64)
+    assert np.array_equal(G.SampleTypeConverter(u64, "u64", "f32"), O.convert("u64_to_f32", u64))
+    f64 = np.concatenate([rng.uniform(-2, 2, 100003), [0.1, 1e-50, 1e50, -1e50, np.nan]])
+    a, b = G.SampleTypeConverter(f64, "f64", "f32"), O.convert("f64_to_f32", f64)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a[:-1], f64[:-1].astype(np.float32))
+
+
 def test_sample_type_converter_egress(G, O):
     # f32 -> device formats (src/stream.rs:538-545): saturation, truncation toward zero, NaN -> 0
     x = np.concatenate([rnd(1, 100000, 1.5), np.float32([0, -0.0, 1, -1, 0.99999, -0.99999, 2, -2, np.nan, np.inf, -np.inf, 1e-9])])
