@@ -99,6 +99,14 @@ rh_status rh_channels_convert(float *dst, const float *src, size_t frames, uint3
 /* ---- Amplify: src/source/amplify.rs:64 */
 rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_stream stream);
 
+/* ---- Distortion: src/source/distortion.rs:66-72.  threshold < 0 or NaN: RH_ERR_INVALID (f32::clamp panics). */
+rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, float threshold, rh_stream stream);
+/* ---- LinearGainRamp, fade_in (0 -> 1, then 1.0), fade_out (1 -> 0, clamp_end): src/source/linear_ramp.rs:79-110,
+ * fadein.rs:11-13, fadeout.rs:13.  Stateless: sample_offset = samples of the stream already processed. */
+rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels,
+                              uint32_t sample_rate, uint64_t duration_ns, float start_gain, float end_gain,
+                              int32_t clamp_end, rh_stream stream);
+
 /* ---- ChannelVolume / Spatial: src/source/channel_volume.rs:71-88, src/source/spatial.rs:48-69.
  * gains_host has out_ch entries (out_ch <= 16).  dst holds frames*out_ch samples. */
 rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_t in_ch,

@@ -349,6 +349,61 @@ struct Amplify : Source {
     uint32_t sample_rate() const override { return input->sample_rate(); }
 };
 
+// ---------------------------------------------------------- Distortion ----
+// src/source/distortion.rs:66-72: v = value * gain; v.clamp(-t, t)  (f32::clamp: NaN stays NaN)
+struct Distortion : Source {
+    Source *input;
+    float gain, threshold;
+    Distortion(Source *in, float g, float t) : input(in), gain(g), threshold(t) {}
+    ~Distortion() override { delete input; }
+    bool next(float &out) override {
+        float v;
+        if (!input->next(v)) return false;
+        v = v * gain;
+        const float lo = -threshold, hi = threshold;
+        if (v < lo) v = lo;
+        if (v > hi) v = hi;
+        out = v;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
+// ------------------------------------------------------- LinearGainRamp ----
+// src/source/linear_ramp.rs:79-110 (fade_in = ramp(0,1,false) fadein.rs:11-13; fade_out = ramp(1,0,true)
+// fadeout.rs:13).  `elapsed` is a Duration in whole nanoseconds that advances by NANOS_PER_SEC / rate
+// (integer division) once per frame, counted by `sample_idx` which only runs while the ramp does;
+// duration_to_float = Duration::as_secs_f32 = secs as f32 + nanos as f32 / 1e9 (math.rs:118-122).
+struct LinearGainRamp : Source {
+    Source *input;
+    uint64_t elapsed_ns = 0, total_ns, sample_idx = 0;
+    float start_gain, end_gain;
+    bool clamp_end;
+    LinearGainRamp(Source *in, uint64_t ns, float a, float b, bool c) : input(in), total_ns(ns), start_gain(a), end_gain(b), clamp_end(c) {}
+    ~LinearGainRamp() override { delete input; }
+    static float secs_f32(uint64_t ns) { return (float)(ns / 1000000000ull) + (float)(uint32_t)(ns % 1000000000ull) / 1000000000.0f; }
+    bool next(float &out) override {
+        float factor;
+        if (elapsed_ns >= total_ns) {
+            factor = clamp_end ? end_gain : 1.0f;
+        } else {
+            sample_idx += 1;
+            const float p = secs_f32(elapsed_ns) / secs_f32(total_ns);
+            factor = start_gain * (1.0f - p) + end_gain * p;
+        }
+        if (sample_idx % input->channels() == 0) elapsed_ns += 1000000000ull / input->sample_rate();
+        float v;
+        if (!input->next(v)) return false;
+        out = v * factor;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
 // ----------------------------------------------------------- BltFilter ----
 // src/source/blt.rs:502-544 (to_applier), :558-560 (apply), :397-410/:431-451/
 // :472-492 (Mono/Stereo/Multi all reduce to per-channel state indexed by
@@ -658,6 +713,8 @@ void *orc_uniform(void *in, int ch, unsigned rate) {
     return new UniformSourceIterator((Source *)in, (uint16_t)ch, rate);
 }
 void *orc_amplify(void *in, float factor) { return new Amplify((Source *)in, factor); }
+void *orc_distortion(void *in, float gain, float threshold) { return new Distortion((Source *)in, gain, threshold); }
+void *orc_linear_gain_ramp(void *in, unsigned long long ns, float a, float b, int clamp_end) { return new LinearGainRamp((Source *)in, ns, a, b, clamp_end != 0); }
 void *orc_low_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, false, freq, q); }
 void *orc_high_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, true, freq, q); }
 void *orc_delay(void *in, unsigned long long ns) { return new Delay((Source *)in, ns); }

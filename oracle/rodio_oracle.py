@@ -39,6 +39,8 @@ def _load():
         "orc_channel_count_converter": (vp, [vp, C.c_int, C.c_int]),
         "orc_uniform": (vp, [vp, C.c_int, C.c_uint]),
         "orc_amplify": (vp, [vp, C.c_float]),
+        "orc_distortion": (vp, [vp, C.c_float, C.c_float]),
+        "orc_linear_gain_ramp": (vp, [vp, C.c_ulonglong, C.c_float, C.c_float, C.c_int]),
         "orc_low_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_high_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_delay": (vp, [vp, C.c_ulonglong]),
@@ -139,6 +141,18 @@ class Source:
     # -- rodio's builder methods (src/source/mod.rs:255-731) ------------------
     def amplify(self, factor):
         return Source(_lib.orc_amplify(self._take(), factor))
+
+    def distortion(self, gain, threshold):
+        return Source(_lib.orc_distortion(self._take(), gain, threshold))
+
+    def linear_gain_ramp(self, duration_ns, start_gain, end_gain, clamp_end):
+        return Source(_lib.orc_linear_gain_ramp(self._take(), duration_ns, start_gain, end_gain, int(clamp_end)))
+
+    def fade_in(self, duration_ns):  # fadein.rs:11-13
+        return self.linear_gain_ramp(duration_ns, 0.0, 1.0, False)
+
+    def fade_out(self, duration_ns):  # fadeout.rs:13
+        return self.linear_gain_ramp(duration_ns, 1.0, 0.0, True)
 
     def low_pass(self, freq, q=0.5):
         return Source(_lib.orc_low_pass(self._take(), freq, q))

@@ -46,6 +46,36 @@ struct I64ToF32 { typedef int64_t In; typedef float Out; static __device__ __for
 struct U64ToF32 { typedef uint64_t In; typedef float Out; static __device__ __forceinline__ Out cvt(In s) { return (float)(int64_t)(s - 0x8000000000000000ull) / 9223372036854775808.0f; } };
 struct F64ToF32 { typedef double In; typedef float Out; static __device__ __forceinline__ Out cvt(In s) { return (float)s; } };
 
+// Distortion: src/source/distortion.rs:66-72  (v = x*gain; v.clamp(-t, t); NaN stays NaN)
+__global__ __launch_bounds__(kBlock) void k_distortion(float *__restrict__ dst, const float *__restrict__ src, size_t n, float gain, float threshold) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float v = src[i] * gain;
+        v = v < -threshold ? -threshold : v;
+        v = v > threshold ? threshold : v;
+        dst[i] = v;
+    }
+}
+// LinearGainRamp (fade_in / fade_out): src/source/linear_ramp.rs:79-110.  The iterator's `elapsed` is a
+// pure function of the frame index while the ramp runs (f * (1e9 / rate) ns), so the op is stateless:
+// sample k0+i of the stream is in frame (k0+i)/channels.
+__device__ __forceinline__ float secs_f32(uint64_t ns) { return (float)(ns / 1000000000ull) + (float)(uint32_t)(ns % 1000000000ull) / 1000000000.0f; }
+__global__ __launch_bounds__(kBlock) void k_linear_gain_ramp(float *__restrict__ dst, const float *__restrict__ src, size_t n, uint64_t k0, uint32_t channels, uint64_t step_ns,
+                                                             uint64_t total_ns, float total_s, float start_gain, float end_gain, float after) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t frame = (k0 + i) / channels;
+        // elapsed >= total  <=>  frame >= ceil(total / step); guard the product against wrap-around
+        const bool done = step_ns != 0 && frame >= (total_ns + step_ns - 1) / step_ns;
+        float factor = after;
+        if (!done) {
+            const float p = secs_f32(frame * step_ns) / total_s;
+            factor = start_gain * (1.0f - p) + end_gain * p;
+        }
+        dst[i] = src[i] * factor;
+    }
+}
+
 template <typename Op>
 __global__ __launch_bounds__(kBlock) void k_convert(typename Op::Out *__restrict__ dst, const typename Op::In *__restrict__ src, size_t n) {
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -64,6 +94,28 @@ rh_status launch(typename Op::Out *dst, const typename Op::In *src, size_t n, rh
 }  // namespace
 
 extern "C" {
+rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, float threshold, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!(threshold >= 0.0f)) return RH_ERR_INVALID;  // f32::clamp panics when min > max or NaN
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_distortion, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, float start_gain,
+                              float end_gain, int32_t clamp_end, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || sample_rate == 0 || duration_ns == 0) return RH_ERR_INVALID;  // linear_ramp.rs:34 asserts a non-zero duration
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    const uint64_t step_ns = 1000000000ull / sample_rate;  // linear_ramp.rs:98-100 (0 above 1 GHz: the ramp never advances)
+    const float total_s = (float)(duration_ns / 1000000000ull) + (float)(uint32_t)(duration_ns % 1000000000ull) / 1000000000.0f;
+    hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, duration_ns, total_s, start_gain,
+                       end_gain, clamp_end ? end_gain : 1.0f);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
 rh_status rh_convert_f32_to_u8(uint8_t *dst, const float *src, size_t n, rh_stream s) { return launch<F32ToU8>(dst, src, n, s); }
 rh_status rh_convert_f32_to_i24(int32_t *dst, const float *src, size_t n, rh_stream s) { return launch<F32ToI24>(dst, src, n, s); }
 rh_status rh_convert_f32_to_u24(int32_t *dst, const float *src, size_t n, rh_stream s) { return launch<F32ToU24>(dst, src, n, s); }

@@ -101,6 +101,25 @@ class GpuSource:
         check(lib.rh_amplify(_ptr(out), _ptr(self.samples), len(self), factor, _stream()), "rh_amplify")
         return GpuSource(out, self._channels, self._sample_rate, self.span_len)
 
+    def distortion(self, gain: float, threshold: float) -> "GpuSource":
+        _ensure()
+        out = _dev_empty(len(self))
+        check(lib.rh_distortion(_ptr(out), _ptr(self.samples), len(self), gain, threshold, _stream()), "rh_distortion")
+        return GpuSource(out, self._channels, self._sample_rate, self.span_len)
+
+    def linear_gain_ramp(self, duration_ns: int, start_gain: float, end_gain: float, clamp_end: bool, sample_offset: int = 0) -> "GpuSource":
+        _ensure()
+        out = _dev_empty(len(self))
+        check(lib.rh_linear_gain_ramp(_ptr(out), _ptr(self.samples), len(self), sample_offset, self._channels, self._sample_rate,
+                                      duration_ns, start_gain, end_gain, int(clamp_end), _stream()), "rh_linear_gain_ramp")
+        return GpuSource(out, self._channels, self._sample_rate, self.span_len)
+
+    def fade_in(self, duration_ns: int) -> "GpuSource":  # fadein.rs:11-13
+        return self.linear_gain_ramp(duration_ns, 0.0, 1.0, False)
+
+    def fade_out(self, duration_ns: int) -> "GpuSource":  # fadeout.rs:13
+        return self.linear_gain_ramp(duration_ns, 1.0, 0.0, True)
+
     def _blt(self, kind: int, freq: int, q: float, mode: int) -> "GpuSource":
         _ensure()
         co = biquad_coeffs(kind, freq, q, self._sample_rate)

@@ -281,6 +281,36 @@ def test_sample_type_converter_egress(G, O):
         assert np.array_equal(G.SampleTypeConverter(x, "f32", dst), O.convert(f"f32_to_{dst}", x)), dst
 
 
+def test_distortion_bit_exact(G, O):
+    # src/source/distortion.rs:66-72
+    x = np.concatenate([rnd(31, 100003, 2.0), np.float32([0, -0.0, 0.5, -0.5, np.inf, -np.inf])])
+    for gain, thr in [(3.0, 0.5), (0.5, 2.0), (1.0, 0.0), (-4.0, 0.25)]:
+        ref = O.TestSource(x, 1, 48000).distortion(gain, thr).collect()
+        assert np.array_equal(G.TestSource(x, 1, 48000).distortion(gain, thr).collect(), ref)
+    with pytest.raises(G.RhError):
+        G.TestSource(x, 1, 48000).distortion(1.0, -1.0)
+
+
+def test_linear_gain_ramp_golden_and_bit_exact(G, O):
+    # the reference's own vectors (linear_ramp.rs:176-210) ...
+    ones = np.ones(10, np.float32)
+    assert G.TestSource(ones, 1, 1).linear_gain_ramp(4_000_000_000, 0.0, 1.0, True).collect().tolist() == [0.0, 0.25, 0.5, 0.75] + [1.0] * 6
+    assert G.TestSource(ones, 1, 1).linear_gain_ramp(4_000_000_000, 0.0, 0.5, True).collect().tolist() == [0.0, 0.125, 0.25, 0.375] + [0.5] * 6
+    # ... and the oracle on realistic streams: stereo 48 kHz (20 833 ns steps), 6 channels, fades
+    x = rnd(33, 2 * 60000, 0.8)
+    for ns, a, b, clamp in [(500_000_000, 0.0, 1.0, False), (500_000_000, 1.0, 0.0, True), (1_234_567_891, 0.3, 2.5, True), (10_000, 0.0, 1.0, False)]:
+        ref = O.TestSource(x, 2, 48000).linear_gain_ramp(ns, a, b, clamp).collect()
+        assert np.array_equal(G.TestSource(x, 2, 48000).linear_gain_ramp(ns, a, b, clamp).collect(), ref)
+    x6 = rnd(34, 6 * 9000)
+    assert np.array_equal(G.TestSource(x6, 6, 44100).fade_in(150_000_000).collect(), O.TestSource(x6, 6, 44100).fade_in(150_000_000).collect())
+    assert np.array_equal(G.TestSource(x6, 6, 44100).fade_out(150_000_000).collect(), O.TestSource(x6, 6, 44100).fade_out(150_000_000).collect())
+    # block streaming through sample_offset
+    ref = O.TestSource(x, 2, 48000).fade_in(700_000_000).collect()
+    a = G.TestSource(x[:50002], 2, 48000).linear_gain_ramp(700_000_000, 0.0, 1.0, False).collect()
+    b = G.TestSource(x[50002:], 2, 48000).linear_gain_ramp(700_000_000, 0.0, 1.0, False, sample_offset=50002).collect()
+    assert np.array_equal(np.concatenate([a, b]), ref)
+
+
 def test_amplify_bit_exact(G, O):
     x = rnd(2, 100001)
     for f in (1.2, 0.8, -0.3, 0.0):

@@ -293,3 +293,21 @@ def test_golden_music_excerpt_conversions(O):
     six = f32[: (len(f32) // 6) * 6]
     out = O.ChannelCountConverter(O.TestSource(six, 6, 44100), 6, 2).collect()
     assert np.array_equal(out, _golden("music_excerpt_6to2.npy"))
+
+
+# ------------------------------------------------ LinearGainRamp ----
+def test_linear_ramp_golden(O):
+    # src/source/linear_ramp.rs:176-192 and :194-210: 10 samples of 1.0, 1 channel, 1 Hz, 4 s ramp
+    ones = np.ones(10, np.float32)
+    out = O.TestSource(ones, 1, 1).linear_gain_ramp(4_000_000_000, 0.0, 1.0, True).collect()
+    assert out.tolist() == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    out = O.TestSource(ones, 1, 1).linear_gain_ramp(4_000_000_000, 0.0, 0.5, True).collect()
+    assert out.tolist() == [0.0, 0.125, 0.25, 0.375, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5]
+
+
+def test_linear_ramp_seek_values(O):
+    # src/source/linear_ramp.rs:213-222 (the part before the first seek): cycle [0, .4, .8], 10 s ramp
+    x = np.float32([0.0, 0.4, 0.8] * 7)[:20]
+    out = O.TestSource(x, 1, 1).linear_gain_ramp(10_000_000_000, 0.0, 1.0, True).collect()
+    assert np.allclose(out[:3], [0.0, 0.04, 0.16], atol=1e-6)
+    assert np.allclose(out[10:13], x[10:13], atol=1e-6)  # ramp finished: gain 1.0
