@@ -8,30 +8,32 @@
 //   UniformSourceIterator::next  src/source/uniform.rs:78-97        (span chunking)
 //   SampleRateConverter::next    src/conversions/sample_rate.rs:131-201, src/math.rs:23-26
 //
+// Two kernels share the decomposition:
+//   k_rlm_fast  equal-length batches (the benchmark): everything that couples lanes and tiles is done
+//               once on the SUM over the sources; tiles never wait for each other inside the source loop
+//   k_rlm_wave  ragged batches: per-source scan and per-(source, tile) carries, exchanged in groups of 8
+//
 // Work decomposition (wave64, no MFMA -- there is no contraction here):
 //   * one WAVE (= one 64-lane workgroup) owns a tile of L = 64*R consecutive OUTPUT frames for
 //     ALL sources; a lane owns a run of R consecutive frames.  The wave walks the sources in
 //     insertion order and keeps the mix accumulators (R stereo frames per lane) in registers,
-//     so the mixer sum costs no memory traffic and keeps the reference's source order.
-//     Single-wave workgroups need no barrier at all: ~9 fully decoupled waves per CU.
+//     so the mixer sum costs no memory traffic.  Single-wave workgroups need no barrier at all.
 //   * the input frames of (source, tile) are contiguous in HBM.  They are fetched with
-//     global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a ring of NS LDS stages,
-//     NS-1 sources ahead, and retired with a counted s_waitcnt vmcnt; the lerp taps are
-//     ds_read_b64.  HBM traffic = input once + mixed output once (+ ~1% carry granules).
+//     global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a ring of NS LDS stages and retired
+//     with a counted s_waitcnt vmcnt; the lerp taps are ds_read2_b64, all issued before the
+//     arithmetic.  HBM traffic = input once + mixed output once (+ one 128-byte line per chunk).
 //     The DMA is issued from inline asm so that hipcc neither drains it at the next load
 //     (cdna_hip_programming.md "Pipelining across barriers") nor counts it: every wait for it
 //     is placed by hand below.
 //   * the biquad is a linear recurrence along time.  Each lane runs it over its run from a zero
-//     state, the run-end states are combined with a wave64 Kogge-Stone scan (DPP, no LDS) over
-//     the 2x2 companion-matrix powers B^(R*2^k) (host-computed in f64), and tiles are chained
+//     state; the run-end states are combined with a wave64 Kogge-Stone scan (DPP, no LDS) over
+//     the 2x2 state-matrix powers B^(R*2^k) (host-computed in f64), and tiles are chained
 //     through HBM "granules" ({epoch,value} 8-byte words, one agent-scope relaxed store each;
 //     cdna_hip_programming.md G16 form R2).  A tile needs only the zero-state aggregates of its
 //     J predecessors, where J is the number of tiles after which ||B^(L*J)|| < 2^-40 (the filter
 //     is stable, so older history is below f32 resolution): no chained inclusive prefix, hence
-//     no serial dependency along the 2000+ tiles.  The correction g1[r]*S1 + g2[r]*S2
-//     (homogeneous response to the true start state S) is added D = NS sources later, which
-//     hides the hand-off latency behind the next sources' streaming; the granules themselves
-//     are fetched by LDS-DMA too, so they ride the same counted-vmcnt pipeline.
+//     no serial dependency along the tiles.  The homogeneous response g1[r]*S1 + g2[r]*S2 to the
+//     true start state S of a lane is added once, after the last source, from summed states.
 //   * tiles are numbered by an atomic ticket, so a tile only ever waits for tiles that already
 //     hold a wave slot: progress does not depend on dispatch order or residency.
 #include <cmath>
