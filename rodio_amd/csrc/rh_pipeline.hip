@@ -533,6 +533,10 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
 #ifdef RH_PHASE_PROFILE
     RH_PH(5)
     if (p.prof && lane == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        ph_t[6] = ((unsigned long long)xcc << 32) | hwid;
         ph_t[7] = ph_start;
         for (int i = 0; i < 8; ++i) p.prof[(uint64_t)tile * 8 + i] = ph_t[i];
     }
@@ -1117,11 +1121,15 @@ const Variant *find_variant(const Variant (&tab)[N], int R, int kv_needed, int N
     return best;
 }
 // Single-wave workgroups with `lds` dynamic bytes the hardware co-schedules on one CU.
+// LDS is handed out in 1 280-byte granules (160 KiB / 128), which the occupancy query does not round to:
+// measured with tools/prof_simd.py -- a 27 136-byte request fits 5 times per CU, not 6.
+constexpr uint32_t kLdsGranule = 1280, kLdsGranules = 128;
 int blocks_per_cu(const void *fn, size_t lds) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return 0;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess) return 0;
-    return n;
+    const int by_lds = lds ? (int)(kLdsGranules / ((lds + kLdsGranule - 1) / kLdsGranule)) : n;
+    return n < by_lds ? n : by_lds;
 }
 // Vectors (2 frames = 16 B) per lane a stage must hold for a tile of L output frames.
 int kv_needed(uint64_t L, uint32_t F, uint32_t T) {
@@ -1306,9 +1314,9 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     if (tiles > 0 && !p->cfg.no_balance) {
         const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
         if ((int)per_cu <= pl->resident_per_cu) {
-            uint32_t want = (uint32_t)((160u * 1024u) / per_cu) & ~511u;
+            uint32_t want = (uint32_t)(kLdsGranules / per_cu) * kLdsGranule;  // whole granules: exactly per_cu fit
             if (want > 64u * 1024u) want = 64u * 1024u;
-            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= 512;
+            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= kLdsGranule;
             if (want > pl->lds_bytes) p->launch_lds = want;
         }
     }
