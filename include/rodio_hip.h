@@ -254,7 +254,7 @@ rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *ds
                             uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream);
 /* Optional: time the candidate launch geometries of the equal-length kernel on the sources that are set
  * (a few runs each into dst, which is overwritten) and keep the fastest -- like a GEMM library's
- * find step.  Synchronises.  Ragged batches keep the model's choice.  Reports the geometry kept. */
+ * find step.  Synchronises.  Works on whichever kernel the current sources take.  Reports the geometry kept. */
 rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream,
                           uint32_t *frames_per_lane, uint32_t *ring_stages);
 /* After a synchronise: 0 if the last run completed, RH_ERR_TIMEOUT if a bounded wait expired. */

@@ -1110,6 +1110,7 @@ const Variant kFast[] = {
 // The general kernel (ragged batches) is heavier; it ships in two tile sizes.
 const Variant kWave[] = {
     RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
+    RH_WAVE(9, 5, 2), RH_WAVE(10, 5, 2), RH_WAVE(10, 6, 2), RH_WAVE(12, 6, 2), RH_WAVE(12, 7, 2),
 };
 #undef RH_FAST
 #undef RH_WAVE
@@ -1395,13 +1396,14 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
-    bool fast_in_tried = false;
+    bool fast_in_tried = false, wave_in_tried = false;
     for (Plan &c : p->tried) {
         fast_in_tried = fast_in_tried || c.d_tabs == p->fast.d_tabs;
+        wave_in_tried = wave_in_tried || c.d_tabs == p->wave.d_tabs;
         if (c.d_tabs) (void)hipFree(c.d_tabs);
     }
     if (p->fast.d_tabs && !fast_in_tried) (void)hipFree(p->fast.d_tabs);
-    if (p->wave.d_tabs) (void)hipFree(p->wave.d_tabs);
+    if (p->wave.d_tabs && !wave_in_tried) (void)hipFree(p->wave.d_tabs);
     if (p->d_srcs) (void)hipFree(p->d_srcs);
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
@@ -1494,9 +1496,11 @@ rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *ds
 rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream, uint32_t *frames_per_lane, uint32_t *ring_stages) {
     RH_REQUIRE_INIT();
     if (!p || !dst) return RH_ERR_INVALID;
-    if (p->plan == &p->fast && p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
+    if (p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
+        const bool general = p->plan == &p->wave;
+        Plan &slot = general ? p->wave : p->fast;
         rh::ResampleGeom g;
-        rh_status st = rh::make_resample_geom(p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
+        rh_status st = rh::make_resample_geom(general ? p->cfg.max_in_frames : p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
         if (st != RH_OK) return st;
         hipStream_t s = rh::as_stream(stream);
         hipEvent_t e0, e1;
@@ -1520,24 +1524,24 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
         };
         float best_ms = 0.f;
         st = time_current(best_ms);
-        Plan best = p->fast;
-        p->tried.reserve(64);
+        Plan best = slot;
+        p->tried.reserve(128);
         {  // every table the handle ever owned is freed through `tried`
             bool have = false;
-            for (const Plan &c : p->tried) have = have || c.d_tabs == p->fast.d_tabs;
-            if (!have) p->tried.push_back(p->fast);
+            for (const Plan &c : p->tried) have = have || c.d_tabs == slot.d_tabs;
+            if (!have) p->tried.push_back(slot);
         }
         for (int R = 2; R <= kMaxR && st == RH_OK; ++R) {
             for (int NS = 2; NS <= 3; ++NS) {
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
-                if (make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS) != RH_OK) continue;
+                if ((general ? make_plan(p, cand, kWave, true, g, (uint32_t)R, (uint32_t)NS) : make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK) continue;
                 p->tried.push_back(cand);
                 const uint64_t tiles = (p->out_frames + 64ull * R - 1) / (64ull * R);
                 const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
                 if ((int)per_cu > cand.resident_per_cu) continue;  // would run in passes: never the fastest
-                p->fast = cand;
-                if ((st = activate_plan(p, &p->fast)) != RH_OK) break;
+                slot = cand;
+                if ((st = activate_plan(p, &slot)) != RH_OK) break;
                 float ms = 0.f;
                 if ((st = time_current(ms)) != RH_OK) break;
                 if (ms < best_ms) {
@@ -1546,11 +1550,11 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
                 }
             }
         }
-        p->fast = best;
+        slot = best;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         if (st != RH_OK) return st;
-        st = activate_plan(p, &p->fast);
+        st = activate_plan(p, &slot);
         if (st != RH_OK) return st;
     }
     if (frames_per_lane) *frames_per_lane = (uint32_t)p->plan->v->R;
