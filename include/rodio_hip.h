@@ -252,6 +252,10 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
 /* The same over the sources [first, first+count) only (a sub-mix; count = 1: one filtered stream). */
 rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst,
                             uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream);
+/* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels
+ * (equal-length sources only: RH_ERR_UNSUPPORTED otherwise).  One launch for all sources. */
+rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames,
+                           rh_stream stream);
 /* Optional: time the candidate launch geometries of the equal-length kernel on the sources that are set
  * (a few runs each into dst, which is overwritten) and keep the fastest -- like a GEMM library's
  * find step.  Synchronises.  Works on whichever kernel the current sources take.  Reports the geometry kept. */

@@ -113,6 +113,8 @@ struct Params {
     uint32_t ticket_base;  // value of *ticket when this launch starts (the counter is never reset)
     unsigned long long *prof;  // RH_PHASE_PROFILE builds: [tiles][8] cycles per phase
     uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
+    uint32_t batch_streams;    // k_rlm_fast: > 0 = no mixing: ticket k is tile k / batch_streams of source k % batch_streams
+    uint64_t out_stride;       // ... whose output row starts out_stride floats after the previous one
     Uniforms u;
 };
 
@@ -122,6 +124,12 @@ struct Cursor {
 };
 __device__ __forceinline__ Cursor cursor_at(uint64_t m, const Params &p) {
     Cursor c;
+    if (p.T == 1 && p.F == 1 && !p.chunk_out) {  // pass-through converter: no divisions
+        c.k = 0;
+        c.ml = c.il = m;
+        c.num = 0;
+        return c;
+    }
     c.k = p.chunk_out ? m / p.chunk_out : 0;
     c.ml = m - c.k * p.chunk_out;
     const uint64_t pp = c.ml * p.F;
@@ -275,7 +283,11 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
 
     const int lane = threadIdx.x;
-    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    const uint32_t ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    // batch mode (no mixer: every source keeps its own output row): tickets run tile-major over the
+    // sources, so the predecessor tiles of a stream always hold earlier tickets
+    const uint32_t stream = p.batch_streams ? ticket % p.batch_streams : 0u;
+    const uint32_t tile = p.batch_streams ? ticket / p.batch_streams : ticket;
     constexpr uint32_t L = 64u * R;
     const uint32_t m_tile0 = tile * L;
     const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
@@ -343,9 +355,9 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
     v2f E1 = {0.f, 0.f}, E2 = {0.f, 0.f};  // sum over the sources of the run-end states (w[-1], w[-2])
 
-    const uint32_t S = p.n_sources;
+    const uint32_t S = p.batch_streams ? 1u : p.n_sources;
     typedef __attribute__((address_space(4))) const uint64_t cu64;
-    cu64 *const desc = (cu64 *)(uintptr_t)p.srcs;  // 16-byte descriptors: the pointer is the first qword
+    cu64 *const desc = (cu64 *)(uintptr_t)(p.srcs + stream);  // 16-byte descriptors: the pointer is the first qword
     auto stage_source = [&](const void *data, uint32_t stage_off) {
 #pragma unroll
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
             if (lane < 4) {
                 const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
                 const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
-                __hip_atomic_store(p.gran + (uint64_t)tile * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.gran + ((uint64_t)stream * p.n_tiles + tile) * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         float Q[4];
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         float c[4] = {0.f, 0.f, 0.f, 0.f};
         if (Jc > 0) {
             const bool want = (uint32_t)lane < Jc;
-            const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
+            const unsigned long long *gp = p.gran + ((uint64_t)stream * p.n_tiles + (tile - 1 - (want ? lane : 0))) * 4;
             unsigned long long gv[4] = {0, 0, 0, 0};
             bool ok = false, dead = false;
             uint32_t spins = 0;
@@ -538,12 +550,12 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         ph_t[6] = ((unsigned long long)xcc << 32) | hwid;
         ph_t[7] = ph_start;
-        for (int i = 0; i < 8; ++i) p.prof[(uint64_t)tile * 8 + i] = ph_t[i];
+        for (int i = 0; i < 8; ++i) p.prof[(uint64_t)ticket * 8 + i] = ph_t[i];
     }
 #endif
 
     // ---- mixed output: R stereo frames per lane -----------------------------------------------------
-    float *o = p.out + (uint64_t)m0 * 2;
+    float *o = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m0 * 2;
     if (R % 2 == 0) {
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
@@ -1295,7 +1307,7 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     const uint64_t L = 64ull * pl->v->R;
     const uint64_t tiles = (M + L - 1) / L;
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    const size_t words = (pl->general ? (size_t)p->n_sources : 1) * tiles * 4;
+    const size_t words = (size_t)(p->n_sources ? p->n_sources : 1) * tiles * 4;  // per (source, tile): general kernel and batch mode
     if (p->filt && words > p->gran_words) {
         if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
         p->d_gran = nullptr;
@@ -1444,7 +1456,20 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     return rh_rlm_run_subset(p, 0, p->n_sources, dst, out_capacity_frames, out_frames, stream);
 }
 
+static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride);
+
 rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
+    return rlm_launch(p, first, count, dst, out_capacity_frames, out_frames, stream, 0, 0);
+}
+
+rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames, rh_stream stream) {
+    if (!p) return RH_ERR_INVALID;
+    if (p->plan != &p->fast) return RH_ERR_UNSUPPORTED;  // equal-length sources only
+    if (p->n_sources > 1 && (dst_stride_frames < p->out_frames || (dst_stride_frames * 2) % 4 != 0)) return RH_ERR_INVALID;
+    return rlm_launch(p, 0, p->n_sources, dst, dst_stride_frames, out_frames, stream, p->n_sources, dst_stride_frames * 2);
+}
+
+static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
     if (first > p->n_sources || count > p->n_sources - first) return RH_ERR_INVALID;
@@ -1482,14 +1507,19 @@ rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.ticket_base = p->ticket_base;
     k.prof = p->d_prof;
     k.eq_frames = p->eq_frames;
+    k.batch_streams = batch_streams;
+    k.out_stride = out_stride;
     k.u = pl.uni;
     void *args[] = {&k};
-    hipError_t e = hipLaunchKernel(pl.kernel, dim3(p->n_tiles), dim3(64), args, p->launch_lds, s);
+    const uint64_t grid = (uint64_t)p->n_tiles * (batch_streams ? batch_streams : 1);
+    if (grid > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
+    // batch mode fills the chip many times over: no residency shaping, the bare LDS request
+    hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? pl.lds_bytes : p->launch_lds, s);
     if (e != hipSuccess) {
         rh::set_hip_error(e, "k_rlm launch");
         return RH_ERR_HIP;
     }
-    p->ticket_base += p->n_tiles;  // every launch takes exactly n_tiles tickets
+    p->ticket_base += (uint32_t)grid;  // every launch takes exactly one ticket per workgroup
     return RH_OK;
 }
 
@@ -1618,9 +1648,9 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     return RH_OK;
 }
 
-// Time-parallel stand-alone biquad (rh_biquad mode 1): every stream is one launch of the equal-length
-// kernel over a single "source" with the pass-through converter (from == to: tap weight 0), i.e. the
-// per-lane zero-state runs + wave scan + tile look-back of DESIGN.md 4.2 without a mixer.  One handle is
+// Time-parallel stand-alone biquad (rh_biquad mode 1): the equal-length kernel in batch mode (no mixer:
+// every stream keeps its own output row) with the pass-through converter (from == to: tap weight 0), i.e.
+// the per-lane zero-state runs + wave scan + tile look-back of DESIGN.md 4.2, all streams in one launch.  One handle is
 // cached per (coefficients, block length); like every handle it serves one thread at a time.
 rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream) {
     RH_REQUIRE_INIT();
@@ -1644,6 +1674,10 @@ rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t
         for (int k = 0; k < 5; ++k) cfg.custom_coeffs[k] = cache_co[k] = coeffs5_host[k];
         cfg.max_sources = n_streams;
         cfg.max_in_frames = frames;
+        // one source per wave: the fixed cost per wave (tables, scan, look-back) wants the longest runs
+        // (measured, 64 x 1 Mi frames: R = 8 2.5 ms, 12 1.6 ms, 16 1.2 ms, 20 0.93 ms)
+        if (frames >= 64u * kMaxR * 4u) cfg.frames_per_lane = kMaxR;
+        if (const char *e = getenv("RH_BIQUAD_R")) cfg.frames_per_lane = (uint32_t)atoi(e);  // tuning aid
         rh_status st = rh_rlm_create(&cache, &cfg);
         if (st != RH_OK) return st;
         cache_frames = frames;
@@ -1653,7 +1687,7 @@ rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t
     std::vector<uint64_t> lens(n_streams, frames);
     for (uint32_t s = 0; s < n_streams; ++s) ptrs[s] = src + (uint64_t)s * frames * 2;
     rh_status st = rh_rlm_set_sources(cache, ptrs.data(), lens.data(), n_streams);
-    for (uint32_t s = 0; s < n_streams && st == RH_OK; ++s) st = rh_rlm_run_subset(cache, s, 1, dst + (uint64_t)s * frames * 2, frames, nullptr, stream);
+    if (st == RH_OK) st = rh_rlm_run_batch(cache, dst, frames, nullptr, stream);
     return st;
 }
 

@@ -497,6 +497,16 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
 
+    def run_batch(self):
+        """No mixing: returns [S, out_frames*channels], row s = UniformSourceIterator(src_s).low_pass(...)."""
+        torch = _t()
+        S = len(self._keep)
+        stride = (self.out_frames + 1) // 2 * 2
+        out = torch.empty((S, stride * self.channels), device="cuda", dtype=torch.float32)
+        m = C.c_uint64(0)
+        check(lib.rh_rlm_run_batch(self._h, _ptr(out), stride, C.byref(m), _stream()), "rh_rlm_run_batch")
+        return out[:, : m.value * self.channels]
+
     def autotune(self, out=None):
         """Time the candidate geometries on the current sources and keep the fastest (synchronises)."""
         if out is None:

@@ -642,6 +642,28 @@ def test_fused_more_tiles_than_resident_waves(G, O, general):
     assert err <= TOL and err <= 2e-5 * peak + 1e-7
 
 
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300), (None, 0)])
+def test_fused_batch_mode_per_source_rows(G, O, filt, freq):
+    # rh_rlm_run_batch: the same kernel without the mixer -- row s = UniformSourceIterator(src_s).low_pass(f)
+    import torch
+
+    S, n = 7, 40011
+    xs = [rnd(1300 + s, 2 * n, 0.5) for s in range(S)]
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=S, max_in_frames=n, frames_per_lane=8)
+    p.set_sources([torch.from_numpy(x).cuda() for x in xs])
+    rows = p.run_batch().cpu().numpy()
+    p.check_status()
+    for s in range(S):
+        ref = _oracle_pipeline(O, [xs[s]], 44100, 48000, None, filt, freq)
+        assert rows.shape[1] == len(ref)
+        if filt is None:
+            assert np.array_equal(rows[s], ref)
+        else:
+            truth = _truth_pipeline(O, [xs[s]], 44100, 48000, None, filt, freq)
+            _check_filtered(f"batch row {s} {filt}", rows[s], ref, truth)
+    p.close()
+
+
 def test_fused_matches_unfused_gpu_ops(G, O):
     # fused kernel vs the standalone ops (resample -> sequential biquad -> ordered mix), 64 sources
     S, n = 64, 50000
