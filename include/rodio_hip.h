@@ -252,6 +252,19 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
 /* The same over the sources [first, first+count) only (a sub-mix; count = 1: one filtered stream). */
 rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst,
                             uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream);
+/* Block streaming of the fused path: the same sources arrive block by block (what a `GpuMixer` shim does
+ * with its upstream iterators).  begin() starts a stream; every block() call passes, per source, a device
+ * pointer to `avail_frames` input frames that start where the previous call's *consumed_frames left off
+ * (the caller keeps the unconsumed frames in front of the new ones), and receives *out_frames mixed frames
+ * in dst.  flush != 0 ends the stream (rodio's None): the remaining frames and the verbatim last frame are
+ * emitted.  Across blocks the handle carries the converter's position and the summed filter state; the
+ * concatenated output equals one rh_rlm_run over the whole stream to f32 rounding (<= 1e-6 in the tests).
+ * Continuous sources only (span_len == 0); one set of sources per stream. */
+rh_status rh_rlm_stream_begin(rh_rlm *p);
+rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources,
+                              uint64_t avail_frames, int32_t flush, float *dst,
+                              uint64_t out_capacity_frames, uint64_t *out_frames,
+                              uint64_t *consumed_frames, rh_stream stream);
 /* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels
  * (equal-length sources only: RH_ERR_UNSUPPORTED otherwise).  One launch for all sources. */
 rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames,

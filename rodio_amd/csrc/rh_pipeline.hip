@@ -115,6 +115,11 @@ struct Params {
     uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
     uint32_t batch_streams;    // k_rlm_fast: > 0 = no mixing: ticket k is tile k / batch_streams of source k % batch_streams
     uint64_t out_stride;       // ... whose output row starts out_stride floats after the previous one
+    // k_rlm_fast, block streaming (st_mode: 0 off, 1 block of a running stream, 2 its last block):
+    uint32_t st_mode, st_active;  // st_active: output frames this block emits (a multiple of R in mode 1)
+    uint64_t st_m0, st_g0;        // global index of the block's first output frame / of input frame 0 of the buffers
+    const float *st_win;          // summed filter state (scan basis) at output frame st_m0
+    float *st_wout;               // ... at st_m0 + st_active, written by the lane that would come next
     Uniforms u;
 };
 
@@ -291,17 +296,24 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     constexpr uint32_t L = 64u * R;
     const uint32_t m_tile0 = tile * L;
     const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
-    const bool first = (m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
+    const uint64_t mg0 = p.st_mode ? p.st_m0 : 0;  // block streaming: this launch starts at global output frame st_m0
+    const bool first = (mg0 + m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
     const uint32_t Mout = (uint32_t)p.out_frames;
     const uint32_t Ns = p.eq_frames;  // every source has Ns frames (and Mout output frames)
+    const uint64_t g0 = p.st_mode ? p.st_g0 : 0;  // ... and the buffers start at global input frame st_g0
+    // mode 1: lanes at or past st_active belong to the next block (their input has not arrived yet)
+    const bool lane_on = p.st_mode != 1 || m0 < p.st_active;
+    const bool state_tile = p.st_mode == 1 && tile == p.st_active / L;  // holds the lane whose start state is the block's end state
 
     uint32_t i_base, nvec;
     {
         uint64_t ib, ie;
         uint32_t nn;
-        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        cursor_resolve(cursor_at(mg0 + m_tile0 >= 2 ? mg0 + m_tile0 - 2 : 0, p), p, ib, nn);
+        ib = ib > g0 ? ib - g0 : 0;  // index inside the buffers
         ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
-        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        cursor_resolve(cursor_at(mg0 + m_tile0 + L - 1, p), p, ie, nn);
+        ie = ie > g0 ? ie - g0 : 0;
         ie += 1;
         uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
         if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
@@ -326,14 +338,14 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     {
         const uint32_t dthr = Ns - 1 - i_base;
         const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
-        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+        Cursor c = cursor_at(first ? 0 : mg0 + m0 - 2, p);
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
             const bool dummy = first && rr < 2;
             uint64_t i;
             uint32_t num;
             cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * 8u);
             if (edge && offA[rr] >= thr) num = 0;  // verbatim last frame (and frames past it, never stored)
             if (edge && offA[rr] > thr) offA[rr] = thr;
             wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
 #pragma unroll
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
     };
-    const bool live = Mout > m_tile0 && Ns > 0;  // always true for a launched tile; keeps Ns-1 honest
+    const bool live = Mout > m_tile0 && Ns > 0;  // false only for the state tile of a block that ends on a tile boundary
     // The ring: NS stages, and -- because a source's taps are pulled into registers in one go -- NS
     // sources in flight: the stage of source s is re-targeted by the DMA of source s+NS as soon as the
     // taps of s have returned, BEFORE the arithmetic of s.
@@ -442,7 +454,8 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     }
     wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
 
-    if (FILT && live) {
+    if (FILT && (live || state_tile)) {
+        if (!lane_on) E1 = E2 = v2f{0.f, 0.f};
         const Tables *__restrict__ tb = p.tabs;
         float lM[4], b15[4], b31[4], kM[4];
 #pragma unroll
@@ -533,9 +546,21 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
                 c[q] = readlane_f(c[q], 15) + readlane_f(c[q], 31);
             }
         }
+        if (p.st_mode && tile < p.J) {  // the stream's state at the block start still reaches this tile: + B^(L*tile) * W_in
+            const float *M = tb->lookM[tile];
+            const float w0 = p.st_win[0], w1 = p.st_win[1], w2 = p.st_win[2], w3 = p.st_win[3];
+            mat_acc(M, w0, w1, c[0], c[1]);
+            mat_acc(M, w2, w3, c[2], c[3]);
+        }
         // the merged homogeneous response: start state = Q + B^(R*lane) * carry
         mat_acc(lM, c[0], c[1], Q[0], Q[1]);
         mat_acc(lM, c[2], c[3], Q[2], Q[3]);
+        if (state_tile && (uint32_t)lane == (p.st_active % L) / R) {  // the first lane of the next block: its start state is the block's end state
+            p.st_wout[0] = Q[0];
+            p.st_wout[1] = Q[1];
+            p.st_wout[2] = Q[2];
+            p.st_wout[3] = Q[3];
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             acc[r].x = fma_(p.u.g[r][0], Q[0], fma_(p.u.g[r][1], Q[1], acc[r].x));
@@ -1185,6 +1210,12 @@ struct rh_rlm {
     uint64_t out_frames = 0;
     uint32_t epoch = 0;
     uint32_t ticket_base = 0;
+    // block streaming (rh_rlm_stream_*)
+    bool st_on = false, st_done = false;
+    uint64_t st_g0 = 0, st_m = 0;
+    uint32_t st_nsrc = 0;
+    float *d_w[2] = {nullptr, nullptr};
+    int st_cur = 0;
 };
 
 namespace {
@@ -1307,7 +1338,7 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     const uint64_t L = 64ull * pl->v->R;
     const uint64_t tiles = (M + L - 1) / L;
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    const size_t words = (size_t)(p->n_sources ? p->n_sources : 1) * tiles * 4;  // per (source, tile): general kernel and batch mode
+    const size_t words = (size_t)(p->n_sources ? p->n_sources : 1) * (tiles + 1) * 4;  // per (source, tile): general kernel and batch mode; +1: streaming's end-state tile
     if (p->filt && words > p->gran_words) {
         if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
         p->d_gran = nullptr;
@@ -1420,6 +1451,8 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_prof) (void)hipFree(p->d_prof);
+    for (int k = 0; k < 2; ++k)
+        if (p->d_w[k]) (void)hipFree(p->d_w[k]);
     delete p;
     return RH_OK;
 }
@@ -1456,7 +1489,14 @@ rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64
     return rh_rlm_run_subset(p, 0, p->n_sources, dst, out_capacity_frames, out_frames, stream);
 }
 
-static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride);
+struct StreamArgs {
+    uint32_t mode = 0, active = 0;
+    uint64_t m0 = 0, g0 = 0;
+    const float *win = nullptr;
+    float *wout = nullptr;
+};
+static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
+                            const StreamArgs &sa = StreamArgs());
 
 rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
     return rlm_launch(p, first, count, dst, out_capacity_frames, out_frames, stream, 0, 0);
@@ -1469,7 +1509,8 @@ rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, ui
     return rlm_launch(p, 0, p->n_sources, dst, dst_stride_frames, out_frames, stream, p->n_sources, dst_stride_frames * 2);
 }
 
-static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride) {
+static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
+                            const StreamArgs &sa) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
     if (first > p->n_sources || count > p->n_sources - first) return RH_ERR_INVALID;
@@ -1509,6 +1550,12 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.eq_frames = p->eq_frames;
     k.batch_streams = batch_streams;
     k.out_stride = out_stride;
+    k.st_mode = sa.mode;
+    k.st_active = sa.active;
+    k.st_m0 = sa.m0;
+    k.st_g0 = sa.g0;
+    k.st_win = sa.win;
+    k.st_wout = sa.wout;
     k.u = pl.uni;
     void *args[] = {&k};
     const uint64_t grid = (uint64_t)p->n_tiles * (batch_streams ? batch_streams : 1);
@@ -1589,6 +1636,96 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
     }
     if (frames_per_lane) *frames_per_lane = (uint32_t)p->plan->v->R;
     if (ring_stages) *ring_stages = (uint32_t)p->plan->v->NS;
+    return RH_OK;
+}
+
+// ---- block streaming of the fused path (equal-length blocks, the same sources in every block) -------
+// What crosses a block boundary: the converter's position (st_g0: global index of frame 0 of the caller's
+// buffers; st_m: output frames emitted) and the SUM over the sources of the filter state at st_m (4 floats,
+// scan basis) -- the merged-state kernel never needs a per-source state.  A block emits whole lane runs only
+// (a multiple of R output frames), so that the state at its end is a lane's start state; the frames that are
+// left over stay with the caller: *consumed tells how many of the frames it passed are done with.
+rh_status rh_rlm_stream_begin(rh_rlm *p) {
+    RH_REQUIRE_INIT();
+    if (!p) return RH_ERR_INVALID;
+    if (p->cfg.span_len != 0) return RH_ERR_UNSUPPORTED;  // spans are converted one by one (uniform.rs:56-67): use rh_rlm_run per span
+    for (int k = 0; k < 2; ++k) {
+        if (!p->d_w[k]) RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_w[k]), 4 * sizeof(float)));
+        RH_HIP_TRY(hipMemset(p->d_w[k], 0, 4 * sizeof(float)));
+    }
+    p->st_on = true;
+    p->st_done = false;
+    p->st_g0 = p->st_m = 0;
+    p->st_nsrc = 0;
+    p->st_cur = 0;
+    return RH_OK;
+}
+
+rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
+                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
+    if (n_sources == 0 || n_sources > p->cfg.max_sources || avail_frames > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
+    if (p->st_nsrc && p->st_nsrc != n_sources) return RH_ERR_INVALID;  // the summed state belongs to one set of sources
+    *out_frames = 0;
+    *consumed_frames = 0;
+    const uint64_t F = p->F, T = p->T, R = p->fast.v->R, L = 64 * R;
+    const uint64_t N = p->st_g0 + avail_frames;  // input frames of the stream that exist so far
+    uint64_t m_end = 0;                           // output frames computable from them
+    if (N > 0) {
+        const unsigned __int128 num = (unsigned __int128)(N - 1) * T;
+        const uint64_t c1 = (uint64_t)((num + F - 1) / F);  // every m with floor(m*F/T) <= N-2
+        m_end = c1;
+        if (flush && (unsigned __int128)c1 * F < (unsigned __int128)N * T) m_end = c1 + 1;  // + the verbatim last frame
+    }
+    uint64_t out = m_end > p->st_m ? m_end - p->st_m : 0;
+    if (!flush) out = out / R * R;
+    if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
+    if (out > out_capacity_frames) return RH_ERR_CAPACITY;
+    if (out > 0 || flush) {
+        if (out > 0) {
+            if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
+            std::vector<SrcDesc> h(n_sources);
+            for (uint32_t s = 0; s < n_sources; ++s) {
+                if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
+                h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out};
+            }
+            RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, rh::as_stream(stream)));
+            RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(stream)));  // h is a stack object
+            p->equal = true;
+            p->eq_frames = (uint32_t)avail_frames;
+            p->n_sources = n_sources;
+            p->out_frames = out;
+            rh_status st = activate_plan(p, &p->fast);
+            if (st != RH_OK) return st;
+            const uint64_t tiles = flush ? (out + L - 1) / L : out / L + 1;  // + the tile that holds the end-state lane
+            p->n_tiles = (uint32_t)tiles;
+            if (p->filt && (size_t)tiles * 4 > p->gran_words) return RH_ERR_CAPACITY;  // activate_plan sized it for ceil(out/L)+... never smaller
+            StreamArgs sa;
+            sa.mode = flush ? 2u : 1u;
+            sa.active = (uint32_t)out;
+            sa.m0 = p->st_m;
+            sa.g0 = p->st_g0;
+            sa.win = p->d_w[p->st_cur];
+            sa.wout = p->d_w[p->st_cur ^ 1];
+            st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
+            if (st != RH_OK) return st;
+            if (!flush && p->filt) p->st_cur ^= 1;
+        }
+        p->st_m += out;
+        p->st_nsrc = n_sources;
+    }
+    if (flush) {
+        p->st_done = true;
+        *consumed_frames = avail_frames;
+    } else {
+        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T)
+        const uint64_t keep_from = p->st_m >= 2 ? (uint64_t)(((unsigned __int128)(p->st_m - 2) * F) / T) : 0;
+        const uint64_t cons = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
+        *consumed_frames = cons < avail_frames ? cons : avail_frames;
+        p->st_g0 += *consumed_frames;
+    }
+    *out_frames = out;
     return RH_OK;
 }
 

@@ -497,6 +497,29 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
 
+    # -- block streaming: feed(blocks) returns the mixed frames that became computable ------------------
+    def stream_begin(self):
+        check(lib.rh_rlm_stream_begin(self._h), "rh_rlm_stream_begin")
+        self._left = None
+
+    def stream_feed(self, blocks, flush=False):
+        """blocks: one device tensor of NEW interleaved samples per source (equal lengths).  The unconsumed
+        tail of the previous call is kept here, as a Rust shim would keep it in its own buffers."""
+        torch = _t()
+        ch = self.channels
+        bufs = list(blocks) if self._left is None else [torch.cat([l, b]) for l, b in zip(self._left, blocks)]
+        n = len(bufs)
+        avail = bufs[0].numel() // ch
+        ptrs = (C.c_void_p * n)(*[b.data_ptr() if b.numel() else 0 for b in bufs])
+        cap = int(avail * (self.cfg.to_rate / self.cfg.from_rate + 1)) + 64
+        out = _dev_empty(max(cap * ch, 4))
+        m, c = C.c_uint64(0), C.c_uint64(0)
+        check(lib.rh_rlm_stream_block(self._h, ptrs, n, avail, int(flush), _ptr(out), cap, C.byref(m), C.byref(c), _stream()),
+              "rh_rlm_stream_block")
+        self._keep = bufs  # the launch reads them asynchronously
+        self._left = [b[c.value * ch:].clone() for b in bufs]
+        return out[: m.value * ch]
+
     def run_batch(self):
         """No mixing: returns [S, out_frames*channels], row s = UniformSourceIterator(src_s).low_pass(...)."""
         torch = _t()

@@ -664,6 +664,38 @@ def test_fused_batch_mode_per_source_rows(G, O, filt, freq):
     p.close()
 
 
+@pytest.mark.parametrize("filt,freq,R", [("low_pass", 200, 8), ("high_pass", 300, 4), ("low_pass", 20, 8), (None, 0, 9)])
+def test_fused_block_streaming_equals_one_pass(G, O, filt, freq, R):
+    # rh_rlm_stream_*: the same sources fed block by block (random block lengths, including tiny ones);
+    # the concatenation equals the one-pass mix: bit for bit without the filter, <= 1e-6 with it
+    import torch
+
+    S, n = 6, 50000
+    rng = np.random.default_rng(77 + R)
+    xs = [rnd(1400 + s, 2 * n, 1.0 / S) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, filt, freq)
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=S, max_in_frames=n, frames_per_lane=R)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    p.set_sources(xd)
+    one = p.run().cpu().numpy().copy()
+    for trial in range(3):
+        cuts = [0] + sorted(set(int(c) for c in rng.integers(1, n, size=[1, 6, 25][trial]))) + [n]
+        p.stream_begin()
+        outs = []
+        for k in range(len(cuts) - 1):
+            outs.append(p.stream_feed([x[2 * cuts[k]: 2 * cuts[k + 1]] for x in xd], flush=(k == len(cuts) - 2)))
+        p.check_status()
+        got = torch.cat(outs).cpu().numpy()
+        assert len(got) == len(ref), (trial, len(got), len(ref))
+        if filt is None:
+            assert np.array_equal(got, ref)
+        else:
+            d1, d2 = float(np.max(np.abs(got - one))), float(np.max(np.abs(got - ref)))
+            print(f"[stream {filt}{freq} R{R} blocks={len(cuts) - 1}] |stream-onepass|={d1:.2e} |stream-oracle|={d2:.2e}")
+            assert d1 <= 1e-6 and d2 <= TOL
+    p.close()
+
+
 def test_fused_matches_unfused_gpu_ops(G, O):
     # fused kernel vs the standalone ops (resample -> sequential biquad -> ordered mix), 64 sources
     S, n = 64, 50000
