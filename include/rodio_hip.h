@@ -107,6 +107,14 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
                               uint32_t sample_rate, uint64_t duration_ns, float start_gain, float end_gain,
                               int32_t clamp_end, rh_stream stream);
 
+/* ---- TakeDuration (+ its fade-out filter): src/source/take.rs:96-148.  src holds n samples of the stream that
+ * start at sample_offset; dst (capacity n + channels) receives *out_samples: the samples the duration
+ * still admits, then the zeros that complete a cut frame.  *ended = 1 when the duration expires in this
+ * block (rodio's None follows).  An upstream that ends first simply stops calling. */
+rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels,
+                           uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out,
+                           uint64_t *out_samples, int32_t *ended, rh_stream stream);
+
 /* ---- ChannelVolume / Spatial: src/source/channel_volume.rs:71-88, src/source/spatial.rs:48-69.
  * gains_host has out_ch entries (out_ch <= 16).  dst holds frames*out_ch samples. */
 rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_t in_ch,

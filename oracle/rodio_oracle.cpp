@@ -404,6 +404,52 @@ struct LinearGainRamp : Source {
     uint32_t sample_rate() const override { return input->sample_rate(); }
 };
 
+// -------------------------------------------------------- TakeDuration ----
+// src/source/take.rs:96-148: emits input samples while remaining >= duration_per_sample
+// (= 1e9 / (rate*channels) ns, integer), optional fade-out filter `sample * remaining_ms / total_ms`
+// (:33-38, as_millis() as f32) applied BEFORE the decrement, then pads the frame it cut with silence
+// (:107-115, mod.rs:853-862).  An input that ends first ends the stream without padding (:119).
+struct TakeDuration : Source {
+    Source *input;
+    uint64_t remaining_ns, requested_ns, dps_ns;
+    bool fade_out;
+    unsigned in_frame = 0, silence = 0;
+    TakeDuration(Source *in, uint64_t ns, bool fade) : input(in), remaining_ns(ns), requested_ns(ns), fade_out(fade) {
+        dps_ns = 1000000000ull / ((uint64_t)in->sample_rate() * in->channels());
+    }
+    ~TakeDuration() override { delete input; }
+    bool next(float &out) override {
+        for (;;) {
+            if (silence > 0) {
+                silence -= 1;
+                out = 0.0f;
+                return true;
+            }
+            if (remaining_ns < dps_ns) {
+                silence = in_frame > 0 ? input->channels() - in_frame : 0;
+                if (silence > 0) {
+                    in_frame = 0;
+                    continue;
+                }
+                return false;
+            }
+            float v;
+            if (!input->next(v)) return false;
+            in_frame = (in_frame + 1) % input->channels();
+            if (fade_out) {
+                const float remaining = (float)(remaining_ns / 1000000ull), total = (float)(requested_ns / 1000000ull);
+                v = v * remaining / total;
+            }
+            remaining_ns -= dps_ns;
+            out = v;
+            return true;
+        }
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
 // ----------------------------------------------------------- BltFilter ----
 // src/source/blt.rs:502-544 (to_applier), :558-560 (apply), :397-410/:431-451/
 // :472-492 (Mono/Stereo/Multi all reduce to per-channel state indexed by
@@ -713,6 +759,7 @@ void *orc_uniform(void *in, int ch, unsigned rate) {
     return new UniformSourceIterator((Source *)in, (uint16_t)ch, rate);
 }
 void *orc_amplify(void *in, float factor) { return new Amplify((Source *)in, factor); }
+void *orc_take_duration(void *in, unsigned long long ns, int fade_out) { return new TakeDuration((Source *)in, ns, fade_out != 0); }
 void *orc_distortion(void *in, float gain, float threshold) { return new Distortion((Source *)in, gain, threshold); }
 void *orc_linear_gain_ramp(void *in, unsigned long long ns, float a, float b, int clamp_end) { return new LinearGainRamp((Source *)in, ns, a, b, clamp_end != 0); }
 void *orc_low_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, false, freq, q); }

@@ -40,6 +40,7 @@ def _load():
         "orc_uniform": (vp, [vp, C.c_int, C.c_uint]),
         "orc_amplify": (vp, [vp, C.c_float]),
         "orc_distortion": (vp, [vp, C.c_float, C.c_float]),
+        "orc_take_duration": (vp, [vp, C.c_ulonglong, C.c_int]),
         "orc_linear_gain_ramp": (vp, [vp, C.c_ulonglong, C.c_float, C.c_float, C.c_int]),
         "orc_low_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_high_pass": (vp, [vp, C.c_uint, C.c_float]),
@@ -141,6 +142,9 @@ class Source:
     # -- rodio's builder methods (src/source/mod.rs:255-731) ------------------
     def amplify(self, factor):
         return Source(_lib.orc_amplify(self._take(), factor))
+
+    def take_duration(self, duration_ns, fade_out=False):  # take.rs; fade_out = set_filter_fadeout()
+        return Source(_lib.orc_take_duration(self._take(), duration_ns, int(fade_out)))
 
     def distortion(self, gain, threshold):
         return Source(_lib.orc_distortion(self._take(), gain, threshold))

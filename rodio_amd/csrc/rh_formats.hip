@@ -76,6 +76,23 @@ __global__ __launch_bounds__(kBlock) void k_linear_gain_ramp(float *__restrict__
     }
 }
 
+// TakeDuration: src/source/take.rs:96-148.  out[i] = x[i] (optionally * remaining_ms / total_ms, the
+// fade-out filter of :33-38) for the `take` samples the duration admits, then `pad` zeros that complete
+// the frame.  remaining at sample k of the stream = duration - k * (1e9 / (rate*channels)).
+__global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ dst, const float *__restrict__ src, uint64_t take, uint64_t pad, uint64_t k0, uint64_t dps_ns,
+                                                          uint64_t duration_ns, int fade) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const float total = (float)(duration_ns / 1000000ull);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < take + pad; i += stride) {
+        float v = 0.0f;
+        if (i < take) {
+            v = src[i];
+            if (fade) v = v * (float)((duration_ns - (k0 + i) * dps_ns) / 1000000ull) / total;
+        }
+        dst[i] = v;
+    }
+}
+
 template <typename Op>
 __global__ __launch_bounds__(kBlock) void k_convert(typename Op::Out *__restrict__ dst, const typename Op::In *__restrict__ src, size_t n) {
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -113,6 +130,25 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
     const float total_s = (float)(duration_ns / 1000000000ull) + (float)(uint32_t)(duration_ns % 1000000000ull) / 1000000000.0f;
     hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, duration_ns, total_s, start_gain,
                        end_gain, clamp_end ? end_gain : 1.0f);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out,
+                           uint64_t *out_samples, int32_t *ended, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || sample_rate == 0 || !out_samples) return RH_ERR_INVALID;
+    const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);  // take.rs:63-67
+    if (dps == 0) return RH_ERR_UNSUPPORTED;  // above 1 GHz*channel the reference never expires
+    const uint64_t K = duration_ns / dps;  // samples of the stream the duration admits
+    const uint64_t left = K > sample_offset ? K - sample_offset : 0;
+    const uint64_t take = n < left ? n : left;
+    const bool expires_here = left <= n;                       // the duration runs out inside this block (or exactly at its end)
+    const uint64_t pad = expires_here && K % channels ? channels - K % channels : 0;
+    *out_samples = take + pad;
+    if (ended) *ended = expires_here ? 1 : 0;
+    if (take + pad == 0) return RH_OK;
+    if (!dst || (take && !src)) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_for(take + pad)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, sample_offset, dps, duration_ns, fade_out ? 1 : 0);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -353,14 +353,6 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         }
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
-#ifdef RH_SPLIT_TAPS
-    int offB[R + 2];
-#pragma unroll
-    for (int rr = 0; rr < R + 2; ++rr) {
-        offB[rr] = offA[rr] + 8;
-        asm volatile("" : "+v"(offB[rr]));  // opaque: two ds_read_b64 instead of one ds_read2_b64
-    }
-#endif
 
     v2f acc[R];
 #pragma unroll
@@ -397,11 +389,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
 #pragma unroll
             for (int rr = 0; rr < R + 2; ++rr) {
                 ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
-#ifdef RH_SPLIT_TAPS
-                tb2[rr] = *(const lds_f2 *)(buf + offB[rr]);
-#else
                 tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
-#endif
             }
         }
         // every tap is in a register: the stage is free for source s+NS

@@ -101,6 +101,14 @@ class GpuSource:
         check(lib.rh_amplify(_ptr(out), _ptr(self.samples), len(self), factor, _stream()), "rh_amplify")
         return GpuSource(out, self._channels, self._sample_rate, self.span_len)
 
+    def take_duration(self, duration_ns: int, fade_out: bool = False) -> "GpuSource":
+        _ensure()
+        out = _dev_empty(len(self) + self._channels)
+        m, ended = C.c_uint64(0), C.c_int32(0)
+        check(lib.rh_take_duration(_ptr(out), _ptr(self.samples), len(self), 0, self._channels, self._sample_rate, duration_ns,
+                                   int(fade_out), C.byref(m), C.byref(ended), _stream()), "rh_take_duration")
+        return GpuSource(out[: m.value], self._channels, self._sample_rate, self.span_len)
+
     def distortion(self, gain: float, threshold: float) -> "GpuSource":
         _ensure()
         out = _dev_empty(len(self))

@@ -281,6 +281,22 @@ def test_sample_type_converter_egress(G, O):
         assert np.array_equal(G.SampleTypeConverter(x, "f32", dst), O.convert(f"f32_to_{dst}", x)), dst
 
 
+def test_take_duration_golden_and_bit_exact(G, O):
+    # the reference's vectors (take.rs:247-280) ...
+    nps = 1_000_000_000 // (44100 * 2)
+    assert G.TestSource(np.ones(10, np.float32), 2, 44100).take_duration(nps * 5).collect().tolist() == [1.0] * 5 + [0.0]
+    assert len(G.TestSource(np.ones(100, np.float32), 1, 48000).take_duration(int(np.float32(1e9) / np.float32(48000)) * 10).collect()) == 10
+    assert len(G.TestSource(np.ones(100, np.float32), 1, 48000).take_duration(0).collect()) == 0
+    # ... and the oracle: expiry mid-stream / mid-frame, input shorter than the duration, fade-out filter
+    x = rnd(35, 6 * 20000)
+    for ch, rate, ns, fade in [(2, 48000, 100_000_000, False), (2, 48000, 100_000_000, True), (6, 44100, 123_456_789, True),
+                               (3, 44100, 11_337 * 7, False), (2, 48000, 10_000_000_000, True), (1, 8000, 1_000_000, True)]:
+        xs = x[: (len(x) // ch) * ch]
+        ref = O.TestSource(xs, ch, rate).take_duration(ns, fade).collect()
+        got = G.TestSource(xs, ch, rate).take_duration(ns, fade).collect()
+        assert np.array_equal(got, ref), (ch, rate, ns, fade, len(got), len(ref))
+
+
 def test_distortion_bit_exact(G, O):
     # src/source/distortion.rs:66-72
     x = np.concatenate([rnd(31, 100003, 2.0), np.float32([0, -0.0, 0.5, -0.5, np.inf, -np.inf])])

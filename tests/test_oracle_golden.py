@@ -311,3 +311,17 @@ def test_linear_ramp_seek_values(O):
     out = O.TestSource(x, 1, 1).linear_gain_ramp(10_000_000_000, 0.0, 1.0, True).collect()
     assert np.allclose(out[:3], [0.0, 0.04, 0.16], atol=1e-6)
     assert np.allclose(out[10:13], x[10:13], atol=1e-6)  # ramp finished: gain 1.0
+
+
+# ------------------------------------------------------ TakeDuration ----
+def test_take_duration_golden(O):
+    # src/source/take.rs:247-261: a duration of exactly 10 sample periods (mono, 48 kHz) yields 10 samples
+    nps = int(np.float32(1_000_000_000) / np.float32(48000))
+    x = np.ones(100, np.float32)
+    assert len(O.TestSource(x, 1, 48000).take_duration(nps * 10).collect()) == 10
+    # :263-280: stereo 44.1 kHz, 5 sample periods -> the cut frame is completed with silence
+    nps = 1_000_000_000 // (44100 * 2)
+    out = O.TestSource(np.ones(10, np.float32), 2, 44100).take_duration(nps * 5).collect()
+    assert out.tolist() == [1.0, 1.0, 1.0, 1.0, 1.0, 0.0]
+    # :241-245: zero duration -> nothing
+    assert len(O.TestSource(x, 1, 48000).take_duration(0).collect()) == 0

@@ -118,6 +118,12 @@ int main(int argc, char **argv) {
     CHECK(hipMemset(d_in, 0, S * src_bytes + (1 << 20)));
     CHECK(hipMalloc(&d_out, 64 << 20));
     const uint64_t stride = src_bytes / 4;
+    if (cal && argv[1][0] == 'f') {  // ceiling study: 4 waves per CU, 8 KiB stages, plain VALU work per 8 bytes
+        for (int flops : {0, 2, 4, 6, 8, 10, 12}) run<8, 2, 1>(d_in, d_out, S, 1024, stride, flops);
+        for (int flops : {0, 4, 8, 10}) run<8, 3, 1>(d_in, d_out, S, 1024, stride, flops);
+        for (int flops : {0, 4, 8, 10}) run<4, 2, 1>(d_in, d_out, S, 2048, stride, flops);
+        return 0;
+    }
     if (cal && argv[1][0] == 'm') {  // mimic: R=10 tiles of config 2 (640 out frames -> 588 in frames = 294 vectors; 298 fetched)
         const uint32_t vstride = 294, nvec = 298, tiles = 1784;
         CHECK(hipFuncSetAttribute((const void *)k_mimic<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
