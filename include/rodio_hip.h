@@ -91,6 +91,22 @@ rh_status rh_convert_i64_to_f32(float *dst, const int64_t *src, size_t n, rh_str
 rh_status rh_convert_u64_to_f32(float *dst, const uint64_t *src, size_t n, rh_stream stream);
 rh_status rh_convert_f64_to_f32(float *dst, const double *src, size_t n, rh_stream stream);
 
+/* ---- WAV / PCM either side of the path (src/decoder/wav.rs:94-172 ingest, src/wav_output.rs:62-96 egress).
+ * probe (host, no GPU): walks the RIFF chunks of a file image.  decode: `data` is a DEVICE copy of the data
+ * chunk (8-bit unsigned, 16/24/32-bit signed LE or 32-bit float); dst receives *out_samples f32 samples --
+ * n_samples plus the silence that completes a cut frame (wav.rs:161-169).  header (host): the 44-byte
+ * 32-bit-float header wav_to_writer produces, for the whole frames of n_samples (wav_output.rs:98-140);
+ * the payload is the f32 block itself.  Returns the bytes written (0 = does not fit). */
+typedef struct rh_wav_info {
+    uint32_t channels, sample_rate, bits_per_sample;
+    int32_t is_float;
+    uint64_t data_offset, data_bytes, samples;
+} rh_wav_info;
+rh_status rh_wav_probe_host(const uint8_t *bytes, size_t size, rh_wav_info *info);
+rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uint32_t channels,
+                        uint32_t bits_per_sample, int32_t is_float, uint64_t *out_samples, rh_stream stream);
+size_t rh_wav_header_f32_host(uint8_t *out, size_t cap, uint32_t channels, uint32_t sample_rate, uint64_t n_samples);
+
 /* ---- ChannelCountConverter: src/conversions/channels.rs:57-85.  Bit-exact.
  * dst holds frames*to_ch samples. */
 rh_status rh_channels_convert(float *dst, const float *src, size_t frames, uint32_t from_ch,

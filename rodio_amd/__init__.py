@@ -23,12 +23,15 @@ from .source import (  # noqa: F401
     Spatial,
     TestSource,
     UniformSourceIterator,
+    WavDecoder,
     biquad_batch,
     biquad_coeffs,
     delay_samples,
     init,
     reverb_spatial_batch,
     spatial_gains,
+    wav_probe,
+    wav_to_bytes,
     spatial_gains_batch,
 )
 

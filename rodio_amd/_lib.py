@@ -34,6 +34,11 @@ class AgcParams(C.Structure):
                 ("absolute_max_gain", C.c_float), ("floor", C.c_float)]
 
 
+class WavInfo(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bits_per_sample", C.c_uint32), ("is_float", C.c_int32),
+                ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64), ("samples", C.c_uint64)]
+
+
 class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
@@ -116,6 +121,9 @@ SIGNATURES = {
     "rh_echo_destroy": (i32, [vp]),
     "rh_echo_process": (i32, [vp, vp, vp, u64, vp]),
     "rh_echo_flush": (i32, [vp, vp, vp]),
+    "rh_wav_probe_host": (i32, [vp, sz, C.POINTER(WavInfo)]),
+    "rh_wav_decode": (i32, [vp, vp, u64, u32, u32, i32, C.POINTER(u64), vp]),
+    "rh_wav_header_f32_host": (sz, [vp, sz, u32, u32, u64]),
     "rh_take_duration": (i32, [vp, vp, u64, u64, u32, u32, u64, i32, C.POINTER(u64), C.POINTER(i32), vp]),
     "rh_distortion": (i32, [vp, vp, sz, f32, f32, vp]),
     "rh_linear_gain_ramp": (i32, [vp, vp, sz, u64, u32, u32, u64, f32, f32, i32, vp]),

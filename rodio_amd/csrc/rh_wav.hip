@@ -1,0 +1,134 @@
+// rh_wav.hip -- the on-disk PCM format either side of the path:
+//   ingest  src/decoder/wav.rs:94-172 (hound: 8-bit unsigned, 16/24/32-bit signed LE, 32-bit float ->
+//           `to_sample::<f32>()`); a trailing partial frame is completed with silence (:161-169)
+//   egress  src/wav_output.rs:62-96 (`wav_to_writer`: 32-bit float WAVE, whole frames only, :98-140)
+// The RIFF chunk walk and the header are host work (rh_wav_probe_host / rh_wav_header_f32_host: plain C,
+// no GPU); the sample conversion runs on the device straight from the file bytes, so a file -> file job
+// never does the int -> float pass on the CPU.  hound is an un-vendored dependency (Cargo.lock): its
+// byte-level behaviour is restated from the WAVE specification -- parity unpinned.
+#include <cstring>
+
+#include "rh_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// 24-bit packed little-endian samples: byte address 3*i is unaligned, so every lane reads 3 bytes.
+__global__ __launch_bounds__(kBlock) void k_pcm24_to_f32(float *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint8_t *b = src + 3 * i;
+        int32_t v = (int32_t)b[0] | ((int32_t)b[1] << 8) | ((int32_t)(int8_t)b[2] << 16);  // sign-extended I24 (wav.rs:126-131)
+        dst[i] = (float)v / 8388608.0f;
+    }
+}
+// zero-fill [from, to): the silence that completes a cut frame
+__global__ __launch_bounds__(kBlock) void k_fill_zero(float *__restrict__ dst, size_t from, size_t to) {
+    const size_t i = from + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < to) dst[i] = 0.0f;
+}
+
+uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+void wr32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+void wr16(uint8_t *p, uint16_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+
+}  // namespace
+
+extern "C" {
+
+rh_status rh_wav_probe_host(const uint8_t *bytes, size_t size, rh_wav_info *info) {
+    if (!bytes || !info || size < 12) return RH_ERR_INVALID;
+    if (std::memcmp(bytes, "RIFF", 4) != 0 || std::memcmp(bytes + 8, "WAVE", 4) != 0) return RH_ERR_INVALID;
+    std::memset(info, 0, sizeof(*info));
+    bool have_fmt = false;
+    size_t pos = 12;
+    while (pos + 8 <= size) {
+        const uint32_t len = rd32(bytes + pos + 4);
+        const uint8_t *body = bytes + pos + 8;
+        if (std::memcmp(bytes + pos, "fmt ", 4) == 0) {
+            if (len < 16 || pos + 8 + 16 > size) return RH_ERR_INVALID;
+            uint16_t tag = rd16(body);
+            info->channels = rd16(body + 2);
+            info->sample_rate = rd32(body + 4);
+            info->bits_per_sample = rd16(body + 14);
+            if (tag == 0xFFFE && len >= 40 && pos + 8 + 40 <= size) tag = rd16(body + 24);  // WAVE_FORMAT_EXTENSIBLE: sub-format GUID
+            info->is_float = tag == 3;
+            if (tag != 1 && tag != 3) return RH_ERR_UNSUPPORTED;
+            have_fmt = true;
+        } else if (std::memcmp(bytes + pos, "data", 4) == 0) {
+            if (!have_fmt) return RH_ERR_INVALID;
+            info->data_offset = pos + 8;
+            uint64_t n = len;
+            if (pos + 8 + n > size) n = size - (pos + 8);  // truncated file: what is there
+            info->data_bytes = n;
+            const uint32_t bps = (info->bits_per_sample + 7u) / 8u;
+            if (bps == 0 || info->channels == 0 || info->sample_rate == 0) return RH_ERR_INVALID;
+            info->samples = n / bps;
+            return RH_OK;
+        }
+        pos += 8 + (size_t)len + (len & 1u);
+    }
+    return RH_ERR_INVALID;
+}
+
+rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uint32_t channels, uint32_t bits_per_sample, int32_t is_float, uint64_t *out_samples, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || !out_samples) return RH_ERR_INVALID;
+    const uint64_t rem = n_samples % channels;
+    const uint64_t total = n_samples + (rem ? channels - rem : 0);  // wav.rs:161-169
+    *out_samples = total;
+    if (total == 0) return RH_OK;
+    if (!dst || (n_samples && !data)) return RH_ERR_INVALID;
+    hipStream_t s = rh::as_stream(stream);
+    rh_status st = RH_OK;
+    if (is_float) {
+        if (bits_per_sample != 32) return RH_ERR_UNSUPPORTED;  // wav.rs:107-117
+        RH_HIP_TRY(hipMemcpyAsync(dst, data, n_samples * 4, hipMemcpyDeviceToDevice, s));
+    } else if (bits_per_sample == 8) {
+        st = rh_convert_u8_to_f32(dst, data, n_samples, stream);  // the file holds unsigned bytes; hound hands rodio i8 = b - 128
+    } else if (bits_per_sample == 16) {
+        if (reinterpret_cast<uintptr_t>(data) & 1u) return RH_ERR_INVALID;
+        st = rh_convert_i16_to_f32(dst, reinterpret_cast<const int16_t *>(data), n_samples, stream);
+    } else if (bits_per_sample == 24) {
+        if (n_samples) {
+            hipLaunchKernelGGL(k_pcm24_to_f32, dim3(rh::grid_for(n_samples)), dim3(kBlock), 0, s, dst, data, (size_t)n_samples);
+            RH_CHECK_LAUNCH();
+        }
+    } else if (bits_per_sample == 32) {
+        if (reinterpret_cast<uintptr_t>(data) & 3u) return RH_ERR_INVALID;
+        st = rh_convert_i32_to_f32(dst, reinterpret_cast<const int32_t *>(data), n_samples, stream);
+    } else {
+        return RH_ERR_UNSUPPORTED;  // "unofficial" depths (wav.rs:137-151)
+    }
+    if (st != RH_OK) return st;
+    if (total > n_samples) {
+        hipLaunchKernelGGL(k_fill_zero, dim3(1), dim3(kBlock), 0, s, dst, (size_t)n_samples, (size_t)total);
+        RH_CHECK_LAUNCH();
+    }
+    return RH_OK;
+}
+
+size_t rh_wav_header_f32_host(uint8_t *out, size_t cap, uint32_t channels, uint32_t sample_rate, uint64_t n_samples) {
+    // canonical 44-byte header, format tag 3 (IEEE float), 32 bits -- what wav_output.rs:66-71 asks hound for
+    if (!out || cap < 44 || channels == 0 || channels > 65535) return 0;
+    const uint64_t whole = n_samples - n_samples % channels;  // WholeFrames, wav_output.rs:98-140
+    const uint64_t bytes = whole * 4;
+    if (bytes > 0xffffffffull - 36) return 0;
+    std::memcpy(out, "RIFF", 4);
+    wr32(out + 4, (uint32_t)(36 + bytes));
+    std::memcpy(out + 8, "WAVEfmt ", 8);
+    wr32(out + 16, 16);
+    wr16(out + 20, 3);
+    wr16(out + 22, (uint16_t)channels);
+    wr32(out + 24, sample_rate);
+    wr32(out + 28, sample_rate * channels * 4);
+    wr16(out + 32, (uint16_t)(channels * 4));
+    wr16(out + 34, 32);
+    std::memcpy(out + 36, "data", 4);
+    wr32(out + 40, (uint32_t)bytes);
+    return 44;
+}
+
+}  // extern "C"

@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AgcParams, LimitParams, RlmConfig, RlmGeometry, check, lib
+from ._lib import AgcParams, LimitParams, RhError, RlmConfig, RlmGeometry, check, lib
 
 _torch = None
 _initialized = False
@@ -262,6 +262,40 @@ def SampleTypeConverter(samples, src: str, dst: str) -> np.ndarray:
     check(getattr(lib, fn)(_ptr(d_out), _ptr(d_in), a.size, _stream()), fn)
     torch.cuda.current_stream().synchronize()
     return d_out.cpu().numpy().view(dt).copy()
+
+
+# ---- WAV either side of the path -----------------------------------------------------------------
+def wav_probe(file_bytes: bytes):
+    """RIFF chunk walk on the host (no GPU needed): dict of the fmt fields + data chunk position."""
+    info = _lib.WavInfo()
+    buf = (C.c_uint8 * len(file_bytes)).from_buffer_copy(file_bytes)
+    check(lib.rh_wav_probe_host(buf, len(file_bytes), C.byref(info)), "rh_wav_probe_host")
+    return {n: getattr(info, n) for n, _ in _lib.WavInfo._fields_}
+
+
+def WavDecoder(file_bytes: bytes) -> "GpuSource":
+    """src/decoder/wav.rs: the data chunk goes to the device as bytes and is converted there."""
+    _ensure()
+    torch = _t()
+    w = wav_probe(file_bytes)
+    raw = np.frombuffer(file_bytes, dtype=np.uint8, count=w["data_bytes"], offset=w["data_offset"])
+    d_in = torch.from_numpy(raw.copy()).to("cuda") if raw.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+    out = _dev_empty(w["samples"] + w["channels"])
+    m = C.c_uint64(0)
+    check(lib.rh_wav_decode(_ptr(out), _ptr(d_in) if raw.size else None, w["samples"], w["channels"], w["bits_per_sample"],
+                            w["is_float"], C.byref(m), _stream()), "rh_wav_decode")
+    return GpuSource(out[: m.value], w["channels"], w["sample_rate"], None)
+
+
+def wav_to_bytes(source: "GpuSource") -> bytes:
+    """src/wav_output.rs:62-96: 32-bit float WAVE of the source's whole frames."""
+    n = len(source)
+    hdr = (C.c_uint8 * 44)()
+    k = lib.rh_wav_header_f32_host(hdr, 44, source.channels(), source.sample_rate(), n)
+    if k != 44:
+        raise RhError(1, "rh_wav_header_f32_host")
+    whole = n - n % source.channels()
+    return bytes(hdr) + source.samples[:whole].cpu().numpy().astype("<f4").tobytes()
 
 
 # ---- effects -------------------------------------------------------------------------------

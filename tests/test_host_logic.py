@@ -74,3 +74,56 @@ def test_delay_samples(rh, O):
     for _ in range(100):
         ns, rate, ch = int(rng.integers(0, 10**10)), int(rng.integers(1, 400000)), int(rng.integers(1, 9))
         assert rh.delay_samples(ns, rate, ch) == O.delay_samples(ns, rate, ch)
+
+
+# ------------------------------------------------------------------ WAV container (host side) ----
+def _wav_bytes(ch, rate, bits, payload, fmt_tag=1, extensible=False, junk=False):
+    import struct
+
+    bps = (bits + 7) // 8
+    if extensible:
+        sub = struct.pack("<H", fmt_tag) + bytes.fromhex("000000001000800000aa00389b71")
+        fmt = struct.pack("<HHIIHHHHI", 0xFFFE, ch, rate, rate * ch * bps, ch * bps, bits, 22, bits, 0) + sub
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, ch, rate, rate * ch * bps, ch * bps, bits)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if junk:
+        chunks += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\0"  # odd-sized chunk + pad byte
+    chunks += b"data" + struct.pack("<I", len(payload)) + payload
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def test_wav_probe_walks_chunks(rh):
+    import numpy as np
+
+    pay = np.arange(12, dtype="<i2").tobytes()
+    w = rh.wav_probe(_wav_bytes(2, 44100, 16, pay))
+    assert (w["channels"], w["sample_rate"], w["bits_per_sample"], w["is_float"], w["samples"], w["data_offset"]) == (2, 44100, 16, 0, 12, 44)
+    w = rh.wav_probe(_wav_bytes(6, 48000, 24, b"\0" * 36, extensible=True, junk=True))
+    assert (w["channels"], w["bits_per_sample"], w["samples"], w["is_float"]) == (6, 24, 12, 0)
+    w = rh.wav_probe(_wav_bytes(1, 8000, 32, b"\0" * 16, fmt_tag=3))
+    assert w["is_float"] == 1 and w["samples"] == 4
+    # truncated data chunk: what is there
+    full = _wav_bytes(2, 44100, 16, pay)
+    assert rh.wav_probe(full[:-4])["samples"] == 10
+    import pytest
+
+    with pytest.raises(rh.RhError):
+        rh.wav_probe(b"RIFX" + full[4:])
+    with pytest.raises(rh.RhError):
+        rh.wav_probe(_wav_bytes(2, 44100, 16, pay, fmt_tag=0x55))  # MP3-in-WAV: not PCM
+
+
+def test_wav_header_f32_matches_the_spec(rh):
+    import ctypes as C
+    import struct
+
+    from rodio_amd import _lib
+
+    hdr = (C.c_uint8 * 44)()
+    assert _lib.lib.rh_wav_header_f32_host(hdr, 44, 2, 48000, 7) == 44  # 7 samples: 3 whole stereo frames
+    b = bytes(hdr)
+    assert b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data"
+    assert struct.unpack("<I", b[4:8])[0] == 36 + 24 and struct.unpack("<I", b[40:44])[0] == 24
+    assert struct.unpack("<HHIIHH", b[20:36]) == (3, 2, 48000, 48000 * 8, 8, 32)
+    assert _lib.lib.rh_wav_header_f32_host(hdr, 40, 2, 48000, 8) == 0
