@@ -249,39 +249,95 @@ __device__ __forceinline__ float rev_at(const float *__restrict__ x, size_t i, s
 struct StreamGains {
     const float *g;  // device [n_streams][2]
 };
+// Long delays (config 3: D = 65 536 samples): walk the stream in steps of D.  A lane owns the 4-sample
+// column c and visits i = c, c+D, c+2D, ...: the direct tap of one step is the echo tap of the next, so it
+// stays in registers and every input byte is loaded exactly once -- no reliance on a cache holding 4*D
+// bytes per stream between the two uses (measured before: FETCH_SIZE = 1.77x the input with the schedule
+// below, which re-reads the echo tap through L2 / Infinity Cache).  Same arithmetic, same bits.
+__global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain,
+                                                                const float *__restrict__ gains, size_t src_stride, size_t dst_stride, uint32_t n_streams) {
+    // n % 4 == 0, delay % 4 == 0, 16-byte aligned rows; columns = delay / 4
+    const size_t cols = delay / 4;
+    const size_t total = n + delay;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < cols * n_streams; w += stride) {
+        const uint32_t stream = (uint32_t)(w / cols);
+        const size_t c = (w - (size_t)stream * cols) * 4;
+        const float *x = src + (size_t)stream * src_stride;
+        float *o = dst + (size_t)stream * dst_stride;
+        const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
+        float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i0 = c; i0 < total; i0 += 4 * delay) {
+            float4 a4[4];  // four steps of loads in flight before the first one is consumed
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + (size_t)u * delay;
+                a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n) a4[u] = *reinterpret_cast<const float4 *>(x + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + (size_t)u * delay;
+                if (i >= total) break;
+                const float4 a = a4[u];
+                float r[4];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {prev.x, prev.y, prev.z, prev.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
+                    r[k] = (i < n) ? (av[k] + s2) : s2;
+                }
+                float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
+                m0 = m0 / 2.0f;
+                m1 = m1 / 2.0f;
+                *reinterpret_cast<float4 *>(o + i) = make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1);
+                prev = a;
+            }
+        }
+    }
+}
+
+// XCD-aware schedule: the echo tap x[i-D] is 4*D bytes (256 KiB in config 3) behind the direct tap.
+// Block b runs on XCD b % 8 (observed placement; speed only), whose 4 MiB L2 is private, so the
+// delayed read is an L2 hit only if the SAME XCD read that line a moment ago: each XCD therefore walks
+// whole streams (s = xcd, xcd+8, ...) one after the other with all of its blocks side by side --
+// its L2 then sees D*4 bytes * 2 between a line's two uses instead of that times the number of
+// concurrent streams (measured on config 3: 0.268 ms with all 64 streams in flight on every XCD).
 template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void k_reverb_spatial(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain,
-                                                           const float *__restrict__ gains, size_t src_stride, size_t dst_stride, size_t frames_out) {
-    const uint32_t stream = blockIdx.y;
-    const float *x = src + (size_t)stream * src_stride;
-    float *o = dst + (size_t)stream * dst_stride;
-    const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    if (VEC4) {  // n % 4 == 0, delay % 4 == 0, 16-byte aligned rows
-        const size_t quads = (frames_out + 1) / 2;
-        for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += stride) {
-            const size_t i = 4 * q;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (i < n) a = *reinterpret_cast<const float4 *>(x + i);
-            if (i >= delay) b = *reinterpret_cast<const float4 *>(x + i - delay);  // i - delay < n because i < n + delay
-            float r[4];
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+                                                           const float *__restrict__ gains, size_t src_stride, size_t dst_stride, size_t frames_out, uint32_t n_streams) {
+    const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    const size_t stride = (size_t)nbx * kBlock;
+    for (uint32_t stream = xcd; stream < n_streams; stream += 8) {
+        const float *x = src + (size_t)stream * src_stride;
+        float *o = dst + (size_t)stream * dst_stride;
+        const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
+        if (VEC4) {  // n % 4 == 0, delay % 4 == 0, 16-byte aligned rows
+            const size_t quads = (frames_out + 1) / 2;
+            for (size_t q = (size_t)lb * kBlock + threadIdx.x; q < quads; q += stride) {
+                const size_t i = 4 * q;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (i < n) a = *reinterpret_cast<const float4 *>(x + i);
+                if (i >= delay) b = *reinterpret_cast<const float4 *>(x + i - delay);  // i - delay < n because i < n + delay
+                float r[4];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
-                r[k] = (i < n) ? (av[k] + s2) : s2;
+                for (int k = 0; k < 4; ++k) {
+                    const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
+                    r[k] = (i < n) ? (av[k] + s2) : s2;
+                }
+                float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
+                m0 = m0 / 2.0f;
+                m1 = m1 / 2.0f;
+                *reinterpret_cast<float4 *>(o + i) = make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1);
             }
-            float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
-            m0 = m0 / 2.0f;
-            m1 = m1 / 2.0f;
-            *reinterpret_cast<float4 *>(o + i) = make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1);
-        }
-    } else {
-        for (size_t f = (size_t)blockIdx.x * kBlock + threadIdx.x; f < frames_out; f += stride) {
-            const float r0 = rev_at(x, 2 * f, n, delay, gain), r1 = rev_at(x, 2 * f + 1, n, delay, gain);
-            float m = (0.0f + r0) + r1;
-            m = m / 2.0f;
-            *reinterpret_cast<float2 *>(o + 2 * f) = make_float2(m * g0, m * g1);
+        } else {
+            for (size_t f = (size_t)lb * kBlock + threadIdx.x; f < frames_out; f += stride) {
+                const float r0 = rev_at(x, 2 * f, n, delay, gain), r1 = rev_at(x, 2 * f + 1, n, delay, gain);
+                float m = (0.0f + r0) + r1;
+                m = m / 2.0f;
+                *reinterpret_cast<float2 *>(o + 2 * f) = make_float2(m * g0, m * g1);
+            }
         }
     }
 }
@@ -381,15 +437,20 @@ rh_status rh_reverb_spatial(float *dst, const float *src, size_t n, size_t delay
     if (frames_out == 0) return RH_OK;
     if (!dst || !src || !gains_dev) return RH_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 7u) return RH_ERR_INVALID;
-    if (n_streams > 65535u) return RH_ERR_UNSUPPORTED;
     const bool vec4 = n % 4 == 0 && delay_samples % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 &&
                       ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0;
-    // enough workgroups for 256 CUs x 8 in total, spread over the streams
+    // 8 workgroups per CU, split evenly over the 8 XCDs; small jobs get fewer (still a multiple of 8)
     const size_t items = vec4 ? (frames_out + 1) / 2 : frames_out;
-    unsigned gx = rh::grid_for(items, kBlock, (256u * 8u + n_streams - 1) / n_streams);
-    const dim3 grid(gx, n_streams);
-    if (vec4) hipLaunchKernelGGL(k_reverb_spatial<true>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out);
-    else hipLaunchKernelGGL(k_reverb_spatial<false>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out);
+    const unsigned per_xcd_want = rh::grid_for(items, kBlock, 256u);  // blocks that have work on one stream
+    const unsigned gx = 8u * (per_xcd_want < 256u ? per_xcd_want : 256u);
+    const dim3 grid(gx);
+    if (vec4 && delay_samples >= 4096 && (delay_samples / 4) * n_streams >= 64u * 1024u) {
+        // enough independent columns to fill the chip: every input byte once
+        const size_t lanes = (delay_samples / 4) * n_streams;
+        hipLaunchKernelGGL(k_reverb_spatial_cols, dim3(rh::grid_for(lanes, kBlock, 256u * 16u)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams);
+    } else if (vec4)
+        hipLaunchKernelGGL(k_reverb_spatial<true>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out, n_streams);
+    else hipLaunchKernelGGL(k_reverb_spatial<false>, grid, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, frames_out, n_streams);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
