@@ -123,6 +123,8 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
                               uint32_t sample_rate, uint64_t duration_ns, float start_gain, float end_gain,
                               int32_t clamp_end, rh_stream stream);
 
+/* ---- Delay: src/source/delay.rs:8-16,68-75: rh_delay_samples() zeros, then the n input samples (dst holds both). */
+rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samples, rh_stream stream);
 /* ---- TakeDuration (+ its fade-out filter): src/source/take.rs:96-148.  src holds n samples of the stream that
  * start at sample_offset; dst (capacity n + channels) receives *out_samples: the samples the duration
  * still admits, then the zeros that complete a cut frame.  *ended = 1 when the duration expires in this

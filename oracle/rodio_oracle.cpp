@@ -34,6 +34,12 @@
 
 namespace {
 
+inline uint32_t sat_cast_u32(float v) {  // Rust `v as u32`
+    if (v != v || v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
 // ---------------------------------------------------------------- Source ----
 // src/source/mod.rs:179-218 -- `trait Source: Iterator<Item = Sample>`.
 // next() returns false for rodio's `None`.
@@ -540,6 +546,23 @@ struct Delay : Source {
     uint32_t sample_rate() const override { return input->sample_rate(); }
 };
 
+// --------------------------------------------------------------- Speed ----
+// src/source/speed.rs:104-133: samples pass through; the reported rate is (rate as f32 * factor).max(1.0) as u32
+struct Speed : Source {
+    Source *input;
+    float factor;
+    Speed(Source *in, float f) : input(in), factor(f) {}
+    ~Speed() override { delete input; }
+    bool next(float &out) override { return input->next(out); }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override {
+        float r = (float)input->sample_rate() * factor;
+        if (!(r > 1.0f)) r = 1.0f;
+        return sat_cast_u32(r);
+    }
+};
+
 // ----------------------------------------------------------------- Mix ----
 // src/source/mix.rs:10-22 (both inputs wrapped in UniformSourceIterator at
 // input1's format), :43-53 (next)
@@ -765,6 +788,7 @@ void *orc_linear_gain_ramp(void *in, unsigned long long ns, float a, float b, in
 void *orc_low_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, false, freq, q); }
 void *orc_high_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, true, freq, q); }
 void *orc_delay(void *in, unsigned long long ns) { return new Delay((Source *)in, ns); }
+void *orc_speed(void *in, float factor) { return new Speed((Source *)in, factor); }
 // source/mod.rs:628-634 -- reverb = self.mix(self.clone().amplify(a).delay(d)).  The clone of
 // a `Buffered` source (buffered.rs:97-126) replays identical samples, so the oracle
 // materialises the input once and builds both branches from it.

@@ -45,6 +45,7 @@ def _load():
         "orc_low_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_high_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_delay": (vp, [vp, C.c_ulonglong]),
+        "orc_speed": (vp, [vp, C.c_float]),
         "orc_reverb": (vp, [vp, C.c_ulonglong, C.c_float]),
         "orc_channel_volume": (vp, [vp, f32p, C.c_int]),
         "orc_spatial": (vp, [vp, f32p, f32p, f32p]),
@@ -163,6 +164,9 @@ class Source:
 
     def high_pass(self, freq, q=0.5):
         return Source(_lib.orc_high_pass(self._take(), freq, q))
+
+    def speed(self, factor):  # speed.rs: only the reported sample rate changes
+        return Source(_lib.orc_speed(self._take(), factor))
 
     def delay(self, ns):
         return Source(_lib.orc_delay(self._take(), ns))

@@ -124,6 +124,7 @@ SIGNATURES = {
     "rh_wav_probe_host": (i32, [vp, sz, C.POINTER(WavInfo)]),
     "rh_wav_decode": (i32, [vp, vp, u64, u32, u32, i32, C.POINTER(u64), vp]),
     "rh_wav_header_f32_host": (sz, [vp, sz, u32, u32, u64]),
+    "rh_delay": (i32, [vp, vp, u64, u64, vp]),
     "rh_take_duration": (i32, [vp, vp, u64, u64, u32, u32, u64, i32, C.POINTER(u64), C.POINTER(i32), vp]),
     "rh_distortion": (i32, [vp, vp, sz, f32, f32, vp]),
     "rh_linear_gain_ramp": (i32, [vp, vp, sz, u64, u32, u32, u64, f32, f32, i32, vp]),

@@ -76,6 +76,11 @@ __global__ __launch_bounds__(kBlock) void k_linear_gain_ramp(float *__restrict__
     }
 }
 
+// Delay: src/source/delay.rs:68-75 -- `delay` samples of silence, then the input.
+__global__ __launch_bounds__(kBlock) void k_delay(float *__restrict__ dst, const float *__restrict__ src, uint64_t n, uint64_t delay) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n + delay; i += stride) dst[i] = i < delay ? 0.0f : src[i - delay];
+}
 // TakeDuration: src/source/take.rs:96-148.  out[i] = x[i] (optionally * remaining_ms / total_ms, the
 // fade-out filter of :33-38) for the `take` samples the duration admits, then `pad` zeros that complete
 // the frame.  remaining at sample k of the stream = duration - k * (1e9 / (rate*channels)).
@@ -130,6 +135,14 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
     const float total_s = (float)(duration_ns / 1000000000ull) + (float)(uint32_t)(duration_ns % 1000000000ull) / 1000000000.0f;
     hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, duration_ns, total_s, start_gain,
                        end_gain, clamp_end ? end_gain : 1.0f);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samples, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (n + delay_samples == 0) return RH_OK;
+    if (!dst || (n && !src)) return RH_ERR_INVALID;
+    hipLaunchKernelGGL(k_delay, dim3(rh::grid_for(n + delay_samples)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

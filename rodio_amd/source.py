@@ -101,6 +101,19 @@ class GpuSource:
         check(lib.rh_amplify(_ptr(out), _ptr(self.samples), len(self), factor, _stream()), "rh_amplify")
         return GpuSource(out, self._channels, self._sample_rate, self.span_len)
 
+    def speed(self, factor: float) -> "GpuSource":
+        """src/source/speed.rs:104-133: the samples are untouched, the reported rate is scaled."""
+        r = np.float32(self._sample_rate) * np.float32(factor)
+        return GpuSource(self.samples, self._channels, int(max(r, np.float32(1.0))), self.span_len)
+
+    def delay(self, duration_ns: int) -> "GpuSource":
+        """src/source/delay.rs:8-16,68-75."""
+        _ensure()
+        d = delay_samples(duration_ns, self._sample_rate, self._channels)
+        out = _dev_empty(len(self) + d)
+        check(lib.rh_delay(_ptr(out), _ptr(self.samples), len(self), d, _stream()), "rh_delay")
+        return GpuSource(out, self._channels, self._sample_rate, None if self.span_len is None else self.span_len + d)
+
     def take_duration(self, duration_ns: int, fade_out: bool = False) -> "GpuSource":
         _ensure()
         out = _dev_empty(len(self) + self._channels)
@@ -197,18 +210,44 @@ def SampleRateConverter(inp: GpuSource, from_rate: int, to_rate: int, channels: 
     """src/conversions/sample_rate.rs:52-57 (same argument order).  span_len applies
     UniformSourceIterator's chunking (0 = one continuous stream)."""
     _ensure()
-    frames = len(inp) // channels
+    torch = _t()
+    frames, rem = divmod(len(inp), channels)
+    if from_rate == to_rate and rem:  # sample_rate.rs:133-136: pure pass-through, half frames included
+        return GpuSource(inp.samples.clone(), channels, to_rate, None)
     m = C.c_uint64(0)
     check(lib.rh_resample_out_frames(frames, from_rate, to_rate, channels, span_len, C.byref(m)), "rh_resample_out_frames")
     out = _dev_empty(m.value * channels)
     check(lib.rh_resample_linear(_ptr(out), _ptr(inp.samples), frames, from_rate, to_rate, channels, span_len,
                                  _stream()), "rh_resample_linear")
+    if rem and span_len == 0:
+        # A stream that ends mid-frame (rodio's own `reverb` with an odd delay produces one; the sources'
+        # contract source/mod.rs:169-178 forbids it).  sample_rate.rs:174-200: frames are Vecs, the zip of
+        # the last whole frame with the partial one yields only `rem` samples per output position, then
+        # the partial frame is drained verbatim.  A handful of samples: done here, on the host, in f32.
+        g = np.gcd(from_rate, to_rate)
+        F, T = from_rate // g, to_rate // g
+        tail_in = inp.samples[max(frames - 1, 0) * channels:].cpu().numpy()
+        part = tail_in[-rem:]
+        if frames == 0:
+            return GpuSource(_upload(part), channels, to_rate, None)
+        last = tail_in[:channels]
+        c1 = -((-(frames - 1) * T) // F)  # output positions whose two taps are whole frames
+        tail, mm = [], c1
+        while (mm * F) // T == frames - 1:
+            num = np.float32((mm * F) % T)
+            tail += [np.float32(last[c] + (part[c] - last[c]) * num / np.float32(T)) for c in range(rem)]  # math.rs:23-26
+            mm += 1
+        if (mm * F) // T == frames:
+            tail += [np.float32(v) for v in part]
+        out = torch.cat([out[: c1 * channels], _upload(np.asarray(tail, np.float32))]) if tail else out[: c1 * channels]
     return GpuSource(out, channels, to_rate, None)
 
 
 def ChannelCountConverter(inp: GpuSource, from_ch: int, to_ch: int) -> GpuSource:
     """src/conversions/channels.rs:28."""
     _ensure()
+    if from_ch == to_ch:  # channels.rs:57-85 degenerates to a pass-through, half frames included
+        return GpuSource(inp.samples, to_ch, inp.sample_rate(), inp.span_len)
     frames = len(inp) // from_ch
     out = _dev_empty(frames * to_ch)
     check(lib.rh_channels_convert(_ptr(out), _ptr(inp.samples), frames, from_ch, to_ch, _stream()), "rh_channels_convert")

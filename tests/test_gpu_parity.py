@@ -747,6 +747,34 @@ def test_fused_block_streaming_equals_one_pass(G, O, filt, freq, R):
     p.close()
 
 
+def _bench_long(M, src, reverb_via=None):
+    """benches/pipeline.rs:16-37 (`long`), spelled with the adapter methods both mirrors share."""
+    x = (src.high_pass(300).amplify(1.2).speed(0.9).automatic_gain_control()
+         .delay(500_000_000).fade_in(2_000_000_000).take_duration(10_000_000_000, fade_out=True))
+    x = x.reverb(50_000_000, 0.3)  # .buffered() only makes the clone possible; .skippable() passes through
+    return M.UniformSourceIterator(x, 2, 40000)
+
+
+def test_reference_bench_chains(G, O):
+    # BASELINE config 1, as the reference really spells it (SURVEY F6): benches/pipeline.rs `short`
+    # (amplify(1.2).low_pass(200)) and `long` (9 adapters -> reverb -> UniformSourceIterator to 40 kHz) on
+    # the committed excerpt of assets/music.wav continued by 3 s of noise (44.1 kHz stereo)
+    import os
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    x = np.concatenate([np.load(os.path.join(gdir, "music_excerpt_f32.npy")), rnd(77, 2 * 132300, 0.3)])
+    ref = O.TestSource(x, 2, 44100).amplify(1.2).low_pass(200).collect()
+    assert np.array_equal(G.TestSource(x, 2, 44100).amplify(1.2).low_pass(200).collect(), ref)  # `short`, sequential biquad: bit-exact
+    par = G.TestSource(x, 2, 44100).amplify(1.2).low_pass(200, mode=1).collect()                # the time-parallel filter
+    assert float(np.max(np.abs(par - ref))) <= TOL
+    ref = _bench_long(O, O.TestSource(x, 2, 44100)).collect()
+    got = _bench_long(G, G.TestSource(x, 2, 44100)).collect()
+    assert len(got) == len(ref) and len(ref) > 2 * 40000
+    err = float(np.max(np.abs(got - ref)))
+    print(f"[bench long] samples={len(ref)} max_abs_err={err:.3e} peak={float(np.max(np.abs(ref))):.3e}")
+    assert err <= TOL  # AGC uses sqrt/division chains: device libm rounding, everything else is exact
+
+
 def test_fused_matches_unfused_gpu_ops(G, O):
     # fused kernel vs the standalone ops (resample -> sequential biquad -> ordered mix), 64 sources
     S, n = 64, 50000
