@@ -1204,6 +1204,7 @@ struct rh_rlm {
     uint32_t st_nsrc = 0;
     float *d_w[2] = {nullptr, nullptr};
     int st_cur = 0;
+    std::vector<SrcDesc> h_desc;  // staging for the per-block descriptor upload (outlives the async copy)
 };
 
 namespace {
@@ -1673,13 +1674,16 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
     if (out > 0 || flush) {
         if (out > 0) {
             if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
-            std::vector<SrcDesc> h(n_sources);
+            // one staging area per handle: a previous block's copy must have been consumed before it is
+            // rewritten, which the stream order of (copy, kernel) pairs on ONE stream guarantees only after
+            // the copy itself has read the host memory -- pageable-memory copies return after staging
+            std::vector<SrcDesc> &h = p->h_desc;
+            h.resize(n_sources);
             for (uint32_t s = 0; s < n_sources; ++s) {
                 if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
                 h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out};
             }
             RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, rh::as_stream(stream)));
-            RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(stream)));  // h is a stack object
             p->equal = true;
             p->eq_frames = (uint32_t)avail_frames;
             p->n_sources = n_sources;

@@ -578,6 +578,14 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
 
+    def run_subset(self, first, count, out=None):
+        """Mix of the sources [first, first+count) only."""
+        if out is None:
+            out = _dev_empty(max(self.out_frames * self.channels, 4))
+        m = C.c_uint64(0)
+        check(lib.rh_rlm_run_subset(self._h, first, count, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run_subset")
+        return out[: m.value * self.channels]
+
     # -- block streaming: feed(blocks) returns the mixed frames that became computable ------------------
     def stream_begin(self):
         check(lib.rh_rlm_stream_begin(self._h), "rh_rlm_stream_begin")

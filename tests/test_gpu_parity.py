@@ -775,6 +775,49 @@ def test_reference_bench_chains(G, O):
     assert err <= TOL  # AGC uses sqrt/division chains: device libm rounding, everything else is exact
 
 
+def test_fused_subset_and_argument_errors(G, O):
+    import ctypes as C
+
+    import torch
+
+    from rodio_amd import _lib
+
+    S, n = 6, 30000
+    xs = [rnd(1500 + s, 2 * n, 0.2) for s in range(S)]
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    p.set_sources(xd)
+    sub = p.run_subset(2, 3).cpu().numpy()
+    p.check_status()
+    ref = _oracle_pipeline(O, xs[2:5], 44100, 48000, None, "low_pass", 200)
+    assert len(sub) == len(ref) and float(np.max(np.abs(sub - ref))) <= TOL
+    with pytest.raises(G.RhError):
+        p.run_subset(4, 3)  # past the end
+    small = torch.empty(16, device="cuda")
+    with pytest.raises(G.RhError):
+        p.run(small)  # RH_ERR_CAPACITY
+    with pytest.raises(G.RhError):
+        p.set_sources(xd + xd)  # more than max_sources
+    with pytest.raises(G.RhError):
+        p.set_sources([xd[0][1:]])  # not 16-byte aligned
+    p.close()
+    for bad in [dict(channels=1), dict(from_rate=96000 * 3, to_rate=44100), dict(filter="low_pass", freq=30000)]:
+        kw = dict(from_rate=44100, to_rate=48000, channels=2, span_len=None, filter="low_pass", freq=200)
+        kw.update(bad)
+        with pytest.raises(G.RhError):
+            G.ResampleLowpassMix(kw["from_rate"], kw["to_rate"], kw["channels"], kw["span_len"], kw["filter"], kw["freq"], 0.5)
+    # streaming needs begin(); a finished stream refuses more blocks
+    q = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+    with pytest.raises(G.RhError):
+        q._left = None
+        q.stream_feed([x[:2000] for x in xd])
+    q.stream_begin()
+    q.stream_feed([x[:2000] for x in xd], flush=True)
+    with pytest.raises(G.RhError):
+        q.stream_feed([x[:2000] for x in xd])
+    q.close()
+
+
 def test_fused_matches_unfused_gpu_ops(G, O):
     # fused kernel vs the standalone ops (resample -> sequential biquad -> ordered mix), 64 sources
     S, n = 64, 50000
