@@ -322,6 +322,18 @@ typedef struct rh_rlm_geometry_info {
 } rh_rlm_geometry_info;
 rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info);
 
+/* ---- multi-GPU: one process per GPU, sources sharded over the ranks, the mixer sum (src/mixer.rs:185-198 is the
+ * only place rodio's streams meet) completed by ONE collective per mixed block over RCCL / xGMI.  Rank 0 calls
+ * rh_comm_unique_id and hands the 128 bytes to the other ranks (any out-of-band channel); every rank then calls
+ * rh_comm_init on its own device.  all-reduce leaves the full mix on every rank; reduce only on `root` (the
+ * rank that owns the sink).  Both run in place on `stream`, behind the kernel that produced the block. */
+typedef struct rh_comm rh_comm;
+rh_status rh_comm_unique_id(uint8_t out128[128]);
+rh_status rh_comm_init(rh_comm **out, int32_t rank, int32_t nranks, const uint8_t uid128[128]);
+rh_status rh_comm_destroy(rh_comm *c);
+rh_status rh_allreduce_sum_f32(rh_comm *c, float *buf, size_t n, rh_stream stream);
+rh_status rh_reduce_sum_f32(rh_comm *c, float *buf, size_t n, int32_t root, rh_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

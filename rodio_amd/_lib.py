@@ -129,6 +129,11 @@ SIGNATURES = {
     "rh_distortion": (i32, [vp, vp, sz, f32, f32, vp]),
     "rh_linear_gain_ramp": (i32, [vp, vp, sz, u64, u32, u32, u64, f32, f32, i32, vp]),
     "rh_reverb_spatial": (i32, [vp, vp, sz, sz, f32, vp, u32, sz, sz, vp]),
+    "rh_comm_unique_id": (i32, [vp]),
+    "rh_comm_init": (i32, [C.POINTER(vp), i32, i32, vp]),
+    "rh_comm_destroy": (i32, [vp]),
+    "rh_allreduce_sum_f32": (i32, [vp, vp, sz, vp]),
+    "rh_reduce_sum_f32": (i32, [vp, vp, sz, i32, vp]),
     "rh_rlm_create": (i32, [C.POINTER(vp), C.POINTER(RlmConfig)]),
     "rh_rlm_destroy": (i32, [vp]),
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),

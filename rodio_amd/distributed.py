@@ -81,3 +81,54 @@ class ShardedResampleLowpassMix:
             out[local.numel(): self.out_frames * ch].zero_()
         mixed = out[: self.out_frames * ch]
         return mixed, all_reduce_mix(mixed, self.group, async_op)
+
+
+class NativeComm:
+    """The C-ABI communicator (rh_comm_*: RCCL without PyTorch in the loop) -- what a Rust host uses.
+    Rank 0 creates the id with NativeComm.unique_id() and ships the 128 bytes to the other ranks."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        buf = (C.c_uint8 * 128)()
+        check(lib.rh_comm_unique_id(buf), "rh_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, rank: int, nranks: int, uid: bytes):
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(lib.rh_comm_init(C.byref(self._h), rank, nranks, buf), "rh_comm_init")
+
+    def all_reduce(self, block, stream=None):
+        import ctypes as C
+
+        import torch
+
+        from ._lib import check, lib
+
+        s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.rh_allreduce_sum_f32(self._h, C.c_void_p(block.data_ptr()), block.numel(), s), "rh_allreduce_sum_f32")
+
+    def reduce(self, block, root=0, stream=None):
+        import ctypes as C
+
+        import torch
+
+        from ._lib import check, lib
+
+        s = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        check(lib.rh_reduce_sum_f32(self._h, C.c_void_p(block.data_ptr()), block.numel(), root, s), "rh_reduce_sum_f32")
+
+    def close(self):
+        from ._lib import lib
+
+        if self._h:
+            lib.rh_comm_destroy(self._h)
+            self._h = None

@@ -938,3 +938,25 @@ def test_cfg2_chunked_variant_matches_unchunked_away_from_seams(G, cfg2):
     assert np.array_equal(oc[: 17832 * 2], ou[: 17832 * 2])
     pc.close()
     pu.close()
+
+
+def test_native_comm_single_rank(G):
+    # rh_comm_*: the RCCL entry points of the C ABI.  One GPU here, so one rank: the all-reduce and the reduce
+    # are the identity, but id exchange, communicator set-up, the in-place collective on the caller's
+    # stream and tear-down all run for real.
+    import torch
+
+    from rodio_amd.distributed import NativeComm
+
+    uid = NativeComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = NativeComm(0, 1, uid)
+    x = torch.rand(1141308 * 2, device="cuda")
+    y = x.clone()
+    comm.all_reduce(y)
+    comm.reduce(y, root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    with pytest.raises(G.RhError):
+        comm.reduce(y, root=1)
+    comm.close()
