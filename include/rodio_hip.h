@@ -273,6 +273,11 @@ rh_status rh_rlm_destroy(rh_rlm *p);
  * samples; *out_frames = max over sources of the resampled length. */
 rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
                              const uint64_t *in_frames_host, uint32_t n_sources);
+/* Optional per-source Amplify factors (src/source/amplify.rs:64; Player::set_volume): source s contributes
+ * gains[s] * (its converted, filtered stream).  The chain is linear, so it does not matter where in it rodio
+ * applies the factor; without a filter the result stays bit-identical to amplify-then-convert.  Sources beyond
+ * n keep 1.0.  Takes effect for the sources that are set and for every later set_sources / stream block. */
+rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n);
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames,
                      rh_stream stream);
 /* The same over the sources [first, first+count) only (a sub-mix; count = 1: one filtered stream). */

@@ -64,11 +64,14 @@ constexpr int kGroupLag = RH_CARRY_DEFER;  // a source group's carries are fetch
 constexpr int kMaxLook = 32;              // 2 lanes x 16 B of LDS-DMA per predecessor tile: 64 lanes
 constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
 
-struct SrcDesc {          // 16 bytes: one s_load_dwordx4
+struct SrcDesc {          // 32 bytes, read with s_load (constant address space)
     const float *data;
     uint32_t frames;      // N_s   (< 2^29)
     uint32_t out_frames;  // M_s   (< 2^31)
+    float gain;           // Amplify factor of the source (amplify.rs:64); the chain is linear, so it scales the mix term
+    uint32_t pad[3];
 };
+static_assert(sizeof(SrcDesc) == 32, "descriptor stride");
 
 // ---- the biquad as data -----------------------------------------------------------------------
 // H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z) with c1 = b1 - b0*a1, c2 = b2 - b0*a2.  The recursive
@@ -361,7 +364,9 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
 
     const uint32_t S = p.batch_streams ? 1u : p.n_sources;
     typedef __attribute__((address_space(4))) const uint64_t cu64;
-    cu64 *const desc = (cu64 *)(uintptr_t)(p.srcs + stream);  // 16-byte descriptors: the pointer is the first qword
+    cu64 *const desc = (cu64 *)(uintptr_t)(p.srcs + stream);  // 32-byte descriptors: the pointer is the first qword ...
+    typedef __attribute__((address_space(4))) const float cf32;
+    cf32 *const dgain = (cf32 *)(uintptr_t)(p.srcs + stream);  // ... the gain is float 4
     auto stage_source = [&](const void *data, uint32_t stage_off) {
 #pragma unroll
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
@@ -373,8 +378,9 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     uint32_t st_cur = 0;
 #pragma unroll
     for (int d = 0; d < NS; ++d)
-        if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[2 * d], d * kStage);
-    uint64_t ptr_pref = NS < S ? desc[2 * NS] : 0;  // fetched one iteration ahead of its use
+        if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[4 * d], d * kStage);
+    uint64_t ptr_pref = NS < S ? desc[4 * NS] : 0;  // fetched one iteration ahead of its use
+    float g_next = S ? dgain[4] : 1.0f;              // gain of source 0
     RH_PH_DECL
 
     for (uint32_t s = 0; s < S && live; ++s) {
@@ -395,7 +401,9 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
         // every tap is in a register: the stage is free for source s+NS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (s + NS < S) stage_source((const void *)(uintptr_t)ptr_pref, st_cur);
-        ptr_pref = s + NS + 1 < S ? desc[2 * (uint64_t)(s + NS + 1)] : 0;
+        ptr_pref = s + NS + 1 < S ? desc[4 * (uint64_t)(s + NS + 1)] : 0;
+        const float g = g_next;  // Amplify factor of source s
+        g_next = s + 1 < S ? dgain[8 * (uint64_t)(s + 1) + 4] : 1.0f;
         RH_PH(1)
         auto tap = [&](int rr) -> v2f {
             const v2f a = ta[rr], b = tb2[rr];
@@ -403,9 +411,10 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
             if (FILT) {
                 x.x = fma_(b.x - a.x, wgt[rr], a.x);
                 x.y = fma_(b.y - a.y, wgt[rr], a.y);
-            } else {  // math.rs:25: first + (second - first) * num / den, exactly
-                x.x = a.x + div_T((b.x - a.x) * wgt[rr], p.Tf, p.rcpT);
-                x.y = a.y + div_T((b.y - a.y) * wgt[rr], p.Tf, p.rcpT);
+            } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
+                const float ax = a.x * g, ay = a.y * g, bx = b.x * g, by = b.y * g;
+                x.x = ax + div_T((bx - ax) * wgt[rr], p.Tf, p.rcpT);
+                x.y = ay + div_T((by - ay) * wgt[rr], p.Tf, p.rcpT);
             }
             return x;
         };
@@ -419,15 +428,17 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
                 v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
                 w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
                 w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
-                acc[r].x += fma_(b0, x.x, w.x);
-                acc[r].y += fma_(b0, x.y, w.y);
+                acc[r].x = fma_(g, fma_(b0, x.x, w.x), acc[r].x);  // the source's gain rides on the mix (linear chain)
+                acc[r].y = fma_(g, fma_(b0, x.y, w.y), acc[r].y);
                 w2 = w1;
                 w1 = w;
                 x2 = x1;
                 x1 = x;
             }
-            E1 += w1;
-            E2 += w2;
+            E1.x = fma_(g, w1.x, E1.x);
+            E1.y = fma_(g, w1.y, E1.y);
+            E2.x = fma_(g, w2.x, E2.x);
+            E2.y = fma_(g, w2.y, E2.y);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -716,14 +727,16 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     struct Desc {
         const void *data;
         uint32_t frames, out_frames;
+        float gain;
     };
     auto load_desc = [&](uint32_t s) -> Desc {
-        Desc d{nullptr, 0, 0};
+        Desc d{nullptr, 0, 0, 1.0f};
         if (s < S) {
-            const uint64_t lo = desc[4 * (uint64_t)s], hi = desc[4 * (uint64_t)s + 1];
+            const uint64_t lo = desc[8 * (uint64_t)s], hi = desc[8 * (uint64_t)s + 1];
             d.data = (const void *)(uintptr_t)(lo | (hi << 32));
-            d.frames = desc[4 * (uint64_t)s + 2];
-            d.out_frames = desc[4 * (uint64_t)s + 3];
+            d.frames = desc[8 * (uint64_t)s + 2];
+            d.out_frames = desc[8 * (uint64_t)s + 3];
+            d.gain = __uint_as_float(desc[8 * (uint64_t)s + 4]);
         }
         return d;
     };
@@ -769,14 +782,19 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
 
     // ---- prologue: sources 0..NS-2 into stages 0..NS-2 -------------------------------------------
     uint32_t Ms_ring[NS], Ns_ring[NS];  // [d]: out_frames / frames of source s+d
+    float g_ring[NS];                  // ... and its Amplify factor
 #pragma unroll
-    for (int d = 0; d < NS; ++d) Ms_ring[d] = Ns_ring[d] = 0;
+    for (int d = 0; d < NS; ++d) {
+        Ms_ring[d] = Ns_ring[d] = 0;
+        g_ring[d] = 1.0f;
+    }
     uint32_t st_cur = 0;  // LDS byte offset of the stage of source s
 #pragma unroll
     for (int d = 0; d < NS - 1; ++d) {
         const Desc sd = load_desc(d);
         Ms_ring[d] = sd.out_frames;
         Ns_ring[d] = sd.frames;
+        g_ring[d] = sd.gain;
         if (sd.out_frames > m_tile0) {
             stage_source(sd.data, sd.frames, d * kStage);
             iss |= 1u << d;
@@ -808,6 +826,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
             if (st_new >= NS * kStage) st_new -= NS * kStage;
             Ms_ring[NS - 1] = sd_pref.out_frames;
             Ns_ring[NS - 1] = sd_pref.frames;
+            g_ring[NS - 1] = sd_pref.gain;
             if (s + NS - 1 < S && sd_pref.out_frames > m_tile0) {
                 stage_source(sd_pref.data, sd_pref.frames, st_new);
                 iss |= 1u << (NS - 1);
@@ -869,6 +888,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         uint64_t merged = 0;
         if (active) {
             const uint32_t Ns = Ns_ring[0];
+            const float g = g_ring[0];  // Amplify factor of source s: rides on the mix and on the run-end state
             // edge: some lane needs masking, or the staged span reaches past the source (verbatim last frame)
             const bool edge = !full || i_base + 2u * nvec > Ns;
             const uint32_t dthr = Ns - 1 - i_base;  // active => i_base <= Ns-1
@@ -879,14 +899,15 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 if (FILT) {
                     x.x = fma_(b.x - a.x, wgt[rr], a.x);
                     x.y = fma_(b.y - a.y, wgt[rr], a.y);
-                } else {  // math.rs:25: first + (second - first) * num / den, exactly
-                    x.x = a.x + div_T((b.x - a.x) * wgt[rr], p.Tf, p.rcpT);
-                    x.y = a.y + div_T((b.y - a.y) * wgt[rr], p.Tf, p.rcpT);
+                } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
+                    const float ax = a.x * g, ay = a.y * g, bx = b.x * g, by = b.y * g;
+                    x.x = ax + div_T((bx - ax) * wgt[rr], p.Tf, p.rcpT);
+                    x.y = ay + div_T((by - ay) * wgt[rr], p.Tf, p.rcpT);
                 }
                 if (decltype(edge_tag)::value) {  // the source's last frame is emitted verbatim
                     const bool last = offA[rr] >= thr;
-                    x.x = last ? a.x : x.x;
-                    x.y = last ? a.y : x.y;
+                    x.x = last ? (FILT ? a.x : a.x * g) : x.x;
+                    x.y = last ? (FILT ? a.y : a.y * g) : x.y;
                 }
                 return x;
             };
@@ -909,8 +930,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                             yx = v ? yx : 0.0f;
                             yy = v ? yy : 0.0f;
                         }
-                        acc[r].x += yx;
-                        acc[r].y += yy;
+                        acc[r].x = fma_(g, yx, acc[r].x);
+                        acc[r].y = fma_(g, yy, acc[r].y);
                         w2 = w1;
                         w1 = w;
                         x2 = x1;
@@ -922,8 +943,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 RH_PH(4)
                 // ---- run end state in the scan basis, then the wave64 inclusive scan ----
                 float P[4] = {0.f, 0.f, 0.f, 0.f};
-                mat_acc(p.u.Tm, w1.x, w2.x, P[0], P[1]);
-                mat_acc(p.u.Tm, w1.y, w2.y, P[2], P[3]);
+                mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
+                mat_acc(p.u.Tm, w1.y * g, w2.y * g, P[2], P[3]);
 #define RH_SCAN_STEP(K, N)                                                                          \
     {                                                                                               \
         const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
@@ -1016,6 +1037,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         for (int d = 0; d + 1 < NS; ++d) {
             Ms_ring[d] = Ms_ring[d + 1];
             Ns_ring[d] = Ns_ring[d + 1];
+            g_ring[d] = g_ring[d + 1];
         }
         st_cur += kStage;
         if (st_cur >= NS * kStage) st_cur = 0;
@@ -1204,7 +1226,8 @@ struct rh_rlm {
     uint32_t st_nsrc = 0;
     float *d_w[2] = {nullptr, nullptr};
     int st_cur = 0;
-    std::vector<SrcDesc> h_desc;  // staging for the per-block descriptor upload (outlives the async copy)
+    std::vector<SrcDesc> h_desc;  // host copy of the descriptor table (staging of the async uploads)
+    std::vector<float> gains;     // per-source Amplify factors (1.0 when unset)
 };
 
 namespace {
@@ -1450,7 +1473,8 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
     RH_REQUIRE_INIT();
     if (!p || (n_sources && (!srcs_host || !in_frames_host))) return RH_ERR_INVALID;
     if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
-    std::vector<SrcDesc> h(n_sources);
+    std::vector<SrcDesc> &h = p->h_desc;
+    h.resize(n_sources);
     uint64_t M = 0;
     bool equal = true;
     for (uint32_t s = 0; s < n_sources; ++s) {
@@ -1460,7 +1484,7 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
         rh_status st = rh::make_resample_geom(in_frames_host[s], p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
         if (st != RH_OK) return st;
         if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
-        h[s] = SrcDesc{srcs_host[s], (uint32_t)in_frames_host[s], (uint32_t)g.out_frames};
+        h[s] = SrcDesc{srcs_host[s], (uint32_t)in_frames_host[s], (uint32_t)g.out_frames, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
         if (g.out_frames > M) M = g.out_frames;
         equal = equal && in_frames_host[s] == in_frames_host[0];
     }
@@ -1471,6 +1495,17 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
     p->out_frames = M;
     // equal-length batch: the merged-state kernel; otherwise the general one
     return activate_plan(p, (equal && !p->cfg.force_general) ? &p->fast : &p->wave);
+}
+
+rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
+    RH_REQUIRE_INIT();
+    if (!p || (n && !gains_host) || n > p->cfg.max_sources) return RH_ERR_INVALID;
+    p->gains.assign(gains_host, gains_host + n);
+    if (!p->st_on && p->n_sources && p->h_desc.size() == p->n_sources) {  // sources already set: refresh their descriptors
+        for (uint32_t s = 0; s < p->n_sources; ++s) p->h_desc[s].gain = s < n ? gains_host[s] : 1.0f;
+        RH_HIP_TRY(hipMemcpy(p->d_srcs, p->h_desc.data(), sizeof(SrcDesc) * p->n_sources, hipMemcpyHostToDevice));
+    }
+    return RH_OK;
 }
 
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
@@ -1681,7 +1716,7 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
             h.resize(n_sources);
             for (uint32_t s = 0; s < n_sources; ++s) {
                 if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
-                h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out};
+                h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
             }
             RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, rh::as_stream(stream)));
             p->equal = true;

@@ -578,6 +578,11 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_run(self._h, _ptr(out), out.numel() // self.channels, C.byref(m), _stream()), "rh_rlm_run")
         return out[: m.value * self.channels]
 
+    def set_gains(self, gains):
+        """Per-source Amplify factors (`src.amplify(g)` / Player::set_volume): folded into the fused kernel."""
+        g = np.ascontiguousarray(gains, dtype=np.float32)
+        check(lib.rh_rlm_set_gains(self._h, g.ctypes.data_as(_lib.f32p), g.size), "rh_rlm_set_gains")
+
     def run_subset(self, first, count, out=None):
         """Mix of the sources [first, first+count) only."""
         if out is None:

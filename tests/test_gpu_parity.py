@@ -747,6 +747,102 @@ def test_fused_block_streaming_equals_one_pass(G, O, filt, freq, R):
     p.close()
 
 
+# ------------------------------------------------- per-source gains folded into the fused kernel ----
+def _oracle_pipeline_gains(O, xs, gains, frm, to, span, filt, freq):
+    """mixer.add(UniformSourceIterator(src.amplify(g)).low_pass(f)) -- rodio's per-source volume."""
+    m = O.Mixer(2, to)
+    for x, g in zip(xs, gains):
+        src = O.TestSource(x, 2, frm) if not span else O.SpanSource(x, 2, frm, span)
+        u = O.UniformSourceIterator(src.amplify(float(g)), 2, to)
+        if filt == "low_pass":
+            u = u.low_pass(freq)
+        elif filt == "high_pass":
+            u = u.high_pass(freq)
+        m.add(u)
+    return m.collect()
+
+
+@pytest.mark.parametrize("general", [0, 1])
+@pytest.mark.parametrize("span", [None, 32768])
+def test_fused_gains_unfiltered_bit_exact(G, O, general, span):
+    # without a filter the gain is applied to the taps before the lerp: amplify.rs:64 then math.rs:25, bit for bit
+    import torch
+
+    ns = [30000] * 7 if not general else [30000, 29999, 147, 0, 12345, 30000, 1]
+    xs = [rnd(2100 + i, 2 * n) for i, n in enumerate(ns)]
+    gains = np.array([1.0, 0.5, 0.3, 1.7, 0.0, -0.25, 0.999], dtype=np.float32)
+    ref = _oracle_pipeline_gains(O, xs, gains, 44100, 48000, span, None, 0)
+    p = G.ResampleLowpassMix(44100, 48000, 2, span, None, 0, 0.5, max_sources=len(xs), max_in_frames=30000, frames_per_lane=6, force_general=general)
+    ts = [torch.from_numpy(x).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs]
+    p.set_gains(gains)
+    p.set_sources(ts)
+    out = p.run().cpu().numpy().copy()
+    p.check_status()
+    assert np.array_equal(out, ref)
+    # changing the gains after set_sources refreshes the descriptors; fewer gains than sources: the rest are 1.0
+    p.set_gains(gains[:2])
+    out2 = p.run().cpu().numpy().copy()
+    ref2 = _oracle_pipeline_gains(O, xs, [1.0, 0.5] + [1.0] * (len(xs) - 2), 44100, 48000, span, None, 0)
+    assert np.array_equal(out2, ref2)
+    p.close()
+
+
+@pytest.mark.parametrize("R,general", [(8, 0), (18, 0), (5, 0), (8, 1), (6, 1)])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
+def test_fused_gains_filtered(G, O, R, general, filt, freq):
+    import torch
+    from scipy.signal import lfilter
+
+    S = 9
+    ns = [40000] * S if not general else [40000, 39999, 20000, 148, 0, 40000, 3, 31000, 40000]
+    xs = [rnd(2200 + i, 2 * n, 0.12) for i, n in enumerate(ns)]  # mix peak ~0.5: the f32 reference itself stays inside the tolerance
+    gains = np.linspace(0.1, 1.3, S).astype(np.float32)
+    gains[3] = 0.0
+    ref = _oracle_pipeline_gains(O, xs, gains, 44100, 48000, None, filt, freq)
+    co = O.blt_coeffs(filt, freq, 0.5, 48000).astype(np.float64)
+    truth = np.zeros(len(ref) // 2 * 2).reshape(-1, 2)
+    for x, g in zip(xs, gains):
+        r = O.UniformSourceIterator(O.TestSource(x, 2, 44100).amplify(float(g)), 2, 48000).collect().astype(np.float64).reshape(-1, 2)
+        if len(r):
+            truth[: len(r)] += lfilter(co[:3], [1.0, co[3], co[4]], r, axis=0)
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=S, max_in_frames=40000, frames_per_lane=R, force_general=general)
+    p.set_gains(gains)
+    p.set_sources([torch.from_numpy(x).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs])
+    out = p.run().cpu().numpy().copy()
+    p.check_status()
+    _check_filtered(f"gains {filt}{freq} R{R} g{general}", out, ref, truth.reshape(-1))
+    # batch rows carry the gain too (batch mode is for equal-length sources)
+    rows = p.run_batch().cpu().numpy() if not general else []
+    for s in (1, 3, 8) if not general else ():
+        r1 = _oracle_pipeline_gains(O, [xs[s]], [gains[s]], 44100, 48000, None, filt, freq)
+        assert float(np.max(np.abs(rows[s][: len(r1)] - r1), initial=0.0)) <= TOL
+    p.close()
+
+
+def test_fused_gains_block_streaming(G, O):
+    import torch
+
+    S, n = 5, 30000
+    xs = [rnd(2300 + s, 2 * n, 0.3) for s in range(S)]
+    gains = np.array([0.9, 0.1, 1.5, 0.5, 0.7], dtype=np.float32)
+    for filt, freq in ((None, 0), ("low_pass", 200)):
+        ref = _oracle_pipeline_gains(O, xs, gains, 44100, 48000, None, filt, freq)
+        p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=S, max_in_frames=n, frames_per_lane=8)
+        p.set_gains(gains)
+        xd = [torch.from_numpy(x).cuda() for x in xs]
+        cuts = [0, 1000, 1001, 9000, 22222, n]
+        p.stream_begin()
+        outs = [p.stream_feed([x[2 * cuts[k]: 2 * cuts[k + 1]] for x in xd], flush=(k == len(cuts) - 2)) for k in range(len(cuts) - 1)]
+        p.check_status()
+        got = torch.cat(outs).cpu().numpy()
+        assert len(got) == len(ref)
+        if filt is None:
+            assert np.array_equal(got, ref)
+        else:
+            assert float(np.max(np.abs(got - ref))) <= TOL
+        p.close()
+
+
 def _bench_long(M, src, reverb_via=None):
     """benches/pipeline.rs:16-37 (`long`), spelled with the adapter methods both mirrors share."""
     x = (src.high_pass(300).amplify(1.2).speed(0.9).automatic_gain_control()
