@@ -296,6 +296,17 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
                               uint64_t avail_frames, int32_t flush, float *dst,
                               uint64_t out_capacity_frames, uint64_t *out_frames,
                               uint64_t *consumed_frames, rh_stream stream);
+/* The same for sources that end at different times (what a mixer usually holds): source s passes
+ * avail_frames_host[s] frames; ended_host[s] != 0 says that these are its last ones (rodio's None; sticky).
+ * All sources run on one clock (they start with the stream).  Live sources bound what a block can emit (whole
+ * tiles of 64*frames_per_lane output frames; everything once all sources have ended, which ends the stream);
+ * *consumed_frames is common to all sources: each drops min(consumed, what it holds).  The handle keeps one
+ * filter state PER SOURCE across blocks (this entry always takes the ragged-batch kernel).  begin() as above;
+ * a stream uses one of the two block entries throughout. */
+rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host,
+                                const uint8_t *ended_host, uint32_t n_sources, float *dst,
+                                uint64_t out_capacity_frames, uint64_t *out_frames,
+                                uint64_t *consumed_frames, rh_stream stream);
 /* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels
  * (equal-length sources only: RH_ERR_UNSUPPORTED otherwise).  One launch for all sources. */
 rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames,

@@ -142,6 +142,7 @@ SIGNATURES = {
     "rh_rlm_run_subset": (i32, [vp, u32, u32, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_stream_begin": (i32, [vp]),
     "rh_rlm_stream_block": (i32, [vp, C.POINTER(vp), u32, u64, i32, vp, u64, C.POINTER(u64), C.POINTER(u64), vp]),
+    "rh_rlm_stream_block_v": (i32, [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_uint8), u32, vp, u64, C.POINTER(u64), C.POINTER(u64), vp]),
     "rh_rlm_run_batch": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_autotune": (i32, [vp, vp, u64, vp, C.POINTER(u32), C.POINTER(u32)]),
     "rh_rlm_last_status": (i32, [vp]),

@@ -121,6 +121,10 @@ struct Params {
     // k_rlm_fast, block streaming (st_mode: 0 off, 1 block of a running stream, 2 its last block):
     uint32_t st_mode, st_active;  // st_active: output frames this block emits (a multiple of R in mode 1)
     uint64_t st_m0, st_g0;        // global index of the block's first output frame / of input frame 0 of the buffers
+    // k_rlm_wave keeps one aggregate row per source: gran_cols columns, tile t in column t + col0.  Streaming sets
+    // col0 = 1: column 0 then holds the source's filter state at the block start, i.e. the aggregate of a virtual
+    // predecessor tile -- the look-back needs no other change.
+    uint32_t gran_cols, col0;
     const float *st_win;          // summed filter state (scan basis) at output frame st_m0
     float *st_wout;               // ... at st_m0 + st_active, written by the lane that would come next
     Uniforms u;
@@ -616,17 +620,23 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     constexpr uint32_t L = 64u * R;
     const uint32_t m_tile0 = tile * L;  // host: out_frames < 2^31
     const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
-    const bool first = (m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
+    const uint64_t mg0 = p.st_mode ? p.st_m0 : 0;  // block streaming: this launch starts at global output frame st_m0 ...
+    const uint64_t g0 = p.st_mode ? p.st_g0 : 0;   // ... and the buffers start at global input frame st_g0
+    const bool first = (mg0 + m0 == 0);  // stream start: x'[-1] = x'[-2] = 0
     const uint32_t Mout = (uint32_t)p.out_frames;
+    const uint32_t col = tile + p.col0;  // this tile's column in the per-source aggregate rows
+    const uint32_t ncol = p.gran_cols;
 
     // ---- input span of this tile (identical for every source) -------------------------------
     uint32_t i_base, nvec;
     {
         uint64_t ib, ie;
         uint32_t nn;
-        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        cursor_resolve(cursor_at(mg0 + m_tile0 >= 2 ? mg0 + m_tile0 - 2 : 0, p), p, ib, nn);
+        ib = ib > g0 ? ib - g0 : 0;  // index inside the buffers
         ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
-        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        cursor_resolve(cursor_at(mg0 + m_tile0 + L - 1, p), p, ie, nn);
+        ie = ie > g0 ? ie - g0 : 0;
         ie += 1;
         uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
         if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
@@ -651,14 +661,14 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     int offA[R + 2];
     float wgt[R + 2];
     {
-        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+        Cursor c = cursor_at(first ? 0 : mg0 + m0 - 2, p);
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
             const bool dummy = first && rr < 2;
             uint64_t i;
             uint32_t num;
             cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * 8u);
             wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
             if (!dummy) cursor_next(c, p);
         }
@@ -669,10 +679,10 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     // of a group, the aggregates of 4 predecessor tiles: lane = src*8 + pred*2 + half (16 B each);
     // NI = ceil(J/4) instructions cover all J predecessors.  Lane l < 32 then owns the 32-byte set
     // (src = l>>2, pred = l&3) of every instruction.
-    const uint32_t Jc = p.J < tile ? p.J : tile;  // uniform: predecessors that exist
+    const uint32_t Jc = p.J < col ? p.J : col;  // uniform: predecessors that exist (streaming: + the block-start state)
     const uint32_t NI = (Jc + 3) >> 2;
     const uint32_t gsrc = lane >> 3, gpred = (lane >> 1) & 3;
-    const uint32_t gr_off0 = gsrc * p.n_tiles * 32u + (Jc - 1 - gpred) * 32u + (lane & 1) * 16u;  // instruction 0; -128 per further one
+    const uint32_t gr_off0 = gsrc * ncol * 32u + (Jc - 1 - gpred) * 32u + (lane & 1) * 16u;  // instruction 0; -128 per further one
     const uint32_t set_src = lane >> 2, set_pred = lane & 3;  // lanes < 32
 
     const Tables *__restrict__ tb = p.tabs;
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
             grp_first = s - 8 * kGroupLag;
             grp_mask = (uint32_t)(mrg >> (8 * kGroupLag - 8)) & 0xffu;  // bit 7-src
             if (Jc > 0 && grp_mask && !dead) {
-                const unsigned long long *gb = p.gran + ((uint64_t)grp_first * p.n_tiles + (tile - Jc)) * 4;
+                const unsigned long long *gb = p.gran + ((uint64_t)grp_first * ncol + (col - Jc)) * 4;
                 const bool src_on = (grp_mask >> (7 - gsrc)) & 1u;
                 for (uint32_t i = 0; i < NI; ++i)
                     if (src_on && gpred + 4 * i < Jc) glds16_sc1(gb, gr_off0 - 128u * i, lds0 + kGranBase + 1024u * i);
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 }
 #ifndef RH_DIAG_NO_CARRY_WAIT  // diagnostic build: free-running tiles (wrong results), to price the lock-step
                 if (!dead && !__all(ok || !want)) {  // a neighbour is more than 8*(kGroupLag-1) sources behind
-                    const unsigned long long *gp = p.gran + ((uint64_t)(grp_first + (want ? set_src : 0)) * p.n_tiles + (tile - 1 - (want ? set_pred + 4 * i : 0))) * 4;
+                    const unsigned long long *gp = p.gran + ((uint64_t)(grp_first + (want ? set_src : 0)) * ncol + (col - 1 - (want ? set_pred + 4 * i : 0))) * 4;
                     poll_sets(gp, want, gv, ok);
                 }
 #endif
@@ -988,7 +998,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                         const bool want = (uint32_t)lane < Jc;
                         unsigned long long gv[4] = {0, 0, 0, 0};
                         bool ok = false;
-                        poll_sets(p.gran + ((uint64_t)s * p.n_tiles + (tile - 1 - (want ? lane : 0))) * 4, want, gv, ok);
+                        poll_sets(p.gran + ((uint64_t)s * ncol + (col - 1 - (want ? lane : 0))) * 4, want, gv, ok);
                         if (want && ok && !dead) {
                             const v4f k4 = *(const lds_f4 *)(lds + kLookBase + lane * 16);
                             const float kM[4] = {k4.x, k4.y, k4.z, k4.w};
@@ -1026,7 +1036,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
             if (lane < 32 && ((pubmask >> (lane >> 2)) & 1u)) {
                 const float ev = *(const RH_LDS float *)(lds + kPubBase + lane * 4);
                 const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
-                __hip_atomic_store(p.gran + ((uint64_t)((s & ~7u) + (lane >> 2)) * p.n_tiles + tile) * 4 + (lane & 3), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.gran + ((uint64_t)((s & ~7u) + (lane >> 2)) * ncol + col) * 4 + (lane & 3), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             pubmask = 0;
         }
@@ -1083,6 +1093,30 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         for (int r = 0; r < R; ++r)
             if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
     }
+}
+
+// Block streaming with per-source filter states (k_rlm_wave): after a block of n_tiles whole tiles, the state of
+// source s at the block's end is what tile n_tiles would have received as its carry -- the look-back over the
+// aggregates the block has just published (and, for short blocks, the previous block-start state in column 0).
+// One lane per source; the result becomes column 0 of the next launch (tagged with ITS epoch).  col_next = 0
+// writes the zero state a stream starts from.
+__global__ __launch_bounds__(64) void k_rlm_state(unsigned long long *gran, const Tables *__restrict__ tabs, uint32_t n_sources, uint32_t ncol, uint32_t col_next, uint32_t J,
+                                                  uint32_t epoch, uint32_t next_epoch) {
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= n_sources) return;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t Jc = J < col_next ? J : col_next;
+    unsigned long long *row = gran + (uint64_t)s * ncol * 4;
+    for (uint32_t j = 0; j < Jc; ++j) {
+        const unsigned long long *g = row + (uint64_t)(col_next - 1 - j) * 4;
+        const unsigned long long g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+        // a source that had ended before that tile published nothing there: it has no state to carry either
+        if ((uint32_t)(g0 >> 32) != epoch || (uint32_t)(g1 >> 32) != epoch || (uint32_t)(g2 >> 32) != epoch || (uint32_t)(g3 >> 32) != epoch) continue;
+        const float kM[4] = {tabs->lookM[j][0], tabs->lookM[j][1], tabs->lookM[j][2], tabs->lookM[j][3]};
+        mat_acc(kM, __uint_as_float((uint32_t)g0), __uint_as_float((uint32_t)g1), c[0], c[1]);
+        mat_acc(kM, __uint_as_float((uint32_t)g2), __uint_as_float((uint32_t)g3), c[2], c[3]);
+    }
+    for (int q = 0; q < 4; ++q) row[q] = ((unsigned long long)next_epoch << 32) | __float_as_uint(c[q]);
 }
 
 // ------------------------------------------------------------------ host side ----
@@ -1228,6 +1262,9 @@ struct rh_rlm {
     int st_cur = 0;
     std::vector<SrcDesc> h_desc;  // host copy of the descriptor table (staging of the async uploads)
     std::vector<float> gains;     // per-source Amplify factors (1.0 when unset)
+    // block streaming with per-source states (rh_rlm_stream_block_v)
+    std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
+    uint32_t st_cols = 0;            // columns of an aggregate row for the stream (0: no such stream yet)
 };
 
 namespace {
@@ -1518,6 +1555,7 @@ struct StreamArgs {
     uint64_t m0 = 0, g0 = 0;
     const float *win = nullptr;
     float *wout = nullptr;
+    uint32_t gran_cols = 0;  // != 0: per-source states (k_rlm_wave), aggregate rows of this many columns, tile 0 in column 1
 };
 static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
                             const StreamArgs &sa = StreamArgs());
@@ -1580,6 +1618,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.st_g0 = sa.g0;
     k.st_win = sa.win;
     k.st_wout = sa.wout;
+    k.gran_cols = sa.gran_cols ? sa.gran_cols : p->n_tiles;
+    k.col0 = sa.gran_cols ? 1u : 0u;
     k.u = pl.uni;
     void *args[] = {&k};
     const uint64_t grid = (uint64_t)p->n_tiles * (batch_streams ? batch_streams : 1);
@@ -1682,6 +1722,8 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     p->st_g0 = p->st_m = 0;
     p->st_nsrc = 0;
     p->st_cur = 0;
+    p->st_total.clear();
+    p->st_cols = 0;
     return RH_OK;
 }
 
@@ -1690,7 +1732,7 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
     RH_REQUIRE_INIT();
     if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
     if (n_sources == 0 || n_sources > p->cfg.max_sources || avail_frames > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
-    if (p->st_nsrc && p->st_nsrc != n_sources) return RH_ERR_INVALID;  // the summed state belongs to one set of sources
+    if (p->st_cols || (p->st_nsrc && p->st_nsrc != n_sources)) return RH_ERR_INVALID;  // the summed state belongs to one set of sources (and one kind of stream)
     *out_frames = 0;
     *consumed_frames = 0;
     const uint64_t F = p->F, T = p->T, R = p->fast.v->R, L = 64 * R;
@@ -1750,6 +1792,119 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
         const uint64_t keep_from = p->st_m >= 2 ? (uint64_t)(((unsigned __int128)(p->st_m - 2) * F) / T) : 0;
         const uint64_t cons = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
         *consumed_frames = cons < avail_frames ? cons : avail_frames;
+        p->st_g0 += *consumed_frames;
+    }
+    *out_frames = out;
+    return RH_OK;
+}
+
+// ---- block streaming with per-source filter states (ragged batches: sources of one clock that end at
+// different times) -- k_rlm_wave, whose look-back is per source anyway.  A block emits whole tiles, so the state
+// that crosses the boundary is a tile carry: k_rlm_state folds the block's aggregates into column 0 of the
+// aggregate rows, where the next launch finds it as the aggregate of a virtual predecessor tile.
+static uint64_t total_out_frames(uint64_t N, uint64_t F, uint64_t T) {  // sample_rate.rs:131-201 in closed form (continuous source)
+    if (N == 0) return 0;
+    const unsigned __int128 num = (unsigned __int128)(N - 1) * T;
+    const uint64_t c1 = (uint64_t)((num + F - 1) / F);
+    return (unsigned __int128)c1 * F < (unsigned __int128)N * T ? c1 + 1 : c1;
+}
+
+rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
+                                uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames || !avail_frames_host || !ended_host) return RH_ERR_INVALID;
+    if (n_sources == 0 || n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
+    if (p->st_nsrc && (p->st_nsrc != n_sources || !p->st_cols)) return RH_ERR_INVALID;  // one set of sources, one kind of stream
+    *out_frames = 0;
+    *consumed_frames = 0;
+    const uint64_t F = p->F, T = p->T, L = 64ull * p->wave.v->R;
+    hipStream_t hs = rh::as_stream(stream);
+    if (!p->st_cols) {  // first block of the stream: size the aggregate rows once (the states live in them), zero states
+        rh::ResampleGeom g;
+        rh_status st = rh::make_resample_geom(p->cfg.max_in_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &g);
+        if (st != RH_OK) return st;
+        const uint64_t cols = (g.out_frames + L - 1) / L + 2;
+        if (cols > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
+        const size_t words = (size_t)p->cfg.max_sources * cols * 4;
+        if (p->filt && words > p->gran_words) {
+            if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
+            p->d_gran = nullptr;
+            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
+            RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));
+            p->gran_words = words;
+        }
+        p->st_cols = (uint32_t)cols;
+        p->st_total.assign(n_sources, ~0ull);
+        if (p->filt) hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
+    }
+    // what every source can still give: a live one every frame whose two taps have arrived, an ended one all it has left
+    uint64_t live_min = ~0ull, ended_max = 0;
+    bool any_live = false;
+    for (uint32_t s = 0; s < n_sources; ++s) {
+        if (avail_frames_host[s] > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
+        if (p->st_total[s] == ~0ull && ended_host[s]) p->st_total[s] = p->st_g0 + avail_frames_host[s];
+        if (p->st_total[s] == ~0ull) {
+            const uint64_t N = p->st_g0 + avail_frames_host[s];
+            const uint64_t m_end = N ? (uint64_t)((((unsigned __int128)(N - 1) * T) + F - 1) / F) : 0;  // every m with floor(m*F/T) <= N-2
+            const uint64_t can = m_end > p->st_m ? m_end - p->st_m : 0;
+            live_min = can < live_min ? can : live_min;
+            any_live = true;
+        } else {
+            const uint64_t M = total_out_frames(p->st_total[s], F, T);
+            const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
+            ended_max = rem > ended_max ? rem : ended_max;
+        }
+    }
+    const bool final_block = !any_live;
+    const uint64_t out = final_block ? ended_max : live_min / L * L;
+    if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
+    if (out > out_capacity_frames) return RH_ERR_CAPACITY;
+    if (out > 0) {
+        if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
+        const uint64_t tiles = (out + L - 1) / L;
+        if (tiles + 1 > p->st_cols) return RH_ERR_CAPACITY;
+        std::vector<SrcDesc> &h = p->h_desc;
+        h.resize(n_sources);
+        for (uint32_t s = 0; s < n_sources; ++s) {
+            uint64_t ms = out;
+            if (p->st_total[s] != ~0ull) {
+                const uint64_t M = total_out_frames(p->st_total[s], F, T);
+                const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
+                ms = rem < out ? rem : out;
+            }
+            if (ms && (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u))) return RH_ERR_INVALID;
+            h[s] = SrcDesc{ms ? srcs_host[s] : nullptr, ms ? (uint32_t)avail_frames_host[s] : 0u, (uint32_t)ms, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+        }
+        RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, hs));
+        p->equal = false;
+        p->n_sources = n_sources;
+        p->out_frames = out;
+        rh_status st = activate_plan(p, &p->wave);  // never reallocates the rows: they were sized for the largest block
+        if (st != RH_OK) return st;
+        StreamArgs sa;
+        sa.mode = final_block ? 2u : 1u;
+        sa.active = (uint32_t)out;
+        sa.m0 = p->st_m;
+        sa.g0 = p->st_g0;
+        sa.gran_cols = p->st_cols;
+        st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
+        if (st != RH_OK) return st;
+        if (!final_block && p->filt)
+            hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)tiles + 1u, (uint32_t)p->wave.J, p->epoch,
+                               p->epoch + 1);
+        p->st_m += out;
+    }
+    p->st_nsrc = n_sources;
+    if (final_block) {
+        p->st_done = true;
+        uint64_t mx = 0;
+        for (uint32_t s = 0; s < n_sources; ++s) mx = avail_frames_host[s] > mx ? avail_frames_host[s] : mx;
+        *consumed_frames = mx;
+    } else {
+        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T).  The
+        // caller drops min(consumed, what it holds) frames of every source.
+        const uint64_t keep_from = p->st_m >= 2 ? (uint64_t)(((unsigned __int128)(p->st_m - 2) * F) / T) : 0;
+        *consumed_frames = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
         p->st_g0 += *consumed_frames;
     }
     *out_frames = out;

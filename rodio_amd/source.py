@@ -614,6 +614,24 @@ class ResampleLowpassMix:
         self._left = [b[c.value * ch:].clone() for b in bufs]
         return out[: m.value * ch]
 
+    def stream_feed_v(self, blocks, ended):
+        """Per-source states: blocks[s] = NEW interleaved samples of source s (any length, also empty), ended[s] = it
+        will deliver no more.  Returns the mixed frames this block could emit (whole tiles until all have ended)."""
+        torch = _t()
+        ch = self.channels
+        bufs = list(blocks) if self._left is None else [torch.cat([l, b]) if b.numel() else l for l, b in zip(self._left, blocks)]
+        n = len(bufs)
+        avail = (C.c_uint64 * n)(*[b.numel() // ch for b in bufs])
+        end = (C.c_uint8 * n)(*[1 if e else 0 for e in ended])
+        ptrs = (C.c_void_p * n)(*[b.data_ptr() if b.numel() else 0 for b in bufs])
+        cap = int(max(avail) * (self.cfg.to_rate / self.cfg.from_rate + 1)) + 64
+        out = _dev_empty(max(cap * ch, 4))
+        m, c = C.c_uint64(0), C.c_uint64(0)
+        check(lib.rh_rlm_stream_block_v(self._h, ptrs, avail, end, n, _ptr(out), cap, C.byref(m), C.byref(c), _stream()), "rh_rlm_stream_block_v")
+        self._keep = bufs  # the launch reads them asynchronously
+        self._left = [b[min(c.value * ch, b.numel()):].clone() for b in bufs]
+        return out[: m.value * ch]
+
     def run_batch(self):
         """No mixing: returns [S, out_frames*channels], row s = UniformSourceIterator(src_s).low_pass(...)."""
         torch = _t()

@@ -747,6 +747,43 @@ def test_fused_block_streaming_equals_one_pass(G, O, filt, freq, R):
     p.close()
 
 
+@pytest.mark.parametrize("filt,freq,R", [("low_pass", 200, 8), ("high_pass", 300, 4), ("low_pass", 1000, 6), (None, 0, 6)])
+def test_fused_block_streaming_per_source_states(G, O, filt, freq, R):
+    # rh_rlm_stream_block_v: sources that end at different times, fed block by block; each keeps its own filter state
+    # across the blocks.  The concatenation equals the one-pass mix of the ragged batch.
+    import torch
+
+    ns = [50000, 31000, 12345, 50000, 147, 0, 49999, 2, 20480, 40001, 50000]
+    gains = np.linspace(0.5, 1.2, len(ns)).astype(np.float32)
+    xs = [rnd(2500 + i, 2 * n, 0.1) for i, n in enumerate(ns)]
+    ref = _oracle_pipeline_gains(O, xs, gains, 44100, 48000, None, filt, freq)
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=len(ns), max_in_frames=max(ns), frames_per_lane=R)
+    p.set_gains(gains)
+    xd = [torch.from_numpy(x).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs]
+    p.set_sources(xd)
+    one = p.run().cpu().numpy().copy()
+    p.check_status()
+    assert p.geometry()["general_kernel"] == 1
+    rng = np.random.default_rng(99 + R)
+    for trial in range(3):
+        cuts = [0] + sorted(set(int(c) for c in rng.integers(1, max(ns), size=[1, 5, 20][trial]))) + [max(ns)]
+        p.stream_begin()
+        outs = []
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k], cuts[k + 1]
+            outs.append(p.stream_feed_v([x[2 * min(lo, n): 2 * min(hi, n)] for x, n in zip(xd, ns)], [n <= hi for n in ns]))
+        p.check_status()
+        got = torch.cat(outs).cpu().numpy()
+        assert len(got) == len(ref), (trial, len(got), len(ref))
+        if filt is None:
+            assert np.array_equal(got, ref)
+        else:
+            d1, d2 = float(np.max(np.abs(got - one))), float(np.max(np.abs(got - ref)))
+            print(f"[stream_v {filt}{freq} R{R} blocks={len(cuts) - 1}] |stream-onepass|={d1:.2e} |stream-oracle|={d2:.2e}")
+            assert d1 <= 1e-6 and d2 <= TOL
+    p.close()
+
+
 # ------------------------------------------------- per-source gains folded into the fused kernel ----
 def _oracle_pipeline_gains(O, xs, gains, frm, to, span, filt, freq):
     """mixer.add(UniformSourceIterator(src.amplify(g)).low_pass(f)) -- rodio's per-source volume."""

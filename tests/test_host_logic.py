@@ -143,6 +143,12 @@ def test_out_frames_property_random_rates(rh, O):
         if span_eff and min(span_eff, 32768) % ch:  # uniform.rs:56 would cut a frame in two: rejected (RH_ERR_UNSUPPORTED)
             assert _out_frames(rh, n, frm, to, ch, span_eff)[0] == 3
             return
+        import math
+
+        gg = math.gcd(frm, to)
+        if (frm // gg) * (to // gg) > 0xFFFFFFFF:  # the reference's u32 position arithmetic would overflow (sample_rate.rs:45-47): rejected
+            assert _out_frames(rh, n, frm, to, ch, span_eff)[0] == 3
+            return
         x = np.arange(n * ch, dtype=np.float32)
         if span_eff:
             ref = O.UniformSourceIterator(O.SpanSource(x, ch, frm, span_eff), ch, to).collect()
