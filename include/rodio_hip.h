@@ -53,6 +53,11 @@ rh_status rh_free(void *p);
 rh_status rh_memset(void *p, int32_t value, size_t bytes, rh_stream stream);
 rh_status rh_memcpy_h2d(void *dst, const void *src_host, size_t bytes, rh_stream stream);
 rh_status rh_memcpy_d2h(void *dst_host, const void *src, size_t bytes, rh_stream stream);
+/* For a pull-model shim (include/rodio_hip.hpp): page-locked host blocks, copies that do not synchronise. */
+rh_status rh_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, rh_stream stream);
+rh_status rh_memcpy_d2d(void *dst, const void *src, size_t bytes, rh_stream stream);
+rh_status rh_host_alloc(void **out, size_t bytes);
+rh_status rh_host_free(void *p);
 rh_status rh_stream_create(rh_stream *out);
 rh_status rh_stream_destroy(rh_stream s);
 rh_status rh_stream_synchronize(rh_stream s);
@@ -60,6 +65,7 @@ rh_status rh_stream_synchronize(rh_stream s);
 rh_status rh_event_create(void **out);
 rh_status rh_event_destroy(void *ev);
 rh_status rh_event_record(void *ev, rh_stream stream);
+rh_status rh_event_synchronize(void *ev);
 rh_status rh_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
 
 /* ---- SampleTypeConverter ("DataConverter") ---------------------------------------------

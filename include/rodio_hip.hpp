@@ -1,0 +1,584 @@
+// rodio_hip.hpp -- C++17 host-side mirror of rodio's `Source` interface over the C ABI of rodio_hip.h.
+//
+// rodio is compiled code whose extension point is the trait `Source: Iterator<Item = f32>`
+// (/root/reference/src/source/mod.rs:179-218): anything that implements it can be handed to
+// `Mixer::add` (src/mixer.rs:58-66), `Player::append` (src/player.rs:104-108) or `queue.append`
+// (src/queue.rs:62-70).  This header is that boundary for a C++ host (and the model for the Rust shim of
+// INTEGRATION.md): pull-model adapters that own their upstream by value, pre-pull a block, run it
+// through librodio_hip.so on the GPU and serve `next()` from page-locked memory, one block ahead.
+//
+//   GpuSource  one upstream + a chain of adapters built with rodio's method names
+//              (amplify, low_pass, high_pass, reverb, channel_volume, limit, automatic_gain_control, ...)
+//   GpuMixer   mixer::mixer(2, rate) where every added source goes through
+//              UniformSourceIterator(.., 2, rate) [.low_pass(f) / .high_pass(f)] [.amplify(g)] and the ordered sum:
+//              the fused kernel, block by block, one filter state per source (rh_rlm_stream_block_v)
+//
+// Header-only; needs nothing but rodio_hip.h and librodio_hip.so.  There is no CPU compute path: every
+// arithmetic operation on samples happens in the library; a missing GPU surfaces as rodio_hip::Error.
+// One object is used from one thread at a time (rodio: `Send`, not `Sync`).
+#ifndef RODIO_HIP_HPP
+#define RODIO_HIP_HPP
+
+#include <algorithm>
+#include <chrono>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rodio_hip.h"
+
+namespace rodio_hip {
+
+class Error : public std::runtime_error {
+public:
+    Error(rh_status st, const std::string &what) : std::runtime_error(what + ": " + rh_status_string(st) + hip_detail(st)), status(st) {}
+    rh_status status;
+
+private:
+    static std::string hip_detail(rh_status st) { return st == RH_ERR_HIP ? std::string(" (") + rh_last_hip_error() + ")" : std::string(); }
+};
+inline void check(rh_status st, const char *what) {
+    if (st != RH_OK) throw Error(st, what);
+}
+/// Binds the library to a gfx950 device (once per process).
+inline void init(int device = 0) { check(rh_init(device), "rh_init"); }
+
+using Nanos = std::chrono::nanoseconds;
+
+// ---------------------------------------------------------------- trait Source (source/mod.rs:179-218) ----
+class Source {
+public:
+    virtual ~Source() = default;
+    /// `Iterator::next`: the next interleaved sample, or nullopt at the end of the stream (never an error).
+    virtual std::optional<float> next() = 0;
+    virtual std::optional<std::size_t> current_span_len() const { return std::nullopt; }
+    virtual std::uint16_t channels() const = 0;
+    virtual std::uint32_t sample_rate() const = 0;
+    virtual std::optional<Nanos> total_duration() const { return std::nullopt; }
+    /// `try_seek`: false == SeekError::NotSupported (source/mod.rs:766-787).
+    virtual bool try_seek(Nanos) { return false; }
+    /// Bulk form of next() that block adapters pull with; the default is the per-sample loop.
+    virtual std::size_t read(float *dst, std::size_t n) {
+        std::size_t k = 0;
+        for (; k < n; ++k) {
+            const std::optional<float> v = next();
+            if (!v) break;
+            dst[k] = *v;
+        }
+        return k;
+    }
+};
+using BoxSource = std::unique_ptr<Source>;
+
+/// buffer.rs:20-71: a source over samples held in memory.
+class SamplesBuffer : public Source {
+public:
+    SamplesBuffer(std::uint16_t channels, std::uint32_t sample_rate, std::vector<float> data) : ch_(channels), rate_(sample_rate), data_(std::move(data)) {
+        if (!channels || !sample_rate) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
+    }
+    std::optional<float> next() override { return pos_ < data_.size() ? std::optional<float>(data_[pos_++]) : std::nullopt; }
+    std::size_t read(float *dst, std::size_t n) override {
+        const std::size_t k = std::min(n, data_.size() - pos_);
+        std::memcpy(dst, data_.data() + pos_, k * sizeof(float));
+        pos_ += k;
+        return k;
+    }
+    std::uint16_t channels() const override { return ch_; }
+    std::uint32_t sample_rate() const override { return rate_; }
+    std::optional<Nanos> total_duration() const override {
+        return Nanos((std::int64_t)((data_.size() / ch_) * 1000000000ull / rate_));
+    }
+
+private:
+    std::uint16_t ch_;
+    std::uint32_t rate_;
+    std::vector<float> data_;
+    std::size_t pos_ = 0;
+};
+
+// ---------------------------------------------------------------- device plumbing ----
+namespace detail {
+class DeviceBuf {
+public:
+    DeviceBuf() = default;
+    explicit DeviceBuf(std::size_t floats) { reset(floats); }
+    DeviceBuf(const DeviceBuf &) = delete;
+    DeviceBuf &operator=(const DeviceBuf &) = delete;
+    ~DeviceBuf() {
+        if (p_) (void)rh_free(p_);
+    }
+    void reset(std::size_t floats) {
+        if (floats <= n_) return;
+        if (p_) check(rh_free(p_), "rh_free");
+        p_ = nullptr;
+        check(rh_malloc(&p_, floats * sizeof(float)), "rh_malloc");
+        n_ = floats;
+    }
+    float *get() const { return static_cast<float *>(p_); }
+    std::size_t size() const { return n_; }
+
+private:
+    void *p_ = nullptr;
+    std::size_t n_ = 0;
+};
+class PinnedBuf {
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() {
+        if (p_) (void)rh_host_free(p_);
+    }
+    void reset(std::size_t floats) {
+        if (floats <= n_) return;
+        if (p_) check(rh_host_free(p_), "rh_host_free");
+        p_ = nullptr;
+        check(rh_host_alloc(&p_, floats * sizeof(float)), "rh_host_alloc");
+        n_ = floats;
+    }
+    float *get() const { return static_cast<float *>(p_); }
+    std::size_t size() const { return n_; }
+
+private:
+    void *p_ = nullptr;
+    std::size_t n_ = 0;
+};
+
+/// What every GPU-backed source shares: two page-locked result blocks, one served while the other is in
+/// flight.  A subclass implements enqueue(): pull upstream, copy in, launch, copy out -- all asynchronous on
+/// `stream_`; the sizes are known on the host when it returns.
+class BlockPump : public Source {
+public:
+    BlockPump() {
+        check(rh_stream_create(&stream_), "rh_stream_create");
+        for (Slot &s : slot_) check(rh_event_create(&s.done), "rh_event_create");
+    }
+    ~BlockPump() override {
+        (void)rh_stream_synchronize(stream_);
+        for (Slot &s : slot_)
+            if (s.done) (void)rh_event_destroy(s.done);
+        (void)rh_stream_destroy(stream_);
+    }
+    std::optional<float> next() override {
+        while (pos_ == cur().n) {
+            if (!advance()) return std::nullopt;
+        }
+        return cur().out.get()[pos_++];
+    }
+    std::size_t read(float *dst, std::size_t n) override {
+        std::size_t k = 0;
+        while (k < n) {
+            if (pos_ == cur().n && !advance()) break;
+            const std::size_t take = std::min(n - k, cur().n - pos_);
+            std::memcpy(dst + k, cur().out.get() + pos_, take * sizeof(float));
+            pos_ += take;
+            k += take;
+        }
+        return k;
+    }
+
+protected:
+    struct Slot {
+        PinnedBuf in, out;  // staging of the pulled samples / the processed block
+        std::size_t n = 0;  // samples in `out`
+        bool last = false;  // upstream ended with this block
+        void *done = nullptr;
+    };
+    /// Fills `s` (n, last) and enqueues everything that produces s.out on stream_.
+    virtual void enqueue(Slot &s) = 0;
+    rh_stream stream_ = nullptr;
+
+private:
+    Slot &cur() { return slot_[cur_]; }
+    void submit(Slot &s) {
+        enqueue(s);
+        check(rh_event_record(s.done, stream_), "rh_event_record");
+    }
+    bool advance() {
+        if (ended_) return false;
+        if (!primed_) {
+            submit(slot_[0]);
+            primed_ = true;
+            cur_ = 0;
+        } else {
+            if (cur().last) {
+                ended_ = true;
+                return false;
+            }
+            cur_ ^= 1;  // the block that was enqueued while the previous one was being served
+        }
+        check(rh_event_synchronize(cur().done), "rh_event_synchronize");
+        pos_ = 0;
+        if (!cur().last) submit(slot_[cur_ ^ 1]);  // prefetch: pull and process one block ahead
+        return true;
+    }
+    Slot slot_[2];
+    int cur_ = 0;
+    std::size_t pos_ = 0;
+    bool primed_ = false, ended_ = false;
+};
+}  // namespace detail
+
+// ---------------------------------------------------------------- GpuSource: adapter chain on one upstream ----
+/// `upstream.amplify(..).low_pass(..)...` with the chain executed block-wise on the GPU.  Adapters with
+/// memory (filters, limiter, AGC, reverb, converters) carry it across blocks: any block size gives the bits
+/// of one pass.  The upstream must keep its format (a source whose channels()/sample_rate() change
+/// mid-stream is what UniformSourceIterator is for: convert first).
+class GpuSource : public detail::BlockPump {
+public:
+    explicit GpuSource(BoxSource upstream, std::size_t block_frames = 1u << 15) : up_(std::move(upstream)), block_frames_(block_frames ? block_frames : 1) {
+        if (!up_) throw std::invalid_argument("upstream");
+        ch_ = up_->channels();
+        rate_ = up_->sample_rate();
+    }
+    // -- Source
+    std::uint16_t channels() const override { return ch_; }
+    std::uint32_t sample_rate() const override { return rate_; }
+    Source &inner() { return *up_; }
+    BoxSource into_inner() { return std::move(up_); }
+
+    // -- builder methods (source/mod.rs:255-731); call before the first next()
+    GpuSource &amplify(float factor) {  // amplify.rs:64
+        return push([factor](Ctx &c) { check(rh_amplify(c.out, c.in, c.n, factor, c.stream), "rh_amplify"); return c.n; });
+    }
+    GpuSource &distortion(float gain, float threshold) {  // distortion.rs:66-72
+        return push([=](Ctx &c) { check(rh_distortion(c.out, c.in, c.n, gain, threshold, c.stream), "rh_distortion"); return c.n; });
+    }
+    GpuSource &low_pass(std::uint32_t freq) { return blt(0, freq, 0.5f); }   // blt.rs:11-16
+    GpuSource &high_pass(std::uint32_t freq) { return blt(1, freq, 0.5f); }  // blt.rs:18-24
+    GpuSource &low_pass_with_q(std::uint32_t freq, float q) { return blt(0, freq, q); }
+    GpuSource &high_pass_with_q(std::uint32_t freq, float q) { return blt(1, freq, q); }
+    GpuSource &reverb(Nanos duration, float amplitude) {  // source/mod.rs:628-634
+        const std::uint64_t d = rh_delay_samples((std::uint64_t)duration.count(), rate_, ch_);
+        auto h = std::make_shared<Handle<rh_echo>>();
+        check(rh_echo_create(&h->p, d, amplitude), "rh_echo_create");
+        h->destroy = [](rh_echo *e) { (void)rh_echo_destroy(e); };
+        return push(
+            [h, d](Ctx &c) {
+                if (c.n) check(rh_echo_process(h->p, c.out, c.in, c.n, c.stream), "rh_echo_process");
+                if (!c.flush) return c.n;
+                if (d) check(rh_echo_flush(h->p, c.out + c.n, c.stream), "rh_echo_flush");  // the delayed clone outlives the source
+                return c.n + (std::size_t)d;
+            },
+            [d](std::size_t n) { return n + (std::size_t)d; });
+    }
+    GpuSource &channel_volume(std::vector<float> gains) {  // channel_volume.rs:71-88
+        const std::uint16_t in_ch = ch_;
+        const std::uint16_t out_ch = (std::uint16_t)gains.size();
+        if (!out_ch) throw std::invalid_argument("channel_volume: no output channels");
+        push([gains, in_ch, out_ch](Ctx &c) {
+            const std::size_t frames = c.n / in_ch;
+            check(rh_channel_volume(c.out, c.in, frames, in_ch, gains.data(), out_ch, c.stream), "rh_channel_volume");
+            return frames * out_ch;
+        }, [in_ch, out_ch](std::size_t n) { return n / in_ch * out_ch; });
+        ch_ = out_ch;
+        return *this;
+    }
+    GpuSource &spatial(const float emitter[3], const float left_ear[3], const float right_ear[3]) {  // spatial.rs:19-24,48-69
+        float g[2];
+        check(rh_spatial_gains(emitter, left_ear, right_ear, g), "rh_spatial_gains");
+        return channel_volume({g[0], g[1]});
+    }
+    GpuSource &convert_channels(std::uint16_t to) {  // ChannelCountConverter, channels.rs:57-85
+        const std::uint16_t from = ch_;
+        if (!to) throw std::invalid_argument("channels are NonZero in rodio");
+        push([from, to](Ctx &c) {
+            const std::size_t frames = c.n / from;
+            check(rh_channels_convert(c.out, c.in, frames, from, to, c.stream), "rh_channels_convert");
+            return frames * to;
+        }, [from, to](std::size_t n) { return n / from * to; });
+        ch_ = to;
+        return *this;
+    }
+    GpuSource &convert_sample_rate(std::uint32_t to) {  // SampleRateConverter, sample_rate.rs:52-201
+        const std::uint32_t from = rate_;
+        const std::uint16_t ch = ch_;
+        if (!to) throw std::invalid_argument("sample_rate is NonZero in rodio");
+        if (from == to) return *this;  // sample_rate.rs:133-136
+        auto h = std::make_shared<Handle<rh_resampler>>();
+        check(rh_resampler_create(&h->p, from, to, ch), "rh_resampler_create");
+        h->destroy = [](rh_resampler *r) { (void)rh_resampler_destroy(r); };
+        push([h, ch](Ctx &c) {
+            std::uint64_t m = 0;
+            check(rh_resampler_process(h->p, c.out, c.out_cap / ch, c.in, c.n / ch, c.flush ? 1 : 0, &m, c.stream), "rh_resampler_process");
+            return (std::size_t)m * ch;
+        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 2) * to / from + 2) * ch; });
+        rate_ = to;
+        return *this;
+    }
+    /// UniformSourceIterator::new(src, channels, rate) for a continuous source (uniform.rs:78-97: channels first, then rate).
+    GpuSource &uniform(std::uint16_t channels, std::uint32_t sample_rate) {
+        if (channels != ch_) convert_channels(channels);
+        return convert_sample_rate(sample_rate);
+    }
+    GpuSource &limit(const rh_limit_params &settings) {  // limit.rs:94-130,853-988
+        const std::uint16_t ch = ch_;
+        const std::uint32_t rate = rate_;
+        auto st = state(2u * ch);
+        return push([=](Ctx &c) {
+            check(rh_limit(c.out, c.in, c.n / ch, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
+            return c.n / ch * ch;
+        });
+    }
+    GpuSource &automatic_gain_control(const rh_agc_params &settings) {  // agc.rs:133-171,397-504
+        const std::uint32_t rate = rate_;
+        auto st = std::make_shared<detail::DeviceBuf>(rh_agc_state_floats());
+        check(rh_agc_state_init(st->get(), 1, stream_), "rh_agc_state_init");
+        return push([=](Ctx &c) {
+            check(rh_agc(c.out, c.in, c.n, rate, 1, &settings, st->get(), c.stream), "rh_agc");
+            return c.n;
+        });
+    }
+    GpuSource &linear_gain_ramp(Nanos duration, float start_gain, float end_gain, bool clamp_end) {  // linear_ramp.rs:79-110
+        const std::uint16_t ch = ch_;
+        const std::uint32_t rate = rate_;
+        auto pos = std::make_shared<std::uint64_t>(0);
+        return push([=](Ctx &c) {
+            check(rh_linear_gain_ramp(c.out, c.in, c.n, *pos, ch, rate, (std::uint64_t)duration.count(), start_gain, end_gain, clamp_end ? 1 : 0, c.stream), "rh_linear_gain_ramp");
+            *pos += c.n;
+            return c.n;
+        });
+    }
+    GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13
+    GpuSource &fade_out(Nanos duration) { return linear_gain_ramp(duration, 1.0f, 0.0f, true); }  // fadeout.rs:13
+
+protected:
+    void enqueue(Slot &s) override {
+        const std::size_t want = block_frames_ * up_->channels();
+        s.in.reset(want);
+        if (up_->channels() != in_ch() || up_->sample_rate() != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
+        std::size_t n = up_->read(s.in.get(), want);
+        n -= n % up_->channels();  // sources end on frame boundaries (source/mod.rs:169-178)
+        const bool flush = n < want;
+        // capacity of the ping-pong buffers: the largest block any stage can emit
+        std::size_t cap = want, m = want;
+        for (const Stage &st : stages_) cap = std::max(cap, m = st.bound(m));
+        cap = ((cap + 3) & ~std::size_t(3)) + 64;  // + room for one padding frame
+        a_.reset(cap);
+        b_.reset(cap);
+        s.out.reset(cap);
+        float *cur = a_.get(), *oth = b_.get();
+        if (n) check(rh_memcpy_h2d(cur, s.in.get(), n * sizeof(float), stream_), "rh_memcpy_h2d");
+        for (Stage &st : stages_) {
+            Ctx c{oth, cur, n, cap, flush, stream_};
+            n = st.run(c);
+            std::swap(cur, oth);
+        }
+        if (n) check(rh_memcpy_d2h_async(s.out.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
+        s.n = n;
+        s.last = flush;
+    }
+
+private:
+    struct Ctx {
+        float *out;
+        const float *in;
+        std::size_t n, out_cap;
+        bool flush;
+        rh_stream stream;
+    };
+    struct Stage {
+        std::function<std::size_t(Ctx &)> run;
+        std::function<std::size_t(std::size_t)> bound;
+    };
+    template <class T>
+    struct Handle {
+        T *p = nullptr;
+        void (*destroy)(T *) = nullptr;
+        ~Handle() {
+            if (p && destroy) destroy(p);
+        }
+    };
+    template <class F>
+    GpuSource &push(F run) {
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }});
+        return *this;
+    }
+    template <class F, class B>
+    GpuSource &push(F run, B bound) {
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound)});
+        return *this;
+    }
+    std::shared_ptr<detail::DeviceBuf> state(std::size_t floats) {
+        auto st = std::make_shared<detail::DeviceBuf>(floats);
+        check(rh_memset(st->get(), 0, floats * sizeof(float), stream_), "rh_memset");
+        return st;
+    }
+    GpuSource &blt(int kind, std::uint32_t freq, float q) {  // blt.rs:502-544,558-560 -- same operation order, bit for bit
+        const std::uint16_t ch = ch_;
+        float co[5];
+        check(rh_biquad_coeffs(kind, freq, q, rate_, co), "rh_biquad_coeffs");
+        std::vector<float> coeffs(co, co + 5);
+        auto st = state(4u * ch);
+        return push([=](Ctx &c) {
+            std::size_t frames = c.n / ch;
+            const std::size_t rem = c.n % ch;
+            if (rem && c.flush) {  // a stream can end inside a frame (reverb with an odd delay): blt.rs:431-451 still filters those samples
+                check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
+                frames += 1;       // the zero padding only touches channels the stream no longer has
+            }
+            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), 0, c.stream), "rh_biquad");
+            return rem && c.flush ? c.n : frames * ch;
+        });
+    }
+    std::uint16_t in_ch() const { return in_ch_ ? in_ch_ : (in_ch_ = up_->channels()); }
+    std::uint32_t in_rate() const { return in_rate_ ? in_rate_ : (in_rate_ = up_->sample_rate()); }
+
+    BoxSource up_;
+    std::size_t block_frames_;
+    std::uint16_t ch_ = 0;
+    std::uint32_t rate_ = 0;
+    mutable std::uint16_t in_ch_ = 0;
+    mutable std::uint32_t in_rate_ = 0;
+    std::vector<Stage> stages_;
+    detail::DeviceBuf a_, b_;
+};
+
+// ---------------------------------------------------------------- GpuMixer: the fused mixer path ----
+/// What rodio spells
+///     let (mixer, mixed) = mixer::mixer(nz!(2), rate);
+///     mixer.add(UniformSourceIterator::new(src.amplify(g), nz!(2), rate).low_pass(f));   // per source
+/// as ONE source: every block is one launch of the fused kernel (resample + filter + ordered sum), each source
+/// keeping its own converter position and filter state across blocks; sources end when they end.
+/// Sources are stereo and share one input rate (what the fused kernel covers; other layouts go through
+/// GpuSource::uniform first) and join before the first next(): they run on one clock (mixer.rs:120-136 admits
+/// later sources at the next frame; a shim that needs that starts a second GpuMixer and sums the two).
+class GpuMixer : public detail::BlockPump {
+public:
+    struct Options {
+        std::size_t block_frames = 1u << 15;  // input frames pulled per source and block
+        int filter_kind = -1;                 // -1 none, 0 low_pass, 1 high_pass (q = 0.5, blt.rs:11-24)
+        std::uint32_t filter_freq = 0;
+        float filter_q = 0.5f;
+        std::uint32_t frames_per_lane = 0;    // 0 = the library's choice
+    };
+    GpuMixer(std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt) {
+        if (!sample_rate) throw std::invalid_argument("sample_rate is NonZero in rodio");
+        if (!opt_.block_frames) opt_.block_frames = 1;
+    }
+    explicit GpuMixer(std::uint32_t sample_rate) : GpuMixer(sample_rate, Options()) {}
+    ~GpuMixer() override {
+        (void)rh_stream_synchronize(stream_);
+        if (plan_) (void)rh_rlm_destroy(plan_);
+    }
+    /// Mixer::add (mixer.rs:58-66), with the source's volume.
+    void add(BoxSource src, float gain = 1.0f) {
+        if (!src) throw std::invalid_argument("source");
+        if (plan_) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer::add after the stream started");
+        if (src->channels() != 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: stereo sources (convert with GpuSource::uniform first)");
+        if (!srcs_.empty() && src->sample_rate() != srcs_.front().up->sample_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: one input rate per mixer");
+        srcs_.push_back(Src{std::move(src), gain, {}, false});
+    }
+    std::uint16_t channels() const override { return 2; }
+    std::uint32_t sample_rate() const override { return rate_; }
+    std::size_t sources() const { return srcs_.size(); }
+
+protected:
+    void enqueue(Slot &s) override {
+        if (srcs_.empty()) {  // mixer.rs:139-141: a mixer without sources is an ended stream here (nothing to pull)
+            s.n = 0;
+            s.last = true;
+            return;
+        }
+        if (!plan_) start();
+        const std::size_t S = srcs_.size();
+        // pull one block per live source behind the frames the previous block left unconsumed
+        std::size_t max_frames = 0;
+        for (Src &x : srcs_) {
+            if (!x.ended) {
+                const std::size_t old = x.held.size(), want = opt_.block_frames * 2;
+                x.held.resize(old + want);
+                std::size_t got = x.up->read(x.held.data() + old, want);
+                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
+                x.held.resize(old + got);
+                x.ended = got < want;
+            }
+            max_frames = std::max(max_frames, x.held.size() / 2);
+        }
+        if (max_frames > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
+        s.in.reset(S * row_);
+        s.out.reset(out_cap_frames_ * 2);
+        din_.reset(S * row_);
+        std::vector<const float *> ptrs(S);
+        std::vector<std::uint64_t> avail(S);
+        std::vector<std::uint8_t> ended(S);
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = srcs_[i];
+            std::memcpy(s.in.get() + i * row_, x.held.data(), x.held.size() * sizeof(float));
+            ptrs[i] = din_.get() + i * row_;
+            avail[i] = x.held.size() / 2;
+            ended[i] = x.ended ? 1 : 0;
+        }
+        // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
+        check(rh_memcpy_h2d(din_.get(), s.in.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
+        std::uint64_t out = 0, consumed = 0;
+        check(rh_rlm_stream_block_v(plan_, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, dout_.get(), out_cap_frames_, &out, &consumed, stream_), "rh_rlm_stream_block_v");
+        if (out) check(rh_memcpy_d2h_async(s.out.get(), dout_.get(), out * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+        bool all_ended = true;
+        for (Src &x : srcs_) {
+            const std::size_t drop = std::min<std::size_t>(consumed * 2, x.held.size());
+            x.held.erase(x.held.begin(), x.held.begin() + (std::ptrdiff_t)drop);
+            all_ended = all_ended && x.ended;
+        }
+        s.n = (std::size_t)out * 2;
+        s.last = all_ended;  // the call that saw every source ended emitted everything that was left
+    }
+
+private:
+    struct Src {
+        BoxSource up;
+        float gain;
+        std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved)
+        bool ended;
+    };
+    void start() {
+        const std::uint32_t from = srcs_.front().up->sample_rate();
+        rh_rlm_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.from_rate = from;
+        cfg.to_rate = rate_;
+        cfg.channels = 2;
+        cfg.span_len = 0;
+        cfg.filter_kind = opt_.filter_kind;
+        cfg.filter_freq = opt_.filter_freq;
+        cfg.filter_q = opt_.filter_q;
+        if (from == rate_) {  // sample_rate.rs:133-136: the converter passes through; the plan then takes explicit coefficients
+            cfg.filter_kind = 2;
+            cfg.custom_coeffs[0] = 1.0f;  // identity when there is no filter
+            if (opt_.filter_kind >= 0) check(rh_biquad_coeffs(opt_.filter_kind, opt_.filter_freq, opt_.filter_q, rate_, cfg.custom_coeffs), "rh_biquad_coeffs");
+        }
+        cfg.max_sources = (std::uint32_t)srcs_.size();
+        // a block can hold what the previous one left over: less than two tiles' worth of input
+        cap_frames_ = opt_.block_frames + 4096;
+        cfg.max_in_frames = cap_frames_;
+        cfg.frames_per_lane = opt_.frames_per_lane;
+        check(rh_rlm_create(&plan_, &cfg), "rh_rlm_create");
+        std::vector<float> gains;
+        for (const Src &x : srcs_) gains.push_back(x.gain);
+        check(rh_rlm_set_gains(plan_, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
+        check(rh_rlm_stream_begin(plan_), "rh_rlm_stream_begin");
+        row_ = (cap_frames_ * 2 + 3) & ~std::size_t(3);  // 16-byte aligned rows
+        std::uint64_t m = 0;
+        check(rh_resample_out_frames(cap_frames_, from, rate_, 2, 0, &m), "rh_resample_out_frames");
+        out_cap_frames_ = m + 64;
+        dout_.reset(out_cap_frames_ * 2);
+    }
+
+    std::uint32_t rate_;
+    Options opt_;
+    std::vector<Src> srcs_;
+    rh_rlm *plan_ = nullptr;
+    std::size_t cap_frames_ = 0, row_ = 0;
+    std::uint64_t out_cap_frames_ = 0;
+    detail::DeviceBuf din_, dout_;
+};
+
+}  // namespace rodio_hip
+#endif  // RODIO_HIP_HPP

@@ -62,7 +62,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
+    build_host_mirror_test(force, run)
     return LIB
+
+
+def build_host_mirror_test(force: bool, run) -> str:
+    """The C++ host mirror (include/rodio_hip.hpp) is header-only; its test driver is a plain g++ program over
+    the C ABI -- no HIP headers, the way a host application links the library."""
+    root = os.path.join(HERE, "..")
+    src = os.path.join(root, "tests", "cpp", "host_mirror_test.cpp")
+    exe = os.path.join(root, "tests", "cpp", "host_mirror_test")
+    deps = [src, os.path.join(root, "include", "rodio_hip.hpp"), os.path.join(root, "include", "rodio_hip.h"), LIB]
+    if force or _stale(exe, deps):
+        run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lrodio_hip",
+             "-Wl,-rpath,$ORIGIN/../../rodio_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    return exe
 
 
 if __name__ == "__main__":

@@ -94,6 +94,29 @@ rh_status rh_memcpy_d2h(void *dst_host, const void *src, size_t bytes, rh_stream
     RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(stream)));
     return RH_OK;
 }
+rh_status rh_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, rh::as_stream(stream)));
+    return RH_OK;
+}
+rh_status rh_memcpy_d2d(void *dst, const void *src, size_t bytes, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rh::as_stream(stream)));
+    return RH_OK;
+}
+rh_status rh_host_alloc(void **out, size_t bytes) {
+    RH_REQUIRE_INIT();
+    if (!out) return RH_ERR_INVALID;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return RH_ERR_NOMEM;
+    RH_HIP_TRY(e);
+    return RH_OK;
+}
+rh_status rh_host_free(void *p) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipHostFree(p));
+    return RH_OK;
+}
 rh_status rh_stream_create(rh_stream *out) {
     RH_REQUIRE_INIT();
     hipStream_t s;
@@ -126,6 +149,11 @@ rh_status rh_event_destroy(void *ev) {
 rh_status rh_event_record(void *ev, rh_stream stream) {
     RH_REQUIRE_INIT();
     RH_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), rh::as_stream(stream)));
+    return RH_OK;
+}
+rh_status rh_event_synchronize(void *ev) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
     return RH_OK;
 }
 rh_status rh_event_elapsed_ms(void *start, void *stop, float *ms) {

@@ -1,0 +1,171 @@
+// Driver for tests/test_host_mirror.py: runs rodio-style pull chains through include/rodio_hip.hpp (the C++
+// host mirror over the C ABI) on raw f32 files and writes what `next()` returned.  Test infrastructure:
+// the expected values come from the oracle on the Python side.
+//
+//   host_mirror_test mixer <dir> <S> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
+//       <dir>/src_<i>.f32 (stereo, interleaved), <dir>/gains.f32  ->  <dir>/out.f32
+//   host_mirror_test bench <S> <frames> <block_frames>
+//       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
+//   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
+//       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE
+//       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T channel_volume:G0,G1,.. spatial
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "rodio_hip.hpp"
+
+namespace rh = rodio_hip;
+
+static std::vector<float> read_f32(const std::string &path) {
+    std::vector<float> v;
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n / 4);
+    if (n && std::fread(v.data(), 4, v.size(), f) != v.size()) throw std::runtime_error("short read " + path);
+    std::fclose(f);
+    return v;
+}
+static void write_f32(const std::string &path, const std::vector<float> &v) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    if (!v.empty()) std::fwrite(v.data(), 4, v.size(), f);
+    std::fclose(f);
+}
+static std::vector<std::string> split(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    std::stringstream ss(s);
+    std::string item;
+    while (std::getline(ss, item, sep)) out.push_back(item);
+    return out;
+}
+// the consumer: like the cpal callback, it takes samples one at a time; every so often in bulk, as wav_to_writer would
+static std::vector<float> drain(rh::Source &src) {
+    std::vector<float> out;
+    float chunk[777];
+    for (int round = 0;; ++round) {
+        if (round % 3 == 2) {
+            const size_t k = src.read(chunk, 777);
+            out.insert(out.end(), chunk, chunk + k);
+            if (k < 777) break;
+        } else {
+            bool ended = false;
+            for (int i = 0; i < 1000; ++i) {
+                const std::optional<float> v = src.next();
+                if (!v) {
+                    ended = true;
+                    break;
+                }
+                out.push_back(*v);
+            }
+            if (ended) break;
+        }
+    }
+    if (src.next()) throw std::runtime_error("a source that ended produced another sample");
+    return out;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: host_mirror_test mixer|chain <dir> ... (see the source)\n");
+        return 2;
+    }
+    try {
+        const std::string mode = argv[1], dir = argv[2];
+        rh::init(0);
+        std::vector<float> out;
+        if (mode == "bench" && argc == 5) {
+            const int S = std::atoi(argv[2]);
+            const size_t frames = (size_t)std::atoll(argv[3]);
+            rh::GpuMixer::Options opt;
+            opt.filter_kind = 0;
+            opt.filter_freq = 200;
+            opt.block_frames = (size_t)std::atoll(argv[4]);
+            rh::GpuMixer mixer(48000, opt);
+            uint32_t lcg = 12345u;
+            for (int i = 0; i < S; ++i) {
+                std::vector<float> x(frames * 2);
+                for (float &v : x) {
+                    lcg = lcg * 1664525u + 1013904223u;
+                    v = ((float)(lcg >> 8) / 8388608.0f - 1.0f) / (float)S;
+                }
+                mixer.add(std::make_unique<rh::SamplesBuffer>(2, 44100, std::move(x)));
+            }
+            std::vector<float> chunk(1u << 16);
+            size_t total = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const size_t k = mixer.read(chunk.data(), chunk.size());
+                total += k;
+                if (k < chunk.size()) break;
+            }
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("{\"pull_path\": \"GpuMixer\", \"sources\": %d, \"in_frames\": %zu, \"block_frames\": %zu, \"out_samples\": %zu, \"seconds\": %.4f, \"Msamples_per_s_in\": %.1f}\n", S, frames,
+                        opt.block_frames, total, sec, (double)S * (double)frames * 2.0 / sec / 1e6);
+            return 0;
+        }
+        if (mode == "mixer" && argc == 10) {
+            const int S = std::atoi(argv[3]);
+            const uint32_t from = (uint32_t)std::atoll(argv[4]), to = (uint32_t)std::atoll(argv[5]);
+            rh::GpuMixer::Options opt;
+            opt.filter_kind = std::atoi(argv[6]);
+            opt.filter_freq = (uint32_t)std::atoll(argv[7]);
+            opt.block_frames = (size_t)std::atoll(argv[8]);
+            opt.frames_per_lane = (uint32_t)std::atoll(argv[9]);
+            const std::vector<float> gains = read_f32(dir + "/gains.f32");
+            rh::GpuMixer mixer(to, opt);
+            for (int i = 0; i < S; ++i)
+                mixer.add(std::make_unique<rh::SamplesBuffer>(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i));
+            if (mixer.channels() != 2 || mixer.sample_rate() != to) throw std::runtime_error("format");
+            out = drain(mixer);
+        } else if (mode == "chain" && argc >= 6) {
+            const uint16_t ch = (uint16_t)std::atoi(argv[3]);
+            const uint32_t rate = (uint32_t)std::atoll(argv[4]);
+            rh::GpuSource g(std::make_unique<rh::SamplesBuffer>(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
+            for (int a = 6; a < argc; ++a) {
+                const std::vector<std::string> t = split(argv[a], ':');
+                const std::string &op = t[0];
+                if (op == "amplify") g.amplify(std::stof(t.at(1)));
+                else if (op == "low_pass") g.low_pass((uint32_t)std::stoul(t.at(1)));
+                else if (op == "high_pass") g.high_pass((uint32_t)std::stoul(t.at(1)));
+                else if (op == "reverb") g.reverb(rh::Nanos(std::stoll(t.at(1))), std::stof(t.at(2)));
+                else if (op == "uniform") g.uniform((uint16_t)std::stoul(t.at(1)), (uint32_t)std::stoul(t.at(2)));
+                else if (op == "channels") g.convert_channels((uint16_t)std::stoul(t.at(1)));
+                else if (op == "limit") g.limit(rh_limit_params{-1.0f, 4.0f, 5000000ull, 100000000ull});
+                else if (op == "agc") g.automatic_gain_control(rh_agc_params{1.0f, 4000000000ull, 0ull, 7.0f, 0.0f});
+                else if (op == "fade_in") g.fade_in(rh::Nanos(std::stoll(t.at(1))));
+                else if (op == "fade_out") g.fade_out(rh::Nanos(std::stoll(t.at(1))));
+                else if (op == "distortion") g.distortion(std::stof(t.at(1)), std::stof(t.at(2)));
+                else if (op == "channel_volume") {
+                    std::vector<float> gains;
+                    for (const std::string &x : split(t.at(1), ',')) gains.push_back(std::stof(x));
+                    g.channel_volume(gains);
+                } else if (op == "spatial") {
+                    const float e[3] = {0.5f, 0.0f, 1.0f}, l[3] = {-1.0f, 0.0f, 0.0f}, r[3] = {1.0f, 0.0f, 0.0f};
+                    g.spatial(e, l, r);
+                } else throw std::runtime_error("unknown op " + op);
+            }
+            std::FILE *meta = std::fopen((dir + "/format.txt").c_str(), "w");
+            if (meta) {
+                std::fprintf(meta, "%u %u\n", (unsigned)g.channels(), (unsigned)g.sample_rate());
+                std::fclose(meta);
+            }
+            out = drain(g);
+        } else {
+            std::fprintf(stderr, "bad arguments\n");
+            return 2;
+        }
+        write_f32(dir + "/out.f32", out);
+        std::printf("%zu samples\n", out.size());
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "host_mirror_test: %s\n", e.what());
+        return 1;
+    }
+}

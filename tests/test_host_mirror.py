@@ -1,0 +1,127 @@
+"""The C++ host mirror (include/rodio_hip.hpp): rodio-style pull chains -- `Source::next()` one sample at a
+time -- over the C ABI, block-prefetched on the GPU.  tests/cpp/host_mirror_test.cpp builds the chains; the
+expected samples come from the oracle's per-sample iterator chains.  Reads like rodio's own adapter tests:
+same constructors, same method names, end of stream == None."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+TOL = 1e-5
+
+
+def rnd(seed, n, scale=1.0):
+    return (np.random.default_rng(seed).uniform(-1, 1, n) * scale).astype(np.float32)
+
+
+def test_driver_is_built_and_links_only_the_c_abi():
+    assert os.path.exists(EXE), "run python rodio_amd/build.py"
+    r = subprocess.run([EXE], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    # the host mirror needs nothing but the C ABI: no HIP runtime symbols of its own
+    nm = subprocess.run(["nm", "-D", "--undefined-only", EXE], capture_output=True, text=True).stdout
+    syms = [l.split()[-1] for l in nm.splitlines() if l.strip()]
+    assert "rh_rlm_stream_block_v" in syms and not [x for x in syms if x.startswith(("hip", "hsa", "roc"))]
+
+
+def test_no_gpu_is_an_error_not_a_fallback(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rnd(1, 64).tofile(tmp_path / "src_0.f32")
+    r = subprocess.run([EXE, "chain", str(tmp_path), "2", "48000", "16", "amplify:0.5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "rh_init" in r.stderr
+    assert not (tmp_path / "out.f32").exists()
+
+
+def _run(args, tmp_path):
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+
+
+# ------------------------------------------------------------------ GpuMixer: the fused path, pulled ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200), (1, 300)])
+@pytest.mark.parametrize("block,R", [(4096, 4), (30000, 8), (1000, 3)])
+def test_gpu_mixer_pull_equals_rodio_chain(O, tmp_path, filt, freq, block, R):
+    ns = [40000, 25000, 12345, 40000, 147, 0, 39999, 2]
+    gains = np.array([1.0, 0.5, 0.8, 1.2, 0.3, 1.0, 0.9, 0.7], dtype=np.float32)
+    xs = [rnd(3000 + i, 2 * n, 0.12) for i, n in enumerate(ns)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    gains.tofile(tmp_path / "gains.f32")
+    got = _run(["mixer", tmp_path, len(ns), 44100, 48000, filt, freq, block, R], tmp_path)
+    m = O.Mixer(2, 48000)
+    for x, g in zip(xs, gains):
+        u = O.UniformSourceIterator(O.TestSource(x, 2, 44100).amplify(float(g)), 2, 48000)
+        m.add(u.low_pass(freq) if filt == 0 else u.high_pass(freq) if filt == 1 else u)
+    ref = m.collect()
+    assert len(got) == len(ref)
+    if filt < 0:
+        assert np.array_equal(got, ref)  # resample + ordered sum: bit for bit
+    else:
+        assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+@pytest.mark.gpu
+def test_gpu_mixer_same_rate_passthrough_and_empty(O, tmp_path):
+    # from == to: the converter passes through (sample_rate.rs:133-136); without a filter the mix is the ordered sum
+    ns = [5000, 3000, 4999]
+    xs = [rnd(3100 + i, 2 * n) for i, n in enumerate(ns)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    np.ones(3, dtype=np.float32).tofile(tmp_path / "gains.f32")
+    got = _run(["mixer", tmp_path, 3, 48000, 48000, -1, 0, 2048, 4], tmp_path)
+    m = O.Mixer(2, 48000)
+    for x in xs:
+        m.add(O.TestSource(x, 2, 48000))
+    assert np.array_equal(got, m.collect())
+    got = _run(["mixer", tmp_path, 3, 48000, 48000, 0, 1000, 2048, 4], tmp_path)
+    m = O.Mixer(2, 48000)
+    for x in xs:
+        m.add(O.TestSource(x, 2, 48000).low_pass(1000))
+    ref = m.collect()
+    assert len(got) == len(ref) and float(np.max(np.abs(got - ref))) <= TOL
+    # a mixer without sources ends at once
+    got = _run(["mixer", tmp_path, 0, 44100, 48000, -1, 0, 2048, 4], tmp_path)
+    assert len(got) == 0
+
+
+# ------------------------------------------------------------------ GpuSource: adapter chains, pulled ----
+CHAINS = [
+    # (channels, rate, n_frames, ops, oracle chain)
+    (2, 44100, 30001, ["amplify:0.8", "low_pass:200"], lambda O, s: s.amplify(0.8).low_pass(200)),
+    (2, 48000, 20000, ["reverb:20833333:0.3", "high_pass:300"], lambda O, s: s.reverb(20833333, 0.3).high_pass(300)),
+    (1, 8000, 9000, ["uniform:2:48000", "amplify:1.2"], lambda O, s: O.UniformSourceIterator(s, 2, 48000).amplify(1.2)),
+    (6, 44100, 7001, ["channels:2", "uniform:2:48000"], lambda O, s: O.UniformSourceIterator(s, 2, 48000)),
+    (2, 48000, 30000, ["limit"], lambda O, s: s.limit()),
+    (2, 48000, 30000, ["agc"], lambda O, s: s.automatic_gain_control()),
+    (2, 44100, 12000, ["fade_in:100000000", "distortion:2.0:0.6", "fade_out:200000000"],
+     lambda O, s: s.fade_in(100000000).distortion(2.0, 0.6).fade_out(200000000)),
+    (2, 48000, 10000, ["spatial"], lambda O, s: O.Spatial(s, [0.5, 0.0, 1.0], [-1.0, 0.0, 0.0], [1.0, 0.0, 0.0])),
+    (3, 48000, 5000, ["channel_volume:0.5,1.0,0.25,0.75"], lambda O, s: O.ChannelVolume(s, [0.5, 1.0, 0.25, 0.75])),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(CHAINS)))
+@pytest.mark.parametrize("block", [777, 16384])
+def test_gpu_source_chain_pull_is_bit_exact(O, tmp_path, case, block):
+    ch, rate, n, ops, chain = CHAINS[case]
+    x = rnd(3200 + case, ch * n, 0.9)
+    x.tofile(tmp_path / "src_0.f32")
+    got = _run(["chain", tmp_path, ch, rate, block] + ops, tmp_path)
+    ref_src = chain(O, O.TestSource(x, ch, rate))
+    ref = ref_src.collect()
+    fmt = (tmp_path / "format.txt").read_text().split()
+    assert (int(fmt[0]), int(fmt[1])) == (ref_src.channels(), ref_src.sample_rate())
+    assert len(got) == len(ref), (ops, len(got), len(ref))
+    if ops == ["limit"]:  # log2/exp2 per sample (limit.rs:94-130): device and host libm differ in the last bit
+        assert float(np.max(np.abs(got - ref))) <= TOL
+    else:
+        assert np.array_equal(got, ref, equal_nan=True), (ops, float(np.nanmax(np.abs(got - ref))))
