@@ -489,31 +489,28 @@ protected:
         }
         if (!plan_) start();
         const std::size_t S = srcs_.size();
-        // pull one block per live source behind the frames the previous block left unconsumed
-        std::size_t max_frames = 0;
-        for (Src &x : srcs_) {
-            if (!x.ended) {
-                const std::size_t old = x.held.size(), want = opt_.block_frames * 2;
-                x.held.resize(old + want);
-                std::size_t got = x.up->read(x.held.data() + old, want);
-                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
-                x.held.resize(old + got);
-                x.ended = got < want;
-            }
-            max_frames = std::max(max_frames, x.held.size() / 2);
-        }
-        if (max_frames > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
         s.in.reset(S * row_);
         s.out.reset(out_cap_frames_ * 2);
         din_.reset(S * row_);
         std::vector<const float *> ptrs(S);
         std::vector<std::uint64_t> avail(S);
         std::vector<std::uint8_t> ended(S);
+        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]
         for (std::size_t i = 0; i < S; ++i) {
             Src &x = srcs_[i];
-            std::memcpy(s.in.get() + i * row_, x.held.data(), x.held.size() * sizeof(float));
+            float *row = s.in.get() + i * row_;
+            std::size_t have = x.held.size();
+            if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
+            if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
+            if (!x.ended) {
+                const std::size_t want = opt_.block_frames * 2;
+                std::size_t got = x.up->read(row + have, want);  // straight into the staging block
+                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
+                have += got;
+                x.ended = got < want;
+            }
             ptrs[i] = din_.get() + i * row_;
-            avail[i] = x.held.size() / 2;
+            avail[i] = have / 2;
             ended[i] = x.ended ? 1 : 0;
         }
         // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
@@ -522,9 +519,11 @@ protected:
         check(rh_rlm_stream_block_v(plan_, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, dout_.get(), out_cap_frames_, &out, &consumed, stream_), "rh_rlm_stream_block_v");
         if (out) check(rh_memcpy_d2h_async(s.out.get(), dout_.get(), out * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
         bool all_ended = true;
-        for (Src &x : srcs_) {
-            const std::size_t drop = std::min<std::size_t>(consumed * 2, x.held.size());
-            x.held.erase(x.held.begin(), x.held.begin() + (std::ptrdiff_t)drop);
+        for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
+            Src &x = srcs_[i];
+            const float *row = s.in.get() + i * row_;
+            const std::size_t have = (std::size_t)avail[i] * 2, drop = std::min<std::size_t>((std::size_t)consumed * 2, have);
+            x.held.assign(row + drop, row + have);
             all_ended = all_ended && x.ended;
         }
         s.n = (std::size_t)out * 2;
