@@ -123,6 +123,16 @@ rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_st
 
 /* ---- Distortion: src/source/distortion.rs:66-72.  threshold < 0 or NaN: RH_ERR_INVALID (f32::clamp panics). */
 rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, float threshold, rh_stream stream);
+/* Dither: src/source/dither.rs:217-242.  out = x - noise * lsb with lsb = 1 / 2^(target_bits-1) (:180).
+ * algorithm follows the reference's enum order (dither.rs:40-69): 0 GPDF (normal, sigma 0.6), 1 HighPass (blue:
+ * white[k] - white[k-channels]), 2 RPDF (uniform [-1,1]), 3 TPDF (triangular (-1,1), the default).
+ * The reference seeds a SmallRng from system entropy, so its samples are not reproducible; here the noise of
+ * sample k = sample_offset + i is a pure function of (seed, k):
+ *   h = mix(seed ^ mix(k + 1)), mix = the splitmix64 finaliser; u1 = (int(h >> 40) - 2^23) / 2^23,
+ *   u2 = (int((h >> 16) & 0xffffff) - 2^23) / 2^23; TPDF (u1+u2)/2, RPDF u1, GPDF Box-Muller on the same fields.
+ * Stateless: any split of a stream into blocks (with the running sample_offset) equals one pass. */
+rh_status rh_dither(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels,
+                    uint32_t target_bits, int32_t algorithm, uint64_t seed, rh_stream stream);
 /* ---- LinearGainRamp, fade_in (0 -> 1, then 1.0), fade_out (1 -> 0, clamp_end): src/source/linear_ramp.rs:79-110,
  * fadein.rs:11-13, fadeout.rs:13.  Stateless: sample_offset = samples of the stream already processed. */
 rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels,

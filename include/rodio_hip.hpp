@@ -251,6 +251,17 @@ public:
     GpuSource &distortion(float gain, float threshold) {  // distortion.rs:66-72
         return push([=](Ctx &c) { check(rh_distortion(c.out, c.in, c.n, gain, threshold, c.stream), "rh_distortion"); return c.n; });
     }
+    enum class DitherAlgorithm { GPDF = 0, HighPass = 1, RPDF = 2, TPDF = 3 };  // dither.rs:40-69
+    /// dither.rs:217-242; the noise of sample k is a function of (seed, k) -- see rh_dither.
+    GpuSource &dither(std::uint32_t target_bits, DitherAlgorithm algorithm = DitherAlgorithm::TPDF, std::uint64_t seed = 0) {
+        const std::uint16_t ch = ch_;
+        auto pos = std::make_shared<std::uint64_t>(0);
+        return push([=](Ctx &c) {
+            check(rh_dither(c.out, c.in, c.n, *pos, ch, target_bits, (std::int32_t)algorithm, seed, c.stream), "rh_dither");
+            *pos += c.n;
+            return c.n;
+        });
+    }
     GpuSource &low_pass(std::uint32_t freq) { return blt(0, freq, 0.5f); }   // blt.rs:11-16
     GpuSource &high_pass(std::uint32_t freq) { return blt(1, freq, 0.5f); }  // blt.rs:18-24
     GpuSource &low_pass_with_q(std::uint32_t freq, float q) { return blt(0, freq, q); }

@@ -377,6 +377,57 @@ struct Distortion : Source {
     uint32_t sample_rate() const override { return input->sample_rate(); }
 };
 
+// ---------------------------------------------------------------- Dither ----
+// src/source/dither.rs:217-242: out = input - noise * lsb_amplitude; lsb = (1.0 / (1u64 << (bits-1)) as f64) as f32
+// (:180).  The reference's noise comes from SmallRng seeded from system entropy (noise.rs:137,198,378,554): there
+// is nothing to be bit-identical to, so the oracle states the counter-based contract of rh_dither (noise of sample
+// k is a function of (seed, k)) with the reference's distributions: uniform [-1,1] (noise.rs:146), triangular
+// (-1,1) mode 0 (:206), normal sigma 0.6 (:394), blue = white - prev_white per channel (:579).
+struct Dither : Source {
+    Source *input;
+    float lsb;
+    int algorithm;  // dither.rs:40-69 enum order: 0 GPDF, 1 HighPass, 2 RPDF, 3 TPDF
+    uint64_t seed, k = 0;
+    Dither(Source *in, unsigned bits, int alg, uint64_t sd) : input(in), lsb((float)(1.0 / (double)(1ull << (bits - 1)))), algorithm(alg), seed(sd) {}
+    ~Dither() override { delete input; }
+    static uint64_t mix(uint64_t z) {
+        z ^= z >> 30;
+        z *= 0xbf58476d1ce4e5b9ull;
+        z ^= z >> 27;
+        z *= 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        return z;
+    }
+    uint64_t bits_at(uint64_t kk) const { return mix(seed ^ mix(kk + 1)); }
+    static float u1(uint64_t h) { return (float)((int32_t)(h >> 40) - 8388608) * 1.1920928955078125e-07f; }
+    static float u2(uint64_t h) { return (float)((int32_t)((h >> 16) & 0xffffffu) - 8388608) * 1.1920928955078125e-07f; }
+    bool next(float &out) override {
+        float x;
+        if (!input->next(x)) return false;
+        const uint64_t h = bits_at(k);
+        const unsigned ch = input->channels();
+        float noise;
+        if (algorithm == 3) {
+            noise = (u1(h) + u2(h)) * 0.5f;
+        } else if (algorithm == 2) {
+            noise = u1(h);
+        } else if (algorithm == 1) {
+            const float prev = k >= ch ? u1(bits_at(k - ch)) : 0.0f;
+            noise = u1(h) - prev;
+        } else {
+            const float a = (float)((uint32_t)(h >> 40) + 1u) * 5.9604644775390625e-08f;
+            const float b = (float)((uint32_t)(h >> 16) & 0xffffffu) * 5.9604644775390625e-08f;
+            noise = std::sqrt(-2.0f * std::log(a)) * std::cos(6.2831853071795864769f * b) * 0.6f;
+        }
+        k += 1;
+        out = x - noise * lsb;
+        return true;
+    }
+    long current_span_len() const override { return input->current_span_len(); }
+    uint16_t channels() const override { return input->channels(); }
+    uint32_t sample_rate() const override { return input->sample_rate(); }
+};
+
 // ------------------------------------------------------- LinearGainRamp ----
 // src/source/linear_ramp.rs:79-110 (fade_in = ramp(0,1,false) fadein.rs:11-13; fade_out = ramp(1,0,true)
 // fadeout.rs:13).  `elapsed` is a Duration in whole nanoseconds that advances by NANOS_PER_SEC / rate
@@ -783,6 +834,7 @@ void *orc_uniform(void *in, int ch, unsigned rate) {
 }
 void *orc_amplify(void *in, float factor) { return new Amplify((Source *)in, factor); }
 void *orc_take_duration(void *in, unsigned long long ns, int fade_out) { return new TakeDuration((Source *)in, ns, fade_out != 0); }
+void *orc_dither(void *in, unsigned bits, int algorithm, unsigned long long seed) { return new Dither((Source *)in, bits, algorithm, seed); }
 void *orc_distortion(void *in, float gain, float threshold) { return new Distortion((Source *)in, gain, threshold); }
 void *orc_linear_gain_ramp(void *in, unsigned long long ns, float a, float b, int clamp_end) { return new LinearGainRamp((Source *)in, ns, a, b, clamp_end != 0); }
 void *orc_low_pass(void *in, unsigned freq, float q) { return new BltFilter((Source *)in, false, freq, q); }

@@ -40,6 +40,7 @@ def _load():
         "orc_uniform": (vp, [vp, C.c_int, C.c_uint]),
         "orc_amplify": (vp, [vp, C.c_float]),
         "orc_distortion": (vp, [vp, C.c_float, C.c_float]),
+        "orc_dither": (vp, [vp, C.c_uint, C.c_int, C.c_ulonglong]),
         "orc_take_duration": (vp, [vp, C.c_ulonglong, C.c_int]),
         "orc_linear_gain_ramp": (vp, [vp, C.c_ulonglong, C.c_float, C.c_float, C.c_int]),
         "orc_low_pass": (vp, [vp, C.c_uint, C.c_float]),
@@ -146,6 +147,9 @@ class Source:
 
     def take_duration(self, duration_ns, fade_out=False):  # take.rs; fade_out = set_filter_fadeout()
         return Source(_lib.orc_take_duration(self._take(), duration_ns, int(fade_out)))
+
+    def dither(self, target_bits, algorithm="TPDF", seed=0):  # dither.rs:217-242 with the counter-based noise contract
+        return Source(_lib.orc_dither(self._take(), target_bits, {"GPDF": 0, "HighPass": 1, "RPDF": 2, "TPDF": 3}[algorithm], seed))
 
     def distortion(self, gain, threshold):
         return Source(_lib.orc_distortion(self._take(), gain, threshold))

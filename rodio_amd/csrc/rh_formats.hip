@@ -56,6 +56,45 @@ __global__ __launch_bounds__(kBlock) void k_distortion(float *__restrict__ dst, 
         dst[i] = v;
     }
 }
+// Dither: src/source/dither.rs:217-242  out = x - noise * lsb, lsb = 1 / 2^(bits-1).  The reference draws the
+// noise from a SmallRng seeded from system entropy (noise.rs:137,198,378,554), so no two runs of it agree; the
+// contract here is a counter-based generator: the noise of sample k is a pure function of (seed, k), which makes
+// the op stateless and any block split reproduce one pass.  Distributions as in noise.rs: uniform [-1,1] (:146),
+// triangular (-1,1) mode 0 (:206), normal sigma 0.6 (:394), blue = white[k] - white[k - channels] per channel (:579).
+__device__ __forceinline__ uint64_t dither_bits(uint64_t seed, uint64_t k) {
+    auto mix = [](uint64_t z) {  // splitmix64 finaliser
+        z ^= z >> 30;
+        z *= 0xbf58476d1ce4e5b9ull;
+        z ^= z >> 27;
+        z *= 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        return z;
+    };
+    return mix(seed ^ mix(k + 1));
+}
+__device__ __forceinline__ float dither_u1(uint64_t h) { return (float)((int32_t)(h >> 40) - 8388608) * 1.1920928955078125e-07f; }              // 24 bits -> [-1, 1)
+__device__ __forceinline__ float dither_u2(uint64_t h) { return (float)((int32_t)((h >> 16) & 0xffffffu) - 8388608) * 1.1920928955078125e-07f; }
+__global__ __launch_bounds__(kBlock) void k_dither(float *__restrict__ dst, const float *__restrict__ src, size_t n, uint64_t k0, uint32_t channels, float lsb, int32_t algorithm, uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = k0 + i;
+        const uint64_t h = dither_bits(seed, k);
+        float noise;
+        if (algorithm == 3) {  // TPDF
+            noise = (dither_u1(h) + dither_u2(h)) * 0.5f;
+        } else if (algorithm == 2) {  // RPDF
+            noise = dither_u1(h);
+        } else if (algorithm == 1) {  // HighPass: the channel's previous white sample is the one a frame earlier
+            const float prev = k >= channels ? dither_u1(dither_bits(seed, k - channels)) : 0.0f;
+            noise = dither_u1(h) - prev;
+        } else {  // GPDF: Box-Muller on the two 24-bit fields
+            const float a = (float)((uint32_t)(h >> 40) + 1u) * 5.9604644775390625e-08f;       // (0, 1]
+            const float b = (float)((uint32_t)(h >> 16) & 0xffffffu) * 5.9604644775390625e-08f;  // [0, 1)
+            noise = sqrtf(-2.0f * logf(a)) * cosf(6.2831853071795864769f * b) * 0.6f;
+        }
+        dst[i] = src[i] - noise * lsb;
+    }
+}
 // LinearGainRamp (fade_in / fade_out): src/source/linear_ramp.rs:79-110.  The iterator's `elapsed` is a
 // pure function of the frame index while the ramp runs (f * (1e9 / rate) ns), so the op is stateless:
 // sample k0+i of the stream is in frame (k0+i)/channels.
@@ -122,6 +161,16 @@ rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, floa
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
     hipLaunchKernelGGL(k_distortion, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+rh_status rh_dither(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels, uint32_t target_bits, int32_t algorithm, uint64_t seed, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || target_bits == 0 || target_bits > 64 || algorithm < 0 || algorithm > 3) return RH_ERR_INVALID;  // BitDepth is NonZero (dither.rs:176)
+    if (n == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    const float lsb = (float)(1.0 / (double)(1ull << (target_bits - 1)));  // dither.rs:180
+    hipLaunchKernelGGL(k_dither, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, lsb, algorithm, seed);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -128,6 +128,15 @@ class GpuSource:
         check(lib.rh_distortion(_ptr(out), _ptr(self.samples), len(self), gain, threshold, _stream()), "rh_distortion")
         return GpuSource(out, self._channels, self._sample_rate, self.span_len)
 
+    DITHER = {"GPDF": 0, "HighPass": 1, "RPDF": 2, "TPDF": 3}
+
+    def dither(self, target_bits: int, algorithm: str = "TPDF", seed: int = 0, sample_offset: int = 0) -> "GpuSource":
+        """src/source/dither.rs:217-242 with a counter-based noise generator (see rh_dither)."""
+        _ensure()
+        out = _dev_empty(len(self))
+        check(lib.rh_dither(_ptr(out), _ptr(self.samples), len(self), sample_offset, self._channels, target_bits, self.DITHER[algorithm], seed, _stream()), "rh_dither")
+        return GpuSource(out, self._channels, self._sample_rate, self.span_len)
+
     def linear_gain_ramp(self, duration_ns: int, start_gain: float, end_gain: float, clamp_end: bool, sample_offset: int = 0) -> "GpuSource":
         _ensure()
         out = _dev_empty(len(self))

@@ -8,7 +8,7 @@
 //       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
 //   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
 //       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE
-//       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T channel_volume:G0,G1,.. spatial
+//       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T dither:BITS:ALG:SEED channel_volume:G0,G1,.. spatial
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -141,6 +141,7 @@ int main(int argc, char **argv) {
                 else if (op == "agc") g.automatic_gain_control(rh_agc_params{1.0f, 4000000000ull, 0ull, 7.0f, 0.0f});
                 else if (op == "fade_in") g.fade_in(rh::Nanos(std::stoll(t.at(1))));
                 else if (op == "fade_out") g.fade_out(rh::Nanos(std::stoll(t.at(1))));
+                else if (op == "dither") g.dither((uint32_t)std::stoul(t.at(1)), (rh::GpuSource::DitherAlgorithm)std::stoi(t.at(2)), std::stoull(t.at(3)));
                 else if (op == "distortion") g.distortion(std::stof(t.at(1)), std::stof(t.at(2)));
                 else if (op == "channel_volume") {
                     std::vector<float> gains;

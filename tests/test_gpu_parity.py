@@ -362,6 +362,36 @@ def test_linear_gain_ramp_golden_and_bit_exact(G, O):
     assert np.array_equal(np.concatenate([a, b]), ref)
 
 
+@pytest.mark.parametrize("alg", ["TPDF", "RPDF", "HighPass", "GPDF"])
+@pytest.mark.parametrize("ch,bits", [(1, 16), (2, 16), (2, 24), (6, 8)])
+def test_dither_counter_based_noise(G, O, alg, ch, bits):
+    # the same (seed, sample index) -> noise contract on both sides: bit-exact (GPDF: logf/cosf differ in the last bit)
+    import torch
+    from rodio_amd import _lib
+    import ctypes as C
+
+    n = ch * 30011
+    x = rnd(2600 + ch, n, 0.8)
+    for seed in (0, 0xDEADBEEFCAFE):
+        ref = O.TestSource(x, ch, 48000).dither(bits, alg, seed).collect()
+        out = G.TestSource(x, ch, 48000).dither(bits, alg, seed).collect()
+        if alg == "GPDF":
+            assert float(np.max(np.abs(out - ref))) <= 1e-7
+        else:
+            assert np.array_equal(out, ref)
+        # stateless: blocks with the running sample offset equal one pass
+        xd = torch.from_numpy(x).cuda()
+        got = torch.empty_like(xd)
+        cuts = [0, ch * 1, ch * 777, ch * 20000, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            st = _lib.lib.rh_dither(C.c_void_p(got[a:].data_ptr()), C.c_void_p(xd[a:].data_ptr()), b - a, a, ch, bits, G.GpuSource.DITHER[alg], seed, None)
+            assert st == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), out)
+    assert _lib.lib.rh_dither(None, None, 0, 0, 2, 0, 3, 0, None) == 1  # BitDepth is NonZero
+    assert _lib.lib.rh_dither(None, None, 0, 0, 2, 16, 4, 0, None) == 1
+
+
 def test_amplify_bit_exact(G, O):
     x = rnd(2, 100001)
     for f in (1.2, 0.8, -0.3, 0.0):

@@ -104,6 +104,8 @@ CHAINS = [
     (2, 44100, 12000, ["fade_in:100000000", "distortion:2.0:0.6", "fade_out:200000000"],
      lambda O, s: s.fade_in(100000000).distortion(2.0, 0.6).fade_out(200000000)),
     (2, 48000, 10000, ["spatial"], lambda O, s: O.Spatial(s, [0.5, 0.0, 1.0], [-1.0, 0.0, 0.0], [1.0, 0.0, 0.0])),
+    (2, 48000, 9000, ["amplify:0.5", "dither:16:3:42"], lambda O, s: s.amplify(0.5).dither(16, "TPDF", 42)),
+    (2, 44100, 9000, ["dither:24:1:7"], lambda O, s: s.dither(24, "HighPass", 7)),
     (3, 48000, 5000, ["channel_volume:0.5,1.0,0.25,0.75"], lambda O, s: O.ChannelVolume(s, [0.5, 1.0, 0.25, 0.75])),
 ]
 

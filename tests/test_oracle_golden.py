@@ -325,3 +325,43 @@ def test_take_duration_golden(O):
     assert out.tolist() == [1.0, 1.0, 1.0, 1.0, 1.0, 0.0]
     # :241-245: zero duration -> nothing
     assert len(O.TestSource(x, 1, 48000).take_duration(0).collect()) == 0
+
+
+# ------------------------------------------------------------------ dither ----
+def test_dither_reference_test_properties(O):
+    """The reference's noise is entropy-seeded, so its tests pin properties, not samples (dither.rs:301-393):
+    the dither stays within 2 LSB of the input (test_dither_adds_noise), HighPass noise has negative lag-1
+    autocorrelation per channel and independent channels (test_highpass_dither_multichannel_independence).
+    The counter-based restatement must have them, plus the distributions' moments (noise.rs:156,216,394)."""
+    sr, bits = 44100, 16
+    lsb = np.float32(1.0 / (1 << (bits - 1)))
+    t = np.arange(441) / sr
+    x = np.sin(2 * np.pi * 440 * t).astype(np.float32)
+    for seed in (0, 1, 12345):
+        y = O.TestSource(x, 1, sr).dither(bits, "TPDF", seed).collect()
+        assert np.all(np.isfinite(y)) and np.max(np.abs(y - x)) <= 2 * lsb and np.any(y != x)
+    z = np.zeros(2 * 200000, dtype=np.float32)
+    for seed in (7, 8):
+        hp = O.TestSource(z, 2, sr).dither(bits, "HighPass", seed).collect() / -lsb
+        left, right = hp[0::2].astype(np.float64), hp[1::2].astype(np.float64)
+        assert np.mean(left[:-1] * left[1:]) < 0 and np.mean(right[:-1] * right[1:]) < 0
+        assert abs(np.mean(left * right)) < 0.01
+        # lag-1 autocorrelation of white[k] - white[k-1] is -1/2 of its variance (2/3)
+        assert abs(np.mean(left[:-1] * left[1:]) + 1.0 / 3.0) < 0.01
+    n = 400000
+    z = np.zeros(n, dtype=np.float32)
+    # Triangular(-1, 1, mode 0) (noise.rs:206) has variance 1/6: sigma 0.408 LSB, the "optimal 0.408 LSB" of
+    # noise.rs:387 (the 2/sqrt(6) that WhiteTriangular::std_dev() reports at :216-218 is the figure for (-2, 2))
+    for alg, std, bound in (("TPDF", 1 / np.sqrt(6), 1.0), ("RPDF", np.sqrt(1 / 3), 1.0), ("GPDF", 0.6, 6 * 0.6)):
+        w = (O.TestSource(z, 1, sr).dither(bits, alg, 99).collect() / -lsb).astype(np.float64)
+        assert abs(np.mean(w)) < 0.005 and abs(np.std(w) - std) < 0.005 and np.max(np.abs(w)) <= bound
+        assert abs(np.mean(w[:-1] * w[1:])) < 0.005  # white
+    # different seeds give different noise; the same seed the same
+    a = O.TestSource(z[:1000], 1, sr).dither(bits, "TPDF", 1).collect()
+    b = O.TestSource(z[:1000], 1, sr).dither(bits, "TPDF", 2).collect()
+    c = O.TestSource(z[:1000], 1, sr).dither(bits, "TPDF", 1).collect()
+    assert np.array_equal(a, c) and not np.array_equal(a, b)
+    # lsb for the depths rodio names (dither.rs:180)
+    for bits2 in (8, 16, 24, 32):
+        y = O.TestSource(z[:4096], 1, sr).dither(bits2, "RPDF", 5).collect()
+        assert 0 < np.max(np.abs(y)) <= 1.0 / (1 << (bits2 - 1))
