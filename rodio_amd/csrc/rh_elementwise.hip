@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_int_to_f32(float *__restrict__ dst, 
     const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     for (size_t v = tid; v < nvec; v += stride) {
-        uint4 raw = src4[v];
+        uint4 raw = rh::ld_nt(src4 + v);
         T vals[VEC];
         __builtin_memcpy(vals, &raw, 16);
         float out[VEC];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_f32_to_int(T *__restrict__ dst, cons
         const size_t nvec = n / 4;
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         for (size_t v = tid; v < nvec; v += stride) {
-            float4 r = s4[v];
+            float4 r = rh::ld_nt(s4 + v);
             T o[4] = {FromF32<T>::cvt(r.x), FromF32<T>::cvt(r.y), FromF32<T>::cvt(r.z), FromF32<T>::cvt(r.w)};
             __builtin_memcpy(dst + v * 4, o, sizeof(o));
         }
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(kBlock) void k_channels_convert(float *__restrict__
         const size_t f = o / to;
         const uint32_t k = (uint32_t)(o - f * to);
         float v;
-        if (k < from) v = src[f * from + k];
-        else if (k == 1) v = src[f * from];
+        if (k < from) v = rh::ld_nt(src + f * from + k);
+        else if (k == 1) v = rh::ld_nt(src + f * from);
         else v = 0.0f;
-        dst[o] = v;
+        rh::st_nt(dst + o, v);
     }
 }
 // Stereo <-> N fast paths are not needed for correctness; the generic kernel already writes
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void k_amplify(float *__restrict__ dst, con
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
         for (size_t v = tid; v < nvec; v += stride) {
-            float4 r = s4[v];
-            d4[v] = make_float4(r.x * factor, r.y * factor, r.z * factor, r.w * factor);
+            float4 r = rh::ld_nt(s4 + v);
+            rh::st_nt(d4 + v, make_float4(r.x * factor, r.y * factor, r.z * factor, r.w * factor));
         }
         done = nvec * 4;
     }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols(float *__restric
             for (int u = 0; u < 4; ++u) {
                 const size_t i = i0 + (size_t)u * delay;
                 a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < n) a4[u] = *reinterpret_cast<const float4 *>(x + i);
+                if (i < n) a4[u] = rh::ld_nt(reinterpret_cast<const float4 *>(x + i));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols(float *__restric
                 float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
                 m0 = m0 / 2.0f;
                 m1 = m1 / 2.0f;
-                *reinterpret_cast<float4 *>(o + i) = make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1);
+                rh::st_nt(reinterpret_cast<float4 *>(o + i), make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1));
                 prev = a;
             }
         }
