@@ -617,7 +617,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     static_assert(KV * (NS - 1) < 64, "vmcnt range");
     constexpr uint32_t kStage = KV * 1024;        // bytes of one LDS input stage
     constexpr uint32_t kPubBase = NS * kStage;    // 8 x 16 B: this tile's aggregates of the current source group
-    constexpr uint32_t kLookBase = kPubBase + 128;             // kMaxLook x 16 B: B^(L*j)
+    constexpr uint32_t kCntBase = kPubBase + 128;              // 32 B: per recent source, how many predecessor tiles hold its own aggregate
+    constexpr uint32_t kLookBase = kCntBase + 32;              // kMaxLook x 16 B: B^(L*j)
     constexpr uint32_t kGranBase = kLookBase + kMaxLook * 16;  // NI x 1 KiB: predecessor aggregates of one source group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // explicit LDS address space: a generic pointer here turns every tap into a flat_load
@@ -714,6 +715,14 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     // and applied once after the last source: Qacc = sum of the lanes' zero-carry start states,
     // Cacc = this lane's share (its sets) of the summed tile carries.
     float Qacc[4] = {0.f, 0.f, 0.f, 0.f}, Cacc[4] = {0.f, 0.f, 0.f, 0.f};
+    // A source that stays whole for this tile and the next J ("stable") never needs an aggregate of its own: every
+    // tile that consumes it applies its correction merged.  Such sources only add their run-end state to a sum that
+    // is scanned and published ONCE per tile (row n_sources of the table), as in k_rlm_fast; the per-source scan and
+    // exchange below is left to the few sources that end within J tiles.  Streaming keeps every source on its own
+    // (the block-end states are per source).
+    const bool indiv_all = p.col0 != 0;
+    const uint32_t m_stable = m_tile0 + (p.J + 1u) * L;
+    v2f E1s = {0.f, 0.f}, E2s = {0.f, 0.f};
     uint64_t mrg = 0;      // bit k: source s-1-k was merged into Qacc
     uint32_t pubmask = 0;  // bit (s&7): source s of the current group has an aggregate in the pub area
     uint32_t grp_mask = 0; // merged flags (bit 7-src) of the group whose aggregates are in flight
@@ -874,7 +883,9 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         if (FILT && (s & 7) == 2 && s >= 8 * kGroupLag && Jc > 0 && grp_mask) {
             const bool src_on = lane < 32 && ((grp_mask >> (7 - set_src)) & 1u);
             for (uint32_t i = 0; i < NI; ++i) {
-                const bool want = src_on && set_pred + 4 * i < Jc;
+                // only the predecessors in which the source already ran on its own hold an aggregate of it
+                const uint32_t have = src_on ? *(const RH_LDS unsigned char *)(lds + kCntBase + ((grp_first + set_src) & 31u)) : 0u;
+                const bool want = src_on && set_pred + 4 * i < have;
                 unsigned long long gv[4] = {0, 0, 0, 0};
                 bool ok = false;
                 if (want && !dead) {
@@ -960,6 +971,18 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 if (!edge) run(std::false_type{});
                 else run(std::true_type{});
                 RH_PH(4)
+                if (!indiv_all && Ms >= m_stable) {  // stable: joins the summed state, nothing else
+                    E1s.x = fma_(g, w1.x, E1s.x);
+                    E1s.y = fma_(g, w1.y, E1s.y);
+                    E2s.x = fma_(g, w2.x, E2s.x);
+                    E2s.y = fma_(g, w2.y, E2s.y);
+                } else {
+                {  // how many predecessor tiles saw this source as not stable (and published it on its own)
+                    const uint32_t tM = Ms / L;
+                    uint32_t have = indiv_all ? Jc : (tile + p.J > tM ? tile + p.J - tM : 0u);
+                    have = have < Jc ? have : Jc;
+                    if (lane == 0) *(RH_LDS unsigned char *)(lds + kCntBase + (s & 31u)) = (unsigned char)have;
+                }
                 // ---- run end state in the scan basis, then the wave64 inclusive scan ----
                 float P[4] = {0.f, 0.f, 0.f, 0.f};
                 mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
@@ -1026,6 +1049,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                         acc[r].y += v ? hy : 0.0f;
                     }
                 }
+                }  // individual source
             } else {
                 auto run = [&](auto masked) {
 #pragma unroll
@@ -1074,6 +1098,59 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     }
 #endif
 
+    if (FILT && !indiv_all) {  // the stable sources' summed state: one scan, one published aggregate, one look-back
+        float P[4] = {0.f, 0.f, 0.f, 0.f};
+        mat_acc(p.u.Tm, E1s.x, E2s.x, P[0], P[1]);
+        mat_acc(p.u.Tm, E1s.y, E2s.y, P[2], P[3]);
+#define RH_SCAN_STEP(K, N)                                                                          \
+    {                                                                                               \
+        const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
+        const float q2 = dpp0<kDppRowShr + N, 0xf>(P[2]), q3 = dpp0<kDppRowShr + N, 0xf>(P[3]);     \
+        mat_acc(p.u.scanM[K], q0, q1, P[0], P[1]);                                                  \
+        mat_acc(p.u.scanM[K], q2, q3, P[2], P[3]);                                                  \
+    }
+        RH_SCAN_STEP(0, 1)
+        RH_SCAN_STEP(1, 2)
+        RH_SCAN_STEP(2, 4)
+        RH_SCAN_STEP(3, 8)
+#undef RH_SCAN_STEP
+        {
+            const float q0 = dpp0<kDppBcast15, 0xa>(P[0]), q1 = dpp0<kDppBcast15, 0xa>(P[1]);
+            const float q2 = dpp0<kDppBcast15, 0xa>(P[2]), q3 = dpp0<kDppBcast15, 0xa>(P[3]);
+            mat_acc(b15, q0, q1, P[0], P[1]);
+            mat_acc(b15, q2, q3, P[2], P[3]);
+        }
+        {
+            const float q0 = dpp0<kDppBcast31, 0xc>(P[0]), q1 = dpp0<kDppBcast31, 0xc>(P[1]);
+            const float q2 = dpp0<kDppBcast31, 0xc>(P[2]), q3 = dpp0<kDppBcast31, 0xc>(P[3]);
+            mat_acc(b31, q0, q1, P[0], P[1]);
+            mat_acc(b31, q2, q3, P[2], P[3]);
+        }
+        unsigned long long *const sum_row = p.gran + (uint64_t)S * ncol * 4;
+        {
+            const float e0 = readlane_f(P[0], 63), e1 = readlane_f(P[1], 63);
+            const float e2 = readlane_f(P[2], 63), e3 = readlane_f(P[3], 63);
+            if (lane < 4) {
+                const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+                const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
+                __hip_atomic_store(sum_row + (uint64_t)col * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Qacc[q] += dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
+        if (Jc > 0) {  // lane j < Jc: predecessor j's summed aggregate (they finish about now)
+            const bool want = (uint32_t)lane < Jc;
+            unsigned long long gv[4] = {0, 0, 0, 0};
+            bool ok = false;
+            poll_sets(sum_row + (uint64_t)(col - 1 - (want ? lane : 0)) * 4, want, gv, ok);
+            if (want && ok && !dead) {
+                const v4f k4 = *(const lds_f4 *)(lds + kLookBase + lane * 16);
+                const float kM[4] = {k4.x, k4.y, k4.z, k4.w};
+                mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), Cacc[0], Cacc[1]);
+                mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), Cacc[2], Cacc[3]);
+            }
+        }
+    }
     if (FILT) {  // the merged homogeneous response: start state = Qacc + B^(R*lane) * (summed tile carries)
         reduce_carry(Cacc);
         mat_acc(lM, Cacc[0], Cacc[1], Qacc[0], Qacc[1]);
@@ -1193,14 +1270,14 @@ const Variant kFast[] = {
     RH_FAST(12, 6, 2),  RH_FAST(12, 6, 3),  RH_FAST(12, 7, 2), RH_FAST(12, 7, 3), RH_FAST(12, 13, 2),
     RH_FAST(14, 7, 2),  RH_FAST(14, 8, 2),
     RH_FAST(16, 8, 2),  RH_FAST(16, 8, 3),  RH_FAST(16, 9, 2), RH_FAST(16, 9, 3),
-    RH_FAST(18, 9, 2),  RH_FAST(18, 10, 2),
-    RH_FAST(20, 10, 2), RH_FAST(20, 11, 2),
+    RH_FAST(18, 9, 2),  RH_FAST(18, 9, 3),  RH_FAST(18, 10, 2),
+    RH_FAST(20, 10, 2), RH_FAST(20, 10, 3), RH_FAST(20, 11, 2),
 #endif
 };
 // The general kernel (ragged batches) is heavier; it ships in two tile sizes.
 const Variant kWave[] = {
     RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
-    RH_WAVE(9, 5, 2), RH_WAVE(10, 5, 2), RH_WAVE(10, 6, 2), RH_WAVE(12, 6, 2), RH_WAVE(12, 7, 2),
+    RH_WAVE(9, 5, 2), RH_WAVE(9, 5, 3), RH_WAVE(10, 5, 2), RH_WAVE(10, 5, 3), RH_WAVE(10, 6, 2), RH_WAVE(12, 6, 2), RH_WAVE(12, 6, 3), RH_WAVE(12, 7, 2),
 };
 #undef RH_FAST
 #undef RH_WAVE
@@ -1291,7 +1368,7 @@ uint32_t look_tiles(const M2 &B, uint64_t L) {
 }
 size_t lds_bytes_of(const Variant &v, bool general, uint32_t J) {
     size_t n = (size_t)v.NS * v.KV * 1024;
-    if (general) n += 128 + kMaxLook * 16 + (size_t)((J + 3) / 4) * 1024;
+    if (general) n += 128 + 32 + kMaxLook * 16 + (size_t)((J + 3) / 4) * 1024;
     return n;
 }
 
@@ -1396,7 +1473,7 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     const uint64_t L = 64ull * pl->v->R;
     const uint64_t tiles = (M + L - 1) / L;
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    const size_t words = (size_t)(p->n_sources ? p->n_sources : 1) * (tiles + 1) * 4;  // per (source, tile): general kernel and batch mode; +1: streaming's end-state tile
+    const size_t words = (size_t)(p->n_sources + 1) * (tiles + 1) * 4;  // per (source, tile): general kernel (+ its row of summed aggregates) and batch mode; +1: streaming's end-state tile
     if (p->filt && words > p->gran_words) {
         if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
         p->d_gran = nullptr;

@@ -10,9 +10,12 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define LDS __attribute__((address_space(3)))
 
+#ifndef RING_NT
+#define RING_NT " nt"  // -DRING_NT='""' for the plain fetch
+#endif
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RING_NT "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
