@@ -243,7 +243,10 @@ __device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32
 #endif
     // nt: every source byte is read once per launch -- a streaming (non-temporal) fetch does not displace what the
     // caches could reuse and, measured, lifts the achievable read rate from 6.3 to 7.0 TB/s (tools/ubench/read_bw.hip)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+#ifndef RH_GLDS_POL
+#define RH_GLDS_POL " nt"
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" RH_GLDS_POL "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
