@@ -42,5 +42,6 @@ res = {
     "fetch_correction": 2.0,
     "hbm_bytes_per_launch": (fetch_kib * 1024.0 * 2.0 + write_kib * 1024.0) if fetch_kib and write_kib is not None else None,
     "dispatches_averaged": [n1, n2, n3],
+    "geometry": {"frames_per_lane": opt("--frames-per-lane", 0), "ring_stages": opt("--ring-stages", 0)},
 }
 print(json.dumps(res, indent=1))
