@@ -59,18 +59,21 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *in, float *out, uin
 // The fused kernel's exact read pattern: tile t of source s reads nvec 16-byte vectors starting at vector
 // t*vstride (+ s*src_stride): chunks are 16-byte but not 128-byte aligned, the KV*64 - nvec surplus lanes
 // re-fetch the chunk's last vector.
-template <int KV, int NS>
-__global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t vstride, uint32_t nvec) {
+template <int KV, int NS, int A = 1>
+__global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t vstride, uint32_t nvec_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS unsigned char *)smem;
     uint32_t off[KV];
+    const uint32_t v0 = tile * vstride, va = v0 & ~(uint32_t)(A - 1);  // span start rounded down to A vectors (A*16 bytes)
+    uint32_t nvec = nvec_ + (v0 - va);
+    nvec = nvec < (uint32_t)KV * 64 ? nvec : (uint32_t)KV * 64;
 #pragma unroll
     for (int kk = 0; kk < KV; ++kk) {
         uint32_t j = lane + kk * 64;
         j = j < nvec ? j : nvec - 1;
-        off[kk] = ((uint64_t)tile * vstride + j) * 4;  // floats
+        off[kk] = (va + j) * 4;  // floats
     }
     auto issue = [&](uint32_t s) {
         const float *g = in + (uint64_t)s * src_stride_f;
@@ -125,6 +128,40 @@ int main(int argc, char **argv) {
         for (int flops : {0, 2, 4, 6, 8, 10, 12}) run<8, 2, 1>(d_in, d_out, S, 1024, stride, flops);
         for (int flops : {0, 4, 8, 10}) run<8, 3, 1>(d_in, d_out, S, 1024, stride, flops);
         for (int flops : {0, 4, 8, 10}) run<4, 2, 1>(d_in, d_out, S, 2048, stride, flops);
+        return 0;
+    }
+    if (cal && argv[1][0] == 't') {  // timing of the kernel's chunk patterns (R = 18: 1152 out frames -> 1058.4 in frames = 529.2 vectors, 533 fetched)
+        auto timeit = [&](const char *name, auto kern, uint32_t tiles, size_t lds, uint32_t vstride, uint32_t nvec) {
+            CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(tiles), dim3(64), lds, 0, d_in, d_out, S, stride, vstride, nvec);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double bytes = (double)S * ((double)(tiles - 1) * vstride + nvec) * 16.0;
+            printf("%-34s tiles %5u vstride %4u nvec %4u lds %6zu : %.3f ms  %.0f GB/s (distinct bytes)\n", name, tiles, vstride, nvec, lds, best, bytes / best / 1e6);
+        };
+        timeit("aligned 8 KiB chunks KV8", k_mimic<8, 2>, 1024, 16384, 512, 512);
+        timeit("aligned 9 KiB chunks KV9", k_mimic<9, 2>, 910, 18432, 576, 576);
+        timeit("R18 pattern KV9 (clamped tail)", k_mimic<9, 2>, 991, 18432, 529, 533);
+        timeit("R18 pattern KV9, lds 40960", k_mimic<9, 2>, 991, 40960, 529, 533);
+        timeit("R18 stride, 9 full instr", k_mimic<9, 2>, 991, 40960, 529, 576);
+        timeit("R18, starts on 128 B (kernel)", k_mimic<9, 2, 8>, 991, 40960, 529, 533);
+        timeit("R18, starts on 256 B", k_mimic<9, 2, 16>, 991, 40960, 529, 533);
+        timeit("R18, starts on 512 B, KV9", k_mimic<9, 2, 32>, 991, 40960, 529, 533);
+        timeit("R18, starts on 1 KiB, KV10", k_mimic<10, 2, 64>, 991, 40960, 529, 533);
+        timeit("R18, starts on 4 KiB, KV10", k_mimic<10, 2, 256>, 991, 40960, 529, 533);
+        timeit("R9 pattern KV5", k_mimic<5, 2>, 1982, 20480, 265, 269);
+        timeit("R9, starts on 128 B", k_mimic<5, 2, 8>, 1982, 20480, 265, 269);
+        timeit("R10 pattern KV5", k_mimic<5, 2>, 1784, 23040, 294, 298);
         return 0;
     }
     if (cal && argv[1][0] == 'm') {  // mimic: R=10 tiles of config 2 (640 out frames -> 588 in frames = 294 vectors; 298 fetched)
