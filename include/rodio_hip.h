@@ -234,6 +234,13 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
                     uint32_t n_streams, const float coeffs5_host[5], float *state, int32_t mode,
                     rh_stream stream);
 
+/* ---- src/math.rs:51-56,86-90,110-113 (host): dB <-> linear as the reference spells them (2^(dB*0.05*log2 10),
+ * log2(x)*log10(2)*20) and the smoothing coefficient exp(-1/(seconds*rate)) of the limiter and the AGC.
+ * Amplify::set_log_factor / Source::amplify_decibel (amplify.rs:33-35) is rh_amplify with rh_db_to_linear(dB). */
+float rh_db_to_linear(float decibels);
+float rh_linear_to_db(float linear);
+float rh_duration_to_coefficient(uint64_t duration_ns, uint32_t sample_rate);
+
 /* ---- Limit: src/source/limit.rs:94-130,853-988.  state: 2*channels floats
  * {integrator, peak} per channel (optional). */
 typedef struct rh_limit_params {

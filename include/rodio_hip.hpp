@@ -248,6 +248,7 @@ public:
     GpuSource &amplify(float factor) {  // amplify.rs:64
         return push([factor](Ctx &c) { check(rh_amplify(c.out, c.in, c.n, factor, c.stream), "rh_amplify"); return c.n; });
     }
+    GpuSource &amplify_decibel(float db) { return amplify(rh_db_to_linear(db)); }  // amplify.rs:33-35, math.rs:51-56
     GpuSource &distortion(float gain, float threshold) {  // distortion.rs:66-72
         return push([=](Ctx &c) { check(rh_distortion(c.out, c.in, c.n, gain, threshold, c.stream), "rh_distortion"); return c.n; });
     }

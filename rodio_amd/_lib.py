@@ -132,6 +132,9 @@ SIGNATURES = {
     "rh_delay": (i32, [vp, vp, u64, u64, vp]),
     "rh_take_duration": (i32, [vp, vp, u64, u64, u32, u32, u64, i32, C.POINTER(u64), C.POINTER(i32), vp]),
     "rh_distortion": (i32, [vp, vp, sz, f32, f32, vp]),
+    "rh_db_to_linear": (f32, [f32]),
+    "rh_linear_to_db": (f32, [f32]),
+    "rh_duration_to_coefficient": (f32, [u64, u32]),
     "rh_dither": (i32, [vp, vp, sz, u64, u32, u32, i32, u64, vp]),
     "rh_linear_gain_ramp": (i32, [vp, vp, sz, u64, u32, u32, u64, f32, f32, i32, vp]),
     "rh_reverb_spatial": (i32, [vp, vp, sz, sz, f32, vp, u32, sz, sz, vp]),

@@ -280,4 +280,9 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
     return RH_OK;
 }
 
+// ---- src/math.rs:51-56,86-90,110-113: the scalar helpers behind Amplify::set_log_factor / amplify_decibel
+// (amplify.rs:33-35), the limiter and the AGC.  Host arithmetic, the reference's expressions.
+float rh_db_to_linear(float decibels) { return powf(2.0f, decibels * 0.05f * 3.32192809488736234787f); }
+float rh_linear_to_db(float linear) { return log2f(linear) * 0.30102999566398119521f * 20.0f; }
+float rh_duration_to_coefficient(uint64_t duration_ns, uint32_t sample_rate) { return duration_to_coefficient(duration_ns, sample_rate); }
 }  // extern "C"

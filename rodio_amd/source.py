@@ -101,6 +101,10 @@ class GpuSource:
         check(lib.rh_amplify(_ptr(out), _ptr(self.samples), len(self), factor, _stream()), "rh_amplify")
         return GpuSource(out, self._channels, self._sample_rate, self.span_len)
 
+    def amplify_decibel(self, db: float) -> "GpuSource":
+        """source/mod.rs amplify_decibel / Amplify::set_log_factor (amplify.rs:33-35): factor = db_to_linear(dB)."""
+        return self.amplify(float(lib.rh_db_to_linear(db)))
+
     def speed(self, factor: float) -> "GpuSource":
         """src/source/speed.rs:104-133: the samples are untouched, the reported rate is scaled."""
         r = np.float32(self._sample_rate) * np.float32(factor)

@@ -167,3 +167,25 @@ def test_resampler_pending_frames_property(rh):
 
     h = C.c_void_p()
     assert _lib.lib.rh_resampler_create(C.byref(h), 44100, 48000, 2) in (0, 6)  # RH_OK with a GPU, NOT_INITIALIZED without
+
+
+def test_db_helpers_match_the_reference_table(rh, O):
+    """math.rs:238-339: the 27-row dB table (within 1 %) and the round trip (<= 16 eps); and bit-equality with the
+    oracle's restatement of the same expressions."""
+    from rodio_amd import _lib
+
+    L = _lib.lib
+    table = [(100.0, 100000.0), (90.0, 31623.0), (80.0, 10000.0), (70.0, 3162.3), (60.0, 1000.0), (50.0, 316.23), (40.0, 100.0), (30.0, 31.623),
+             (20.0, 10.0), (10.0, 3.1623), (5.0, 1.7783), (1.0, 1.1220), (0.0, 1.0), (-1.0, 0.89125), (-5.0, 0.56234), (-10.0, 0.31623), (-20.0, 0.1),
+             (-30.0, 0.031623), (-40.0, 0.01), (-50.0, 0.0031623), (-60.0, 0.001), (-70.0, 0.00031623), (-80.0, 0.0001), (-90.0, 0.000031623), (-100.0, 0.00001)]
+    for db, lin in table:
+        assert abs(L.rh_db_to_linear(db) - lin) <= 0.01 * lin
+        assert abs(L.rh_linear_to_db(lin) - db) <= max(0.01 * abs(db), 0.01)
+        assert L.rh_db_to_linear(db) == O.db_to_linear(db) and L.rh_linear_to_db(lin) == O.linear_to_db(lin)
+    eps = np.finfo(np.float32).eps
+    for db in np.linspace(-60, 20, 161):
+        back = L.rh_linear_to_db(L.rh_db_to_linear(float(db)))
+        assert abs(back - db) <= 16 * eps * max(abs(db), 1.0)
+    assert L.rh_linear_to_db(0.0) == -np.inf and np.isnan(L.rh_linear_to_db(-1.0))
+    for ns, rate in [(5_000_000, 48000), (100_000_000, 44100), (4_000_000_000, 48000), (1, 8000)]:
+        assert L.rh_duration_to_coefficient(ns, rate) == O.duration_to_coefficient(ns, rate)
