@@ -123,6 +123,10 @@ public:
     }
     float *get() const { return static_cast<float *>(p_); }
     std::size_t size() const { return n_; }
+    void swap(DeviceBuf &o) {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+    }
 
 private:
     void *p_ = nullptr;
@@ -193,6 +197,8 @@ protected:
     };
     /// Fills `s` (n, last) and enqueues everything that produces s.out on stream_.
     virtual void enqueue(Slot &s) = 0;
+    /// A source that returned None may yield samples again (rodio's MixerSource after a later Mixer::add).
+    virtual bool can_resume() const { return false; }
     rh_stream stream_ = nullptr;
 
 private:
@@ -202,7 +208,10 @@ private:
         check(rh_event_record(s.done, stream_), "rh_event_record");
     }
     bool advance() {
-        if (ended_) return false;
+        if (ended_) {
+            if (!can_resume()) return false;
+            ended_ = primed_ = false;
+        }
         if (!primed_) {
             submit(slot_[0]);
             primed_ = true;
@@ -459,9 +468,14 @@ private:
 ///     mixer.add(UniformSourceIterator::new(src.amplify(g), nz!(2), rate).low_pass(f));   // per source
 /// as ONE source: every block is one launch of the fused kernel (resample + filter + ordered sum), each source
 /// keeping its own converter position and filter state across blocks; sources end when they end.
-/// Sources are stereo and share one input rate (what the fused kernel covers; other layouts go through
-/// GpuSource::uniform first) and join before the first next(): they run on one clock (mixer.rs:120-136 admits
-/// later sources at the next frame; a shim that needs that starts a second GpuMixer and sums the two).
+/// Sources are stereo; the sources added together share one input rate (what the fused kernel covers; other
+/// layouts go through GpuSource::uniform first).
+///
+/// add() may be called at any time (Mixer::add, mixer.rs:58-66).  Sources added before the first next() start
+/// with the stream.  Sources added later start at the next block that is pulled (mixer.rs:120-136 admits them at
+/// the next frame; here the blocks already in flight -- at most two -- play out first): they form a new
+/// *generation* with its own clock and its own fused stream, and the generations' mixes are summed in insertion
+/// order by rh_mix_sum.  An empty mixer is an ended stream (there is nothing to pull).
 class GpuMixer : public detail::BlockPump {
 public:
     struct Options {
@@ -478,68 +492,84 @@ public:
     explicit GpuMixer(std::uint32_t sample_rate) : GpuMixer(sample_rate, Options()) {}
     ~GpuMixer() override {
         (void)rh_stream_synchronize(stream_);
-        if (plan_) (void)rh_rlm_destroy(plan_);
+        for (auto &g : gens_)
+            if (g->plan) (void)rh_rlm_destroy(g->plan);
     }
     /// Mixer::add (mixer.rs:58-66), with the source's volume.
     void add(BoxSource src, float gain = 1.0f) {
         if (!src) throw std::invalid_argument("source");
-        if (plan_) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer::add after the stream started");
         if (src->channels() != 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: stereo sources (convert with GpuSource::uniform first)");
-        if (!srcs_.empty() && src->sample_rate() != srcs_.front().up->sample_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: one input rate per mixer");
-        srcs_.push_back(Src{std::move(src), gain, {}, false});
+        if (!pending_.empty() && src->sample_rate() != pending_.front().up->sample_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: sources added together share one input rate");
+        pending_.push_back(Src{std::move(src), gain, {}, false});
     }
     std::uint16_t channels() const override { return 2; }
     std::uint32_t sample_rate() const override { return rate_; }
-    std::size_t sources() const { return srcs_.size(); }
+    /// Output frame (of this mixer) at which the most recently started generation joined.
+    std::uint64_t last_join_frame() const { return last_join_; }
 
 protected:
+    bool can_resume() const override { return !pending_.empty(); }  // mixer.rs:117-136: None while empty, samples again after add()
     void enqueue(Slot &s) override {
-        if (srcs_.empty()) {  // mixer.rs:139-141: a mixer without sources is an ended stream here (nothing to pull)
+        if (!pending_.empty()) start_generation();
+        if (gens_.empty()) {  // nothing to pull
             s.n = 0;
             s.last = true;
             return;
         }
-        if (!plan_) start();
-        const std::size_t S = srcs_.size();
-        s.in.reset(S * row_);
-        s.out.reset(out_cap_frames_ * 2);
-        din_.reset(S * row_);
-        std::vector<const float *> ptrs(S);
-        std::vector<std::uint64_t> avail(S);
-        std::vector<std::uint8_t> ended(S);
-        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]
-        for (std::size_t i = 0; i < S; ++i) {
-            Src &x = srcs_[i];
-            float *row = s.in.get() + i * row_;
-            std::size_t have = x.held.size();
-            if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
-            if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
-            if (!x.ended) {
-                const std::size_t want = opt_.block_frames * 2;
-                std::size_t got = x.up->read(row + have, want);  // straight into the staging block
-                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
-                have += got;
-                x.ended = got < want;
+        s.out.reset(out_cap_frames_ * 2 * 2);
+        // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
+        for (auto &gp : gens_)
+            if (!gp->done) run_block(*gp, s);
+        // 2. the frames every unfinished generation has reached; finished ones give what they have left
+        std::uint64_t n = ~0ull, most = 0;
+        bool any_live = false;
+        for (auto &gp : gens_) {
+            most = std::max(most, gp->fill);
+            if (!gp->done) {
+                any_live = true;
+                n = std::min(n, gp->fill);
             }
-            ptrs[i] = din_.get() + i * row_;
-            avail[i] = have / 2;
-            ended[i] = x.ended ? 1 : 0;
         }
-        // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
-        check(rh_memcpy_h2d(din_.get(), s.in.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
-        std::uint64_t out = 0, consumed = 0;
-        check(rh_rlm_stream_block_v(plan_, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, dout_.get(), out_cap_frames_, &out, &consumed, stream_), "rh_rlm_stream_block_v");
-        if (out) check(rh_memcpy_d2h_async(s.out.get(), dout_.get(), out * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
-        bool all_ended = true;
-        for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
-            Src &x = srcs_[i];
-            const float *row = s.in.get() + i * row_;
-            const std::size_t have = (std::size_t)avail[i] * 2, drop = std::min<std::size_t>((std::size_t)consumed * 2, have);
-            x.held.assign(row + drop, row + have);
-            all_ended = all_ended && x.ended;
+        if (!any_live) n = most;
+        // 3. sum the generations in insertion order (a single one is already the mix) and send the block to the host
+        if (n) {
+            const float *mixed = gens_.front()->queue();
+            if (gens_.size() > 1) {
+                std::vector<const float *> ptrs;
+                std::vector<std::uint64_t> start, len;
+                for (auto &gp : gens_) {
+                    ptrs.push_back(gp->queue());
+                    start.push_back(0);
+                    len.push_back(std::min(gp->fill, n) * 2);
+                }
+                dmix_.reset(out_cap_frames_ * 2 * 2);
+                check(rh_mix_sum(dmix_.get(), n * 2, ptrs.data(), start.data(), len.data(), (std::uint32_t)ptrs.size(), stream_), "rh_mix_sum");
+                mixed = dmix_.get();
+            }
+            check(rh_memcpy_d2h_async(s.out.get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
         }
-        s.n = (std::size_t)out * 2;
-        s.last = all_ended;  // the call that saw every source ended emitted everything that was left
+        // 4. what a generation produced beyond n waits at the front of its (other) queue buffer
+        for (auto &gp : gens_) {
+            Gen &g = *gp;
+            const std::uint64_t used = std::min(g.fill, n), rem = g.fill - used, pad = rem & 1;  // the fused kernel writes 16-byte aligned blocks behind it
+            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * 2, g.queue() + used * 2, rem * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            g.cur ^= 1;
+            g.head = pad;
+            g.fill = rem;
+        }
+        // the slot's staging block stays in use until this block's copies have run: generations are only retired here,
+        // after their last frames were scheduled; their plans are destroyed once the stream has drained them
+        scheduled_ += n;
+        bool all_done = true;
+        for (auto &gp : gens_) all_done = all_done && gp->done && gp->fill == 0;
+        if (all_done) {
+            check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
+            for (auto &gp : gens_)
+                if (gp->plan) check(rh_rlm_destroy(gp->plan), "rh_rlm_destroy");
+            gens_.clear();
+        }
+        s.n = (std::size_t)n * 2;
+        s.last = gens_.empty() && pending_.empty();
     }
 
 private:
@@ -549,8 +579,23 @@ private:
         std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved)
         bool ended;
     };
-    void start() {
-        const std::uint32_t from = srcs_.front().up->sample_rate();
+    struct Gen {  // sources that joined together: one clock, one fused stream
+        std::vector<Src> srcs;
+        rh_rlm *plan = nullptr;
+        detail::DeviceBuf din, q[2];  // staged input rows; mixed output not yet served (ping-pong)
+        detail::PinnedBuf stage[2];   // one staging block per slot in flight
+        int cur = 0, slot = 0;
+        std::uint64_t head = 0, fill = 0;  // q[cur] holds `fill` frames from frame `head` on (head in {0,1}: the END stays 16-byte aligned)
+        bool done = false;                 // the stream emitted its last frame
+        const float *queue() const { return q[cur].get() + head * 2; }
+        float *queue_end() { return q[cur].get() + (head + fill) * 2; }
+    };
+    void start_generation() {
+        auto gp = std::make_unique<Gen>();
+        Gen &g = *gp;
+        g.srcs = std::move(pending_);
+        pending_.clear();
+        const std::uint32_t from = g.srcs.front().up->sample_rate();
         rh_rlm_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.from_rate = from;
@@ -565,30 +610,83 @@ private:
             cfg.custom_coeffs[0] = 1.0f;  // identity when there is no filter
             if (opt_.filter_kind >= 0) check(rh_biquad_coeffs(opt_.filter_kind, opt_.filter_freq, opt_.filter_q, rate_, cfg.custom_coeffs), "rh_biquad_coeffs");
         }
-        cfg.max_sources = (std::uint32_t)srcs_.size();
-        // a block can hold what the previous one left over: less than two tiles' worth of input
-        cap_frames_ = opt_.block_frames + 4096;
+        cfg.max_sources = (std::uint32_t)g.srcs.size();
+        cap_frames_ = opt_.block_frames + 4096;  // a block can hold what the previous one left over: less than two tiles' worth of input
         cfg.max_in_frames = cap_frames_;
         cfg.frames_per_lane = opt_.frames_per_lane;
-        check(rh_rlm_create(&plan_, &cfg), "rh_rlm_create");
+        check(rh_rlm_create(&g.plan, &cfg), "rh_rlm_create");
         std::vector<float> gains;
-        for (const Src &x : srcs_) gains.push_back(x.gain);
-        check(rh_rlm_set_gains(plan_, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
-        check(rh_rlm_stream_begin(plan_), "rh_rlm_stream_begin");
+        for (const Src &x : g.srcs) gains.push_back(x.gain);
+        check(rh_rlm_set_gains(g.plan, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
+        check(rh_rlm_stream_begin(g.plan), "rh_rlm_stream_begin");
         row_ = (cap_frames_ * 2 + 3) & ~std::size_t(3);  // 16-byte aligned rows
         std::uint64_t m = 0;
         check(rh_resample_out_frames(cap_frames_, from, rate_, 2, 0, &m), "rh_resample_out_frames");
-        out_cap_frames_ = m + 64;
-        dout_.reset(out_cap_frames_ * 2);
+        out_cap_frames_ = std::max<std::uint64_t>(out_cap_frames_, m + 64);
+        for (auto &other : gens_)  // rates differ between generations: every queue holds two of the largest blocks
+            for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * 2, (other->head + other->fill) * 2);
+        for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * 2);
+        last_join_ = scheduled_;
+        gens_.push_back(std::move(gp));
+    }
+    void grow_keep(detail::DeviceBuf &b, std::size_t floats, std::size_t keep) {
+        if (b.size() >= floats) return;
+        detail::DeviceBuf n(floats);
+        if (keep) check(rh_memcpy_d2d(n.get(), b.get(), keep * sizeof(float), stream_), "rh_memcpy_d2d");
+        check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
+        b.swap(n);
+    }
+    void run_block(Gen &g, Slot &) {
+        const std::size_t S = g.srcs.size();
+        detail::PinnedBuf &stage = g.stage[g.slot];
+        g.slot ^= 1;
+        stage.reset(S * row_);
+        g.din.reset(S * row_);
+        std::vector<const float *> ptrs(S);
+        std::vector<std::uint64_t> avail(S);
+        std::vector<std::uint8_t> ended(S);
+        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            float *row = stage.get() + i * row_;
+            std::size_t have = x.held.size();
+            if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
+            if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
+            if (!x.ended) {
+                const std::size_t want = opt_.block_frames * 2;
+                std::size_t got = x.up->read(row + have, want);  // straight into the staging block
+                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
+                have += got;
+                x.ended = got < want;
+            }
+            ptrs[i] = g.din.get() + i * row_;
+            avail[i] = have / 2;
+            ended[i] = x.ended ? 1 : 0;
+        }
+        // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
+        check(rh_memcpy_h2d(g.din.get(), stage.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
+        std::uint64_t out = 0, consumed = 0;
+        check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+              "rh_rlm_stream_block_v");
+        g.fill += out;
+        bool all_ended = true;
+        for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
+            Src &x = g.srcs[i];
+            const float *row = stage.get() + i * row_;
+            const std::size_t have = (std::size_t)avail[i] * 2, drop = std::min<std::size_t>((std::size_t)consumed * 2, have);
+            x.held.assign(row + drop, row + have);
+            all_ended = all_ended && x.ended;
+        }
+        g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }
 
     std::uint32_t rate_;
     Options opt_;
-    std::vector<Src> srcs_;
-    rh_rlm *plan_ = nullptr;
+    std::vector<Src> pending_;
+    std::vector<std::unique_ptr<Gen>> gens_;
     std::size_t cap_frames_ = 0, row_ = 0;
-    std::uint64_t out_cap_frames_ = 0;
-    detail::DeviceBuf din_, dout_;
+    std::uint64_t out_cap_frames_ = 0, scheduled_ = 0, last_join_ = 0;
+    detail::DeviceBuf dmix_;
 };
 
 }  // namespace rodio_hip

@@ -4,6 +4,9 @@
 //
 //   host_mirror_test mixer <dir> <S> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
 //       <dir>/src_<i>.f32 (stereo, interleaved), <dir>/gains.f32  ->  <dir>/out.f32
+//   host_mirror_test late <dir> <S0> <S1> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane> <pull_first>
+//       sources 0..S0-1 are added before the first next(); after <pull_first> samples were served, S1 more are added
+//       (Mixer::add on a running mixer).  Writes out.f32 and join.txt (the output frame at which they joined).
 //   host_mirror_test bench <S> <frames> <block_frames>
 //       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
 //   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
@@ -110,7 +113,33 @@ int main(int argc, char **argv) {
                         opt.block_frames, total, sec, (double)S * (double)frames * 2.0 / sec / 1e6);
             return 0;
         }
-        if (mode == "mixer" && argc == 10) {
+        if (mode == "late" && argc == 12) {
+            const int S0 = std::atoi(argv[3]), S1 = std::atoi(argv[4]);
+            const uint32_t from = (uint32_t)std::atoll(argv[5]), to = (uint32_t)std::atoll(argv[6]);
+            rh::GpuMixer::Options opt;
+            opt.filter_kind = std::atoi(argv[7]);
+            opt.filter_freq = (uint32_t)std::atoll(argv[8]);
+            opt.block_frames = (size_t)std::atoll(argv[9]);
+            opt.frames_per_lane = (uint32_t)std::atoll(argv[10]);
+            const size_t pull_first = (size_t)std::atoll(argv[11]);
+            const std::vector<float> gains = read_f32(dir + "/gains.f32");
+            rh::GpuMixer mixer(to, opt);
+            auto add = [&](int i) { mixer.add(std::make_unique<rh::SamplesBuffer>(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i)); };
+            for (int i = 0; i < S0; ++i) add(i);
+            for (size_t k = 0; k < pull_first; ++k) {
+                const std::optional<float> v = mixer.next();
+                if (!v) break;
+                out.push_back(*v);
+            }
+            for (int i = S0; i < S0 + S1; ++i) add(i);
+            const std::vector<float> rest = drain(mixer);
+            out.insert(out.end(), rest.begin(), rest.end());
+            std::FILE *jf = std::fopen((dir + "/join.txt").c_str(), "w");
+            if (jf) {
+                std::fprintf(jf, "%llu\n", (unsigned long long)mixer.last_join_frame());
+                std::fclose(jf);
+            }
+        } else if (mode == "mixer" && argc == 10) {
             const int S = std::atoi(argv[3]);
             const uint32_t from = (uint32_t)std::atoll(argv[4]), to = (uint32_t)std::atoll(argv[5]);
             rh::GpuMixer::Options opt;

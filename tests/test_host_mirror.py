@@ -92,6 +92,43 @@ def test_gpu_mixer_same_rate_passthrough_and_empty(O, tmp_path):
     assert len(got) == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
+@pytest.mark.parametrize("pull_first", [10, 30001, 200000])
+def test_gpu_mixer_add_on_a_running_mixer(O, tmp_path, filt, freq, pull_first):
+    # Mixer::add while the mixer is being pulled: the new sources start at a later output frame (reported by the shim;
+    # rodio admits them at the next frame, the shim after the blocks already in flight) and run on their own clock
+    ns = [60000, 45000, 30011, 52000, 20000]
+    S0, S1 = 3, 2
+    gains = np.array([1.0, 0.5, 0.8, 1.1, 0.6], dtype=np.float32)
+    xs = [rnd(3300 + i, 2 * n, 0.15) for i, n in enumerate(ns)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    gains.tofile(tmp_path / "gains.f32")
+    got = _run(["late", tmp_path, S0, S1, 44100, 48000, filt, freq, 8192, 4, pull_first], tmp_path)
+    join = int((tmp_path / "join.txt").read_text())
+
+    def mix(idx):
+        m = O.Mixer(2, 48000)
+        for i in idx:
+            u = O.UniformSourceIterator(O.TestSource(xs[i], 2, 44100).amplify(float(gains[i])), 2, 48000)
+            m.add(u.low_pass(freq) if filt == 0 else u)
+        return m.collect()
+
+    a, b = mix(range(S0)), mix(range(S0, S0 + S1))
+    if pull_first >= len(a):  # the mixer had run empty (None) before the new sources arrived: it resumes where it stopped
+        assert join * 2 == len(a)
+    ref = np.zeros(max(len(a), join * 2 + len(b)), dtype=np.float32)
+    ref[: len(a)] = a
+    ref[join * 2: join * 2 + len(b)] += b  # generations are summed as groups, in insertion order
+    assert join * 2 >= pull_first - 1 or pull_first > len(a)
+    assert len(got) == len(ref), (len(got), len(ref), join)
+    if filt < 0:
+        assert np.array_equal(got, ref)
+    else:
+        assert float(np.max(np.abs(got - ref))) <= TOL
+
+
 # ------------------------------------------------------------------ GpuSource: adapter chains, pulled ----
 CHAINS = [
     # (channels, rate, n_frames, ops, oracle chain)
