@@ -247,6 +247,7 @@ public:
         ch_ = up_->channels();
         rate_ = up_->sample_rate();
     }
+    ~GpuSource() override { (void)rh_stream_synchronize(stream_); }  // nothing of the chain may still run when its buffers go
     // -- Source
     std::uint16_t channels() const override { return ch_; }
     std::uint32_t sample_rate() const override { return rate_; }

@@ -1924,7 +1924,14 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         }
         p->st_cols = (uint32_t)cols;
         p->st_total.assign(n_sources, ~0ull);
-        if (p->filt) hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
+        if (p->filt && p->epoch >= 0xf0000000u) {  // keep the epoch tag from wrapping inside a stream (its states live in the table)
+            RH_HIP_TRY(hipMemsetAsync(p->d_gran, 0, p->gran_words * 8, hs));
+            p->epoch = 0;
+        }
+        if (p->filt) {
+            hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
+            RH_CHECK_LAUNCH();
+        }
     }
     // what every source can still give: a live one every frame whose two taps have arrived, an ended one all it has left
     uint64_t live_min = ~0ull, ended_max = 0;
@@ -1978,9 +1985,11 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         sa.gran_cols = p->st_cols;
         st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
         if (st != RH_OK) return st;
-        if (!final_block && p->filt)
+        if (!final_block && p->filt) {
             hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)tiles + 1u, (uint32_t)p->wave.J, p->epoch,
                                p->epoch + 1);
+            RH_CHECK_LAUNCH();
+        }
         p->st_m += out;
     }
     p->st_nsrc = n_sources;
