@@ -297,7 +297,7 @@ __device__ __forceinline__ void wait_groups(int n) {
 // source that ends inside a tile needs its own masked correction.
 // =================================================================================================
 template <int R, int KV, int NS, bool FILT>
-__global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(const Params p) {
+__global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {
     static_assert(R <= kMaxR, "frames per lane");
     static_assert(NS >= 2 && NS <= 4, "ring depth");
     static_assert(KV * (NS - 1) < 64, "vmcnt range");
@@ -399,28 +399,19 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
     float g_next = S ? dgain[4] : 1.0f;              // gain of source 0
     RH_PH_DECL
 
-    for (uint32_t s = 0; s < S && live; ++s) {
-        {  // the stage of source s has landed when at most the groups issued after it are outstanding
-            const uint32_t left = S - 1 - s;
-            wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
-        }
-        RH_PH(2)
-        v2f ta[R + 2], tb2[R + 2];
-        {
-            const lds_u8 *buf = lds + st_cur;
+    // Software pipeline over the sources: while source s is being computed, the taps of source s+1 are already on their
+    // way from the LDS (two register sets, the loop body is written out twice so that they swap without moves).
+    // Per iteration: taps(s) complete -> stage(s) is free -> DMA of source s+NS into it -> stage(s+1) landed ->
+    // tap reads of s+1 issued -> arithmetic of s.
+    auto read_taps = [&](uint32_t stage_off, v2f (&qa)[R + 2], v2f (&qb)[R + 2]) {
+        const lds_u8 *buf = lds + stage_off;
 #pragma unroll
-            for (int rr = 0; rr < R + 2; ++rr) {
-                ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
-                tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
-            }
+        for (int rr = 0; rr < R + 2; ++rr) {
+            qa[rr] = *(const lds_f2 *)(buf + offA[rr]);
+            qb[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
         }
-        // every tap is in a register: the stage is free for source s+NS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s + NS < S) stage_source((const void *)(uintptr_t)ptr_pref, st_cur);
-        ptr_pref = s + NS + 1 < S ? desc[4 * (uint64_t)(s + NS + 1)] : 0;
-        const float g = g_next;  // Amplify factor of source s
-        g_next = s + 1 < S ? dgain[8 * (uint64_t)(s + 1) + 4] : 1.0f;
-        RH_PH(1)
+    };
+    auto compute = [&](const v2f (&ta)[R + 2], const v2f (&tb2)[R + 2], const float g) {
         auto tap = [&](int rr) -> v2f {
             const v2f a = ta[rr], b = tb2[rr];
             v2f x;
@@ -463,9 +454,35 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : 2)) void k_rlm_fast(
                 acc[r].y += x.y;
             }
         }
+    };
+    auto iteration = [&](const uint32_t s, const v2f (&ca)[R + 2], const v2f (&cb)[R + 2], v2f (&na)[R + 2], v2f (&nb)[R + 2]) {
+        // the taps of source s are in registers: its stage is free for source s+NS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RH_PH(2)
+        if (s + NS < S) stage_source((const void *)(uintptr_t)ptr_pref, st_cur);
+        ptr_pref = s + NS + 1 < S ? desc[4 * (uint64_t)(s + NS + 1)] : 0;
+        const float g = g_next;  // Amplify factor of source s
+        g_next = s + 1 < S ? dgain[8 * (uint64_t)(s + 1) + 4] : 1.0f;
         st_cur += kStage;
         if (st_cur >= NS * kStage) st_cur = 0;
+        if (s + 1 < S) {  // the stage of source s+1 has landed when at most the groups issued after it are outstanding
+            const uint32_t left = S - 2 - s;
+            wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
+            read_taps(st_cur, na, nb);
+        }
+        RH_PH(1)
+        compute(ca, cb, g);
         RH_PH(4)
+    };
+    v2f tA[R + 2], tB[R + 2], uA[R + 2], uB[R + 2];
+    if (live && S) {
+        const uint32_t left = S - 1;
+        wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
+        read_taps(0, tA, tB);
+    }
+    for (uint32_t s = 0; s < S && live; s += 2) {
+        iteration(s, tA, tB, uA, uB);
+        if (s + 1 < S) iteration(s + 1, uA, uB, tA, tB);
     }
     wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
 
