@@ -277,7 +277,7 @@ typedef struct rh_rlm_config {
     uint32_t from_rate, to_rate;
     uint32_t channels;     /* 2 (stereo) in this round */
     uint64_t span_len;     /* 0 = None; else chunk of min(span_len, 32768) samples */
-    int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter, 2 = custom_coeffs (from_rate == to_rate allowed) */
+    int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter, 2 = custom_coeffs; from_rate == to_rate: the converter passes through */
     uint32_t filter_freq;
     float filter_q;        /* rodio's low_pass() uses 0.5 (blt.rs:11-16) */
     uint32_t max_sources;

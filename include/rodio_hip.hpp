@@ -199,6 +199,8 @@ protected:
     virtual void enqueue(Slot &s) = 0;
     /// A source that returned None may yield samples again (rodio's MixerSource after a later Mixer::add).
     virtual bool can_resume() const { return false; }
+    /// Called when a block's work has completed, before it is served: a place to surface device-side failures.
+    virtual void block_done() {}
     rh_stream stream_ = nullptr;
 
 private:
@@ -224,6 +226,7 @@ private:
             cur_ ^= 1;  // the block that was enqueued while the previous one was being served
         }
         check(rh_event_synchronize(cur().done), "rh_event_synchronize");
+        block_done();
         pos_ = 0;
         if (!cur().last) submit(slot_[cur_ ^ 1]);  // prefetch: pull and process one block ahead
         return true;
@@ -496,11 +499,21 @@ public:
         for (auto &g : gens_)
             if (g->plan) (void)rh_rlm_destroy(g->plan);
     }
-    /// Mixer::add (mixer.rs:58-66), with the source's volume.
+    /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: what the fused kernel does not take as it
+    /// is -- a channel count other than 2, or a rate more than twice the mixer's -- first runs through the matching
+    /// GPU adapter (ChannelCountConverter / SampleRateConverter, uniform.rs:78-97 order), still one pull chain.
     void add(BoxSource src, float gain = 1.0f) {
         if (!src) throw std::invalid_argument("source");
-        if (src->channels() != 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: stereo sources (convert with GpuSource::uniform first)");
-        if (!pending_.empty() && src->sample_rate() != pending_.front().up->sample_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: sources added together share one input rate");
+        const std::uint16_t ch = src->channels();
+        const std::uint32_t from = src->sample_rate();
+        if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
+        const bool steep = fused_ratio_unsupported(from, rate_);
+        if (ch != 2 || steep) {
+            auto conv = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
+            if (ch != 2) conv->convert_channels(2);
+            if (steep) conv->convert_sample_rate(rate_);
+            src = std::move(conv);
+        }
         pending_.push_back(Src{std::move(src), gain, {}, false});
     }
     std::uint16_t channels() const override { return 2; }
@@ -510,6 +523,10 @@ public:
 
 protected:
     bool can_resume() const override { return !pending_.empty(); }  // mixer.rs:117-136: None while empty, samples again after add()
+    void block_done() override {  // a bounded wait inside the fused kernel expired (never seen on a healthy device): fail loudly
+        for (auto &g : gens_)
+            if (g->plan) check(rh_rlm_last_status(g->plan), "rh_rlm_last_status");
+    }
     void enqueue(Slot &s) override {
         if (!pending_.empty()) start_generation();
         if (gens_.empty()) {  // nothing to pull
@@ -591,11 +608,33 @@ private:
         const float *queue() const { return q[cur].get() + head * 2; }
         float *queue_end() { return q[cur].get() + (head + fill) * 2; }
     };
-    void start_generation() {
+    static bool fused_ratio_unsupported(std::uint32_t from, std::uint32_t to) {  // rh_rlm_create: reduced from/to <= 2, from*to within u32
+        std::uint64_t a = from, b = to;
+        while (b) {
+            const std::uint64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        const std::uint64_t F = from / a, T = to / a;
+        return F > 2 * T || F * T > 0xffffffffull;
+    }
+    void start_generation() {  // the sources that joined together: one fused stream per input rate, in order of first appearance
+        std::vector<Src> all = std::move(pending_);
+        pending_.clear();
+        std::vector<std::uint32_t> rates;
+        for (const Src &x : all)
+            if (std::find(rates.begin(), rates.end(), x.up->sample_rate()) == rates.end()) rates.push_back(x.up->sample_rate());
+        for (const std::uint32_t r : rates) {
+            std::vector<Src> group;
+            for (Src &x : all)
+                if (x.up && x.up->sample_rate() == r) group.push_back(std::move(x));
+            start_stream(std::move(group));
+        }
+    }
+    void start_stream(std::vector<Src> srcs) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
-        g.srcs = std::move(pending_);
-        pending_.clear();
+        g.srcs = std::move(srcs);
         const std::uint32_t from = g.srcs.front().up->sample_rate();
         rh_rlm_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
@@ -606,11 +645,6 @@ private:
         cfg.filter_kind = opt_.filter_kind;
         cfg.filter_freq = opt_.filter_freq;
         cfg.filter_q = opt_.filter_q;
-        if (from == rate_) {  // sample_rate.rs:133-136: the converter passes through; the plan then takes explicit coefficients
-            cfg.filter_kind = 2;
-            cfg.custom_coeffs[0] = 1.0f;  // identity when there is no filter
-            if (opt_.filter_kind >= 0) check(rh_biquad_coeffs(opt_.filter_kind, opt_.filter_freq, opt_.filter_q, rate_, cfg.custom_coeffs), "rh_biquad_coeffs");
-        }
         cfg.max_sources = (std::uint32_t)g.srcs.size();
         cap_frames_ = opt_.block_frames + 4096;  // a block can hold what the previous one left over: less than two tiles' worth of input
         cfg.max_in_frames = cap_frames_;

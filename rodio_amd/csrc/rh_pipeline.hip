@@ -1532,8 +1532,7 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     RH_REQUIRE_INIT();
     if (!out || !cfg || cfg->from_rate == 0 || cfg->to_rate == 0 || cfg->channels == 0 || cfg->max_sources == 0) return RH_ERR_INVALID;
     if (cfg->channels != 2) return RH_ERR_UNSUPPORTED;
-    // passthrough converter (sample_rate.rs:133-136): only as the time-parallel stand-alone filter (filter_kind 2)
-    if (cfg->from_rate == cfg->to_rate && cfg->filter_kind != 2) return RH_ERR_UNSUPPORTED;
+    // from_rate == to_rate: the converter passes through (sample_rate.rs:133-136): filter + ordered mix only
     if (cfg->max_in_frames >= (1ull << 29)) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets inside a source
     rh::ResampleGeom g;
     rh_status st = rh::make_resample_geom(cfg->max_in_frames, cfg->from_rate, cfg->to_rate, cfg->channels, cfg->span_len, &g);
@@ -1931,7 +1930,7 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         if (st != RH_OK) return st;
         const uint64_t cols = (g.out_frames + L - 1) / L + 2;
         if (cols > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-        const size_t words = (size_t)p->cfg.max_sources * cols * 4;
+        const size_t words = (size_t)(p->cfg.max_sources + 1) * cols * 4;  // as activate_plan counts: one row per source + the row of summed aggregates
         if (p->filt && words > p->gran_words) {
             if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
             p->d_gran = nullptr;

@@ -4,6 +4,8 @@
 //
 //   host_mirror_test mixer <dir> <S> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
 //       <dir>/src_<i>.f32 (stereo, interleaved), <dir>/gains.f32  ->  <dir>/out.f32
+//   host_mirror_test mixany <dir> <S> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
+//       like mixer, but every source has its own layout: <dir>/spec.txt holds "channels rate gain" per source
 //   host_mirror_test late <dir> <S0> <S1> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane> <pull_first>
 //       sources 0..S0-1 are added before the first next(); after <pull_first> samples were served, S1 more are added
 //       (Mixer::add on a running mixer).  Writes out.f32 and join.txt (the output frame at which they joined).
@@ -113,7 +115,26 @@ int main(int argc, char **argv) {
                         opt.block_frames, total, sec, (double)S * (double)frames * 2.0 / sec / 1e6);
             return 0;
         }
-        if (mode == "late" && argc == 12) {
+        if (mode == "mixany" && argc == 9) {
+            const int S = std::atoi(argv[3]);
+            const uint32_t to = (uint32_t)std::atoll(argv[4]);
+            rh::GpuMixer::Options opt;
+            opt.filter_kind = std::atoi(argv[5]);
+            opt.filter_freq = (uint32_t)std::atoll(argv[6]);
+            opt.block_frames = (size_t)std::atoll(argv[7]);
+            opt.frames_per_lane = (uint32_t)std::atoll(argv[8]);
+            std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
+            if (!sf) throw std::runtime_error("spec.txt");
+            rh::GpuMixer mixer(to, opt);
+            for (int i = 0; i < S; ++i) {
+                unsigned ch = 0, rate = 0;
+                float gain = 1.0f;
+                if (std::fscanf(sf, "%u %u %f", &ch, &rate, &gain) != 3) throw std::runtime_error("spec.txt: short");
+                mixer.add(std::make_unique<rh::SamplesBuffer>((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gain);
+            }
+            std::fclose(sf);
+            out = drain(mixer);
+        } else if (mode == "late" && argc == 12) {
             const int S0 = std::atoi(argv[3]), S1 = std::atoi(argv[4]);
             const uint32_t from = (uint32_t)std::atoll(argv[5]), to = (uint32_t)std::atoll(argv[6]);
             rh::GpuMixer::Options opt;

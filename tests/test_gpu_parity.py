@@ -886,6 +886,55 @@ def test_fused_gains_filtered(G, O, R, general, filt, freq):
     p.close()
 
 
+@pytest.mark.parametrize("general", [0, 1])
+def test_fused_same_rate_is_the_ordered_mix(G, O, general):
+    # from_rate == to_rate: the converter passes through (sample_rate.rs:133-136); without a filter the fused kernel is the
+    # ordered mixer sum of the amplified sources, bit for bit; with one, the filtered mix
+    import torch
+
+    ns = [20000] * 5 if not general else [20000, 19999, 5, 0, 12000]
+    xs = [rnd(2800 + i, 2 * n) for i, n in enumerate(ns)]
+    gains = np.array([1.0, 0.9, 0.6, 1.3, 0.25], dtype=np.float32)
+    for filt, freq in ((None, 0), ("high_pass", 300)):
+        m = O.Mixer(2, 48000)
+        for x, g in zip(xs, gains):
+            a = O.TestSource(x, 2, 48000).amplify(float(g))
+            m.add(a.high_pass(freq) if filt else a)
+        ref = m.collect()
+        p = G.ResampleLowpassMix(48000, 48000, 2, None, filt, freq, 0.5, max_sources=len(xs), max_in_frames=20000, frames_per_lane=6, force_general=general)
+        p.set_gains(gains)
+        p.set_sources([torch.from_numpy(x).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs])
+        out = p.run().cpu().numpy().copy()
+        p.check_status()
+        assert len(out) == len(ref)
+        if filt is None:
+            assert np.array_equal(out, ref)
+        else:
+            assert float(np.max(np.abs(out - ref))) <= 5e-5  # full-scale sources: the f32 reference recurrence itself is ~1e-5 from exact
+        p.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_fused_block_streaming_per_source_states_few_sources(G, O, S):
+    # one source per stream is what a GpuMixer rate group often holds; full-size blocks against a small max_sources
+    import torch
+
+    n = 30000
+    xs = [rnd(2700 + s, 2 * n, 0.1) for s in range(S)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 300)
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 300, 0.5, max_sources=S, max_in_frames=8192 + 4096, frames_per_lane=4)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    p.stream_begin()
+    outs = []
+    cuts = list(range(0, n, 8192)) + [n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        outs.append(p.stream_feed_v([x[2 * a: 2 * b] for x in xd], [b >= n] * S))
+        p.check_status()
+    got = torch.cat(outs).cpu().numpy()
+    assert len(got) == len(ref) and float(np.max(np.abs(got - ref))) <= TOL
+    p.close()
+
+
 def test_fused_gains_block_streaming(G, O):
     import torch
 

@@ -93,6 +93,48 @@ def test_gpu_mixer_same_rate_passthrough_and_empty(O, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 300)])
+def test_gpu_mixer_takes_any_source_layout(O, tmp_path, filt, freq):
+    # mono, 5.1 and stereo sources at four rates (one of them more than twice the mixer's) in one mixer: what the fused
+    # kernel does not take directly is converted by the GPU adapters first; one fused stream per input rate
+    # (the fused stream of a rate group can hold a single source)
+    spec = [(2, 44100, 1.0, 30000), (1, 44100, 0.7, 25000), (2, 48000, 0.9, 20000), (6, 22050, 0.5, 9000), (2, 96000, 0.8, 50000),
+            (2, 192000, 0.6, 70000), (2, 44100, 1.1, 12345), (1, 8000, 0.4, 4000)]
+    xs = [rnd(3400 + i, ch * n, 0.1) for i, (ch, _, _, n) in enumerate(spec)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    (tmp_path / "spec.txt").write_text("".join(f"{ch} {rate} {g}\n" for ch, rate, g, _ in spec))
+    got = _run(["mixany", tmp_path, len(spec), 48000, filt, freq, 8192, 4], tmp_path)
+
+    def chain(i):
+        ch, rate, g, _ = spec[i]
+        u = O.UniformSourceIterator(O.TestSource(xs[i], ch, rate).amplify(float(np.float32(g))), 2, 48000)
+        return u.low_pass(freq) if filt == 0 else u
+
+    whole = O.Mixer(2, 48000)
+    for i in range(len(spec)):
+        whole.add(chain(i))
+    ref_all = whole.collect()
+    assert len(got) == len(ref_all)
+    assert float(np.max(np.abs(got - ref_all))) <= (TOL if filt == 0 else 2e-7)  # the order of the f32 sum differs between the rate groups
+    if filt < 0:  # exactly: the rate groups (in order of first appearance) are summed as groups
+        eff = [48000 if rate > 2 * 48000 else rate for _, rate, _, _ in spec]  # a steep ratio is converted before the fused stream
+        rates = []
+        for rate in eff:
+            if rate not in rates:
+                rates.append(rate)
+        ref = np.zeros(len(ref_all), dtype=np.float32)
+        for r in rates:
+            m = O.Mixer(2, 48000)
+            for i in range(len(spec)):
+                if eff[i] == r:
+                    m.add(chain(i))
+            part = m.collect()
+            ref[: len(part)] += part
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
 @pytest.mark.parametrize("pull_first", [10, 30001, 200000])
 def test_gpu_mixer_add_on_a_running_mixer(O, tmp_path, filt, freq, pull_first):

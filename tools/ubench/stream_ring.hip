@@ -59,7 +59,9 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *in, float *out, uin
 // The fused kernel's exact read pattern: tile t of source s reads nvec 16-byte vectors starting at vector
 // t*vstride (+ s*src_stride): chunks are 16-byte but not 128-byte aligned, the KV*64 - nvec surplus lanes
 // re-fetch the chunk's last vector.
-template <int KV, int NS, int A = 1>
+// CL != 0: the instructions cover blocks aligned to A vectors, but lanes outside the needed span [first 128-byte line of
+// the span, its last vector] are clamped into it -- aligned instructions without fetching more bytes
+template <int KV, int NS, int A = 1, int CL = 0>
 __global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t vstride, uint32_t nvec_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -73,6 +75,10 @@ __global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint3
     for (int kk = 0; kk < KV; ++kk) {
         uint32_t j = lane + kk * 64;
         j = j < nvec ? j : nvec - 1;
+        if (CL) {
+            const uint32_t lo = (v0 & ~7u) - va;  // first vector of the span's first 128-byte line
+            j = j < lo ? lo : j;
+        }
         off[kk] = (va + j) * 4;  // floats
     }
     auto issue = [&](uint32_t s) {
@@ -159,6 +165,10 @@ int main(int argc, char **argv) {
         timeit("R18, starts on 512 B, KV9", k_mimic<9, 2, 32>, 991, 40960, 529, 533);
         timeit("R18, starts on 1 KiB, KV10", k_mimic<10, 2, 64>, 991, 40960, 529, 533);
         timeit("R18, starts on 4 KiB, KV10", k_mimic<10, 2, 256>, 991, 40960, 529, 533);
+        timeit("R18, 1 KiB instr, clamped, KV10", k_mimic<10, 2, 64, 1>, 991, 40960, 529, 533);
+        timeit("R18, 512 B instr, clamped, KV9", k_mimic<9, 2, 32, 1>, 991, 40960, 529, 533);
+        timeit("R18, 256 B instr, clamped, KV9", k_mimic<9, 2, 16, 1>, 991, 40960, 529, 533);
+        timeit("R9, 1 KiB instr, clamped, KV6", k_mimic<6, 2, 64, 1>, 1982, 20480, 265, 269);
         timeit("R9 pattern KV5", k_mimic<5, 2>, 1982, 20480, 265, 269);
         timeit("R9, starts on 128 B", k_mimic<5, 2, 8>, 1982, 20480, 265, 269);
         timeit("R10 pattern KV5", k_mimic<5, 2>, 1784, 23040, 294, 298);
