@@ -536,8 +536,9 @@ protected:
         }
         s.out.reset(out_cap_frames_ * 2 * 2);
         // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
+        // (one that runs ahead of the slowest -- another rate, other tile boundaries -- waits with a full queue)
         for (auto &gp : gens_)
-            if (!gp->done) run_block(*gp, s);
+            if (!gp->done && gp->fill < out_cap_frames_) run_block(*gp, s);
         // 2. the frames every unfinished generation has reached; finished ones give what they have left
         std::uint64_t n = ~0ull, most = 0;
         bool any_live = false;

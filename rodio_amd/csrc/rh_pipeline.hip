@@ -62,7 +62,8 @@ namespace {
 constexpr int kMaxR = 20;
 constexpr int kGroupLag = RH_CARRY_DEFER;  // a source group's carries are fetched kGroupLag groups (of 8 sources) after its own
 constexpr int kMaxLook = 32;              // 2 lanes x 16 B of LDS-DMA per predecessor tile: 64 lanes
-constexpr uint32_t kSpinLimit = 1u << 16;  // x (~1 us load + s_sleep): ~0.1 s, then give up for good
+constexpr uint32_t kSpinLimit = 1u << 22;  // x (~1 us load + s_sleep): seconds, then give up for good.  Waits end by construction (a tile only
+                                           // waits for tiles with earlier tickets); the bound must outlast a GPU that is time-sliced with other processes
 
 struct SrcDesc {          // 32 bytes, read with s_load (constant address space)
     const float *data;
@@ -296,7 +297,12 @@ __device__ __forceinline__ void wait_groups(int n) {
 // homogeneous correction g[r] * (start state).  Ragged batches take k_rlm_wave below instead, where a
 // source that ends inside a tile needs its own masked correction.
 // =================================================================================================
-template <int R, int KV, int NS, bool FILT>
+// RAG: the equal-length kernel as the first half of a ragged batch (rh_rlm_run on sources of different lengths,
+// with a filter).  A tile then takes only the sources that stay whole for it and the J tiles after it ("stable":
+// nothing about them needs a per-source aggregate, see k_rlm_wave) -- for a mixer's worth of tracks that is almost
+// every (tile, source) pair -- and k_rlm_resid, launched behind it, adds the few pairs in which a source is about
+// to end.  Mix order: stable sources first (the filtered pipeline is compared at 1e-5, not bitwise).
+template <int R, int KV, int NS, bool FILT, bool RAG = false>
 __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {
     static_assert(R <= kMaxR, "frames per lane");
     static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -392,11 +398,15 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     // sources in flight: the stage of source s is re-targeted by the DMA of source s+NS as soon as the
     // taps of s have returned, BEFORE the arithmetic of s.
     uint32_t st_cur = 0;
+    uint64_t ptr_pref = 0;
+    float g_next = 1.0f;
+    if (!RAG) {
 #pragma unroll
-    for (int d = 0; d < NS; ++d)
-        if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[4 * d], d * kStage);
-    uint64_t ptr_pref = NS < S ? desc[4 * NS] : 0;  // fetched one iteration ahead of its use
-    float g_next = S ? dgain[4] : 1.0f;              // gain of source 0
+        for (int d = 0; d < NS; ++d)
+            if ((uint32_t)d < S && live) stage_source((const void *)(uintptr_t)desc[4 * d], d * kStage);
+        ptr_pref = NS < S ? desc[4 * NS] : 0;  // fetched one iteration ahead of its use
+        g_next = S ? dgain[4] : 1.0f;          // gain of source 0
+    }
     RH_PH_DECL
 
     // Software pipeline over the sources: while source s is being computed, the taps of source s+1 are already on their
@@ -475,14 +485,73 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         RH_PH(4)
     };
     v2f tA[R + 2], tB[R + 2], uA[R + 2], uB[R + 2];
-    if (live && S) {
-        const uint32_t left = S - 1;
-        wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
-        read_taps(0, tA, tB);
-    }
-    for (uint32_t s = 0; s < S && live; s += 2) {
-        iteration(s, tA, tB, uA, uB);
-        if (s + 1 < S) iteration(s + 1, uA, uB, tA, tB);
+    if (!RAG) {
+        if (live && S) {
+            const uint32_t left = S - 1;
+            wait_groups<KV, NS>((int)(left < (uint32_t)(NS - 1) ? left : (uint32_t)(NS - 1)));
+            read_taps(0, tA, tB);
+        }
+        for (uint32_t s = 0; s < S && live; s += 2) {
+            iteration(s, tA, tB, uA, uB);
+            if (s + 1 < S) iteration(s + 1, uA, uB, tA, tB);
+        }
+    } else if (live) {
+        // The same pipeline over the SUBSEQUENCE of stable sources.  q[0] is the source being computed, q[1..NS-1] are
+        // in flight, q[NS] is the next one to fetch (S: none left).  `issued` / `waited` count DMA groups.
+        typedef __attribute__((address_space(4))) const uint32_t cu32;
+        cu32 *const dwords = (cu32 *)(uintptr_t)p.srcs;
+        // stable: whole for this tile and the J after it -- or until the mix itself ends (such sources share one length,
+        // eq_frames: the host checks it; the end-of-source handling above is theirs)
+        const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
+        const uint32_t m_stable = m_far < Mout ? m_far : Mout;
+        auto next_stable = [&](uint32_t from) {
+            uint32_t k = from;
+            while (k < S && dwords[8 * (uint64_t)k + 3] < m_stable) ++k;
+            return k;
+        };
+        uint32_t q[NS + 1];
+        uint32_t issued = 0, waited = 0;
+        {
+            uint32_t nxt = next_stable(0);
+#pragma unroll
+            for (int d = 0; d < NS; ++d) {
+                q[d] = nxt;
+                if (nxt < S) {
+                    stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)nxt], d * kStage);
+                    ++issued;
+                    nxt = next_stable(nxt + 1);
+                }
+            }
+            q[NS] = nxt;
+        }
+        auto rag_iteration = [&](const v2f (&ca)[R + 2], const v2f (&cb)[R + 2], v2f (&na)[R + 2], v2f (&nb)[R + 2]) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the taps of q[0] are in registers: its stage is free
+            if (q[NS] < S) {
+                stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)q[NS]], st_cur);
+                ++issued;
+            }
+            const float g = dgain[8 * (uint64_t)q[0] + 4];
+            st_cur += kStage;
+            if (st_cur >= NS * kStage) st_cur = 0;
+            if (q[1] < S) {  // the stage of q[1] has landed when only the groups issued after it are outstanding
+                ++waited;
+                wait_groups<KV, NS>((int)(issued - waited));
+                read_taps(st_cur, na, nb);
+            }
+            compute(ca, cb, g);
+#pragma unroll
+            for (int d = 0; d < NS; ++d) q[d] = q[d + 1];
+            q[NS] = q[NS] < S ? next_stable(q[NS] + 1) : S;
+        };
+        if (q[0] < S) {
+            ++waited;
+            wait_groups<KV, NS>((int)(issued - waited));
+            read_taps(0, tA, tB);
+        }
+        while (q[0] < S) {
+            rag_iteration(tA, tB, uA, uB);
+            if (q[0] < S) rag_iteration(uA, uB, tA, tB);
+        }
     }
     wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
 
@@ -1201,6 +1270,247 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     }
 }
 
+// =================================================================================================
+// k_rlm_resid -- second half of a ragged filtered batch (behind k_rlm_fast<RAG>): the (tile, source) pairs in which
+// the source is NOT stable, i.e. ends inside the tile or within the J tiles after it.  There are at most J+2 such tiles
+// per source, so this kernel is small however large the batch: a tile finds its pairs with a ballot over the
+// descriptors and handles each one start to finish -- stage, lerp, zero-state run (masked past the end of the
+// source), scan, publish the source's own aggregate, poll the predecessors that hold one, correct frame by frame --
+// adding onto what the first half stored.  Same tile geometry, tables and aggregate rows as k_rlm_wave.
+// =================================================================================================
+template <int R, int KV>
+__global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    const int lane = threadIdx.x;
+    // tiles are numbered in arrival order, like everywhere else: a pair polls predecessor tiles, which then hold earlier tickets
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    constexpr uint32_t L = 64u * R;
+    const uint32_t m_tile0 = tile * L;
+    const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
+    const bool first = (m0 == 0);
+    const uint32_t Mout = (uint32_t)p.out_frames;
+    const uint32_t ncol = p.n_tiles;
+    const uint32_t S = p.n_sources;
+    const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
+    const uint32_t m_stable = m_far < Mout ? m_far : Mout;  // sources that last as long as the mix are the first half's to the end
+    // ---- which sources are this tile's: still here, not stable ----
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    cu32 *const desc = (cu32 *)(uintptr_t)p.srcs;
+    const uint32_t *const dsrc = reinterpret_cast<const uint32_t *>(p.srcs);
+    bool any = false;
+    for (uint32_t b = 0; b < S; b += 64) {
+        const uint32_t q = b + lane;
+        const uint32_t ms = q < S ? dsrc[8 * (uint64_t)q + 3] : 0u;
+        any = any || __any(ms > m_tile0 && ms < m_stable);
+    }
+    if (!any) return;  // what k_rlm_fast<RAG> stored for this tile is final
+
+    uint32_t i_base, nvec;
+    {
+        uint64_t ib, ie;
+        uint32_t nn;
+        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        ib &= ~15ull;
+        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        ie += 1;
+        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        if (nv > (uint32_t)(KV * 64)) nv = KV * 64;
+        i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);
+        nvec = __builtin_amdgcn_readfirstlane(nv);
+    }
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = lane + k * 64;
+        j = j < nvec ? j : nvec - 1;
+        goff[k] = (i_base + 2u * j) * 8u;
+    }
+    int offA[R + 2];
+    float wgt[R + 2];
+    {
+        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            const bool dummy = first && rr < 2;
+            uint64_t i;
+            uint32_t num;
+            cursor_resolve(c, p, i, num);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
+            wgt[rr] = dummy ? 0.0f : (float)num / p.Tf;
+            if (!dummy) cursor_next(c, p);
+        }
+    }
+    const Tables *__restrict__ tb = p.tabs;
+    float lM[4], b15[4], b31[4], kM[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lM[q] = tb->laneM[lane][q];
+        b15[q] = tb->bc15M[lane][q];
+        b31[q] = tb->bc31M[lane][q];
+        kM[q] = tb->lookM[lane & (kMaxLook - 1)][q];
+    }
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+    const uint32_t Jc = p.J < tile ? p.J : tile;
+
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = v2f{0.0f, 0.0f};
+        if (m0 + r < Mout) {
+            const float2 v = *reinterpret_cast<const float2 *>(p.out + (uint64_t)(m0 + r) * 2);
+            acc[r] = v2f{v.x, v.y};
+        }
+    }
+    bool dead = false;
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint32_t Ms = desc[8 * (uint64_t)s + 3];
+        if (!(Ms > m_tile0 && Ms < m_stable)) continue;  // uniform
+        const uint64_t plo = desc[8 * (uint64_t)s], phi = desc[8 * (uint64_t)s + 1];
+        const void *data = (const void *)(uintptr_t)(plo | (phi << 32));
+        const uint32_t Ns = desc[8 * (uint64_t)s + 2];
+        const float g = __uint_as_float(desc[8 * (uint64_t)s + 4]);
+        // stage the tile's span of this source (lanes past its end re-fetch its last vector: finite data nothing valid reads)
+        if (i_base + 2u * nvec <= Ns) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + k * 1024);
+        } else {
+            const uint32_t lastoff = ((Ns - 1) & ~1u) * 8u;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + k * 1024);
+        }
+        wait_vm<0>();
+        const uint32_t dthr = Ns - 1 - i_base;  // Ms > m_tile0 => i_base <= Ns-1
+        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
+        const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
+        auto tap = [&](int rr) -> v2f {
+            const v2f a = *(const lds_f2 *)(lds + offA[rr]), b = *(const lds_f2 *)(lds + offA[rr] + 8);
+            v2f x;
+            x.x = fma_(b.x - a.x, wgt[rr], a.x);
+            x.y = fma_(b.y - a.y, wgt[rr], a.y);
+            const bool last = offA[rr] >= thr;  // the source's last frame is emitted verbatim (sample_rate.rs:193-200)
+            x.x = last ? a.x : x.x;
+            x.y = last ? a.y : x.y;
+            return x;
+        };
+        v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
+        v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
+        v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v2f x = tap(r + 2);
+            v2f w;
+            w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
+            w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
+            const bool v = r < nvalid;
+            const float yx = v ? fma_(b0, x.x, w.x) : 0.0f, yy = v ? fma_(b0, x.y, w.y) : 0.0f;
+            acc[r].x = fma_(g, yx, acc[r].x);
+            acc[r].y = fma_(g, yy, acc[r].y);
+            w2 = w1;
+            w1 = w;
+            x2 = x1;
+            x1 = x;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free for the next pair
+        float P[4] = {0.f, 0.f, 0.f, 0.f};
+        mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
+        mat_acc(p.u.Tm, w1.y * g, w2.y * g, P[2], P[3]);
+#define RH_SCAN_STEP(K, N)                                                                          \
+    {                                                                                               \
+        const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
+        const float q2 = dpp0<kDppRowShr + N, 0xf>(P[2]), q3 = dpp0<kDppRowShr + N, 0xf>(P[3]);     \
+        mat_acc(p.u.scanM[K], q0, q1, P[0], P[1]);                                                  \
+        mat_acc(p.u.scanM[K], q2, q3, P[2], P[3]);                                                  \
+    }
+        RH_SCAN_STEP(0, 1)
+        RH_SCAN_STEP(1, 2)
+        RH_SCAN_STEP(2, 4)
+        RH_SCAN_STEP(3, 8)
+#undef RH_SCAN_STEP
+        {
+            const float q0 = dpp0<kDppBcast15, 0xa>(P[0]), q1 = dpp0<kDppBcast15, 0xa>(P[1]);
+            const float q2 = dpp0<kDppBcast15, 0xa>(P[2]), q3 = dpp0<kDppBcast15, 0xa>(P[3]);
+            mat_acc(b15, q0, q1, P[0], P[1]);
+            mat_acc(b15, q2, q3, P[2], P[3]);
+        }
+        {
+            const float q0 = dpp0<kDppBcast31, 0xc>(P[0]), q1 = dpp0<kDppBcast31, 0xc>(P[1]);
+            const float q2 = dpp0<kDppBcast31, 0xc>(P[2]), q3 = dpp0<kDppBcast31, 0xc>(P[3]);
+            mat_acc(b31, q0, q1, P[0], P[1]);
+            mat_acc(b31, q2, q3, P[2], P[3]);
+        }
+        unsigned long long *const row = p.gran + (uint64_t)s * ncol * 4;
+        {  // this source's own aggregate for the tile (a later tile of it polls for it)
+            const float e0 = readlane_f(P[0], 63), e1 = readlane_f(P[1], 63);
+            const float e2 = readlane_f(P[2], 63), e3 = readlane_f(P[3], 63);
+            if (lane < 4) {
+                const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+                const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
+                __hip_atomic_store(row + (uint64_t)tile * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        float Q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Q[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
+        // predecessors in which the source was already on its own (in the others it was stable: its state came with the sums)
+        const uint32_t tM = Ms / L;
+        uint32_t have = tile + p.J > tM ? tile + p.J - tM : 0u;
+        have = have < Jc ? have : Jc;
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (have > 0) {
+            const bool want = (uint32_t)lane < have;
+            const unsigned long long *gp = row + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
+            unsigned long long gv[4] = {0, 0, 0, 0};
+            bool ok = false;
+            uint32_t spins = 0;
+            while (!dead) {
+                if (want && !ok) {
+                    bool all = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
+                    }
+                    ok = all;
+                }
+                if (__all(ok || !want)) break;
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicOr(p.status, 1u);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (want && ok && !dead) {
+                mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
+                mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // sum over lanes 0..31 -> uniform
+                c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 2, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 4, 0xf>(c[q]);
+                c[q] += dpp0<kDppRowShr + 8, 0xf>(c[q]);
+                c[q] = readlane_f(c[q], 15) + readlane_f(c[q], 31);
+            }
+        }
+        mat_acc(lM, c[0], c[1], Q[0], Q[1]);
+        mat_acc(lM, c[2], c[3], Q[2], Q[3]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool v = r < nvalid;
+            const float hx = fma_(p.u.g[r][0], Q[0], p.u.g[r][1] * Q[1]), hy = fma_(p.u.g[r][0], Q[2], p.u.g[r][1] * Q[3]);
+            acc[r].x += v ? hx : 0.0f;
+            acc[r].y += v ? hy : 0.0f;
+        }
+    }
+    float *o = p.out + (uint64_t)m0 * 2;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+}
+
 // Block streaming with per-source filter states (k_rlm_wave): after a block of n_tiles whole tiles, the state of
 // source s at the block's end is what tile n_tiles would have received as its carry -- the look-back over the
 // aggregates the block has just published (and, for short blocks, the previous block-start state in column 0).
@@ -1299,6 +1609,13 @@ const Variant kWave[] = {
     RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
     RH_WAVE(9, 5, 2), RH_WAVE(9, 5, 3), RH_WAVE(10, 5, 2), RH_WAVE(10, 5, 3), RH_WAVE(10, 6, 2), RH_WAVE(12, 6, 2), RH_WAVE(12, 6, 3), RH_WAVE(12, 7, 2),
 };
+// k_rlm_fast<.., RAG>: the first half of a ragged filtered batch, in the tile sizes of the general kernel (both halves
+// share the tile geometry, the tables and the aggregate rows)
+#define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true>, &k_rlm_resid<r, kv>}
+const Variant kRag[] = {
+    RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
+};
+#undef RH_RAG
 #undef RH_FAST
 #undef RH_WAVE
 template <size_t N>
@@ -1348,6 +1665,10 @@ struct rh_rlm {
     Plan fast, wave;        // equal-length batches / ragged batches
     Plan *plan = nullptr;   // chosen by set_sources
     uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
+    // ragged filtered one-shot batches: k_rlm_fast<RAG> over the stable (tile, source) pairs, then k_rlm_resid over the rest
+    bool hybrid = false;
+    const void *rag_kernel = nullptr, *resid_kernel = nullptr;
+    uint32_t rag_lds = 0, resid_lds = 0, rag_frames = 0;
     uint32_t eq_frames = 0;
     bool equal = true;
     std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
@@ -1366,7 +1687,15 @@ struct rh_rlm {
     uint32_t st_nsrc = 0;
     float *d_w[2] = {nullptr, nullptr};
     int st_cur = 0;
-    std::vector<SrcDesc> h_desc;  // host copy of the descriptor table (staging of the async uploads)
+    std::vector<SrcDesc> h_desc;  // host copy of the descriptor table
+    // Block streaming uploads a descriptor table per block while earlier blocks may still be queued: the copies go through
+    // a ring of page-locked tables, and a table is rewritten only after the copy that read it has run (an asynchronous
+    // copy from pageable memory may read its source later than the call -- seen as a block mixed with the next block's
+    // descriptors when the device was busy).
+    static constexpr int kDescRing = 4;
+    SrcDesc *h_ring[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t h_ring_ev[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
+    int h_ring_next = 0;
     std::vector<float> gains;     // per-source Amplify factors (1.0 when unset)
     // block streaming with per-source states (rh_rlm_stream_block_v)
     std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
@@ -1521,6 +1850,39 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     }
     p->plan = pl;
     p->n_tiles = (uint32_t)tiles;
+    // ragged + filter (one-shot runs): almost every (tile, source) pair is "stable" and goes through the lean kernel,
+    // k_rlm_resid adds the rest; both in the tile geometry of the general plan
+    p->hybrid = false;
+    if (pl == &p->wave && p->filt && !p->equal && !p->cfg.force_general && p->h_desc.size() == p->n_sources && tiles > 0 && !getenv("RH_NO_HYBRID")) {
+        // Eligible when (1) the sources that last as long as the mix share one length (the lean kernel's end-of-source
+        // handling is uniform) and (2) no tile holds many sources that are about to end (k_rlm_resid takes a tile's pairs
+        // one after the other; batches whose sources all end within a few frames of each other stay with k_rlm_wave).
+        const uint64_t J = pl->J;
+        uint32_t frames_of_longest = 0;
+        bool ok = true;
+        std::vector<uint32_t> pairs((size_t)tiles, 0u);
+        uint32_t most = 0;
+        for (const SrcDesc &d : p->h_desc) {
+            if (d.out_frames == M) {
+                ok = ok && (!frames_of_longest || frames_of_longest == d.frames);
+                frames_of_longest = d.frames;
+            } else if (d.out_frames > 0) {
+                const uint64_t t_end = (d.out_frames - 1) / L;                 // the tile the source ends in
+                const uint64_t t_lo = (uint64_t)d.out_frames / L > J ? (uint64_t)d.out_frames / L - J : 0;  // first tile with out_frames < (t+1+J)*L
+                for (uint64_t t = t_lo; t <= t_end && t < tiles; ++t) most = std::max(most, ++pairs[(size_t)t]);
+            }
+        }
+        if (ok && frames_of_longest && most <= 24) {
+            if (const Variant *rv = find_variant(kRag, p->wave.v->R, p->wave.v->KV, 2)) {
+                p->rag_kernel = reinterpret_cast<const void *>(rv->filt);
+                p->resid_kernel = reinterpret_cast<const void *>(rv->plain);
+                p->rag_lds = (uint32_t)lds_bytes_of(*rv, false, p->wave.J);
+                p->resid_lds = (uint32_t)rv->KV * 1024u;
+                p->rag_frames = frames_of_longest;
+                p->hybrid = blocks_per_cu(p->rag_kernel, p->rag_lds) >= 1 && blocks_per_cu(p->resid_kernel, p->resid_lds) >= 1;
+            }
+        }
+    }
     return RH_OK;
 }
 
@@ -1607,6 +1969,10 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->d_prof) (void)hipFree(p->d_prof);
     for (int k = 0; k < 2; ++k)
         if (p->d_w[k]) (void)hipFree(p->d_w[k]);
+    for (int k = 0; k < rh_rlm::kDescRing; ++k) {
+        if (p->h_ring_ev[k]) (void)hipEventDestroy(p->h_ring_ev[k]);
+        if (p->h_ring[k]) (void)hipHostFree(p->h_ring[k]);
+    }
     delete p;
     return RH_OK;
 }
@@ -1729,6 +2095,26 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     void *args[] = {&k};
     const uint64_t grid = (uint64_t)p->n_tiles * (batch_streams ? batch_streams : 1);
     if (grid > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
+    if (p->hybrid && &pl == &p->wave && !sa.mode && !batch_streams) {
+        // first half: the stable pairs, summed aggregates into the row behind the `count` per-source rows; second half:
+        // the few pairs in which a source is about to end, on top of the first (k_rlm_resid)
+        Params k1 = k;
+        k1.gran = p->d_gran + (uint64_t)count * p->n_tiles * 4;
+        k1.eq_frames = p->rag_frames;  // the sources that last as long as the mix (one length): the end-of-source handling is theirs
+        void *args1[] = {&k1};
+        hipError_t e1 = hipLaunchKernel(p->rag_kernel, dim3((uint32_t)grid), dim3(64), args1, p->rag_lds, s);
+        if (e1 == hipSuccess) {
+            p->ticket_base += (uint32_t)grid;
+            k.ticket_base = p->ticket_base;
+            e1 = hipLaunchKernel(p->resid_kernel, dim3((uint32_t)grid), dim3(64), args, p->resid_lds, s);
+            p->ticket_base += (uint32_t)grid;
+        }
+        if (e1 != hipSuccess) {
+            rh::set_hip_error(e1, "ragged batch launch");
+            return RH_ERR_HIP;
+        }
+        return RH_OK;
+    }
     // batch mode fills the chip many times over: no residency shaping, the bare LDS request
     hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? pl.lds_bytes : p->launch_lds, s);
     if (e != hipSuccess) {
@@ -1814,6 +2200,22 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
 // scan basis) -- the merged-state kernel never needs a per-source state.  A block emits whole lane runs only
 // (a multiple of R output frames), so that the state at its end is a lane's start state; the frames that are
 // left over stay with the caller: *consumed tells how many of the frames it passed are done with.
+// Upload h_desc[0..n) to d_srcs on `s` through the page-locked ring.
+static rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s) {
+    const int k = p->h_ring_next;
+    p->h_ring_next = (k + 1) % rh_rlm::kDescRing;
+    if (!p->h_ring[k]) {
+        RH_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_ring[k]), sizeof(SrcDesc) * p->cfg.max_sources, hipHostMallocDefault));
+        RH_HIP_TRY(hipEventCreateWithFlags(&p->h_ring_ev[k], hipEventDisableTiming));
+    } else {
+        RH_HIP_TRY(hipEventSynchronize(p->h_ring_ev[k]));  // the copy that last read this table has run (normally long ago)
+    }
+    std::memcpy(p->h_ring[k], p->h_desc.data(), sizeof(SrcDesc) * n);
+    RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, p->h_ring[k], sizeof(SrcDesc) * n, hipMemcpyHostToDevice, s));
+    RH_HIP_TRY(hipEventRecord(p->h_ring_ev[k], s));
+    return RH_OK;
+}
+
 rh_status rh_rlm_stream_begin(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
@@ -1856,16 +2258,16 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
     if (out > 0 || flush) {
         if (out > 0) {
             if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
-            // one staging area per handle: a previous block's copy must have been consumed before it is
-            // rewritten, which the stream order of (copy, kernel) pairs on ONE stream guarantees only after
-            // the copy itself has read the host memory -- pageable-memory copies return after staging
             std::vector<SrcDesc> &h = p->h_desc;
             h.resize(n_sources);
             for (uint32_t s = 0; s < n_sources; ++s) {
                 if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
                 h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
             }
-            RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, rh::as_stream(stream)));
+            {
+                const rh_status up = upload_descriptors(p, n_sources, rh::as_stream(stream));
+                if (up != RH_OK) return up;
+            }
             p->equal = true;
             p->eq_frames = (uint32_t)avail_frames;
             p->n_sources = n_sources;
@@ -1987,7 +2389,10 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
             if (ms && (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u))) return RH_ERR_INVALID;
             h[s] = SrcDesc{ms ? srcs_host[s] : nullptr, ms ? (uint32_t)avail_frames_host[s] : 0u, (uint32_t)ms, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
         }
-        RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice, hs));
+        {
+            const rh_status up = upload_descriptors(p, n_sources, hs);
+            if (up != RH_OK) return up;
+        }
         p->equal = false;
         p->n_sources = n_sources;
         p->out_frames = out;

@@ -249,9 +249,9 @@ rh_status rh_agc_state_init(float *state, uint32_t n_streams, rh_stream stream) 
     if (!state) return RH_ERR_INVALID;
     hipStream_t s = rh::as_stream(stream);
     RH_HIP_TRY(hipMemsetAsync(state, 0, sizeof(float) * kAgcStateFloats * n_streams, s));
-    const float one = 1.0f;  // current_gain starts at 1.0
+    // current_gain starts at 1.0 (0x3f800000): a fill, not an asynchronous copy from a variable that is gone on return
     for (uint32_t i = 0; i < n_streams; ++i)
-        RH_HIP_TRY(hipMemcpyAsync(state + (size_t)i * kAgcStateFloats + 3, &one, sizeof(float), hipMemcpyHostToDevice, s));
+        RH_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + (size_t)i * kAgcStateFloats + 3), 0x3f800000, 1, s));
     return RH_OK;
 }
 
