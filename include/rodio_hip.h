@@ -358,6 +358,7 @@ typedef struct rh_rlm_geometry_info {
     uint32_t resident_waves_per_cu;
     uint32_t n_tiles;          /* grid of the last set_sources */
     uint32_t general_kernel;   /* 1: ragged-batch kernel (per-source carries), 0: equal-length kernel */
+    uint32_t ragged_pair;      /* 1: one-shot runs of this batch take k_rlm_fast<RAG> + k_rlm_resid instead of the ragged-batch kernel */
 } rh_rlm_geometry_info;
 rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info);
 

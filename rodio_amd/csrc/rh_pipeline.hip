@@ -2483,6 +2483,7 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->resident_waves_per_cu = (uint32_t)pl.resident_per_cu;
     info->n_tiles = p->n_tiles;
     info->general_kernel = pl.general ? 1u : 0u;
+    info->ragged_pair = (p->hybrid && p->plan == &p->wave) ? 1u : 0u;
     return RH_OK;
 }
 

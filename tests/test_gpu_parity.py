@@ -886,6 +886,26 @@ def test_fused_gains_filtered(G, O, R, general, filt, freq):
     p.close()
 
 
+def test_fused_ragged_filtered_batches_take_the_kernel_pair(G, O):
+    # one-shot filtered batches of different lengths: k_rlm_fast<RAG> (stable pairs) + k_rlm_resid (sources about to end);
+    # batches whose sources all end together within a tile stay with k_rlm_wave; both agree with the oracle
+    import torch
+
+    n = 60000
+    cases = {"one short": ([n] * 9 + [n // 2], 1), "spread": ([n - 1500 * i for i in range(12)], 1), "all end within a tile": ([n - i for i in range(40)], 0),
+             "longest differ in frames only": ([n] * 3 + [n - 1] * 30, 0)}
+    for tag, (ns, want_pair) in cases.items():
+        xs = [rnd(2900 + i, 2 * m, 0.05) for i, m in enumerate(ns)]
+        ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 300)
+        truth = _truth_pipeline(O, xs, 44100, 48000, None, "low_pass", 300)
+        out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 300)
+        assert geo["general_kernel"] == 1 and geo["ragged_pair"] == want_pair, (tag, geo)
+        _check_filtered("ragged pair " + tag, out, ref, truth)
+        out2, geo2 = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 300, force_general=1)
+        assert geo2["ragged_pair"] == 0
+        assert float(np.max(np.abs(out - out2))) <= 1e-6
+
+
 @pytest.mark.parametrize("general", [0, 1])
 def test_fused_same_rate_is_the_ordered_mix(G, O, general):
     # from_rate == to_rate: the converter passes through (sample_rate.rs:133-136); without a filter the fused kernel is the
