@@ -1614,6 +1614,7 @@ const Variant kWave[] = {
 #define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true>, &k_rlm_resid<r, kv>}
 const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
+    RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
 };
 #undef RH_RAG
 #undef RH_FAST
@@ -1663,12 +1664,10 @@ struct rh_rlm {
     bool filt;
     float coeffs[5];
     Plan fast, wave;        // equal-length batches / ragged batches
+    Plan pair;              // ragged filtered one-shot batches: k_rlm_fast<RAG> (v->filt) + k_rlm_resid (v->plain); v == nullptr: none
     Plan *plan = nullptr;   // chosen by set_sources
     uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
-    // ragged filtered one-shot batches: k_rlm_fast<RAG> over the stable (tile, source) pairs, then k_rlm_resid over the rest
-    bool hybrid = false;
-    const void *rag_kernel = nullptr, *resid_kernel = nullptr;
-    uint32_t rag_lds = 0, resid_lds = 0, rag_frames = 0;
+    uint32_t rag_frames = 0;  // pair plan: the length of the sources that last as long as the mix
     uint32_t eq_frames = 0;
     bool equal = true;
     std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
@@ -1816,6 +1815,32 @@ rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, 
     return RH_OK;
 }
 
+// Can the batch that is set take the kernel pair in the tile geometry of `pl`?  (1) the sources that last as long as the
+// mix share one length (the lean kernel's end-of-source handling is uniform) and (2) no tile holds many sources that are
+// about to end (k_rlm_resid takes a tile's pairs one after the other; batches whose sources all end within a few frames of
+// each other stay with k_rlm_wave).
+bool pair_ok(rh_rlm *p, const Plan &pl) {
+    if (!pl.v || !p->filt || p->equal || p->cfg.force_general || p->h_desc.size() != p->n_sources || getenv("RH_NO_HYBRID")) return false;
+    const uint64_t M = p->out_frames, L = 64ull * pl.v->R, J = pl.J;
+    const uint64_t tiles = (M + L - 1) / L;
+    if (!tiles) return false;
+    uint32_t frames_of_longest = 0, most = 0;
+    std::vector<uint32_t> pairs((size_t)tiles, 0u);
+    for (const SrcDesc &d : p->h_desc) {
+        if (d.out_frames == M) {
+            if (frames_of_longest && frames_of_longest != d.frames) return false;
+            frames_of_longest = d.frames;
+        } else if (d.out_frames > 0) {
+            const uint64_t t_end = (d.out_frames - 1) / L;                                              // the tile the source ends in
+            const uint64_t t_lo = (uint64_t)d.out_frames / L > J ? (uint64_t)d.out_frames / L - J : 0;  // first tile with out_frames < (t+1+J)*L
+            for (uint64_t t = t_lo; t <= t_end && t < tiles; ++t) most = std::max(most, ++pairs[(size_t)t]);
+        }
+    }
+    if (!frames_of_longest || most > 24) return false;
+    p->rag_frames = frames_of_longest;
+    return true;
+}
+
 // Point the handle at a plan for the current batch: grid, aggregate table, LDS request.
 rh_status activate_plan(rh_rlm *p, Plan *pl) {
     const uint64_t M = p->out_frames;
@@ -1850,39 +1875,6 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     }
     p->plan = pl;
     p->n_tiles = (uint32_t)tiles;
-    // ragged + filter (one-shot runs): almost every (tile, source) pair is "stable" and goes through the lean kernel,
-    // k_rlm_resid adds the rest; both in the tile geometry of the general plan
-    p->hybrid = false;
-    if (pl == &p->wave && p->filt && !p->equal && !p->cfg.force_general && p->h_desc.size() == p->n_sources && tiles > 0 && !getenv("RH_NO_HYBRID")) {
-        // Eligible when (1) the sources that last as long as the mix share one length (the lean kernel's end-of-source
-        // handling is uniform) and (2) no tile holds many sources that are about to end (k_rlm_resid takes a tile's pairs
-        // one after the other; batches whose sources all end within a few frames of each other stay with k_rlm_wave).
-        const uint64_t J = pl->J;
-        uint32_t frames_of_longest = 0;
-        bool ok = true;
-        std::vector<uint32_t> pairs((size_t)tiles, 0u);
-        uint32_t most = 0;
-        for (const SrcDesc &d : p->h_desc) {
-            if (d.out_frames == M) {
-                ok = ok && (!frames_of_longest || frames_of_longest == d.frames);
-                frames_of_longest = d.frames;
-            } else if (d.out_frames > 0) {
-                const uint64_t t_end = (d.out_frames - 1) / L;                 // the tile the source ends in
-                const uint64_t t_lo = (uint64_t)d.out_frames / L > J ? (uint64_t)d.out_frames / L - J : 0;  // first tile with out_frames < (t+1+J)*L
-                for (uint64_t t = t_lo; t <= t_end && t < tiles; ++t) most = std::max(most, ++pairs[(size_t)t]);
-            }
-        }
-        if (ok && frames_of_longest && most <= 24) {
-            if (const Variant *rv = find_variant(kRag, p->wave.v->R, p->wave.v->KV, 2)) {
-                p->rag_kernel = reinterpret_cast<const void *>(rv->filt);
-                p->resid_kernel = reinterpret_cast<const void *>(rv->plain);
-                p->rag_lds = (uint32_t)lds_bytes_of(*rv, false, p->wave.J);
-                p->resid_lds = (uint32_t)rv->KV * 1024u;
-                p->rag_frames = frames_of_longest;
-                p->hybrid = blocks_per_cu(p->rag_kernel, p->rag_lds) >= 1 && blocks_per_cu(p->resid_kernel, p->resid_lds) >= 1;
-            }
-        }
-    }
     return RH_OK;
 }
 
@@ -1934,6 +1926,7 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
         st = RH_ERR_INVALID;
     }
+    if (st == RH_OK && p->filt && make_plan(p, p->pair, kRag, false, g, 0, 0) != RH_OK) p->pair.v = nullptr;  // optional
     hipError_t e = hipSuccess;
     if (st == RH_OK) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
@@ -1955,14 +1948,16 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
-    bool fast_in_tried = false, wave_in_tried = false;
+    bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
     for (Plan &c : p->tried) {
         fast_in_tried = fast_in_tried || c.d_tabs == p->fast.d_tabs;
         wave_in_tried = wave_in_tried || c.d_tabs == p->wave.d_tabs;
+        pair_in_tried = pair_in_tried || c.d_tabs == p->pair.d_tabs;
         if (c.d_tabs) (void)hipFree(c.d_tabs);
     }
     if (p->fast.d_tabs && !fast_in_tried) (void)hipFree(p->fast.d_tabs);
     if (p->wave.d_tabs && !wave_in_tried) (void)hipFree(p->wave.d_tabs);
+    if (p->pair.d_tabs && !pair_in_tried) (void)hipFree(p->pair.d_tabs);
     if (p->d_srcs) (void)hipFree(p->d_srcs);
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
@@ -2002,7 +1997,9 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
     p->n_sources = n_sources;
     p->out_frames = M;
     // equal-length batch: the merged-state kernel; otherwise the general one
-    return activate_plan(p, (equal && !p->cfg.force_general) ? &p->fast : &p->wave);
+    if (equal && !p->cfg.force_general) return activate_plan(p, &p->fast);
+    // different lengths + filter: almost every (tile, source) pair is "stable" and goes through the lean kernel of the pair
+    return activate_plan(p, pair_ok(p, p->pair) ? &p->pair : &p->wave);
 }
 
 rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
@@ -2095,18 +2092,18 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     void *args[] = {&k};
     const uint64_t grid = (uint64_t)p->n_tiles * (batch_streams ? batch_streams : 1);
     if (grid > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    if (p->hybrid && &pl == &p->wave && !sa.mode && !batch_streams) {
+    if (&pl == &p->pair && !sa.mode && !batch_streams) {
         // first half: the stable pairs, summed aggregates into the row behind the `count` per-source rows; second half:
         // the few pairs in which a source is about to end, on top of the first (k_rlm_resid)
         Params k1 = k;
         k1.gran = p->d_gran + (uint64_t)count * p->n_tiles * 4;
         k1.eq_frames = p->rag_frames;  // the sources that last as long as the mix (one length): the end-of-source handling is theirs
         void *args1[] = {&k1};
-        hipError_t e1 = hipLaunchKernel(p->rag_kernel, dim3((uint32_t)grid), dim3(64), args1, p->rag_lds, s);
+        hipError_t e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->filt), dim3((uint32_t)grid), dim3(64), args1, pl.lds_bytes, s);
         if (e1 == hipSuccess) {
             p->ticket_base += (uint32_t)grid;
             k.ticket_base = p->ticket_base;
-            e1 = hipLaunchKernel(p->resid_kernel, dim3((uint32_t)grid), dim3(64), args, p->resid_lds, s);
+            e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->plain), dim3((uint32_t)grid), dim3(64), args, (uint32_t)pl.v->KV * 1024u, s);
             p->ticket_base += (uint32_t)grid;
         }
         if (e1 != hipSuccess) {
@@ -2129,10 +2126,10 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
     RH_REQUIRE_INIT();
     if (!p || !dst) return RH_ERR_INVALID;
     if (p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
-        const bool general = p->plan == &p->wave;
-        Plan &slot = general ? p->wave : p->fast;
+        const bool general = p->plan == &p->wave, is_pair = p->plan == &p->pair;
+        Plan &slot = is_pair ? p->pair : general ? p->wave : p->fast;
         rh::ResampleGeom g;
-        rh_status st = rh::make_resample_geom(general ? p->cfg.max_in_frames : p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
+        rh_status st = rh::make_resample_geom((general || is_pair) ? p->cfg.max_in_frames : p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
         if (st != RH_OK) return st;
         hipStream_t s = rh::as_stream(stream);
         hipEvent_t e0, e1;
@@ -2167,7 +2164,14 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
             for (int NS = 2; NS <= 3; ++NS) {
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
-                if ((general ? make_plan(p, cand, kWave, true, g, (uint32_t)R, (uint32_t)NS) : make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK) continue;
+                if ((is_pair   ? make_plan(p, cand, kRag, false, g, (uint32_t)R, (uint32_t)NS)
+                     : general ? make_plan(p, cand, kWave, true, g, (uint32_t)R, (uint32_t)NS)
+                               : make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK)
+                    continue;
+                if (is_pair && !pair_ok(p, cand)) {  // this tile size would put too many ending sources into one tile
+                    p->tried.push_back(cand);
+                    continue;
+                }
                 p->tried.push_back(cand);
                 const uint64_t tiles = (p->out_frames + 64ull * R - 1) / (64ull * R);
                 const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
@@ -2482,8 +2486,8 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->lookback_tiles = pl.J;
     info->resident_waves_per_cu = (uint32_t)pl.resident_per_cu;
     info->n_tiles = p->n_tiles;
-    info->general_kernel = pl.general ? 1u : 0u;
-    info->ragged_pair = (p->hybrid && p->plan == &p->wave) ? 1u : 0u;
+    info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
+    info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
     return RH_OK;
 }
 
