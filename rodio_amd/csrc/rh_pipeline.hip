@@ -2180,7 +2180,7 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
                 if ((st = activate_plan(p, &slot)) != RH_OK) break;
                 float ms = 0.f;
                 if ((st = time_current(ms)) != RH_OK) break;
-                if (ms < best_ms) {
+                if (ms < best_ms * 0.99f) {  // a candidate has to win by more than the run-to-run noise (ties keep the earlier, shallower one)
                     best_ms = ms;
                     best = cand;
                 }
