@@ -92,8 +92,20 @@ public:
     }
     std::uint16_t channels() const override { return ch_; }
     std::uint32_t sample_rate() const override { return rate_; }
-    std::optional<Nanos> total_duration() const override {
-        return Nanos((std::int64_t)((data_.size() / ch_) * 1000000000ull / rate_));
+    std::optional<Nanos> total_duration() const override {  // buffer.rs:45-51
+        return Nanos((std::int64_t)(1000000000ull * (std::uint64_t)data_.size() / rate_ / ch_));
+    }
+    /// buffer.rs:99-121: jump to the sample for `pos`, saturating at the end, keeping the channel the consumer is at.
+    bool try_seek(Nanos pos) override {
+        const std::size_t curr_channel = pos_ % ch_;
+        const std::uint64_t ns = (std::uint64_t)pos.count();
+        const float secs = (float)(ns / 1000000000ull) + (float)(ns % 1000000000ull) / 1000000000.0f;  // math.rs:118-122 duration_to_float
+        const float fpos = secs * (float)rate_ * (float)ch_;
+        std::size_t np = fpos >= 1.8446744e19f ? data_.size() : (std::size_t)fpos;
+        np = std::min(np, data_.size());
+        np = (np + ch_ - 1) / ch_ * ch_;  // next_multiple_of(channels)
+        pos_ = np - curr_channel;
+        return true;
     }
 
 private:

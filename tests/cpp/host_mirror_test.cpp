@@ -4,6 +4,8 @@
 //
 //   host_mirror_test mixer <dir> <S> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
 //       <dir>/src_<i>.f32 (stereo, interleaved), <dir>/gains.f32  ->  <dir>/out.f32
+//   host_mirror_test selftest
+//       host-only checks of the Source mirror (no GPU): the reference's SamplesBuffer tests, buffer.rs:148-207
 //   host_mirror_test mixany <dir> <S> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane>
 //       like mixer, but every source has its own layout: <dir>/spec.txt holds "channels rate gain" per source
 //   host_mirror_test late <dir> <S0> <S1> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane> <pull_first>
@@ -77,6 +79,47 @@ static std::vector<float> drain(rh::Source &src) {
 }
 
 int main(int argc, char **argv) {
+    if (argc == 2 && std::string(argv[1]) == "selftest") {
+        auto expect = [](bool ok, const char *what) {
+            if (!ok) {
+                std::fprintf(stderr, "selftest failed: %s\n", what);
+                std::exit(1);
+            }
+        };
+        {  // buffer.rs:153-159 duration_basic
+            rh::SamplesBuffer buf(2, 2, std::vector<float>(6, 0.0f));
+            expect(buf.total_duration() && buf.total_duration()->count() == 1500000000ll, "duration_basic");
+        }
+        {  // buffer.rs:161-171 iteration
+            rh::SamplesBuffer buf(1, 44100, {1, 2, 3, 4, 5, 6});
+            for (float v = 1; v <= 6; v += 1) expect(buf.next() == std::optional<float>(v), "iteration");
+            expect(!buf.next() && !buf.next(), "iteration end");
+        }
+        {  // buffer.rs:180-205 try_seek::channel_order_stays_correct
+            std::vector<float> d(2000);
+            for (int i = 0; i < 2000; ++i) d[(size_t)i] = (float)i;
+            rh::SamplesBuffer buf(2, 100, d);
+            expect(buf.try_seek(std::chrono::seconds(5)), "seek supported");
+            expect(buf.next() == std::optional<float>(5.0f * 100 * 2), "seek lands on the frame");
+            auto odd = [&]() { const auto s = buf.next(); return s && ((int)*s % 2 == 1); };
+            auto even = [&]() { const auto s = buf.next(); return s && ((int)*s % 2 == 0); };
+            expect(odd(), "channel 1 after the seek");
+            expect(even(), "channel 0 next");
+            expect(buf.try_seek(std::chrono::seconds(6)) && odd(), "a seek from channel 1 continues with channel 1");
+            expect(buf.try_seek(std::chrono::seconds(1000)) && !buf.next(), "seek saturates at the end");
+        }
+        {  // NonZero channels / rate (buffer.rs:40: the types cannot hold 0)
+            bool threw = false;
+            try {
+                rh::SamplesBuffer bad(0, 44100, {});
+            } catch (const std::invalid_argument &) {
+                threw = true;
+            }
+            expect(threw, "zero channels rejected");
+        }
+        std::printf("selftest ok\n");
+        return 0;
+    }
     if (argc < 3) {
         std::fprintf(stderr, "usage: host_mirror_test mixer|chain <dir> ... (see the source)\n");
         return 2;

@@ -104,6 +104,16 @@ def test_golden_channel_volume(G):
     assert G.ChannelVolume(G.TestSource([1.0, 3.0, 2.0, 4.0], 2, 44100), [0.5, 2.0]).collect().tolist() == [1.0, 4.0, 1.5, 6.0]
 
 
+def test_golden_channel_volume_six_channels_from_stereo(G, O):
+    # tests/channel_volume.rs:9-62
+    x = rnd(12, 2 * 4001)
+    out = G.ChannelVolume(G.TestSource(x, 2, 44100), [1.0, 1.0, 0.0, 0.0, 0.0, 0.0]).collect()
+    assert len(out) == 6 * 4001
+    fr = out.reshape(-1, 6)
+    assert np.all(fr[:, 2:] == 0.0) and np.any(fr[:, :2] != 0.0)
+    assert np.array_equal(out, O.ChannelVolume(O.TestSource(x, 2, 44100), [1.0, 1.0, 0.0, 0.0, 0.0, 0.0]).collect())
+
+
 # ==================================================================== random parity ====
 @pytest.mark.parametrize("frm,to,ch,n", [
     (44100, 48000, 2, 100003), (48000, 44100, 2, 65537), (8000, 48000, 1, 5001), (44100, 40000, 2, 33333),

@@ -27,6 +27,12 @@ def test_driver_is_built_and_links_only_the_c_abi():
     assert "rh_rlm_stream_block_v" in syms and not [x for x in syms if x.startswith(("hip", "hsa", "roc"))]
 
 
+def test_samples_buffer_mirror_passes_the_reference_tests():
+    # buffer.rs:148-207 (duration_basic, iteration, try_seek::channel_order_stays_correct) against the C++ SamplesBuffer
+    r = subprocess.run([EXE, "selftest"], capture_output=True, text=True)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stderr
+
+
 def test_no_gpu_is_an_error_not_a_fallback(tmp_path):
     import torch
 

@@ -194,6 +194,19 @@ def test_channel_volume_stereo_to_stereo_with_mixing(O):
     assert out.tolist() == [1.0, 4.0, 1.5, 6.0]
 
 
+def test_channel_volume_six_channels_from_stereo(O):
+    # tests/channel_volume.rs:9-62: a stereo source through ChannelVolume [1,1,0,0,0,0] has output on the first two
+    # of six channels only, and ends on a frame boundary (the reference decodes assets/music.mp3; any stereo stream does)
+    x = (np.random.default_rng(11).uniform(-1, 1, 2 * 4001)).astype(np.float32)
+    src = O.ChannelVolume(O.TestSource(x, 2, 44100), [1.0, 1.0, 0.0, 0.0, 0.0, 0.0])
+    assert src.channels() == 6
+    out = src.collect()
+    assert len(out) % 6 == 0 and len(out) == 6 * 4001
+    fr = out.reshape(-1, 6)
+    assert np.all(fr[:, 2:] == 0.0) and np.any(fr[:, :2] != 0.0)
+    assert np.array_equal(fr[:, 0], fr[:, 1])  # both carry the frame's mono mix (channel_volume.rs:71-88)
+
+
 # ------------------------------------------------------------------ dB table ----
 DECIBELS_LINEAR_TABLE = [
     (100.0, 100000.0), (90.0, 31623.0), (80.0, 10000.0), (70.0, 3162.0), (60.0, 1000.0), (50.0, 316.2),
