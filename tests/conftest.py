@@ -26,3 +26,19 @@ def rh():
     import rodio_amd
 
     return rodio_amd
+
+
+def sine_generator(sample_rate: int, frequency: float, n: int):
+    """Test input only: SignalGenerator::new(rate, f, Sine) restated (src/source/signal_generator.rs:51-53,107-135):
+    period = rate / f, phase_step = 1 / period, sample = sin(TAU * phase), phase = (phase + step).rem_euclid(1), all f32."""
+    import numpy as np
+
+    f32 = np.float32
+    step = f32(1.0) / (f32(sample_rate) / f32(frequency))
+    phase = f32(0.0)
+    ph = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        ph[i] = phase
+        phase = f32(phase + step)
+        phase = f32(phase - np.floor(phase))  # rem_euclid(1.0) of a non-negative value
+    return np.sin(f32(6.2831855) * ph).astype(np.float32)

@@ -342,6 +342,30 @@ def test_take_duration_golden_and_bit_exact(G, O):
         assert np.array_equal(got, ref), (ch, rate, ns, fade, len(got), len(ref))
 
 
+def test_config1_sine_resample_amplify_bit_exact(G, O):
+    # BASELINE configs[0]: 1 x SineWave at 44.1 kHz -> SampleRateConverter to 48 kHz -> amplify(0.8), 10 s
+    from conftest import sine_generator
+
+    x = sine_generator(44100, 440.0, 441000)
+    ref = O.SampleRateConverter(O.TestSource(x, 1, 44100), 44100, 48000, 1).amplify(0.8).collect()
+    out = G.SampleRateConverter(G.TestSource(x, 1, 44100), 44100, 48000, 1).amplify(0.8).collect()
+    assert len(out) == 480000 and np.array_equal(out, ref)
+
+
+def test_golden_crossfade(G, O):
+    # source/crossfade.rs:45-81 through the GPU adapters (take_duration + fade-out filter, fade_in, a two-source mixer)
+    from test_oracle_golden import _crossfade
+
+    d = np.arange(1, 11, dtype=np.float32)
+    out = _crossfade(G, G.TestSource(d, 1, 1), G.TestSource(d, 1, 1), 5_000_000_001)
+    assert len(out) == 5 and np.all(np.abs(out - np.array([1, 2, 3, 4, 5], np.float32)) < 1e-6)
+    out = _crossfade(G, G.TestSource(d, 1, 1), G.TestSource(np.zeros(10, np.float32), 1, 1), 5_000_000_001)
+    assert np.all(np.abs(out - np.array([1.0, 2.0 * 0.8, 3.0 * 0.6, 4.0 * 0.4, 5.0 * 0.2], np.float32)) < 1e-6)
+    x, y = rnd(61, 48000), rnd(62, 48000)
+    assert np.array_equal(_crossfade(G, G.TestSource(x, 1, 48000), G.TestSource(y, 1, 48000), 300_000_000),
+                          _crossfade(O, O.TestSource(x, 1, 48000), O.TestSource(y, 1, 48000), 300_000_000))
+
+
 def test_distortion_bit_exact(G, O):
     # src/source/distortion.rs:66-72
     x = np.concatenate([rnd(31, 100003, 2.0), np.float32([0, -0.0, 0.5, -0.5, np.inf, -np.inf])])

@@ -340,6 +340,51 @@ def test_take_duration_golden(O):
     assert len(O.TestSource(x, 1, 48000).take_duration(0).collect()) == 0
 
 
+def test_sine_generator_restatement_matches_the_reference_vector():
+    # signal_generator.rs:227-238 (TEST_EPSILON = 1e-6): the input of BASELINE config 1
+    from conftest import sine_generator
+
+    w = sine_generator(1000, 100.0, 7)
+    for got, want in zip(w, [0.0, 0.58778525, 0.95105652, 0.95105652, 0.58778525, 0.0, -0.58778554]):
+        assert abs(float(got) - want) <= 2e-6
+
+
+def test_config1_plumbing_on_the_oracle(O):
+    # BASELINE configs[0] (CPU plumbing): SineWave at 44.1 kHz -> SampleRateConverter to 48 kHz -> amplify(0.8)
+    from conftest import sine_generator
+
+    x = sine_generator(44100, 440.0, 44100)
+    out = O.SampleRateConverter(O.TestSource(x, 1, 44100), 44100, 48000, 1).amplify(0.8).collect()
+    assert len(out) == 48000 and np.max(np.abs(out)) <= 0.8 + 1e-6
+    # linear interpolation of a 440 Hz sine sampled at 44.1 kHz stays within the chord error of the true 48 kHz sine
+    t = np.arange(48000) / 48000.0
+    assert np.max(np.abs(out - 0.8 * np.sin(2 * np.pi * 440.0 * t))) < 5e-3  # chord error + the f32 phase accumulator's drift over 1 s
+
+
+# ------------------------------------------------------------------ crossfade = take(+fadeout) + fade_in + mix ----
+def _crossfade(M, fadeout_src, fadein_src, ns):
+    """source/crossfade.rs:10-23: input_fadeout.take_duration(d) with the fade-out filter, mixed with
+    input_fadein.take_duration(d).fade_in(d)  (Mix == a two-source mixer, mix.rs:43-53)."""
+    m = M.Mixer(1, 1)
+    m.add(fadeout_src.take_duration(ns, True))
+    m.add(fadein_src.take_duration(ns).fade_in(ns))
+    return m.collect()
+
+
+def test_crossfade_with_self(O):
+    # crossfade.rs:45-64
+    d = np.arange(1, 11, dtype=np.float32)
+    out = _crossfade(O, O.TestSource(d, 1, 1), O.TestSource(d, 1, 1), 5_000_000_001)
+    assert len(out) == 5 and np.all(np.abs(out - np.array([1, 2, 3, 4, 5], np.float32)) < 1e-6)
+
+
+def test_crossfade_with_silence(O):
+    # crossfade.rs:66-81
+    d = np.arange(1, 11, dtype=np.float32)
+    out = _crossfade(O, O.TestSource(d, 1, 1), O.TestSource(np.zeros(10, np.float32), 1, 1), 5_000_000_001)
+    assert len(out) == 5 and np.all(np.abs(out - np.array([1.0, 2.0 * 0.8, 3.0 * 0.6, 4.0 * 0.4, 5.0 * 0.2], np.float32)) < 1e-6)
+
+
 # ------------------------------------------------------------------ dither (SURVEY 8f row 3) ----
 def test_dither_reference_test_properties(O):
     """The reference's noise is entropy-seeded, so its tests pin properties, not samples (dither.rs:301-393):
