@@ -596,7 +596,10 @@ protected:
         if (all_done) {
             check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
             for (auto &gp : gens_)
-                if (gp->plan) check(rh_rlm_destroy(gp->plan), "rh_rlm_destroy");
+                if (gp->plan) {
+                    check(rh_rlm_last_status(gp->plan), "rh_rlm_last_status");  // the last blocks too: nothing is served unchecked
+                    check(rh_rlm_destroy(gp->plan), "rh_rlm_destroy");
+                }
             gens_.clear();
         }
         s.n = (std::size_t)n * 2;
