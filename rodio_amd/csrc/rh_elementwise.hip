@@ -44,8 +44,7 @@ __global__ __launch_bounds__(kBlock) void k_int_to_f32(float *__restrict__ dst, 
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-    for (size_t v = tid; v < nvec; v += stride) {
-        uint4 raw = rh::ld_nt(src4 + v);
+    auto emit = [&](size_t v, const uint4 &raw) {
         T vals[VEC];
         __builtin_memcpy(vals, &raw, 16);
         float out[VEC];
@@ -54,7 +53,14 @@ __global__ __launch_bounds__(kBlock) void k_int_to_f32(float *__restrict__ dst, 
         float4 *d4 = reinterpret_cast<float4 *>(dst + v * VEC);
 #pragma unroll
         for (int k = 0; k < VEC / 4; ++k) d4[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    };
+    size_t v = tid;
+    for (; v + stride < nvec; v += 2 * stride) {  // two independent 16-byte loads in flight per lane
+        const uint4 r0 = rh::ld_nt(src4 + v), r1 = rh::ld_nt(src4 + v + stride);
+        emit(v, r0);
+        emit(v + stride, r1);
     }
+    if (v < nvec) emit(v, rh::ld_nt(src4 + v));
     for (size_t i = nvec * VEC + tid; i < n; i += stride) dst[i] = ToF32<T>::cvt(src[i]);
 }
 
