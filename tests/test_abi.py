@@ -52,3 +52,24 @@ def test_status_strings(rh):
     for code in range(8):
         assert _lib.lib.rh_status_string(code)
     assert _lib.lib.rh_version() >= 100
+
+
+def test_headers_compile_cleanly(tmp_path):
+    """include/rodio_hip.h is plain C (C99, what an FFI generator reads); include/rodio_hip.hpp is C++17 over nothing but
+    that header.  Both without a warning under -Wall -Wextra -Wpedantic."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    if not (shutil.which("gcc") and shutil.which("g++")):
+        import pytest
+
+        pytest.skip("no host compiler")
+    c = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "rodio_hip.h")], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr
+    src = tmp_path / "hdr.cpp"
+    src.write_text('#include "rodio_hip.hpp"\nint main() { return 0; }\n')
+    cxx = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert cxx.returncode == 0, cxx.stderr
