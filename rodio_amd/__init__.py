@@ -24,7 +24,10 @@ from .source import (  # noqa: F401
     TestSource,
     UniformSourceIterator,
     WavDecoder,
+    agc_batch,
+    agc_state,
     biquad_batch,
+    limit_batch,
     biquad_coeffs,
     delay_samples,
     init,

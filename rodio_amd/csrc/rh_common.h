@@ -40,6 +40,16 @@ void set_hip_error(hipError_t e, const char *what);
 
 inline hipStream_t as_stream(rh_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A fill that has HAPPENED when it returns.  hipMemset on device memory is enqueued on the null stream and returns at once;
+// the library's streams are hipStreamNonBlocking, so a kernel launched on one of them right afterwards does not wait for
+// it -- the fill can then land on state that kernel has already written (tickets taken, aggregates published, filter
+// states stored).  Seen as wrong blocks / RH_ERR_TIMEOUT when the null stream was slow (GPU shared with other
+// processes).  Every fill that initialises kernel-visible state goes through here.
+inline hipError_t fill_now(void *p, int value, size_t bytes) {
+    hipError_t e = hipMemset(p, value, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 // Grid for a memory-bound grid-stride kernel: enough 256-thread blocks to fill 256 CUs x 8,
 // capped so small inputs stay small (cdna_hip_programming.md G11).
 inline unsigned grid_for(size_t work_items, unsigned block = 256, unsigned max_blocks = 256 * 8) {

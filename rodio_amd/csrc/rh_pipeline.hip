@@ -638,6 +638,9 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
                 mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
                 mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
             }
+            // A carry that never arrived: the status word fails the call (rh_rlm_last_status), and the tile is poisoned so
+            // that a block served without that check can never pass for audio.
+            if (dead) c[0] = c[1] = c[2] = c[3] = __builtin_nanf("");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // sum over lanes 0..31 -> uniform
                 c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
@@ -1241,6 +1244,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         }
     }
     if (FILT) {  // the merged homogeneous response: start state = Qacc + B^(R*lane) * (summed tile carries)
+        if (dead) Cacc[0] = Cacc[1] = Cacc[2] = Cacc[3] = __builtin_nanf("");  // a carry never arrived: poison the tile (the status word fails the call)
         reduce_carry(Cacc);
         mat_acc(lM, Cacc[0], Cacc[1], Qacc[0], Qacc[1]);
         mat_acc(lM, Cacc[2], Cacc[3], Qacc[2], Qacc[3]);
@@ -1486,6 +1490,7 @@ __global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
                 mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
                 mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
             }
+            if (dead) c[0] = c[1] = c[2] = c[3] = __builtin_nanf("");  // poison: see k_rlm_fast
 #pragma unroll
             for (int q = 0; q < 4; ++q) {  // sum over lanes 0..31 -> uniform
                 c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
@@ -1699,9 +1704,29 @@ struct rh_rlm {
     // block streaming with per-source states (rh_rlm_stream_block_v)
     std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
     uint32_t st_cols = 0;            // columns of an aggregate row for the stream (0: no such stream yet)
+    // Recorded behind every launch of this handle.  The library's streams are hipStreamNonBlocking: a null-stream
+    // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
+    // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
+    hipEvent_t idle_ev = nullptr;
+    bool launched = false;
 };
 
 namespace {
+
+// Block until every launch of this handle has completed (see rh_rlm::idle_ev).
+rh_status wait_idle(rh_rlm *p) {
+    if (p->launched) {
+        RH_HIP_TRY(hipEventSynchronize(p->idle_ev));
+        p->launched = false;
+    }
+    return RH_OK;
+}
+rh_status mark_launch(rh_rlm *p, hipStream_t s) {
+    if (!p->idle_ev) RH_HIP_TRY(hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming));
+    RH_HIP_TRY(hipEventRecord(p->idle_ev, s));
+    p->launched = true;
+    return RH_OK;
+}
 
 // Predecessor tiles a tile of L frames has to look back at: ||B^(L*J)|| < 2^-40 (older history is
 // below f32 resolution of the state); 0 = pole radius too close to 1 for this tile length.
@@ -1849,17 +1874,21 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
     const size_t words = (size_t)(p->n_sources + 1) * (tiles + 1) * 4;  // per (source, tile): general kernel (+ its row of summed aggregates) and batch mode; +1: streaming's end-state tile
     if (p->filt && words > p->gran_words) {
+        {
+            const rh_status w = wait_idle(p);  // a queued launch may still read the old table
+            if (w != RH_OK) return w;
+        }
         if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
         p->d_gran = nullptr;
         RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
-        RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
+        RH_HIP_TRY(rh::fill_now(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
         p->gran_words = words;
     }
 #ifdef RH_PHASE_PROFILE
     if (p->d_prof) RH_HIP_TRY(hipFree(p->d_prof));
     p->d_prof = nullptr;
     RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_prof), (tiles + 1) * 64));
-    RH_HIP_TRY(hipMemset(p->d_prof, 0, (tiles + 1) * 64));
+    RH_HIP_TRY(rh::fill_now(p->d_prof, 0, (tiles + 1) * 64));
 #endif
     // The most loaded CU sets the pace: pad the LDS request until the dispatcher cannot put more
     // than ceil(tiles/CUs) waves on any CU.
@@ -1931,7 +1960,7 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     if (st == RH_OK) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 64);
-        if (e == hipSuccess) e = hipMemset(p->d_ctl, 0, 64);
+        if (e == hipSuccess) e = rh::fill_now(p->d_ctl, 0, 64);  // the ticket counter: a late fill would renumber tiles in mid-launch
         if (e != hipSuccess) {
             rh::set_hip_error(e, "rh_rlm_create");
             st = e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
@@ -1948,6 +1977,8 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
+    (void)wait_idle(p);  // nothing of this handle may still run when its tables go
+    if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
     bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
     for (Plan &c : p->tried) {
         fast_in_tried = fast_in_tried || c.d_tabs == p->fast.d_tabs;
@@ -1991,6 +2022,10 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
         if (g.out_frames > M) M = g.out_frames;
         equal = equal && in_frames_host[s] == in_frames_host[0];
     }
+    {
+        const rh_status w = wait_idle(p);  // an earlier run of this handle may still be reading the table
+        if (w != RH_OK) return w;
+    }
     if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
     p->equal = equal;
     p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
@@ -2008,6 +2043,10 @@ rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
     p->gains.assign(gains_host, gains_host + n);
     if (!p->st_on && p->n_sources && p->h_desc.size() == p->n_sources) {  // sources already set: refresh their descriptors
         for (uint32_t s = 0; s < p->n_sources; ++s) p->h_desc[s].gain = s < n ? gains_host[s] : 1.0f;
+        {
+            const rh_status w = wait_idle(p);
+            if (w != RH_OK) return w;
+        }
         RH_HIP_TRY(hipMemcpy(p->d_srcs, p->h_desc.data(), sizeof(SrcDesc) * p->n_sources, hipMemcpyHostToDevice));
     }
     return RH_OK;
@@ -2110,7 +2149,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
             rh::set_hip_error(e1, "ragged batch launch");
             return RH_ERR_HIP;
         }
-        return RH_OK;
+        return mark_launch(p, s);
     }
     // batch mode fills the chip many times over: no residency shaping, the bare LDS request
     hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? pl.lds_bytes : p->launch_lds, s);
@@ -2119,7 +2158,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         return RH_ERR_HIP;
     }
     p->ticket_base += (uint32_t)grid;  // every launch takes exactly one ticket per workgroup
-    return RH_OK;
+    return mark_launch(p, s);
 }
 
 rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream, uint32_t *frames_per_lane, uint32_t *ring_stages) {
@@ -2224,9 +2263,13 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
     if (p->cfg.span_len != 0) return RH_ERR_UNSUPPORTED;  // spans are converted one by one (uniform.rs:56-67): use rh_rlm_run per span
+    {
+        const rh_status w = wait_idle(p);  // a previous stream's last block may still read its state words
+        if (w != RH_OK) return w;
+    }
     for (int k = 0; k < 2; ++k) {
         if (!p->d_w[k]) RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_w[k]), 4 * sizeof(float)));
-        RH_HIP_TRY(hipMemset(p->d_w[k], 0, 4 * sizeof(float)));
+        RH_HIP_TRY(rh::fill_now(p->d_w[k], 0, 4 * sizeof(float)));
     }
     p->st_on = true;
     p->st_done = false;
@@ -2338,10 +2381,12 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         if (cols > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
         const size_t words = (size_t)(p->cfg.max_sources + 1) * cols * 4;  // as activate_plan counts: one row per source + the row of summed aggregates
         if (p->filt && words > p->gran_words) {
+            const rh_status w = wait_idle(p);
+            if (w != RH_OK) return w;
             if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
             p->d_gran = nullptr;
             RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
-            RH_HIP_TRY(hipMemset(p->d_gran, 0, words * 8));
+            RH_HIP_TRY(rh::fill_now(p->d_gran, 0, words * 8));
             p->gran_words = words;
         }
         p->st_cols = (uint32_t)cols;
@@ -2353,6 +2398,8 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         if (p->filt) {
             hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
             RH_CHECK_LAUNCH();
+            const rh_status mk = mark_launch(p, hs);
+            if (mk != RH_OK) return mk;
         }
     }
     // what every source can still give: a live one every frame whose two taps have arrived, an ended one all it has left
@@ -2414,6 +2461,8 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
             hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)tiles + 1u, (uint32_t)p->wave.J, p->epoch,
                                p->epoch + 1);
             RH_CHECK_LAUNCH();
+            const rh_status mk = mark_launch(p, hs);
+            if (mk != RH_OK) return mk;
         }
         p->st_m += out;
     }
@@ -2437,10 +2486,14 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
 rh_status rh_rlm_last_status(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
+    {
+        const rh_status w = wait_idle(p);  // every launch of this handle has completed: the words below are final
+        if (w != RH_OK) return w;
+    }
     uint32_t ctl[2] = {0, 0};
-    RH_HIP_TRY(hipMemcpy(ctl, p->d_ctl, 8, hipMemcpyDeviceToHost));  // synchronises with the device
+    RH_HIP_TRY(hipMemcpy(ctl, p->d_ctl, 8, hipMemcpyDeviceToHost));
     if (ctl[1]) {  // sticky until read
-        RH_HIP_TRY(hipMemset(p->d_ctl + 1, 0, 4));
+        RH_HIP_TRY(rh::fill_now(p->d_ctl + 1, 0, 4));
         return RH_ERR_TIMEOUT;
     }
     return RH_OK;
@@ -2449,9 +2502,13 @@ rh_status rh_rlm_last_status(rh_rlm *p) {
 rh_status rh_rlm_late_carries(rh_rlm *p, uint64_t *count) {
     RH_REQUIRE_INIT();
     if (!p || !count) return RH_ERR_INVALID;
+    {
+        const rh_status w = wait_idle(p);
+        if (w != RH_OK) return w;
+    }
     uint32_t v[2] = {0, 0};
     RH_HIP_TRY(hipMemcpy(v, p->d_ctl + 2, 8, hipMemcpyDeviceToHost));
-    RH_HIP_TRY(hipMemset(p->d_ctl + 2, 0, 8));
+    RH_HIP_TRY(rh::fill_now(p->d_ctl + 2, 0, 8));
     *count = v[0] | ((uint64_t)v[1] << 32);  // high word: empty polls (RH_PHASE_PROFILE builds)
     return RH_OK;
 }

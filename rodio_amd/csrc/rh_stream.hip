@@ -172,7 +172,7 @@ rh_status rh_echo_create(rh_echo **out, uint64_t delay_samples, float gain) {
     p->gain = gain;
     for (int k = 0; k < 2 && delay_samples; ++k) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_hist[k]), sizeof(float) * delay_samples);
-        if (e == hipSuccess) e = hipMemset(p->d_hist[k], 0, sizeof(float) * delay_samples);
+        if (e == hipSuccess) e = rh::fill_now(p->d_hist[k], 0, sizeof(float) * delay_samples);  // before the first block's kernel writes it
         if (e != hipSuccess) {
             rh::set_hip_error(e, "rh_echo_create");
             rh_echo_destroy(p);

@@ -413,6 +413,42 @@ def biquad_batch(x, coeffs5, mode=1):
     return out
 
 
+def limit_batch(x, channels, sample_rate, threshold=-1.0, knee_width=4.0, attack_ns=5_000_000, release_ns=100_000_000, state=None, out=None):
+    """rh_limit over the rows of the device tensor x [S, frames*channels] (limit.rs:853-988, one limiter per row).
+    state: optional device tensor [S, 2*channels] {integrator, peak} per channel, carried across blocks (updated in place)."""
+    _ensure()
+    torch = _t()
+    assert x.is_contiguous() and x.dim() == 2
+    S, n = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    p = LimitParams(threshold, knee_width, attack_ns, release_ns)
+    check(lib.rh_limit(_ptr(out), _ptr(x), n // channels, channels, sample_rate, S, C.byref(p), _ptr(state) if state is not None else None, _stream()), "rh_limit")
+    return out
+
+
+def agc_state(n_streams):
+    """Fresh AutomaticGainControl states (agc.rs:209-236) for n_streams rows, on the device."""
+    _ensure()
+    st = _dev_empty(int(lib.rh_agc_state_floats()) * n_streams)
+    check(lib.rh_agc_state_init(_ptr(st), n_streams, _stream()), "rh_agc_state_init")
+    return st
+
+
+def agc_batch(x, sample_rate, target_level=1.0, attack_ns=4_000_000_000, release_ns=0, absolute_max_gain=7.0, floor=0.0, state=None, out=None):
+    """rh_agc over the rows of the device tensor x [S, n_samples] (agc.rs:397-504, one AGC per row; all interleaved channels of a
+    row share it).  state: agc_state(S), carried across blocks."""
+    _ensure()
+    torch = _t()
+    assert x.is_contiguous() and x.dim() == 2
+    S, n = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    p = AgcParams(target_level, attack_ns, release_ns, absolute_max_gain, floor)
+    check(lib.rh_agc(_ptr(out), _ptr(x), n, sample_rate, S, C.byref(p), _ptr(state) if state is not None else None, _stream()), "rh_agc")
+    return out
+
+
 def biquad_coeffs(kind, freq, q, fs) -> np.ndarray:
     out = np.zeros(5, np.float32)
     k = 1 if kind in (1, "high_pass") else 0

@@ -90,6 +90,12 @@ def _truth(O, c):
     return acc.reshape(-1)
 
 
+# Cases whose |gpu - oracle| exceeded 1e-5 and were judged against the f64 truth instead: counted,
+# printed, and bounded by test_fuzz_fallback_budget at the end of this file.
+COMPARED = {"filtered": 0}
+FALLBACKS = []
+
+
 def _compare(tag, c, got, ref, O=None):
     assert len(got) == len(ref), (tag, len(got), len(ref), c["ns"], c["frm"], c["to"])
     if len(ref) == 0:
@@ -98,7 +104,9 @@ def _compare(tag, c, got, ref, O=None):
         assert np.array_equal(got, ref), (tag, float(np.max(np.abs(got - ref))), c["S"], c["ns"], c["frm"], c["to"], c["span"], c["R"])
     else:
         err = float(np.max(np.abs(got - ref)))
+        COMPARED["filtered"] += 1
         if err > TOL:  # the f32 reference recurrence drifts for poles next to 1 (high_pass(100) at 48 kHz: 2e-5 from exact)
+            FALLBACKS.append((tag, c["filt"], c["freq"], c["to"], err))
             truth = _truth(O, c)
             e_gpu, e_ref = float(np.max(np.abs(got - truth))), float(np.max(np.abs(ref - truth)))
             assert e_gpu <= 1e-6 + 0.25 * e_ref and err <= e_ref + e_gpu + 1e-7, (tag, err, e_gpu, e_ref, c["S"], c["frm"], c["to"], c["filt"], c["freq"], c["R"])
@@ -156,3 +164,16 @@ def test_fuzz_block_streaming(G, O, seed):
     got = torch.cat(outs).cpu().numpy() if outs else np.zeros(0, np.float32)
     _compare(f"stream block<= {block}", c, got, ref, O)
     p.close()
+
+
+def test_fuzz_fallback_budget():
+    """How many filtered cases left the 1e-5 bound and were accepted on the f64 criterion.  Only the family whose
+    REFERENCE recurrence is itself > 1e-5 from exact may do so: a high-pass with its poles next to z = 1 (cutoff <= 200 Hz),
+    where y = x - (low-passed x) cancels in f32 (blt.rs:523-542,559).  Anything else fails here."""
+    n = COMPARED["filtered"]
+    print(f"[fuzz] filtered comparisons: {n}; beyond 1e-5 abs (accepted against the f64 truth): {len(FALLBACKS)}")
+    for tag, filt, freq, to, err in FALLBACKS:
+        print(f"    {tag}: {filt}({freq}) @ {to} Hz  |gpu-oracle| = {err:.3e}")
+    stray = [f for f in FALLBACKS if not (f[1] == "high_pass" and f[2] <= 200)]
+    assert not stray, stray
+    assert len(FALLBACKS) <= max(2, n // 8), (len(FALLBACKS), n)
