@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -547,6 +548,7 @@ protected:
             return;
         }
         s.out.reset(out_cap_frames_ * 2 * 2);
+        if (debug_poison()) std::memset(s.out.get(), 0xff, out_cap_frames_ * 2 * 2 * sizeof(float));  // diagnostics: a block served before it arrived reads NaN
         // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
         // (one that runs ahead of the slowest -- another rate, other tile boundaries -- waits with a full queue)
         for (auto &gp : gens_)
@@ -574,6 +576,7 @@ protected:
                     len.push_back(std::min(gp->fill, n) * 2);
                 }
                 dmix_.reset(out_cap_frames_ * 2 * 2);
+                if (debug_poison()) check(rh_memset(dmix_.get(), 0xff, out_cap_frames_ * 2 * 2 * sizeof(float), stream_), "rh_memset");
                 check(rh_mix_sum(dmix_.get(), n * 2, ptrs.data(), start.data(), len.data(), (std::uint32_t)ptrs.size(), stream_), "rh_mix_sum");
                 mixed = dmix_.get();
             }
@@ -717,6 +720,7 @@ private:
         // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
         check(rh_memcpy_h2d(g.din.get(), stage.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
         std::uint64_t out = 0, consumed = 0;
+        if (debug_poison()) check(rh_memset(g.queue_end(), 0xff, (out_cap_frames_ * 2 - g.fill - g.head) * 2 * sizeof(float), stream_), "rh_memset");
         check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
               "rh_rlm_stream_block_v");
         g.fill += out;
@@ -731,6 +735,10 @@ private:
         g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }
 
+    static bool debug_poison() {  // RODIO_HIP_DEBUG_POISON=1: every buffer a block passes through is filled with NaN patterns first
+        static const bool on = std::getenv("RODIO_HIP_DEBUG_POISON") != nullptr;
+        return on;
+    }
     std::uint32_t rate_;
     Options opt_;
     std::vector<Src> pending_;

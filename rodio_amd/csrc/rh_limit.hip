@@ -1,0 +1,890 @@
+// rh_limit.hip -- the limiter (src/source/limit.rs:94-130, :853-873, :903-916, :927-988) as a TIME-PARALLEL kernel.
+//
+// Per channel the reference runs, sample after sample,
+//     g_n = gain computer (log2, soft knee)                          limit.rs:853-873     elementwise
+//     I_n = max(g_n, r*I_{n-1} + (1-r)*g_n)                          limit.rs:909-912     release-smoothed peak hold
+//     P_n = a*P_{n-1} + (1-a)*I_n                                    limit.rs:913         attack smoothing
+//     y_n = x_n * 2^(-max_c P_c * 0.05*log2 10)                      limit.rs:927-988     gain coupled over the channels
+// (r, a = exp(-1/(t*fs)), math.rs:110-113).  Both recurrences are scannable:
+//   * I: the step maps I -> max(g, r*I + (1-r)g) belong to the family I -> max(A, c*I + B), closed under composition:
+//        (A2,c2,B2) o (A1,c1,B1) = (max(A2, c2*A1 + B2), c2*c1, c2*B1 + B2).  c = r^(steps) depends on the POSITION only,
+//        so a segment is two floats (A, B) and every c is a host-computed constant (f64, rounded once).
+//        All values are >= 0 and A >= B, hence (0, 0) acts as the identity and DPP zero-fill needs no special case.
+//   * P: linear, driven by the (now known) I_n: zero-state run + a^(steps) * (start state).
+//
+// Decomposition (wave64, no MFMA -- there is no contraction):
+//   * a workgroup of NW waves = one tile of LW = NW*64*R frames of ONE stream; a wave owns 64*R consecutive frames, a lane R
+//     of them (all channels).  Tiles are handed out by an atomic ticket, tile-major over the streams (ticket k -> tile k / S
+//     of stream k % S), to a persistent grid: a tile only ever waits for tiles with smaller tickets, which run or are done.
+//   * HBM traffic = 4 B in + 4 B out per sample.  The samples of the NEXT tile are requested by LDS-DMA (global_load_lds,
+//     no VGPR round trip) while the current one is worked on; a lane reads its run from LDS (swizzled slots: conflict-free
+//     without padding), the result goes back to the same slots and leaves with coalesced 16-byte stores.
+//   * per tile: gain computer -> lane-local (A,B) -> wave scan (DPP Kogge-Stone) -> the waves' aggregates meet in LDS
+//     (barrier 1) -> workgroup aggregate published -> decoupled look-back over the workgroup tiles in front (a wave polls up
+//     to 64 predecessors at once: aggregates compose in one wave scan; a predecessor whose inclusive state is known ends the
+//     walk; so does r^(LW*j) < 2^-30) -> true I per sample + zero-state P run -> wave scan -> LDS (barrier 2) -> published ->
+//     look-back for P -> per-sample P, channel-coupled max, exp2, multiply -> store.
+//   * hand-off words are plain f32 in a table filled with 0xFF on the stream in front of the launch: all-ones = "not yet",
+//     anything else is the value (the data is the flag, cdna_hip_programming.md G16 form R2); consumers fetch whole sections
+//     with 8/16-byte sc1 loads.
+// What the first versions taught (64 streams x 1 Mi stereo frames, 8 B of traffic per sample; the one-lane-per-stream
+// kernel of round 1 took 3 628 ms):
+//     single-wave tiles, one ticket per tile                      0.99 ms   -- the ticket counter: one device-scope word hands
+//                                                                              out ~85 tickets/us (MI355X_MICROARCH.md "dequeue")
+//     ... 16 tickets per atomic, 8-byte {tag,value} granules      0.78 ms   -- 384 sc1 loads per tile and look-back: L2 request rate
+//     ... f32 words with a NaN-pattern sentinel, 16-byte loads    0.61 ms   -- look-back latency x lockstep (every wave of the chip
+//                                                                              is in the same phase: the phases' times add up)
+//     workgroup tiles (8 waves, LDS exchange, 2 barriers)         0.38 ms
+//     ... 16 frames per lane, LDS-DMA prefetch                    0.33 ms = 3.2 TB/s = 40 % of 8 TB/s (SQ counters: waves wait
+//                                                                              56 % of their cycles, VALU busy 19 %: sync-bound)
+// The sequential kernel of rh_recurrence.hip stays as the reference-order path for layouts this one does not take
+// (rows that are not 16-byte aligned).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "rh_common.h"
+
+namespace rh {
+rh_status limit_seq_launch(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float k5[5], float *state, hipStream_t s);
+float duration_to_coefficient_f32(uint64_t ns, uint32_t sample_rate);
+}  // namespace rh
+
+namespace {
+
+constexpr float LOG2_10 = 3.32192809488736234787f;
+constexpr float LOG10_2 = 0.301029995663981195214f;
+constexpr int kMaxR = 16, kMaxNW = 16;
+constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr float kNegligible = 0x1p-30f;  // a weight below this no longer moves an f32 state of the same magnitude
+
+struct LimitTabs {      // per-lane / per-predecessor constants, f64 on the host, rounded once; travels as a kernel argument
+    float r15[64], r31[64], rlane[64];  // r^(R*((l&15)+1)), r^(R*((l&31)+1)), r^(R*l)
+    float a15[64], a31[64], alane[64];  // the same powers of the attack coefficient
+    float rlook[64], alook[64];         // r^(LW*j), a^(LW*j): weight of the j-th workgroup tile in front (j = 0: the nearest)
+};
+struct LimitArgs {
+    float *dst;
+    const float *src;
+    float *gran;               // [S][tiles][Rec<C>::stride] hand-off words: A[C] B[C] | Iend[C] | Pz[C] | Pend[C] (see Rec)
+    const float *state_in;     // [S][C][2] {integrator, peak} snapshot taken in front of the launch, or nullptr
+    float *state_out;          // the caller's state, or nullptr
+    uint32_t *ctl;             // [0] ticket, [1] status
+    uint64_t frames;           // per stream
+    uint64_t stride;           // floats between streams
+    uint32_t n_streams, tiles; // tiles per stream
+    float threshold, knee_width, inv_knee_8, attack, release;
+    float rscan[4], ascan[4];  // r^(R*2^k), a^(R*2^k), k = 0..3 (row_shr 1,2,4,8)
+    float rL, aL, rLW, aLW;    // r^L, a^L (one wave's share), r^LW, a^LW (one workgroup tile)
+    float rwave[kMaxNW], awave[kMaxNW];  // r^(L*k), a^(L*k): k waves in front inside the workgroup tile
+    float rL64, aL64;          // r^(LW*64), a^(LW*64): one full look-back window
+    uint32_t jI, jP;           // predecessors beyond these are below kNegligible (<= 64)
+    LimitTabs t;
+};
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+constexpr int kRowShr = 0x110, kWaveShr1 = 0x138, kBcast15 = 0x142, kBcast31 = 0x143;
+
+// limit.rs:853-873 (f32::MIN_POSITIVE = 2^-126).  The argument of the logarithm is a normal number (>= 2^-126) and the
+// argument of the exponential below lies in [-50, 0]: the bare v_log_f32 / v_exp_f32 (1 ulp) are what log2f / exp2f reduce
+// to on this range, without their denormal pre- and post-scaling.  The dB scale (log10(2) * 20) and the knee test on
+// 2 * bias are folded into one FMA each: the gain computer is continuous, a last-bit difference in bias_db moves the
+// output by parts in 1e-8.
+struct GainK {
+    float db_per_log2, neg_thr, half_knee, knee_width, inv_knee_8;
+};
+__device__ __forceinline__ float gain_computer(float sample, const GainK &k) {
+    const float bias_db = fma_(__builtin_amdgcn_logf(fabsf(sample) + 1.17549435e-38f), k.db_per_log2, k.neg_thr);
+    const float x = fma_(2.0f, bias_db, k.knee_width);
+    const float soft = x * x * k.inv_knee_8;
+    return bias_db < -k.half_knee ? 0.0f : (fabsf(bias_db) <= k.half_knee ? soft : bias_db);
+}
+
+// Inclusive wave64 scan of max-affine segments (A, B) whose slopes are position constants (see the header).
+__device__ __forceinline__ void scan_maxaff(float &A, float &B, const float (&cs)[4], float c15, float c31) {
+#define RH_STEP(K, N)                                                      \
+    {                                                                      \
+        const float a1 = dpp0<kRowShr + N, 0xf>(A), b1 = dpp0<kRowShr + N, 0xf>(B); \
+        A = fmaxf(A, fma_(cs[K], a1, B));                                  \
+        B = fma_(cs[K], b1, B);                                            \
+    }
+    RH_STEP(0, 1)
+    RH_STEP(1, 2)
+    RH_STEP(2, 4)
+    RH_STEP(3, 8)
+#undef RH_STEP
+    {
+        const float a1 = dpp0<kBcast15, 0xa>(A), b1 = dpp0<kBcast15, 0xa>(B);
+        A = fmaxf(A, fma_(c15, a1, B));
+        B = fma_(c15, b1, B);
+    }
+    {
+        const float a1 = dpp0<kBcast31, 0xc>(A), b1 = dpp0<kBcast31, 0xc>(B);
+        A = fmaxf(A, fma_(c31, a1, B));
+        B = fma_(c31, b1, B);
+    }
+}
+// Inclusive wave64 scan of a linear 1-pole: V_l = sum_{k<=l} c^(R*(l-k)) v_k.
+__device__ __forceinline__ void scan_lin(float &V, const float (&cs)[4], float c15, float c31) {
+    V = fma_(cs[0], dpp0<kRowShr + 1, 0xf>(V), V);
+    V = fma_(cs[1], dpp0<kRowShr + 2, 0xf>(V), V);
+    V = fma_(cs[2], dpp0<kRowShr + 4, 0xf>(V), V);
+    V = fma_(cs[3], dpp0<kRowShr + 8, 0xf>(V), V);
+    V = fma_(c15, dpp0<kBcast15, 0xa>(V), V);
+    V = fma_(c31, dpp0<kBcast31, 0xc>(V), V);
+}
+// plain sums / maxima over the wave (all values >= 0: zero-fill is neutral)
+__device__ __forceinline__ float wave_excl_sum(float v, float &total) {
+    v += dpp0<kRowShr + 1, 0xf>(v);
+    v += dpp0<kRowShr + 2, 0xf>(v);
+    v += dpp0<kRowShr + 4, 0xf>(v);
+    v += dpp0<kRowShr + 8, 0xf>(v);
+    v += dpp0<kBcast15, 0xa>(v);
+    v += dpp0<kBcast31, 0xc>(v);
+    total = readlane_f(v, 63);
+    return dpp0<kWaveShr1, 0xf>(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp0<kRowShr + 1, 0xf>(v));
+    v = fmaxf(v, dpp0<kRowShr + 2, 0xf>(v));
+    v = fmaxf(v, dpp0<kRowShr + 4, 0xf>(v));
+    v = fmaxf(v, dpp0<kRowShr + 8, 0xf>(v));
+    v = fmaxf(v, dpp0<kBcast15, 0xa>(v));
+    v = fmaxf(v, dpp0<kBcast31, 0xc>(v));
+    return readlane_f(v, 63);
+}
+
+// ---- hand-off words ---------------------------------------------------------------------------------------------------
+// A tile publishes its aggregates / end states as plain f32 words in a table that is filled with 0xFF bytes on the stream
+// in front of the launch: the all-ones pattern (a NaN no arithmetic produces; NaNs are published in canonical form) means
+// "not there yet", anything else is the value -- the data is the flag at 4-byte granularity (cdna_hip_programming.md G16,
+// form R2), so a consumer may fetch a whole section with one 16-byte load and a torn load merely reads "not yet".
+// Per tile: [A[C] B[C] | Iend[C] | Pz[C] | Pend[C]], sections aligned for the widest load that fits them.
+template <int C>
+struct Rec {
+    static constexpr int up(int v, int m) { return (v + m - 1) / m * m; }
+    static constexpr int wA = (2 * C) % 4 == 0 ? 4 : ((2 * C) % 2 == 0 ? 2 : 1);  // vector width of the A/B section
+    static constexpr int wS = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);              // ... of the one-per-channel sections
+    static constexpr int oA = 0;
+    static constexpr int oI = up(2 * C, 4);
+    static constexpr int oZ = oI + up(C, wS);
+    static constexpr int oE = oZ + up(C, wS);
+    static constexpr int stride = up(oE + C, 4);
+};
+constexpr uint32_t kNotYet = 0xffffffffu;
+__device__ __forceinline__ bool word_ok(float v) { return __float_as_uint(v) != kNotYet; }
+__device__ __forceinline__ void word_store(float *p, float v) {
+    v = v != v ? __uint_as_float(0x7fc00000u) : v;  // a NaN travels in canonical form, never as the sentinel
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+// N consecutive words with agent-scope (sc1: served by L2, never by this CU's L1) loads of width W.  The loads are inline
+// asm -- hipcc does not see them -- so wait_loads() must stand between them and the first use of the values.
+template <int N, int W>
+__device__ __forceinline__ void load_words(const float *p, float (&out)[N]) {
+    static_assert(N % W == 0, "section width");
+#pragma unroll
+    for (int k = 0; k < N; k += W) {
+        if (W == 4) {
+            v4f_ r;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
+            out[k] = r.x, out[k + 1] = r.y, out[k + 2] = r.z, out[k + 3] = r.w;
+        } else if (W == 2) {
+            v2f_ r;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
+            out[k] = r.x, out[k + 1] = r.y;
+        } else {
+            float r;
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
+            out[k] = r;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(float (&v)[N]) {  // the values are operands: nothing that uses them can move above the wait
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- the tile's samples in LDS -------------------------------------------------------------------------------------------
+// A wave's share of a tile (64 lanes x V 16-byte vectors, V KiB) sits in LDS as 64*V slots.  Slot o*V + (j ^ f(o)) holds
+// vector j of lane o's run; f swizzles the vectors of neighbouring runs so that the 16 lanes one ds_read_b128 / ds_write_b128
+// pass serves hit 16 different bank groups although the rows are not padded (V a power of two <= 16; other V: f = 0, V odd is
+// conflict-free anyway).  The image is written by LDS-DMA straight from HBM (global_load_lds_dwordx4: no VGPR round trip,
+// issued a whole tile ahead) -- the DMA lane that fills slot q simply fetches the vector that belongs there.
+template <int V>
+__device__ __forceinline__ constexpr uint32_t slot_of(uint32_t o, uint32_t j) {
+    return (V > 1 && V <= 16 && (V & (V - 1)) == 0) ? o * V + (j ^ ((o / (16 / V)) & (V - 1))) : o * V + j;
+}
+template <int V>
+__device__ __forceinline__ constexpr uint32_t vec_in_slot(uint32_t q) {  // the inverse: which vector of the share lives in slot q
+    const uint32_t o = q / V, jj = q % V;
+    return (V > 1 && V <= 16 && (V & (V - 1)) == 0) ? o * V + (jj ^ ((o / (16 / V)) & (V - 1))) : q;
+}
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ const void *uniform_ptr(const void *q) {
+    const uint64_t v = (uint64_t)(uintptr_t)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+// One LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) land at LDS byte address lds_dst + lane*16 (M0 is
+// compiler-reserved: saved and restored inside the statement, cdna_hip_programming.md 5.7).  hipcc does not see the load;
+// `nt`: every sample is read once (streaming fetch, +10 % on the achievable read rate on this part).
+__device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
+    const void *sbase = uniform_ptr(sbase_);
+    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+template <int V>
+__device__ __forceinline__ void dma_share(const float *src_share, v4f *buf, int lane) {
+    asm volatile("" : "+v"(lane));  // not hoisted: see limit_tile
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8 *)buf;
+#pragma unroll
+    for (int k = 0; k < V; ++k) glds16(src_share, vec_in_slot<V>(k * 64 + lane) * 16u, lds0 + k * 1024);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#ifdef RH_LIMIT_PROFILE  // diagnostic builds (tools/build_variant.sh): shader cycles per phase of a tile, summed over all tiles
+__device__ unsigned long long g_limit_prof[16];
+#define RH_LP_DECL unsigned long long lp_last = __builtin_readcyclecounter();
+#define RH_LP(i)                                                                  \
+    {                                                                             \
+        const unsigned long long lp_now = __builtin_readcyclecounter();           \
+        lp_acc[i] += lp_now - lp_last;                                            \
+        lp_last = lp_now;                                                         \
+    }
+#define RH_LP_PARAM , unsigned long long (&lp_acc)[8]
+#define RH_LP_ARG , lp_acc
+#else
+#define RH_LP_DECL
+#define RH_LP(i)
+#define RH_LP_PARAM
+#define RH_LP_ARG
+#endif
+
+// One window of a look-back walk.  Lane j looks at tile base-j: the `inc` section holds a predecessor's inclusive (end)
+// state, the `agg` section its zero-state aggregate.  All loads of a poll leave together (one round trip).  Returns j* = the
+// nearest lane whose inclusive state is known (64: none in this window) once every lane in front of it holds an aggregate;
+// virtual entries -- the state the block starts from (tile -1), tiles before it, predecessors whose weight is negligible
+// -- count as known states (zero unless tile -1 with a carried-in state).
+template <int C, int NAGG, int WAGG, int WINC>
+__device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_t base, int lane, uint32_t reach, uint32_t stride, uint32_t off_agg, uint32_t off_inc,
+                                                const float *init, float (&agg)[NAGG], float (&inc)[C], bool &dead) {
+    const int64_t idx = base - lane;
+    const bool real = idx >= 0 && (uint32_t)lane < reach;
+    const float *pr = gran_stream + (real ? (uint64_t)idx : 0) * stride;
+    bool have_agg = !real, have_inc = !real;
+#pragma unroll
+    for (int c = 0; c < NAGG; ++c) agg[c] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) inc[c] = (idx == -1 && init) ? init[2 * c] : 0.0f;
+    uint32_t spins = 0;
+    while (true) {
+        if (real && !have_inc) {
+            float gi[C], ga[NAGG];
+            load_words<C, WINC>(pr + off_inc, gi);
+            if (!have_agg) {
+                load_words<NAGG, WAGG>(pr + off_agg, ga);
+                wait_loads(ga);
+            }
+            wait_loads(gi);
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) ok = ok && word_ok(gi[c]);
+            if (ok) {
+                have_inc = true;
+#pragma unroll
+                for (int c = 0; c < C; ++c) inc[c] = gi[c];
+            } else if (!have_agg) {
+                bool oka = true;
+#pragma unroll
+                for (int c = 0; c < NAGG; ++c) oka = oka && word_ok(ga[c]);
+                if (oka) {
+                    have_agg = true;
+#pragma unroll
+                    for (int c = 0; c < NAGG; ++c) agg[c] = ga[c];
+                }
+            }
+        }
+        const unsigned long long inc_mask = __ballot(have_inc);
+        const uint32_t jstar = inc_mask ? (uint32_t)__builtin_ctzll(inc_mask) : 64u;
+        const unsigned long long need = jstar >= 64 ? ~0ull : ((1ull << jstar) - 1ull);  // lanes in front of j* must hold an aggregate
+        if ((__ballot(have_agg || have_inc) & need) == need) return jstar;
+        if (++spins > kSpinLimit) {
+            dead = true;
+            return 64u;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// One wave's share (L = 64*R frames) of a workgroup tile (NW waves, LW = NW*L frames of one stream).
+//   waves of a workgroup exchange their aggregates through LDS (two barriers per tile); only the workgroup-level
+//   aggregates and end states travel through HBM, one record per LW frames, and every wave walks the (short) look-back over
+//   them on its own -- redundant polls are cheaper than two more barriers.
+template <int C, int R, int NW, bool FULL>
+__device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
+                                           const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf RH_LP_PARAM) {
+    // The lane id is made opaque per tile: everything derived from it (LDS slots, global offsets) is then recomputed here, a
+    // few VALU operations, instead of being hoisted out of the persistent loop into registers that stay occupied for the
+    // whole kernel (which spilled).
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    constexpr int V = C * R / 4;
+    constexpr uint32_t L = 64u * R, LW = L * NW;
+    typedef Rec<C> RC;
+    constexpr uint32_t G = RC::stride;
+    const float rel = a.release, omr = 1.0f - a.release, att = a.attack, oma = 1.0f - a.attack;
+    const GainK gk{LOG10_2 * 20.0f, -a.threshold, 0.5f * a.knee_width, a.knee_width, a.inv_knee_8};
+    const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;  // first frame of this wave's share; nf = valid frames in it (FULL: L)
+    const uint32_t nfl = FULL ? (uint32_t)R : (nf > (uint32_t)lane * R ? (nf - lane * R < (uint32_t)R ? nf - lane * R : R) : 0u);
+    const float *src = a.src + stream * a.stride + f0 * C;
+    float *dst = a.dst + stream * a.stride + f0 * C;
+    const uint32_t nfloat = nf * C;
+    const float *const gstream = a.gran + (uint64_t)stream * a.tiles * G;
+    float *const rec = a.gran + ((uint64_t)stream * a.tiles + tile) * G;
+    const float *const init = a.state_in ? a.state_in + (uint64_t)stream * C * 2 : nullptr;
+    RH_LP_DECL
+    // ---- the samples: whole shares were put into LDS by the DMA issued a tile ago; a short share (end of a stream) is
+    //      fetched here, guarded, into the same slots
+    if (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const uint32_t q = k * 64 + lane, o = 4u * q;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (o + 4 <= nfloat) v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + o));
+            else if (o < nfloat) {
+                v.x = src[o];
+                if (o + 1 < nfloat) v.y = src[o + 1];
+                if (o + 2 < nfloat) v.z = src[o + 2];
+            }
+            lds[slot_of<V>(q / V, q % V)] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    RH_LP(0)
+    // ---- this lane's run: gain computer + lane-local max-affine segment per channel (the samples stay in the LDS row) ----
+    float g[R][C], A[C], B[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) A[c] = B[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const v4f v = lds[slot_of<V>(lane, j)];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
+            float gv = gain_computer(e[i], gk);
+            if (!FULL) gv = (uint32_t)r < nfl ? gv : 0.0f;
+            g[r][c] = gv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float bn = omr * g[r][c];
+            const float An = fmaxf(g[r][c], fma_(rel, A[c], bn)), Bn = fma_(rel, B[c], bn);
+            if (FULL || (uint32_t)r < nfl) {  // frames past the end of the stream are the identity
+                A[c] = An;
+                B[c] = Bn;
+            }
+        }
+    float Ax[C], Bx[C];  // exclusive prefixes inside the wave
+    const float r15 = tab[0][lane], r31 = tab[1][lane];  // per-lane constants live in LDS, not in registers, between their uses
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        scan_maxaff(A[c], B[c], a.rscan, r15, r31);
+        Ax[c] = dpp0<kWaveShr1, 0xf>(A[c]);
+        Bx[c] = dpp0<kWaveShr1, 0xf>(B[c]);
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) xI[wave][c] = A[c], xI[wave][C + c] = B[c];
+    }
+    RH_LP(1)
+    __syncthreads();  // (1) the waves' aggregates are in LDS
+    // prefix over the waves in front of this one, and the workgroup aggregate (uniform; LDS broadcast reads)
+    float Ap[C], Bp[C], AT[C], BT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) Ap[c] = Bp[c] = AT[c] = BT[c] = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < NW; ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (k == wave) Ap[c] = AT[c], Bp[c] = BT[c];
+            const float Ak = xI[k][c], Bk = xI[k][C + c];
+            AT[c] = fmaxf(Ak, fma_(a.rL, AT[c], Bk));
+            BT[c] = fma_(a.rL, BT[c], Bk);
+        }
+    }
+    if (wave == 0 && lane < 2 * C) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = lane == c ? AT[c] : (lane == C + c ? BT[c] : v);
+        word_store(rec + RC::oA + lane, v);
+    }
+    // ---- look-back for the integrator over the workgroup tiles in front: I_in = f_{t-1}(f_{t-2}(... )) -----------------------
+    // With w_j = r^(LW*j) and S_j = sum_{i<j} w_i B_i the composition of a window is
+    //     max_{j<j*} (w_j A_j + S_j)  v  (w_j* Iend_j* + S_j*).
+    // No j* in the window: fold it into (Ao, Bo, Co) and slide on, unless Co has decayed below f32 resolution.
+    bool dead = false;
+    float Iin[C];
+    {
+        float Ao[C], Bo[C], Co = 1.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
+        int64_t base = (int64_t)tile - 1;
+        const float wI = tab[6][lane];
+        while (true) {
+            float AB[2 * C], Ij[C];
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA, RC::wS>(gstream, base, lane, a.jI, G, RC::oA, RC::oI, init, AB, Ij, dead);
+            if (dead) break;
+            const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float tot;
+                const float S = wave_excl_sum(front ? wI * AB[C + c] : 0.0f, tot);
+                const float cand = front ? fma_(wI, AB[c], S) : (star ? fma_(wI, Ij[c], S) : 0.0f);
+                const float Aw = wave_max(cand);
+                Ao[c] = fmaxf(Ao[c], fma_(Co, Aw, Bo[c]));
+                Bo[c] = fma_(Co, tot, Bo[c]);
+            }
+            if (jstar < 64) break;  // reached a known state: Ao contains it
+            Co *= a.rL64;
+            base -= 64;
+            if (Co < kNegligible) break;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
+    }
+    if (wave == 0 && lane < C) {  // the tile's end state of the integrator, for the tiles behind
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = lane == c ? fmaxf(AT[c], fma_(a.rLW, Iin[c], BT[c])) : v;
+        word_store(rec + RC::oI + lane, v);
+    }
+    // The next tile's samples are requested here (LDS-DMA into the other buffer): behind the integrator look-back, whose poll
+    // would otherwise have to wait for them (vmcnt retires in order), and a whole integrator run + barrier ahead of the next
+    // poll and of their use.
+    if (next_src) dma_share<V>(next_src, next_buf, lane);
+    RH_LP(2)
+    // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
+    float I[C], Pz[C];
+    const float rwave = a.rwave[wave], rlane = tab[2][lane];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float Iw = fmaxf(Ap[c], fma_(rwave, Iin[c], Bp[c]));  // this wave's start state
+        I[c] = fmaxf(Ax[c], fma_(rlane, Iw, Bx[c]));                // this lane's
+        Pz[c] = 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float In = fmaxf(g[r][c], rel * I[c] + omr * g[r][c]);   // limit.rs:909-912, the reference's own expression
+            const float Pn = att * Pz[c] + oma * In;                        // limit.rs:913 from a zero state
+            if (FULL || (uint32_t)r < nfl) {
+                I[c] = In;
+                Pz[c] = Pn;
+            }
+            g[r][c] = Pz[c];
+        }
+    float Px[C];
+    const float a15 = tab[3][lane], a31 = tab[4][lane];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float Pi = Pz[c];
+        scan_lin(Pi, a.ascan, a15, a31);
+        Px[c] = dpp0<kWaveShr1, 0xf>(Pi);
+        if (lane == 63) xP[wave][c] = Pi;
+    }
+    RH_LP(3)
+    __syncthreads();  // (2) the waves' zero-state peak aggregates are in LDS
+    float Pp[C], PT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) Pp[c] = PT[c] = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < NW; ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (k == wave) Pp[c] = PT[c];
+            PT[c] = fma_(a.aL, PT[c], xP[k][c]);
+        }
+    }
+    if (wave == 0 && lane < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = lane == c ? PT[c] : v;
+        word_store(rec + RC::oZ + lane, v);
+    }
+    // ---- look-back for the peak: P_in = sum_{j<j*} a^(LW*j) Pz_{t-1-j} + a^(LW*j*) Pend_j* ------------------------------------
+    float Pin[C];
+    {
+        float Co = 1.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) Pin[c] = 0.0f;
+        int64_t base = (int64_t)tile - 1;
+        const float wP = tab[7][lane];
+        while (!dead) {
+            float Zj[C], Ej[C];
+            const uint32_t jstar = poll_window<C, C, RC::wS, RC::wS>(gstream, base, lane, a.jP, G, RC::oZ, RC::oE, init ? init + 1 : nullptr, Zj, Ej, dead);
+            if (dead) break;
+            const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float tot;
+                (void)wave_excl_sum(front ? wP * Zj[c] : (star ? wP * Ej[c] : 0.0f), tot);
+                Pin[c] = fma_(Co, tot, Pin[c]);
+            }
+            if (jstar < 64) break;
+            Co *= a.aL64;
+            base -= 64;
+            if (Co < kNegligible) break;
+        }
+    }
+    if (wave == 0 && lane < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = lane == c ? fma_(a.aLW, Pin[c], PT[c]) : v;
+        word_store(rec + RC::oE + lane, v);
+    }
+    if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
+        if (lane == 0) atomicOr(a.ctl + 1, 1u);
+#pragma unroll
+        for (int c = 0; c < C; ++c) Pin[c] = __builtin_nanf("");
+    }
+    RH_LP(4)
+    // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----
+    float Ps[C], Pcur[C];
+    const float awave = a.awave[wave], alane = tab[5][lane];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float Pw = fma_(awave, Pin[c], Pp[c]);  // this wave's start state
+        Ps[c] = fma_(alane, Pw, Px[c]);               // this lane's
+        Pcur[c] = Ps[c];
+    }
+    const float kexp = -0.05f * LOG2_10;  // math.rs:51-56: 2^(dB * 0.05 * log2 10), the two constants folded
+    __builtin_amdgcn_wave_barrier();
+    float ap = 1.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        v4f v = lds[slot_of<V>(lane, j)];
+        float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
+            if (c == 0) ap *= att;  // a^(r+1)
+            Pcur[c] = fma_(ap, Ps[c], g[r][c]);
+            float mp = C > 2 ? 0.0f : Pcur[0];  // LimitMulti folds from 0.0
+#pragma unroll
+            for (int k = (C > 2 ? 0 : 1); k < C; ++k) mp = fmaxf(mp, Pcur[k]);
+            e[i] = e[i] * __builtin_amdgcn_exp2f(mp * kexp);
+        }
+        v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
+        lds[slot_of<V>(lane, j)] = v;
+    }
+    // the block's end state: the lane that holds the stream's last frame (a stream's last wave share may be short or empty)
+    if (a.state_out && nfl > 0 && f0 + (uint64_t)lane * R + nfl == a.frames) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float pe = Ps[c], apw = 1.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                apw *= att;
+                pe = (uint32_t)r + 1 == nfl ? fma_(apw, Ps[c], g[r][c]) : pe;
+            }
+            a.state_out[((uint64_t)stream * C + c) * 2] = I[c];
+            a.state_out[((uint64_t)stream * C + c) * 2 + 1] = pe;
+        }
+    }
+    RH_LP(5)
+    // ---- LDS rows -> coalesced store -----------------------------------------------------------------------------------
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint32_t q = k * 64 + lane, o = 4u * q;
+        const v4f v = lds[slot_of<V>(q / V, q % V)];
+        if (FULL || o + 4 <= nfloat) *reinterpret_cast<v4f *>(dst + o) = v;
+        else if (o < nfloat) {
+            dst[o] = v.x;
+            if (o + 1 < nfloat) dst[o + 1] = v.y;
+            if (o + 2 < nfloat) dst[o + 2] = v.z;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the rows are free for the next tile
+    RH_LP(6)
+}
+
+template <int C, int R, int NW>
+__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
+    static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW, "a lane's run is whole 16-byte vectors");
+    constexpr int V = C * R / 4;  // 16-byte vectors per lane; a wave's share of a tile is V KiB
+    constexpr uint32_t L = 64u * R, LW = L * NW;
+    __shared__ __attribute__((aligned(1024))) v4f bufs[NW][2][64 * V];  // per wave: the tile being worked on and the one being fetched
+    __shared__ float xI[NW][2 * C], xP[NW][C];
+    __shared__ uint32_t s_ticket[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total = a.n_streams * a.tiles;  // host: < 2^32
+    __shared__ float tab[8][64];  // r15 r31 rlane a15 a31 alane rlook alook per lane (LimitTabs)
+    if (wave == 0) {
+        tab[0][lane] = a.t.r15[lane], tab[1][lane] = a.t.r31[lane], tab[2][lane] = a.t.rlane[lane];
+        tab[3][lane] = a.t.a15[lane], tab[4][lane] = a.t.a31[lane], tab[5][lane] = a.t.alane[lane];
+        tab[6][lane] = a.t.rlook[lane], tab[7][lane] = a.t.alook[lane];
+    }
+#ifdef RH_LIMIT_PROFILE
+    unsigned long long lp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // Tiles are handed out by one ticket per workgroup tile, tile-major over the streams (ticket k -> tile k / S of stream
+    // k % S): a tile only ever waits for tiles with smaller tickets, which run or have finished.  Tickets are taken two
+    // tiles ahead (thread 0, through LDS, published by the barriers of the tile in between): the tile after the current one
+    // is known when the current one starts, so its samples are requested (LDS-DMA) before any of the current tile's work.
+    auto share = [&](uint32_t ticket, const float *&src, uint32_t &nf) {
+        const uint32_t tile = ticket / a.n_streams, stream = ticket - tile * a.n_streams;
+        const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;
+        nf = f0 >= a.frames ? 0u : (a.frames - f0 < L ? (uint32_t)(a.frames - f0) : L);
+        src = a.src + stream * a.stride + f0 * C;
+    };
+    if (threadIdx.x == 0) {
+        s_ticket[0] = atomicAdd(a.ctl, 1u);
+        s_ticket[1] = atomicAdd(a.ctl, 1u);
+    }
+    __syncthreads();
+    uint32_t cur = s_ticket[0], nxt = s_ticket[1];
+    uint32_t n = 0;
+    bool prev_full = false;
+    if (cur < total) {
+        const float *src;
+        uint32_t nf;
+        share(cur, src, nf);
+        if (nf == L) dma_share<V>(src, bufs[wave][0], lane);
+    }
+    while (cur < total) {
+        if (threadIdx.x == 0) s_ticket[(n + 2) % 3] = atomicAdd(a.ctl, 1u);
+        const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
+        const float *src;
+        uint32_t nf;
+        share(cur, src, nf);
+        // this tile's DMA is older than everything else in flight; what may still be pending behind it are the V output stores
+        // of the previous tile (if it was a whole share -- otherwise drain)
+        if (prev_full) wait_vm<V>();
+        else wait_vm<0>();
+        const float *src2 = nullptr;
+        if (nxt < total) {
+            uint32_t nf2;
+            share(nxt, src2, nf2);
+            if (nf2 != L) src2 = nullptr;  // a short share is fetched by its own tile, guarded
+        }
+        if (nf == L) limit_tile<C, R, NW, true>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, src2, bufs[wave][(n + 1) & 1] RH_LP_ARG);
+        else limit_tile<C, R, NW, false>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, src2, bufs[wave][(n + 1) & 1] RH_LP_ARG);
+        prev_full = nf == L;
+        cur = nxt;
+        nxt = s_ticket[(n + 2) % 3];  // written before barrier (1) of the tile just done
+        ++n;
+    }
+    wait_vm<0>();
+#ifdef RH_LIMIT_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_limit_prof[i], lp_acc[i]);
+#endif
+}
+
+// snapshot of the caller's state in front of the launch: the last tile rewrites it while early tiles may still read it
+__global__ void k_copy_f32(float *dst, const float *src, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+using LimitFn = void (*)(const LimitArgs);
+struct LimitVariant {
+    int C, R, NW;
+    LimitFn fn;
+};
+#define RH_LV(c, r, nw) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw>}
+const LimitVariant kVariants[] = {
+    RH_LV(1, 8, 8),  RH_LV(1, 16, 8), RH_LV(1, 16, 16), RH_LV(1, 8, 1),
+    RH_LV(2, 8, 8),  RH_LV(2, 8, 16), RH_LV(2, 8, 4),  RH_LV(2, 8, 1), RH_LV(2, 16, 8), RH_LV(2, 16, 4),
+    RH_LV(3, 4, 8),  RH_LV(3, 4, 1),  RH_LV(4, 4, 8),   RH_LV(4, 4, 1), RH_LV(5, 4, 8), RH_LV(5, 4, 1),
+    RH_LV(6, 4, 8),  RH_LV(6, 4, 1),  RH_LV(7, 4, 8),   RH_LV(7, 4, 1), RH_LV(8, 4, 8), RH_LV(8, 4, 1),
+};
+#undef RH_LV
+
+size_t rec_stride(uint32_t channels) {
+    switch (channels) {
+        case 1: return Rec<1>::stride;
+        case 2: return Rec<2>::stride;
+        case 3: return Rec<3>::stride;
+        case 4: return Rec<4>::stride;
+        case 5: return Rec<5>::stride;
+        case 6: return Rec<6>::stride;
+        case 7: return Rec<7>::stride;
+        default: return Rec<8>::stride;
+    }
+}
+
+double ipow(double b, uint64_t e) {
+    double r = 1.0;
+    while (e) {
+        if (e & 1) r *= b;
+        b *= b;
+        e >>= 1;
+    }
+    return r;
+}
+
+}  // namespace
+
+extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t sample_rate, uint32_t n_streams, const rh_limit_params *p, float *state, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || sample_rate == 0 || !p) return RH_ERR_INVALID;
+    if (channels > 8) return RH_ERR_UNSUPPORTED;
+    if (frames == 0 || n_streams == 0) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    hipStream_t s = rh::as_stream(stream);
+    const float attack = rh::duration_to_coefficient_f32(p->attack_ns, sample_rate);    // limit.rs:96-97
+    const float release = rh::duration_to_coefficient_f32(p->release_ns, sample_rate);
+    const float k5[5] = {p->threshold_db, p->knee_width_db, 1.0f / (8.0f * p->knee_width_db) /* limit.rs:877 */, attack, release};
+    const uint64_t stride = frames * channels;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || stride % 4 == 0);
+    // coefficients outside [0, 1) (zero or negative durations give exp(-inf) = 0 or exp(+x) > 1) leave the scan's premises
+    const bool scannable = release >= 0.0f && release < 1.0f && attack >= 0.0f && attack < 1.0f && p->knee_width_db > 0.0f;
+    const char *force_seq = getenv("RH_LIMIT_SEQ");  // diagnostics: the reference-order kernel
+    if (!aligned || !scannable || (force_seq && force_seq[0] == '1')) return rh::limit_seq_launch(dst, src, frames, channels, n_streams, k5, state, s);
+
+    // Geometry (measured, 64 x 1 Mi and 2048 x 32 Ki stereo frames): workgroups of 8 waves with 16 frames per lane -- tiles of
+    // 8192 frames, one look-back per 128 KiB of traffic -- while that still gives every CU a couple of tiles; shorter blocks
+    // take smaller tiles, down to single-wave ones for a pull shim's block.
+    const uint64_t work = frames * (uint64_t)n_streams;
+    int want_R = 16, want_NW = 8;
+    if (work < 2ull * 8192 * (uint64_t)rh::g_num_cus) want_R = 8, want_NW = 4;
+    if (work < 2ull * 2048 * (uint64_t)rh::g_num_cus) want_R = 8, want_NW = 1;
+    if (const char *e = getenv("RH_LIMIT_R")) want_R = atoi(e);    // tuning aids
+    if (const char *e = getenv("RH_LIMIT_NW")) want_NW = atoi(e);
+    const LimitVariant *v = nullptr;
+    for (const LimitVariant &c : kVariants) {
+        if (c.C != (int)channels) continue;
+        auto score = [&](const LimitVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
+        if (!v || score(c) < score(*v)) v = &c;
+    }
+    if (!v) return RH_ERR_UNSUPPORTED;
+    const uint32_t R = (uint32_t)v->R, NW = (uint32_t)v->NW, L = 64u * R, LW = L * NW;
+    const uint64_t tiles64 = (frames + LW - 1) / LW;
+    if (tiles64 > 0x7fffffffull || tiles64 * n_streams >= 0xfff00000ull) return RH_ERR_UNSUPPORTED;  // tickets are 32-bit
+
+    LimitArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.dst = dst;
+    a.src = src;
+    a.frames = frames;
+    a.stride = stride;
+    a.n_streams = n_streams;
+    a.tiles = (uint32_t)tiles64;
+    a.threshold = k5[0];
+    a.knee_width = k5[1];
+    a.inv_knee_8 = k5[2];
+    a.attack = attack;
+    a.release = release;
+    const double r = release, al = attack;
+    for (int k = 0; k < 4; ++k) {
+        a.rscan[k] = (float)ipow(r, (uint64_t)R << k);
+        a.ascan[k] = (float)ipow(al, (uint64_t)R << k);
+    }
+    a.rL = (float)ipow(r, L);
+    a.aL = (float)ipow(al, L);
+    a.rLW = (float)ipow(r, LW);
+    a.aLW = (float)ipow(al, LW);
+    for (uint32_t k = 0; k < NW; ++k) {
+        a.rwave[k] = (float)ipow(r, (uint64_t)L * k);
+        a.awave[k] = (float)ipow(al, (uint64_t)L * k);
+    }
+    a.rL64 = (float)ipow(r, (uint64_t)LW * 64);
+    a.aL64 = (float)ipow(al, (uint64_t)LW * 64);
+    a.jI = a.jP = 64;
+    for (int l = 0; l < 64; ++l) {
+        a.t.r15[l] = (float)ipow(r, (uint64_t)R * ((l & 15) + 1));
+        a.t.r31[l] = (float)ipow(r, (uint64_t)R * ((l & 31) + 1));
+        a.t.rlane[l] = (float)ipow(r, (uint64_t)R * l);
+        a.t.a15[l] = (float)ipow(al, (uint64_t)R * ((l & 15) + 1));
+        a.t.a31[l] = (float)ipow(al, (uint64_t)R * ((l & 31) + 1));
+        a.t.alane[l] = (float)ipow(al, (uint64_t)R * l);
+        a.t.rlook[l] = (float)ipow(r, (uint64_t)LW * l);
+        a.t.alook[l] = (float)ipow(al, (uint64_t)LW * l);
+        if (a.jI == 64 && a.t.rlook[l] < kNegligible) a.jI = (uint32_t)l;
+        if (a.jP == 64 && a.t.alook[l] < kNegligible) a.jP = (uint32_t)l;
+    }
+    if (a.jI == 0) a.jI = 1;
+    if (a.jP == 0) a.jP = 1;
+
+    // scratch: control words + the carried-in states + the hand-off table, initialised on the stream in front of the launch
+    const size_t n_state = (size_t)n_streams * channels * 2;
+    const size_t gran_bytes = (size_t)n_streams * tiles64 * rec_stride(channels) * sizeof(float);
+    const size_t head = 64 + ((n_state * 4 + 63) & ~size_t(63));
+    unsigned char *scratch = nullptr;
+    RH_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scratch), head + gran_bytes, s));
+    hipError_t e = hipMemsetAsync(scratch, 0, head, s);
+    if (e == hipSuccess) e = hipMemsetAsync(scratch + head, 0xff, gran_bytes, s);  // every word "not yet"
+    a.ctl = reinterpret_cast<uint32_t *>(scratch);
+    a.gran = reinterpret_cast<float *>(scratch + head);
+    if (e == hipSuccess && state) {
+        float *snap = reinterpret_cast<float *>(scratch + 64);
+        hipLaunchKernelGGL(k_copy_f32, dim3((unsigned)((n_state + 255) / 256)), dim3(256), 0, s, snap, state, (uint32_t)n_state);
+        e = hipGetLastError();
+        a.state_in = snap;
+        a.state_out = state;
+    }
+    if (e == hipSuccess) {
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
+        if (const char *w = getenv("RH_LIMIT_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;  // tuning aid: resident workgroups per CU
+        uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
+        const uint64_t total = tiles64 * n_streams;
+        if (grid > total) grid = total;
+        if (e == hipSuccess) {
+            void *args[] = {&a};
+            e = hipLaunchKernel(reinterpret_cast<const void *>(v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
+        }
+    }
+    (void)hipFreeAsync(scratch, s);
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, "rh_limit launch");
+        return RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+
+// Diagnostics, only in -DRH_LIMIT_PROFILE builds (RH_ERR_UNSUPPORTED otherwise): shader cycles per phase {load, gain+segment,
+// look-back I, integrator run, look-back P, gain stage, store} summed over all tiles since the last call.  Not in rodio_hip.h.
+extern "C" rh_status rh_limit_phase_cycles(double out8[8]) {
+#ifdef RH_LIMIT_PROFILE
+    unsigned long long h[16];
+    RH_HIP_TRY(hipDeviceSynchronize());
+    RH_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_limit_prof), sizeof(h)));
+    for (int i = 0; i < 8; ++i) out8[i] = (double)h[i];
+    std::memset(h, 0, sizeof(h));
+    RH_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_limit_prof), h, sizeof(h)));
+    return RH_OK;
+#else
+    (void)out8;
+    return RH_ERR_UNSUPPORTED;
+#endif
+}

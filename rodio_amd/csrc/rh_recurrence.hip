@@ -176,6 +176,24 @@ float duration_to_coefficient(uint64_t ns, uint32_t sample_rate) {
 
 }  // namespace
 
+namespace rh {
+// The reference-order limiter (one lane per stream): what rh_limit (rh_limit.hip) takes for rows that are not 16-byte
+// aligned or for coefficients outside the scan's premises.  k5 = {threshold, knee_width, inv_knee_8, attack, release}.
+rh_status limit_seq_launch(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float k5[5], float *state, hipStream_t s) {
+    if (channels > (uint32_t)kMaxCh) return RH_ERR_UNSUPPORTED;
+    LimitK k;
+    k.threshold = k5[0];
+    k.knee_width = k5[1];
+    k.inv_knee_8 = k5[2];
+    k.attack = k5[3];
+    k.release = k5[4];
+    hipLaunchKernelGGL(k_limit_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, frames, channels, n_streams, k, state);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+float duration_to_coefficient_f32(uint64_t ns, uint32_t sample_rate) { return duration_to_coefficient(ns, sample_rate); }
+}  // namespace rh
+
 extern "C" {
 
 rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate, float out[5]) {
@@ -221,23 +239,6 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
     const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};
     const uint32_t lanes = n_streams * channels;
     hipLaunchKernelGGL(k_biquad_seq, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
-    RH_CHECK_LAUNCH();
-    return RH_OK;
-}
-
-rh_status rh_limit(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t sample_rate, uint32_t n_streams, const rh_limit_params *p, float *state, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (channels == 0 || sample_rate == 0 || !p) return RH_ERR_INVALID;
-    if (channels > kMaxCh) return RH_ERR_UNSUPPORTED;
-    if (frames == 0 || n_streams == 0) return RH_OK;
-    if (!dst || !src) return RH_ERR_INVALID;
-    LimitK k;
-    k.threshold = p->threshold_db;
-    k.knee_width = p->knee_width_db;
-    k.inv_knee_8 = 1.0f / (8.0f * p->knee_width_db);             // limit.rs:877
-    k.attack = duration_to_coefficient(p->attack_ns, sample_rate);  // limit.rs:96-97
-    k.release = duration_to_coefficient(p->release_ns, sample_rate);
-    hipLaunchKernelGGL(k_limit_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -15,6 +15,8 @@
 // This TU is compiled with -ffp-contract=off: the lerp must not become an FMA.
 #include <numeric>
 
+#include <cstring>
+
 #include "rh_common.h"
 
 namespace rh {
@@ -139,13 +141,20 @@ struct MixDesc {
 
 // One lane per output sample, sources visited in insertion order: the rounding sequence of
 // mixer.rs:185-198 (`sum = 0.0; sum += v_s`).  No atomics, no tree: bit-identical to the CPU.
-__global__ __launch_bounds__(kBlock) void k_mix_sum(float *__restrict__ dst, uint64_t out_len, const MixDesc *__restrict__ tbl, uint32_t n_sources) {
+// The source table travels BY VALUE as a kernel argument, kMixChunk sources per launch: nothing to upload, nothing
+// to synchronise, nothing that a later call could overwrite while this launch is still queued.  More sources take
+// further launches that continue from the stored partial sum -- the same left-to-right sequence of f32 additions.
+constexpr uint32_t kMixChunk = 32;
+struct MixTable {
+    MixDesc d[kMixChunk];
+};
+template <bool CONT>
+__global__ __launch_bounds__(kBlock) void k_mix_sum(float *__restrict__ dst, uint64_t out_len, const MixTable tbl, uint32_t n_sources) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x; o < out_len; o += stride) {
-        float acc = 0.0f;
-#pragma unroll 4
+        float acc = CONT ? dst[o] : 0.0f;
         for (uint32_t s = 0; s < n_sources; ++s) {
-            const MixDesc d = tbl[s];
+            const MixDesc d = tbl.d[s];
             const uint64_t rel = o - d.start;  // wraps to huge when o < start
             if (rel < d.len) acc += d.data[rel];
         }
@@ -155,15 +164,19 @@ __global__ __launch_bounds__(kBlock) void k_mix_sum(float *__restrict__ dst, uin
 
 // Same, four consecutive samples per lane (float4 loads) when every start is a multiple of 4
 // samples and every pointer is 16-byte aligned -- the common "all sources start together" case.
-__global__ __launch_bounds__(kBlock) void k_mix_sum_v4(float *__restrict__ dst, uint64_t out_len, const MixDesc *__restrict__ tbl, uint32_t n_sources) {
+template <bool CONT>
+__global__ __launch_bounds__(kBlock) void k_mix_sum_v4(float *__restrict__ dst, uint64_t out_len, const MixTable tbl, uint32_t n_sources) {
     const uint64_t nvec = (out_len + 3) / 4;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
         const uint64_t o = v * 4;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
+        if (CONT) {
+            for (int k = 0; k < 4; ++k)
+                if (o + k < out_len) acc[k] = dst[o + k];
+        }
         for (uint32_t s = 0; s < n_sources; ++s) {
-            const MixDesc d = tbl[s];
+            const MixDesc d = tbl.d[s];
             const uint64_t rel = o - d.start;
             if (rel < d.len) {
                 if (rel + 4 <= d.len) {
@@ -238,32 +251,23 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host, 
         return RH_OK;
     }
     bool vec_ok = (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
-    MixDesc *host = new MixDesc[n_sources];
     for (uint32_t i = 0; i < n_sources; ++i) {
-        host[i] = MixDesc{srcs_host[i], start_host[i], len_host[i]};
-        if (len_host[i] && !srcs_host[i]) {
-            delete[] host;
-            return RH_ERR_INVALID;
-        }
+        if (len_host[i] && !srcs_host[i]) return RH_ERR_INVALID;
         vec_ok = vec_ok && (start_host[i] % 4 == 0) && (reinterpret_cast<uintptr_t>(srcs_host[i]) % 16 == 0);
     }
-    MixDesc *tbl = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&tbl), sizeof(MixDesc) * n_sources, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(tbl, host, sizeof(MixDesc) * n_sources, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s) == hipSuccess ? hipSuccess : hipGetLastError();
-    delete[] host;  // pageable copy has been staged (and the stream drained) by now
-    if (e != hipSuccess) {
-        rh::set_hip_error(e, "rh_mix_sum table upload");
-        if (tbl) (void)hipFreeAsync(tbl, s);
-        return RH_ERR_HIP;
-    }
-    if (vec_ok) hipLaunchKernelGGL(k_mix_sum_v4, dim3(rh::grid_for((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, tbl, n_sources);
-    else hipLaunchKernelGGL(k_mix_sum, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, tbl, n_sources);
-    hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(tbl, s);
-    if (le != hipSuccess) {
-        rh::set_hip_error(le, "k_mix_sum launch");
-        return RH_ERR_HIP;
+    for (uint32_t first = 0; first < n_sources; first += kMixChunk) {
+        const uint32_t n = n_sources - first < kMixChunk ? n_sources - first : kMixChunk;
+        MixTable t;
+        std::memset(&t, 0, sizeof(t));
+        for (uint32_t i = 0; i < n; ++i) t.d[i] = MixDesc{srcs_host[first + i], start_host[first + i], len_host[first + i]};
+        if (vec_ok) {
+            if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, dim3(rh::grid_for((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            else hipLaunchKernelGGL(k_mix_sum_v4<false>, dim3(rh::grid_for((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+        } else {
+            if (first) hipLaunchKernelGGL(k_mix_sum<true>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            else hipLaunchKernelGGL(k_mix_sum<false>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+        }
+        RH_CHECK_LAUNCH();
     }
     return RH_OK;
 }

@@ -177,13 +177,22 @@ class GpuSource:
         return GpuSource(out, self._channels, self._sample_rate, None)
 
     def limit(self, threshold=-1.0, knee_width=4.0, attack_ns=5_000_000, release_ns=100_000_000) -> "GpuSource":
+        """src/source/limit.rs:94-130,853-988.  A stream that ends inside a frame (rodio's own reverb with an odd delay
+        makes one) is still limited sample by sample (limit.rs:927-988 advances one channel per sample): the block is
+        padded to a whole frame -- the limiter is causal, the padding cannot reach the real samples -- and trimmed."""
         _ensure()
+        torch = _t()
         p = LimitParams(threshold, knee_width, attack_ns, release_ns)
-        out = _dev_empty(len(self))
-        frames = len(self) // self._channels
-        check(lib.rh_limit(_ptr(out), _ptr(self.samples), frames, self._channels, self._sample_rate, 1,
+        n = len(self)
+        frames = -(-n // self._channels)
+        src = self.samples
+        if frames * self._channels != n:
+            src = torch.zeros(frames * self._channels, dtype=torch.float32, device="cuda")
+            src[:n] = self.samples
+        out = _dev_empty(frames * self._channels)
+        check(lib.rh_limit(_ptr(out), _ptr(src), frames, self._channels, self._sample_rate, 1,
                            C.byref(p), None, _stream()), "rh_limit")
-        return GpuSource(out[: frames * self._channels], self._channels, self._sample_rate, self.span_len)
+        return GpuSource(out[:n], self._channels, self._sample_rate, self.span_len)
 
     def automatic_gain_control(self, target_level=1.0, attack_ns=4_000_000_000, release_ns=0,
                                absolute_max_gain=7.0, floor=0.0) -> "GpuSource":

@@ -34,7 +34,8 @@ for it in range(rounds):
             if len(got) == len(ref):
                 idx = np.nonzero(got != ref)[0]
                 z = int(np.count_nonzero(got[idx] == 0.0))
-                print(f"  round {it}: {len(idx)} samples differ, frames {idx[0]//2}..{idx[-1]//2} of {len(ref)//2}, zeros among them {z}, max {np.max(np.abs(got-ref)):.3g}")
+                nn = int(np.count_nonzero(np.isnan(got[idx])))
+                print(f"  round {it}: {len(idx)} samples differ, frames {idx[0]//2}..{idx[-1]//2} of {len(ref)//2}, zeros among them {z}, NaNs {nn}, max {np.nanmax(np.abs(got-ref)):.3g}")
             else:
                 print(f"  round {it}: length {len(got)} vs {len(ref)}")
 print("late filt", filt, "bad runs:", bad, "of", rounds * 4)
