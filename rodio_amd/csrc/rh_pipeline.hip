@@ -39,6 +39,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 #include <vector>
@@ -118,6 +119,8 @@ struct Params {
     unsigned long long *prof;  // RH_PHASE_PROFILE builds: [tiles][8] cycles per phase
     uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
     uint32_t batch_streams;    // k_rlm_fast: > 0 = no mixing: ticket k is tile k / batch_streams of source k % batch_streams
+    uint32_t shards;           // batch mode: > 1 = the streams are dealt over this many ticket counters (stream s -> counter s % shards)
+    uint32_t shard_base;       // ... whose common start value for this launch this is (every counter hands out n_tiles * batch_streams / shards tickets)
     uint64_t out_stride;       // ... whose output row starts out_stride floats after the previous one
     // k_rlm_fast, block streaming (st_mode: 0 off, 1 block of a running stream, 2 its last block):
     uint32_t st_mode, st_active;  // st_active: output frames this block emits (a multiple of R in mode 1)
@@ -313,11 +316,25 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
 
     const int lane = threadIdx.x;
-    const uint32_t ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
     // batch mode (no mixer: every source keeps its own output row): tickets run tile-major over the
-    // sources, so the predecessor tiles of a stream always hold earlier tickets
-    const uint32_t stream = p.batch_streams ? ticket % p.batch_streams : 0u;
-    const uint32_t tile = p.batch_streams ? ticket / p.batch_streams : ticket;
+    // sources, so the predecessor tiles of a stream always hold earlier tickets.  One device-scope counter hands out ~85
+    // tickets per microsecond (MI355X_MICROARCH.md "dequeue") -- 64 streams x 820 tiles would spend 0.6 ms on that alone --
+    // so the streams are dealt over `shards` counters on separate cache lines, one per XCD (workgroup b runs on XCD b % 8):
+    // a stream's tiles all come from one counter, which keeps the order that matters.
+    uint32_t ticket, stream, tile;
+    if (p.shards > 1) {
+        const uint32_t x = blockIdx.x % p.shards, per = p.batch_streams / p.shards;
+        ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket + 32u * (1u + x), 1u) - p.shard_base : 0u);
+        stream = x + p.shards * (ticket % per);
+        tile = ticket / per;
+    } else {
+        ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+        stream = p.batch_streams ? ticket % p.batch_streams : 0u;
+        tile = p.batch_streams ? ticket / p.batch_streams : ticket;
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);  // wave-uniform by construction: say so (SGPRs, not VGPRs)
+    stream = __builtin_amdgcn_readfirstlane(stream);
+    tile = __builtin_amdgcn_readfirstlane(tile);
     constexpr uint32_t L = 64u * R;
     const uint32_t m_tile0 = tile * L;
     const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
@@ -1685,6 +1702,7 @@ struct rh_rlm {
     uint64_t out_frames = 0;
     uint32_t epoch = 0;
     uint32_t ticket_base = 0;
+    uint32_t shard_base = 0;  // batch mode with sharded ticket counters (d_ctl + 32*(1+x)): tickets each of them has handed out
     // block streaming (rh_rlm_stream_*)
     bool st_on = false, st_done = false;
     uint64_t st_g0 = 0, st_m = 0;
@@ -1709,6 +1727,7 @@ struct rh_rlm {
     // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
     hipEvent_t idle_ev = nullptr;
     bool launched = false;
+    hipStream_t last_stream = nullptr;  // the stream of the launches idle_ev covers
 };
 
 namespace {
@@ -1725,6 +1744,7 @@ rh_status mark_launch(rh_rlm *p, hipStream_t s) {
     if (!p->idle_ev) RH_HIP_TRY(hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming));
     RH_HIP_TRY(hipEventRecord(p->idle_ev, s));
     p->launched = true;
+    p->last_stream = s;
     return RH_OK;
 }
 
@@ -1959,8 +1979,8 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     hipError_t e = hipSuccess;
     if (st == RH_OK) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 64);
-        if (e == hipSuccess) e = rh::fill_now(p->d_ctl, 0, 64);  // the ticket counter: a late fill would renumber tiles in mid-launch
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 128 * 9);  // control words + 8 ticket counters on their own cache lines
+        if (e == hipSuccess) e = rh::fill_now(p->d_ctl, 0, 128 * 9);  // the ticket counter: a late fill would renumber tiles in mid-launch
         if (e != hipSuccess) {
             rh::set_hip_error(e, "rh_rlm_create");
             st = e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
@@ -2003,7 +2023,10 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     return RH_OK;
 }
 
-rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
+static rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s);
+// on_stream != nullptr: the table travels on that stream through the page-locked ring (ordered behind the launches already
+// queued there, no host synchronisation) -- what rh_biquad mode 1 does per call; nullptr: the synchronous form of the C ABI.
+static rh_status set_sources_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources, const hipStream_t *on_stream) {
     RH_REQUIRE_INIT();
     if (!p || (n_sources && (!srcs_host || !in_frames_host))) return RH_ERR_INVALID;
     if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
@@ -2022,11 +2045,16 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
         if (g.out_frames > M) M = g.out_frames;
         equal = equal && in_frames_host[s] == in_frames_host[0];
     }
-    {
+    if (on_stream && p->launched && p->last_stream == *on_stream) {
+        if (n_sources) {
+            const rh_status up = upload_descriptors(p, n_sources, *on_stream);
+            if (up != RH_OK) return up;
+        }
+    } else {
         const rh_status w = wait_idle(p);  // an earlier run of this handle may still be reading the table
         if (w != RH_OK) return w;
+        if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
     }
-    if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
     p->equal = equal;
     p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
     p->n_sources = n_sources;
@@ -2035,6 +2063,10 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uin
     if (equal && !p->cfg.force_general) return activate_plan(p, &p->fast);
     // different lengths + filter: almost every (tile, source) pair is "stable" and goes through the lean kernel of the pair
     return activate_plan(p, pair_ok(p, p->pair) ? &p->pair : &p->wave);
+}
+
+rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
+    return set_sources_impl(p, srcs_host, in_frames_host, n_sources, nullptr);
 }
 
 rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
@@ -2118,6 +2150,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.prof = p->d_prof;
     k.eq_frames = p->eq_frames;
     k.batch_streams = batch_streams;
+    k.shards = (batch_streams >= 16 && batch_streams % 8 == 0 && !getenv("RH_NO_TICKET_SHARDS")) ? 8u : 1u;
+    k.shard_base = p->shard_base;
     k.out_stride = out_stride;
     k.st_mode = sa.mode;
     k.st_active = sa.active;
@@ -2157,7 +2191,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         rh::set_hip_error(e, "k_rlm launch");
         return RH_ERR_HIP;
     }
-    p->ticket_base += (uint32_t)grid;  // every launch takes exactly one ticket per workgroup
+    if (k.shards > 1) p->shard_base += (uint32_t)(grid / k.shards);
+    else p->ticket_base += (uint32_t)grid;  // every launch takes exactly one ticket per workgroup
     return mark_launch(p, s);
 }
 
@@ -2557,6 +2592,8 @@ rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t
     if (channels != 2 || state) return RH_ERR_UNSUPPORTED;  // stereo blocks from a zero state; mode 0 covers the rest
     if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) return RH_ERR_INVALID;
     if ((frames * 2) % 4 != 0 && n_streams > 1) return RH_ERR_UNSUPPORTED;  // stream rows must stay 16-byte aligned
+    static std::mutex mu;  // the cached plan is process-wide: one call at a time (a call only enqueues)
+    std::lock_guard<std::mutex> lock(mu);
     static rh_rlm *cache = nullptr;
     static float cache_co[5];
     static uint64_t cache_frames = 0;
@@ -2586,7 +2623,8 @@ rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t
     std::vector<const float *> ptrs(n_streams);
     std::vector<uint64_t> lens(n_streams, frames);
     for (uint32_t s = 0; s < n_streams; ++s) ptrs[s] = src + (uint64_t)s * frames * 2;
-    rh_status st = rh_rlm_set_sources(cache, ptrs.data(), lens.data(), n_streams);
+    const hipStream_t hs = rh::as_stream(stream);
+    rh_status st = set_sources_impl(cache, ptrs.data(), lens.data(), n_streams, &hs);
     if (st == RH_OK) st = rh_rlm_run_batch(cache, dst, frames, nullptr, stream);
     return st;
 }
