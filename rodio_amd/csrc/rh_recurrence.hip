@@ -10,6 +10,7 @@
 // so these kernels are latency-bound by construction; the time-parallel biquad used by the
 // headline pipeline lives in rh_pipeline.hip.
 #include <cmath>
+#include <cstdlib>
 
 #include "rh_common.h"
 
@@ -50,6 +51,75 @@ __global__ __launch_bounds__(kBlock) void k_biquad_seq(float *__restrict__ dst, 
         st[1] = x2;
         st[2] = y1;
         st[3] = y2;
+    }
+}
+
+// The same recurrence with the memory side done properly: one lane per STREAM (its C channels are C independent chains,
+// which fills the pipeline between the dependent steps), 16-byte loads and stores of 16 samples at a time, the next 16
+// samples requested before the current ones are worked on.  k_biquad_seq above fetched 4 bytes per lane and used them at
+// once -- a full memory round trip per sample: 1 236 ms for 64 x 1 Mi stereo frames.  The arithmetic (operation order of
+// blt.rs:559, no contraction) and hence every output bit is unchanged; what bounds it now is the dependent chain itself
+// (3 operations deep per sample), which only more streams can fill.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <int C>
+__global__ __launch_bounds__(kBlock) void k_biquad_vec(float *__restrict__ dst, const float *__restrict__ src, uint64_t frames, uint32_t n_streams, Biquad5 k, float *__restrict__ state) {
+    static_assert(16 % C == 0, "a block of 16 samples is whole frames");
+    const uint32_t stream = blockIdx.x * kBlock + threadIdx.x;
+    if (stream >= n_streams) return;
+    const uint64_t total = frames * C;
+    const float *x = src + (uint64_t)stream * total;
+    float *y = dst + (uint64_t)stream * total;
+    float x1[C], x2[C], y1[C], y2[C];
+    float *st = state ? state + (uint64_t)stream * C * 4 : nullptr;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        x1[c] = st ? st[4 * c] : 0.f;
+        x2[c] = st ? st[4 * c + 1] : 0.f;
+        y1[c] = st ? st[4 * c + 2] : 0.f;
+        y2[c] = st ? st[4 * c + 3] : 0.f;
+    }
+    auto step = [&](float xn, int c) {
+        const float r = k.b0 * xn + k.b1 * x1[c] + k.b2 * x2[c] - k.a1 * y1[c] - k.a2 * y2[c];  // blt.rs:559, left to right
+        y2[c] = y1[c];
+        x2[c] = x1[c];
+        y1[c] = r;
+        x1[c] = xn;
+        return r;
+    };
+    const uint64_t blocks = total / 16;
+    const v4f_t *xv = reinterpret_cast<const v4f_t *>(x);
+    v4f_t *yv = reinterpret_cast<v4f_t *>(y);
+    v4f_t cur[4], nxt[4];
+    if (blocks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = __builtin_nontemporal_load(xv + j);
+    }
+    for (uint64_t b = 0; b < blocks; ++b) {
+        if (b + 1 < blocks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = __builtin_nontemporal_load(xv + (b + 1) * 4 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v4f_t o;
+            o.x = step(cur[j].x, (4 * j + 0) % C);
+            o.y = step(cur[j].y, (4 * j + 1) % C);
+            o.z = step(cur[j].z, (4 * j + 2) % C);
+            o.w = step(cur[j].w, (4 * j + 3) % C);
+            yv[b * 4 + j] = o;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    for (uint64_t i = blocks * 16; i < total; ++i) y[i] = step(x[i], (int)(i % C));
+    if (st) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            st[4 * c] = x1[c];
+            st[4 * c + 1] = x2[c];
+            st[4 * c + 2] = y1[c];
+            st[4 * c + 3] = y2[c];
+        }
     }
 }
 
@@ -166,6 +236,108 @@ __global__ __launch_bounds__(kBlock) void k_agc_seq(float *__restrict__ dst, con
     st[3] = current_gain;
 }
 
+// AGC with the memory side done properly: one lane per stream (the recurrences of agc.rs:397-504 branch on their own state
+// and the running sum `sum - old + new` must round in the reference's order, so time stays sequential), but 16 samples per
+// lane arrive with 16-byte loads one block ahead of their use, the squares that leave the RMS window are recomputed from the
+// input 8192 samples back (the same f32 product, bit for bit) instead of a read-modify-write ring, and results leave with
+// 16-byte stores.  The ring of the carried state is only read for the first 8192 samples of a block and rewritten once at
+// its end.  Same arithmetic as k_agc_seq, same bits.
+__global__ __launch_bounds__(kBlock) void k_agc_vec(float *__restrict__ dst, const float *__restrict__ src, uint64_t n_samples, uint32_t n_streams, AgcK k, float *__restrict__ state) {
+    const uint32_t stream = blockIdx.x * kBlock + threadIdx.x;
+    if (stream >= n_streams) return;
+    const float *x = src + (uint64_t)stream * n_samples;
+    float *y = dst + (uint64_t)stream * n_samples;
+    float *st = state ? state + (uint64_t)stream * kAgcStateFloats : nullptr;
+    float *ring = st ? st + 4 : nullptr;
+    float sum = 0.0f, peak_level = 0.0f, current_gain = 1.0f;
+    uint32_t index = 0;
+    if (st) {
+        sum = st[0];
+        index = __float_as_uint(st[1]) & (kRmsWindow - 1);
+        peak_level = st[2];
+        current_gain = st[3];
+    }
+    auto step = [&](float sample, float old_value) {
+        const float sample_value = fabsf(sample);
+        const float coeff = sample_value > peak_level ? 0.0f : k.release_coeff;  // agc.rs:397-407
+        peak_level = peak_level * coeff + sample_value * (1.0f - coeff);
+        const float squared = sample_value * sample_value;  // agc.rs:413-417, :152-163
+        sum = sum - old_value + squared;
+        const float rms = sqrtf(sum / (float)kRmsWindow);
+        const float rms_gain = rms > 0.0f ? k.target_level / rms : k.absolute_max_gain;
+        const float peak_gain = peak_level > 0.0f ? fminf(k.target_level / peak_level, k.absolute_max_gain) : k.absolute_max_gain;
+        const float desired_gain = fmaxf(fminf(rms_gain, peak_gain), k.floor);
+        const float attack_speed = desired_gain > current_gain ? k.attack_coeff : k.release_coeff;
+        current_gain = current_gain * attack_speed + desired_gain * (1.0f - attack_speed);
+        current_gain = current_gain < 0.1f ? 0.1f : (current_gain > k.absolute_max_gain ? k.absolute_max_gain : current_gain);
+        return sample * current_gain;
+    };
+    const uint64_t blocks = n_samples / 16;
+    const v4f_t *xv = reinterpret_cast<const v4f_t *>(x);
+    v4f_t *yv = reinterpret_cast<v4f_t *>(y);
+    // what leaves the window while sample n enters: the square of sample n - 8192 of this block, or, for the block's first
+    // 8192 samples, what the carried ring holds (zeros for a fresh AGC)
+    auto old_block = [&](uint64_t b, v4f_t (&o)[4]) {
+        if (b * 16 >= kRmsWindow) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4f_t v = xv[(b * 16 - kRmsWindow) / 4 + j];  // re-read 32 KiB behind: L2
+                o[j].x = fabsf(v.x) * fabsf(v.x);
+                o[j].y = fabsf(v.y) * fabsf(v.y);
+                o[j].z = fabsf(v.z) * fabsf(v.z);
+                o[j].w = fabsf(v.w) * fabsf(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i0 = index + (uint32_t)(b * 16) + 4 * j;
+                o[j].x = ring ? ring[(i0 + 0) & (kRmsWindow - 1)] : 0.0f;
+                o[j].y = ring ? ring[(i0 + 1) & (kRmsWindow - 1)] : 0.0f;
+                o[j].z = ring ? ring[(i0 + 2) & (kRmsWindow - 1)] : 0.0f;
+                o[j].w = ring ? ring[(i0 + 3) & (kRmsWindow - 1)] : 0.0f;
+            }
+        }
+    };
+    v4f_t cur[4], nxt[4], ocur[4], onxt[4];
+    if (blocks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = xv[j];
+        old_block(0, ocur);
+    }
+    for (uint64_t b = 0; b < blocks; ++b) {
+        if (b + 1 < blocks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = xv[(b + 1) * 4 + j];  // (read again 8192 samples later: no streaming hint)
+            old_block(b + 1, onxt);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v4f_t o;
+            o.x = step(cur[j].x, ocur[j].x);
+            o.y = step(cur[j].y, ocur[j].y);
+            o.z = step(cur[j].z, ocur[j].z);
+            o.w = step(cur[j].w, ocur[j].w);
+            yv[b * 4 + j] = o;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j], ocur[j] = onxt[j];
+    }
+    for (uint64_t i = blocks * 16; i < n_samples; ++i) {
+        float old_value;
+        if (i >= kRmsWindow) old_value = fabsf(x[i - kRmsWindow]) * fabsf(x[i - kRmsWindow]);
+        else old_value = ring ? ring[(index + (uint32_t)i) & (kRmsWindow - 1)] : 0.0f;
+        y[i] = step(x[i], old_value);
+    }
+    if (st) {  // the window the next block starts from: the squares of this block's last 8192 samples, at their ring positions
+        const uint64_t from = n_samples > kRmsWindow ? n_samples - kRmsWindow : 0;
+        for (uint64_t i = from; i < n_samples; ++i) ring[(index + (uint32_t)i) & (kRmsWindow - 1)] = fabsf(x[i]) * fabsf(x[i]);
+        st[0] = sum;
+        st[1] = __uint_as_float((index + (uint32_t)n_samples) & (kRmsWindow - 1));
+        st[2] = peak_level;
+        st[3] = current_gain;
+    }
+}
+
 // Duration::as_secs_f32 then exp(-1/(t*sr)): math.rs:110-122.  Host side, f32.
 float duration_to_coefficient(uint64_t ns, uint32_t sample_rate) {
     const uint64_t secs = ns / 1000000000ull;
@@ -237,8 +409,17 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
     if (mode == 1) return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
     if (mode != 0) return RH_ERR_INVALID;
     const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};
-    const uint32_t lanes = n_streams * channels;
-    hipLaunchKernelGGL(k_biquad_seq, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
+    // rows that start on 16-byte boundaries take the vector kernel (same arithmetic, same bits); anything else the 4-byte one
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || (frames * channels) % 4 == 0) && !getenv("RH_BIQUAD_SEQ");
+    const dim3 grid_v((n_streams + kBlock - 1) / kBlock);
+    if (aligned && channels == 1) hipLaunchKernelGGL(k_biquad_vec<1>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
+    else if (aligned && channels == 2) hipLaunchKernelGGL(k_biquad_vec<2>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
+    else if (aligned && channels == 4) hipLaunchKernelGGL(k_biquad_vec<4>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
+    else if (aligned && channels == 8) hipLaunchKernelGGL(k_biquad_vec<8>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
+    else {
+        const uint32_t lanes = n_streams * channels;
+        hipLaunchKernelGGL(k_biquad_seq, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, channels, n_streams, k, state);
+    }
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -269,6 +450,13 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
     k.absolute_max_gain = p->absolute_max_gain;
     k.floor = p->floor;
     hipStream_t s = rh::as_stream(stream);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || n_samples % 4 == 0);
+    // in place (dst == src) the window's tail could not be re-read from the input: the ring kernel then
+    if (aligned && dst != src && !getenv("RH_AGC_SEQ")) {
+        hipLaunchKernelGGL(k_agc_vec, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, state);
+        RH_CHECK_LAUNCH();
+        return RH_OK;
+    }
     float *st = state;
     if (!st) RH_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&st), sizeof(float) * kAgcStateFloats * n_streams, s));
     hipLaunchKernelGGL(k_agc_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, st, state ? 0 : 1);

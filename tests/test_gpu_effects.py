@@ -1,0 +1,122 @@
+"""The reference-order recurrences in their batched, vector-I/O form (rh_recurrence.hip: k_biquad_vec, k_agc_vec): many
+streams per launch and state carried across blocks, through the Python mirror (`n_streams > 1` was never
+called).  Biquad mode 0 is bit-exact (blt.rs:559 in the reference's order); the AGC is <= 1e-5 (device sqrt / divide)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G(rh):
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    rh.init(0)
+    return rh
+
+
+def rnd(seed, n, scale=1.0):
+    return (np.random.default_rng(seed).uniform(-1, 1, n) * scale).astype(np.float32)
+
+
+def _programme(seed, n):
+    """level changes by 20 dB every few thousand samples: the AGC's attack/release branches and the peak follower all move"""
+    rng = np.random.default_rng(seed)
+    env = np.repeat(10.0 ** (rng.uniform(-1.5, 0.0, n // 3000 + 1)), 3000)[:n]
+    return (rng.uniform(-1, 1, n) * env).astype(np.float32)
+
+
+@pytest.mark.parametrize("ch,S,frames", [(2, 7, 30000), (1, 70, 4099), (2, 64, 8192), (4, 5, 12000), (8, 3, 5000), (3, 4, 1001), (2, 3, 17)])
+def test_biquad_mode0_batch_bit_exact(G, O, ch, S, frames):
+    import torch
+
+    xs = [rnd(10 + s, frames * ch, 0.7) for s in range(S)]
+    co = G.biquad_coeffs("low_pass", 300, 0.5, 48000)
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    out = torch.empty_like(x)
+    from rodio_amd import _lib
+    import ctypes as C
+
+    _lib.check(_lib.lib.rh_biquad(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), frames, ch, S, co.ctypes.data_as(_lib.f32p), None, 0,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rh_biquad")
+    got = out.cpu().numpy()
+    for s in range(S):
+        ref = O.TestSource(xs[s], ch, 48000).low_pass(300).collect()
+        assert np.array_equal(got[s], ref), (s, float(np.max(np.abs(got[s] - ref))))
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4])
+def test_biquad_mode0_state_across_blocks_bit_exact(G, O, ch):
+    import ctypes as C
+
+    import torch
+
+    from rodio_amd import _lib
+
+    S, frames = 3, 20000
+    xs = [rnd(30 + s, frames * ch) for s in range(S)]
+    co = G.biquad_coeffs("high_pass", 120, 0.5, 44100)
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    state = torch.zeros((S, 4 * ch), device="cuda")
+    rng = np.random.default_rng(1)
+    outs, a = [], 0
+    while a < frames:
+        b = min(frames, a + int(rng.choice([1, 5, 16, 333, 4096])))
+        blk = x[:, a * ch: b * ch].contiguous()
+        o = torch.empty_like(blk)
+        _lib.check(_lib.lib.rh_biquad(C.c_void_p(o.data_ptr()), C.c_void_p(blk.data_ptr()), b - a, ch, S, co.ctypes.data_as(_lib.f32p), C.c_void_p(state.data_ptr()), 0,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rh_biquad")
+        outs.append(o)
+        a = b
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    for s in range(S):
+        assert np.array_equal(got[s], O.TestSource(xs[s], ch, 44100).high_pass(120).collect())
+
+
+@pytest.mark.parametrize("S,n", [(5, 60000), (70, 20000), (3, 8192 + 16), (2, 100), (4, 8191), (1, 30011)])
+def test_agc_many_streams_one_launch(G, O, S, n):
+    import torch
+
+    xs = [_programme(50 + s, n) for s in range(S)]
+    out = G.agc_batch(torch.from_numpy(np.stack(xs)).cuda(), 48000).cpu().numpy()
+    for s in range(S):
+        ref = O.TestSource(xs[s], 1, 48000).automatic_gain_control().collect()
+        assert float(np.max(np.abs(out[s] - ref))) <= TOL, s
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2)])
+def test_agc_state_carried_across_blocks_equals_one_pass(G, O, kw):
+    import torch
+
+    S, n = 3, 70000
+    xs = [_programme(80 + s, n) for s in range(S)]
+    refs = [O.TestSource(x, 2, 48000).automatic_gain_control(**kw).collect() for x in xs]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    state = G.agc_state(S)
+    rng = np.random.default_rng(3)
+    outs, a = [], 0
+    while a < n:
+        b = min(n, a + int(rng.choice([4, 64, 1000, 8192, 9000, 20000])))  # below, at and above the 8192-sample RMS window
+        outs.append(G.agc_batch(x[:, a:b].contiguous(), 48000, state=state, **kw))
+        a = b
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    for s in range(S):
+        assert float(np.max(np.abs(got[s] - refs[s]))) <= TOL, s
+
+
+def test_agc_vector_kernel_equals_ring_kernel(G, O):
+    import torch
+
+    xs = [_programme(95 + s, 40000) for s in range(4)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    a = G.agc_batch(x, 48000).cpu().numpy()
+    os.environ["RH_AGC_SEQ"] = "1"
+    try:
+        b = G.agc_batch(x, 48000).cpu().numpy()
+    finally:
+        del os.environ["RH_AGC_SEQ"]
+    assert np.array_equal(a, b)  # the same f32 operations in the same order
