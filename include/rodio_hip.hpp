@@ -187,6 +187,7 @@ public:
         while (pos_ == cur().n) {
             if (!advance()) return std::nullopt;
         }
+        ++handed_out_;
         return cur().out.get()[pos_++];
     }
     std::size_t read(float *dst, std::size_t n) override {
@@ -198,6 +199,7 @@ public:
             pos_ += take;
             k += take;
         }
+        handed_out_ += k;
         return k;
     }
 
@@ -216,12 +218,36 @@ protected:
     virtual void block_done() {}
     rh_stream stream_ = nullptr;
 
-private:
+    // What a subclass needs to patch blocks that are already scheduled (GpuMixer: a source that joins a running mixer at
+    // the next frame, mixer.rs:175-183): the block being served, the one in flight behind it, the read position.
     Slot &cur() { return slot_[cur_]; }
+    Slot &other() { return slot_[cur_ ^ 1]; }
+    int slot_index(const Slot &s) const { return &s == &slot_[0] ? 0 : 1; }
+    int cur_index() const { return cur_; }
+    bool running() const { return primed_ && !ended_; }
+    bool other_in_flight() const { return primed_ && !ended_ && !slot_[cur_].last; }
+    std::size_t position() const { return pos_; }
     void submit(Slot &s) {
         enqueue(s);
         check(rh_event_record(s.done, stream_), "rh_event_record");
     }
+    /// Forget everything that was pulled and processed ahead (after a seek of the upstream): the next next() starts over.
+    /// `keep_phase` = the source's channel count: the stream that follows resumes at the channel the consumer is at (the first
+    /// handed_out % channels samples of the new position are skipped), as rodio's seekable sources do (buffer.rs:110-120) --
+    /// a consumer in the middle of a frame must not see left and right swap.
+    void restart(std::size_t keep_phase = 0) {
+        skip_ = keep_phase ? (std::size_t)(handed_out_ % keep_phase) : 0;
+        check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
+        for (Slot &s : slot_) {
+            s.n = 0;
+            s.last = false;
+        }
+        cur_ = 0;
+        pos_ = 0;
+        primed_ = ended_ = false;
+    }
+
+private:
     bool advance() {
         if (ended_) {
             if (!can_resume()) return false;
@@ -240,13 +266,15 @@ private:
         }
         check(rh_event_synchronize(cur().done), "rh_event_synchronize");
         block_done();
-        pos_ = 0;
+        pos_ = std::min(skip_, cur().n);
+        skip_ = 0;
         if (!cur().last) submit(slot_[cur_ ^ 1]);  // prefetch: pull and process one block ahead
         return true;
     }
     Slot slot_[2];
     int cur_ = 0;
-    std::size_t pos_ = 0;
+    std::size_t pos_ = 0, skip_ = 0;
+    std::uint64_t handed_out_ = 0;
     bool primed_ = false, ended_ = false;
 };
 }  // namespace detail
@@ -269,6 +297,20 @@ public:
     std::uint32_t sample_rate() const override { return rate_; }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
+    /// `try_seek` through the chain, adapter by adapter as rodio does it: an adapter that cannot seek (reverb = Mix,
+    /// mix.rs:116-120) fails the call before anything moved; otherwise the upstream seeks, what was pulled and processed
+    /// ahead is dropped, and every adapter does to its state what its `try_seek` does -- filters and the limiter start
+    /// from zero (blt.rs:350-377, limit.rs:1139-1158), a gain ramp continues from `pos` (linear_ramp.rs:141-146), the AGC
+    /// and the sample-rate converter keep theirs (agc.rs:593-597, uniform.rs:136-144).
+    bool try_seek(Nanos pos) override {
+        for (const Stage &st : stages_)
+            if (!st.seekable) return false;
+        if (!up_->try_seek(pos)) return false;
+        restart(ch_);
+        for (Stage &st : stages_)
+            if (st.on_seek) st.on_seek(pos);
+        return true;
+    }
 
     // -- builder methods (source/mod.rs:255-731); call before the first next()
     GpuSource &amplify(float factor) {  // amplify.rs:64
@@ -305,7 +347,8 @@ public:
                 if (d) check(rh_echo_flush(h->p, c.out + c.n, c.stream), "rh_echo_flush");  // the delayed clone outlives the source
                 return c.n + (std::size_t)d;
             },
-            [d](std::size_t n) { return n + (std::size_t)d; });
+            [d](std::size_t n) { return n + (std::size_t)d; })
+            .not_seekable();
     }
     GpuSource &channel_volume(std::vector<float> gains) {  // channel_volume.rs:71-88
         const std::uint16_t in_ch = ch_;
@@ -360,10 +403,11 @@ public:
         const std::uint16_t ch = ch_;
         const std::uint32_t rate = rate_;
         auto st = state(2u * ch);
+        const rh_stream sm = stream_;
         return push([=](Ctx &c) {
             check(rh_limit(c.out, c.in, c.n / ch, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
             return c.n / ch * ch;
-        });
+        }).on_seek([st, ch, sm](Nanos) { check(rh_memset(st->get(), 0, 2u * ch * sizeof(float), sm), "rh_memset"); });  // limit.rs:1139-1158
     }
     GpuSource &automatic_gain_control(const rh_agc_params &settings) {  // agc.rs:133-171,397-504
         const std::uint32_t rate = rate_;
@@ -382,6 +426,9 @@ public:
             check(rh_linear_gain_ramp(c.out, c.in, c.n, *pos, ch, rate, (std::uint64_t)duration.count(), start_gain, end_gain, clamp_end ? 1 : 0, c.stream), "rh_linear_gain_ramp");
             *pos += c.n;
             return c.n;
+        }).on_seek([pos, ch, rate](Nanos p) {  // linear_ramp.rs:141-146: elapsed = pos
+            const std::uint64_t ns = (std::uint64_t)p.count();  // frames = floor(ns * rate / 1e9) without leaving 64 bits
+            *pos = (ns / 1000000000ull * rate + ns % 1000000000ull * rate / 1000000000ull) * ch;
         });
     }
     GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13
@@ -425,6 +472,8 @@ private:
     struct Stage {
         std::function<std::size_t(Ctx &)> run;
         std::function<std::size_t(std::size_t)> bound;
+        bool seekable = true;                        // false: the adapter answers SeekError::NotSupported (mix.rs:116-120)
+        std::function<void(Nanos)> on_seek = nullptr;  // what the adapter does to its own state after its input was sought
     };
     template <class T>
     struct Handle {
@@ -436,12 +485,20 @@ private:
     };
     template <class F>
     GpuSource &push(F run) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr});
         return *this;
     }
     template <class F, class B>
     GpuSource &push(F run, B bound) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound)});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr});
+        return *this;
+    }
+    GpuSource &on_seek(std::function<void(Nanos)> f) {  // for the stage pushed last
+        stages_.back().on_seek = std::move(f);
+        return *this;
+    }
+    GpuSource &not_seekable() {
+        stages_.back().seekable = false;
         return *this;
     }
     std::shared_ptr<detail::DeviceBuf> state(std::size_t floats) {
@@ -464,7 +521,7 @@ private:
             }
             check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), 0, c.stream), "rh_biquad");
             return rem && c.flush ? c.n : frames * ch;
-        });
+        }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); });  // blt.rs:350-377
     }
     std::uint16_t in_ch() const { return in_ch_ ? in_ch_ : (in_ch_ = up_->channels()); }
     std::uint32_t in_rate() const { return in_rate_ ? in_rate_ : (in_rate_ = up_->sample_rate()); }
@@ -489,10 +546,11 @@ private:
 /// layouts go through GpuSource::uniform first).
 ///
 /// add() may be called at any time (Mixer::add, mixer.rs:58-66).  Sources added before the first next() start
-/// with the stream.  Sources added later start at the next block that is pulled (mixer.rs:120-136 admits them at
-/// the next frame; here the blocks already in flight -- at most two -- play out first): they form a new
-/// *generation* with its own clock and its own fused stream, and the generations' mixes are summed in insertion
-/// order by rh_mix_sum.  An empty mixer is an ended stream (there is nothing to pull).
+/// with the stream.  Sources added later start at the next FRAME of the output, as mixer.rs:175-183 admits them
+/// (late_join: the blocks already mixed beyond that frame -- at most two -- are patched on the device): they form
+/// a new *generation* with its own clock and its own fused stream, and the generations' mixes are summed in
+/// insertion order by rh_mix_sum.  An empty mixer is an ended stream (there is nothing to pull); it resumes after
+/// a later add() at the channel position MixerSource would be at.
 class GpuMixer : public detail::BlockPump {
 public:
     struct Options {
@@ -527,7 +585,22 @@ public:
             if (steep) conv->convert_sample_rate(rate_);
             src = std::move(conv);
         }
-        pending_.push_back(Src{std::move(src), gain, {}, false});
+        if (running()) late_join(Src{std::move(src), gain, {}, false});  // mixer.rs:175-183: admitted at the next frame
+        else pending_.push_back(Src{std::move(src), gain, {}, false});    // starts with the stream (or resumes an ended one)
+    }
+    // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136),
+    // and admits pending sources only at channel 0: an ended mixer that gets a new source after an odd number of calls
+    // returns one more None before the source's first sample.  `calls_` is that position.
+    std::optional<float> next() override {
+        resume_ok_ = (calls_ % 2) == 0;
+        ++calls_;
+        return detail::BlockPump::next();
+    }
+    std::size_t read(float *dst, std::size_t n) override {
+        resume_ok_ = (calls_ % 2) == 0;  // blocks hold whole frames: the position only matters where the stream had ended
+        const std::size_t k = detail::BlockPump::read(dst, n);
+        calls_ += k + (k < n ? 1 : 0);
+        return k;
     }
     std::uint16_t channels() const override { return 2; }
     std::uint32_t sample_rate() const override { return rate_; }
@@ -535,7 +608,7 @@ public:
     std::uint64_t last_join_frame() const { return last_join_; }
 
 protected:
-    bool can_resume() const override { return !pending_.empty(); }  // mixer.rs:117-136: None while empty, samples again after add()
+    bool can_resume() const override { return !pending_.empty() && resume_ok_; }  // mixer.rs:117-136: None while empty, samples again after add()
     void block_done() override {  // a bounded wait inside the fused kernel expired (never seen on a healthy device): fail loudly
         for (auto &g : gens_)
             if (g->plan) check(rh_rlm_last_status(g->plan), "rh_rlm_last_status");
@@ -545,6 +618,8 @@ protected:
         if (gens_.empty()) {  // nothing to pull
             s.n = 0;
             s.last = true;
+            slot_base_[slot_index(s)] = scheduled_;
+            slot_frames_[slot_index(s)] = 0;
             return;
         }
         s.out.reset(out_cap_frames_ * 2 * 2);
@@ -581,7 +656,12 @@ protected:
                 mixed = dmix_.get();
             }
             check(rh_memcpy_d2h_async(s.out.get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            // the block also stays on the device until it has been served: a source that joins in the middle of it is added there
+            dkeep_[slot_index(s)].reset(out_cap_frames_ * 2 * 2);
+            check(rh_memcpy_d2d(dkeep_[slot_index(s)].get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
         }
+        slot_base_[slot_index(s)] = scheduled_;
+        slot_frames_[slot_index(s)] = n;
         // 4. what a generation produced beyond n waits at the front of its (other) queue buffer
         for (auto &gp : gens_) {
             Gen &g = *gp;
@@ -735,6 +815,60 @@ private:
         g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }
 
+    /// Mixer::add on a running mixer.  rodio admits the source at the next frame boundary of the output (mixer.rs:175-183).
+    /// Here up to two blocks are already mixed beyond that frame (the one being served, the one in flight), so the new
+    /// source -- its own generation, its own fused stream and clock from frame J on -- is run ahead synchronously until it
+    /// covers them, added onto their device copies at its offset (rh_mix_sum: old mix first, the newcomer last = insertion
+    /// order, bit for bit without a filter) and the blocks travel to the host again.  From the next block on it is one more
+    /// generation.
+    void late_join(Src item) {
+        const int ci = cur_index();
+        const std::uint64_t consumed = slot_base_[ci] * 2 + position();  // samples already handed out
+        const std::uint64_t J = (consumed + 1) / 2;                        // the next frame boundary
+        const bool flight = other_in_flight();
+        const int li = flight ? ci ^ 1 : ci;                               // the last block that is scheduled
+        const std::uint64_t sched_end = slot_base_[li] + slot_frames_[li];
+        check(rh_stream_synchronize(stream_), "rh_stream_synchronize");   // the blocks about to be patched have been produced
+        std::vector<Src> one;
+        one.push_back(std::move(item));
+        start_stream(std::move(one));
+        last_join_ = J;
+        Gen &g = *gens_.back();
+        const std::uint64_t need = sched_end > J ? sched_end - J : 0;
+        while (g.fill < need && !g.done) {
+            run_block(g, cur());
+            check(rh_stream_synchronize(stream_), "rh_stream_synchronize");  // the staging blocks alternate: never more than one copy in flight here
+        }
+        for (int k = 0; k < (flight ? 2 : 1); ++k) {
+            const int si = k == 0 ? ci : ci ^ 1;
+            Slot &sl = k == 0 ? cur() : other();
+            const std::uint64_t b0 = slot_base_[si], b1 = b0 + slot_frames_[si];
+            const std::uint64_t lo = std::max(J, b0), hi = std::min(b1, J + g.fill);
+            if (hi <= lo) continue;
+            const float *ptrs[2] = {dkeep_[si].get(), g.queue() + (lo - J) * 2};
+            const std::uint64_t start[2] = {0, (lo - b0) * 2}, len[2] = {slot_frames_[si] * 2, (hi - lo) * 2};
+            dmix_.reset(out_cap_frames_ * 2 * 2);
+            check(rh_mix_sum(dmix_.get(), slot_frames_[si] * 2, ptrs, start, len, 2, stream_), "rh_mix_sum");
+            check(rh_memcpy_d2d(dkeep_[si].get(), dmix_.get(), slot_frames_[si] * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            check(rh_memcpy_d2h_async(sl.out.get(), dkeep_[si].get(), slot_frames_[si] * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+        }
+        {  // the newcomer's queue moves on to the frame the next block starts at
+            const std::uint64_t used = std::min(g.fill, need), rem = g.fill - used, pad = rem & 1;
+            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * 2, g.queue() + used * 2, rem * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            g.cur ^= 1;
+            g.head = pad;
+            g.fill = rem;
+        }
+        check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
+        block_done();
+        // a mixer that was about to end goes on: the block that carried the end mark loses it, and if nothing was in flight the
+        // next block is requested now
+        Slot &last_slot = flight ? other() : cur();
+        if (last_slot.last && !(g.done && g.fill == 0)) {
+            last_slot.last = false;
+            if (!flight) submit(other());
+        }
+    }
     static bool debug_poison() {  // RODIO_HIP_DEBUG_POISON=1: every buffer a block passes through is filled with NaN patterns first
         static const bool on = std::getenv("RODIO_HIP_DEBUG_POISON") != nullptr;
         return on;
@@ -745,7 +879,10 @@ private:
     std::vector<std::unique_ptr<Gen>> gens_;
     std::size_t cap_frames_ = 0, row_ = 0;
     std::uint64_t out_cap_frames_ = 0, scheduled_ = 0, last_join_ = 0;
-    detail::DeviceBuf dmix_;
+    detail::DeviceBuf dmix_, dkeep_[2];                       // scratch of rh_mix_sum; device copies of the two scheduled blocks
+    std::uint64_t slot_base_[2] = {0, 0}, slot_frames_[2] = {0, 0};  // mixer frame of a scheduled block's first frame; its length
+    std::uint64_t calls_ = 0;                                 // next() calls so far (MixerSource's channel position, mod 2)
+    bool resume_ok_ = true;
 };
 
 }  // namespace rodio_hip

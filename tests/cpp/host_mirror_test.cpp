@@ -196,8 +196,19 @@ int main(int argc, char **argv) {
                 out.push_back(*v);
             }
             for (int i = S0; i < S0 + S1; ++i) add(i);
+            // a consumer keeps calling next() after a None (the cpal callback plays silence): an ended mixer that was given a
+            // new source answers None until MixerSource's channel position is back at 0 (mixer.rs:120-136)
+            int nones = 0;
+            std::optional<float> v;
+            while (nones < 4 && !(v = mixer.next())) ++nones;
+            if (v) out.push_back(*v);
             const std::vector<float> rest = drain(mixer);
             out.insert(out.end(), rest.begin(), rest.end());
+            std::FILE *nf = std::fopen((dir + "/nones.txt").c_str(), "w");
+            if (nf) {
+                std::fprintf(nf, "%d\n", nones);
+                std::fclose(nf);
+            }
             std::FILE *jf = std::fopen((dir + "/join.txt").c_str(), "w");
             if (jf) {
                 std::fprintf(jf, "%llu\n", (unsigned long long)mixer.last_join_frame());
@@ -250,7 +261,25 @@ int main(int argc, char **argv) {
                 std::fprintf(meta, "%u %u\n", (unsigned)g.channels(), (unsigned)g.sample_rate());
                 std::fclose(meta);
             }
-            out = drain(g);
+            if (const char *after = std::getenv("RH_TEST_SEEK_AFTER")) {  // pull, try_seek, pull on (test_gpu_source_try_seek)
+                const size_t k = (size_t)std::atoll(after);
+                for (size_t i = 0; i < k; ++i) {
+                    const std::optional<float> v = g.next();
+                    if (!v) break;
+                    out.push_back(*v);
+                }
+                const char *ns = std::getenv("RH_TEST_SEEK_NS");
+                const bool ok = g.try_seek(rh::Nanos(ns ? std::atoll(ns) : 0));
+                std::FILE *sk = std::fopen((dir + "/seek.txt").c_str(), "w");
+                if (sk) {
+                    std::fprintf(sk, "%d %zu\n", ok ? 1 : 0, out.size());
+                    std::fclose(sk);
+                }
+            }
+            {
+                const std::vector<float> rest = drain(g);
+                out.insert(out.end(), rest.begin(), rest.end());
+            }
         } else {
             std::fprintf(stderr, "bad arguments\n");
             return 2;

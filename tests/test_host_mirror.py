@@ -142,10 +142,12 @@ def test_gpu_mixer_takes_any_source_layout(O, tmp_path, filt, freq):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
-@pytest.mark.parametrize("pull_first", [10, 30001, 200000])
+@pytest.mark.parametrize("pull_first", [0, 10, 11, 8704 * 2, 8704 * 2 + 1, 30001, 65307 * 2 - 3, 200000])
 def test_gpu_mixer_add_on_a_running_mixer(O, tmp_path, filt, freq, pull_first):
-    # Mixer::add while the mixer is being pulled: the new sources start at a later output frame (reported by the shim;
-    # rodio admits them at the next frame, the shim after the blocks already in flight) and run on their own clock
+    """Mixer::add while the mixer is being pulled.  rodio admits the new sources at the NEXT FRAME of the output
+    (mixer.rs:175-183), whatever the consumer's position: inside a block, on a block boundary, just before the old
+    sources end, after the mixer has run empty.  The reference is the oracle's MixerSource driven the same way:
+    add, pull `pull_first` samples, add, pull on."""
     ns = [60000, 45000, 30011, 52000, 20000]
     S0, S1 = 3, 2
     gains = np.array([1.0, 0.5, 0.8, 1.1, 0.6], dtype=np.float32)
@@ -155,24 +157,38 @@ def test_gpu_mixer_add_on_a_running_mixer(O, tmp_path, filt, freq, pull_first):
     gains.tofile(tmp_path / "gains.f32")
     got = _run(["late", tmp_path, S0, S1, 44100, 48000, filt, freq, 8192, 4, pull_first], tmp_path)
     join = int((tmp_path / "join.txt").read_text())
+    nones = int((tmp_path / "nones.txt").read_text())
 
-    def mix(idx):
-        m = O.Mixer(2, 48000)
-        for i in idx:
-            u = O.UniformSourceIterator(O.TestSource(xs[i], 2, 44100).amplify(float(gains[i])), 2, 48000)
-            m.add(u.low_pass(freq) if filt == 0 else u)
-        return m.collect()
+    def src(i):
+        u = O.UniformSourceIterator(O.TestSource(xs[i], 2, 44100).amplify(float(gains[i])), 2, 48000)
+        return u.low_pass(freq) if filt == 0 else u
 
-    a, b = mix(range(S0)), mix(range(S0, S0 + S1))
-    if pull_first >= len(a):  # the mixer had run empty (None) before the new sources arrived: it resumes where it stopped
-        assert join * 2 == len(a)
-    ref = np.zeros(max(len(a), join * 2 + len(b)), dtype=np.float32)
-    ref[: len(a)] = a
-    ref[join * 2: join * 2 + len(b)] += b  # generations are summed as groups, in insertion order
-    assert join * 2 >= pull_first - 1 or pull_first > len(a)
+    m = O.Mixer(2, 48000)
+    for i in range(S0):
+        m.add(src(i))
+    ref = []
+    for _ in range(pull_first):  # the driver's first loop: stops at the first None
+        v = m.next()
+        if v is None:
+            break
+        ref.append(v)
+    first_len = len(ref)
+    for i in range(S0, S0 + S1):
+        m.add(src(i))
+    ref_nones = 0
+    while ref_nones < 4:
+        v = m.next()
+        if v is not None:
+            ref.append(v)
+            break
+        ref_nones += 1
+    ref = np.concatenate([np.asarray(ref, dtype=np.float32), m.collect()])
+    assert nones == ref_nones
+    if first_len == pull_first:  # the mixer was running: the newcomers start at the next frame boundary
+        assert join == (pull_first + 1) // 2
     assert len(got) == len(ref), (len(got), len(ref), join)
     if filt < 0:
-        assert np.array_equal(got, ref)
+        assert np.array_equal(got, ref), (join, int(np.argmax(got != ref)))
     else:
         assert float(np.max(np.abs(got - ref))) <= TOL
 
@@ -212,3 +228,38 @@ def test_gpu_source_chain_pull_is_bit_exact(O, tmp_path, case, block):
         assert float(np.max(np.abs(got - ref))) <= TOL
     else:
         assert np.array_equal(got, ref, equal_nan=True), (ops, float(np.nanmax(np.abs(got - ref))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", [777, 16384])
+def test_gpu_source_try_seek(O, tmp_path, block):
+    """try_seek through an adapter chain (source/mod.rs:754-758): the upstream SamplesBuffer jumps (buffer.rs:99-121), what the
+    shim had pulled and processed ahead is dropped, filters and the limiter restart from a zero state (blt.rs:350-377,
+    limit.rs:1139-1158) -- so what follows the seek is the chain applied afresh to the rest of the buffer; a chain with reverb
+    in it refuses (mix.rs:116-120) and plays on untouched."""
+    ch, rate, n = 2, 48000, 40000
+    x = rnd(777, ch * n, 0.9)
+    x.tofile(tmp_path / "src_0.f32")
+    pulled, seek_frame = 9001, 12000
+    env = dict(os.environ, RH_TEST_SEEK_AFTER=str(pulled), RH_TEST_SEEK_NS=str(seek_frame * 1_000_000_000 // rate))
+
+    def run(ops):
+        r = subprocess.run([EXE, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        ok, k = (tmp_path / "seek.txt").read_text().split()
+        return np.fromfile(tmp_path / "out.f32", dtype=np.float32), int(ok), int(k)
+
+    got, ok, k = run(["amplify:0.8", "low_pass:200", "distortion:2.0:0.7", "limit"])
+    assert ok == 1 and k == pulled
+    before = O.TestSource(x, ch, rate).amplify(0.8).low_pass(200).distortion(2.0, 0.7).limit().collect()[:pulled]
+    # the consumer is in the middle of a frame (9001 samples handed out): what follows resumes at ITS channel, the right one
+    # (rodio keeps the channel position through a seek, buffer.rs:110-120; the shim's upstream sits on a frame boundary, so it
+    # skips the frame's first sample where rodio's iterator would step one sample back)
+    after = O.TestSource(x[seek_frame * ch:], ch, rate).amplify(0.8).low_pass(200).distortion(2.0, 0.7).limit().collect()[pulled % ch:]
+    ref = np.concatenate([before, after])
+    assert len(got) == len(ref), (len(got), len(ref))
+    assert float(np.max(np.abs(got - ref))) <= TOL
+    got, ok, k = run(["amplify:0.8", "reverb:20833333:0.3", "high_pass:300"])
+    assert ok == 0  # NotSupported, nothing moved: the stream is the unbroken one
+    ref = O.TestSource(x, ch, rate).amplify(0.8).reverb(20833333, 0.3).high_pass(300).collect()
+    assert np.array_equal(got, ref)
