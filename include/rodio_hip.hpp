@@ -571,7 +571,7 @@ public:
             if (g->plan) (void)rh_rlm_destroy(g->plan);
     }
     /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: what the fused kernel does not take as it
-    /// is -- a channel count other than 2, or a rate more than twice the mixer's -- first runs through the matching
+    /// is -- a channel count other than 2, or a rate more than 4.5 times the mixer's -- first runs through the matching
     /// GPU adapter (ChannelCountConverter / SampleRateConverter, uniform.rs:78-97 order), still one pull chain.
     void add(BoxSource src, float gain = 1.0f) {
         if (!src) throw std::invalid_argument("source");
@@ -707,7 +707,7 @@ private:
         const float *queue() const { return q[cur].get() + head * 2; }
         float *queue_end() { return q[cur].get() + (head + fill) * 2; }
     };
-    static bool fused_ratio_unsupported(std::uint32_t from, std::uint32_t to) {  // rh_rlm_create: reduced from/to <= 2, from*to within u32
+    static bool fused_ratio_unsupported(std::uint32_t from, std::uint32_t to) {  // rh_rlm_create: reduced from/to <= 4.5, from*to within u32
         std::uint64_t a = from, b = to;
         while (b) {
             const std::uint64_t t = a % b;
@@ -715,7 +715,7 @@ private:
             b = t;
         }
         const std::uint64_t F = from / a, T = to / a;
-        return F > 2 * T || F * T > 0xffffffffull;
+        return 2 * F > 9 * T || F * T > 0xffffffffull;
     }
     void start_generation() {  // the sources that joined together: one fused stream per input rate, in order of first appearance
         std::vector<Src> all = std::move(pending_);

@@ -36,6 +36,7 @@
 //     true start state S of a lane is added once, after the last source, from summed states.
 //   * tiles are numbered by an atomic ticket, so a tile only ever waits for tiles that already
 //     hold a wave slot: progress does not depend on dispatch order or residency.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -702,7 +703,28 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
 
     // ---- mixed output: R stereo frames per lane -----------------------------------------------------
     float *o = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m0 * 2;
-    if (R % 2 == 0) {
+    if (R % 2 == 0 && !RAG && FILT && p.batch_streams) {
+        // Batch mode writes as many bytes as it reads.  A lane's run is R*8 contiguous bytes, so a wave's float4 store hits
+        // 64 different 128-byte lines with 16 bytes each: ten partial-line writes where one full line would do.  The runs
+        // therefore go through the (now idle) LDS stage -- rows padded by 8 bytes -- and leave as whole lines: lane l stores
+        // frames 2q, 2q+1 of the tile, q = k*64 + l.
+        constexpr uint32_t kRow = R * 8 + 8;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_u8 *row = lds + (uint32_t)lane * kRow;
+#pragma unroll
+        for (int r = 0; r < R; ++r) *(lds_f2 *)(row + r * 8) = acc[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float *ot = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m_tile0 * 2;
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            const uint32_t f = 2u * (k * 64u + (uint32_t)lane);
+            const lds_u8 *src2 = lds + (f / R) * kRow + (f % R) * 8u;
+            const v2f a = *(const lds_f2 *)src2, b = *(const lds_f2 *)(src2 + 8);
+            const uint32_t m = m_tile0 + f;
+            if (m + 1 < Mout) *reinterpret_cast<float4 *>(ot + f * 2) = make_float4(a.x, a.y, b.x, b.y);
+            else if (m < Mout) *reinterpret_cast<float2 *>(ot + f * 2) = make_float2(a.x, a.y);
+        }
+    } else if (R % 2 == 0) {
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
             const uint32_t m = m0 + r;
@@ -1606,15 +1628,15 @@ struct Variant {
 #define RH_WAVE(r, kv, ns) Variant{r, kv, ns, &k_rlm_wave<r, kv, ns, true>, &k_rlm_wave<r, kv, ns, false>}
 // KV KiB of LDS per stage must hold the input span of 64*R output frames: ~R/2 vectors per lane
 // when upsampling (from <= to), up to R+1 for from <= 2*to.  The host picks the smallest KV that fits.
-// Per R: the stage sizes for from/to <= ~0.93 (44.1->48 k), <= 1 and <= 2.
+// Per R: the stage sizes for from/to <= ~0.93 (44.1->48 k), <= 1 and <= 2; R = 3, 4, 6 also for from/to <= 4.5 (192 -> 44.1 k).
 const Variant kFast[] = {
 #ifdef RH_DEV_VARIANTS  // quick development builds
     RH_FAST(4, 2, 2), RH_FAST(4, 2, 3), RH_FAST(5, 3, 2), RH_FAST(6, 3, 2), RH_FAST(6, 3, 3), RH_FAST(8, 4, 2), RH_FAST(8, 4, 3), RH_FAST(9, 5, 2), RH_FAST(9, 5, 3), RH_FAST(12, 6, 3),
 #else
-    RH_FAST(3, 2, 2),   RH_FAST(3, 2, 3),   RH_FAST(3, 4, 2),
-    RH_FAST(4, 2, 2),   RH_FAST(4, 2, 3),   RH_FAST(4, 3, 2),  RH_FAST(4, 3, 3),  RH_FAST(4, 5, 2),
+    RH_FAST(3, 2, 2),   RH_FAST(3, 2, 3),   RH_FAST(3, 4, 2),  RH_FAST(3, 7, 2),
+    RH_FAST(4, 2, 2),   RH_FAST(4, 2, 3),   RH_FAST(4, 3, 2),  RH_FAST(4, 3, 3),  RH_FAST(4, 5, 2),  RH_FAST(4, 9, 2),
     RH_FAST(5, 3, 2),   RH_FAST(5, 3, 3),   RH_FAST(5, 6, 2),
-    RH_FAST(6, 3, 2),   RH_FAST(6, 3, 3),   RH_FAST(6, 4, 2),  RH_FAST(6, 4, 3),  RH_FAST(6, 7, 2),
+    RH_FAST(6, 3, 2),   RH_FAST(6, 3, 3),   RH_FAST(6, 4, 2),  RH_FAST(6, 4, 3),  RH_FAST(6, 7, 2),  RH_FAST(6, 14, 2),
     RH_FAST(7, 4, 2),   RH_FAST(7, 4, 3),   RH_FAST(7, 8, 2),
     RH_FAST(8, 4, 2),   RH_FAST(8, 4, 3),   RH_FAST(8, 4, 4),  RH_FAST(8, 5, 2),  RH_FAST(8, 5, 3),  RH_FAST(8, 9, 2),
     RH_FAST(9, 5, 2),   RH_FAST(9, 5, 3),   RH_FAST(9, 10, 2),
@@ -1628,14 +1650,14 @@ const Variant kFast[] = {
 };
 // The general kernel (ragged batches) is heavier; it ships in two tile sizes.
 const Variant kWave[] = {
-    RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
+    RH_WAVE(6, 3, 2), RH_WAVE(6, 4, 2), RH_WAVE(6, 7, 2), RH_WAVE(6, 14, 2), RH_WAVE(8, 4, 2), RH_WAVE(8, 4, 3), RH_WAVE(8, 5, 2), RH_WAVE(8, 9, 2),
     RH_WAVE(9, 5, 2), RH_WAVE(9, 5, 3), RH_WAVE(10, 5, 2), RH_WAVE(10, 5, 3), RH_WAVE(10, 6, 2), RH_WAVE(12, 6, 2), RH_WAVE(12, 6, 3), RH_WAVE(12, 7, 2),
 };
 // k_rlm_fast<.., RAG>: the first half of a ragged filtered batch, in the tile sizes of the general kernel (both halves
 // share the tile geometry, the tables and the aggregate rows)
 #define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true>, &k_rlm_resid<r, kv>}
 const Variant kRag[] = {
-    RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
+    RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
 };
 #undef RH_RAG
@@ -1940,7 +1962,7 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     rh::ResampleGeom g;
     rh_status st = rh::make_resample_geom(cfg->max_in_frames, cfg->from_rate, cfg->to_rate, cfg->channels, cfg->span_len, &g);
     if (st != RH_OK) return st;
-    if (g.F > 2 * g.T) return RH_ERR_UNSUPPORTED;  // staging is sized for ratios <= 2 (unfused ops cover the rest)
+    if (2ull * g.F > 9ull * g.T) return RH_ERR_UNSUPPORTED;  // staging is sized for ratios <= 4.5: 192 kHz -> 44.1 kHz (the unfused ops cover the rest)
     if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
     rh_rlm *p = new rh_rlm();
     p->cfg = *cfg;
@@ -2186,7 +2208,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         return mark_launch(p, s);
     }
     // batch mode fills the chip many times over: no residency shaping, the bare LDS request
-    hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? pl.lds_bytes : p->launch_lds, s);
+    hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? std::max((uint32_t)pl.v->KV * 1024u, 64u * ((uint32_t)pl.v->R * 8u + 8u)) /* one source per tile: one stage of the ring, reused by the output transpose */ : p->launch_lds, s);
     if (e != hipSuccess) {
         rh::set_hip_error(e, "k_rlm launch");
         return RH_ERR_HIP;
@@ -2613,7 +2635,7 @@ rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t
         cfg.max_in_frames = frames;
         // one source per wave: the fixed cost per wave (tables, scan, look-back) wants the longest runs
         // (measured, 64 x 1 Mi frames: R = 8 2.5 ms, 12 1.6 ms, 16 1.2 ms, 20 0.93 ms)
-        if (frames >= 64u * kMaxR * 4u) cfg.frames_per_lane = kMaxR;
+        if (frames >= 64u * 12u * 4u) cfg.frames_per_lane = 12;  // measured, 64 x 1 Mi frames with the coalesced output path: R = 12 0.40 ms, 16 0.43, 20 0.45
         if (const char *e = getenv("RH_BIQUAD_R")) cfg.frames_per_lane = (uint32_t)atoi(e);  // tuning aid
         rh_status st = rh_rlm_create(&cache, &cfg);
         if (st != RH_OK) return st;

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 N_ONE = int(os.environ.get("RH_FUZZ_ONE", "48"))  # more seeds for a bug hunt: RH_FUZZ_ONE=1000 RH_FUZZ_STREAM=500
 N_STREAM = int(os.environ.get("RH_FUZZ_STREAM", "32"))
 TOL = 1e-5
-RATES = [(44100, 48000), (48000, 44100), (22050, 48000), (32000, 48000), (96000, 48000), (48000, 48000), (8000, 11025), (44100, 40000)]
+RATES = [(44100, 48000), (48000, 44100), (22050, 48000), (32000, 48000), (96000, 48000), (48000, 48000), (8000, 11025), (44100, 40000),
+         (192000, 48000), (192000, 44100), (176400, 48000)]  # ... and the steep ones (from/to <= 4.5)
 
 
 @pytest.fixture(scope="module")
