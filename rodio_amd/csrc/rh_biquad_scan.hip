@@ -1,0 +1,619 @@
+// rh_biquad_scan.hip -- the stand-alone BltFilter (src/source/blt.rs:397-492, :502-544, :558-560) as a TIME-PARALLEL
+// kernel for batches of streams: `rh_biquad` mode 1.
+//
+// The algebra is DESIGN.md 4.2 (the fused kernel's): H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z); the recursive part
+// w = y - b0*x is what travels along time; a lane runs w over its R frames from a ZERO state, the true start states are
+// linear in the run-end states of everything before -- powers of B = Tm A Tm^-1 (Tm: the basis in which those powers are
+// benign in f32; all tables computed on the host in f64 and rounded once) -- and the correction g[r] * (start state) is
+// added once.  What differs from the fused kernel is everything around it (this path has no mixer and as many bytes to
+// write as to read), and that follows the limiter (rh_limit.hip):
+//   * a workgroup of NW waves = one tile of LW = NW*64*R frames of ONE stream; tiles by atomic ticket, tile-major over the
+//     streams, persistent grid;
+//   * the next tile's samples arrive by LDS-DMA while the current one is worked on (plus the two frames in front of a wave's
+//     share: x[n-1], x[n-2] of its first frame); lanes read their runs from swizzled LDS slots, results go back to the same
+//     slots and leave as whole lines: 4 B in + 4 B out per sample;
+//   * wave scan (DPP Kogge-Stone over 2x2 matrices) -> the waves' aggregates meet in LDS (ONE barrier) -> workgroup aggregate
+//     published -> look-back over the J workgroup tiles in front whose weight B^(LW*j) is above 2^-40 (a stable filter forgets:
+//     no chained prefix, a tile never waits for a predecessor's result, only for its zero-state aggregate) -> correction;
+//   * any channel count the variants list, any block length, an optional carried state {x1,x2,y1,y2} per channel in the
+//     layout of mode 0 (blt.rs:404-407) -- so a stream can be filtered block by block on this path too.
+// <= 1e-5 abs against the reference-order recurrence (mode 0 stays the bit-exact path), and no further from the f64 truth.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "rh_common.h"
+
+namespace {
+
+#include "rh_scan_common.h"
+
+constexpr int kMaxR = 16, kMaxNW = 8;
+constexpr uint32_t kSpinLimit = 1u << 22;
+
+struct BqTabs {  // per lane (device memory, cached per filter and geometry): powers of B, row-major 2x2
+    float laneM[64][4];  // B^(R*l)
+    float b15[64][4];    // B^(R*((l&15)+1))
+    float b31[64][4];    // B^(R*((l&31)+1))
+    float lookM[64][4];  // B^(LW*j): weight of the j-th workgroup tile in front (j = 0: the nearest)
+};
+struct BqArgs {
+    float *dst;
+    const float *src;
+    float *gran;            // [S][tiles][2*C] hand-off words: the tiles' zero-state aggregates (scan basis)
+    const float *state_in;  // [S][C][4] {x1,x2,y1,y2} snapshot, or nullptr (zero state)
+    const BqTabs *tabs;
+    uint32_t *ctl;          // [0] ticket, [1] status
+    uint64_t frames, stride;
+    uint32_t n_streams, tiles, J;
+    float b0, c1, c2, na1, na2;
+    float Tm[4];
+    float scanM[4][4];        // B^(R*2^k)
+    float g[kMaxR][2];        // row 0 of A^(r+1) Tm^-1
+    float waveM[kMaxNW][4];   // B^(L*k)
+    float BL[4];              // B^L
+};
+
+__device__ __forceinline__ void mat_acc(const float *M, float x1, float x2, float &y1, float &y2) {
+    y1 = fma_(M[0], x1, fma_(M[1], x2, y1));
+    y2 = fma_(M[2], x1, fma_(M[3], x2, y2));
+}
+
+// Inclusive wave64 scan of 2-vectors under P_l = sum_{k<=l} B^(R*(l-k)) p_k (the fused kernel's, rh_pipeline.hip).
+__device__ __forceinline__ void scan_mat(float &P0, float &P1, const float (&sm)[4][4], const float *b15, const float *b31) {
+#define RH_STEP(K, N)                                                                          \
+    {                                                                                          \
+        const float q0 = dpp0<kRowShr + N, 0xf>(P0), q1 = dpp0<kRowShr + N, 0xf>(P1);          \
+        mat_acc(sm[K], q0, q1, P0, P1);                                                        \
+    }
+    RH_STEP(0, 1)
+    RH_STEP(1, 2)
+    RH_STEP(2, 4)
+    RH_STEP(3, 8)
+#undef RH_STEP
+    {
+        const float q0 = dpp0<kBcast15, 0xa>(P0), q1 = dpp0<kBcast15, 0xa>(P1);
+        mat_acc(b15, q0, q1, P0, P1);
+    }
+    {
+        const float q0 = dpp0<kBcast31, 0xc>(P0), q1 = dpp0<kBcast31, 0xc>(P1);
+        mat_acc(b31, q0, q1, P0, P1);
+    }
+}
+
+template <int C, int R, int NW, bool FULL>
+__device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *halo, float (*xZ)[2 * C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
+                                        const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf, v4f *next_halo, bool &dead) {
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));  // per-tile address arithmetic is recomputed, not hoisted into registers that live for the whole kernel
+    constexpr int V = C * R / 4;
+    constexpr int HV = (2 * C + 3) / 4;  // vectors that hold the two frames in front of a run
+    constexpr uint32_t L = 64u * R, LW = L * NW;
+    constexpr uint32_t G = 2 * C;
+    const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;
+    const uint32_t nfl = FULL ? (uint32_t)R : (nf > (uint32_t)lane * R ? (nf - lane * R < (uint32_t)R ? nf - lane * R : R) : 0u);
+    const float *src = a.src + stream * a.stride + f0 * C;
+    float *dst = a.dst + stream * a.stride + f0 * C;
+    const uint32_t nfloat = nf * C;
+    const float *const gstream = a.gran + (uint64_t)stream * a.tiles * G;
+    float *const rec = a.gran + ((uint64_t)stream * a.tiles + tile) * G;
+    const float *const init = a.state_in ? a.state_in + (uint64_t)stream * C * 4 : nullptr;
+
+    if (!FULL) {  // a short share (end of a stream): fetched here, guarded, into the same slots
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const uint32_t q = k * 64 + lane, o = 4u * q;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (o + 4 <= nfloat) v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + o));
+            else if (o < nfloat) {
+                v.x = src[o];
+                if (o + 1 < nfloat) v.y = src[o + 1];
+                if (o + 2 < nfloat) v.z = src[o + 2];
+            }
+            lds[slot_of<V>(q / V, q % V)] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- x[n-1], x[n-2] of the run's first frame: the previous lane's last two frames; lane 0 takes them from the halo (the
+    //      vectors in front of the share: DMA for whole shares, read here for a short one), the stream's first run from the
+    //      carried state (blt.rs:404-407: x_n1, x_n2) or zeros
+    float x1[C], x2[C];
+    {
+        float h[HV * 4];
+        if (lane > 0) {
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const v4f v = lds[slot_of<V>(lane - 1, V - HV + i)];
+                h[4 * i] = v.x, h[4 * i + 1] = v.y, h[4 * i + 2] = v.z, h[4 * i + 3] = v.w;
+            }
+        } else if (f0 > 0) {
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const v4f v = FULL ? halo[i] : *reinterpret_cast<const v4f *>(src - 4 * (HV - i));
+                h[4 * i] = v.x, h[4 * i + 1] = v.y, h[4 * i + 2] = v.z, h[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < HV * 4; ++i) h[i] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                h[HV * 4 - C + c] = init ? init[4 * c] : 0.0f;          // x[-1]
+                h[HV * 4 - 2 * C + c] = init ? init[4 * c + 1] : 0.0f;  // x[-2]
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            x1[c] = h[HV * 4 - C + c];
+            x2[c] = h[HV * 4 - 2 * C + c];
+        }
+    }
+    // ---- zero-state run: w[n] = c1 x[n-1] + c2 x[n-2] - a1 w[n-1] - a2 w[n-2]; y = b0 x + w kept per sample ----
+    float yz[R][C], w1[C], w2[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) w1[c] = w2[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const v4f v = lds[slot_of<V>(lane, j)];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
+            const float x = e[i];
+            const float w = fma_(a.na1, w1[c], fma_(a.na2, w2[c], fma_(a.c2, x2[c], a.c1 * x1[c])));
+            yz[r][c] = fma_(a.b0, x, w);
+            if (FULL || (uint32_t)r < nfl) {
+                w2[c] = w1[c];
+                w1[c] = w;
+                x2[c] = x1[c];
+                x1[c] = x;
+            }
+        }
+    }
+    // ---- run-end states in the scan basis, wave scan, the waves' aggregates through LDS ----------------------------------
+    float P[C][2], Q[C][2];
+    {
+        float b15[4], b31[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b15[q] = tab[4 + q][lane], b31[q] = tab[8 + q][lane];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            P[c][0] = P[c][1] = 0.0f;
+            mat_acc(a.Tm, w1[c], w2[c], P[c][0], P[c][1]);
+            scan_mat(P[c][0], P[c][1], a.scanM, b15, b31);
+            Q[c][0] = dpp0<kWaveShr1, 0xf>(P[c][0]);  // exclusive: lane 0 gets 0
+            Q[c][1] = dpp0<kWaveShr1, 0xf>(P[c][1]);
+            if (lane == 63) xZ[wave][2 * c] = P[c][0], xZ[wave][2 * c + 1] = P[c][1];
+        }
+    }
+    __syncthreads();  // the waves' aggregates are in LDS
+    float Wp[C][2], ZT[C][2];  // state at this wave's start from the waves in front (zero tile start); the tile's aggregate
+#pragma unroll
+    for (int c = 0; c < C; ++c) Wp[c][0] = Wp[c][1] = ZT[c][0] = ZT[c][1] = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < NW; ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (k == wave) Wp[c][0] = ZT[c][0], Wp[c][1] = ZT[c][1];
+            float n0 = xZ[k][2 * c], n1 = xZ[k][2 * c + 1];
+            mat_acc(a.BL, ZT[c][0], ZT[c][1], n0, n1);
+            ZT[c][0] = n0, ZT[c][1] = n1;
+        }
+    }
+    if (wave == 0 && lane < 2 * C) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v = lane == 2 * c ? ZT[c][0] : (lane == 2 * c + 1 ? ZT[c][1] : v);
+        word_store(rec + lane, v);
+    }
+    // the next tile's samples (and the two frames in front of its share) are requested before the poll: the two latencies overlap
+    if (next_src) {
+        dma_share<V>(next_src, next_buf, lane);
+        if (lane < HV) glds16(next_src - 4 * HV, (uint32_t)lane * 16u, (uint32_t)(uintptr_t)(lds_u8 *)next_halo);
+    }
+    // ---- look-back: T_in = sum_{j<J} B^(LW*j) ZT(t-1-j)  (+ B^(LW*t) z_state while the carried state still reaches) -------
+    float Tin[C][2];
+    {
+        const int64_t idx = (int64_t)tile - 1 - lane;
+        const bool reach = (uint32_t)lane < a.J;
+        const bool real = reach && idx >= 0;
+        float ag[2 * C];
+#pragma unroll
+        for (int c = 0; c < 2 * C; ++c) ag[c] = 0.0f;
+        if (reach && idx == -1 && init) {  // the state the block starts from: w = y - b0*x (companion) -> scan basis
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float s1 = init[4 * c + 2] - a.b0 * init[4 * c], s2 = init[4 * c + 3] - a.b0 * init[4 * c + 1];
+                mat_acc(a.Tm, s1, s2, ag[2 * c], ag[2 * c + 1]);
+            }
+        }
+        const float *pr = gstream + (real ? (uint64_t)idx : 0) * G;
+        bool have = !real;
+        uint32_t spins = 0;
+        while (true) {
+            if (!have) {
+                float gv[2 * C];
+                load_words<2 * C, (2 * C) % 4 == 0 ? 4 : 2>(pr, gv);
+                wait_loads(gv);
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 2 * C; ++c) ok = ok && word_ok(gv[c]);
+                if (ok) {
+                    have = true;
+#pragma unroll
+                    for (int c = 0; c < 2 * C; ++c) ag[c] = gv[c];
+                }
+            }
+            if (__all(have)) break;
+            if (++spins > kSpinLimit) {
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        float lk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lk[q] = tab[12 + q][lane];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float t0 = 0.0f, t1 = 0.0f, tot;
+            if (reach) mat_acc(lk, ag[2 * c], ag[2 * c + 1], t0, t1);
+            (void)wave_excl_sum(t0, tot);
+            Tin[c][0] = tot;
+            (void)wave_excl_sum(t1, tot);
+            Tin[c][1] = tot;
+        }
+        if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
+            if (lane == 0) atomicOr(a.ctl + 1, 1u);
+#pragma unroll
+            for (int c = 0; c < C; ++c) Tin[c][0] = Tin[c][1] = __builtin_nanf("");
+        }
+    }
+    // ---- the homogeneous response to the lane's true start state, the result back into the LDS slots ----------------------
+    {
+        float lM[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lM[q] = tab[q][lane];
+        const float *wM = a.waveM[wave];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float s0 = Wp[c][0], s1 = Wp[c][1];
+            mat_acc(wM, Tin[c][0], Tin[c][1], s0, s1);          // the wave's start state
+            mat_acc(lM, s0, s1, Q[c][0], Q[c][1]);              // the lane's
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        v4f v;
+        float e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
+            e[i] = fma_(a.g[r][0], Q[c][0], fma_(a.g[r][1], Q[c][1], yz[r][c]));
+        }
+        v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
+        lds[slot_of<V>(lane, j)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint32_t q = k * 64 + lane, o = 4u * q;
+        const v4f v = lds[slot_of<V>(q / V, q % V)];
+        if (FULL || o + 4 <= nfloat) *reinterpret_cast<v4f *>(dst + o) = v;
+        else if (o < nfloat) {
+            dst[o] = v.x;
+            if (o + 1 < nfloat) dst[o + 1] = v.y;
+            if (o + 2 < nfloat) dst[o + 2] = v.z;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int C, int R, int NW>
+__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_biquad_scan(const BqArgs a) {
+    static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW && R >= 2, "a lane's run is whole 16-byte vectors");
+    constexpr int V = C * R / 4;
+    constexpr int HV = (2 * C + 3) / 4;
+    constexpr uint32_t L = 64u * R, LW = L * NW;
+    __shared__ __attribute__((aligned(1024))) v4f bufs[NW][2][64 * V];
+    __shared__ __attribute__((aligned(16))) v4f halos[NW][2][4];  // HV <= 4 vectors in front of a share
+    __shared__ float xZ[2][NW][2 * C];  // by tile parity: one barrier per tile separates a tile's writes from its reads, not from the next tile's writes
+    __shared__ float tab[16][64];  // laneM, b15, b31, lookM per lane (BqTabs)
+    __shared__ uint32_t s_ticket[3];
+    static_assert(HV <= 4, "halo");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total = a.n_streams * a.tiles;
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tab[q][lane] = a.tabs->laneM[lane][q];
+            tab[4 + q][lane] = a.tabs->b15[lane][q];
+            tab[8 + q][lane] = a.tabs->b31[lane][q];
+            tab[12 + q][lane] = a.tabs->lookM[lane][q];
+        }
+    }
+    auto share = [&](uint32_t ticket, const float *&src, uint32_t &nf, bool &first) {
+        const uint32_t tile = ticket / a.n_streams, stream = ticket - tile * a.n_streams;
+        const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;
+        nf = f0 >= a.frames ? 0u : (a.frames - f0 < L ? (uint32_t)(a.frames - f0) : L);
+        src = a.src + stream * a.stride + f0 * C;
+        first = f0 == 0;
+    };
+    auto fetch = [&](const float *src, bool first, v4f *buf, v4f *halo) {
+        dma_share<V>(src, buf, lane);
+        if (!first && lane < HV) glds16(src - 4 * HV, (uint32_t)lane * 16u, (uint32_t)(uintptr_t)(lds_u8 *)halo);
+    };
+    if (threadIdx.x == 0) {
+        s_ticket[0] = atomicAdd(a.ctl, 1u);
+        s_ticket[1] = atomicAdd(a.ctl, 1u);
+    }
+    __syncthreads();
+    uint32_t cur = s_ticket[0], nxt = s_ticket[1], n = 0;
+    bool prev_full = false, dead = false;
+    if (cur < total) {
+        const float *src;
+        uint32_t nf;
+        bool first;
+        share(cur, src, nf, first);
+        if (nf == L) fetch(src, first, bufs[wave][0], halos[wave][0]);
+    }
+    while (cur < total) {
+        if (threadIdx.x == 0) s_ticket[(n + 2) % 3] = atomicAdd(a.ctl, 1u);
+        const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
+        const float *src;
+        uint32_t nf;
+        bool first;
+        share(cur, src, nf, first);
+        if (prev_full) wait_vm<V>();  // this tile's DMA is older than the V output stores of the previous tile
+        else wait_vm<0>();
+        const float *src2 = nullptr;
+        bool first2 = false;
+        if (nxt < total) {
+            uint32_t nf2;
+            share(nxt, src2, nf2, first2);
+            if (nf2 != L) src2 = nullptr;
+        }
+        // (the halo of a stream's first share does not exist: bq_tile takes the carried state there, and its DMA must not run)
+        const float *dma_src = src2;
+        v4f *nb = bufs[wave][(n + 1) & 1], *nh = halos[wave][(n + 1) & 1];
+        if (src2 && first2) {  // fetch the share here, without the halo
+            dma_share<V>(src2, nb, lane);
+            dma_src = nullptr;
+        }
+        if (nf == L) bq_tile<C, R, NW, true>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead);
+        else bq_tile<C, R, NW, false>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead);
+        prev_full = nf == L;
+        cur = nxt;
+        nxt = s_ticket[(n + 2) % 3];
+        ++n;
+    }
+    wait_vm<0>();
+}
+
+// ---- carried state: {x1,x2,y1,y2} per channel (blt.rs:404-407), the layout of mode 0 ----------------------------------------
+// in front of the launch: snapshot of the state (the tiles read it while nothing has been written yet) and of the block's last
+// two input frames (in place, dst == src, they are gone afterwards)
+__global__ void k_bq_pre(uint32_t *ctl, uint32_t *words, uint64_t n_words, float *snap, float *xlast, const float *state, const float *src, uint64_t frames, uint64_t stride,
+                         uint32_t C, uint32_t n) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+    // the scratch of the launch: control words zeroed, every hand-off word "not yet" -- by a kernel, in the stream's own buffer
+    // (why not hipMemsetAsync on hipMallocAsync memory: rh_limit.hip, k_limit_init)
+    if (i0 < 16) ctl[i0] = 0u;
+    for (uint64_t i = i0; i < n_words; i += step) words[i] = 0xffffffffu;
+    if (!state) return;
+    for (uint64_t i = i0; i < n; i += step) {  // (stream, channel)
+        const uint32_t s = (uint32_t)i / C, c = (uint32_t)i - s * C;
+        for (int k = 0; k < 4; ++k) snap[4 * i + k] = state[4 * i + k];
+        const float *x = src + (uint64_t)s * stride;
+        xlast[2 * i] = frames >= 1 ? x[(frames - 1) * C + c] : state[4 * i];
+        xlast[2 * i + 1] = frames >= 2 ? x[(frames - 2) * C + c] : (frames == 1 ? state[4 * i] : state[4 * i + 1]);
+    }
+}
+// behind it: the new state from the block's last two inputs and outputs (y1 = the stored output: what the recurrence carries)
+__global__ void k_bq_post(float *state, const float *snap, const float *xlast, const float *dst, uint64_t frames, uint64_t stride, uint32_t C, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = i / C, c = i - s * C;
+    const float *y = dst + (uint64_t)s * stride;
+    state[4 * i] = xlast[2 * i];
+    state[4 * i + 1] = xlast[2 * i + 1];
+    state[4 * i + 2] = frames >= 1 ? y[(frames - 1) * C + c] : snap[4 * i + 2];
+    state[4 * i + 3] = frames >= 2 ? y[(frames - 2) * C + c] : (frames == 1 ? snap[4 * i + 2] : snap[4 * i + 3]);
+}
+
+// ---- host: the tables ----------------------------------------------------------------------------------------------------
+struct M2 {
+    double a, b, c, d;
+};
+M2 mul(const M2 &x, const M2 &y) { return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; }
+M2 mpow(M2 base, uint64_t e) {
+    M2 r{1, 0, 0, 1};
+    while (e) {
+        if (e & 1) r = mul(r, base);
+        base = mul(base, base);
+        e >>= 1;
+    }
+    return r;
+}
+void put(float *dst, const M2 &m) {
+    dst[0] = (float)m.a, dst[1] = (float)m.b, dst[2] = (float)m.c, dst[3] = (float)m.d;
+}
+double norm1(const M2 &m) { return std::fabs(m.a) + std::fabs(m.b) + std::fabs(m.c) + std::fabs(m.d); }
+// scan basis for the companion matrix of z^2 + a1 z + a2 (rh_pipeline.hip)
+void scan_basis(double a1, double a2, M2 &T, M2 &Tinv) {
+    const double disc = a1 * a1 - 4.0 * a2, re = -0.5 * a1;
+    double mu, nu;
+    if (disc < 0.0 && std::sqrt(-disc) * 0.5 > 1e-3) {
+        mu = re;
+        nu = std::sqrt(-disc) * 0.5;
+    } else {
+        const double sq = disc > 0.0 ? std::sqrt(disc) * 0.5 : 0.0;
+        const double l1 = re + sq, l2 = re - sq;
+        mu = std::fabs(l1) < std::fabs(l2) ? l1 : l2;
+        nu = 1.0;
+    }
+    T = {1.0, -mu, 0.0, nu};
+    Tinv = {1.0, mu / nu, 0.0, 1.0 / nu};
+}
+
+struct BqPlan {
+    float co[5];
+    int R, NW;
+    BqArgs proto;  // the uniform constants
+    BqTabs *d_tabs = nullptr;
+};
+std::mutex g_mu;
+std::vector<BqPlan> g_plans;  // a handful of filters per process; tables are uploaded once (synchronously) and kept
+
+// plan for (coefficients, R, NW); nullptr: the filter does not forget within 64 workgroup tiles (or is unstable)
+const BqPlan *get_plan(const float co[5], int R, int NW) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (const BqPlan &p : g_plans)
+        if (p.R == R && p.NW == NW && std::memcmp(p.co, co, sizeof(p.co)) == 0) return &p;
+    const double a1 = co[3], a2 = co[4];
+    if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2)) return nullptr;  // stability triangle
+    const M2 A{-a1, -a2, 1.0, 0.0};
+    M2 Tm, Ti;
+    scan_basis(a1, a2, Tm, Ti);
+    const M2 B = mul(mul(Tm, A), Ti);
+    const uint64_t L = 64ull * R, LW = L * NW;
+    uint32_t J = 0;
+    {
+        const M2 BLW = mpow(B, LW);
+        M2 cur = BLW;
+        for (uint32_t j = 1; j <= 64; ++j) {
+            if (norm1(cur) < 0x1p-40) {
+                J = j;
+                break;
+            }
+            cur = mul(cur, BLW);
+        }
+    }
+    if (J == 0) return nullptr;
+    BqPlan p;
+    std::memcpy(p.co, co, sizeof(p.co));
+    p.R = R;
+    p.NW = NW;
+    BqArgs &u = p.proto;
+    std::memset(&u, 0, sizeof(u));
+    u.J = J;
+    u.b0 = co[0];
+    u.c1 = (float)((double)co[1] - (double)co[0] * a1);
+    u.c2 = (float)((double)co[2] - (double)co[0] * a2);
+    u.na1 = -co[3];
+    u.na2 = -co[4];
+    put(u.Tm, Tm);
+    for (int k = 0; k < 4; ++k) put(u.scanM[k], mpow(B, (uint64_t)R << k));
+    for (int r = 0; r < R; ++r) {
+        const M2 m = mul(mpow(A, r + 1), Ti);
+        u.g[r][0] = (float)m.a;
+        u.g[r][1] = (float)m.b;
+    }
+    for (int k = 0; k < NW; ++k) put(u.waveM[k], mpow(B, L * k));
+    put(u.BL, mpow(B, L));
+    BqTabs *h = new BqTabs();
+    for (int l = 0; l < 64; ++l) {
+        put(h->laneM[l], mpow(B, (uint64_t)R * l));
+        put(h->b15[l], mpow(B, (uint64_t)R * ((l & 15) + 1)));
+        put(h->b31[l], mpow(B, (uint64_t)R * ((l & 31) + 1)));
+        put(h->lookM[l], mpow(B, LW * l));
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p.d_tabs), sizeof(BqTabs));
+    if (e == hipSuccess) e = hipMemcpy(p.d_tabs, h, sizeof(BqTabs), hipMemcpyHostToDevice);  // synchronous: done when this returns
+    delete h;
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, "rh_biquad mode 1 tables");
+        return nullptr;
+    }
+    g_plans.push_back(p);
+    return &g_plans.back();
+}
+
+using BqFn = void (*)(const BqArgs);
+struct BqVariant {
+    int C, R, NW;
+    BqFn fn;
+};
+#define RH_BV(c, r, nw) BqVariant{c, r, nw, &k_biquad_scan<c, r, nw>}
+const BqVariant kVariants[] = {
+    RH_BV(1, 16, 8), RH_BV(1, 16, 1), RH_BV(2, 8, 8), RH_BV(2, 16, 8), RH_BV(2, 8, 4), RH_BV(2, 8, 1), RH_BV(3, 4, 8), RH_BV(3, 4, 1),
+    RH_BV(4, 4, 8),  RH_BV(4, 4, 1),  RH_BV(6, 4, 8), RH_BV(6, 4, 1),  RH_BV(8, 4, 8), RH_BV(8, 4, 1),
+};
+#undef RH_BV
+
+}  // namespace
+
+namespace rh {
+// rh_biquad mode 1.  RH_ERR_UNSUPPORTED when this kernel does not take the call (channel count without a variant, rows that
+// are not 16-byte aligned, a filter that does not forget within 64 tiles): the caller decides what then.
+rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float co[5], float *state, hipStream_t s) {
+    const uint64_t stride = frames * channels;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || stride % 4 == 0);
+    if (!aligned) return RH_ERR_UNSUPPORTED;
+    const uint64_t work = frames * (uint64_t)n_streams;
+    int want_R = channels <= 2 ? 16 : 4, want_NW = 8;  // measured, 64 x 1 Mi stereo frames: R = 16 0.240 ms, R = 8 (two workgroups per CU) 0.261 ms
+    if (work < 2ull * 8192 * (uint64_t)rh::g_num_cus) want_R = channels <= 2 ? 8 : 4;
+    if (work < 2ull * 2048 * (uint64_t)rh::g_num_cus) want_NW = 1;
+    if (const char *e = getenv("RH_BIQUAD_R")) want_R = atoi(e);  // tuning aids
+    if (const char *e = getenv("RH_BIQUAD_NW")) want_NW = atoi(e);
+    const BqVariant *v = nullptr;
+    for (const BqVariant &c : kVariants) {
+        if (c.C != (int)channels) continue;
+        auto score = [&](const BqVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
+        if (!v || score(c) < score(*v)) v = &c;
+    }
+    if (!v) return RH_ERR_UNSUPPORTED;
+    const BqPlan *pl = get_plan(co, v->R, v->NW);
+    if (!pl) return RH_ERR_UNSUPPORTED;
+    const uint32_t R = (uint32_t)v->R, NW = (uint32_t)v->NW, LW = 64u * R * NW;
+    const uint64_t tiles64 = (frames + LW - 1) / LW;
+    if (tiles64 > 0x7fffffffull || tiles64 * n_streams >= 0xfff00000ull) return RH_ERR_UNSUPPORTED;
+
+    BqArgs a = pl->proto;
+    a.dst = dst;
+    a.src = src;
+    a.tabs = pl->d_tabs;
+    a.frames = frames;
+    a.stride = stride;
+    a.n_streams = n_streams;
+    a.tiles = (uint32_t)tiles64;
+    const size_t n_sc = (size_t)n_streams * channels;
+    const size_t gran_bytes = (size_t)n_streams * tiles64 * 2 * channels * sizeof(float);
+    const size_t head = 64 + ((n_sc * 6 * 4 + 63) & ~size_t(63));  // control words, state snapshot [n][4], last inputs [n][2]
+    unsigned char *scratch = nullptr;
+    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
+    a.ctl = reinterpret_cast<uint32_t *>(scratch);
+    a.gran = reinterpret_cast<float *>(scratch + head);
+    float *snap = reinterpret_cast<float *>(scratch + 64), *xlast = snap + n_sc * 4;
+    const uint64_t n_words = gran_bytes / 4;
+    const unsigned pre_wgs = (unsigned)std::min<uint64_t>(1024, (std::max<uint64_t>(n_words, n_sc) + 255) / 256);
+    hipLaunchKernelGGL(k_bq_pre, dim3(pre_wgs), dim3(256), 0, s, a.ctl, reinterpret_cast<uint32_t *>(a.gran), n_words, snap, xlast, state, src, frames, stride, channels, (uint32_t)n_sc);
+    hipError_t e = hipGetLastError();
+    if (state) a.state_in = snap;
+    if (e == hipSuccess) {
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
+        if (const char *w = getenv("RH_BIQUAD_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;
+        uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
+        const uint64_t total = tiles64 * n_streams;
+        if (grid > total) grid = total;
+        if (e == hipSuccess) {
+            void *args[] = {&a};
+            e = hipLaunchKernel(reinterpret_cast<const void *>(v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
+        }
+    }
+    if (e == hipSuccess && state) {
+        hipLaunchKernelGGL(k_bq_post, dim3((unsigned)((n_sc + 255) / 256)), dim3(256), 0, s, state, snap, xlast, dst, frames, stride, channels, (uint32_t)n_sc);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, "rh_biquad mode 1 launch");
+        return RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+}  // namespace rh

@@ -50,6 +50,18 @@ inline hipError_t fill_now(void *p, int value, size_t bytes) {
     return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
+// A fill ON a stream, by a kernel of this library (rh_runtime.hip): whatever initialises state that a later kernel reads is
+// ordered the way kernels are (hipMemsetAsync was part of the limiter's wrong-state flake, rh_limit.hip, k_limit_init).
+hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s);
+
+// Scratch memory for one launch on stream `s`: a buffer owned by the library, one per stream, grown on demand (which waits
+// for the stream once) and reused by every later launch on that stream -- launches on a stream run one after the other, so
+// do their uses of it.  Not hipMallocAsync/hipFreeAsync per call: blocks of the stream-ordered pool were seen to change
+// under a launch that was still using them (zeros where the launch had written: 2 of 150 short GpuSource chains on ROCm 7.2
+// even with every fill done by our own kernels, 0 of 750 with this -- profiles/r02_limit_flake.md).  Freed by rh_stream_destroy for the
+// library's own streams; a foreign stream's buffer (a few hundred KiB) lives until the process ends.
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out);
+
 // Grid for a memory-bound grid-stride kernel: enough 256-thread blocks to fill 256 CUs x 8,
 // capped so small inputs stay small (cdna_hip_programming.md G11).
 inline unsigned grid_for(size_t work_items, unsigned block = 256, unsigned max_blocks = 256 * 8) {

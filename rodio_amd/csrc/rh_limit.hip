@@ -20,9 +20,9 @@
 //     no VGPR round trip) while the current one is worked on; a lane reads its run from LDS (swizzled slots: conflict-free
 //     without padding), the result goes back to the same slots and leaves with coalesced 16-byte stores.
 //   * per tile: gain computer -> lane-local (A,B) -> wave scan (DPP Kogge-Stone) -> the waves' aggregates meet in LDS
-//     (barrier 1) -> workgroup aggregate published -> decoupled look-back over the workgroup tiles in front (a wave polls up
-//     to 64 predecessors at once: aggregates compose in one wave scan; a predecessor whose inclusive state is known ends the
-//     walk; so does r^(LW*j) < 2^-30) -> true I per sample + zero-state P run -> wave scan -> LDS (barrier 2) -> published ->
+//     (barrier 1) -> workgroup aggregate published -> look-back over the workgroup tiles in front (a wave polls up to 64
+//     predecessors at once: their zero-state aggregates compose in one wave scan; the walk ends at the state the block starts
+//     from or where r^(LW*j) < 2^-30 -- never at a predecessor's end state, so the result does not depend on timing) -> true I per sample + zero-state P run -> wave scan -> LDS (barrier 2) -> published ->
 //     look-back for P -> per-sample P, channel-coupled max, exp2, multiply -> store.
 //   * hand-off words are plain f32 in a table filled with 0xFF on the stream in front of the launch: all-ones = "not yet",
 //     anything else is the value (the data is the flag, cdna_hip_programming.md G16 form R2); consumers fetch whole sections
@@ -51,6 +51,8 @@ float duration_to_coefficient_f32(uint64_t ns, uint32_t sample_rate);
 }  // namespace rh
 
 namespace {
+
+#include "rh_scan_common.h"
 
 constexpr float LOG2_10 = 3.32192809488736234787f;
 constexpr float LOG10_2 = 0.301029995663981195214f;
@@ -81,14 +83,6 @@ struct LimitArgs {
     uint32_t jI, jP;           // predecessors beyond these are below kNegligible (<= 64)
     LimitTabs t;
 };
-
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp0(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
-}
-__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-constexpr int kRowShr = 0x110, kWaveShr1 = 0x138, kBcast15 = 0x142, kBcast31 = 0x143;
 
 // limit.rs:853-873 (f32::MIN_POSITIVE = 2^-126).  The argument of the logarithm is a normal number (>= 2^-126) and the
 // argument of the exponential below lies in [-50, 0]: the bare v_log_f32 / v_exp_f32 (1 ulp) are what log2f / exp2f reduce
@@ -138,33 +132,12 @@ __device__ __forceinline__ void scan_lin(float &V, const float (&cs)[4], float c
     V = fma_(c15, dpp0<kBcast15, 0xa>(V), V);
     V = fma_(c31, dpp0<kBcast31, 0xc>(V), V);
 }
-// plain sums / maxima over the wave (all values >= 0: zero-fill is neutral)
-__device__ __forceinline__ float wave_excl_sum(float v, float &total) {
-    v += dpp0<kRowShr + 1, 0xf>(v);
-    v += dpp0<kRowShr + 2, 0xf>(v);
-    v += dpp0<kRowShr + 4, 0xf>(v);
-    v += dpp0<kRowShr + 8, 0xf>(v);
-    v += dpp0<kBcast15, 0xa>(v);
-    v += dpp0<kBcast31, 0xc>(v);
-    total = readlane_f(v, 63);
-    return dpp0<kWaveShr1, 0xf>(v);
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp0<kRowShr + 1, 0xf>(v));
-    v = fmaxf(v, dpp0<kRowShr + 2, 0xf>(v));
-    v = fmaxf(v, dpp0<kRowShr + 4, 0xf>(v));
-    v = fmaxf(v, dpp0<kRowShr + 8, 0xf>(v));
-    v = fmaxf(v, dpp0<kBcast15, 0xa>(v));
-    v = fmaxf(v, dpp0<kBcast31, 0xc>(v));
-    return readlane_f(v, 63);
-}
-
 // ---- hand-off words ---------------------------------------------------------------------------------------------------
 // A tile publishes its aggregates / end states as plain f32 words in a table that is filled with 0xFF bytes on the stream
 // in front of the launch: the all-ones pattern (a NaN no arithmetic produces; NaNs are published in canonical form) means
 // "not there yet", anything else is the value -- the data is the flag at 4-byte granularity (cdna_hip_programming.md G16,
 // form R2), so a consumer may fetch a whole section with one 16-byte load and a torn load merely reads "not yet".
-// Per tile: [A[C] B[C] | Iend[C] | Pz[C] | Pend[C]], sections aligned for the widest load that fits them.
+// Per tile: [A[C] B[C] | (unused) | Pz[C] | (unused)], sections aligned for the widest load that fits them.
 template <int C>
 struct Rec {
     static constexpr int up(int v, int m) { return (v + m - 1) / m * m; }
@@ -176,92 +149,6 @@ struct Rec {
     static constexpr int oE = oZ + up(C, wS);
     static constexpr int stride = up(oE + C, 4);
 };
-constexpr uint32_t kNotYet = 0xffffffffu;
-__device__ __forceinline__ bool word_ok(float v) { return __float_as_uint(v) != kNotYet; }
-__device__ __forceinline__ void word_store(float *p, float v) {
-    v = v != v ? __uint_as_float(0x7fc00000u) : v;  // a NaN travels in canonical form, never as the sentinel
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-typedef float v2f_ __attribute__((ext_vector_type(2)));
-typedef float v4f_ __attribute__((ext_vector_type(4)));
-// N consecutive words with agent-scope (sc1: served by L2, never by this CU's L1) loads of width W.  The loads are inline
-// asm -- hipcc does not see them -- so wait_loads() must stand between them and the first use of the values.
-template <int N, int W>
-__device__ __forceinline__ void load_words(const float *p, float (&out)[N]) {
-    static_assert(N % W == 0, "section width");
-#pragma unroll
-    for (int k = 0; k < N; k += W) {
-        if (W == 4) {
-            v4f_ r;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
-            out[k] = r.x, out[k + 1] = r.y, out[k + 2] = r.z, out[k + 3] = r.w;
-        } else if (W == 2) {
-            v2f_ r;
-            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
-            out[k] = r.x, out[k + 1] = r.y;
-        } else {
-            float r;
-            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(r) : "v"(p + k) : "memory");
-            out[k] = r;
-        }
-    }
-}
-template <int N>
-__device__ __forceinline__ void wait_loads(float (&v)[N]) {  // the values are operands: nothing that uses them can move above the wait
-#pragma unroll
-    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
-}
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// ---- the tile's samples in LDS -------------------------------------------------------------------------------------------
-// A wave's share of a tile (64 lanes x V 16-byte vectors, V KiB) sits in LDS as 64*V slots.  Slot o*V + (j ^ f(o)) holds
-// vector j of lane o's run; f swizzles the vectors of neighbouring runs so that the 16 lanes one ds_read_b128 / ds_write_b128
-// pass serves hit 16 different bank groups although the rows are not padded (V a power of two <= 16; other V: f = 0, V odd is
-// conflict-free anyway).  The image is written by LDS-DMA straight from HBM (global_load_lds_dwordx4: no VGPR round trip,
-// issued a whole tile ahead) -- the DMA lane that fills slot q simply fetches the vector that belongs there.
-template <int V>
-__device__ __forceinline__ constexpr uint32_t slot_of(uint32_t o, uint32_t j) {
-    return (V > 1 && V <= 16 && (V & (V - 1)) == 0) ? o * V + (j ^ ((o / (16 / V)) & (V - 1))) : o * V + j;
-}
-template <int V>
-__device__ __forceinline__ constexpr uint32_t vec_in_slot(uint32_t q) {  // the inverse: which vector of the share lives in slot q
-    const uint32_t o = q / V, jj = q % V;
-    return (V > 1 && V <= 16 && (V & (V - 1)) == 0) ? o * V + (jj ^ ((o / (16 / V)) & (V - 1))) : q;
-}
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-__device__ __forceinline__ const void *uniform_ptr(const void *q) {
-    const uint64_t v = (uint64_t)(uintptr_t)q;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
-// One LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) land at LDS byte address lds_dst + lane*16 (M0 is
-// compiler-reserved: saved and restored inside the statement, cdna_hip_programming.md 5.7).  hipcc does not see the load;
-// `nt`: every sample is read once (streaming fetch, +10 % on the achievable read rate on this part).
-__device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
-    const void *sbase = uniform_ptr(sbase_);
-    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-template <int V>
-__device__ __forceinline__ void dma_share(const float *src_share, v4f *buf, int lane) {
-    asm volatile("" : "+v"(lane));  // not hoisted: see limit_tile
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8 *)buf;
-#pragma unroll
-    for (int k = 0; k < V; ++k) glds16(src_share, vec_in_slot<V>(k * 64 + lane) * 16u, lds0 + k * 1024);
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 #ifdef RH_LIMIT_PROFILE  // diagnostic builds (tools/build_variant.sh): shader cycles per phase of a tile, summed over all tiles
 __device__ unsigned long long g_limit_prof[16];
 #define RH_LP_DECL unsigned long long lp_last = __builtin_readcyclecounter();
@@ -280,54 +167,41 @@ __device__ unsigned long long g_limit_prof[16];
 #define RH_LP_ARG
 #endif
 
-// One window of a look-back walk.  Lane j looks at tile base-j: the `inc` section holds a predecessor's inclusive (end)
-// state, the `agg` section its zero-state aggregate.  All loads of a poll leave together (one round trip).  Returns j* = the
-// nearest lane whose inclusive state is known (64: none in this window) once every lane in front of it holds an aggregate;
-// virtual entries -- the state the block starts from (tile -1), tiles before it, predecessors whose weight is negligible
-// -- count as known states (zero unless tile -1 with a carried-in state).
-template <int C, int NAGG, int WAGG, int WINC>
-__device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_t base, int lane, uint32_t reach, uint32_t stride, uint32_t off_agg, uint32_t off_inc,
+// One window of a look-back walk.  Lane j looks at tile base-j and fetches its zero-state aggregate (all loads of a poll leave
+// together: one round trip; the poll repeats until every lane has its words).  Returns j* = the nearest lane that stands for a
+// KNOWN STATE instead of a tile: the state the block starts from (tile -1, `init`), a tile before it, or a predecessor whose
+// weight is negligible (taken as zero).  Real predecessors never contribute anything but their aggregate, whatever else they
+// may have published by now: which tiles have finished when this one polls depends on timing, and f32 composition is not
+// associative -- this way the result does not depend on it (the same input gives the same bits, run after run).
+template <int C, int NAGG, int WAGG>
+__device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_t base, int lane, uint32_t reach, uint32_t stride, uint32_t off_agg,
                                                 const float *init, float (&agg)[NAGG], float (&inc)[C], bool &dead) {
     const int64_t idx = base - lane;
     const bool real = idx >= 0 && (uint32_t)lane < reach;
     const float *pr = gran_stream + (real ? (uint64_t)idx : 0) * stride;
-    bool have_agg = !real, have_inc = !real;
+    bool have = !real;
 #pragma unroll
     for (int c = 0; c < NAGG; ++c) agg[c] = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; ++c) inc[c] = (idx == -1 && init) ? init[2 * c] : 0.0f;
+    const unsigned long long virt = __ballot(!real);
+    const uint32_t jstar = virt ? (uint32_t)__builtin_ctzll(virt) : 64u;
     uint32_t spins = 0;
     while (true) {
-        if (real && !have_inc) {
-            float gi[C], ga[NAGG];
-            load_words<C, WINC>(pr + off_inc, gi);
-            if (!have_agg) {
-                load_words<NAGG, WAGG>(pr + off_agg, ga);
-                wait_loads(ga);
-            }
-            wait_loads(gi);
+        if (!have) {
+            float ga[NAGG];
+            load_words<NAGG, WAGG>(pr + off_agg, ga);
+            wait_loads(ga);
             bool ok = true;
 #pragma unroll
-            for (int c = 0; c < C; ++c) ok = ok && word_ok(gi[c]);
+            for (int c = 0; c < NAGG; ++c) ok = ok && word_ok(ga[c]);
             if (ok) {
-                have_inc = true;
+                have = true;
 #pragma unroll
-                for (int c = 0; c < C; ++c) inc[c] = gi[c];
-            } else if (!have_agg) {
-                bool oka = true;
-#pragma unroll
-                for (int c = 0; c < NAGG; ++c) oka = oka && word_ok(ga[c]);
-                if (oka) {
-                    have_agg = true;
-#pragma unroll
-                    for (int c = 0; c < NAGG; ++c) agg[c] = ga[c];
-                }
+                for (int c = 0; c < NAGG; ++c) agg[c] = ga[c];
             }
         }
-        const unsigned long long inc_mask = __ballot(have_inc);
-        const uint32_t jstar = inc_mask ? (uint32_t)__builtin_ctzll(inc_mask) : 64u;
-        const unsigned long long need = jstar >= 64 ? ~0ull : ((1ull << jstar) - 1ull);  // lanes in front of j* must hold an aggregate
-        if ((__ballot(have_agg || have_inc) & need) == need) return jstar;
+        if (__all(have || (uint32_t)lane > jstar)) return jstar;  // lanes behind j* are not needed
         if (++spins > kSpinLimit) {
             dead = true;
             return 64u;
@@ -456,7 +330,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         const float wI = tab[6][lane];
         while (true) {
             float AB[2 * C], Ij[C];
-            const uint32_t jstar = poll_window<C, 2 * C, RC::wA, RC::wS>(gstream, base, lane, a.jI, G, RC::oA, RC::oI, init, AB, Ij, dead);
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gstream, base, lane, a.jI, G, RC::oA, init, AB, Ij, dead);
             if (dead) break;
             const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
 #pragma unroll
@@ -475,12 +349,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
-    }
-    if (wave == 0 && lane < C) {  // the tile's end state of the integrator, for the tiles behind
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) v = lane == c ? fmaxf(AT[c], fma_(a.rLW, Iin[c], BT[c])) : v;
-        word_store(rec + RC::oI + lane, v);
     }
     // The next tile's samples are requested here (LDS-DMA into the other buffer): behind the integrator look-back, whose poll
     // would otherwise have to wait for them (vmcnt retires in order), and a whole integrator run + barrier ahead of the next
@@ -546,7 +414,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         const float wP = tab[7][lane];
         while (!dead) {
             float Zj[C], Ej[C];
-            const uint32_t jstar = poll_window<C, C, RC::wS, RC::wS>(gstream, base, lane, a.jP, G, RC::oZ, RC::oE, init ? init + 1 : nullptr, Zj, Ej, dead);
+            const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, base, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead);
             if (dead) break;
             const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
 #pragma unroll
@@ -560,12 +428,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
             base -= 64;
             if (Co < kNegligible) break;
         }
-    }
-    if (wave == 0 && lane < C) {
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) v = lane == c ? fma_(a.aLW, Pin[c], PT[c]) : v;
-        word_store(rec + RC::oE + lane, v);
     }
     if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
         if (lane == 0) atomicOr(a.ctl + 1, 1u);
@@ -707,10 +569,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
 #endif
 }
 
-// snapshot of the caller's state in front of the launch: the last tile rewrites it while early tiles may still read it
-__global__ void k_copy_f32(float *dst, const float *src, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+// Everything the launch finds in its scratch, written by ONE kernel of this library in front of it: the control words (ticket
+// counter, status) zeroed, a snapshot of the caller's states (the last tile of a stream rewrites the state while early tiles
+// may still read it), every hand-off word "not yet".  The scratch itself is the stream's own buffer (rh::stream_scratch).
+// Neither hipMallocAsync/hipFreeAsync per call nor hipMemsetAsync: with them ~7 % of short GpuSource chains carried a wrong
+// state into one tile (a zero aggregate or a zeroed state snapshot where the launch had written something else); either
+// change alone lowered the rate, only both removed it (profiles/r02_limit_flake.md).
+__global__ void k_limit_init(uint32_t *ctl, float *snap, const float *state, uint32_t n_state, uint32_t *words, uint64_t n_words) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+    if (i0 < 16) ctl[i0] = 0u;
+    for (uint64_t i = i0; i < n_state; i += step) snap[i] = state[i];
+    for (uint64_t i = i0; i < n_words; i += step) words[i] = 0xffffffffu;
 }
 
 using LimitFn = void (*)(const LimitArgs);
@@ -833,23 +702,20 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     if (a.jI == 0) a.jI = 1;
     if (a.jP == 0) a.jP = 1;
 
-    // scratch: control words + the carried-in states + the hand-off table, initialised on the stream in front of the launch
+    // scratch: control words + the carried-in states + the hand-off table, initialised by k_limit_init in front of the launch
     const size_t n_state = (size_t)n_streams * channels * 2;
     const size_t gran_bytes = (size_t)n_streams * tiles64 * rec_stride(channels) * sizeof(float);
     const size_t head = 64 + ((n_state * 4 + 63) & ~size_t(63));
     unsigned char *scratch = nullptr;
-    RH_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&scratch), head + gran_bytes, s));
-    hipError_t e = hipMemsetAsync(scratch, 0, head, s);
-    if (e == hipSuccess) e = hipMemsetAsync(scratch + head, 0xff, gran_bytes, s);  // every word "not yet"
+    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.gran = reinterpret_cast<float *>(scratch + head);
-    if (e == hipSuccess && state) {
-        float *snap = reinterpret_cast<float *>(scratch + 64);
-        hipLaunchKernelGGL(k_copy_f32, dim3((unsigned)((n_state + 255) / 256)), dim3(256), 0, s, snap, state, (uint32_t)n_state);
-        e = hipGetLastError();
-        a.state_in = snap;
-        a.state_out = state;
-    }
+    float *snap = reinterpret_cast<float *>(scratch + 64);
+    const uint64_t n_words = gran_bytes / 4;
+    const unsigned init_wgs = (unsigned)std::min<uint64_t>(1024, (std::max<uint64_t>(n_words, n_state) + 255) / 256);
+    hipLaunchKernelGGL(k_limit_init, dim3(init_wgs), dim3(256), 0, s, a.ctl, snap, state, state ? (uint32_t)n_state : 0u, reinterpret_cast<uint32_t *>(a.gran), n_words);
+    hipError_t e = hipGetLastError();
+    if (state) a.state_in = snap, a.state_out = state;
     if (e == hipSuccess) {
         int per_cu = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
@@ -859,12 +725,12 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
         const uint64_t total = tiles64 * n_streams;
         if (grid > total) grid = total;
+        if (const char *g = getenv("RH_LIMIT_GRID")) grid = atoi(g) > 0 ? (uint64_t)atoi(g) : grid;  // diagnostics
         if (e == hipSuccess) {
             void *args[] = {&a};
             e = hipLaunchKernel(reinterpret_cast<const void *>(v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
         }
     }
-    (void)hipFreeAsync(scratch, s);
     if (e != hipSuccess) {
         rh::set_hip_error(e, "rh_limit launch");
         return RH_ERR_HIP;

@@ -400,13 +400,24 @@ rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample
 }
 
 rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream);
+}  // extern "C" (reopened below)
+namespace rh {
+rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float co[5], float *state, hipStream_t s);
+}
+extern "C" {
 
 rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, int32_t mode, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (channels == 0 || !coeffs5_host) return RH_ERR_INVALID;
     if (frames == 0 || n_streams == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    if (mode == 1) return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+    if (mode == 1) {  // time-parallel: the dedicated scan kernel (rh_biquad_scan.hip); what it does not take -- rows that are not
+                      // 16-byte aligned, a filter that does not forget within 64 tiles -- goes to the fused kernel's batch mode
+                      // (stereo, zero state) or is refused
+        const rh_status st = rh::biquad_scan_launch(dst, src, frames, channels, n_streams, coeffs5_host, state, rh::as_stream(stream));
+        if (st != RH_ERR_UNSUPPORTED || getenv("RH_BIQUAD_NO_FALLBACK")) return st;
+        return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+    }
     if (mode != 0) return RH_ERR_INVALID;
     const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};
     // rows that start on 16-byte boundaries take the vector kernel (same arithmetic, same bits); anything else the 4-byte one
@@ -426,14 +437,18 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
 
 size_t rh_agc_state_floats(void) { return kAgcStateFloats; }
 
+// agc.rs:397-421: everything zero but current_gain = 1.0 (word 3 of a stream's state); one kernel on the caller's stream
+__global__ void k_agc_state_init(float *state, size_t n) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < n; i += step) state[i] = (i % kAgcStateFloats == 3) ? 1.0f : 0.0f;
+}
+
 rh_status rh_agc_state_init(float *state, uint32_t n_streams, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (!state) return RH_ERR_INVALID;
     hipStream_t s = rh::as_stream(stream);
-    RH_HIP_TRY(hipMemsetAsync(state, 0, sizeof(float) * kAgcStateFloats * n_streams, s));
-    // current_gain starts at 1.0 (0x3f800000): a fill, not an asynchronous copy from a variable that is gone on return
-    for (uint32_t i = 0; i < n_streams; ++i)
-        RH_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + (size_t)i * kAgcStateFloats + 3), 0x3f800000, 1, s));
+    hipLaunchKernelGGL(k_agc_state_init, dim3(rh::grid_for((size_t)kAgcStateFloats * n_streams)), dim3(256), 0, s, state, (size_t)kAgcStateFloats * n_streams);
+    RH_CHECK_LAUNCH();
     return RH_OK;
 }
 
@@ -458,10 +473,9 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
         return RH_OK;
     }
     float *st = state;
-    if (!st) RH_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&st), sizeof(float) * kAgcStateFloats * n_streams, s));
+    if (!st) RH_HIP_TRY(rh::stream_scratch(s, sizeof(float) * kAgcStateFloats * n_streams, reinterpret_cast<void **>(&st)));
     hipLaunchKernelGGL(k_agc_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, st, state ? 0 : 1);
     hipError_t le = hipGetLastError();
-    if (!state) (void)hipFreeAsync(st, s);
     if (le != hipSuccess) {
         rh::set_hip_error(le, "k_agc_seq launch");
         return RH_ERR_HIP;

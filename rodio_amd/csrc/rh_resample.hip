@@ -247,7 +247,7 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host, 
     if (!dst || (n_sources && (!srcs_host || !start_host || !len_host))) return RH_ERR_INVALID;
     hipStream_t s = rh::as_stream(stream);
     if (n_sources == 0) {  // an empty mixer yields nothing (mixer.rs:131-135); caller asked for zeros
-        RH_HIP_TRY(hipMemsetAsync(dst, 0, out_len * sizeof(float), s));
+        RH_HIP_TRY(rh::fill_async(dst, 0, out_len * sizeof(float), s));
         return RH_OK;
     }
     bool vec_ok = (reinterpret_cast<uintptr_t>(dst) % 16 == 0);

@@ -1,6 +1,8 @@
 // rh_runtime.hip -- device bring-up, memory/stream/event helpers of the C ABI.
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "rh_common.h"
 
@@ -11,6 +13,63 @@ int g_num_cus = 256;
 static thread_local std::string g_last_error;
 void set_hip_error(hipError_t e, const char *what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+namespace {
+// bytes [0, n) of p: the unaligned head and tail byte by byte, the 4-byte aligned body word by word
+__global__ void k_fill(unsigned char *p, uint32_t word, size_t n) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    const size_t head = ((4u - (reinterpret_cast<uintptr_t>(p) & 3u)) & 3u) < n ? ((4u - (reinterpret_cast<uintptr_t>(p) & 3u)) & 3u) : n;
+    const size_t words = (n - head) / 4, tail0 = head + words * 4;
+    uint32_t *w = reinterpret_cast<uint32_t *>(p + head);
+    for (size_t i = i0; i < words; i += step) w[i] = word;
+    if (i0 < head) p[i0] = (unsigned char)word;
+    if (i0 < n - tail0) p[tail0 + i0] = (unsigned char)word;
+}
+}  // namespace
+namespace {
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+std::mutex g_scratch_mu;
+std::unordered_map<hipStream_t, Scratch> g_scratch;
+}  // namespace
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    Scratch &e = g_scratch[s];
+    if (e.cap < bytes) {
+        if (e.p) {  // launches on `s` may still be using it
+            hipError_t w = hipStreamSynchronize(s);
+            if (w != hipSuccess) return w;
+            (void)hipFree(e.p);
+            e.p = nullptr;
+            e.cap = 0;
+        }
+        size_t cap = size_t(1) << 20;
+        while (cap < bytes) cap *= 2;
+        hipError_t m = hipMalloc(&e.p, cap);
+        if (m != hipSuccess) {
+            e.p = nullptr;
+            return m;
+        }
+        e.cap = cap;
+    }
+    *out = e.p;
+    return hipSuccess;
+}
+static void drop_stream_scratch(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch.find(s);
+    if (it == g_scratch.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_scratch.erase(it);
+}
+hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    const uint32_t b = (uint32_t)value & 0xffu;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(bytes / 16 + 1)), dim3(256), 0, s, static_cast<unsigned char *>(p), b * 0x01010101u, bytes);
+    return hipGetLastError();
 }
 }  // namespace rh
 
@@ -80,7 +139,9 @@ rh_status rh_free(void *p) {
 }
 rh_status rh_memset(void *p, int32_t value, size_t bytes, rh_stream stream) {
     RH_REQUIRE_INIT();
-    RH_HIP_TRY(hipMemsetAsync(p, value, bytes, rh::as_stream(stream)));
+    if (!bytes) return RH_OK;
+    if (!p) return RH_ERR_INVALID;
+    RH_HIP_TRY(rh::fill_async(p, value, bytes, rh::as_stream(stream)));
     return RH_OK;
 }
 rh_status rh_memcpy_h2d(void *dst, const void *src_host, size_t bytes, rh_stream stream) {
@@ -126,6 +187,8 @@ rh_status rh_stream_create(rh_stream *out) {
 }
 rh_status rh_stream_destroy(rh_stream s) {
     RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(s)));
+    rh::drop_stream_scratch(rh::as_stream(s));
     RH_HIP_TRY(hipStreamDestroy(rh::as_stream(s)));
     return RH_OK;
 }

@@ -120,3 +120,95 @@ def test_agc_vector_kernel_equals_ring_kernel(G, O):
     finally:
         del os.environ["RH_AGC_SEQ"]
     assert np.array_equal(a, b)  # the same f32 operations in the same order
+
+
+# ---- rh_biquad mode 1: the dedicated time-parallel kernel (rh_biquad_scan.hip) ------------------------------------------
+def _biquad(G, x, frames, ch, S, co, mode, state=None):
+    import ctypes as C
+
+    import torch
+
+    from rodio_amd import _lib
+
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib.rh_biquad(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), frames, ch, S, co.ctypes.data_as(_lib.f32p),
+                                  C.c_void_p(state.data_ptr()) if state is not None else None, mode, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rh_biquad")
+    return out
+
+
+def _truth(x, co, ch):
+    from scipy.signal import lfilter
+
+    c = co.astype(np.float64)
+    return lfilter(c[:3], [1.0, c[3], c[4]], x.astype(np.float64).reshape(-1, ch), axis=0).reshape(-1)
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("frames", [1, 2, 3, 255, 512, 513, 4096, 4097, 8192 + 5, 70001])
+def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
+    import torch
+
+    os.environ["RH_BIQUAD_NO_FALLBACK"] = "1"  # the new kernel or nothing
+    try:
+        S = 3 if (frames * ch) % 4 == 0 else 1  # rows of a batch must start on 16-byte boundaries
+        xs = [rnd(200 + 7 * ch + s, frames * ch, 0.4) for s in range(S)]  # (the f32 recurrence of a high-pass itself sits ~1e-5 from exact at full scale)
+        x = torch.from_numpy(np.stack(xs)).cuda()
+        for kind, freq in (("low_pass", 200), ("high_pass", 300)):
+            co = G.biquad_coeffs(kind, freq, 0.5, 48000)
+            par = _biquad(G, x, frames, ch, S, co, 1).cpu().numpy()
+            seq = _biquad(G, x, frames, ch, S, co, 0).cpu().numpy()
+            for s in range(S):
+                d = float(np.max(np.abs(par[s] - seq[s])))
+                t = _truth(xs[s], co, ch)
+                e_par, e_seq = float(np.max(np.abs(par[s] - t))), float(np.max(np.abs(seq[s] - t)))
+                assert d <= TOL, (kind, s, d)
+                assert e_par <= 2.0 * e_seq + 1e-7, (kind, s, e_par, e_seq)
+    finally:
+        del os.environ["RH_BIQUAD_NO_FALLBACK"]
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4])
+def test_biquad_mode1_state_across_blocks(G, O, ch):
+    import torch
+
+    S, frames = 4, 60000
+    xs = [rnd(300 + s, frames * ch, 0.8) for s in range(S)]
+    co = G.biquad_coeffs("low_pass", 150, 0.5, 44100)
+    refs = [O.TestSource(x, ch, 44100).low_pass(150).collect() for x in xs]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    state = torch.zeros((S, 4 * ch), device="cuda")
+    rng = np.random.default_rng(9)
+    outs, a = [], 0
+    while a < frames:
+        b = min(frames, a + 4 * int(rng.choice([1, 2, 100, 1024, 5000])))  # multiples of 4 frames: rows stay 16-byte aligned
+        blk = x[:, a * ch: b * ch].contiguous()
+        outs.append(_biquad(G, blk, b - a, ch, S, co, 1, state))
+        a = b
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    for s in range(S):
+        assert float(np.max(np.abs(got[s] - refs[s]))) <= TOL, s
+    # the state is mode 0's {x1,x2,y1,y2}: a last block through the reference-order kernel continues the stream
+    tail = [rnd(400 + s, 1000 * ch) for s in range(S)]
+    t = torch.from_numpy(np.stack(tail)).cuda()
+    st2 = state.clone()
+    a_ = _biquad(G, t, 1000, ch, S, co, 0, state).cpu().numpy()
+    b_ = _biquad(G, t, 1000, ch, S, co, 1, st2).cpu().numpy()
+    for s in range(S):
+        full = O.TestSource(np.concatenate([xs[s], tail[s]]), ch, 44100).low_pass(150).collect()[frames * ch:]
+        assert float(np.max(np.abs(a_[s] - full))) <= TOL and float(np.max(np.abs(b_[s] - full))) <= TOL
+
+
+def test_biquad_mode1_long_memory_and_many_streams(G, O):
+    import torch
+
+    # low_pass(20) at 48 kHz: poles at ~0.9974, the carry reaches back several 4096-frame tiles; 96 streams in one launch
+    S, frames, ch = 96, 40000, 2
+    xs = [rnd(500 + s, frames * ch, 0.2) for s in range(S)]  # (poles this close to z = 1: the f32 reference recurrence itself is ~1e-5 from exact at half scale)
+    co = G.biquad_coeffs("low_pass", 20, 0.5, 48000)
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    par = _biquad(G, x, frames, ch, S, co, 1).cpu().numpy()
+    for s in (0, 17, S - 1):
+        ref = O.TestSource(xs[s], ch, 48000).low_pass(20).collect()
+        t = _truth(xs[s], co, ch)
+        assert float(np.max(np.abs(par[s] - ref))) <= TOL
+        assert float(np.max(np.abs(par[s] - t))) <= 2.0 * float(np.max(np.abs(ref - t))) + 1e-7
