@@ -37,11 +37,20 @@
 //     workgroup tiles (8 waves, LDS exchange, 2 barriers)         0.38 ms
 //     ... 16 frames per lane, LDS-DMA prefetch                    0.33 ms = 3.2 TB/s = 40 % of 8 TB/s (SQ counters: waves wait
 //                                                                              56 % of their cycles, VALU busy 19 %: sync-bound)
+//     ... two channels per instruction (v_pk_*_f32, -23 % VALU)   0.31 ms = 43 %; 2048 streams x 32 Ki: 0.305 ms
+//     ... one poll point per tile when streams > workgroups       0.31 ms = 43 %; 2048 streams x 32 Ki: 0.280 ms = 48 %
+//         (the next tile's integrator look-back rides on this tile's peak look-back; with FEW streams that chains the
+//          workgroups -- 0.76 ms -- so there the walk stays inside the tile)
+// What is left per tile (~9 us for 128 KiB of traffic, one workgroup of 8 waves per CU because of the 128 KiB of LDS the
+// double-buffered 16-frame runs take): ~3 us of vector arithmetic, the rest is the poll round trip(s) and the two barriers
+// with nothing else resident to fill them; 8 frames per lane and two workgroups per CU measures slower (0.35 ms: the scans
+// and look-backs amortise over half as many samples).
 // The sequential kernel of rh_recurrence.hip stays as the reference-order path for layouts this one does not take
 // (rows that are not 16-byte aligned).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "rh_common.h"
 
@@ -210,13 +219,166 @@ __device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_
     }
 }
 
+// The poll point of a tile (see limit_tile): the first window of the peak look-back of THIS tile and the first window of the
+// integrator look-back of the workgroup's NEXT tile, fetched together -- one round trip to L2 instead of one per look-back.
+template <int C>
+struct PollPair {
+    float Z[C], E[C], AB[2 * C], Ij[C];
+    uint32_t jstarP, jstarI;
+};
+template <int C>
+__device__ __forceinline__ void poll_pair(const float *gsP, int64_t baseP, uint32_t reachP, const float *initP, const float *gsI, int64_t baseI, uint32_t reachI,
+                                          const float *initI, bool wantI, int lane, PollPair<C> &o, bool &dead) {
+    typedef Rec<C> RC;
+    constexpr uint32_t G = RC::stride;
+    const int64_t idxP = baseP - lane, idxI = baseI - lane;
+    const bool realP = idxP >= 0 && (uint32_t)lane < reachP, realI = wantI && idxI >= 0 && (uint32_t)lane < reachI;
+    const float *pP = gsP + (realP ? (uint64_t)idxP : 0) * G + RC::oZ, *pI = gsI + (realI ? (uint64_t)idxI : 0) * G + RC::oA;
+    bool haveP = !realP, haveI = !realI;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        o.Z[c] = 0.0f, o.AB[c] = o.AB[C + c] = 0.0f;
+        o.E[c] = (idxP == -1 && initP) ? initP[2 * c] : 0.0f;
+        o.Ij[c] = (idxI == -1 && initI) ? initI[2 * c] : 0.0f;
+    }
+    const unsigned long long virtP = __ballot(!realP), virtI = __ballot(!realI);
+    o.jstarP = virtP ? (uint32_t)__builtin_ctzll(virtP) : 64u;
+    o.jstarI = virtI ? (uint32_t)__builtin_ctzll(virtI) : 64u;
+    uint32_t spins = 0;
+    while (true) {
+        float gz[C], ga[2 * C];
+        if (!haveP) load_words<C, RC::wS>(pP, gz);
+        if (!haveI) load_words<2 * C, RC::wA>(pI, ga);
+        if (!haveP) wait_loads(gz);
+        if (!haveI) wait_loads(ga);
+        if (!haveP) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) ok = ok && word_ok(gz[c]);
+            if (ok) {
+                haveP = true;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o.Z[c] = gz[c];
+            }
+        }
+        if (!haveI) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 2 * C; ++c) ok = ok && word_ok(ga[c]);
+            if (ok) {
+                haveI = true;
+#pragma unroll
+                for (int c = 0; c < 2 * C; ++c) o.AB[c] = ga[c];
+            }
+        }
+        if (__all((haveP || (uint32_t)lane > o.jstarP) && (haveI || (uint32_t)lane > o.jstarI))) return;
+        if (++spins > kSpinLimit) {
+            dead = true;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// ---- two channels per instruction ------------------------------------------------------------------------------------------
+// The kernel is VALU-bound (r02 PMC: 47 vector instructions per sample, ~60 % of its duration), and gfx950 executes the f32
+// multiply / add / FMA on PAIRS of registers at full rate (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32).  With an even channel
+// count the channels of a frame go through the per-sample arithmetic two at a time (T = f2); the operations are the same IEEE
+// operations in the same order, so the bits do not change.  max, log2, exp2, compares and DPP moves have no packed form.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int C>
+struct Pk {
+    static constexpr int W = C % 2 == 0 ? 2 : 1, N = C / W;
+    typedef typename std::conditional<W == 2, f2, float>::type T;
+};
+template <class T>
+__device__ __forceinline__ T splat(float s);
+template <>
+__device__ __forceinline__ float splat<float>(float s) { return s; }
+template <>
+__device__ __forceinline__ f2 splat<f2>(float s) { return (f2)(s); }
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fma_(a, b, c); }
+__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) {
+    f2 r;
+    r.x = fmaxf(a.x, b.x), r.y = fmaxf(a.y, b.y);
+    return r;
+}
+__device__ __forceinline__ float comp(float v, int) { return v; }
+__device__ __forceinline__ float comp(f2 v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ float pair_of(const float *p, float) { return p[0]; }
+__device__ __forceinline__ f2 pair_of(const float *p, f2) {
+    f2 r;
+    r.x = p[0], r.y = p[1];
+    return r;
+}
+template <int CTRL, int MASK>
+__device__ __forceinline__ float vdpp(float v) { return dpp0<CTRL, MASK>(v); }
+template <int CTRL, int MASK>
+__device__ __forceinline__ f2 vdpp(f2 v) {
+    f2 r;
+    r.x = dpp0<CTRL, MASK>(v.x), r.y = dpp0<CTRL, MASK>(v.y);
+    return r;
+}
+__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f2 vsel(bool c, f2 a, f2 b) { return c ? a : b; }
+
+// limit.rs:853-873 for one sample or a pair (see gain_computer above: the same expression, with the lower knee branch
+// expressed as a clamp: 2*bias + knee < 0 exactly when bias < -knee/2, and then the square is the reference's 0.0).
+__device__ __forceinline__ float log2_mag(float s) { return __builtin_amdgcn_logf(fabsf(s) + 1.17549435e-38f); }
+__device__ __forceinline__ f2 log2_mag(f2 s) {
+    f2 r;
+    r.x = log2_mag(s.x), r.y = log2_mag(s.y);
+    return r;
+}
+template <class T>
+__device__ __forceinline__ T gain_computer_v(T sample, const GainK &k) {
+    const T bias_db = vfma(log2_mag(sample), splat<T>(k.db_per_log2), splat<T>(k.neg_thr));
+    const T x = vmax(vfma(splat<T>(2.0f), bias_db, splat<T>(k.knee_width)), splat<T>(0.0f));
+    const T soft = x * x * splat<T>(k.inv_knee_8);
+    if constexpr (sizeof(T) == 8) {
+        f2 r;
+        r.x = !(bias_db.x <= k.half_knee) ? bias_db.x : soft.x;  // (a NaN sample stays a NaN, as in the reference)
+        r.y = !(bias_db.y <= k.half_knee) ? bias_db.y : soft.y;
+        return r;
+    } else
+        return !(bias_db <= k.half_knee) ? bias_db : soft;
+}
+template <class T>
+__device__ __forceinline__ void scan_maxaff_v(T &A, T &B, const float (&cs)[4], float c15, float c31) {
+#define RH_STEP(CS, CTRL, MASK)                                            \
+    {                                                                      \
+        const T a1 = vdpp<CTRL, MASK>(A), b1 = vdpp<CTRL, MASK>(B);       \
+        A = vmax(A, vfma(splat<T>(CS), a1, B));                            \
+        B = vfma(splat<T>(CS), b1, B);                                     \
+    }
+    RH_STEP(cs[0], kRowShr + 1, 0xf)
+    RH_STEP(cs[1], kRowShr + 2, 0xf)
+    RH_STEP(cs[2], kRowShr + 4, 0xf)
+    RH_STEP(cs[3], kRowShr + 8, 0xf)
+    RH_STEP(c15, kBcast15, 0xa)
+    RH_STEP(c31, kBcast31, 0xc)
+#undef RH_STEP
+}
+template <class T>
+__device__ __forceinline__ void scan_lin_v(T &V, const float (&cs)[4], float c15, float c31) {
+    V = vfma(splat<T>(cs[0]), vdpp<kRowShr + 1, 0xf>(V), V);
+    V = vfma(splat<T>(cs[1]), vdpp<kRowShr + 2, 0xf>(V), V);
+    V = vfma(splat<T>(cs[2]), vdpp<kRowShr + 4, 0xf>(V), V);
+    V = vfma(splat<T>(cs[3]), vdpp<kRowShr + 8, 0xf>(V), V);
+    V = vfma(splat<T>(c15), vdpp<kBcast15, 0xa>(V), V);
+    V = vfma(splat<T>(c31), vdpp<kBcast31, 0xc>(V), V);
+}
+
 // One wave's share (L = 64*R frames) of a workgroup tile (NW waves, LW = NW*L frames of one stream).
 //   waves of a workgroup exchange their aggregates through LDS (two barriers per tile); only the workgroup-level
 //   aggregates and end states travel through HBM, one record per LW frames, and every wave walks the (short) look-back over
 //   them on its own -- redundant polls are cheaper than two more barriers.
-template <int C, int R, int NW, bool FULL>
+template <int C, int R, int NW, bool FULL, bool SKEW>
 __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
-                                           const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf RH_LP_PARAM) {
+                                           const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
+                                           const uint32_t nstream, const float *next_src, v4f *next_buf RH_LP_PARAM) {
     // The lane id is made opaque per tile: everything derived from it (LDS slots, global offsets) is then recomputed here, a
     // few VALU operations, instead of being hoisted out of the persistent loop into registers that stay occupied for the
     // whole kernel (which spilled).
@@ -226,7 +388,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     constexpr uint32_t L = 64u * R, LW = L * NW;
     typedef Rec<C> RC;
     constexpr uint32_t G = RC::stride;
-    const float rel = a.release, omr = 1.0f - a.release, att = a.attack, oma = 1.0f - a.attack;
+    typedef typename Pk<C>::T T;
+    constexpr int W = Pk<C>::W, N = Pk<C>::N;
+    static_assert(W == 1 || 4 % W == 0, "a pair never straddles two 16-byte vectors");
+    const float att = a.attack;
+    const T relT = splat<T>(a.release), omrT = splat<T>(1.0f - a.release), attT = splat<T>(a.attack), omaT = splat<T>(1.0f - a.attack);
     const GainK gk{LOG10_2 * 20.0f, -a.threshold, 0.5f * a.knee_width, a.knee_width, a.inv_knee_8};
     const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;  // first frame of this wave's share; nf = valid frames in it (FULL: L)
     const uint32_t nfl = FULL ? (uint32_t)R : (nf > (uint32_t)lane * R ? (nf - lane * R < (uint32_t)R ? nf - lane * R : R) : 0u);
@@ -237,6 +403,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     float *const rec = a.gran + ((uint64_t)stream * a.tiles + tile) * G;
     const float *const init = a.state_in ? a.state_in + (uint64_t)stream * C * 2 : nullptr;
     RH_LP_DECL
+    // The next tile's samples (LDS-DMA into the other buffer, whose last reader was the previous tile's store) are requested in
+    // front of everything when this tile has no poll before its integrator run: its one poll point then lies a whole gain +
+    // integrator run behind them (vmcnt retires in order: a poll waits for every fetch issued before it).
+    const bool had_I = SKEW && have_I;
+    if (had_I && next_src) dma_share<V>(next_src, next_buf, lane);
     // ---- the samples: whole shares were put into LDS by the DMA issued a tile ago; a short share (end of a stream) is
     //      fetched here, guarded, into the same slots
     if (!FULL) {
@@ -256,166 +427,174 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     __builtin_amdgcn_wave_barrier();
     RH_LP(0)
     // ---- this lane's run: gain computer + lane-local max-affine segment per channel (the samples stay in the LDS row) ----
-    float g[R][C], A[C], B[C];
+    T g[R][N], A[N], B[N];
 #pragma unroll
-    for (int c = 0; c < C; ++c) A[c] = B[c] = 0.0f;
+    for (int p = 0; p < N; ++p) A[p] = B[p] = splat<T>(0.0f);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const v4f v = lds[slot_of<V>(lane, j)];
         const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
-            float gv = gain_computer(e[i], gk);
-            if (!FULL) gv = (uint32_t)r < nfl ? gv : 0.0f;
-            g[r][c] = gv;
+        for (int i = 0; i < 4; i += W) {
+            const int r = (4 * j + i) / C, p = ((4 * j + i) % C) / W;
+            T gv = gain_computer_v<T>(pair_of(e + i, T()), gk);
+            if (!FULL) gv = vsel((uint32_t)r < nfl, gv, splat<T>(0.0f));
+            g[r][p] = gv;
         }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float bn = omr * g[r][c];
-            const float An = fmaxf(g[r][c], fma_(rel, A[c], bn)), Bn = fma_(rel, B[c], bn);
+        for (int p = 0; p < N; ++p) {
+            const T bn = omrT * g[r][p];
+            const T An = vmax(g[r][p], vfma(relT, A[p], bn)), Bn = vfma(relT, B[p], bn);
             if (FULL || (uint32_t)r < nfl) {  // frames past the end of the stream are the identity
-                A[c] = An;
-                B[c] = Bn;
+                A[p] = An;
+                B[p] = Bn;
             }
         }
-    float Ax[C], Bx[C];  // exclusive prefixes inside the wave
+    T Ax[N], Bx[N];  // exclusive prefixes inside the wave
     const float r15 = tab[0][lane], r31 = tab[1][lane];  // per-lane constants live in LDS, not in registers, between their uses
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        scan_maxaff(A[c], B[c], a.rscan, r15, r31);
-        Ax[c] = dpp0<kWaveShr1, 0xf>(A[c]);
-        Bx[c] = dpp0<kWaveShr1, 0xf>(B[c]);
+    for (int p = 0; p < N; ++p) {
+        scan_maxaff_v<T>(A[p], B[p], a.rscan, r15, r31);
+        Ax[p] = vdpp<kWaveShr1, 0xf>(A[p]);
+        Bx[p] = vdpp<kWaveShr1, 0xf>(B[p]);
     }
     if (lane == 63) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) xI[wave][c] = A[c], xI[wave][C + c] = B[c];
+        for (int c = 0; c < C; ++c) xI[wave][c] = comp(A[c / W], c % W), xI[wave][C + c] = comp(B[c / W], c % W);
     }
     RH_LP(1)
     __syncthreads();  // (1) the waves' aggregates are in LDS
     // prefix over the waves in front of this one, and the workgroup aggregate (uniform; LDS broadcast reads)
-    float Ap[C], Bp[C], AT[C], BT[C];
+    T Ap[N], Bp[N], AT[N], BT[N];
 #pragma unroll
-    for (int c = 0; c < C; ++c) Ap[c] = Bp[c] = AT[c] = BT[c] = 0.0f;
+    for (int p = 0; p < N; ++p) Ap[p] = Bp[p] = AT[p] = BT[p] = splat<T>(0.0f);
+    const T rLT = splat<T>(a.rL);
 #pragma unroll 1
     for (int k = 0; k < NW; ++k) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (k == wave) Ap[c] = AT[c], Bp[c] = BT[c];
-            const float Ak = xI[k][c], Bk = xI[k][C + c];
-            AT[c] = fmaxf(Ak, fma_(a.rL, AT[c], Bk));
-            BT[c] = fma_(a.rL, BT[c], Bk);
+        for (int p = 0; p < N; ++p) {
+            if (k == wave) Ap[p] = AT[p], Bp[p] = BT[p];
+            const T Ak = pair_of(&xI[k][p * W], T()), Bk = pair_of(&xI[k][C + p * W], T());
+            AT[p] = vmax(Ak, vfma(rLT, AT[p], Bk));
+            BT[p] = vfma(rLT, BT[p], Bk);
         }
     }
     if (wave == 0 && lane < 2 * C) {
         float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) v = lane == c ? AT[c] : (lane == C + c ? BT[c] : v);
+        for (int c = 0; c < C; ++c) v = lane == c ? comp(AT[c / W], c % W) : (lane == C + c ? comp(BT[c / W], c % W) : v);
         word_store(rec + RC::oA + lane, v);
     }
     // ---- look-back for the integrator over the workgroup tiles in front: I_in = f_{t-1}(f_{t-2}(... )) -----------------------
     // With w_j = r^(LW*j) and S_j = sum_{i<j} w_i B_i the composition of a window is
     //     max_{j<j*} (w_j A_j + S_j)  v  (w_j* Iend_j* + S_j*).
     // No j* in the window: fold it into (Ao, Bo, Co) and slide on, unless Co has decayed below f32 resolution.
+    // A workgroup's first tile walks this look-back here; every later tile received Iin from the poll point of the tile before.
     bool dead = false;
     float Iin[C];
-    {
+#pragma unroll
+    for (int c = 0; c < C; ++c) Iin[c] = Icarry[c];
+    const float wI = tab[6][lane];
+    // folds one polled window (aggregates AB, known state Ij at lane j*) into (Ao, Bo): true when the walk is over
+    auto fold_I = [&](float (&Ao)[C], float (&Bo)[C], float &Co, const float (&AB)[2 * C], const float (&Ij)[C], uint32_t jstar) {
+        const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float tot;
+            const float S = wave_excl_sum(front ? wI * AB[C + c] : 0.0f, tot);
+            const float cand = front ? fma_(wI, AB[c], S) : (star ? fma_(wI, Ij[c], S) : 0.0f);
+            const float Aw = wave_max(cand);
+            Ao[c] = fmaxf(Ao[c], fma_(Co, Aw, Bo[c]));
+            Bo[c] = fma_(Co, tot, Bo[c]);
+        }
+        if (jstar < 64) return true;  // reached a known state: Ao contains it
+        Co *= a.rL64;
+        return Co < kNegligible;
+    };
+    if (!have_I) {
         float Ao[C], Bo[C], Co = 1.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
         int64_t base = (int64_t)tile - 1;
-        const float wI = tab[6][lane];
         while (true) {
             float AB[2 * C], Ij[C];
             const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gstream, base, lane, a.jI, G, RC::oA, init, AB, Ij, dead);
             if (dead) break;
-            const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float tot;
-                const float S = wave_excl_sum(front ? wI * AB[C + c] : 0.0f, tot);
-                const float cand = front ? fma_(wI, AB[c], S) : (star ? fma_(wI, Ij[c], S) : 0.0f);
-                const float Aw = wave_max(cand);
-                Ao[c] = fmaxf(Ao[c], fma_(Co, Aw, Bo[c]));
-                Bo[c] = fma_(Co, tot, Bo[c]);
-            }
-            if (jstar < 64) break;  // reached a known state: Ao contains it
-            Co *= a.rL64;
+            if (fold_I(Ao, Bo, Co, AB, Ij, jstar)) break;
             base -= 64;
-            if (Co < kNegligible) break;
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
     }
-    // The next tile's samples are requested here (LDS-DMA into the other buffer): behind the integrator look-back, whose poll
-    // would otherwise have to wait for them (vmcnt retires in order), and a whole integrator run + barrier ahead of the next
-    // poll and of their use.
-    if (next_src) dma_share<V>(next_src, next_buf, lane);
+    // (with the look-back above, the next tile's samples are requested behind its poll)
+    if (!had_I && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(2)
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
-    float I[C], Pz[C];
+    T I[N], Pz[N];
     const float rwave = a.rwave[wave], rlane = tab[2][lane];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float Iw = fmaxf(Ap[c], fma_(rwave, Iin[c], Bp[c]));  // this wave's start state
-        I[c] = fmaxf(Ax[c], fma_(rlane, Iw, Bx[c]));                // this lane's
-        Pz[c] = 0.0f;
+    for (int p = 0; p < N; ++p) {
+        const T Iw = vmax(Ap[p], vfma(splat<T>(rwave), pair_of(Iin + p * W, T()), Bp[p]));  // this wave's start state
+        I[p] = vmax(Ax[p], vfma(splat<T>(rlane), Iw, Bx[p]));                               // this lane's
+        Pz[p] = splat<T>(0.0f);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float In = fmaxf(g[r][c], rel * I[c] + omr * g[r][c]);   // limit.rs:909-912, the reference's own expression
-            const float Pn = att * Pz[c] + oma * In;                        // limit.rs:913 from a zero state
+        for (int p = 0; p < N; ++p) {
+            const T In = vmax(g[r][p], relT * I[p] + omrT * g[r][p]);  // limit.rs:909-912, the reference's own expression
+            const T Pn = attT * Pz[p] + omaT * In;                      // limit.rs:913 from a zero state
             if (FULL || (uint32_t)r < nfl) {
-                I[c] = In;
-                Pz[c] = Pn;
+                I[p] = In;
+                Pz[p] = Pn;
             }
-            g[r][c] = Pz[c];
+            g[r][p] = Pz[p];
         }
-    float Px[C];
+    T Px[N];
     const float a15 = tab[3][lane], a31 = tab[4][lane];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        float Pi = Pz[c];
-        scan_lin(Pi, a.ascan, a15, a31);
-        Px[c] = dpp0<kWaveShr1, 0xf>(Pi);
-        if (lane == 63) xP[wave][c] = Pi;
+    for (int p = 0; p < N; ++p) {
+        T Pi = Pz[p];
+        scan_lin_v<T>(Pi, a.ascan, a15, a31);
+        Px[p] = vdpp<kWaveShr1, 0xf>(Pi);
+        if (lane == 63) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) xP[wave][p * W + w] = comp(Pi, w);
+        }
     }
     RH_LP(3)
     __syncthreads();  // (2) the waves' zero-state peak aggregates are in LDS
-    float Pp[C], PT[C];
+    T Pp[N], PT[N];
 #pragma unroll
-    for (int c = 0; c < C; ++c) Pp[c] = PT[c] = 0.0f;
+    for (int p = 0; p < N; ++p) Pp[p] = PT[p] = splat<T>(0.0f);
+    const T aLT = splat<T>(a.aL);
 #pragma unroll 1
     for (int k = 0; k < NW; ++k) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (k == wave) Pp[c] = PT[c];
-            PT[c] = fma_(a.aL, PT[c], xP[k][c]);
+        for (int p = 0; p < N; ++p) {
+            if (k == wave) Pp[p] = PT[p];
+            PT[p] = vfma(aLT, PT[p], pair_of(&xP[k][p * W], T()));
         }
     }
     if (wave == 0 && lane < C) {
         float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) v = lane == c ? PT[c] : v;
+        for (int c = 0; c < C; ++c) v = lane == c ? comp(PT[c / W], c % W) : v;
         word_store(rec + RC::oZ + lane, v);
     }
-    // ---- look-back for the peak: P_in = sum_{j<j*} a^(LW*j) Pz_{t-1-j} + a^(LW*j*) Pend_j* ------------------------------------
+    // ---- the poll point: look-back for the peak of this tile, P_in = sum_{j<j*} a^(LW*j) Pz_{t-1-j} + a^(LW*j*) Pend_j*, and the
+    //      integrator look-back of the workgroup's next tile (ticket order: its predecessors run or are done, and their
+    //      zero-state aggregates depend on nothing) -- both first windows in one round trip ----------------------------------
     float Pin[C];
     {
         float Co = 1.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) Pin[c] = 0.0f;
-        int64_t base = (int64_t)tile - 1;
         const float wP = tab[7][lane];
-        while (!dead) {
-            float Zj[C], Ej[C];
-            const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, base, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead);
-            if (dead) break;
+        auto fold_P = [&](const float (&Zj)[C], const float (&Ej)[C], uint32_t jstar) {
             const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -423,11 +602,43 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
                 (void)wave_excl_sum(front ? wP * Zj[c] : (star ? wP * Ej[c] : 0.0f), tot);
                 Pin[c] = fma_(Co, tot, Pin[c]);
             }
-            if (jstar < 64) break;
+            if (jstar < 64) return true;
             Co *= a.aL64;
-            base -= 64;
-            if (Co < kNegligible) break;
+            return Co < kNegligible;
+        };
+        const float *const gnext = a.gran + (uint64_t)nstream * a.tiles * G;
+        const float *const ninit = a.state_in ? a.state_in + (uint64_t)nstream * C * 2 : nullptr;
+        float Ao[C], Bo[C], CoI = 1.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
+        bool doneP = dead, doneI = dead || !SKEW || !has_next;
+        int64_t baseP = (int64_t)tile - 1, baseI = (int64_t)ntile - 1;
+        if (SKEW && !dead) {
+            PollPair<C> q;
+            poll_pair<C>(gstream, baseP, a.jP, init ? init + 1 : nullptr, gnext, baseI, a.jI, ninit, has_next, lane, q, dead);
+            if (!dead) {
+                doneP = fold_P(q.Z, q.E, q.jstarP);
+                if (has_next) doneI = fold_I(Ao, Bo, CoI, q.AB, q.Ij, q.jstarI);
+                baseP -= 64, baseI -= 64;
+            }
         }
+        while (!doneP && !dead) {  // (further windows: coefficients that do not forget within 64 tiles)
+            float Zj[C], Ej[C];
+            const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, baseP, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead);
+            if (dead) break;
+            doneP = fold_P(Zj, Ej, jstar);
+            baseP -= 64;
+        }
+        while (!doneI && !dead) {
+            float AB[2 * C], Ij[C];
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gnext, baseI, lane, a.jI, G, RC::oA, ninit, AB, Ij, dead);
+            if (dead) break;
+            doneI = fold_I(Ao, Bo, CoI, AB, Ij, jstar);
+            baseI -= 64;
+        }
+        have_I = SKEW && has_next && !dead;
+#pragma unroll
+        for (int c = 0; c < C; ++c) Icarry[c] = Ao[c];
     }
     if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
         if (lane == 0) atomicOr(a.ctl + 1, 1u);
@@ -436,13 +647,15 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     }
     RH_LP(4)
     // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----
-    float Ps[C], Pcur[C];
+    T Ps[N];
+    float Pcur[C];
     const float awave = a.awave[wave], alane = tab[5][lane];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float Pw = fma_(awave, Pin[c], Pp[c]);  // this wave's start state
-        Ps[c] = fma_(alane, Pw, Px[c]);               // this lane's
-        Pcur[c] = Ps[c];
+    for (int p = 0; p < N; ++p) {
+        const T Pw = vfma(splat<T>(awave), pair_of(Pin + p * W, T()), Pp[p]);  // this wave's start state
+        Ps[p] = vfma(splat<T>(alane), Pw, Px[p]);                              // this lane's
+#pragma unroll
+        for (int w = 0; w < W; ++w) Pcur[p * W + w] = comp(Ps[p], w);
     }
     const float kexp = -0.05f * LOG2_10;  // math.rs:51-56: 2^(dB * 0.05 * log2 10), the two constants folded
     __builtin_amdgcn_wave_barrier();
@@ -452,14 +665,28 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         v4f v = lds[slot_of<V>(lane, j)];
         float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (4 * j + i) / C, c = (4 * j + i) % C;
-            if (c == 0) ap *= att;  // a^(r+1)
-            Pcur[c] = fma_(ap, Ps[c], g[r][c]);
-            float mp = C > 2 ? 0.0f : Pcur[0];  // LimitMulti folds from 0.0
+        for (int i = 0; i < 4; i += W) {
+            const int r = (4 * j + i) / C, c0 = (4 * j + i) % C, p = c0 / W;
+            if (c0 == 0) ap *= att;  // a^(r+1)
+            const T Pnew = vfma(splat<T>(ap), Ps[p], g[r][p]);
+            // the reference advances one sample at a time: the gain of channel c sees this frame's peaks of the channels up to
+            // c and the previous frame's of the others
+            float mpw[W];
 #pragma unroll
-            for (int k = (C > 2 ? 0 : 1); k < C; ++k) mp = fmaxf(mp, Pcur[k]);
-            e[i] = e[i] * __builtin_amdgcn_exp2f(mp * kexp);
+            for (int w = 0; w < W; ++w) {
+                Pcur[c0 + w] = comp(Pnew, w);
+                float mp = C > 2 ? 0.0f : Pcur[0];  // LimitMulti folds from 0.0
+#pragma unroll
+                for (int k = (C > 2 ? 0 : 1); k < C; ++k) mp = fmaxf(mp, Pcur[k]);
+                mpw[w] = mp;
+            }
+            const T gain_db = pair_of(mpw, T()) * splat<T>(kexp);
+            T gain;
+            if constexpr (W == 2) gain.x = __builtin_amdgcn_exp2f(gain_db.x), gain.y = __builtin_amdgcn_exp2f(gain_db.y);
+            else gain = __builtin_amdgcn_exp2f(gain_db);
+            const T out = pair_of(e + i, T()) * gain;
+#pragma unroll
+            for (int w = 0; w < W; ++w) e[i + w] = comp(out, w);
         }
         v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
         lds[slot_of<V>(lane, j)] = v;
@@ -468,13 +695,14 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     if (a.state_out && nfl > 0 && f0 + (uint64_t)lane * R + nfl == a.frames) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float pe = Ps[c], apw = 1.0f;
+            const float ps = comp(Ps[c / W], c % W);
+            float pe = ps, apw = 1.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 apw *= att;
-                pe = (uint32_t)r + 1 == nfl ? fma_(apw, Ps[c], g[r][c]) : pe;
+                pe = (uint32_t)r + 1 == nfl ? fma_(apw, ps, comp(g[r][c / W], c % W)) : pe;
             }
-            a.state_out[((uint64_t)stream * C + c) * 2] = I[c];
+            a.state_out[((uint64_t)stream * C + c) * 2] = comp(I[c / W], c % W);
             a.state_out[((uint64_t)stream * C + c) * 2 + 1] = pe;
         }
     }
@@ -496,7 +724,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     RH_LP(6)
 }
 
-template <int C, int R, int NW>
+template <int C, int R, int NW, bool SKEW>
 __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
     static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW, "a lane's run is whole 16-byte vectors");
     constexpr int V = C * R / 4;  // 16-byte vectors per lane; a wave's share of a tile is V KiB
@@ -532,7 +760,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
     __syncthreads();
     uint32_t cur = s_ticket[0], nxt = s_ticket[1];
     uint32_t n = 0;
-    bool prev_full = false;
+    bool prev_full = false, have_I = false;
+    float Icarry[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) Icarry[c] = 0.0f;
     if (cur < total) {
         const float *src;
         uint32_t nf;
@@ -555,8 +786,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
             share(nxt, src2, nf2);
             if (nf2 != L) src2 = nullptr;  // a short share is fetched by its own tile, guarded
         }
-        if (nf == L) limit_tile<C, R, NW, true>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, src2, bufs[wave][(n + 1) & 1] RH_LP_ARG);
-        else limit_tile<C, R, NW, false>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, src2, bufs[wave][(n + 1) & 1] RH_LP_ARG);
+        // SKEW (the host's choice when there are more streams than workgroups): the integrator look-back of the next tile is
+        // walked at THIS tile's poll point.  Its predecessors are then old tickets (nearest: nxt - S < cur) that published long
+        // ago.  With few streams the predecessor of the next tile is some workgroup's own next tile; waiting for it here would
+        // chain the workgroups (measured: 64 streams, 0.31 -> 0.76 ms).
+        const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
+        const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
+        v4f *const buf2 = bufs[wave][(n + 1) & 1];
+        if (nf == L) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2 RH_LP_ARG);
+        else limit_tile<C, R, NW, false, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2 RH_LP_ARG);
         prev_full = nf == L;
         cur = nxt;
         nxt = s_ticket[(n + 2) % 3];  // written before barrier (1) of the tile just done
@@ -585,9 +823,9 @@ __global__ void k_limit_init(uint32_t *ctl, float *snap, const float *state, uin
 using LimitFn = void (*)(const LimitArgs);
 struct LimitVariant {
     int C, R, NW;
-    LimitFn fn;
+    LimitFn fn, fn_skew;  // fn_skew: the variant with the skewed integrator look-back, or nullptr
 };
-#define RH_LV(c, r, nw) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw>}
+#define RH_LV(c, r, nw) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw, false>, (nw) >= 4 ? &k_limit_scan<c, r, nw, ((nw) >= 4)> : nullptr}
 const LimitVariant kVariants[] = {
     RH_LV(1, 8, 8),  RH_LV(1, 16, 8), RH_LV(1, 16, 16), RH_LV(1, 8, 1),
     RH_LV(2, 8, 8),  RH_LV(2, 8, 16), RH_LV(2, 8, 4),  RH_LV(2, 8, 1), RH_LV(2, 16, 8), RH_LV(2, 16, 4),
@@ -728,7 +966,9 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
         if (const char *g = getenv("RH_LIMIT_GRID")) grid = atoi(g) > 0 ? (uint64_t)atoi(g) : grid;  // diagnostics
         if (e == hipSuccess) {
             void *args[] = {&a};
-            e = hipLaunchKernel(reinterpret_cast<const void *>(v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
+            bool skew = v->fn_skew && grid < n_streams;  // see k_limit_scan: only with more streams than workgroups
+            if (const char *k = getenv("RH_LIMIT_SKEW")) skew = v->fn_skew && k[0] == '1';  // tuning aid
+            e = hipLaunchKernel(reinterpret_cast<const void *>(skew ? v->fn_skew : v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
         }
     }
     if (e != hipSuccess) {
