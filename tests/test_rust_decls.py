@@ -1,0 +1,137 @@
+"""INTEGRATION.md's Rust shim has never met a compiler (no cargo in this image), so this is what a compiler would check
+first: every `extern "C"` declaration and `#[repr(C)]` struct in the Rust text is compared, type by type, with the
+prototype / struct of the same name in include/rodio_hip.h (missing 2: "nothing checks that its
+#[repr(C)] structs match the header")."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Rust type -> the C spellings it may stand for (after whitespace / const normalisation below)
+SCALARS = {
+    "f32": "float", "f64": "double", "i8": "int8_t", "u8": "uint8_t", "i16": "int16_t", "u16": "uint16_t", "i32": "int32_t",
+    "u32": "uint32_t", "i64": "int64_t", "u64": "uint64_t", "usize": "size_t", "core::ffi::c_void": "void", "c_void": "void",
+    "core::ffi::c_char": "char", "RhStatus": "rh_status", "RhStream": "rh_stream", "RhEvent": "rh_event",
+}
+STRUCTS = {"RhRlm": "rh_rlm", "RhRlmConfig": "rh_rlm_config", "RhEcho": "rh_echo", "RhResampler": "rh_resampler", "RhLimitParams": "rh_limit_params",
+           "RhAgcParams": "rh_agc_params", "RhComm": "rh_comm"}
+
+
+def rust_to_c(t):
+    t = t.strip()
+    if t.startswith("*mut "):
+        return rust_to_c(t[5:]) + " *"
+    if t.startswith("*const "):
+        return rust_to_c(t[7:]) + " const *"
+    if t in SCALARS:
+        return SCALARS[t]
+    if t in STRUCTS:
+        return STRUCTS[t]
+    raise AssertionError(f"Rust type {t!r} has no C counterpart in this table")
+
+
+def norm_c(t):
+    """'const float *const *srcs' style spellings -> canonical 'const float * const *' tokens, name stripped by the caller"""
+    toks = re.sub(r"\s+", " ", t.replace("*", " * ")).strip().split(" ")
+    if len(toks) >= 2 and toks[0] == "const":  # 'const T' -> 'T const' (east const, what rust_to_c emits)
+        toks = [toks[1], "const"] + toks[2:]
+    return " ".join(toks)
+
+
+def c_params(proto):
+    inner = proto[proto.index("(") + 1: proto.rindex(")")].strip()
+    if inner in ("", "void"):
+        return []
+    out = []
+    for p in inner.split(","):
+        p = p.strip()
+        m = re.match(r"^(.*?)(\b[A-Za-z_][A-Za-z0-9_]*)?(\[\d*\])?$", p)
+        ty, name, arr = m.group(1), m.group(2), m.group(3)
+        if name in ("float", "void", "char", "rh_stream", "rh_event") or (name and name.endswith("_t")):  # unnamed parameter
+            ty, name = ty + name, None
+        ty = norm_c(ty)
+        if arr:  # `float out[8]` decays to a pointer
+            ty = ty + " *"
+        out.append(ty)
+    return out
+
+
+def header():
+    text = open(os.path.join(ROOT, "include", "rodio_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_ \*]*?)\b(rh_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        protos[m.group(2)] = (norm_c(m.group(1)), c_params("(" + m.group(3) + ")"))
+    structs = {}
+    for m in re.finditer(r"typedef struct (rh_[a-z0-9_]+)\s*\{(.*?)\}\s*\1\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ty, names = decl.split(None, 1)
+            for n in names.split(","):
+                n = n.strip()
+                a = re.match(r"^(\w+)\[(\d+)\]$", n)
+                fields.append((a.group(1), f"{ty}[{a.group(2)}]") if a else (n, ty))
+        structs[m.group(1)] = fields
+    return protos, structs
+
+
+def rust_blocks():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = "\n".join(re.findall(r"```rust\n(.*?)```", md, flags=re.S))
+    code = re.sub(r"//[^\n]*", "", code)
+    fns = {}
+    for blk in re.findall(r'extern "C"\s*\{(.*?)\n\}', code, flags=re.S):
+        for m in re.finditer(r"pub fn (rh_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", blk, flags=re.S):
+            args = [a.strip() for a in re.sub(r"\s+", " ", m.group(2)).split(",") if a.strip()]
+            fns[m.group(1)] = ([a.split(":", 1)[1].strip() for a in args], (m.group(3) or "()").strip())
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", code, flags=re.S):
+        fields = []
+        for f in m.group(2).split(","):
+            f = re.sub(r"\s+", " ", f).strip()
+            if not f:
+                continue
+            name, ty = f.replace("pub ", "").split(":", 1)
+            fields.append((name.strip(), ty.strip()))
+        structs[m.group(1)] = fields
+    return fns, structs
+
+
+def test_every_rust_extern_matches_the_header_prototype():
+    protos, _ = header()
+    fns, _ = rust_blocks()
+    assert len(fns) >= 25, sorted(fns)
+    for name, (args, ret) in sorted(fns.items()):
+        assert name in protos, f"{name} is declared in INTEGRATION.md but not in include/rodio_hip.h"
+        c_ret, c_args = protos[name]
+        assert norm_c(rust_to_c(ret)) == c_ret, (name, ret, c_ret)
+        assert len(args) == len(c_args), (name, args, c_args)
+        for i, (r, c) in enumerate(zip(args, c_args)):
+            want = norm_c(rust_to_c(r))
+            # top-level const of a by-value parameter / pointer (`T *const p`) is not part of the ABI
+            c = re.sub(r" \* const$", " *", c)
+            assert want == c, f"{name} argument {i}: Rust `{r}` = C `{want}`, header says `{c}`"
+
+
+def test_repr_c_structs_match_the_header_field_by_field():
+    _, cstructs = header()
+    _, rstructs = rust_blocks()
+    checked = 0
+    for rname, rfields in rstructs.items():
+        if rfields and rfields[0][0] == "_private":  # opaque handle
+            assert STRUCTS[rname] not in cstructs  # ... and the header keeps it opaque too
+            continue
+        cname = STRUCTS[rname]
+        assert cname in cstructs, (rname, cname)
+        cf = cstructs[cname]
+        assert [n for n, _ in rfields] == [n for n, _ in cf], (rname, [n for n, _ in rfields], [n for n, _ in cf])
+        for (n, rt), (_, ct) in zip(rfields, cf):
+            a = re.match(r"^\[(\w+); (\d+)\]$", rt)
+            want = f"{SCALARS[a.group(1)]}[{a.group(2)}]" if a else SCALARS[rt]
+            assert want == ct, (rname, n, rt, ct)
+        checked += 1
+    assert checked >= 1
