@@ -404,6 +404,7 @@ public:
         const std::uint32_t rate = rate_;
         auto st = state(2u * ch);
         const rh_stream sm = stream_;
+        scan_kernels_ = true;
         return push([=](Ctx &c) {
             check(rh_limit(c.out, c.in, c.n / ch, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
             return c.n / ch * ch;
@@ -435,6 +436,9 @@ public:
     GpuSource &fade_out(Nanos duration) { return linear_gain_ramp(duration, 1.0f, 0.0f, true); }  // fadeout.rs:13
 
 protected:
+    void block_done() override {  // a bounded wait inside the limiter's scan expired (never seen on a healthy device): fail loudly
+        if (scan_kernels_) check(rh_async_status(), "rh_async_status");
+    }
     void enqueue(Slot &s) override {
         const std::size_t want = block_frames_ * up_->channels();
         s.in.reset(want);
@@ -534,6 +538,7 @@ private:
     mutable std::uint32_t in_rate_ = 0;
     std::vector<Stage> stages_;
     detail::DeviceBuf a_, b_;
+    bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
 };
 
 // ---------------------------------------------------------------- GpuMixer: the fused mixer path ----

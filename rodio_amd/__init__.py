@@ -25,6 +25,7 @@ from .source import (  # noqa: F401
     UniformSourceIterator,
     WavDecoder,
     agc_batch,
+    async_status,
     agc_state,
     biquad_batch,
     limit_batch,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "rh_version": (i32, []),
     "rh_status_string": (C.c_char_p, [i32]),
     "rh_last_hip_error": (C.c_char_p, []),
+    "rh_async_status": (i32, []),
     "rh_init": (i32, [i32]),
     "rh_device_name": (i32, [C.c_char_p, sz]),
     "rh_malloc": (i32, [C.POINTER(vp), sz]),

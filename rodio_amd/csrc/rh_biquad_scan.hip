@@ -45,7 +45,9 @@ struct BqArgs {
     float *gran;            // [S][tiles][2*C] hand-off words: the tiles' zero-state aggregates (scan basis)
     const float *state_in;  // [S][C][4] {x1,x2,y1,y2} snapshot, or nullptr (zero state)
     const BqTabs *tabs;
-    uint32_t *ctl;          // [0] ticket, [1] status
+    uint32_t *ctl;          // [0] ticket
+    uint32_t *status;          // the library's sticky failure word (rh_async_status)
+    uint32_t spin;             // polls of one hand-off before the tile gives up (kSpinLimit; RH_SCAN_SPIN_LIMIT overrides)
     uint64_t frames, stride;
     uint32_t n_streams, tiles, J;
     float b0, c1, c2, na1, na2;
@@ -246,7 +248,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
                 }
             }
             if (__all(have)) break;
-            if (++spins > kSpinLimit) {
+            if (++spins > a.spin) {
                 dead = true;
                 break;
             }
@@ -265,7 +267,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
             Tin[c][1] = tot;
         }
         if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
-            if (lane == 0) atomicOr(a.ctl + 1, 1u);
+            if (lane == 0) atomicOr(a.status, 1u);
 #pragma unroll
             for (int c = 0; c < C; ++c) Tin[c][0] = Tin[c][1] = __builtin_nanf("");
         }
@@ -539,7 +541,8 @@ struct BqVariant {
 #define RH_BV(c, r, nw) BqVariant{c, r, nw, &k_biquad_scan<c, r, nw>}
 const BqVariant kVariants[] = {
     RH_BV(1, 16, 8), RH_BV(1, 16, 1), RH_BV(2, 8, 8), RH_BV(2, 16, 8), RH_BV(2, 8, 4), RH_BV(2, 8, 1), RH_BV(3, 4, 8), RH_BV(3, 4, 1),
-    RH_BV(4, 4, 8),  RH_BV(4, 4, 1),  RH_BV(6, 4, 8), RH_BV(6, 4, 1),  RH_BV(8, 4, 8), RH_BV(8, 4, 1),
+    RH_BV(4, 4, 8),  RH_BV(4, 4, 1),  RH_BV(5, 4, 8), RH_BV(5, 4, 1),  RH_BV(6, 4, 8), RH_BV(6, 4, 1), RH_BV(7, 4, 8), RH_BV(7, 4, 1),
+    RH_BV(8, 4, 8),  RH_BV(8, 4, 1),
 };
 #undef RH_BV
 
@@ -585,6 +588,8 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     unsigned char *scratch = nullptr;
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
+    a.status = rh::g_async_status;
+    a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64), *xlast = snap + n_sc * 4;
     const uint64_t n_words = gran_bytes / 4;

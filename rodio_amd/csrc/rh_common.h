@@ -13,6 +13,7 @@ namespace rh {
 extern bool g_initialized;
 extern int g_device;
 extern int g_num_cus;
+extern uint32_t *g_async_status;  // device word: sticky failure flag of the state-less scan kernels (rh_async_status)
 void set_hip_error(hipError_t e, const char *what);
 
 #define RH_HIP_TRY(expr)                                   \

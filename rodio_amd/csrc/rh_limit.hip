@@ -80,7 +80,9 @@ struct LimitArgs {
     float *gran;               // [S][tiles][Rec<C>::stride] hand-off words: A[C] B[C] | Iend[C] | Pz[C] | Pend[C] (see Rec)
     const float *state_in;     // [S][C][2] {integrator, peak} snapshot taken in front of the launch, or nullptr
     float *state_out;          // the caller's state, or nullptr
-    uint32_t *ctl;             // [0] ticket, [1] status
+    uint32_t *ctl;             // [0] ticket
+    uint32_t *status;          // the library's sticky failure word (rh_async_status)
+    uint32_t spin;             // polls of one hand-off before the tile gives up (kSpinLimit; RH_SCAN_SPIN_LIMIT overrides: tests of the failure path)
     uint64_t frames;           // per stream
     uint64_t stride;           // floats between streams
     uint32_t n_streams, tiles; // tiles per stream
@@ -184,7 +186,7 @@ __device__ unsigned long long g_limit_prof[16];
 // associative -- this way the result does not depend on it (the same input gives the same bits, run after run).
 template <int C, int NAGG, int WAGG>
 __device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_t base, int lane, uint32_t reach, uint32_t stride, uint32_t off_agg,
-                                                const float *init, float (&agg)[NAGG], float (&inc)[C], bool &dead) {
+                                                const float *init, float (&agg)[NAGG], float (&inc)[C], bool &dead, const uint32_t spin_limit) {
     const int64_t idx = base - lane;
     const bool real = idx >= 0 && (uint32_t)lane < reach;
     const float *pr = gran_stream + (real ? (uint64_t)idx : 0) * stride;
@@ -211,7 +213,7 @@ __device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_
             }
         }
         if (__all(have || (uint32_t)lane > jstar)) return jstar;  // lanes behind j* are not needed
-        if (++spins > kSpinLimit) {
+        if (++spins > spin_limit) {
             dead = true;
             return 64u;
         }
@@ -228,7 +230,7 @@ struct PollPair {
 };
 template <int C>
 __device__ __forceinline__ void poll_pair(const float *gsP, int64_t baseP, uint32_t reachP, const float *initP, const float *gsI, int64_t baseI, uint32_t reachI,
-                                          const float *initI, bool wantI, int lane, PollPair<C> &o, bool &dead) {
+                                          const float *initI, bool wantI, int lane, PollPair<C> &o, bool &dead, const uint32_t spin_limit) {
     typedef Rec<C> RC;
     constexpr uint32_t G = RC::stride;
     const int64_t idxP = baseP - lane, idxI = baseI - lane;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void poll_pair(const float *gsP, int64_t baseP, uint3
             }
         }
         if (__all((haveP || (uint32_t)lane > o.jstarP) && (haveI || (uint32_t)lane > o.jstarI))) return;
-        if (++spins > kSpinLimit) {
+        if (++spins > spin_limit) {
             dead = true;
             return;
         }
@@ -521,7 +523,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         int64_t base = (int64_t)tile - 1;
         while (true) {
             float AB[2 * C], Ij[C];
-            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gstream, base, lane, a.jI, G, RC::oA, init, AB, Ij, dead);
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gstream, base, lane, a.jI, G, RC::oA, init, AB, Ij, dead, a.spin);
             if (dead) break;
             if (fold_I(Ao, Bo, Co, AB, Ij, jstar)) break;
             base -= 64;
@@ -615,7 +617,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         int64_t baseP = (int64_t)tile - 1, baseI = (int64_t)ntile - 1;
         if (SKEW && !dead) {
             PollPair<C> q;
-            poll_pair<C>(gstream, baseP, a.jP, init ? init + 1 : nullptr, gnext, baseI, a.jI, ninit, has_next, lane, q, dead);
+            poll_pair<C>(gstream, baseP, a.jP, init ? init + 1 : nullptr, gnext, baseI, a.jI, ninit, has_next, lane, q, dead, a.spin);
             if (!dead) {
                 doneP = fold_P(q.Z, q.E, q.jstarP);
                 if (has_next) doneI = fold_I(Ao, Bo, CoI, q.AB, q.Ij, q.jstarI);
@@ -624,14 +626,14 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         }
         while (!doneP && !dead) {  // (further windows: coefficients that do not forget within 64 tiles)
             float Zj[C], Ej[C];
-            const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, baseP, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead);
+            const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, baseP, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead, a.spin);
             if (dead) break;
             doneP = fold_P(Zj, Ej, jstar);
             baseP -= 64;
         }
         while (!doneI && !dead) {
             float AB[2 * C], Ij[C];
-            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gnext, baseI, lane, a.jI, G, RC::oA, ninit, AB, Ij, dead);
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gnext, baseI, lane, a.jI, G, RC::oA, ninit, AB, Ij, dead, a.spin);
             if (dead) break;
             doneI = fold_I(Ao, Bo, CoI, AB, Ij, jstar);
             baseI -= 64;
@@ -641,7 +643,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         for (int c = 0; c < C; ++c) Icarry[c] = Ao[c];
     }
     if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
-        if (lane == 0) atomicOr(a.ctl + 1, 1u);
+        if (lane == 0) atomicOr(a.status, 1u);
 #pragma unroll
         for (int c = 0; c < C; ++c) Pin[c] = __builtin_nanf("");
     }
@@ -947,6 +949,8 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     unsigned char *scratch = nullptr;
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
+    a.status = rh::g_async_status;
+    a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64);
     const uint64_t n_words = gran_bytes / 4;

@@ -10,6 +10,7 @@ namespace rh {
 bool g_initialized = false;
 int g_device = -1;
 int g_num_cus = 256;
+uint32_t *g_async_status = nullptr;
 static thread_local std::string g_last_error;
 void set_hip_error(hipError_t e, const char *what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -112,8 +113,21 @@ rh_status rh_init(int32_t device) {
     }
     rh::g_num_cus = prop.multiProcessorCount;
     rh::g_device = device;
+    if (!rh::g_async_status) {
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&rh::g_async_status), 128));
+        RH_HIP_TRY(rh::fill_now(rh::g_async_status, 0, 128));
+    }
     rh::g_initialized = true;
     return RH_OK;
+}
+
+rh_status rh_async_status(void) {
+    RH_REQUIRE_INIT();
+    uint32_t v = 0;
+    RH_HIP_TRY(hipMemcpy(&v, rh::g_async_status, sizeof(v), hipMemcpyDeviceToHost));
+    if (!v) return RH_OK;
+    RH_HIP_TRY(rh::fill_now(rh::g_async_status, 0, sizeof(v)));
+    return RH_ERR_TIMEOUT;
 }
 
 rh_status rh_device_name(char *buf, size_t cap) {

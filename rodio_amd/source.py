@@ -44,6 +44,14 @@ def init(device: int = 0):
     _initialized = True
 
 
+def async_status(synchronize: bool = True):
+    """rh_async_status(): raises RhError(RH_ERR_TIMEOUT) if a hand-off inside a handle-less scan kernel (`limit`, `biquad_batch`
+    mode 1) expired in a launch that has completed -- by default after a device synchronise."""
+    if synchronize:
+        _t().cuda.synchronize()
+    check(lib.rh_async_status(), "rh_async_status")
+
+
 def _ensure():
     if not _initialized:
         init(_t().cuda.current_device() if _t().cuda.is_available() else 0)

@@ -143,7 +143,7 @@ def _truth(x, co, ch):
     return lfilter(c[:3], [1.0, c[3], c[4]], x.astype(np.float64).reshape(-1, ch), axis=0).reshape(-1)
 
 
-@pytest.mark.parametrize("ch", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("frames", [1, 2, 3, 255, 512, 513, 4096, 4097, 8192 + 5, 70001])
 def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
     import torch
@@ -165,6 +165,7 @@ def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
                 assert e_par <= 2.0 * e_seq + 1e-7, (kind, s, e_par, e_seq)
     finally:
         del os.environ["RH_BIQUAD_NO_FALLBACK"]
+    G.async_status()  # no hand-off inside the scan expired
 
 
 @pytest.mark.parametrize("ch", [1, 2, 4])

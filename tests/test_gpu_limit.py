@@ -125,6 +125,7 @@ def test_limiter_full_block_every_sample(G, O):
     err = float(np.max(np.abs(out - ref)))
     print(f"[limit 1 Mi frames] err={err:.3e}")
     assert err <= TOL
+    G.async_status()  # rh_async_status: no hand-off inside the scan expired in anything launched so far
 
 
 def test_limiter_reference_order_kernel_agrees(G, O):
@@ -189,3 +190,37 @@ def test_reference_limiter_stereo_processing(G, O):  # tests/limit.rs:111-155
     y = G.SamplesBuffer(2, 44100, st).limit(threshold=-3.0).collect()
     assert float(np.max(np.abs(y[0::2]))) <= 1.5 and float(np.max(np.abs(y[1::2]))) <= 1.5
     assert float(np.max(np.abs(y - O.SamplesBuffer(2, 44100, st).limit(threshold=-3.0).collect()))) <= TOL
+
+
+def test_an_expired_hand_off_is_reported_and_poisons_the_output(G, O):
+    """The failure path of the handle-less scan kernels (never seen on a healthy device): with the poll budget forced to zero
+    (RH_SCAN_SPIN_LIMIT=0: a hand-off that is not there at the first look counts as lost) tiles give up, their output is NaN --
+    never plausible audio -- and rh_async_status reports RH_ERR_TIMEOUT once."""
+    import torch
+
+    from rodio_amd import _lib
+
+    G.async_status()  # clean slate
+    x = torch.from_numpy(np.stack([_signal(70 + s, 1 << 18, 2) for s in range(64)])).cuda()
+    os.environ["RH_SCAN_SPIN_LIMIT"] = "0"
+    try:
+        bad = 0
+        for _ in range(5):  # tiles of one stream run side by side: some first looks come too early
+            out = G.limit_batch(x, 2, 48000)
+            torch.cuda.synchronize()
+            bad += int(torch.isnan(out).sum())
+        co = G.biquad_coeffs("low_pass", 200, 0.5, 48000)
+        outb = G.biquad_batch(x, co, mode=1)
+        torch.cuda.synchronize()
+        bad += int(torch.isnan(outb).sum())
+    finally:
+        del os.environ["RH_SCAN_SPIN_LIMIT"]
+    assert bad > 0, "no hand-off was late in six launches of 64 x 32 tiles: the test lost its premise"
+    with pytest.raises(_lib.RhError) as e:
+        G.async_status()
+    assert e.value.status == 5  # RH_ERR_TIMEOUT
+    G.async_status()  # sticky once, then clear
+    out = G.limit_batch(x, 2, 48000)  # and the next launch is whole again
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(out).any())
+    G.async_status()
