@@ -586,7 +586,8 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     const size_t gran_bytes = (size_t)n_streams * tiles64 * 2 * channels * sizeof(float);
     const size_t head = 64 + ((n_sc * 6 * 4 + 63) & ~size_t(63));  // control words, state snapshot [n][4], last inputs [n][2]
     unsigned char *scratch = nullptr;
-    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
+    std::unique_lock<std::mutex> scratch_hold;
+    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
     a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;

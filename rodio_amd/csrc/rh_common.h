@@ -1,5 +1,6 @@
 // rh_common.h -- shared host-side helpers of librodio_hip (gfx950 only).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -61,7 +62,9 @@ hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s);
 // under a launch that was still using them (zeros where the launch had written: 2 of 150 short GpuSource chains on ROCm 7.2
 // even with every fill done by our own kernels, 0 of 750 with this -- profiles/r02_limit_flake.md).  Freed by rh_stream_destroy for the
 // library's own streams; a foreign stream's buffer (a few hundred KiB) lives until the process ends.
-hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out);
+// The caller keeps `hold` (taken here) until its last launch that uses the buffer is enqueued: two host threads that launch on
+// the same stream then cannot interleave their initialisation and kernel launches.
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold);
 
 // Grid for a memory-bound grid-stride kernel: enough 256-thread blocks to fill 256 CUs x 8,
 // capped so small inputs stay small (cdna_hip_programming.md G11).

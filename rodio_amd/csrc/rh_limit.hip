@@ -947,7 +947,8 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     const size_t gran_bytes = (size_t)n_streams * tiles64 * rec_stride(channels) * sizeof(float);
     const size_t head = 64 + ((n_state * 4 + 63) & ~size_t(63));
     unsigned char *scratch = nullptr;
-    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch)));
+    std::unique_lock<std::mutex> scratch_hold;
+    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
     a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;

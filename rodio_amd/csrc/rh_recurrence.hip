@@ -473,7 +473,8 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
         return RH_OK;
     }
     float *st = state;
-    if (!st) RH_HIP_TRY(rh::stream_scratch(s, sizeof(float) * kAgcStateFloats * n_streams, reinterpret_cast<void **>(&st)));
+    std::unique_lock<std::mutex> scratch_hold;  // a state-less call borrows the stream's scratch for the kernel's own state
+    if (!st) RH_HIP_TRY(rh::stream_scratch(s, sizeof(float) * kAgcStateFloats * n_streams, reinterpret_cast<void **>(&st), scratch_hold));
     hipLaunchKernelGGL(k_agc_seq, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, st, state ? 0 : 1);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {

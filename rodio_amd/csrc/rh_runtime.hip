@@ -36,8 +36,8 @@ struct Scratch {
 std::mutex g_scratch_mu;
 std::unordered_map<hipStream_t, Scratch> g_scratch;
 }  // namespace
-hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out) {
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold) {
+    hold = std::unique_lock<std::mutex>(g_scratch_mu);
     Scratch &e = g_scratch[s];
     if (e.cap < bytes) {
         if (e.p) {  // launches on `s` may still be using it

@@ -23,4 +23,4 @@ st = fn(buf)
 names = ["load", "gain+segment", "lookback_I", "integrator", "lookback_P", "gain_stage", "store"]
 tot = sum(buf[:7]) or 1
 print(json.dumps({"status": st, "ms": e0.elapsed_time(e1) / reps, "cycles_share": {k: round(buf[i] / tot, 3) for i, k in enumerate(names)},
-                  "cycles_per_tile": {k: round(buf[i] / reps / (S * -(-n // (64 * 8))), 0) for i, k in enumerate(names)}}))
+                  "counter_units_per_wave_share": {k: round(buf[i] / reps / (S * -(-n // (64 * 16))), 0) for i, k in enumerate(names)}}))  # shares of 64 x 16 frames (the shipped R = 16)
