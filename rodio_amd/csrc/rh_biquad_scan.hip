@@ -48,6 +48,7 @@ struct BqArgs {
     uint32_t *ctl;          // [0] ticket
     uint32_t *status;          // the library's sticky failure word (rh_async_status)
     uint32_t spin;             // polls of one hand-off before the tile gives up (kSpinLimit; RH_SCAN_SPIN_LIMIT overrides)
+    uint32_t dma_top;          // 1: the next tile's samples are requested at the top of a tile, not right in front of its poll
     uint64_t frames, stride;
     uint32_t n_streams, tiles, J;
     float b0, c1, c2, na1, na2;
@@ -91,6 +92,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     int lane = lane_;
     asm volatile("" : "+v"(lane));  // per-tile address arithmetic is recomputed, not hoisted into registers that live for the whole kernel
     constexpr int V = C * R / 4;
+    constexpr int kPrefixUnroll = C <= 2 ? NW : 1;
     constexpr int HV = (2 * C + 3) / 4;  // vectors that hold the two frames in front of a run
     constexpr uint32_t L = 64u * R, LW = L * NW;
     constexpr uint32_t G = 2 * C;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     float Wp[C][2], ZT[C][2];  // state at this wave's start from the waves in front (zero tile start); the tile's aggregate
 #pragma unroll
     for (int c = 0; c < C; ++c) Wp[c][0] = Wp[c][1] = ZT[c][0] = ZT[c][1] = 0.0f;
-#pragma unroll 1
+#pragma unroll kPrefixUnroll  // few channels: all LDS reads of the loop leave together (one latency instead of NW)
     for (int k = 0; k < NW; ++k) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -209,11 +211,15 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
         for (int c = 0; c < C; ++c) v = lane == 2 * c ? ZT[c][0] : (lane == 2 * c + 1 ? ZT[c][1] : v);
         word_store(rec + lane, v);
     }
-    // the next tile's samples (and the two frames in front of its share) are requested before the poll: the two latencies overlap
+    // (a.dma_top = 0 only: the next tile's samples and the two frames in front of its share requested right before the poll --
+    //  the poll then retires behind them, vmcnt being in order: 6 % slower than requesting them at the top of the tile)
     if (next_src) {
         dma_share<V>(next_src, next_buf, lane);
         if (lane < HV) glds16(next_src - 4 * HV, (uint32_t)lane * 16u, (uint32_t)(uintptr_t)(lds_u8 *)next_halo);
     }
+    float lk[4], lM[4];  // per-lane matrices of the look-back and of the correction: read here, a poll ahead of their use
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lk[q] = tab[12 + q][lane], lM[q] = tab[q][lane];
     // ---- look-back: T_in = sum_{j<J} B^(LW*j) ZT(t-1-j)  (+ B^(LW*t) z_state while the carried state still reaches) -------
     float Tin[C][2];
     {
@@ -254,9 +260,6 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        float lk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lk[q] = tab[12 + q][lane];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float t0 = 0.0f, t1 = 0.0f, tot;
@@ -274,9 +277,6 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     }
     // ---- the homogeneous response to the lane's true start state, the result back into the LDS slots ----------------------
     {
-        float lM[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lM[q] = tab[q][lane];
         const float *wM = a.waveM[wave];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
         // (the halo of a stream's first share does not exist: bq_tile takes the carried state there, and its DMA must not run)
         const float *dma_src = src2;
         v4f *nb = bufs[wave][(n + 1) & 1], *nh = halos[wave][(n + 1) & 1];
-        if (src2 && first2) {  // fetch the share here, without the halo
-            dma_share<V>(src2, nb, lane);
+        if (src2 && (first2 || a.dma_top)) {  // fetched here: a stream's first share has no halo; dma_top: see BqArgs
+            fetch(src2, first2, nb, nh);
             dma_src = nullptr;
         }
         if (nf == L) bq_tile<C, R, NW, true>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead);
@@ -590,6 +590,7 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
+    a.dma_top = getenv("RH_SCAN_DMA_TOP") ? (uint32_t)atoi(getenv("RH_SCAN_DMA_TOP")) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
     a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64), *xlast = snap + n_sc * 4;

@@ -39,6 +39,7 @@
 //                                                                              56 % of their cycles, VALU busy 19 %: sync-bound)
 //     ... two channels per instruction (v_pk_*_f32, -23 % VALU)   0.31 ms = 43 %; 2048 streams x 32 Ki: 0.305 ms
 //     ... one poll point per tile when streams > workgroups       0.31 ms = 43 %; 2048 streams x 32 Ki: 0.280 ms = 48 %
+//     ... the next tile's DMA at the top of every tile            0.286 ms = 47 %; 2048 streams x 32 Ki: 0.288 ms = 47 %
 //         (the next tile's integrator look-back rides on this tile's peak look-back; with FEW streams that chains the
 //          workgroups -- 0.76 ms -- so there the walk stays inside the tile)
 // What is left per tile (~9 us for 128 KiB of traffic, one workgroup of 8 waves per CU because of the 128 KiB of LDS the
@@ -83,6 +84,7 @@ struct LimitArgs {
     uint32_t *ctl;             // [0] ticket
     uint32_t *status;          // the library's sticky failure word (rh_async_status)
     uint32_t spin;             // polls of one hand-off before the tile gives up (kSpinLimit; RH_SCAN_SPIN_LIMIT overrides: tests of the failure path)
+    uint32_t dma_top;          // 1: the next tile's samples are requested at the top of every tile
     uint64_t frames;           // per stream
     uint64_t stride;           // floats between streams
     uint32_t n_streams, tiles; // tiles per stream
@@ -393,6 +395,9 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     typedef typename Pk<C>::T T;
     constexpr int W = Pk<C>::W, N = Pk<C>::N;
     static_assert(W == 1 || 4 % W == 0, "a pair never straddles two 16-byte vectors");
+    // the loops over the waves' aggregates: where registers allow (the variants that run 2 waves per SIMD) all their LDS reads
+    // leave together, one latency instead of NW
+    constexpr int kPrefixUnroll = (C <= 2 && C * R > 16) ? NW : 1;
     const float att = a.attack;
     const T relT = splat<T>(a.release), omrT = splat<T>(1.0f - a.release), attT = splat<T>(a.attack), omaT = splat<T>(1.0f - a.attack);
     const GainK gk{LOG10_2 * 20.0f, -a.threshold, 0.5f * a.knee_width, a.knee_width, a.inv_knee_8};
@@ -406,10 +411,12 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     const float *const init = a.state_in ? a.state_in + (uint64_t)stream * C * 2 : nullptr;
     RH_LP_DECL
     // The next tile's samples (LDS-DMA into the other buffer, whose last reader was the previous tile's store) are requested in
-    // front of everything when this tile has no poll before its integrator run: its one poll point then lies a whole gain +
-    // integrator run behind them (vmcnt retires in order: a poll waits for every fetch issued before it).
+    // front of everything: vmcnt retires in order, so a poll waits for every fetch issued before it, and the top of the tile
+    // is as far ahead of the polls as a fetch can be (a.dma_top = 0, the round-2 first version, put it behind the integrator
+    // look-back: that poll was then free, but the peak poll paid the whole fetch latency).
     const bool had_I = SKEW && have_I;
-    if (had_I && next_src) dma_share<V>(next_src, next_buf, lane);
+    const bool dma_first = had_I || a.dma_top;
+    if (dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     // ---- the samples: whole shares were put into LDS by the DMA issued a tile ago; a short share (end of a stream) is
     //      fetched here, guarded, into the same slots
     if (!FULL) {
@@ -429,6 +436,8 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     __builtin_amdgcn_wave_barrier();
     RH_LP(0)
     // ---- this lane's run: gain computer + lane-local max-affine segment per channel (the samples stay in the LDS row) ----
+    // (per-lane constants live in LDS, not in registers, between their uses; each is read a phase ahead of its use)
+    const float r15 = tab[0][lane], r31 = tab[1][lane];
     T g[R][N], A[N], B[N];
 #pragma unroll
     for (int p = 0; p < N; ++p) A[p] = B[p] = splat<T>(0.0f);
@@ -456,7 +465,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
             }
         }
     T Ax[N], Bx[N];  // exclusive prefixes inside the wave
-    const float r15 = tab[0][lane], r31 = tab[1][lane];  // per-lane constants live in LDS, not in registers, between their uses
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         scan_maxaff_v<T>(A[p], B[p], a.rscan, r15, r31);
@@ -467,6 +475,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
         for (int c = 0; c < C; ++c) xI[wave][c] = comp(A[c / W], c % W), xI[wave][C + c] = comp(B[c / W], c % W);
     }
+    const float wI = tab[6][lane], rlane = tab[2][lane];
     RH_LP(1)
     __syncthreads();  // (1) the waves' aggregates are in LDS
     // prefix over the waves in front of this one, and the workgroup aggregate (uniform; LDS broadcast reads)
@@ -474,7 +483,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
     for (int p = 0; p < N; ++p) Ap[p] = Bp[p] = AT[p] = BT[p] = splat<T>(0.0f);
     const T rLT = splat<T>(a.rL);
-#pragma unroll 1
+#pragma unroll kPrefixUnroll
     for (int k = 0; k < NW; ++k) {
 #pragma unroll
         for (int p = 0; p < N; ++p) {
@@ -499,7 +508,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     float Iin[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) Iin[c] = Icarry[c];
-    const float wI = tab[6][lane];
     // folds one polled window (aggregates AB, known state Ij at lane j*) into (Ao, Bo): true when the walk is over
     auto fold_I = [&](float (&Ao)[C], float (&Bo)[C], float &Co, const float (&AB)[2 * C], const float (&Ij)[C], uint32_t jstar) {
         const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
@@ -531,12 +539,12 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
         for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
     }
-    // (with the look-back above, the next tile's samples are requested behind its poll)
-    if (!had_I && next_src) dma_share<V>(next_src, next_buf, lane);
+    if (!dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(2)
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
     T I[N], Pz[N];
-    const float rwave = a.rwave[wave], rlane = tab[2][lane];
+    const float rwave = a.rwave[wave];
+    const float a15 = tab[3][lane], a31 = tab[4][lane];
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         const T Iw = vmax(Ap[p], vfma(splat<T>(rwave), pair_of(Iin + p * W, T()), Bp[p]));  // this wave's start state
@@ -556,7 +564,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
             g[r][p] = Pz[p];
         }
     T Px[N];
-    const float a15 = tab[3][lane], a31 = tab[4][lane];
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         T Pi = Pz[p];
@@ -567,13 +574,14 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
             for (int w = 0; w < W; ++w) xP[wave][p * W + w] = comp(Pi, w);
         }
     }
+    const float wP = tab[7][lane], alane = tab[5][lane];
     RH_LP(3)
     __syncthreads();  // (2) the waves' zero-state peak aggregates are in LDS
     T Pp[N], PT[N];
 #pragma unroll
     for (int p = 0; p < N; ++p) Pp[p] = PT[p] = splat<T>(0.0f);
     const T aLT = splat<T>(a.aL);
-#pragma unroll 1
+#pragma unroll kPrefixUnroll
     for (int k = 0; k < NW; ++k) {
 #pragma unroll
         for (int p = 0; p < N; ++p) {
@@ -595,7 +603,6 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         float Co = 1.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) Pin[c] = 0.0f;
-        const float wP = tab[7][lane];
         auto fold_P = [&](const float (&Zj)[C], const float (&Ej)[C], uint32_t jstar) {
             const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
 #pragma unroll
@@ -651,7 +658,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----
     T Ps[N];
     float Pcur[C];
-    const float awave = a.awave[wave], alane = tab[5][lane];
+    const float awave = a.awave[wave];
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         const T Pw = vfma(splat<T>(awave), pair_of(Pin + p * W, T()), Pp[p]);  // this wave's start state
@@ -951,6 +958,7 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
+    a.dma_top = getenv("RH_SCAN_DMA_TOP") ? (uint32_t)atoi(getenv("RH_SCAN_DMA_TOP")) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
     a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64);
