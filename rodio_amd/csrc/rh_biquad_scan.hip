@@ -88,7 +88,8 @@ __device__ __forceinline__ void scan_mat(float &P0, float &P1, const float (&sm)
 
 template <int C, int R, int NW, bool FULL>
 __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *halo, float (*xZ)[2 * C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
-                                        const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf, v4f *next_halo, bool &dead) {
+                                        const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf, v4f *next_halo, bool &dead, const uint32_t ticket_ahead,
+                                        uint32_t *ticket_slot) {
     int lane = lane_;
     asm volatile("" : "+v"(lane));  // per-tile address arithmetic is recomputed, not hoisted into registers that live for the whole kernel
     constexpr int V = C * R / 4;
@@ -191,6 +192,9 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
             if (lane == 63) xZ[wave][2 * c] = P[c][0], xZ[wave][2 * c + 1] = P[c][1];
         }
     }
+    // the ticket taken at the top of the tile (for the tile after next) goes to LDS only here: its atomic has had the whole run to
+    // return, instead of holding wave 0 -- and with it the workgroup at this barrier -- for a device-scope round trip
+    if (threadIdx.x == 0) *ticket_slot = ticket_ahead;
     __syncthreads();  // the waves' aggregates are in LDS
     float Wp[C][2], ZT[C][2];  // state at this wave's start from the waves in front (zero tile start); the tile's aggregate
 #pragma unroll
@@ -362,7 +366,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
         if (nf == L) fetch(src, first, bufs[wave][0], halos[wave][0]);
     }
     while (cur < total) {
-        if (threadIdx.x == 0) s_ticket[(n + 2) % 3] = atomicAdd(a.ctl, 1u);
+        uint32_t ticket_ahead = 0;
+        if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u);  // stored by bq_tile in front of its barrier
+        uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
         const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
         const float *src;
         uint32_t nf;
@@ -384,8 +390,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
             fetch(src2, first2, nb, nh);
             dma_src = nullptr;
         }
-        if (nf == L) bq_tile<C, R, NW, true>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead);
-        else bq_tile<C, R, NW, false>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead);
+        if (nf == L) bq_tile<C, R, NW, true>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
+        else bq_tile<C, R, NW, false>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
         prev_full = nf == L;
         cur = nxt;
         nxt = s_ticket[(n + 2) % 3];

@@ -382,7 +382,7 @@ __device__ __forceinline__ void scan_lin_v(T &V, const float (&cs)[4], float c15
 template <int C, int R, int NW, bool FULL, bool SKEW>
 __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
                                            const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
-                                           const uint32_t nstream, const float *next_src, v4f *next_buf RH_LP_PARAM) {
+                                           const uint32_t nstream, const float *next_src, v4f *next_buf, const uint32_t ticket_ahead, uint32_t *ticket_slot RH_LP_PARAM) {
     // The lane id is made opaque per tile: everything derived from it (LDS slots, global offsets) is then recomputed here, a
     // few VALU operations, instead of being hoisted out of the persistent loop into registers that stay occupied for the
     // whole kernel (which spilled).
@@ -575,6 +575,9 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         }
     }
     const float wP = tab[7][lane], alane = tab[5][lane];
+    // the ticket taken at the top of the tile (for the tile after next) goes to LDS only here: its atomic has had two phases to
+    // return, instead of holding wave 0 -- and with it the whole workgroup at barrier (1) -- for a device-scope round trip
+    if (threadIdx.x == 0) *ticket_slot = ticket_ahead;
     RH_LP(3)
     __syncthreads();  // (2) the waves' zero-state peak aggregates are in LDS
     T Pp[N], PT[N];
@@ -780,7 +783,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
         if (nf == L) dma_share<V>(src, bufs[wave][0], lane);
     }
     while (cur < total) {
-        if (threadIdx.x == 0) s_ticket[(n + 2) % 3] = atomicAdd(a.ctl, 1u);
+        uint32_t ticket_ahead = 0;
+        if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u);  // stored by limit_tile in front of its second barrier
+        uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
         const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
         const float *src;
         uint32_t nf;
@@ -802,11 +807,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
         const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
         const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
         v4f *const buf2 = bufs[wave][(n + 1) & 1];
-        if (nf == L) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2 RH_LP_ARG);
-        else limit_tile<C, R, NW, false, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2 RH_LP_ARG);
+        if (nf == L) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        else limit_tile<C, R, NW, false, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
         prev_full = nf == L;
         cur = nxt;
-        nxt = s_ticket[(n + 2) % 3];  // written before barrier (1) of the tile just done
+        nxt = s_ticket[(n + 2) % 3];  // written before barrier (2) of the tile just done
         ++n;
     }
     wait_vm<0>();
