@@ -284,50 +284,7 @@ __device__ __forceinline__ void poll_pair(const float *gsP, int64_t baseP, uint3
     }
 }
 
-// ---- two channels per instruction ------------------------------------------------------------------------------------------
-// The kernel is VALU-bound (r02 PMC: 47 vector instructions per sample, ~60 % of its duration), and gfx950 executes the f32
-// multiply / add / FMA on PAIRS of registers at full rate (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32).  With an even channel
-// count the channels of a frame go through the per-sample arithmetic two at a time (T = f2); the operations are the same IEEE
-// operations in the same order, so the bits do not change.  max, log2, exp2, compares and DPP moves have no packed form.
-typedef float f2 __attribute__((ext_vector_type(2)));
-template <int C>
-struct Pk {
-    static constexpr int W = C % 2 == 0 ? 2 : 1, N = C / W;
-    typedef typename std::conditional<W == 2, f2, float>::type T;
-};
-template <class T>
-__device__ __forceinline__ T splat(float s);
-template <>
-__device__ __forceinline__ float splat<float>(float s) { return s; }
-template <>
-__device__ __forceinline__ f2 splat<f2>(float s) { return (f2)(s); }
-__device__ __forceinline__ float vfma(float a, float b, float c) { return fma_(a, b, c); }
-__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ f2 vmax(f2 a, f2 b) {
-    f2 r;
-    r.x = fmaxf(a.x, b.x), r.y = fmaxf(a.y, b.y);
-    return r;
-}
-__device__ __forceinline__ float comp(float v, int) { return v; }
-__device__ __forceinline__ float comp(f2 v, int i) { return i ? v.y : v.x; }
-__device__ __forceinline__ float pair_of(const float *p, float) { return p[0]; }
-__device__ __forceinline__ f2 pair_of(const float *p, f2) {
-    f2 r;
-    r.x = p[0], r.y = p[1];
-    return r;
-}
-template <int CTRL, int MASK>
-__device__ __forceinline__ float vdpp(float v) { return dpp0<CTRL, MASK>(v); }
-template <int CTRL, int MASK>
-__device__ __forceinline__ f2 vdpp(f2 v) {
-    f2 r;
-    r.x = dpp0<CTRL, MASK>(v.x), r.y = dpp0<CTRL, MASK>(v.y);
-    return r;
-}
-__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
-__device__ __forceinline__ f2 vsel(bool c, f2 a, f2 b) { return c ? a : b; }
-
+// (two channels per instruction: f2, Pk<C>, splat / vfma / vmax / comp / pair_of / vdpp / vsel -- rh_scan_common.h)
 // limit.rs:853-873 for one sample or a pair (see gain_computer above: the same expression, with the lower knee branch
 // expressed as a clamp: 2*bias + knee < 0 exactly when bias < -knee/2, and then the square is the reference's 0.0).
 __device__ __forceinline__ float log2_mag(float s) { return __builtin_amdgcn_logf(fabsf(s) + 1.17549435e-38f); }

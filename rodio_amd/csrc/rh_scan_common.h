@@ -2,6 +2,8 @@
 // DPP cross-lane moves, wave reductions, the f32 hand-off words with their 0xFF "not yet" pattern, the swizzled LDS
 // tile image and its LDS-DMA fetch.  gfx950 only; include inside an anonymous namespace of a .hip file.
 #pragma once
+#include <type_traits>
+
 #include "rh_common.h"
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -32,6 +34,51 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp0<kBcast31, 0xc>(v));
     return readlane_f(v, 63);
 }
+
+// ---- two channels per instruction ------------------------------------------------------------------------------------------
+// The limiter spends most of its issue slots on vector arithmetic (r02 PMC: 47 instructions per sample), and gfx950 executes the f32
+// multiply / add / FMA on PAIRS of registers at full rate (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32).  With an even channel
+// count the channels of a frame go through the per-sample arithmetic two at a time (T = f2); the operations are the same IEEE
+// operations in the same order, so the bits do not change.  max, log2, exp2, compares and DPP moves have no packed form.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int C>
+struct Pk {
+    static constexpr int W = C % 2 == 0 ? 2 : 1, N = C / W;
+    typedef typename std::conditional<W == 2, f2, float>::type T;
+};
+template <class T>
+__device__ __forceinline__ T splat(float s);
+template <>
+__device__ __forceinline__ float splat<float>(float s) { return s; }
+template <>
+__device__ __forceinline__ f2 splat<f2>(float s) { return (f2)(s); }
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fma_(a, b, c); }
+__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) {
+    f2 r;
+    r.x = fmaxf(a.x, b.x), r.y = fmaxf(a.y, b.y);
+    return r;
+}
+__device__ __forceinline__ float comp(float v, int) { return v; }
+__device__ __forceinline__ float comp(f2 v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ float pair_of(const float *p, float) { return p[0]; }
+__device__ __forceinline__ f2 pair_of(const float *p, f2) {
+    f2 r;
+    r.x = p[0], r.y = p[1];
+    return r;
+}
+template <int CTRL, int MASK>
+__device__ __forceinline__ float vdpp(float v) { return dpp0<CTRL, MASK>(v); }
+template <int CTRL, int MASK>
+__device__ __forceinline__ f2 vdpp(f2 v) {
+    f2 r;
+    r.x = dpp0<CTRL, MASK>(v.x), r.y = dpp0<CTRL, MASK>(v.y);
+    return r;
+}
+__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f2 vsel(bool c, f2 a, f2 b) { return c ? a : b; }
+
 
 constexpr uint32_t kNotYet = 0xffffffffu;
 __device__ __forceinline__ bool word_ok(float v) { return __float_as_uint(v) != kNotYet; }
