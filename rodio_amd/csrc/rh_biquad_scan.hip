@@ -606,9 +606,14 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     hipError_t e = hipGetLastError();
     if (state) a.state_in = snap;
     if (e == hipSuccess) {
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
-        if (per_cu < 1) per_cu = 1;
+        static int occupancy[sizeof(kVariants) / sizeof(kVariants[0])];  // asked once per variant
+        int &per_cu_cached = occupancy[v - kVariants];
+        if (per_cu_cached == 0) {
+            int q = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
+            per_cu_cached = q < 1 ? 1 : q;
+        }
+        int per_cu = per_cu_cached;
         if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
         if (const char *w = getenv("RH_BIQUAD_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;

@@ -880,36 +880,59 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     a.inv_knee_8 = k5[2];
     a.attack = attack;
     a.release = release;
-    const double r = release, al = attack;
-    for (int k = 0; k < 4; ++k) {
-        a.rscan[k] = (float)ipow(r, (uint64_t)R << k);
-        a.ascan[k] = (float)ipow(al, (uint64_t)R << k);
+    // every power of the two coefficients the kernel uses (f64, rounded once): ~600 of them, the same for every block of a
+    // stream -- a pull shim calls this once per block, so the last set is kept per host thread
+    struct Consts {
+        float release = -1.0f, attack = -1.0f;
+        uint32_t R = 0, NW = 0;
+        LimitArgs a;
+    };
+    static thread_local Consts cache;
+    if (cache.release != release || cache.attack != attack || cache.R != R || cache.NW != NW) {
+        LimitArgs &c = cache.a;
+        std::memset(&c, 0, sizeof(c));
+        const double r = release, al = attack;
+        for (int k = 0; k < 4; ++k) {
+            c.rscan[k] = (float)ipow(r, (uint64_t)R << k);
+            c.ascan[k] = (float)ipow(al, (uint64_t)R << k);
+        }
+        c.rL = (float)ipow(r, L);
+        c.aL = (float)ipow(al, L);
+        c.rLW = (float)ipow(r, LW);
+        c.aLW = (float)ipow(al, LW);
+        for (uint32_t k = 0; k < NW; ++k) {
+            c.rwave[k] = (float)ipow(r, (uint64_t)L * k);
+            c.awave[k] = (float)ipow(al, (uint64_t)L * k);
+        }
+        c.rL64 = (float)ipow(r, (uint64_t)LW * 64);
+        c.aL64 = (float)ipow(al, (uint64_t)LW * 64);
+        c.jI = c.jP = 64;
+        for (int l = 0; l < 64; ++l) {
+            c.t.r15[l] = (float)ipow(r, (uint64_t)R * ((l & 15) + 1));
+            c.t.r31[l] = (float)ipow(r, (uint64_t)R * ((l & 31) + 1));
+            c.t.rlane[l] = (float)ipow(r, (uint64_t)R * l);
+            c.t.a15[l] = (float)ipow(al, (uint64_t)R * ((l & 15) + 1));
+            c.t.a31[l] = (float)ipow(al, (uint64_t)R * ((l & 31) + 1));
+            c.t.alane[l] = (float)ipow(al, (uint64_t)R * l);
+            c.t.rlook[l] = (float)ipow(r, (uint64_t)LW * l);
+            c.t.alook[l] = (float)ipow(al, (uint64_t)LW * l);
+            if (c.jI == 64 && c.t.rlook[l] < kNegligible) c.jI = (uint32_t)l;
+            if (c.jP == 64 && c.t.alook[l] < kNegligible) c.jP = (uint32_t)l;
+        }
+        if (c.jI == 0) c.jI = 1;
+        if (c.jP == 0) c.jP = 1;
+        cache.release = release, cache.attack = attack, cache.R = R, cache.NW = NW;
     }
-    a.rL = (float)ipow(r, L);
-    a.aL = (float)ipow(al, L);
-    a.rLW = (float)ipow(r, LW);
-    a.aLW = (float)ipow(al, LW);
-    for (uint32_t k = 0; k < NW; ++k) {
-        a.rwave[k] = (float)ipow(r, (uint64_t)L * k);
-        a.awave[k] = (float)ipow(al, (uint64_t)L * k);
+    {
+        const LimitArgs &c = cache.a;
+        std::memcpy(a.rscan, c.rscan, sizeof(a.rscan));
+        std::memcpy(a.ascan, c.ascan, sizeof(a.ascan));
+        a.rL = c.rL, a.aL = c.aL, a.rLW = c.rLW, a.aLW = c.aLW, a.rL64 = c.rL64, a.aL64 = c.aL64;
+        std::memcpy(a.rwave, c.rwave, sizeof(a.rwave));
+        std::memcpy(a.awave, c.awave, sizeof(a.awave));
+        a.jI = c.jI, a.jP = c.jP;
+        a.t = c.t;
     }
-    a.rL64 = (float)ipow(r, (uint64_t)LW * 64);
-    a.aL64 = (float)ipow(al, (uint64_t)LW * 64);
-    a.jI = a.jP = 64;
-    for (int l = 0; l < 64; ++l) {
-        a.t.r15[l] = (float)ipow(r, (uint64_t)R * ((l & 15) + 1));
-        a.t.r31[l] = (float)ipow(r, (uint64_t)R * ((l & 31) + 1));
-        a.t.rlane[l] = (float)ipow(r, (uint64_t)R * l);
-        a.t.a15[l] = (float)ipow(al, (uint64_t)R * ((l & 15) + 1));
-        a.t.a31[l] = (float)ipow(al, (uint64_t)R * ((l & 31) + 1));
-        a.t.alane[l] = (float)ipow(al, (uint64_t)R * l);
-        a.t.rlook[l] = (float)ipow(r, (uint64_t)LW * l);
-        a.t.alook[l] = (float)ipow(al, (uint64_t)LW * l);
-        if (a.jI == 64 && a.t.rlook[l] < kNegligible) a.jI = (uint32_t)l;
-        if (a.jP == 64 && a.t.alook[l] < kNegligible) a.jP = (uint32_t)l;
-    }
-    if (a.jI == 0) a.jI = 1;
-    if (a.jP == 0) a.jP = 1;
 
     // scratch: control words + the carried-in states + the hand-off table, initialised by k_limit_init in front of the launch
     const size_t n_state = (size_t)n_streams * channels * 2;
@@ -930,9 +953,14 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     hipError_t e = hipGetLastError();
     if (state) a.state_in = snap, a.state_out = state;
     if (e == hipSuccess) {
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
-        if (per_cu < 1) per_cu = 1;
+        static int occupancy[sizeof(kVariants) / sizeof(kVariants[0])];  // asked once per variant (both instantiations share registers and LDS)
+        int &per_cu_cached = occupancy[v - kVariants];
+        if (per_cu_cached == 0) {
+            int q = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
+            per_cu_cached = q < 1 ? 1 : q;
+        }
+        int per_cu = per_cu_cached;
         if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
         if (const char *w = getenv("RH_LIMIT_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;  // tuning aid: resident workgroups per CU
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
