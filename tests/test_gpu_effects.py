@@ -168,7 +168,7 @@ def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
     G.async_status()  # no hand-off inside the scan expired
 
 
-@pytest.mark.parametrize("ch", [1, 2, 4])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 7, 8])
 def test_biquad_mode1_state_across_blocks(G, O, ch):
     import torch
 

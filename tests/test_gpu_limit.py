@@ -59,7 +59,9 @@ def test_limiter_is_actually_limiting_in_these_tests(G, O):
     assert float(np.max(np.abs(out - x))) > 0.5
 
 
-@pytest.mark.parametrize("ch,S,frames", [(2, 5, 40000), (1, 33, 9001), (2, 64, 16384), (3, 7, 12000), (2, 300, 2048)])
+# (2, 300, 16384) and (2, 1100, 2100): more streams than resident workgroups on the 8-wave and the 4-wave geometry -- the
+# variant that walks the next tile's integrator look-back at the current tile's poll point (k_limit_scan<.., SKEW>)
+@pytest.mark.parametrize("ch,S,frames", [(2, 5, 40000), (1, 33, 9001), (2, 64, 16384), (3, 7, 12000), (2, 300, 2048), (2, 300, 16384), (2, 1100, 2100), (1, 520, 9000)])
 def test_limiter_many_streams_one_launch(G, O, ch, S, frames):
     import torch
 
@@ -69,6 +71,28 @@ def test_limiter_many_streams_one_launch(G, O, ch, S, frames):
     for s in range(S):
         ref = _oracle(O, xs[s], ch, 44100, threshold=-3.0)
         assert float(np.max(np.abs(out[s] - ref))) <= TOL, s
+
+
+def test_limiter_one_poll_point_variant_with_few_streams(G, O):
+    """RH_LIMIT_SKEW=1 forces the one-poll-point variant where the host would not choose it (few streams: the predecessors of a
+    workgroup's next tile are other workgroups' next tiles, so the workgroups wait for each other in a chain): slow, still right."""
+    import torch
+
+    S, frames, ch = 6, 200000, 2
+    xs = [_signal(1200 + s, frames, ch, loud=1.2) for s in range(S)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    outs = {}
+    for skew in ("0", "1"):
+        os.environ["RH_LIMIT_SKEW"] = skew
+        try:
+            outs[skew] = G.limit_batch(x, ch, 48000).cpu().numpy()
+        finally:
+            del os.environ["RH_LIMIT_SKEW"]
+    for s in range(S):
+        ref = _oracle(O, xs[s], ch, 48000)
+        assert float(np.max(np.abs(outs["1"][s] - ref))) <= TOL, s
+    assert np.array_equal(outs["0"], outs["1"])  # the same compositions in the same order: the same bits
+    G.async_status()
 
 
 @pytest.mark.parametrize("ch", [1, 2, 5])
