@@ -213,3 +213,54 @@ def test_biquad_mode1_long_memory_and_many_streams(G, O):
         t = _truth(xs[s], co, ch)
         assert float(np.max(np.abs(par[s] - ref))) <= TOL
         assert float(np.max(np.abs(par[s] - t))) <= 2.0 * float(np.max(np.abs(ref - t))) + 1e-7
+
+
+# ---- the runtime pieces behind the handle-less kernels ---------------------------------------------------------------------
+def test_rh_memset_any_alignment_and_size(G):
+    """rh_memset is a kernel of the library (rh::fill_async), not hipMemsetAsync: unaligned heads and tails, every size class."""
+    import ctypes as C
+
+    import torch
+
+    from rodio_amd import _lib
+
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    ref = np.zeros(1 << 16, np.uint8)
+    rng = np.random.default_rng(5)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for off, n in [(0, 1 << 16), (1, 1), (3, 2), (5, 3), (2, 7), (1, 4097), (4, 4096), (7, 30001), (0, 0), (65535, 1)] + [(int(rng.integers(0, 60000)), int(rng.integers(1, 5000))) for _ in range(40)]:
+        val = int(rng.integers(0, 256))
+        _lib.check(_lib.lib.rh_memset(C.c_void_p(buf.data_ptr() + off), val, n, stream), "rh_memset")
+        ref[off: off + n] = val
+    assert np.array_equal(buf.cpu().numpy(), ref)
+
+
+def test_stream_scratch_grows_and_shrinks_between_calls(G, O):
+    """The per-stream scratch of the scan kernels starts at 1 MiB; a batch of 30 000 short streams needs more (one record per
+    stream): the buffer is replaced behind a stream synchronise, and calls before and after are unaffected."""
+    import torch
+
+    def run(S, frames, seed):
+        xs = [rnd(seed + s, frames * 2, 0.9) for s in range(S)]
+        out = G.limit_batch(torch.from_numpy(np.stack(xs)).cuda(), 2, 48000).cpu().numpy()
+        pick = np.random.default_rng(seed).choice(S, size=min(S, 40), replace=False)
+        for s in pick:
+            ref = O.TestSource(xs[s], 2, 48000).limit().collect()
+            assert float(np.max(np.abs(out[s] - ref))) <= TOL, (S, frames, int(s))
+
+    run(3, 5000, 7000)
+    run(30000, 64, 8000)  # 30 000 records of 48 bytes: beyond the first MiB
+    run(5, 3000, 9000)
+    G.async_status()
+
+
+def test_agc_without_a_state_in_place(G, O):
+    """rh_agc with state == NULL and dst == src takes the ring kernel with its state in the stream's scratch."""
+    import torch
+
+    xs = [_programme(1300 + s, 30000) for s in range(6)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    out = G.agc_batch(x, 44100, out=x).cpu().numpy()
+    for s in range(6):
+        ref = O.TestSource(xs[s], 2, 44100).automatic_gain_control().collect()
+        assert float(np.max(np.abs(out[s] - ref))) <= TOL, s
