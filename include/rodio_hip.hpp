@@ -432,6 +432,45 @@ public:
             *pos = (ns / 1000000000ull * rate + ns % 1000000000ull * rate / 1000000000ull) * ch;
         });
     }
+    /// `take_duration(d)`, with `set_filter_fadeout()` when `fade_out` (take.rs:96-148): the samples the duration admits, a cut
+    /// frame completed with zeros, then the end of the stream.  Seeking moves the upstream only (take.rs forwards try_seek).
+    GpuSource &take_duration(Nanos duration, bool fade_out = false) {
+        const std::uint16_t ch = ch_;
+        const std::uint32_t rate = rate_;
+        auto pos = std::make_shared<std::uint64_t>(0);
+        auto done = std::make_shared<bool>(false);
+        return push(
+            [=](Ctx &c) {
+                c.end = true;
+                if (*done) return std::size_t(0);
+                std::uint64_t m = 0;
+                std::int32_t ended = 0;
+                check(rh_take_duration(c.out, c.in, c.n, *pos, ch, rate, (std::uint64_t)duration.count(), fade_out ? 1 : 0, &m, &ended, c.stream), "rh_take_duration");
+                *pos += c.n;
+                *done = ended != 0;
+                c.end = *done;
+                return (std::size_t)m;
+            },
+            [ch](std::size_t n) { return n + ch; });
+    }
+    /// `delay(d)` (delay.rs:8-16,68-75): rh_delay_samples() zeros in front of the stream.  Not seekable here (rodio's Delay
+    /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
+    GpuSource &delay(Nanos duration) {
+        const std::uint64_t d = rh_delay_samples((std::uint64_t)duration.count(), rate_, ch_);
+        auto first = std::make_shared<bool>(true);
+        return push(
+                   [=](Ctx &c) {
+                       if (*first) {
+                           *first = false;
+                           check(rh_delay(c.out, c.in, c.n, d, c.stream), "rh_delay");
+                           return c.n + (std::size_t)d;
+                       }
+                       check(rh_amplify(c.out, c.in, c.n, 1.0f, c.stream), "rh_amplify");  // x * 1.0 == x: a copy into the other buffer
+                       return c.n;
+                   },
+                   [d](std::size_t n) { return n + (std::size_t)d; })
+            .not_seekable();
+    }
     GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13
     GpuSource &fade_out(Nanos duration) { return linear_gain_ramp(duration, 1.0f, 0.0f, true); }  // fadeout.rs:13
 
@@ -455,14 +494,16 @@ protected:
         s.out.reset(cap);
         float *cur = a_.get(), *oth = b_.get();
         if (n) check(rh_memcpy_h2d(cur, s.in.get(), n * sizeof(float), stream_), "rh_memcpy_h2d");
+        bool ends = flush;  // the upstream ended, or a stage says so: the stages behind it see the end of their input
         for (Stage &st : stages_) {
-            Ctx c{oth, cur, n, cap, flush, stream_};
+            Ctx c{oth, cur, n, cap, ends, stream_};
             n = st.run(c);
+            ends = ends || c.end;
             std::swap(cur, oth);
         }
         if (n) check(rh_memcpy_d2h_async(s.out.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
         s.n = n;
-        s.last = flush;
+        s.last = ends;
     }
 
 private:
@@ -472,6 +513,7 @@ private:
         std::size_t n, out_cap;
         bool flush;
         rh_stream stream;
+        bool end = false;  // set by a stage: the stream ends with this block although the upstream has more (take_duration)
     };
     struct Stage {
         std::function<std::size_t(Ctx &)> run;

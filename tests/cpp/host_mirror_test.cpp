@@ -14,7 +14,7 @@
 //   host_mirror_test bench <S> <frames> <block_frames>
 //       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
 //   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
-//       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE
+//       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE take:NS:FADE delay:NS
 //       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T dither:BITS:ALG:SEED channel_volume:G0,G1,.. spatial
 #include <chrono>
 #include <cstdio>
@@ -243,6 +243,8 @@ int main(int argc, char **argv) {
                 else if (op == "channels") g.convert_channels((uint16_t)std::stoul(t.at(1)));
                 else if (op == "limit") g.limit(rh_limit_params{-1.0f, 4.0f, 5000000ull, 100000000ull});
                 else if (op == "agc") g.automatic_gain_control(rh_agc_params{1.0f, 4000000000ull, 0ull, 7.0f, 0.0f});
+                else if (op == "take") g.take_duration(rh::Nanos(std::stoll(t.at(1))), std::stoi(t.at(2)) != 0);
+                else if (op == "delay") g.delay(rh::Nanos(std::stoll(t.at(1))));
                 else if (op == "fade_in") g.fade_in(rh::Nanos(std::stoll(t.at(1))));
                 else if (op == "fade_out") g.fade_out(rh::Nanos(std::stoll(t.at(1))));
                 else if (op == "dither") g.dither((uint32_t)std::stoul(t.at(1)), (rh::GpuSource::DitherAlgorithm)std::stoi(t.at(2)), std::stoull(t.at(3)));

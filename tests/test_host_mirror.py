@@ -208,6 +208,12 @@ CHAINS = [
     (2, 48000, 9000, ["amplify:0.5", "dither:16:3:42"], lambda O, s: s.amplify(0.5).dither(16, "TPDF", 42)),
     (2, 44100, 9000, ["dither:24:1:7"], lambda O, s: s.dither(24, "HighPass", 7)),
     (3, 48000, 5000, ["channel_volume:0.5,1.0,0.25,0.75"], lambda O, s: O.ChannelVolume(s, [0.5, 1.0, 0.25, 0.75])),
+    # take_duration ends the stream before the upstream does (take.rs:96-148); with its fade-out; a cut frame is completed with zeros
+    (2, 48000, 30000, ["take:300000000:1"], lambda O, s: s.take_duration(300000000, True)),
+    (3, 48000, 9000, ["amplify:0.7", "take:100000007:0"], lambda O, s: s.amplify(0.7).take_duration(100000007, False)),
+    (2, 44100, 20000, ["delay:10000000", "low_pass:500", "take:250000000:0"], lambda O, s: s.delay(10000000).low_pass(500).take_duration(250000000, False)),
+    (2, 48000, 6000, ["take:50000000:0", "reverb:20833333:0.4"], lambda O, s: s.take_duration(50000000, False).reverb(20833333, 0.4)),  # the tail behind a cut stream
+    (1, 22050, 3000, ["delay:300000000"], lambda O, s: s.delay(300000000)),  # more silence than one block holds
 ]
 
 
