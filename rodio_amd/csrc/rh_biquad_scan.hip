@@ -133,7 +133,8 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
                 const v4f v = lds[slot_of<V>(lane - 1, V - HV + i)];
                 h[4 * i] = v.x, h[4 * i + 1] = v.y, h[4 * i + 2] = v.z, h[4 * i + 3] = v.w;
             }
-        } else if (f0 > 0) {
+        } else if (f0 > 0 && (FULL || nf > 0)) {  // (an EMPTY share past the end of the stream has no frames in front of it to read:
+                                                  //  its address may lie beyond the last stream's buffer)
 #pragma unroll
             for (int i = 0; i < HV; ++i) {
                 const v4f v = FULL ? halo[i] : *reinterpret_cast<const v4f *>(src - 4 * (HV - i));
@@ -144,8 +145,8 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
             for (int i = 0; i < HV * 4; ++i) h[i] = 0.0f;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                h[HV * 4 - C + c] = init ? init[4 * c] : 0.0f;          // x[-1]
-                h[HV * 4 - 2 * C + c] = init ? init[4 * c + 1] : 0.0f;  // x[-2]
+                h[HV * 4 - C + c] = (init && f0 == 0) ? init[4 * c] : 0.0f;          // x[-1]
+                h[HV * 4 - 2 * C + c] = (init && f0 == 0) ? init[4 * c + 1] : 0.0f;  // x[-2]
             }
         }
 #pragma unroll
@@ -561,17 +562,29 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     const uint64_t stride = frames * channels;
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || stride % 4 == 0);
     if (!aligned) return RH_ERR_UNSUPPORTED;
-    const uint64_t work = frames * (uint64_t)n_streams;
-    int want_R = channels <= 2 ? 16 : 4, want_NW = 8;  // measured, 64 x 1 Mi stereo frames: R = 16 0.240 ms, R = 8 (two workgroups per CU) 0.261 ms
-    if (work < 2ull * 8192 * (uint64_t)rh::g_num_cus) want_R = channels <= 2 ? 8 : 4;
-    if (work < 2ull * 2048 * (uint64_t)rh::g_num_cus) want_NW = 1;
-    if (const char *e = getenv("RH_BIQUAD_R")) want_R = atoi(e);  // tuning aids
-    if (const char *e = getenv("RH_BIQUAD_NW")) want_NW = atoi(e);
+    // Geometry: the longest tile a stream fills at least half of, more frames per lane among equals (rh_limit.hip has the
+    // measurements: 8192-frame tiles from 64 x 1 Mi frames down to 256 x 8192, 0.240 ms with R = 16 against 0.261 ms with R = 8)
     const BqVariant *v = nullptr;
-    for (const BqVariant &c : kVariants) {
-        if (c.C != (int)channels) continue;
-        auto score = [&](const BqVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
-        if (!v || score(c) < score(*v)) v = &c;
+    if (getenv("RH_BIQUAD_R") || getenv("RH_BIQUAD_NW")) {  // tuning aids: the variant closest to the request
+        const int want_R = getenv("RH_BIQUAD_R") ? atoi(getenv("RH_BIQUAD_R")) : 16, want_NW = getenv("RH_BIQUAD_NW") ? atoi(getenv("RH_BIQUAD_NW")) : 8;
+        for (const BqVariant &c : kVariants) {
+            if (c.C != (int)channels) continue;
+            auto score = [&](const BqVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
+            if (!v || score(c) < score(*v)) v = &c;
+        }
+    } else {
+        auto tile_of = [](const BqVariant &x) { return (uint64_t)64 * x.R * x.NW; };
+        for (const BqVariant &c : kVariants) {
+            if (c.C != (int)channels) continue;
+            if (!v) {
+                v = &c;
+                continue;
+            }
+            const bool fits_c = tile_of(c) <= 2 * frames, fits_v = tile_of(*v) <= 2 * frames;
+            const bool better = fits_c != fits_v ? fits_c
+                                : (fits_c ? (tile_of(c) > tile_of(*v) || (tile_of(c) == tile_of(*v) && c.R > v->R)) : tile_of(c) < tile_of(*v));
+            if (better) v = &c;
+        }
     }
     if (!v) return RH_ERR_UNSUPPORTED;
     const BqPlan *pl = get_plan(co, v->R, v->NW);

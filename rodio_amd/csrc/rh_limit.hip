@@ -847,20 +847,33 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     const char *force_seq = getenv("RH_LIMIT_SEQ");  // diagnostics: the reference-order kernel
     if (!aligned || !scannable || (force_seq && force_seq[0] == '1')) return rh::limit_seq_launch(dst, src, frames, channels, n_streams, k5, state, s);
 
-    // Geometry (measured, 64 x 1 Mi and 2048 x 32 Ki stereo frames): workgroups of 8 waves with 16 frames per lane -- tiles of
-    // 8192 frames, one look-back per 128 KiB of traffic -- while that still gives every CU a couple of tiles; shorter blocks
-    // take smaller tiles, down to single-wave ones for a pull shim's block.
-    const uint64_t work = frames * (uint64_t)n_streams;
-    int want_R = 16, want_NW = 8;
-    if (work < 2ull * 8192 * (uint64_t)rh::g_num_cus) want_R = 8, want_NW = 4;
-    if (work < 2ull * 2048 * (uint64_t)rh::g_num_cus) want_R = 8, want_NW = 1;
-    if (const char *e = getenv("RH_LIMIT_R")) want_R = atoi(e);    // tuning aids
-    if (const char *e = getenv("RH_LIMIT_NW")) want_NW = atoi(e);
+    // Geometry: the LONGEST tile (64 * R * NW frames) that a stream fills at least half of; among equals, more frames per lane.
+    // Long tiles amortise the scans and the look-backs, and a slowly decaying recurrence (100 ms of release) reaches back
+    // over MANY short tiles: measured (profiles/r02_scan_geometry_midsize.txt) 8192-frame tiles win from 64 x 1 Mi frames down to
+    // 256 x 8192 (21 us against 49 us with single-wave tiles), although the short batches then have fewer tiles than the chip
+    // has CUs.  Single-wave tiles are for blocks of a few hundred frames (a pull shim's).
     const LimitVariant *v = nullptr;
-    for (const LimitVariant &c : kVariants) {
-        if (c.C != (int)channels) continue;
-        auto score = [&](const LimitVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
-        if (!v || score(c) < score(*v)) v = &c;
+    if (getenv("RH_LIMIT_R") || getenv("RH_LIMIT_NW")) {  // tuning aids: the variant closest to the request
+        const int want_R = getenv("RH_LIMIT_R") ? atoi(getenv("RH_LIMIT_R")) : 16, want_NW = getenv("RH_LIMIT_NW") ? atoi(getenv("RH_LIMIT_NW")) : 8;
+        for (const LimitVariant &c : kVariants) {
+            if (c.C != (int)channels) continue;
+            auto score = [&](const LimitVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
+            if (!v || score(c) < score(*v)) v = &c;
+        }
+    } else {
+        auto tile_of = [](const LimitVariant &x) { return (uint64_t)64 * x.R * x.NW; };
+        for (const LimitVariant &c : kVariants) {
+            if (c.C != (int)channels || c.NW > 8) continue;  // (16-wave tiles: only on request)
+            if (!v) {
+                v = &c;
+                continue;
+            }
+            const bool fits_c = tile_of(c) <= 2 * frames, fits_v = tile_of(*v) <= 2 * frames;
+            const bool better = fits_c != fits_v ? fits_c
+                                : (fits_c ? (tile_of(c) > tile_of(*v) || (tile_of(c) == tile_of(*v) && c.R > v->R))   // the longest that fits
+                                          : tile_of(c) < tile_of(*v));                                                // nothing fits: the shortest
+            if (better) v = &c;
+        }
     }
     if (!v) return RH_ERR_UNSUPPORTED;
     const uint32_t R = (uint32_t)v->R, NW = (uint32_t)v->NW, L = 64u * R, LW = L * NW;
