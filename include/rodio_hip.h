@@ -230,9 +230,11 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host,
  * state (optional device pointer, 4*channels floats {x1,x2,y1,y2} per channel) carries the
  * filter across blocks; NULL = zero state, not written back.
  * mode 0 = sequential per (source,channel) stream, same op order as blt.rs:559 (bit-exact);
- * mode 1 = time-parallel scan (<=1e-5 abs): stereo streams, state == NULL, frames*2 % 4 == 0
- *          for n_streams > 1 (16-byte rows); anything else returns RH_ERR_UNSUPPORTED -- use mode 0.
- * The batch form filters n_streams equally shaped blocks laid out back to back. */
+ * mode 1 = time-parallel scan (<=1e-5 abs): 1 to 8 channels, the same state as mode 0 (a stream may
+ *          change modes between blocks); rows must start on 16-byte boundaries (dst, src, and frames*channels % 4 == 0
+ *          for n_streams > 1) -- otherwise RH_ERR_UNSUPPORTED: use mode 0.  dst == src runs in mode 0 (the scan reads
+ *          the two frames in front of every share after a neighbour may have overwritten them).
+ * The batch form filters n_streams equally shaped blocks laid out back to back.  Mode 0 works in place. */
 rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate,
                            float out_coeffs5[5]);
 rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t channels,
@@ -247,7 +249,8 @@ float rh_linear_to_db(float linear);
 float rh_duration_to_coefficient(uint64_t duration_ns, uint32_t sample_rate);
 
 /* ---- Limit: src/source/limit.rs:94-130,853-988.  state: 2*channels floats
- * {integrator, peak} per channel (optional). */
+ * {integrator, peak} per channel (optional).  Works in place (dst == src).  A hand-off that expires inside the
+ * kernel poisons the output with NaN and is reported by rh_async_status(). */
 typedef struct rh_limit_params {
     float threshold_db; /* LimitSettings::threshold  (default -1) */
     float knee_width_db;/* LimitSettings::knee_width (default 4)  */

@@ -414,9 +414,14 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
     if (mode == 1) {  // time-parallel: the dedicated scan kernel (rh_biquad_scan.hip); what it does not take -- rows that are not
                       // 16-byte aligned, a filter that does not forget within 64 tiles -- goes to the fused kernel's batch mode
                       // (stereo, zero state) or is refused
-        const rh_status st = rh::biquad_scan_launch(dst, src, frames, channels, n_streams, coeffs5_host, state, rh::as_stream(stream));
-        if (st != RH_ERR_UNSUPPORTED || getenv("RH_BIQUAD_NO_FALLBACK")) return st;
-        return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+        const uint64_t total = frames * channels * (uint64_t)n_streams;
+        const bool overlap = dst < src + total && src < dst + total;  // in place: the scan would read halo frames a neighbour has overwritten
+        if (!overlap) {
+            const rh_status st = rh::biquad_scan_launch(dst, src, frames, channels, n_streams, coeffs5_host, state, rh::as_stream(stream));
+            if (st != RH_ERR_UNSUPPORTED || getenv("RH_BIQUAD_NO_FALLBACK")) return st;
+            return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+        }
+        mode = 0;
     }
     if (mode != 0) return RH_ERR_INVALID;
     const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};

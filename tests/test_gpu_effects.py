@@ -264,3 +264,29 @@ def test_agc_without_a_state_in_place(G, O):
     for s in range(6):
         ref = O.TestSource(xs[s], 2, 44100).automatic_gain_control().collect()
         assert float(np.max(np.abs(out[s] - ref))) <= TOL, s
+
+
+def test_in_place_calls(G, O):
+    """dst == src: the limiter works in place (a tile reads only its own frames); rh_biquad mode 1 would read the two frames in
+    front of a share after a neighbour has overwritten them, so an in-place call takes mode 0 -- bit-exact to the oracle."""
+    import torch
+
+    S, frames, ch = 5, 40000, 2
+    xs = [rnd(1500 + s, frames * ch, 0.9) for s in range(S)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    co = G.biquad_coeffs("low_pass", 300, 0.5, 48000)
+    y = x.clone()
+    _biquad_inplace = y
+    from rodio_amd import _lib
+    import ctypes as C
+
+    _lib.check(_lib.lib.rh_biquad(C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()), frames, ch, S, co.ctypes.data_as(_lib.f32p), None, 1,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rh_biquad")
+    got = _biquad_inplace.cpu().numpy()
+    for s in range(S):
+        assert np.array_equal(got[s], O.TestSource(xs[s], ch, 48000).low_pass(300).collect()), s
+    z = x.clone()
+    G.limit_batch(z, ch, 48000, out=z)
+    ref = G.limit_batch(x, ch, 48000)
+    assert torch.equal(z, ref)
+    G.async_status()
