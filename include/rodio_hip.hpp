@@ -617,23 +617,24 @@ public:
         for (auto &g : gens_)
             if (g->plan) (void)rh_rlm_destroy(g->plan);
     }
-    /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: what the fused kernel does not take as it
-    /// is -- a channel count other than 2, or a rate more than 4.5 times the mixer's -- first runs through the matching
-    /// GPU adapter (ChannelCountConverter / SampleRateConverter, uniform.rs:78-97 order), still one pull chain.
+    /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source (uniform.rs:78-97: channels first, then the rate):
+    /// a channel count other than 2 is staged in the source's own layout and converted on the device in front of the fused
+    /// launch (ChannelCountConverter, rh_channels_convert: a mono source crosses PCIe as mono); a rate more than 4.5 times the
+    /// mixer's first runs through the GPU SampleRateConverter adapter, still one pull chain.
     void add(BoxSource src, float gain = 1.0f) {
         if (!src) throw std::invalid_argument("source");
-        const std::uint16_t ch = src->channels();
+        std::uint16_t ch = src->channels();
         const std::uint32_t from = src->sample_rate();
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
-        const bool steep = fused_ratio_unsupported(from, rate_);
-        if (ch != 2 || steep) {
+        if (fused_ratio_unsupported(from, rate_)) {
             auto conv = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
             if (ch != 2) conv->convert_channels(2);
-            if (steep) conv->convert_sample_rate(rate_);
+            conv->convert_sample_rate(rate_);
             src = std::move(conv);
+            ch = 2;
         }
-        if (running()) late_join(Src{std::move(src), gain, {}, false});  // mixer.rs:175-183: admitted at the next frame
-        else pending_.push_back(Src{std::move(src), gain, {}, false});    // starts with the stream (or resumes an ended one)
+        if (running()) late_join(Src{std::move(src), gain, {}, false, ch});  // mixer.rs:175-183: admitted at the next frame
+        else pending_.push_back(Src{std::move(src), gain, {}, false, ch});    // starts with the stream (or resumes an ended one)
     }
     // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136),
     // and admits pending sources only at channel 0: an ended mixer that gets a new source after an odd number of calls
@@ -740,14 +741,17 @@ private:
     struct Src {
         BoxSource up;
         float gain;
-        std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved)
+        std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved, in the source's own channel layout)
         bool ended;
+        std::uint16_t ch = 2;     // the source's channel count (what is not stereo is converted on the device, block by block)
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
         rh_rlm *plan = nullptr;
         detail::DeviceBuf din, q[2];  // staged input rows; mixed output not yet served (ping-pong)
         detail::PinnedBuf stage[2];   // one staging block per slot in flight
+        detail::PinnedBuf side[2];    // ... and one for the sources that are not stereo, in their own layout
+        detail::DeviceBuf dside;
         int cur = 0, slot = 0;
         std::uint64_t head = 0, fill = 0;  // q[cur] holds `fill` frames from frame `head` on (head in {0,1}: the END stays 16-byte aligned)
         bool done = false;                 // the stream emitted its last frame
@@ -826,26 +830,46 @@ private:
         std::vector<const float *> ptrs(S);
         std::vector<std::uint64_t> avail(S);
         std::vector<std::uint8_t> ended(S);
-        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]
+        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]; a source that
+        // is not stereo has its row in the side block instead, in its own layout
+        std::vector<std::size_t> side_off(S, 0);
+        std::size_t side_floats = 0;
+        for (std::size_t i = 0; i < S; ++i)
+            if (g.srcs[i].ch != 2) {
+                side_off[i] = side_floats;
+                side_floats += (cap_frames_ * g.srcs[i].ch + 3) & ~std::size_t(3);
+            }
+        detail::PinnedBuf &side = g.side[g.slot ^ 1];  // (g.slot was flipped above: the same parity as `stage`)
+        if (side_floats) {
+            side.reset(side_floats);
+            g.dside.reset(side_floats);
+        }
         for (std::size_t i = 0; i < S; ++i) {
             Src &x = g.srcs[i];
-            float *row = stage.get() + i * row_;
+            const std::size_t ch = x.ch;
+            float *row = ch == 2 ? stage.get() + i * row_ : side.get() + side_off[i];
             std::size_t have = x.held.size();
-            if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
+            if (have / ch + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
             if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
             if (!x.ended) {
-                const std::size_t want = opt_.block_frames * 2;
+                const std::size_t want = opt_.block_frames * ch;
                 std::size_t got = x.up->read(row + have, want);  // straight into the staging block
-                got -= got % 2;  // sources end on frame boundaries (source/mod.rs:169-178)
+                got -= got % ch;  // sources end on frame boundaries (source/mod.rs:169-178)
                 have += got;
                 x.ended = got < want;
             }
             ptrs[i] = g.din.get() + i * row_;
-            avail[i] = have / 2;
+            avail[i] = have / ch;
             ended[i] = x.ended ? 1 : 0;
         }
         // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
         check(rh_memcpy_h2d(g.din.get(), stage.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
+        if (side_floats) {  // ChannelCountConverter on the device (channels.rs:57-85), into the stereo rows the fused launch reads
+            check(rh_memcpy_h2d(g.dside.get(), side.get(), side_floats * sizeof(float), stream_), "rh_memcpy_h2d");
+            for (std::size_t i = 0; i < S; ++i)
+                if (g.srcs[i].ch != 2 && avail[i])
+                    check(rh_channels_convert(g.din.get() + i * row_, g.dside.get() + side_off[i], (std::size_t)avail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
+        }
         std::uint64_t out = 0, consumed = 0;
         if (debug_poison()) check(rh_memset(g.queue_end(), 0xff, (out_cap_frames_ * 2 - g.fill - g.head) * 2 * sizeof(float), stream_), "rh_memset");
         check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
@@ -854,8 +878,9 @@ private:
         bool all_ended = true;
         for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
             Src &x = g.srcs[i];
-            const float *row = stage.get() + i * row_;
-            const std::size_t have = (std::size_t)avail[i] * 2, drop = std::min<std::size_t>((std::size_t)consumed * 2, have);
+            const std::size_t ch = x.ch;
+            const float *row = ch == 2 ? stage.get() + i * row_ : side.get() + side_off[i];
+            const std::size_t have = (std::size_t)avail[i] * ch, drop = std::min<std::size_t>((std::size_t)consumed * ch, have);
             x.held.assign(row + drop, row + have);
             all_ended = all_ended && x.ended;
         }

@@ -101,11 +101,11 @@ def test_gpu_mixer_same_rate_passthrough_and_empty(O, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 300)])
 def test_gpu_mixer_takes_any_source_layout(O, tmp_path, filt, freq):
-    # mono, 5.1 and stereo sources at four rates (one of them more than twice the mixer's) in one mixer: what the fused
-    # kernel does not take directly is converted by the GPU adapters first; one fused stream per input rate
-    # (the fused stream of a rate group can hold a single source)
+    # mono, 3-channel, 5.1 and stereo sources at five rates (two of them steeper than 4.5 : 1) in one mixer: sources that are
+    # not stereo are staged in their own layout and converted on the device in front of the fused launch; a steep ratio goes
+    # through the GPU SampleRateConverter adapter first; one fused stream per input rate (a rate group can hold a single source)
     spec = [(2, 44100, 1.0, 30000), (1, 44100, 0.7, 25000), (2, 48000, 0.9, 20000), (6, 22050, 0.5, 9000), (2, 96000, 0.8, 50000),
-            (2, 192000, 0.6, 70000), (2, 44100, 1.1, 12345), (1, 8000, 0.4, 4000)]
+            (2, 192000, 0.6, 70000), (2, 44100, 1.1, 12345), (1, 8000, 0.4, 4000), (3, 48000, 0.3, 7000), (1, 192000, 0.5, 40000)]
     xs = [rnd(3400 + i, ch * n, 0.1) for i, (ch, _, _, n) in enumerate(spec)]
     for i, x in enumerate(xs):
         x.tofile(tmp_path / f"src_{i}.f32")
