@@ -525,8 +525,15 @@ class Mixer:
         return out
 
     def next(self):
-        p = self.pull(1)
-        return float(p[0]) if len(p) else None
+        """MixerSource::next (mixer.rs:120-136): the channel position advances on EVERY call, also on the ones that return None
+        (an empty mixer); a source added meanwhile starts at the next frame boundary, so an odd number of None calls is
+        followed by one more None before its first sample."""
+        m = self._mix()
+        p = self._pos
+        self._pos += 1
+        if any(st <= p < st + len(u) for u, st in self._srcs):
+            return float(m[p])
+        return None
 
     def collect(self) -> np.ndarray:
         return self.pull(1 << 62)

@@ -95,6 +95,32 @@ def test_golden_mixer(G):
     assert m.next() == 15.0
 
 
+def test_mixer_channel_position_advances_on_none_like_the_reference(G, O):
+    """mixer.rs:120-136: an empty MixerSource returns None AND advances its channel position; a source added after an odd
+    number of such calls waits for the next frame boundary (one more None).  The mirror and the oracle's MixerSource are driven
+    with the same sequence of calls."""
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        gm, om = G.Mixer(2, 48000), O.Mixer(2, 48000)
+        got, ref = [], []
+        for step in range(8):
+            kind = rng.integers(0, 3)
+            if kind == 0:  # a few calls, empty or not
+                k = int(rng.integers(1, 6))
+                got += [gm.next() for _ in range(k)]
+                ref += [om.next() for _ in range(k)]
+            else:  # a short stereo source joins
+                x = rng.uniform(-1, 1, 2 * int(rng.integers(1, 5))).astype(np.float32)
+                gm.add(G.SamplesBuffer(2, 48000, x))
+                om.add(O.TestSource(x, 2, 48000))
+                k = int(rng.integers(0, 4))
+                got += [gm.next() for _ in range(k)]
+                ref += [om.next() for _ in range(k)]
+        got += [gm.next() for _ in range(12)]
+        ref += [om.next() for _ in range(12)]
+        assert got == ref, (trial, got, ref)
+
+
 def test_golden_channel_volume(G):
     # src/source/channel_volume.rs:135-166
     f = np.float32
