@@ -190,6 +190,42 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
                              uint32_t to_rate, uint32_t channels, uint64_t span_len,
                              rh_stream stream);
 
+/* ---- UniformSourceIterator span by span: src/source/uniform.rs:50-97.  rodio re-builds its converter chain
+ *        Take{n: current_span_len().min(32768)} -> SampleRateConverter(from_rate -> to_rate, from_ch) -> ChannelCountConverter(from_ch -> to_ch)
+ * whenever the current one runs dry, so a source that reports spans (SamplesBuffer buffer.rs:76-82, Buffered buffered.rs:109,
+ * the decoders symphonia.rs:199-201) is converted span by span: each span starts a fresh converter and ends with its last frame
+ * verbatim (sample_rate.rs:193-200); rate and layout may change from span to span.  Spans are independent work items, and so
+ * are the pieces a span is cut into when it arrives in blocks.  A SEGMENT = output frames [m0, m1) (span-relative) of one span:
+ *   src          device pointer to input frame `src_frame0` of the span (src_frames frames of from_ch samples are there)
+ *   dst          device pointer: output frame m0 lands at dst[0 .. to_ch)
+ *   span_frames  input frames of the WHOLE span once it is complete -- its last frame is then emitted verbatim and nothing
+ *                follows; UINT64_MAX while the span is still open (more input will come, or current_span_len() == None)
+ * Output frame m reads input frames floor(m*F/T) and +1 (F/T = from/to reduced); the caller keeps the frames the next
+ * segment's first tap needs (rh_uniform_first_tap).  Bit-exact with the reference (lerp as mul, IEEE divide, add).
+ * Spans must hold whole frames (the trait's contract, source/mod.rs:196-200).
+ * rh_uniform_span_frames: output frames computable from the first span_in_frames input frames of a span; complete != 0 adds
+ * the verbatim last frame.  rh_uniform_segments validates and launches a host table (any number of segments, sources, formats
+ * in one call); the _dev form takes the table from DEVICE memory unvalidated (it can travel in the caller's staging copy);
+ * max_out_frames = the largest m1 - m0 in it. */
+typedef struct rh_uniform_seg {
+    const float *src;
+    float *dst;
+    uint64_t src_frame0, src_frames;
+    uint64_t m0, m1;
+    uint64_t span_frames;
+    uint32_t from_rate, to_rate;
+    uint32_t from_ch, to_ch;
+    float gain;          /* Amplify in FRONT of the converter (mixer.add(src.amplify(g)), amplify.rs:64): both taps are scaled
+                          * before the lerp, which is the reference's order of operations; 1.0 = none (x * 1.0 == x) */
+    uint32_t reserved;   /* 0 */
+} rh_uniform_seg;
+rh_status rh_uniform_span_frames(uint64_t span_in_frames, uint32_t from_rate, uint32_t to_rate, int32_t complete,
+                                 uint64_t *out_frames);
+rh_status rh_uniform_first_tap(uint64_t out_frame, uint32_t from_rate, uint32_t to_rate, uint64_t *in_frame);
+rh_status rh_uniform_segments(const rh_uniform_seg *segs_host, uint32_t n_segs, rh_stream stream);
+rh_status rh_uniform_segments_dev(const rh_uniform_seg *segs_dev, uint32_t n_segs, uint64_t max_out_frames,
+                                  rh_stream stream);
+
 /* ---- block streaming: the same two adapters when the stream arrives in blocks (what a `Source` shim
  * does: pull a block upstream, process, serve next() from it).  The handle keeps what the reference's
  * iterator keeps between samples; ANY split of a stream into blocks gives the bits of one pass.

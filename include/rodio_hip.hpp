@@ -91,6 +91,8 @@ public:
         pos_ += k;
         return k;
     }
+    /// buffer.rs:76-82: the whole buffer is one span -- Some(len) until it is exhausted, then Some(0).
+    std::optional<std::size_t> current_span_len() const override { return pos_ >= data_.size() ? 0 : data_.size(); }
     std::uint16_t channels() const override { return ch_; }
     std::uint32_t sample_rate() const override { return rate_; }
     std::optional<Nanos> total_duration() const override {  // buffer.rs:45-51
@@ -166,6 +168,182 @@ public:
 private:
     void *p_ = nullptr;
     std::size_t n_ = 0;
+};
+
+/// One run of samples pulled from a source inside ONE span of it.
+struct Piece {
+    std::size_t n;       // samples (whole frames of `ch` channels)
+    bool opens, closes;  // the first / the last samples of their span
+    std::uint16_t ch;
+    std::uint32_t rate;
+};
+
+/// Pulls a source the way UniformSourceIterator does (uniform.rs:50-97): whenever its converter chain has run dry it asks
+/// `current_span_len()`, `channels()` and `sample_rate()` -- in that order, at exactly that position of the stream -- and
+/// admits min(span, 32768) samples (`Take`, uniform.rs:56,148-178) to the chain it builds for them.  A span ends when that
+/// many samples were taken or when the source returns None; the stream ends when a fresh chain yields nothing
+/// (Some(0), or None at once).  read_piece() never crosses a span boundary.
+class SpanReader {
+public:
+    static constexpr std::size_t kOpenEnded = ~std::size_t(0);
+    explicit SpanReader(Source *up = nullptr) : up_(up) {}
+    bool ended() const { return ended_; }
+    /// Format of the span the next read_piece() continues or opens (builds the next chain if none is open); false at the
+    /// end of the stream.
+    bool peek(std::uint16_t &ch, std::uint32_t &rate) {
+        if (!open_ && !bootstrap()) return false;
+        ch = ch_;
+        rate = rate_;
+        return true;
+    }
+    /// After peek(): the next piece is the first of its span.
+    bool opens_next() const { return fresh_; }
+    /// Frames the open span still admits (kOpenEnded: current_span_len() was None).
+    std::size_t left_frames() const { return left_ == kOpenEnded ? kOpenEnded : left_ / ch_; }
+    /// Up to max_frames frames of the current span into dst; false: the stream is over and nothing was produced.
+    bool read_piece(float *dst, std::size_t max_frames, Piece &out) {
+        if (ended_ || (!open_ && !bootstrap())) return false;
+        std::size_t want = max_frames > kOpenEnded / ch_ ? kOpenEnded : max_frames * ch_;
+        want = std::min(want, left_);
+        want -= want % ch_;
+        std::size_t got = want ? up_->read(dst, want) : 0;
+        const bool none = got < want;  // the source returned None inside the span
+        got -= got % ch_;              // sources end on frame boundaries (source/mod.rs:169-178)
+        if (left_ != kOpenEnded) left_ -= got;
+        const bool closes = none || left_ == 0;
+        out = Piece{got, fresh_, closes, ch_, rate_};
+        const bool produced = got != 0 || (closes && !fresh_);  // a span that had samples before ends here: its last frame is due
+        if (got) fresh_ = false;
+        if (closes) open_ = false;
+        if (none) ended_ = true;  // the chain rodio builds next yields nothing: None
+        return produced;
+    }
+    /// After a seek of the source: what was pulled ahead is gone, the next read builds a fresh chain.
+    void restart() {
+        open_ = false;
+        ended_ = false;
+    }
+
+private:
+    bool bootstrap() {  // uniform.rs:50-68
+        const std::optional<std::size_t> span = up_->current_span_len();
+        ch_ = up_->channels();
+        rate_ = up_->sample_rate();
+        if (!ch_ || !rate_) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
+        if (span && *span == 0) {  // Take{n: 0}: the chain is empty, next() is None
+            ended_ = true;
+            return false;
+        }
+        left_ = span ? std::min<std::size_t>(*span, 32768) : kOpenEnded;
+        // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels, and
+        // rodio then rotates the channels of every later span.  That is not reproduced here: it is refused.
+        if (left_ != kOpenEnded && left_ % ch_) throw Error(RH_ERR_UNSUPPORTED, "a span of " + std::to_string(left_) + " samples cuts a frame of " + std::to_string(ch_) + " channels");
+        open_ = true;
+        fresh_ = true;
+        return true;
+    }
+    Source *up_;
+    bool open_ = false, fresh_ = true, ended_ = false;
+    std::size_t left_ = 0;
+    std::uint16_t ch_ = 0;
+    std::uint32_t rate_ = 0;
+};
+
+/// Turns the pieces of one source into the segments rh_uniform_segments converts (UniformSourceIterator::new(src, to_ch,
+/// to_rate), span by span).  The planner only counts: the owner lays the samples out as one row
+///     [ the frames held() says the previous block left | the samples of this block's pieces, back to back ]
+/// (on the host or on the device), hands every piece to add() in order, and after the last one keeps the frames
+/// [keep_offset(), keep_offset() + keep_samples()) of the row for the next block.
+class UniformPlanner {
+public:
+    struct Seg {
+        std::size_t src_off;  // samples from the start of the row
+        std::size_t dst_off;  // output FRAMES from the first frame this block produces
+        rh_uniform_seg g;     // everything but the two pointers
+    };
+    UniformPlanner(std::uint16_t to_ch = 2, std::uint32_t to_rate = 48000) : to_ch_(to_ch), to_rate_(to_rate) {}
+    /// Start of a block: the row begins with held_samples() samples of the open span (none if no span is open).
+    void begin_block() {
+        pos_ = held_;
+        row_off_ = 0;
+        out_ = 0;
+        keep_off_ = 0;  // a block that brings nothing for the open span keeps what it held
+        keep_n_ = held_;
+    }
+    std::size_t held_samples() const { return held_; }
+    /// The largest number of further input frames of the open (or a fresh) span that cannot produce more than `room`
+    /// output frames, and the smallest that produces at least `want` (both before the span's verbatim last frame).
+    void budget(std::uint32_t rate, bool fresh, std::uint64_t want, std::uint64_t room, std::uint64_t &need, std::uint64_t &most) const {
+        const std::uint64_t in = fresh ? 0 : span_in_, m = fresh ? 0 : span_m_;
+        // ready(N) = ceil((N-1)*T/F) for N >= 1 (lerp taps), +1 when the span closes.  first_tap(k) = floor(k*F/T).
+        std::uint64_t a = 0, b = 0;
+        check(rh_uniform_first_tap(m + want, rate, to_rate_, &a), "rh_uniform_first_tap");              // ready(N) >= m + want  <=  N-1 >= ceil((m+want)*F/T)
+        check(rh_uniform_first_tap(room ? m + room - 1 : m, rate, to_rate_, &b), "rh_uniform_first_tap");  // ready(N) + 1 <= m + room  <=  N-1 <= floor((m+room-1)*F/T)
+        const std::uint64_t n_need = a + 2, n_most = room ? b + 1 : in;
+        need = n_need > in ? n_need - in : 0;
+        most = n_most > in ? n_most - in : 0;
+    }
+    void add(const Piece &p, std::vector<Seg> &segs) {
+        if (p.opens) {
+            span_in_ = span_m_ = 0;
+            row_off_ = pos_;  // the span's frame 0 sits here
+            row_frame0_ = 0;
+        }
+        const std::uint64_t f = p.n / p.ch;
+        span_in_ += f;
+        pos_ += p.n;
+        std::uint64_t ready = 0;
+        check(rh_uniform_span_frames(span_in_, p.rate, to_rate_, p.closes ? 1 : 0, &ready), "rh_uniform_span_frames");
+        if (ready > span_m_) {
+            Seg sg;
+            sg.src_off = row_off_;
+            sg.dst_off = out_;
+            std::memset(&sg.g, 0, sizeof sg.g);
+            sg.g.src_frame0 = row_frame0_;
+            sg.g.src_frames = span_in_ - row_frame0_;
+            sg.g.m0 = span_m_;
+            sg.g.m1 = ready;
+            sg.g.span_frames = p.closes ? span_in_ : UINT64_MAX;
+            sg.g.from_rate = p.rate;
+            sg.g.to_rate = to_rate_;
+            sg.g.from_ch = p.ch;
+            sg.g.to_ch = to_ch_;
+            sg.g.gain = 1.0f;
+            segs.push_back(sg);
+            out_ += ready - span_m_;
+            span_m_ = ready;
+        }
+        if (p.closes) {
+            held_ = 0;
+            keep_off_ = keep_n_ = 0;
+        } else {  // the frames the span's next output frame reads first stay
+            std::uint64_t first = 0;
+            check(rh_uniform_first_tap(span_m_, p.rate, to_rate_, &first), "rh_uniform_first_tap");
+            first = std::max(first, row_frame0_);
+            first = std::min(first, span_in_);
+            keep_off_ = row_off_ + (std::size_t)(first - row_frame0_) * p.ch;
+            keep_n_ = (std::size_t)(span_in_ - first) * p.ch;
+            held_ = keep_n_;
+            next_frame0_ = first;
+        }
+    }
+    /// End of a block: the next row starts with the kept frames.
+    void end_block() {
+        row_frame0_ = next_frame0_;
+        if (!held_) row_frame0_ = span_in_;
+    }
+    std::size_t keep_offset() const { return keep_off_; }
+    std::size_t keep_samples() const { return keep_n_; }
+    std::uint64_t out_frames() const { return out_; }
+    std::uint16_t to_channels() const { return to_ch_; }
+
+private:
+    std::uint16_t to_ch_;
+    std::uint32_t to_rate_;
+    std::uint64_t span_in_ = 0, span_m_ = 0;        // input frames received / output frames planned of the open span
+    std::uint64_t row_frame0_ = 0, next_frame0_ = 0;  // span frame index of the first frame the row holds of the open span
+    std::size_t row_off_ = 0, pos_ = 0, held_ = 0, keep_off_ = 0, keep_n_ = 0;
+    std::uint64_t out_ = 0;
 };
 
 /// What every GPU-backed source shares: two page-locked result blocks, one served while the other is in
@@ -290,6 +468,7 @@ public:
         if (!up_) throw std::invalid_argument("upstream");
         ch_ = up_->channels();
         rate_ = up_->sample_rate();
+        reader_ = detail::SpanReader(up_.get());
     }
     ~GpuSource() override { (void)rh_stream_synchronize(stream_); }  // nothing of the chain may still run when its buffers go
     // -- Source
@@ -306,6 +485,7 @@ public:
         for (const Stage &st : stages_)
             if (!st.seekable) return false;
         if (!up_->try_seek(pos)) return false;
+        reader_.restart();
         restart(ch_);
         for (Stage &st : stages_)
             if (st.on_seek) st.on_seek(pos);
@@ -348,7 +528,8 @@ public:
                 return c.n + (std::size_t)d;
             },
             [d](std::size_t n) { return n + (std::size_t)d; })
-            .not_seekable();
+            .not_seekable()
+            .spans(1);  // Mix::current_span_len() is None (mix.rs:92-94)
     }
     GpuSource &channel_volume(std::vector<float> gains) {  // channel_volume.rs:71-88
         const std::uint16_t in_ch = ch_;
@@ -374,7 +555,7 @@ public:
             const std::size_t frames = c.n / from;
             check(rh_channels_convert(c.out, c.in, frames, from, to, c.stream), "rh_channels_convert");
             return frames * to;
-        }, [from, to](std::size_t n) { return n / from * to; });
+        }, [from, to](std::size_t n) { return n / from * to; }).spans(1);  // a bare converter is an iterator, not a Source: what wraps it sees no spans
         ch_ = to;
         return *this;
     }
@@ -390,14 +571,71 @@ public:
             std::uint64_t m = 0;
             check(rh_resampler_process(h->p, c.out, c.out_cap / ch, c.in, c.n / ch, c.flush ? 1 : 0, &m, c.stream), "rh_resampler_process");
             return (std::size_t)m * ch;
-        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 2) * to / from + 2) * ch; });
+        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 2) * to / from + 2) * ch; }).spans(1);
         rate_ = to;
         return *this;
     }
-    /// UniformSourceIterator::new(src, channels, rate) for a continuous source (uniform.rs:78-97: channels first, then rate).
+    /// UniformSourceIterator::new(src, channels, rate) (uniform.rs:50-97).  The upstream is pulled the way rodio pulls it:
+    /// `current_span_len()` is asked whenever the converter chain has run dry, min(span, 32768) samples go to a FRESH
+    /// SampleRateConverter -> ChannelCountConverter pair, and every span ends with its last frame verbatim -- so a
+    /// SamplesBuffer or a decoder (which report spans) and a generator (None: one continuous conversion) each come out as
+    /// they do in rodio.  Spans travel through the adapters in front that keep the sample count (amplify, filters, limiter,
+    /// ...: they forward current_span_len()); behind reverb (Mix: None, mix.rs:92-94) or a bare converter the stream is
+    /// continuous.  Behind take_duration / delay / channel_volume a spanned upstream is refused (their span arithmetic is
+    /// not mirrored).
     GpuSource &uniform(std::uint16_t channels, std::uint32_t sample_rate) {
-        if (channels != ch_) convert_channels(channels);
-        return convert_sample_rate(sample_rate);
+        if (!channels || !sample_rate) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
+        int rule = 0;
+        for (const Stage &st : stages_)
+            if (st.span_rule) rule = st.span_rule;
+        if (rule == 2 && up_->current_span_len()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::uniform behind take_duration / delay / channel_volume on a source that reports spans");
+        if (rule != 0) {  // continuous from here on: ChannelCountConverter(SampleRateConverter(..)) once (uniform.rs:62-67)
+            const std::uint16_t from_ch = ch_;
+            convert_sample_rate(sample_rate);
+            if (channels != from_ch) convert_channels(channels);
+            stages_.back().span_rule = 1;
+            return *this;
+        }
+        span_aware_ = true;
+        auto plan = std::make_shared<detail::UniformPlanner>(channels, sample_rate);
+        auto win = std::make_shared<detail::DeviceBuf>();
+        auto keep = std::make_shared<detail::DeviceBuf>();
+        const std::uint16_t in_ch = ch_;
+        const std::uint32_t from = rate_, to = sample_rate;
+        push(
+            [=](Ctx &c) {
+                plan->begin_block();
+                const std::size_t hs = plan->held_samples();
+                win->reset(hs + c.n + 4);
+                if (hs) check(rh_memcpy_d2d(win->get(), keep->get(), hs * sizeof(float), c.stream), "rh_memcpy_d2d");
+                if (c.n) check(rh_memcpy_d2d(win->get() + hs, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
+                std::vector<detail::UniformPlanner::Seg> segs;
+                for (const detail::Piece &p : pieces_) plan->add(p, segs);
+                plan->end_block();
+                std::vector<rh_uniform_seg> table;
+                for (const detail::UniformPlanner::Seg &sg : segs) {
+                    rh_uniform_seg g = sg.g;
+                    g.src = win->get() + sg.src_off;
+                    g.dst = c.out + sg.dst_off * channels;
+                    table.push_back(g);
+                }
+                if ((plan->out_frames() + 1) * channels > c.out_cap) throw Error(RH_ERR_CAPACITY, "GpuSource::uniform: block capacity");
+                check(rh_uniform_segments(table.data(), (std::uint32_t)table.size(), c.stream), "rh_uniform_segments");
+                if (const std::size_t kn = plan->keep_samples()) {
+                    keep->reset(kn);
+                    check(rh_memcpy_d2d(keep->get(), win->get() + plan->keep_offset(), kn * sizeof(float), c.stream), "rh_memcpy_d2d");
+                }
+                return (std::size_t)plan->out_frames() * channels;
+            },
+            [this, in_ch, channels, from, to](std::size_t n) {  // every span may add its verbatim last frame
+                const std::uint64_t f = n / in_ch;
+                return (std::size_t)(std::max<std::uint64_t>(f, f * to / from + 2) + 2 * (pieces_.size() + 2)) * channels;
+            })
+            .on_seek([plan, channels, sample_rate](Nanos) { *plan = detail::UniformPlanner(channels, sample_rate); });  // what was pulled ahead is gone: the next span starts a fresh chain
+        stages_.back().span_rule = 1;
+        ch_ = channels;
+        rate_ = sample_rate;
+        return *this;
     }
     GpuSource &limit(const rh_limit_params &settings) {  // limit.rs:94-130,853-988
         const std::uint16_t ch = ch_;
@@ -482,9 +720,26 @@ protected:
         const std::size_t want = block_frames_ * up_->channels();
         s.in.reset(want);
         if (up_->channels() != in_ch() || up_->sample_rate() != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
-        std::size_t n = up_->read(s.in.get(), want);
-        n -= n % up_->channels();  // sources end on frame boundaries (source/mod.rs:169-178)
-        const bool flush = n < want;
+        std::size_t n = 0;
+        bool flush = false;
+        pieces_.clear();
+        if (span_aware_) {  // a UniformSourceIterator is in the chain: pull span by span, asking for the span where rodio asks
+            while (n < want) {
+                detail::Piece pc;
+                const bool produced = reader_.read_piece(s.in.get() + n, (want - n) / in_ch(), pc);
+                if (produced) {
+                    if (pc.ch != in_ch() || pc.rate != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
+                    pieces_.push_back(pc);
+                    n += pc.n;
+                }
+                if (reader_.ended() || !produced) break;
+            }
+            flush = reader_.ended();
+        } else {
+            n = up_->read(s.in.get(), want);
+            n -= n % up_->channels();  // sources end on frame boundaries (source/mod.rs:169-178)
+            flush = n < want;
+        }
         // capacity of the ping-pong buffers: the largest block any stage can emit
         std::size_t cap = want, m = want;
         for (const Stage &st : stages_) cap = std::max(cap, m = st.bound(m));
@@ -520,6 +775,7 @@ private:
         std::function<std::size_t(std::size_t)> bound;
         bool seekable = true;                        // false: the adapter answers SeekError::NotSupported (mix.rs:116-120)
         std::function<void(Nanos)> on_seek = nullptr;  // what the adapter does to its own state after its input was sought
+        int span_rule = 0;  // what current_span_len() is behind the adapter: 0 the input's (one sample out per sample in), 1 None (Mix, the converters), 2 the input's with another sample count
     };
     template <class T>
     struct Handle {
@@ -531,12 +787,12 @@ private:
     };
     template <class F>
     GpuSource &push(F run) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr, 0});
         return *this;
     }
     template <class F, class B>
     GpuSource &push(F run, B bound) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr, 2});
         return *this;
     }
     GpuSource &on_seek(std::function<void(Nanos)> f) {  // for the stage pushed last
@@ -545,6 +801,10 @@ private:
     }
     GpuSource &not_seekable() {
         stages_.back().seekable = false;
+        return *this;
+    }
+    GpuSource &spans(int rule) {
+        stages_.back().span_rule = rule;
         return *this;
     }
     std::shared_ptr<detail::DeviceBuf> state(std::size_t floats) {
@@ -579,6 +839,9 @@ private:
     mutable std::uint16_t in_ch_ = 0;
     mutable std::uint32_t in_rate_ = 0;
     std::vector<Stage> stages_;
+    detail::SpanReader reader_{nullptr};
+    std::vector<detail::Piece> pieces_;  // the spans of the block being enqueued
+    bool span_aware_ = false;
     detail::DeviceBuf a_, b_;
     bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
 };
@@ -589,8 +852,13 @@ private:
 ///     mixer.add(UniformSourceIterator::new(src.amplify(g), nz!(2), rate).low_pass(f));   // per source
 /// as ONE source: every block is one launch of the fused kernel (resample + filter + ordered sum), each source
 /// keeping its own converter position and filter state across blocks; sources end when they end.
-/// Sources are stereo; the sources added together share one input rate (what the fused kernel covers; other
-/// layouts go through GpuSource::uniform first).
+/// Every source is pulled the way Mixer::add's UniformSourceIterator pulls it (uniform.rs:50-97).  Sources whose
+/// current_span_len() is None (generators, anything behind a UniformSourceIterator) are continuous streams: they go
+/// straight into the fused kernel (resample + filter + sum in one pass, one fused stream per input rate).  If a source
+/// reports SPANS (SamplesBuffer, Buffered, the decoders), rodio converts it span by span -- a fresh converter every
+/// min(span, 32768) samples, each span's last frame verbatim, rate and layout free to change between spans -- and so
+/// does the generation it joins: its sources are converted segment by segment on the device (rh_uniform_segments, one
+/// launch per block for all of them, any rates and layouts) and the fused kernel filters and mixes the converted rows.
 ///
 /// add() may be called at any time (Mixer::add, mixer.rs:58-66).  Sources added before the first next() start
 /// with the stream.  Sources added later start at the next FRAME of the output, as mixer.rs:175-183 admits them
@@ -626,15 +894,12 @@ public:
         std::uint16_t ch = src->channels();
         const std::uint32_t from = src->sample_rate();
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
-        if (fused_ratio_unsupported(from, rate_)) {
-            auto conv = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
-            if (ch != 2) conv->convert_channels(2);
-            conv->convert_sample_rate(rate_);
-            src = std::move(conv);
-            ch = 2;
-        }
-        if (running()) late_join(Src{std::move(src), gain, {}, false, ch});  // mixer.rs:175-183: admitted at the next frame
-        else pending_.push_back(Src{std::move(src), gain, {}, false, ch});    // starts with the stream (or resumes an ended one)
+        Src item;
+        item.up = std::move(src);
+        item.gain = gain;
+        item.ch = ch;
+        if (running()) late_join(std::move(item));  // mixer.rs:175-183: admitted at the next frame
+        else pending_.push_back(std::move(item));    // starts with the stream (or resumes an ended one)
     }
     // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136),
     // and admits pending sources only at channel 0: an ended mixer that gets a new source after an odd number of calls
@@ -740,10 +1005,14 @@ protected:
 private:
     struct Src {
         BoxSource up;
-        float gain;
+        float gain = 1.0f;
         std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved, in the source's own channel layout)
-        bool ended;
+        bool ended = false;
         std::uint16_t ch = 2;     // the source's channel count (what is not stereo is converted on the device, block by block)
+        // span-by-span generations: how rodio's UniformSourceIterator would pull this source, and where its converted frames wait
+        detail::SpanReader reader{nullptr};
+        detail::UniformPlanner plan;
+        std::uint64_t have = 0, off = 0;  // converted frames not yet mixed: `have` of them from frame `off` of the source's device row
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
@@ -755,6 +1024,12 @@ private:
         int cur = 0, slot = 0;
         std::uint64_t head = 0, fill = 0;  // q[cur] holds `fill` frames from frame `head` on (head in {0,1}: the END stays 16-byte aligned)
         bool done = false;                 // the stream emitted its last frame
+        // span-by-span generations (`staged`): the sources are converted to the mixer's format first, row by row
+        bool staged = false;
+        std::uint64_t target = 0, crow = 0;  // converted frames a block tops every row up to; capacity of a row (frames)
+        detail::DeviceBuf conv[2], dtab;     // converted rows (ping-pong: what a block leaves moves to the front of the other set); segment table
+        detail::PinnedBuf tab[2];
+        int ccur = 0;
         const float *queue() const { return q[cur].get() + head * 2; }
         float *queue_end() { return q[cur].get() + (head + fill) * 2; }
     };
@@ -768,9 +1043,27 @@ private:
         const std::uint64_t F = from / a, T = to / a;
         return 2 * F > 9 * T || F * T > 0xffffffffull;
     }
-    void start_generation() {  // the sources that joined together: one fused stream per input rate, in order of first appearance
+    static bool spanned(const Src &x) { return x.up->current_span_len().has_value(); }
+    /// A continuous source the fused kernel cannot take as it is (rate ratio above 4.5) gets the GPU converter adapter in front.
+    void make_direct(Src &x) {
+        if (!fused_ratio_unsupported(x.up->sample_rate(), rate_)) return;
+        auto conv = std::make_unique<GpuSource>(std::move(x.up), opt_.block_frames);
+        if (x.ch != 2) conv->convert_channels(2);
+        conv->convert_sample_rate(rate_);
+        x.up = std::move(conv);
+        x.ch = 2;
+    }
+    void start_generation() {  // the sources that joined together
         std::vector<Src> all = std::move(pending_);
         pending_.clear();
+        bool any_spans = false;
+        for (const Src &x : all) any_spans = any_spans || spanned(x);
+        if (any_spans) {  // span by span, as rodio converts them: one stream for all of them, in insertion order
+            start_stream(std::move(all), true);
+            return;
+        }
+        // continuous sources: one fused stream per input rate, in order of first appearance
+        for (Src &x : all) make_direct(x);
         std::vector<std::uint32_t> rates;
         for (const Src &x : all)
             if (std::find(rates.begin(), rates.end(), x.up->sample_rate()) == rates.end()) rates.push_back(x.up->sample_rate());
@@ -778,14 +1071,15 @@ private:
             std::vector<Src> group;
             for (Src &x : all)
                 if (x.up && x.up->sample_rate() == r) group.push_back(std::move(x));
-            start_stream(std::move(group));
+            start_stream(std::move(group), false);
         }
     }
-    void start_stream(std::vector<Src> srcs) {
+    void start_stream(std::vector<Src> srcs, bool staged) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
         g.srcs = std::move(srcs);
-        const std::uint32_t from = g.srcs.front().up->sample_rate();
+        g.staged = staged;
+        const std::uint32_t from = staged ? rate_ : g.srcs.front().up->sample_rate();  // staged: the fused kernel sees converted rows
         rh_rlm_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.from_rate = from;
@@ -797,16 +1091,26 @@ private:
         cfg.filter_q = opt_.filter_q;
         cfg.max_sources = (std::uint32_t)g.srcs.size();
         cap_frames_ = opt_.block_frames + 4096;  // a block can hold what the previous one left over: less than two tiles' worth of input
-        cfg.max_in_frames = cap_frames_;
+        if (staged) {
+            g.target = opt_.block_frames + 64 * 20 + 8;  // a block emits whole tiles (at most 64 * 20 frames each) and keeps two frames of history
+            g.crow = g.target + 64;
+            for (Src &x : g.srcs) {
+                x.reader = detail::SpanReader(x.up.get());
+                x.plan = detail::UniformPlanner(2, rate_);
+            }
+            const std::size_t crowf = ((std::size_t)g.crow * 2 + 3) & ~std::size_t(3);
+            for (auto &b : g.conv) b.reset(g.srcs.size() * crowf);
+        }
+        cfg.max_in_frames = staged ? g.crow : cap_frames_;
         cfg.frames_per_lane = opt_.frames_per_lane;
         check(rh_rlm_create(&g.plan, &cfg), "rh_rlm_create");
         std::vector<float> gains;
-        for (const Src &x : g.srcs) gains.push_back(x.gain);
+        for (const Src &x : g.srcs) gains.push_back(staged ? 1.0f : x.gain);  // staged: the factor sits in front of the converter, where Mixer::add(src.amplify(g)) has it
         check(rh_rlm_set_gains(g.plan, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
         check(rh_rlm_stream_begin(g.plan), "rh_rlm_stream_begin");
         row_ = (cap_frames_ * 2 + 3) & ~std::size_t(3);  // 16-byte aligned rows
         std::uint64_t m = 0;
-        check(rh_resample_out_frames(cap_frames_, from, rate_, 2, 0, &m), "rh_resample_out_frames");
+        check(rh_resample_out_frames(staged ? g.crow : cap_frames_, from, rate_, 2, 0, &m), "rh_resample_out_frames");
         out_cap_frames_ = std::max<std::uint64_t>(out_cap_frames_, m + 64);
         for (auto &other : gens_)  // rates differ between generations: every queue holds two of the largest blocks
             for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * 2, (other->head + other->fill) * 2);
@@ -821,7 +1125,137 @@ private:
         check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
         b.swap(n);
     }
+    /// One block of a span-by-span generation.  Every source is topped up to `target` converted frames: it is pulled piece by
+    /// piece (a piece never crosses a span; its length is budgeted so that its output fits the row whatever the span does), the
+    /// pieces are planned into segments, ONE copy brings all rows to the device, ONE launch converts all segments of all sources
+    /// (plus the frames the last block left over, moved to the front of the other row set), and the fused kernel -- its converter
+    /// passing through -- filters and mixes the rows.
+    void run_block_staged(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        detail::PinnedBuf &stage = g.stage[g.slot];
+        detail::PinnedBuf &tabh = g.tab[g.slot];
+        g.slot ^= 1;
+        const std::size_t crowf = ((std::size_t)g.crow * 2 + 3) & ~std::size_t(3);
+        // 1. layout of the staging block: a row per live source, sized for what it is about to pull in its current format
+        std::vector<std::size_t> row_off(S, 0), row_cap(S, 0);
+        std::size_t total = 0;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            row_off[i] = total;
+            std::uint16_t ch = 0;
+            std::uint32_t rate = 0;
+            if (!x.ended && !x.reader.peek(ch, rate)) x.ended = true;  // the chain rodio would build now is empty
+            if (x.ended) continue;
+            const std::uint64_t want = g.target > x.have ? g.target - x.have : 0;
+            const std::uint64_t in_frames = want * rate / rate_ + 8;
+            row_cap[i] = x.plan.held_samples() + (std::size_t)in_frames * ch;
+            total += (row_cap[i] + 3) & ~std::size_t(3);
+        }
+        stage.reset(total ? total : 4);
+        g.din.reset(total ? total : 4);
+        std::vector<rh_uniform_seg> table;
+        std::uint64_t max_out = 0;
+        const int oc = g.ccur, nc = g.ccur ^ 1;
+        for (std::size_t i = 0; i < S; ++i) {  // what the last block left over: to the front of the other row set
+            Src &x = g.srcs[i];
+            if (!x.have) continue;
+            rh_uniform_seg sg;
+            std::memset(&sg, 0, sizeof sg);
+            sg.src = g.conv[oc].get() + i * crowf + x.off * 2;
+            sg.dst = g.conv[nc].get() + i * crowf;
+            sg.src_frames = sg.m1 = x.have;
+            sg.span_frames = UINT64_MAX;
+            sg.from_rate = sg.to_rate = rate_;
+            sg.from_ch = sg.to_ch = 2;
+            sg.gain = 1.0f;
+            table.push_back(sg);
+            max_out = std::max(max_out, x.have);
+        }
+        // 2. pull and plan
+        std::vector<detail::UniformPlanner::Seg> segs;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            if (x.ended) continue;
+            float *row = stage.get() + row_off[i];
+            x.plan.begin_block();
+            std::size_t fill = x.plan.held_samples();
+            if (fill) std::memcpy(row, x.held.data(), fill * sizeof(float));
+            segs.clear();
+            for (;;) {
+                std::uint16_t ch = 0;
+                std::uint32_t rate = 0;
+                if (!x.reader.peek(ch, rate)) {
+                    x.ended = true;
+                    break;
+                }
+                const std::uint64_t now = x.have + x.plan.out_frames();
+                if (now >= g.target) break;
+                std::uint64_t need = 0, most = 0;
+                x.plan.budget(rate, x.reader.opens_next(), g.target - now, g.crow - now, need, most);
+                const std::uint64_t n = std::min<std::uint64_t>(std::min(need, most), (row_cap[i] - fill) / ch);
+                if (!n) break;
+                detail::Piece pc;
+                const bool produced = x.reader.read_piece(row + fill, (std::size_t)n, pc);  // straight into the staging block
+                if (produced) {
+                    fill += pc.n;
+                    x.plan.add(pc, segs);
+                }
+                if (x.reader.ended()) {
+                    x.ended = true;
+                    break;
+                }
+                if (!produced) break;
+            }
+            x.plan.end_block();
+            x.held.assign(row + x.plan.keep_offset(), row + x.plan.keep_offset() + x.plan.keep_samples());
+            for (const detail::UniformPlanner::Seg &sg : segs) {
+                rh_uniform_seg t = sg.g;
+                t.src = g.din.get() + row_off[i] + sg.src_off;
+                t.dst = g.conv[nc].get() + i * crowf + (x.have + sg.dst_off) * 2;
+                t.gain = x.gain;
+                table.push_back(t);
+                max_out = std::max<std::uint64_t>(max_out, t.m1 - t.m0);
+            }
+            x.have += x.plan.out_frames();
+            if (x.have > g.crow) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
+        }
+        // 3. one copy, one conversion launch
+        if (total) check(rh_memcpy_h2d(g.din.get(), stage.get(), total * sizeof(float), stream_), "rh_memcpy_h2d");
+        if (!table.empty()) {
+            const std::size_t tf = table.size() * sizeof(rh_uniform_seg) / sizeof(float);
+            tabh.reset(tf);
+            g.dtab.reset(tf);
+            std::memcpy(tabh.get(), table.data(), tf * sizeof(float));
+            check(rh_memcpy_h2d(g.dtab.get(), tabh.get(), tf * sizeof(float), stream_), "rh_memcpy_h2d");
+            check(rh_uniform_segments_dev(reinterpret_cast<const rh_uniform_seg *>(g.dtab.get()), (std::uint32_t)table.size(), max_out, stream_), "rh_uniform_segments_dev");
+        }
+        g.ccur = nc;
+        // 4. filter + ordered sum of the converted rows
+        std::vector<const float *> ptrs(S);
+        std::vector<std::uint64_t> avail(S);
+        std::vector<std::uint8_t> ended(S);
+        bool all_ended = true;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            x.off = 0;
+            ptrs[i] = g.conv[nc].get() + i * crowf;
+            avail[i] = x.have;
+            ended[i] = x.ended ? 1 : 0;
+            all_ended = all_ended && x.ended;
+        }
+        std::uint64_t out = 0, consumed = 0;
+        check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+              "rh_rlm_stream_block_v");
+        g.fill += out;
+        for (Src &x : g.srcs) {
+            const std::uint64_t d = std::min(consumed, x.have);
+            x.off = d;
+            x.have -= d;
+        }
+        g.done = all_ended;  // the call that saw every source ended emitted everything that was left
+    }
     void run_block(Gen &g, Slot &) {
+        if (g.staged) return run_block_staged(g);
         const std::size_t S = g.srcs.size();
         detail::PinnedBuf &stage = g.stage[g.slot];
         g.slot ^= 1;
@@ -901,9 +1335,11 @@ private:
         const int li = flight ? ci ^ 1 : ci;                               // the last block that is scheduled
         const std::uint64_t sched_end = slot_base_[li] + slot_frames_[li];
         check(rh_stream_synchronize(stream_), "rh_stream_synchronize");   // the blocks about to be patched have been produced
+        const bool staged = spanned(item);
+        if (!staged) make_direct(item);
         std::vector<Src> one;
         one.push_back(std::move(item));
-        start_stream(std::move(one));
+        start_stream(std::move(one), staged);
         last_join_ = J;
         Gen &g = *gens_.back();
         const std::uint64_t need = sched_end > J ? sched_end - J : 0;

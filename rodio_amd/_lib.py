@@ -39,6 +39,11 @@ class WavInfo(C.Structure):
                 ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64), ("samples", C.c_uint64)]
 
 
+class UniformSeg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_frame0", C.c_uint64), ("src_frames", C.c_uint64), ("m0", C.c_uint64), ("m1", C.c_uint64),
+                ("span_frames", C.c_uint64), ("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("from_ch", C.c_uint32), ("to_ch", C.c_uint32), ("gain", C.c_float), ("reserved", C.c_uint32)]
+
+
 class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
@@ -110,6 +115,10 @@ SIGNATURES = {
     "rh_echo_mix": (i32, [vp, vp, sz, sz, f32, vp]),
     "rh_resample_out_frames": (i32, [u64, u32, u32, u32, u64, C.POINTER(u64)]),
     "rh_resample_linear": (i32, [vp, vp, u64, u32, u32, u32, u64, vp]),
+    "rh_uniform_span_frames": (i32, [u64, u32, u32, i32, C.POINTER(u64)]),
+    "rh_uniform_first_tap": (i32, [u64, u32, u32, C.POINTER(u64)]),
+    "rh_uniform_segments": (i32, [C.POINTER(UniformSeg), u32, vp]),
+    "rh_uniform_segments_dev": (i32, [vp, u32, u64, vp]),
     "rh_mix_sum": (i32, [vp, sz, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), u32, vp]),
     "rh_biquad_coeffs": (i32, [i32, u32, f32, u32, f32p]),
     "rh_biquad": (i32, [vp, vp, u64, u32, u32, f32p, vp, i32, vp]),

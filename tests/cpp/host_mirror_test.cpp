@@ -52,6 +52,31 @@ static std::vector<std::string> split(const std::string &s, char sep) {
     while (std::getline(ss, item, sep)) out.push_back(item);
     return out;
 }
+// The sources of the chains.  RH_TEST_SOURCE picks what `current_span_len()` says (the samples are the same):
+//   test (default)  None -- the TestSource of rodio's benches (benches/shared.rs:32-34): one continuous stream
+//   buffer          rodio's SamplesBuffer: Some(len) until exhausted, then Some(0)  (buffer.rs:76-82)
+//   spans:K         Some(K) throughout: spans of K samples, like a decoder's packets or Buffered's spans (buffered.rs:109)
+class TestSource : public rh::SamplesBuffer {
+public:
+    using rh::SamplesBuffer::SamplesBuffer;
+    std::optional<std::size_t> current_span_len() const override { return std::nullopt; }
+};
+class SpanSource : public rh::SamplesBuffer {
+public:
+    SpanSource(std::uint16_t ch, std::uint32_t rate, std::vector<float> d, std::size_t span) : rh::SamplesBuffer(ch, rate, std::move(d)), span_(span) {}
+    std::optional<std::size_t> current_span_len() const override { return span_; }
+
+private:
+    std::size_t span_;
+};
+static rh::BoxSource make_source(std::uint16_t ch, std::uint32_t rate, std::vector<float> data) {
+    const char *e = std::getenv("RH_TEST_SOURCE");
+    const std::string kind = e ? e : "test";
+    if (kind == "buffer") return std::make_unique<rh::SamplesBuffer>(ch, rate, std::move(data));
+    if (kind.rfind("spans:", 0) == 0) return std::make_unique<SpanSource>(ch, rate, std::move(data), (std::size_t)std::atoll(kind.c_str() + 6));
+    if (kind != "test") throw std::runtime_error("RH_TEST_SOURCE=" + kind);
+    return std::make_unique<TestSource>(ch, rate, std::move(data));
+}
 // the consumer: like the cpal callback, it takes samples one at a time; every so often in bulk, as wav_to_writer would
 static std::vector<float> drain(rh::Source &src) {
     std::vector<float> out;
@@ -108,6 +133,36 @@ int main(int argc, char **argv) {
             expect(buf.try_seek(std::chrono::seconds(6)) && odd(), "a seek from channel 1 continues with channel 1");
             expect(buf.try_seek(std::chrono::seconds(1000)) && !buf.next(), "seek saturates at the end");
         }
+        {  // buffer.rs:76-82: the whole buffer is one span; Some(0) once exhausted (is_exhausted, source/mod.rs:203-207)
+            rh::SamplesBuffer buf(2, 48000, {1, 2, 3, 4});
+            expect(buf.current_span_len() == std::optional<std::size_t>(4), "span = len");
+            (void)buf.next();
+            expect(buf.current_span_len() == std::optional<std::size_t>(4), "span stays the total length");
+            for (int i = 0; i < 3; ++i) (void)buf.next();
+            expect(buf.current_span_len() == std::optional<std::size_t>(0), "Some(0) when exhausted");
+        }
+        {  // SpanReader pulls like UniformSourceIterator (uniform.rs:50-68): min(span, 32768) samples per chain, then it asks again
+            std::vector<float> d(70000);
+            for (size_t i = 0; i < d.size(); ++i) d[i] = (float)i;
+            rh::SamplesBuffer buf(2, 44100, d);
+            rh::detail::SpanReader rd(&buf);
+            std::vector<float> tmp(70000);
+            rh::detail::Piece pc;
+            expect(rd.read_piece(tmp.data(), 20000, pc) && pc.n == 32768 && pc.opens && pc.closes && pc.ch == 2 && pc.rate == 44100, "first span: 32768 samples");
+            expect(rd.read_piece(tmp.data(), 10000, pc) && pc.n == 20000 && pc.opens && !pc.closes, "second span opens");
+            expect(rd.read_piece(tmp.data(), 100000, pc) && pc.n == 12768 && !pc.opens && pc.closes && tmp[0] == 52768.0f, "second span closes at 32768");
+            expect(rd.read_piece(tmp.data(), 100000, pc) && pc.n == 70000 - 65536 && pc.opens && pc.closes && rd.ended(), "the last span is what is left: the source returns None inside it");
+            expect(!rd.read_piece(tmp.data(), 100000, pc), "the stream is over");
+            bool threw = false;
+            try {  // min(span, 32768) cuts a frame of 6 channels: rodio rotates the channels from there on; refused here
+                rh::SamplesBuffer six(6, 48000, std::vector<float>(6 * 6000, 0.0f));
+                rh::detail::SpanReader r6(&six);
+                (void)r6.read_piece(tmp.data(), 10, pc);
+            } catch (const rh::Error &e) {
+                threw = e.status == RH_ERR_UNSUPPORTED;
+            }
+            expect(threw, "a span that cuts a frame is refused");
+        }
         {  // NonZero channels / rate (buffer.rs:40: the types cannot hold 0)
             bool threw = false;
             try {
@@ -143,7 +198,7 @@ int main(int argc, char **argv) {
                     lcg = lcg * 1664525u + 1013904223u;
                     v = ((float)(lcg >> 8) / 8388608.0f - 1.0f) / (float)S;
                 }
-                mixer.add(std::make_unique<rh::SamplesBuffer>(2, 44100, std::move(x)));
+                mixer.add(make_source(2, 44100, std::move(x)));
             }
             std::vector<float> chunk(1u << 16);
             size_t total = 0;
@@ -173,7 +228,7 @@ int main(int argc, char **argv) {
                 unsigned ch = 0, rate = 0;
                 float gain = 1.0f;
                 if (std::fscanf(sf, "%u %u %f", &ch, &rate, &gain) != 3) throw std::runtime_error("spec.txt: short");
-                mixer.add(std::make_unique<rh::SamplesBuffer>((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gain);
+                mixer.add(make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gain);
             }
             std::fclose(sf);
             out = drain(mixer);
@@ -188,7 +243,7 @@ int main(int argc, char **argv) {
             const size_t pull_first = (size_t)std::atoll(argv[11]);
             const std::vector<float> gains = read_f32(dir + "/gains.f32");
             rh::GpuMixer mixer(to, opt);
-            auto add = [&](int i) { mixer.add(std::make_unique<rh::SamplesBuffer>(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i)); };
+            auto add = [&](int i) { mixer.add(make_source(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i)); };
             for (int i = 0; i < S0; ++i) add(i);
             for (size_t k = 0; k < pull_first; ++k) {
                 const std::optional<float> v = mixer.next();
@@ -225,13 +280,13 @@ int main(int argc, char **argv) {
             const std::vector<float> gains = read_f32(dir + "/gains.f32");
             rh::GpuMixer mixer(to, opt);
             for (int i = 0; i < S; ++i)
-                mixer.add(std::make_unique<rh::SamplesBuffer>(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i));
+                mixer.add(make_source(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i));
             if (mixer.channels() != 2 || mixer.sample_rate() != to) throw std::runtime_error("format");
             out = drain(mixer);
         } else if (mode == "chain" && argc >= 6) {
             const uint16_t ch = (uint16_t)std::atoi(argv[3]);
             const uint32_t rate = (uint32_t)std::atoll(argv[4]);
-            rh::GpuSource g(std::make_unique<rh::SamplesBuffer>(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
+            rh::GpuSource g(make_source(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
             for (int a = 6; a < argc; ++a) {
                 const std::vector<std::string> t = split(argv[a], ':');
                 const std::string &op = t[0];

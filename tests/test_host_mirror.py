@@ -269,3 +269,122 @@ def test_gpu_source_try_seek(O, tmp_path, block):
     assert ok == 0  # NotSupported, nothing moved: the stream is the unbroken one
     ref = O.TestSource(x, ch, rate).amplify(0.8).reverb(20833333, 0.3).high_pass(300).collect()
     assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ sources that report spans ----
+# Mixer::add wraps every source in a UniformSourceIterator (mixer.rs:58-66), which re-builds its converter chain every
+# min(current_span_len, 32768) samples (uniform.rs:50-68).  A SamplesBuffer (buffer.rs:76-82), a Buffered source or a
+# decoder therefore comes out of rodio's mixer converted span by span -- with a seam every 16 384 stereo frames when the
+# rates differ -- and so it must here.  RH_TEST_SOURCE selects what the driver's sources report.
+def _span_source(O, kind, x, ch, rate, i=0):
+    if kind == "mixed":
+        kind = ["test", "buffer", "spans:4096"][i % 3]
+    if kind == "buffer":
+        return O.SamplesBuffer(ch, rate, x)
+    if kind.startswith("spans:"):
+        return O.SpanSource(x, ch, rate, int(kind[6:]))
+    return O.TestSource(x, ch, rate)
+
+
+def _run_env(args, tmp_path, **env):
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr
+    return np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["buffer", "spans:32768", "spans:2304", "mixed"])
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
+@pytest.mark.parametrize("block", [777, 16384])
+def test_gpu_mixer_converts_spanned_sources_span_by_span(O, tmp_path, kind, filt, freq, block):
+    # stereo and mono buffers at the mixer's rate and at three others; the first one is the verdict's case: 100 000 stereo
+    # frames 44.1 -> 48 kHz (7 spans: six seams in the converted stream)
+    spec = [(2, 44100, 1.0, 100000), (1, 44100, 0.7, 70000), (2, 48000, 0.9, 50000), (2, 22050, 0.5, 30000), (1, 96000, 0.8, 60001), (2, 44100, 1.1, 16384), (2, 44100, 0.6, 16385)]
+    xs = [rnd(3600 + i, ch * n, 0.1) for i, (ch, _, _, n) in enumerate(spec)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    (tmp_path / "spec.txt").write_text("".join(f"{ch} {rate} {g}\n" for ch, rate, g, _ in spec))
+    got = _run_env(["mixany", tmp_path, len(spec), 48000, filt, freq, block, 4], tmp_path, RH_TEST_SOURCE=kind)
+    m = O.Mixer(2, 48000)
+    for i, (ch, rate, g, _) in enumerate(spec):
+        u = O.UniformSourceIterator(_span_source(O, kind, xs[i], ch, rate, i).amplify(float(np.float32(g))), 2, 48000)
+        m.add(u.low_pass(freq) if filt == 0 else u)
+    ref = m.collect()
+    assert len(got) == len(ref), (len(got), len(ref))
+    if filt < 0:
+        assert np.array_equal(got, ref), int(np.argmax(got != ref))  # span-wise conversion + ordered sum: bit for bit
+    else:
+        assert float(np.max(np.abs(got - ref))) <= TOL
+    if kind == "buffer" and filt < 0:  # the seams are real: the continuous-stream answer differs
+        c = O.Mixer(2, 48000)
+        for i, (ch, rate, g, _) in enumerate(spec):
+            c.add(O.UniformSourceIterator(O.TestSource(xs[i], ch, rate).amplify(float(np.float32(g))), 2, 48000))
+        cont = c.collect()
+        assert len(cont) != len(ref) or not np.array_equal(cont, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["buffer", "spans:1000"])
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
+@pytest.mark.parametrize("pull_first", [11, 8704 * 2 + 1, 40000])
+def test_gpu_mixer_late_join_of_spanned_sources(O, tmp_path, kind, filt, freq, pull_first):
+    ns = [60000, 45000, 30011, 52000, 20000]
+    S0, S1 = 3, 2
+    gains = np.array([1.0, 0.5, 0.8, 1.1, 0.6], dtype=np.float32)
+    xs = [rnd(3700 + i, 2 * n, 0.15) for i, n in enumerate(ns)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    gains.tofile(tmp_path / "gains.f32")
+    got = _run_env(["late", tmp_path, S0, S1, 44100, 48000, filt, freq, 8192, 4, pull_first], tmp_path, RH_TEST_SOURCE=kind)
+
+    def src(i):
+        u = O.UniformSourceIterator(_span_source(O, kind, xs[i], 2, 44100).amplify(float(gains[i])), 2, 48000)
+        return u.low_pass(freq) if filt == 0 else u
+
+    m = O.Mixer(2, 48000)
+    for i in range(S0):
+        m.add(src(i))
+    ref = [m.next() for _ in range(pull_first)]
+    assert None not in ref
+    for i in range(S0, S0 + S1):
+        m.add(src(i))
+    ref = np.concatenate([np.asarray(ref, dtype=np.float32), m.collect()])
+    assert len(got) == len(ref), (len(got), len(ref))
+    if filt < 0:
+        assert np.array_equal(got, ref), int(np.argmax(got != ref))
+    else:
+        assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+SPAN_CHAINS = [
+    (2, 44100, 100000, ["uniform:2:48000"], lambda O, s: O.UniformSourceIterator(s, 2, 48000)),
+    (1, 44100, 70000, ["uniform:2:48000", "low_pass:200"], lambda O, s: O.UniformSourceIterator(s, 2, 48000).low_pass(200)),
+    (2, 48000, 40000, ["amplify:0.8", "uniform:2:44100"], lambda O, s: O.UniformSourceIterator(s.amplify(0.8), 2, 44100)),
+    (2, 22050, 33000, ["high_pass:300", "uniform:1:48000", "amplify:1.2"], lambda O, s: O.UniformSourceIterator(s.high_pass(300), 1, 48000).amplify(1.2)),
+    (2, 44100, 20000, ["uniform:2:44100"], lambda O, s: O.UniformSourceIterator(s, 2, 44100)),
+    # behind reverb (Mix: current_span_len() is None, mix.rs:92-94) the converter runs as one continuous stream
+    (2, 44100, 30000, ["reverb:20000000:0.3", "uniform:2:48000"], lambda O, s: O.UniformSourceIterator(s.reverb(20000000, 0.3), 2, 48000)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(SPAN_CHAINS)))
+@pytest.mark.parametrize("kind", ["buffer", "spans:32768", "spans:1500", "test"])
+@pytest.mark.parametrize("block", [777, 16384])
+def test_gpu_source_uniform_converts_span_by_span(O, tmp_path, case, kind, block):
+    ch, rate, n, ops, chain = SPAN_CHAINS[case]
+    x = rnd(3800 + case, ch * n, 0.9)
+    x.tofile(tmp_path / "src_0.f32")
+    got = _run_env(["chain", tmp_path, ch, rate, block] + ops, tmp_path, RH_TEST_SOURCE=kind)
+    ref = chain(O, _span_source(O, kind, x, ch, rate)).collect()
+    assert len(got) == len(ref), (ops, kind, len(got), len(ref))
+    if any(op.startswith(("low_pass", "high_pass")) for op in ops):
+        assert float(np.max(np.abs(got - ref))) <= TOL
+    else:
+        assert np.array_equal(got, ref), (ops, kind, int(np.argmax(got != ref)))
+
+
+def test_span_reader_and_samples_buffer_follow_rodio():
+    # buffer.rs:76-82, uniform.rs:50-68 on the host side alone (no GPU): part of `selftest`
+    r = subprocess.run([EXE, "selftest"], capture_output=True, text=True)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stderr
