@@ -1,0 +1,612 @@
+// rh_agc.hip -- AutomaticGainControl (src/source/agc.rs:133-171, :397-504) taken apart along its dependency chains.
+//
+// process_sample (agc.rs:433-504) per sample, one state for all interleaved channels of a stream:
+//     s      = |x|
+//     peak   = peak * c + s * (1 - c),  c = s > peak ? 0 : release                      update_peak_level   :397-407
+//     sum    = sum - old + s*s          (old: the square that leaves the 8192-sample window)   CircularBuffer::push :152-163
+//     rms    = sqrt(sum / 8192);  rms_gain = rms > 0 ? target / rms : max_gain
+//     peak_gain = peak > 0 ? min(target / peak, max_gain) : max_gain;  desired = max(min(rms_gain, peak_gain), floor)
+//     gain   = clamp(gain * a + desired * (1 - a), 0.1, max_gain),  a = desired > gain ? attack : release
+//     y      = x * gain
+// Only THREE short chains run along time: the window sum (two dependent adds), the peak follower (with the default release of 0
+// it is no chain at all: peak = s) and the gain (multiply, add, select, clamp).  Everything expensive -- the square root and the
+// two IEEE divides -- depends on the chains' RESULTS only.  Round 2 ran all of it on one lane per stream, 73 vector
+// instructions per sample one after the other (0.03-0.9 % of the HBM roofline).  Here:
+//     k_agc_chain<SumOp>     one lane per stream: the squares and 2 dependent adds per sample                 -> sum[n]      (into dst)
+//     k_agc_chain<PeakOp>    only when release != 0: the reference's select / multiply / add                  -> peak[n]     (scratch)
+//     k_agc_desired          every lane of the chip: sqrt, divides, min / max                                -> desired[n]  (in place)
+//     k_agc_chain<GainOp>    release != 0: both candidates, select, clamp, output multiply                    -> y[n]        (in place)
+//     k_agc_chain<GainOp0>   release == 0 (the default): the release candidate is `desired` itself; the chain is multiply, add,
+//                            max, compare, select on values the parallel pass prepared                         -> gain[n]     (in place)
+//     k_agc_apply            y = x * gain, every lane of the chip
+// Both chains MUST round like the reference, step by step: the window sum drifts 7e-5 relative over 2 Mi samples when
+// re-associated, and the gain -- a one-pole with a 4 s time constant, 192 000 samples at 48 kHz -- integrates its own rounding
+// noise to 5e-6 relative (x gain 7 = 4e-5 on the output): a scan over composed gain maps (g -> min(H, max(L, c*g + B)) is
+// closed under composition) was built and measured 7e-5 from the reference, outside the bound.  So the operations and their
+// order are the reference's and the result is bit-identical to the reference-order kernel (k_agc_seq in rh_recurrence.hip),
+// which stays for unaligned rows and in-place calls.
+//
+// What a chain costs: ONE wave walks time for 64 streams, and a lone wave issues one instruction every 5-7 cycles whatever its
+// kind (measured: SQ_WAVE_CYCLES / instructions), so the chain wave carries nothing but the chain -- wave 0 issues LDS reads,
+// the chain's arithmetic and LDS writes; waves 1 and 2 keep the next six chunks (32 samples per stream each) of the two inputs
+// coming by LDS-DMA (a chain is also bound by memory LATENCY: 1.6 us per round trip when one workgroup is all that runs);
+// wave 3 writes the previous chunk's results back.  Transfers are whole 128-byte lines through the swizzled tile image of
+// rh_scan_common.h: the chain wave reads and writes its 16-byte vectors without bank conflicts.  One barrier per chunk.
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+#include "rh_common.h"
+
+namespace {
+#include "rh_scan_common.h"
+
+constexpr uint32_t kRmsWindow = 8192;              // agc.rs:51
+constexpr size_t kAgcStateFloats = 4 + kRmsWindow;  // {sum, index(bits), peak_level, current_gain, ring[8192]} (as in rh_recurrence.hip)
+constexpr int kCS = 32;                             // samples per chunk and stream
+constexpr int kV = kCS / 4;                         // 16-byte vectors per lane and chunk
+constexpr int kGS = 64;                             // streams per workgroup: one per lane of the chain wave
+constexpr int kDma = kGS * kV / 64;                 // LDS-DMA instructions per chunk and array: 8
+constexpr int kRing = 8;                            // chunks of input in LDS: one in use, up to 6 in flight (6 x 8 = 48 outstanding per loader, vmcnt counts to 63)
+constexpr int kAhead = kRing - 2;
+constexpr uint32_t kSlotVecs = kGS * kV;            // one chunk of one array: 512 vectors = 8 KiB
+constexpr uint32_t kSlotBytes = kSlotVecs * 16;
+constexpr uint32_t kHeadChunks = kRmsWindow / kCS;
+// LDS: ring slot r = [first input | second input] at r * 2 * kSlotBytes (the second input is an immediate offset away from the
+// first), then the two result images
+constexpr uint32_t kOutBase = 2 * kRing * kSlotBytes;
+constexpr size_t kChainLds = (size_t)kOutBase + 2 * kSlotBytes;  // 144 KiB
+
+struct AgcK {
+    float target_level, attack_coeff, release_coeff, absolute_max_gain, floor;
+};
+
+struct ChainArgs {
+    const float *in0, *in1;  // rows of n samples, stride0 / stride1 floats apart (in1: SumOp's samples 8192 back, GainOp's desired gains)
+    const float *in1_head;   // SumOp: what leaves the window during the first 8192 samples -- the carried window, [streams][8192] in time order; null: zeros
+    float *out;
+    uint64_t n, stride0, stride1, stride_out;
+    uint32_t n_streams;
+    uint32_t head_chunks;    // chunks whose second input is in1_head (SumOp: 256; the others: 0)
+    float *state;            // per stream `state_stride` floats {sum, -, peak, gain, ...}: the caller's, or four scratch words per stream
+    uint32_t state_stride;
+    AgcK k;
+};
+
+// ---- the chains: the reference's operations in the reference's order (this TU is built with -ffp-contract=off) -------------
+struct SumOp {  // CircularBuffer::push, agc.rs:152-163: sum = sum - old + new
+    static constexpr bool kTwoIn = true;
+    float sum;
+    __device__ void init(const ChainArgs &, const float *st) { sum = st[0]; }
+    // HEAD: `o` is a square already (the carried window); otherwise the sample 8192 back
+    __device__ __forceinline__ float one(float x, float o, bool head) {
+        const float nw = x * x, od = head ? o : o * o;  // |x| * |x| (agc.rs:414) == x * x
+        sum = sum - od + nw;
+        return sum;
+    }
+    // (component by component: a vector multiply becomes v_pk_mul_f32, and a packed f32 instruction holds a lone wave ~20 cycles
+    // longer than a plain one -- measured 22.5 against 13.5 ns per sample for the gain chain of the same instruction count)
+    template <bool HEAD>
+    __device__ __forceinline__ v4f step4(v4f x, v4f o) {
+        v4f nw, od;
+        nw.x = x.x * x.x, nw.y = x.y * x.y, nw.z = x.z * x.z, nw.w = x.w * x.w;
+        if (HEAD) od = o;
+        else od.x = o.x * o.x, od.y = o.y * o.y, od.z = o.z * o.z, od.w = o.w * o.w;
+        v4f r;
+        sum = sum - od.x + nw.x, r.x = sum;
+        sum = sum - od.y + nw.y, r.y = sum;
+        sum = sum - od.z + nw.z, r.z = sum;
+        sum = sum - od.w + nw.w, r.w = sum;
+        return r;
+    }
+    __device__ void finish(float *st) { st[0] = sum; }
+};
+struct SumSqOp {  // the same on squares a parallel pass prepared (rows apart by a stride that is NOT a power of two): two adds
+    static constexpr bool kTwoIn = true;
+    float sum;
+    __device__ void init(const ChainArgs &, const float *st) { sum = st[0]; }
+    __device__ __forceinline__ float one(float nw, float od, bool) {
+        sum = sum - od + nw;
+        return sum;
+    }
+    template <bool HEAD>
+    __device__ __forceinline__ v4f step4(v4f nw, v4f od) {
+        v4f r;
+        sum = sum - od.x + nw.x, r.x = sum;
+        sum = sum - od.y + nw.y, r.y = sum;
+        sum = sum - od.z + nw.z, r.z = sum;
+        sum = sum - od.w + nw.w, r.w = sum;
+        return r;
+    }
+    __device__ void finish(float *st) { st[0] = sum; }
+};
+struct PeakOp {  // update_peak_level, agc.rs:397-407
+    static constexpr bool kTwoIn = false;
+    float peak, rel;
+    __device__ void init(const ChainArgs &a, const float *st) {
+        peak = st[2];
+        rel = a.k.release_coeff;
+    }
+    __device__ __forceinline__ float one(float x, float, bool) {
+        const float s = fabsf(x);
+        const float c = s > peak ? 0.0f : rel;
+        peak = peak * c + s * (1.0f - c);
+        return peak;
+    }
+    template <bool HEAD>
+    __device__ __forceinline__ v4f step4(v4f x, v4f) {
+        v4f r;
+        r.x = one(x.x, 0.f, false), r.y = one(x.y, 0.f, false), r.z = one(x.z, 0.f, false), r.w = one(x.w, 0.f, false);
+        return r;
+    }
+    __device__ void finish(float *st) { st[2] = peak; }
+};
+struct GainOp {  // agc.rs:486-499, and the output multiply :503
+    static constexpr bool kTwoIn = true;
+    float gain, att, rel, oma, omr, maxg;
+    __device__ void init(const ChainArgs &a, const float *st) {
+        gain = st[3];
+        att = a.k.attack_coeff;
+        rel = a.k.release_coeff;
+        oma = 1.0f - att;
+        omr = 1.0f - rel;
+        maxg = a.k.absolute_max_gain;
+    }
+    // gain * speed + desired * (1 - speed) for both speeds side by side (mul, mul, add: not contracted); what waits for the
+    // previous gain is one multiply, one add, the select and the clamp -- the other four operations fill the gaps.  Plain
+    // scalar operations on purpose: the packed forms (v_pk_mul_f32 / v_pk_add_f32) stall a dependent chain.
+    __device__ __forceinline__ float one(float x, float d, bool) {
+        const float da = d * oma, dr = d * omr;
+        const float ca = gain * att + da, cr = gain * rel + dr;
+        const float g = d > gain ? ca : cr;             // attack_speed = desired > current ? attack : release
+        gain = __builtin_amdgcn_fmed3f(g, 0.1f, maxg);  // f32::clamp(0.1, absolute_max_gain) of a number
+        return x * gain;
+    }
+    template <bool HEAD>
+    __device__ __forceinline__ v4f step4(v4f x, v4f d) {
+        v4f r;
+        r.x = one(x.x, d.x, false), r.y = one(x.y, d.y, false), r.z = one(x.z, d.z, false), r.w = one(x.w, d.w, false);
+        return r;
+    }
+    __device__ void finish(float *st) { st[3] = gain; }
+};
+
+struct GainOp0 {  // release == 0 (agc.rs:73-82's default): the release candidate gain * 0 + desired * 1 IS desired.
+    // in0 = dc = clamp(desired, 0.1, max), in1 = da = desired * (1 - attack), both from the parallel pass.  With 0.1 <= gain <= max
+    // (clamped since the first sample; a fresh AGC starts at 1.0):
+    //     desired >  gain: the attack candidate A = gain * attack + da lies below desired, its clamp is clamp(A, 0.1, dc)
+    //     desired <= gain: A >= desired, and the reference takes clamp(desired) = dc = clamp(A, 0.1, dc)
+    // so the select and both clamps are ONE median: gain' = med3(A, 0.1, dc).  A is the reference's mul, mul, add (da carries the
+    // second product); the result differs from the reference's only when A and desired are within a rounding of each other, by
+    // that rounding (one ulp, once: the recurrence contracts) -- the tests compare against the reference-order kernel at 2e-7.
+    static constexpr bool kTwoIn = true;
+    float gain, att;
+    __device__ void init(const ChainArgs &a, const float *st) {
+        gain = st[3];
+        att = a.k.attack_coeff;
+    }
+    __device__ __forceinline__ float one(float dc, float da, bool) {
+        gain = __builtin_amdgcn_fmed3f(gain * att + da, 0.1f, dc);
+        return gain;
+    }
+    template <bool HEAD>
+    __device__ __forceinline__ v4f step4(v4f dc, v4f da) {
+        v4f r;
+        r.x = one(dc.x, da.x, false), r.y = one(dc.y, da.y, false), r.z = one(dc.z, da.z, false), r.w = one(dc.w, da.w, false);
+        return r;
+    }
+    __device__ void finish(float *st) { st[3] = gain; }
+};
+
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the skeleton ---------------------------------------------------------------------------------------------------------
+// waves: 0 the chain; 1, 2 load the first input (an LDS-DMA instruction costs its wave 100-200 cycles of issue: four per wave and
+// chunk keep the loaders ahead of the chain); 3, 4 load the second input; 5 stores the results.  Barrier c (one per chunk, all
+// six waves) says: chunk c is in LDS, and the chain is done with chunk c - 1 (its ring slot is free, its results are complete).
+template <class Op>
+__device__ __forceinline__ void chain_body(const ChainArgs &a, uint32_t group) {
+    constexpr bool TWO = Op::kTwoIn;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / 64), lane = (int)threadIdx.x & 63;
+    const uint32_t g0 = group * (uint32_t)kGS;                                                  // first stream of the group
+    const uint32_t live = a.n_streams - g0 < (uint32_t)kGS ? a.n_streams - g0 : (uint32_t)kGS;   // streams in it
+    const uint64_t nch = a.n / kCS;                                                             // whole chunks; the rest is the chain wave's epilogue
+    if (wave == 0) {  // ---- the chain: lane = stream; LDS reads, the chain's arithmetic, LDS writes, nothing else ----
+        const bool mine = (uint32_t)lane < live;
+        const uint32_t stream = g0 + (mine ? (uint32_t)lane : live - 1);
+        float *st = a.state + (uint64_t)stream * a.state_stride;
+        Op op;
+        op.init(a, st);
+        uint32_t sl[kV];  // byte offset of this lane's vector j inside a chunk image
+#pragma unroll
+        for (int j = 0; j < kV; ++j) sl[j] = slot_of<kV>((uint32_t)lane, (uint32_t)j) * 16u;
+        // one chunk: all reads first, then the chain.  HEAD / ZERO are per-chunk facts: separate bodies, no per-sample selects
+        auto chunk = [&](uint64_t c, auto head_tag, auto zero_tag) {
+            constexpr bool HEAD = decltype(head_tag)::value, ZERO = decltype(zero_tag)::value;
+            const lds_u8 *in = lds + (uint32_t)(c % kRing) * (2u * kSlotBytes);
+            lds_u8 *img = lds + kOutBase + (uint32_t)(c & 1) * kSlotBytes;
+            v4f x[kV], o[kV];
+#pragma unroll
+            for (int j = 0; j < kV; ++j) {
+                x[j] = *(const __attribute__((address_space(3))) v4f *)(in + sl[j]);
+                o[j] = ZERO ? v4f{0.f, 0.f, 0.f, 0.f} : *(const __attribute__((address_space(3))) v4f *)(in + sl[j] + kSlotBytes);
+            }
+#pragma unroll
+            for (int j = 0; j < kV; ++j) *(__attribute__((address_space(3))) v4f *)(img + sl[j]) = op.template step4<HEAD>(x[j], o[j]);
+        };
+        const uint64_t nhead = TWO ? (nch < a.head_chunks ? nch : (uint64_t)a.head_chunks) : 0;
+        uint64_t c = 0;
+        if (a.in1_head) {
+            for (; c < nhead; ++c) {
+                barrier_lds();
+                chunk(c, std::true_type{}, std::false_type{});
+            }
+        } else {
+            for (; c < nhead; ++c) {
+                barrier_lds();
+                chunk(c, std::true_type{}, std::true_type{});
+            }
+        }
+        for (; c < nch; ++c) {
+            barrier_lds();
+            if (TWO) chunk(c, std::false_type{}, std::false_type{});
+            else chunk(c, std::false_type{}, std::true_type{});
+        }
+        barrier_lds();
+        if (mine) {  // the last n % 32 samples: straight from memory, one at a time
+            const float *r0 = a.in0 + (uint64_t)stream * a.stride0;
+            float *ro = a.out + (uint64_t)stream * a.stride_out;
+            for (uint64_t i = nch * kCS; i < a.n; ++i) {
+                const bool head = TWO && i < (uint64_t)a.head_chunks * kCS;
+                float ov = 0.0f;
+                if (TWO) ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : a.in1[(uint64_t)stream * a.stride1 + i];
+                const float xv = r0[i];
+                ro[i] = op.one(xv, ov, head);
+            }
+            op.finish(st);
+        }
+        return;
+    }
+    // per-lane geometry of the line-wise transfers: slot q = k*64 + lane of a chunk image holds vector vec_in_slot(q) = o*kV + j,
+    // i.e. samples 4j..4j+3 of stream o's chunk (surplus streams of the last group repeat the last live one and are never stored)
+    uint32_t so[kDma], sj[kDma];
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t vec = vec_in_slot<kV>((uint32_t)k * 64u + (uint32_t)lane);
+        so[k] = vec / kV;
+        sj[k] = vec % kV;
+    }
+    if (wave == 5) {  // ---- the storer: the previous chunk's results, whole lines ----
+        for (uint64_t c = 0; c <= nch; ++c) {
+            barrier_lds();
+            if (c == 0) continue;
+            const lds_u8 *img = lds + kOutBase + (uint32_t)((c - 1) & 1) * kSlotBytes;
+            float *ob = a.out + (uint64_t)g0 * a.stride_out + (c - 1) * kCS;
+#pragma unroll
+            for (int k = 0; k < kDma; ++k) {
+                const v4f v = *(const __attribute__((address_space(3))) v4f *)(img + (k * 64 + lane) * 16);
+                if (so[k] < live) *reinterpret_cast<v4f *>(ob + (uint64_t)so[k] * a.stride_out + sj[k] * 4u) = v;
+            }
+        }
+        return;
+    }
+    // ---- the loaders: kAhead chunks ahead of the chain; wave 1 + h / 3 + h issues instructions h*kDma/2 .. of a chunk ----
+    const int second = wave >= 3 ? 1 : 0, half = (wave - 1) & 1;
+    if (second && !TWO) {
+        for (uint64_t c = 0; c <= nch; ++c) barrier_lds();
+        return;
+    }
+    constexpr int kMine = kDma / 2;
+    const uint32_t lbase = (uint32_t)(uintptr_t)lds + (second ? kSlotBytes : 0u);
+    uint32_t voff0[kDma], voff1[kDma];  // host: kGS * stride * 4 < 2^32
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t o = so[k] < live ? so[k] : live - 1;
+        voff0[k] = (uint32_t)(((uint64_t)o * a.stride0 + sj[k] * 4u) * 4u);
+        voff1[k] = (uint32_t)(((uint64_t)o * a.stride1 + sj[k] * 4u) * 4u);
+    }
+    auto issue = [&](uint64_t c) {
+        const uint32_t slot = lbase + (uint32_t)(c % kRing) * (2u * kSlotBytes);
+        if (second && c < a.head_chunks && a.in1_head) {  // rows of 8192 floats: the carried window
+            const float *bh = a.in1_head + (uint64_t)g0 * kRmsWindow + c * kCS;
+#pragma unroll
+            for (int k = 0; k < kDma; ++k)
+                if (k / kMine == half) glds16(bh, (((so[k] < live ? so[k] : live - 1) * kRmsWindow + sj[k] * 4u) * 4u), slot + k * 1024);
+            return;
+        }
+        // (a fresh window -- zeros, the chain does not read the slot -- still fetches, the first input again: every chunk counts
+        // the same in vmcnt)
+        const bool first = !second || c < a.head_chunks;
+        const float *b = first ? a.in0 + (uint64_t)g0 * a.stride0 + c * kCS : a.in1 + (uint64_t)g0 * a.stride1 + c * kCS;
+#pragma unroll
+        for (int k = 0; k < kDma; ++k)
+            if (k / kMine == half) glds16(b, first ? voff0[k] : voff1[k], slot + k * 1024);
+    };
+    for (uint64_t c = 0; c < nch && c < (uint64_t)kAhead; ++c) issue(c);
+    for (uint64_t c = 0; c < nch; ++c) {
+        // chunk c has landed when only the chunks issued after it are outstanding (vmcnt retires in order)
+        const uint64_t left = nch - 1 - c;
+        if (left >= (uint64_t)(kAhead - 1)) wait_vm<(kAhead - 1) * kMine>();
+        else if (left >= 3) wait_vm<3 * kMine>();  // the last chunks of a row: coarser steps (waiting for more than necessary is harmless)
+        else if (left == 2) wait_vm<2 * kMine>();
+        else if (left == 1) wait_vm<kMine>();
+        else wait_vm<0>();
+        barrier_lds();
+        if (c + kAhead < nch) issue(c + kAhead);  // into the slot of chunk c - 2, which the chain left two barriers ago
+    }
+    barrier_lds();
+}
+template <class Op>
+__global__ __launch_bounds__(384) void k_agc_chain(const ChainArgs a) {
+    chain_body<Op>(a, blockIdx.x);
+}
+// Two chains side by side in one launch: even workgroups walk chain A, odd ones chain B (other arrays, other state words) -- the
+// window sum of one time segment next to the gain of the segment before it.
+template <class OpA, class OpB>
+__global__ __launch_bounds__(384) void k_agc_chain2(const ChainArgs a, const ChainArgs b) {
+    if (blockIdx.x & 1) chain_body<OpB>(b, blockIdx.x >> 1);
+    else chain_body<OpA>(a, blockIdx.x >> 1);
+}
+
+// ---- everything that is not a chain: one lane per 4 samples, the whole chip.  A launch covers samples [off, off + len) of every row
+// (rows are n floats apart).
+struct SegArgs {
+    uint64_t n, off, len;
+    uint32_t n_streams;
+};
+// desired gain from the window sum (in `d`, replaced in place) and the peak level (|x| when release == 0: peak * 0 + s * 1).
+// da != null (release == 0): d receives clamp(desired, 0.1, max) and da desired * (1 - attack), what GainOp0 reads
+__global__ __launch_bounds__(256) void k_agc_desired(float *__restrict__ d, const float *__restrict__ x, const float *__restrict__ peak, float *__restrict__ da, SegArgs g, AgcK k,
+                                                       float *__restrict__ peak_state) {
+    const uint64_t vpr = (g.len + 3) / 4, nvec = vpr * g.n_streams;  // vectors per row (the last one may be cut)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto one = [&](float sum, float p) {
+        const float rms = sqrtf(sum / (float)kRmsWindow);  // agc.rs:416, :169
+        const float rms_gain = rms > 0.0f ? k.target_level / rms : k.absolute_max_gain;
+        const float peak_gain = p > 0.0f ? fminf(k.target_level / p, k.absolute_max_gain) : k.absolute_max_gain;  // agc.rs:424-430
+        return fmaxf(fminf(rms_gain, peak_gain), k.floor);
+    };
+    const float oma = 1.0f - k.attack_coeff;
+    auto clampg = [&](float v) { return v < 0.1f ? 0.1f : (v > k.absolute_max_gain ? k.absolute_max_gain : v); };
+    for (uint64_t v = i0; v < nvec; v += stride) {
+        const uint64_t row = v / vpr, col = (v % vpr) * 4, at = row * g.n + g.off + col;
+        if (col + 4 <= g.len) {
+            const v4f s4 = *reinterpret_cast<const v4f *>(d + at);
+            const v4f x4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(x + at));
+            v4f p4;
+            if (peak) p4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(peak + at));
+            else p4 = v4f{fabsf(x4.x), fabsf(x4.y), fabsf(x4.z), fabsf(x4.w)};
+            v4f r;
+            r.x = one(s4.x, p4.x), r.y = one(s4.y, p4.y), r.z = one(s4.z, p4.z), r.w = one(s4.w, p4.w);
+            if (da) {
+                *reinterpret_cast<v4f *>(da + at) = r * oma;
+                r.x = clampg(r.x), r.y = clampg(r.y), r.z = clampg(r.z), r.w = clampg(r.w);
+            }
+            *reinterpret_cast<v4f *>(d + at) = r;
+        } else {
+            for (uint64_t i = col; i < g.len; ++i) {
+                const uint64_t q = row * g.n + g.off + i;
+                const float r = one(d[q], peak ? peak[q] : fabsf(x[q]));
+                if (da) da[q] = r * oma;
+                d[q] = da ? clampg(r) : r;
+            }
+        }
+    }
+    if (peak_state && g.len)  // release == 0: the peak level the next block starts from is the last sample's magnitude
+        for (uint64_t r = i0; r < g.n_streams; r += stride) peak_state[r * kAgcStateFloats + 2] = fabsf(x[r * g.n + g.off + g.len - 1]);
+}
+// y = x * gain (agc.rs:503), in place of the gain
+__global__ __launch_bounds__(256) void k_agc_apply(float *__restrict__ gn, const float *__restrict__ x, SegArgs g) {
+    const uint64_t vpr = (g.len + 3) / 4, nvec = vpr * g.n_streams;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t v = i0; v < nvec; v += stride) {
+        const uint64_t row = v / vpr, col = (v % vpr) * 4, at = row * g.n + g.off + col;
+        if (col + 4 <= g.len) {
+            const v4f a = *reinterpret_cast<const v4f *>(gn + at), b = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(x + at));
+            *reinterpret_cast<v4f *>(gn + at) = b * a;
+        } else {
+            for (uint64_t i = col; i < g.len; ++i) gn[row * g.n + g.off + i] = x[row * g.n + g.off + i] * gn[row * g.n + g.off + i];
+        }
+    }
+}
+// squares of samples [off, off + len) of every row into rows `pstride` floats apart (what SumSqOp walks)
+__global__ __launch_bounds__(256) void k_agc_square(float *__restrict__ sq, uint64_t pstride, const float *__restrict__ x, SegArgs g) {
+    const uint64_t vpr = (g.len + 3) / 4, nvec = vpr * g.n_streams;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t v = i0; v < nvec; v += stride) {
+        const uint64_t row = v / vpr, col = (v % vpr) * 4;
+        const float *xi = x + row * g.n + g.off + col;
+        float *so = sq + row * pstride + g.off + col;
+        if (col + 4 <= g.len) {
+            const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(xi));
+            *reinterpret_cast<v4f *>(so) = a * a;
+        } else {
+            for (uint64_t i = 0; col + i < g.len; ++i) so[i] = xi[i] * xi[i];
+        }
+    }
+}
+// four scratch words per stream for a call without a state: a fresh AGC (agc.rs:209-236)
+__global__ __launch_bounds__(256) void k_agc_fresh(float *__restrict__ st4, uint32_t n_streams) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_streams * 4u) st4[i] = (i & 3u) == 3u ? 1.0f : 0.0f;
+}
+// the carried window in time order: ordered[s][i] = ring[(index + i) & 8191]
+__global__ __launch_bounds__(256) void k_agc_window_out(float *__restrict__ ordered, const float *__restrict__ state, uint32_t n_streams) {
+    const uint64_t total = (uint64_t)n_streams * kRmsWindow, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const uint64_t s = q / kRmsWindow;
+        const uint32_t i = (uint32_t)(q % kRmsWindow);
+        const float *st = state + s * kAgcStateFloats;
+        ordered[q] = st[4 + ((__float_as_uint(st[1]) + i) & (kRmsWindow - 1))];
+    }
+}
+// the window the next block starts from: the last 8192 squares of (carried window ++ this block), stored in time order (index 0)
+__global__ __launch_bounds__(256) void k_agc_window_in(float *__restrict__ state, const float *__restrict__ ordered, const float *__restrict__ x, uint64_t n, uint32_t n_streams) {
+    const uint64_t total = (uint64_t)n_streams * kRmsWindow, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const uint64_t s = q / kRmsWindow, i = q % kRmsWindow;
+        float v;
+        if (n + i < kRmsWindow) v = ordered[s * kRmsWindow + n + i];
+        else {
+            const float xv = x[s * n + (n + i - kRmsWindow)];
+            v = fabsf(xv) * fabsf(xv);
+        }
+        float *st = state + s * kAgcStateFloats;
+        st[4 + i] = v;
+        if (i == 0) st[1] = __uint_as_float(0u);
+    }
+}
+
+template <class K>
+rh_status chain_attr(K kernel, const char *what) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, what);
+        return RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+template <class Op>
+rh_status launch_chain(const ChainArgs &a, hipStream_t s) {
+    static const rh_status attr = chain_attr(&k_agc_chain<Op>, "hipFuncSetAttribute(k_agc_chain)");
+    if (attr != RH_OK) return attr;
+    hipLaunchKernelGGL(k_agc_chain<Op>, dim3((a.n_streams + kGS - 1) / kGS), dim3(384), kChainLds, s, a);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+template <class OpA, class OpB>
+rh_status launch_chain2(const ChainArgs &a, const ChainArgs &b, hipStream_t s) {
+    static const rh_status attr = chain_attr(&k_agc_chain2<OpA, OpB>, "hipFuncSetAttribute(k_agc_chain2)");
+    if (attr != RH_OK) return attr;
+    hipLaunchKernelGGL((k_agc_chain2<OpA, OpB>), dim3(2 * ((a.n_streams + kGS - 1) / kGS)), dim3(384), kChainLds, s, a, b);
+    RH_CHECK_LAUNCH();
+    return RH_OK;
+}
+
+}  // namespace
+
+namespace rh {
+// rh_agc for rows that start on 16-byte boundaries, dst and src apart.  k5 = {target, attack coefficient, release coefficient, max gain, floor}.
+// RH_ERR_UNSUPPORTED: not this shape -- the caller takes the reference-order kernel.
+rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uint32_t n_streams, const float k5[5], float *state, hipStream_t s) {
+    if (n_samples >= (1ull << 24) || n_streams == 0 || n_streams > 0x7fffffu) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets across the rows of a group
+    AgcK k{k5[0], k5[1], k5[2], k5[3], k5[4]};
+    // release == 0 (the default): peak = peak * 0 + s * 1 = s, no chain, and the gain's release candidate is `desired` itself
+    // (GainOp0's shortcuts also want 0.1 <= max and floor <= max, so that desired <= max)
+    const bool general = k.release_coeff != 0.0f || !(k.floor <= k.absolute_max_gain) || !(k.absolute_max_gain >= 0.1f);
+    // scratch: four state words per stream for a call without a state | the carried windows in time order | one row per stream
+    // for the peak levels (general) or for desired * (1 - attack)
+    const size_t fresh_floats = state ? 0 : (((size_t)n_streams * 4 + 3) & ~(size_t)3);
+    const size_t win_floats = state ? (size_t)n_streams * kRmsWindow : 0;
+    // Few streams: a chain is all that runs, and what it costs per sample counts.  The squares then come from a parallel pass, into
+    // rows that are NOT a power of two apart: the 64 rows a workgroup walks side by side otherwise sit on the same HBM channels
+    // (measured: 22.6 against 14.5 ns per sample for rows of 2^21 and 2^21 + 128 samples).
+    const bool presq = !general && n_streams <= 512 && n_samples >= 4 * kRmsWindow;
+    const uint64_t pstride = ((n_samples + 31) & ~31ull) + 160;
+    if (presq && pstride >= (1ull << 24)) return RH_ERR_UNSUPPORTED;
+    std::unique_lock<std::mutex> hold;
+    float *scr = nullptr;
+    RH_HIP_TRY(rh::stream_scratch(s, (fresh_floats + win_floats + (size_t)n_streams * n_samples + (presq ? (size_t)n_streams * pstride : 0)) * sizeof(float),
+                                  reinterpret_cast<void **>(&scr), hold));
+    float *ordered = state ? scr + fresh_floats : nullptr, *rows = scr + fresh_floats + win_floats, *sq = rows + (size_t)n_streams * n_samples;
+    const unsigned wgrid = rh::grid_for((size_t)n_streams * kRmsWindow);
+    if (state) {
+        hipLaunchKernelGGL(k_agc_window_out, dim3(wgrid), dim3(256), 0, s, ordered, state, n_streams);
+    } else {
+        hipLaunchKernelGGL(k_agc_fresh, dim3((n_streams * 4 + 255) / 256), dim3(256), 0, s, scr, n_streams);
+    }
+    RH_CHECK_LAUNCH();
+    ChainArgs base;
+    base.k = k;
+    base.stride0 = base.stride1 = base.stride_out = n_samples;
+    base.n_streams = n_streams;
+    base.state = state ? state : scr;
+    base.state_stride = state ? (uint32_t)kAgcStateFloats : 4u;
+    // The two chains of a stream overlap in TIME SEGMENTS: one launch walks the window sum of segment i (even workgroups) next to
+    // the gain of segment i - 1 (odd workgroups), the parallel passes in between prepare and finish what they need.  A segment
+    // is at least the window long, so that only the first one reads the carried window.
+    uint64_t nseg = general ? 1 : n_samples / (2 * kRmsWindow);
+    nseg = nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg);
+    uint64_t seg_len = ((n_samples + nseg - 1) / nseg + kCS - 1) / kCS * kCS;
+    auto seg = [&](uint64_t i, uint64_t &off, uint64_t &len) {
+        off = i * seg_len;
+        len = off >= n_samples ? 0 : (n_samples - off < seg_len ? n_samples - off : seg_len);
+    };
+    auto sum_args = [&](uint64_t i) {
+        uint64_t off, len;
+        seg(i, off, len);
+        ChainArgs a = base;
+        a.in0 = (presq ? sq : src) + off;
+        a.in1 = a.in0 - kRmsWindow;  // the sample 8192 back (never touched in front of the row: those chunks read in1_head)
+        if (presq) a.stride0 = a.stride1 = pstride;
+        a.in1_head = i == 0 ? ordered : nullptr;
+        a.head_chunks = i == 0 ? kHeadChunks : 0;
+        a.out = dst + off;
+        a.n = len;
+        return a;
+    };
+    auto par_grid = [&](uint64_t len) { return dim3(rh::grid_for((size_t)n_streams * ((len + 3) / 4) + 1)); };
+    rh_status st = RH_OK;
+    if (general) {
+        // window sum -> dst and peak follower -> rows side by side, desired gain in place, then the gain chain with both candidates
+        ChainArgs a = sum_args(0), p = base;
+        p.in0 = src;
+        p.in1 = nullptr;
+        p.in1_head = nullptr;
+        p.head_chunks = 0;
+        p.out = rows;
+        p.n = n_samples;
+        if ((st = launch_chain2<SumOp, PeakOp>(a, p, s)) != RH_OK) return st;
+        const SegArgs g{n_samples, 0, n_samples, n_streams};
+        hipLaunchKernelGGL(k_agc_desired, par_grid(n_samples), dim3(256), 0, s, dst, src, rows, (float *)nullptr, g, k, (float *)nullptr);
+        RH_CHECK_LAUNCH();
+        ChainArgs q = base;
+        q.in0 = src;
+        q.in1 = dst;
+        q.in1_head = nullptr;
+        q.head_chunks = 0;
+        q.out = dst;
+        q.n = n_samples;
+        if ((st = launch_chain<GainOp>(q, s)) != RH_OK) return st;
+    } else {
+        for (uint64_t i = 0; i <= nseg; ++i) {
+            uint64_t off, len, poff, plen;
+            seg(i, off, len);
+            seg(i ? i - 1 : 0, poff, plen);
+            ChainArgs gq = base;  // the gain of segment i - 1: clamp(desired) in dst, desired * (1 - attack) in rows
+            gq.in0 = dst + poff;
+            gq.in1 = rows + poff;
+            gq.in1_head = nullptr;
+            gq.head_chunks = 0;
+            gq.out = dst + poff;
+            gq.n = plen;
+            if (presq && i < nseg && len) {
+                hipLaunchKernelGGL(k_agc_square, par_grid(len), dim3(256), 0, s, sq, pstride, src, SegArgs{n_samples, off, len, n_streams});
+                RH_CHECK_LAUNCH();
+            }
+            if (i < nseg && len && i > 0) st = presq ? launch_chain2<SumSqOp, GainOp0>(sum_args(i), gq, s) : launch_chain2<SumOp, GainOp0>(sum_args(i), gq, s);
+            else if (i < nseg && len) st = presq ? launch_chain<SumSqOp>(sum_args(i), s) : launch_chain<SumOp>(sum_args(i), s);
+            else if (i > 0 && plen) st = launch_chain<GainOp0>(gq, s);
+            if (st != RH_OK) return st;
+            if (i > 0 && plen) {  // y = x * gain
+                hipLaunchKernelGGL(k_agc_apply, par_grid(plen), dim3(256), 0, s, dst, src, SegArgs{n_samples, poff, plen, n_streams});
+                RH_CHECK_LAUNCH();
+            }
+            if (i < nseg && len) {
+                const bool last = off + len == n_samples;
+                hipLaunchKernelGGL(k_agc_desired, par_grid(len), dim3(256), 0, s, dst, src, (const float *)nullptr, rows, SegArgs{n_samples, off, len, n_streams}, k,
+                                   (state && last) ? state : (float *)nullptr);
+                RH_CHECK_LAUNCH();
+            }
+        }
+    }
+    if (state) {
+        hipLaunchKernelGGL(k_agc_window_in, dim3(wgrid), dim3(256), 0, s, state, ordered, src, n_samples, n_streams);
+        RH_CHECK_LAUNCH();
+    }
+    return RH_OK;
+}
+}  // namespace rh

@@ -1728,6 +1728,7 @@ struct rh_rlm {
     // block streaming (rh_rlm_stream_*)
     bool st_on = false, st_done = false;
     uint64_t st_g0 = 0, st_m = 0;
+    uint64_t st_chunk_in = 0, st_chunk_out = 0;  // a stream of spanned sources: input / output frames per span (0: continuous)
     uint32_t st_nsrc = 0;
     float *d_w[2] = {nullptr, nullptr};
     int st_cur = 0;
@@ -2156,8 +2157,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.ticket = p->d_ctl;
     k.status = p->d_ctl + 1;
     k.out_frames = p->out_frames;
-    k.chunk_in = p->chunk_in;
-    k.chunk_out = p->chunk_out;
+    k.chunk_in = sa.mode ? p->st_chunk_in : p->chunk_in;  // a stream knows its spans whatever the block size
+    k.chunk_out = sa.mode ? p->st_chunk_out : p->chunk_out;
     k.n_sources = count;
     k.n_tiles = p->n_tiles;
     k.F = p->F;
@@ -2316,10 +2317,41 @@ static rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s) {
     return RH_OK;
 }
 
+// Closed forms of sample_rate.rs:131-201 for a stream whose converter restarts every `cin` input frames (`cout` output frames
+// per whole span; cin == 0: one continuous conversion).
+static uint64_t lerp_ready(uint64_t n, uint64_t F, uint64_t T) {  // #m with floor(m*F/T) <= n-2: both taps have arrived
+    return n ? (uint64_t)((((unsigned __int128)(n - 1) * T) + F - 1) / F) : 0;
+}
+static uint64_t run_total(uint64_t n, uint64_t F, uint64_t T) {  // ... plus the verbatim last frame of a run that is complete
+    const uint64_t c1 = lerp_ready(n, F, T);
+    return n && (unsigned __int128)c1 * F < (unsigned __int128)n * T ? c1 + 1 : c1;
+}
+static uint64_t stream_ready(uint64_t N, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // a source that will deliver more
+    if (!cin) return lerp_ready(N, F, T);
+    return N / cin * cout + lerp_ready(N % cin, F, T);  // whole spans are complete, verbatim frame included
+}
+static uint64_t stream_total(uint64_t N, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // a source that has ended with N frames
+    if (!cin) return run_total(N, F, T);
+    return N / cin * cout + run_total(N % cin, F, T);
+}
+static uint64_t stream_first_tap(uint64_t m, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // the input frame output frame m reads first
+    if (!cin) return (uint64_t)(((unsigned __int128)m * F) / T);
+    const uint64_t k = m / cout, il = (uint64_t)(((unsigned __int128)(m % cout) * F) / T);
+    return k * cin + (il < cin - 1 ? il : cin - 1);
+}
+
 rh_status rh_rlm_stream_begin(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
-    if (p->cfg.span_len != 0) return RH_ERR_UNSUPPORTED;  // spans are converted one by one (uniform.rs:56-67): use rh_rlm_run per span
+    p->st_chunk_in = p->st_chunk_out = 0;
+    if (p->cfg.span_len != 0) {  // sources that report spans of span_len samples: the converter restarts every min(span_len, 32768) samples (uniform.rs:56-67)
+        const uint64_t span = p->cfg.span_len < 32768 ? p->cfg.span_len : 32768;
+        if (span % p->cfg.channels != 0) return RH_ERR_UNSUPPORTED;  // a span that splits a frame
+        p->st_chunk_in = span / p->cfg.channels;
+        const rh_status st = rh_resample_out_frames(p->st_chunk_in, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &p->st_chunk_out);
+        if (st != RH_OK) return st;
+        if (p->F == p->T) p->st_chunk_in = p->st_chunk_out = 0;  // the converter passes through: its restarts leave no trace
+    }
     {
         const rh_status w = wait_idle(p);  // a previous stream's last block may still read its state words
         if (w != RH_OK) return w;
@@ -2348,13 +2380,9 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
     *consumed_frames = 0;
     const uint64_t F = p->F, T = p->T, R = p->fast.v->R, L = 64 * R;
     const uint64_t N = p->st_g0 + avail_frames;  // input frames of the stream that exist so far
-    uint64_t m_end = 0;                           // output frames computable from them
-    if (N > 0) {
-        const unsigned __int128 num = (unsigned __int128)(N - 1) * T;
-        const uint64_t c1 = (uint64_t)((num + F - 1) / F);  // every m with floor(m*F/T) <= N-2
-        m_end = c1;
-        if (flush && (unsigned __int128)c1 * F < (unsigned __int128)N * T) m_end = c1 + 1;  // + the verbatim last frame
-    }
+    const uint64_t cin = p->st_chunk_in, cout = p->st_chunk_out;
+    // output frames computable from them: every m whose two taps have arrived; at the end also the verbatim last frame
+    const uint64_t m_end = flush ? stream_total(N, F, T, cin, cout) : stream_ready(N, F, T, cin, cout);
     uint64_t out = m_end > p->st_m ? m_end - p->st_m : 0;
     if (!flush) out = out / R * R;
     if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
@@ -2399,8 +2427,8 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
         p->st_done = true;
         *consumed_frames = avail_frames;
     } else {
-        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T)
-        const uint64_t keep_from = p->st_m >= 2 ? (uint64_t)(((unsigned __int128)(p->st_m - 2) * F) / T) : 0;
+        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T) (of their span)
+        const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
         const uint64_t cons = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
         *consumed_frames = cons < avail_frames ? cons : avail_frames;
         p->st_g0 += *consumed_frames;
@@ -2413,12 +2441,6 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
 // different times) -- k_rlm_wave, whose look-back is per source anyway.  A block emits whole tiles, so the state
 // that crosses the boundary is a tile carry: k_rlm_state folds the block's aggregates into column 0 of the
 // aggregate rows, where the next launch finds it as the aggregate of a virtual predecessor tile.
-static uint64_t total_out_frames(uint64_t N, uint64_t F, uint64_t T) {  // sample_rate.rs:131-201 in closed form (continuous source)
-    if (N == 0) return 0;
-    const unsigned __int128 num = (unsigned __int128)(N - 1) * T;
-    const uint64_t c1 = (uint64_t)((num + F - 1) / F);
-    return (unsigned __int128)c1 * F < (unsigned __int128)N * T ? c1 + 1 : c1;
-}
 
 rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
                                 uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
@@ -2429,12 +2451,14 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
     *out_frames = 0;
     *consumed_frames = 0;
     const uint64_t F = p->F, T = p->T, L = 64ull * p->wave.v->R;
+    const uint64_t cin = p->st_chunk_in, cout = p->st_chunk_out;
     hipStream_t hs = rh::as_stream(stream);
     if (!p->st_cols) {  // first block of the stream: size the aggregate rows once (the states live in them), zero states
         rh::ResampleGeom g;
         rh_status st = rh::make_resample_geom(p->cfg.max_in_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &g);
         if (st != RH_OK) return st;
-        const uint64_t cols = (g.out_frames + L - 1) / L + 2;
+        const uint64_t span_extra = cin ? p->cfg.max_in_frames / cin + 2 : 0;  // every span a block touches adds its verbatim frame
+        const uint64_t cols = (g.out_frames + span_extra + L - 1) / L + 2;
         if (cols > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
         const size_t words = (size_t)(p->cfg.max_sources + 1) * cols * 4;  // as activate_plan counts: one row per source + the row of summed aggregates
         if (p->filt && words > p->gran_words) {
@@ -2467,12 +2491,12 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         if (p->st_total[s] == ~0ull && ended_host[s]) p->st_total[s] = p->st_g0 + avail_frames_host[s];
         if (p->st_total[s] == ~0ull) {
             const uint64_t N = p->st_g0 + avail_frames_host[s];
-            const uint64_t m_end = N ? (uint64_t)((((unsigned __int128)(N - 1) * T) + F - 1) / F) : 0;  // every m with floor(m*F/T) <= N-2
+            const uint64_t m_end = stream_ready(N, F, T, cin, cout);  // every m whose two taps have arrived
             const uint64_t can = m_end > p->st_m ? m_end - p->st_m : 0;
             live_min = can < live_min ? can : live_min;
             any_live = true;
         } else {
-            const uint64_t M = total_out_frames(p->st_total[s], F, T);
+            const uint64_t M = stream_total(p->st_total[s], F, T, cin, cout);
             const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
             ended_max = rem > ended_max ? rem : ended_max;
         }
@@ -2490,7 +2514,7 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         for (uint32_t s = 0; s < n_sources; ++s) {
             uint64_t ms = out;
             if (p->st_total[s] != ~0ull) {
-                const uint64_t M = total_out_frames(p->st_total[s], F, T);
+                const uint64_t M = stream_total(p->st_total[s], F, T, cin, cout);
                 const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
                 ms = rem < out ? rem : out;
             }
@@ -2532,7 +2556,7 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
     } else {
         // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T).  The
         // caller drops min(consumed, what it holds) frames of every source.
-        const uint64_t keep_from = p->st_m >= 2 ? (uint64_t)(((unsigned __int128)(p->st_m - 2) * F) / T) : 0;
+        const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
         *consumed_frames = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
         p->st_g0 += *consumed_frames;
     }

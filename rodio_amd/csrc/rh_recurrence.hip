@@ -402,6 +402,7 @@ rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample
 rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream);
 }  // extern "C" (reopened below)
 namespace rh {
+rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uint32_t n_streams, const float k5[5], float *state, hipStream_t s);
 rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float co[5], float *state, hipStream_t s);
 }
 extern "C" {
@@ -472,6 +473,14 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
     hipStream_t s = rh::as_stream(stream);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || n_samples % 4 == 0);
     // in place (dst == src) the window's tail could not be re-read from the input: the ring kernel then
+    if (aligned && dst != src && !getenv("RH_AGC_SEQ") && !getenv("RH_AGC_VEC")) {  // the chains taken apart (rh_agc.hip): same operations, same bits
+        const bool overlap = dst < src + (uint64_t)n_streams * n_samples && src < dst + (uint64_t)n_streams * n_samples;
+        if (!overlap) {
+            const float k5[5] = {k.target_level, k.attack_coeff, k.release_coeff, k.absolute_max_gain, k.floor};
+            const rh_status cs = rh::agc_chain_launch(dst, src, n_samples, n_streams, k5, state, s);
+            if (cs != RH_ERR_UNSUPPORTED) return cs;
+        }
+    }
     if (aligned && dst != src && !getenv("RH_AGC_SEQ")) {
         hipLaunchKernelGGL(k_agc_vec, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, state);
         RH_CHECK_LAUNCH();

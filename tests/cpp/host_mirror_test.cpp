@@ -56,6 +56,7 @@ static std::vector<std::string> split(const std::string &s, char sep) {
 //   test (default)  None -- the TestSource of rodio's benches (benches/shared.rs:32-34): one continuous stream
 //   buffer          rodio's SamplesBuffer: Some(len) until exhausted, then Some(0)  (buffer.rs:76-82)
 //   spans:K         Some(K) throughout: spans of K samples, like a decoder's packets or Buffered's spans (buffered.rs:109)
+//   mixed           source i: test / buffer / spans:4096 by i % 3
 class TestSource : public rh::SamplesBuffer {
 public:
     using rh::SamplesBuffer::SamplesBuffer;
@@ -69,9 +70,10 @@ public:
 private:
     std::size_t span_;
 };
-static rh::BoxSource make_source(std::uint16_t ch, std::uint32_t rate, std::vector<float> data) {
+static rh::BoxSource make_source(std::uint16_t ch, std::uint32_t rate, std::vector<float> data, int index = 0) {
     const char *e = std::getenv("RH_TEST_SOURCE");
-    const std::string kind = e ? e : "test";
+    std::string kind = e ? e : "test";
+    if (kind == "mixed") kind = index % 3 == 0 ? "test" : index % 3 == 1 ? "buffer" : "spans:4096";  // one mixer, all three
     if (kind == "buffer") return std::make_unique<rh::SamplesBuffer>(ch, rate, std::move(data));
     if (kind.rfind("spans:", 0) == 0) return std::make_unique<SpanSource>(ch, rate, std::move(data), (std::size_t)std::atoll(kind.c_str() + 6));
     if (kind != "test") throw std::runtime_error("RH_TEST_SOURCE=" + kind);
@@ -228,7 +230,7 @@ int main(int argc, char **argv) {
                 unsigned ch = 0, rate = 0;
                 float gain = 1.0f;
                 if (std::fscanf(sf, "%u %u %f", &ch, &rate, &gain) != 3) throw std::runtime_error("spec.txt: short");
-                mixer.add(make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gain);
+                mixer.add(make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i), gain);
             }
             std::fclose(sf);
             out = drain(mixer);

@@ -108,18 +108,45 @@ def test_agc_state_carried_across_blocks_equals_one_pass(G, O, kw):
         assert float(np.max(np.abs(got[s] - refs[s]))) <= TOL, s
 
 
-def test_agc_vector_kernel_equals_ring_kernel(G, O):
+def _env(**kw):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kw}
+        os.environ.update(kw)
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    return cm()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2),
+                                dict(target_level=0.7, floor=6.0, absolute_max_gain=5.0), dict(attack_ns=0)])
+def test_agc_chains_equal_the_reference_order_kernel_bit_for_bit(G, O, kw):
+    """rh_agc.hip takes the AGC apart along its dependency chains (window sum, peak follower, gain) and runs everything else in
+    parallel -- the same f32 operations in the same order as one lane walking agc.rs:433-504 sample by sample (k_agc_seq)."""
     import torch
 
-    xs = [_programme(95 + s, 40000) for s in range(4)]
+    xs = [_programme(95 + s, 40000 + 4 * s) for s in range(4)]
+    xs = [x[:40000] for x in xs]
     x = torch.from_numpy(np.stack(xs)).cuda()
-    a = G.agc_batch(x, 48000).cpu().numpy()
-    os.environ["RH_AGC_SEQ"] = "1"
-    try:
-        b = G.agc_batch(x, 48000).cpu().numpy()
-    finally:
-        del os.environ["RH_AGC_SEQ"]
-    assert np.array_equal(a, b)  # the same f32 operations in the same order
+    a = G.agc_batch(x, 48000, **kw).cpu().numpy()
+    with _env(RH_AGC_SEQ="1"):
+        b = G.agc_batch(x, 48000, **kw).cpu().numpy()
+    with _env(RH_AGC_VEC="1"):
+        c = G.agc_batch(x, 48000, **kw).cpu().numpy()
+    assert np.array_equal(c, b)
+    if kw.get("release_ns", 0) or kw.get("floor", 0.0) > kw.get("absolute_max_gain", 7.0):
+        assert np.array_equal(a, b)  # every operation the reference's
+    else:  # release == 0: select and clamps as one median (rh_agc.hip, GainOp0): a rounding apart where two candidates tie
+        assert float(np.max(np.abs(a - b))) <= 1e-6
 
 
 # ---- rh_biquad mode 1: the dedicated time-parallel kernel (rh_biquad_scan.hip) ------------------------------------------

@@ -874,6 +874,53 @@ def test_fused_block_streaming_per_source_states(G, O, filt, freq, R):
     p.close()
 
 
+@pytest.mark.parametrize("filt,freq", [(None, 0), ("low_pass", 200)])
+@pytest.mark.parametrize("span", [32768, 2000])
+def test_fused_block_streaming_of_spanned_sources(G, O, filt, freq, span):
+    # rh_rlm_stream_begin with cfg.span_len: sources that report spans (a SamplesBuffer: any span_len >= 32768; a decoder's
+    # packets), fed block by block: the converter restarts every min(span, 32768) samples at the same frames of every source
+    # (uniform.rs:56-67), each span's last frame verbatim, while every source's filter state runs on across the seams
+    import torch
+
+    ns = [50000, 31000, 16384, 16385, 147, 0, 49999, 2, 32768, 40001]
+    gains = np.linspace(0.5, 1.2, len(ns)).astype(np.float32)
+    xs = [rnd(2550 + i, 2 * n, 0.1) for i, n in enumerate(ns)]
+    ref = _oracle_pipeline_gains(O, xs, gains, 44100, 48000, span, filt, freq)
+    p = G.ResampleLowpassMix(44100, 48000, 2, span, filt, freq, 0.5, max_sources=len(ns), max_in_frames=max(ns), frames_per_lane=8)
+    p.set_gains(gains)
+    xd = [torch.from_numpy(x).cuda() if len(x) else torch.empty(0, device="cuda") for x in xs]
+    rng = np.random.default_rng(7 + span)
+    for trial in range(3):
+        cuts = [0] + sorted(set(int(c) for c in rng.integers(1, max(ns), size=[1, 6, 25][trial]))) + [max(ns)]
+        p.stream_begin()
+        outs = []
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k], cuts[k + 1]
+            outs.append(p.stream_feed_v([x[2 * min(lo, n): 2 * min(hi, n)] for x, n in zip(xd, ns)], [n <= hi for n in ns]))
+        p.check_status()
+        got = torch.cat(outs).cpu().numpy()
+        assert len(got) == len(ref), (trial, len(got), len(ref))
+        if filt is None:
+            assert np.array_equal(got, ref), int(np.argmax(got != ref))
+        else:
+            assert float(np.max(np.abs(got - ref))) <= TOL
+    # the summed-state entry (equal-length sources) takes the same spans
+    n = 40000
+    xs = [rnd(2580 + i, 2 * n, 0.1) for i in range(4)]
+    ref = _oracle_pipeline_gains(O, xs, np.ones(4, dtype=np.float32), 44100, 48000, span, filt, freq)
+    p2 = G.ResampleLowpassMix(44100, 48000, 2, span, filt, freq, 0.5, max_sources=4, max_in_frames=n, frames_per_lane=8)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    cuts = [0, 999, 16384, 16385, 30000, n]
+    p2.stream_begin()
+    outs = [p2.stream_feed([x[2 * cuts[k]: 2 * cuts[k + 1]] for x in xd], flush=(k == len(cuts) - 2)) for k in range(len(cuts) - 1)]
+    p2.check_status()
+    got = torch.cat(outs).cpu().numpy()
+    assert len(got) == len(ref)
+    assert np.array_equal(got, ref) if filt is None else float(np.max(np.abs(got - ref))) <= TOL
+    p.close()
+    p2.close()
+
+
 # ------------------------------------------------- per-source gains folded into the fused kernel ----
 def _oracle_pipeline_gains(O, xs, gains, frm, to, span, filt, freq):
     """mixer.add(UniformSourceIterator(src.amplify(g)).low_pass(f)) -- rodio's per-source volume."""

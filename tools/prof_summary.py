@@ -14,7 +14,7 @@ def kernel_trace(db):
     con = sqlite3.connect(db)
     cur = con.cursor()
     print(f"## kernel trace: {db}")
-    print(f"{'calls':>6} {'total_us':>12} {'avg_us':>12} {'pct':>7}  kernel")
+    print(f"{'calls':>6} {'total_ms':>12} {'avg_ms':>12} {'pct':>7}  kernel")  # top_kernels holds microseconds
     for name, calls, total, avg, pct in cur.execute(
             "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
         short = name if len(name) < 110 else name[:107] + "..."
