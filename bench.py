@@ -79,9 +79,10 @@ def elapsed(lib, _lib, evs):
     return ms
 
 
-def pmc_traffic(argv, kernel_like):
+def pmc_traffic(argv, kernel_like, per_call=False):
     """HBM bytes per launch of the kernels matching `kernel_like`: two rocprofv3 --pmc passes of this script (TCC has 4 slots:
-    FETCH_SIZE takes 3, WRITE_SIZE 2), each a short run.  Returns (bytes, detail) or (None, reason)."""
+    FETCH_SIZE takes 3, WRITE_SIZE 2), each a short run.  per_call: the operation is several kernels -- the sum over every
+    matching dispatch of the child run, divided by the calls the child says it made.  Returns (bytes, detail) or (None, reason)."""
     exe = shutil.which("rocprofv3")
     if not exe or os.environ.get("RH_BENCH_NO_PMC") == "1":
         return None, "rocprofv3 not available" if not exe else "disabled (RH_BENCH_NO_PMC=1)"
@@ -101,9 +102,18 @@ def pmc_traffic(argv, kernel_like):
             rows = con.execute("select kernel_name, value from counters_collection where counter_name=? and kernel_name like ? order by dispatch_id", (counter, kernel_like)).fetchall()
             if not rows:
                 return None, f"no {kernel_like} dispatch in the {counter} pass"
-            last = rows[-1][0]
-            sel = [v for k, v in rows if k == last][-4:]
-            vals[counter] = sum(sel) / len(sel)
+            if per_call:
+                calls = None
+                for line in r.stdout.decode(errors="replace").splitlines():
+                    if line.startswith("{") and '"child"' in line:
+                        calls = json.loads(line).get("calls")
+                if not calls:
+                    return None, "the profiling child did not report its calls"
+                vals[counter] = sum(v for _, v in rows) / calls
+            else:
+                last = rows[-1][0]
+                sel = [v for k, v in rows if k == last][-4:]
+                vals[counter] = sum(sel) / len(sel)
         except Exception as e:  # noqa: BLE001 -- the benchmark line must still come out
             return None, f"{counter}: {e}"
         finally:
@@ -323,8 +333,29 @@ def headline(args, argv):
         dist.destroy_process_group()
 
 
-def side(args):
-    """Single-GPU configurations other than the headline: one JSON line with the same fields."""
+def _timed_oracle(fn, units, what, cores=1):
+    t0 = time.perf_counter()
+    out = fn()
+    dt = time.perf_counter() - t0
+    return out, {"value": units / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+                 "sample": f"{what}, {dt:.2f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
+
+
+def _parity(got, ref, tol, what):
+    import numpy as np
+
+    if got.shape != ref.shape:
+        return {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}", "vs": what}
+    if tol == 0:
+        return {"samples_compared": int(ref.size), "bit_exact": bool(np.array_equal(got, ref)), "tolerance": 0, "ok": bool(np.array_equal(got, ref)), "vs": what}
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    return {"samples_compared": int(ref.size), "max_abs_err": float(d.max()) if d.size else 0.0, "peak": float(np.abs(ref).max()) if ref.size else 0.0, "tolerance": tol,
+            "ok": bool(d.size == 0 or d.max() <= tol), "vs": what}
+
+
+def side(args, argv):
+    """Single-GPU configurations other than the headline: one JSON line with the same fields -- `parity` against the oracle,
+    `cpu_baseline` (the oracle timed on a bounded sample of the same workload) and live `roofline.traffic` included."""
     import numpy as np
     import torch
 
@@ -336,57 +367,126 @@ def side(args):
     lib = _lib.lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     cfg = args.config
-    kernels = []  # (name, fn, algorithmic bytes per launch, units per launch, unit)
+    child = os.environ.get("RH_BENCH_CHILD") == "1"
+    kernels = []  # (name, fn, algorithmic bytes per launch, units per launch)
+    checks = None  # () -> (parity dict, cpu_baseline dict), run once after the timing
+    like = "%"
+    per_call = False
 
     if cfg == "3":
-        S, n = 64, 2 << 20
-        x = torch.from_numpy(np.stack([(np.random.default_rng(5678 + s).uniform(-1, 1, n) * 0.25).astype(np.float32) for s in range(S)])).cuda()
+        from oracle import rodio_oracle as O
+
+        S, n, ns = 64, 2 << 20, 682_666_667
+        host = np.stack([(np.random.default_rng(5678 + s).uniform(-1, 1, n) * 0.25).astype(np.float32) for s in range(S)])
+        x = torch.from_numpy(host).cuda()
         em = [[0.5 + 0.01 * s, 0, 1] for s in range(S)]
-        d = rh.delay_samples(682_666_667, 48000, 2)
+        d = rh.delay_samples(ns, 48000, 2)
         out = torch.empty((S, n + d), device="cuda")
         gd = rh.spatial_gains_batch(em, [-1, 0, 0], [1, 0, 0])
         alg = 4 * S * n + 4 * S * (n + d)
-        kernels.append(("reverb_spatial", lambda: rh.reverb_spatial_batch(x, 48000, 682_666_667, 0.3, None, None, None, out=out, gains_dev=gd), alg, S * n))
-        workload = f"reverb(682 666 667 ns = {d} samples, 0.3) -> Spatial on {S} sources x {n} interleaved stereo samples @ 48 kHz (BASELINE config 3), one fused launch"
+        kernels.append(("reverb_spatial", lambda: rh.reverb_spatial_batch(x, 48000, ns, 0.3, None, None, None, out=out, gains_dev=gd), alg, S * n))
+        workload = f"reverb({ns} ns = {d} samples, 0.3) -> Spatial on {S} sources x {n} interleaved stereo samples @ 48 kHz, default_rng(5678+s) U(-1,1)*0.25 (BASELINE config 3), one fused launch"
         metric = "Msamples/s through reverb+spatial"
+        like = "%reverb_spatial%"
+
+        def checks():
+            from concurrent.futures import ThreadPoolExecutor
+
+            def row(s_):
+                return O.Spatial(O.TestSource(host[s_], 2, 48000).reverb(ns, 0.3), em[s_], [-1, 0, 0], [1, 0, 0]).collect()
+
+            t0 = time.perf_counter()
+            first = [row(s_) for s_ in range(8)]  # the baseline: 8 sources, one thread
+            dt = time.perf_counter() - t0
+            base = {"value": 8 * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                    "sample": f"sources 0..7 of the workload (8 x {n} samples through reverb -> Spatial), one thread, {dt:.2f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
+            with ThreadPoolExecutor(min(os.cpu_count() or 1, S)) as ex:  # every row of the timed launch (ctypes drops the GIL)
+                ref = np.stack(first + list(ex.map(row, range(8, S))))
+            return _parity(out.cpu().numpy(), ref, 1e-5, f"oracle Spatial(reverb(x)) chains, all {S} rows of the timed launch"), base
     elif cfg == "5":
-        ex = np.load(os.path.join(ROOT, "tests", "golden", "music_excerpt_i16.npy"))
-        i16 = torch.from_numpy(np.tile(ex, 4096)).cuda()
-        n = i16.numel()
-        f32 = torch.empty(n, device="cuda", dtype=torch.float32)
+        from oracle import rodio_oracle as O
+
+        wav = open(os.path.join(ROOT, "tests", "golden", "music.wav"), "rb").read()  # the reference's assets/music.wav (tests/golden/make_golden.py)
+        info = rh.wav_probe(wav)
+        raw = np.frombuffer(wav, dtype=np.uint8, count=info["data_bytes"], offset=info["data_offset"])
+        pcm = raw.view("<i2")
+        assert info["samples"] == 894654 and info["bits_per_sample"] == 16 and not info["is_float"], info
+        tile = 1024
+        d_raw = torch.from_numpy(np.tile(raw, tile)).cuda()  # the data chunk, tiled x1024 so that a launch is not launch-bound
+        n = info["samples"] * tile
+        f32 = torch.empty(n + 8, device="cuda", dtype=torch.float32)
         frames6 = n // 6
         out2 = torch.empty(frames6 * 2, device="cuda", dtype=torch.float32)
-        kernels.append(("i16_to_f32", lambda: lib.rh_convert_i16_to_f32(C.c_void_p(f32.data_ptr()), C.c_void_p(i16.data_ptr()), n, stream), 6 * n, n))
-        kernels.append(("channels_6_to_2", lambda: lib.rh_channels_convert(C.c_void_p(out2.data_ptr()), C.c_void_p(f32.data_ptr()), frames6, 6, 2, stream), 32 * frames6, frames6 * 6))
-        workload = f"music.wav excerpt (32 768 i16 samples of the reference asset) tiled x4096 = {n} samples: i16 -> f32, then 6 -> 2 channels (BASELINE config 5)"
+        m = C.c_uint64(0)
+        kernels.append(("wav_decode_i16_to_f32", lambda: _lib.check(lib.rh_wav_decode(C.c_void_p(f32.data_ptr()), C.c_void_p(d_raw.data_ptr()), n, 2, 16, 0, C.byref(m), stream), "rh_wav_decode"), 6 * n, n))
+        kernels.append(("channels_6_to_2", lambda: _lib.check(lib.rh_channels_convert(C.c_void_p(out2.data_ptr()), C.c_void_p(f32.data_ptr()), frames6, 6, 2, stream), "rh_channels_convert"), 32 * frames6, frames6 * 6))
+        workload = (f"assets/music.wav data chunk ({info['samples']} PCM16 samples, RIFF probed by rh_wav_probe_host) tiled x{tile} = {n} samples: i16 -> f32 on the device "
+                    f"(rh_wav_decode), then the f32 stream re-framed as {frames6} frames x 6 ch -> ChannelCountConverter(6 -> 2) (BASELINE config 5)")
         metric = "Msamples/s through i16->f32 DataConverter"
+        like = "%k_int_to_f32%"
+
+        def checks():
+            ns_ = info["samples"]
+            reps = 400  # a measurable sample: the chunk converts in about a millisecond
+            ref1, base = _timed_oracle(lambda: [O.convert("i16_to_f32", pcm) for _ in range(reps)][-1], ns_ * reps, f"the whole data chunk ({ns_} samples) i16 -> f32, {reps} passes, one thread")
+            ref2 = O.ChannelCountConverter(O.TestSource(ref1[: ns_ // 6 * 6], 6, 44100), 6, 2).collect()
+            got1 = f32[:ns_].cpu().numpy()
+            got2 = out2[: ns_ // 6 * 2].cpu().numpy()  # the first tile = the untiled chunk: 149 109 frames -> 298 218 samples
+            p1 = _parity(got1, ref1, 0, "oracle i16 -> f32 (dasp_sample 0.11.0 restated), the whole data chunk")
+            p2 = _parity(got2, ref2, 0, "oracle ChannelCountConverter(6 -> 2), 149 109 frames")
+            whole = bool(torch.equal(f32[: ns_ * tile].view(tile, ns_), f32[:ns_].expand(tile, ns_)))  # every tile decoded alike
+            return {"ok": p1["ok"] and p2["ok"] and whole, "i16_to_f32": p1, "channels_6_to_2": p2, "all_tiles_equal": whole}, base
     elif cfg in ("limit", "agc", "biquad"):
+        from oracle import rodio_oracle as O
+
         S = args.sources if args.sources != 256 else 64
         n = args.frames
-        x = torch.from_numpy(np.stack([(np.random.default_rng(4321 + s).uniform(-1, 1, 2 * n) * 0.9).astype(np.float32) for s in range(S)])).cuda()
+        host = np.stack([(np.random.default_rng(4321 + s).uniform(-1, 1, 2 * n) * 0.9).astype(np.float32) for s in range(S)])
+        x = torch.from_numpy(host).cuda()
         out = torch.empty_like(x)
         alg = 8 * S * 2 * n
         if cfg == "limit":
             kernels.append(("limit", lambda: rh.limit_batch(x, 2, 48000, out=out), alg, S * 2 * n))
+            like, chain, tol = "%k_limit_scan%", (lambda src: src.limit()), 1e-5
         elif cfg == "agc":
             kernels.append(("agc", lambda: rh.agc_batch(x, 48000, out=out), alg, S * 2 * n))
+            like, chain, tol, per_call = "%k_agc%", (lambda src: src.automatic_gain_control()), 1e-5, True
         else:
             co = rh.biquad_coeffs("low_pass", 200, 0.5, 48000)
-            kernels.append(("biquad_time_parallel", lambda: rh.biquad_batch(x, co, mode=1), alg, S * 2 * n))
+            outs_b = {}
+            kernels.append(("biquad_time_parallel", lambda: outs_b.__setitem__("o", rh.biquad_batch(x, co, mode=1)), alg, S * 2 * n))
             kernels.append(("biquad_reference_order", lambda: rh.biquad_batch(x, co, mode=0), alg, S * 2 * n))
-        workload = f"{cfg}: {S} stereo streams x {n} frames @ 48 kHz, default settings, 4 B in + 4 B out per sample"
+            like, chain, tol = "%k_biquad_scan%", (lambda src: src.low_pass(200)), 1e-5
+        workload = f"{cfg}: {S} stereo streams x {n} frames @ 48 kHz, default settings, default_rng(4321+s) U(-1,1)*0.9, 4 B in + 4 B out per sample"
         metric = f"Msamples/s through {cfg}"
+
+        def checks():
+            # streams of the timed launch through the oracle's chain, one thread, until about 5 s of CPU work are spent (at least 3)
+            rows_, refs, t0 = [], [], time.perf_counter()
+            for r in range(S):
+                rows_.append(r)
+                refs.append(chain(O.TestSource(host[r], 2, 48000)).collect())
+                if len(rows_) >= 3 and time.perf_counter() - t0 > 5.0:
+                    break
+            dt = time.perf_counter() - t0
+            base = {"value": len(rows_) * 2 * n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                    "sample": f"streams 0..{rows_[-1]} of the workload ({len(rows_)} x {2 * n} samples), one thread, {dt:.2f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
+            got = (outs_b["o"] if cfg == "biquad" else out)[rows_].cpu().numpy()
+            return _parity(got, np.stack(refs), tol, f"oracle chains of streams 0..{rows_[-1]} of the timed launch"), base
     else:
         sys.exit(f"unknown --config {cfg}")
 
     rows = []
+    calls = 0
     for name, fn, alg, units in kernels:
         fn()
+        calls += 1
         torch.cuda.synchronize()
-        slow = name in ("agc", "biquad_reference_order")
+        slow = name == "biquad_reference_order"
         steps = max(2, args.steps // 10) if slow else args.steps
         for _ in range(0 if slow else args.warmup):
             fn()
+            calls += 1
         evs = events(lib, _lib, steps)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -396,16 +496,26 @@ def side(args):
             lib.rh_event_record(evs[k][1], stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        calls += steps
         ms = elapsed(lib, _lib, evs)
         kms = sum(ms) / len(ms)
         rows.append({"kernel": name, "steps": steps, "ms_per_step": dt / steps * 1e3, "kernel_ms": kms, "algorithmic_bytes_per_launch": alg,
                      "achieved_GBps": alg / kms / 1e6, "frac": alg / kms / 1e6 / HBM_PEAK_GBS, "Msamples_per_s": units / (dt / steps) / 1e6})
+        if child:
+            break  # the counter passes look at the head kernel only
+    if child:
+        print(json.dumps({"child": True, "calls": calls}), flush=True)
+        return
+    rh.async_status()
     head = rows[0]
+    traffic, traffic_how = pmc_traffic(argv, like, per_call)
     res = {"metric": metric, "value": head["Msamples_per_s"], "unit": "Msamples/s", "n_gpus": 1, "steps": head["steps"], "warmup": args.warmup,
-           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16->f32" if cfg == "5" else "f32", "data": "synthetic" if cfg != "5" else "the reference's assets/music.wav, tiled",
            "config": {"workload": workload, "kernels": rows},
-           "roofline": {"bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"], "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": head["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"], "traffic": traffic, "traffic_detail": traffic_how,
                         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "kernel_ms": head["kernel_ms"]}}
+    if not args.no_cpu_baseline and checks is not None:
+        res["parity"], res["cpu_baseline"] = checks()
     print(json.dumps(res), flush=True)
 
 
@@ -438,7 +548,7 @@ def main():
             argv.append("--no-autotune")
         headline(args, argv)
     else:
-        side(args)
+        side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames)])
 
 
 if __name__ == "__main__":

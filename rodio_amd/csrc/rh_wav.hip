@@ -104,7 +104,7 @@ rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uin
     }
     if (st != RH_OK) return st;
     if (total > n_samples) {
-        hipLaunchKernelGGL(k_fill_zero, dim3(1), dim3(kBlock), 0, s, dst, (size_t)n_samples, (size_t)total);
+        hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((total - n_samples + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, dst, (size_t)n_samples, (size_t)total);  // up to channels - 1 samples: a header may say 65 535 channels
         RH_CHECK_LAUNCH();
     }
     return RH_OK;

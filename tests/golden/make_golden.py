@@ -7,6 +7,8 @@ keep a 32 768-sample excerpt that contains both quiet and loud passages, and wri
   music_excerpt_f32.npy      dasp_sample 0.11.0 `i16 -> f32`:  s as f32 / 32768.0   (sample.rs:42-44)
   music_excerpt_6to2.npy     the f32 stream re-framed as 6 channels -> ChannelCountConverter(6 -> 2):
                              channels >= 2 of every frame are dropped (channels.rs:57-85)
+  music.wav                  the asset itself (1.8 MB, cc-by-sa: /root/reference/assets/README.md), byte for byte: BASELINE config 5
+                             at full size feeds the real RIFF image through rh_wav_probe_host / rh_wav_decode
 The expected arrays are computed here with numpy from the cited formulas, independently of oracle/.
 """
 import os
@@ -44,4 +46,8 @@ if __name__ == "__main__":
     np.save(os.path.join(HERE, "music_excerpt_i16.npy"), ex)
     np.save(os.path.join(HERE, "music_excerpt_f32.npy"), f32)
     np.save(os.path.join(HERE, "music_excerpt_6to2.npy"), np.ascontiguousarray(frames6[:, :2]).reshape(-1))
+    import shutil
+
+    shutil.copyfile(WAV, os.path.join(HERE, "music.wav"))
+    os.chmod(os.path.join(HERE, "music.wav"), 0o644)
     print("excerpt", ex.shape, "min/max", ex.min(), ex.max(), "nonzero", int(np.count_nonzero(ex)))

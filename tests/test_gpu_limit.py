@@ -123,7 +123,29 @@ def test_limiter_state_carried_across_blocks_equals_one_pass(G, O, ch):
     assert float(np.max(np.abs(got_tail - ref_tail))) <= TOL
 
 
-@pytest.mark.parametrize("attack_ms,release_ms,tol", [(5, 100, TOL), (20, 1000, TOL), (800, 3000, 5e-4)])
+def _limit_f64(x, ch, rate, threshold=-1.0, knee_width=4.0, attack_ns=5_000_000, release_ns=100_000_000):
+    """limit.rs:853-988 in float64 (the recurrences as vectorised-where-possible numpy; the coefficients rounded to f32 like
+    the reference's): the ground truth an ill-conditioned setting is measured against."""
+    from rodio_amd import _lib
+
+    att = float(_lib.lib.rh_duration_to_coefficient(attack_ns, rate))  # math.rs:110-113 in f32, as the kernels and the oracle get it
+    rel = float(_lib.lib.rh_duration_to_coefficient(release_ns, rate))
+    xv = x.astype(np.float64).reshape(-1, ch)
+    bias = np.log2(np.abs(xv) + 1.17549435e-38) * 0.30102999566398119521 * 20.0 - threshold
+    kb = bias * 2.0
+    g = np.where(kb < -knee_width, 0.0, np.where(np.abs(kb) <= knee_width, (kb + knee_width) ** 2 / (8.0 * knee_width), bias))
+    integ = np.zeros(ch)
+    peak = np.zeros(ch)
+    out = np.empty_like(xv)
+    for n in range(xv.shape[0]):
+        for c in range(ch):  # the channels' peaks are read as they stand when each sample is processed (limit.rs:946-960)
+            integ[c] = max(g[n, c], rel * integ[c] + (1.0 - rel) * g[n, c])
+            peak[c] = att * peak[c] + (1.0 - att) * integ[c]
+            out[n, c] = xv[n, c] * 2.0 ** (-peak.max() * 0.05 * 3.32192809488736234787)
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("attack_ms,release_ms,tol", [(5, 100, TOL), (20, 1000, TOL), (800, 3000, None)])
 def test_limiter_lookback_walks_several_windows(G, O, attack_ms, release_ms, tol):
     """r^(64 tiles) is not negligible for any of these (64 tiles = 1.4 s at most): a tile composes several windows of
     aggregates, or meets an inclusive state, before it knows its start state.  The last setting (attack 0.8 s, release 3 s) is
@@ -137,7 +159,18 @@ def test_limiter_lookback_walks_several_windows(G, O, attack_ms, release_ms, tol
     out = G.TestSource(x, ch, 48000).limit(**kw).collect()
     err = float(np.max(np.abs(out - ref)))
     print(f"[limit attack {attack_ms} ms release {release_ms} ms] err={err:.3e}")
-    assert err <= tol
+    if tol is not None:
+        assert err <= tol
+        return
+    # the ill-conditioned setting: no fixed bound against the reference's f32 recurrence, whose own accumulated rounding depends on
+    # the evaluation order -- the GPU result must be no further from the float64 truth than the reference itself is (x2 + 1e-7)
+    n64 = 120000  # frames: the python loop below costs a second per 100 000 samples
+    truth = _limit_f64(x[: n64 * ch], ch, 48000, **kw)
+    e_ref = float(np.max(np.abs(ref[: n64 * ch] - truth)))
+    e_gpu = float(np.max(np.abs(out[: n64 * ch] - truth)))
+    print(f"[limit attack {attack_ms} ms release {release_ms} ms] |reference - f64| = {e_ref:.3e}, |gpu - f64| = {e_gpu:.3e}")
+    assert e_gpu <= 2.0 * e_ref + 1e-7
+    assert err <= 5e-4  # and the two f32 evaluations stay together over the whole stream
 
 
 def test_limiter_full_block_every_sample(G, O):

@@ -109,4 +109,9 @@ def test_biquad_mode1_random_shapes(G, O, case):
     finally:
         del os.environ["RH_BIQUAD_NO_FALLBACK"]
     assert float((par - seq).abs().max()) <= TOL, (ch, S, frames, carry, kind, freq)
+    # and against the oracle's BltFilter itself (blt.rs:397-560), not only against the reference-order kernel: first and last stream
+    for s_ in sorted({0, S - 1}):
+        src = O.TestSource(xs[s_], ch, 48000)
+        ref = (src.low_pass(freq) if kind == "low_pass" else src.high_pass(freq)).collect()
+        assert float(np.max(np.abs(par[s_].cpu().numpy() - ref))) <= TOL, (s_, ch, S, frames, carry, kind, freq)
     G.async_status()
