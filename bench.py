@@ -316,6 +316,13 @@ def headline(args, argv):
                          "traffic": traffic, "traffic_detail": traffic_how, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_avg_ms},
         }
         if multi:
+            one = args.one_gpu_value
+            if one is None and args.one_gpu_line:  # a JSON line (or a file holding one) of the same bench at --gpus 1
+                txt = open(args.one_gpu_line).read() if os.path.exists(args.one_gpu_line) else args.one_gpu_line
+                one = float(json.loads(txt.strip().splitlines()[-1])["value"])
+            if one:
+                multi["efficiency_vs_1gpu"] = res["value"] / (world * one)  # weak scaling: N ranks do N times the work of one
+                multi["one_gpu_value"] = one
             res["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline and not ragged:
             base, ref = cpu_baseline(host, S, N, span, args.freq)
@@ -535,6 +542,8 @@ def main():
     ap.add_argument("--force-general", type=int, default=0)
     ap.add_argument("--no-autotune", action="store_true", help="keep the cost model's launch geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-gpu-value", type=float, default=None, help="Msamples/s of this bench at --gpus 1: an N > 1 run then prints multi_gpu.efficiency_vs_1gpu")
+    ap.add_argument("--one-gpu-line", default=None, help="... or the 1-GPU JSON line itself / a file that holds it")
     args = ap.parse_args()
     import torch
 

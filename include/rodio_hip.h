@@ -46,6 +46,8 @@ typedef void *rh_stream; /* hipStream_t */
 int32_t rh_version(void);
 const char *rh_status_string(rh_status s);
 const char *rh_last_hip_error(void);
+/* Binds the library to a gfx950 device.  Also (re-)reads the library's diagnostic / tuning environment variables (DESIGN.md
+ * 7.1): nothing reads the environment on a call's way to a launch. */
 rh_status rh_init(int32_t device);
 rh_status rh_device_name(char *buf, size_t cap);
 /* The handle-less time-parallel kernels (rh_limit, rh_biquad mode 1) wait for hand-offs between their tiles with a bound.
@@ -66,6 +68,11 @@ rh_status rh_host_free(void *p);
 rh_status rh_stream_create(rh_stream *out);
 rh_status rh_stream_destroy(rh_stream s);
 rh_status rh_stream_synchronize(rh_stream s);
+/* The scan kernels (rh_limit, rh_biquad mode 1, rh_agc) keep a scratch buffer per stream, grown on demand and reused by every
+ * later launch on that stream; rh_stream_destroy frees it for the library's own streams.  For a stream of the caller's (a
+ * PyTorch stream, ...) that is about to be destroyed: synchronises it and frees its buffer (a handle value the runtime
+ * recycles must not inherit one). */
+rh_status rh_stream_release_scratch(rh_stream s);
 /* HIP-event timing on `stream` (bench.py measures the kernels on the stream they run on). */
 rh_status rh_event_create(void **out);
 rh_status rh_event_destroy(void *ev);
@@ -267,9 +274,10 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host,
  * filter across blocks; NULL = zero state, not written back.
  * mode 0 = sequential per (source,channel) stream, same op order as blt.rs:559 (bit-exact);
  * mode 1 = time-parallel scan (<=1e-5 abs): 1 to 8 channels, the same state as mode 0 (a stream may
- *          change modes between blocks); rows must start on 16-byte boundaries (dst, src, and frames*channels % 4 == 0
- *          for n_streams > 1) -- otherwise RH_ERR_UNSUPPORTED: use mode 0.  dst == src runs in mode 0 (the scan reads
- *          the two frames in front of every share after a neighbour may have overwritten them).
+ *          change modes between blocks).  A call the scan kernel does not take -- rows that do not start on 16-byte boundaries
+ *          (dst, src, and frames*channels % 4 == 0 for n_streams > 1), more than 8 channels, a filter that does not forget
+ *          within 64 tiles, dst == src (the scan reads the two frames in front of every share after a neighbour may have
+ *          overwritten them) -- runs in mode 0 instead: never an error, the exact bits, slower.
  * The batch form filters n_streams equally shaped blocks laid out back to back.  Mode 0 works in place. */
 rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample_rate,
                            float out_coeffs5[5]);

@@ -511,6 +511,13 @@ public:
             return c.n;
         });
     }
+    /// The filters run time-parallel (rh_biquad mode 1: <= 1e-5 from rodio's f32 recurrence and no further from the exact
+    /// response than that recurrence itself; blocks the scan kernel does not take continue in reference order on the same
+    /// state).  exact_filters(true): the reference's operation order throughout, bit for bit, one lane per channel.
+    GpuSource &exact_filters(bool on = true) {
+        exact_filters_ = on;
+        return *this;
+    }
     GpuSource &low_pass(std::uint32_t freq) { return blt(0, freq, 0.5f); }   // blt.rs:11-16
     GpuSource &high_pass(std::uint32_t freq) { return blt(1, freq, 0.5f); }  // blt.rs:18-24
     GpuSource &low_pass_with_q(std::uint32_t freq, float q) { return blt(0, freq, q); }
@@ -812,7 +819,7 @@ private:
         check(rh_memset(st->get(), 0, floats * sizeof(float), stream_), "rh_memset");
         return st;
     }
-    GpuSource &blt(int kind, std::uint32_t freq, float q) {  // blt.rs:502-544,558-560 -- same operation order, bit for bit
+    GpuSource &blt(int kind, std::uint32_t freq, float q) {  // blt.rs:502-544,558-560
         const std::uint16_t ch = ch_;
         float co[5];
         check(rh_biquad_coeffs(kind, freq, q, rate_, co), "rh_biquad_coeffs");
@@ -825,7 +832,7 @@ private:
                 check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
                 frames += 1;       // the zero padding only touches channels the stream no longer has
             }
-            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), 0, c.stream), "rh_biquad");
+            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), exact_filters_ ? 0 : 1, c.stream), "rh_biquad");
             return rem && c.flush ? c.n : frames * ch;
         }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); });  // blt.rs:350-377
     }
@@ -842,6 +849,7 @@ private:
     detail::SpanReader reader_{nullptr};
     std::vector<detail::Piece> pieces_;  // the spans of the block being enqueued
     bool span_aware_ = false;
+    bool exact_filters_ = false;
     detail::DeviceBuf a_, b_;
     bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
 };

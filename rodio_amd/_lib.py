@@ -81,6 +81,7 @@ SIGNATURES = {
     "rh_stream_create": (i32, [C.POINTER(vp)]),
     "rh_stream_destroy": (i32, [vp]),
     "rh_stream_synchronize": (i32, [vp]),
+    "rh_stream_release_scratch": (i32, [vp]),
     "rh_event_create": (i32, [C.POINTER(vp)]),
     "rh_event_destroy": (i32, [vp]),
     "rh_event_record": (i32, [vp, vp]),

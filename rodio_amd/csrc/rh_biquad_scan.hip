@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <list>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -472,15 +474,27 @@ struct BqPlan {
     int R, NW;
     BqArgs proto;  // the uniform constants
     BqTabs *d_tabs = nullptr;
+    BqPlan() = default;
+    BqPlan(const BqPlan &) = delete;
+    BqPlan &operator=(const BqPlan &) = delete;
+    ~BqPlan() {
+        if (d_tabs) (void)hipFree(d_tabs);  // (hipFree waits for the device: no queued launch still reads the table)
+    }
 };
+// The cache: most recently used first, at most kMaxPlans filters (a swept cutoff does not grow it); a caller holds its plan
+// through a shared_ptr, so a plan another thread evicts meanwhile lives until the launch that uses it has been enqueued.
+constexpr size_t kMaxPlans = 32;
 std::mutex g_mu;
-std::vector<BqPlan> g_plans;  // a handful of filters per process; tables are uploaded once (synchronously) and kept
+std::list<std::shared_ptr<BqPlan>> g_plans;
 
 // plan for (coefficients, R, NW); nullptr: the filter does not forget within 64 workgroup tiles (or is unstable)
-const BqPlan *get_plan(const float co[5], int R, int NW) {
+std::shared_ptr<const BqPlan> get_plan(const float co[5], int R, int NW) {
     std::lock_guard<std::mutex> lock(g_mu);
-    for (const BqPlan &p : g_plans)
-        if (p.R == R && p.NW == NW && std::memcmp(p.co, co, sizeof(p.co)) == 0) return &p;
+    for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+        if ((*it)->R == R && (*it)->NW == NW && std::memcmp((*it)->co, co, sizeof((*it)->co)) == 0) {
+            g_plans.splice(g_plans.begin(), g_plans, it);
+            return g_plans.front();
+        }
     const double a1 = co[3], a2 = co[4];
     if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2)) return nullptr;  // stability triangle
     const M2 A{-a1, -a2, 1.0, 0.0};
@@ -501,7 +515,8 @@ const BqPlan *get_plan(const float co[5], int R, int NW) {
         }
     }
     if (J == 0) return nullptr;
-    BqPlan p;
+    auto pp = std::make_shared<BqPlan>();
+    BqPlan &p = *pp;
     std::memcpy(p.co, co, sizeof(p.co));
     p.R = R;
     p.NW = NW;
@@ -536,8 +551,9 @@ const BqPlan *get_plan(const float co[5], int R, int NW) {
         rh::set_hip_error(e, "rh_biquad mode 1 tables");
         return nullptr;
     }
-    g_plans.push_back(p);
-    return &g_plans.back();
+    g_plans.push_front(pp);
+    while (g_plans.size() > kMaxPlans) g_plans.pop_back();
+    return pp;
 }
 
 using BqFn = void (*)(const BqArgs);
@@ -565,8 +581,8 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     // Geometry: the longest tile a stream fills at least half of, more frames per lane among equals (rh_limit.hip has the
     // measurements: 8192-frame tiles from 64 x 1 Mi frames down to 256 x 8192, 0.240 ms with R = 16 against 0.261 ms with R = 8)
     const BqVariant *v = nullptr;
-    if (getenv("RH_BIQUAD_R") || getenv("RH_BIQUAD_NW")) {  // tuning aids: the variant closest to the request
-        const int want_R = getenv("RH_BIQUAD_R") ? atoi(getenv("RH_BIQUAD_R")) : 16, want_NW = getenv("RH_BIQUAD_NW") ? atoi(getenv("RH_BIQUAD_NW")) : 8;
+    if (rh::knob(rh::K_BIQUAD_R) || rh::knob(rh::K_BIQUAD_NW)) {  // tuning aids: the variant closest to the request
+        const int want_R = rh::knob(rh::K_BIQUAD_R) ? atoi(rh::knob(rh::K_BIQUAD_R)) : 16, want_NW = rh::knob(rh::K_BIQUAD_NW) ? atoi(rh::knob(rh::K_BIQUAD_NW)) : 8;
         for (const BqVariant &c : kVariants) {
             if (c.C != (int)channels) continue;
             auto score = [&](const BqVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
@@ -587,7 +603,7 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
         }
     }
     if (!v) return RH_ERR_UNSUPPORTED;
-    const BqPlan *pl = get_plan(co, v->R, v->NW);
+    const std::shared_ptr<const BqPlan> pl = get_plan(co, v->R, v->NW);
     if (!pl) return RH_ERR_UNSUPPORTED;
     const uint32_t R = (uint32_t)v->R, NW = (uint32_t)v->NW, LW = 64u * R * NW;
     const uint64_t tiles64 = (frames + LW - 1) / LW;
@@ -609,8 +625,8 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
-    a.dma_top = getenv("RH_SCAN_DMA_TOP") ? (uint32_t)atoi(getenv("RH_SCAN_DMA_TOP")) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
-    a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
+    a.dma_top = rh::knob(rh::K_SCAN_DMA_TOP) ? (uint32_t)atoi(rh::knob(rh::K_SCAN_DMA_TOP)) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
+    a.spin = rh::knob(rh::K_SCAN_SPIN_LIMIT) ? (uint32_t)strtoul(rh::knob(rh::K_SCAN_SPIN_LIMIT), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64), *xlast = snap + n_sc * 4;
     const uint64_t n_words = gran_bytes / 4;
@@ -628,7 +644,7 @@ rh_status biquad_scan_launch(float *dst, const float *src, uint64_t frames, uint
         }
         int per_cu = per_cu_cached;
         if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
-        if (const char *w = getenv("RH_BIQUAD_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;
+        if (const char *w = rh::knob(rh::K_BIQUAD_WGS)) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
         const uint64_t total = tiles64 * n_streams;
         if (grid > total) grid = total;

@@ -17,6 +17,15 @@ extern int g_num_cus;
 extern uint32_t *g_async_status;  // device word: sticky failure flag of the state-less scan kernels (rh_async_status)
 void set_hip_error(hipError_t e, const char *what);
 
+// Diagnostics / tuning variables.  They are read ONCE, by rh_init() -- never on a call's way to a launch; a
+// process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
+enum Knob {
+    K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
+    K_LIMIT_SKEW, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_COUNT
+};
+const char *knob(Knob k);
+void load_knobs();
+
 #define RH_HIP_TRY(expr)                                   \
     do {                                                   \
         hipError_t _e = (expr);                            \

@@ -844,7 +844,7 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || stride % 4 == 0);
     // coefficients outside [0, 1) (zero or negative durations give exp(-inf) = 0 or exp(+x) > 1) leave the scan's premises
     const bool scannable = release >= 0.0f && release < 1.0f && attack >= 0.0f && attack < 1.0f && p->knee_width_db > 0.0f;
-    const char *force_seq = getenv("RH_LIMIT_SEQ");  // diagnostics: the reference-order kernel
+    const char *force_seq = rh::knob(rh::K_LIMIT_SEQ);  // diagnostics: the reference-order kernel
     if (!aligned || !scannable || (force_seq && force_seq[0] == '1')) return rh::limit_seq_launch(dst, src, frames, channels, n_streams, k5, state, s);
 
     // Geometry: the LONGEST tile (64 * R * NW frames) that a stream fills at least half of; among equals, more frames per lane.
@@ -853,8 +853,8 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     // 256 x 8192 (21 us against 49 us with single-wave tiles), although the short batches then have fewer tiles than the chip
     // has CUs.  Single-wave tiles are for blocks of a few hundred frames (a pull shim's).
     const LimitVariant *v = nullptr;
-    if (getenv("RH_LIMIT_R") || getenv("RH_LIMIT_NW")) {  // tuning aids: the variant closest to the request
-        const int want_R = getenv("RH_LIMIT_R") ? atoi(getenv("RH_LIMIT_R")) : 16, want_NW = getenv("RH_LIMIT_NW") ? atoi(getenv("RH_LIMIT_NW")) : 8;
+    if (rh::knob(rh::K_LIMIT_R) || rh::knob(rh::K_LIMIT_NW)) {  // tuning aids: the variant closest to the request
+        const int want_R = rh::knob(rh::K_LIMIT_R) ? atoi(rh::knob(rh::K_LIMIT_R)) : 16, want_NW = rh::knob(rh::K_LIMIT_NW) ? atoi(rh::knob(rh::K_LIMIT_NW)) : 8;
         for (const LimitVariant &c : kVariants) {
             if (c.C != (int)channels) continue;
             auto score = [&](const LimitVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
@@ -956,8 +956,8 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
-    a.dma_top = getenv("RH_SCAN_DMA_TOP") ? (uint32_t)atoi(getenv("RH_SCAN_DMA_TOP")) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
-    a.spin = getenv("RH_SCAN_SPIN_LIMIT") ? (uint32_t)strtoul(getenv("RH_SCAN_SPIN_LIMIT"), nullptr, 10) : kSpinLimit;
+    a.dma_top = rh::knob(rh::K_SCAN_DMA_TOP) ? (uint32_t)atoi(rh::knob(rh::K_SCAN_DMA_TOP)) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
+    a.spin = rh::knob(rh::K_SCAN_SPIN_LIMIT) ? (uint32_t)strtoul(rh::knob(rh::K_SCAN_SPIN_LIMIT), nullptr, 10) : kSpinLimit;
     a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64);
     const uint64_t n_words = gran_bytes / 4;
@@ -975,15 +975,15 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
         }
         int per_cu = per_cu_cached;
         if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
-        if (const char *w = getenv("RH_LIMIT_WGS")) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;  // tuning aid: resident workgroups per CU
+        if (const char *w = rh::knob(rh::K_LIMIT_WGS)) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;  // tuning aid: resident workgroups per CU
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
         const uint64_t total = tiles64 * n_streams;
         if (grid > total) grid = total;
-        if (const char *g = getenv("RH_LIMIT_GRID")) grid = atoi(g) > 0 ? (uint64_t)atoi(g) : grid;  // diagnostics
+        if (const char *g = rh::knob(rh::K_LIMIT_GRID)) grid = atoi(g) > 0 ? (uint64_t)atoi(g) : grid;  // diagnostics
         if (e == hipSuccess) {
             void *args[] = {&a};
             bool skew = v->fn_skew && grid < n_streams;  // see k_limit_scan: only with more streams than workgroups
-            if (const char *k = getenv("RH_LIMIT_SKEW")) skew = v->fn_skew && k[0] == '1';  // tuning aid
+            if (const char *k = rh::knob(rh::K_LIMIT_SKEW)) skew = v->fn_skew && k[0] == '1';  // tuning aid
             e = hipLaunchKernel(reinterpret_cast<const void *>(skew ? v->fn_skew : v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
         }
     }

@@ -1888,7 +1888,7 @@ rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, 
 // about to end (k_rlm_resid takes a tile's pairs one after the other; batches whose sources all end within a few frames of
 // each other stay with k_rlm_wave).
 bool pair_ok(rh_rlm *p, const Plan &pl) {
-    if (!pl.v || !p->filt || p->equal || p->cfg.force_general || p->h_desc.size() != p->n_sources || getenv("RH_NO_HYBRID")) return false;
+    if (!pl.v || !p->filt || p->equal || p->cfg.force_general || p->h_desc.size() != p->n_sources || rh::knob(rh::K_NO_HYBRID)) return false;
     const uint64_t M = p->out_frames, L = 64ull * pl.v->R, J = pl.J;
     const uint64_t tiles = (M + L - 1) / L;
     if (!tiles) return false;
@@ -2173,7 +2173,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.prof = p->d_prof;
     k.eq_frames = p->eq_frames;
     k.batch_streams = batch_streams;
-    k.shards = (batch_streams >= 16 && batch_streams % 8 == 0 && !getenv("RH_NO_TICKET_SHARDS")) ? 8u : 1u;
+    k.shards = (batch_streams >= 16 && batch_streams % 8 == 0 && !rh::knob(rh::K_NO_TICKET_SHARDS)) ? 8u : 1u;
     k.shard_base = p->shard_base;
     k.out_stride = out_stride;
     k.st_mode = sa.mode;
@@ -2600,7 +2600,7 @@ rh_status rh_rlm_phase_cycles(rh_rlm *p, double out8[8]) {
     if (!p->d_prof) return RH_ERR_UNSUPPORTED;  // not an RH_PHASE_PROFILE build
     std::vector<unsigned long long> h((size_t)p->n_tiles * 8);
     RH_HIP_TRY(hipMemcpy(h.data(), p->d_prof, h.size() * 8, hipMemcpyDeviceToHost));
-    if (const char *path = getenv("RH_PROF_DUMP")) {  // raw [tiles][8] u64 for tools/prof_tiles.py
+    if (const char *path = rh::knob(rh::K_PROF_DUMP)) {  // raw [tiles][8] u64 for tools/prof_tiles.py
         if (FILE *f = fopen(path, "wb")) {
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
@@ -2627,52 +2627,6 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
     info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
     return RH_OK;
-}
-
-// Time-parallel stand-alone biquad (rh_biquad mode 1): the equal-length kernel in batch mode (no mixer:
-// every stream keeps its own output row) with the pass-through converter (from == to: tap weight 0), i.e.
-// the per-lane zero-state runs + wave scan + tile look-back of DESIGN.md 4.2, all streams in one launch.  One handle is
-// cached per (coefficients, block length); like every handle it serves one thread at a time.
-rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (channels != 2 || state) return RH_ERR_UNSUPPORTED;  // stereo blocks from a zero state; mode 0 covers the rest
-    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) return RH_ERR_INVALID;
-    if ((frames * 2) % 4 != 0 && n_streams > 1) return RH_ERR_UNSUPPORTED;  // stream rows must stay 16-byte aligned
-    static std::mutex mu;  // the cached plan is process-wide: one call at a time (a call only enqueues)
-    std::lock_guard<std::mutex> lock(mu);
-    static rh_rlm *cache = nullptr;
-    static float cache_co[5];
-    static uint64_t cache_frames = 0;
-    static uint32_t cache_streams = 0;
-    bool same = cache && cache_frames >= frames && cache_streams >= n_streams;
-    for (int k = 0; k < 5 && same; ++k) same = cache_co[k] == coeffs5_host[k];
-    if (!same) {
-        if (cache) rh_rlm_destroy(cache);
-        cache = nullptr;
-        rh_rlm_config cfg;
-        std::memset(&cfg, 0, sizeof(cfg));
-        cfg.from_rate = cfg.to_rate = 1;
-        cfg.channels = 2;
-        cfg.filter_kind = 2;
-        for (int k = 0; k < 5; ++k) cfg.custom_coeffs[k] = cache_co[k] = coeffs5_host[k];
-        cfg.max_sources = n_streams;
-        cfg.max_in_frames = frames;
-        // one source per wave: the fixed cost per wave (tables, scan, look-back) wants the longest runs
-        // (measured, 64 x 1 Mi frames: R = 8 2.5 ms, 12 1.6 ms, 16 1.2 ms, 20 0.93 ms)
-        if (frames >= 64u * 12u * 4u) cfg.frames_per_lane = 12;  // measured, 64 x 1 Mi frames with the coalesced output path: R = 12 0.40 ms, 16 0.43, 20 0.45
-        if (const char *e = getenv("RH_BIQUAD_R")) cfg.frames_per_lane = (uint32_t)atoi(e);  // tuning aid
-        rh_status st = rh_rlm_create(&cache, &cfg);
-        if (st != RH_OK) return st;
-        cache_frames = frames;
-        cache_streams = n_streams;
-    }
-    std::vector<const float *> ptrs(n_streams);
-    std::vector<uint64_t> lens(n_streams, frames);
-    for (uint32_t s = 0; s < n_streams; ++s) ptrs[s] = src + (uint64_t)s * frames * 2;
-    const hipStream_t hs = rh::as_stream(stream);
-    rh_status st = set_sources_impl(cache, ptrs.data(), lens.data(), n_streams, &hs);
-    if (st == RH_OK) st = rh_rlm_run_batch(cache, dst, frames, nullptr, stream);
-    return st;
 }
 
 }  // extern "C"

@@ -399,7 +399,6 @@ rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample
     return RH_OK;
 }
 
-rh_status rh_biquad_scan(float *dst, const float *src, uint64_t frames, uint32_t channels, uint32_t n_streams, const float coeffs5_host[5], float *state, rh_stream stream);
 }  // extern "C" (reopened below)
 namespace rh {
 rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uint32_t n_streams, const float k5[5], float *state, hipStream_t s);
@@ -412,22 +411,21 @@ rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t chan
     if (channels == 0 || !coeffs5_host) return RH_ERR_INVALID;
     if (frames == 0 || n_streams == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    if (mode == 1) {  // time-parallel: the dedicated scan kernel (rh_biquad_scan.hip); what it does not take -- rows that are not
-                      // 16-byte aligned, a filter that does not forget within 64 tiles -- goes to the fused kernel's batch mode
-                      // (stereo, zero state) or is refused
+    if (mode == 1) {  // time-parallel: the dedicated scan kernel (rh_biquad_scan.hip).  What it does not take -- rows that are not
+                      // 16-byte aligned, a filter that does not forget within 64 tiles (a very low cutoff on short tiles), more than
+                      // 8 channels -- continues in the reference-order kernel below: the same state layout, the exact bits, slower.
         const uint64_t total = frames * channels * (uint64_t)n_streams;
         const bool overlap = dst < src + total && src < dst + total;  // in place: the scan would read halo frames a neighbour has overwritten
         if (!overlap) {
             const rh_status st = rh::biquad_scan_launch(dst, src, frames, channels, n_streams, coeffs5_host, state, rh::as_stream(stream));
-            if (st != RH_ERR_UNSUPPORTED || getenv("RH_BIQUAD_NO_FALLBACK")) return st;
-            return rh_biquad_scan(dst, src, frames, channels, n_streams, coeffs5_host, state, stream);
+            if (st != RH_ERR_UNSUPPORTED || rh::knob(rh::K_BIQUAD_NO_FALLBACK)) return st;
         }
         mode = 0;
     }
     if (mode != 0) return RH_ERR_INVALID;
     const Biquad5 k{coeffs5_host[0], coeffs5_host[1], coeffs5_host[2], coeffs5_host[3], coeffs5_host[4]};
     // rows that start on 16-byte boundaries take the vector kernel (same arithmetic, same bits); anything else the 4-byte one
-    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || (frames * channels) % 4 == 0) && !getenv("RH_BIQUAD_SEQ");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || (frames * channels) % 4 == 0) && !rh::knob(rh::K_BIQUAD_SEQ);
     const dim3 grid_v((n_streams + kBlock - 1) / kBlock);
     if (aligned && channels == 1) hipLaunchKernelGGL(k_biquad_vec<1>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
     else if (aligned && channels == 2) hipLaunchKernelGGL(k_biquad_vec<2>, grid_v, dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, n_streams, k, state);
@@ -473,7 +471,7 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
     hipStream_t s = rh::as_stream(stream);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (n_streams == 1 || n_samples % 4 == 0);
     // in place (dst == src) the window's tail could not be re-read from the input: the ring kernel then
-    if (aligned && dst != src && !getenv("RH_AGC_SEQ") && !getenv("RH_AGC_VEC")) {  // the chains taken apart (rh_agc.hip): same operations, same bits
+    if (aligned && dst != src && !rh::knob(rh::K_AGC_SEQ) && !rh::knob(rh::K_AGC_VEC)) {  // the chains taken apart (rh_agc.hip): same operations, same bits
         const bool overlap = dst < src + (uint64_t)n_streams * n_samples && src < dst + (uint64_t)n_streams * n_samples;
         if (!overlap) {
             const float k5[5] = {k.target_level, k.attack_coeff, k.release_coeff, k.absolute_max_gain, k.floor};
@@ -481,7 +479,7 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
             if (cs != RH_ERR_UNSUPPORTED) return cs;
         }
     }
-    if (aligned && dst != src && !getenv("RH_AGC_SEQ")) {
+    if (aligned && dst != src && !rh::knob(rh::K_AGC_SEQ)) {
         hipLaunchKernelGGL(k_agc_vec, dim3((n_streams + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dst, src, n_samples, n_streams, k, state);
         RH_CHECK_LAUNCH();
         return RH_OK;

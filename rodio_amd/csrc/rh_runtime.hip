@@ -1,4 +1,5 @@
 // rh_runtime.hip -- device bring-up, memory/stream/event helpers of the C ABI.
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -16,6 +17,21 @@ void set_hip_error(hipError_t e, const char *what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 
+namespace {
+const char *const kKnobNames[K_COUNT] = {"RH_AGC_SEQ", "RH_AGC_VEC", "RH_BIQUAD_NO_FALLBACK", "RH_BIQUAD_SEQ", "RH_BIQUAD_R", "RH_BIQUAD_NW", "RH_BIQUAD_WGS", "RH_LIMIT_SEQ",
+                                         "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
+                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP"};
+std::string g_knob_val[K_COUNT];
+bool g_knob_set[K_COUNT];
+}  // namespace
+void load_knobs() {
+    for (int k = 0; k < K_COUNT; ++k) {
+        const char *v = getenv(kKnobNames[k]);
+        g_knob_set[k] = v != nullptr;
+        g_knob_val[k] = v ? v : "";
+    }
+}
+const char *knob(Knob k) { return g_knob_set[k] ? g_knob_val[k].c_str() : nullptr; }
 namespace {
 // bytes [0, n) of p: the unaligned head and tail byte by byte, the 4-byte aligned body word by word
 __global__ void k_fill(unsigned char *p, uint32_t word, size_t n) {
@@ -95,6 +111,7 @@ const char *rh_status_string(rh_status s) {
 const char *rh_last_hip_error(void) { return rh::g_last_error.c_str(); }
 
 rh_status rh_init(int32_t device) {
+    rh::load_knobs();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
@@ -204,6 +221,12 @@ rh_status rh_stream_destroy(rh_stream s) {
     RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(s)));
     rh::drop_stream_scratch(rh::as_stream(s));
     RH_HIP_TRY(hipStreamDestroy(rh::as_stream(s)));
+    return RH_OK;
+}
+rh_status rh_stream_release_scratch(rh_stream s) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(s)));
+    rh::drop_stream_scratch(rh::as_stream(s));
     return RH_OK;
 }
 rh_status rh_stream_synchronize(rh_stream s) {

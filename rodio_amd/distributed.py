@@ -61,6 +61,7 @@ class ShardedResampleLowpassMix:
         from .source import ResampleLowpassMix
 
         self.rank, self.world, self.group = rank, world, group
+        self.check = kw.pop("check_status", True)  # synchronise and read the shard's status word in front of the collective
         self.pipe = ResampleLowpassMix(*args, **kw)
         self.out_frames = 0
 
@@ -77,6 +78,8 @@ class ShardedResampleLowpassMix:
         if out is None:
             out = torch.empty(max(self.out_frames * ch, 4), device="cuda", dtype=torch.float32)
         local = self.pipe.run(out)
+        if self.check:  # a hand-off that timed out poisons its tile with NaN: it must not reach the other ranks' mixes as well
+            self.pipe.check_status()
         if local.numel() < self.out_frames * ch:  # this shard's sources are shorter than another rank's
             out[local.numel(): self.out_frames * ch].zero_()
         mixed = out[: self.out_frames * ch]

@@ -430,6 +430,16 @@ def biquad_batch(x, coeffs5, mode=1):
     return out
 
 
+def _check_state(state, shape, who):
+    """A carried state is a contiguous float32 device tensor of exactly the elements the kernel will read and write."""
+    if state is None:
+        return
+    torch = _t()
+    want = int(np.prod(shape))
+    if state.dtype != torch.float32 or not state.is_cuda or not state.is_contiguous() or state.numel() != want:
+        raise ValueError(f"{who}: state must be a contiguous float32 CUDA tensor of {want} elements (shape {tuple(shape)}), got {state.dtype} {tuple(state.shape)} on {state.device}")
+
+
 def limit_batch(x, channels, sample_rate, threshold=-1.0, knee_width=4.0, attack_ns=5_000_000, release_ns=100_000_000, state=None, out=None):
     """rh_limit over the rows of the device tensor x [S, frames*channels] (limit.rs:853-988, one limiter per row).
     state: optional device tensor [S, 2*channels] {integrator, peak} per channel, carried across blocks (updated in place)."""
@@ -437,6 +447,9 @@ def limit_batch(x, channels, sample_rate, threshold=-1.0, knee_width=4.0, attack
     torch = _t()
     assert x.is_contiguous() and x.dim() == 2
     S, n = x.shape
+    if n % channels:
+        raise ValueError(f"rows of {n} samples are not whole frames of {channels} channels (the kernel's row stride is frames * channels)")
+    _check_state(state, (S, 2 * channels), "limit_batch")
     if out is None:
         out = torch.empty_like(x)
     p = LimitParams(threshold, knee_width, attack_ns, release_ns)
@@ -459,6 +472,7 @@ def agc_batch(x, sample_rate, target_level=1.0, attack_ns=4_000_000_000, release
     torch = _t()
     assert x.is_contiguous() and x.dim() == 2
     S, n = x.shape
+    _check_state(state, (S * int(lib.rh_agc_state_floats()),), "agc_batch")
     if out is None:
         out = torch.empty_like(x)
     p = AgcParams(target_level, attack_ns, release_ns, absolute_max_gain, floor)

@@ -42,3 +42,25 @@ def sine_generator(sample_rate: int, frequency: float, n: int):
         phase = f32(phase + step)
         phase = f32(phase - np.floor(phase))  # rem_euclid(1.0) of a non-negative value
     return np.sin(f32(6.2831855) * ph).astype(np.float32)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def knobs(**env):
+    """The library's diagnostic / tuning variables are read once, by rh_init(): set them, re-read, run, restore."""
+    import rodio_amd
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    rodio_amd.init(0)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        rodio_amd.init(0)

@@ -15,7 +15,7 @@
 //       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
 //   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
 //       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE take:NS:FADE delay:NS
-//       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T dither:BITS:ALG:SEED channel_volume:G0,G1,.. spatial
+//       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T dither:BITS:ALG:SEED channel_volume:G0,G1,.. spatial exact (filters in reference order)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -292,7 +292,8 @@ int main(int argc, char **argv) {
             for (int a = 6; a < argc; ++a) {
                 const std::vector<std::string> t = split(argv[a], ':');
                 const std::string &op = t[0];
-                if (op == "amplify") g.amplify(std::stof(t.at(1)));
+                if (op == "exact") g.exact_filters(true);
+                else if (op == "amplify") g.amplify(std::stof(t.at(1)));
                 else if (op == "low_pass") g.low_pass((uint32_t)std::stoul(t.at(1)));
                 else if (op == "high_pass") g.high_pass((uint32_t)std::stoul(t.at(1)));
                 else if (op == "reverb") g.reverb(rh::Nanos(std::stoll(t.at(1))), std::stof(t.at(2)));

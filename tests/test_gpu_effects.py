@@ -108,23 +108,7 @@ def test_agc_state_carried_across_blocks_equals_one_pass(G, O, kw):
         assert float(np.max(np.abs(got[s] - refs[s]))) <= TOL, s
 
 
-def _env(**kw):
-    import contextlib
-
-    @contextlib.contextmanager
-    def cm():
-        old = {k: os.environ.get(k) for k in kw}
-        os.environ.update(kw)
-        try:
-            yield
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
-
-    return cm()
+from conftest import knobs as _env  # noqa: E402
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2),
@@ -175,8 +159,7 @@ def _truth(x, co, ch):
 def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
     import torch
 
-    os.environ["RH_BIQUAD_NO_FALLBACK"] = "1"  # the new kernel or nothing
-    try:
+    with _env(RH_BIQUAD_NO_FALLBACK="1"):  # the new kernel or nothing
         S = 3 if (frames * ch) % 4 == 0 else 1  # rows of a batch must start on 16-byte boundaries
         xs = [rnd(200 + 7 * ch + s, frames * ch, 0.4) for s in range(S)]  # (the f32 recurrence of a high-pass itself sits ~1e-5 from exact at full scale)
         x = torch.from_numpy(np.stack(xs)).cuda()
@@ -190,8 +173,6 @@ def test_biquad_mode1_channels_and_boundaries(G, O, ch, frames):
                 e_par, e_seq = float(np.max(np.abs(par[s] - t))), float(np.max(np.abs(seq[s] - t)))
                 assert d <= TOL, (kind, s, d)
                 assert e_par <= 2.0 * e_seq + 1e-7, (kind, s, e_par, e_seq)
-    finally:
-        del os.environ["RH_BIQUAD_NO_FALLBACK"]
     G.async_status()  # no hand-off inside the scan expired
 
 

@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import knobs  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -83,11 +84,8 @@ def test_limiter_one_poll_point_variant_with_few_streams(G, O):
     x = torch.from_numpy(np.stack(xs)).cuda()
     outs = {}
     for skew in ("0", "1"):
-        os.environ["RH_LIMIT_SKEW"] = skew
-        try:
+        with knobs(RH_LIMIT_SKEW=skew):
             outs[skew] = G.limit_batch(x, ch, 48000).cpu().numpy()
-        finally:
-            del os.environ["RH_LIMIT_SKEW"]
     for s in range(S):
         ref = _oracle(O, xs[s], ch, 48000)
         assert float(np.max(np.abs(outs["1"][s] - ref))) <= TOL, s
@@ -189,11 +187,8 @@ def test_limiter_reference_order_kernel_agrees(G, O):
     # RH_LIMIT_SEQ=1 forces the one-lane-per-stream kernel (what unaligned batches take)
     x = _signal(9, 30000, 2)
     ref = _oracle(O, x, 2, 48000)
-    os.environ["RH_LIMIT_SEQ"] = "1"
-    try:
+    with knobs(RH_LIMIT_SEQ="1"):
         seq = G.TestSource(x, 2, 48000).limit().collect()
-    finally:
-        del os.environ["RH_LIMIT_SEQ"]
     par = G.TestSource(x, 2, 48000).limit().collect()
     assert float(np.max(np.abs(seq - ref))) <= TOL and float(np.max(np.abs(par - seq))) <= TOL
 
@@ -259,8 +254,7 @@ def test_an_expired_hand_off_is_reported_and_poisons_the_output(G, O):
 
     G.async_status()  # clean slate
     x = torch.from_numpy(np.stack([_signal(70 + s, 1 << 18, 2) for s in range(64)])).cuda()
-    os.environ["RH_SCAN_SPIN_LIMIT"] = "0"
-    try:
+    with knobs(RH_SCAN_SPIN_LIMIT="0"):
         bad = 0
         for _ in range(12):  # tiles of one stream run side by side: some first looks come too early
             out = G.limit_batch(x, 2, 48000)
@@ -272,8 +266,6 @@ def test_an_expired_hand_off_is_reported_and_poisons_the_output(G, O):
         outb = G.biquad_batch(x, co, mode=1)
         torch.cuda.synchronize()
         bad += int(torch.isnan(outb).sum())
-    finally:
-        del os.environ["RH_SCAN_SPIN_LIMIT"]
     assert bad > 0, "no hand-off was late in thirteen launches of 64 x 32 tiles: the test lost its premise"
     with pytest.raises(_lib.RhError) as e:
         G.async_status()

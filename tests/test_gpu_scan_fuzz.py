@@ -5,6 +5,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+from conftest import knobs  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -91,8 +92,7 @@ def test_biquad_mode1_random_shapes(G, O, case):
     co = G.biquad_coeffs(kind, freq, 0.5, 48000)
     xs = [(rng.uniform(-1, 1, frames * ch) * 0.3).astype(np.float32) for _ in range(S)]
     x = torch.from_numpy(np.stack(xs)).cuda()
-    os.environ["RH_BIQUAD_NO_FALLBACK"] = "1"  # the scan kernel or nothing
-    try:
+    with knobs(RH_BIQUAD_NO_FALLBACK="1"):  # the scan kernel or nothing
         if carry:
             st1, st0 = torch.zeros((S, 4 * ch), device="cuda"), torch.zeros((S, 4 * ch), device="cuda")
             p1, p0 = [], []
@@ -106,8 +106,6 @@ def test_biquad_mode1_random_shapes(G, O, case):
             par, seq = torch.cat(p1, dim=1), torch.cat(p0, dim=1)
         else:
             par, seq = _biquad(G, x, frames, ch, S, co, 1), _biquad(G, x, frames, ch, S, co, 0)
-    finally:
-        del os.environ["RH_BIQUAD_NO_FALLBACK"]
     assert float((par - seq).abs().max()) <= TOL, (ch, S, frames, carry, kind, freq)
     # and against the oracle's BltFilter itself (blt.rs:397-560), not only against the reference-order kernel: first and last stream
     for s_ in sorted({0, S - 1}):

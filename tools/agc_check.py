@@ -19,9 +19,11 @@ for S, n in shapes:
     res = {}
     for name, env in (("chain", {}), ("vec", {"RH_AGC_VEC": "1"}), ("seq", {"RH_AGC_SEQ": "1"})):
         os.environ.update(env)
+        G.init(0)  # the library reads its variables in rh_init
         res[name] = G.agc_batch(x, 48000).cpu().numpy()
         for k in env:
             del os.environ[k]
+        G.init(0)
     ref = O.TestSource(xs[0], 1, 48000).automatic_gain_control().collect()
     line = f"S={S} n={n}: seq-oracle {np.max(np.abs(res['seq'][0] - ref)):.2e}"
     for name in ("chain", "vec"):
