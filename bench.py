@@ -21,6 +21,7 @@ SURVEY.md 8(e)).  Rank 0 prints ONE JSON line.
 The other configurations (single GPU, one JSON line each; evidence for the numbers in DESIGN.md / README.md):
 
     python bench.py --config 2span      # config 2 with current_span_len = 32768 (uniform.rs:56-67 restarts the converter)
+    python bench.py --config 2mono      # config 2 on MONO sources (the fused kernels' channel count is a template parameter)
     python bench.py --config 3          # reverb(65 536 samples) -> Spatial on 64 sources (rh_reverb_spatial)
     python bench.py --config 5          # i16 -> f32 and 6 -> 2 channels on the music.wav excerpt, tiled
     python bench.py --config ragged     # config 2 with source lengths uniform in [N/2, N]
@@ -49,14 +50,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def make_sources(S, N, first, total):
-    """[S, N*2] f32 on the host: source `first + s` of a `total`-source job, U(-1,1) / total from
+def make_sources(S, N, first, total, ch=2):
+    """[S, N*ch] f32 on the host: source `first + s` of a `total`-source job, U(-1,1) / total from
     numpy.random.default_rng(1234 + global index) -- BASELINE.md section 3, cfg 2 and cfg 4."""
     import numpy as np
 
-    x = np.empty((S, N * 2), dtype=np.float32)
+    x = np.empty((S, N * ch), dtype=np.float32)
     for s in range(S):
-        x[s] = (np.random.default_rng(1234 + first + s).uniform(-1.0, 1.0, 2 * N) * (1.0 / total)).astype(np.float32)
+        x[s] = (np.random.default_rng(1234 + first + s).uniform(-1.0, 1.0, ch * N) * (1.0 / total)).astype(np.float32)
     return x
 
 
@@ -123,7 +124,7 @@ def pmc_traffic(argv, kernel_like, per_call=False):
                "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of this script, mean over the last dispatches"}
 
 
-def cpu_baseline(x, S, N, span, freq, want_all_cores=True):
+def cpu_baseline(x, S, N, span, freq, want_all_cores=True, ch=2):
     """The oracle's iterator-pull pipeline (a virtual next() per adapter like rodio's Box<dyn Source>), one thread, the whole
     workload; its output is kept for the parity check.  Then the same with the sources sharded over the cores (first 1/4 of
     every source: a bounded sample)."""
@@ -131,12 +132,12 @@ def cpu_baseline(x, S, N, span, freq, want_all_cores=True):
 
     from oracle import rodio_oracle as O
 
-    data = x.reshape(S, N, 2)
+    data = x.reshape(S, N, ch)
     t0 = time.perf_counter()
     ref = O.pipeline_resample_lowpass_mix(data, 44100, 48000, span if span else O.SPAN_NONE, freq, 0.5, want_output=True)
     dt = time.perf_counter() - t0
     res = {
-        "value": S * N * 2 / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "value": S * N * ch / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": f"the whole workload: {S} sources x {N} frames, {dt:.1f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores",
     }
     if want_all_cores:
@@ -149,7 +150,7 @@ def cpu_baseline(x, S, N, span, freq, want_all_cores=True):
         with ThreadPoolExecutor(cores) as ex:  # ctypes drops the GIL
             list(ex.map(lambda sh: O.pipeline_resample_lowpass_mix(sh, 44100, 48000, span if span else O.SPAN_NONE, freq, 0.5, want_output=False), shards))
         dm = time.perf_counter() - t0
-        res["all_cores"] = {"value": S * n4 * 2 / dm / 1e6, "unit": "Msamples/s", "cores": cores,
+        res["all_cores"] = {"value": S * n4 * ch / dm / 1e6, "unit": "Msamples/s", "cores": cores,
                             "sample": f"sources sharded over {cores} threads, first {n4} frames of each, {dm:.2f} s; an upper bound (rodio's mixer is single-threaded, stream.rs:538-545)"}
     return res, ref
 
@@ -181,19 +182,19 @@ def headline(args, argv):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    S, N, Cn = args.sources, args.frames, 2
+    S, N, Cn = args.sources, args.frames, (1 if args.config == "2mono" else 2)
     span = 32768 if args.config == "2span" else args.span
     ragged = args.config == "ragged"
     child = os.environ.get("RH_BENCH_CHILD") == "1"  # a rocprofv3 --pmc pass of ourselves: same launches, no extras
     # sources [rank*S, (rank+1)*S) of a (S*world)-source job: seeds 1234 + global index, scale 1/(S*world) (cfg 2 / cfg 4)
-    host = make_sources(S, N, rank * S, S * world)
+    host = make_sources(S, N, rank * S, S * world, Cn)
     data = torch.from_numpy(host).cuda()
     lens = [N] * S
     if ragged:
         lens = [int(v) for v in np.random.default_rng(1).integers(N // 2, N + 1, S)]
     pipe = rh.ResampleLowpassMix(44100, 48000, Cn, span or None, "low_pass", args.freq, 0.5, max_sources=S,
                                  max_in_frames=N, frames_per_lane=args.frames_per_lane, ring_stages=args.ring_stages, no_balance=args.no_balance, force_general=args.force_general)
-    pipe.set_sources([data[s, : 2 * lens[s]] for s in range(S)])
+    pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
     M = pipe.out_frames
     tuned = None
     if not (args.no_autotune or args.frames_per_lane or args.ring_stages):
@@ -280,7 +281,7 @@ def headline(args, argv):
                  "reduce_check": {"samples": k, "max_abs_err_vs_rank_ordered_sum_of_partials": float((red[:k] - acc).abs().max()), "peak": float(acc.abs().max())}}
 
     if rank == 0 and child:
-        print(json.dumps({"child": True, "kernel_ms": kernel_avg_ms}), flush=True)
+        print(json.dumps({"child": True, "kernel_ms": kernel_avg_ms, "calls": args.warmup + args.steps}), flush=True)
     elif rank == 0:
         in_samples = sum(lens) * Cn
         alg_bytes = 4 * in_samples + 4 * M * Cn
@@ -290,7 +291,8 @@ def headline(args, argv):
         child_argv = [a for a in argv]
         child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
         child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
-        traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, "%k_rlm%")
+        # (a ragged batch is two kernels per launch: the sum over both, per call)
+        traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, "%k_rlm%", per_call=bool(geo["ragged_pair"]))
         ph = pipe.phase_cycles()
         if ph is not None:
             geo["phase_cycles"] = [round(x) for x in ph]
@@ -305,7 +307,7 @@ def headline(args, argv):
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{S} f32 stereo sources/GPU x {N} frames" + (" (lengths uniform in [N/2, N])" if ragged else "")
+                "workload": f"{S} f32 {'mono' if Cn == 1 else 'stereo'} sources/GPU x {N} frames" + (" (lengths uniform in [N/2, N])" if ragged else "")
                             + f", 44.1->48 kHz linear resample + low_pass({args.freq}) + ordered Mixer sum"
                             + (f", span_len={span}" if span else ", span_len=None")
                             + f"; numpy default_rng(1234+s) U(-1,1)/{S * world}"
@@ -324,8 +326,23 @@ def headline(args, argv):
                 multi["efficiency_vs_1gpu"] = res["value"] / (world * one)  # weak scaling: N ranks do N times the work of one
                 multi["one_gpu_value"] = one
             res["multi_gpu"] = multi
+        if world == 1 and not args.no_cpu_baseline and ragged:  # sources of different lengths: the oracle's Mixer over per-source chains, one thread, the whole workload
+            from oracle import rodio_oracle as O
+
+            t0 = time.perf_counter()
+            mx = O.Mixer(Cn, 48000)
+            for s_ in range(S):
+                mx.add(O.UniformSourceIterator(O.TestSource(host[s_, : Cn * lens[s_]], Cn, 44100), Cn, 48000).low_pass(args.freq))
+            ref = mx.collect()
+            dtc = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": in_samples / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                   "sample": f"the whole workload ({S} sources, {in_samples} samples), {dtc:.1f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
+            got = outs[(args.steps - 1) & 1].cpu().numpy()
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64)) if got.shape == ref.shape else None
+            res["parity"] = ({"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()), "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5),
+                              "vs": "oracle Mixer over the per-source chains, the timed launch's whole block"} if d is not None else {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"})
         if world == 1 and not args.no_cpu_baseline and not ragged:
-            base, ref = cpu_baseline(host, S, N, span, args.freq)
+            base, ref = cpu_baseline(host, S, N, span, args.freq, ch=Cn)
             res["cpu_baseline"] = base
             got = outs[(args.steps - 1) & 1].cpu().numpy()  # the last timed launch's block
             if got.shape == ref.shape:
@@ -531,7 +548,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="2", help="2 (default, the driver line), 2span, 3, 5, ragged, limit, agc, biquad")
+    ap.add_argument("--config", default="2", help="2 (default, the driver line), 2span, 2mono, 3, 5, ragged, limit, agc, biquad")
     ap.add_argument("--sources", type=int, default=256, help="sources per GPU (side configs: streams)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
@@ -549,7 +566,7 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    if args.config in ("2", "2span", "ragged"):
+    if args.config in ("2", "2span", "2mono", "ragged"):
         # the arguments a profiling child must repeat to launch the same kernels
         argv = ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames), "--span", str(args.span), "--freq", str(args.freq),
                 "--frames-per-lane", str(args.frames_per_lane), "--ring-stages", str(args.ring_stages), "--no-balance", str(args.no_balance), "--force-general", str(args.force_general)]

@@ -327,7 +327,7 @@ rh_status rh_agc(float *dst, const float *src, uint64_t n_samples, uint32_t samp
  * Replaces uniform.rs:78-97 + sample_rate.rs:131-201 + blt.rs:397-451 + mixer.rs:185-198. */
 typedef struct rh_rlm_config {
     uint32_t from_rate, to_rate;
-    uint32_t channels;     /* 2 (stereo) in this round */
+    uint32_t channels;     /* 1 (mono) or 2 (stereo): the frames of every source and of the mix (other layouts: rh_channels_convert / rh_uniform_segments in front) */
     uint64_t span_len;     /* 0 = None; else chunk of min(span_len, 32768) samples */
     int32_t filter_kind;   /* 0 = low_pass, 1 = high_pass, -1 = no filter, 2 = custom_coeffs; from_rate == to_rate: the converter passes through */
     uint32_t filter_freq;

@@ -893,10 +893,10 @@ public:
         for (auto &g : gens_)
             if (g->plan) (void)rh_rlm_destroy(g->plan);
     }
-    /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source (uniform.rs:78-97: channels first, then the rate):
-    /// a channel count other than 2 is staged in the source's own layout and converted on the device in front of the fused
-    /// launch (ChannelCountConverter, rh_channels_convert: a mono source crosses PCIe as mono); a rate more than 4.5 times the
-    /// mixer's first runs through the GPU SampleRateConverter adapter, still one pull chain.
+    /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: mono sources form fused streams of their own (the kernel
+    /// reads mono frames, the mono mix becomes stereo once per block); a channel count above 2 is staged in the source's own
+    /// layout and converted on the device in front of the fused launch (ChannelCountConverter, rh_channels_convert); a rate more
+    /// than 4.5 times the mixer's first runs through the GPU SampleRateConverter adapter, still one pull chain.
     void add(BoxSource src, float gain = 1.0f) {
         if (!src) throw std::invalid_argument("source");
         std::uint16_t ch = src->channels();
@@ -1032,6 +1032,8 @@ private:
         int cur = 0, slot = 0;
         std::uint64_t head = 0, fill = 0;  // q[cur] holds `fill` frames from frame `head` on (head in {0,1}: the END stays 16-byte aligned)
         bool done = false;                 // the stream emitted its last frame
+        bool mono = false;                 // a fused stream of mono sources (rh_rlm_config.channels = 1): mono rows in, a mono mix out ...
+        detail::DeviceBuf qm;              // ... which ChannelCountConverter(1 -> 2) (channels.rs:64-73) turns into the stereo queue, once per block
         // span-by-span generations (`staged`): the sources are converted to the mixer's format first, row by row
         bool staged = false;
         std::uint64_t target = 0, crow = 0;  // converted frames a block tops every row up to; capacity of a row (frames)
@@ -1070,29 +1072,33 @@ private:
             start_stream(std::move(all), true);
             return;
         }
-        // continuous sources: one fused stream per input rate, in order of first appearance
+        // continuous sources: one fused stream per input rate -- and one for its mono sources, which the kernel reads as they are
+        // (4 bytes per frame) -- in order of first appearance
         for (Src &x : all) make_direct(x);
-        std::vector<std::uint32_t> rates;
-        for (const Src &x : all)
-            if (std::find(rates.begin(), rates.end(), x.up->sample_rate()) == rates.end()) rates.push_back(x.up->sample_rate());
-        for (const std::uint32_t r : rates) {
+        std::vector<std::pair<std::uint32_t, bool>> keys;
+        for (const Src &x : all) {
+            const std::pair<std::uint32_t, bool> k(x.up->sample_rate(), x.ch == 1);
+            if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+        }
+        for (const auto &k : keys) {
             std::vector<Src> group;
             for (Src &x : all)
-                if (x.up && x.up->sample_rate() == r) group.push_back(std::move(x));
-            start_stream(std::move(group), false);
+                if (x.up && x.up->sample_rate() == k.first && (x.ch == 1) == k.second) group.push_back(std::move(x));
+            start_stream(std::move(group), false, k.second);
         }
     }
-    void start_stream(std::vector<Src> srcs, bool staged) {
+    void start_stream(std::vector<Src> srcs, bool staged, bool mono = false) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
         g.srcs = std::move(srcs);
         g.staged = staged;
+        g.mono = mono && !staged;
         const std::uint32_t from = staged ? rate_ : g.srcs.front().up->sample_rate();  // staged: the fused kernel sees converted rows
         rh_rlm_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.from_rate = from;
         cfg.to_rate = rate_;
-        cfg.channels = 2;
+        cfg.channels = g.mono ? 1 : 2;
         cfg.span_len = 0;
         cfg.filter_kind = opt_.filter_kind;
         cfg.filter_freq = opt_.filter_freq;
@@ -1118,7 +1124,7 @@ private:
         check(rh_rlm_stream_begin(g.plan), "rh_rlm_stream_begin");
         row_ = (cap_frames_ * 2 + 3) & ~std::size_t(3);  // 16-byte aligned rows
         std::uint64_t m = 0;
-        check(rh_resample_out_frames(staged ? g.crow : cap_frames_, from, rate_, 2, 0, &m), "rh_resample_out_frames");
+        check(rh_resample_out_frames(staged ? g.crow : cap_frames_, from, rate_, cfg.channels, 0, &m), "rh_resample_out_frames");
         out_cap_frames_ = std::max<std::uint64_t>(out_cap_frames_, m + 64);
         for (auto &other : gens_)  // rates differ between generations: every queue holds two of the largest blocks
             for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * 2, (other->head + other->fill) * 2);
@@ -1267,6 +1273,8 @@ private:
         const std::size_t S = g.srcs.size();
         detail::PinnedBuf &stage = g.stage[g.slot];
         g.slot ^= 1;
+        const std::size_t native = g.mono ? 1 : 2;                                              // channels of the rows the fused launch reads
+        const std::size_t row_ = g.mono ? ((cap_frames_ + 3) & ~std::size_t(3)) : this->row_;   // floats per row
         stage.reset(S * row_);
         g.din.reset(S * row_);
         std::vector<const float *> ptrs(S);
@@ -1277,7 +1285,7 @@ private:
         std::vector<std::size_t> side_off(S, 0);
         std::size_t side_floats = 0;
         for (std::size_t i = 0; i < S; ++i)
-            if (g.srcs[i].ch != 2) {
+            if (g.srcs[i].ch != native) {
                 side_off[i] = side_floats;
                 side_floats += (cap_frames_ * g.srcs[i].ch + 3) & ~std::size_t(3);
             }
@@ -1289,7 +1297,7 @@ private:
         for (std::size_t i = 0; i < S; ++i) {
             Src &x = g.srcs[i];
             const std::size_t ch = x.ch;
-            float *row = ch == 2 ? stage.get() + i * row_ : side.get() + side_off[i];
+            float *row = ch == native ? stage.get() + i * row_ : side.get() + side_off[i];
             std::size_t have = x.held.size();
             if (have / ch + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
             if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
@@ -1309,19 +1317,26 @@ private:
         if (side_floats) {  // ChannelCountConverter on the device (channels.rs:57-85), into the stereo rows the fused launch reads
             check(rh_memcpy_h2d(g.dside.get(), side.get(), side_floats * sizeof(float), stream_), "rh_memcpy_h2d");
             for (std::size_t i = 0; i < S; ++i)
-                if (g.srcs[i].ch != 2 && avail[i])
+                if (g.srcs[i].ch != native && avail[i])
                     check(rh_channels_convert(g.din.get() + i * row_, g.dside.get() + side_off[i], (std::size_t)avail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
         }
         std::uint64_t out = 0, consumed = 0;
         if (debug_poison()) check(rh_memset(g.queue_end(), 0xff, (out_cap_frames_ * 2 - g.fill - g.head) * 2 * sizeof(float), stream_), "rh_memset");
-        check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
-              "rh_rlm_stream_block_v");
+        if (g.mono) {  // the mono mix of the block, then ChannelCountConverter(1 -> 2) behind the stereo queue (one pass over the MIX, not per source)
+            g.qm.reset(out_cap_frames_ * 2);
+            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.qm.get(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+                  "rh_rlm_stream_block_v");
+            if (out) check(rh_channels_convert(g.queue_end(), g.qm.get(), (std::size_t)out, 1, 2, stream_), "rh_channels_convert");
+        } else {
+            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+                  "rh_rlm_stream_block_v");
+        }
         g.fill += out;
         bool all_ended = true;
         for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
             Src &x = g.srcs[i];
             const std::size_t ch = x.ch;
-            const float *row = ch == 2 ? stage.get() + i * row_ : side.get() + side_off[i];
+            const float *row = ch == native ? stage.get() + i * row_ : side.get() + side_off[i];
             const std::size_t have = (std::size_t)avail[i] * ch, drop = std::min<std::size_t>((std::size_t)consumed * ch, have);
             x.held.assign(row + drop, row + have);
             all_ended = all_ended && x.ended;

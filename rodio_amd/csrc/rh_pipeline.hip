@@ -306,8 +306,47 @@ __device__ __forceinline__ void wait_groups(int n) {
 // nothing about them needs a per-source aggregate, see k_rlm_wave) -- for a mixer's worth of tracks that is almost
 // every (tile, source) pair -- and k_rlm_resid, launched behind it, adds the few pairs in which a source is about
 // to end.  Mix order: stable sources first (the filtered pipeline is compared at 1e-5, not bitwise).
-template <int R, int KV, int NS, bool FILT, bool RAG = false>
+// ---- channel count as a template parameter (C = 1: mono, C = 2: stereo) -------------------------------------------------------------
+// A frame is C floats.  Everything per channel goes through these few helpers, written so that C = 2 spells out exactly the
+// operations the stereo kernels always had (component by component, same order): the stereo code objects do not change.
+template <int C>
+struct Chan;
+template <>
+struct Chan<2> {
+    typedef v2f V;                    // one frame in registers
+    static constexpr uint32_t kFB = 8;   // bytes per frame
+    static constexpr uint32_t kVF = 2;   // frames per 16-byte vector
+    static __device__ __forceinline__ V zero() { return v2f{0.0f, 0.0f}; }
+    static __device__ __forceinline__ V ld_lds(const lds_u8 *q) { return *(const lds_f2 *)q; }
+    static __device__ __forceinline__ float get(const V &v, int c) { return c ? v.y : v.x; }
+    static __device__ __forceinline__ void set(V &v, int c, float x) {
+        if (c) v.y = x;
+        else v.x = x;
+    }
+};
+template <>
+struct Chan<1> {
+    typedef float V;
+    static constexpr uint32_t kFB = 4;
+    static constexpr uint32_t kVF = 4;
+    static __device__ __forceinline__ V zero() { return 0.0f; }
+    static __device__ __forceinline__ V ld_lds(const lds_u8 *q) { return *(const RH_LDS float *)q; }
+    static __device__ __forceinline__ float get(const V &v, int) { return v; }
+    static __device__ __forceinline__ void set(V &v, int, float x) { v = x; }
+};
+// component-wise helpers (v2f: .x then .y, the order the stereo kernels spell)
+__device__ __forceinline__ v2f vfma_s(float s, v2f a, v2f c) { return v2f{fma_(s, a.x, c.x), fma_(s, a.y, c.y)}; }
+__device__ __forceinline__ float vfma_s(float s, float a, float c) { return fma_(s, a, c); }
+__device__ __forceinline__ v2f vmul_s(v2f a, float s) { return v2f{a.x * s, a.y * s}; }
+__device__ __forceinline__ float vmul_s(float a, float s) { return a * s; }
+__device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
+__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+
+template <int R, int KV, int NS, bool FILT, bool RAG = false, int C = 2>
 __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {
+    typedef Chan<C> CH;
+    typedef typename CH::V V;
+    constexpr uint32_t FB = CH::kFB, VF = CH::kVF;
     static_assert(R <= kMaxR, "frames per lane");
     static_assert(NS >= 2 && NS <= 4, "ring depth");
     static_assert(KV * (NS - 1) < 64, "vmcnt range");
@@ -354,11 +393,11 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         uint32_t nn;
         cursor_resolve(cursor_at(mg0 + m_tile0 >= 2 ? mg0 + m_tile0 - 2 : 0, p), p, ib, nn);
         ib = ib > g0 ? ib - g0 : 0;  // index inside the buffers
-        ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
+        ib &= ~(uint64_t)(128u / FB - 1u);  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
         cursor_resolve(cursor_at(mg0 + m_tile0 + L - 1, p), p, ie, nn);
         ie = ie > g0 ? ie - g0 : 0;
         ie += 1;
-        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        uint32_t nv = (uint32_t)((ie - ib + VF) / VF);
         if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
         i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);
         nvec = __builtin_amdgcn_readfirstlane(nv);
@@ -366,21 +405,21 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     // The tile reaches past the end of the sources: lanes beyond it re-fetch the last 16-byte vector
     // (finite data no valid output reads), and the last frame's second tap is replaced by the first
     // (sample_rate.rs:193-200: the last frame is emitted verbatim).  Same for every source here.
-    const bool edge = i_base + 2u * nvec > Ns;
-    const uint32_t lastoff = ((Ns - 1) & ~1u) * 8u;
+    const bool edge = i_base + VF * nvec > Ns;
+    const uint32_t lastoff = ((Ns - 1) & ~(VF - 1u)) * FB;
     uint32_t goff[KV];
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
         uint32_t j = lane + k * 64;
         j = j < nvec ? j : nvec - 1;
-        goff[k] = (i_base + 2u * j) * 8u;
+        goff[k] = (i_base + VF * j) * FB;
         if (edge && goff[k] > lastoff) goff[k] = lastoff;
     }
     int offA[R + 2];
     float wgt[R + 2];
     {
         const uint32_t dthr = Ns - 1 - i_base;
-        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
+        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * FB);
         Cursor c = cursor_at(first ? 0 : mg0 + m0 - 2, p);
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
@@ -388,7 +427,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
             uint64_t i;
             uint32_t num;
             cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * 8u);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * FB);
             if (edge && offA[rr] >= thr) num = 0;  // verbatim last frame (and frames past it, never stored)
             if (edge && offA[rr] > thr) offA[rr] = thr;
             wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
@@ -397,10 +436,10 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
-    v2f acc[R];
+    V acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
-    v2f E1 = {0.f, 0.f}, E2 = {0.f, 0.f};  // sum over the sources of the run-end states (w[-1], w[-2])
+    for (int r = 0; r < R; ++r) acc[r] = CH::zero();
+    V E1 = CH::zero(), E2 = CH::zero();  // sum over the sources of the run-end states (w[-1], w[-2])
 
     const uint32_t S = p.batch_streams ? 1u : p.n_sources;
     typedef __attribute__((address_space(4))) const uint64_t cu64;
@@ -431,59 +470,60 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     // way from the LDS (two register sets, the loop body is written out twice so that they swap without moves).
     // Per iteration: taps(s) complete -> stage(s) is free -> DMA of source s+NS into it -> stage(s+1) landed ->
     // tap reads of s+1 issued -> arithmetic of s.
-    auto read_taps = [&](uint32_t stage_off, v2f (&qa)[R + 2], v2f (&qb)[R + 2]) {
+    auto read_taps = [&](uint32_t stage_off, V (&qa)[R + 2], V (&qb)[R + 2]) {
         const lds_u8 *buf = lds + stage_off;
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
-            qa[rr] = *(const lds_f2 *)(buf + offA[rr]);
-            qb[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
+            qa[rr] = CH::ld_lds(buf + offA[rr]);
+            qb[rr] = CH::ld_lds(buf + offA[rr] + FB);
         }
     };
-    auto compute = [&](const v2f (&ta)[R + 2], const v2f (&tb2)[R + 2], const float g) {
-        auto tap = [&](int rr) -> v2f {
-            const v2f a = ta[rr], b = tb2[rr];
-            v2f x;
-            if (FILT) {
-                x.x = fma_(b.x - a.x, wgt[rr], a.x);
-                x.y = fma_(b.y - a.y, wgt[rr], a.y);
-            } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
-                const float ax = a.x * g, ay = a.y * g, bx = b.x * g, by = b.y * g;
-                x.x = ax + div_T((bx - ax) * wgt[rr], p.Tf, p.rcpT);
-                x.y = ay + div_T((by - ay) * wgt[rr], p.Tf, p.rcpT);
+    auto compute = [&](const V (&ta)[R + 2], const V (&tb2)[R + 2], const float g) {
+        auto tap = [&](int rr) -> V {
+            const V a = ta[rr], b = tb2[rr];
+            V x;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float ac = CH::get(a, c), bc = CH::get(b, c);
+                if (FILT) {
+                    CH::set(x, c, fma_(bc - ac, wgt[rr], ac));
+                } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
+                    const float ag = ac * g, bg = bc * g;
+                    CH::set(x, c, ag + div_T((bg - ag) * wgt[rr], p.Tf, p.rcpT));
+                }
             }
             return x;
         };
         if (FILT) {
-            v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
-            v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
-            v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+            V x2 = first ? CH::zero() : tap(0);
+            V x1 = first ? CH::zero() : tap(1);
+            V w1 = CH::zero(), w2 = CH::zero();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const v2f x = tap(r + 2);
-                v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
-                w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
-                w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
-                acc[r].x = fma_(g, fma_(b0, x.x, w.x), acc[r].x);  // the source's gain rides on the mix (linear chain)
-                acc[r].y = fma_(g, fma_(b0, x.y, w.y), acc[r].y);
+                const V x = tap(r + 2);
+                V w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float wc = fma_(na1, CH::get(w1, c), fma_(na2, CH::get(w2, c), fma_(c2, CH::get(x2, c), c1 * CH::get(x1, c))));
+                    CH::set(w, c, wc);
+                    CH::set(acc[r], c, fma_(g, fma_(b0, CH::get(x, c), wc), CH::get(acc[r], c)));  // the source's gain rides on the mix (linear chain)
+                }
                 w2 = w1;
                 w1 = w;
                 x2 = x1;
                 x1 = x;
             }
-            E1.x = fma_(g, w1.x, E1.x);
-            E1.y = fma_(g, w1.y, E1.y);
-            E2.x = fma_(g, w2.x, E2.x);
-            E2.y = fma_(g, w2.y, E2.y);
+            E1 = vfma_s(g, w1, E1);
+            E2 = vfma_s(g, w2, E2);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const v2f x = tap(r + 2);
-                acc[r].x += x.x;
-                acc[r].y += x.y;
+                const V x = tap(r + 2);
+                acc[r] += x;
             }
         }
     };
-    auto iteration = [&](const uint32_t s, const v2f (&ca)[R + 2], const v2f (&cb)[R + 2], v2f (&na)[R + 2], v2f (&nb)[R + 2]) {
+    auto iteration = [&](const uint32_t s, const V (&ca)[R + 2], const V (&cb)[R + 2], V (&na)[R + 2], V (&nb)[R + 2]) {
         // the taps of source s are in registers: its stage is free for source s+NS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RH_PH(2)
@@ -502,7 +542,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         compute(ca, cb, g);
         RH_PH(4)
     };
-    v2f tA[R + 2], tB[R + 2], uA[R + 2], uB[R + 2];
+    V tA[R + 2], tB[R + 2], uA[R + 2], uB[R + 2];
     if (!RAG) {
         if (live && S) {
             const uint32_t left = S - 1;
@@ -542,7 +582,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
             }
             q[NS] = nxt;
         }
-        auto rag_iteration = [&](const v2f (&ca)[R + 2], const v2f (&cb)[R + 2], v2f (&na)[R + 2], v2f (&nb)[R + 2]) {
+        auto rag_iteration = [&](const V (&ca)[R + 2], const V (&cb)[R + 2], V (&na)[R + 2], V (&nb)[R + 2]) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the taps of q[0] are in registers: its stage is free
             if (q[NS] < S) {
                 stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)q[NS]], st_cur);
@@ -574,7 +614,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
 
     if (FILT && (live || state_tile)) {
-        if (!lane_on) E1 = E2 = v2f{0.f, 0.f};
+        if (!lane_on) E1 = E2 = CH::zero();
         const Tables *__restrict__ tb = p.tabs;
         float lM[4], b15[4], b31[4], kM[4];
 #pragma unroll
@@ -584,16 +624,17 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
             b31[q] = tb->bc31M[lane][q];
             kM[q] = tb->lookM[lane & (kMaxLook - 1)][q];
         }
-        // ---- summed run-end states in the scan basis, then the wave64 inclusive scan ----
-        float P[4] = {0.f, 0.f, 0.f, 0.f};
-        mat_acc(p.u.Tm, E1.x, E2.x, P[0], P[1]);
-        mat_acc(p.u.Tm, E1.y, E2.y, P[2], P[3]);
+        // ---- summed run-end states in the scan basis, then the wave64 inclusive scan (P[2c], P[2c+1]: channel c) ----
+        float P[2 * C];
+#pragma unroll
+        for (int q = 0; q < 2 * C; ++q) P[q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) mat_acc(p.u.Tm, CH::get(E1, c), CH::get(E2, c), P[2 * c], P[2 * c + 1]);
 #define RH_SCAN_STEP(K, N)                                                                          \
     {                                                                                               \
-        const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
-        const float q2 = dpp0<kDppRowShr + N, 0xf>(P[2]), q3 = dpp0<kDppRowShr + N, 0xf>(P[3]);     \
-        mat_acc(p.u.scanM[K], q0, q1, P[0], P[1]);                                                  \
-        mat_acc(p.u.scanM[K], q2, q3, P[2], P[3]);                                                  \
+        float sq[2 * C];                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 2 * C; ++q) sq[q] = dpp0<kDppRowShr + N, 0xf>(P[q]);   \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) mat_acc(p.u.scanM[K], sq[2 * c], sq[2 * c + 1], P[2 * c], P[2 * c + 1]); \
     }
         RH_SCAN_STEP(0, 1)
         RH_SCAN_STEP(1, 2)
@@ -601,43 +642,52 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         RH_SCAN_STEP(3, 8)
 #undef RH_SCAN_STEP
         {  // rows 1 and 3 take the inclusive prefix of the row before them
-            const float q0 = dpp0<kDppBcast15, 0xa>(P[0]), q1 = dpp0<kDppBcast15, 0xa>(P[1]);
-            const float q2 = dpp0<kDppBcast15, 0xa>(P[2]), q3 = dpp0<kDppBcast15, 0xa>(P[3]);
-            mat_acc(b15, q0, q1, P[0], P[1]);
-            mat_acc(b15, q2, q3, P[2], P[3]);
+            float sq[2 * C];
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) sq[q] = dpp0<kDppBcast15, 0xa>(P[q]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) mat_acc(b15, sq[2 * c], sq[2 * c + 1], P[2 * c], P[2 * c + 1]);
         }
         {  // rows 2 and 3 take the inclusive prefix of lanes 0..31
-            const float q0 = dpp0<kDppBcast31, 0xc>(P[0]), q1 = dpp0<kDppBcast31, 0xc>(P[1]);
-            const float q2 = dpp0<kDppBcast31, 0xc>(P[2]), q3 = dpp0<kDppBcast31, 0xc>(P[3]);
-            mat_acc(b31, q0, q1, P[0], P[1]);
-            mat_acc(b31, q2, q3, P[2], P[3]);
+            float sq[2 * C];
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) sq[q] = dpp0<kDppBcast31, 0xc>(P[q]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) mat_acc(b31, sq[2 * c], sq[2 * c + 1], P[2 * c], P[2 * c + 1]);
         }
-        {  // publish the tile aggregate (lane 63's inclusive prefix): 4 granules, one 32-byte store
-            const float e0 = readlane_f(P[0], 63), e1 = readlane_f(P[1], 63);
-            const float e2 = readlane_f(P[2], 63), e3 = readlane_f(P[3], 63);
-            if (lane < 4) {
-                const float ev = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+        {  // publish the tile aggregate (lane 63's inclusive prefix): 2C granules of the tile's 4-word slot, one store
+            float e[2 * C];
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) e[q] = readlane_f(P[q], 63);
+            if (lane < 2 * C) {
+                float ev = e[0];
+#pragma unroll
+                for (int q = 1; q < 2 * C; ++q) ev = lane == q ? e[q] : ev;
                 const unsigned long long word = ((unsigned long long)p.epoch << 32) | __float_as_uint(ev);
                 __hip_atomic_store(p.gran + ((uint64_t)stream * p.n_tiles + tile) * 4 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        float Q[4];
+        float Q[2 * C];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Q[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
+        for (int q = 0; q < 2 * C; ++q) Q[q] = dpp0<kDppWaveShr1, 0xf>(P[q]);  // exclusive: lane 0 gets 0
         // ---- the tile carry: lane j < J polls predecessor tile-1-j (they finish about now) ----
         const uint32_t Jc = p.J < tile ? p.J : tile;
-        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        float c[2 * C];
+#pragma unroll
+        for (int q = 0; q < 2 * C; ++q) c[q] = 0.f;
         if (Jc > 0) {
             const bool want = (uint32_t)lane < Jc;
             const unsigned long long *gp = p.gran + ((uint64_t)stream * p.n_tiles + (tile - 1 - (want ? lane : 0))) * 4;
-            unsigned long long gv[4] = {0, 0, 0, 0};
+            unsigned long long gv[2 * C];
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) gv[q] = 0;
             bool ok = false, dead = false;
             uint32_t spins = 0;
             while (true) {
                 if (want && !ok) {
                     bool all = true;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 2 * C; ++q) {
                         gv[q] = __hip_atomic_load(gp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         all = all && ((uint32_t)(gv[q] >> 32) == p.epoch);
                     }
@@ -653,14 +703,17 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
             }
             if (lane == 0 && spins) atomicAdd(p.status + 1, spins);  // statistics: polls that found nothing yet
             if (want && ok && !dead) {
-                mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
-                mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) mat_acc(kM, __uint_as_float((uint32_t)gv[2 * ch]), __uint_as_float((uint32_t)gv[2 * ch + 1]), c[2 * ch], c[2 * ch + 1]);
             }
             // A carry that never arrived: the status word fails the call (rh_rlm_last_status), and the tile is poisoned so
             // that a block served without that check can never pass for audio.
-            if (dead) c[0] = c[1] = c[2] = c[3] = __builtin_nanf("");
+            if (dead) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {  // sum over lanes 0..31 -> uniform
+                for (int q = 0; q < 2 * C; ++q) c[q] = __builtin_nanf("");
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) {  // sum over lanes 0..31 -> uniform
                 c[q] += dpp0<kDppRowShr + 1, 0xf>(c[q]);
                 c[q] += dpp0<kDppRowShr + 2, 0xf>(c[q]);
                 c[q] += dpp0<kDppRowShr + 4, 0xf>(c[q]);
@@ -670,23 +723,20 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         }
         if (p.st_mode && tile < p.J) {  // the stream's state at the block start still reaches this tile: + B^(L*tile) * W_in
             const float *M = tb->lookM[tile];
-            const float w0 = p.st_win[0], w1 = p.st_win[1], w2 = p.st_win[2], w3 = p.st_win[3];
-            mat_acc(M, w0, w1, c[0], c[1]);
-            mat_acc(M, w2, w3, c[2], c[3]);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(M, p.st_win[2 * ch], p.st_win[2 * ch + 1], c[2 * ch], c[2 * ch + 1]);
         }
         // the merged homogeneous response: start state = Q + B^(R*lane) * carry
-        mat_acc(lM, c[0], c[1], Q[0], Q[1]);
-        mat_acc(lM, c[2], c[3], Q[2], Q[3]);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);
         if (state_tile && (uint32_t)lane == (p.st_active % L) / R) {  // the first lane of the next block: its start state is the block's end state
-            p.st_wout[0] = Q[0];
-            p.st_wout[1] = Q[1];
-            p.st_wout[2] = Q[2];
-            p.st_wout[3] = Q[3];
+#pragma unroll
+            for (int q = 0; q < 2 * C; ++q) p.st_wout[q] = Q[q];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc[r].x = fma_(p.u.g[r][0], Q[0], fma_(p.u.g[r][1], Q[1], acc[r].x));
-            acc[r].y = fma_(p.u.g[r][0], Q[2], fma_(p.u.g[r][1], Q[3], acc[r].y));
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) CH::set(acc[r], ch, fma_(p.u.g[r][0], Q[2 * ch], fma_(p.u.g[r][1], Q[2 * ch + 1], CH::get(acc[r], ch))));
         }
     }
 #ifdef RH_PHASE_PROFILE
@@ -701,8 +751,28 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     }
 #endif
 
-    // ---- mixed output: R stereo frames per lane -----------------------------------------------------
-    float *o = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m0 * 2;
+    // ---- mixed output: R frames per lane -----------------------------------------------------
+    float *o = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m0 * C;
+    if (C == 1) {  // mono: a lane's run is R floats; 16-byte stores where the run is whole vectors inside the mix (R % 4 == 0: m0 * 4 is 16-byte aligned)
+        float *of = reinterpret_cast<float *>(o);
+        if (R % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r + 3 < R; r += 4) {
+                const uint32_t m = m0 + r;
+                if (m + 3 < Mout) *reinterpret_cast<float4 *>(of + r) = make_float4(CH::get(acc[r], 0), CH::get(acc[r + 1], 0), CH::get(acc[r + 2], 0), CH::get(acc[r + 3], 0));
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (m + k < Mout) of[r + k] = CH::get(acc[r + k], 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (m0 + r < Mout) of[r] = CH::get(acc[r], 0);
+        }
+        return;
+    }
     if (R % 2 == 0 && !RAG && FILT && p.batch_streams) {
         // Batch mode writes as many bytes as it reads.  A lane's run is R*8 contiguous bytes, so a wave's float4 store hits
         // 64 different 128-byte lines with 16 bytes each: ten partial-line writes where one full line would do.  The runs
@@ -712,7 +782,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_u8 *row = lds + (uint32_t)lane * kRow;
 #pragma unroll
-        for (int r = 0; r < R; ++r) *(lds_f2 *)(row + r * 8) = acc[r];
+        for (int r = 0; r < R; ++r) *(lds_f2 *)(row + r * 8) = v2f{CH::get(acc[r], 0), CH::get(acc[r], C - 1)};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float *ot = p.out + (uint64_t)stream * p.out_stride + (uint64_t)m_tile0 * 2;
 #pragma unroll
@@ -729,20 +799,24 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
         for (int r = 0; r + 1 < R; r += 2) {
             const uint32_t m = m0 + r;
             if (m + 1 < Mout) {
-                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(CH::get(acc[r], 0), CH::get(acc[r], C - 1), CH::get(acc[r + 1], 0), CH::get(acc[r + 1], C - 1));
             } else if (m < Mout) {
-                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(CH::get(acc[r], 0), CH::get(acc[r], C - 1));
             }
         }
     } else {  // odd R: a lane's run starts on an 8-byte boundary only
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(CH::get(acc[r], 0), CH::get(acc[r], C - 1));
     }
 }
 
-template <int R, int KV, int NS, bool FILT>
+// (C = 1: the frames are mono; the per-source aggregates keep their 4-word slots, the second channel's words travel as zeros)
+template <int R, int KV, int NS, bool FILT, int C = 2>
 __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params p) {
+    typedef Chan<C> CH;
+    typedef typename CH::V V;
+    constexpr uint32_t FB = CH::kFB, VF = CH::kVF;
     static_assert(R <= kMaxR, "frames per lane");
     static_assert(NS >= 2 && NS <= 4, "ring depth");
     static_assert(KV * (NS - 1) < 64, "vmcnt range");
@@ -775,11 +849,11 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         uint32_t nn;
         cursor_resolve(cursor_at(mg0 + m_tile0 >= 2 ? mg0 + m_tile0 - 2 : 0, p), p, ib, nn);
         ib = ib > g0 ? ib - g0 : 0;  // index inside the buffers
-        ib &= ~15ull;  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
+        ib &= ~(uint64_t)(128u / FB - 1u);  // the staged span starts on a 128-byte line: every DMA instruction covers whole lines
         cursor_resolve(cursor_at(mg0 + m_tile0 + L - 1, p), p, ie, nn);
         ie = ie > g0 ? ie - g0 : 0;
         ie += 1;
-        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        uint32_t nv = (uint32_t)((ie - ib + VF) / VF);
         if (nv > (uint32_t)(KV * 64)) nv = KV * 64;  // host sizes KV so this never bites
         i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);  // host: in_frames < 2^29
         nvec = __builtin_amdgcn_readfirstlane(nv);
@@ -792,7 +866,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     for (int k = 0; k < KV; ++k) {
         uint32_t j = lane + k * 64;
         j = j < nvec ? j : nvec - 1;
-        goff[k] = (i_base + 2u * j) * 8u;
+        goff[k] = (i_base + VF * j) * FB;
     }
 
     // ---- per-lane tap table: LDS byte offset of frame i(m) and the lerp weight ----------------
@@ -809,7 +883,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
             uint64_t i;
             uint32_t num;
             cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * 8u);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)(i - g0) - i_base) * FB);
             wgt[rr] = dummy ? 0.0f : (FILT ? (float)num / p.Tf : (float)num);
             if (!dummy) cursor_next(c, p);
         }
@@ -839,9 +913,9 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     }
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
-    v2f acc[R];
+    V acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = v2f{0.0f, 0.0f};
+    for (int r = 0; r < R; ++r) acc[r] = CH::zero();
     // The homogeneous corrections of all sources share g[] and laneM, so they are summed as STATES
     // and applied once after the last source: Qacc = sum of the lanes' zero-carry start states,
     // Cacc = this lane's share (its sets) of the summed tile carries.
@@ -853,7 +927,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     // (the block-end states are per source).
     const bool indiv_all = p.col0 != 0;
     const uint32_t m_stable = m_tile0 + (p.J + 1u) * L;
-    v2f E1s = {0.f, 0.f}, E2s = {0.f, 0.f};
+    V E1s = CH::zero(), E2s = CH::zero();
     uint64_t mrg = 0;      // bit k: source s-1-k was merged into Qacc
     uint32_t pubmask = 0;  // bit (s&7): source s of the current group has an aggregate in the pub area
     uint32_t grp_mask = 0; // merged flags (bit 7-src) of the group whose aggregates are in flight
@@ -870,11 +944,11 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
     // valid output reads, except as the second tap of the source's last frame, which
     // sample_rate.rs:193-200 emits verbatim -- the edge variant of the run selects the first tap there.
     auto stage_source = [&](const void *data, uint32_t frames, uint32_t stage_off) {
-        if (i_base + 2u * nvec <= frames) {
+        if (i_base + VF * nvec <= frames) {
 #pragma unroll
             for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
         } else {
-            const uint32_t lastoff = ((frames - 1) & ~1u) * 8u;
+            const uint32_t lastoff = ((frames - 1) & ~(VF - 1u)) * FB;
 #pragma unroll
             for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + stage_off + k * 1024);
         }
@@ -1000,13 +1074,13 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         // (3b) all lerp taps of source s leave for the LDS now, so that their latency overlaps the carry step
         const uint32_t Ms = Ms_ring[0];
         const bool active = s < S && Ms > m_tile0;  // this tile still holds frames of source s
-        v2f ta[R + 2], tb2[R + 2];
+        V ta[R + 2], tb2[R + 2];
         if (active) {
             const lds_u8 *buf = lds + st_cur;
 #pragma unroll
             for (int rr = 0; rr < R + 2; ++rr) {
-                ta[rr] = *(const lds_f2 *)(buf + offA[rr]);
-                tb2[rr] = *(const lds_f2 *)(buf + offA[rr] + 8);
+                ta[rr] = CH::ld_lds(buf + offA[rr]);
+                tb2[rr] = CH::ld_lds(buf + offA[rr] + FB);
             }
             asm volatile("" ::: "memory");  // keep the reads above the carry step
         }
@@ -1051,48 +1125,49 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
             const uint32_t Ns = Ns_ring[0];
             const float g = g_ring[0];  // Amplify factor of source s: rides on the mix and on the run-end state
             // edge: some lane needs masking, or the staged span reaches past the source (verbatim last frame)
-            const bool edge = !full || i_base + 2u * nvec > Ns;
+            const bool edge = !full || i_base + VF * nvec > Ns;
             const uint32_t dthr = Ns - 1 - i_base;  // active => i_base <= Ns-1
-            const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
-            auto tap = [&](int rr, auto edge_tag) -> v2f {
-                const v2f a = ta[rr], b = tb2[rr];
-                v2f x;
-                if (FILT) {
-                    x.x = fma_(b.x - a.x, wgt[rr], a.x);
-                    x.y = fma_(b.y - a.y, wgt[rr], a.y);
-                } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
-                    const float ax = a.x * g, ay = a.y * g, bx = b.x * g, by = b.y * g;
-                    x.x = ax + div_T((bx - ax) * wgt[rr], p.Tf, p.rcpT);
-                    x.y = ay + div_T((by - ay) * wgt[rr], p.Tf, p.rcpT);
-                }
-                if (decltype(edge_tag)::value) {  // the source's last frame is emitted verbatim
-                    const bool last = offA[rr] >= thr;
-                    x.x = last ? (FILT ? a.x : a.x * g) : x.x;
-                    x.y = last ? (FILT ? a.y : a.y * g) : x.y;
+            const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * FB);
+            auto tap = [&](int rr, auto edge_tag) -> V {
+                const V a = ta[rr], b = tb2[rr];
+                V x;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float ac = CH::get(a, c), bc = CH::get(b, c);
+                    float xc;
+                    if (FILT) {
+                        xc = fma_(bc - ac, wgt[rr], ac);
+                    } else {  // amplify.rs:64 then math.rs:25: first + (second - first) * num / den, exactly
+                        const float ag = ac * g, bg = bc * g;
+                        xc = ag + div_T((bg - ag) * wgt[rr], p.Tf, p.rcpT);
+                    }
+                    if (decltype(edge_tag)::value) {  // the source's last frame is emitted verbatim
+                        const bool last = offA[rr] >= thr;
+                        xc = last ? (FILT ? ac : ac * g) : xc;
+                    }
+                    CH::set(x, c, xc);
                 }
                 return x;
             };
             // lanes past the end of the source contribute nothing (the reference's iterator ended)
             const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
             if (FILT) {
-                v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+                V w1 = CH::zero(), w2 = CH::zero();
                 auto run = [&](auto masked) {
-                    v2f x2 = first ? v2f{0.f, 0.f} : tap(0, masked);
-                    v2f x1 = first ? v2f{0.f, 0.f} : tap(1, masked);
+                    V x2 = first ? CH::zero() : tap(0, masked);
+                    V x1 = first ? CH::zero() : tap(1, masked);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const v2f x = tap(r + 2, masked);
-                        v2f w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
-                        w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
-                        w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
-                        float yx = fma_(b0, x.x, w.x), yy = fma_(b0, x.y, w.y);
-                        if (decltype(masked)::value) {
-                            const bool v = r < nvalid;
-                            yx = v ? yx : 0.0f;
-                            yy = v ? yy : 0.0f;
+                        const V x = tap(r + 2, masked);
+                        V w;  // zero-state step of the recursive part; the w1 term goes last (shortest chain)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float wc = fma_(na1, CH::get(w1, c), fma_(na2, CH::get(w2, c), fma_(c2, CH::get(x2, c), c1 * CH::get(x1, c))));
+                            CH::set(w, c, wc);
+                            float yc = fma_(b0, CH::get(x, c), wc);
+                            if (decltype(masked)::value) yc = r < nvalid ? yc : 0.0f;
+                            CH::set(acc[r], c, fma_(g, yc, CH::get(acc[r], c)));
                         }
-                        acc[r].x = fma_(g, yx, acc[r].x);
-                        acc[r].y = fma_(g, yy, acc[r].y);
                         w2 = w1;
                         w1 = w;
                         x2 = x1;
@@ -1103,10 +1178,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 else run(std::true_type{});
                 RH_PH(4)
                 if (!indiv_all && Ms >= m_stable) {  // stable: joins the summed state, nothing else
-                    E1s.x = fma_(g, w1.x, E1s.x);
-                    E1s.y = fma_(g, w1.y, E1s.y);
-                    E2s.x = fma_(g, w2.x, E2s.x);
-                    E2s.y = fma_(g, w2.y, E2s.y);
+                    E1s = vfma_s(g, w1, E1s);
+                    E2s = vfma_s(g, w2, E2s);
                 } else {
                 {  // how many predecessor tiles saw this source as not stable (and published it on its own)
                     const uint32_t tM = Ms / L;
@@ -1116,8 +1189,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 }
                 // ---- run end state in the scan basis, then the wave64 inclusive scan ----
                 float P[4] = {0.f, 0.f, 0.f, 0.f};
-                mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
-                mat_acc(p.u.Tm, w1.y * g, w2.y * g, P[2], P[3]);
+#pragma unroll
+                for (int c = 0; c < C; ++c) mat_acc(p.u.Tm, CH::get(w1, c) * g, CH::get(w2, c) * g, P[2 * c], P[2 * c + 1]);
 #define RH_SCAN_STEP(K, N)                                                                          \
     {                                                                                               \
         const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
@@ -1175,9 +1248,11 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const bool v = r < nvalid;
-                        const float hx = fma_(p.u.g[r][0], Qnew[0], p.u.g[r][1] * Qnew[1]), hy = fma_(p.u.g[r][0], Qnew[2], p.u.g[r][1] * Qnew[3]);
-                        acc[r].x += v ? hx : 0.0f;
-                        acc[r].y += v ? hy : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float h = fma_(p.u.g[r][0], Qnew[2 * c], p.u.g[r][1] * Qnew[2 * c + 1]);
+                            CH::set(acc[r], c, CH::get(acc[r], c) + (v ? h : 0.0f));
+                        }
                     }
                 }
                 }  // individual source
@@ -1185,10 +1260,9 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
                 auto run = [&](auto masked) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        v2f x = tap(r + 2, masked);
+                        V x = tap(r + 2, masked);
                         if (decltype(masked)::value && !(r < nvalid)) continue;  // an ended source adds nothing, not even +0.0
-                        acc[r].x += x.x;
-                        acc[r].y += x.y;
+                        acc[r] += x;
                     }
                 };
                 if (!edge) run(std::false_type{});
@@ -1231,8 +1305,8 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
 
     if (FILT && !indiv_all) {  // the stable sources' summed state: one scan, one published aggregate, one look-back
         float P[4] = {0.f, 0.f, 0.f, 0.f};
-        mat_acc(p.u.Tm, E1s.x, E2s.x, P[0], P[1]);
-        mat_acc(p.u.Tm, E1s.y, E2s.y, P[2], P[3]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) mat_acc(p.u.Tm, CH::get(E1s, c), CH::get(E2s, c), P[2 * c], P[2 * c + 1]);
 #define RH_SCAN_STEP(K, N)                                                                          \
     {                                                                                               \
         const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
@@ -1289,27 +1363,44 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
         mat_acc(lM, Cacc[2], Cacc[3], Qacc[2], Qacc[3]);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc[r].x = fma_(p.u.g[r][0], Qacc[0], fma_(p.u.g[r][1], Qacc[1], acc[r].x));
-            acc[r].y = fma_(p.u.g[r][0], Qacc[2], fma_(p.u.g[r][1], Qacc[3], acc[r].y));
+#pragma unroll
+            for (int c = 0; c < C; ++c) CH::set(acc[r], c, fma_(p.u.g[r][0], Qacc[2 * c], fma_(p.u.g[r][1], Qacc[2 * c + 1], CH::get(acc[r], c))));
         }
     }
 
-    // ---- mixed output: R stereo frames per lane -----------------------------------------------------
-    float *o = p.out + (uint64_t)m0 * 2;
-    if (R % 2 == 0) {
+    // ---- mixed output: R frames per lane -----------------------------------------------------
+    float *o = p.out + (uint64_t)m0 * C;
+    if (C == 1) {
+        if (R % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r + 3 < R; r += 4) {
+                const uint32_t m = m0 + r;
+                if (m + 3 < Mout) *reinterpret_cast<float4 *>(o + r) = make_float4(CH::get(acc[r], 0), CH::get(acc[r + 1], 0), CH::get(acc[r + 2], 0), CH::get(acc[r + 3], 0));
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (m + k < Mout) o[r + k] = CH::get(acc[r + k], 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (m0 + r < Mout) o[r] = CH::get(acc[r], 0);
+        }
+    } else if (R % 2 == 0) {
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) {
             const uint32_t m = m0 + r;
             if (m + 1 < Mout) {
-                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+                *reinterpret_cast<float4 *>(o + r * 2) = make_float4(CH::get(acc[r], 0), CH::get(acc[r], C - 1), CH::get(acc[r + 1], 0), CH::get(acc[r + 1], C - 1));
             } else if (m < Mout) {
-                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+                *reinterpret_cast<float2 *>(o + r * 2) = make_float2(CH::get(acc[r], 0), CH::get(acc[r], C - 1));
             }
         }
     } else {  // odd R: a lane's run starts on an 8-byte boundary only
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(acc[r].x, acc[r].y);
+            if (m0 + r < Mout) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(CH::get(acc[r], 0), CH::get(acc[r], C - 1));
     }
 }
 
@@ -1660,14 +1751,36 @@ const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
 };
+// mono (C = 1): a frame is 4 bytes, so a stage holds twice the frames per KiB
+#define RH_FAST1(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, false, 1>, &k_rlm_fast<r, kv, ns, false, false, 1>}
+#define RH_WAVE1(r, kv, ns) Variant{r, kv, ns, &k_rlm_wave<r, kv, ns, true, 1>, &k_rlm_wave<r, kv, ns, false, 1>}
+const Variant kFast1[] = {
+    RH_FAST1(4, 2, 2),  RH_FAST1(4, 3, 2),  RH_FAST1(4, 5, 2),  RH_FAST1(6, 2, 2),  RH_FAST1(6, 4, 2),  RH_FAST1(6, 7, 2),  RH_FAST1(8, 2, 2),   RH_FAST1(8, 3, 2),
+    RH_FAST1(8, 5, 2),  RH_FAST1(8, 10, 2), RH_FAST1(9, 3, 2),  RH_FAST1(9, 5, 2),  RH_FAST1(10, 3, 2), RH_FAST1(10, 6, 2), RH_FAST1(12, 3, 2),  RH_FAST1(12, 4, 2),
+    RH_FAST1(12, 7, 2), RH_FAST1(16, 4, 2), RH_FAST1(16, 5, 2), RH_FAST1(16, 9, 2), RH_FAST1(18, 5, 2), RH_FAST1(18, 5, 3), RH_FAST1(18, 10, 2), RH_FAST1(20, 5, 2),
+    RH_FAST1(20, 6, 2), RH_FAST1(20, 11, 2),
+};
+const Variant kWave1[] = {
+    RH_WAVE1(6, 2, 2), RH_WAVE1(6, 4, 2), RH_WAVE1(6, 7, 2), RH_WAVE1(8, 2, 2),  RH_WAVE1(8, 3, 2),  RH_WAVE1(8, 5, 2),  RH_WAVE1(8, 10, 2),
+    RH_WAVE1(9, 3, 2), RH_WAVE1(9, 5, 2), RH_WAVE1(10, 3, 2), RH_WAVE1(10, 6, 2), RH_WAVE1(12, 3, 2), RH_WAVE1(12, 4, 2), RH_WAVE1(12, 7, 2),
+};
+#undef RH_FAST1
+#undef RH_WAVE1
 #undef RH_RAG
 #undef RH_FAST
 #undef RH_WAVE
+struct VariantTab {
+    const Variant *v;
+    size_t n;
+};
 template <size_t N>
-const Variant *find_variant(const Variant (&tab)[N], int R, int kv_needed, int NS) {  // smallest KV >= kv_needed
+constexpr VariantTab tab_of(const Variant (&t)[N]) { return VariantTab{t, N}; }
+const Variant *find_variant(VariantTab tab, int R, int kv_needed, int NS) {  // smallest KV >= kv_needed
     const Variant *best = nullptr;
-    for (const Variant &v : tab)
+    for (size_t i = 0; i < tab.n; ++i) {
+        const Variant &v = tab.v[i];
         if (v.R == R && v.NS == NS && v.KV >= kv_needed && (!best || v.KV < best->KV)) best = &v;
+    }
     return best;
 }
 // Single-wave workgroups with `lds` dynamic bytes the hardware co-schedules on one CU.
@@ -1681,10 +1794,11 @@ int blocks_per_cu(const void *fn, size_t lds) {
     const int by_lds = lds ? (int)(kLdsGranules / ((lds + kLdsGranule - 1) / kLdsGranule)) : n;
     return n < by_lds ? n : by_lds;
 }
-// Vectors (2 frames = 16 B) per lane a stage must hold for a tile of L output frames.
-int kv_needed(uint64_t L, uint32_t F, uint32_t T) {
-    const uint64_t span = ((L + 1) * F) / T + 5 + 14;  // i(m0+L-1) - i(m0-2) + tap + alignment to a 128-byte line
-    const uint64_t nvec = span / 2 + 2;
+// Vectors (16 B = 2 stereo or 4 mono frames) per lane a stage must hold for a tile of L output frames.
+int kv_needed(uint64_t L, uint32_t F, uint32_t T, uint32_t channels) {
+    const uint64_t fb = 4ull * channels, vf = 16 / fb;
+    const uint64_t span = ((L + 1) * F) / T + 5 + (128 / fb - 2);  // i(m0+L-1) - i(m0-2) + tap + alignment to a 128-byte line
+    const uint64_t nvec = span / vf + 2;
     return (int)((nvec + 63) / 64);
 }
 
@@ -1793,8 +1907,7 @@ size_t lds_bytes_of(const Variant &v, bool general, uint32_t J) {
 // frame + `per_source` per source one after the other; the issue interval falls with occupancy
 // (measured, tools/ubench/valu_rate.hip: 4.3 / 3.0 / 2.7 cycles per wave-instruction at 1 / 2 / 4
 // waves per SIMD).
-template <size_t N>
-rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, const rh::ResampleGeom &g, uint32_t want_R, uint32_t want_NS) {
+rh_status make_plan(rh_rlm *p, Plan &pl, VariantTab tab, bool general, const rh::ResampleGeom &g, uint32_t want_R, uint32_t want_NS) {
     const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
     M2 Tm, Ti;
     scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
@@ -1814,7 +1927,7 @@ rh_status make_plan(rh_rlm *p, Plan &pl, const Variant (&tab)[N], bool general, 
         const uint64_t per_cu = (tiles + cus - 1) / cus;
         for (int NS = 2; NS <= 4; ++NS) {
             if (want_NS && (int)want_NS != NS) continue;
-            const Variant *v = find_variant(tab, R, kv_needed(L, g.F, g.T), NS);
+            const Variant *v = find_variant(tab, R, kv_needed(L, g.F, g.T, p->cfg.channels), NS);
             if (!v) continue;
             const void *fn = reinterpret_cast<const void *>(p->filt ? v->filt : v->plain);
             const int resident = blocks_per_cu(fn, lds_bytes_of(*v, general, Jr));
@@ -1957,7 +2070,7 @@ extern "C" {
 rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     RH_REQUIRE_INIT();
     if (!out || !cfg || cfg->from_rate == 0 || cfg->to_rate == 0 || cfg->channels == 0 || cfg->max_sources == 0) return RH_ERR_INVALID;
-    if (cfg->channels != 2) return RH_ERR_UNSUPPORTED;
+    if (cfg->channels != 1 && cfg->channels != 2) return RH_ERR_UNSUPPORTED;  // mono and stereo frames inside the fused kernels; other layouts: rh_channels_convert / rh_uniform_segments in front
     // from_rate == to_rate: the converter passes through (sample_rate.rs:133-136): filter + ordered mix only
     if (cfg->max_in_frames >= (1ull << 29)) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets inside a source
     rh::ResampleGeom g;
@@ -1991,14 +2104,17 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     }
     // two plans: equal-length batches (k_rlm_fast) and ragged ones (k_rlm_wave).  The geometry
     // overrides of the config address the fast plan; the general plan follows them when it can.
-    st = make_plan(p, p->fast, kFast, false, g, cfg->frames_per_lane, cfg->ring_stages);
+    const bool mono = cfg->channels == 1;
+    const VariantTab t_fast = mono ? tab_of(kFast1) : tab_of(kFast), t_wave = mono ? tab_of(kWave1) : tab_of(kWave);
+    st = make_plan(p, p->fast, t_fast, false, g, cfg->frames_per_lane, cfg->ring_stages);
+    if (st == RH_ERR_UNSUPPORTED && mono && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->fast, t_fast, false, g, 0, 0);  // (fewer mono tile sizes are built)
     if (st == RH_OK) {
-        st = make_plan(p, p->wave, kWave, true, g, cfg->frames_per_lane, cfg->ring_stages);
-        if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->wave, kWave, true, g, 0, 0);
+        st = make_plan(p, p->wave, t_wave, true, g, cfg->frames_per_lane, cfg->ring_stages);
+        if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->wave, t_wave, true, g, 0, 0);
     } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
         st = RH_ERR_INVALID;
     }
-    if (st == RH_OK && p->filt && make_plan(p, p->pair, kRag, false, g, 0, 0) != RH_OK) p->pair.v = nullptr;  // optional
+    if (st == RH_OK && p->filt && !mono && make_plan(p, p->pair, tab_of(kRag), false, g, 0, 0) != RH_OK) p->pair.v = nullptr;  // optional (stereo only)
     hipError_t e = hipSuccess;
     if (st == RH_OK) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
@@ -2128,7 +2244,7 @@ rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *ds
 
 rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames, rh_stream stream) {
     if (!p) return RH_ERR_INVALID;
-    if (p->plan != &p->fast) return RH_ERR_UNSUPPORTED;  // equal-length sources only
+    if (p->plan != &p->fast || p->cfg.channels != 2) return RH_ERR_UNSUPPORTED;  // equal-length stereo sources only
     if (p->n_sources > 1 && (dst_stride_frames < p->out_frames || (dst_stride_frames * 2) % 4 != 0)) return RH_ERR_INVALID;
     return rlm_launch(p, 0, p->n_sources, dst, dst_stride_frames, out_frames, stream, p->n_sources, dst_stride_frames * 2);
 }
@@ -2261,9 +2377,10 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
             for (int NS = 2; NS <= 3; ++NS) {
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
-                if ((is_pair   ? make_plan(p, cand, kRag, false, g, (uint32_t)R, (uint32_t)NS)
-                     : general ? make_plan(p, cand, kWave, true, g, (uint32_t)R, (uint32_t)NS)
-                               : make_plan(p, cand, kFast, false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK)
+                const bool mono = p->cfg.channels == 1;
+                if ((is_pair   ? make_plan(p, cand, tab_of(kRag), false, g, (uint32_t)R, (uint32_t)NS)
+                     : general ? make_plan(p, cand, mono ? tab_of(kWave1) : tab_of(kWave), true, g, (uint32_t)R, (uint32_t)NS)
+                               : make_plan(p, cand, mono ? tab_of(kFast1) : tab_of(kFast), false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK)
                     continue;
                 if (is_pair && !pair_ok(p, cand)) {  // this tile size would put too many ending sources into one tile
                     p->tried.push_back(cand);

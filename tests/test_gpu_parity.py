@@ -1139,7 +1139,7 @@ def test_fused_subset_and_argument_errors(G, O):
     with pytest.raises(G.RhError):
         p.set_sources([xd[0][1:]])  # not 16-byte aligned
     p.close()
-    for bad in [dict(channels=1), dict(from_rate=96000 * 3, to_rate=44100), dict(filter="low_pass", freq=30000)]:
+    for bad in [dict(channels=3), dict(from_rate=96000 * 3, to_rate=44100), dict(filter="low_pass", freq=30000)]:
         kw = dict(from_rate=44100, to_rate=48000, channels=2, span_len=None, filter="low_pass", freq=200)
         kw.update(bad)
         with pytest.raises(G.RhError):

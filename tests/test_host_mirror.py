@@ -123,12 +123,13 @@ def test_gpu_mixer_takes_any_source_layout(O, tmp_path, filt, freq):
     ref_all = whole.collect()
     assert len(got) == len(ref_all)
     assert float(np.max(np.abs(got - ref_all))) <= (TOL if filt == 0 else 2e-7)  # the order of the f32 sum differs between the rate groups
-    if filt < 0:  # exactly: the rate groups (in order of first appearance) are summed as groups
-        eff = [48000 if 2 * rate > 9 * 48000 else rate for _, rate, _, _ in spec]  # a steep ratio (> 4.5) is converted before the fused stream
+    if filt < 0:  # exactly: the fused streams (one per rate, and one for its mono sources; in order of first appearance) are summed as groups
+        steep = [2 * rate > 9 * 48000 for _, rate, _, _ in spec]  # a steep ratio (> 4.5) is converted (to stereo, 48 kHz) before the fused stream
+        eff = [(48000, False) if steep[i] else (rate, ch == 1) for i, (ch, rate, _, _) in enumerate(spec)]
         rates = []
-        for rate in eff:
-            if rate not in rates:
-                rates.append(rate)
+        for k in eff:
+            if k not in rates:
+                rates.append(k)
         ref = np.zeros(len(ref_all), dtype=np.float32)
         for r in rates:
             m = O.Mixer(2, 48000)
@@ -217,6 +218,10 @@ CHAINS = [
 ]
 
 
+# the chains of CHAINS whose last adapter is their only filter, without it (the filter's input, for a float64 evaluation)
+CHAINS_PRE = {0: lambda O, s: s.amplify(0.8), 1: lambda O, s: s.reverb(20833333, 0.3)}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", range(len(CHAINS)))
 @pytest.mark.parametrize("block", [777, 16384])
@@ -230,9 +235,36 @@ def test_gpu_source_chain_pull_is_bit_exact(O, tmp_path, case, block):
     fmt = (tmp_path / "format.txt").read_text().split()
     assert (int(fmt[0]), int(fmt[1])) == (ref_src.channels(), ref_src.sample_rate())
     assert len(got) == len(ref), (ops, len(got), len(ref))
-    filtered = any(op.startswith(("low_pass", "high_pass")) for op in ops)
-    if ops == ["limit"] or filtered:  # log2/exp2 per sample (limit.rs:94-130): device and host libm differ in the last bit;
-        assert float(np.max(np.abs(got - ref))) <= TOL  # the filters run time-parallel (rh_biquad mode 1, <= 1e-5)
+    filtered = [op for op in ops if op.startswith(("low_pass", "high_pass"))]
+    if ops == ["limit"]:  # log2/exp2 per sample (limit.rs:94-130): device and host libm differ in the last bit
+        assert float(np.max(np.abs(got - ref))) <= TOL
+    elif filtered:
+        # The filters run time-parallel (rh_biquad mode 1).  rodio's f32 recurrence and any other evaluation order of the same
+        # filter are both ~1e-5 x peak away from the exact response for these cutoffs (a double pole at 0.96 amplifies rounding
+        # by 1 / (1 - p)^2): at full scale the two f32 results differ by that much.  The contract is therefore the one of the
+        # kernel's own tests: no further from the float64 response than the reference itself (x2 + 1e-7), and together within
+        # 1e-5 per unit of peak.
+        peak = max(1.0, float(np.max(np.abs(ref))))
+        assert float(np.max(np.abs(got - ref))) <= 2 * TOL * peak, (ops, float(np.max(np.abs(got - ref))), peak)
+        if ops[-1] == filtered[-1] and len(filtered) == 1:  # the filter closes the chain: its input is the oracle's chain without it
+            kind, freq = filtered[0].split(":")
+            pre = CHAINS_PRE[case](O, O.TestSource(x, ch, rate)).collect().astype(np.float64)
+            import rodio_amd
+
+            co = [float(v) for v in rodio_amd.biquad_coeffs(kind, int(freq), 0.5, ref_src.sample_rate())]
+            oc = ref_src.channels()
+            truth = np.zeros(len(pre))
+            for c in range(oc):  # blt.rs:558-560 in float64, channel by channel (a stream that ends inside a frame: the channels' own lengths)
+                xc = pre[c::oc]
+                yc = np.zeros(len(xc))
+                x1 = x2 = y1 = y2 = 0.0
+                for n_ in range(len(xc)):
+                    v = co[0] * xc[n_] + co[1] * x1 + co[2] * x2 - co[3] * y1 - co[4] * y2
+                    x2, x1, y2, y1 = x1, xc[n_], y1, v
+                    yc[n_] = v
+                truth[c::oc] = yc
+            e_ref, e_gpu = float(np.max(np.abs(ref - truth))), float(np.max(np.abs(got - truth)))
+            assert e_gpu <= 2.0 * e_ref + 1e-7, (ops, e_gpu, e_ref)
     else:
         assert np.array_equal(got, ref, equal_nan=True), (ops, float(np.nanmax(np.abs(got - ref))))
     if filtered:  # ... and bit for bit in the reference's operation order on request
@@ -268,11 +300,11 @@ def test_gpu_source_try_seek(O, tmp_path, block):
     after = O.TestSource(x[seek_frame * ch:], ch, rate).amplify(0.8).low_pass(200).distortion(2.0, 0.7).limit().collect()[pulled % ch:]
     ref = np.concatenate([before, after])
     assert len(got) == len(ref), (len(got), len(ref))
-    assert float(np.max(np.abs(got - ref))) <= TOL
+    assert float(np.max(np.abs(got - ref))) <= 2 * TOL  # (a time-parallel filter in the chain)
     got, ok, k = run(["amplify:0.8", "reverb:20833333:0.3", "high_pass:300"])
     assert ok == 0  # NotSupported, nothing moved: the stream is the unbroken one
     ref = O.TestSource(x, ch, rate).amplify(0.8).reverb(20833333, 0.3).high_pass(300).collect()
-    assert np.array_equal(got, ref)
+    assert len(got) == len(ref) and float(np.max(np.abs(got - ref))) <= 2 * TOL * max(1.0, float(np.max(np.abs(ref))))  # (a time-parallel filter closes the chain)
 
 
 # ------------------------------------------------------------------ sources that report spans ----
@@ -382,8 +414,8 @@ def test_gpu_source_uniform_converts_span_by_span(O, tmp_path, case, kind, block
     got = _run_env(["chain", tmp_path, ch, rate, block] + ops, tmp_path, RH_TEST_SOURCE=kind)
     ref = chain(O, _span_source(O, kind, x, ch, rate)).collect()
     assert len(got) == len(ref), (ops, kind, len(got), len(ref))
-    if any(op.startswith(("low_pass", "high_pass")) for op in ops):
-        assert float(np.max(np.abs(got - ref))) <= TOL
+    if any(op.startswith(("low_pass", "high_pass")) for op in ops):  # time-parallel filters: see test_gpu_source_chain_pull_is_bit_exact
+        assert float(np.max(np.abs(got - ref))) <= 2 * TOL * max(1.0, float(np.max(np.abs(ref))))
     else:
         assert np.array_equal(got, ref), (ops, kind, int(np.argmax(got != ref)))
 
