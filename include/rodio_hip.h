@@ -59,6 +59,8 @@ rh_status rh_malloc(void **out, size_t bytes);
 rh_status rh_free(void *p);
 rh_status rh_memset(void *p, int32_t value, size_t bytes, rh_stream stream);
 rh_status rh_memcpy_h2d(void *dst, const void *src_host, size_t bytes, rh_stream stream);
+/* `rows` rows of `width_bytes` each, `pitch_bytes` apart on both sides: a block of staged rows without the unused ends. */
+rh_status rh_memcpy_h2d_rows(void *dst, const void *src_host, size_t pitch_bytes, size_t width_bytes, size_t rows, rh_stream stream);
 rh_status rh_memcpy_d2h(void *dst_host, const void *src, size_t bytes, rh_stream stream);
 /* For a pull-model shim (include/rodio_hip.hpp): page-locked host blocks, copies that do not synchronise. */
 rh_status rh_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, rh_stream stream);
@@ -78,6 +80,8 @@ rh_status rh_event_create(void **out);
 rh_status rh_event_destroy(void *ev);
 rh_status rh_event_record(void *ev, rh_stream stream);
 rh_status rh_event_synchronize(void *ev);
+/* Work queued on `stream` after this call starts once the work recorded by `ev` has completed (no host wait). */
+rh_status rh_stream_wait_event(rh_stream stream, void *ev);
 rh_status rh_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
 
 /* ---- SampleTypeConverter ("DataConverter") ---------------------------------------------

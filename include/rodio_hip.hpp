@@ -20,16 +20,21 @@
 #define RODIO_HIP_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -147,6 +152,90 @@ private:
     void *p_ = nullptr;
     std::size_t n_ = 0;
 };
+/// A few host threads for the per-source pulls of one block.  Sources are independent objects and one thread drives one source at
+/// a time (rodio: `Source: Send`); the caller takes items too, and the first exception of an item reaches the caller.
+class Workers {
+public:
+    explicit Workers(unsigned threads) {
+        for (unsigned i = 1; i < threads; ++i) th_.emplace_back([this] { loop(); });
+    }
+    Workers(const Workers &) = delete;
+    Workers &operator=(const Workers &) = delete;
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    unsigned threads() const { return (unsigned)th_.size() + 1; }
+    /// fn(i) for i in [first, last), in any order, on any of the threads; returns when all of them have returned.
+    template <class F>
+    void run(std::size_t first, std::size_t last, F &&fn) {
+        if (th_.empty() || last - first < 2) {
+            for (std::size_t i = first; i < last; ++i) fn(i);
+            return;
+        }
+        std::function<void(std::size_t)> f = std::ref(fn);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            next_.store(first, std::memory_order_relaxed);
+            last_ = last;
+            err_ = nullptr;
+            ++gen_;
+        }
+        wake_.notify_all();
+        work(f, last);
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = nullptr;  // a thread that wakes up late finds nothing to do
+        idle_.wait(lk, [this] { return active_ == 0; });
+        if (err_) std::rethrow_exception(err_);
+    }
+
+private:
+    void work(const std::function<void(std::size_t)> &f, std::size_t last) {
+        for (;;) {
+            const std::size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= last) return;
+            try {
+                f(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!err_) err_ = std::current_exception();
+                next_.store(last, std::memory_order_relaxed);  // the other items are not started
+            }
+        }
+    }
+    void loop() {
+        std::uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            wake_.wait(lk, [&] { return quit_ || gen_ != seen; });
+            if (quit_) return;
+            seen = gen_;
+            if (!job_) continue;
+            const std::function<void(std::size_t)> *f = job_;
+            const std::size_t last = last_;
+            ++active_;
+            lk.unlock();
+            work(*f, last);
+            lk.lock();
+            if (--active_ == 0) idle_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable wake_, idle_;
+    const std::function<void(std::size_t)> *job_ = nullptr;
+    std::atomic<std::size_t> next_{0};
+    std::size_t last_ = 0;
+    std::uint64_t gen_ = 0;
+    unsigned active_ = 0;
+    bool quit_ = false;
+    std::exception_ptr err_;
+};
 class PinnedBuf {
 public:
     PinnedBuf() = default;
@@ -168,6 +257,19 @@ public:
 private:
     void *p_ = nullptr;
     std::size_t n_ = 0;
+};
+class Event {
+public:
+    Event() { check(rh_event_create(&e_), "rh_event_create"); }
+    Event(const Event &) = delete;
+    Event &operator=(const Event &) = delete;
+    ~Event() {
+        if (e_) (void)rh_event_destroy(e_);
+    }
+    void *get() const { return e_; }
+
+private:
+    void *e_ = nullptr;
 };
 
 /// One run of samples pulled from a source inside ONE span of it.
@@ -381,7 +483,16 @@ public:
         return k;
     }
 
+    /// Where the host's time went: submitting blocks, preparing the next one ahead of the wait, pulling the upstreams (`pull_s`: a
+    /// part of the other two), waiting for the device.
+    struct Timing {
+        double submit_s = 0, prefetch_s = 0, pull_s = 0, wait_s = 0;
+        std::uint64_t blocks = 0;
+    };
+    const Timing &timing() const { return timing_; }
+
 protected:
+    Timing timing_;
     struct Slot {
         PinnedBuf in, out;  // staging of the pulled samples / the processed block
         std::size_t n = 0;  // samples in `out`
@@ -390,6 +501,9 @@ protected:
     };
     /// Fills `s` (n, last) and enqueues everything that produces s.out on stream_.
     virtual void enqueue(Slot &s) = 0;
+    /// The host-only part of the next enqueue() (pulling the upstreams into a staging block), called while the device still works
+    /// on the block about to be served: what it prepares, the next enqueue() finds done.  Optional.
+    virtual void prefetch() {}
     /// A source that returned None may yield samples again (rodio's MixerSource after a later Mixer::add).
     virtual bool can_resume() const { return false; }
     /// Called when a block's work has completed, before it is served: a place to surface device-side failures.
@@ -406,8 +520,11 @@ protected:
     bool other_in_flight() const { return primed_ && !ended_ && !slot_[cur_].last; }
     std::size_t position() const { return pos_; }
     void submit(Slot &s) {
+        const auto t0 = std::chrono::steady_clock::now();
         enqueue(s);
         check(rh_event_record(s.done, stream_), "rh_event_record");
+        timing_.submit_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++timing_.blocks;
     }
     /// Forget everything that was pulled and processed ahead (after a seek of the upstream): the next next() starts over.
     /// `keep_phase` = the source's channel count: the stream that follows resumes at the channel the consumer is at (the first
@@ -441,8 +558,15 @@ private:
                 return false;
             }
             cur_ ^= 1;  // the block that was enqueued while the previous one was being served
+            if (!cur().last) {
+                const auto t0 = std::chrono::steady_clock::now();
+                prefetch();
+                timing_.prefetch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
         }
+        const auto t0 = std::chrono::steady_clock::now();
         check(rh_event_synchronize(cur().done), "rh_event_synchronize");
+        timing_.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         block_done();
         pos_ = std::min(skip_, cur().n);
         skip_ = 0;
@@ -882,16 +1006,21 @@ public:
         std::uint32_t filter_freq = 0;
         float filter_q = 0.5f;
         std::uint32_t frames_per_lane = 0;    // 0 = the library's choice
+        unsigned host_threads = 0;            // threads that pull the sources of a block (0 = min(cores, 16); 1 = the caller alone)
     };
     GpuMixer(std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt) {
         if (!sample_rate) throw std::invalid_argument("sample_rate is NonZero in rodio");
         if (!opt_.block_frames) opt_.block_frames = 1;
+        check(rh_stream_create(&copy_stream_), "rh_stream_create");
     }
     explicit GpuMixer(std::uint32_t sample_rate) : GpuMixer(sample_rate, Options()) {}
     ~GpuMixer() override {
+        (void)rh_stream_synchronize(copy_stream_);
         (void)rh_stream_synchronize(stream_);
         for (auto &g : gens_)
             if (g->plan) (void)rh_rlm_destroy(g->plan);
+        gens_.clear();
+        (void)rh_stream_destroy(copy_stream_);
     }
     /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: mono sources form fused streams of their own (the kernel
     /// reads mono frames, the mono mix becomes stereo once per block); a channel count above 2 is staged in the source's own
@@ -1025,13 +1154,24 @@ private:
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
         rh_rlm *plan = nullptr;
-        detail::DeviceBuf din, q[2];  // staged input rows; mixed output not yet served (ping-pong)
+        detail::DeviceBuf din[2], q[2];  // staged input rows (one set per staging block); mixed output not yet served (ping-pong)
+        detail::Event copied[2];         // ... recorded on the copy stream behind the copies that fill din[i]
         detail::PinnedBuf stage[2];   // one staging block per slot in flight
         detail::PinnedBuf side[2];    // ... and one for the sources that are not stereo, in their own layout
-        detail::DeviceBuf dside;
+        detail::DeviceBuf dside[2];
         int cur = 0, slot = 0;
         std::uint64_t head = 0, fill = 0;  // q[cur] holds `fill` frames from frame `head` on (head in {0,1}: the END stays 16-byte aligned)
         bool done = false;                 // the stream emitted its last frame
+        // the host half of a block that has been pulled and not yet issued (pull_block / issue_block)
+        bool pulled = false;
+        int pslot = 0;
+        std::vector<const float *> pptrs;
+        std::vector<std::uint64_t> pavail;
+        std::vector<std::uint8_t> pended;
+        std::vector<std::size_t> pside_off;
+        std::size_t pside = 0, ptotal = 0;
+        std::vector<rh_uniform_seg> ptable;
+        std::uint64_t pmax_out = 0;
         bool mono = false;                 // a fused stream of mono sources (rh_rlm_config.channels = 1): mono rows in, a mono mix out ...
         detail::DeviceBuf qm;              // ... which ChannelCountConverter(1 -> 2) (channels.rs:64-73) turns into the stereo queue, once per block
         // span-by-span generations (`staged`): the sources are converted to the mixer's format first, row by row
@@ -1139,16 +1279,44 @@ private:
         check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
         b.swap(n);
     }
-    /// One block of a span-by-span generation.  Every source is topped up to `target` converted frames: it is pulled piece by
-    /// piece (a piece never crosses a span; its length is budgeted so that its output fits the row whatever the span does), the
-    /// pieces are planned into segments, ONE copy brings all rows to the device, ONE launch converts all segments of all sources
-    /// (plus the frames the last block left over, moved to the front of the other row set), and the fused kernel -- its converter
-    /// passing through -- filters and mixes the rows.
-    void run_block_staged(Gen &g) {
-        const std::size_t S = g.srcs.size();
-        detail::PinnedBuf &stage = g.stage[g.slot];
-        detail::PinnedBuf &tabh = g.tab[g.slot];
+    /// One block of a generation = its host half (pull_block: the upstreams are pulled into a page-locked staging block, by a few
+    /// threads) and its device half (issue_block: copies and launches on stream_).  BlockPump runs the host half of the next
+    /// block while the device still works on the block about to be served (prefetch()).
+    void run_block(Gen &g, Slot &) {
+        if (!g.pulled) pull_block(g);
+        issue_block(g);
+    }
+    void prefetch() override {
+        if (!pending_.empty()) return;  // a new generation starts with the next block: enqueue() does it all
+        for (auto &gp : gens_)
+            if (!gp->done && gp->fill < out_cap_frames_ && !gp->pulled) pull_block(*gp);
+    }
+    void pull_block(Gen &g) {
+        g.pslot = g.slot;
         g.slot ^= 1;
+        if (g.staged) pull_block_staged(g);
+        else pull_block_direct(g);
+        g.pulled = true;
+    }
+    void issue_block(Gen &g) {
+        g.pulled = false;
+        if (g.staged) issue_block_staged(g);
+        else issue_block_direct(g);
+    }
+    template <class F>
+    void pull_sources(std::size_t frames, std::size_t n, F &&fn) {
+        const auto t0 = std::chrono::steady_clock::now();
+        pullers(frames).run(0, n, fn);
+        timing_.pull_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    /// A span-by-span generation.  Every source is topped up to `target` converted frames: it is pulled piece by piece (a piece
+    /// never crosses a span; its length is budgeted so that its output fits the row whatever the span does), the pieces are
+    /// planned into segments; then ONE copy brings all rows to the device, ONE launch converts all segments of all sources (plus
+    /// the frames the last block left over, moved to the front of the other row set), and the fused kernel -- its converter
+    /// passing through -- filters and mixes the rows.
+    void pull_block_staged(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        detail::PinnedBuf &stage = g.stage[g.pslot];
         const std::size_t crowf = ((std::size_t)g.crow * 2 + 3) & ~std::size_t(3);
         // 1. layout of the staging block: a row per live source, sized for what it is about to pull in its current format
         std::vector<std::size_t> row_off(S, 0), row_cap(S, 0);
@@ -1166,9 +1334,12 @@ private:
             total += (row_cap[i] + 3) & ~std::size_t(3);
         }
         stage.reset(total ? total : 4);
-        g.din.reset(total ? total : 4);
-        std::vector<rh_uniform_seg> table;
-        std::uint64_t max_out = 0;
+        detail::DeviceBuf &din = g.din[g.pslot];
+        din.reset(total ? total : 4);
+        g.ptotal = total;
+        std::vector<rh_uniform_seg> &table = g.ptable;
+        table.clear();
+        g.pmax_out = 0;
         const int oc = g.ccur, nc = g.ccur ^ 1;
         for (std::size_t i = 0; i < S; ++i) {  // what the last block left over: to the front of the other row set
             Src &x = g.srcs[i];
@@ -1183,18 +1354,18 @@ private:
             sg.from_ch = sg.to_ch = 2;
             sg.gain = 1.0f;
             table.push_back(sg);
-            max_out = std::max(max_out, x.have);
+            g.pmax_out = std::max(g.pmax_out, x.have);
         }
-        // 2. pull and plan
-        std::vector<detail::UniformPlanner::Seg> segs;
-        for (std::size_t i = 0; i < S; ++i) {
+        // 2. pull and plan (one source per thread at a time; the segments join the table in source order)
+        std::vector<std::vector<rh_uniform_seg>> planned(S);
+        pull_sources(total / 2, S, [&](std::size_t i) {
             Src &x = g.srcs[i];
-            if (x.ended) continue;
+            if (x.ended) return;
             float *row = stage.get() + row_off[i];
             x.plan.begin_block();
             std::size_t fill = x.plan.held_samples();
             if (fill) std::memcpy(row, x.held.data(), fill * sizeof(float));
-            segs.clear();
+            std::vector<detail::UniformPlanner::Seg> segs;
             for (;;) {
                 std::uint16_t ch = 0;
                 std::uint32_t rate = 0;
@@ -1224,24 +1395,38 @@ private:
             x.held.assign(row + x.plan.keep_offset(), row + x.plan.keep_offset() + x.plan.keep_samples());
             for (const detail::UniformPlanner::Seg &sg : segs) {
                 rh_uniform_seg t = sg.g;
-                t.src = g.din.get() + row_off[i] + sg.src_off;
+                t.src = din.get() + row_off[i] + sg.src_off;
                 t.dst = g.conv[nc].get() + i * crowf + (x.have + sg.dst_off) * 2;
                 t.gain = x.gain;
-                table.push_back(t);
-                max_out = std::max<std::uint64_t>(max_out, t.m1 - t.m0);
+                planned[i].push_back(t);
             }
             x.have += x.plan.out_frames();
             if (x.have > g.crow) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
-        }
-        // 3. one copy, one conversion launch
-        if (total) check(rh_memcpy_h2d(g.din.get(), stage.get(), total * sizeof(float), stream_), "rh_memcpy_h2d");
+        });
+        for (std::size_t i = 0; i < S; ++i)
+            for (const rh_uniform_seg &t : planned[i]) {
+                table.push_back(t);
+                g.pmax_out = std::max<std::uint64_t>(g.pmax_out, t.m1 - t.m0);
+            }
+        // 3. one copy for all rows, on the copy stream: it runs beside the launches of the block before
+        if (total) check(rh_memcpy_h2d(din.get(), stage.get(), total * sizeof(float), copy_stream_), "rh_memcpy_h2d");
+        check(rh_event_record(g.copied[g.pslot].get(), copy_stream_), "rh_event_record");
+    }
+    void issue_block_staged(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        detail::PinnedBuf &tabh = g.tab[g.pslot];
+        const std::size_t crowf = ((std::size_t)g.crow * 2 + 3) & ~std::size_t(3);
+        const std::vector<rh_uniform_seg> &table = g.ptable;
+        const int nc = g.ccur ^ 1;
+        // ... one conversion launch behind it
+        check(rh_stream_wait_event(stream_, g.copied[g.pslot].get()), "rh_stream_wait_event");
         if (!table.empty()) {
             const std::size_t tf = table.size() * sizeof(rh_uniform_seg) / sizeof(float);
             tabh.reset(tf);
             g.dtab.reset(tf);
             std::memcpy(tabh.get(), table.data(), tf * sizeof(float));
             check(rh_memcpy_h2d(g.dtab.get(), tabh.get(), tf * sizeof(float), stream_), "rh_memcpy_h2d");
-            check(rh_uniform_segments_dev(reinterpret_cast<const rh_uniform_seg *>(g.dtab.get()), (std::uint32_t)table.size(), max_out, stream_), "rh_uniform_segments_dev");
+            check(rh_uniform_segments_dev(reinterpret_cast<const rh_uniform_seg *>(g.dtab.get()), (std::uint32_t)table.size(), g.pmax_out, stream_), "rh_uniform_segments_dev");
         }
         g.ccur = nc;
         // 4. filter + ordered sum of the converted rows
@@ -1268,36 +1453,35 @@ private:
         }
         g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }
-    void run_block(Gen &g, Slot &) {
-        if (g.staged) return run_block_staged(g);
+    /// A generation of one format.  Row i of the page-locked block = [frames the previous block left unconsumed | one freshly
+    /// pulled block]; a source that is not in the layout the fused launch reads has its row in the side block, in its own layout.
+    std::size_t row_floats(const Gen &g) const { return g.mono ? ((cap_frames_ + 3) & ~std::size_t(3)) : row_; }
+    void pull_block_direct(Gen &g) {
         const std::size_t S = g.srcs.size();
-        detail::PinnedBuf &stage = g.stage[g.slot];
-        g.slot ^= 1;
-        const std::size_t native = g.mono ? 1 : 2;                                              // channels of the rows the fused launch reads
-        const std::size_t row_ = g.mono ? ((cap_frames_ + 3) & ~std::size_t(3)) : this->row_;   // floats per row
+        detail::PinnedBuf &stage = g.stage[g.pslot], &side = g.side[g.pslot];
+        const std::size_t native = g.mono ? 1 : 2;  // channels of the rows the fused launch reads
+        const std::size_t row_ = row_floats(g);
         stage.reset(S * row_);
-        g.din.reset(S * row_);
-        std::vector<const float *> ptrs(S);
-        std::vector<std::uint64_t> avail(S);
-        std::vector<std::uint8_t> ended(S);
-        // row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled block]; a source that
-        // is not stereo has its row in the side block instead, in its own layout
-        std::vector<std::size_t> side_off(S, 0);
-        std::size_t side_floats = 0;
+        detail::DeviceBuf &din = g.din[g.pslot], &dside = g.dside[g.pslot];
+        din.reset(S * row_);
+        g.pptrs.assign(S, nullptr);
+        g.pavail.assign(S, 0);
+        g.pended.assign(S, 0);
+        g.pside_off.assign(S, 0);
+        g.pside = 0;
         for (std::size_t i = 0; i < S; ++i)
             if (g.srcs[i].ch != native) {
-                side_off[i] = side_floats;
-                side_floats += (cap_frames_ * g.srcs[i].ch + 3) & ~std::size_t(3);
+                g.pside_off[i] = g.pside;
+                g.pside += (cap_frames_ * g.srcs[i].ch + 3) & ~std::size_t(3);
             }
-        detail::PinnedBuf &side = g.side[g.slot ^ 1];  // (g.slot was flipped above: the same parity as `stage`)
-        if (side_floats) {
-            side.reset(side_floats);
-            g.dside.reset(side_floats);
+        if (g.pside) {
+            side.reset(g.pside);
+            dside.reset(g.pside);
         }
-        for (std::size_t i = 0; i < S; ++i) {
+        pull_sources(S * opt_.block_frames, S, [&](std::size_t i) {
             Src &x = g.srcs[i];
             const std::size_t ch = x.ch;
-            float *row = ch == native ? stage.get() + i * row_ : side.get() + side_off[i];
+            float *row = ch == native ? stage.get() + i * row_ : side.get() + g.pside_off[i];
             std::size_t have = x.held.size();
             if (have / ch + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
             if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
@@ -1308,27 +1492,38 @@ private:
                 have += got;
                 x.ended = got < want;
             }
-            ptrs[i] = g.din.get() + i * row_;
-            avail[i] = have / ch;
-            ended[i] = x.ended ? 1 : 0;
-        }
-        // one copy for all rows (the gaps between them travel too: rows are short of cap_frames_ only at the end)
-        check(rh_memcpy_h2d(g.din.get(), stage.get(), S * row_ * sizeof(float), stream_), "rh_memcpy_h2d");
-        if (side_floats) {  // ChannelCountConverter on the device (channels.rs:57-85), into the stereo rows the fused launch reads
-            check(rh_memcpy_h2d(g.dside.get(), side.get(), side_floats * sizeof(float), stream_), "rh_memcpy_h2d");
+            g.pptrs[i] = din.get() + i * row_;
+            g.pavail[i] = have / ch;
+            g.pended[i] = x.ended ? 1 : 0;
+        });
+        // one copy for all rows -- what the longest row holds of every row: the rows differ by a few frames, the unused ends stay --
+        // on the copy stream: it runs beside the launches of the block before
+        std::size_t width = 0;
+        for (std::size_t i = 0; i < S; ++i)
+            if (g.srcs[i].ch == native) width = std::max<std::size_t>(width, (std::size_t)g.pavail[i] * native);
+        if (width) check(rh_memcpy_h2d_rows(din.get(), stage.get(), row_ * sizeof(float), width * sizeof(float), S, copy_stream_), "rh_memcpy_h2d_rows");
+        if (g.pside) check(rh_memcpy_h2d(dside.get(), side.get(), g.pside * sizeof(float), copy_stream_), "rh_memcpy_h2d");
+        check(rh_event_record(g.copied[g.pslot].get(), copy_stream_), "rh_event_record");
+    }
+    void issue_block_direct(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        detail::PinnedBuf &stage = g.stage[g.pslot], &side = g.side[g.pslot];
+        const std::size_t native = g.mono ? 1 : 2;
+        const std::size_t row_ = row_floats(g);
+        check(rh_stream_wait_event(stream_, g.copied[g.pslot].get()), "rh_stream_wait_event");
+        if (g.pside)  // ChannelCountConverter on the device (channels.rs:57-85), into the rows the fused launch reads
             for (std::size_t i = 0; i < S; ++i)
-                if (g.srcs[i].ch != native && avail[i])
-                    check(rh_channels_convert(g.din.get() + i * row_, g.dside.get() + side_off[i], (std::size_t)avail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
-        }
+                if (g.srcs[i].ch != native && g.pavail[i])
+                    check(rh_channels_convert(g.din[g.pslot].get() + i * row_, g.dside[g.pslot].get() + g.pside_off[i], (std::size_t)g.pavail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
         std::uint64_t out = 0, consumed = 0;
         if (debug_poison()) check(rh_memset(g.queue_end(), 0xff, (out_cap_frames_ * 2 - g.fill - g.head) * 2 * sizeof(float), stream_), "rh_memset");
         if (g.mono) {  // the mono mix of the block, then ChannelCountConverter(1 -> 2) behind the stereo queue (one pass over the MIX, not per source)
             g.qm.reset(out_cap_frames_ * 2);
-            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.qm.get(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+            check(rh_rlm_stream_block_v(g.plan, g.pptrs.data(), g.pavail.data(), g.pended.data(), (std::uint32_t)S, g.qm.get(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
                   "rh_rlm_stream_block_v");
             if (out) check(rh_channels_convert(g.queue_end(), g.qm.get(), (std::size_t)out, 1, 2, stream_), "rh_channels_convert");
         } else {
-            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+            check(rh_rlm_stream_block_v(g.plan, g.pptrs.data(), g.pavail.data(), g.pended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
                   "rh_rlm_stream_block_v");
         }
         g.fill += out;
@@ -1336,8 +1531,8 @@ private:
         for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
             Src &x = g.srcs[i];
             const std::size_t ch = x.ch;
-            const float *row = ch == native ? stage.get() + i * row_ : side.get() + side_off[i];
-            const std::size_t have = (std::size_t)avail[i] * ch, drop = std::min<std::size_t>((std::size_t)consumed * ch, have);
+            const float *row = ch == native ? stage.get() + i * row_ : side.get() + g.pside_off[i];
+            const std::size_t have = (std::size_t)g.pavail[i] * ch, drop = std::min<std::size_t>((std::size_t)consumed * ch, have);
             x.held.assign(row + drop, row + have);
             all_ended = all_ended && x.ended;
         }
@@ -1408,6 +1603,15 @@ private:
     Options opt_;
     std::vector<Src> pending_;
     std::vector<std::unique_ptr<Gen>> gens_;
+    // the threads that pull a block's sources: made at the first block that is worth them
+    detail::Workers &pullers(std::size_t frames) {
+        if (opt_.host_threads == 1 || frames < (std::size_t(1) << 18)) return solo_;
+        if (!pool_) pool_.reset(new detail::Workers(opt_.host_threads ? opt_.host_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+        return *pool_;
+    }
+    detail::Workers solo_{1};
+    rh_stream copy_stream_ = nullptr;  // host-to-device copies of the staged rows: the link stays busy while stream_ runs the block before
+    std::unique_ptr<detail::Workers> pool_;
     std::size_t cap_frames_ = 0, row_ = 0;
     std::uint64_t out_cap_frames_ = 0, scheduled_ = 0, last_join_ = 0;
     detail::DeviceBuf dmix_, dkeep_[2];                       // scratch of rh_mix_sum; device copies of the two scheduled blocks

@@ -72,12 +72,14 @@ SIGNATURES = {
     "rh_free": (i32, [vp]),
     "rh_memset": (i32, [vp, i32, sz, vp]),
     "rh_memcpy_h2d": (i32, [vp, vp, sz, vp]),
+    "rh_memcpy_h2d_rows": (i32, [vp, vp, sz, sz, sz, vp]),
     "rh_memcpy_d2h": (i32, [vp, vp, sz, vp]),
     "rh_memcpy_d2h_async": (i32, [vp, vp, C.c_size_t, vp]),
     "rh_memcpy_d2d": (i32, [vp, vp, C.c_size_t, vp]),
     "rh_host_alloc": (i32, [C.POINTER(vp), C.c_size_t]),
     "rh_host_free": (i32, [vp]),
     "rh_event_synchronize": (i32, [vp]),
+    "rh_stream_wait_event": (i32, [vp, vp]),
     "rh_stream_create": (i32, [C.POINTER(vp)]),
     "rh_stream_destroy": (i32, [vp]),
     "rh_stream_synchronize": (i32, [vp]),

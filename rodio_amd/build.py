@@ -74,7 +74,7 @@ def build_host_mirror_test(force: bool, run) -> str:
     exe = os.path.join(root, "tests", "cpp", "host_mirror_test")
     deps = [src, os.path.join(root, "include", "rodio_hip.hpp"), os.path.join(root, "include", "rodio_hip.h"), LIB]
     if force or _stale(exe, deps):
-        run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lrodio_hip",
+        run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lrodio_hip",
              "-Wl,-rpath,$ORIGIN/../../rodio_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
     return exe
 

@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what);
 // process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
 enum Knob {
     K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
-    K_LIMIT_SKEW, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_COUNT
+    K_LIMIT_SKEW, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_COUNT
 };
 const char *knob(Knob k);
 void load_knobs();
@@ -74,6 +74,8 @@ hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s);
 // The caller keeps `hold` (taken here) until its last launch that uses the buffer is enqueued: two host threads that launch on
 // the same stream then cannot interleave their initialisation and kernel launches.
 hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold);
+// device-to-device copy as a launch on `hs` (hipMemcpyAsync DeviceToDevice makes the calling thread wait for the queue ahead of it)
+hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
 
 // Grid for a memory-bound grid-stride kernel: enough 256-thread blocks to fill 256 CUs x 8,
 // capped so small inputs stay small (cdna_hip_programming.md G11).

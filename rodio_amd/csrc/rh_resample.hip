@@ -222,7 +222,7 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
     if (!dst || !src) return RH_ERR_INVALID;
     hipStream_t s = rh::as_stream(stream);
     if (g.F == g.T) {  // sample_rate.rs:133-136 passthrough
-        RH_HIP_TRY(hipMemcpyAsync(dst, src, in_frames * channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+        RH_HIP_TRY(rh::copy_d2d(dst, src, in_frames * channels * sizeof(float), s));
         return RH_OK;
     }
     const unsigned grid = rh::grid_for(g.out_frames);

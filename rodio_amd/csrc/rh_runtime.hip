@@ -1,4 +1,5 @@
 // rh_runtime.hip -- device bring-up, memory/stream/event helpers of the C ABI.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -20,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what) {
 namespace {
 const char *const kKnobNames[K_COUNT] = {"RH_AGC_SEQ", "RH_AGC_VEC", "RH_BIQUAD_NO_FALLBACK", "RH_BIQUAD_SEQ", "RH_BIQUAD_R", "RH_BIQUAD_NW", "RH_BIQUAD_WGS", "RH_LIMIT_SEQ",
                                          "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
-                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP"};
+                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC"};
 std::string g_knob_val[K_COUNT];
 bool g_knob_set[K_COUNT];
 }  // namespace
@@ -86,6 +87,32 @@ hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
     const uint32_t b = (uint32_t)value & 0xffu;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(bytes / 16 + 1)), dim3(256), 0, s, static_cast<unsigned char *>(p), b * 0x01010101u, bytes);
+    return hipGetLastError();
+}
+}  // namespace rh
+
+namespace {
+// A device copy as a kernel: hipMemcpyAsync(DeviceToDevice) makes the calling thread wait for the work queued before it
+// (measured: the shim's submit path spent 2.7 ms per block there), a launch does not.  W = the widest word both pointers and the
+// length are aligned to.
+template <typename W>
+__global__ void k_copy(W *__restrict__ dst, const W *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+template <typename W>
+void launch_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / sizeof(W);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)rh::g_num_cus * 16);
+    hipLaunchKernelGGL(k_copy<W>, dim3(blocks ? blocks : 1), dim3(256), 0, s, static_cast<W *>(dst), static_cast<const W *>(src), n);
+}
+}  // namespace
+namespace rh {
+hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs) {
+    if (!bytes) return hipSuccess;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | (uintptr_t)bytes;
+    if ((a & 15u) == 0) launch_copy<uint4>(dst, src, bytes, hs);
+    else if ((a & 3u) == 0) launch_copy<uint32_t>(dst, src, bytes, hs);
+    else launch_copy<unsigned char>(dst, src, bytes, hs);
     return hipGetLastError();
 }
 }  // namespace rh
@@ -180,6 +207,13 @@ rh_status rh_memcpy_h2d(void *dst, const void *src_host, size_t bytes, rh_stream
     RH_HIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, rh::as_stream(stream)));
     return RH_OK;
 }
+rh_status rh_memcpy_h2d_rows(void *dst, const void *src_host, size_t pitch_bytes, size_t width_bytes, size_t rows, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!rows || !width_bytes) return RH_OK;
+    if (!dst || !src_host || width_bytes > pitch_bytes) return RH_ERR_INVALID;
+    RH_HIP_TRY(hipMemcpy2DAsync(dst, pitch_bytes, src_host, pitch_bytes, width_bytes, rows, hipMemcpyHostToDevice, rh::as_stream(stream)));
+    return RH_OK;
+}
 rh_status rh_memcpy_d2h(void *dst_host, const void *src, size_t bytes, rh_stream stream) {
     RH_REQUIRE_INIT();
     RH_HIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, rh::as_stream(stream)));
@@ -193,13 +227,17 @@ rh_status rh_memcpy_d2h_async(void *dst_host, const void *src, size_t bytes, rh_
 }
 rh_status rh_memcpy_d2d(void *dst, const void *src, size_t bytes, rh_stream stream) {
     RH_REQUIRE_INIT();
-    RH_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rh::as_stream(stream)));
+    if (!bytes) return RH_OK;
+    if (!dst || !src) return RH_ERR_INVALID;
+    RH_HIP_TRY(rh::copy_d2d(dst, src, bytes, rh::as_stream(stream)));
     return RH_OK;
 }
 rh_status rh_host_alloc(void **out, size_t bytes) {
     RH_REQUIRE_INIT();
     if (!out) return RH_ERR_INVALID;
-    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    unsigned flags = hipHostMallocDefault;
+    if (const char *k = rh::knob(rh::K_HOST_ALLOC)) flags = (unsigned)std::strtoul(k, nullptr, 0);
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, flags);
     if (e == hipErrorOutOfMemory) return RH_ERR_NOMEM;
     RH_HIP_TRY(e);
     return RH_OK;
@@ -249,6 +287,12 @@ rh_status rh_event_destroy(void *ev) {
 rh_status rh_event_record(void *ev, rh_stream stream) {
     RH_REQUIRE_INIT();
     RH_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), rh::as_stream(stream)));
+    return RH_OK;
+}
+rh_status rh_stream_wait_event(rh_stream stream, void *ev) {
+    RH_REQUIRE_INIT();
+    if (!ev) return RH_ERR_INVALID;
+    RH_HIP_TRY(hipStreamWaitEvent(rh::as_stream(stream), reinterpret_cast<hipEvent_t>(ev), 0));
     return RH_OK;
 }
 rh_status rh_event_synchronize(void *ev) {

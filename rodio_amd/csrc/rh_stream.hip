@@ -146,7 +146,7 @@ rh_status rh_resampler_process(rh_resampler *p, float *dst, uint64_t dst_capacit
     if (m1 > m0) {
         if (!dst) return RH_ERR_INVALID;
         if (p->F == p->T) {  // sample_rate.rs:133-136 passthrough
-            RH_HIP_TRY(hipMemcpyAsync(dst, src, in_frames * p->channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+            RH_HIP_TRY(rh::copy_d2d(dst, src, in_frames * p->channels * sizeof(float), s));
         } else {
             const uint64_t verbatim_from = flush ? total - 1 : ~0ull;
             const unsigned grid = rh::grid_for(m1 - m0);
@@ -157,7 +157,7 @@ rh_status rh_resampler_process(rh_resampler *p, float *dst, uint64_t dst_capacit
         }
     }
     if (in_frames)  // the next block's frame n0-1 (enqueued behind the kernel that still reads the old one)
-        RH_HIP_TRY(hipMemcpyAsync(p->d_carry, src + (in_frames - 1) * p->channels, sizeof(float) * p->channels, hipMemcpyDeviceToDevice, s));
+        RH_HIP_TRY(rh::copy_d2d(p->d_carry, src + (in_frames - 1) * p->channels, sizeof(float) * p->channels, s));
     p->total_in = total;
     p->total_out = m1;
     p->finished = flush != 0;

@@ -85,7 +85,7 @@ rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uin
     rh_status st = RH_OK;
     if (is_float) {
         if (bits_per_sample != 32) return RH_ERR_UNSUPPORTED;  // wav.rs:107-117
-        RH_HIP_TRY(hipMemcpyAsync(dst, data, n_samples * 4, hipMemcpyDeviceToDevice, s));
+        RH_HIP_TRY(rh::copy_d2d(dst, data, n_samples * 4, s));
     } else if (bits_per_sample == 8) {
         st = rh_convert_u8_to_f32(dst, data, n_samples, stream);  // the file holds unsigned bytes; hound hands rodio i8 = b - 128
     } else if (bits_per_sample == 16) {

@@ -11,11 +11,12 @@
 //   host_mirror_test late <dir> <S0> <S1> <from_rate> <to_rate> <filter_kind> <freq> <block_frames> <frames_per_lane> <pull_first>
 //       sources 0..S0-1 are added before the first next(); after <pull_first> samples were served, S1 more are added
 //       (Mixer::add on a running mixer).  Writes out.f32 and join.txt (the output frame at which they joined).
-//   host_mirror_test bench <S> <frames> <block_frames>
+//   host_mirror_test bench <S> <frames> <block_frames> [host_threads]
 //       times the pull path end to end (host samples in, mixed host samples out: PCIe inclusive) on S synthetic sources
 //   host_mirror_test chain <dir> <channels> <rate> <block_frames> <op> [<op> ...]
 //       <dir>/src_0.f32  ->  <dir>/out.f32 ; ops: amplify:F low_pass:HZ high_pass:HZ reverb:NS:AMP uniform:CH:RATE take:NS:FADE delay:NS
 //       channels:N limit agc fade_in:NS fade_out:NS distortion:G:T dither:BITS:ALG:SEED channel_volume:G0,G1,.. spatial exact (filters in reference order)
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -174,6 +175,30 @@ int main(int argc, char **argv) {
             }
             expect(threw, "zero channels rejected");
         }
+        {  // the threads that pull a block's sources: every item once, jobs back to back, the first exception reaches the caller
+            rh::detail::Workers pool(4);
+            expect(pool.threads() == 4, "workers: thread count");
+            for (int round = 0; round < 200; ++round) {
+                const size_t n = (size_t)(round % 37) + (round % 5 == 0 ? 0 : 1);
+                std::vector<int> hit(n + 3, 0);
+                pool.run(3, n + 3, [&](size_t i) { hit[i] += 1; });
+                bool ok = hit[0] == 0 && hit[1] == 0 && hit[2] == 0;
+                for (size_t i = 3; i < n + 3; ++i) ok = ok && hit[i] == 1;
+                expect(ok, "workers: every item once");
+            }
+            bool threw = false;
+            try {
+                pool.run(0, 64, [&](size_t i) {
+                    if (i == 17) throw std::runtime_error("item 17");
+                });
+            } catch (const std::runtime_error &e) {
+                threw = std::string(e.what()) == "item 17";
+            }
+            expect(threw, "workers: the exception of an item reaches the caller");
+            std::atomic<int> count{0};
+            pool.run(0, 1000, [&](size_t) { count.fetch_add(1); });
+            expect(count.load() == 1000, "workers: usable after an exception");
+        }
         std::printf("selftest ok\n");
         return 0;
     }
@@ -185,13 +210,14 @@ int main(int argc, char **argv) {
         const std::string mode = argv[1], dir = argv[2];
         rh::init(0);
         std::vector<float> out;
-        if (mode == "bench" && argc == 5) {
+        if (mode == "bench" && (argc == 5 || argc == 6)) {
             const int S = std::atoi(argv[2]);
             const size_t frames = (size_t)std::atoll(argv[3]);
             rh::GpuMixer::Options opt;
             opt.filter_kind = 0;
             opt.filter_freq = 200;
             opt.block_frames = (size_t)std::atoll(argv[4]);
+            opt.host_threads = argc == 6 ? (unsigned)std::atoi(argv[5]) : 0;
             rh::GpuMixer mixer(48000, opt);
             uint32_t lcg = 12345u;
             for (int i = 0; i < S; ++i) {
@@ -203,16 +229,33 @@ int main(int argc, char **argv) {
                 mixer.add(make_source(2, 44100, std::move(x)));
             }
             std::vector<float> chunk(1u << 16);
-            size_t total = 0;
+            // the first read starts the stream (plan, page-locked blocks, device rows): timed apart from the steady state
             const auto t0 = std::chrono::steady_clock::now();
+            size_t total = mixer.read(chunk.data(), chunk.size());
+            const size_t first = total;
+            const auto t1 = std::chrono::steady_clock::now();
+            // ... and so is the end: the reads that see the stream finish (the last block, the plan's teardown)
+            size_t steady = 0;
+            auto t2 = t1;
             for (;;) {
                 const size_t k = mixer.read(chunk.data(), chunk.size());
                 total += k;
                 if (k < chunk.size()) break;
+                if (mixer.timing().blocks * opt.block_frames < frames) {  // the upstreams still have frames to give: steady state
+                    steady = total - first;
+                    t2 = std::chrono::steady_clock::now();
+                }
             }
-            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            std::printf("{\"pull_path\": \"GpuMixer\", \"sources\": %d, \"in_frames\": %zu, \"block_frames\": %zu, \"out_samples\": %zu, \"seconds\": %.4f, \"Msamples_per_s_in\": %.1f}\n", S, frames,
-                        opt.block_frames, total, sec, (double)S * (double)frames * 2.0 / sec / 1e6);
+            const double start_s = std::chrono::duration<double>(t1 - t0).count();
+            const double sec = std::chrono::duration<double>(t2 - t1).count();
+            const double end_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+            const double in_samples = (double)S * (double)frames * 2.0 * (double)steady / (double)total;  // the share of the input behind the steady part
+            // the bound of this path is the host link: every input sample crosses it once (PCIe 5.0 x16: 63 GB/s one way)
+            const double gbps = in_samples * sizeof(float) / sec / 1e9;
+            std::printf("{\"pull_path\": \"GpuMixer\", \"sources\": %d, \"in_frames\": %zu, \"block_frames\": %zu, \"host_threads\": %u, \"out_samples\": %zu, \"start_seconds\": %.4f, \"seconds\": %.4f, \"end_seconds\": %.4f, "
+                        "\"Msamples_per_s_in\": %.1f, \"host_link\": {\"achieved\": %.2f, \"peak\": 63.0, \"unit\": \"GB/s\", \"frac\": %.3f}, \"host_seconds\": {\"pull\": %.4f, \"prefetch\": %.4f, \"submit\": %.4f, \"wait\": %.4f, \"blocks\": %llu}}\n",
+                        S, frames, opt.block_frames, opt.host_threads, total, start_s, sec, end_s, in_samples / sec / 1e6, gbps, gbps / 63.0, mixer.timing().pull_s, mixer.timing().prefetch_s, mixer.timing().submit_s,
+                        mixer.timing().wait_s, (unsigned long long)mixer.timing().blocks);
             return 0;
         }
         if (mode == "mixany" && argc == 9) {
