@@ -1056,6 +1056,8 @@ public:
     std::uint32_t sample_rate() const override { return rate_; }
     /// Output frame (of this mixer) at which the most recently started generation joined.
     std::uint64_t last_join_frame() const { return last_join_; }
+    /// Threads that have pulled sources so far (1 until a block was large enough for the pool).
+    unsigned pull_threads() const { return pool_ ? pool_->threads() : 1; }
 
 protected:
     bool can_resume() const override { return !pending_.empty() && resume_ok_; }  // mixer.rs:117-136: None while empty, samples again after add()

@@ -277,6 +277,7 @@ int main(int argc, char **argv) {
             }
             std::fclose(sf);
             out = drain(mixer);
+            std::fprintf(stderr, "pull_threads=%u\n", mixer.pull_threads());
         } else if (mode == "late" && argc == 12) {
             const int S0 = std::atoi(argv[3]), S1 = std::atoi(argv[4]);
             const uint32_t from = (uint32_t)std::atoll(argv[5]), to = (uint32_t)std::atoll(argv[6]);

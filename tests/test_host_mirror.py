@@ -360,6 +360,36 @@ def test_gpu_mixer_converts_spanned_sources_span_by_span(O, tmp_path, kind, filt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["test", "mixed"])
+@pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
+def test_gpu_mixer_blocks_pulled_by_the_thread_pool(O, tmp_path, kind, filt, freq):
+    # blocks large enough for the pool (sources x block frames >= 2^18): the sources are pulled by several host
+    # threads, a block ahead of the wait, and travel on the copy stream -- the samples are rodio's all the same
+    # ("test": one format, one fused stream of 12; "mixed": three formats and span kinds, one staged generation of 12)
+    spec = [(2, 44100, 0.5 + 0.05 * i, 60000 + 1111 * i) if kind == "test" else (2 if i % 4 else 1, (44100, 48000, 32000)[i % 3], 0.5 + 0.05 * i, 60000 + 1111 * i) for i in range(12)]
+    xs = [rnd(4700 + i, ch * n, 0.08) for i, (ch, _, _, n) in enumerate(spec)]
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    (tmp_path / "spec.txt").write_text("".join(f"{ch} {rate} {g}\n" for ch, rate, g, _ in spec))
+    r = subprocess.run([EXE, "mixany", str(tmp_path), str(len(spec)), "48000", str(filt), str(freq), "32768", "0"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    assert r.returncode == 0, r.stderr
+    if (os.cpu_count() or 1) > 1:
+        assert int(r.stderr.split("pull_threads=")[1].split()[0]) > 1, r.stderr
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    m = O.Mixer(2, 48000)
+    for i, (ch, rate, g, _) in enumerate(spec):
+        u = O.UniformSourceIterator(_span_source(O, kind, xs[i], ch, rate, i).amplify(float(np.float32(g))), 2, 48000)
+        m.add(u.low_pass(freq) if filt == 0 else u)
+    ref = m.collect()
+    assert len(got) == len(ref), (len(got), len(ref))
+    if filt < 0:
+        assert np.array_equal(got, ref), int(np.argmax(got != ref))
+    else:
+        assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["buffer", "spans:1000"])
 @pytest.mark.parametrize("filt,freq", [(-1, 0), (0, 200)])
 @pytest.mark.parametrize("pull_first", [11, 8704 * 2 + 1, 40000])
