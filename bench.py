@@ -100,7 +100,9 @@ def pmc_traffic(argv, kernel_like, per_call=False):
             con = sqlite3.connect(dbs[0])
             # the timed launches are the last ones of the run: the geometry autotune's dispatches of other template
             # instances are left out by taking the kernel name of the last dispatch
-            rows = con.execute("select kernel_name, value from counters_collection where counter_name=? and kernel_name like ? order by dispatch_id", (counter, kernel_like)).fetchall()
+            likes = kernel_like if isinstance(kernel_like, (list, tuple)) else [kernel_like]
+            rows = con.execute("select kernel_name, value from counters_collection where counter_name=? and (" + " or ".join("kernel_name like ?" for _ in likes) + ") order by dispatch_id",
+                               (counter, *likes)).fetchall()
             if not rows:
                 return None, f"no {kernel_like} dispatch in the {counter} pass"
             if per_call:
@@ -291,8 +293,9 @@ def headline(args, argv):
         child_argv = [a for a in argv]
         child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
         child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
-        # (a ragged batch is two kernels per launch: the sum over both, per call)
-        traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, "%k_rlm%", per_call=bool(geo["ragged_pair"]))
+        # (a ragged batch and a mix-first batch are two kernels per launch: the sum over both, per call)
+        two = bool(geo["ragged_pair"]) or bool(geo.get("mix_first"))
+        traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, ["%k_rlm%", "%k_mix_%"], per_call=two)
         ph = pipe.phase_cycles()
         if ph is not None:
             geo["phase_cycles"] = [round(x) for x in ph]
@@ -300,7 +303,7 @@ def headline(args, argv):
         geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
         if tuned:
             geo["autotuned"] = True
-        kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_fast")
+        kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
         res = {
             "metric": "Msamples/s through resample+low_pass+mix pipeline",
             "value": in_samples * world * args.steps / dt / 1e6,

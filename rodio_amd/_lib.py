@@ -53,7 +53,7 @@ class RlmConfig(C.Structure):
 
 class RlmGeometry(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("threads", "frames_per_lane", "ring_stages", "stage_kib", "lds_bytes",
-                                           "lookback_tiles", "resident_waves_per_cu", "n_tiles", "general_kernel", "ragged_pair")]
+                                           "lookback_tiles", "resident_waves_per_cu", "n_tiles", "general_kernel", "ragged_pair", "mix_first")]
 
 
 vp, sz, u32, u64, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int32, C.c_float

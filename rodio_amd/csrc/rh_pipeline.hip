@@ -117,6 +117,9 @@ struct Params {
     float Tf, rcpT;
     uint32_t epoch, J;
     uint32_t ticket_base;  // value of *ticket when this launch starts (the counter is never reset)
+    uint32_t direct;       // k_rlm_fast: tile = blockIdx.x, no ticket.  Only for launches whose workgroups are all resident at once (the host
+                           // checks): then no tile can wait for one that has no slot yet.  One counter hands out ~85 tickets per microsecond,
+                           // which a one-source launch (mix first) cannot hide.
     unsigned long long *prof;  // RH_PHASE_PROFILE builds: [tiles][8] cycles per phase
     uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
     uint32_t batch_streams;    // k_rlm_fast: > 0 = no mixing: ticket k is tile k / batch_streams of source k % batch_streams
@@ -362,7 +365,11 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
     // so the streams are dealt over `shards` counters on separate cache lines, one per XCD (workgroup b runs on XCD b % 8):
     // a stream's tiles all come from one counter, which keeps the order that matters.
     uint32_t ticket, stream, tile;
-    if (p.shards > 1) {
+    if (p.direct) {
+        ticket = blockIdx.x;
+        stream = 0;
+        tile = ticket;
+    } else if (p.shards > 1) {
         const uint32_t x = blockIdx.x % p.shards, per = p.batch_streams / p.shards;
         ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket + 32u * (1u + x), 1u) - p.shard_base : 0u);
         stream = x + p.shards * (ticket % per);
@@ -1405,6 +1412,226 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
 }
 
 // =================================================================================================
+// k_mix_rows -- "mix first".  The converter and the filter are linear and, for a batch of equal-length sources of one format,
+// the same for every source (same taps, same weights, same span seams, same end):
+//     sum_s filter(resample(g_s * x_s)) = filter(resample(sum_s g_s * x_s)).
+// So a filtered equal-length batch (the benchmark) is mixed at the INPUT rate first -- this kernel: y[n] = sum_s g_s * x_s[n],
+// sources in insertion order, one pass over every input byte as whole aligned 16-byte vectors, nothing else to do per byte --
+// and the fused kernel then converts and filters ONE stream (y: 1/S of the input).  The streaming pass is what the roofline
+// prices: S * N * C * 4 bytes in, N * C * 4 out.  (Without a filter the batch stays on the per-source path: that one is
+// bit-exact with rodio's ordered sum of converted samples; the filtered path is compared at 1e-5 either way.)
+// =================================================================================================
+template <int U>
+__global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
+                                                  const uint32_t frames, const uint32_t out_frames) {
+    typedef __attribute__((address_space(4))) const uint64_t cu64;
+    typedef __attribute__((address_space(4))) const float cf32;
+    typedef RH_GLB const v4f glb_cf4;
+    cu64 *const desc = (cu64 *)(uintptr_t)srcs;
+    cf32 *const dgain = (cf32 *)(uintptr_t)srcs;
+    const uint64_t nvec = n_floats / 4;
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * U) + threadIdx.x;
+    v4f acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = v4f{0.f, 0.f, 0.f, 0.f};
+    constexpr int SB = 8 / U > 2 ? 8 / U : 2;  // sources per step: 8 (or 2*U) vector loads per lane
+    if (base + (uint64_t)(U - 1) * 256u < nvec) {  // every vector of this lane is whole and inside
+        // Two register sets: while the vectors of one step are summed, the loads of the next are in flight and the pointers
+        // and gains of the step after that are on their way through the scalar cache (the body is written out twice so that
+        // the sets swap without moves).
+        const uint32_t steps = n_sources / SB;
+        uint64_t pN[SB];
+        float gN[SB];
+        auto fetch_desc = [&](uint32_t j) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                pN[k] = desc[4 * (uint64_t)(j * SB + k)];
+                gN[k] = dgain[8 * (uint64_t)(j * SB + k) + 4];
+            }
+        };
+        auto issue = [&](v4f (&v)[SB][U], float (&g)[SB]) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)pN[k];
+                g[k] = gN[k];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[k][u] = __builtin_nontemporal_load(ptr + base + (uint64_t)u * 256u);
+            }
+        };
+        auto consume = [&](const v4f (&v)[SB][U], const float (&g)[SB]) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[u].x = fma_(g[k], v[k][u].x, acc[u].x);
+                    acc[u].y = fma_(g[k], v[k][u].y, acc[u].y);
+                    acc[u].z = fma_(g[k], v[k][u].z, acc[u].z);
+                    acc[u].w = fma_(g[k], v[k][u].w, acc[u].w);
+                }
+        };
+        v4f vA[SB][U], vB[SB][U];
+        float gA[SB], gB[SB];
+        // (the loads of the next step are issued unconditionally inside the loop: a conditional issue makes the compiler wait
+        // for the newest load of either path, which drains the pipeline every step)
+        if (steps) {
+            fetch_desc(0);
+            issue(vA, gA);
+            if (steps > 1) fetch_desc(1);
+            uint32_t j = 0;
+            for (; j + 2 < steps; j += 2) {
+                issue(vB, gB);         // step j+1
+                fetch_desc(j + 2);
+                consume(vA, gA);       // step j
+                issue(vA, gA);         // step j+2
+                fetch_desc(j + 3 < steps ? j + 3 : steps - 1);
+                consume(vB, gB);       // step j+1
+            }
+            if (j + 1 < steps) {  // two steps left: A in flight, B's descriptors fetched
+                issue(vB, gB);
+                consume(vA, gA);
+                consume(vB, gB);
+            } else {
+                consume(vA, gA);
+            }
+        }
+        for (uint32_t s = steps * SB; s < n_sources; ++s) {
+            glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)desc[4 * (uint64_t)s];
+            const float g = dgain[8 * (uint64_t)s + 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const v4f v = __builtin_nontemporal_load(ptr + base + (uint64_t)u * 256u);
+                acc[u].x = fma_(g, v.x, acc[u].x);
+                acc[u].y = fma_(g, v.y, acc[u].y);
+                acc[u].z = fma_(g, v.z, acc[u].z);
+                acc[u].w = fma_(g, v.w, acc[u].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<v4f *>(y + 4 * (base + (uint64_t)u * 256u)) = acc[u];
+    } else {  // the last workgroup: vector by vector, guarded
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = base + (uint64_t)u * 256u;
+            if (i >= nvec) break;
+            v4f a = v4f{0.f, 0.f, 0.f, 0.f};
+            for (uint32_t s = 0; s < n_sources; ++s) {
+                glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)desc[4 * (uint64_t)s];
+                const float g = dgain[8 * (uint64_t)s + 4];
+                const v4f v = ptr[i];
+                a.x = fma_(g, v.x, a.x), a.y = fma_(g, v.y, a.y), a.z = fma_(g, v.z, a.z), a.w = fma_(g, v.w, a.w);
+            }
+            *reinterpret_cast<v4f *>(y + 4 * i) = a;
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t t = nvec * 4 + threadIdx.x;  // the floats behind the last whole vector (a mono batch of a length not divisible by 4)
+        if (t < n_floats) {
+            float a = 0.f;
+            for (uint32_t s = 0; s < n_sources; ++s) a = fma_(dgain[8 * (uint64_t)s + 4], ((glb_cf32 *)(uintptr_t)desc[4 * (uint64_t)s])[t], a);
+            y[t] = a;
+        }
+        if (threadIdx.x == 0) {  // the one-entry descriptor table the fused launch behind this one reads
+            ydesc->data = y;
+            ydesc->frames = frames;
+            ydesc->out_frames = out_frames;
+            ydesc->gain = 1.0f;
+            ydesc->pad[0] = ydesc->pad[1] = ydesc->pad[2] = 0;
+        }
+    }
+}
+
+// The same sum for long rows, in the shape that reaches the read ceiling of this part (tools/ubench/stream_ring: 7.19 TB/s):
+// one wave owns chunk t -- 8 KiB, aligned -- of EVERY source; it pulls the chunks through a ring of NS LDS stages with LDS-DMA
+// (8 instructions of 1 KiB per source, no registers held by data in flight), reads its own 8 vectors of a landed stage back
+// and accumulates.  A row of n_floats gives ceil(n_floats / 2048) waves: for rows that fill the chip (the host decides).
+template <int NS>
+__global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
+                                                 const uint32_t frames, const uint32_t out_frames) {
+    constexpr int KV = 8;
+    constexpr uint32_t kStage = KV * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * kStage];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    typedef __attribute__((address_space(4))) const uint64_t cu64;
+    typedef __attribute__((address_space(4))) const float cf32;
+    cu64 *const desc = (cu64 *)(uintptr_t)srcs;
+    cf32 *const dgain = (cf32 *)(uintptr_t)srcs;
+    const int lane = threadIdx.x;
+    const uint64_t nvec = n_floats / 4;
+    const uint64_t v0 = (uint64_t)blockIdx.x * (KV * 64);  // first vector of this wave's chunk
+    // byte offsets of this lane's KV vectors inside a row; vectors past the end of the row re-fetch its last one (never stored)
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint64_t j = v0 + (uint64_t)k * 64 + lane;
+        j = j < nvec ? j : nvec - 1;
+        goff[k] = (uint32_t)(j * 16);  // rows are < 2^32 bytes (frames < 2^29)
+    }
+    auto stage_source = [&](uint32_t s_, uint32_t stage) {
+        const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+    };
+    v4f acc[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) acc[k] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (v0 < nvec) {
+#pragma unroll
+        for (int d = 0; d < NS - 1; ++d)
+            if ((uint32_t)d < n_sources) stage_source(d, d);
+        uint32_t st = 0;
+        float g_next = n_sources ? dgain[4] : 0.f;
+        for (uint32_t s_ = 0; s_ < n_sources; ++s_) {
+            const float g = g_next;
+            g_next = s_ + 1 < n_sources ? dgain[8 * (uint64_t)(s_ + 1) + 4] : 0.f;
+            // the stage that source s_-1 was read from is free (its reads were waited for): source s_+NS-1 goes there
+            if (s_ + NS - 1 < n_sources) {
+                uint32_t into = st + NS - 1;
+                into = into >= (uint32_t)NS ? into - NS : into;
+                stage_source(s_ + NS - 1, into);
+                wait_vm<KV *(NS - 1)>();
+            } else {
+                const uint32_t left = n_sources - 1 - s_;  // groups issued after this source's
+                wait_groups<KV, NS>((int)left);
+            }
+            const lds_u8 *buf = lds + st * kStage;
+            v4f v[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(buf + k * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage may be re-targeted by the next DMA
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                acc[k].x = fma_(g, v[k].x, acc[k].x);
+                acc[k].y = fma_(g, v[k].y, acc[k].y);
+                acc[k].z = fma_(g, v[k].z, acc[k].z);
+                acc[k].w = fma_(g, v[k].w, acc[k].w);
+            }
+            st = st + 1 == (uint32_t)NS ? 0 : st + 1;
+        }
+        wait_vm<0>();
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const uint64_t j = v0 + (uint64_t)k * 64 + lane;
+            if (j < nvec) *reinterpret_cast<v4f *>(y + 4 * j) = acc[k];
+        }
+    }
+    if (blockIdx.x == 0) {
+        const uint64_t t = nvec * 4 + lane;  // the floats behind the last whole vector
+        if (t < n_floats) {
+            float a = 0.f;
+            for (uint32_t s_ = 0; s_ < n_sources; ++s_) a = fma_(dgain[8 * (uint64_t)s_ + 4], ((glb_cf32 *)(uintptr_t)desc[4 * (uint64_t)s_])[t], a);
+            y[t] = a;
+        }
+        if (lane == 0) {
+            ydesc->data = y;
+            ydesc->frames = frames;
+            ydesc->out_frames = out_frames;
+            ydesc->gain = 1.0f;
+            ydesc->pad[0] = ydesc->pad[1] = ydesc->pad[2] = 0;
+        }
+    }
+}
+
+// =================================================================================================
 // k_rlm_resid -- second half of a ragged filtered batch (behind k_rlm_fast<RAG>): the (tile, source) pairs in which
 // the source is NOT stable, i.e. ends inside the tile or within the J tiles after it.  There are at most J+2 such tiles
 // per source, so this kernel is small however large the batch: a tile finds its pairs with a ballot over the
@@ -1833,6 +2060,8 @@ struct rh_rlm {
     unsigned long long *d_gran = nullptr;
     size_t gran_words = 0;
     uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status, [2] late carries, [3] empty polls
+    float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
+    size_t mix_floats = 0;
     unsigned long long *d_prof = nullptr;
     uint32_t n_sources = 0, n_tiles = 0;
     uint64_t out_frames = 0;
@@ -2151,6 +2380,7 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->d_srcs) (void)hipFree(p->d_srcs);
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->d_mix) (void)hipFree(p->d_mix);
     if (p->d_prof) (void)hipFree(p->d_prof);
     for (int k = 0; k < 2; ++k)
         if (p->d_w[k]) (void)hipFree(p->d_w[k]);
@@ -2235,6 +2465,10 @@ struct StreamArgs {
     float *wout = nullptr;
     uint32_t gran_cols = 0;  // != 0: per-source states (k_rlm_wave), aggregate rows of this many columns, tile 0 in column 1
 };
+// Mix first (k_mix_rows / k_mix_ring in front of a one-source fused launch): one-shot runs of filtered equal-length batches.
+static bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool streaming, bool batch) {
+    return &pl == &p->fast && p->filt && !streaming && !batch && count >= 2 && !rh::knob(rh::K_NO_MIX_FIRST);
+}
 static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
                             const StreamArgs &sa = StreamArgs());
 
@@ -2286,6 +2520,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.epoch = p->epoch;
     k.J = pl.J;
     k.ticket_base = p->ticket_base;
+    k.direct = 0;
     k.prof = p->d_prof;
     k.eq_frames = p->eq_frames;
     k.batch_streams = batch_streams;
@@ -2324,13 +2559,47 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         }
         return mark_launch(p, s);
     }
+    // Mix first: a filtered batch of equal-length sources is summed at the input rate (k_mix_rows: the one pass over the input),
+    // and the fused kernel converts and filters that ONE stream.
+    if (mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0)) {
+        const uint64_t n_floats = (uint64_t)p->eq_frames * p->cfg.channels;
+        const size_t need = (size_t)((n_floats + 3) & ~3ull) + 64;  // the row (16-byte vectors), then the descriptor on its own 128 bytes
+        if (need > p->mix_floats) {
+            const rh_status w = wait_idle(p);
+            if (w != RH_OK) return w;
+            if (p->d_mix) RH_HIP_TRY(hipFree(p->d_mix));
+            p->d_mix = nullptr;
+            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_mix), need * sizeof(float)));
+            p->mix_floats = need;
+        }
+        SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32));
+        int U = 4;  // measured (256 x 1 Mi stereo frames): 0.410 / 0.409 / 0.342 ms for 1 / 2 / 4 vectors per lane
+        if (const char *u = rh::knob(rh::K_MIX_U)) U = atoi(u);
+        const uint64_t nvec = n_floats / 4;
+        const uint32_t per = 256u * (uint32_t)(U == 1 ? 1 : U == 2 ? 2 : 4);
+        const uint32_t wgs = (uint32_t)std::max<uint64_t>(1, (nvec + per - 1) / per);
+        const uint64_t ring_waves = (nvec + 511) / 512;  // 8 KiB chunks
+        int ring = ring_waves >= 2ull * rh::g_num_cus ? 2 : 0;  // ring depth; 0: the vector-load kernel (short rows: more, smaller pieces)
+        if (const char *u = rh::knob(rh::K_MIX_U)) ring = atoi(u) >= 10 ? atoi(u) - 10 : 0;  // tuning aid: 12 / 13 = ring of 2 / 3 stages, 1 / 2 / 4 = vector loads
+        if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        RH_CHECK_LAUNCH();
+        k.srcs = ydesc;
+        k.n_sources = 1;
+        // every tile of the one-stream launch resident at once: no tickets (see Params::direct)
+        k.direct = (uint64_t)p->n_tiles <= (uint64_t)rh::g_num_cus * (uint64_t)std::max(pl.resident_per_cu, 0) ? 1u : 0u;
+    }
     // batch mode fills the chip many times over: no residency shaping, the bare LDS request
     hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? std::max((uint32_t)pl.v->KV * 1024u, 64u * ((uint32_t)pl.v->R * 8u + 8u)) /* one source per tile: one stage of the ring, reused by the output transpose */ : p->launch_lds, s);
     if (e != hipSuccess) {
         rh::set_hip_error(e, "k_rlm launch");
         return RH_ERR_HIP;
     }
-    if (k.shards > 1) p->shard_base += (uint32_t)(grid / k.shards);
+    if (k.direct) {}  // no tickets taken
+    else if (k.shards > 1) p->shard_base += (uint32_t)(grid / k.shards);
     else p->ticket_base += (uint32_t)grid;  // every launch takes exactly one ticket per workgroup
     return mark_launch(p, s);
 }
@@ -2743,6 +3012,7 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->n_tiles = p->n_tiles;
     info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
     info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
+    info->mix_first = mix_first_applies(p, pl, p->n_sources, false, false) ? 1u : 0u;
     return RH_OK;
 }
 

@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/kt_cmd.sh <tag> <command...>   (GPU box) kernel trace only -> gpurun_out/prof/<tag>/summary.txt
+tag=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$R/gpurun_out/prof/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cd $R
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- "$@" > $out/kt.log 2>&1
+python tools/prof_summary.py $out/kt/kt_results.db | cut -c1-220 > $out/summary.txt
+cat $out/summary.txt
