@@ -43,6 +43,7 @@
 #include <mutex>
 #include <numeric>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "rh_common.h"
@@ -1632,6 +1633,308 @@ __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ src
 }
 
 // =================================================================================================
+// k_rlm_chunk -- mix first in ONE kernel, for rows long enough to fill the chip (stereo).  Tile t owns the ALIGNED 8 KiB chunk t
+// of every source: it sums the chunks through the LDS-DMA ring exactly as k_mix_ring does (the pass that reaches the read
+// ceiling, no re-fetched line), and then converts and filters ITS part of the one mixed stream itself -- no mixed row in memory,
+// no second launch.  What makes that possible:
+//   * a tile's output frames are those whose SECOND tap lies in its chunk (frames m_lo[t] .. m_lo[t+1]-1, a table of the host's:
+//     1114 or 1115 of them at 44.1 -> 48 kHz): the only input a tile lacks is the end of the chunk before it -- the first tap of
+//     its first frame, and the taps of the two frames x'[m_lo-1], x'[m_lo-2] the filter looks back at.  Those are MIXED frames:
+//     the tile before publishes its last 4 of them (tagged words, like the aggregates) as soon as its source loop ends;
+//   * lanes take runs of R frames as in k_rlm_fast; the tile's last lane takes what is left (v <= R frames) and the lanes behind
+//     it idle.  The scan is the uniform one; only the tile aggregate needs the short run: A = B^v * (prefix of the lane before)
+//     + (own run), one 2x2 product with a table of B^v;
+//   * tiles have different lengths, so the look-back weights B^(m_lo[t] - m_lo[t-j]) come from a table per tile (host, f64).
+// Waits only ever go to EARLIER tiles, and the host launches this kernel only when every tile is resident at once.
+// =================================================================================================
+struct ChunkArgs {
+    const uint32_t *m_lo;      // [n_tiles + 1]: first output frame of every tile; m_lo[n_tiles] = out_frames
+    unsigned long long *halo;  // [n_tiles][8] {epoch, f32 bits}: the last 4 mixed frames of the tile's chunk
+    const float *lookT;        // [n_tiles][J][4]: B^(m_lo[t] - m_lo[t-j]), j = 0 .. J-1 (the weight of tile t-1-j's aggregate)
+    const float *powM;         // [R + 1][4]: B^v
+};
+template <int R>
+__global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const ChunkArgs q) {
+    constexpr int KV = 8, NS = 2, H = 4;
+    constexpr uint32_t kStage = KV * 1024, P = 1024;          // bytes of a ring stage = one chunk; stereo frames per chunk
+    constexpr uint32_t MB = NS * kStage + 64;                 // the mixed chunk: halo frames at MB - 32 .. MB, 16 spare bytes behind it
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MB + kStage + 64];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    typedef __attribute__((address_space(4))) const uint64_t cu64;
+    typedef __attribute__((address_space(4))) const float cf32;
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    cu64 *const desc = (cu64 *)(uintptr_t)p.srcs;
+    cf32 *const dgain = (cf32 *)(uintptr_t)p.srcs;
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t Ns = p.eq_frames, S = p.n_sources;
+    const uint32_t m_lo = ((cu32 *)(uintptr_t)q.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q.m_lo)[tile + 1];
+    const uint32_t n_t = m_hi - m_lo;                          // <= 64 * R (host)
+    const uint32_t m0 = m_lo + (uint32_t)lane * R;
+    const int nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);  // frames of this lane's run
+    const bool first = (m0 == 0);                              // stream start: x'[-1] = x'[-2] = 0
+    // ---- taps and weights of the lane's R + 2 frames: LDS offsets into [halo | chunk] ----
+    int offA[R + 2];
+    float wgt[R + 2];
+    {
+        const int64_t fbase = (int64_t)tile * P;
+        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            const bool dummy = first && rr < 2;
+            uint64_t i;
+            uint32_t num;
+            cursor_resolve(c, p, i, num);
+            if (i + 1 >= Ns) {  // the last frame is emitted verbatim (sample_rate.rs:193-200); frames past it are never stored
+                i = Ns - 1;
+                num = 0;
+            }
+            int64_t f = (int64_t)i - fbase;
+            f = f < -H ? -H : (f > (int64_t)P - 1 ? (int64_t)P - 1 : f);  // (only frames that are not stored leave the range)
+            offA[rr] = dummy ? (int)MB : (int)MB + (int)f * 8;
+            wgt[rr] = dummy ? 0.0f : (float)num / p.Tf;
+            if (!dummy) cursor_next(c, p);
+        }
+    }
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+
+    // ---- the sum of chunk `tile` of every source (k_mix_ring) ----
+    const uint32_t nvec = Ns / 2;  // 16-byte vectors of a row (host: Ns even)
+    const uint32_t v0 = tile * (KV * 64);
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = v0 + (uint32_t)k * 64 + lane;
+        j = j < nvec ? j : nvec - 1;  // past the end of the row: its last vector again (finite, never a tap of a stored frame)
+        goff[k] = j * 16;
+    }
+    auto stage_source = [&](uint32_t s_, uint32_t stage) {
+        const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+    };
+    v4f acc[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) acc[k] = v4f{0.f, 0.f, 0.f, 0.f};
+    {
+        if (S) stage_source(0, 0);
+        uint32_t st = 0;
+        float g_next = S ? dgain[4] : 0.f;
+        for (uint32_t s_ = 0; s_ < S; ++s_) {
+            const float g = g_next;
+            g_next = s_ + 1 < S ? dgain[8 * (uint64_t)(s_ + 1) + 4] : 0.f;
+            if (s_ + 1 < S) {
+                stage_source(s_ + 1, st ^ 1u);
+                wait_vm<KV>();
+            } else {
+                wait_vm<0>();
+            }
+            const lds_u8 *buf = lds + st * kStage;
+            v4f v[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(buf + k * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage may be re-targeted by the next DMA
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                acc[k].x = fma_(g, v[k].x, acc[k].x);
+                acc[k].y = fma_(g, v[k].y, acc[k].y);
+                acc[k].z = fma_(g, v[k].z, acc[k].z);
+                acc[k].w = fma_(g, v[k].w, acc[k].w);
+            }
+            st ^= 1u;
+        }
+    }
+    // ---- the mixed chunk into the LDS; its last 4 frames to the tile behind; the last 4 frames of the tile in front ----
+#pragma unroll
+    for (int k = 0; k < KV; ++k) *(lds_f4 *)(lds + MB + (uint32_t)(k * 64 + lane) * 16) = acc[k];
+    if (lane == 0) *(lds_f4 *)(lds + MB + kStage) = v4f{0.f, 0.f, 0.f, 0.f};  // the second tap of a verbatim last frame at the end of a chunk: finite, weight 0
+    if (lane >= 62) {  // vectors 510, 511 of the chunk = frames P-4 .. P-1
+        unsigned long long *hp = q.halo + (uint64_t)tile * 8 + (uint32_t)(lane - 62) * 4;
+        const float e[4] = {acc[KV - 1].x, acc[KV - 1].y, acc[KV - 1].z, acc[KV - 1].w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)p.epoch << 32) | __float_as_uint(e[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool dead = false;
+    if (tile == 0) {
+        if (lane < 8) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = 0.0f;
+    } else {
+        const bool want = lane < 8;
+        const unsigned long long *hp = q.halo + (uint64_t)(tile - 1) * 8 + (want ? lane : 0);
+        unsigned long long hv = 0;
+        bool ok = false;
+        uint32_t spins = 0;
+        while (true) {
+            if (want && !ok) {
+                hv = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t)(hv >> 32) == p.epoch;
+            }
+            if (__all(ok || !want)) break;
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicOr(p.status, 1u);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (want) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = dead ? __builtin_nanf("") : __uint_as_float((uint32_t)hv);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the lane's run of the mixed stream: lerp, zero-state biquad; the run-end state after nfl frames ----
+    v2f out[R];
+    v2f E1 = v2f{0.f, 0.f}, E2 = v2f{0.f, 0.f};
+    {
+        v2f ta[R + 2], tb2[R + 2];
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            ta[rr] = *(const lds_f2 *)(lds + offA[rr]);
+            tb2[rr] = *(const lds_f2 *)(lds + offA[rr] + 8);
+        }
+        auto tap = [&](int rr) -> v2f { return v2f{fma_(tb2[rr].x - ta[rr].x, wgt[rr], ta[rr].x), fma_(tb2[rr].y - ta[rr].y, wgt[rr], ta[rr].y)}; };
+        v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
+        v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
+        v2f w1 = v2f{0.f, 0.f}, w2 = v2f{0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v2f x = tap(r + 2);
+            v2f w;
+            w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
+            w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
+            out[r] = v2f{fma_(b0, x.x, w.x), fma_(b0, x.y, w.y)};
+            w2 = w1;
+            w1 = w;
+            x2 = x1;
+            x1 = x;
+            if (r + 1 == nfl) {
+                E1 = w1;
+                E2 = w2;
+            }
+        }
+    }
+    // ---- scan of the run-end states (scan basis), as in k_rlm_fast ----
+    const Tables *__restrict__ tb = p.tabs;
+    float lM[4], b15[4], b31[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lM[k] = tb->laneM[lane][k];
+        b15[k] = tb->bc15M[lane][k];
+        b31[k] = tb->bc31M[lane][k];
+    }
+    float Pq[4] = {0.f, 0.f, 0.f, 0.f};
+    mat_acc(p.u.Tm, E1.x, E2.x, Pq[0], Pq[1]);
+    mat_acc(p.u.Tm, E1.y, E2.y, Pq[2], Pq[3]);
+    const float own[4] = {Pq[0], Pq[1], Pq[2], Pq[3]};
+#define RH_CSCAN(K, N)                                                                             \
+    {                                                                                              \
+        float sq[4];                                                                               \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppRowShr + N, 0xf>(Pq[k]);     \
+        mat_acc(p.u.scanM[K], sq[0], sq[1], Pq[0], Pq[1]);                                         \
+        mat_acc(p.u.scanM[K], sq[2], sq[3], Pq[2], Pq[3]);                                         \
+    }
+    RH_CSCAN(0, 1)
+    RH_CSCAN(1, 2)
+    RH_CSCAN(2, 4)
+    RH_CSCAN(3, 8)
+#undef RH_CSCAN
+    {
+        float sq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppBcast15, 0xa>(Pq[k]);
+        mat_acc(b15, sq[0], sq[1], Pq[0], Pq[1]);
+        mat_acc(b15, sq[2], sq[3], Pq[2], Pq[3]);
+    }
+    {
+        float sq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppBcast31, 0xc>(Pq[k]);
+        mat_acc(b31, sq[0], sq[1], Pq[0], Pq[1]);
+        mat_acc(b31, sq[2], sq[3], Pq[2], Pq[3]);
+    }
+    {  // the tile aggregate: the short last run on top of the inclusive prefix of the lane before it
+        const int nl = (int)((n_t + R - 1) / R);  // lanes with frames (uniform)
+        float A[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nl >= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) A[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own[k]), nl - 1));
+        }
+        if (nl >= 2) {
+            const uint32_t v = n_t - (uint32_t)(nl - 1) * R;  // 1 .. R
+            cf32 *pw = (cf32 *)(uintptr_t)(q.powM + 4 * v);
+            const float M[4] = {pw[0], pw[1], pw[2], pw[3]};
+            float xp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xp[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pq[k]), nl - 2));
+            mat_acc(M, xp[0], xp[1], A[0], A[1]);
+            mat_acc(M, xp[2], xp[3], A[2], A[3]);
+        }
+        if (lane < 4) {
+            float ev = A[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) ev = lane == k ? A[k] : ev;
+            __hip_atomic_store(p.gran + (uint64_t)tile * 4 + lane, ((unsigned long long)p.epoch << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float Q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Q[k] = dpp0<kDppWaveShr1, 0xf>(Pq[k]);  // exclusive: the prefix of the lanes before (all of them whole runs)
+    // ---- the tile carry: lane j < J polls tile-1-j, weights it with B^(m_lo[tile] - m_lo[tile-j]) ----
+    const uint32_t Jc = p.J < tile ? p.J : tile;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (Jc > 0) {
+        const bool want = (uint32_t)lane < Jc;
+        const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
+        const float *kp = q.lookT + ((uint64_t)tile * p.J + (want ? lane : 0)) * 4;
+        const float kM[4] = {kp[0], kp[1], kp[2], kp[3]};
+        unsigned long long gv[4] = {0, 0, 0, 0};
+        bool ok = false;
+        uint32_t spins = 0;
+        while (true) {
+            if (want && !ok) {
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gv[k] = __hip_atomic_load(gp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all = all && ((uint32_t)(gv[k] >> 32) == p.epoch);
+                }
+                ok = all;
+            }
+            if (__all(ok || !want)) break;
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicOr(p.status, 1u);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (lane == 0 && spins) atomicAdd(p.status + 1, spins);
+        if (want && ok && !dead) {
+            mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
+            mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // sum over lanes 0..31 -> uniform
+            c[k] += dpp0<kDppRowShr + 1, 0xf>(c[k]);
+            c[k] += dpp0<kDppRowShr + 2, 0xf>(c[k]);
+            c[k] += dpp0<kDppRowShr + 4, 0xf>(c[k]);
+            c[k] += dpp0<kDppRowShr + 8, 0xf>(c[k]);
+            c[k] = readlane_f(c[k], 15) + readlane_f(c[k], 31);
+        }
+    }
+    if (dead) c[0] = c[1] = c[2] = c[3] = __builtin_nanf("");  // a hand-off that never arrived: the status word fails the call, the tile is poisoned
+    mat_acc(lM, c[0], c[1], Q[0], Q[1]);  // start state of the lane's run = Q + B^(R*lane) * carry
+    mat_acc(lM, c[2], c[3], Q[2], Q[3]);
+    float *o = p.out + (uint64_t)m0 * 2;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float yl = fma_(p.u.g[r][0], Q[0], fma_(p.u.g[r][1], Q[1], out[r].x));
+        const float yr = fma_(p.u.g[r][0], Q[2], fma_(p.u.g[r][1], Q[3], out[r].y));
+        if (r < nfl) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(yl, yr);
+    }
+}
+
+// =================================================================================================
 // k_rlm_resid -- second half of a ragged filtered batch (behind k_rlm_fast<RAG>): the (tile, source) pairs in which
 // the source is NOT stable, i.e. ends inside the tile or within the J tiles after it.  There are at most J+2 such tiles
 // per source, so this kernel is small however large the batch: a tile finds its pairs with a ballot over the
@@ -2030,6 +2333,21 @@ int kv_needed(uint64_t L, uint32_t F, uint32_t T, uint32_t channels) {
 }
 
 // One launch plan: a kernel variant with its tables.
+// k_rlm_chunk: tables for runs of 18 frames, the tile boundaries of the batch that is set, the hand-off tables.
+struct ChunkPlan {
+    static constexpr int kR = 18;
+    bool tabs_ok = false, ok = false;  // filter tables built / the batch that is set can take the kernel
+    Uniforms uni;
+    Tables *d_tabs = nullptr;
+    float *d_pow = nullptr;            // [kR + 1][4]
+    uint32_t *d_mlo = nullptr;         // [n_tiles + 1]
+    float *d_look = nullptr;           // [n_tiles][J][4]
+    unsigned long long *d_halo = nullptr;  // [n_tiles][8]
+    unsigned long long *d_gran = nullptr;  // [n_tiles][4]
+    size_t cap_tiles = 0, cap_look = 0;
+    uint32_t n_tiles = 0, J = 0, frames = 0;
+    int resident_per_cu = 0;
+};
 struct Plan {
     const Variant *v = nullptr;
     const void *kernel = nullptr;
@@ -2062,6 +2380,7 @@ struct rh_rlm {
     uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status, [2] late carries, [3] empty polls
     float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
     size_t mix_floats = 0;
+    ChunkPlan chunk;            // mix first in one kernel (k_rlm_chunk)
     unsigned long long *d_prof = nullptr;
     uint32_t n_sources = 0, n_tiles = 0;
     uint64_t out_frames = 0;
@@ -2225,6 +2544,141 @@ rh_status make_plan(rh_rlm *p, Plan &pl, VariantTab tab, bool general, const rh:
     return RH_OK;
 }
 
+// k_rlm_chunk for the batch that is set (equal lengths): tile boundaries, look-back weights, residency.  Leaves chunk.ok false
+// where the kernel does not apply -- the two-kernel form of mix first (or the per-source kernel) runs instead.
+rh_status build_chunk(rh_rlm *p) {
+    ChunkPlan &c = p->chunk;
+    c.ok = false;
+    constexpr int R = ChunkPlan::kR;
+    constexpr uint64_t P = 1024, H = 4;
+    if (!p->filt || !p->equal || p->cfg.channels != 2 || p->cfg.force_general || p->n_sources < 2 || rh::knob(rh::K_NO_CHUNK) || rh::knob(rh::K_NO_MIX_FIRST)) return RH_OK;
+    const uint64_t Ns = p->eq_frames, M = p->out_frames;
+    if (Ns < 2 || (Ns & 1) || M == 0) return RH_OK;  // (whole 16-byte vectors)
+    const uint64_t tiles = (Ns + P - 1) / P;
+    if (tiles < 2ull * (uint64_t)rh::g_num_cus) return RH_OK;  // short rows: more, smaller pieces fill the chip better
+    const void *fn = reinterpret_cast<const void *>(&k_rlm_chunk<R>);
+    if (!c.resident_per_cu) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0) != hipSuccess) return RH_OK;
+        c.resident_per_cu = n < 1 ? -1 : n;
+    }
+    if (c.resident_per_cu < 1 || tiles > (uint64_t)rh::g_num_cus * (uint64_t)c.resident_per_cu) return RH_OK;  // every tile resident at once
+    // the input frame of an output frame (cursor_at / cursor_resolve, and the verbatim last frame)
+    const uint64_t F = p->F, T = p->T, cin = p->chunk_in, cout = p->chunk_out;
+    auto in_index = [&](uint64_t m) -> uint64_t {
+        const uint64_t k = cout ? m / cout : 0, ml = m - k * cout;
+        uint64_t il = ml * F / T;
+        if (cout && il + 1 >= cin) il = cin - 1;
+        const uint64_t i = k * cin + il;
+        return i + 1 >= Ns ? Ns - 1 : i;
+    };
+    std::vector<uint32_t> mlo((size_t)tiles + 1);
+    mlo[0] = 0;
+    for (uint64_t t = 1; t < tiles; ++t) {  // the first frame whose second tap lies in chunk t or behind it
+        uint64_t lo = mlo[(size_t)t - 1], hi = M;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (in_index(mid) + 1 >= t * P) hi = mid;
+            else lo = mid + 1;
+        }
+        mlo[(size_t)t] = (uint32_t)lo;
+    }
+    mlo[(size_t)tiles] = (uint32_t)M;
+    uint64_t n_min = ~0ull;
+    for (uint64_t t = 0; t < tiles; ++t) {
+        const uint64_t n = mlo[(size_t)t + 1] - mlo[(size_t)t];
+        if (n == 0 || n > 64ull * R) return RH_OK;  // a ratio that puts more frames into a chunk than 64 runs hold (or none)
+        if (t + 1 < tiles) n_min = std::min(n_min, n);
+        if (t > 0) {  // the two frames the filter looks back at, and the first tap of the first frame: in the 4 frames in front of the chunk
+            const uint64_t m = mlo[(size_t)t];
+            if (m < 2 || in_index(m - 2) + H < t * P || in_index(m) + 1 < t * P) return RH_OK;
+        }
+    }
+    const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
+    M2 Tm, Ti;
+    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
+    const M2 B = mul(mul(Tm, A), Ti);
+    const uint32_t J = look_tiles(B, n_min);
+    if (J == 0 || J > 32) return RH_OK;
+    {
+        const rh_status w = wait_idle(p);  // an earlier run may still read the tables
+        if (w != RH_OK) return w;
+    }
+    if (!c.tabs_ok) {
+        Tables *h = new Tables();
+        std::memset(h, 0, sizeof(Tables));
+        Uniforms &U = c.uni;
+        std::memset(&U, 0, sizeof(U));
+        U.b0 = p->coeffs[0];
+        U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
+        U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
+        U.a1 = p->coeffs[3];
+        U.a2 = p->coeffs[4];
+        put(U.Tm, Tm);
+        for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, (uint64_t)R << k));
+        for (int r = 0; r < R; ++r) {
+            const M2 m = mul(mpow(A, r + 1), Ti);
+            U.g[r][0] = (float)m.a;
+            U.g[r][1] = (float)m.b;
+        }
+        for (int l = 0; l < 64; ++l) {
+            put(h->laneM[l], mpow(B, (uint64_t)R * l));
+            put(h->bc15M[l], mpow(B, (uint64_t)R * ((l & 15) + 1)));
+            put(h->bc31M[l], mpow(B, (uint64_t)R * ((l & 31) + 1)));
+        }
+        float pw[R + 1][4];
+        for (int v = 0; v <= R; ++v) put(pw[v], mpow(B, (uint64_t)v));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&c.d_tabs), sizeof(Tables));
+        if (e == hipSuccess) e = hipMemcpy(c.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.d_pow), sizeof(pw));
+        if (e == hipSuccess) e = hipMemcpy(c.d_pow, pw, sizeof(pw), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) {
+            rh::set_hip_error(e, "k_rlm_chunk tables");
+            return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
+        }
+        c.tabs_ok = true;
+    }
+    if ((size_t)tiles > c.cap_tiles) {
+        if (c.d_mlo) RH_HIP_TRY(hipFree(c.d_mlo));
+        if (c.d_halo) RH_HIP_TRY(hipFree(c.d_halo));
+        if (c.d_gran) RH_HIP_TRY(hipFree(c.d_gran));
+        c.d_mlo = nullptr, c.d_halo = nullptr, c.d_gran = nullptr, c.cap_tiles = 0;
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_mlo), ((size_t)tiles + 1) * 4));
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_halo), (size_t)tiles * 64));
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_gran), (size_t)tiles * 32));
+        RH_HIP_TRY(rh::fill_now(c.d_halo, 0, (size_t)tiles * 64));  // tag 0 = never written (launch tags start at 1)
+        RH_HIP_TRY(rh::fill_now(c.d_gran, 0, (size_t)tiles * 32));
+        c.cap_tiles = (size_t)tiles;
+    }
+    const size_t look_floats = (size_t)tiles * J * 4;
+    if (look_floats > c.cap_look) {
+        if (c.d_look) RH_HIP_TRY(hipFree(c.d_look));
+        c.d_look = nullptr, c.cap_look = 0;
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_look), look_floats * 4));
+        c.cap_look = look_floats;
+    }
+    std::vector<float> look(look_floats, 0.0f);
+    {
+        // B^d for the few distances that occur (tiles of n_min or n_min + 1 frames, seams aside): memoised
+        std::unordered_map<uint64_t, M2> memo;
+        for (uint64_t t = 1; t < tiles; ++t)
+            for (uint32_t j = 0; j < J && j < t; ++j) {
+                const uint64_t d = (uint64_t)mlo[(size_t)t] - mlo[(size_t)(t - j)];
+                auto it = memo.find(d);
+                if (it == memo.end()) it = memo.emplace(d, mpow(B, d)).first;
+                put(&look[((size_t)t * J + j) * 4], it->second);
+            }
+    }
+    RH_HIP_TRY(hipMemcpy(c.d_mlo, mlo.data(), mlo.size() * 4, hipMemcpyHostToDevice));
+    RH_HIP_TRY(hipMemcpy(c.d_look, look.data(), look_floats * 4, hipMemcpyHostToDevice));
+    c.n_tiles = (uint32_t)tiles;
+    c.J = J;
+    c.frames = (uint32_t)Ns;
+    c.ok = true;
+    return RH_OK;
+}
+
 // Can the batch that is set take the kernel pair in the tile geometry of `pl`?  (1) the sources that last as long as the
 // mix share one length (the lean kernel's end-of-source handling is uniform) and (2) no tile holds many sources that are
 // about to end (k_rlm_resid takes a tile's pairs one after the other; batches whose sources all end within a few frames of
@@ -2381,6 +2835,12 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->d_gran) (void)hipFree(p->d_gran);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->d_mix) (void)hipFree(p->d_mix);
+    if (p->chunk.d_tabs) (void)hipFree(p->chunk.d_tabs);
+    if (p->chunk.d_pow) (void)hipFree(p->chunk.d_pow);
+    if (p->chunk.d_mlo) (void)hipFree(p->chunk.d_mlo);
+    if (p->chunk.d_look) (void)hipFree(p->chunk.d_look);
+    if (p->chunk.d_halo) (void)hipFree(p->chunk.d_halo);
+    if (p->chunk.d_gran) (void)hipFree(p->chunk.d_gran);
     if (p->d_prof) (void)hipFree(p->d_prof);
     for (int k = 0; k < 2; ++k)
         if (p->d_w[k]) (void)hipFree(p->d_w[k]);
@@ -2428,8 +2888,13 @@ static rh_status set_sources_impl(rh_rlm *p, const float *const *srcs_host, cons
     p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
     p->n_sources = n_sources;
     p->out_frames = M;
+    p->chunk.ok = false;
     // equal-length batch: the merged-state kernel; otherwise the general one
-    if (equal && !p->cfg.force_general) return activate_plan(p, &p->fast);
+    if (equal && !p->cfg.force_general) {
+        const rh_status st = activate_plan(p, &p->fast);
+        if (st != RH_OK || on_stream) return st;
+        return build_chunk(p);
+    }
     // different lengths + filter: almost every (tile, source) pair is "stable" and goes through the lean kernel of the pair
     return activate_plan(p, pair_ok(p, p->pair) ? &p->pair : &p->wave);
 }
@@ -2497,6 +2962,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     p->epoch += 1;
     if (p->epoch == 0) {  // tag wrap: old tags could alias, start over from a clean table
         if (p->d_gran) RH_HIP_TRY(hipMemsetAsync(p->d_gran, 0, p->gran_words * 8, s));
+        if (p->chunk.d_halo) RH_HIP_TRY(hipMemsetAsync(p->chunk.d_halo, 0, p->chunk.cap_tiles * 64, s));
+        if (p->chunk.d_gran) RH_HIP_TRY(hipMemsetAsync(p->chunk.d_gran, 0, p->chunk.cap_tiles * 32, s));
         p->epoch = 1;
     }
     Params k;
@@ -2561,6 +3028,23 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     }
     // Mix first: a filtered batch of equal-length sources is summed at the input rate (k_mix_rows: the one pass over the input),
     // and the fused kernel converts and filters that ONE stream.
+    if (p->chunk.ok && mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0) && count == p->n_sources && first == 0) {
+        // mix first in one kernel: every tile sums its aligned chunk of every source, then converts and filters its part of the mix
+        const ChunkPlan &c = p->chunk;
+        k.tabs = c.d_tabs;
+        k.gran = c.d_gran;
+        k.n_tiles = c.n_tiles;
+        k.J = c.J;
+        k.u = c.uni;
+        ChunkArgs ca;
+        ca.m_lo = c.d_mlo;
+        ca.halo = c.d_halo;
+        ca.lookT = c.d_look;
+        ca.powM = c.d_pow;
+        hipLaunchKernelGGL(k_rlm_chunk<ChunkPlan::kR>, dim3(c.n_tiles), dim3(64), 0, s, k, ca);
+        RH_CHECK_LAUNCH();
+        return mark_launch(p, s);
+    }
     if (mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0)) {
         const uint64_t n_floats = (uint64_t)p->eq_frames * p->cfg.channels;
         const size_t need = (size_t)((n_floats + 3) & ~3ull) + 64;  // the row (16-byte vectors), then the descriptor on its own 128 bytes
@@ -3012,7 +3496,7 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->n_tiles = p->n_tiles;
     info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
     info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
-    info->mix_first = mix_first_applies(p, pl, p->n_sources, false, false) ? 1u : 0u;
+    info->mix_first = mix_first_applies(p, pl, p->n_sources, false, false) ? (p->chunk.ok ? 2u : 1u) : 0u;
     return RH_OK;
 }
 

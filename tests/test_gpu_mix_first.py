@@ -1,0 +1,216 @@
+"""Mix first: a filtered batch of equal-length sources is summed at the input rate (k_mix_rows for short rows,
+k_mix_ring for rows that fill the chip) and the fused kernel converts and filters that one stream --
+sum_s filter(resample(g_s x_s)) = filter(resample(sum_s g_s x_s)).  Checked against the oracle's per-source chains
+(UniformSourceIterator(src.amplify(g)).low_pass(f) summed by the Mixer, mixer.rs:58-66, uniform.rs:50-97, blt.rs) and against
+the per-source path of the same library (RH_NO_MIX_FIRST)."""
+import numpy as np
+import pytest
+from conftest import knobs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def G(rh):
+    import torch
+
+    assert torch.cuda.is_available()
+    rh.init(0)
+    return rh
+
+
+def rnd(seed, n, scale=1.0):
+    return (np.random.default_rng(seed).uniform(-1, 1, n) * scale).astype(np.float32)
+
+
+_refs = {}
+
+
+def _oracle(O, xs, frm, to, span, filt, freq, gains, ch, key=None):
+    if key is not None and key in _refs:  # the same reference for every summing kernel
+        return _refs[key]
+    ref = _oracle_run(O, xs, frm, to, span, filt, freq, gains, ch)
+    if key is not None:
+        _refs[key] = ref
+    return ref
+
+
+def _oracle_run(O, xs, frm, to, span, filt, freq, gains, ch):
+    m = O.Mixer(ch, to)
+    for i, x in enumerate(xs):
+        src = O.TestSource(x, ch, frm) if not span else O.SpanSource(x, ch, frm, span)
+        if gains is not None:
+            src = src.amplify(float(gains[i]))
+        u = O.UniformSourceIterator(src, ch, to)
+        m.add(u.low_pass(freq) if filt == "low_pass" else u.high_pass(freq))
+    return m.collect()
+
+
+def _run(G, xs, frm, to, ch, span, filt, freq, gains, R=0):
+    import torch
+
+    S, n = len(xs), len(xs[0]) // ch
+    p = G.ResampleLowpassMix(frm, to, ch, span, filt, freq, 0.5, max_sources=S, max_in_frames=n, frames_per_lane=R)
+    if gains is not None:
+        p.set_gains(gains)
+    p.set_sources([torch.from_numpy(x).cuda() for x in xs])
+    geo = p.geometry()
+    got = p.run().cpu().numpy()
+    again = p.run().cpu().numpy()  # the mixed row and its descriptor are the handle's: a second run finds them in place
+    p.check_status()
+    p.close()
+    assert np.array_equal(got, again)
+    return got, geo
+
+
+# which summing kernel: RH_MIX_U = 1 / 2 / 4 vector loads per lane (k_mix_rows), 12 / 13 the LDS-DMA ring of 2 / 3 stages (k_mix_ring)
+@pytest.mark.parametrize("mix", [None, "1", "2", "4", "12", "13"])
+@pytest.mark.parametrize("ch,n", [(2, 30000), (1, 30001), (2, 1537), (1, 4099), (2, 70000)])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
+def test_mix_first_equals_rodio_chain(G, O, mix, ch, n, filt, freq):
+    S = 9
+    xs = [rnd(6100 + s, n * ch, 0.1) for s in range(S)]
+    gains = np.array([1.0, 0.5, 1.7, 0.0, -0.25, 0.9, 1.0, 0.3, 1.1], dtype=np.float32)
+    ref = _oracle(O, xs, 44100, 48000, None, filt, freq, gains, ch, key=(ch, n, filt, freq))
+    with knobs(**({"RH_MIX_U": mix} if mix else {})):
+        got, geo = _run(G, xs, 44100, 48000, ch, None, filt, freq, gains)
+    assert geo["mix_first"] == 1 and geo["general_kernel"] == 0
+    assert len(got) == len(ref)
+    assert float(np.max(np.abs(got - ref))) <= TOL
+    with knobs(RH_NO_MIX_FIRST="1"):  # the per-source path of the same handle type: the two agree far inside the tolerance
+        per_source, geo2 = _run(G, xs, 44100, 48000, ch, None, filt, freq, gains)
+    assert geo2["mix_first"] == 0
+    assert float(np.max(np.abs(got - per_source))) <= 2e-6
+
+
+@pytest.mark.parametrize("frm,to", [(48000, 44100), (48000, 48000), (22050, 48000), (192000, 44100)])
+@pytest.mark.parametrize("span", [None, 32768, 3000])
+def test_mix_first_rates_and_spans(G, O, frm, to, span):
+    # the seams of spanned sources (uniform.rs:50-68: the converter restarts, the last frame of a span is emitted verbatim) are
+    # the same for every source of the batch: they commute with the sum like the rest of the converter
+    S, n, ch = 6, 80000, 2
+    xs = [rnd(6200 + s, n * ch, 0.15) for s in range(S)]
+    ref = _oracle(O, xs, frm, to, span, "low_pass", 200, None, ch)
+    got, geo = _run(G, xs, frm, to, ch, span, "low_pass", 200, None)
+    assert geo["mix_first"] == 1
+    assert len(got) == len(ref)
+    assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+def test_mix_first_does_not_apply_where_it_would_change_bits_or_cannot(G, O):
+    import torch
+
+    S, n = 4, 20000
+    xs = [rnd(6300 + s, n * 2, 0.2) for s in range(S)]
+    # without a filter the batch is rodio's ordered sum of converted samples, bit for bit: it stays per source
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, None, 0, 0.5, max_sources=S, max_in_frames=n)
+    p.set_sources([torch.from_numpy(x).cuda() for x in xs])
+    assert p.geometry()["mix_first"] == 0
+    m = O.Mixer(2, 48000)
+    for x in xs:
+        m.add(O.UniformSourceIterator(O.TestSource(x, 2, 44100), 2, 48000))
+    assert np.array_equal(p.run().cpu().numpy(), m.collect())
+    p.close()
+    # sources of different lengths end at different frames (each one's last frame is emitted verbatim): not one stream
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+    p.set_sources([torch.from_numpy(x[: 2 * (n - 1000 * s)]).cuda() for s, x in enumerate(xs)])
+    assert p.geometry()["mix_first"] == 0
+    p.close()
+    # a single source is its own mix
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+    p.set_sources([torch.from_numpy(xs[0]).cuda()])
+    assert p.geometry()["mix_first"] == 0
+    got = p.run().cpu().numpy()
+    ref = O.UniformSourceIterator(O.TestSource(xs[0], 2, 44100), 2, 48000).low_pass(200).collect()
+    assert float(np.max(np.abs(got - ref))) <= TOL
+    p.close()
+
+
+def _truth(xs, frm, to, ch, kind, freq):
+    """The same chain in float64: linear interpolation at rodio's positions (sample_rate.rs:131-201: frame floor(m*F/T), weight
+    (m*F mod T)/T, the last frame verbatim), the biquad with rodio's f32 coefficients (blt.rs:558-560), the sum."""
+    import math
+
+    import rodio_amd
+    from scipy.signal import lfilter
+
+    g = math.gcd(frm, to)
+    F, T = frm // g, to // g
+    n = len(xs[0]) // ch
+    M = ((n - 1) * T + F - 1) // F + 1 if F != T else n
+    m = np.arange(M, dtype=np.int64)
+    i = np.minimum(m * F // T, n - 1)
+    w = ((m * F) % T).astype(np.float64) / T
+    j = np.minimum(i + 1, n - 1)
+    co = [float(v) for v in rodio_amd.biquad_coeffs(kind, int(freq), 0.5, to)]
+    out = np.zeros((M, ch))
+    for x in xs:
+        f = x.astype(np.float64).reshape(n, ch)
+        lerp = f[i] + (f[j] - f[i]) * w[:, None]
+        out += lfilter(co[:3], [1.0, co[3], co[4]], lerp, axis=0)
+    return out.reshape(-1)
+
+
+def test_mix_first_full_scale_sources(G, O):
+    # 64 sources at full scale: the input-rate mix reaches ~15 before the filter takes the band above 200 Hz away again.  rodio's
+    # f32 recurrence and any other evaluation order of the same filter are both ~1e-5 x peak away from the exact response at this
+    # cutoff (poles at 0.974: rounding is amplified by 1 / (1 - p)^2), so the contract is the one of the other time-parallel
+    # filters (test_host_mirror.py): together within 2e-5 per unit of peak, and no further from the float64 response than the
+    # reference itself (x 2 + 1e-7).
+    S, n = 64, 40000
+    xs = [rnd(6400 + s, n * 2, 1.0) for s in range(S)]
+    ref = _oracle(O, xs, 44100, 48000, None, "low_pass", 200, None, 2)
+    got, geo = _run(G, xs, 44100, 48000, 2, None, "low_pass", 200, None)
+    assert geo["mix_first"] == 1
+    peak = max(1.0, float(np.max(np.abs(ref))))
+    assert float(np.max(np.abs(got - ref))) <= 2 * TOL * peak
+    truth = _truth(xs, 44100, 48000, 2, "low_pass", 200)
+    assert len(truth) == len(ref)
+    e_ref, e_gpu = float(np.max(np.abs(ref - truth))), float(np.max(np.abs(got - truth)))
+    assert e_gpu <= 2.0 * e_ref + 1e-7 * peak, (e_gpu, e_ref)
+
+
+# ---- k_rlm_chunk: mix first in one kernel, for stereo rows of at least 2 x 256 chunks of 1024 frames ---------------------------------
+@pytest.mark.parametrize("frm,to,span,n,want", [
+    (44100, 48000, None, 600000, 2), (44100, 48000, 32768, 600000, 2), (44100, 48000, 3000, 524288, 2), (48000, 44100, None, 700001 - 1, 2),
+    (48000, 48000, None, 600000, 2), (48000, 32000, 5000, 600000, 2),
+    (96000, 44100, 5000, 600000, 1),   # more than 2 input frames per output frame: the filter's look-back leaves the 4 frames in front of a chunk
+    (44100, 48000, None, 600001, 1),   # an odd length: not whole 16-byte vectors -> the two-launch form
+    (22050, 48000, None, 600000, 1),   # more than 64 x 18 output frames per chunk -> the two-launch form
+    (44100, 48000, None, 200000, 1),   # too few chunks to fill the chip -> the two-launch form
+])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
+def test_chunk_kernel_equals_rodio_chain(G, O, frm, to, span, n, want, filt, freq):
+    S, ch = 3, 2
+    xs = [rnd(6500 + s, n * ch, 0.3) for s in range(S)]
+    gains = np.array([1.0, 0.5, -0.75], dtype=np.float32)
+    ref = _oracle(O, xs, frm, to, span, filt, freq, gains, ch)
+    got, geo = _run(G, xs, frm, to, ch, span, filt, freq, gains)
+    assert geo["mix_first"] == want, geo
+    assert len(got) == len(ref)
+    err = np.abs(got - ref)
+    assert float(np.max(err)) <= TOL, (int(np.argmax(err)), float(np.max(err)))
+    if want == 2:
+        with knobs(RH_NO_CHUNK="1"):  # the two-launch form of the same sum: the two agree far inside the tolerance
+            two, geo2 = _run(G, xs, frm, to, ch, span, filt, freq, gains)
+        assert geo2["mix_first"] == 1
+        assert float(np.max(np.abs(got - two))) <= 2e-6
+
+
+def test_chunk_kernel_many_sources_and_low_cutoff(G, O):
+    # 40 sources; a 30 Hz high-pass: poles at 0.996, the carry reaches back over 7 tiles, and rounding is amplified by
+    # 1 / (1 - p)^2 = 65 000 -- rodio's f32 recurrence is 1e-4 away from the exact response here, and so is every other f32
+    # evaluation of this filter (the per-source kernels too).  The contract is the truth-relative one (see above).
+    S, n = 40, 540000
+    xs = [rnd(6600 + s, n * 2, 0.05) for s in range(S)]
+    ref = _oracle(O, xs, 44100, 48000, None, "high_pass", 30, None, 2)
+    got, geo = _run(G, xs, 44100, 48000, 2, None, "high_pass", 30, None)
+    assert geo["mix_first"] == 2
+    truth = _truth(xs, 44100, 48000, 2, "high_pass", 30)
+    assert len(truth) == len(ref) == len(got)
+    e_ref, e_gpu = float(np.max(np.abs(ref - truth))), float(np.max(np.abs(got - truth)))
+    assert e_gpu <= 2.0 * e_ref + 1e-7, (e_gpu, e_ref)
+    with knobs(RH_NO_CHUNK="1"):
+        two, _ = _run(G, xs, 44100, 48000, 2, None, "high_pass", 30, None)
+    assert float(np.max(np.abs(two - truth))) <= 2.0 * e_ref + 1e-7

@@ -99,6 +99,44 @@ __global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint3
     out[(uint64_t)tile * 64 + lane] = acc.x + acc.y;
 }
 
+// "Mix first" inside one kernel: tile t owns the ALIGNED 8 KiB chunk t of every source (8 full instructions) and needs one
+// 128-byte line on either side of it (the neighbours' taps): a ninth instruction whose lanes 0..7 / 8..15 fetch the line
+// before / after the chunk, the other lanes clamped onto the last of them.  HALO = 0: without the ninth instruction.
+template <int NS, int HALO>
+__global__ __launch_bounds__(64) void k_halo(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KV = 8 + HALO;
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS unsigned char *)smem;
+    uint32_t off[KV];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) off[kk] = (tile * 512u + kk * 64u + lane) * 4;
+    if (HALO) {
+        const uint32_t l = lane < 16 ? lane : 15;
+        int64_t v = l < 8 ? (int64_t)tile * 512 - 8 + l : (int64_t)tile * 512 + 512 + (l - 8);
+        if (v < 0) v = 0;
+        if (v >= (int64_t)n_chunks * 512) v = (int64_t)n_chunks * 512 - 1;
+        off[KV - 1] = (uint32_t)v * 4;
+    }
+    auto issue = [&](uint32_t s) {
+        const float *g = in + (uint64_t)s * src_stride_f;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (s % NS) * KV * 1024);
+#pragma unroll
+        for (int kk = 0; kk < KV; ++kk) glds16(g + off[kk], dst + kk * 1024);
+    };
+    for (uint32_t s = 0; s < NS - 1 && s < S; ++s) issue(s);
+    v2f acc = {0.f, 0.f};
+    for (uint32_t s = 0; s < S; ++s) {
+        if (s + NS - 1 < S) { issue(s + NS - 1); wait_vm<KV *(NS - 1)>(); } else wait_vm<0>();
+        const LDS unsigned char *st = (const LDS unsigned char *)smem + (s % NS) * KV * 1024;
+#pragma unroll
+        for (int q = 0; q < KV * 2; ++q) acc += *(const LDS v2f *)(st + (q * 64 + lane) * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    out[(uint64_t)tile * 64 + lane] = acc.x + acc.y;
+}
+
 template <int KV, int NS, int WAVES>
 void run(const float *d_in, float *d_out, uint32_t S, uint64_t total_tiles, uint64_t src_stride_f, int flops) {
     const uint32_t blocks = total_tiles / WAVES;
@@ -155,6 +193,27 @@ int main(int argc, char **argv) {
             const double bytes = (double)S * ((double)(tiles - 1) * vstride + nvec) * 16.0;
             printf("%-34s tiles %5u vstride %4u nvec %4u lds %6zu : %.3f ms  %.0f GB/s (distinct bytes)\n", name, tiles, vstride, nvec, lds, best, bytes / best / 1e6);
         };
+        auto timeh = [&](const char *name, auto kern, size_t lds) {
+            CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(1024), dim3(64), lds, 0, d_in, d_out, S, stride, 1024u);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            printf("%-34s lds %6zu : %.3f ms  %.0f GB/s (2 GiB)\n", name, lds, best, 2147483648.0 / best / 1e6);
+        };
+        timeh("aligned 8 KiB, no halo, ring 2", k_halo<2, 0>, 2 * 8 * 1024);
+        timeh("aligned 8 KiB + halo instr, ring 2", k_halo<2, 1>, 2 * 9 * 1024);
+        timeh("aligned 8 KiB + halo, ring 2, 40K", k_halo<2, 1>, 40960);
+        timeh("aligned 8 KiB + halo instr, ring 3", k_halo<3, 1>, 3 * 9 * 1024);
         timeit("aligned 8 KiB chunks KV8", k_mimic<8, 2>, 1024, 16384, 512, 512);
         timeit("aligned 9 KiB chunks KV9", k_mimic<9, 2>, 910, 18432, 576, 576);
         timeit("R18 pattern KV9 (clamped tail)", k_mimic<9, 2>, 991, 18432, 529, 533);
