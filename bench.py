@@ -294,7 +294,7 @@ def headline(args, argv):
         child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
         child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
         # (a ragged batch and a mix-first batch are two kernels per launch: the sum over both, per call)
-        two = bool(geo["ragged_pair"]) or bool(geo.get("mix_first"))
+        two = bool(geo["ragged_pair"]) or geo.get("mix_first") == 1
         traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, ["%k_rlm%", "%k_mix_%"], per_call=two)
         ph = pipe.phase_cycles()
         if ph is not None:
@@ -303,7 +303,7 @@ def headline(args, argv):
         geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
         if tuned:
             geo["autotuned"] = True
-        kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
+        kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_chunk" if geo.get("mix_first") == 2 else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
         res = {
             "metric": "Msamples/s through resample+low_pass+mix pipeline",
             "value": in_samples * world * args.steps / dt / 1e6,

@@ -343,6 +343,11 @@ typedef struct rh_rlm_config {
     uint32_t no_balance;      /* diagnostics: 1 = do not pad the LDS request to even out waves per CU */
     uint32_t force_general;   /* diagnostics/tests: 1 = use the ragged-batch kernel even for equal lengths */
     float custom_coeffs[5];   /* filter_kind 2: {b0,b1,b2,a1,a2}, already divided by a0 */
+    uint32_t filter_first;    /* 1 = `mixer.add(src.low_pass(f))`: the filter runs on every source BEFORE the converter, at from_rate (source/mod.rs:255-275:
+                               * a filter takes its sample rate from its input; mixer.rs:58-66 converts what it is given).  0 = the benchmark's spelling,
+                               * `mixer.add(UniformSourceIterator::new(src, ..).low_pass(f))`: convert, then filter at to_rate.  With 1, one-shot runs of
+                               * equal-length batches (sum the sources, filter that one stream, convert it: three linear stages, compared at 1e-5);
+                               * rh_rlm_run on sources of different lengths and the rh_rlm_stream_* calls return RH_ERR_UNSUPPORTED. */
 } rh_rlm_config;
 typedef struct rh_rlm rh_rlm;
 rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg);

@@ -48,7 +48,7 @@ class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
                 ("filter_q", C.c_float), ("max_sources", C.c_uint32), ("max_in_frames", C.c_uint64),
-                ("frames_per_lane", C.c_uint32), ("ring_stages", C.c_uint32), ("no_balance", C.c_uint32), ("force_general", C.c_uint32), ("custom_coeffs", C.c_float * 5)]
+                ("frames_per_lane", C.c_uint32), ("ring_stages", C.c_uint32), ("no_balance", C.c_uint32), ("force_general", C.c_uint32), ("custom_coeffs", C.c_float * 5), ("filter_first", C.c_uint32)]
 
 
 class RlmGeometry(C.Structure):

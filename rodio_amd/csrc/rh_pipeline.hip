@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params 
 // =================================================================================================
 template <int U>
 __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
-                                                  const uint32_t frames, const uint32_t out_frames) {
+                                                  const uint32_t frames, const uint32_t out_frames, const float *desc_row) {
     typedef __attribute__((address_space(4))) const uint64_t cu64;
     typedef __attribute__((address_space(4))) const float cf32;
     typedef RH_GLB const v4f glb_cf4;
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
             y[t] = a;
         }
         if (threadIdx.x == 0) {  // the one-entry descriptor table the fused launch behind this one reads
-            ydesc->data = y;
+            ydesc->data = desc_row;  // the row the launch behind this one reads: the mix, or what a filter makes of it
             ydesc->frames = frames;
             ydesc->out_frames = out_frames;
             ydesc->gain = 1.0f;
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
 // and accumulates.  A row of n_floats gives ceil(n_floats / 2048) waves: for rows that fill the chip (the host decides).
 template <int NS>
 __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
-                                                 const uint32_t frames, const uint32_t out_frames) {
+                                                 const uint32_t frames, const uint32_t out_frames, const float *desc_row) {
     constexpr int KV = 8;
     constexpr uint32_t kStage = KV * 1024;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * kStage];
@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ src
             y[t] = a;
         }
         if (lane == 0) {
-            ydesc->data = y;
+            ydesc->data = desc_row;  // the row the launch behind this one reads: the mix, or what a filter makes of it
             ydesc->frames = frames;
             ydesc->out_frames = out_frames;
             ydesc->gain = 1.0f;
@@ -1674,6 +1674,24 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     const uint32_t m0 = m_lo + (uint32_t)lane * R;
     const int nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);  // frames of this lane's run
     const bool first = (m0 == 0);                              // stream start: x'[-1] = x'[-2] = 0
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+
+    // ---- the sum of chunk `tile` of every source (k_mix_ring) ----
+    const uint32_t nvec = Ns / 2;  // 16-byte vectors of a row (host: Ns even)
+    const uint32_t v0 = tile * (KV * 64);
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = v0 + (uint32_t)k * 64 + lane;
+        j = j < nvec ? j : nvec - 1;  // past the end of the row: its last vector again (finite, never a tap of a stored frame)
+        goff[k] = j * 16;
+    }
+    auto stage_source = [&](uint32_t s_, uint32_t stage) {
+        const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+    };
+    if (S) stage_source(0, 0);  // the first chunk is on its way while the lane works out its taps
     // ---- taps and weights of the lane's R + 2 frames: LDS offsets into [halo | chunk] ----
     int offA[R + 2];
     float wgt[R + 2];
@@ -1697,28 +1715,10 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             if (!dummy) cursor_next(c, p);
         }
     }
-    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
-
-    // ---- the sum of chunk `tile` of every source (k_mix_ring) ----
-    const uint32_t nvec = Ns / 2;  // 16-byte vectors of a row (host: Ns even)
-    const uint32_t v0 = tile * (KV * 64);
-    uint32_t goff[KV];
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-        uint32_t j = v0 + (uint32_t)k * 64 + lane;
-        j = j < nvec ? j : nvec - 1;  // past the end of the row: its last vector again (finite, never a tap of a stored frame)
-        goff[k] = j * 16;
-    }
-    auto stage_source = [&](uint32_t s_, uint32_t stage) {
-        const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
-#pragma unroll
-        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
-    };
     v4f acc[KV];
 #pragma unroll
     for (int k = 0; k < KV; ++k) acc[k] = v4f{0.f, 0.f, 0.f, 0.f};
     {
-        if (S) stage_source(0, 0);
         uint32_t st = 0;
         float g_next = S ? dgain[4] : 0.f;
         for (uint32_t s_ = 0; s_ < S; ++s_) {
@@ -2381,6 +2381,8 @@ struct rh_rlm {
     float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
     size_t mix_floats = 0;
     ChunkPlan chunk;            // mix first in one kernel (k_rlm_chunk)
+    bool pre_filter = false;    // cfg.filter_first: the filter runs at from_rate in front of the converter (the fused kernels then run without one)
+    float pre_coeffs[5] = {1.f, 0.f, 0.f, 0.f, 0.f};
     unsigned long long *d_prof = nullptr;
     uint32_t n_sources = 0, n_tiles = 0;
     uint64_t out_frames = 0;
@@ -2768,7 +2770,23 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     p->chunk_in = g.n_chunks > 1 ? g.chunk_in : 0;
     p->chunk_out = g.n_chunks > 1 ? g.chunk_out : 0;
     p->filt = cfg->filter_kind >= 0;
-    if (cfg->filter_kind == 2) {  // coefficients given ({b0,b1,b2,a1,a2}, already divided by a0)
+    if (cfg->filter_first && p->filt) {  // mixer.add(src.low_pass(f)): coefficients at the SOURCE rate; the converter behind it runs bare
+        if (cfg->filter_kind == 2) {
+            for (int k = 0; k < 5; ++k) p->pre_coeffs[k] = cfg->custom_coeffs[k];
+        } else {
+            st = rh_biquad_coeffs(cfg->filter_kind, cfg->filter_freq, cfg->filter_q, cfg->from_rate, p->pre_coeffs);
+            if (st != RH_OK) {
+                delete p;
+                return st;
+            }
+        }
+        p->pre_filter = true;
+        p->filt = false;
+    }
+    if (p->pre_filter) {
+        p->coeffs[0] = 1.f;
+        p->coeffs[1] = p->coeffs[2] = p->coeffs[3] = p->coeffs[4] = 0.f;
+    } else if (cfg->filter_kind == 2) {  // coefficients given ({b0,b1,b2,a1,a2}, already divided by a0)
         for (int k = 0; k < 5; ++k) p->coeffs[k] = cfg->custom_coeffs[k];
         const double a1 = p->coeffs[3], a2 = p->coeffs[4];  // stability triangle: the look-back needs a decaying filter
         if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2)) {
@@ -3045,9 +3063,12 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         RH_CHECK_LAUNCH();
         return mark_launch(p, s);
     }
-    if (mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0)) {
+    const bool pre = p->pre_filter;
+    if (pre && (&pl != &p->fast || sa.mode || batch_streams)) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs of equal-length batches (rodio_hip.h)
+    if (pre || mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0)) {
         const uint64_t n_floats = (uint64_t)p->eq_frames * p->cfg.channels;
-        const size_t need = (size_t)((n_floats + 3) & ~3ull) + 64;  // the row (16-byte vectors), then the descriptor on its own 128 bytes
+        const size_t row = (size_t)((n_floats + 3) & ~3ull);
+        const size_t need = row * (pre ? 2 : 1) + 64;  // the mixed row (16-byte vectors) [, the filtered row], then the descriptor on its own 128 bytes
         if (need > p->mix_floats) {
             const rh_status w = wait_idle(p);
             if (w != RH_OK) return w;
@@ -3057,6 +3078,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
             p->mix_floats = need;
         }
         SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32));
+        float *const frow = pre ? p->d_mix + row : p->d_mix;  // the row the fused launch reads
         int U = 4;  // measured (256 x 1 Mi stereo frames): 0.410 / 0.409 / 0.342 ms for 1 / 2 / 4 vectors per lane
         if (const char *u = rh::knob(rh::K_MIX_U)) U = atoi(u);
         const uint64_t nvec = n_floats / 4;
@@ -3065,12 +3087,17 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         const uint64_t ring_waves = (nvec + 511) / 512;  // 8 KiB chunks
         int ring = ring_waves >= 2ull * rh::g_num_cus ? 2 : 0;  // ring depth; 0: the vector-load kernel (short rows: more, smaller pieces)
         if (const char *u = rh::knob(rh::K_MIX_U)) ring = atoi(u) >= 10 ? atoi(u) - 10 : 0;  // tuning aid: 12 / 13 = ring of 2 / 3 stages, 1 / 2 / 4 = vector loads
-        if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
-        else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
-        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
-        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
-        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, p->eq_frames, (uint32_t)p->out_frames);
+        const uint32_t nf = p->eq_frames, mf = (uint32_t)p->out_frames;
+        if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
+        else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
+        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
+        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
+        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
         RH_CHECK_LAUNCH();
+        if (pre) {  // the filter of `src.low_pass(f)`, at from_rate, on the mix (time-parallel: rh_biquad mode 1, zero state)
+            const rh_status fs = rh_biquad(frow, p->d_mix, p->eq_frames, p->cfg.channels, 1, p->pre_coeffs, nullptr, 1, stream);
+            if (fs != RH_OK) return fs;
+        }
         k.srcs = ydesc;
         k.n_sources = 1;
         // every tile of the one-stream launch resident at once: no tickets (see Params::direct)
@@ -3213,6 +3240,7 @@ static uint64_t stream_first_tap(uint64_t m, uint64_t F, uint64_t T, uint64_t ci
 rh_status rh_rlm_stream_begin(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
+    if (p->pre_filter) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs only (rodio_hip.h)
     p->st_chunk_in = p->st_chunk_out = 0;
     if (p->cfg.span_len != 0) {  // sources that report spans of span_len samples: the converter restarts every min(span_len, 32768) samples (uniform.rs:56-67)
         const uint64_t span = p->cfg.span_len < 32768 ? p->cfg.span_len : 32768;
@@ -3496,7 +3524,7 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     info->n_tiles = p->n_tiles;
     info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
     info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
-    info->mix_first = mix_first_applies(p, pl, p->n_sources, false, false) ? (p->chunk.ok ? 2u : 1u) : 0u;
+    info->mix_first = (p->pre_filter && p->plan == &p->fast) ? 1u : mix_first_applies(p, pl, p->n_sources, false, false) ? (p->chunk.ok ? 2u : 1u) : 0u;
     return RH_OK;
 }
 

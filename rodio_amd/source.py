@@ -626,11 +626,12 @@ class ResampleLowpassMix:
     current_span_len() (None/0 = continuous)."""
 
     def __init__(self, from_rate, to_rate, channels=2, span_len=None, filter="low_pass", freq=200, q=0.5,
-                 max_sources=256, max_in_frames=1 << 20, frames_per_lane=0, ring_stages=0, no_balance=0, force_general=0):
+                 max_sources=256, max_in_frames=1 << 20, frames_per_lane=0, ring_stages=0, no_balance=0, force_general=0, filter_first=False):
         _ensure()
         kind = {"low_pass": 0, "high_pass": 1, None: -1, "none": -1}[filter]
         self.cfg = RlmConfig(from_rate, to_rate, channels, int(span_len or 0), kind, freq, q, max_sources,
                              max_in_frames, frames_per_lane, ring_stages, no_balance, force_general)
+        self.cfg.filter_first = 1 if filter_first else 0  # `mixer.add(src.low_pass(f))`: filter at from_rate, then convert (rodio_hip.h)
         self._h = C.c_void_p()
         check(lib.rh_rlm_create(C.byref(self._h), C.byref(self.cfg)), "rh_rlm_create")
         self.channels = channels

@@ -726,7 +726,7 @@ impl GpuMixer {
         let cfg = RhRlmConfig {
             from_rate: from, to_rate: self.rate, channels: 2, span_len: 0, filter_kind: self.opt.filter_kind, filter_freq: self.opt.filter_freq, filter_q: self.opt.filter_q,
             max_sources: g.srcs.len() as u32, max_in_frames: if staged { g.crow } else { self.cap_frames as u64 },
-            frames_per_lane: self.opt.frames_per_lane, ring_stages: 0, no_balance: 0, force_general: 0, custom_coeffs: [0.0; 5],
+            frames_per_lane: self.opt.frames_per_lane, ring_stages: 0, no_balance: 0, force_general: 0, custom_coeffs: [0.0; 5], filter_first: 0,
         };
         ck(unsafe { rh_rlm_create(&mut g.plan, &cfg) }, "rh_rlm_create");
         // staged: the factor sits in front of the converter, where Mixer::add(src.amplify(g)) has it

@@ -214,3 +214,34 @@ def test_chunk_kernel_many_sources_and_low_cutoff(G, O):
     with knobs(RH_NO_CHUNK="1"):
         two, _ = _run(G, xs, 44100, 48000, 2, None, "high_pass", 30, None)
     assert float(np.max(np.abs(two - truth))) <= 2.0 * e_ref + 1e-7
+
+
+# ---- rh_rlm_config.filter_first: `mixer.add(src.low_pass(f))` -- the filter at the source's rate, in front of the converter -------------
+@pytest.mark.parametrize("frm,to,n", [(44100, 48000, 50000), (48000, 44100, 30001), (44100, 48000, 600000)])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("low_pass", 1000), ("high_pass", 300)])
+def test_filter_before_the_converter(G, O, frm, to, n, filt, freq):
+    import torch
+
+    S, ch = 5, 2
+    xs = [rnd(6700 + s, n * ch, 0.2) for s in range(S)]
+    gains = np.array([1.0, 0.5, -0.75, 0.25, 1.5], dtype=np.float32)
+    m = O.Mixer(ch, to)
+    for x, g in zip(xs, gains):  # source/mod.rs:255-275: the filter takes the rate of its input; mixer.rs:58-66 converts what it is given
+        src = O.TestSource(x, ch, frm).amplify(float(g))
+        m.add(O.UniformSourceIterator(src.low_pass(freq) if filt == "low_pass" else src.high_pass(freq), ch, to))
+    ref = m.collect()
+    p = G.ResampleLowpassMix(frm, to, ch, None, filt, freq, 0.5, max_sources=S, max_in_frames=n, filter_first=True)
+    p.set_gains(gains)
+    p.set_sources([torch.from_numpy(x).cuda() for x in xs])
+    got = p.run().cpu().numpy()
+    p.check_status()
+    assert len(got) == len(ref)
+    assert float(np.max(np.abs(got - ref))) <= TOL
+    # the other order is a different signal (the benchmark's spelling: convert, then filter at the mixer's rate)
+    other = _oracle(O, xs, frm, to, None, filt, freq, gains, ch)
+    assert float(np.max(np.abs(other - ref))) > 10 * TOL
+    # sources of different lengths: not with this flag
+    p.set_sources([torch.from_numpy(x[: 2 * (n - 100 * s)]).cuda() for s, x in enumerate(xs)])
+    with pytest.raises(Exception):
+        p.run()
+    p.close()
