@@ -1670,9 +1670,12 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     const uint32_t tile = blockIdx.x;
     const uint32_t Ns = p.eq_frames, S = p.n_sources;
     const uint32_t m_lo = ((cu32 *)(uintptr_t)q.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q.m_lo)[tile + 1];
-    const uint32_t n_t = m_hi - m_lo;                          // <= 64 * R (host)
     const uint32_t m0 = m_lo + (uint32_t)lane * R;
-    const int nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);  // frames of this lane's run
+    int nfl;  // frames of this lane's run
+    {
+        const uint32_t n_t = m_hi - m_lo;  // <= 64 * R (host)
+        nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);
+    }
     const bool first = (m0 == 0);                              // stream start: x'[-1] = x'[-2] = 0
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
@@ -1853,6 +1856,10 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         mat_acc(b31, sq[2], sq[3], Pq[2], Pq[3]);
     }
     {  // the tile aggregate: the short last run on top of the inclusive prefix of the lane before it
+        // (the tile's bounds are read again here rather than kept in scalar registers across the source loop)
+        uint32_t tile_again = tile;
+        asm volatile("" : "+s"(tile_again));
+        const uint32_t n_t = ((cu32 *)(uintptr_t)q.m_lo)[tile_again + 1] - ((cu32 *)(uintptr_t)q.m_lo)[tile_again];
         const int nl = (int)((n_t + R - 1) / R);  // lanes with frames (uniform)
         float A[4] = {0.f, 0.f, 0.f, 0.f};
         if (nl >= 1) {
