@@ -28,9 +28,9 @@
 //
 // What a chain costs: ONE wave walks time for 64 streams, and a lone wave issues one instruction every 5-7 cycles whatever its
 // kind (measured: SQ_WAVE_CYCLES / instructions), so the chain wave carries nothing but the chain -- wave 0 issues LDS reads,
-// the chain's arithmetic and LDS writes; waves 1 and 2 keep the next six chunks (32 samples per stream each) of the two inputs
-// coming by LDS-DMA (a chain is also bound by memory LATENCY: 1.6 us per round trip when one workgroup is all that runs);
-// wave 3 writes the previous chunk's results back.  Transfers are whole 128-byte lines through the swizzled tile image of
+// the chain's arithmetic and LDS writes; waves 1 to 4 keep the next six chunks (32 samples per stream each) of the two inputs
+// coming by LDS-DMA, half an array each (an LDS-DMA issue costs its wave 100-300 cycles, and a chain is also bound by memory
+// LATENCY: 1.6 us per round trip when one workgroup is all that runs); wave 5 writes the previous chunk's results back.  Transfers are whole 128-byte lines through the swizzled tile image of
 // rh_scan_common.h: the chain wave reads and writes its 16-byte vectors without bank conflicts.  One barrier per chunk.
 #include <cmath>
 #include <cstdlib>
