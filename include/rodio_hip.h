@@ -53,7 +53,8 @@ rh_status rh_device_name(char *buf, size_t cap);
 /* The handle-less time-parallel kernels (rh_limit, rh_biquad mode 1) wait for hand-offs between their tiles with a bound.
  * A wait that expires (never seen on a healthy device) poisons the tile with NaN and sets a sticky word on the device:
  * RH_ERR_TIMEOUT here, once, then RH_OK again.  Covers the launches that have COMPLETED (synchronise the stream or an event
- * recorded behind them first); does not wait for anything itself.  (Handles have their own: rh_rlm_last_status.) */
+ * recorded behind them first); does not wait for anything itself.  (Handles have their own: rh_rlm_last_status.)  One word per
+ * device (the one rh_init last bound), shared by every chain on it: the call that reads it first gets the report. */
 rh_status rh_async_status(void);
 rh_status rh_malloc(void **out, size_t bytes);
 rh_status rh_free(void *p);

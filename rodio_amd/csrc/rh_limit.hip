@@ -694,7 +694,9 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 }
 
 template <int C, int R, int NW, bool SKEW>
-__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
+// (occupancy bound: 4 workgroups per CU where the registers allow it without a spill -- 4 channels x 4 frames do not: a spill is a
+// vector-memory operation of the compiler's own inside the counted waits of the LDS-DMA; tests/test_code_objects.py checks)
+__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
     static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW, "a lane's run is whole 16-byte vectors");
     constexpr int V = C * R / 4;  // 16-byte vectors per lane; a wave's share of a tile is V KiB
     constexpr uint32_t L = 64u * R, LW = L * NW;

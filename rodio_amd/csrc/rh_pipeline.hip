@@ -347,7 +347,7 @@ __device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x :
 __device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
 
 template <int R, int KV, int NS, bool FILT, bool RAG = false, int C = 2>
-__global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {
+__global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {  // (no spills: tests/test_code_objects.py)
     typedef Chan<C> CH;
     typedef typename CH::V V;
     constexpr uint32_t FB = CH::kFB, VF = CH::kVF;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? 5 : R <= 6 ? 3 : R <= 12 ? 2 : 1)) vo
 
 // (C = 1: the frames are mono; the per-source aggregates keep their 4-word slots, the second channel's words travel as zeros)
 template <int R, int KV, int NS, bool FILT, int C = 2>
-__global__ __launch_bounds__(64, (R <= 8 ? 3 : 2)) void k_rlm_wave(const Params p) {
+__global__ __launch_bounds__(64, (R <= 8 && KV <= 5 ? 3 : 2)) void k_rlm_wave(const Params p) {  // (no spills: tests/test_code_objects.py)
     typedef Chan<C> CH;
     typedef typename CH::V V;
     constexpr uint32_t FB = CH::kFB, VF = CH::kVF;

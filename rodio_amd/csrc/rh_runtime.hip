@@ -157,9 +157,14 @@ rh_status rh_init(int32_t device) {
     }
     rh::g_num_cus = prop.multiProcessorCount;
     rh::g_device = device;
-    if (!rh::g_async_status) {
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&rh::g_async_status), 128));
-        RH_HIP_TRY(rh::fill_now(rh::g_async_status, 0, 128));
+    {  // the sticky failure word of the handle-less scan kernels lives on the device it reports about: one per device ever bound
+        static uint32_t *per_device[64] = {nullptr};
+        if (device >= 64) return RH_ERR_UNSUPPORTED;
+        if (!per_device[device]) {
+            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&per_device[device]), 128));
+            RH_HIP_TRY(rh::fill_now(per_device[device], 0, 128));
+        }
+        rh::g_async_status = per_device[device];
     }
     rh::g_initialized = true;
     return RH_OK;
