@@ -1694,7 +1694,22 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 #pragma unroll
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
     };
-    if (S) stage_source(0, 0);  // the first chunk is on its way while the lane works out its taps
+    if (S) stage_source(0, 0);  // the first two chunks are on their way while the lane works out its taps
+    if (S > 1) stage_source(1, 1);
+    // the lane's rows of the filter tables and its look-back weight: fetched here, a source loop away from their use
+    const Tables *__restrict__ tb = p.tabs;
+    float lM[4], b15[4], b31[4], kM[4];
+    {
+        const uint32_t Jc0 = p.J < tile ? p.J : tile;
+        const float *kp = q.lookT + ((uint64_t)tile * p.J + ((uint32_t)lane < Jc0 ? lane : 0)) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lM[k] = tb->laneM[lane][k];
+            b15[k] = tb->bc15M[lane][k];
+            b31[k] = tb->bc31M[lane][k];
+            kM[k] = kp[k];
+        }
+    }
     // ---- taps and weights of the lane's R + 2 frames: LDS offsets into [halo | chunk] ----
     int offA[R + 2];
     float wgt[R + 2];
@@ -1703,6 +1718,11 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         Cursor c = cursor_at(first ? 0 : m0 - 2, p);
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
+#if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 2
+            offA[rr] = (int)MB + rr * 8;
+            wgt[rr] = 0.5f;
+            continue;
+#endif
             const bool dummy = first && rr < 2;
             uint64_t i;
             uint32_t num;
@@ -1727,17 +1747,16 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         for (uint32_t s_ = 0; s_ < S; ++s_) {
             const float g = g_next;
             g_next = s_ + 1 < S ? dgain[8 * (uint64_t)(s_ + 1) + 4] : 0.f;
-            if (s_ + 1 < S) {
-                stage_source(s_ + 1, st ^ 1u);
-                wait_vm<KV>();
-            } else {
-                wait_vm<0>();
-            }
+            // source s_ has landed when at most the group behind it is outstanding (compiler-issued loads in between only make
+            // the wait stricter)
+            if (s_ + 1 < S) wait_vm<KV>();
+            else wait_vm<0>();
             const lds_u8 *buf = lds + st * kStage;
             v4f v[KV];
 #pragma unroll
             for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(buf + k * 1024 + lane * 16);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage may be re-targeted by the next DMA
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk is in registers: its stage is free ...
+            if (s_ + 2 < S) stage_source(s_ + 2, st);           // ... for the source after next, requested before this one is summed
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 acc[k].x = fma_(g, v[k].x, acc[k].x);
@@ -1748,16 +1767,28 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             st ^= 1u;
         }
     }
-    // ---- the mixed chunk into the LDS; its last 4 frames to the tile behind; the last 4 frames of the tile in front ----
+#ifdef RH_CHUNK_DIAG  // diagnostics builds (tools/build_variant.sh): the source loop alone (+ the tap prologue unless RH_CHUNK_DIAG == 2)
+    {
+        float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < KV; ++k) *(lds_f4 *)(lds + MB + (uint32_t)(k * 64 + lane) * 16) = acc[k];
-    if (lane == 0) *(lds_f4 *)(lds + MB + kStage) = v4f{0.f, 0.f, 0.f, 0.f};  // the second tap of a verbatim last frame at the end of a chunk: finite, weight 0
+        for (int k = 0; k < KV; ++k) t += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) t += wgt[rr] + (float)offA[rr];
+        p.out[(uint64_t)tile * 64 + lane] = t + lM[0] + b15[0] + b31[0] + kM[0] + (float)nfl + (first ? 1.f : 0.f);
+        return;
+    }
+#endif
+    // ---- the chunk's last 4 mixed frames to the tile behind (first: it is waiting for them); the mixed chunk into the LDS; the
+    // last 4 frames of the tile in front ----
     if (lane >= 62) {  // vectors 510, 511 of the chunk = frames P-4 .. P-1
         unsigned long long *hp = q.halo + (uint64_t)tile * 8 + (uint32_t)(lane - 62) * 4;
         const float e[4] = {acc[KV - 1].x, acc[KV - 1].y, acc[KV - 1].z, acc[KV - 1].w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)p.epoch << 32) | __float_as_uint(e[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) *(lds_f4 *)(lds + MB + (uint32_t)(k * 64 + lane) * 16) = acc[k];
+    if (lane == 0) *(lds_f4 *)(lds + MB + kStage) = v4f{0.f, 0.f, 0.f, 0.f};  // the second tap of a verbatim last frame at the end of a chunk: finite, weight 0
     bool dead = false;
     if (tile == 0) {
         if (lane < 8) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = 0.0f;
@@ -1778,7 +1809,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
                 dead = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(1);
         }
         if (want) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = dead ? __builtin_nanf("") : __uint_as_float((uint32_t)hv);
     }
@@ -1817,14 +1848,6 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         }
     }
     // ---- scan of the run-end states (scan basis), as in k_rlm_fast ----
-    const Tables *__restrict__ tb = p.tabs;
-    float lM[4], b15[4], b31[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        lM[k] = tb->laneM[lane][k];
-        b15[k] = tb->bc15M[lane][k];
-        b31[k] = tb->bc31M[lane][k];
-    }
     float Pq[4] = {0.f, 0.f, 0.f, 0.f};
     mat_acc(p.u.Tm, E1.x, E2.x, Pq[0], Pq[1]);
     mat_acc(p.u.Tm, E1.y, E2.y, Pq[2], Pq[3]);
@@ -1892,8 +1915,6 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     if (Jc > 0) {
         const bool want = (uint32_t)lane < Jc;
         const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
-        const float *kp = q.lookT + ((uint64_t)tile * p.J + (want ? lane : 0)) * 4;
-        const float kM[4] = {kp[0], kp[1], kp[2], kp[3]};
         unsigned long long gv[4] = {0, 0, 0, 0};
         bool ok = false;
         uint32_t spins = 0;
