@@ -1653,11 +1653,15 @@ struct ChunkArgs {
     const float *lookT;        // [n_tiles][J][4]: B^(m_lo[t] - m_lo[t-j]), j = 0 .. J-1 (the weight of tile t-1-j's aggregate)
     const float *powM;         // [R + 1][4]: B^v
 };
-template <int R>
+// C: channels of a frame; KV: KiB of a chunk (8 for stereo: 1024 frames; 4 for mono: 1024 frames too -- the tile stays at 64 runs of 18).
+template <int R, int C, int KV>
 __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const ChunkArgs q) {
-    constexpr int KV = 8, NS = 2, H = 4;
-    constexpr uint32_t kStage = KV * 1024, P = 1024;          // bytes of a ring stage = one chunk; stereo frames per chunk
-    constexpr uint32_t MB = NS * kStage + 64;                 // the mixed chunk: halo frames at MB - 32 .. MB, 16 spare bytes behind it
+    typedef Chan<C> CH;
+    typedef typename CH::V V;
+    constexpr int NS = 2, H = 4;
+    constexpr uint32_t FB = CH::kFB;
+    constexpr uint32_t kStage = KV * 1024, P = kStage / FB;   // bytes of a ring stage = one chunk; frames per chunk
+    constexpr uint32_t MB = NS * kStage + 64;                 // the mixed chunk: halo frames at MB - H * FB .. MB, 16 spare bytes behind it
     __shared__ __attribute__((aligned(1024))) unsigned char smem[MB + kStage + 64];
     lds_u8 *const lds = (lds_u8 *)smem;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
@@ -1680,7 +1684,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
     // ---- the sum of chunk `tile` of every source (k_mix_ring) ----
-    const uint32_t nvec = Ns / 2;  // 16-byte vectors of a row (host: Ns even)
+    const uint32_t nvec = Ns * C / 4;  // 16-byte vectors of a row (host: whole vectors)
     const uint32_t v0 = tile * (KV * 64);
     uint32_t goff[KV];
 #pragma unroll
@@ -1733,7 +1737,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             }
             int64_t f = (int64_t)i - fbase;
             f = f < -H ? -H : (f > (int64_t)P - 1 ? (int64_t)P - 1 : f);  // (only frames that are not stored leave the range)
-            offA[rr] = dummy ? (int)MB : (int)MB + (int)f * 8;
+            offA[rr] = dummy ? (int)MB : (int)MB + (int)f * (int)FB;
             wgt[rr] = dummy ? 0.0f : (float)num / p.Tf;
             if (!dummy) cursor_next(c, p);
         }
@@ -1780,8 +1784,9 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 #endif
     // ---- the chunk's last 4 mixed frames to the tile behind (first: it is waiting for them); the mixed chunk into the LDS; the
     // last 4 frames of the tile in front ----
-    if (lane >= 62) {  // vectors 510, 511 of the chunk = frames P-4 .. P-1
-        unsigned long long *hp = q.halo + (uint64_t)tile * 8 + (uint32_t)(lane - 62) * 4;
+    constexpr int NHV = H * FB / 16;  // vectors that hold the chunk's last 4 frames: the last lanes' last vector
+    if (lane >= 64 - NHV) {
+        unsigned long long *hp = q.halo + (uint64_t)tile * 8 + (uint32_t)(lane - (64 - NHV)) * 4;
         const float e[4] = {acc[KV - 1].x, acc[KV - 1].y, acc[KV - 1].z, acc[KV - 1].w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)p.epoch << 32) | __float_as_uint(e[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1791,9 +1796,9 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     if (lane == 0) *(lds_f4 *)(lds + MB + kStage) = v4f{0.f, 0.f, 0.f, 0.f};  // the second tap of a verbatim last frame at the end of a chunk: finite, weight 0
     bool dead = false;
     if (tile == 0) {
-        if (lane < 8) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = 0.0f;
+        if (lane < H * C) *(RH_LDS float *)(lds + MB - H * FB + lane * 4) = 0.0f;
     } else {
-        const bool want = lane < 8;
+        const bool want = lane < H * C;
         const unsigned long long *hp = q.halo + (uint64_t)(tile - 1) * 8 + (want ? lane : 0);
         unsigned long long hv = 0;
         bool ok = false;
@@ -1811,53 +1816,62 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (want) *(RH_LDS float *)(lds + MB - 32 + lane * 4) = dead ? __builtin_nanf("") : __uint_as_float((uint32_t)hv);
+        if (want) *(RH_LDS float *)(lds + MB - H * FB + lane * 4) = dead ? __builtin_nanf("") : __uint_as_float((uint32_t)hv);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
     // ---- the lane's run of the mixed stream: lerp, zero-state biquad; the run-end state after nfl frames ----
-    v2f out[R];
-    v2f E1 = v2f{0.f, 0.f}, E2 = v2f{0.f, 0.f};
+    V out[R];
+    V E1 = CH::zero(), E2 = CH::zero();
     {
-        v2f ta[R + 2], tb2[R + 2];
+        V ta[R + 2], tb2[R + 2];
 #pragma unroll
         for (int rr = 0; rr < R + 2; ++rr) {
-            ta[rr] = *(const lds_f2 *)(lds + offA[rr]);
-            tb2[rr] = *(const lds_f2 *)(lds + offA[rr] + 8);
+            ta[rr] = CH::ld_lds(lds + offA[rr]);
+            tb2[rr] = CH::ld_lds(lds + offA[rr] + FB);
         }
-        auto tap = [&](int rr) -> v2f { return v2f{fma_(tb2[rr].x - ta[rr].x, wgt[rr], ta[rr].x), fma_(tb2[rr].y - ta[rr].y, wgt[rr], ta[rr].y)}; };
-        v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
-        v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
-        v2f w1 = v2f{0.f, 0.f}, w2 = v2f{0.f, 0.f};
+        auto tap = [&](int rr) -> V {
+            V x;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) CH::set(x, ch, fma_(CH::get(tb2[rr], ch) - CH::get(ta[rr], ch), wgt[rr], CH::get(ta[rr], ch)));
+            return x;
+        };
+        V x2 = first ? CH::zero() : tap(0);
+        V x1 = first ? CH::zero() : tap(1);
+        V w1 = CH::zero(), w2 = CH::zero();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const v2f x = tap(r + 2);
-            v2f w;
-            w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
-            w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
-            out[r] = v2f{fma_(b0, x.x, w.x), fma_(b0, x.y, w.y)};
+            const V x = tap(r + 2);
+            V w;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float wc = fma_(na1, CH::get(w1, ch), fma_(na2, CH::get(w2, ch), fma_(c2, CH::get(x2, ch), c1 * CH::get(x1, ch))));
+                CH::set(w, ch, wc);
+                CH::set(out[r], ch, fma_(b0, CH::get(x, ch), wc));
+            }
             w2 = w1;
             w1 = w;
             x2 = x1;
             x1 = x;
-            if (r + 1 == nfl) {
-                E1 = w1;
-                E2 = w2;
-            }
+            E1 = vsel(r + 1 == nfl, w1, E1);
+            E2 = vsel(r + 1 == nfl, w2, E2);
         }
     }
     // ---- scan of the run-end states (scan basis), as in k_rlm_fast ----
-    float Pq[4] = {0.f, 0.f, 0.f, 0.f};
-    mat_acc(p.u.Tm, E1.x, E2.x, Pq[0], Pq[1]);
-    mat_acc(p.u.Tm, E1.y, E2.y, Pq[2], Pq[3]);
-    const float own[4] = {Pq[0], Pq[1], Pq[2], Pq[3]};
+    float Pq[2 * C];
+#pragma unroll
+    for (int k = 0; k < 2 * C; ++k) Pq[k] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) mat_acc(p.u.Tm, CH::get(E1, ch), CH::get(E2, ch), Pq[2 * ch], Pq[2 * ch + 1]);
+    float own[2 * C];
+#pragma unroll
+    for (int k = 0; k < 2 * C; ++k) own[k] = Pq[k];
 #define RH_CSCAN(K, N)                                                                             \
     {                                                                                              \
-        float sq[4];                                                                               \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppRowShr + N, 0xf>(Pq[k]);     \
-        mat_acc(p.u.scanM[K], sq[0], sq[1], Pq[0], Pq[1]);                                         \
-        mat_acc(p.u.scanM[K], sq[2], sq[3], Pq[2], Pq[3]);                                         \
+        float sq[2 * C];                                                                           \
+        _Pragma("unroll") for (int k = 0; k < 2 * C; ++k) sq[k] = dpp0<kDppRowShr + N, 0xf>(Pq[k]); \
+        _Pragma("unroll") for (int ch = 0; ch < C; ++ch) mat_acc(p.u.scanM[K], sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]); \
     }
     RH_CSCAN(0, 1)
     RH_CSCAN(1, 2)
@@ -1865,18 +1879,18 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     RH_CSCAN(3, 8)
 #undef RH_CSCAN
     {
-        float sq[4];
+        float sq[2 * C];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppBcast15, 0xa>(Pq[k]);
-        mat_acc(b15, sq[0], sq[1], Pq[0], Pq[1]);
-        mat_acc(b15, sq[2], sq[3], Pq[2], Pq[3]);
+        for (int k = 0; k < 2 * C; ++k) sq[k] = dpp0<kDppBcast15, 0xa>(Pq[k]);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mat_acc(b15, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]);
     }
     {
-        float sq[4];
+        float sq[2 * C];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sq[k] = dpp0<kDppBcast31, 0xc>(Pq[k]);
-        mat_acc(b31, sq[0], sq[1], Pq[0], Pq[1]);
-        mat_acc(b31, sq[2], sq[3], Pq[2], Pq[3]);
+        for (int k = 0; k < 2 * C; ++k) sq[k] = dpp0<kDppBcast31, 0xc>(Pq[k]);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mat_acc(b31, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]);
     }
     {  // the tile aggregate: the short last run on top of the inclusive prefix of the lane before it
         // (the tile's bounds are read again here rather than kept in scalar registers across the source loop)
@@ -1884,45 +1898,51 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         asm volatile("" : "+s"(tile_again));
         const uint32_t n_t = ((cu32 *)(uintptr_t)q.m_lo)[tile_again + 1] - ((cu32 *)(uintptr_t)q.m_lo)[tile_again];
         const int nl = (int)((n_t + R - 1) / R);  // lanes with frames (uniform)
-        float A[4] = {0.f, 0.f, 0.f, 0.f};
+        float A[2 * C];
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) A[k] = 0.f;
         if (nl >= 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) A[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own[k]), nl - 1));
+            for (int k = 0; k < 2 * C; ++k) A[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own[k]), nl - 1));
         }
         if (nl >= 2) {
             const uint32_t v = n_t - (uint32_t)(nl - 1) * R;  // 1 .. R
             cf32 *pw = (cf32 *)(uintptr_t)(q.powM + 4 * v);
             const float M[4] = {pw[0], pw[1], pw[2], pw[3]};
-            float xp[4];
+            float xp[2 * C];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xp[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pq[k]), nl - 2));
-            mat_acc(M, xp[0], xp[1], A[0], A[1]);
-            mat_acc(M, xp[2], xp[3], A[2], A[3]);
+            for (int k = 0; k < 2 * C; ++k) xp[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pq[k]), nl - 2));
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(M, xp[2 * ch], xp[2 * ch + 1], A[2 * ch], A[2 * ch + 1]);
         }
-        if (lane < 4) {
+        if (lane < 2 * C) {
             float ev = A[0];
 #pragma unroll
-            for (int k = 1; k < 4; ++k) ev = lane == k ? A[k] : ev;
+            for (int k = 1; k < 2 * C; ++k) ev = lane == k ? A[k] : ev;
             __hip_atomic_store(p.gran + (uint64_t)tile * 4 + lane, ((unsigned long long)p.epoch << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    float Q[4];
+    float Q[2 * C];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Q[k] = dpp0<kDppWaveShr1, 0xf>(Pq[k]);  // exclusive: the prefix of the lanes before (all of them whole runs)
+    for (int k = 0; k < 2 * C; ++k) Q[k] = dpp0<kDppWaveShr1, 0xf>(Pq[k]);  // exclusive: the prefix of the lanes before (all of them whole runs)
     // ---- the tile carry: lane j < J polls tile-1-j, weights it with B^(m_lo[tile] - m_lo[tile-j]) ----
     const uint32_t Jc = p.J < tile ? p.J : tile;
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    float c[2 * C];
+#pragma unroll
+    for (int k = 0; k < 2 * C; ++k) c[k] = 0.f;
     if (Jc > 0) {
         const bool want = (uint32_t)lane < Jc;
         const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
-        unsigned long long gv[4] = {0, 0, 0, 0};
+        unsigned long long gv[2 * C];
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) gv[k] = 0;
         bool ok = false;
         uint32_t spins = 0;
         while (true) {
             if (want && !ok) {
                 bool all = true;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 2 * C; ++k) {
                     gv[k] = __hip_atomic_load(gp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     all = all && ((uint32_t)(gv[k] >> 32) == p.epoch);
                 }
@@ -1938,11 +1958,11 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         }
         if (lane == 0 && spins) atomicAdd(p.status + 1, spins);
         if (want && ok && !dead) {
-            mat_acc(kM, __uint_as_float((uint32_t)gv[0]), __uint_as_float((uint32_t)gv[1]), c[0], c[1]);
-            mat_acc(kM, __uint_as_float((uint32_t)gv[2]), __uint_as_float((uint32_t)gv[3]), c[2], c[3]);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(kM, __uint_as_float((uint32_t)gv[2 * ch]), __uint_as_float((uint32_t)gv[2 * ch + 1]), c[2 * ch], c[2 * ch + 1]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // sum over lanes 0..31 -> uniform
+        for (int k = 0; k < 2 * C; ++k) {  // sum over lanes 0..31 -> uniform
             c[k] += dpp0<kDppRowShr + 1, 0xf>(c[k]);
             c[k] += dpp0<kDppRowShr + 2, 0xf>(c[k]);
             c[k] += dpp0<kDppRowShr + 4, 0xf>(c[k]);
@@ -1950,15 +1970,22 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             c[k] = readlane_f(c[k], 15) + readlane_f(c[k], 31);
         }
     }
-    if (dead) c[0] = c[1] = c[2] = c[3] = __builtin_nanf("");  // a hand-off that never arrived: the status word fails the call, the tile is poisoned
-    mat_acc(lM, c[0], c[1], Q[0], Q[1]);  // start state of the lane's run = Q + B^(R*lane) * carry
-    mat_acc(lM, c[2], c[3], Q[2], Q[3]);
-    float *o = p.out + (uint64_t)m0 * 2;
+    if (dead) {  // a hand-off that never arrived: the status word fails the call, the tile is poisoned
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) c[k] = __builtin_nanf("");
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);  // start state of the lane's run = Q + B^(R*lane) * carry
+    float *o = p.out + (uint64_t)m0 * C;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const float yl = fma_(p.u.g[r][0], Q[0], fma_(p.u.g[r][1], Q[1], out[r].x));
-        const float yr = fma_(p.u.g[r][0], Q[2], fma_(p.u.g[r][1], Q[3], out[r].y));
-        if (r < nfl) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(yl, yr);
+        float y[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) y[ch] = fma_(p.u.g[r][0], Q[2 * ch], fma_(p.u.g[r][1], Q[2 * ch + 1], CH::get(out[r], ch)));
+        if (r < nfl) {
+            if (C == 2) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(y[0], y[C - 1]);
+            else o[r] = y[0];
+        }
     }
 }
 
@@ -2363,11 +2390,13 @@ int kv_needed(uint64_t L, uint32_t F, uint32_t T, uint32_t channels) {
 // One launch plan: a kernel variant with its tables.
 // k_rlm_chunk: tables for runs of 18 frames, the tile boundaries of the batch that is set, the hand-off tables.
 struct ChunkPlan {
-    static constexpr int kR = 18;
-    bool tabs_ok = false, ok = false;  // filter tables built / the batch that is set can take the kernel
+    int R = 18, KV = 8;                // frames per lane; KiB per chunk (stereo: 18 / 8; mono: 18 / 4: 1024 frames per chunk either way)
+    const void *fn = nullptr;          // the instance for (R, channels, KV)
+    int tabs_R = 0;                    // the R the filter tables were built for (0: none yet)
+    bool ok = false;                   // the batch that is set can take the kernel
     Uniforms uni;
     Tables *d_tabs = nullptr;
-    float *d_pow = nullptr;            // [kR + 1][4]
+    float *d_pow = nullptr;            // [R + 1][4]
     uint32_t *d_mlo = nullptr;         // [n_tiles + 1]
     float *d_look = nullptr;           // [n_tiles][J][4]
     unsigned long long *d_halo = nullptr;  // [n_tiles][8]
@@ -2579,18 +2608,27 @@ rh_status make_plan(rh_rlm *p, Plan &pl, VariantTab tab, bool general, const rh:
 rh_status build_chunk(rh_rlm *p) {
     ChunkPlan &c = p->chunk;
     c.ok = false;
-    constexpr int R = ChunkPlan::kR;
-    constexpr uint64_t P = 1024, H = 4;
-    if (!p->filt || !p->equal || p->cfg.channels != 2 || p->cfg.force_general || p->n_sources < 2 || rh::knob(rh::K_NO_CHUNK) || rh::knob(rh::K_NO_MIX_FIRST)) return RH_OK;
+    constexpr uint64_t H = 4;
+    const uint32_t C = p->cfg.channels;
+    if (!p->filt || !p->equal || p->cfg.force_general || p->n_sources < 2 || rh::knob(rh::K_NO_CHUNK) || rh::knob(rh::K_NO_MIX_FIRST)) return RH_OK;
+    // the instance: chunks of 1024 frames in runs of 18 (stereo: 8 KiB, mono: 4 KiB); RH_CHUNK_HALF: stereo chunks of 512 frames in runs of 9
+    const bool half = C == 2 && rh::knob(rh::K_CHUNK_HALF);
+    const int R = half ? 9 : 18, KV = (C == 2 && !half) ? 8 : 4;
+    const void *fn = C == 1 ? reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 4>)
+                     : half ? reinterpret_cast<const void *>(&k_rlm_chunk<9, 2, 4>)
+                            : reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 8>);
+    const uint64_t P = (uint64_t)KV * 1024 / (4 * C);
     const uint64_t Ns = p->eq_frames, M = p->out_frames;
-    if (Ns < 2 || (Ns & 1) || M == 0) return RH_OK;  // (whole 16-byte vectors)
+    if (Ns < 2 || (Ns * C) % 4 != 0 || M == 0) return RH_OK;  // (whole 16-byte vectors)
     const uint64_t tiles = (Ns + P - 1) / P;
     if (tiles < 2ull * (uint64_t)rh::g_num_cus) return RH_OK;  // short rows: more, smaller pieces fill the chip better
-    const void *fn = reinterpret_cast<const void *>(&k_rlm_chunk<R>);
-    if (!c.resident_per_cu) {
+    if (c.fn != fn) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0) != hipSuccess) return RH_OK;
         c.resident_per_cu = n < 1 ? -1 : n;
+        c.fn = fn;
+        c.R = R;
+        c.KV = KV;
     }
     if (c.resident_per_cu < 1 || tiles > (uint64_t)rh::g_num_cus * (uint64_t)c.resident_per_cu) return RH_OK;  // every tile resident at once
     // the input frame of an output frame (cursor_at / cursor_resolve, and the verbatim last frame)
@@ -2634,7 +2672,10 @@ rh_status build_chunk(rh_rlm *p) {
         const rh_status w = wait_idle(p);  // an earlier run may still read the tables
         if (w != RH_OK) return w;
     }
-    if (!c.tabs_ok) {
+    if (c.tabs_R != R) {
+        if (c.d_tabs) RH_HIP_TRY(hipFree(c.d_tabs));
+        if (c.d_pow) RH_HIP_TRY(hipFree(c.d_pow));
+        c.d_tabs = nullptr, c.d_pow = nullptr, c.tabs_R = 0;
         Tables *h = new Tables();
         std::memset(h, 0, sizeof(Tables));
         Uniforms &U = c.uni;
@@ -2656,7 +2697,8 @@ rh_status build_chunk(rh_rlm *p) {
             put(h->bc15M[l], mpow(B, (uint64_t)R * ((l & 15) + 1)));
             put(h->bc31M[l], mpow(B, (uint64_t)R * ((l & 31) + 1)));
         }
-        float pw[R + 1][4];
+        float pw[kMaxR + 1][4];
+        std::memset(pw, 0, sizeof(pw));
         for (int v = 0; v <= R; ++v) put(pw[v], mpow(B, (uint64_t)v));
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&c.d_tabs), sizeof(Tables));
         if (e == hipSuccess) e = hipMemcpy(c.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
@@ -2667,7 +2709,7 @@ rh_status build_chunk(rh_rlm *p) {
             rh::set_hip_error(e, "k_rlm_chunk tables");
             return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
         }
-        c.tabs_ok = true;
+        c.tabs_R = R;
     }
     if ((size_t)tiles > c.cap_tiles) {
         if (c.d_mlo) RH_HIP_TRY(hipFree(c.d_mlo));
@@ -3087,8 +3129,12 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         ca.halo = c.d_halo;
         ca.lookT = c.d_look;
         ca.powM = c.d_pow;
-        hipLaunchKernelGGL(k_rlm_chunk<ChunkPlan::kR>, dim3(c.n_tiles), dim3(64), 0, s, k, ca);
-        RH_CHECK_LAUNCH();
+        void *cargs[] = {&k, &ca};
+        const hipError_t ce = hipLaunchKernel(c.fn, dim3(c.n_tiles), dim3(64), cargs, 0, s);
+        if (ce != hipSuccess) {
+            rh::set_hip_error(ce, "k_rlm_chunk launch");
+            return RH_ERR_HIP;
+        }
         return mark_launch(p, s);
     }
     const bool pre = p->pre_filter;

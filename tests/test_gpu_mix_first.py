@@ -245,3 +245,35 @@ def test_filter_before_the_converter(G, O, frm, to, n, filt, freq):
     with pytest.raises(Exception):
         p.run()
     p.close()
+
+
+@pytest.mark.parametrize("frm,to,span,n", [(44100, 48000, None, 600000), (44100, 48000, 32768, 600004), (48000, 44100, None, 800000), (48000, 48000, 3000, 600000)])
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
+def test_chunk_kernel_mono(G, O, frm, to, span, n, filt, freq):
+    # mono rows: chunks of 4 KiB = 1024 frames, the same 64 runs of 18 frames per tile
+    S, ch = 3, 1
+    xs = [rnd(6800 + s, n, 0.3) for s in range(S)]
+    gains = np.array([1.0, 0.5, -0.75], dtype=np.float32)
+    ref = _oracle(O, xs, frm, to, span, filt, freq, gains, ch)
+    got, geo = _run(G, xs, frm, to, ch, span, filt, freq, gains)
+    assert geo["mix_first"] == 2, geo
+    assert len(got) == len(ref)
+    err = np.abs(got - ref)
+    assert float(np.max(err)) <= TOL, (int(np.argmax(err)), float(np.max(err)))
+    with knobs(RH_NO_CHUNK="1"):
+        two, geo2 = _run(G, xs, frm, to, ch, span, filt, freq, gains)
+    assert geo2["mix_first"] == 1
+    assert float(np.max(np.abs(got - two))) <= 2e-6
+
+
+@pytest.mark.parametrize("frm,to,span,n", [(44100, 48000, None, 600000), (44100, 48000, 32768, 600000), (48000, 44100, None, 700000)])
+def test_chunk_kernel_half_chunks(G, O, frm, to, span, n):
+    # RH_CHUNK_HALF: the stereo instance with chunks of 512 frames in runs of 9 (a tuning aid: twice the tiles, two per SIMD)
+    S, ch = 3, 2
+    xs = [rnd(6900 + s, n * ch, 0.3) for s in range(S)]
+    ref = _oracle(O, xs, frm, to, span, "low_pass", 200, None, ch)
+    with knobs(RH_CHUNK_HALF="1"):
+        got, geo = _run(G, xs, frm, to, ch, span, "low_pass", 200, None)
+    assert geo["mix_first"] == 2, geo
+    assert len(got) == len(ref)
+    assert float(np.max(np.abs(got - ref))) <= TOL
