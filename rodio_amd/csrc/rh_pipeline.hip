@@ -346,7 +346,9 @@ __device__ __forceinline__ float vmul_s(float a, float s) { return a * s; }
 __device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
 __device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
 
-template <int R, int KV, int NS, bool FILT, bool RAG = false, int C = 2>
+// SUMF (with RAG): sum first -- the stable sources of a tile share the tile's span, taps and weights, so their spans are SUMMED as
+// they land (one FMA per float) and the lerp, the zero-state filter and everything behind it run once, on the sum (§4.6).
+template <int R, int KV, int NS, bool FILT, bool RAG = false, int C = 2, bool SUMF = false>
 __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <= 12 ? 2 : 1)) void k_rlm_fast(const Params p) {  // (no spills: tests/test_code_objects.py)
     typedef Chan<C> CH;
     typedef typename CH::V V;
@@ -609,14 +611,54 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
             for (int d = 0; d < NS; ++d) q[d] = q[d + 1];
             q[NS] = q[NS] < S ? next_stable(q[NS] + 1) : S;
         };
-        if (q[0] < S) {
-            ++waited;
-            wait_groups<KV, NS>((int)(issued - waited));
+        if constexpr (SUMF) {
+            v4f accv[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) accv[k] = v4f{0.f, 0.f, 0.f, 0.f};
+            while (q[0] < S) {
+                ++waited;
+                wait_groups<KV, NS>((int)(issued - waited));  // the stage of q[0] has landed
+                const lds_u8 *buf = lds + st_cur;
+                v4f v[KV];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(buf + k * 1024 + lane * 16);
+                const float g = dgain[8 * (uint64_t)q[0] + 4];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the span is in registers: its stage is free
+                if (q[NS] < S) {
+                    stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)q[NS]], st_cur);
+                    ++issued;
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    accv[k].x = fma_(g, v[k].x, accv[k].x);
+                    accv[k].y = fma_(g, v[k].y, accv[k].y);
+                    accv[k].z = fma_(g, v[k].z, accv[k].z);
+                    accv[k].w = fma_(g, v[k].w, accv[k].w);
+                }
+                st_cur += kStage;
+                if (st_cur >= NS * kStage) st_cur = 0;
+#pragma unroll
+                for (int d = 0; d < NS; ++d) q[d] = q[d + 1];
+                q[NS] = q[NS] < S ? next_stable(q[NS] + 1) : S;
+            }
+            wait_vm<0>();
+            // the summed span takes the place of a source's in stage 0: one lerp, one zero-state run
+#pragma unroll
+            for (int k = 0; k < KV; ++k) *(lds_f4 *)(lds + k * 1024 + lane * 16) = accv[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
             read_taps(0, tA, tB);
-        }
-        while (q[0] < S) {
-            rag_iteration(tA, tB, uA, uB);
-            if (q[0] < S) rag_iteration(uA, uB, tA, tB);
+            compute(tA, tB, 1.0f);
+        } else {
+            if (q[0] < S) {
+                ++waited;
+                wait_groups<KV, NS>((int)(issued - waited));
+                read_taps(0, tA, tB);
+            }
+            while (q[0] < S) {
+                rag_iteration(tA, tB, uA, uB);
+                if (q[0] < S) rag_iteration(uA, uB, tA, tB);
+            }
         }
     }
     wait_vm<0>();  // nothing of this wave may still be in flight towards its LDS
@@ -2331,7 +2373,11 @@ const Variant kWave[] = {
 };
 // k_rlm_fast<.., RAG>: the first half of a ragged filtered batch, in the tile sizes of the general kernel (both halves
 // share the tile geometry, the tables and the aggregate rows)
+#ifdef RH_RAG_NO_SUMF  // diagnostics builds: the per-source first half
 #define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true>, &k_rlm_resid<r, kv>}
+#else
+#define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true, 2, true>, &k_rlm_resid<r, kv>}
+#endif
 const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
