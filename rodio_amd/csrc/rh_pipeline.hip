@@ -38,6 +38,8 @@
 //     hold a wave slot: progress does not depend on dispatch order or residency.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -1694,7 +1696,15 @@ struct ChunkArgs {
     unsigned long long *halo;  // [n_tiles][8] {epoch, f32 bits}: the last 4 mixed frames of the tile's chunk
     const float *lookT;        // [n_tiles][J][4]: B^(m_lo[t] - m_lo[t-j]), j = 0 .. J-1 (the weight of tile t-1-j's aggregate)
     const float *powM;         // [R + 1][4]: B^v
+    const float *uni;          // the plan's Uniforms as an array of floats in device memory (Params::u holds the same values)
 };
+#if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 3  // diagnostics builds: shader cycles per phase behind the source loop, summed over the tiles into ctl[8..15]
+#define RH_CPH(i) { const unsigned long long cph_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(p.ticket + 8 + (i), (uint32_t)(cph_now - cph_last)); cph_last = cph_now; }
+#define RH_CPH_DECL unsigned long long cph_last = __builtin_readcyclecounter();
+#else
+#define RH_CPH(i)
+#define RH_CPH_DECL
+#endif
 // C: channels of a frame; KV: KiB of a chunk (8 for stereo: 1024 frames; 4 for mono: 1024 frames too -- the tile stays at 64 runs of 18).
 template <int R, int C, int KV>
 __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const ChunkArgs q) {
@@ -1718,12 +1728,25 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     const uint32_t m_lo = ((cu32 *)(uintptr_t)q.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q.m_lo)[tile + 1];
     const uint32_t m0 = m_lo + (uint32_t)lane * R;
     int nfl;  // frames of this lane's run
+    // what the part behind the source loop needs of the tile's bounds lives in VECTOR registers across the loop (scalar registers
+    // are short there, and a scalar load behind the loop is a memory round trip nothing hides): the frame count and B^v
+    uint32_t n_t_v;
+    float pwv[4];
     {
         const uint32_t n_t = m_hi - m_lo;  // <= 64 * R (host)
         nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);
+        const uint32_t nl0 = (n_t + R - 1) / R;
+        const uint32_t v = nl0 ? n_t - (nl0 - 1) * R : 0;  // frames of the last lane's run, 1 .. R
+        n_t_v = n_t;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(n_t_v) : "s"(n_t));
+        const float *pw = q.powM + 4 * v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pwv[k] = pw[k];
+            asm volatile("" : "+v"(pwv[k]));  // (a vector load of a uniform address: the values stay in vector registers)
+        }
     }
     const bool first = (m0 == 0);                              // stream start: x'[-1] = x'[-2] = 0
-    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
 
     // ---- the sum of chunk `tile` of every source (k_mix_ring) ----
     const uint32_t nvec = Ns * C / 4;  // 16-byte vectors of a row (host: whole vectors)
@@ -1743,10 +1766,24 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     if (S) stage_source(0, 0);  // the first two chunks are on their way while the lane works out its taps
     if (S > 1) stage_source(1, 1);
     // the lane's rows of the filter tables and its look-back weight: fetched here, a source loop away from their use
+    // Everything the part behind the source loop needs from the kernel arguments is worked out HERE and parked in vector
+    // registers: a scalar load of a kernel argument behind the loop is a memory round trip that nothing hides (the compiler
+    // re-loads arguments rather than keep them: twelve such trips, one after the other, before this was done).
     const Tables *__restrict__ tb = p.tabs;
     float lM[4], b15[4], b31[4], kM[4];
+    constexpr int NHV = H * FB / 16;  // vectors that hold the chunk's last 4 frames: the last lanes' last vector
+    const uint32_t Jc = p.J < tile ? p.J : tile;
+    int want_look = (uint32_t)lane < Jc ? 1 : 0;
+    uint64_t a_halo_pub = (uint64_t)(uintptr_t)(q.halo + (uint64_t)tile * 8 + (uint32_t)(lane >= 64 - NHV ? lane - (64 - NHV) : 0) * 4);
+    uint64_t a_halo_poll = (uint64_t)(uintptr_t)(q.halo + (uint64_t)(tile ? tile - 1 : 0) * 8 + (lane < H * C ? lane : 0));
+    uint64_t a_gran_pub = (uint64_t)(uintptr_t)(p.gran + (uint64_t)tile * 4 + (lane < 2 * C ? lane : 0));
+    uint64_t a_gran_poll = (uint64_t)(uintptr_t)(p.gran + (uint64_t)(tile ? tile - 1 - (want_look ? lane : 0) : 0) * 4);
+    uint64_t a_out = (uint64_t)(uintptr_t)(p.out + ((uint64_t)m_lo + (uint32_t)lane) * C);  // frame `lane` of the tile
+    uint32_t epoch_v = p.epoch;
+    float U = q.uni[lane < 61 ? lane : 60];  // lane l holds float l of the Uniforms: {b0, c1, c2, a1, a2, Tm[4], scanM[4][4], g[r][2] ...}
+    asm volatile("" : "+v"(want_look), "+v"(a_halo_pub), "+v"(a_halo_poll), "+v"(a_gran_pub), "+v"(a_gran_poll), "+v"(a_out), "+v"(epoch_v), "+v"(U));
     {
-        const uint32_t Jc0 = p.J < tile ? p.J : tile;
+        const uint32_t Jc0 = Jc;
         const float *kp = q.lookT + ((uint64_t)tile * p.J + ((uint32_t)lane < Jc0 ? lane : 0)) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1813,7 +1850,8 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             st ^= 1u;
         }
     }
-#ifdef RH_CHUNK_DIAG  // diagnostics builds (tools/build_variant.sh): the source loop alone (+ the tap prologue unless RH_CHUNK_DIAG == 2)
+    RH_CPH_DECL
+#if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG < 3  // diagnostics builds (tools/build_variant.sh): the source loop alone (+ the tap prologue unless RH_CHUNK_DIAG == 2)
     {
         float t = 0.f;
 #pragma unroll
@@ -1826,12 +1864,11 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 #endif
     // ---- the chunk's last 4 mixed frames to the tile behind (first: it is waiting for them); the mixed chunk into the LDS; the
     // last 4 frames of the tile in front ----
-    constexpr int NHV = H * FB / 16;  // vectors that hold the chunk's last 4 frames: the last lanes' last vector
     if (lane >= 64 - NHV) {
-        unsigned long long *hp = q.halo + (uint64_t)tile * 8 + (uint32_t)(lane - (64 - NHV)) * 4;
+        unsigned long long *hp = (unsigned long long *)(uintptr_t)a_halo_pub;
         const float e[4] = {acc[KV - 1].x, acc[KV - 1].y, acc[KV - 1].z, acc[KV - 1].w};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)p.epoch << 32) | __float_as_uint(e[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)epoch_v << 32) | __float_as_uint(e[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int k = 0; k < KV; ++k) *(lds_f4 *)(lds + MB + (uint32_t)(k * 64 + lane) * 16) = acc[k];
@@ -1841,14 +1878,14 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         if (lane < H * C) *(RH_LDS float *)(lds + MB - H * FB + lane * 4) = 0.0f;
     } else {
         const bool want = lane < H * C;
-        const unsigned long long *hp = q.halo + (uint64_t)(tile - 1) * 8 + (want ? lane : 0);
+        const unsigned long long *hp = (const unsigned long long *)(uintptr_t)a_halo_poll;
         unsigned long long hv = 0;
         bool ok = false;
         uint32_t spins = 0;
         while (true) {
             if (want && !ok) {
                 hv = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (uint32_t)(hv >> 32) == p.epoch;
+                ok = (uint32_t)(hv >> 32) == epoch_v;
             }
             if (__all(ok || !want)) break;
             if (++spins > kSpinLimit) {
@@ -1862,8 +1899,10 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    RH_CPH(0)  // LDS image of the mixed chunk + the halo of the tile in front
 
     // ---- the lane's run of the mixed stream: lerp, zero-state biquad; the run-end state after nfl frames ----
+    const float b0 = readlane_f(U, 0), c1 = readlane_f(U, 1), c2 = readlane_f(U, 2), na1 = -readlane_f(U, 3), na2 = -readlane_f(U, 4);
     V out[R];
     V E1 = CH::zero(), E2 = CH::zero();
     {
@@ -1900,12 +1939,16 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             E2 = vsel(r + 1 == nfl, w2, E2);
         }
     }
+    RH_CPH(1)  // taps, lerp, zero-state run
     // ---- scan of the run-end states (scan basis), as in k_rlm_fast ----
     float Pq[2 * C];
 #pragma unroll
     for (int k = 0; k < 2 * C; ++k) Pq[k] = 0.f;
+    {
+        const float Tm[4] = {readlane_f(U, 5), readlane_f(U, 6), readlane_f(U, 7), readlane_f(U, 8)};
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) mat_acc(p.u.Tm, CH::get(E1, ch), CH::get(E2, ch), Pq[2 * ch], Pq[2 * ch + 1]);
+        for (int ch = 0; ch < C; ++ch) mat_acc(Tm, CH::get(E1, ch), CH::get(E2, ch), Pq[2 * ch], Pq[2 * ch + 1]);
+    }
     float own[2 * C];
 #pragma unroll
     for (int k = 0; k < 2 * C; ++k) own[k] = Pq[k];
@@ -1913,7 +1956,8 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     {                                                                                              \
         float sq[2 * C];                                                                           \
         _Pragma("unroll") for (int k = 0; k < 2 * C; ++k) sq[k] = dpp0<kDppRowShr + N, 0xf>(Pq[k]); \
-        _Pragma("unroll") for (int ch = 0; ch < C; ++ch) mat_acc(p.u.scanM[K], sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]); \
+        const float sM[4] = {readlane_f(U, 9 + 4 * K), readlane_f(U, 10 + 4 * K), readlane_f(U, 11 + 4 * K), readlane_f(U, 12 + 4 * K)}; \
+        _Pragma("unroll") for (int ch = 0; ch < C; ++ch) mat_acc(sM, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]); \
     }
     RH_CSCAN(0, 1)
     RH_CSCAN(1, 2)
@@ -1935,10 +1979,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         for (int ch = 0; ch < C; ++ch) mat_acc(b31, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]);
     }
     {  // the tile aggregate: the short last run on top of the inclusive prefix of the lane before it
-        // (the tile's bounds are read again here rather than kept in scalar registers across the source loop)
-        uint32_t tile_again = tile;
-        asm volatile("" : "+s"(tile_again));
-        const uint32_t n_t = ((cu32 *)(uintptr_t)q.m_lo)[tile_again + 1] - ((cu32 *)(uintptr_t)q.m_lo)[tile_again];
+        const uint32_t n_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_t_v);
         const int nl = (int)((n_t + R - 1) / R);  // lanes with frames (uniform)
         float A[2 * C];
 #pragma unroll
@@ -1948,9 +1989,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             for (int k = 0; k < 2 * C; ++k) A[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own[k]), nl - 1));
         }
         if (nl >= 2) {
-            const uint32_t v = n_t - (uint32_t)(nl - 1) * R;  // 1 .. R
-            cf32 *pw = (cf32 *)(uintptr_t)(q.powM + 4 * v);
-            const float M[4] = {pw[0], pw[1], pw[2], pw[3]};
+            const float M[4] = {readfirstlane_f(pwv[0]), readfirstlane_f(pwv[1]), readfirstlane_f(pwv[2]), readfirstlane_f(pwv[3])};  // B^v
             float xp[2 * C];
 #pragma unroll
             for (int k = 0; k < 2 * C; ++k) xp[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pq[k]), nl - 2));
@@ -1961,20 +2000,20 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
             float ev = A[0];
 #pragma unroll
             for (int k = 1; k < 2 * C; ++k) ev = lane == k ? A[k] : ev;
-            __hip_atomic_store(p.gran + (uint64_t)tile * 4 + lane, ((unsigned long long)p.epoch << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long *)(uintptr_t)a_gran_pub, ((unsigned long long)epoch_v << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     float Q[2 * C];
 #pragma unroll
     for (int k = 0; k < 2 * C; ++k) Q[k] = dpp0<kDppWaveShr1, 0xf>(Pq[k]);  // exclusive: the prefix of the lanes before (all of them whole runs)
+    RH_CPH(2)  // scan, aggregate, publish
     // ---- the tile carry: lane j < J polls tile-1-j, weights it with B^(m_lo[tile] - m_lo[tile-j]) ----
-    const uint32_t Jc = p.J < tile ? p.J : tile;
     float c[2 * C];
 #pragma unroll
     for (int k = 0; k < 2 * C; ++k) c[k] = 0.f;
-    if (Jc > 0) {
-        const bool want = (uint32_t)lane < Jc;
-        const unsigned long long *gp = p.gran + (uint64_t)(tile - 1 - (want ? lane : 0)) * 4;
+    if (tile > 0) {
+        const bool want = want_look != 0;
+        const unsigned long long *gp = (const unsigned long long *)(uintptr_t)a_gran_poll;
         unsigned long long gv[2 * C];
 #pragma unroll
         for (int k = 0; k < 2 * C; ++k) gv[k] = 0;
@@ -1986,7 +2025,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 #pragma unroll
                 for (int k = 0; k < 2 * C; ++k) {
                     gv[k] = __hip_atomic_load(gp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    all = all && ((uint32_t)(gv[k] >> 32) == p.epoch);
+                    all = all && ((uint32_t)(gv[k] >> 32) == epoch_v);
                 }
                 ok = all;
             }
@@ -2016,19 +2055,42 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 #pragma unroll
         for (int k = 0; k < 2 * C; ++k) c[k] = __builtin_nanf("");
     }
+    RH_CPH(3)  // look-back
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);  // start state of the lane's run = Q + B^(R*lane) * carry
-    float *o = p.out + (uint64_t)m0 * C;
+    // A lane's run is R * FB contiguous bytes, so a store of one frame per lane touches 64 different lines.  The runs go through
+    // the (now idle) ring stages -- rows padded by one frame -- and leave as whole lines: lane l stores frame k * 64 + l of the tile.
+    constexpr uint32_t kRow = (R + 1) * FB;
+    {
+        lds_u8 *row = lds + (uint32_t)lane * kRow;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float y[C];
+        for (int r = 0; r < R; ++r) {
+            V y;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) y[ch] = fma_(p.u.g[r][0], Q[2 * ch], fma_(p.u.g[r][1], Q[2 * ch + 1], CH::get(out[r], ch)));
-        if (r < nfl) {
-            if (C == 2) *reinterpret_cast<float2 *>(o + r * 2) = make_float2(y[0], y[C - 1]);
-            else o[r] = y[0];
+            for (int ch = 0; ch < C; ++ch) CH::set(y, ch, fma_(readlane_f(U, 25 + 2 * r), Q[2 * ch], fma_(readlane_f(U, 26 + 2 * r), Q[2 * ch + 1], CH::get(out[r], ch))));
+            if (C == 2) *(lds_f2 *)(row + r * FB) = v2f{CH::get(y, 0), CH::get(y, C - 1)};
+            else *(RH_LDS float *)(row + r * FB) = CH::get(y, 0);
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t n_t = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_t_v);
+        float *ot = (float *)(uintptr_t)a_out;  // this lane's frame of every group of 64
+        for (uint32_t f0 = 0; f0 < n_t; f0 += 64) {
+            const uint32_t f = f0 + (uint32_t)lane;
+            if (f < n_t) {
+                const lds_u8 *src2 = lds + (f / R) * kRow + (f % R) * FB;
+                if (C == 2) {
+                    const v2f a = *(const lds_f2 *)src2;
+                    *reinterpret_cast<float2 *>(ot + (uint64_t)f0 * 2) = make_float2(a.x, a.y);
+                } else {
+                    ot[f0] = *(const RH_LDS float *)src2;
+                }
+            }
+        }
+    }
+    RH_CPH(4)  // correction + stores (issue)
 }
 
 // =================================================================================================
@@ -2443,6 +2505,7 @@ struct ChunkPlan {
     Uniforms uni;
     Tables *d_tabs = nullptr;
     float *d_pow = nullptr;            // [R + 1][4]
+    float *d_uni = nullptr;            // `uni` as floats, for the kernel's lanes
     uint32_t *d_mlo = nullptr;         // [n_tiles + 1]
     float *d_look = nullptr;           // [n_tiles][J][4]
     unsigned long long *d_halo = nullptr;  // [n_tiles][8]
@@ -2721,7 +2784,8 @@ rh_status build_chunk(rh_rlm *p) {
     if (c.tabs_R != R) {
         if (c.d_tabs) RH_HIP_TRY(hipFree(c.d_tabs));
         if (c.d_pow) RH_HIP_TRY(hipFree(c.d_pow));
-        c.d_tabs = nullptr, c.d_pow = nullptr, c.tabs_R = 0;
+        if (c.d_uni) RH_HIP_TRY(hipFree(c.d_uni));
+        c.d_tabs = nullptr, c.d_pow = nullptr, c.d_uni = nullptr, c.tabs_R = 0;
         Tables *h = new Tables();
         std::memset(h, 0, sizeof(Tables));
         Uniforms &U = c.uni;
@@ -2750,6 +2814,9 @@ rh_status build_chunk(rh_rlm *p) {
         if (e == hipSuccess) e = hipMemcpy(c.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.d_pow), sizeof(pw));
         if (e == hipSuccess) e = hipMemcpy(c.d_pow, pw, sizeof(pw), hipMemcpyHostToDevice);
+        static_assert(offsetof(Uniforms, Tm) == 20 && offsetof(Uniforms, scanM) == 36 && offsetof(Uniforms, g) == 100, "the kernel reads the Uniforms by float index");
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.d_uni), sizeof(Uniforms));
+        if (e == hipSuccess) e = hipMemcpy(c.d_uni, &U, sizeof(Uniforms), hipMemcpyHostToDevice);
         delete h;
         if (e != hipSuccess) {
             rh::set_hip_error(e, "k_rlm_chunk tables");
@@ -2954,6 +3021,13 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
     (void)wait_idle(p);  // nothing of this handle may still run when its tables go
+#if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 3
+    if (p->d_ctl && p->chunk.ok) {
+        uint32_t h[8] = {0};
+        (void)hipMemcpy(h, p->d_ctl + 8, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "chunk phases (cycles summed over tiles and launches): image+halo %u  run %u  scan+publish %u  look-back %u  correction+stores %u\n", h[0], h[1], h[2], h[3], h[4]);
+    }
+#endif
     if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
     bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
     for (Plan &c : p->tried) {
@@ -2971,6 +3045,7 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->d_mix) (void)hipFree(p->d_mix);
     if (p->chunk.d_tabs) (void)hipFree(p->chunk.d_tabs);
     if (p->chunk.d_pow) (void)hipFree(p->chunk.d_pow);
+    if (p->chunk.d_uni) (void)hipFree(p->chunk.d_uni);
     if (p->chunk.d_mlo) (void)hipFree(p->chunk.d_mlo);
     if (p->chunk.d_look) (void)hipFree(p->chunk.d_look);
     if (p->chunk.d_halo) (void)hipFree(p->chunk.d_halo);
@@ -3175,6 +3250,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         ca.halo = c.d_halo;
         ca.lookT = c.d_look;
         ca.powM = c.d_pow;
+        ca.uni = c.d_uni;
         void *cargs[] = {&k, &ca};
         const hipError_t ce = hipLaunchKernel(c.fn, dim3(c.n_tiles), dim3(64), cargs, 0, s);
         if (ce != hipSuccess) {
