@@ -1723,7 +1723,10 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     cu64 *const desc = (cu64 *)(uintptr_t)p.srcs;
     cf32 *const dgain = (cf32 *)(uintptr_t)p.srcs;
     const int lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
+    // Every tile resident at once (the host knows): tile = workgroup.  More tiles than slots: tiles are handed out by a ticket, so
+    // that a tile only ever waits for tiles that already run or have finished (its waits go to earlier tiles only).
+    uint32_t tile = blockIdx.x;
+    if (!p.direct) tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
     const uint32_t Ns = p.eq_frames, S = p.n_sources;
     const uint32_t m_lo = ((cu32 *)(uintptr_t)q.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q.m_lo)[tile + 1];
     const uint32_t m0 = m_lo + (uint32_t)lane * R;
@@ -2513,6 +2516,7 @@ struct ChunkPlan {
     size_t cap_tiles = 0, cap_look = 0;
     uint32_t n_tiles = 0, J = 0, frames = 0;
     int resident_per_cu = 0;
+    bool direct = true;
 };
 struct Plan {
     const Variant *v = nullptr;
@@ -2720,26 +2724,24 @@ rh_status build_chunk(rh_rlm *p) {
     constexpr uint64_t H = 4;
     const uint32_t C = p->cfg.channels;
     if (!p->filt || !p->equal || p->cfg.force_general || p->n_sources < 2 || rh::knob(rh::K_NO_CHUNK) || rh::knob(rh::K_NO_MIX_FIRST)) return RH_OK;
-    // the instance: chunks of 1024 frames in runs of 18 (stereo: 8 KiB, mono: 4 KiB); RH_CHUNK_HALF: stereo chunks of 512 frames in runs of 9
-    const bool half = C == 2 && rh::knob(rh::K_CHUNK_HALF);
-    const int R = half ? 9 : 18, KV = (C == 2 && !half) ? 8 : 4;
-    const void *fn = C == 1 ? reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 4>)
-                     : half ? reinterpret_cast<const void *>(&k_rlm_chunk<9, 2, 4>)
-                            : reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 8>);
-    const uint64_t P = (uint64_t)KV * 1024 / (4 * C);
+    // The instances, in the order they are tried: chunks of 1024 frames in runs of 18 (stereo: 8 KiB, mono: 4 KiB), then chunks of
+    // 512 frames in runs of 18 for converters that make more than 1152 frames of 1024 (ratios up to 2.25: 22.05 -> 48 kHz).
+    // RH_CHUNK_HALF (a tuning aid): stereo chunks of 512 frames in runs of 9.
+    struct Inst {
+        int R, KV;
+        const void *fn;
+    };
+    std::vector<Inst> cand;
+    if (C == 2 && rh::knob(rh::K_CHUNK_HALF)) cand.push_back({9, 4, reinterpret_cast<const void *>(&k_rlm_chunk<9, 2, 4>)});
+    if (C == 2) {
+        cand.push_back({18, 8, reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 8>)});
+        cand.push_back({18, 4, reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 4>)});
+    } else {
+        cand.push_back({18, 4, reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 4>)});
+        cand.push_back({18, 2, reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 2>)});
+    }
     const uint64_t Ns = p->eq_frames, M = p->out_frames;
     if (Ns < 2 || (Ns * C) % 4 != 0 || M == 0) return RH_OK;  // (whole 16-byte vectors)
-    const uint64_t tiles = (Ns + P - 1) / P;
-    if (tiles < 2ull * (uint64_t)rh::g_num_cus) return RH_OK;  // short rows: more, smaller pieces fill the chip better
-    if (c.fn != fn) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0) != hipSuccess) return RH_OK;
-        c.resident_per_cu = n < 1 ? -1 : n;
-        c.fn = fn;
-        c.R = R;
-        c.KV = KV;
-    }
-    if (c.resident_per_cu < 1 || tiles > (uint64_t)rh::g_num_cus * (uint64_t)c.resident_per_cu) return RH_OK;  // every tile resident at once
     // the input frame of an output frame (cursor_at / cursor_resolve, and the verbatim last frame)
     const uint64_t F = p->F, T = p->T, cin = p->chunk_in, cout = p->chunk_out;
     auto in_index = [&](uint64_t m) -> uint64_t {
@@ -2749,28 +2751,52 @@ rh_status build_chunk(rh_rlm *p) {
         const uint64_t i = k * cin + il;
         return i + 1 >= Ns ? Ns - 1 : i;
     };
-    std::vector<uint32_t> mlo((size_t)tiles + 1);
-    mlo[0] = 0;
-    for (uint64_t t = 1; t < tiles; ++t) {  // the first frame whose second tap lies in chunk t or behind it
-        uint64_t lo = mlo[(size_t)t - 1], hi = M;
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) / 2;
-            if (in_index(mid) + 1 >= t * P) hi = mid;
-            else lo = mid + 1;
+    std::vector<uint32_t> mlo;
+    uint64_t tiles = 0, n_min = ~0ull;
+    int R = 0, KV = 0;
+    const void *fn = nullptr;
+    for (const Inst &in : cand) {
+        const uint64_t P = (uint64_t)in.KV * 1024 / (4 * C);
+        tiles = (Ns + P - 1) / P;
+        if (tiles < 2ull * (uint64_t)rh::g_num_cus || tiles > 0x3fffffffull) continue;  // short rows: more, smaller pieces fill the chip better
+        mlo.assign((size_t)tiles + 1, 0u);
+        for (uint64_t t = 1; t < tiles; ++t) {  // the first frame whose second tap lies in chunk t or behind it
+            uint64_t lo = mlo[(size_t)t - 1], hi = M;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (in_index(mid) + 1 >= t * P) hi = mid;
+                else lo = mid + 1;
+            }
+            mlo[(size_t)t] = (uint32_t)lo;
         }
-        mlo[(size_t)t] = (uint32_t)lo;
-    }
-    mlo[(size_t)tiles] = (uint32_t)M;
-    uint64_t n_min = ~0ull;
-    for (uint64_t t = 0; t < tiles; ++t) {
-        const uint64_t n = mlo[(size_t)t + 1] - mlo[(size_t)t];
-        if (n == 0 || n > 64ull * R) return RH_OK;  // a ratio that puts more frames into a chunk than 64 runs hold (or none)
-        if (t + 1 < tiles) n_min = std::min(n_min, n);
-        if (t > 0) {  // the two frames the filter looks back at, and the first tap of the first frame: in the 4 frames in front of the chunk
-            const uint64_t m = mlo[(size_t)t];
-            if (m < 2 || in_index(m - 2) + H < t * P || in_index(m) + 1 < t * P) return RH_OK;
+        mlo[(size_t)tiles] = (uint32_t)M;
+        bool fits = true;
+        n_min = ~0ull;
+        for (uint64_t t = 0; t < tiles && fits; ++t) {
+            const uint64_t n = mlo[(size_t)t + 1] - mlo[(size_t)t];
+            if (n == 0 || n > 64ull * in.R) fits = false;  // a ratio that puts more frames into a chunk than 64 runs hold (or none)
+            if (t + 1 < tiles) n_min = std::min(n_min, n);
+            if (t > 0 && fits) {  // the two frames the filter looks back at, and the first tap of the first frame: in the 4 frames in front of the chunk
+                const uint64_t m = mlo[(size_t)t];
+                if (m < 2 || in_index(m - 2) + H < t * P || in_index(m) + 1 < t * P) fits = false;
+            }
+        }
+        if (fits) {
+            R = in.R, KV = in.KV, fn = in.fn;
+            break;
         }
     }
+    if (!fn) return RH_OK;
+    if (c.fn != fn) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0) != hipSuccess) return RH_OK;
+        c.resident_per_cu = n < 1 ? -1 : n;
+        c.fn = fn;
+        c.R = R;
+        c.KV = KV;
+    }
+    if (c.resident_per_cu < 1) return RH_OK;
+    c.direct = tiles <= (uint64_t)rh::g_num_cus * (uint64_t)c.resident_per_cu;  // every tile resident at once: no tickets
     const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
     M2 Tm, Ti;
     scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
@@ -3251,12 +3277,14 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         ca.lookT = c.d_look;
         ca.powM = c.d_pow;
         ca.uni = c.d_uni;
+        k.direct = c.direct ? 1u : 0u;
         void *cargs[] = {&k, &ca};
         const hipError_t ce = hipLaunchKernel(c.fn, dim3(c.n_tiles), dim3(64), cargs, 0, s);
         if (ce != hipSuccess) {
             rh::set_hip_error(ce, "k_rlm_chunk launch");
             return RH_ERR_HIP;
         }
+        if (!c.direct) p->ticket_base += c.n_tiles;  // one ticket per workgroup
         return mark_launch(p, s);
     }
     const bool pre = p->pre_filter;

@@ -177,7 +177,8 @@ def test_mix_first_full_scale_sources(G, O):
     (48000, 48000, None, 600000, 2), (48000, 32000, 5000, 600000, 2),
     (96000, 44100, 5000, 600000, 1),   # more than 2 input frames per output frame: the filter's look-back leaves the 4 frames in front of a chunk
     (44100, 48000, None, 600001, 1),   # an odd length: not whole 16-byte vectors -> the two-launch form
-    (22050, 48000, None, 600000, 1),   # more than 64 x 18 output frames per chunk -> the two-launch form
+    (22050, 48000, None, 600000, 2),   # more than 64 x 18 output frames per 1024-frame chunk: the instance with chunks of 512 frames
+    (16000, 48000, 32768, 600000, 1),  # ratio 3: more than 64 x 18 frames even of 512 -> the two-launch form
     (44100, 48000, None, 200000, 1),   # too few chunks to fill the chip -> the two-launch form
 ])
 @pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
@@ -274,6 +275,19 @@ def test_chunk_kernel_half_chunks(G, O, frm, to, span, n):
     ref = _oracle(O, xs, frm, to, span, "low_pass", 200, None, ch)
     with knobs(RH_CHUNK_HALF="1"):
         got, geo = _run(G, xs, frm, to, ch, span, "low_pass", 200, None)
+    assert geo["mix_first"] == 2, geo
+    assert len(got) == len(ref)
+    assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+@pytest.mark.parametrize("ch,n", [(2, 2_600_000), (1, 3_400_000)])
+def test_chunk_kernel_more_tiles_than_slots(G, O, ch, n):
+    # rows with more chunks than workgroups fit on the chip at once: the tiles are handed out by a ticket (a tile only waits for
+    # earlier tiles, which run or have finished), no longer by workgroup index
+    S = 2
+    xs = [rnd(7000 + s, n * ch, 0.3) for s in range(S)]
+    ref = _oracle(O, xs, 44100, 48000, None, "low_pass", 200, None, ch)
+    got, geo = _run(G, xs, 44100, 48000, ch, None, "low_pass", 200, None)
     assert geo["mix_first"] == 2, geo
     assert len(got) == len(ref)
     assert float(np.max(np.abs(got - ref))) <= TOL
