@@ -646,6 +646,7 @@ struct Src {
 struct Gen {
     srcs: Vec<Src>, plan: *mut RhRlm, din: DeviceBuf, q: [DeviceBuf; 2], stage: [PinnedBuf; 2], side: [PinnedBuf; 2], dside: DeviceBuf,
     cur: usize, slot: usize, head: u64, fill: u64, done: bool,
+    mono: bool, qm: DeviceBuf,                                                       // a fused stream of mono sources (channels = 1): the mono mix, made stereo once per block
     staged: bool, target: u64, crow: u64, conv: [DeviceBuf; 2], dtab: DeviceBuf, tab: [PinnedBuf; 2], ccur: usize,
 }
 impl Gen {
@@ -699,24 +700,26 @@ impl GpuMixer {
     fn start_generation(&mut self) {
         let mut all = std::mem::take(&mut self.pending);
         if all.iter().any(|x| x.up.current_span_len().is_some()) {               // span by span, as rodio converts them: one stream, insertion order
-            self.start_stream(all, true);
+            self.start_stream(all, true, false);
             return;
         }
         for x in &mut all { self.make_direct(x); }
-        let mut rates: Vec<u32> = Vec::new();                                      // continuous sources: one fused stream per input rate, in order of first appearance
-        for x in &all { let r = x.up.sample_rate().get(); if !rates.contains(&r) { rates.push(r); } }
-        for r in rates {
-            let (group, rest): (Vec<Src>, Vec<Src>) = all.into_iter().partition(|x| x.up.sample_rate().get() == r);
+        // continuous sources: one fused stream per (input rate, mono or not), in order of first appearance; mono sources form
+        // streams of mono frames (the kernel reads 4 bytes per frame, the mono mix becomes stereo once per block)
+        let mut kinds: Vec<(u32, bool)> = Vec::new();
+        for x in &all { let k = (x.up.sample_rate().get(), x.ch == 1); if !kinds.contains(&k) { kinds.push(k); } }
+        for (r, mono) in kinds {
+            let (group, rest): (Vec<Src>, Vec<Src>) = all.into_iter().partition(|x| x.up.sample_rate().get() == r && (x.ch == 1) == mono);
             all = rest;
-            self.start_stream(group, false);
+            self.start_stream(group, false, mono);
         }
     }
-    fn start_stream(&mut self, srcs: Vec<Src>, staged: bool) {
+    fn start_stream(&mut self, srcs: Vec<Src>, staged: bool, mono: bool) {
         let from = if staged { self.rate } else { srcs[0].up.sample_rate().get() };
         self.cap_frames = self.opt.block_frames + 4096;                            // a block can hold what the previous one left over
         let mut g = Gen { srcs, plan: ptr::null_mut(), din: DeviceBuf::new(), q: [DeviceBuf::new(), DeviceBuf::new()], stage: [PinnedBuf::new(), PinnedBuf::new()],
                           side: [PinnedBuf::new(), PinnedBuf::new()], dside: DeviceBuf::new(), cur: 0, slot: 0, head: 0, fill: 0, done: false,
-                          staged, target: 0, crow: 0, conv: [DeviceBuf::new(), DeviceBuf::new()], dtab: DeviceBuf::new(), tab: [PinnedBuf::new(), PinnedBuf::new()], ccur: 0 };
+                          mono: mono && !staged, qm: DeviceBuf::new(), staged, target: 0, crow: 0, conv: [DeviceBuf::new(), DeviceBuf::new()], dtab: DeviceBuf::new(), tab: [PinnedBuf::new(), PinnedBuf::new()], ccur: 0 };
         if staged {
             g.target = self.opt.block_frames as u64 + 64 * 20 + 8;                 // a block emits whole tiles (at most 64 * 20 frames) and keeps two frames of history
             g.crow = g.target + 64;
@@ -724,7 +727,7 @@ impl GpuMixer {
             for b in &mut g.conv { b.reserve(g.srcs.len() * crowf); }
         }
         let cfg = RhRlmConfig {
-            from_rate: from, to_rate: self.rate, channels: 2, span_len: 0, filter_kind: self.opt.filter_kind, filter_freq: self.opt.filter_freq, filter_q: self.opt.filter_q,
+            from_rate: from, to_rate: self.rate, channels: if g.mono { 1 } else { 2 }, span_len: 0, filter_kind: self.opt.filter_kind, filter_freq: self.opt.filter_freq, filter_q: self.opt.filter_q,
             max_sources: g.srcs.len() as u32, max_in_frames: if staged { g.crow } else { self.cap_frames as u64 },
             frames_per_lane: self.opt.frames_per_lane, ring_stages: 0, no_balance: 0, force_general: 0, custom_coeffs: [0.0; 5], filter_first: 0,
         };
@@ -760,8 +763,10 @@ impl GpuMixer {
     /// One block of a continuous generation: every source's row = [frames the previous block left unconsumed | a freshly pulled
     /// block]; one copy, the fused launch (resample + filter + ordered sum), what the converter has not consumed is kept.
     fn run_block_direct(&mut self, gi: usize) {
-        let (row_len, cap_frames, block_frames, stream, out_cap) = (self.row, self.cap_frames, self.opt.block_frames, self.pump.stream, self.out_cap_frames);
+        let (cap_frames, block_frames, stream, out_cap) = (self.cap_frames, self.opt.block_frames, self.pump.stream, self.out_cap_frames);
         let g = &mut self.gens[gi];
+        let native: u16 = if g.mono { 1 } else { 2 };                              // channels of the rows the fused launch reads
+        let row_len = if g.mono { (cap_frames + 3) & !3 } else { self.row };        // floats per row
         let s_n = g.srcs.len();
         let slot = g.slot;
         g.slot ^= 1;
@@ -770,14 +775,14 @@ impl GpuMixer {
         let mut side_off = vec![0usize; s_n];
         let mut side_floats = 0usize;
         for (i, x) in g.srcs.iter().enumerate() {
-            if x.ch != 2 { side_off[i] = side_floats; side_floats += (cap_frames * x.ch as usize + 3) & !3; }
+            if x.ch != native { side_off[i] = side_floats; side_floats += (cap_frames * x.ch as usize + 3) & !3; }
         }
         if side_floats > 0 { g.side[slot].reserve(side_floats); g.dside.reserve(side_floats); }
         let (mut ptrs, mut avail, mut ended) = (Vec::with_capacity(s_n), Vec::with_capacity(s_n), Vec::with_capacity(s_n));
         for i in 0..s_n {
             let x = &mut g.srcs[i];
             let ch = x.ch as usize;
-            let row: &mut [f32] = if ch == 2 { &mut g.stage[slot].slice_mut(s_n * row_len)[i * row_len..(i + 1) * row_len] }
+            let row: &mut [f32] = if ch == native as usize { &mut g.stage[slot].slice_mut(s_n * row_len)[i * row_len..(i + 1) * row_len] }
                                   else { &mut g.side[slot].slice_mut(side_floats)[side_off[i]..] };
             let mut have = x.held.len();
             assert!(have / ch + if x.ended { 0 } else { block_frames } <= cap_frames, "GpuMixer: held frames exceed the plan");
@@ -797,19 +802,26 @@ impl GpuMixer {
         if side_floats > 0 {                                                        // ChannelCountConverter on the device (channels.rs:57-85), into the stereo rows
             ck(unsafe { rh_memcpy_h2d(g.dside.p.cast(), g.side[slot].p.cast(), side_floats * 4, stream) }, "rh_memcpy_h2d");
             for i in 0..s_n {
-                if g.srcs[i].ch != 2 && avail[i] > 0 {
+                if g.srcs[i].ch != native && avail[i] > 0 {
                     ck(unsafe { rh_channels_convert(g.din.p.add(i * row_len), g.dside.p.add(side_off[i]), avail[i] as usize, g.srcs[i].ch as u32, 2, stream) }, "rh_channels_convert");
                 }
             }
         }
         let (mut out, mut consumed) = (0u64, 0u64);
-        ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.queue_end(), out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
-           "rh_rlm_stream_block_v");
+        if g.mono {                                                                 // the mono mix of the block, then ChannelCountConverter(1 -> 2) (channels.rs:64-73) behind the stereo queue
+            g.qm.reserve(out_cap as usize * 2);
+            ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.qm.p, out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
+               "rh_rlm_stream_block_v");
+            if out > 0 { ck(unsafe { rh_channels_convert(g.queue_end(), g.qm.p, out as usize, 1, 2, stream) }, "rh_channels_convert"); }
+        } else {
+            ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.queue_end(), out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
+               "rh_rlm_stream_block_v");
+        }
         g.fill += out;
         let mut all_ended = true;
         for i in 0..s_n {                                                           // keep what the converter has not consumed (a few hundred frames)
             let ch = g.srcs[i].ch as usize;
-            let row: &[f32] = if ch == 2 { &g.stage[slot].slice(s_n * row_len)[i * row_len..] } else { &g.side[slot].slice(side_floats)[side_off[i]..] };
+            let row: &[f32] = if ch == native as usize { &g.stage[slot].slice(s_n * row_len)[i * row_len..] } else { &g.side[slot].slice(side_floats)[side_off[i]..] };
             let have = avail[i] as usize * ch;
             let drop = (consumed as usize * ch).min(have);
             let x = &mut g.srcs[i];
@@ -937,7 +949,8 @@ impl GpuMixer {
         ck(unsafe { rh_stream_synchronize(stream) }, "rh_stream_synchronize");     // the blocks about to be patched have been produced
         let staged = item.up.current_span_len().is_some();
         if !staged { self.make_direct(&mut item); }
-        self.start_stream(vec![item], staged);
+        let mono = !staged && item.ch == 1;
+        self.start_stream(vec![item], staged, mono);
         self.last_join = j;
         let gi = self.gens.len() - 1;
         let need = sched_end.saturating_sub(j);
