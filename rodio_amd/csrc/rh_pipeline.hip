@@ -2803,6 +2803,7 @@ rh_status build_chunk(rh_rlm *p) {
     const M2 B = mul(mul(Tm, A), Ti);
     const uint32_t J = look_tiles(B, n_min);
     if (J == 0 || J > 32) return RH_OK;
+    if ((uint64_t)tiles * J * 16 > (64ull << 20)) return RH_OK;  // (the per-tile look-back table: a filter that forgets slowly over very long rows)
     {
         const rh_status w = wait_idle(p);  // an earlier run may still read the tables
         if (w != RH_OK) return w;
