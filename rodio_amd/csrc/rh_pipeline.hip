@@ -2579,7 +2579,7 @@ struct rh_rlm {
     // block streaming with per-source states (rh_rlm_stream_block_v)
     std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
     uint32_t st_cols = 0;            // columns of an aggregate row for the stream (0: no such stream yet)
-    // Recorded behind every launch of this handle.  The library's streams are hipStreamNonBlocking: a null-stream
+    // Recorded (by wait_idle) behind what the handle has queued.  The library's streams are hipStreamNonBlocking: a null-stream
     // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
     // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
     hipEvent_t idle_ev = nullptr;
@@ -2589,17 +2589,22 @@ struct rh_rlm {
 
 namespace {
 
-// Block until every launch of this handle has completed (see rh_rlm::idle_ev).
+// Block until every launch of this handle has completed.  The event is recorded HERE, behind everything the handle has queued on
+// its stream (streams run in order), not behind every launch: a launch costs no API call and no marker on the device for it.
 rh_status wait_idle(rh_rlm *p) {
     if (p->launched) {
+        if (!p->idle_ev) RH_HIP_TRY(hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming));
+        RH_HIP_TRY(hipEventRecord(p->idle_ev, p->last_stream));
         RH_HIP_TRY(hipEventSynchronize(p->idle_ev));
         p->launched = false;
     }
     return RH_OK;
 }
 rh_status mark_launch(rh_rlm *p, hipStream_t s) {
-    if (!p->idle_ev) RH_HIP_TRY(hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming));
-    RH_HIP_TRY(hipEventRecord(p->idle_ev, s));
+    if (p->launched && p->last_stream != s) {  // the handle moves to another stream: what it queued on the old one first
+        const rh_status w = wait_idle(p);
+        if (w != RH_OK) return w;
+    }
     p->launched = true;
     p->last_stream = s;
     return RH_OK;
