@@ -17,6 +17,16 @@ SURVEY.md 8(e)).  Rank 0 prints ONE JSON line.
                  thread, on the WHOLE workload (12-13 s); `all_cores` = the same with the sources sharded over the host's cores
                  (an upper bound: rodio's mixer is single-threaded by construction).
   parity       = every output frame of the timed launch against that oracle run.
+  roofline.per_source = the same batch in the same run with every source on its own through the converter and the filter
+                 (rh_rlm_set_mix_first(0): the path sources with filters or lengths of their own take): kernel time, fraction,
+                 traffic and parity of the GENERAL kernel beside the headline's specialisation.
+
+N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when no launcher has; under the
+driver's `python -m torch.distributed.run ... bench.py --gpus N` it is a rank.  The line then also carries `multi_gpu` (ranks
+seen, the collective alone through torch.distributed AND through the C ABI's rh_allreduce_sum_f32, overlap, the reduced block
+against the ranks' partials), `parity` of the ALL-REDUCED block against the oracle over all S*N sources (every rank runs the
+oracle over its shard on its share of the cores), `cpu_baseline` and rank 0's `roofline` with live traffic.  The kernel's tiles go
+by ticket there (rh_rlm_set_exclusive(0)): RCCL's kernels share the CUs.
 
 The other configurations (single GPU, one JSON line each; evidence for the numbers in DESIGN.md / README.md):
 
@@ -89,6 +99,10 @@ def pmc_traffic(argv, kernel_like, per_call=False):
         return None, "rocprofv3 not available" if not exe else "disabled (RH_BENCH_NO_PMC=1)"
     vals = {}
     env = dict(os.environ, RH_BENCH_CHILD="1", TMPDIR="/tmp")
+    for k in list(env):  # an N > 1 run profiles rank 0's kernel in a single-process child: nothing of the launcher's environment goes along
+        if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT",
+                 "RH_BENCH_ONE_DEVICE", "RH_BENCH_SPAWNED") or k.startswith("TORCHELASTIC_") or k.startswith("NCCL_ASYNC"):
+            env.pop(k)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="rh_pmc_", dir="/tmp")
         try:
@@ -157,6 +171,41 @@ def cpu_baseline(x, S, N, span, freq, want_all_cores=True, ch=2):
     return res, ref
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per GPU, under
+    torch.distributed.run on 127.0.0.1 (the form the driver uses for N > 1, spelled out by us when it does not).  The ranks'
+    stdout passes through: rank 0 prints the one JSON line."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RH_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def shard_oracle(host, S, N, Cn, span, freq, threads):
+    """The oracle's mix of `host`'s S sources, the sources dealt over `threads` host threads: every thread runs the restated
+    rodio pipeline (ordered f32 sum inside) over its sources, the threads' mixes are added in f64.  (ctypes drops the GIL.)"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import rodio_oracle as O
+
+    data = host.reshape(S, N, Cn)
+    threads = max(1, min(threads, S))
+    shards = [np.ascontiguousarray(data[i::threads]) for i in range(threads)]
+    with ThreadPoolExecutor(threads) as ex:
+        outs = list(ex.map(lambda sh: O.pipeline_resample_lowpass_mix(sh, 44100, 48000, span if span else O.SPAN_NONE, freq, 0.5, want_output=True), shards))
+    ref = np.zeros(outs[0].shape, dtype=np.float64)
+    for o in outs:
+        ref += o
+    return ref
+
+
 def headline(args, argv):
     import numpy as np
     import torch
@@ -169,11 +218,13 @@ def headline(args, argv):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:
+        sys.exit(f"bench.py --gpus {args.gpus} inside a launcher of {world} rank(s): the two must agree")
     # RH_BENCH_ONE_DEVICE=1: development aid for a 1-GPU box -- every rank time-shares cuda:0 and the
     # collective goes through gloo (RCCL refuses two ranks on one device).  Not a measurement mode.
     one_dev = os.environ.get("RH_BENCH_ONE_DEVICE") == "1"
+    if world > 1 and not one_dev and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py --gpus {world}: {torch.cuda.device_count()} GPU(s) visible (RH_BENCH_ONE_DEVICE=1 time-shares one device over gloo: a development aid, not a measurement)")
     dev = 0 if one_dev else local_rank
     torch.cuda.set_device(dev)
     rh.init(dev)
@@ -183,6 +234,14 @@ def headline(args, argv):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if (world > 1 and one_dev) else "cuda"  # where small tensors of host-side collectives live
+
+    def allreduce_scalar(v, op):
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     S, N, Cn = args.sources, args.frames, (1 if args.config == "2mono" else 2)
     span = 32768 if args.config == "2span" else args.span
@@ -196,6 +255,11 @@ def headline(args, argv):
         lens = [int(v) for v in np.random.default_rng(1).integers(N // 2, N + 1, S)]
     pipe = rh.ResampleLowpassMix(44100, 48000, Cn, span or None, "low_pass", args.freq, 0.5, max_sources=S,
                                  max_in_frames=N, frames_per_lane=args.frames_per_lane, ring_stages=args.ring_stages, no_balance=args.no_balance, force_general=args.force_general)
+    # N > 1: the all-reduce of block k runs on RCCL's stream beside the kernel of block k+1 -- the kernel does not have the CUs to
+    # itself, so its tiles go by ticket (rodio_hip.h: rh_rlm_set_exclusive)
+    pipe.set_exclusive(world == 1 and not args.shared_device)
+    if args.per_source:
+        pipe.set_mix_first(False)
     pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
     M = pipe.out_frames
     tuned = None
@@ -207,7 +271,7 @@ def headline(args, argv):
     lib = _lib.lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def step(k, ev=None):
+    def step(k, ev=None, reduce=True):
         buf = outs[k & 1]
         if works[k & 1] is not None:  # the all-reduce that last used this buffer (stream-level wait)
             works[k & 1].wait()
@@ -217,7 +281,7 @@ def headline(args, argv):
         pipe.run(buf)
         if ev is not None:
             lib.rh_event_record(ev[1], stream)
-        if world > 1:  # the mixer sum across the source shards: one RCCL all-reduce over xGMI,
+        if world > 1 and reduce:  # the mixer sum across the source shards: one RCCL all-reduce over xGMI,
             works[k & 1] = D.all_reduce_mix(buf, async_op=True)  # rodio_amd/distributed.py; overlaps step k+1
 
     def drain():
@@ -245,17 +309,26 @@ def headline(args, argv):
     dt = time.perf_counter() - t0
     pipe.check_status()  # a tile hand-off that timed out fails the run here (and would have poisoned the block)
     if world > 1:
-        t = torch.tensor([dt], device="cuda" if not one_dev else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = allreduce_scalar(dt, dist.ReduceOp.MAX)
     kernel_ms = elapsed(lib, _lib, evs)
     kernel_avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     ms_per_step = dt / args.steps * 1e3
+    mixed_last = outs[(args.steps - 1) & 1]  # the last timed step's block: the FULL mix on every rank once its all-reduce has run
 
-    # ---- untimed diagnostics of the N > 1 path: the collective alone, and the reduced block against the ranks' partials ----
+    if child:
+        if rank == 0:
+            print(json.dumps({"child": True, "kernel_ms": kernel_avg_ms, "calls": args.warmup + args.steps}), flush=True)
+        return
+
+    # ---- untimed diagnostics of the N > 1 path: the collective alone, the reduced block against the ranks' partials, the ranks seen --
     multi = None
+    local = None
     if world > 1:
-        local = pipe.run(outs[0]).clone()  # this rank's partial mix
+        kmax = allreduce_scalar(kernel_avg_ms, dist.ReduceOp.MAX)
+        kmin = allreduce_scalar(kernel_avg_ms, dist.ReduceOp.MIN)
+        seen = int(round(allreduce_scalar(1.0, dist.ReduceOp.SUM)))
+        local = torch.empty_like(outs[0])
+        pipe.run(local)  # this rank's partial mix
         torch.cuda.synchronize()
         red = local.clone()
         reps = 10
@@ -277,87 +350,205 @@ def headline(args, argv):
         acc = torch.zeros(k, device=local.device, dtype=torch.float32)
         for r_ in range(world):
             acc += parts[r_]
-        exposed = max(ms_per_step - kernel_avg_ms, 0.0)
-        multi = {"allreduce_ms": allreduce_ms, "allreduce_bytes": int(local.numel() * 4),
+        exposed = max(ms_per_step - kmax, 0.0)
+        multi = {"n_ranks_seen": seen, "backend": dist.get_backend(), "kernel_ms_max_over_ranks": kmax, "kernel_ms_min_over_ranks": kmin,
+                 "allreduce_ms": allreduce_ms, "allreduce_bytes": int(local.numel() * 4),
                  "exposed_ms_per_step": exposed, "overlap_frac": max(0.0, min(1.0, 1.0 - exposed / allreduce_ms)) if allreduce_ms > 0 else None,
                  "reduce_check": {"samples": k, "max_abs_err_vs_rank_ordered_sum_of_partials": float((red[:k] - acc).abs().max()), "peak": float(acc.abs().max())}}
+        # the C ABI's own collective (rh_comm_* over a dlopen'ed RCCL, what a Rust host would call): the same reduction, timed the same way
+        if one_dev:
+            multi["native_comm"] = {"skipped": "RCCL refuses two ranks on one device (RH_BENCH_ONE_DEVICE=1)"}
+        else:
+            try:
+                box = [D.NativeComm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = D.NativeComm(rank, world, box[0])
+                nat = local.clone()
+                comm.all_reduce(nat)
+                torch.cuda.synchronize()
+                diff = float((nat - red).abs().max())
+                dist.barrier()
+                e0.record()
+                for _ in range(reps):
+                    comm.all_reduce(nat)
+                e1.record()
+                torch.cuda.synchronize()
+                multi["native_comm"] = {"allreduce_ms": e0.elapsed_time(e1) / reps, "max_abs_diff_vs_torch_distributed": diff, "entry": "rh_allreduce_sum_f32"}
+                comm.close()
+            except Exception as e:  # noqa: BLE001 -- the line must still come out; the failure is in it
+                multi["native_comm"] = {"error": str(e)[:300]}
 
-    if rank == 0 and child:
-        print(json.dumps({"child": True, "kernel_ms": kernel_avg_ms, "calls": args.warmup + args.steps}), flush=True)
-    elif rank == 0:
-        in_samples = sum(lens) * Cn
-        alg_bytes = 4 * in_samples + 4 * M * Cn
-        achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-        geo = pipe.geometry()
-        # the profiling passes repeat this run's launches: same workload, the geometry the autotune kept, no autotune of their own
-        child_argv = [a for a in argv]
-        child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
-        child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
-        # (a ragged batch and a mix-first batch are two kernels per launch: the sum over both, per call)
-        two = bool(geo["ragged_pair"]) or geo.get("mix_first") == 1
-        traffic, traffic_how = (None, "single-GPU runs only") if world > 1 else pmc_traffic(child_argv, ["%k_rlm%", "%k_mix_%"], per_call=two)
-        ph = pipe.phase_cycles()
-        if ph is not None:
-            geo["phase_cycles"] = [round(x) for x in ph]
-        lc = pipe.late_carries()
-        geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
-        if tuned:
-            geo["autotuned"] = True
-        kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_chunk" if geo.get("mix_first") == 2 else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
-        res = {
-            "metric": "Msamples/s through resample+low_pass+mix pipeline",
-            "value": in_samples * world * args.steps / dt / 1e6,
-            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"{S} f32 {'mono' if Cn == 1 else 'stereo'} sources/GPU x {N} frames" + (" (lengths uniform in [N/2, N])" if ragged else "")
-                            + f", 44.1->48 kHz linear resample + low_pass({args.freq}) + ordered Mixer sum"
-                            + (f", span_len={span}" if span else ", span_len=None")
-                            + f"; numpy default_rng(1234+s) U(-1,1)/{S * world}"
-                            + (f"; {world} ranks, sources sharded {S}/rank, RCCL all-reduce of the mixed block" if world > 1 else ""),
-                "sources_per_gpu": S, "in_frames": N, "out_frames": M, "channels": Cn, "kernel": kern, "geometry": geo,
-            },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_detail": traffic_how, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_avg_ms},
-        }
-        if multi:
-            one = args.one_gpu_value
-            if one is None and args.one_gpu_line:  # a JSON line (or a file holding one) of the same bench at --gpus 1
-                txt = open(args.one_gpu_line).read() if os.path.exists(args.one_gpu_line) else args.one_gpu_line
-                one = float(json.loads(txt.strip().splitlines()[-1])["value"])
-            if one:
-                multi["efficiency_vs_1gpu"] = res["value"] / (world * one)  # weak scaling: N ranks do N times the work of one
-                multi["one_gpu_value"] = one
-            res["multi_gpu"] = multi
-        if world == 1 and not args.no_cpu_baseline and ragged:  # sources of different lengths: the oracle's Mixer over per-source chains, one thread, the whole workload
+    # ---- the per-source path in the same run: the same batch with every source on its own through the converter and the filter
+    # (rh_rlm_set_mix_first(0): what sources with filters / lengths of their own take) -- the general number beside the headline's
+    per_source = None
+    if not ragged and not args.per_source and not args.no_per_source and pipe.geometry().get("mix_first"):
+        pipe.set_mix_first(False)
+        pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
+        if not (args.no_autotune or args.frames_per_lane or args.ring_stages):
+            pipe.autotune()
+        ps_out = torch.empty(M * Cn, device="cuda", dtype=torch.float32)
+        for _ in range(args.warmup):
+            pipe.run(ps_out)
+        pevs = events(lib, _lib, args.steps)
+        torch.cuda.synchronize()
+        for k in range(args.steps):
+            lib.rh_event_record(pevs[k][0], stream)
+            pipe.run(ps_out)
+            lib.rh_event_record(pevs[k][1], stream)
+        torch.cuda.synchronize()
+        pipe.check_status()
+        pms = elapsed(lib, _lib, pevs)
+        pgeo = pipe.geometry()
+        per_source = {"kernel_ms": sum(pms) / len(pms), "out": ps_out, "geometry": {k_: pgeo[k_] for k_ in ("frames_per_lane", "ring_stages", "n_tiles", "general_kernel", "mix_first")}}
+        pipe.set_mix_first(True)
+        pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
+
+    # ---- parity and the CPU baseline ---------------------------------------------------------------------------------------
+    in_samples = sum(lens) * Cn
+    cores = os.cpu_count() or 1
+    base = parity = None
+    ref = None
+    if not args.no_cpu_baseline and ragged and world == 1:  # sources of different lengths: the oracle's Mixer over per-source chains, one thread, the whole workload
+        from oracle import rodio_oracle as O
+
+        t0 = time.perf_counter()
+        mx = O.Mixer(Cn, 48000)
+        for s_ in range(S):
+            mx.add(O.UniformSourceIterator(O.TestSource(host[s_, : Cn * lens[s_]], Cn, 44100), Cn, 48000).low_pass(args.freq))
+        ref = mx.collect()
+        dtc = time.perf_counter() - t0
+        base = {"value": in_samples / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": f"the whole workload ({S} sources, {in_samples} samples), {dtc:.1f} s; restated rodio CPU iterator path (not rustc-compiled); host has {cores} logical cores"}
+        got = mixed_last.cpu().numpy()
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64)) if got.shape == ref.shape else None
+        parity = ({"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()), "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5),
+                   "vs": "oracle Mixer over the per-source chains, the timed launch's whole block"} if d is not None else {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"})
+    elif not args.no_cpu_baseline and not ragged and world == 1:
+        base, ref = cpu_baseline(host, S, N, span, args.freq, ch=Cn)
+        got = mixed_last.cpu().numpy()  # the last timed launch's block
+        if got.shape == ref.shape:
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            parity = {"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()),
+                      "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5), "vs": "oracle (restated rodio CPU path), the timed launch's whole block"}
+        else:
+            parity = {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"}
+    elif not args.no_cpu_baseline and not ragged:
+        # N > 1.  (1) rank 0 times the one-thread oracle on a bounded sample of ITS shard while the other ranks wait (no contention
+        # for the cores); (2) every rank runs the oracle over its whole shard on its share of the cores; (3) its own partial mix is
+        # compared with that, and the ALL-REDUCED block of the last timed step with the f64 sum of all ranks' oracle mixes.
+        if rank == 0:
             from oracle import rodio_oracle as O
 
+            nb = min(S, max(1, args.baseline_sources))
             t0 = time.perf_counter()
-            mx = O.Mixer(Cn, 48000)
-            for s_ in range(S):
-                mx.add(O.UniformSourceIterator(O.TestSource(host[s_, : Cn * lens[s_]], Cn, 44100), Cn, 48000).low_pass(args.freq))
-            ref = mx.collect()
+            O.pipeline_resample_lowpass_mix(host.reshape(S, N, Cn)[:nb], 44100, 48000, span if span else O.SPAN_NONE, args.freq, 0.5, want_output=False)
             dtc = time.perf_counter() - t0
-            res["cpu_baseline"] = {"value": in_samples / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                   "sample": f"the whole workload ({S} sources, {in_samples} samples), {dtc:.1f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
-            got = outs[(args.steps - 1) & 1].cpu().numpy()
-            d = np.abs(got.astype(np.float64) - ref.astype(np.float64)) if got.shape == ref.shape else None
-            res["parity"] = ({"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()), "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5),
-                              "vs": "oracle Mixer over the per-source chains, the timed launch's whole block"} if d is not None else {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"})
-        if world == 1 and not args.no_cpu_baseline and not ragged:
-            base, ref = cpu_baseline(host, S, N, span, args.freq, ch=Cn)
-            res["cpu_baseline"] = base
-            got = outs[(args.steps - 1) & 1].cpu().numpy()  # the last timed launch's block
-            if got.shape == ref.shape:
-                d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-                res["parity"] = {"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()),
-                                 "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5), "vs": "oracle (restated rodio CPU path), the timed launch's whole block"}
+            base = {"value": nb * N * Cn / dtc / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                    "sample": f"sources 0..{nb - 1} of rank 0's shard ({nb} x {N} frames), one thread, {dtc:.1f} s; restated rodio CPU iterator path (not rustc-compiled); host has {cores} logical cores"}
+        dist.barrier()
+        threads = max(1, cores // world)
+        t0 = time.perf_counter()
+        ref_shard = shard_oracle(host, S, N, Cn, span, args.freq, threads)
+        dto = time.perf_counter() - t0
+        mine = local.cpu().numpy().astype(np.float64)
+        err_mine = float(np.abs(mine - ref_shard).max()) if mine.shape == ref_shard.shape else float("inf")
+        err_parts = allreduce_scalar(err_mine, dist.ReduceOp.MAX)
+        dto_max = allreduce_scalar(dto, dist.ReduceOp.MAX)
+        tot = torch.from_numpy(ref_shard).to(cdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ref = tot.cpu().numpy()
+        if rank == 0:
+            got = mixed_last.cpu().numpy().astype(np.float64)
+            ok_shape = got.shape == ref.shape
+            err = float(np.abs(got - ref).max()) if ok_shape else float("inf")
+            parity = {"frames_compared": int(len(ref) // Cn) if ok_shape else 0, "of": int(M), "max_abs_err": err, "peak": float(np.abs(ref).max()), "tolerance": 1e-5,
+                      "per_rank_partial_max_abs_err": err_parts, "ok": bool(err <= 1e-5 and err_parts <= 1e-5),
+                      "vs": f"the all-reduced block of the last timed step against the oracle over all {S * world} sources (every rank its shard on {threads} threads, {dto_max:.1f} s; "
+                            f"thread and rank mixes added in f64), and every rank's partial mix against its shard's oracle mix"}
+            base["all_cores"] = {"value": S * world * N * Cn / dto_max / 1e6, "unit": "Msamples/s", "cores": threads * world,
+                                 "sample": f"the whole job: {S * world} sources sharded over {world} ranks x {threads} threads, {dto_max:.2f} s; an upper bound (rodio's mixer is single-threaded, stream.rs:538-545)"}
+    if per_source is not None:
+        alg_b = 4 * in_samples + 4 * M * Cn
+        ps = {"kernel": "k_rlm_fast (every source through the converter and the filter on its own, merged filter state)", "kernel_ms": per_source["kernel_ms"],
+              "achieved": alg_b / (per_source["kernel_ms"] * 1e-3) / 1e9, "frac": alg_b / (per_source["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "geometry": per_source["geometry"]}
+        cmp_ref = ref if world == 1 else None
+        if world > 1 and not args.no_cpu_baseline:
+            cmp_ref = ref_shard
+        if cmp_ref is not None:
+            gotp = per_source["out"].cpu().numpy().astype(np.float64)
+            if gotp.shape == cmp_ref.shape:
+                e_ = float(np.abs(gotp - cmp_ref.astype(np.float64)).max())
+                ps["parity"] = {"max_abs_err": e_, "tolerance": 1e-5, "ok": bool(e_ <= 1e-5), "frames_compared": int(len(cmp_ref) // Cn),
+                                "vs": "the same oracle run" if world == 1 else "this rank's shard of the oracle run"}
             else:
-                res["parity"] = {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"}
-        print(json.dumps(res), flush=True)
+                ps["parity"] = {"ok": False, "error": f"length {gotp.shape} vs oracle {cmp_ref.shape}"}
+        per_source = ps
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    # ---- rank 0 alone from here: the counter passes (single-process children on this rank's GPU) and the line ----------------
+    alg_bytes = 4 * in_samples + 4 * M * Cn
+    achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+    geo = pipe.geometry()
+    # the profiling passes repeat this run's launches: same workload, the geometry the autotune kept, no autotune of their own
+    child_argv = [a for a in argv]
+    child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
+    child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
+    if world > 1 or args.shared_device:
+        child_argv.append("--shared-device")  # tiles by ticket, as in this run
+    # (a ragged batch and a mix-first batch are two kernels per launch: the sum over both, per call)
+    two = bool(geo["ragged_pair"]) or geo.get("mix_first") == 1
+    traffic, traffic_how = pmc_traffic(child_argv, ["%k_rlm%", "%k_mix_%"], per_call=two)
+    if per_source is not None:
+        pa = [a for a in argv]
+        pa[pa.index("--frames-per-lane") + 1] = str(per_source["geometry"]["frames_per_lane"])
+        pa[pa.index("--ring-stages") + 1] = str(per_source["geometry"]["ring_stages"])
+        per_source["traffic"], per_source["traffic_detail"] = pmc_traffic(pa + ["--per-source"], ["%k_rlm%"], per_call=False)
+    ph = pipe.phase_cycles()
+    if ph is not None:
+        geo["phase_cycles"] = [round(x) for x in ph]
+    lc = pipe.late_carries()
+    geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
+    if tuned:
+        geo["autotuned"] = True
+    geo["tiles_by"] = "workgroup index (exclusive device)" if (world == 1 and not args.shared_device) else "ticket (the device is shared with the collective's kernels)"
+    kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_chunk" if geo.get("mix_first") == 2 else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
+    res = {
+        "metric": "Msamples/s through resample+low_pass+mix pipeline",
+        "value": in_samples * world * args.steps / dt / 1e6,
+        "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{S} f32 {'mono' if Cn == 1 else 'stereo'} sources/GPU x {N} frames" + (" (lengths uniform in [N/2, N])" if ragged else "")
+                        + f", 44.1->48 kHz linear resample + low_pass({args.freq}) + ordered Mixer sum"
+                        + (f", span_len={span}" if span else ", span_len=None")
+                        + f"; numpy default_rng(1234+s) U(-1,1)/{S * world}"
+                        + (f"; {world} ranks, sources sharded {S}/rank, RCCL all-reduce of the mixed block" if world > 1 else ""),
+            "sources_per_gpu": S, "in_frames": N, "out_frames": M, "channels": Cn, "kernel": kern, "geometry": geo,
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_detail": traffic_how, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_avg_ms,
+                     "of": "rank 0's kernel (every rank runs the same kernel on its own 256-source shard)" if world > 1 else "the one kernel of a step"},
+    }
+    if per_source is not None:
+        res["roofline"]["per_source"] = per_source
+    if multi:
+        one = args.one_gpu_value
+        if one is None and args.one_gpu_line:  # a JSON line (or a file holding one) of the same bench at --gpus 1
+            txt = open(args.one_gpu_line).read() if os.path.exists(args.one_gpu_line) else args.one_gpu_line
+            one = float(json.loads(txt.strip().splitlines()[-1])["value"])
+        if one:
+            multi["efficiency_vs_1gpu"] = res["value"] / (world * one)  # weak scaling: N ranks do N times the work of one
+            multi["one_gpu_value"] = one
+        res["multi_gpu"] = multi
+    if base is not None:
+        res["cpu_baseline"] = base
+    if parity is not None:
+        res["parity"] = parity
+    print(json.dumps(res), flush=True)
 
 
 def _timed_oracle(fn, units, what, cores=1):
@@ -562,9 +753,15 @@ def main():
     ap.add_argument("--force-general", type=int, default=0)
     ap.add_argument("--no-autotune", action="store_true", help="keep the cost model's launch geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-source", action="store_true", help="the headline batch on the per-source path (rh_rlm_set_mix_first(0)); the default line carries it as roofline.per_source")
+    ap.add_argument("--no-per-source", action="store_true", help="skip the per-source leg of the default line")
+    ap.add_argument("--shared-device", action="store_true", help="tiles by ticket although one rank runs (rh_rlm_set_exclusive(0)): what the N > 1 ranks do")
+    ap.add_argument("--baseline-sources", type=int, default=64, help="N > 1: sources of rank 0's shard the one-thread CPU baseline times")
     ap.add_argument("--one-gpu-value", type=float, default=None, help="Msamples/s of this bench at --gpus 1: an N > 1 run then prints multi_gpu.efficiency_vs_1gpu")
     ap.add_argument("--one-gpu-line", default=None, help="... or the 1-GPU JSON line itself / a file that holds it")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)  # (does not return)
     import torch
 
     if not torch.cuda.is_available():
@@ -575,6 +772,8 @@ def main():
                 "--frames-per-lane", str(args.frames_per_lane), "--ring-stages", str(args.ring_stages), "--no-balance", str(args.no_balance), "--force-general", str(args.force_general)]
         if args.no_autotune:
             argv.append("--no-autotune")
+        if args.per_source:
+            argv.append("--per-source")
         headline(args, argv)
     else:
         side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames)])

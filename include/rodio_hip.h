@@ -363,6 +363,17 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
  * applies the factor; without a filter the result stays bit-identical to amplify-then-convert.  Sources beyond
  * n keep 1.0.  Takes effect for the sources that are set and for every later set_sources / stream block. */
 rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n);
+/* May the launches of this handle assume that they have the device to themselves?  exclusive != 0 (the default: a one-shot job on
+ * its own): a launch whose tiles are all resident at once numbers them by workgroup index.  exclusive == 0: other work shares the
+ * CUs while the handle runs -- a collective on a second stream (the N > 1 ranks of bench.py: the all-reduce of block k overlaps the
+ * kernel of block k+1), copy launches (GpuMixer), another process -- and tiles are handed out by ticket, which needs neither full
+ * residency nor in-order dispatch: a tile only ever waits for tiles that already hold a wave slot.  Same results either way. */
+rh_status rh_rlm_set_exclusive(rh_rlm *p, int32_t exclusive);
+/* "Mix first" (DESIGN.md 4.6): filtered sources of one length and one filter are summed at the input rate and converted and
+ * filtered once (the converter and the filter are linear).  enable == 0 keeps every source on its own through the converter and
+ * the filter (what a batch of per-source filters or lengths takes anyway); results agree within the 1e-5 of the filtered path.
+ * Takes effect from the next run / stream block. */
+rh_status rh_rlm_set_mix_first(rh_rlm *p, int32_t enable);
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames,
                      rh_stream stream);
 /* The same over the sources [first, first+count) only (a sub-mix; count = 1: one filtered stream). */

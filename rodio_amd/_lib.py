@@ -161,6 +161,8 @@ SIGNATURES = {
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_set_gains": (i32, [vp, f32p, u32]),
+    "rh_rlm_set_exclusive": (i32, [vp, i32]),
+    "rh_rlm_set_mix_first": (i32, [vp, i32]),
     "rh_rlm_run_subset": (i32, [vp, u32, u32, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_stream_begin": (i32, [vp]),
     "rh_rlm_stream_block": (i32, [vp, C.POINTER(vp), u32, u64, i32, vp, u64, C.POINTER(u64), C.POINTER(u64), vp]),

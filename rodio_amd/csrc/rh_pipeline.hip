@@ -2585,26 +2585,51 @@ struct rh_rlm {
     hipEvent_t idle_ev = nullptr;
     bool launched = false;
     hipStream_t last_stream = nullptr;  // the stream of the launches idle_ev covers
+    // rh_rlm_set_exclusive: may a launch assume that nothing else occupies CUs while it runs?  Only then does a launch whose tiles
+    // all fit at once take tile = workgroup index (Params::direct); otherwise tiles are handed out by ticket, which needs neither
+    // residency nor in-order dispatch: a tile only ever waits for tiles that already hold a wave slot.
+    bool exclusive = true;
+    bool mix_first_on = true;  // rh_rlm_set_mix_first
 };
 
 namespace {
 
+// Every live handle, for rh::rlm_stream_retired (rh_stream_destroy / rh_stream_release_scratch call it after they have
+// synchronised the stream): a handle whose last launches went to a stream that is about to go must not record an event on it later.
+std::mutex g_handles_mu;
+std::vector<rh_rlm *> g_handles;
+
 // Block until every launch of this handle has completed.  The event is recorded HERE, behind everything the handle has queued on
 // its stream (streams run in order), not behind every launch: a launch costs no API call and no marker on the device for it.
+// The stream may be gone by now if it was a caller's own (a PyTorch stream destroyed behind the library's back; the library's
+// streams tell the handle when they go): the record then fails, and the whole device is waited for instead.  Either way the handle
+// comes out idle -- a failure here must not wedge every later set_sources / set_gains / stream_begin.
 rh_status wait_idle(rh_rlm *p) {
     if (p->launched) {
-        if (!p->idle_ev) RH_HIP_TRY(hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming));
-        RH_HIP_TRY(hipEventRecord(p->idle_ev, p->last_stream));
-        RH_HIP_TRY(hipEventSynchronize(p->idle_ev));
+        hipError_t e = hipSuccess;
+        if (!p->idle_ev) e = hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(p->idle_ev, p->last_stream);
+        if (e == hipSuccess) e = hipEventSynchronize(p->idle_ev);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (the sticky error of the failed record)
+            e = hipDeviceSynchronize();
+        }
         p->launched = false;
+        p->last_stream = nullptr;
+        if (e != hipSuccess) {
+            rh::set_hip_error(e, "wait_idle");
+            return RH_ERR_HIP;
+        }
     }
     return RH_OK;
 }
+// In front of the first kernel of a launch on `s`: a handle that moves to another stream waits for what it queued on the old one
+// BEFORE anything is queued on the new one (the kernels of the two streams would otherwise share d_gran / d_ctl / d_mix).
+rh_status pre_launch(rh_rlm *p, hipStream_t s) {
+    if (p->launched && p->last_stream != s) return wait_idle(p);
+    return RH_OK;
+}
 rh_status mark_launch(rh_rlm *p, hipStream_t s) {
-    if (p->launched && p->last_stream != s) {  // the handle moves to another stream: what it queued on the old one first
-        const rh_status w = wait_idle(p);
-        if (w != RH_OK) return w;
-    }
     p->launched = true;
     p->last_stream = s;
     return RH_OK;
@@ -2965,6 +2990,18 @@ rh_status activate_plan(rh_rlm *p, Plan *pl) {
 
 }  // namespace
 
+namespace rh {
+// `s` has been synchronised and is about to be destroyed (or its scratch released): handles whose launches went there are idle.
+void rlm_stream_retired(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_handles_mu);
+    for (rh_rlm *p : g_handles)
+        if (p->launched && p->last_stream == s) {
+            p->launched = false;
+            p->last_stream = nullptr;
+        }
+}
+}  // namespace rh
+
 extern "C" {
 
 rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
@@ -3046,13 +3083,33 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
         return st;
     }
     p->plan = &p->fast;
+    {
+        std::lock_guard<std::mutex> lk(g_handles_mu);
+        g_handles.push_back(p);
+    }
     *out = p;
+    return RH_OK;
+}
+
+rh_status rh_rlm_set_exclusive(rh_rlm *p, int32_t exclusive) {
+    if (!p) return RH_ERR_INVALID;
+    p->exclusive = exclusive != 0;
+    return RH_OK;
+}
+
+rh_status rh_rlm_set_mix_first(rh_rlm *p, int32_t enable) {
+    if (!p) return RH_ERR_INVALID;
+    p->mix_first_on = enable != 0;
     return RH_OK;
 }
 
 rh_status rh_rlm_destroy(rh_rlm *p) {
     if (!p) return RH_OK;
     (void)wait_idle(p);  // nothing of this handle may still run when its tables go
+    {
+        std::lock_guard<std::mutex> lk(g_handles_mu);
+        g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), p), g_handles.end());
+    }
 #if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 3
     if (p->d_ctl && p->chunk.ok) {
         uint32_t h[8] = {0};
@@ -3172,8 +3229,11 @@ struct StreamArgs {
     uint32_t gran_cols = 0;  // != 0: per-source states (k_rlm_wave), aggregate rows of this many columns, tile 0 in column 1
 };
 // Mix first (k_mix_rows / k_mix_ring in front of a one-source fused launch): one-shot runs of filtered equal-length batches.
-static bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool streaming, bool batch) {
-    return &pl == &p->fast && p->filt && !streaming && !batch && count >= 2 && !rh::knob(rh::K_NO_MIX_FIRST);
+// ... and blocks of a stream that carries ONE summed state (rh_rlm_stream_block; rh_rlm_stream_block_v while its sources run
+// together): the state of the sum is the sum of the states, so the block is summed first and the one mixed row streams through
+// the fused kernel with the stream's state words.  `per_source_states`: streams whose blocks carry a state per source.
+static bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool per_source_states, bool batch) {
+    return &pl == &p->fast && p->filt && p->mix_first_on && !per_source_states && !batch && count >= 2 && !rh::knob(rh::K_NO_MIX_FIRST);
 }
 static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
                             const StreamArgs &sa = StreamArgs());
@@ -3199,6 +3259,10 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     if (!dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
     if (out_capacity_frames < p->out_frames) return RH_ERR_CAPACITY;
     hipStream_t s = rh::as_stream(stream);
+    {
+        const rh_status w = pre_launch(p, s);
+        if (w != RH_OK) return w;
+    }
     const Plan &pl = *p->plan;
     p->epoch += 1;
     if (p->epoch == 0) {  // tag wrap: old tags could alias, start over from a clean table
@@ -3269,7 +3333,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     }
     // Mix first: a filtered batch of equal-length sources is summed at the input rate (k_mix_rows: the one pass over the input),
     // and the fused kernel converts and filters that ONE stream.
-    if (p->chunk.ok && mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0) && count == p->n_sources && first == 0) {
+    if (p->chunk.ok && !sa.mode && mix_first_applies(p, pl, count, false, batch_streams != 0) && count == p->n_sources && first == 0) {
         // mix first in one kernel: every tile sums its aligned chunk of every source, then converts and filters its part of the mix
         const ChunkPlan &c = p->chunk;
         k.tabs = c.d_tabs;
@@ -3283,21 +3347,21 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         ca.lookT = c.d_look;
         ca.powM = c.d_pow;
         ca.uni = c.d_uni;
-        k.direct = c.direct ? 1u : 0u;
+        k.direct = (c.direct && p->exclusive) ? 1u : 0u;
         void *cargs[] = {&k, &ca};
         const hipError_t ce = hipLaunchKernel(c.fn, dim3(c.n_tiles), dim3(64), cargs, 0, s);
         if (ce != hipSuccess) {
             rh::set_hip_error(ce, "k_rlm_chunk launch");
             return RH_ERR_HIP;
         }
-        if (!c.direct) p->ticket_base += c.n_tiles;  // one ticket per workgroup
+        if (!k.direct) p->ticket_base += c.n_tiles;  // one ticket per workgroup
         return mark_launch(p, s);
     }
     const bool pre = p->pre_filter;
     if (pre && (&pl != &p->fast || sa.mode || batch_streams)) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs of equal-length batches (rodio_hip.h)
-    if (pre || mix_first_applies(p, pl, count, sa.mode != 0, batch_streams != 0)) {
+    if (pre || mix_first_applies(p, pl, count, sa.gran_cols != 0, batch_streams != 0)) {
         const uint64_t n_floats = (uint64_t)p->eq_frames * p->cfg.channels;
-        const size_t row = (size_t)((n_floats + 3) & ~3ull);
+        const size_t row = (size_t)(((sa.mode ? (uint64_t)p->cfg.max_in_frames * p->cfg.channels : n_floats) + 3) & ~3ull);  // a stream: sized once, for its largest block
         const size_t need = row * (pre ? 2 : 1) + 64;  // the mixed row (16-byte vectors) [, the filtered row], then the descriptor on its own 128 bytes
         if (need > p->mix_floats) {
             const rh_status w = wait_idle(p);
@@ -3331,7 +3395,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         k.srcs = ydesc;
         k.n_sources = 1;
         // every tile of the one-stream launch resident at once: no tickets (see Params::direct)
-        k.direct = (uint64_t)p->n_tiles <= (uint64_t)rh::g_num_cus * (uint64_t)std::max(pl.resident_per_cu, 0) ? 1u : 0u;
+        k.direct = (p->exclusive && (uint64_t)p->n_tiles <= (uint64_t)rh::g_num_cus * (uint64_t)std::max(pl.resident_per_cu, 0)) ? 1u : 0u;
     }
     // batch mode fills the chip many times over: no residency shaping, the bare LDS request
     hipError_t e = hipLaunchKernel(pl.kernel, dim3((uint32_t)grid), dim3(64), args, batch_streams ? std::max((uint32_t)pl.v->KV * 1024u, 64u * ((uint32_t)pl.v->R * 8u + 8u)) /* one source per tile: one stage of the ring, reused by the output transpose */ : p->launch_lds, s);
@@ -3532,6 +3596,7 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
             p->eq_frames = (uint32_t)avail_frames;
             p->n_sources = n_sources;
             p->out_frames = out;
+            p->chunk.ok = false;  // (the tile tables of k_rlm_chunk belong to a one-shot batch)
             rh_status st = activate_plan(p, &p->fast);
             if (st != RH_OK) return st;
             const uint64_t tiles = flush ? (out + L - 1) / L : out / L + 1;  // + the tile that holds the end-state lane
@@ -3605,6 +3670,8 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
             p->epoch = 0;
         }
         if (p->filt) {
+            const rh_status pw = pre_launch(p, hs);
+            if (pw != RH_OK) return pw;
             hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
             RH_CHECK_LAUNCH();
             const rh_status mk = mark_launch(p, hs);

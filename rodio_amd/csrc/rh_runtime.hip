@@ -263,6 +263,7 @@ rh_status rh_stream_destroy(rh_stream s) {
     RH_REQUIRE_INIT();
     RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(s)));
     rh::drop_stream_scratch(rh::as_stream(s));
+    rh::rlm_stream_retired(rh::as_stream(s));
     RH_HIP_TRY(hipStreamDestroy(rh::as_stream(s)));
     return RH_OK;
 }
@@ -270,6 +271,7 @@ rh_status rh_stream_release_scratch(rh_stream s) {
     RH_REQUIRE_INIT();
     RH_HIP_TRY(hipStreamSynchronize(rh::as_stream(s)));
     rh::drop_stream_scratch(rh::as_stream(s));
+    rh::rlm_stream_retired(rh::as_stream(s));
     return RH_OK;
 }
 rh_status rh_stream_synchronize(rh_stream s) {

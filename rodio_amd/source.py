@@ -671,6 +671,15 @@ class ResampleLowpassMix:
         g = np.ascontiguousarray(gains, dtype=np.float32)
         check(lib.rh_rlm_set_gains(self._h, g.ctypes.data_as(_lib.f32p), g.size), "rh_rlm_set_gains")
 
+    def set_exclusive(self, exclusive=True):
+        """False: other work shares the CUs while this handle runs (a collective on a second stream, copy launches): tiles by
+        ticket instead of by workgroup index (rodio_hip.h)."""
+        check(lib.rh_rlm_set_exclusive(self._h, 1 if exclusive else 0), "rh_rlm_set_exclusive")
+
+    def set_mix_first(self, enable=True):
+        """False: every source goes through the converter and the filter on its own (the general path)."""
+        check(lib.rh_rlm_set_mix_first(self._h, 1 if enable else 0), "rh_rlm_set_mix_first")
+
     def run_subset(self, first, count, out=None):
         """Mix of the sources [first, first+count) only."""
         if out is None:

@@ -91,6 +91,61 @@ def test_bench_two_ranks_time_sharing_one_device(G):
     assert 0.0 <= mg["overlap_frac"] <= 1.0
 
 
+def test_bench_gpus_2_spawns_its_own_ranks_and_prints_a_complete_line(G):
+    """`python bench.py --gpus 2` -- plain, no torch.distributed.run around it -- must start its ranks
+    itself, and the N > 1 line must carry parity against the ORACLE (not only against the ranks' own partials), the CPU
+    baseline, the roofline of the per-rank kernel with live traffic, and the ranks the communicator saw.  One GPU here, so
+    the two ranks time-share it over gloo (RH_BENCH_ONE_DEVICE=1); the tiles of the kernel go by ticket as on the real node."""
+    import shutil
+
+    env = dict(os.environ, RH_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--sources", "16", "--frames", "262144", "--baseline-sources", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["sources_per_gpu"] == 16
+    mg = d["multi_gpu"]
+    assert mg["n_ranks_seen"] == 2 and mg["backend"] == "gloo"
+    assert "skipped" in mg["native_comm"]  # RCCL refuses two ranks on one device; with two devices the entry holds allreduce_ms
+    assert "ticket" in d["config"]["geometry"]["tiles_by"]
+    par = d["parity"]
+    assert par["ok"] and par["max_abs_err"] <= 1e-5 and par["per_rank_partial_max_abs_err"] <= 1e-5 and par["frames_compared"] == d["config"]["out_frames"]
+    assert "oracle over all 32 sources" in par["vs"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["kernel_ms"] > 0
+    if shutil.which("rocprofv3"):
+        assert rf["traffic"] and 0.9 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.3 * rf["algorithmic_bytes_per_launch"], rf
+    ps = rf["per_source"]
+    assert ps["parity"]["ok"] and ps["kernel_ms"] > 0 and ps["geometry"]["mix_first"] == 0
+
+
+def test_tiles_by_ticket_give_the_bits_of_tiles_by_workgroup_index(G):
+    """rh_rlm_set_exclusive(0) (what the N > 1 ranks and GpuMixer use: other kernels share the CUs) only changes how a launch
+    numbers its tiles: k_rlm_chunk and the one-stream launch of the two-kernel form give the same bits either way."""
+    import torch
+
+    S, n = 24, 600_000  # >= 2 x 256 chunks of 1024 frames: k_rlm_chunk applies
+    xs = [torch.from_numpy((np.random.default_rng(77 + s).uniform(-1, 1, 2 * n) / S).astype(np.float32)).cuda() for s in range(S)]
+    outs = {}
+    for excl in (True, False):
+        p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+        p.set_exclusive(excl)
+        p.set_sources(xs)
+        assert p.geometry()["mix_first"] == 2
+        for _ in range(3):
+            o = p.run().clone()
+        p.check_status()
+        outs[excl] = o
+        p.close()
+    assert torch.equal(outs[True], outs[False])
+
+
 def _comm_worker(rank, uid, q):
     import torch
 
