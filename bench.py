@@ -454,7 +454,7 @@ def headline(args, argv):
         err_mine = float(np.abs(mine - ref_shard).max()) if mine.shape == ref_shard.shape else float("inf")
         err_parts = allreduce_scalar(err_mine, dist.ReduceOp.MAX)
         dto_max = allreduce_scalar(dto, dist.ReduceOp.MAX)
-        tot = torch.from_numpy(ref_shard).to(cdev)
+        tot = torch.from_numpy(ref_shard.copy()).to(cdev)  # (a copy: on the CPU path the all-reduce below would otherwise sum INTO ref_shard)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         ref = tot.cpu().numpy()
         if rank == 0:

@@ -291,3 +291,34 @@ def test_chunk_kernel_more_tiles_than_slots(G, O, ch, n):
     assert geo["mix_first"] == 2, geo
     assert len(got) == len(ref)
     assert float(np.max(np.abs(got - ref))) <= TOL
+
+
+def test_block_streaming_sums_first_too(G, O):
+    """rh_rlm_stream_block carries ONE summed filter state, and the state of the sum is the sum of the states: a block of a
+    stream is summed at the input rate (k_mix_ring for blocks that fill the chip, k_mix_rows for short ones) and the one mixed
+    row streams through the fused kernel with the stream's state words.  Blocks of 600 000 frames (the ring) and short ones;
+    the concatenation against the oracle's per-source chains and against the per-source path of the same stream."""
+    import torch
+
+    S, n = 4, 1_250_000
+    xs = [rnd(4200 + s, 2 * n, 1.0 / S) for s in range(S)]
+    gains = np.array([1.0, 0.5, 1.25, 0.75], dtype=np.float32)
+    ref = _oracle(O, xs, 44100, 48000, None, "low_pass", 200, gains, 2)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    got = {}
+    for mix_first in (True, False):
+        p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=700_000)
+        p.set_gains(gains)
+        p.set_mix_first(mix_first)
+        p.stream_begin()
+        cuts = [0, 600_000, 1_200_000, 1_200_700, 1_249_000, n]
+        outs = []
+        for k in range(len(cuts) - 1):
+            outs.append(p.stream_feed([x[2 * cuts[k]: 2 * cuts[k + 1]] for x in xd], flush=(k == len(cuts) - 2)))
+        p.check_status()
+        got[mix_first] = torch.cat(outs).cpu().numpy()
+        p.close()
+    assert len(got[True]) == len(ref) == len(got[False])
+    e_first, e_each, e_between = (float(np.max(np.abs(got[True] - ref))), float(np.max(np.abs(got[False] - ref))), float(np.max(np.abs(got[True] - got[False]))))
+    print(f"[stream mix first] |mix first - oracle| {e_first:.2e}  |per source - oracle| {e_each:.2e}  |between| {e_between:.2e}")
+    assert e_first <= TOL and e_each <= TOL and e_between <= 2e-6
