@@ -336,7 +336,43 @@ __device__ __forceinline__ void scan_lin_v(T &V, const float (&cs)[4], float c15
 //   waves of a workgroup exchange their aggregates through LDS (two barriers per tile); only the workgroup-level
 //   aggregates and end states travel through HBM, one record per LW frames, and every wave walks the (short) look-back over
 //   them on its own -- redundant polls are cheaper than two more barriers.
-template <int C, int R, int NW, bool FULL, bool SKEW>
+// One share's fetch when it is short (the end of a stream): guarded vector loads into the share's LDS slots, zeros behind the end.
+template <int C, int V>
+__device__ __forceinline__ void load_share_guarded(const float *src, v4f *lds, const uint32_t nfloat, int lane) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint32_t q = k * 64 + lane, o = 4u * q;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (o + 4 <= nfloat) v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + o));
+        else if (o < nfloat) {
+            v.x = src[o];
+            if (o + 1 < nfloat) v.y = src[o + 1];
+            if (o + 2 < nfloat) v.z = src[o + 2];
+        }
+        lds[slot_of<V>(q / V, q % V)] = v;
+    }
+}
+// One share's results, LDS rows -> whole lines.  Streaming (nt) stores: every output byte is written once, and a 1:1 stream of
+// reads and writes moves 5-8 % faster with them (tools/ubench/write_bw.hip; the limiter 0.278 -> 0.257 ms, the biquad 0.212 -> 0.204).
+template <int V, bool FULL>
+__device__ __forceinline__ void store_share(float *dst, const v4f *lds, const uint32_t nfloat, int lane) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const uint32_t q = k * 64 + lane, o = 4u * q;
+        const v4f v = lds[slot_of<V>(q / V, q % V)];
+        if (FULL || o + 4 <= nfloat) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(dst + o));
+        else if (o < nfloat) {
+            dst[o] = v.x;
+            if (o + 1 < nfloat) dst[o + 1] = v.y;
+            if (o + 2 < nfloat) dst[o + 2] = v.z;
+        }
+    }
+}
+
+// NIO > 0: the workgroup has NIO more waves that do nothing but move samples (k_limit_scan): this function then neither fetches
+// nor stores, and its polls are the only vector-memory loads of its wave -- a poll retires when ITS data arrives, not behind
+// 16 KiB of LDS-DMA and stores in the in-order vmcnt queue.
+template <int C, int R, int NW, bool FULL, bool SKEW, int NIO = 0>
 __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
                                            const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
                                            const uint32_t nstream, const float *next_src, v4f *next_buf, const uint32_t ticket_ahead, uint32_t *ticket_slot RH_LP_PARAM) {
@@ -373,23 +409,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     // look-back: that poll was then free, but the peak poll paid the whole fetch latency).
     const bool had_I = SKEW && have_I;
     const bool dma_first = had_I || a.dma_top;
-    if (dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
+    if (NIO == 0 && dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     // ---- the samples: whole shares were put into LDS by the DMA issued a tile ago; a short share (end of a stream) is
-    //      fetched here, guarded, into the same slots
-    if (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const uint32_t q = k * 64 + lane, o = 4u * q;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (o + 4 <= nfloat) v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + o));
-            else if (o < nfloat) {
-                v.x = src[o];
-                if (o + 1 < nfloat) v.y = src[o + 1];
-                if (o + 2 < nfloat) v.z = src[o + 2];
-            }
-            lds[slot_of<V>(q / V, q % V)] = v;
-        }
-    }
+    //      fetched here, guarded, into the same slots.  (FULL is a property of the TILE -- every wave of the workgroup runs the same
+    //      instantiation, barriers included; a whole share inside a short tile arrived by DMA like any other)
+    if (NIO == 0 && !FULL && nf != L) load_share_guarded<C, V>(src, lds, nfloat, lane);
     __builtin_amdgcn_wave_barrier();
     RH_LP(0)
     // ---- this lane's run: gain computer + lane-local max-affine segment per channel (the samples stay in the LDS row) ----
@@ -481,7 +505,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         Co *= a.rL64;
         return Co < kNegligible;
     };
+#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK  // timing experiment only (wrong results): what do the polls cost?
+    if (false) {
+#else
     if (!have_I) {
+#endif
         float Ao[C], Bo[C], Co = 1.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
@@ -496,7 +524,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
         for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
     }
-    if (!dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
+    if (NIO == 0 && !dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(2)
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
     T I[N], Pz[N];
@@ -581,6 +609,10 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
         for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
         bool doneP = dead, doneI = dead || !SKEW || !has_next;
+#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK
+        doneP = doneI = true;
+        dead = true;  // (skips the poll pair below; un-poisoned again right after)
+#endif
         int64_t baseP = (int64_t)tile - 1, baseI = (int64_t)ntile - 1;
         if (SKEW && !dead) {
             PollPair<C> q;
@@ -609,6 +641,9 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 #pragma unroll
         for (int c = 0; c < C; ++c) Icarry[c] = Ao[c];
     }
+#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK
+    dead = false;
+#endif
     if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
         if (lane == 0) atomicOr(a.status, 1u);
 #pragma unroll
@@ -678,26 +713,32 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     RH_LP(5)
     // ---- LDS rows -> coalesced store -----------------------------------------------------------------------------------
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const uint32_t q = k * 64 + lane, o = 4u * q;
-        const v4f v = lds[slot_of<V>(q / V, q % V)];
-        if (FULL || o + 4 <= nfloat) *reinterpret_cast<v4f *>(dst + o) = v;
-        else if (o < nfloat) {
-            dst[o] = v.x;
-            if (o + 1 < nfloat) dst[o + 1] = v.y;
-            if (o + 2 < nfloat) dst[o + 2] = v.z;
-        }
+    if (NIO == 0) {
+        if (FULL || nf == L) store_share<V, true>(dst, lds, nfloat, lane);
+        else store_share<V, false>(dst, lds, nfloat, lane);
     }
     __builtin_amdgcn_wave_barrier();  // the rows are free for the next tile
     RH_LP(6)
 }
 
-template <int C, int R, int NW, bool SKEW>
+// NIO = 0: every wave fetches (LDS-DMA, a tile ahead) and stores its own share.  NIO > 0: the workgroup has NIO I/O waves behind
+// its NW computing waves; they own the samples' way in and out, the computing waves touch vector memory for their hand-offs only.
+//
+// Why (round 4, tools/ubench/write_bw.hip): the kernel without its look-backs takes 0.214 ms, with them 0.245 -- not because a
+// poll's round trip is long but because `s_waitcnt vmcnt(0)` behind a poll retires the wave's whole in-order queue first: the
+// 8 KiB of LDS-DMA for the next tile and the 8 KiB of stores of the last one.  Every poll was a drain of the wave's I/O, twice per
+// tile, and a drained queue is bandwidth not used.  And the I/O skeleton itself -- 8 waves each moving 8 KiB shares through their
+// own ring -- copies at 5.2 TB/s, where TWO waves moving the whole 64 KiB tile reach 6.07 TB/s (the memory system likes fewer,
+// longer queues: 4 waves 5.99, 8 waves 5.28).  So: B0 at the top of a tile = "the tile's samples have landed AND the tile before
+// is complete in its rows"; behind it the I/O waves store the tile before (LDS rows -> whole lines, nt) and request the tile
+// after into the buffer that just became free -- one burst per tile period, a full period ahead of its use -- then sit out
+// barriers (1) and (2).  The computing waves' vmcnt holds polls and publishes, nothing else.
+template <int C, int R, int NW, bool SKEW, int NIO = 0>
 // (occupancy bound: 4 workgroups per CU where the registers allow it without a spill -- 4 channels x 4 frames do not: a spill is a
 // vector-memory operation of the compiler's own inside the counted waits of the LDS-DMA; tests/test_code_objects.py checks)
-__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
+__global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
     static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW, "a lane's run is whole 16-byte vectors");
+    static_assert(NIO == 0 || NW % NIO == 0, "every I/O wave moves the same number of shares");
     constexpr int V = C * R / 4;  // 16-byte vectors per lane; a wave's share of a tile is V KiB
     constexpr uint32_t L = 64u * R, LW = L * NW;
     __shared__ __attribute__((aligned(1024))) v4f bufs[NW][2][64 * V];  // per wave: the tile being worked on and the one being fetched
@@ -718,12 +759,18 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2)
     // k % S): a tile only ever waits for tiles with smaller tickets, which run or have finished.  Tickets are taken two
     // tiles ahead (thread 0, through LDS, published by the barriers of the tile in between): the tile after the current one
     // is known when the current one starts, so its samples are requested (LDS-DMA) before any of the current tile's work.
-    auto share = [&](uint32_t ticket, const float *&src, uint32_t &nf) {
+    auto share_of = [&](uint32_t ticket, int w, const float *&src, float *&dst, uint32_t &nf) {
         const uint32_t tile = ticket / a.n_streams, stream = ticket - tile * a.n_streams;
-        const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;
+        const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)w * L;
         nf = f0 >= a.frames ? 0u : (a.frames - f0 < L ? (uint32_t)(a.frames - f0) : L);
         src = a.src + stream * a.stride + f0 * C;
+        dst = a.dst + stream * a.stride + f0 * C;
     };
+    auto share = [&](uint32_t ticket, const float *&src, uint32_t &nf) {
+        float *dst;
+        share_of(ticket, wave, src, dst, nf);
+    };
+    auto tile_full = [&](uint32_t ticket) { return ((uint64_t)(ticket / a.n_streams) + 1) * LW <= a.frames; };  // every share of the tile is whole
     if (threadIdx.x == 0) {
         s_ticket[0] = atomicAdd(a.ctl, 1u);
         s_ticket[1] = atomicAdd(a.ctl, 1u);
@@ -735,6 +782,71 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2)
     float Icarry[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) Icarry[c] = 0.0f;
+    if constexpr (NIO > 0) {
+        constexpr int PER = NW / NIO;  // shares per I/O wave
+        const bool io = wave >= NW;
+        const int w0 = (wave - NW) * PER;
+        // a tile's way in: whole shares by LDS-DMA, the short ones at the end of a stream guarded (zeros behind the end)
+        auto io_fetch = [&](uint32_t ticket, int b) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const float *src;
+                float *dst;
+                uint32_t nf;
+                share_of(ticket, w0 + i, src, dst, nf);
+                if (nf == L) dma_share<V>(src, bufs[w0 + i][b], lane);
+                else load_share_guarded<C, V>(src, bufs[w0 + i][b], nf * C, lane);
+            }
+        };
+        auto io_store = [&](uint32_t ticket, int b) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const float *src;
+                float *dst;
+                uint32_t nf;
+                share_of(ticket, w0 + i, src, dst, nf);
+                if (nf == L) store_share<V, true>(dst, bufs[w0 + i][b], nf * C, lane);
+                else if (nf) store_share<V, false>(dst, bufs[w0 + i][b], nf * C, lane);
+            }
+        };
+        if (io && cur < total) io_fetch(cur, 0);
+        uint32_t prev = 0;
+        while (cur < total) {
+            if (io) {
+                wait_vm<0>();                                      // this tile's samples have landed (and the stores of two tiles ago are done)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a guarded share went through registers into its slots)
+                __syncthreads();                                   // B0: ... and every computing wave has left the tile before
+                // the I/O waves stand at the computing waves' barriers too: their work is dealt over the intervals so that they are
+                // never the last to arrive -- the stores in the short interval up to (1) (the gain computer), the requests in the
+                // long one up to (2) (integrator look-back + run), nothing behind (2)
+                if (n > 0) io_store(prev, (n - 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows have been read: their buffer is free
+                __syncthreads();                                   // (1)
+                if (nxt < total) io_fetch(nxt, (n + 1) & 1);
+                __syncthreads();                                   // (2)
+            } else {
+                uint32_t ticket_ahead = 0;
+                if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u);  // stored by limit_tile in front of its second barrier
+                uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
+                const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
+                const float *src;
+                uint32_t nf;
+                share(cur, src, nf);
+                const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
+                const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
+                __syncthreads();  // B0
+                if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW, NIO>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+                else limit_tile<C, R, NW, false, SKEW, NIO>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+            }
+            prev = cur;
+            cur = nxt;
+            nxt = s_ticket[(n + 2) % 3];  // written before barrier (2) of the tile just done
+            ++n;
+        }
+        __syncthreads();  // the last tile is complete in its rows
+        if (io && n > 0) io_store(prev, (n - 1) & 1);
+        wait_vm<0>();
+    } else {
     if (cur < total) {
         const float *src;
         uint32_t nf;
@@ -766,7 +878,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2)
         const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
         const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
         v4f *const buf2 = bufs[wave][(n + 1) & 1];
-        if (nf == L) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        // FULL is the TILE's property, the same for every wave of the workgroup: all of them run one instantiation, barriers included
+        if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
         else limit_tile<C, R, NW, false, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
         prev_full = nf == L;
         cur = nxt;
@@ -774,6 +887,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2)
         ++n;
     }
     wait_vm<0>();
+    }
 #ifdef RH_LIMIT_PROFILE
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_limit_prof[i], lp_acc[i]);
@@ -797,15 +911,19 @@ using LimitFn = void (*)(const LimitArgs);
 struct LimitVariant {
     int C, R, NW;
     LimitFn fn, fn_skew;  // fn_skew: the variant with the skewed integrator look-back, or nullptr
+    int NIO;              // I/O waves behind the NW computing waves (0: every wave moves its own share)
 };
-#define RH_LV(c, r, nw) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw, false>, (nw) >= 4 ? &k_limit_scan<c, r, nw, ((nw) >= 4)> : nullptr}
+#define RH_LV(c, r, nw) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw, false>, (nw) >= 4 ? &k_limit_scan<c, r, nw, ((nw) >= 4)> : nullptr, 0}
+#define RH_LVIO(c, r, nw, nio) LimitVariant{c, r, nw, &k_limit_scan<c, r, nw, false, nio>, &k_limit_scan<c, r, nw, true, nio>, nio}
 const LimitVariant kVariants[] = {
+    RH_LVIO(2, 16, 6, 2),  // 6 computing + 2 I/O waves, tiles of 6144 frames: only with RH_LIMIT_NIO=1 (rh_limit)
     RH_LV(1, 8, 8),  RH_LV(1, 16, 8), RH_LV(1, 16, 16), RH_LV(1, 8, 1),
     RH_LV(2, 8, 8),  RH_LV(2, 8, 16), RH_LV(2, 8, 4),  RH_LV(2, 8, 1), RH_LV(2, 16, 8), RH_LV(2, 16, 4),
     RH_LV(3, 4, 8),  RH_LV(3, 4, 1),  RH_LV(4, 4, 8),   RH_LV(4, 4, 1), RH_LV(5, 4, 8), RH_LV(5, 4, 1),
     RH_LV(6, 4, 8),  RH_LV(6, 4, 1),  RH_LV(7, 4, 8),   RH_LV(7, 4, 1), RH_LV(8, 4, 8), RH_LV(8, 4, 1),
 };
 #undef RH_LV
+#undef RH_LVIO
 
 size_t rec_stride(uint32_t channels) {
     switch (channels) {
@@ -858,14 +976,20 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     if (rh::knob(rh::K_LIMIT_R) || rh::knob(rh::K_LIMIT_NW)) {  // tuning aids: the variant closest to the request
         const int want_R = rh::knob(rh::K_LIMIT_R) ? atoi(rh::knob(rh::K_LIMIT_R)) : 16, want_NW = rh::knob(rh::K_LIMIT_NW) ? atoi(rh::knob(rh::K_LIMIT_NW)) : 8;
         for (const LimitVariant &c : kVariants) {
-            if (c.C != (int)channels) continue;
+            if (c.C != (int)channels || c.NIO) continue;
             auto score = [&](const LimitVariant &x) { return 10 * std::abs(x.NW - want_NW) + std::abs(x.R - want_R); };
             if (!v || score(c) < score(*v)) v = &c;
         }
     } else {
         auto tile_of = [](const LimitVariant &x) { return (uint64_t)64 * x.R * x.NW; };
+        const char *nio_knob = rh::knob(rh::K_LIMIT_NIO);
+        const bool want_io = nio_knob && nio_knob[0] == '1';  // RH_LIMIT_NIO=1: the I/O-wave variant (measured SLOWER: DESIGN.md 5.1; kept selectable so that the
+        for (const LimitVariant &c : kVariants) {             // measurement can be repeated, and tested: tests/test_gpu_limit.py)
+            if (want_io && c.NIO && c.C == (int)channels && tile_of(c) <= 2 * frames) v = &c;
+        }
         for (const LimitVariant &c : kVariants) {
-            if (c.C != (int)channels || c.NW > 8) continue;  // (16-wave tiles: only on request)
+            if (v && v->NIO) break;
+            if (c.C != (int)channels || c.NW > 8 || c.NIO) continue;  // (16-wave tiles: only on request)
             if (!v) {
                 v = &c;
                 continue;
@@ -972,11 +1096,11 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
         int &per_cu_cached = occupancy[v - kVariants];
         if (per_cu_cached == 0) {
             int q = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(v->fn), 64 * (int)NW, 0);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(v->fn), 64 * (int)(NW + v->NIO), 0);
             per_cu_cached = q < 1 ? 1 : q;
         }
         int per_cu = per_cu_cached;
-        if (per_cu * (int)NW > 16) per_cu = 16 / (int)NW > 0 ? 16 / (int)NW : 1;
+        if (per_cu * (int)(NW + v->NIO) > 16) per_cu = 16 / (int)(NW + v->NIO) > 0 ? 16 / (int)(NW + v->NIO) : 1;
         if (const char *w = rh::knob(rh::K_LIMIT_WGS)) per_cu = atoi(w) > 0 ? atoi(w) : per_cu;  // tuning aid: resident workgroups per CU
         uint64_t grid = (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
         const uint64_t total = tiles64 * n_streams;
@@ -986,7 +1110,7 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
             void *args[] = {&a};
             bool skew = v->fn_skew && grid < n_streams;  // see k_limit_scan: only with more streams than workgroups
             if (const char *k = rh::knob(rh::K_LIMIT_SKEW)) skew = v->fn_skew && k[0] == '1';  // tuning aid
-            e = hipLaunchKernel(reinterpret_cast<const void *>(skew ? v->fn_skew : v->fn), dim3((uint32_t)grid), dim3(64 * NW), args, 0, s);
+            e = hipLaunchKernel(reinterpret_cast<const void *>(skew ? v->fn_skew : v->fn), dim3((uint32_t)grid), dim3(64 * (NW + (uint32_t)v->NIO)), args, 0, s);
         }
     }
     if (e != hipSuccess) {

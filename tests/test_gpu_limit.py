@@ -93,6 +93,32 @@ def test_limiter_one_poll_point_variant_with_few_streams(G, O):
     G.async_status()
 
 
+@pytest.mark.parametrize("S,frames", [(5, 40000), (70, 16384), (300, 13000), (3, 6144 * 3), (3, 6144 * 3 + 1)])
+def test_limiter_io_wave_variant(G, O, S, frames):
+    """RH_LIMIT_NIO=1: the variant with two I/O waves behind six computing waves (tiles of 6144 frames; the computing waves' polls
+    then travel alone in vmcnt).  Measured slower than the shipped geometry, kept selectable so that the measurement
+    can be repeated -- and right: short last tiles, streams that end on a tile boundary, more streams than workgroups (one poll
+    point), state carried across two blocks."""
+    import torch
+
+    ch = 2
+    xs = [_signal(3100 + s, frames, ch, loud=0.6 + 0.07 * (s % 30)) for s in range(S)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    with knobs(RH_LIMIT_NIO="1"):
+        out = G.limit_batch(x, ch, 48000).cpu().numpy()
+        half = (frames // 2) * ch
+        st = torch.zeros((S, ch * 2), device="cuda")
+        a = G.limit_batch(x[:, :half].contiguous(), ch, 48000, state=st).cpu().numpy()
+        b = G.limit_batch(x[:, half:].contiguous(), ch, 48000, state=st).cpu().numpy()
+    shipped = G.limit_batch(x, ch, 48000).cpu().numpy()
+    for s in range(min(S, 12)):
+        ref = _oracle(O, xs[s], ch, 48000)
+        assert float(np.max(np.abs(out[s] - ref))) <= TOL, s
+        assert float(np.max(np.abs(np.concatenate([a[s], b[s]]) - ref))) <= TOL, s
+    assert float(np.max(np.abs(out - shipped))) <= 2e-6
+    G.async_status()
+
+
 @pytest.mark.parametrize("ch", [1, 2, 5])
 def test_limiter_state_carried_across_blocks_equals_one_pass(G, O, ch):
     import torch

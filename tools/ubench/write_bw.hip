@@ -152,6 +152,60 @@ __global__ __launch_bounds__(64 * NW) void k_copy_ring(v4f *__restrict__ dst, co
     }
 }
 
+// "I/O waves": NIO waves move whole 64 KiB tiles (8 shares of 8 KiB) through two 64 KiB LDS buffers for a workgroup whose other
+// waves would only compute: the shape of a scan kernel whose compute waves never touch vector memory (their polls then travel
+// alone in vmcnt).  Each I/O wave owns 8/NIO shares of a tile.
+template <int NIO, int LNT, int SP>
+__global__ __launch_bounds__(64 * NIO) void k_copy_iow(v4f *__restrict__ dst, const v4f *__restrict__ src, size_t n) {
+    constexpr int KV = 8, SH = 8, PER = SH / NIO;  // KiB per share, shares per tile, shares per I/O wave
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SH * KV * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+    const size_t tiles = n / (SH * KV * 64);
+    size_t t = blockIdx.x;
+    if (t >= tiles) return;
+    auto stage_tile = [&](size_t tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int sh = wave * PER + i;
+            const uint64_t b = (uint64_t)(uintptr_t)(src + (tile * SH + sh) * (KV * 64));
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+            const void *sb = (const void *)(((uint64_t)hi << 32) | lo);
+#pragma unroll
+            for (int k = 0; k < KV; ++k) glds16<LNT>(sb, (uint32_t)(k * 1024 + lane * 16), lds0 + (buf * SH + sh) * (KV * 1024) + k * 1024);
+        }
+    };
+    int buf = 0;
+    stage_tile(t, 0);
+    for (;;) {
+        const size_t t2 = t + gridDim.x;
+        const bool more = t2 < tiles;
+        if (more) {
+            stage_tile(t2, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * KV) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // (where the compute waves would take over the tile, and hand it back)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int sh = wave * PER + i;
+            v4f v[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(lds + (buf * SH + sh) * (KV * 1024) + k * 1024 + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            v4f *o = dst + (t * SH + sh) * (KV * 64) + lane;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) st<SP>(o + k * 64, v[k]);
+        }
+        if (!more) break;
+        __syncthreads();
+        t = t2;
+        buf ^= 1;
+    }
+}
+
 __global__ void k_pattern(v4f *dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -267,6 +321,20 @@ int main(int argc, char **argv) {
     RG(4, 1, 0)
     RG(8, 1, 0)
     RG(8, 0, 0)
+    RG(8, 1, 1)
+    RG(4, 1, 1)
+#define IW(NIO, LNT, SP)                                                                                                                    \
+    {                                                                                                                                       \
+        snprintf(name, sizeof name, "I/O-wave tile copy (64 KiB tiles, 2 x 64 KiB LDS), %d I/O waves, %s DMA, %s stores, 1 workgroup per CU", NIO, LNT ? "nt" : "plain", SP ? "nt" : "plain"); \
+        rep(name, B, time_ms([&] { hipLaunchKernelGGL((k_copy_iow<NIO, LNT, SP>), dim3(cus), dim3(64 * NIO), 0, 0, b, a, n); }));          \
+    }
+
+    IW(2, 1, 0)
+    IW(4, 1, 0)
+    IW(8, 1, 0)
+    IW(2, 1, 1)
+    IW(4, 1, 1)
+    IW(8, 1, 1)
     printf("# check: %llu vectors of dst differed from src over all copy variants\n", total_bad);
     return total_bad != 0;
 }
