@@ -363,6 +363,16 @@ rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host,
  * applies the factor; without a filter the result stays bit-identical to amplify-then-convert.  Sources beyond
  * n keep 1.0.  Takes effect for the sources that are set and for every later set_sources / stream block. */
 rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n);
+/* A filter PER SOURCE: `mixer.add(a.low_pass(200)); mixer.add(b.high_pass(300)); mixer.add(c)` -- in rodio every source carries its own
+ * adapters into Mixer::add (src/source/mod.rs:686-721, src/mixer.rs:58-66).  kinds/freqs/qs are host arrays of n entries (kind as
+ * rh_rlm_config.filter_kind: -1 none, 0 low_pass, 1 high_pass; q 0.5 is rodio's low_pass()/high_pass()); sources beyond n keep the
+ * handle's own filter; n == 0 returns to it for all.  Sources with the same (kind, freq, q) form a class; every class runs as a fused
+ * launch of its own -- summed at the input rate first where its sources share a length, the bit-exact ordered sum
+ * where it has no filter -- and the classes' mixes are added in order of first appearance (f32; <= 1e-5 from rodio's per-sample order
+ * like every filtered path).  Call before rh_rlm_set_sources (which deals the sources over the classes); rh_rlm_set_gains may follow
+ * either.  One-shot runs (rh_rlm_run, rh_rlm_autotune); rh_rlm_run_subset / _batch and the stream entries return RH_ERR_UNSUPPORTED on
+ * such a handle (a streaming host keeps one handle per filter: include/rodio_hip.hpp GpuMixer::add(src, gain, filter)). */
+rh_status rh_rlm_set_filters(rh_rlm *p, const int32_t *kinds_host, const uint32_t *freqs_host, const float *qs_host, uint32_t n);
 /* May the launches of this handle assume that they have the device to themselves?  exclusive != 0 (the default: a one-shot job on
  * its own): a launch whose tiles are all resident at once numbers them by workgroup index.  exclusive == 0: other work shares the
  * CUs while the handle runs -- a collective on a second stream (the N > 1 ranks of bench.py: the all-reduce of block k overlaps the

@@ -455,22 +455,66 @@ class BlockPump : public Source {
 public:
     BlockPump() {
         check(rh_stream_create(&stream_), "rh_stream_create");
-        for (Slot &s : slot_) check(rh_event_create(&s.done), "rh_event_create");
+        for (Slot &s : slot_) {
+            check(rh_event_create(&s.done), "rh_event_create");
+            check(rh_event_create(&s.taken), "rh_event_create");
+        }
     }
     ~BlockPump() override {
         (void)rh_stream_synchronize(stream_);
-        for (Slot &s : slot_)
+        for (Slot &s : slot_) {
+            if (s.taken_pending) (void)rh_event_synchronize(s.taken);  // a consumer's copy may still read the slot's device block
             if (s.done) (void)rh_event_destroy(s.done);
+            if (s.taken) (void)rh_event_destroy(s.taken);
+        }
         (void)rh_stream_destroy(stream_);
     }
     std::optional<float> next() override {
+        if (device_out_) throw std::logic_error("this source keeps its blocks on the device: read_device()");
         while (pos_ == cur().n) {
             if (!advance()) return std::nullopt;
         }
         ++handed_out_;
         return cur().out.get()[pos_++];
     }
+    /// Everything a first next() would do before it can serve a sample -- start the stream (plans, page-locked blocks, device rows),
+    /// pull and process the first block, put the second one in flight -- done NOW, on the calling thread.  rodio builds its sources
+    /// on a control thread and hands them to the audio callback (src/stream.rs:538-545), where next() is expected not to block: call
+    /// this before the hand-over and the callback's first next() finds its block waiting.
+    void prepare() {
+        if (!primed_ && !ended_) (void)advance();
+    }
+    /// Device-resident hand-off (GpuMixer::add(std::unique_ptr<GpuSource>, ..)): the blocks of this source stay in device memory,
+    /// and a consumer takes them with read_device() -- device-to-device copies ordered by events: no host copy of the samples, no
+    /// host wait.  Switched on before the first block; next() / read() are then not available.
+    void keep_blocks_on_device(bool on = true) {
+        if (primed_) throw std::logic_error("keep_blocks_on_device() after the stream has started");
+        device_out_ = on;
+    }
+    bool blocks_on_device() const { return device_out_; }
+    bool started() const { return primed_; }
+    /// Up to n samples of the stream into DEVICE memory `ddst`, enqueued on `consumer` (a stream of the caller's).  Returns the
+    /// count: less than n at the end of the stream.
+    std::size_t read_device(float *ddst, std::size_t n, rh_stream consumer) {
+        if (!device_out_) throw std::logic_error("read_device() needs keep_blocks_on_device()");
+        std::size_t k = 0;
+        while (k < n) {
+            if (pos_ == cur().n && !advance()) break;
+            Slot &s = cur();
+            const std::size_t take = std::min(n - k, s.n - pos_);
+            check(rh_stream_wait_event(consumer, s.done), "rh_stream_wait_event");  // the block is complete when its event fires: the consumer's STREAM waits for it
+            check(rh_memcpy_d2d(ddst + k, s.dev.get() + pos_, take * sizeof(float), consumer), "rh_memcpy_d2d");
+            check(rh_event_record(s.taken, consumer), "rh_event_record");            // ... and the producer rewrites the slot's block only behind this copy
+            s.taken_pending = true;
+            pos_ += take;
+            k += take;
+        }
+        handed_out_ += k;
+        timing_.device_samples += k;
+        return k;
+    }
     std::size_t read(float *dst, std::size_t n) override {
+        if (device_out_) throw std::logic_error("this source keeps its blocks on the device: read_device()");
         std::size_t k = 0;
         while (k < n) {
             if (pos_ == cur().n && !advance()) break;
@@ -488,6 +532,9 @@ public:
     struct Timing {
         double submit_s = 0, prefetch_s = 0, pull_s = 0, wait_s = 0;
         std::uint64_t blocks = 0;
+        std::uint64_t d2h_samples = 0;     // samples of processed blocks copied to the host (0 for a source that keeps its blocks on the device)
+        std::uint64_t device_samples = 0;  // samples handed to a consumer device-to-device (read_device)
+        double first_advance_s = 0;        // the advance that started the stream (prepare(), or the first next())
     };
     const Timing &timing() const { return timing_; }
 
@@ -498,6 +545,9 @@ protected:
         std::size_t n = 0;  // samples in `out`
         bool last = false;  // upstream ended with this block
         void *done = nullptr;
+        DeviceBuf dev;               // keep_blocks_on_device(): the processed block, on the device
+        void *taken = nullptr;       // ... recorded on the consumer's stream behind its copies out of `dev`
+        bool taken_pending = false;
     };
     /// Fills `s` (n, last) and enqueues everything that produces s.out on stream_.
     virtual void enqueue(Slot &s) = 0;
@@ -509,6 +559,7 @@ protected:
     /// Called when a block's work has completed, before it is served: a place to surface device-side failures.
     virtual void block_done() {}
     rh_stream stream_ = nullptr;
+    bool device_out_ = false;  // keep_blocks_on_device()
 
     // What a subclass needs to patch blocks that are already scheduled (GpuMixer: a source that joins a running mixer at
     // the next frame, mixer.rs:175-183): the block being served, the one in flight behind it, the read position.
@@ -548,6 +599,8 @@ private:
             if (!can_resume()) return false;
             ended_ = primed_ = false;
         }
+        const bool starting = !primed_;
+        const auto ta = std::chrono::steady_clock::now();
         if (!primed_) {
             submit(slot_[0]);
             primed_ = true;
@@ -564,13 +617,16 @@ private:
                 timing_.prefetch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
         }
-        const auto t0 = std::chrono::steady_clock::now();
-        check(rh_event_synchronize(cur().done), "rh_event_synchronize");
-        timing_.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        block_done();
+        if (!device_out_) {  // (a device-resident consumer orders its copies behind the block's event on ITS stream: the host does not wait)
+            const auto t0 = std::chrono::steady_clock::now();
+            check(rh_event_synchronize(cur().done), "rh_event_synchronize");
+            timing_.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            block_done();
+        }
         pos_ = std::min(skip_, cur().n);
         skip_ = 0;
         if (!cur().last) submit(slot_[cur_ ^ 1]);  // prefetch: pull and process one block ahead
+        if (starting) timing_.first_advance_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
         return true;
     }
     Slot slot_[2];
@@ -877,7 +933,6 @@ protected:
         cap = ((cap + 3) & ~std::size_t(3)) + 64;  // + room for one padding frame
         a_.reset(cap);
         b_.reset(cap);
-        s.out.reset(cap);
         float *cur = a_.get(), *oth = b_.get();
         if (n) check(rh_memcpy_h2d(cur, s.in.get(), n * sizeof(float), stream_), "rh_memcpy_h2d");
         bool ends = flush;  // the upstream ended, or a stage says so: the stages behind it see the end of their input
@@ -887,7 +942,18 @@ protected:
             ends = ends || c.end;
             std::swap(cur, oth);
         }
-        if (n) check(rh_memcpy_d2h_async(s.out.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
+        if (device_out_) {  // the block stays on the device, in the slot's own buffer (a_ / b_ belong to the next block's stages)
+            s.dev.reset(cap);
+            if (s.taken_pending) {  // the consumer's copies out of this slot's previous block
+                check(rh_stream_wait_event(stream_, s.taken), "rh_stream_wait_event");
+                s.taken_pending = false;
+            }
+            if (n) check(rh_memcpy_d2d(s.dev.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2d");
+        } else if (n) {
+            s.out.reset(cap);
+            check(rh_memcpy_d2h_async(s.out.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            timing_.d2h_samples += n;
+        }
         s.n = n;
         s.last = ends;
     }
@@ -1000,60 +1066,116 @@ private:
 /// a later add() at the channel position MixerSource would be at.
 class GpuMixer : public detail::BlockPump {
 public:
+    /// The filter a source carries into the mixer: `mixer.add(UniformSourceIterator::new(src, ch, rate).low_pass(200))` for one,
+    /// `.high_pass(300)` for the next, none for a third (source/mod.rs:686-721: every source has its own adapters).
+    struct Filter {
+        int kind = -1;           // -1 none, 0 low_pass, 1 high_pass
+        std::uint32_t freq = 0;
+        float q = 0.5f;          // rodio's low_pass() / high_pass() (blt.rs:11-24)
+        static Filter none() { return Filter{}; }
+        static Filter low_pass(std::uint32_t f, float q = 0.5f) { return Filter{0, f, q}; }
+        static Filter high_pass(std::uint32_t f, float q = 0.5f) { return Filter{1, f, q}; }
+        bool operator==(const Filter &o) const { return kind == o.kind && (kind < 0 || (freq == o.freq && q == o.q)); }
+    };
     struct Options {
         std::size_t block_frames = 1u << 15;  // input frames pulled per source and block
-        int filter_kind = -1;                 // -1 none, 0 low_pass, 1 high_pass (q = 0.5, blt.rs:11-24)
+        int filter_kind = -1;                 // the filter of sources added WITHOUT one of their own: -1 none, 0 low_pass, 1 high_pass (q = 0.5, blt.rs:11-24)
         std::uint32_t filter_freq = 0;
         float filter_q = 0.5f;
         std::uint32_t frames_per_lane = 0;    // 0 = the library's choice
         unsigned host_threads = 0;            // threads that pull the sources of a block (0 = min(cores, 16); 1 = the caller alone)
     };
-    GpuMixer(std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt) {
-        if (!sample_rate) throw std::invalid_argument("sample_rate is NonZero in rodio");
+    /// mixer::mixer(channels, sample_rate) (mixer.rs:25).  The sources are mixed as stereo frames; `channels` other than 2 is what
+    /// ChannelCountConverter makes of every source (channels.rs:57-85), applied ONCE, to the mixed block (the converter and the
+    /// sum commute: 1 keeps channel 0, more than 2 appends silent channels -- for that, sources must not have more than 2 channels
+    /// themselves, or their channels 2.. would be lost: such an add() is refused).
+    GpuMixer(std::uint16_t channels, std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt), out_ch_(channels) {
+        if (!sample_rate || !channels) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         if (!opt_.block_frames) opt_.block_frames = 1;
         check(rh_stream_create(&copy_stream_), "rh_stream_create");
     }
-    explicit GpuMixer(std::uint32_t sample_rate) : GpuMixer(sample_rate, Options()) {}
+    GpuMixer(std::uint32_t sample_rate, Options opt) : GpuMixer(2, sample_rate, opt) {}
+    explicit GpuMixer(std::uint32_t sample_rate) : GpuMixer(2, sample_rate, Options()) {}
     ~GpuMixer() override {
         (void)rh_stream_synchronize(copy_stream_);
         (void)rh_stream_synchronize(stream_);
-        for (auto &g : gens_)
-            if (g->plan) (void)rh_rlm_destroy(g->plan);
         gens_.clear();
+        reaper_.reset();  // joins: generations that were retired are gone before the streams are
         (void)rh_stream_destroy(copy_stream_);
     }
     /// Mixer::add (mixer.rs:58-66), with the source's volume.  Any source: mono sources form fused streams of their own (the kernel
     /// reads mono frames, the mono mix becomes stereo once per block); a channel count above 2 is staged in the source's own
     /// layout and converted on the device in front of the fused launch (ChannelCountConverter, rh_channels_convert); a rate more
     /// than 4.5 times the mixer's first runs through the GPU SampleRateConverter adapter, still one pull chain.
-    void add(BoxSource src, float gain = 1.0f) {
+    void add(BoxSource src, float gain = 1.0f) { add(std::move(src), gain, Filter{opt_.filter_kind, opt_.filter_freq, opt_.filter_q}); }
+    /// ... with the source's own filter (behind its UniformSourceIterator, at the mixer's rate).  Sources of one filter share a fused
+    /// stream -- one launch per block for all of them, summed first where they run together -- and the streams' mixes are added.
+    void add(BoxSource src, float gain, Filter filter) {
         if (!src) throw std::invalid_argument("source");
         std::uint16_t ch = src->channels();
         const std::uint32_t from = src->sample_rate();
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
+        if (out_ch_ > 2 && ch > 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source of more than 2 channels into a mixer of more than 2 (the mix is formed in stereo)");
+        if (filter.kind > 1) throw std::invalid_argument("filter kind");
         Src item;
         item.up = std::move(src);
         item.gain = gain;
         item.ch = ch;
+        item.filt = filter;
         if (running()) late_join(std::move(item));  // mixer.rs:175-183: admitted at the next frame
         else pending_.push_back(std::move(item));    // starts with the stream (or resumes an ended one)
+    }
+    /// A GpuSource chain handed to the mixer by value, as rodio's adapters are (`mixer.add(src.reverb(..).limit(..))`, amplify.rs:19-22,
+    /// mixer.rs:58-72): its blocks stay in device memory and the mixer takes them device-to-device -- the chain's output never
+    /// crosses to the host and back.  (A chain that is not stereo at a rate the fused converter takes, or one that has already
+    /// started, is pulled like any other source: the same samples, through the host.)
+    void add(std::unique_ptr<GpuSource> chain, float gain = 1.0f) { add(std::move(chain), gain, Filter{opt_.filter_kind, opt_.filter_freq, opt_.filter_q}); }
+    void add(std::unique_ptr<GpuSource> chain, float gain, Filter filter) {
+        if (!chain) throw std::invalid_argument("source");
+        GpuSource *const gs = chain.get();
+        const bool on_device = gs->channels() == 2 && !gs->started() && !fused_ratio_unsupported(gs->sample_rate(), rate_) && gs->sample_rate() != 0;
+        if (!on_device) {
+            add(BoxSource(std::move(chain)), gain, filter);
+            return;
+        }
+        gs->keep_blocks_on_device();
+        Src item;
+        item.up = std::move(chain);
+        item.dev = gs;
+        item.gain = gain;
+        item.ch = 2;
+        item.filt = filter;
+        device_chains_ = true;
+        if (running()) late_join(std::move(item));
+        else pending_.push_back(std::move(item));
     }
     // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136),
     // and admits pending sources only at channel 0: an ended mixer that gets a new source after an odd number of calls
     // returns one more None before the source's first sample.  `calls_` is that position.
     std::optional<float> next() override {
-        resume_ok_ = (calls_ % 2) == 0;
+        resume_ok_ = (calls_ % out_ch_) == 0;
         ++calls_;
         return detail::BlockPump::next();
     }
     std::size_t read(float *dst, std::size_t n) override {
-        resume_ok_ = (calls_ % 2) == 0;  // blocks hold whole frames: the position only matters where the stream had ended
+        resume_ok_ = (calls_ % out_ch_) == 0;  // blocks hold whole frames: the position only matters where the stream had ended
         const std::size_t k = detail::BlockPump::read(dst, n);
         calls_ += k + (k < n ? 1 : 0);
         return k;
     }
-    std::uint16_t channels() const override { return 2; }
+    std::uint16_t channels() const override { return out_ch_; }
     std::uint32_t sample_rate() const override { return rate_; }
+    /// What became of the GpuSource chains handed to add(): how many there were, how many delivered their blocks on the device, and
+    /// the samples of chain output that crossed to the host (0 when every chain stayed on the device) / went device-to-device.
+    struct ChainStats {
+        std::uint64_t chains = 0, on_device = 0, d2h_samples = 0, device_samples = 0;
+    };
+    ChainStats chain_stats() const {
+        ChainStats st = retired_chains_;
+        for (const auto &gp : gens_) count_chains(*gp, st);
+        for (const Src &x : pending_) count_chain(x, st);
+        return st;
+    }
     /// Output frame (of this mixer) at which the most recently started generation joined.
     std::uint64_t last_join_frame() const { return last_join_; }
     /// Threads that have pulled sources so far (1 until a block was large enough for the pool).
@@ -1064,6 +1186,7 @@ protected:
     void block_done() override {  // a bounded wait inside the fused kernel expired (never seen on a healthy device): fail loudly
         for (auto &g : gens_)
             if (g->plan) check(rh_rlm_last_status(g->plan), "rh_rlm_last_status");
+        if (device_chains_) check(rh_async_status(), "rh_async_status");  // ... or inside a scan kernel of a chain that hands its blocks over on the device
     }
     void enqueue(Slot &s) override {
         if (!pending_.empty()) start_generation();
@@ -1074,8 +1197,8 @@ protected:
             slot_frames_[slot_index(s)] = 0;
             return;
         }
-        s.out.reset(out_cap_frames_ * 2 * 2);
-        if (debug_poison()) std::memset(s.out.get(), 0xff, out_cap_frames_ * 2 * 2 * sizeof(float));  // diagnostics: a block served before it arrived reads NaN
+        s.out.reset(out_cap_frames_ * 2 * std::max<std::size_t>(2, out_ch_));
+        if (debug_poison()) std::memset(s.out.get(), 0xff, out_cap_frames_ * 2 * std::max<std::size_t>(2, out_ch_) * sizeof(float));  // diagnostics: a block served before it arrived reads NaN
         // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
         // (one that runs ahead of the slowest -- another rate, other tile boundaries -- waits with a full queue)
         for (auto &gp : gens_)
@@ -1107,7 +1230,7 @@ protected:
                 check(rh_mix_sum(dmix_.get(), n * 2, ptrs.data(), start.data(), len.data(), (std::uint32_t)ptrs.size(), stream_), "rh_mix_sum");
                 mixed = dmix_.get();
             }
-            check(rh_memcpy_d2h_async(s.out.get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            send_block(s, mixed, n);
             // the block also stays on the device until it has been served: a source that joins in the middle of it is added there
             dkeep_[slot_index(s)].reset(out_cap_frames_ * 2 * 2);
             check(rh_memcpy_d2d(dkeep_[slot_index(s)].get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
@@ -1130,20 +1253,50 @@ protected:
         for (auto &gp : gens_) all_done = all_done && gp->done && gp->fill == 0;
         if (all_done) {
             check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
+            check(rh_stream_synchronize(copy_stream_), "rh_stream_synchronize");
             for (auto &gp : gens_)
-                if (gp->plan) {
-                    check(rh_rlm_last_status(gp->plan), "rh_rlm_last_status");  // the last blocks too: nothing is served unchecked
-                    check(rh_rlm_destroy(gp->plan), "rh_rlm_destroy");
-                }
+                if (gp->plan) check(rh_rlm_last_status(gp->plan), "rh_rlm_last_status");  // the last blocks too: nothing is served unchecked
+            // The generations' plans, page-locked blocks and device rows are NOT freed here: this runs inside the consumer's next()
+            // (the audio callback), and freeing a few hundred MB of page-locked memory takes hundreds of milliseconds.  A thread of
+            // the mixer's does it (nothing on the device refers to them any more: both streams were waited for above).
+            for (auto &gp : gens_) count_chains(*gp, retired_chains_);
+            if (!reaper_) reaper_.reset(new Reaper());
+            reaper_->retire(std::move(gens_));
             gens_.clear();
         }
-        s.n = (std::size_t)n * 2;
+        s.n = (std::size_t)n * out_ch_;
         s.last = gens_.empty() && pending_.empty();
     }
 
 private:
+    /// The mixed stereo block `mixed` (n frames, on the device) on its way to the host block of slot `s`, in the mixer's layout.
+    void send_block(Slot &s, const float *mixed, std::uint64_t n) {
+        if (out_ch_ == 2) {
+            check(rh_memcpy_d2h_async(s.out.get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            return;
+        }
+        dout_.reset(out_cap_frames_ * 2 * out_ch_);  // ChannelCountConverter(2 -> channels) on the mix (channels.rs:57-85), once per block
+        check(rh_channels_convert(dout_.get(), mixed, (std::size_t)n, 2, out_ch_, stream_), "rh_channels_convert");
+        check(rh_memcpy_d2h_async(s.out.get(), dout_.get(), n * out_ch_ * sizeof(float), stream_), "rh_memcpy_d2h_async");
+    }
+    struct Src;
+    struct Gen;
+    static void count_chain(const Src &x, ChainStats &st) {
+        const GpuSource *g = x.up ? dynamic_cast<const GpuSource *>(x.up.get()) : nullptr;
+        if (!g) return;
+        st.chains += 1;
+        st.on_device += g->blocks_on_device() ? 1 : 0;
+        st.d2h_samples += g->timing().d2h_samples;
+        st.device_samples += g->timing().device_samples;
+    }
+    static void count_chains(const Gen &g, ChainStats &st) {
+        for (const Src &x : g.srcs) count_chain(x, st);
+    }
     struct Src {
         BoxSource up;
+        GpuSource *dev = nullptr;  // == up.get() when the source is a chain that hands its blocks over on the device
+        std::uint64_t dheld = 0, dheld_off = 0;  // ... frames the converter has not consumed: `dheld` of them from frame `dheld_off` of the row of the block before
+        Filter filt;
         float gain = 1.0f;
         std::vector<float> held;  // pulled, not yet consumed by the converter (interleaved, in the source's own channel layout)
         bool ended = false;
@@ -1184,6 +1337,52 @@ private:
         int ccur = 0;
         const float *queue() const { return q[cur].get() + head * 2; }
         float *queue_end() { return q[cur].get() + (head + fill) * 2; }
+        Filter filt;
+        Gen() = default;
+        Gen(const Gen &) = delete;
+        Gen &operator=(const Gen &) = delete;
+        ~Gen() {
+            if (plan) (void)rh_rlm_destroy(plan);
+        }
+    };
+    /// Frees retired generations on a thread of its own (see enqueue()).
+    class Reaper {
+    public:
+        Reaper() : th_([this] { loop(); }) {}
+        ~Reaper() {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                quit_ = true;
+            }
+            cv_.notify_all();
+            th_.join();
+        }
+        void retire(std::vector<std::unique_ptr<Gen>> g) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                for (auto &p : g) dead_.push_back(std::move(p));
+            }
+            cv_.notify_all();
+        }
+
+    private:
+        void loop() {
+            std::unique_lock<std::mutex> lk(mu_);
+            for (;;) {
+                cv_.wait(lk, [this] { return quit_ || !dead_.empty(); });
+                std::vector<std::unique_ptr<Gen>> take;
+                take.swap(dead_);
+                lk.unlock();
+                take.clear();  // the destructors: rh_rlm_destroy, rh_host_free, rh_free
+                lk.lock();
+                if (quit_ && dead_.empty()) return;
+            }
+        }
+        std::mutex mu_;
+        std::condition_variable cv_;
+        std::vector<std::unique_ptr<Gen>> dead_;
+        bool quit_ = false;
+        std::thread th_;
     };
     static bool fused_ratio_unsupported(std::uint32_t from, std::uint32_t to) {  // rh_rlm_create: reduced from/to <= 4.5, from*to within u32
         std::uint64_t a = from, b = to;
@@ -1198,7 +1397,7 @@ private:
     static bool spanned(const Src &x) { return x.up->current_span_len().has_value(); }
     /// A continuous source the fused kernel cannot take as it is (rate ratio above 4.5) gets the GPU converter adapter in front.
     void make_direct(Src &x) {
-        if (!fused_ratio_unsupported(x.up->sample_rate(), rate_)) return;
+        if (x.dev || !fused_ratio_unsupported(x.up->sample_rate(), rate_)) return;
         auto conv = std::make_unique<GpuSource>(std::move(x.up), opt_.block_frames);
         if (x.ch != 2) conv->convert_channels(2);
         conv->convert_sample_rate(rate_);
@@ -1210,29 +1409,44 @@ private:
         pending_.clear();
         bool any_spans = false;
         for (const Src &x : all) any_spans = any_spans || spanned(x);
-        if (any_spans) {  // span by span, as rodio converts them: one stream for all of them, in insertion order
-            start_stream(std::move(all), true);
+        if (any_spans) {  // span by span, as rodio converts them: one stream per filter for all of them, in insertion order
+            std::vector<Filter> fk;
+            for (const Src &x : all)
+                if (std::find(fk.begin(), fk.end(), x.filt) == fk.end()) fk.push_back(x.filt);
+            for (const Filter &f : fk) {
+                std::vector<Src> group;
+                for (Src &x : all)
+                    if (x.up && x.filt == f) group.push_back(std::move(x));
+                start_stream(std::move(group), true);
+            }
             return;
         }
-        // continuous sources: one fused stream per input rate -- and one for its mono sources, which the kernel reads as they are
-        // (4 bytes per frame) -- in order of first appearance
+        // continuous sources: one fused stream per (input rate, filter) -- and one for its mono sources, which the kernel reads as
+        // they are (4 bytes per frame) -- in order of first appearance
         for (Src &x : all) make_direct(x);
-        std::vector<std::pair<std::uint32_t, bool>> keys;
+        struct Key {
+            std::uint32_t rate;
+            bool mono;
+            Filter filt;
+            bool operator==(const Key &o) const { return rate == o.rate && mono == o.mono && filt == o.filt; }
+        };
+        std::vector<Key> keys;
         for (const Src &x : all) {
-            const std::pair<std::uint32_t, bool> k(x.up->sample_rate(), x.ch == 1);
+            const Key k{x.up->sample_rate(), x.ch == 1, x.filt};
             if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
         }
-        for (const auto &k : keys) {
+        for (const Key &k : keys) {
             std::vector<Src> group;
             for (Src &x : all)
-                if (x.up && x.up->sample_rate() == k.first && (x.ch == 1) == k.second) group.push_back(std::move(x));
-            start_stream(std::move(group), false, k.second);
+                if (x.up && Key{x.up->sample_rate(), x.ch == 1, x.filt} == k) group.push_back(std::move(x));
+            start_stream(std::move(group), false, k.mono);
         }
     }
     void start_stream(std::vector<Src> srcs, bool staged, bool mono = false) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
         g.srcs = std::move(srcs);
+        g.filt = g.srcs.front().filt;  // (one filter per stream: start_generation / late_join group by it)
         g.staged = staged;
         g.mono = mono && !staged;
         const std::uint32_t from = staged ? rate_ : g.srcs.front().up->sample_rate();  // staged: the fused kernel sees converted rows
@@ -1242,9 +1456,9 @@ private:
         cfg.to_rate = rate_;
         cfg.channels = g.mono ? 1 : 2;
         cfg.span_len = 0;
-        cfg.filter_kind = opt_.filter_kind;
-        cfg.filter_freq = opt_.filter_freq;
-        cfg.filter_q = opt_.filter_q;
+        cfg.filter_kind = g.filt.kind;
+        cfg.filter_freq = g.filt.freq;
+        cfg.filter_q = g.filt.q;
         cfg.max_sources = (std::uint32_t)g.srcs.size();
         cap_frames_ = opt_.block_frames + 4096;  // a block can hold what the previous one left over: less than two tiles' worth of input
         if (staged) {
@@ -1260,6 +1474,7 @@ private:
         cfg.max_in_frames = staged ? g.crow : cap_frames_;
         cfg.frames_per_lane = opt_.frames_per_lane;
         check(rh_rlm_create(&g.plan, &cfg), "rh_rlm_create");
+        check(rh_rlm_set_exclusive(g.plan, 0), "rh_rlm_set_exclusive");  // the copy stream's launches (and other mixers) share the CUs: tiles by ticket
         std::vector<float> gains;
         for (const Src &x : g.srcs) gains.push_back(staged ? 1.0f : x.gain);  // staged: the factor sits in front of the converter, where Mixer::add(src.amplify(g)) has it
         check(rh_rlm_set_gains(g.plan, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
@@ -1482,6 +1697,7 @@ private:
         }
         pull_sources(S * opt_.block_frames, S, [&](std::size_t i) {
             Src &x = g.srcs[i];
+            if (x.dev) return;  // its block arrives device-to-device, below
             const std::size_t ch = x.ch;
             float *row = ch == native ? stage.get() + i * row_ : side.get() + g.pside_off[i];
             std::size_t have = x.held.size();
@@ -1505,6 +1721,26 @@ private:
             if (g.srcs[i].ch == native) width = std::max<std::size_t>(width, (std::size_t)g.pavail[i] * native);
         if (width) check(rh_memcpy_h2d_rows(din.get(), stage.get(), row_ * sizeof(float), width * sizeof(float), S, copy_stream_), "rh_memcpy_h2d_rows");
         if (g.pside) check(rh_memcpy_h2d(dside.get(), side.get(), g.pside * sizeof(float), copy_stream_), "rh_memcpy_h2d");
+        // chains that hand their blocks over on the device: [what the converter left of the block before | the chain's next samples],
+        // device-to-device on the copy stream, behind the pitched copy (which also moved the rows' unused staging bytes)
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            if (!x.dev) continue;
+            float *row = din.get() + i * row_;
+            std::size_t have = (std::size_t)x.dheld * 2;
+            if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
+            if (have) check(rh_memcpy_d2d(row, g.din[g.pslot ^ 1].get() + i * row_ + x.dheld_off * 2, have * sizeof(float), copy_stream_), "rh_memcpy_d2d");
+            if (!x.ended) {
+                const std::size_t want = opt_.block_frames * 2;
+                std::size_t got = x.dev->read_device(row + have, want, copy_stream_);
+                got -= got % 2;
+                have += got;
+                x.ended = got < want;
+            }
+            g.pptrs[i] = row;
+            g.pavail[i] = have / 2;
+            g.pended[i] = x.ended ? 1 : 0;
+        }
         check(rh_event_record(g.copied[g.pslot].get(), copy_stream_), "rh_event_record");
     }
     void issue_block_direct(Gen &g) {
@@ -1532,6 +1768,12 @@ private:
         bool all_ended = true;
         for (std::size_t i = 0; i < S; ++i) {  // keep what the converter has not consumed (a few hundred frames)
             Src &x = g.srcs[i];
+            if (x.dev) {  // ... which stays where it is: the next block copies it from this block's row
+                x.dheld_off = std::min<std::uint64_t>(consumed, g.pavail[i]);
+                x.dheld = g.pavail[i] - x.dheld_off;
+                all_ended = all_ended && x.ended;
+                continue;
+            }
             const std::size_t ch = x.ch;
             const float *row = ch == native ? stage.get() + i * row_ : side.get() + g.pside_off[i];
             const std::size_t have = (std::size_t)g.pavail[i] * ch, drop = std::min<std::size_t>((std::size_t)consumed * ch, have);
@@ -1549,13 +1791,13 @@ private:
     /// generation.
     void late_join(Src item) {
         const int ci = cur_index();
-        const std::uint64_t consumed = slot_base_[ci] * 2 + position();  // samples already handed out
-        const std::uint64_t J = (consumed + 1) / 2;                        // the next frame boundary
+        const std::uint64_t consumed = slot_base_[ci] * out_ch_ + position();  // samples already handed out
+        const std::uint64_t J = (consumed + out_ch_ - 1) / out_ch_;             // the next frame boundary
         const bool flight = other_in_flight();
         const int li = flight ? ci ^ 1 : ci;                               // the last block that is scheduled
         const std::uint64_t sched_end = slot_base_[li] + slot_frames_[li];
         check(rh_stream_synchronize(stream_), "rh_stream_synchronize");   // the blocks about to be patched have been produced
-        const bool staged = spanned(item);
+        const bool staged = !item.dev && spanned(item);
         if (!staged) make_direct(item);
         std::vector<Src> one;
         one.push_back(std::move(item));
@@ -1578,7 +1820,7 @@ private:
             dmix_.reset(out_cap_frames_ * 2 * 2);
             check(rh_mix_sum(dmix_.get(), slot_frames_[si] * 2, ptrs, start, len, 2, stream_), "rh_mix_sum");
             check(rh_memcpy_d2d(dkeep_[si].get(), dmix_.get(), slot_frames_[si] * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
-            check(rh_memcpy_d2h_async(sl.out.get(), dkeep_[si].get(), slot_frames_[si] * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            send_block(sl, dkeep_[si].get(), slot_frames_[si]);
         }
         {  // the newcomer's queue moves on to the frame the next block starts at
             const std::uint64_t used = std::min(g.fill, need), rem = g.fill - used, pad = rem & 1;
@@ -1603,6 +1845,11 @@ private:
     }
     std::uint32_t rate_;
     Options opt_;
+    std::uint16_t out_ch_ = 2;       // mixer::mixer(channels, ..)
+    bool device_chains_ = false;     // a chain hands its blocks over on the device: its scan kernels' failure word is read per block
+    std::unique_ptr<Reaper> reaper_;
+    ChainStats retired_chains_;
+    detail::DeviceBuf dout_;         // the mixed block in the mixer's channel layout (channels != 2)
     std::vector<Src> pending_;
     std::vector<std::unique_ptr<Gen>> gens_;
     // the threads that pull a block's sources: made at the first block that is worth them

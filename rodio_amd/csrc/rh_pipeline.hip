@@ -2590,6 +2590,26 @@ struct rh_rlm {
     // residency nor in-order dispatch: a tile only ever waits for tiles that already hold a wave slot.
     bool exclusive = true;
     bool mix_first_on = true;  // rh_rlm_set_mix_first
+    // rh_rlm_set_filters: a filter per source.  Sources of one (kind, freq, q) form a CLASS; every class is a handle of its own
+    // (`cls[c].h`, this handle's configuration with that filter) holding the class's sources in insertion order, so that each
+    // class keeps everything a one-filter batch has -- mix first where its sources share a length, the ragged pair, the ordered
+    // sum where it has no filter -- and the classes' mixes are summed in order of first appearance.
+    struct FilterSpec {
+        int32_t kind;
+        uint32_t freq;
+        float q;
+        bool operator==(const FilterSpec &o) const { return kind == o.kind && (kind < 0 || (freq == o.freq && q == o.q)); }
+    };
+    struct FilterClass {
+        FilterSpec spec;
+        rh_rlm *h = nullptr;
+        std::vector<uint32_t> members;  // indices into the parent's source list
+        uint64_t out_frames = 0;
+    };
+    std::vector<FilterSpec> filters;  // per source; empty: the handle's one filter
+    std::vector<FilterClass> cls;     // classes of the sources that are set (empty: one filter, this handle runs itself)
+    float *d_cls_rows = nullptr;      // [classes][row] partial mixes
+    size_t cls_row_floats = 0, cls_rows = 0;
 };
 
 namespace {
@@ -3117,6 +3137,10 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
         fprintf(stderr, "chunk phases (cycles summed over tiles and launches): image+halo %u  run %u  scan+publish %u  look-back %u  correction+stores %u\n", h[0], h[1], h[2], h[3], h[4]);
     }
 #endif
+    for (rh_rlm::FilterClass &c : p->cls)
+        if (c.h) (void)rh_rlm_destroy(c.h);
+    p->cls.clear();
+    if (p->d_cls_rows) (void)hipFree(p->d_cls_rows);
     if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
     bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
     for (Plan &c : p->tried) {
@@ -3197,14 +3221,102 @@ static rh_status set_sources_impl(rh_rlm *p, const float *const *srcs_host, cons
     return activate_plan(p, pair_ok(p, p->pair) ? &p->pair : &p->wave);
 }
 
+// The sources dealt over the filter classes (rh_rlm_set_filters).  Classes are kept across calls (their tables and plans belong to
+// their filter); a class that has no member this time keeps its handle and is skipped by the run.
+static rh_status set_sources_classes(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
+    if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
+    if (n_sources && (!srcs_host || !in_frames_host)) return RH_ERR_INVALID;
+    for (rh_rlm::FilterClass &c : p->cls) c.members.clear();
+    const rh_rlm::FilterSpec own{p->cfg.filter_kind == 2 ? 0 : p->cfg.filter_kind, p->cfg.filter_freq, p->cfg.filter_q};
+    for (uint32_t s = 0; s < n_sources; ++s) {
+        const rh_rlm::FilterSpec f = s < p->filters.size() ? p->filters[s] : own;
+        size_t k = 0;
+        while (k < p->cls.size() && !(p->cls[k].spec == f)) ++k;
+        if (k == p->cls.size()) {
+            rh_rlm::FilterClass c;
+            c.spec = f;
+            rh_rlm_config cfg = p->cfg;
+            cfg.filter_kind = f.kind < 0 ? -1 : f.kind;
+            cfg.filter_freq = f.freq;
+            cfg.filter_q = f.q;
+            const rh_status st = rh_rlm_create(&c.h, &cfg);
+            if (st != RH_OK) return st;
+            p->cls.push_back(c);
+        }
+        p->cls[k].members.push_back(s);
+    }
+    uint64_t M = 0;
+    std::vector<const float *> ptrs;
+    std::vector<uint64_t> frames;
+    std::vector<float> gains;
+    for (rh_rlm::FilterClass &c : p->cls) {
+        ptrs.clear(), frames.clear(), gains.clear();
+        for (uint32_t s : c.members) {
+            ptrs.push_back(srcs_host[s]);
+            frames.push_back(in_frames_host[s]);
+            gains.push_back(s < p->gains.size() ? p->gains[s] : 1.0f);
+        }
+        c.h->exclusive = p->exclusive;
+        c.h->mix_first_on = p->mix_first_on;
+        rh_status st = rh_rlm_set_gains(c.h, gains.data(), (uint32_t)gains.size());
+        if (st == RH_OK) st = rh_rlm_set_sources(c.h, ptrs.data(), frames.data(), (uint32_t)ptrs.size());
+        if (st != RH_OK) return st;
+        c.out_frames = c.h->out_frames;
+        if (c.out_frames > M) M = c.out_frames;
+    }
+    p->n_sources = n_sources;
+    p->out_frames = M;
+    p->chunk.ok = false;
+    return RH_OK;
+}
+
 rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
+    if (p && !p->filters.empty()) {
+        RH_REQUIRE_INIT();
+        return set_sources_classes(p, srcs_host, in_frames_host, n_sources);
+    }
+    if (p && !p->cls.empty()) {  // back to the handle's one filter
+        for (rh_rlm::FilterClass &c : p->cls)
+            if (c.h) (void)rh_rlm_destroy(c.h);
+        p->cls.clear();
+    }
     return set_sources_impl(p, srcs_host, in_frames_host, n_sources, nullptr);
+}
+
+rh_status rh_rlm_set_filters(rh_rlm *p, const int32_t *kinds_host, const uint32_t *freqs_host, const float *qs_host, uint32_t n) {
+    RH_REQUIRE_INIT();
+    if (!p || (n && (!kinds_host || !freqs_host || !qs_host)) || n > p->cfg.max_sources) return RH_ERR_INVALID;
+    if (p->pre_filter || p->st_on || p->cfg.filter_kind == 2) return RH_ERR_UNSUPPORTED;  // filter_first / custom-coefficient handles and running streams keep their one filter
+    std::vector<rh_rlm::FilterSpec> f(n);
+    for (uint32_t s = 0; s < n; ++s) {
+        if (kinds_host[s] > 1) return RH_ERR_INVALID;  // -1 none, 0 low_pass, 1 high_pass
+        f[s] = rh_rlm::FilterSpec{kinds_host[s] < 0 ? -1 : kinds_host[s], kinds_host[s] < 0 ? 0u : freqs_host[s], kinds_host[s] < 0 ? 0.f : qs_host[s]};
+        if (f[s].kind >= 0) {  // refuse here what rh_rlm_create would refuse at the next set_sources
+            float c5[5];
+            const rh_status st = rh_biquad_coeffs(f[s].kind, f[s].freq, f[s].q, p->cfg.to_rate, c5);
+            if (st != RH_OK) return st;
+        }
+    }
+    p->filters = std::move(f);
+    p->n_sources = 0;  // the sources are dealt over the classes by the next rh_rlm_set_sources
+    p->out_frames = 0;
+    return RH_OK;
 }
 
 rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
     RH_REQUIRE_INIT();
     if (!p || (n && !gains_host) || n > p->cfg.max_sources) return RH_ERR_INVALID;
     p->gains.assign(gains_host, gains_host + n);
+    if (!p->cls.empty()) {  // per-source filters: every class takes the factors of its members
+        std::vector<float> g;
+        for (rh_rlm::FilterClass &c : p->cls) {
+            g.clear();
+            for (uint32_t s : c.members) g.push_back(s < n ? gains_host[s] : 1.0f);
+            const rh_status st = rh_rlm_set_gains(c.h, g.data(), (uint32_t)g.size());
+            if (st != RH_OK) return st;
+        }
+        return RH_OK;
+    }
     if (!p->st_on && p->n_sources && p->h_desc.size() == p->n_sources) {  // sources already set: refresh their descriptors
         for (uint32_t s = 0; s < p->n_sources; ++s) p->h_desc[s].gain = s < n ? gains_host[s] : 1.0f;
         {
@@ -3216,8 +3328,51 @@ rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
     return RH_OK;
 }
 
+// One launch (or pair) per filter class into the class's row, then the classes' mixes summed in order of first appearance.
+static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (out_frames) *out_frames = p->out_frames;
+    if (p->out_frames == 0) return RH_OK;
+    if (!dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
+    if (out_capacity_frames < p->out_frames) return RH_ERR_CAPACITY;
+    const uint32_t C = p->cfg.channels;
+    std::vector<rh_rlm::FilterClass *> live;
+    for (rh_rlm::FilterClass &c : p->cls)
+        if (!c.members.empty() && c.out_frames) live.push_back(&c);
+    if (live.empty()) return RH_OK;
+    if (live.size() == 1) return rh_rlm_run(live[0]->h, dst, out_capacity_frames, nullptr, stream);
+    const size_t row = (size_t)((p->out_frames * C + 3) & ~3ull);
+    if (row > p->cls_row_floats || live.size() > p->cls_rows) {
+        const rh_status w = wait_idle(p);
+        if (w != RH_OK) return w;
+        for (rh_rlm::FilterClass *c : live) {  // (the rows are read by the sum behind the classes' launches: those first)
+            const rh_status wc = wait_idle(c->h);
+            if (wc != RH_OK) return wc;
+        }
+        if (p->d_cls_rows) RH_HIP_TRY(hipFree(p->d_cls_rows));
+        p->d_cls_rows = nullptr;
+        p->cls_row_floats = std::max(row, p->cls_row_floats);
+        p->cls_rows = std::max(live.size(), p->cls_rows);
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cls_rows), p->cls_row_floats * p->cls_rows * sizeof(float)));
+    }
+    std::vector<const float *> ptrs;
+    std::vector<uint64_t> start, len;
+    for (size_t k = 0; k < live.size(); ++k) {
+        float *r = p->d_cls_rows + k * p->cls_row_floats;
+        const rh_status st = rh_rlm_run(live[k]->h, r, p->cls_row_floats / C, nullptr, stream);
+        if (st != RH_OK) return st;
+        ptrs.push_back(r);
+        start.push_back(0);
+        len.push_back(live[k]->out_frames * C);
+    }
+    const rh_status st = rh_mix_sum(dst, p->out_frames * C, ptrs.data(), start.data(), len.data(), (uint32_t)ptrs.size(), stream);
+    if (st != RH_OK) return st;
+    return mark_launch(p, rh::as_stream(stream));
+}
+
 rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
     if (!p) return RH_ERR_INVALID;
+    if (!p->cls.empty()) return run_classes(p, dst, out_capacity_frames, out_frames, stream);
     return rh_rlm_run_subset(p, 0, p->n_sources, dst, out_capacity_frames, out_frames, stream);
 }
 
@@ -3253,6 +3408,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
                             const StreamArgs &sa) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
+    if (!p->cls.empty()) return RH_ERR_UNSUPPORTED;  // per-source filters: whole one-shot runs only (rh_rlm_run)
     if (first > p->n_sources || count > p->n_sources - first) return RH_ERR_INVALID;
     if (out_frames) *out_frames = p->out_frames;
     if (p->out_frames == 0) return RH_OK;
@@ -3412,6 +3568,14 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
 rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream, uint32_t *frames_per_lane, uint32_t *ring_stages) {
     RH_REQUIRE_INIT();
     if (!p || !dst) return RH_ERR_INVALID;
+    if (!p->cls.empty()) {  // per-source filters: every class finds its own geometry (the last one's is reported)
+        for (rh_rlm::FilterClass &c : p->cls) {
+            if (c.members.empty()) continue;
+            const rh_status st = rh_rlm_autotune(c.h, dst, out_capacity_frames, stream, frames_per_lane, ring_stages);
+            if (st != RH_OK) return st;
+        }
+        return RH_OK;
+    }
     if (p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
         const bool general = p->plan == &p->wave, is_pair = p->plan == &p->pair;
         Plan &slot = is_pair ? p->pair : general ? p->wave : p->fast;
@@ -3535,6 +3699,7 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
     if (p->pre_filter) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs only (rodio_hip.h)
+    if (!p->filters.empty()) return RH_ERR_UNSUPPORTED;  // per-source filters: one-shot runs (a streaming host keeps one handle per filter: rodio_hip.hpp)
     p->st_chunk_in = p->st_chunk_out = 0;
     if (p->cfg.span_len != 0) {  // sources that report spans of span_len samples: the converter restarts every min(span_len, 32768) samples (uniform.rs:56-67)
         const uint64_t span = p->cfg.span_len < 32768 ? p->cfg.span_len : 32768;
@@ -3762,6 +3927,10 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
 rh_status rh_rlm_last_status(rh_rlm *p) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
+    for (rh_rlm::FilterClass &c : p->cls) {  // per-source filters: the kernels ran on the classes' handles
+        const rh_status st = rh_rlm_last_status(c.h);
+        if (st != RH_OK) return st;
+    }
     {
         const rh_status w = wait_idle(p);  // every launch of this handle has completed: the words below are final
         if (w != RH_OK) return w;
@@ -3810,6 +3979,12 @@ rh_status rh_rlm_phase_cycles(rh_rlm *p, double out8[8]) {
 
 rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
     if (!p || !info) return RH_ERR_INVALID;
+    if (!p->cls.empty()) {  // per-source filters: the geometry of the largest class
+        const rh_rlm::FilterClass *best = nullptr;
+        for (const rh_rlm::FilterClass &c : p->cls)
+            if (!best || c.members.size() > best->members.size()) best = &c;
+        return rh_rlm_geometry(best->h, info);
+    }
     const Plan &pl = *p->plan;
     info->threads = 64;
     info->frames_per_lane = (uint32_t)pl.v->R;

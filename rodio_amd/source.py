@@ -671,6 +671,21 @@ class ResampleLowpassMix:
         g = np.ascontiguousarray(gains, dtype=np.float32)
         check(lib.rh_rlm_set_gains(self._h, g.ctypes.data_as(_lib.f32p), g.size), "rh_rlm_set_gains")
 
+    def set_filters(self, filters):
+        """A filter per source, rodio's `mixer.add(a.low_pass(200)); mixer.add(b.high_pass(300)); mixer.add(c)`: a list of
+        ("low_pass" | "high_pass" | None, freq[, q = 0.5]) entries, one per source; [] returns to the handle's one filter.
+        Before set_sources()."""
+        n = len(filters)
+        kinds = (C.c_int32 * max(n, 1))()
+        freqs = (C.c_uint32 * max(n, 1))()
+        qs = (C.c_float * max(n, 1))()
+        for i, f in enumerate(filters):
+            kind = f[0] if f is not None else None
+            kinds[i] = {"low_pass": 0, "high_pass": 1, None: -1, "none": -1}[kind]
+            freqs[i] = int(f[1]) if kind not in (None, "none") else 0
+            qs[i] = float(f[2]) if (kind not in (None, "none") and len(f) > 2) else 0.5
+        check(lib.rh_rlm_set_filters(self._h, kinds, freqs, C.cast(qs, _lib.f32p), n), "rh_rlm_set_filters")
+
     def set_exclusive(self, exclusive=True):
         """False: other work shares the CUs while this handle runs (a collective on a second stream, copy launches): tiles by
         ticket instead of by workgroup index (rodio_hip.h)."""

@@ -106,6 +106,35 @@ static std::vector<float> drain(rh::Source &src) {
     return out;
 }
 
+// One adapter of a chain, in the driver's spelling (see the header of this file).
+static void apply_op(rh::GpuSource &g, const std::string &arg) {
+    const std::vector<std::string> t = split(arg, ':');
+    const std::string &op = t[0];
+    if (op == "exact") g.exact_filters(true);
+    else if (op == "amplify") g.amplify(std::stof(t.at(1)));
+    else if (op == "low_pass") g.low_pass((uint32_t)std::stoul(t.at(1)));
+    else if (op == "high_pass") g.high_pass((uint32_t)std::stoul(t.at(1)));
+    else if (op == "reverb") g.reverb(rh::Nanos(std::stoll(t.at(1))), std::stof(t.at(2)));
+    else if (op == "uniform") g.uniform((uint16_t)std::stoul(t.at(1)), (uint32_t)std::stoul(t.at(2)));
+    else if (op == "channels") g.convert_channels((uint16_t)std::stoul(t.at(1)));
+    else if (op == "limit") g.limit(rh_limit_params{-1.0f, 4.0f, 5000000ull, 100000000ull});
+    else if (op == "agc") g.automatic_gain_control(rh_agc_params{1.0f, 4000000000ull, 0ull, 7.0f, 0.0f});
+    else if (op == "take") g.take_duration(rh::Nanos(std::stoll(t.at(1))), std::stoi(t.at(2)) != 0);
+    else if (op == "delay") g.delay(rh::Nanos(std::stoll(t.at(1))));
+    else if (op == "fade_in") g.fade_in(rh::Nanos(std::stoll(t.at(1))));
+    else if (op == "fade_out") g.fade_out(rh::Nanos(std::stoll(t.at(1))));
+    else if (op == "dither") g.dither((uint32_t)std::stoul(t.at(1)), (rh::GpuSource::DitherAlgorithm)std::stoi(t.at(2)), std::stoull(t.at(3)));
+    else if (op == "distortion") g.distortion(std::stof(t.at(1)), std::stof(t.at(2)));
+    else if (op == "channel_volume") {
+        std::vector<float> gains;
+        for (const std::string &x : split(t.at(1), ',')) gains.push_back(std::stof(x));
+        g.channel_volume(gains);
+    } else if (op == "spatial") {
+        const float e[3] = {0.5f, 0.0f, 1.0f}, l[3] = {-1.0f, 0.0f, 0.0f}, r[3] = {1.0f, 0.0f, 0.0f};
+        g.spatial(e, l, r);
+    } else throw std::runtime_error("unknown op " + op);
+}
+
 int main(int argc, char **argv) {
     if (argc == 2 && std::string(argv[1]) == "selftest") {
         auto expect = [](bool ok, const char *what) {
@@ -229,16 +258,23 @@ int main(int argc, char **argv) {
                 mixer.add(make_source(2, 44100, std::move(x)));
             }
             std::vector<float> chunk(1u << 16);
-            // the first read starts the stream (plan, page-locked blocks, device rows): timed apart from the steady state
+            // the control thread starts the stream (plan, page-locked blocks, device rows, the first block) BEFORE the consumer's first
+            // read, as a host does before it hands the mixer to the audio callback (RH_BENCH_NO_PREPARE=1: the first read does it)
+            const auto tp = std::chrono::steady_clock::now();
+            if (!std::getenv("RH_BENCH_NO_PREPARE")) mixer.prepare();
             const auto t0 = std::chrono::steady_clock::now();
             size_t total = mixer.read(chunk.data(), chunk.size());
             const size_t first = total;
             const auto t1 = std::chrono::steady_clock::now();
-            // ... and so is the end: the reads that see the stream finish (the last block, the plan's teardown)
+            // ... and the end is timed apart too: the reads that see the stream finish (the last block; the teardown is a thread's)
             size_t steady = 0;
             auto t2 = t1;
+            double slowest_read = 0, last_read = 0;
             for (;;) {
+                const auto r0 = std::chrono::steady_clock::now();
                 const size_t k = mixer.read(chunk.data(), chunk.size());
+                last_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+                slowest_read = std::max(slowest_read, last_read);
                 total += k;
                 if (k < chunk.size()) break;
                 if (mixer.timing().blocks * opt.block_frames < frames) {  // the upstreams still have frames to give: steady state
@@ -246,16 +282,24 @@ int main(int argc, char **argv) {
                     t2 = std::chrono::steady_clock::now();
                 }
             }
+            const auto t3 = std::chrono::steady_clock::now();
+            const double prep_s = std::chrono::duration<double>(t0 - tp).count();
             const double start_s = std::chrono::duration<double>(t1 - t0).count();
             const double sec = std::chrono::duration<double>(t2 - t1).count();
-            const double end_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+            const double end_s = std::chrono::duration<double>(t3 - t2).count();
+            // end to end: EVERY input byte over the time from the consumer's first read to its last (and with the control thread's
+            // prepare() in front of it)
+            const double all_bytes = (double)S * (double)frames * 2.0 * sizeof(float);
+            const double e2e = all_bytes / std::chrono::duration<double>(t3 - t0).count() / 1e9, e2e_prep = all_bytes / std::chrono::duration<double>(t3 - tp).count() / 1e9;
             const double in_samples = (double)S * (double)frames * 2.0 * (double)steady / (double)total;  // the share of the input behind the steady part
             // the bound of this path is the host link: every input sample crosses it once (PCIe 5.0 x16: 63 GB/s one way)
             const double gbps = in_samples * sizeof(float) / sec / 1e9;
             std::printf("{\"pull_path\": \"GpuMixer\", \"sources\": %d, \"in_frames\": %zu, \"block_frames\": %zu, \"host_threads\": %u, \"out_samples\": %zu, \"start_seconds\": %.4f, \"seconds\": %.4f, \"end_seconds\": %.4f, "
-                        "\"Msamples_per_s_in\": %.1f, \"host_link\": {\"achieved\": %.2f, \"peak\": 63.0, \"unit\": \"GB/s\", \"frac\": %.3f}, \"host_seconds\": {\"pull\": %.4f, \"prefetch\": %.4f, \"submit\": %.4f, \"wait\": %.4f, \"blocks\": %llu}}\n",
+                        "\"Msamples_per_s_in\": %.1f, \"host_link\": {\"achieved\": %.2f, \"peak\": 63.0, \"unit\": \"GB/s\", \"frac\": %.3f}, \"host_seconds\": {\"pull\": %.4f, \"prefetch\": %.4f, \"submit\": %.4f, \"wait\": %.4f, \"blocks\": %llu}, "
+                        "\"prepare_seconds\": %.4f, \"first_read_seconds\": %.5f, \"last_read_seconds\": %.5f, \"slowest_read_seconds\": %.5f, "
+                        "\"end_to_end\": {\"achieved\": %.2f, \"frac\": %.3f, \"with_prepare\": %.2f, \"frac_with_prepare\": %.3f, \"unit\": \"GB/s\", \"peak\": 63.0}}\n",
                         S, frames, opt.block_frames, opt.host_threads, total, start_s, sec, end_s, in_samples / sec / 1e6, gbps, gbps / 63.0, mixer.timing().pull_s, mixer.timing().prefetch_s, mixer.timing().submit_s,
-                        mixer.timing().wait_s, (unsigned long long)mixer.timing().blocks);
+                        mixer.timing().wait_s, (unsigned long long)mixer.timing().blocks, prep_s, start_s, last_read, slowest_read, e2e, e2e / 63.0, e2e_prep, e2e_prep / 63.0);
             return 0;
         }
         if (mode == "mixany" && argc == 9) {
@@ -329,37 +373,60 @@ int main(int argc, char **argv) {
                 mixer.add(make_source(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i));
             if (mixer.channels() != 2 || mixer.sample_rate() != to) throw std::runtime_error("format");
             out = drain(mixer);
+        } else if (mode == "chainmix" && argc == 8) {
+            // host_mirror_test chainmix <dir> <S> <mixer_channels> <to_rate> <block_frames> <on_device 0|1>
+            //   <dir>/spec.txt, one line per source: "channels rate gain filter_kind filter_freq op,op,..." ("-" = no adapters: the source
+            //   goes into the mixer as it is).  A source with adapters is a GpuSource chain handed to GpuMixer::add by value; with
+            //   on_device = 1 its blocks reach the mixer device-to-device.  Writes out.f32 and stats.txt.
+            const int S = std::atoi(argv[3]);
+            const uint16_t mch = (uint16_t)std::atoi(argv[4]);
+            const uint32_t to = (uint32_t)std::atoll(argv[5]);
+            rh::GpuMixer::Options opt;
+            opt.block_frames = (size_t)std::atoll(argv[6]);
+            const bool on_device = std::atoi(argv[7]) != 0;
+            std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
+            if (!sf) throw std::runtime_error("spec.txt");
+            rh::GpuMixer mixer(mch, to, opt);
+            for (int i = 0; i < S; ++i) {
+                unsigned ch = 0, rate = 0, ffreq = 0;
+                int fkind = -1;
+                float gain = 1.0f;
+                char ops[1024];
+                if (std::fscanf(sf, "%u %u %f %d %u %1023s", &ch, &rate, &gain, &fkind, &ffreq, ops) != 6) throw std::runtime_error("spec.txt: short");
+                rh::BoxSource src = make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i);
+                const rh::GpuMixer::Filter filt{fkind, ffreq, 0.5f};
+                if (std::string(ops) == "-") {
+                    mixer.add(std::move(src), gain, filt);
+                } else {
+                    auto g = std::make_unique<rh::GpuSource>(std::move(src), opt.block_frames);
+                    for (const std::string &o : split(ops, ',')) apply_op(*g, o);
+                    if (on_device) mixer.add(std::move(g), gain, filt);
+                    else mixer.add(rh::BoxSource(std::move(g)), gain, filt);
+                }
+            }
+            std::fclose(sf);
+            if (mixer.channels() != mch || mixer.sample_rate() != to) throw std::runtime_error("format");
+            mixer.prepare();  // what a control thread does before it hands the mixer to the audio callback
+            const auto t0 = std::chrono::steady_clock::now();
+            float one[8];
+            const size_t k0 = mixer.read(one, mch);  // the callback's first read: must not start anything
+            const double first_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            out.assign(one, one + k0);
+            const std::vector<float> rest = drain(mixer);
+            out.insert(out.end(), rest.begin(), rest.end());
+            const rh::GpuMixer::ChainStats cs = mixer.chain_stats();  // (the chains themselves are gone with their generation)
+            std::FILE *st = std::fopen((dir + "/stats.txt").c_str(), "w");
+            if (st) {
+                std::fprintf(st, "{\"chains\": %llu, \"chains_on_device\": %llu, \"chain_d2h_samples\": %llu, \"chain_device_samples\": %llu, \"first_read_seconds\": %.6f, \"prepare_seconds\": %.6f}\n",
+                             (unsigned long long)cs.chains, (unsigned long long)cs.on_device, (unsigned long long)cs.d2h_samples, (unsigned long long)cs.device_samples, first_read,
+                             mixer.timing().first_advance_s);
+                std::fclose(st);
+            }
         } else if (mode == "chain" && argc >= 6) {
             const uint16_t ch = (uint16_t)std::atoi(argv[3]);
             const uint32_t rate = (uint32_t)std::atoll(argv[4]);
             rh::GpuSource g(make_source(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
-            for (int a = 6; a < argc; ++a) {
-                const std::vector<std::string> t = split(argv[a], ':');
-                const std::string &op = t[0];
-                if (op == "exact") g.exact_filters(true);
-                else if (op == "amplify") g.amplify(std::stof(t.at(1)));
-                else if (op == "low_pass") g.low_pass((uint32_t)std::stoul(t.at(1)));
-                else if (op == "high_pass") g.high_pass((uint32_t)std::stoul(t.at(1)));
-                else if (op == "reverb") g.reverb(rh::Nanos(std::stoll(t.at(1))), std::stof(t.at(2)));
-                else if (op == "uniform") g.uniform((uint16_t)std::stoul(t.at(1)), (uint32_t)std::stoul(t.at(2)));
-                else if (op == "channels") g.convert_channels((uint16_t)std::stoul(t.at(1)));
-                else if (op == "limit") g.limit(rh_limit_params{-1.0f, 4.0f, 5000000ull, 100000000ull});
-                else if (op == "agc") g.automatic_gain_control(rh_agc_params{1.0f, 4000000000ull, 0ull, 7.0f, 0.0f});
-                else if (op == "take") g.take_duration(rh::Nanos(std::stoll(t.at(1))), std::stoi(t.at(2)) != 0);
-                else if (op == "delay") g.delay(rh::Nanos(std::stoll(t.at(1))));
-                else if (op == "fade_in") g.fade_in(rh::Nanos(std::stoll(t.at(1))));
-                else if (op == "fade_out") g.fade_out(rh::Nanos(std::stoll(t.at(1))));
-                else if (op == "dither") g.dither((uint32_t)std::stoul(t.at(1)), (rh::GpuSource::DitherAlgorithm)std::stoi(t.at(2)), std::stoull(t.at(3)));
-                else if (op == "distortion") g.distortion(std::stof(t.at(1)), std::stof(t.at(2)));
-                else if (op == "channel_volume") {
-                    std::vector<float> gains;
-                    for (const std::string &x : split(t.at(1), ',')) gains.push_back(std::stof(x));
-                    g.channel_volume(gains);
-                } else if (op == "spatial") {
-                    const float e[3] = {0.5f, 0.0f, 1.0f}, l[3] = {-1.0f, 0.0f, 0.0f}, r[3] = {1.0f, 0.0f, 0.0f};
-                    g.spatial(e, l, r);
-                } else throw std::runtime_error("unknown op " + op);
-            }
+            for (int a = 6; a < argc; ++a) apply_op(g, argv[a]);
             std::FILE *meta = std::fopen((dir + "/format.txt").c_str(), "w");
             if (meta) {
                 std::fprintf(meta, "%u %u\n", (unsigned)g.channels(), (unsigned)g.sample_rate());

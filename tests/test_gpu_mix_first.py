@@ -322,3 +322,46 @@ def test_block_streaming_sums_first_too(G, O):
     e_first, e_each, e_between = (float(np.max(np.abs(got[True] - ref))), float(np.max(np.abs(got[False] - ref))), float(np.max(np.abs(got[True] - got[False]))))
     print(f"[stream mix first] |mix first - oracle| {e_first:.2e}  |per source - oracle| {e_each:.2e}  |between| {e_between:.2e}")
     assert e_first <= TOL and e_each <= TOL and e_between <= 2e-6
+
+
+@pytest.mark.parametrize("n_equal", [True, False])
+def test_a_filter_per_source_in_the_fused_mixer(G, O, n_equal):
+    """rh_rlm_set_filters (VERDICT r03 missing #2): `mixer.add(a.low_pass(200)); mixer.add(b.high_pass(300)); mixer.add(c)` -- rodio's
+    sources carry their own adapters into Mixer::add (source/mod.rs:686-721, mixer.rs:58-66).  Eight sources, three filters and none:
+    the sources of a filter form a class that runs as its own fused launch (summed first where their lengths agree), the classes'
+    mixes are added.  Against the oracle's Mixer over the per-source chains; gains on top; then back to the handle's one filter."""
+    import torch
+
+    S = 8
+    ns = [60000] * S if n_equal else [60000, 41000, 60000, 12345, 60000, 2, 25000, 59999]
+    filters = [("low_pass", 200), ("high_pass", 300), None, ("low_pass", 200), ("low_pass", 1000), ("high_pass", 300), None, ("low_pass", 1000)]
+    gains = np.linspace(0.4, 1.1, S).astype(np.float32)
+    xs = [rnd(6100 + i, 2 * n, 0.1) for i, n in enumerate(ns)]
+    m = O.Mixer(2, 48000)
+    for x, f, g in zip(xs, filters, gains):
+        u = O.UniformSourceIterator(O.TestSource(x, 2, 44100).amplify(float(g)), 2, 48000)
+        m.add(u if f is None else (u.low_pass(f[1]) if f[0] == "low_pass" else u.high_pass(f[1])))
+    ref = m.collect()
+    p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=max(ns))
+    p.set_filters(filters)
+    p.set_gains(gains)
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    p.set_sources(xd)
+    got = p.run().cpu().numpy()
+    again = p.run().cpu().numpy()
+    p.check_status()
+    assert len(got) == len(ref)
+    e = float(np.max(np.abs(got - ref)))
+    print(f"[filters per source, equal lengths {n_equal}] |gpu - oracle| = {e:.2e}")
+    assert e <= TOL and np.array_equal(got, again)
+    # the stream entries are for one-filter handles (a streaming host keeps one handle per filter)
+    with pytest.raises(G.RhError):
+        p.stream_begin()
+    # back to the handle's one filter: low_pass(200) for every source
+    p.set_filters([])
+    p.set_sources(xd)
+    one = p.run().cpu().numpy()
+    p.check_status()
+    ref1 = _oracle(O, xs, 44100, 48000, None, "low_pass", 200, gains, 2)
+    assert len(one) == len(ref1) and float(np.max(np.abs(one - ref1))) <= TOL
+    p.close()
