@@ -416,6 +416,17 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
                                 const uint8_t *ended_host, uint32_t n_sources, float *dst,
                                 uint64_t out_capacity_frames, uint64_t *out_frames,
                                 uint64_t *consumed_frames, rh_stream stream);
+/* rh_rlm_stream_block_v, sources that RUN TOGETHER: while every source is live and passes the same number of frames -- what a mixer's
+ * sources do from the moment they are added until the first of them ends -- their filter states need not be told apart: the stream
+ * carries their SUM (as rh_rlm_stream_block does) and every block is summed at the input rate first and converted and filtered once
+ * (DESIGN.md 4.6).  When a source ends or falls behind, the states of the others are recovered from the rows of the block BEFORE
+ * (a replay of its last few tiles through the per-source kernel: a stable filter has forgotten what lies further back) and the stream
+ * goes on with one state per source.  The caller opts in by promising what the recovery needs: on != 0 = "the rows I pass to a block
+ * stay valid and unchanged until the work of the NEXT block call has run" (three row sets in rotation do: include/rodio_hip.hpp).
+ * Between rh_rlm_stream_begin and the stream's first block.  Without it -- the default -- every block takes the per-source kernel. */
+rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on);
+/* Diagnostics: blocks of the current stream that ran on the summed state / on one state per source, and recoveries in between. */
+rh_status rh_rlm_stream_stats(rh_rlm *p, uint32_t *summed_blocks, uint32_t *per_source_blocks, uint32_t *recoveries);
 /* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels
  * (equal-length sources only: RH_ERR_UNSUPPORTED otherwise).  One launch for all sources. */
 rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames,

@@ -274,10 +274,12 @@ private:
 
 /// One run of samples pulled from a source inside ONE span of it.
 struct Piece {
-    std::size_t n;       // samples (whole frames of `ch` channels)
+    std::size_t n;       // samples: whole frames of `ch` channels, and behind them `tail` samples of a frame the span's end cuts
     bool opens, closes;  // the first / the last samples of their span
     std::uint16_t ch;
     std::uint32_t rate;
+    std::size_t tail = 0;   // closes only: samples of a CUT last frame (uniform.rs:56: `.min(32768)` cuts frames of 3, 5, 6, 7 channels; so does a source that ends inside a frame)
+    bool by_none = false;   // closes only: the span ended because the source returned None, not because its samples were counted out
 };
 
 /// Pulls a source the way UniformSourceIterator does (uniform.rs:50-97): whenever its converter chain has run dry it asks
@@ -302,18 +304,21 @@ public:
     bool opens_next() const { return fresh_; }
     /// Frames the open span still admits (kOpenEnded: current_span_len() was None).
     std::size_t left_frames() const { return left_ == kOpenEnded ? kOpenEnded : left_ / ch_; }
-    /// Up to max_frames frames of the current span into dst; false: the stream is over and nothing was produced.
+    /// Up to max_frames frames of the current span into dst (dst has room for one more frame: the samples of a frame the span's end
+    /// cuts come along with the last whole frames, Piece::tail); false: the stream is over and nothing was produced.
     bool read_piece(float *dst, std::size_t max_frames, Piece &out) {
         if (ended_ || (!open_ && !bootstrap())) return false;
         std::size_t want = max_frames > kOpenEnded / ch_ ? kOpenEnded : max_frames * ch_;
         want = std::min(want, left_);
         want -= want % ch_;
+        if (left_ != kOpenEnded && left_ - want < ch_) want = left_;  // the rest of the span is a cut frame: its samples belong to this span's chain
         std::size_t got = want ? up_->read(dst, want) : 0;
         const bool none = got < want;  // the source returned None inside the span
-        got -= got % ch_;              // sources end on frame boundaries (source/mod.rs:169-178)
         if (left_ != kOpenEnded) left_ -= got;
         const bool closes = none || left_ == 0;
-        out = Piece{got, fresh_, closes, ch_, rate_};
+        const std::size_t tail = closes ? got % ch_ : 0;  // (what becomes of it is the planner's business: it knows the target format)
+        if (!closes) got -= got % ch_;
+        out = Piece{got, fresh_, closes, ch_, rate_, tail, none};
         const bool produced = got != 0 || (closes && !fresh_);  // a span that had samples before ends here: its last frame is due
         if (got) fresh_ = false;
         if (closes) open_ = false;
@@ -337,9 +342,10 @@ private:
             return false;
         }
         left_ = span ? std::min<std::size_t>(*span, 32768) : kOpenEnded;
-        // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels, and
-        // rodio then rotates the channels of every later span.  That is not reproduced here: it is refused.
-        if (left_ != kOpenEnded && left_ % ch_) throw Error(RH_ERR_UNSUPPORTED, "a span of " + std::to_string(left_) + " samples cuts a frame of " + std::to_string(ch_) + " channels");
+        // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels: the chain rodio
+        // builds for such a span ends inside a frame, and the next chain starts there -- every later span has its channels rotated.
+        // The reader hands the cut frame's samples over with the span (Piece::tail) and goes on at the sample behind them, as rodio's
+        // source does; what the converters make of a cut frame is UniformPlanner::add's business.
         open_ = true;
         fresh_ = true;
         return true;
@@ -391,9 +397,23 @@ public:
             row_off_ = pos_;  // the span's frame 0 sits here
             row_frame0_ = 0;
         }
-        const std::uint64_t f = p.n / p.ch;
+        const std::uint64_t f = (p.n - p.tail) / p.ch;
         span_in_ += f;
         pos_ += p.n;
+        if (p.closes && p.tail) {
+            // A frame the span's end cuts.  At the mixer's own rate the SampleRateConverter passes through (sample_rate.rs:133-136) and the
+            // ChannelCountConverter behind it emits, for the cut frame, the output channels its samples cover (channels.rs:57-85: position k
+            // < from reads the input, the None behind the last sample ends the chain): a whole output frame when the cut frame holds at
+            // least min(from, to) samples -- one more frame for the segment, of which the kernel reads just those channels.  The next span
+            // starts at the sample behind the cut: its channels are rotated, as they are in rodio.
+            const std::size_t nc = std::min<std::size_t>(p.ch, to_ch_);
+            if (p.rate == to_rate_ && p.tail >= nc) span_in_ += 1;
+            else if (!p.by_none)  // (a cut frame in front of a real rate conversion: the converter's end game with a short frame -- runs of `tail` samples regrouped
+                                  // by the channel converter -- is not reproduced; neither is an output frame that would come out short)
+                throw Error(RH_ERR_UNSUPPORTED, "a span of a " + std::to_string(p.ch) + "-channel source ends inside a frame (" + std::to_string(p.tail) + " samples): reproduced only at the mixer's own rate" +
+                                                    (p.rate == to_rate_ ? ", and when the cut frame covers an output frame" : ""));
+            // by_none with a short tail: the source ended inside a frame; its last samples are dropped (source/mod.rs:169-178: sources end on frame boundaries)
+        }
         std::uint64_t ready = 0;
         check(rh_uniform_span_frames(span_in_, p.rate, to_rate_, p.closes ? 1 : 0, &ready), "rh_uniform_span_frames");
         if (ready > span_m_) {
@@ -1309,7 +1329,9 @@ private:
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
         rh_rlm *plan = nullptr;
-        detail::DeviceBuf din[2], q[2];  // staged input rows (one set per staging block); mixed output not yet served (ping-pong)
+        detail::DeviceBuf din[3], q[2];  // staged input rows, THREE sets in rotation: the rows of a block stay untouched until the block after it has run
+                                         // (rh_rlm_stream_keep_history: sources that run together are summed first); mixed output not yet served (ping-pong)
+        int dnext = 0, pd = 0, pd_prev = -1;  // the row set the next pull takes / the one of the block that was pulled last / the one before it
         detail::Event copied[2];         // ... recorded on the copy stream behind the copies that fill din[i]
         detail::PinnedBuf stage[2];   // one staging block per slot in flight
         detail::PinnedBuf side[2];    // ... and one for the sources that are not stereo, in their own layout
@@ -1479,6 +1501,9 @@ private:
         for (const Src &x : g.srcs) gains.push_back(staged ? 1.0f : x.gain);  // staged: the factor sits in front of the converter, where Mixer::add(src.amplify(g)) has it
         check(rh_rlm_set_gains(g.plan, gains.data(), (std::uint32_t)gains.size()), "rh_rlm_set_gains");
         check(rh_rlm_stream_begin(g.plan), "rh_rlm_stream_begin");
+        // sources that start together run together until the first of them ends: their blocks are summed first (rodio_hip.h).  The rows of
+        // a direct generation rotate through three sets, which is what the recovery at that moment needs; converted rows (staged) do not.
+        if (!staged) check(rh_rlm_stream_keep_history(g.plan, 1), "rh_rlm_stream_keep_history");
         row_ = (cap_frames_ * 2 + 3) & ~std::size_t(3);  // 16-byte aligned rows
         std::uint64_t m = 0;
         check(rh_resample_out_frames(staged ? g.crow : cap_frames_, from, rate_, cfg.channels, 0, &m), "rh_resample_out_frames");
@@ -1511,6 +1536,9 @@ private:
     void pull_block(Gen &g) {
         g.pslot = g.slot;
         g.slot ^= 1;
+        g.pd_prev = g.pd_prev < 0 && g.dnext == 0 ? -1 : g.pd;
+        g.pd = g.dnext;
+        g.dnext = (g.dnext + 1) % 3;
         if (g.staged) pull_block_staged(g);
         else pull_block_direct(g);
         g.pulled = true;
@@ -1679,7 +1707,7 @@ private:
         const std::size_t native = g.mono ? 1 : 2;  // channels of the rows the fused launch reads
         const std::size_t row_ = row_floats(g);
         stage.reset(S * row_);
-        detail::DeviceBuf &din = g.din[g.pslot], &dside = g.dside[g.pslot];
+        detail::DeviceBuf &din = g.din[g.pd], &dside = g.dside[g.pslot];
         din.reset(S * row_);
         g.pptrs.assign(S, nullptr);
         g.pavail.assign(S, 0);
@@ -1729,7 +1757,7 @@ private:
             float *row = din.get() + i * row_;
             std::size_t have = (std::size_t)x.dheld * 2;
             if (have / 2 + (x.ended ? 0 : opt_.block_frames) > cap_frames_) throw Error(RH_ERR_CAPACITY, "GpuMixer: held frames exceed the plan");
-            if (have) check(rh_memcpy_d2d(row, g.din[g.pslot ^ 1].get() + i * row_ + x.dheld_off * 2, have * sizeof(float), copy_stream_), "rh_memcpy_d2d");
+            if (have) check(rh_memcpy_d2d(row, g.din[g.pd_prev].get() + i * row_ + x.dheld_off * 2, have * sizeof(float), copy_stream_), "rh_memcpy_d2d");
             if (!x.ended) {
                 const std::size_t want = opt_.block_frames * 2;
                 std::size_t got = x.dev->read_device(row + have, want, copy_stream_);
@@ -1752,7 +1780,7 @@ private:
         if (g.pside)  // ChannelCountConverter on the device (channels.rs:57-85), into the rows the fused launch reads
             for (std::size_t i = 0; i < S; ++i)
                 if (g.srcs[i].ch != native && g.pavail[i])
-                    check(rh_channels_convert(g.din[g.pslot].get() + i * row_, g.dside[g.pslot].get() + g.pside_off[i], (std::size_t)g.pavail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
+                    check(rh_channels_convert(g.din[g.pd].get() + i * row_, g.dside[g.pslot].get() + g.pside_off[i], (std::size_t)g.pavail[i], g.srcs[i].ch, 2, stream_), "rh_channels_convert");
         std::uint64_t out = 0, consumed = 0;
         if (debug_poison()) check(rh_memset(g.queue_end(), 0xff, (out_cap_frames_ * 2 - g.fill - g.head) * 2 * sizeof(float), stream_), "rh_memset");
         if (g.mono) {  // the mono mix of the block, then ChannelCountConverter(1 -> 2) behind the stereo queue (one pass over the MIX, not per source)

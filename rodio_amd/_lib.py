@@ -162,6 +162,8 @@ SIGNATURES = {
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
     "rh_rlm_set_gains": (i32, [vp, f32p, u32]),
     "rh_rlm_set_filters": (i32, [vp, C.POINTER(i32), C.POINTER(u32), f32p, u32]),
+    "rh_rlm_stream_keep_history": (i32, [vp, i32]),
+    "rh_rlm_stream_stats": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
     "rh_rlm_set_exclusive": (i32, [vp, i32]),
     "rh_rlm_set_mix_first": (i32, [vp, i32]),
     "rh_rlm_run_subset": (i32, [vp, u32, u32, vp, u64, C.POINTER(u64), vp]),

@@ -2579,6 +2579,18 @@ struct rh_rlm {
     // block streaming with per-source states (rh_rlm_stream_block_v)
     std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
     uint32_t st_cols = 0;            // columns of an aggregate row for the stream (0: no such stream yet)
+    // rh_rlm_stream_block_v while its sources RUN TOGETHER (all live, equal frames per block): the summed state of
+    // rh_rlm_stream_block -- so the block is summed first -- until a source ends or falls behind.  Then the per-source states are
+    // recovered from the rows of the block before (rh_rlm_stream_keep_history: the caller has kept them) and the stream goes on
+    // with one state per source.
+    bool st_history = false;     // rh_rlm_stream_keep_history
+    bool st_together = false;    // the stream still runs on the summed state
+    bool st_decided = false;     // ... or has decided not to
+    std::vector<const float *> st_prev_ptrs;  // the block before: its rows,
+    uint64_t st_prev_avail = 0, st_prev_g0 = 0, st_prev_m = 0, st_prev_out = 0;  // frames per row, global index of frame 0, first output frame, output frames
+    float *d_replay = nullptr;   // where the recovery's replay of the last tiles writes its (unused) mix
+    size_t replay_floats = 0;
+    uint32_t st_n_summed = 0, st_n_each = 0, st_n_recover = 0;  // rh_rlm_stream_stats
     // Recorded (by wait_idle) behind what the handle has queued.  The library's streams are hipStreamNonBlocking: a null-stream
     // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
     // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
@@ -3164,6 +3176,7 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     if (p->chunk.d_halo) (void)hipFree(p->chunk.d_halo);
     if (p->chunk.d_gran) (void)hipFree(p->chunk.d_gran);
     if (p->d_prof) (void)hipFree(p->d_prof);
+    if (p->d_replay) (void)hipFree(p->d_replay);
     for (int k = 0; k < 2; ++k)
         if (p->d_w[k]) (void)hipFree(p->d_w[k]);
     for (int k = 0; k < rh_rlm::kDescRing; ++k) {
@@ -3529,9 +3542,12 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         }
         SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32));
         float *const frow = pre ? p->d_mix + row : p->d_mix;  // the row the fused launch reads
-        int U = 4;  // measured (256 x 1 Mi stereo frames): 0.410 / 0.409 / 0.342 ms for 1 / 2 / 4 vectors per lane
-        if (const char *u = rh::knob(rh::K_MIX_U)) U = atoi(u);
         const uint64_t nvec = n_floats / 4;
+        int U = 4;  // measured (256 x 1 Mi stereo frames): 0.410 / 0.409 / 0.342 ms for 1 / 2 / 4 vectors per lane
+        // ... where the row fills the chip.  A stream's block is a short row (64 Ki frames: 128 workgroups at U = 4): fewer vectors per lane, more
+        // workgroups, the same loads in flight per lane (8: the kernel takes 8 / U sources per step)
+        while (U > 1 && (nvec + 256ull * U - 1) / (256ull * U) < 2ull * (uint64_t)rh::g_num_cus) U /= 2;
+        if (const char *u = rh::knob(rh::K_MIX_U)) U = atoi(u);
         const uint32_t per = 256u * (uint32_t)(U == 1 ? 1 : U == 2 ? 2 : 4);
         const uint32_t wgs = (uint32_t)std::max<uint64_t>(1, (nvec + per - 1) / per);
         const uint64_t ring_waves = (nvec + 511) / 512;  // 8 KiB chunks
@@ -3724,10 +3740,40 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     p->st_cur = 0;
     p->st_total.clear();
     p->st_cols = 0;
+    p->st_together = p->st_decided = false;
+    p->st_n_summed = p->st_n_each = p->st_n_recover = 0;
+    p->st_prev_ptrs.clear();
+    p->st_prev_avail = p->st_prev_g0 = p->st_prev_m = p->st_prev_out = 0;
     return RH_OK;
 }
 
+rh_status rh_rlm_stream_stats(rh_rlm *p, uint32_t *summed_blocks, uint32_t *per_source_blocks, uint32_t *recoveries) {
+    if (!p) return RH_ERR_INVALID;
+    if (summed_blocks) *summed_blocks = p->st_n_summed;
+    if (per_source_blocks) *per_source_blocks = p->st_n_each;
+    if (recoveries) *recoveries = p->st_n_recover;
+    return RH_OK;
+}
+
+rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on) {
+    if (!p) return RH_ERR_INVALID;
+    if (p->st_on && (p->st_nsrc || p->st_decided)) return RH_ERR_INVALID;  // before the stream's first block
+    p->st_history = on != 0;
+    return RH_OK;
+}
+
+static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
+                                     uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream);
+
 rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
+                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
+    if (p->st_together || p->st_decided) return RH_ERR_INVALID;  // a stream uses one of the two block entries throughout
+    return stream_block_summed(p, srcs_host, n_sources, avail_frames, flush, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+}
+
+static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
                               uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
@@ -3776,6 +3822,7 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
             sa.wout = p->d_w[p->st_cur ^ 1];
             st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
             if (st != RH_OK) return st;
+            p->st_n_summed += 1;
             if (!flush && p->filt) p->st_cur ^= 1;
         }
         p->st_m += out;
@@ -3805,13 +3852,52 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
     RH_REQUIRE_INIT();
     if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames || !avail_frames_host || !ended_host) return RH_ERR_INVALID;
     if (n_sources == 0 || n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
-    if (p->st_nsrc && (p->st_nsrc != n_sources || !p->st_cols)) return RH_ERR_INVALID;  // one set of sources, one kind of stream
+    if (p->st_nsrc && (p->st_nsrc != n_sources || (!p->st_cols && !p->st_together))) return RH_ERR_INVALID;  // one set of sources, one kind of stream
     *out_frames = 0;
     *consumed_frames = 0;
     const uint64_t F = p->F, T = p->T, L = 64ull * p->wave.v->R;
     const uint64_t cin = p->st_chunk_in, cout = p->st_chunk_out;
     hipStream_t hs = rh::as_stream(stream);
-    if (!p->st_cols) {  // first block of the stream: size the aggregate rows once (the states live in them), zero states
+    // ---- the sources run TOGETHER (all live, the same frames each): one summed state, the block summed first -------------------
+    // What a recovery needs of the block before: K = J tiles of the per-source kernel, replayed from a zero state (the filter has
+    // forgotten what lies further back: ||B^K|| < 2^-40).  So a block stays on the summed state only if it emits at least K frames;
+    // a stream whose first block does not never starts on it.
+    const uint64_t K = (uint64_t)(p->filt ? p->wave.J : 0) * L;
+    if (!p->st_decided) {
+        p->st_decided = true;
+        p->st_together = p->st_history && p->filt && p->mix_first_on && n_sources >= 2 && K > 0 && !rh::knob(rh::K_NO_MIX_FIRST);
+    }
+    if (p->st_together) {
+        bool same = true, any_ended = false, all_ended = true;
+        for (uint32_t s = 0; s < n_sources; ++s) {
+            same = same && avail_frames_host[s] == avail_frames_host[0];
+            any_ended = any_ended || ended_host[s] != 0;
+            all_ended = all_ended && ended_host[s] != 0;
+        }
+        const uint64_t N = p->st_g0 + avail_frames_host[0];
+        const uint64_t ready = stream_ready(N, F, T, cin, cout);
+        const uint64_t Rf = p->fast.v->R;
+        const uint64_t would = ready > p->st_m ? (ready - p->st_m) / Rf * Rf : 0;
+        if (same && all_ended) {  // they end together too: the summed stream's last block
+            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 1, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+            if (st == RH_OK) p->st_together = false;  // (st_done is set: nothing follows)
+            return st;
+        }
+        if (same && !any_ended && would >= K) {
+            const uint64_t g0 = p->st_g0, m0 = p->st_m;
+            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 0, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+            if (st != RH_OK) return st;
+            p->st_prev_ptrs.assign(srcs_host, srcs_host + n_sources);
+            p->st_prev_avail = avail_frames_host[0];
+            p->st_prev_g0 = g0;
+            p->st_prev_m = m0;
+            p->st_prev_out = *out_frames;
+            return RH_OK;
+        }
+        p->st_together = false;  // a source ends or falls behind, or the block is short: one state per source from here on
+    }
+    const bool recover = !p->st_cols && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
+    if (!p->st_cols) {  // first block of the per-source stream: size the aggregate rows once (the states live in them), zero states
         rh::ResampleGeom g;
         rh_status st = rh::make_resample_geom(p->cfg.max_in_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &g);
         if (st != RH_OK) return st;
@@ -3842,6 +3928,48 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
             const rh_status mk = mark_launch(p, hs);
             if (mk != RH_OK) return mk;
         }
+    }
+    if (recover) {
+        // The states the summed stream never kept: replay the last K output frames of the block before through the per-source kernel
+        // from a zero state (its rows are still there: rh_rlm_stream_keep_history), mix discarded, and fold the replay's aggregates
+        // into column 0 -- exactly what the end of a per-source block does.
+        const uint64_t m0 = p->st_m - K;  // >= st_prev_m: that block emitted at least K frames
+        const size_t need = (size_t)K * p->cfg.channels + 64;
+        if (need > p->replay_floats) {
+            const rh_status w = wait_idle(p);
+            if (w != RH_OK) return w;
+            if (p->d_replay) RH_HIP_TRY(hipFree(p->d_replay));
+            p->d_replay = nullptr;
+            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_replay), need * sizeof(float)));
+            p->replay_floats = need;
+        }
+        std::vector<SrcDesc> &h = p->h_desc;
+        h.resize(n_sources);
+        for (uint32_t s = 0; s < n_sources; ++s)
+            h[s] = SrcDesc{p->st_prev_ptrs[s], (uint32_t)p->st_prev_avail, (uint32_t)K, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+        {
+            const rh_status up = upload_descriptors(p, n_sources, hs);
+            if (up != RH_OK) return up;
+        }
+        p->equal = false;
+        p->n_sources = n_sources;
+        p->out_frames = K;
+        rh_status st = activate_plan(p, &p->wave);
+        if (st != RH_OK) return st;
+        StreamArgs sa;
+        sa.mode = 1u;
+        sa.active = (uint32_t)K;
+        sa.m0 = m0;
+        sa.g0 = p->st_prev_g0;
+        sa.gran_cols = p->st_cols;
+        st = rlm_launch(p, 0, n_sources, p->d_replay, K, nullptr, stream, 0, 0, sa);
+        if (st != RH_OK) return st;
+        hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)(K / L) + 1u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
+        RH_CHECK_LAUNCH();
+        const rh_status mk = mark_launch(p, hs);
+        if (mk != RH_OK) return mk;
+        p->st_prev_ptrs.clear();
+        p->st_n_recover += 1;
     }
     // what every source can still give: a live one every frame whose two taps have arrived, an ended one all it has left
     uint64_t live_min = ~0ull, ended_max = 0;
@@ -3898,6 +4026,7 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
         sa.gran_cols = p->st_cols;
         st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
         if (st != RH_OK) return st;
+        p->st_n_each += 1;
         if (!final_block && p->filt) {
             hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)tiles + 1u, (uint32_t)p->wave.J, p->epoch,
                                p->epoch + 1);

@@ -636,6 +636,7 @@ class ResampleLowpassMix:
         check(lib.rh_rlm_create(C.byref(self._h), C.byref(self.cfg)), "rh_rlm_create")
         self.channels = channels
         self._keep = None
+        self._keep_prev = None
         self.out_frames = 0
 
     def geometry(self):
@@ -704,9 +705,19 @@ class ResampleLowpassMix:
         return out[: m.value * self.channels]
 
     # -- block streaming: feed(blocks) returns the mixed frames that became computable ------------------
-    def stream_begin(self):
+    def stream_begin(self, keep_history=False):
+        """keep_history: stream_feed_v() may run on the summed state while its sources run together (rh_rlm_stream_keep_history): the
+        mirror then keeps the rows of the block before alive, as the recovery needs them."""
         check(lib.rh_rlm_stream_begin(self._h), "rh_rlm_stream_begin")
+        check(lib.rh_rlm_stream_keep_history(self._h, 1 if keep_history else 0), "rh_rlm_stream_keep_history")
         self._left = None
+        self._keep_prev = None
+
+    def stream_stats(self):
+        """(blocks on the summed state, blocks with one state per source, recoveries) of the current stream."""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib.rh_rlm_stream_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "rh_rlm_stream_stats")
+        return a.value, b.value, c.value
 
     def stream_feed(self, blocks, flush=False):
         """blocks: one device tensor of NEW interleaved samples per source (equal lengths).  The unconsumed
@@ -740,6 +751,7 @@ class ResampleLowpassMix:
         out = _dev_empty(max(cap * ch, 4))
         m, c = C.c_uint64(0), C.c_uint64(0)
         check(lib.rh_rlm_stream_block_v(self._h, ptrs, avail, end, n, _ptr(out), cap, C.byref(m), C.byref(c), _stream()), "rh_rlm_stream_block_v")
+        self._keep_prev = self._keep  # (keep_history: the next call may replay the end of this block's rows)
         self._keep = bufs  # the launch reads them asynchronously
         self._left = [b[min(c.value * ch, b.numel()):].clone() for b in bufs]
         return out[: m.value * ch]

@@ -185,15 +185,32 @@ int main(int argc, char **argv) {
             expect(rd.read_piece(tmp.data(), 100000, pc) && pc.n == 12768 && !pc.opens && pc.closes && tmp[0] == 52768.0f, "second span closes at 32768");
             expect(rd.read_piece(tmp.data(), 100000, pc) && pc.n == 70000 - 65536 && pc.opens && pc.closes && rd.ended(), "the last span is what is left: the source returns None inside it");
             expect(!rd.read_piece(tmp.data(), 100000, pc), "the stream is over");
-            bool threw = false;
-            try {  // min(span, 32768) cuts a frame of 6 channels: rodio rotates the channels from there on; refused here
-                rh::SamplesBuffer six(6, 48000, std::vector<float>(6 * 6000, 0.0f));
+            {  // min(span, 32768) cuts a frame of 6 channels (32768 = 5461 * 6 + 2): the cut frame's samples come with the span, the next span
+               // starts behind them -- rotated, as in rodio; the source ends 4 samples into a frame
+                std::vector<float> d6(6 * 6000);
+                for (size_t i = 0; i < d6.size(); ++i) d6[i] = (float)i;
+                rh::SamplesBuffer six(6, 48000, d6);
                 rh::detail::SpanReader r6(&six);
-                (void)r6.read_piece(tmp.data(), 10, pc);
-            } catch (const rh::Error &e) {
-                threw = e.status == RH_ERR_UNSUPPORTED;
+                std::vector<float> t6(40000);
+                expect(r6.read_piece(t6.data(), 100000, pc) && pc.n == 32768 && pc.tail == 2 && pc.closes && !pc.by_none && t6[32767] == 32767.0f, "the span's cut frame comes with it");
+                expect(r6.read_piece(t6.data(), 100000, pc) && pc.n == 36000 - 32768 && pc.tail == (36000 - 32768) % 6 && pc.closes && pc.by_none && t6[0] == 32768.0f, "the next span starts behind the cut");
+                // what the converters make of it: at the mixer's rate one more output frame (the channels the cut frame covers) ...
+                rh::detail::UniformPlanner same(2, 48000);
+                std::vector<rh::detail::UniformPlanner::Seg> segs;
+                same.begin_block();
+                same.add(rh::detail::Piece{32768, true, true, 6, 48000, 2, false}, segs);
+                expect(segs.size() == 1 && segs[0].g.m1 == 5462 && segs[0].g.src_frames == 5462 && same.out_frames() == 5462, "a cut frame at the mixer's rate: one more output frame");
+                // ... and in front of a real rate conversion it is refused
+                bool threw = false;
+                try {
+                    rh::detail::UniformPlanner other(2, 44100);
+                    other.begin_block();
+                    other.add(rh::detail::Piece{32768, true, true, 6, 48000, 2, false}, segs);
+                } catch (const rh::Error &e) {
+                    threw = e.status == RH_ERR_UNSUPPORTED;
+                }
+                expect(threw, "a cut frame in front of a rate conversion is refused");
             }
-            expect(threw, "a span that cuts a frame is refused");
         }
         {  // NonZero channels / rate (buffer.rs:40: the types cannot hold 0)
             bool threw = false;

@@ -365,3 +365,66 @@ def test_a_filter_per_source_in_the_fused_mixer(G, O, n_equal):
     ref1 = _oracle(O, xs, 44100, 48000, None, "low_pass", 200, gains, 2)
     assert len(one) == len(ref1) and float(np.max(np.abs(one - ref1))) <= TOL
     p.close()
+
+
+@pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
+@pytest.mark.parametrize("case", ["end together", "end apart", "short first block", "short block in the middle", "one falls behind"])
+def test_block_streaming_of_sources_that_run_together(G, O, filt, freq, case):
+    """rh_rlm_stream_block_v + rh_rlm_stream_keep_history (VERDICT r03 missing #5): what a mixer's sources do from the moment they are
+    added until the first of them ends -- all live, the same frames per block -- runs on the SUMMED state, every block summed first.
+    When a source ends, falls behind, or a block is too short to recover from, the per-source states are recovered from the rows of
+    the block before and the stream goes on with one state per source.  Every case against the oracle's per-source chains and against
+    the same stream without the history (one state per source throughout)."""
+    import torch
+
+    S = 6
+    ns = {"end together": [90000] * S, "end apart": [90000, 61000, 90000, 45000, 90000, 40000], "short first block": [90000, 61000, 90000, 90000, 90000, 90000],
+          "short block in the middle": [90000] * S, "one falls behind": [90000] * S}[case]
+    cuts = {"end together": [0, 25000, 50000, 75000, 90000], "end apart": [0, 25000, 50000, 75000, 90000], "short first block": [0, 700, 30000, 60000, 90000],
+            "short block in the middle": [0, 30000, 30300, 60000, 90000], "one falls behind": [0, 25000, 50000, 75000, 90000]}[case]
+    gains = np.linspace(0.5, 1.3, S).astype(np.float32)
+    xs = [rnd(7100 + i, 2 * n, 0.15) for i, n in enumerate(ns)]
+    m = O.Mixer(2, 48000)
+    for x, g in zip(xs, gains):
+        u = O.UniformSourceIterator(O.TestSource(x, 2, 44100).amplify(float(g)), 2, 48000)
+        m.add(u.low_pass(freq) if filt == "low_pass" else u.high_pass(freq))
+    ref = m.collect()
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    got = {}
+    for hist in (True, False):
+        p = G.ResampleLowpassMix(44100, 48000, 2, None, filt, freq, 0.5, max_sources=S, max_in_frames=max(ns))
+        p.set_gains(gains)
+        p.stream_begin(keep_history=hist)
+        outs = []
+        fed = [0] * S  # frames of every source passed so far
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k], cuts[k + 1]
+            blocks, ended = [], []
+            for s_, (x, n) in enumerate(zip(xd, ns)):
+                a, b = min(fed[s_], n), min(hi, n)
+                if case == "one falls behind" and s_ == 2 and k == 1:
+                    b = a + (b - a) // 2  # this source delivers half a block once (a decoder that stalls): the others run ahead of it
+                blocks.append(x[2 * a: 2 * b])
+                fed[s_] = b
+                ended.append(b >= n)
+            outs.append(p.stream_feed_v(blocks, ended))
+        while not all(f >= n for f, n in zip(fed, ns)):  # (the source that fell behind delivers its rest)
+            blocks, ended = [], []
+            for s_, (x, n) in enumerate(zip(xd, ns)):
+                blocks.append(x[2 * fed[s_]: 2 * n])
+                fed[s_] = n
+                ended.append(True)
+            outs.append(p.stream_feed_v(blocks, ended))
+        p.check_status()
+        got[hist] = torch.cat(outs).cpu().numpy()
+        summed, each, rec = p.stream_stats()
+        if not hist:
+            assert summed == 0 and rec == 0 and each >= 4
+        else:  # which blocks ran how: the cases are what their names say
+            want = {"end together": (4, 0, 0), "end apart": (1, 3, 1), "short first block": (0, 4, 0), "short block in the middle": (1, 2, 1), "one falls behind": (1, 3, 1)}[case]
+            assert (summed, each, rec) == want, (case, summed, each, rec)
+        p.close()
+    assert len(got[True]) == len(ref) == len(got[False]), (len(got[True]), len(got[False]), len(ref))
+    e_t, e_s, e_b = float(np.max(np.abs(got[True] - ref))), float(np.max(np.abs(got[False] - ref))), float(np.max(np.abs(got[True] - got[False])))
+    print(f"[together: {case} {filt}{freq}] |together - oracle| {e_t:.2e}  |per source - oracle| {e_s:.2e}  |between| {e_b:.2e}")
+    assert e_t <= TOL and e_s <= TOL and e_b <= 2e-6
