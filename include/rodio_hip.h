@@ -289,6 +289,14 @@ rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample
 rh_status rh_biquad(float *dst, const float *src, uint64_t frames, uint32_t channels,
                     uint32_t n_streams, const float coeffs5_host[5], float *state, int32_t mode,
                     rh_stream stream);
+/* THE FILTER CONTRACT.  Every time-parallel evaluation of a low_pass / high_pass in this library (rh_biquad mode 1, the fused rh_rlm_*
+ * path) is CLOSER to the exact response than rodio's own f32 recurrence is, so its distance from rodio is rodio's rounding noise -- which
+ * the recurrence amplifies by ~1 / (1 - r)^2 for poles of radius r.  Returns 1 where that distance stays <= 1e-5 for a FULL-SCALE source
+ * (|x| <= 1; it scales with the peak): low_pass with 1 - r >= 0.0125 (>= 100 Hz at 48 kHz), high_pass with 1 - r >= 0.075 (>= 600 Hz at
+ * 48 kHz); measured table: profiles/r04_filter_contract.txt.  0 outside: a drop-in for rodio's samples then takes rh_biquad mode 0 (the
+ * reference's order, bit for bit) -- include/rodio_hip.hpp does so on its own (GpuSource: per filter; GpuMixer: the source gets a chain
+ * amplify -> uniform -> filter in mode 0 of its own and enters the mixer unfiltered). */
+int32_t rh_filter_scan_ok(int32_t kind, uint32_t freq, float q, uint32_t sample_rate);
 
 /* ---- src/math.rs:51-56,86-90,110-113 (host): dB <-> linear as the reference spells them (2^(dB*0.05*log2 10),
  * log2(x)*log10(2)*20) and the smoothing coefficient exp(-1/(seconds*rate)) of the limiter and the AGC.

@@ -711,11 +711,15 @@ public:
             return c.n;
         });
     }
-    /// The filters run time-parallel (rh_biquad mode 1: <= 1e-5 from rodio's f32 recurrence and no further from the exact
-    /// response than that recurrence itself; blocks the scan kernel does not take continue in reference order on the same
-    /// state).  exact_filters(true): the reference's operation order throughout, bit for bit, one lane per channel.
+    /// How the filters of this chain run.  By default (neither call) every filter decides for itself by THE FILTER CONTRACT
+    /// (rodio_hip.h, rh_filter_scan_ok): time-parallel (rh_biquad mode 1) where that stays within 1e-5 of rodio's own f32
+    /// recurrence for a full-scale source, the reference's operation order (mode 0, bit for bit, one lane per channel) where it
+    /// would not -- low cutoffs, where rodio's recurrence amplifies its own rounding noise past 1e-5.  exact_filters(true): the
+    /// reference's order throughout.  exact_filters(false): time-parallel throughout -- closer to the exact response than rodio
+    /// is, further than 1e-5 from rodio at low cutoffs.  (Blocks the scan kernel does not take run in reference order on the
+    /// same state either way.)
     GpuSource &exact_filters(bool on = true) {
-        exact_filters_ = on;
+        filter_mode_ = on ? 1 : 2;
         return *this;
     }
     GpuSource &low_pass(std::uint32_t freq) { return blt(0, freq, 0.5f); }   // blt.rs:11-16
@@ -1035,6 +1039,7 @@ private:
         check(rh_biquad_coeffs(kind, freq, q, rate_, co), "rh_biquad_coeffs");
         std::vector<float> coeffs(co, co + 5);
         auto st = state(4u * ch);
+        const bool exact = filter_mode_ == 1 || (filter_mode_ == 0 && !rh_filter_scan_ok(kind, freq, q, rate_));  // the filter contract (rodio_hip.h)
         return push([=](Ctx &c) {
             std::size_t frames = c.n / ch;
             const std::size_t rem = c.n % ch;
@@ -1042,7 +1047,7 @@ private:
                 check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
                 frames += 1;       // the zero padding only touches channels the stream no longer has
             }
-            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), exact_filters_ ? 0 : 1, c.stream), "rh_biquad");
+            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), exact ? 0 : 1, c.stream), "rh_biquad");
             return rem && c.flush ? c.n : frames * ch;
         }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); });  // blt.rs:350-377
     }
@@ -1059,7 +1064,7 @@ private:
     detail::SpanReader reader_{nullptr};
     std::vector<detail::Piece> pieces_;  // the spans of the block being enqueued
     bool span_aware_ = false;
-    bool exact_filters_ = false;
+    int filter_mode_ = 0;  // 0: by the filter contract, per filter; 1: reference order throughout; 2: time-parallel throughout
     detail::DeviceBuf a_, b_;
     bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
 };
@@ -1104,6 +1109,13 @@ public:
         float filter_q = 0.5f;
         std::uint32_t frames_per_lane = 0;    // 0 = the library's choice
         unsigned host_threads = 0;            // threads that pull the sources of a block (0 = min(cores, 16); 1 = the caller alone)
+        // THE FILTER CONTRACT (rodio_hip.h, rh_filter_scan_ok).  The fused kernel evaluates the filters time-parallel, which stays within
+        // 1e-5 of rodio's own f32 recurrence only where that recurrence does not amplify its rounding noise past it (low_pass >= 100 Hz,
+        // high_pass >= 600 Hz at 48 kHz, full-scale sources).  true (default): a source whose filter lies outside gets a chain of its own --
+        // amplify -> UniformSourceIterator -> the filter in rodio's operation order, bit for bit -- and enters the mix unfiltered, on the
+        // device: rodio's samples, at the price of per-source launches.  false: every filter stays in the fused kernel (closer to the
+        // exact response than rodio is; at low cutoffs further than 1e-5 from rodio).
+        bool reference_exact_filters = true;
     };
     /// mixer::mixer(channels, sample_rate) (mixer.rs:25).  The sources are mixed as stereo frames; `channels` other than 2 is what
     /// ChannelCountConverter makes of every source (channels.rs:57-85), applied ONCE, to the mixed block (the converter and the
@@ -1137,6 +1149,17 @@ public:
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         if (out_ch_ > 2 && ch > 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source of more than 2 channels into a mixer of more than 2 (the mix is formed in stereo)");
         if (filter.kind > 1) throw std::invalid_argument("filter kind");
+        if (filter.kind >= 0 && opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) {
+            // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
+            auto chain = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
+            chain->exact_filters(true);
+            if (gain != 1.0f) chain->amplify(gain);
+            chain->uniform(2, rate_);
+            if (filter.kind == 0) chain->low_pass_with_q(filter.freq, filter.q);
+            else chain->high_pass_with_q(filter.freq, filter.q);
+            add(std::move(chain), 1.0f, Filter::none());
+            return;
+        }
         Src item;
         item.up = std::move(src);
         item.gain = gain;

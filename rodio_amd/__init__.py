@@ -31,6 +31,7 @@ from .source import (  # noqa: F401
     limit_batch,
     biquad_coeffs,
     delay_samples,
+    filter_scan_ok,
     init,
     reverb_spatial_batch,
     spatial_gains,

@@ -160,6 +160,7 @@ SIGNATURES = {
     "rh_rlm_destroy": (i32, [vp]),
     "rh_rlm_set_sources": (i32, [vp, C.POINTER(vp), C.POINTER(u64), u32]),
     "rh_rlm_run": (i32, [vp, vp, u64, C.POINTER(u64), vp]),
+    "rh_filter_scan_ok": (i32, [i32, u32, f32, u32]),
     "rh_rlm_set_gains": (i32, [vp, f32p, u32]),
     "rh_rlm_set_filters": (i32, [vp, C.POINTER(i32), C.POINTER(u32), f32p, u32]),
     "rh_rlm_stream_keep_history": (i32, [vp, i32]),

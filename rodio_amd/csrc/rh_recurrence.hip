@@ -399,6 +399,30 @@ rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t sample
     return RH_OK;
 }
 
+// Where the time-parallel evaluation of a low_pass / high_pass stays within 1e-5 of rodio's OWN f32 recurrence for a full-scale source
+// (|x| <= 1).  The scan is the more accurate of the two (profiles/r04_filter_contract.txt: 400 000 frames of full-scale noise; its
+// distance from an f64 evaluation is 3e-8 .. 5e-6 where the reference's is 1e-7 .. 6e-3), so |scan - reference| IS the reference's
+// rounding noise -- the recurrence y = b0 x + b1 x1 + b2 x2 - a1 y1 - a2 y2 amplifies every rounding by 1 / A(z), i.e. by
+// ~1 / (1 - r)^2 for poles of radius r, and a high-pass (b = {1, -2, 1} / a0: full-size terms that cancel) feeds it 30 times more of
+// it than a low-pass (tiny b).  Measured, 44.1 / 48 / 96 kHz, q = 0.5:
+//     low_pass : 1 - r >= 0.0125 (100 Hz at 48 kHz, 200 Hz at 96 kHz): <= 7.4e-6;   below: 1.2e-5 (50 Hz) .. 4e-5 (10 Hz)
+//     high_pass: 1 - r >= 0.075  (600 Hz at 48 kHz)                   : <= 5e-6;     below: 8.6e-6 (500 Hz), 1.9e-5 (300), 3.3e-5 (200) .. 3e-3 (10)
+// The error scales with the signal's peak.  Outside the region a drop-in takes the reference-order kernel (rh_biquad mode 0, bit
+// for bit); include/rodio_hip.hpp does that on its own.
+int32_t rh_filter_scan_ok(int32_t kind, uint32_t freq, float q, uint32_t sample_rate) {
+    float c[5];
+    if (rh_biquad_coeffs(kind, freq, q, sample_rate, c) != RH_OK) return 0;
+    const double a1 = c[3], a2 = c[4], disc = a1 * a1 - 4.0 * a2;
+    double r;
+    if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        r = fmax(fabs((-a1 + sq) / 2.0), fabs((-a1 - sq) / 2.0));
+    } else {
+        r = sqrt(a2 > 0.0 ? a2 : 0.0);
+    }
+    return (1.0 - r) >= (kind == 0 ? 0.0125 : 0.075) ? 1 : 0;
+}
+
 }  // extern "C" (reopened below)
 namespace rh {
 rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uint32_t n_streams, const float k5[5], float *state, hipStream_t s);

@@ -487,6 +487,12 @@ def biquad_coeffs(kind, freq, q, fs) -> np.ndarray:
     return out
 
 
+def filter_scan_ok(kind, freq, q, fs) -> bool:
+    """The filter contract (rodio_hip.h, rh_filter_scan_ok): does the time-parallel evaluation of this low_pass / high_pass stay within
+    1e-5 of rodio's own f32 recurrence for a full-scale source?"""
+    return bool(lib.rh_filter_scan_ok(1 if kind in (1, "high_pass") else 0, int(freq), float(q), int(fs)))
+
+
 def delay_samples(ns, rate, ch) -> int:
     return int(lib.rh_delay_samples(ns, rate, ch))
 

@@ -586,3 +586,38 @@ def test_gpu_mixer_refuses_a_cut_frame_in_front_of_a_rate_conversion(tmp_path):
     (tmp_path / "spec.txt").write_text("6 44100 1.0\n")
     r = subprocess.run([EXE, "mixany", str(tmp_path), "1", "48000", "-1", "0", "6000", "4"], capture_output=True, text=True, timeout=300, env=dict(os.environ, RH_TEST_SOURCE="buffer"))
     assert r.returncode == 1 and "ends inside a frame" in r.stderr and "unsupported" in r.stderr.lower(), r.stderr
+
+
+
+@pytest.mark.gpu
+def test_gpu_source_low_cutoffs_run_in_the_reference_order(O, tmp_path):
+    """THE FILTER CONTRACT (rodio_hip.h): a full-scale source through high_pass(100) -- rodio's own recurrence is 8e-5 from the exact
+    response there, so nothing but rodio's operation order stays within 1e-5 of rodio: GpuSource takes it on its own (bit for bit),
+    and keeps the time-parallel kernel for low_pass(1000) behind it (inside the region: <= 1e-5)."""
+    x = rnd(9300, 2 * 120000, 1.0)
+    x.tofile(tmp_path / "src_0.f32")
+    got = _run(["chain", tmp_path, 2, 48000, 20000, "high_pass:100"], tmp_path)
+    ref = O.TestSource(x, 2, 48000).high_pass(100).collect()
+    assert np.array_equal(got, ref)
+    got2 = _run(["chain", tmp_path, 2, 48000, 20000, "high_pass:100", "low_pass:1000"], tmp_path)
+    ref2 = O.TestSource(x, 2, 48000).high_pass(100).low_pass(1000).collect()
+    assert len(got2) == len(ref2) and float(np.max(np.abs(got2 - ref2))) <= TOL
+
+
+@pytest.mark.gpu
+def test_gpu_mixer_low_cutoffs_run_in_the_reference_order(O, tmp_path):
+    """... and GpuMixer: full-scale sources with high_pass(100) / low_pass(40) get a chain of their own (amplify -> uniform -> the filter in
+    rodio's order) and enter the mix unfiltered, on the device; the source with low_pass(1000) stays in the fused kernel.  <= 1e-5 from
+    the oracle's Mixer at FULL SCALE -- which the fused kernel's time-parallel high_pass(100) is not (rodio itself is 8e-5 from exact)."""
+    ns = [60000, 45000, 60000, 30000]
+    specs = [
+        (rnd(9400, 2 * ns[0], 1.0), 2, 44100, 0.9, 1, 100, []),
+        (rnd(9401, 2 * ns[1], 1.0), 2, 48000, 1.0, 0, 40, []),
+        (rnd(9402, 2 * ns[2], 1.0), 2, 44100, 0.8, 0, 1000, []),
+        (rnd(9403, ns[3], 1.0), 1, 44100, 1.0, 1, 100, []),
+    ]
+    got, ref, st = _chainmix(O, tmp_path, specs, 2, 48000, 8192, True)
+    assert len(got) == len(ref)
+    e = float(np.max(np.abs(got - ref)))
+    assert e <= TOL, e
+    assert st["chains"] == 3 and st["chains_on_device"] == 3 and st["chain_d2h_samples"] == 0
