@@ -517,7 +517,7 @@ def test_gpu_source_chains_reach_the_mixer_on_the_device(O, tmp_path, on_device)
         (rnd(5200, 2 * ns[0], 0.5), 2, 44100, 0.8, 0, 200, ["reverb:21000000:0.3", "limit"]),
         (rnd(5201, 2 * ns[1], 0.4), 2, 44100, 1.0, 0, 200, ["amplify:1.5", "high_pass:300"]),
         (rnd(5202, 2 * ns[2], 0.1), 2, 44100, 0.7, 0, 200, []),  # a plain source beside them
-        (rnd(5203, 2 * ns[3], 0.9), 2, 48000, 0.5, 1, 300, ["limit"]),
+        (rnd(5203, 2 * ns[3], 0.9), 2, 48000, 0.5, 1, 1000, ["limit"]),  # (high_pass(1000): inside the filter contract, so the mixer's fused kernel takes it)
     ]
     got, ref, st = _chainmix(O, tmp_path, specs, 2, 48000, 8192, on_device)
     assert len(got) == len(ref)
