@@ -9,9 +9,12 @@
 //! * [`GpuSource<I>`] -- one upstream and a chain of adapters built with rodio's method names (`amplify`, `low_pass`, `reverb`,
 //!   `limit`, `automatic_gain_control`, `uniform`, ...), executed block-wise on the device; adapter memory is carried across
 //!   blocks, so any block size gives the samples of one pass.
-//! * [`GpuMixer`] -- `mixer::mixer(2, rate)` where every added source goes through `UniformSourceIterator::new(src.amplify(g), 2,
-//!   rate)` (`Mixer::add` wraps every source in one, `mixer.rs:58-66`) `[.low_pass(f)]` and the ordered sum: the fused kernel,
-//!   block by block.  Sources may be added while the mixer is playing (they join at the next frame, `mixer.rs:175-183`).
+//! * [`GpuMixer`] -- `mixer::mixer(channels, rate)` where every added source goes through `UniformSourceIterator::new(src.amplify(g),
+//!   .., rate)` (`Mixer::add` wraps every source in one, `mixer.rs:58-66`) and ITS OWN filter (`add_filtered`: rodio's sources carry
+//!   their adapters into the mixer) and the ordered sum: the fused kernel, block by block, one fused stream per (rate, filter).
+//!   Sources may be added while the mixer is playing (they join at the next frame, `mixer.rs:175-183`).  A [`GpuSource`] chain handed
+//!   over with `add_chain` keeps its blocks in device memory: the mixer takes them device-to-device.  `prepare()` starts the stream on
+//!   the calling (control) thread, a reaper thread frees what has ended: the consumer's `next()` neither starts nor tears down.
 //!
 //! Both pull their upstream the way `UniformSourceIterator` does (`src/source/uniform.rs:50-97`): `current_span_len()` is asked
 //! whenever the converter chain has run dry, `min(span, 32768)` samples go to a FRESH converter pair, and every span ends with
@@ -20,9 +23,9 @@
 //! There is no CPU compute path: every arithmetic operation on samples happens in the library.  One object is used from one
 //! thread at a time (`Send`, not `Sync`, like every rodio source).
 //!
-//! This is the Rust twin of `include/rodio_hip.hpp` (C++17, compiled and tested in the repository: `tests/test_host_mirror.py`);
-//! the image the library was developed in has no Rust toolchain, so this crate has been checked against the header
-//! (`tests/test_rust_decls.py`) but not against `rustc`.
+//! This is the Rust twin of `include/rodio_hip.hpp` (C++17, compiled and tested in the repository: `tests/test_host_mirror.py`),
+//! method for method (`tests/test_rust_decls.py` compares the two); the image the library was developed in has no Rust toolchain,
+//! so this crate has been checked against the header and against its twin but not against `rustc`.
 
 pub mod ffi;
 
@@ -30,7 +33,8 @@ use ffi::*;
 use rodio::source::SeekError;
 use rodio::{ChannelCount, SampleRate, Source};
 use std::ptr;
-use std::time::Duration;
+use std::sync::{mpsc, Arc, Mutex};
+use std::time::{Duration, Instant};
 
 // ------------------------------------------------------------------------------------------------ errors ----
 /// A library call that failed (`rh_status != RH_OK`).  `Iterator::next` cannot return it: the adapters panic with it, as rodio's own
@@ -75,6 +79,11 @@ impl DeviceBuf {
     }
 }
 impl Drop for DeviceBuf { fn drop(&mut self) { if !self.p.is_null() { unsafe { rh_free(self.p.cast()); } } } }
+// The buffers are plain owners of device / page-locked memory: moving one to another thread (a stage closure, the reaper) is fine,
+// and nothing mutates through a shared reference.  (Edition-2021 closures capture disjoint FIELDS: without these impls a closure
+// that names `buf.p` captures a bare `*mut f32`, which is not Send.)
+unsafe impl Send for DeviceBuf {}
+unsafe impl Sync for DeviceBuf {}
 struct PinnedBuf { p: *mut f32, n: usize }
 impl PinnedBuf {
     fn new() -> Self { PinnedBuf { p: ptr::null_mut(), n: 0 } }
@@ -92,6 +101,20 @@ impl PinnedBuf {
     fn slice_mut(&mut self, n: usize) -> &mut [f32] { unsafe { std::slice::from_raw_parts_mut(self.p, n) } }
 }
 impl Drop for PinnedBuf { fn drop(&mut self) { if !self.p.is_null() { unsafe { rh_host_free(self.p.cast()); } } } }
+unsafe impl Send for PinnedBuf {}
+unsafe impl Sync for PinnedBuf {}
+/// A HIP event (`rh_event_create`), destroyed with its owner.
+struct Event(*mut core::ffi::c_void);
+impl Event {
+    fn new() -> Self { let mut e = ptr::null_mut(); ck(unsafe { rh_event_create(&mut e) }, "rh_event_create"); Event(e) }
+}
+impl Drop for Event { fn drop(&mut self) { if !self.0.is_null() { unsafe { rh_event_destroy(self.0); } } } }
+unsafe impl Send for Event {}
+/// A raw pointer that may travel to a scoped pull thread (every thread gets rows of its own).
+#[derive(Clone, Copy)]
+struct SendPtr(*mut f32);
+unsafe impl Send for SendPtr {}
+unsafe impl Sync for SendPtr {}
 
 /// Bulk form of `next()`: what a block adapter pulls with.
 fn read_into(src: &mut dyn Source, dst: &mut [f32]) -> usize {
@@ -105,7 +128,12 @@ fn read_into(src: &mut dyn Source, dst: &mut [f32]) -> usize {
 // ------------------------------------------------------------------------------------------------ spans ----
 /// One run of samples pulled from a source inside ONE span of it.
 #[derive(Clone, Copy, Debug)]
-pub struct Piece { pub n: usize, pub opens: bool, pub closes: bool, pub ch: u16, pub rate: u32 }
+pub struct Piece {
+    pub n: usize,            // samples: whole frames of `ch` channels, and behind them `tail` samples of a frame the span's end cuts
+    pub opens: bool, pub closes: bool, pub ch: u16, pub rate: u32,
+    pub tail: usize,         // closes only: samples of a CUT last frame (uniform.rs:56: `.min(32768)` cuts frames of 3, 5, 6, 7 channels)
+    pub by_none: bool,       // closes only: the span ended because the source returned None, not because its samples were counted out
+}
 
 /// Pulls a source the way `UniformSourceIterator` does (`uniform.rs:50-97`): whenever its converter chain has run dry it asks
 /// `current_span_len()`, `channels()` and `sample_rate()` -- in that order, at exactly that position of the stream -- and admits
@@ -129,9 +157,10 @@ impl SpanReader {
         self.rate = up.sample_rate().get();
         if span == Some(0) { self.ended = true; return false; }                  // Take{n: 0}: the chain is empty, next() is None
         self.left = span.map(|s| s.min(32768)).unwrap_or(OPEN_ENDED);
-        // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels, and rodio
-        // then rotates the channels of every later span.  That is not reproduced: it is refused.
-        assert!(self.left == OPEN_ENDED || self.left % self.ch as usize == 0, "a span of {} samples cuts a frame of {} channels", self.left, self.ch);
+        // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels: the chain rodio
+        // builds for such a span ends inside a frame and the next one starts there -- every later span has its channels rotated.  The
+        // reader hands the cut frame's samples over with the span (`Piece::tail`) and goes on at the sample behind them, as rodio's
+        // source does; what the converters make of a cut frame is `UniformPlanner::add`'s business.
         self.open = true;
         self.fresh = true;
         true
@@ -142,12 +171,14 @@ impl SpanReader {
         let ch = self.ch as usize;
         let mut want = max_frames.saturating_mul(ch).min(self.left).min(dst.len());
         want -= want % ch;
+        if self.left != OPEN_ENDED && self.left - want < ch && self.left <= dst.len() { want = self.left; }   // the rest of the span is a cut frame: its samples belong to this span's chain
         let mut got = if want > 0 { read_into(up, &mut dst[..want]) } else { 0 };
         let none = got < want;                                                    // the source returned None inside the span
-        got -= got % ch;                                                          // sources end on frame boundaries (source/mod.rs:169-178)
         if self.left != OPEN_ENDED { self.left -= got; }
         let closes = none || self.left == 0;
-        let piece = Piece { n: got, opens: self.fresh, closes, ch: self.ch, rate: self.rate };
+        let tail = if closes { got % ch } else { 0 };                             // (what becomes of it is the planner's business: it knows the target format)
+        if !closes { got -= got % ch; }
+        let piece = Piece { n: got, opens: self.fresh, closes, ch: self.ch, rate: self.rate, tail, by_none: none };
         let produced = got != 0 || (closes && !self.fresh);                       // a span that had samples before ends here: its last frame is due
         if got != 0 { self.fresh = false; }
         if closes { self.open = false; }
@@ -198,8 +229,20 @@ impl UniformPlanner {
     }
     pub fn add(&mut self, p: &Piece, segs: &mut Vec<PlannedSeg>) {
         if p.opens { self.span_in = 0; self.span_m = 0; self.row_off = self.pos; self.row_frame0 = 0; }
-        self.span_in += (p.n / p.ch as usize) as u64;
+        self.span_in += ((p.n - p.tail) / p.ch as usize) as u64;
         self.pos += p.n;
+        if p.closes && p.tail > 0 {
+            // A frame the span's end cuts.  At the mixer's own rate the SampleRateConverter passes through (sample_rate.rs:133-136) and the
+            // ChannelCountConverter behind it emits, for the cut frame, the output channels its samples cover (channels.rs:57-85): a whole
+            // output frame when the cut frame holds at least min(from, to) samples -- one more frame for the segment, of which the kernel
+            // reads just those channels.  The next span starts at the sample behind the cut: its channels are rotated, as in rodio.
+            let nc = (p.ch as usize).min(self.to_ch as usize);
+            if p.rate == self.to_rate && p.tail >= nc { self.span_in += 1; }
+            else if !p.by_none {
+                panic!("{}", RhError { status: RH_ERR_UNSUPPORTED, what: "a span ends inside a frame of a source that is also rate-converted (or whose cut frame is shorter than an output frame): reproduced only at the mixer's own rate" });
+            }
+            // by_none with a short tail: the source ended inside a frame; its last samples are dropped (source/mod.rs:169-178)
+        }
         let ready = self.span_frames(self.span_in, p.rate, p.closes);
         if ready > self.span_m {
             let g = RhUniformSeg {
@@ -225,19 +268,27 @@ impl UniformPlanner {
 }
 
 // ------------------------------------------------------------------------------------------------ block pump ----
-struct Slot { stage: PinnedBuf, out: PinnedBuf, n: usize, last: bool, done: *mut core::ffi::c_void }
+/// Where the host's time went, and what crossed to the host (`detail::BlockPump::Timing` of rodio_hip.hpp).
+#[derive(Clone, Copy, Default, Debug)]
+pub struct Timing {
+    pub submit_s: f64, pub prefetch_s: f64, pub pull_s: f64, pub wait_s: f64, pub blocks: u64,
+    pub d2h_samples: u64,      // samples of processed blocks copied to the host (0 for a source that keeps its blocks on the device)
+    pub device_samples: u64,   // samples handed to a consumer device-to-device (`read_device`)
+    pub first_advance_s: f64,  // the advance that started the stream (`prepare()`, or the first `next()`)
+}
+struct Slot {
+    stage: PinnedBuf, out: PinnedBuf, n: usize, last: bool, done: Event,
+    dev: DeviceBuf, taken: Event, taken_pending: bool,   // keep_blocks_on_device(): the processed block on the device; recorded on the consumer's stream behind its copies
+}
 /// Two page-locked result blocks, one served while the other is in flight.
-struct Pump { slot: [Slot; 2], cur: usize, pos: usize, skip: usize, handed_out: u64, primed: bool, ended: bool, stream: RhStream }
+struct Pump { slot: [Slot; 2], cur: usize, pos: usize, skip: usize, handed_out: u64, primed: bool, ended: bool, stream: RhStream, device_out: bool, timing: Timing }
+unsafe impl Send for Pump {}
 impl Pump {
     fn new() -> Self {
         let mut stream: RhStream = ptr::null_mut();
         ck(unsafe { rh_stream_create(&mut stream) }, "rh_stream_create");
-        let mk = || {
-            let mut ev = ptr::null_mut();
-            ck(unsafe { rh_event_create(&mut ev) }, "rh_event_create");
-            Slot { stage: PinnedBuf::new(), out: PinnedBuf::new(), n: 0, last: false, done: ev }
-        };
-        Pump { slot: [mk(), mk()], cur: 0, pos: 0, skip: 0, handed_out: 0, primed: false, ended: false, stream }
+        let mk = || Slot { stage: PinnedBuf::new(), out: PinnedBuf::new(), n: 0, last: false, done: Event::new(), dev: DeviceBuf::new(), taken: Event::new(), taken_pending: false };
+        Pump { slot: [mk(), mk()], cur: 0, pos: 0, skip: 0, handed_out: 0, primed: false, ended: false, stream, device_out: false, timing: Timing::default() }
     }
     fn running(&self) -> bool { self.primed && !self.ended }
     fn other_in_flight(&self) -> bool { self.primed && !self.ended && !self.slot[self.cur].last }
@@ -253,7 +304,7 @@ impl Drop for Pump {
     fn drop(&mut self) {
         unsafe {
             rh_stream_synchronize(self.stream);
-            for s in &self.slot { rh_event_destroy(s.done); }
+            for s in &self.slot { if s.taken_pending { rh_event_synchronize(s.taken.0); } }   // a consumer's copy may still read the slot's device block
             rh_stream_destroy(self.stream);
         }
     }
@@ -265,34 +316,84 @@ trait BlockSource {
     fn enqueue(&mut self, i: usize);
     fn can_resume(&self) -> bool { false }
     fn block_done(&mut self) {}
+    /// The host-only part of the next enqueue() (pulling the upstreams into a staging block), called while the device still works on the
+    /// block about to be served.  Optional.
+    fn prefetch(&mut self) {}
     fn submit(&mut self, i: usize) {
+        let t0 = Instant::now();
         self.enqueue(i);
         let p = self.pump();
-        ck(unsafe { rh_event_record(p.slot[i].done, p.stream) }, "rh_event_record");
+        ck(unsafe { rh_event_record(p.slot[i].done.0, p.stream) }, "rh_event_record");
+        p.timing.submit_s += t0.elapsed().as_secs_f64();
+        p.timing.blocks += 1;
     }
     fn advance(&mut self) -> bool {
         if self.pump().ended {
             if !self.can_resume() { return false; }
             let p = self.pump(); p.ended = false; p.primed = false;
         }
-        if !self.pump().primed {
+        let starting = !self.pump().primed;
+        let ta = Instant::now();
+        if starting {
             self.submit(0);
             let p = self.pump(); p.primed = true; p.cur = 0;
         } else {
             let p = self.pump();
             if p.slot[p.cur].last { p.ended = true; return false; }
             p.cur ^= 1;                                                            // the block that was enqueued while the previous one was being served
+            if !p.slot[p.cur].last {
+                let t0 = Instant::now();
+                self.prefetch();
+                self.pump().timing.prefetch_s += t0.elapsed().as_secs_f64();
+            }
         }
         let cur = self.pump().cur;
-        ck(unsafe { rh_event_synchronize(self.pump().slot[cur].done) }, "rh_event_synchronize");
-        self.block_done();
+        if !self.pump().device_out {   // (a device-resident consumer orders its copies behind the block's event on ITS stream: the host does not wait)
+            let t0 = Instant::now();
+            ck(unsafe { rh_event_synchronize(self.pump().slot[cur].done.0) }, "rh_event_synchronize");
+            self.pump().timing.wait_s += t0.elapsed().as_secs_f64();
+            self.block_done();
+        }
         let p = self.pump();
         p.pos = p.skip.min(p.slot[cur].n);
         p.skip = 0;
         if !p.slot[cur].last { self.submit(cur ^ 1); }                            // prefetch: pull and process one block ahead
+        if starting { self.pump().timing.first_advance_s = ta.elapsed().as_secs_f64(); }
         true
     }
+    /// Everything a first `next()` would do before it can serve a sample -- start the stream (plans, page-locked blocks, device rows),
+    /// pull and process the first block, put the second one in flight -- done NOW, on the calling thread.  rodio builds its sources on
+    /// a control thread and hands them to the audio callback (`src/stream.rs:538-545`), where `next()` is expected not to block.
+    fn prepare_stream(&mut self) {
+        let p = self.pump();
+        if !p.primed && !p.ended { self.advance(); }
+    }
+    /// Up to `n` samples of the stream into DEVICE memory `ddst`, enqueued on `consumer` (a stream of the caller's); the count, less
+    /// than `n` at the end of the stream.  Needs `device_out` (`keep_blocks_on_device`).
+    fn read_device_impl(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize {
+        assert!(self.pump().device_out, "read_device() needs keep_blocks_on_device()");
+        let mut k = 0;
+        while k < n {
+            { let p = self.pump(); if p.pos == p.slot[p.cur].n && !self.advance() { break; } }
+            let p = self.pump();
+            let cur = p.cur;
+            let take = (n - k).min(p.slot[cur].n - p.pos);
+            unsafe {
+                ck(rh_stream_wait_event(consumer, p.slot[cur].done.0), "rh_stream_wait_event");   // the block is complete when its event fires: the consumer's STREAM waits for it
+                ck(rh_memcpy_d2d(ddst.add(k).cast(), p.slot[cur].dev.p.add(p.pos).cast(), take * 4, consumer), "rh_memcpy_d2d");
+                ck(rh_event_record(p.slot[cur].taken.0, consumer), "rh_event_record");            // ... and the producer rewrites the slot's block only behind this copy
+            }
+            p.slot[cur].taken_pending = true;
+            p.pos += take;
+            k += take;
+        }
+        let p = self.pump();
+        p.handed_out += k as u64;
+        p.timing.device_samples += k as u64;
+        k
+    }
     fn next_sample(&mut self) -> Option<f32> {
+        assert!(!self.pump().device_out, "this source keeps its blocks on the device: read_device()");
         loop {
             let p = self.pump();
             if p.pos < p.slot[p.cur].n {
@@ -319,11 +420,14 @@ impl<T> Drop for Handle<T> { fn drop(&mut self) { if !self.p.is_null() { unsafe 
 unsafe impl<T> Send for Handle<T> {}
 struct State(DeviceBuf);
 unsafe impl Send for State {}
+unsafe impl Sync for State {}   // (shared through Arc by a stage and its on_seek: both run on the thread that owns the chain)
+unsafe impl<T> Sync for Handle<T> {}
 
 /// `upstream.amplify(..).low_pass(..)...` with the chain executed block-wise on the GPU.
 pub struct GpuSource<I: Source> {
     up: I, block_frames: usize, ch: u16, rate: u32, in_ch: u16, in_rate: u32,
-    stages: Vec<Stage>, reader: SpanReader, pieces: Vec<Piece>, span_aware: bool, exact_filters: bool, scan_kernels: bool,
+    stages: Vec<Stage>, reader: SpanReader, pieces: Vec<Piece>, span_aware: bool, scan_kernels: bool,
+    filter_mode: u8,   // 0: by the filter contract, per filter (rh_filter_scan_ok); 1: reference order throughout; 2: time-parallel throughout
     a: DeviceBuf, b: DeviceBuf, pump: Pump,
 }
 unsafe impl<I: Source + Send> Send for GpuSource<I> {}
@@ -332,7 +436,7 @@ impl<I: Source> GpuSource<I> {
     pub fn new(upstream: I, block_frames: usize) -> Self {
         let (ch, rate) = (upstream.channels().get(), upstream.sample_rate().get());
         GpuSource { up: upstream, block_frames: block_frames.max(1), ch, rate, in_ch: ch, in_rate: rate, stages: Vec::new(), reader: SpanReader::new(),
-                    pieces: Vec::new(), span_aware: false, exact_filters: false, scan_kernels: false, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new() }
+                    pieces: Vec::new(), span_aware: false, scan_kernels: false, filter_mode: 0, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new() }
     }
     pub fn inner(&self) -> &I { &self.up }
     pub fn inner_mut(&mut self) -> &mut I { &mut self.up }
@@ -358,9 +462,26 @@ impl<I: Source> GpuSource<I> {
         self.push(move |c| { ck(unsafe { rh_distortion(c.out, c.inp, c.n, gain, threshold, c.stream) }, "rh_distortion"); c.n }, |n, _| n, 0);
         self
     }
-    /// The filters run time-parallel (rh_biquad mode 1: <= 1e-5 from rodio's f32 recurrence); `exact_filters(true)`: the reference's
-    /// operation order throughout, bit for bit.
-    pub fn exact_filters(mut self, on: bool) -> Self { self.exact_filters = on; self }
+    /// How the filters of this chain run.  By default every filter decides for itself by THE FILTER CONTRACT (`rodio_hip.h`,
+    /// `rh_filter_scan_ok`): time-parallel (`rh_biquad` mode 1) where that stays within 1e-5 of rodio's own f32 recurrence for a
+    /// full-scale source, the reference's operation order (mode 0, bit for bit) where it would not -- low cutoffs, where rodio's
+    /// recurrence amplifies its own rounding noise past 1e-5.  `exact_filters(true)`: the reference's order throughout;
+    /// `exact_filters(false)`: time-parallel throughout (closer to the exact response than rodio is, further than 1e-5 from rodio at
+    /// low cutoffs).
+    pub fn exact_filters(mut self, on: bool) -> Self { self.filter_mode = if on { 1 } else { 2 }; self }
+    /// See [`GpuMixer::prepare`]: the stream is started on the calling thread, the consumer's first `next()` finds its block waiting.
+    pub fn prepare(&mut self) { self.prepare_stream(); }
+    /// Device-resident hand-off (`GpuMixer::add_chain`): the blocks stay in device memory, a consumer takes them with `read_device`.
+    /// Before the first block; `next()` is then not available.
+    pub fn keep_blocks_on_device(&mut self, on: bool) {
+        assert!(!self.pump.primed, "keep_blocks_on_device() after the stream has started");
+        self.pump.device_out = on;
+    }
+    pub fn blocks_on_device(&self) -> bool { self.pump.device_out }
+    pub fn started(&self) -> bool { self.pump.primed }
+    pub fn timing(&self) -> Timing { self.pump.timing }
+    /// Up to `n` samples of the chain's output into DEVICE memory, enqueued on `consumer`: see `detail::BlockPump::read_device`.
+    pub fn read_device(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize { self.read_device_impl(ddst, n, consumer) }
     pub fn low_pass(self, freq: u32) -> Self { self.blt(0, freq, 0.5) }          // blt.rs:11-16
     pub fn high_pass(self, freq: u32) -> Self { self.blt(1, freq, 0.5) }         // blt.rs:18-24
     pub fn low_pass_with_q(self, freq: u32, q: f32) -> Self { self.blt(0, freq, q) }
@@ -370,7 +491,8 @@ impl<I: Source> GpuSource<I> {
         let mut co = [0f32; 5];
         ck(unsafe { rh_biquad_coeffs(kind, freq, q, self.rate, co.as_mut_ptr()) }, "rh_biquad_coeffs");
         let st = self.state(4 * ch as usize);
-        let (st2, sm, mode) = (st.clone(), self.pump.stream as usize, if self.exact_filters { 0 } else { 1 });
+        let exact = self.filter_mode == 1 || (self.filter_mode == 0 && unsafe { rh_filter_scan_ok(kind, freq, q, self.rate) } == 0);   // the filter contract (rodio_hip.h)
+        let (st2, sm, mode) = (st.clone(), self.pump.stream as usize, if exact { 0 } else { 1 });
         let stage = self.push(move |c| {
             let frames = c.n / ch as usize;
             ck(unsafe { rh_biquad(c.out, c.inp, frames as u64, ch, 1, co.as_ptr(), st.0.p, mode, c.stream) }, "rh_biquad");
@@ -385,6 +507,7 @@ impl<I: Source> GpuSource<I> {
         ck(unsafe { rh_echo_create(&mut e, d, amplitude) }, "rh_echo_create");
         let h = Handle { p: e, destroy: rh_echo_destroy };
         let stage = self.push(move |c| {
+            let h = &h;   // (the whole handle moves into the closure -- it is Send and dropped with the stage -- not just its raw pointer field)
             if c.n > 0 { ck(unsafe { rh_echo_process(h.p, c.out, c.inp, c.n as u64, c.stream) }, "rh_echo_process"); }
             if !c.flush { return c.n; }
             if d > 0 { ck(unsafe { rh_echo_flush(h.p, c.out.add(c.n), c.stream) }, "rh_echo_flush"); }                 // the delayed clone outlives the source
@@ -404,6 +527,24 @@ impl<I: Source> GpuSource<I> {
         self.ch = out_ch as u16;
         self
     }
+    /// `Spatial` (spatial.rs:19-24,48-69): the two ear gains from the positions, then `ChannelVolume`.
+    pub fn spatial(self, emitter: [f32; 3], left_ear: [f32; 3], right_ear: [f32; 3]) -> Self {
+        let mut g = [0f32; 2];
+        ck(unsafe { rh_spatial_gains(emitter.as_ptr(), left_ear.as_ptr(), right_ear.as_ptr(), g.as_mut_ptr()) }, "rh_spatial_gains");
+        self.channel_volume(vec![g[0], g[1]])
+    }
+    /// `dither(target_bits, algorithm)` (dither.rs:217-242); algorithm in the reference's enum order: 0 GPDF, 1 HighPass, 2 RPDF, 3 TPDF (the
+    /// default).  The noise of sample k is a function of (seed, k) -- see `rh_dither` in rodio_hip.h.
+    pub fn dither(mut self, target_bits: u32, algorithm: i32, seed: u64) -> Self {
+        let ch = self.ch as u32;
+        let mut pos = 0u64;
+        self.push(move |c| {
+            ck(unsafe { rh_dither(c.out, c.inp, c.n, pos, ch, target_bits, algorithm, seed, c.stream) }, "rh_dither");
+            pos += c.n as u64;
+            c.n
+        }, |n, _| n, 0);
+        self
+    }
     pub fn convert_channels(mut self, to: ChannelCount) -> Self {                 // ChannelCountConverter, channels.rs:57-85
         let (from, to) = (self.ch as usize, to.get() as usize);
         self.push(move |c| {
@@ -421,6 +562,7 @@ impl<I: Source> GpuSource<I> {
         ck(unsafe { rh_resampler_create(&mut r, from, to, ch as u32) }, "rh_resampler_create");
         let h = Handle { p: r, destroy: rh_resampler_destroy };
         self.push(move |c| {
+            let h = &h;   // (whole-struct capture: see reverb)
             let mut m = 0u64;
             ck(unsafe { rh_resampler_process(h.p, c.out, (c.out_cap / ch) as u64, c.inp, (c.n / ch) as u64, c.flush as i32, &mut m, c.stream) }, "rh_resampler_process");
             m as usize * ch
@@ -445,6 +587,7 @@ impl<I: Source> GpuSource<I> {
         let plan2 = plan.clone();
         let (mut win, mut keep) = (State(DeviceBuf::new()), State(DeviceBuf::new()));
         let stage = self.push(move |c| {
+            let (win, keep) = (&mut win, &mut keep);   // (whole-struct capture)
             let mut plan = plan.lock().unwrap();
             plan.begin_block();
             let hs = plan.held_samples();
@@ -497,7 +640,7 @@ impl<I: Source> GpuSource<I> {
         d.reserve(unsafe { rh_agc_state_floats() });
         ck(unsafe { rh_agc_state_init(d.p, 1, self.pump.stream) }, "rh_agc_state_init");
         let st = State(d);
-        self.push(move |c| { ck(unsafe { rh_agc(c.out, c.inp, c.n as u64, rate, 1, &settings, st.0.p, c.stream) }, "rh_agc"); c.n }, |n, _| n, 0);
+        self.push(move |c| { let st = &st; ck(unsafe { rh_agc(c.out, c.inp, c.n as u64, rate, 1, &settings, st.0.p, c.stream) }, "rh_agc"); c.n }, |n, _| n, 0);
         self
     }
     pub fn linear_gain_ramp(mut self, duration: Duration, start_gain: f32, end_gain: f32, clamp_end: bool) -> Self {   // linear_ramp.rs:79-110
@@ -588,7 +731,6 @@ impl<I: Source> BlockSource for GpuSource<I> {
         cap = ((cap + 3) & !3) + 64;
         self.a.reserve(cap);
         self.b.reserve(cap);
-        self.pump.slot[i].out.reserve(cap);
         let (mut cur, mut oth) = (self.a.p, self.b.p);
         let stream = self.pump.stream;
         if n > 0 { ck(unsafe { rh_memcpy_h2d(cur.cast(), self.pump.slot[i].stage.p.cast(), n * 4, stream) }, "rh_memcpy_h2d"); }
@@ -599,10 +741,38 @@ impl<I: Source> BlockSource for GpuSource<I> {
             ends = ends || c.end;
             std::mem::swap(&mut cur, &mut oth);
         }
-        if n > 0 { ck(unsafe { rh_memcpy_d2h_async(self.pump.slot[i].out.p.cast(), cur.cast(), n * 4, stream) }, "rh_memcpy_d2h_async"); }
+        if self.pump.device_out {   // the block stays on the device, in the slot's own buffer (a / b belong to the next block's stages)
+            let sl = &mut self.pump.slot[i];
+            sl.dev.reserve(cap);
+            if sl.taken_pending { ck(unsafe { rh_stream_wait_event(stream, sl.taken.0) }, "rh_stream_wait_event"); sl.taken_pending = false; }   // the consumer's copies out of this slot's previous block
+            if n > 0 { ck(unsafe { rh_memcpy_d2d(sl.dev.p.cast(), cur.cast(), n * 4, stream) }, "rh_memcpy_d2d"); }
+        } else if n > 0 {
+            self.pump.slot[i].out.reserve(cap);
+            ck(unsafe { rh_memcpy_d2h_async(self.pump.slot[i].out.p.cast(), cur.cast(), n * 4, stream) }, "rh_memcpy_d2h_async");
+            self.pump.timing.d2h_samples += n as u64;
+        }
         self.pump.slot[i].n = n;
         self.pump.slot[i].last = ends;
     }
+}
+/// A chain the mixer may take on the device (`GpuMixer::add_chain`): a `Source` that can also hand its blocks over device-to-device.
+pub trait DeviceChain: Send {
+    fn as_source(&mut self) -> &mut dyn Source;
+    fn as_source_ref(&self) -> &dyn Source;
+    fn keep_blocks_on_device(&mut self, on: bool);
+    fn blocks_on_device(&self) -> bool;
+    fn started(&self) -> bool;
+    fn read_device(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize;
+    fn timing(&self) -> Timing;
+}
+impl<I: Source + Send> DeviceChain for GpuSource<I> {
+    fn as_source(&mut self) -> &mut dyn Source { self }
+    fn as_source_ref(&self) -> &dyn Source { self }
+    fn keep_blocks_on_device(&mut self, on: bool) { GpuSource::keep_blocks_on_device(self, on) }
+    fn blocks_on_device(&self) -> bool { GpuSource::blocks_on_device(self) }
+    fn started(&self) -> bool { GpuSource::started(self) }
+    fn read_device(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize { GpuSource::read_device(self, ddst, n, consumer) }
+    fn timing(&self) -> Timing { GpuSource::timing(self) }
 }
 impl<I: Source> Iterator for GpuSource<I> {
     type Item = f32;
@@ -628,38 +798,102 @@ impl<I: Source> Source for GpuSource<I> {
 }
 
 // ------------------------------------------------------------------------------------------------ GpuMixer ----
+/// The filter a source carries into the mixer: `mixer.add(UniformSourceIterator::new(src, ch, rate).low_pass(200))` for one,
+/// `.high_pass(300)` for the next, none for a third (source/mod.rs:686-721: every source has its own adapters).
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub struct MixerFilter {
+    pub kind: i32,    // -1 none, 0 low_pass, 1 high_pass
+    pub freq: u32,
+    pub q: f32,       // rodio's low_pass() / high_pass() use 0.5 (blt.rs:11-24)
+}
+impl MixerFilter {
+    pub fn none() -> Self { MixerFilter { kind: -1, freq: 0, q: 0.5 } }
+    pub fn low_pass(freq: u32) -> Self { MixerFilter { kind: 0, freq, q: 0.5 } }
+    pub fn high_pass(freq: u32) -> Self { MixerFilter { kind: 1, freq, q: 0.5 } }
+    fn same(&self, o: &MixerFilter) -> bool { self.kind == o.kind && (self.kind < 0 || (self.freq == o.freq && self.q == o.q)) }
+}
+
 #[derive(Clone, Copy)]
 pub struct MixerOptions {
     pub block_frames: usize,         // frames pulled per source and block
-    pub filter_kind: i32,            // -1 none, 0 low_pass, 1 high_pass (q = 0.5, blt.rs:11-24)
+    pub filter_kind: i32,            // the filter of sources added WITHOUT one of their own: -1 none, 0 low_pass, 1 high_pass (q = 0.5, blt.rs:11-24)
     pub filter_freq: u32,
     pub filter_q: f32,
     pub frames_per_lane: u32,        // 0 = the library's choice
+    pub host_threads: u32,           // threads that pull the sources of a block (0 = min(cores, 16); 1 = the caller alone)
+    /// THE FILTER CONTRACT (`rodio_hip.h`, `rh_filter_scan_ok`).  true (default): a source whose filter lies outside the region in which the
+    /// fused kernel's time-parallel filter stays within 1e-5 of rodio's own recurrence gets a chain of its own -- amplify ->
+    /// UniformSourceIterator -> the filter in rodio's operation order, bit for bit -- and enters the mix unfiltered, on the device.
+    pub reference_exact_filters: bool,
 }
-impl Default for MixerOptions { fn default() -> Self { MixerOptions { block_frames: 1 << 15, filter_kind: -1, filter_freq: 0, filter_q: 0.5, frames_per_lane: 0 } } }
+impl Default for MixerOptions {
+    fn default() -> Self { MixerOptions { block_frames: 1 << 15, filter_kind: -1, filter_freq: 0, filter_q: 0.5, frames_per_lane: 0, host_threads: 0, reference_exact_filters: true } }
+}
 
+/// What became of the `GpuSource` chains handed to `add_chain`: how many there were, how many delivered their blocks on the device, the
+/// samples of chain output that crossed to the host (0 when every chain stayed on the device) / went device-to-device.
+#[derive(Clone, Copy, Default, Debug)]
+pub struct ChainStats { pub chains: u64, pub on_device: u64, pub d2h_samples: u64, pub device_samples: u64 }
+
+enum Upstream { Host(Box<dyn Source + Send>), Chain(Box<dyn DeviceChain>) }
+impl Upstream {
+    fn src(&mut self) -> &mut dyn Source { match self { Upstream::Host(s) => s.as_mut(), Upstream::Chain(c) => c.as_source() } }
+    fn src_ref(&self) -> &dyn Source { match self { Upstream::Host(s) => s.as_ref(), Upstream::Chain(c) => c.as_source_ref() } }
+    fn on_device(&self) -> bool { matches!(self, Upstream::Chain(c) if c.blocks_on_device()) }
+}
 struct Src {
-    up: Box<dyn Source + Send>, gain: f32, held: Vec<f32>, ended: bool, ch: u16,
+    up: Upstream, gain: f32, filt: MixerFilter, held: Vec<f32>, ended: bool, ch: u16,
+    dheld: u64, dheld_off: u64,                                                  // a device chain: frames the converter has not consumed, in the row of the block before
     reader: SpanReader, plan: UniformPlanner, have: u64, off: u64,               // span-by-span generations
+}
+unsafe impl Send for Src {}
+fn count_chain(x: &Src, st: &mut ChainStats) {
+    if let Upstream::Chain(c) = &x.up {
+        st.chains += 1;
+        st.on_device += c.blocks_on_device() as u64;
+        st.d2h_samples += c.timing().d2h_samples;
+        st.device_samples += c.timing().device_samples;
+    }
 }
 /// Sources that joined together: one clock, one fused stream.
 struct Gen {
-    srcs: Vec<Src>, plan: *mut RhRlm, din: DeviceBuf, q: [DeviceBuf; 2], stage: [PinnedBuf; 2], side: [PinnedBuf; 2], dside: DeviceBuf,
+    srcs: Vec<Src>, plan: *mut RhRlm, filt: MixerFilter,
+    din: [DeviceBuf; 3], dnext: usize, pd: usize, pd_prev: Option<usize>,          // staged input rows, THREE sets in rotation: a block's rows stay untouched until the block after it has run
+    q: [DeviceBuf; 2], stage: [PinnedBuf; 2], side: [PinnedBuf; 2], dside: [DeviceBuf; 2], copied: [Event; 2],
     cur: usize, slot: usize, head: u64, fill: u64, done: bool,
+    // the host half of a block that has been pulled and not yet issued (pull_block / issue_block)
+    pulled: bool, pslot: usize, pptrs: Vec<*const f32>, pavail: Vec<u64>, pended: Vec<u8>, pside_off: Vec<usize>, pside: usize, ptable: Vec<RhUniformSeg>, pmax_out: u64,
     mono: bool, qm: DeviceBuf,                                                       // a fused stream of mono sources (channels = 1): the mono mix, made stereo once per block
     staged: bool, target: u64, crow: u64, conv: [DeviceBuf; 2], dtab: DeviceBuf, tab: [PinnedBuf; 2], ccur: usize,
 }
+unsafe impl Send for Gen {}   // (retired generations are freed by the reaper thread)
 impl Gen {
     fn queue(&self) -> *const f32 { unsafe { self.q[self.cur].p.add(self.head as usize * 2) } }
     fn queue_end(&self) -> *mut f32 { unsafe { self.q[self.cur].p.add((self.head + self.fill) as usize * 2) } }
 }
+impl Drop for Gen { fn drop(&mut self) { if !self.plan.is_null() { unsafe { rh_rlm_destroy(self.plan); } } } }
 
-/// What rodio spells `let (mixer, mixed) = mixer::mixer(nz!(2), rate); mixer.add(src.amplify(g)) ...` (every added source goes
-/// through `UniformSourceIterator::new(.., 2, rate)`, optionally `.low_pass(f)` / `.high_pass(f)`) as ONE source.
+/// Frees retired generations (plans, page-locked blocks, device rows) on a thread of its own: the consumer's `next()` -- the audio
+/// callback -- only hands them over.
+struct Reaper { tx: Option<mpsc::Sender<Vec<Gen>>>, th: Option<std::thread::JoinHandle<()>> }
+impl Reaper {
+    fn new() -> Self {
+        let (tx, rx) = mpsc::channel::<Vec<Gen>>();
+        let th = std::thread::spawn(move || { for dead in rx { drop(dead); } });   // the destructors: rh_rlm_destroy, rh_host_free, rh_free
+        Reaper { tx: Some(tx), th: Some(th) }
+    }
+    fn retire(&self, g: Vec<Gen>) { let _ = self.tx.as_ref().unwrap().send(g); }
+}
+impl Drop for Reaper { fn drop(&mut self) { self.tx.take(); if let Some(t) = self.th.take() { let _ = t.join(); } } }
+
+/// What rodio spells `let (mixer, mixed) = mixer::mixer(channels, rate); mixer.add(src.amplify(g)) ...` (every added source goes
+/// through `UniformSourceIterator::new(.., rate)`, optionally `.low_pass(f)` / `.high_pass(f)` of its own) as ONE source.
 pub struct GpuMixer {
-    rate: u32, opt: MixerOptions, pending: Vec<Src>, gens: Vec<Gen>,
+    rate: u32, out_ch: u16, opt: MixerOptions, pending: Vec<Src>, gens: Vec<Gen>,
     cap_frames: usize, row: usize, out_cap_frames: u64, scheduled: u64, last_join: u64,
-    dmix: DeviceBuf, dkeep: [DeviceBuf; 2], slot_base: [u64; 2], slot_frames: [u64; 2], calls: u64, resume_ok: bool,
+    dmix: DeviceBuf, dout: DeviceBuf, dkeep: [DeviceBuf; 2], slot_base: [u64; 2], slot_frames: [u64; 2], calls: u64, resume_ok: bool,
+    copy_stream: RhStream,              // host-to-device copies of the staged rows: the link stays busy while the pump's stream runs the block before
+    device_chains: bool, retired_chains: ChainStats, reaper: Option<Reaper>,
     pump: Pump,
 }
 unsafe impl Send for GpuMixer {}
@@ -672,54 +906,121 @@ fn fused_ratio_unsupported(from: u32, to: u32) -> bool {                        
 }
 
 impl GpuMixer {
-    pub fn new(sample_rate: SampleRate, opt: MixerOptions) -> Self {
+    /// `mixer::mixer(2, sample_rate)`.
+    pub fn new(sample_rate: SampleRate, opt: MixerOptions) -> Self { Self::with_channels(ChannelCount::new(2).unwrap(), sample_rate, opt) }
+    /// `mixer::mixer(channels, sample_rate)` (mixer.rs:25).  The sources are mixed as stereo frames; `channels` other than 2 is what
+    /// ChannelCountConverter makes of every source (channels.rs:57-85), applied ONCE, to the mixed block (the converter and the sum
+    /// commute: 1 keeps channel 0, more than 2 appends silent channels -- for that, sources must not have more than 2 channels).
+    pub fn with_channels(channels: ChannelCount, sample_rate: SampleRate, opt: MixerOptions) -> Self {
         let mut opt = opt;
         opt.block_frames = opt.block_frames.max(1);
-        GpuMixer { rate: sample_rate.get(), opt, pending: Vec::new(), gens: Vec::new(), cap_frames: 0, row: 0, out_cap_frames: 0, scheduled: 0, last_join: 0,
-                   dmix: DeviceBuf::new(), dkeep: [DeviceBuf::new(), DeviceBuf::new()], slot_base: [0; 2], slot_frames: [0; 2], calls: 0, resume_ok: true, pump: Pump::new() }
+        let mut copy_stream: RhStream = ptr::null_mut();
+        ck(unsafe { rh_stream_create(&mut copy_stream) }, "rh_stream_create");
+        GpuMixer { rate: sample_rate.get(), out_ch: channels.get(), opt, pending: Vec::new(), gens: Vec::new(), cap_frames: 0, row: 0, out_cap_frames: 0, scheduled: 0, last_join: 0,
+                   dmix: DeviceBuf::new(), dout: DeviceBuf::new(), dkeep: [DeviceBuf::new(), DeviceBuf::new()], slot_base: [0; 2], slot_frames: [0; 2], calls: 0, resume_ok: true,
+                   copy_stream, device_chains: false, retired_chains: ChainStats::default(), reaper: None, pump: Pump::new() }
     }
+    fn default_filter(&self) -> MixerFilter { MixerFilter { kind: self.opt.filter_kind, freq: self.opt.filter_freq, q: self.opt.filter_q } }
     /// `Mixer::add` (mixer.rs:58-66), with the source's volume (`mixer.add(src.amplify(gain))`).  May be called at any time.
-    pub fn add(&mut self, src: Box<dyn Source + Send>, gain: f32) {
+    pub fn add(&mut self, src: Box<dyn Source + Send>, gain: f32) { let f = self.default_filter(); self.add_filtered(src, gain, f); }
+    /// ... with the source's own filter (behind its UniformSourceIterator, at the mixer's rate).  Sources of one filter share a fused
+    /// stream -- one launch per block for all of them, summed first while they run together -- and the streams' mixes are added.
+    pub fn add_filtered(&mut self, src: Box<dyn Source + Send>, gain: f32, filter: MixerFilter) {
         let ch = src.channels().get();
-        let item = Src { up: src, gain, held: Vec::new(), ended: false, ch, reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have: 0, off: 0 };
+        assert!(!(self.out_ch > 2 && ch > 2), "GpuMixer: a source of more than 2 channels into a mixer of more than 2 (the mix is formed in stereo)");
+        assert!(filter.kind <= 1, "filter kind");
+        if filter.kind >= 0 && self.opt.reference_exact_filters && unsafe { rh_filter_scan_ok(filter.kind, filter.freq, filter.q, self.rate) } == 0 {
+            // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
+            let mut chain = GpuSource::new(src, self.opt.block_frames).exact_filters(true);
+            if gain != 1.0 { chain = chain.amplify(gain); }
+            chain = chain.uniform(ChannelCount::new(2).unwrap(), SampleRate::new(self.rate).unwrap());
+            chain = if filter.kind == 0 { chain.low_pass_with_q(filter.freq, filter.q) } else { chain.high_pass_with_q(filter.freq, filter.q) };
+            self.add_chain_filtered(Box::new(chain), 1.0, MixerFilter::none());
+            return;
+        }
+        let item = Src { up: Upstream::Host(src), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have: 0, off: 0 };
         if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
+    }
+    /// A `GpuSource` chain handed to the mixer by value, as rodio's adapters are (`mixer.add(src.reverb(..).limit(..))`, amplify.rs:19-22,
+    /// mixer.rs:58-72): its blocks stay in device memory and the mixer takes them device-to-device -- the chain's output never crosses
+    /// to the host and back.  (A chain that is not stereo at a rate the fused converter takes, or one that has already started, is
+    /// pulled like any other source: the same samples, through the host.)
+    pub fn add_chain(&mut self, chain: Box<dyn DeviceChain>, gain: f32) { let f = self.default_filter(); self.add_chain_filtered(chain, gain, f); }
+    pub fn add_chain_filtered(&mut self, mut chain: Box<dyn DeviceChain>, gain: f32, filter: MixerFilter) {
+        let (ch, rate) = (chain.as_source_ref().channels().get(), chain.as_source_ref().sample_rate().get());
+        let on_device = ch == 2 && !chain.started() && !fused_ratio_unsupported(rate, self.rate);
+        if on_device { chain.keep_blocks_on_device(true); self.device_chains = true; }
+        let item = Src { up: Upstream::Chain(chain), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have: 0, off: 0 };
+        if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
+    }
+    /// Everything a first `next()` would do before it can serve a sample, done NOW on the calling thread (see `BlockSource::prepare_stream`):
+    /// call it on the control thread before the mixer goes to the audio callback.
+    pub fn prepare(&mut self) { self.prepare_stream(); }
+    pub fn timing(&self) -> Timing { self.pump.timing }
+    pub fn chain_stats(&self) -> ChainStats {
+        let mut st = self.retired_chains;
+        for g in &self.gens { for x in &g.srcs { count_chain(x, &mut st); } }
+        for x in &self.pending { count_chain(x, &mut st); }
+        st
     }
     /// Output frame (of this mixer) at which the most recently started generation joined.
     pub fn last_join_frame(&self) -> u64 { self.last_join }
+    /// Threads that pull a block's sources.
+    pub fn pull_threads(&self) -> u32 {
+        if self.opt.host_threads != 0 { self.opt.host_threads } else { (std::thread::available_parallelism().map(|n| n.get()).unwrap_or(1) as u32).min(16) }
+    }
 
     fn make_direct(&self, x: &mut Src) {
         // A continuous source the fused kernel cannot take as it is (rate ratio above 4.5) gets the GPU converter adapter in front.
-        if !fused_ratio_unsupported(x.up.sample_rate().get(), self.rate) { return; }
-        let up = std::mem::replace(&mut x.up, Box::new(rodio::source::Empty::new()));
+        if x.up.on_device() || !fused_ratio_unsupported(x.up.src_ref().sample_rate().get(), self.rate) { return; }
+        let up = match std::mem::replace(&mut x.up, Upstream::Host(Box::new(rodio::source::Empty::new()))) {
+            Upstream::Host(s) => s,
+            Upstream::Chain(c) => Box::new(ChainAsSource(c)) as Box<dyn Source + Send>,
+        };
         let mut conv = GpuSource::new(up, self.opt.block_frames);
         if x.ch != 2 { conv = conv.convert_channels(ChannelCount::new(2).unwrap()); }
         conv = conv.convert_sample_rate(SampleRate::new(self.rate).unwrap());
-        x.up = Box::new(conv);
+        x.up = Upstream::Host(Box::new(conv));
         x.ch = 2;
     }
     fn start_generation(&mut self) {
         let mut all = std::mem::take(&mut self.pending);
-        if all.iter().any(|x| x.up.current_span_len().is_some()) {               // span by span, as rodio converts them: one stream, insertion order
-            self.start_stream(all, true, false);
+        if all.iter().any(|x| x.up.src_ref().current_span_len().is_some()) {       // span by span, as rodio converts them: one stream per filter, insertion order
+            let mut fk: Vec<MixerFilter> = Vec::new();
+            for x in &all { if !fk.iter().any(|f| f.same(&x.filt)) { fk.push(x.filt); } }
+            for f in fk {
+                let (group, rest): (Vec<Src>, Vec<Src>) = all.into_iter().partition(|x| x.filt.same(&f));
+                all = rest;
+                self.start_stream(group, true, false);
+            }
             return;
         }
         for x in &mut all { self.make_direct(x); }
-        // continuous sources: one fused stream per (input rate, mono or not), in order of first appearance; mono sources form
+        // continuous sources: one fused stream per (input rate, mono or not, filter), in order of first appearance; mono sources form
         // streams of mono frames (the kernel reads 4 bytes per frame, the mono mix becomes stereo once per block)
-        let mut kinds: Vec<(u32, bool)> = Vec::new();
-        for x in &all { let k = (x.up.sample_rate().get(), x.ch == 1); if !kinds.contains(&k) { kinds.push(k); } }
-        for (r, mono) in kinds {
-            let (group, rest): (Vec<Src>, Vec<Src>) = all.into_iter().partition(|x| x.up.sample_rate().get() == r && (x.ch == 1) == mono);
+        let mut kinds: Vec<(u32, bool, MixerFilter)> = Vec::new();
+        for x in &all {
+            let k = (x.up.src_ref().sample_rate().get(), x.ch == 1, x.filt);
+            if !kinds.iter().any(|o| o.0 == k.0 && o.1 == k.1 && o.2.same(&k.2)) { kinds.push(k); }
+        }
+        for (r, mono, f) in kinds {
+            let (group, rest): (Vec<Src>, Vec<Src>) = all.into_iter().partition(|x| x.up.src_ref().sample_rate().get() == r && (x.ch == 1) == mono && x.filt.same(&f));
             all = rest;
             self.start_stream(group, false, mono);
         }
     }
     fn start_stream(&mut self, srcs: Vec<Src>, staged: bool, mono: bool) {
-        let from = if staged { self.rate } else { srcs[0].up.sample_rate().get() };
+        let from = if staged { self.rate } else { srcs[0].up.src_ref().sample_rate().get() };
+        let filt = srcs[0].filt;                                                   // (one filter per stream: start_generation / late_join group by it)
         self.cap_frames = self.opt.block_frames + 4096;                            // a block can hold what the previous one left over
-        let mut g = Gen { srcs, plan: ptr::null_mut(), din: DeviceBuf::new(), q: [DeviceBuf::new(), DeviceBuf::new()], stage: [PinnedBuf::new(), PinnedBuf::new()],
-                          side: [PinnedBuf::new(), PinnedBuf::new()], dside: DeviceBuf::new(), cur: 0, slot: 0, head: 0, fill: 0, done: false,
-                          mono: mono && !staged, qm: DeviceBuf::new(), staged, target: 0, crow: 0, conv: [DeviceBuf::new(), DeviceBuf::new()], dtab: DeviceBuf::new(), tab: [PinnedBuf::new(), PinnedBuf::new()], ccur: 0 };
+        let mut g = Gen { srcs, plan: ptr::null_mut(), filt, din: [DeviceBuf::new(), DeviceBuf::new(), DeviceBuf::new()], dnext: 0, pd: 0, pd_prev: None,
+                          q: [DeviceBuf::new(), DeviceBuf::new()], stage: [PinnedBuf::new(), PinnedBuf::new()], side: [PinnedBuf::new(), PinnedBuf::new()],
+                          dside: [DeviceBuf::new(), DeviceBuf::new()], copied: [Event::new(), Event::new()], cur: 0, slot: 0, head: 0, fill: 0, done: false,
+                          pulled: false, pslot: 0, pptrs: Vec::new(), pavail: Vec::new(), pended: Vec::new(), pside_off: Vec::new(), pside: 0, ptable: Vec::new(), pmax_out: 0,
+                          mono: mono && !staged, qm: DeviceBuf::new(), staged, target: 0, crow: 0, conv: [DeviceBuf::new(), DeviceBuf::new()], dtab: DeviceBuf::new(),
+                          tab: [PinnedBuf::new(), PinnedBuf::new()], ccur: 0 };
         if staged {
             g.target = self.opt.block_frames as u64 + 64 * 20 + 8;                 // a block emits whole tiles (at most 64 * 20 frames) and keeps two frames of history
             g.crow = g.target + 64;
@@ -727,15 +1028,19 @@ impl GpuMixer {
             for b in &mut g.conv { b.reserve(g.srcs.len() * crowf); }
         }
         let cfg = RhRlmConfig {
-            from_rate: from, to_rate: self.rate, channels: if g.mono { 1 } else { 2 }, span_len: 0, filter_kind: self.opt.filter_kind, filter_freq: self.opt.filter_freq, filter_q: self.opt.filter_q,
+            from_rate: from, to_rate: self.rate, channels: if g.mono { 1 } else { 2 }, span_len: 0, filter_kind: filt.kind, filter_freq: filt.freq, filter_q: filt.q,
             max_sources: g.srcs.len() as u32, max_in_frames: if staged { g.crow } else { self.cap_frames as u64 },
             frames_per_lane: self.opt.frames_per_lane, ring_stages: 0, no_balance: 0, force_general: 0, custom_coeffs: [0.0; 5], filter_first: 0,
         };
         ck(unsafe { rh_rlm_create(&mut g.plan, &cfg) }, "rh_rlm_create");
+        ck(unsafe { rh_rlm_set_exclusive(g.plan, 0) }, "rh_rlm_set_exclusive");   // the copy stream's launches (and other mixers) share the CUs: tiles by ticket
         // staged: the factor sits in front of the converter, where Mixer::add(src.amplify(g)) has it
         let gains: Vec<f32> = g.srcs.iter().map(|x| if staged { 1.0 } else { x.gain }).collect();
         ck(unsafe { rh_rlm_set_gains(g.plan, gains.as_ptr(), gains.len() as u32) }, "rh_rlm_set_gains");
         ck(unsafe { rh_rlm_stream_begin(g.plan) }, "rh_rlm_stream_begin");
+        // sources that start together run together until the first of them ends: their blocks are summed first (rodio_hip.h).  The rows of a
+        // direct generation rotate through three sets, which is what the recovery at that moment needs; converted rows (staged) do not.
+        if !staged { ck(unsafe { rh_rlm_stream_keep_history(g.plan, 1) }, "rh_rlm_stream_keep_history"); }
         self.row = (self.cap_frames * 2 + 3) & !3;
         let mut m = 0u64;
         ck(unsafe { rh_resample_out_frames(if staged { g.crow } else { self.cap_frames as u64 }, from, self.rate, 2, 0, &mut m) }, "rh_resample_out_frames");
@@ -760,69 +1065,166 @@ impl GpuMixer {
         self.gens.push(g);
     }
 
-    /// One block of a continuous generation: every source's row = [frames the previous block left unconsumed | a freshly pulled
-    /// block]; one copy, the fused launch (resample + filter + ordered sum), what the converter has not consumed is kept.
-    fn run_block_direct(&mut self, gi: usize) {
-        let (cap_frames, block_frames, stream, out_cap) = (self.cap_frames, self.opt.block_frames, self.pump.stream, self.out_cap_frames);
-        let g = &mut self.gens[gi];
-        let native: u16 = if g.mono { 1 } else { 2 };                              // channels of the rows the fused launch reads
-        let row_len = if g.mono { (cap_frames + 3) & !3 } else { self.row };        // floats per row
-        let s_n = g.srcs.len();
-        let slot = g.slot;
-        g.slot ^= 1;
-        g.stage[slot].reserve(s_n * row_len);
-        g.din.reserve(s_n * row_len);
-        let mut side_off = vec![0usize; s_n];
-        let mut side_floats = 0usize;
-        for (i, x) in g.srcs.iter().enumerate() {
-            if x.ch != native { side_off[i] = side_floats; side_floats += (cap_frames * x.ch as usize + 3) & !3; }
+    /// One block of a generation = its host half (pull_block: the upstreams are pulled into a page-locked staging block, by a few
+    /// threads, and the copy is queued on the copy stream) and its device half (issue_block: launches on the pump's stream, behind the
+    /// copy's event).  The pump runs the host half of the next block while the device still works on the block about to be served.
+    fn run_block(&mut self, gi: usize) {
+        if !self.gens[gi].pulled { self.pull_block(gi); }
+        self.issue_block(gi);
+    }
+    fn pull_block(&mut self, gi: usize) {
+        {
+            let g = &mut self.gens[gi];
+            g.pslot = g.slot;
+            g.slot ^= 1;
+            g.pd_prev = if g.pd_prev.is_none() && g.dnext == 0 { None } else { Some(g.pd) };
+            g.pd = g.dnext;
+            g.dnext = (g.dnext + 1) % 3;
         }
-        if side_floats > 0 { g.side[slot].reserve(side_floats); g.dside.reserve(side_floats); }
-        let (mut ptrs, mut avail, mut ended) = (Vec::with_capacity(s_n), Vec::with_capacity(s_n), Vec::with_capacity(s_n));
+        let t0 = Instant::now();
+        if self.gens[gi].staged { self.pull_block_staged(gi) } else { self.pull_block_direct(gi) }
+        self.pump.timing.pull_s += t0.elapsed().as_secs_f64();
+        self.gens[gi].pulled = true;
+    }
+    fn issue_block(&mut self, gi: usize) {
+        self.gens[gi].pulled = false;
+        if self.gens[gi].staged { self.issue_block_staged(gi) } else { self.issue_block_direct(gi) }
+    }
+
+    /// A generation of one format.  Row i of the page-locked block = [frames the previous block left unconsumed | one freshly pulled
+    /// block]; a source that is not in the layout the fused launch reads has its row in the side block, in its own layout; a chain
+    /// that hands its blocks over on the device has its row filled device-to-device.
+    fn pull_block_direct(&mut self, gi: usize) {
+        let (cap_frames, block_frames, copy_stream, threads) = (self.cap_frames, self.opt.block_frames, self.copy_stream, self.pull_threads() as usize);
+        let row_stereo = self.row;
+        let g = &mut self.gens[gi];
+        let native: usize = if g.mono { 1 } else { 2 };                            // channels of the rows the fused launch reads
+        let row_len = if g.mono { (cap_frames + 3) & !3 } else { row_stereo };      // floats per row
+        let s_n = g.srcs.len();
+        let (slot, pd) = (g.pslot, g.pd);
+        g.stage[slot].reserve(s_n * row_len);
+        g.din[pd].reserve(s_n * row_len);
+        g.pptrs = vec![ptr::null(); s_n];
+        g.pavail = vec![0; s_n];
+        g.pended = vec![0; s_n];
+        g.pside_off = vec![0; s_n];
+        g.pside = 0;
+        for (i, x) in g.srcs.iter().enumerate() {
+            if x.ch as usize != native { g.pside_off[i] = g.pside; g.pside += (cap_frames * x.ch as usize + 3) & !3; }
+        }
+        if g.pside > 0 { g.side[slot].reserve(g.pside); g.dside[slot].reserve(g.pside); }
+        // the host sources, a few at a time on scoped threads: sources are independent objects, one thread drives one source at a time
+        let (stage_p, side_p, din_p) = (SendPtr(g.stage[slot].p), SendPtr(g.side[slot].p), SendPtr(g.din[pd].p));
+        let side_off = g.pside_off.clone();
+        let mut results: Vec<(u64, u8)> = vec![(0, 0); s_n];
+        {
+            let pull_one = |i: usize, x: &mut Src, res: &mut (u64, u8)| {
+                if x.up.on_device() { return; }                                     // its block arrives device-to-device, below
+                let ch = x.ch as usize;
+                let row: &mut [f32] = unsafe {
+                    if ch == native { std::slice::from_raw_parts_mut(stage_p.0.add(i * row_len), row_len) } else { std::slice::from_raw_parts_mut(side_p.0.add(side_off[i]), cap_frames * ch) }
+                };
+                let mut have = x.held.len();
+                assert!(have / ch + if x.ended { 0 } else { block_frames } <= cap_frames, "GpuMixer: held frames exceed the plan");
+                row[..have].copy_from_slice(&x.held);
+                if !x.ended {
+                    let want = block_frames * ch;
+                    let mut got = read_into(x.up.src(), &mut row[have..have + want]);   // straight into the staging block
+                    got -= got % ch;                                                // sources end on frame boundaries (source/mod.rs:169-178)
+                    have += got;
+                    x.ended = got < want;
+                }
+                *res = ((have / ch) as u64, x.ended as u8);
+            };
+            let big = s_n * block_frames >= (1 << 18) && threads > 1 && s_n > 1;
+            if big {
+                let per = (s_n + threads - 1) / threads;
+                std::thread::scope(|sc| {
+                    for (k, (xs, rs)) in g.srcs.chunks_mut(per).zip(results.chunks_mut(per)).enumerate() {
+                        let pull_one = &pull_one;
+                        sc.spawn(move || { for (j, (x, r)) in xs.iter_mut().zip(rs.iter_mut()).enumerate() { pull_one(k * per + j, x, r); } });
+                    }
+                });
+            } else {
+                for (i, (x, r)) in g.srcs.iter_mut().zip(results.iter_mut()).enumerate() { pull_one(i, x, r); }
+            }
+        }
         for i in 0..s_n {
+            g.pptrs[i] = unsafe { din_p.0.add(i * row_len) } as *const f32;
+            g.pavail[i] = results[i].0;
+            g.pended[i] = results[i].1;
+        }
+        // one copy for all rows -- what the longest row holds of every row: the rows differ by a few frames, the unused ends stay -- on
+        // the copy stream: it runs beside the launches of the block before
+        let width = (0..s_n).filter(|&i| g.srcs[i].ch as usize == native).map(|i| g.pavail[i] as usize * native).max().unwrap_or(0);
+        unsafe {
+            if width > 0 { ck(rh_memcpy_h2d_rows(g.din[pd].p.cast(), g.stage[slot].p.cast(), row_len * 4, width * 4, s_n, copy_stream), "rh_memcpy_h2d_rows"); }
+            if g.pside > 0 { ck(rh_memcpy_h2d(g.dside[slot].p.cast(), g.side[slot].p.cast(), g.pside * 4, copy_stream), "rh_memcpy_h2d"); }
+        }
+        // chains that hand their blocks over on the device: [what the converter left of the block before | the chain's next samples],
+        // device-to-device on the copy stream, behind the pitched copy
+        for i in 0..s_n {
+            if !g.srcs[i].up.on_device() { continue; }
+            let row = unsafe { g.din[pd].p.add(i * row_len) };
+            let prev = g.pd_prev.map(|k| g.din[k].p);
             let x = &mut g.srcs[i];
-            let ch = x.ch as usize;
-            let row: &mut [f32] = if ch == native as usize { &mut g.stage[slot].slice_mut(s_n * row_len)[i * row_len..(i + 1) * row_len] }
-                                  else { &mut g.side[slot].slice_mut(side_floats)[side_off[i]..] };
-            let mut have = x.held.len();
-            assert!(have / ch + if x.ended { 0 } else { block_frames } <= cap_frames, "GpuMixer: held frames exceed the plan");
-            row[..have].copy_from_slice(&x.held);
+            let mut have = x.dheld as usize * 2;
+            assert!(have / 2 + if x.ended { 0 } else { block_frames } <= cap_frames, "GpuMixer: held frames exceed the plan");
+            if have > 0 { ck(unsafe { rh_memcpy_d2d(row.cast(), prev.unwrap().add(i * row_len + x.dheld_off as usize * 2).cast(), have * 4, copy_stream) }, "rh_memcpy_d2d"); }
             if !x.ended {
-                let want = block_frames * ch;
-                let mut got = read_into(x.up.as_mut(), &mut row[have..have + want]);   // straight into the staging block
-                got -= got % ch;                                                    // sources end on frame boundaries (source/mod.rs:169-178)
+                let want = block_frames * 2;
+                let mut got = match &mut x.up { Upstream::Chain(c) => c.read_device(unsafe { row.add(have) }, want, copy_stream), Upstream::Host(_) => unreachable!() };
+                got -= got % 2;
                 have += got;
                 x.ended = got < want;
             }
-            ptrs.push(unsafe { g.din.p.add(i * row_len) } as *const f32);
-            avail.push((have / ch) as u64);
-            ended.push(x.ended as u8);
+            g.pptrs[i] = row as *const f32;
+            g.pavail[i] = (have / 2) as u64;
+            g.pended[i] = x.ended as u8;
         }
-        ck(unsafe { rh_memcpy_h2d(g.din.p.cast(), g.stage[slot].p.cast(), s_n * row_len * 4, stream) }, "rh_memcpy_h2d");
-        if side_floats > 0 {                                                        // ChannelCountConverter on the device (channels.rs:57-85), into the stereo rows
-            ck(unsafe { rh_memcpy_h2d(g.dside.p.cast(), g.side[slot].p.cast(), side_floats * 4, stream) }, "rh_memcpy_h2d");
+        ck(unsafe { rh_event_record(g.copied[slot].0, copy_stream) }, "rh_event_record");
+    }
+    fn issue_block_direct(&mut self, gi: usize) {
+        let (cap_frames, stream, out_cap) = (self.cap_frames, self.pump.stream, self.out_cap_frames);
+        let row_stereo = self.row;
+        let g = &mut self.gens[gi];
+        let native: usize = if g.mono { 1 } else { 2 };
+        let row_len = if g.mono { (cap_frames + 3) & !3 } else { row_stereo };
+        let s_n = g.srcs.len();
+        let (slot, pd) = (g.pslot, g.pd);
+        ck(unsafe { rh_stream_wait_event(stream, g.copied[slot].0) }, "rh_stream_wait_event");
+        if g.pside > 0 {                                                            // ChannelCountConverter on the device (channels.rs:57-85), into the rows the fused launch reads
             for i in 0..s_n {
-                if g.srcs[i].ch != native && avail[i] > 0 {
-                    ck(unsafe { rh_channels_convert(g.din.p.add(i * row_len), g.dside.p.add(side_off[i]), avail[i] as usize, g.srcs[i].ch as u32, 2, stream) }, "rh_channels_convert");
+                if g.srcs[i].ch as usize != native && g.pavail[i] > 0 {
+                    ck(unsafe { rh_channels_convert(g.din[pd].p.add(i * row_len), g.dside[slot].p.add(g.pside_off[i]), g.pavail[i] as usize, g.srcs[i].ch as u32, 2, stream) }, "rh_channels_convert");
                 }
             }
         }
         let (mut out, mut consumed) = (0u64, 0u64);
         if g.mono {                                                                 // the mono mix of the block, then ChannelCountConverter(1 -> 2) (channels.rs:64-73) behind the stereo queue
             g.qm.reserve(out_cap as usize * 2);
-            ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.qm.p, out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
+            ck(unsafe { rh_rlm_stream_block_v(g.plan, g.pptrs.as_ptr(), g.pavail.as_ptr(), g.pended.as_ptr(), s_n as u32, g.qm.p, out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
                "rh_rlm_stream_block_v");
             if out > 0 { ck(unsafe { rh_channels_convert(g.queue_end(), g.qm.p, out as usize, 1, 2, stream) }, "rh_channels_convert"); }
         } else {
-            ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.queue_end(), out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
+            ck(unsafe { rh_rlm_stream_block_v(g.plan, g.pptrs.as_ptr(), g.pavail.as_ptr(), g.pended.as_ptr(), s_n as u32, g.queue_end(), out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
                "rh_rlm_stream_block_v");
         }
         g.fill += out;
         let mut all_ended = true;
+        let side_floats = g.pside;
         for i in 0..s_n {                                                           // keep what the converter has not consumed (a few hundred frames)
+            let avail = g.pavail[i];
+            if g.srcs[i].up.on_device() {                                          // ... which stays where it is: the next block copies it from this block's row
+                let x = &mut g.srcs[i];
+                x.dheld_off = consumed.min(avail);
+                x.dheld = avail - x.dheld_off;
+                all_ended = all_ended && x.ended;
+                continue;
+            }
             let ch = g.srcs[i].ch as usize;
-            let row: &[f32] = if ch == native as usize { &g.stage[slot].slice(s_n * row_len)[i * row_len..] } else { &g.side[slot].slice(side_floats)[side_off[i]..] };
-            let have = avail[i] as usize * ch;
+            let row: &[f32] = if ch == native { &g.stage[slot].slice(s_n * row_len)[i * row_len..] } else { &g.side[slot].slice(side_floats)[g.pside_off[i]..] };
+            let have = avail as usize * ch;
             let drop = (consumed as usize * ch).min(have);
             let x = &mut g.srcs[i];
             x.held.clear();
@@ -832,17 +1234,16 @@ impl GpuMixer {
         g.done = all_ended;                                                         // the call that saw every source ended emitted everything that was left
     }
 
-    /// One block of a span-by-span generation.  Every source is topped up to `target` converted frames: it is pulled piece by piece
-    /// (a piece never crosses a span; its length is budgeted so that its output fits the row whatever the span does), the pieces are
-    /// planned into segments, ONE copy brings all rows to the device, ONE launch converts all segments of all sources (plus the frames
-    /// the last block left over, moved to the front of the other row set), and the fused kernel -- its converter passing through --
-    /// filters and mixes the rows.
-    fn run_block_staged(&mut self, gi: usize) {
-        let (rate, stream, out_cap) = (self.rate, self.pump.stream, self.out_cap_frames);
+    /// A span-by-span generation.  Every source is topped up to `target` converted frames: it is pulled piece by piece (a piece never
+    /// crosses a span; its length is budgeted so that its output fits the row whatever the span does), the pieces are planned into
+    /// segments; then ONE copy brings all rows to the device (copy stream), ONE launch converts all segments of all sources (plus the
+    /// frames the last block left over, moved to the front of the other row set), and the fused kernel -- its converter passing
+    /// through -- filters and mixes the rows.
+    fn pull_block_staged(&mut self, gi: usize) {
+        let (rate, copy_stream) = (self.rate, self.copy_stream);
         let g = &mut self.gens[gi];
         let s_n = g.srcs.len();
-        let slot = g.slot;
-        g.slot ^= 1;
+        let (slot, pd) = (g.pslot, g.pd);
         let crowf = (g.crow as usize * 2 + 3) & !3;
         // 1. layout of the staging block: a row per live source, sized for what it is about to pull in its current format
         let (mut row_off, mut row_cap) = (vec![0usize; s_n], vec![0usize; s_n]);
@@ -851,7 +1252,7 @@ impl GpuMixer {
             row_off[i] = total;
             let x = &mut g.srcs[i];
             if x.ended { continue; }
-            match x.reader.peek(x.up.as_mut()) {
+            match x.reader.peek(x.up.src()) {
                 None => { x.ended = true; }                                         // the chain rodio would build now is empty
                 Some((ch, r)) => {
                     let want = g.target.saturating_sub(x.have);
@@ -862,17 +1263,18 @@ impl GpuMixer {
             }
         }
         g.stage[slot].reserve(total.max(4));
-        g.din.reserve(total.max(4));
-        let mut table: Vec<RhUniformSeg> = Vec::new();
-        let mut max_out = 0u64;
+        g.din[pd].reserve(total.max(4));
+        g.ptable.clear();
+        g.pmax_out = 0;
         let (oc, nc) = (g.ccur, g.ccur ^ 1);
         for (i, x) in g.srcs.iter().enumerate() {                                  // what the last block left over: to the front of the other row set
             if x.have == 0 { continue; }
-            table.push(RhUniformSeg { src: unsafe { g.conv[oc].p.add(i * crowf + x.off as usize * 2) }, dst: unsafe { g.conv[nc].p.add(i * crowf) }, src_frame0: 0, src_frames: x.have,
-                                      m0: 0, m1: x.have, span_frames: u64::MAX, from_rate: rate, to_rate: rate, from_ch: 2, to_ch: 2, gain: 1.0, reserved: 0 });
-            max_out = max_out.max(x.have);
+            g.ptable.push(RhUniformSeg { src: unsafe { g.conv[oc].p.add(i * crowf + x.off as usize * 2) }, dst: unsafe { g.conv[nc].p.add(i * crowf) }, src_frame0: 0, src_frames: x.have,
+                                         m0: 0, m1: x.have, span_frames: u64::MAX, from_rate: rate, to_rate: rate, from_ch: 2, to_ch: 2, gain: 1.0, reserved: 0 });
+            g.pmax_out = g.pmax_out.max(x.have);
         }
-        // 2. pull and plan
+        // 2. pull and plan (the spans of a source are pulled in order by one thread; the sources one after the other here -- the C++ twin
+        // deals them over its pull threads the same way the direct generations do)
         let stage_all = g.stage[slot].slice_mut(total.max(4));
         for i in 0..s_n {
             let x = &mut g.srcs[i];
@@ -883,13 +1285,13 @@ impl GpuMixer {
             row[..fill].copy_from_slice(&x.held[..fill]);
             let mut segs: Vec<PlannedSeg> = Vec::new();
             loop {
-                let (ch, r) = match x.reader.peek(x.up.as_mut()) { Some(f) => f, None => { x.ended = true; break; } };
+                let (ch, r) = match x.reader.peek(x.up.src()) { Some(f) => f, None => { x.ended = true; break; } };
                 let now = x.have + x.plan.out_frames();
                 if now >= g.target { break; }
                 let (need, most) = x.plan.budget(r, x.reader.opens_next(), g.target - now, g.crow - now);
                 let n = need.min(most).min(((row_cap[i] - fill) / ch as usize) as u64) as usize;
                 if n == 0 { break; }
-                let piece = x.reader.read_piece(x.up.as_mut(), &mut row[fill..], n);   // straight into the staging block
+                let piece = x.reader.read_piece(x.up.src(), &mut row[fill..], n);   // straight into the staging block
                 if let Some(pc) = piece { fill += pc.n; x.plan.add(&pc, &mut segs); }
                 if x.reader.ended() { x.ended = true; break; }
                 if piece.is_none() { break; }
@@ -899,25 +1301,35 @@ impl GpuMixer {
             x.held.extend_from_slice(&row[x.plan.keep_offset()..x.plan.keep_offset() + x.plan.keep_samples()]);
             for sg in &segs {
                 let mut t = sg.g;
-                t.src = unsafe { g.din.p.add(row_off[i] + sg.src_off) };
+                t.src = unsafe { g.din[pd].p.add(row_off[i] + sg.src_off) };
                 t.dst = unsafe { g.conv[nc].p.add(i * crowf + (x.have as usize + sg.dst_off) * 2) };
                 t.gain = x.gain;
-                max_out = max_out.max(t.m1 - t.m0);
-                table.push(t);
+                g.pmax_out = g.pmax_out.max(t.m1 - t.m0);
+                g.ptable.push(t);
             }
             x.have += x.plan.out_frames();
             assert!(x.have <= g.crow, "GpuMixer: converted frames exceed the row");
         }
-        // 3. one copy, one conversion launch
-        if total > 0 { ck(unsafe { rh_memcpy_h2d(g.din.p.cast(), g.stage[slot].p.cast(), total * 4, stream) }, "rh_memcpy_h2d"); }
-        if !table.is_empty() {
-            let tf = table.len() * std::mem::size_of::<RhUniformSeg>() / 4;
+        // 3. one copy for all rows, on the copy stream: it runs beside the launches of the block before
+        if total > 0 { ck(unsafe { rh_memcpy_h2d(g.din[pd].p.cast(), g.stage[slot].p.cast(), total * 4, copy_stream) }, "rh_memcpy_h2d"); }
+        ck(unsafe { rh_event_record(g.copied[slot].0, copy_stream) }, "rh_event_record");
+    }
+    fn issue_block_staged(&mut self, gi: usize) {
+        let (stream, out_cap) = (self.pump.stream, self.out_cap_frames);
+        let g = &mut self.gens[gi];
+        let s_n = g.srcs.len();
+        let slot = g.pslot;
+        let crowf = (g.crow as usize * 2 + 3) & !3;
+        let nc = g.ccur ^ 1;
+        ck(unsafe { rh_stream_wait_event(stream, g.copied[slot].0) }, "rh_stream_wait_event");
+        if !g.ptable.is_empty() {                                                   // ... one conversion launch behind the copy
+            let tf = g.ptable.len() * std::mem::size_of::<RhUniformSeg>() / 4;
             g.tab[slot].reserve(tf);
             g.dtab.reserve(tf);
             unsafe {
-                ptr::copy_nonoverlapping(table.as_ptr() as *const f32, g.tab[slot].p, tf);
+                ptr::copy_nonoverlapping(g.ptable.as_ptr() as *const f32, g.tab[slot].p, tf);
                 ck(rh_memcpy_h2d(g.dtab.p.cast(), g.tab[slot].p.cast(), tf * 4, stream), "rh_memcpy_h2d");
-                ck(rh_uniform_segments_dev(g.dtab.p as *const RhUniformSeg, table.len() as u32, max_out, stream), "rh_uniform_segments_dev");
+                ck(rh_uniform_segments_dev(g.dtab.p as *const RhUniformSeg, g.ptable.len() as u32, g.pmax_out, stream), "rh_uniform_segments_dev");
             }
         }
         g.ccur = nc;
@@ -932,7 +1344,21 @@ impl GpuMixer {
         for x in &mut g.srcs { let d = consumed.min(x.have); x.off = d; x.have -= d; }
         g.done = g.srcs.iter().all(|x| x.ended);
     }
-    fn run_block(&mut self, gi: usize) { if self.gens[gi].staged { self.run_block_staged(gi) } else { self.run_block_direct(gi) } }
+
+    /// The mixed stereo block `mixed` (n frames, on the device) on its way to the host block of slot `i`, in the mixer's layout.
+    fn send_block(&mut self, i: usize, mixed: *const f32, n: u64) {
+        let stream = self.pump.stream;
+        if self.out_ch == 2 {
+            ck(unsafe { rh_memcpy_d2h_async(self.pump.slot[i].out.p.cast(), mixed.cast(), (n * 2 * 4) as usize, stream) }, "rh_memcpy_d2h_async");
+            return;
+        }
+        let oc = self.out_ch as usize;
+        self.dout.reserve(self.out_cap_frames as usize * 2 * oc);                 // ChannelCountConverter(2 -> channels) on the mix (channels.rs:57-85), once per block
+        unsafe {
+            ck(rh_channels_convert(self.dout.p, mixed, n as usize, 2, oc as u32, stream), "rh_channels_convert");
+            ck(rh_memcpy_d2h_async(self.pump.slot[i].out.p.cast(), self.dout.p.cast(), n as usize * oc * 4, stream), "rh_memcpy_d2h_async");
+        }
+    }
 
     /// `Mixer::add` on a running mixer.  rodio admits the source at the next frame boundary of the output (mixer.rs:175-183).  Here up to
     /// two blocks are already mixed beyond that frame (the one being served, the one in flight), so the new source -- its own
@@ -940,14 +1366,15 @@ impl GpuMixer {
     /// device copies at its offset (rh_mix_sum: old mix first, the newcomer last = insertion order) and the blocks travel to the host again.
     fn late_join(&mut self, mut item: Src) {
         let ci = self.pump.cur;
-        let consumed = self.slot_base[ci] * 2 + self.pump.pos as u64;               // samples already handed out
-        let j = (consumed + 1) / 2;                                                  // the next frame boundary
+        let oc = self.out_ch as u64;
+        let consumed = self.slot_base[ci] * oc + self.pump.pos as u64;              // samples already handed out
+        let j = (consumed + oc - 1) / oc;                                            // the next frame boundary
         let flight = self.pump.other_in_flight();
         let li = if flight { ci ^ 1 } else { ci };
         let sched_end = self.slot_base[li] + self.slot_frames[li];
         let stream = self.pump.stream;
         ck(unsafe { rh_stream_synchronize(stream) }, "rh_stream_synchronize");     // the blocks about to be patched have been produced
-        let staged = item.up.current_span_len().is_some();
+        let staged = !item.up.on_device() && item.up.src_ref().current_span_len().is_some();
         if !staged { self.make_direct(&mut item); }
         let mono = !staged && item.ch == 1;
         self.start_stream(vec![item], staged, mono);
@@ -961,17 +1388,17 @@ impl GpuMixer {
         for k in 0..(if flight { 2 } else { 1 }) {
             let si = if k == 0 { ci } else { ci ^ 1 };
             let (b0, b1) = (self.slot_base[si], self.slot_base[si] + self.slot_frames[si]);
-            let g = &self.gens[gi];
-            let (lo, hi) = (j.max(b0), b1.min(j + g.fill));
+            let (lo, hi) = { let g = &self.gens[gi]; (j.max(b0), b1.min(j + g.fill)) };
             if hi <= lo { continue; }
-            let ptrs = [self.dkeep[si].p as *const f32, unsafe { g.queue().add(((lo - j) * 2) as usize) }];
+            let ptrs = [self.dkeep[si].p as *const f32, unsafe { self.gens[gi].queue().add(((lo - j) * 2) as usize) }];
             let (start, len) = ([0u64, (lo - b0) * 2], [self.slot_frames[si] * 2, (hi - lo) * 2]);
             self.dmix.reserve(self.out_cap_frames as usize * 4);
             unsafe {
                 ck(rh_mix_sum(self.dmix.p, (self.slot_frames[si] * 2) as usize, ptrs.as_ptr(), start.as_ptr(), len.as_ptr(), 2, stream), "rh_mix_sum");
                 ck(rh_memcpy_d2d(self.dkeep[si].p.cast(), self.dmix.p.cast(), (self.slot_frames[si] * 2 * 4) as usize, stream), "rh_memcpy_d2d");
-                ck(rh_memcpy_d2h_async(self.pump.slot[si].out.p.cast(), self.dkeep[si].p.cast(), (self.slot_frames[si] * 2 * 4) as usize, stream), "rh_memcpy_d2h_async");
             }
+            let (keep, frames) = (self.dkeep[si].p as *const f32, self.slot_frames[si]);
+            self.send_block(si, keep, frames);
         }
         {   // the newcomer's queue moves on to the frame the next block starts at
             let g = &mut self.gens[gi];
@@ -984,12 +1411,23 @@ impl GpuMixer {
         self.block_done();
         // a mixer that was about to end goes on: the block that carried the end mark loses it, and if nothing was in flight the next block is requested now
         let last_i = if flight { ci ^ 1 } else { ci };
-        let g = &self.gens[gi];
-        if self.pump.slot[last_i].last && !(g.done && g.fill == 0) {
+        let (gdone, gfill) = (self.gens[gi].done, self.gens[gi].fill);
+        if self.pump.slot[last_i].last && !(gdone && gfill == 0) {
             self.pump.slot[last_i].last = false;
             if !flight { self.submit(ci ^ 1); }
         }
     }
+}
+
+/// A device chain pulled through the host after all (a steep rate ratio in front of it): `Source` by delegation.
+struct ChainAsSource(Box<dyn DeviceChain>);
+impl Iterator for ChainAsSource { type Item = f32; fn next(&mut self) -> Option<f32> { self.0.as_source().next() } }
+impl Source for ChainAsSource {
+    fn current_span_len(&self) -> Option<usize> { self.0.as_source_ref().current_span_len() }
+    fn channels(&self) -> ChannelCount { self.0.as_source_ref().channels() }
+    fn sample_rate(&self) -> SampleRate { self.0.as_source_ref().sample_rate() }
+    fn total_duration(&self) -> Option<Duration> { self.0.as_source_ref().total_duration() }
+    fn try_seek(&mut self, pos: Duration) -> Result<(), SeekError> { self.0.as_source().try_seek(pos) }
 }
 
 impl BlockSource for GpuMixer {
@@ -997,6 +1435,14 @@ impl BlockSource for GpuMixer {
     fn can_resume(&self) -> bool { !self.pending.is_empty() && self.resume_ok }     // mixer.rs:117-136: None while empty, samples again after add()
     fn block_done(&mut self) {                                                    // a bounded wait inside the fused kernel expired (never seen on a healthy device): fail loudly
         for g in &self.gens { if !g.plan.is_null() { ck(unsafe { rh_rlm_last_status(g.plan) }, "rh_rlm_last_status"); } }
+        if self.device_chains { ck(unsafe { rh_async_status() }, "rh_async_status"); }   // ... or inside a scan kernel of a chain that hands its blocks over on the device
+    }
+    fn prefetch(&mut self) {
+        if !self.pending.is_empty() { return; }                                     // a new generation starts with the next block: enqueue() does it all
+        for gi in 0..self.gens.len() {
+            let g = &self.gens[gi];
+            if !g.done && g.fill < self.out_cap_frames && !g.pulled { self.pull_block(gi); }
+        }
     }
     fn enqueue(&mut self, i: usize) {
         if !self.pending.is_empty() { self.start_generation(); }
@@ -1006,7 +1452,8 @@ impl BlockSource for GpuMixer {
             return;
         }
         let stream = self.pump.stream;
-        self.pump.slot[i].out.reserve(self.out_cap_frames as usize * 4);
+        let oc = self.out_ch as usize;
+        self.pump.slot[i].out.reserve(self.out_cap_frames as usize * 2 * oc.max(2));
         // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
         for gi in 0..self.gens.len() { if !self.gens[gi].done && self.gens[gi].fill < self.out_cap_frames { self.run_block(gi); } }
         // 2. the frames every unfinished generation has reached; finished ones give what they have left
@@ -1023,11 +1470,9 @@ impl BlockSource for GpuMixer {
                 ck(unsafe { rh_mix_sum(self.dmix.p, (n * 2) as usize, ptrs.as_ptr(), start.as_ptr(), len.as_ptr(), ptrs.len() as u32, stream) }, "rh_mix_sum");
                 mixed = self.dmix.p;
             }
+            self.send_block(i, mixed, n);
             self.dkeep[i].reserve(self.out_cap_frames as usize * 4);              // the block also stays on the device until it has been served (late_join)
-            unsafe {
-                ck(rh_memcpy_d2h_async(self.pump.slot[i].out.p.cast(), mixed.cast(), (n * 2 * 4) as usize, stream), "rh_memcpy_d2h_async");
-                ck(rh_memcpy_d2d(self.dkeep[i].p.cast(), mixed.cast(), (n * 2 * 4) as usize, stream), "rh_memcpy_d2d");
-            }
+            ck(unsafe { rh_memcpy_d2d(self.dkeep[i].p.cast(), mixed.cast(), (n * 2 * 4) as usize, stream) }, "rh_memcpy_d2d");
         }
         self.slot_base[i] = self.scheduled;
         self.slot_frames[i] = n;
@@ -1040,31 +1485,36 @@ impl BlockSource for GpuMixer {
         }
         self.scheduled += n;
         if self.gens.iter().all(|g| g.done && g.fill == 0) {
-            ck(unsafe { rh_stream_synchronize(stream) }, "rh_stream_synchronize");
-            for g in self.gens.drain(..) {
-                if !g.plan.is_null() {
-                    ck(unsafe { rh_rlm_last_status(g.plan) }, "rh_rlm_last_status"); // the last blocks too: nothing is served unchecked
-                    ck(unsafe { rh_rlm_destroy(g.plan) }, "rh_rlm_destroy");
-                }
+            unsafe {
+                ck(rh_stream_synchronize(stream), "rh_stream_synchronize");
+                ck(rh_stream_synchronize(self.copy_stream), "rh_stream_synchronize");
             }
+            for g in &self.gens { if !g.plan.is_null() { ck(unsafe { rh_rlm_last_status(g.plan) }, "rh_rlm_last_status"); } }   // the last blocks too: nothing is served unchecked
+            // The generations' plans, page-locked blocks and device rows are NOT freed here: this runs inside the consumer's next() (the
+            // audio callback), and freeing a few hundred MB of page-locked memory takes hundreds of milliseconds.  The reaper does it.
+            let mut st = self.retired_chains;
+            for g in &self.gens { for x in &g.srcs { count_chain(x, &mut st); } }
+            self.retired_chains = st;
+            let dead: Vec<Gen> = self.gens.drain(..).collect();
+            self.reaper.get_or_insert_with(Reaper::new).retire(dead);
         }
-        self.pump.slot[i].n = n as usize * 2;
+        self.pump.slot[i].n = n as usize * oc;
         self.pump.slot[i].last = self.gens.is_empty() && self.pending.is_empty();
     }
 }
 impl Iterator for GpuMixer {
     type Item = f32;
     // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136), and admits
-    // pending sources only at channel 0: an ended mixer that gets a new source after an odd number of calls returns one more None.
+    // pending sources only at channel 0: an ended mixer that gets a new source in the middle of a frame returns None until the frame is over.
     fn next(&mut self) -> Option<f32> {
-        self.resume_ok = self.calls % 2 == 0;
+        self.resume_ok = self.calls % self.out_ch as u64 == 0;
         self.calls += 1;
         self.next_sample()
     }
 }
 impl Source for GpuMixer {
     fn current_span_len(&self) -> Option<usize> { None }
-    fn channels(&self) -> ChannelCount { ChannelCount::new(2).unwrap() }
+    fn channels(&self) -> ChannelCount { ChannelCount::new(self.out_ch).unwrap() }
     fn sample_rate(&self) -> SampleRate { SampleRate::new(self.rate).unwrap() }
     fn total_duration(&self) -> Option<Duration> { None }
     fn try_seek(&mut self, _: Duration) -> Result<(), SeekError> { Err(SeekError::NotSupported { underlying_source: "rodio_hip::GpuMixer (like MixerSource, mixer.rs:160-170)" }) }
@@ -1072,8 +1522,11 @@ impl Source for GpuMixer {
 impl Drop for GpuMixer {
     fn drop(&mut self) {
         unsafe {
+            rh_stream_synchronize(self.copy_stream);
             rh_stream_synchronize(self.pump.stream);
-            for g in &self.gens { if !g.plan.is_null() { rh_rlm_destroy(g.plan); } }
         }
+        self.gens.clear();
+        self.reaper.take();   // joins: generations that were retired are gone before the streams are
+        unsafe { rh_stream_destroy(self.copy_stream); }
     }
 }

@@ -184,3 +184,65 @@ def test_crate_files_exist():
     for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), os.path.join("src", "ffi.rs")):
         assert os.path.exists(os.path.join(CRATE, f)), f
     assert 'rodio = { version = "0.22"' in open(os.path.join(CRATE, "Cargo.toml")).read()
+
+
+def _cpp_public_methods(cls):
+    """Names of the public member functions of class `cls` in include/rodio_hip.hpp (its own public sections; constructors,
+    destructors and operators aside)."""
+    text = open(os.path.join(ROOT, "include", "rodio_hip.hpp")).read()
+    start = text.index(f"class {cls} ")
+    body = text[text.index("{", start) + 1:]
+    depth, end = 1, 0
+    for i, c in enumerate(body):  # the class body
+        depth += c == "{"
+        depth -= c == "}"
+        if depth == 0:
+            end = i
+            break
+    body = body[:end]
+    names, public = set(), False
+    for line in body.split("\n"):
+        s = line.strip()
+        if re.match(r"^(public|protected|private):", s):
+            public = s.startswith("public")
+            continue
+        if not public or not line.startswith("    ") or line.startswith("     "):  # members sit at one indentation level
+            continue
+        m = re.match(r"^(?:virtual |static |explicit |inline )*[\w:<>,\*& ]+?[ \*&]([a-z_][a-z0-9_]*)\s*\(", s)
+        if m and not s.startswith(("//", "///", "using ", "struct ", "class ", "enum ", "return ", "if ", "for ", "throw ")) and m.group(1) not in (cls,):
+            names.add(m.group(1))
+    return names
+
+
+def test_the_rust_twin_has_every_public_method_of_the_cpp_host_mirror():
+    """the crate is the twin of include/rodio_hip.hpp, method for method.  Every public member function of
+    rodio_hip::GpuSource / GpuMixer (and of their base, detail::BlockPump) has a same-named method in src/lib.rs -- with the few
+    spellings that MUST differ between the languages listed here, each with its reason."""
+    code = open(os.path.join(CRATE, "src", "lib.rs")).read()
+    rust_fns = set(re.findall(r"\bfn ([a-z_][a-z0-9_]*)\s*[<(]", code))
+    other = {
+        "read": "next_sample",  # Source::read (the bulk form of next()): rodio's trait has no such method; the pump serves next() from its block
+        "inner": "inner", "into_inner": "into_inner",
+        "channels": "channels", "sample_rate": "sample_rate",
+    }
+    # overloads of the C++ side get names of their own in Rust
+    overloads = {"add": ["add", "add_filtered", "add_chain", "add_chain_filtered"]}
+    missing = []
+    for cls in ("BlockPump", "GpuSource", "GpuMixer"):
+        names = _cpp_public_methods(cls)
+        assert len(names) >= (4 if cls == "BlockPump" else 8), (cls, names)
+        for n in sorted(names):
+            want = overloads.get(n, [other.get(n, n)])
+            if cls == "BlockPump" and n == "prepare":
+                want = ["prepare_stream", "prepare"]
+            if cls == "BlockPump" and n == "read_device":
+                want = ["read_device_impl", "read_device"]
+            for w in want:
+                if w not in rust_fns:
+                    missing.append(f"{cls}::{n} -> fn {w}")
+    assert not missing, missing
+    # ... and what the twin needs besides: the structs and options of the mixer, the device hand-off trait, the reaper, the copy stream
+    for item in ("pub struct MixerFilter", "pub reference_exact_filters: bool", "pub host_threads: u32", "pub trait DeviceChain", "struct Reaper", "copy_stream: RhStream",
+                 "rh_rlm_stream_keep_history", "rh_filter_scan_ok", "std::thread::scope", "pub struct ChainStats", "pub fn with_channels", "unsafe impl Sync for State",
+                 "pub tail: usize"):
+        assert item in code, item
