@@ -672,8 +672,9 @@ def side(args, argv):
         else:
             co = rh.biquad_coeffs("low_pass", 200, 0.5, 48000)
             outs_b = {}
-            kernels.append(("biquad_time_parallel", lambda: outs_b.__setitem__("o", rh.biquad_batch(x, co, mode=1)), alg, S * 2 * n))
-            kernels.append(("biquad_reference_order", lambda: rh.biquad_batch(x, co, mode=0), alg, S * 2 * n))
+            out0 = torch.empty_like(x)  # (outputs allocated once: a 512 MiB torch.empty_like per step costs the allocator more than the kernel takes)
+            kernels.append(("biquad_time_parallel", lambda: outs_b.__setitem__("o", rh.biquad_batch(x, co, mode=1, out=out)), alg, S * 2 * n))
+            kernels.append(("biquad_reference_order", lambda: rh.biquad_batch(x, co, mode=0, out=out0), alg, S * 2 * n))
             like, chain, tol = "%k_biquad_scan%", (lambda src: src.low_pass(200)), 1e-5
         workload = f"{cfg}: {S} stereo streams x {n} frames @ 48 kHz, default settings, default_rng(4321+s) U(-1,1)*0.9, 4 B in + 4 B out per sample"
         metric = f"Msamples/s through {cfg}"

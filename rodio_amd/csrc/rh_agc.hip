@@ -23,8 +23,13 @@
 // re-associated, and the gain -- a one-pole with a 4 s time constant, 192 000 samples at 48 kHz -- integrates its own rounding
 // noise to 5e-6 relative (x gain 7 = 4e-5 on the output): a scan over composed gain maps (g -> min(H, max(L, c*g + B)) is
 // closed under composition) was built and measured 7e-5 from the reference, outside the bound.  So the operations and their
-// order are the reference's and the result is bit-identical to the reference-order kernel (k_agc_seq in rh_recurrence.hip),
-// which stays for unaligned rows and in-place calls.
+// order are the reference's.  The general path (GainOp: any release) is bit-identical to the reference-order kernel (k_agc_seq in
+// rh_recurrence.hip, which stays for unaligned rows and in-place calls); the default-parameter path (GainOp0, release == 0) folds
+// the select and the clamp into one median and is bit-identical EXCEPT where the attack candidate and `desired` lie within a rounding
+// of each other, where it differs by that rounding (one ulp, not accumulating: the recurrence contracts) -- measured 0.0 on every
+// test signal, compared at 2e-7.  Non-finite samples: agc.rs's f32::clamp propagates a NaN into current_gain for good; v_med3_f32
+// returns the median of the finite operands, so after a NaN / Inf sample this path recovers where the reference (and k_agc_seq) stay
+// poisoned.  Audio does not carry NaNs; a caller that must reproduce the poisoning uses RH_AGC_SEQ.
 //
 // What a chain costs: ONE wave walks time for 64 streams, and a lone wave issues one instruction every 5-7 cycles whatever its
 // kind (measured: SQ_WAVE_CYCLES / instructions), so the chain wave carries nothing but the chain -- wave 0 issues LDS reads,
@@ -509,9 +514,26 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     if (presq && pstride >= (1ull << 24)) return RH_ERR_UNSUPPORTED;
     std::unique_lock<std::mutex> hold;
     float *scr = nullptr;
-    RH_HIP_TRY(rh::stream_scratch(s, (fresh_floats + win_floats + (size_t)n_streams * n_samples + (presq ? (size_t)n_streams * pstride : 0)) * sizeof(float),
-                                  reinterpret_cast<void **>(&scr), hold));
-    float *ordered = state ? scr + fresh_floats : nullptr, *rows = scr + fresh_floats + win_floats, *sq = rows + (size_t)n_streams * n_samples;
+    // the `rows` region rounded up to whole 16-byte vectors: the squares behind it are written with v4f stores and fetched by 16-byte
+    // LDS-DMA (one stream of an odd length -- 1 x 40 001 -- would otherwise put them 4 to 12 bytes off)
+    const size_t rows_floats = ((size_t)n_streams * n_samples + 3) & ~(size_t)3;
+    const size_t scratch_floats = fresh_floats + win_floats + rows_floats + (presq ? (size_t)n_streams * pstride : 0);
+    // The scratch is as large as the batch (twice with the squares) and stays with the stream: a batch that would pin more than 8 GiB
+    // that way, or whose scratch cannot be had at all, takes the reference-order kernels instead -- they need none (RH_ERR_UNSUPPORTED
+    // is the caller's cue; a failed allocation must not fail a call that worked before the chain existed)
+    if (scratch_floats * sizeof(float) > (8ull << 30)) return RH_ERR_UNSUPPORTED;
+    {
+        const hipError_t e = rh::stream_scratch(s, scratch_floats * sizeof(float), reinterpret_cast<void **>(&scr), hold);
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+            (void)hipGetLastError();
+            return RH_ERR_UNSUPPORTED;
+        }
+        if (e != hipSuccess) {
+            rh::set_hip_error(e, "rh_agc scratch");
+            return RH_ERR_HIP;
+        }
+    }
+    float *ordered = state ? scr + fresh_floats : nullptr, *rows = scr + fresh_floats + win_floats, *sq = rows + rows_floats;
     const unsigned wgrid = rh::grid_for((size_t)n_streams * kRmsWindow);
     if (state) {
         hipLaunchKernelGGL(k_agc_window_out, dim3(wgrid), dim3(256), 0, s, ordered, state, n_streams);
@@ -548,7 +570,7 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
         a.n = len;
         return a;
     };
-    auto par_grid = [&](uint64_t len) { return dim3(rh::grid_for((size_t)n_streams * ((len + 3) / 4) + 1)); };
+    auto par_grid = [&](uint64_t len) { return dim3(rh::grid_tiles((size_t)n_streams * ((len + 3) / 4) + 1)); };
     rh_status st = RH_OK;
     if (general) {
         // window sum -> dst and peak follower -> rows side by side, desired gain in place, then the gain chain with both candidates

@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what);
 // process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
 enum Knob {
     K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
-    K_LIMIT_SKEW, K_LIMIT_NIO, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_COUNT
+    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_COUNT
 };
 const char *knob(Knob k);
 void load_knobs();
@@ -73,21 +73,37 @@ hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s);
 // library's own streams; a foreign stream's buffer (a few hundred KiB) lives until the process ends.
 // The caller keeps `hold` (taken here) until its last launch that uses the buffer is enqueued: two host threads that launch on
 // the same stream then cannot interleave their initialisation and kernel launches.
-hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold);
+// What the last user of a stream's scratch left behind, for a user that can save itself work when IT was the last one (the scan
+// kernels: hand-off tables that the launch before has already cleared).  Zeroed when the buffer is (re)allocated and by every call
+// that does not ask for it (another user has written over the scratch since).  Read and written under `hold`.
+struct ScratchAux {
+    uint64_t tag;          // who / what shape (0: nobody)
+    uint32_t ticket_base;  // value of the scratch's ticket counter when the next launch starts
+    uint32_t parity;       // which of two tables the next launch works on
+};
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold, ScratchAux **aux = nullptr);
 // device-to-device copy as a launch on `hs` (hipMemcpyAsync DeviceToDevice makes the calling thread wait for the queue ahead of it)
 hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
 // rh_pipeline.hip: `s` has been synchronised and is about to go -- fused-pipeline handles whose launches went there are idle now
 // (they record their idle event lazily, on the stream of their last launch: never on a destroyed one).
 void rlm_stream_retired(hipStream_t s);
 
-// Grid for a memory-bound grid-stride kernel: enough 256-thread blocks to fill 256 CUs x 8,
-// capped so small inputs stay small (cdna_hip_programming.md G11).
+// Grid for a memory-bound grid-stride kernel whose lanes handle SMALL items (one sample, one frame): enough 256-thread blocks to
+// fill 256 CUs x 8, capped so that a workgroup has a few KiB to do.
 inline unsigned grid_for(size_t work_items, unsigned block = 256, unsigned max_blocks = 256 * 8) {
     size_t b = (work_items + block - 1) / block;
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
     return static_cast<unsigned>(b);
 }
+
+// Grid for an elementwise kernel whose lanes handle 16-BYTE VECTORS: one vector per lane -- a workgroup owns 256 consecutive vectors
+// (4 KiB) and exits; the dispatcher is the loop.  tools/ubench/write_bw.hip measured the capped grid-stride shape 20-48 % behind
+// this one (copy 512 MiB -> 512 MiB: 4.3-5.4 TB/s grid-stride, 6.35 TB/s with a workgroup per 4 KiB; the 1:2 expansion of i16 -> f32:
+// 0.170 -> 0.137 ms): what the chip works on at any moment is then ONE compact window of the address range per stream instead of
+// 2048 fronts 8 MiB apart.  (Not for 4-byte items: a workgroup with 1 KiB to do loses -- rh_channels_convert 0.72 -> 0.65.)  The
+// kernels keep their loops (a batch beyond 2^22 workgroups walks on); they simply run once.
+inline unsigned grid_tiles(size_t vectors, unsigned block = 256) { return grid_for(vectors, block, 1u << 22); }
 
 // Streaming (non-temporal) accesses for data touched once per launch: on gfx950 a plain read stream tops out at
 // ~6.3 TB/s, the same stream with `nt` at ~7.0 TB/s (tools/ubench/read_bw.hip).

@@ -223,7 +223,7 @@ rh_status launch_int_to_f32(float *dst, const T *src, size_t n, rh_stream stream
     if (!dst || !src) return RH_ERR_INVALID;
     constexpr int VEC = 16 / sizeof(T);
     if (aligned16(dst) && aligned16(src)) {
-        hipLaunchKernelGGL(k_int_to_f32<T>, dim3(rh::grid_for(n / VEC + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
+        hipLaunchKernelGGL(k_int_to_f32<T>, dim3(rh::grid_tiles(n / VEC + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
     } else {
         hipLaunchKernelGGL(k_int_to_f32_scalar<T>, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
     }
@@ -236,7 +236,7 @@ rh_status launch_f32_to_int(T *dst, const float *src, size_t n, rh_stream stream
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
     const int vec_ok = aligned16(src) && (reinterpret_cast<uintptr_t>(dst) % (4 * sizeof(T)) == 0);
-    hipLaunchKernelGGL(k_f32_to_int<T>, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
+    hipLaunchKernelGGL(k_f32_to_int<T>, dim3(rh::grid_tiles(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -359,7 +359,7 @@ static rh_status i32_like(float *dst, const int32_t *src, size_t n, float scale,
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_i32_to_f32, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, scale, (int)(aligned16(dst) && aligned16(src)));
+    hipLaunchKernelGGL(k_i32_to_f32, dim3(rh::grid_tiles(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, scale, (int)(aligned16(dst) && aligned16(src)));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -384,7 +384,7 @@ rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_st
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_amplify, dim3(rh::grid_for(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, factor, (int)(aligned16(dst) && aligned16(src)));
+    hipLaunchKernelGGL(k_amplify, dim3(rh::grid_tiles(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, factor, (int)(aligned16(dst) && aligned16(src)));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -79,6 +79,9 @@ struct LimitArgs {
     float *dst;
     const float *src;
     float *gran;               // [S][tiles][Rec<C>::stride] hand-off words: A[C] B[C] | Iend[C] | Pz[C] | Pend[C] (see Rec)
+    float *gran_other;         // the table of the NEXT launch on this stream: every tile sets its record there back to "not yet" when it is done
+                               // (nullptr: the next launch initialises its own table)
+    uint32_t ticket_base;      // value of ctl[0] when this launch starts (the counter is never reset)
     const float *state_in;     // [S][C][2] {integrator, peak} snapshot taken in front of the launch, or nullptr
     float *state_out;          // the caller's state, or nullptr
     uint32_t *ctl;             // [0] ticket
@@ -718,6 +721,9 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         else store_share<V, false>(dst, lds, nfloat, lane);
     }
     __builtin_amdgcn_wave_barrier();  // the rows are free for the next tile
+    // the hand-off table of the NEXT launch on this stream (the two alternate): this tile's record there back to "not yet" -- the launch
+    // in front of this one used it, nothing reads it now, and the next launch then needs no kernel in front of it to clear it
+    if (a.gran_other && wave == 0 && (uint32_t)lane < G) a.gran_other[((uint64_t)stream * a.tiles + tile) * G + lane] = __uint_as_float(kNotYet);
     RH_LP(6)
 }
 
@@ -772,8 +778,8 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
     };
     auto tile_full = [&](uint32_t ticket) { return ((uint64_t)(ticket / a.n_streams) + 1) * LW <= a.frames; };  // every share of the tile is whole
     if (threadIdx.x == 0) {
-        s_ticket[0] = atomicAdd(a.ctl, 1u);
-        s_ticket[1] = atomicAdd(a.ctl, 1u);
+        s_ticket[0] = atomicAdd(a.ctl, 1u) - a.ticket_base;
+        s_ticket[1] = atomicAdd(a.ctl, 1u) - a.ticket_base;
     }
     __syncthreads();
     uint32_t cur = s_ticket[0], nxt = s_ticket[1];
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
                 __syncthreads();                                   // (2)
             } else {
                 uint32_t ticket_ahead = 0;
-                if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u);  // stored by limit_tile in front of its second barrier
+                if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u) - a.ticket_base;  // stored by limit_tile in front of its second barrier
                 uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
                 const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
                 const float *src;
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
     }
     while (cur < total) {
         uint32_t ticket_ahead = 0;
-        if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u);  // stored by limit_tile in front of its second barrier
+        if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u) - a.ticket_base;  // stored by limit_tile in front of its second barrier
         uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
         const uint32_t tile = cur / a.n_streams, stream = cur - tile * a.n_streams;
         const float *src;
@@ -1073,23 +1079,41 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
         a.t = c.t;
     }
 
-    // scratch: control words + the carried-in states + the hand-off table, initialised by k_limit_init in front of the launch
+    // scratch: control words + the carried-in states + TWO hand-off tables.  A launch works on one of them and sets the other one's
+    // records back to "not yet" as its tiles finish, so the next launch of the same shape on this stream finds its table clean and its
+    // ticket counter where the host knows it to be: no kernel in front of it (k_limit_init and its boundary were 5 % of a 0.27 ms call).
+    // The first launch of a shape, a launch with a carried state (its snapshot is a kernel anyway) and a launch behind another user of
+    // the stream's scratch (rh::ScratchAux) initialise both tables.
     const size_t n_state = (size_t)n_streams * channels * 2;
-    const size_t gran_bytes = (size_t)n_streams * tiles64 * rec_stride(channels) * sizeof(float);
+    const size_t gran_bytes = (((size_t)n_streams * tiles64 * rec_stride(channels) * sizeof(float)) + 63) & ~size_t(63);
     const size_t head = 64 + ((n_state * 4 + 63) & ~size_t(63));
     unsigned char *scratch = nullptr;
     std::unique_lock<std::mutex> scratch_hold;
-    RH_HIP_TRY(rh::stream_scratch(s, head + gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold));
+    rh::ScratchAux *aux = nullptr;
+    RH_HIP_TRY(rh::stream_scratch(s, head + 2 * gran_bytes, reinterpret_cast<void **>(&scratch), scratch_hold, &aux));
+    uint64_t tag = 0x4c494d4954ull;  // "LIMIT", then the shape (FNV-1a)
+    for (uint64_t v : {(uint64_t)n_streams, tiles64, (uint64_t)channels, (uint64_t)head, (uint64_t)gran_bytes, (uint64_t)reinterpret_cast<uintptr_t>(scratch)}) tag = (tag ^ v) * 0x100000001b3ull;
+    tag |= 1;  // (never 0)
+    const char *init_knob = rh::knob(rh::K_LIMIT_INIT);
+    const bool clean = !state && aux->tag == tag && !(init_knob && init_knob[0] == '1');
     a.ctl = reinterpret_cast<uint32_t *>(scratch);
     a.status = rh::g_async_status;
     a.dma_top = rh::knob(rh::K_SCAN_DMA_TOP) ? (uint32_t)atoi(rh::knob(rh::K_SCAN_DMA_TOP)) : 1u;  // measured: 0.312 -> 0.286 ms (limiter), 0.234 -> 0.221 ms (biquad), 64 x 1 Mi frames
     a.spin = rh::knob(rh::K_SCAN_SPIN_LIMIT) ? (uint32_t)strtoul(rh::knob(rh::K_SCAN_SPIN_LIMIT), nullptr, 10) : kSpinLimit;
-    a.gran = reinterpret_cast<float *>(scratch + head);
     float *snap = reinterpret_cast<float *>(scratch + 64);
-    const uint64_t n_words = gran_bytes / 4;
-    const unsigned init_wgs = (unsigned)std::min<uint64_t>(1024, (std::max<uint64_t>(n_words, n_state) + 255) / 256);
-    hipLaunchKernelGGL(k_limit_init, dim3(init_wgs), dim3(256), 0, s, a.ctl, snap, state, state ? (uint32_t)n_state : 0u, reinterpret_cast<uint32_t *>(a.gran), n_words);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (!clean) {
+        const uint64_t n_words = 2 * gran_bytes / 4;
+        const unsigned init_wgs = (unsigned)std::min<uint64_t>(1024, (std::max<uint64_t>(n_words, n_state) + 255) / 256);
+        hipLaunchKernelGGL(k_limit_init, dim3(init_wgs), dim3(256), 0, s, a.ctl, snap, state, state ? (uint32_t)n_state : 0u, reinterpret_cast<uint32_t *>(scratch + head), n_words);
+        e = hipGetLastError();
+        aux->tag = state ? 0 : tag;
+        aux->ticket_base = 0;
+        aux->parity = 0;
+    }
+    a.gran = reinterpret_cast<float *>(scratch + head + (state ? 0 : aux->parity) * gran_bytes);
+    a.gran_other = state ? nullptr : reinterpret_cast<float *>(scratch + head + (aux->parity ^ 1u) * gran_bytes);
+    a.ticket_base = aux->ticket_base;
     if (state) a.state_in = snap, a.state_out = state;
     if (e == hipSuccess) {
         static int occupancy[sizeof(kVariants) / sizeof(kVariants[0])];  // asked once per variant (both instantiations share registers and LDS)
@@ -1111,9 +1135,14 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
             bool skew = v->fn_skew && grid < n_streams;  // see k_limit_scan: only with more streams than workgroups
             if (const char *k = rh::knob(rh::K_LIMIT_SKEW)) skew = v->fn_skew && k[0] == '1';  // tuning aid
             e = hipLaunchKernel(reinterpret_cast<const void *>(skew ? v->fn_skew : v->fn), dim3((uint32_t)grid), dim3(64 * (NW + (uint32_t)v->NIO)), args, 0, s);
+            if (e == hipSuccess && !state) {  // every workgroup takes two tickets ahead and one per tile it works on
+                aux->ticket_base += (uint32_t)(total + 2 * grid);
+                aux->parity ^= 1u;
+            }
         }
     }
     if (e != hipSuccess) {
+        aux->tag = 0;  // (whatever state the tables are in: the next call starts over)
         rh::set_hip_error(e, "rh_limit launch");
         return RH_ERR_HIP;
     }

@@ -261,8 +261,8 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host, 
         std::memset(&t, 0, sizeof(t));
         for (uint32_t i = 0; i < n; ++i) t.d[i] = MixDesc{srcs_host[first + i], start_host[first + i], len_host[first + i]};
         if (vec_ok) {
-            if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, dim3(rh::grid_for((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
-            else hipLaunchKernelGGL(k_mix_sum_v4<false>, dim3(rh::grid_for((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, dim3(rh::grid_tiles((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            else hipLaunchKernelGGL(k_mix_sum_v4<false>, dim3(rh::grid_tiles((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
         } else {
             if (first) hipLaunchKernelGGL(k_mix_sum<true>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
             else hipLaunchKernelGGL(k_mix_sum<false>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);

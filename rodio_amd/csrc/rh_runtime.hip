@@ -20,7 +20,7 @@ void set_hip_error(hipError_t e, const char *what) {
 
 namespace {
 const char *const kKnobNames[K_COUNT] = {"RH_AGC_SEQ", "RH_AGC_VEC", "RH_BIQUAD_NO_FALLBACK", "RH_BIQUAD_SEQ", "RH_BIQUAD_R", "RH_BIQUAD_NW", "RH_BIQUAD_WGS", "RH_LIMIT_SEQ",
-                                         "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_LIMIT_NIO", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
+                                         "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_LIMIT_NIO", "RH_LIMIT_INIT", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
                                          "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC", "RH_NO_MIX_FIRST", "RH_MIX_U", "RH_NO_CHUNK", "RH_CHUNK_HALF"};
 std::string g_knob_val[K_COUNT];
 bool g_knob_set[K_COUNT];
@@ -49,14 +49,18 @@ namespace {
 struct Scratch {
     void *p = nullptr;
     size_t cap = 0;
+    ScratchAux aux{0, 0, 0};
 };
 std::mutex g_scratch_mu;
 std::unordered_map<hipStream_t, Scratch> g_scratch;
 }  // namespace
-hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold) {
+hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold, ScratchAux **aux) {
     hold = std::unique_lock<std::mutex>(g_scratch_mu);
     Scratch &e = g_scratch[s];
+    if (aux) *aux = &e.aux;
+    else e.aux = ScratchAux{0, 0, 0};  // this caller writes over whatever the last one left
     if (e.cap < bytes) {
+        e.aux = ScratchAux{0, 0, 0};
         if (e.p) {  // launches on `s` may still be using it
             hipError_t w = hipStreamSynchronize(s);
             if (w != hipSuccess) return w;
@@ -86,7 +90,7 @@ static void drop_stream_scratch(hipStream_t s) {
 hipError_t fill_async(void *p, int value, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
     const uint32_t b = (uint32_t)value & 0xffu;
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(bytes / 16 + 1)), dim3(256), 0, s, static_cast<unsigned char *>(p), b * 0x01010101u, bytes);
+    hipLaunchKernelGGL(k_fill, dim3(grid_tiles(bytes / 16 + 1)), dim3(256), 0, s, static_cast<unsigned char *>(p), b * 0x01010101u, bytes);
     return hipGetLastError();
 }
 }  // namespace rh

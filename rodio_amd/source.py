@@ -417,14 +417,15 @@ def reverb_spatial_batch(x, sample_rate, duration_ns, amplitude, emitters, left,
     return out[:, :n_out]
 
 
-def biquad_batch(x, coeffs5, mode=1):
+def biquad_batch(x, coeffs5, mode=1, out=None):
     """rh_biquad over the rows of the device tensor x [S, frames*2] (stereo streams laid out back to
     back).  mode 0 = sequential (bit-exact), mode 1 = time-parallel scan."""
     _ensure()
     torch = _t()
     assert x.is_contiguous() and x.dim() == 2
     S, n = x.shape
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
     co = np.ascontiguousarray(coeffs5, dtype=np.float32)
     check(lib.rh_biquad(_ptr(out), _ptr(x), n // 2, 2, S, co.ctypes.data_as(_lib.f32p), None, mode, _stream()), "rh_biquad")
     return out

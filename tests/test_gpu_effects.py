@@ -113,9 +113,10 @@ from conftest import knobs as _env  # noqa: E402
 
 @pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2),
                                 dict(target_level=0.7, floor=6.0, absolute_max_gain=5.0), dict(attack_ns=0)])
-def test_agc_chains_equal_the_reference_order_kernel_bit_for_bit(G, O, kw):
+def test_agc_chains_equal_the_reference_order_kernel(G, O, kw):
     """rh_agc.hip takes the AGC apart along its dependency chains (window sum, peak follower, gain) and runs everything else in
-    parallel -- the same f32 operations in the same order as one lane walking agc.rs:433-504 sample by sample (k_agc_seq)."""
+    parallel -- the same f32 operations in the same order as one lane walking agc.rs:433-504 sample by sample (k_agc_seq): bit for bit
+    on the general path (any release), within one rounding on the default-parameter path, where select and clamp are one median."""
     import torch
 
     xs = [_programme(95 + s, 40000 + 4 * s) for s in range(4)]
@@ -131,6 +132,24 @@ def test_agc_chains_equal_the_reference_order_kernel_bit_for_bit(G, O, kw):
         assert np.array_equal(a, b)  # every operation the reference's
     else:  # release == 0: select and clamps as one median (rh_agc.hip, GainOp0): a rounding apart where two candidates tie
         assert float(np.max(np.abs(a - b))) <= 1e-6
+
+
+@pytest.mark.parametrize("S,n", [(1, 40001), (1, 32770), (3, 40003), (2, 65537)])
+def test_agc_one_stream_of_an_odd_length_above_the_square_pass_threshold(G, O, S, n):
+    """rows of n >= 32 768 samples take the parallel square pass, whose rows sit BEHIND the per-stream rows in the scratch:
+    with n_streams * n_samples not a multiple of 4 (one stream of 40 001 samples) its 16-byte stores and LDS-DMA fetches were 4 to 12
+    bytes off.  The region is rounded up to whole vectors now; these shapes are compared with the oracle and the reference-order kernel."""
+    import torch
+
+    xs = [_programme(300 + s, n + 8)[:n] for s in range(S)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    a = G.agc_batch(x, 48000).cpu().numpy()
+    with _env(RH_AGC_SEQ="1"):
+        b = G.agc_batch(x, 48000).cpu().numpy()
+    assert float(np.max(np.abs(a - b))) <= 1e-6
+    for s_ in range(S):
+        ref = O.TestSource(xs[s_], 1, 48000).automatic_gain_control().collect()
+        assert float(np.max(np.abs(a[s_] - ref))) <= TOL, s_
 
 
 # ---- rh_biquad mode 1: the dedicated time-parallel kernel (rh_biquad_scan.hip) ------------------------------------------

@@ -61,6 +61,38 @@ __global__ __launch_bounds__(256) void k_copy_tile(v4f *__restrict__ dst, const 
     for (int u = 0; u < U; ++u) st<SP>(dst + base + u * 256, v[u]);
 }
 
+// 1:2 expansion (the shape of i16 -> f32: 16 B in, 32 B out per lane-vector), one workgroup per tile of 256 * U input vectors, no loop.
+template <int U, int LP, int SP>
+__global__ __launch_bounds__(256) void k_expand_tile(v4f *__restrict__ dst, const v4f *__restrict__ src, size_t n) {
+    const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    v4f v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld<LP>(src + base + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        st<SP>(dst + 2 * (base + u * 256), v[u]);
+        st<SP>(dst + 2 * (base + u * 256) + 1, v[u] * 2.0f);
+    }
+}
+// ... and the grid-stride form the conversion kernels had (2 loads in flight, grid 2048)
+template <int SP>
+__global__ __launch_bounds__(256) void k_expand_gs(v4f *__restrict__ dst, const v4f *__restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+        const v4f a = ld<1>(src + i), b = ld<1>(src + i + stride);
+        st<SP>(dst + 2 * i, a);
+        st<SP>(dst + 2 * i + 1, a * 2.0f);
+        st<SP>(dst + 2 * (i + stride), b);
+        st<SP>(dst + 2 * (i + stride) + 1, b * 2.0f);
+    }
+    if (i < n) {
+        const v4f a = ld<1>(src + i);
+        st<SP>(dst + 2 * i, a);
+        st<SP>(dst + 2 * i + 1, a * 2.0f);
+    }
+}
+
 // Persistent tile copy with a software pipeline: the loads of tile k+1 are in flight while tile k is stored.
 template <int U, int LP, int SP>
 __global__ __launch_bounds__(256) void k_copy_pipe(v4f *__restrict__ dst, const v4f *__restrict__ src, size_t n) {
@@ -335,6 +367,24 @@ int main(int argc, char **argv) {
     IW(2, 1, 1)
     IW(4, 1, 1)
     IW(8, 1, 1)
+    {  // 1:2 expansion: half/2 bytes in, half bytes out
+        const size_t ne = n / 2;
+        const double Be = 0.75 * (double)half * 2.0 / 2.0 * 1.0;  // (half/2 read + half written)
+        auto rep2 = [&](const char *nm, double ms) { printf("%-84s %.4f ms  %.2f TB/s\n", nm, ms, 0.75 * (double)half / ms / 1e9); fflush(stdout); };
+        (void)Be;
+        rep2("expand 1:2, grid-stride (grid 2048, 2 loads in flight), plain stores", time_ms([&] { hipLaunchKernelGGL((k_expand_gs<0>), dim3(2048), dim3(256), 0, 0, b, a, ne); }));
+#define EX(U, LP, SP)                                                                                                                          \
+        {                                                                                                                                      \
+            snprintf(name, sizeof name, "expand 1:2, tile (one workgroup per %d KiB in, no loop), %s loads, %s stores", 4 * U, LP ? "nt" : "plain", SP ? "nt" : "plain"); \
+            rep2(name, time_ms([&] { hipLaunchKernelGGL((k_expand_tile<U, LP, SP>), dim3((unsigned)(ne / (256 * U))), dim3(256), 0, 0, b, a, ne); })); \
+        }
+        EX(1, 1, 0)
+        EX(2, 1, 0)
+        EX(4, 1, 0)
+        EX(1, 1, 1)
+        EX(2, 1, 1)
+        EX(1, 0, 0)
+    }
     printf("# check: %llu vectors of dst differed from src over all copy variants\n", total_bad);
     return total_bad != 0;
 }
