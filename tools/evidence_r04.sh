@@ -19,9 +19,11 @@ case "$1" in
     for c in 3 5 ragged limit agc biquad; do python bench.py --config $c > $E/r04_bench_$c.json 2>/dev/null; done
     for c in limit agc biquad; do python bench.py --config $c --sources 2048 --frames 32768 > $E/r04_bench_${c}_2048.json 2>/dev/null; done
     for c in limit biquad 3 5 ragged; do
+        case $c in limit) export RH_PROF_KERNEL=k_limit_scan;; biquad) export RH_PROF_KERNEL=k_biquad_scan;; 3) export RH_PROF_KERNEL=reverb_spatial;; 5) export RH_PROF_KERNEL=k_int_to_f32;; *) export RH_PROF_KERNEL=k_rlm;; esac
         bash tools/pmc_cmd.sh r04_$c python bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
         cp gpurun_out/prof/r04_$c/summary.txt $E/r04_${c}_kernel_trace_pmc.txt
     done
+    export RH_PROF_KERNEL=k_agc
     bash tools/pmc_cmd.sh r04_agc python bench.py --config agc --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
     cp gpurun_out/prof/r04_agc/summary.txt $E/r04_agc_64x1Mi_kernel_trace_pmc.txt
     ;;
