@@ -138,6 +138,10 @@ struct Params {
     uint32_t gran_cols, col0;
     const float *st_win;          // summed filter state (scan basis) at output frame st_m0
     float *st_wout;               // ... at st_m0 + st_active, written by the lane that would come next
+    // k_rlm_fast<RAG, SUMF>: 1 = a tile also handles its own (tile, source) pairs in which the source is about to end (rag_run_pairs),
+    // on top of its mix of the stable sources and before it stores; the per-source aggregate rows lie in front of `gran`.  Sources
+    // that are not among the longest end between output frames rag_pairs_from and rag_pairs_to: only tiles near that range look.
+    uint32_t rag_merge, rag_pairs_from, rag_pairs_to;
     Uniforms u;
 };
 
@@ -241,6 +245,13 @@ __device__ __forceinline__ const void *uniform_ptr(const void *q) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
+#ifndef RH_GLDS_POL
+#ifdef RH_GLDS_PLAIN
+#define RH_GLDS_POL ""
+#else
+#define RH_GLDS_POL " nt"
+#endif
+#endif
 __device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
     const void *sbase = uniform_ptr(sbase_);
     const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
@@ -254,9 +265,6 @@ __device__ __forceinline__ void glds16(const void *sbase_, uint32_t voff, uint32
 #endif
     // nt: every source byte is read once per launch -- a streaming (non-temporal) fetch does not displace what the
     // caches could reuse and, measured, lifts the achievable read rate from 6.3 to 7.0 TB/s (tools/ubench/read_bw.hip)
-#ifndef RH_GLDS_POL
-#define RH_GLDS_POL " nt"
-#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" RH_GLDS_POL "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
@@ -271,6 +279,55 @@ __device__ __forceinline__ void glds16_sc1(const void *sbase_, uint32_t voff, ui
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
+}
+// N LDS-DMA instructions whose sources AND destinations lie 1 KiB apart (lane l of instruction k: sbase + voff + 1024 k -> lds_dst +
+// 1024 k + 16 l): the instruction's immediate offset moves both addresses, so the run shares ONE M0 and ONE offset register.
+// Groups of 8 (immediates -4096 .. 3072 around a base 4 KiB in) and of 4 (0 .. 3072).
+__device__ __forceinline__ void glds16_x8(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
+    const void *sbase = uniform_ptr(sbase_);
+    const uint32_t lds_mid = __builtin_amdgcn_readfirstlane(lds_dst_ + 4096u);
+    const uint32_t vmid = voff + 4096u;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:-4096" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:-3072" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:-2048" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:-1024" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072" RH_GLDS_POL "\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(vmid), "s"(sbase), "s"(lds_mid)
+                 : "memory");
+}
+__device__ __forceinline__ void glds16_x4(const void *sbase_, uint32_t voff, uint32_t lds_dst_) {
+    const void *sbase = uniform_ptr(sbase_);
+    const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" RH_GLDS_POL "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:3072" RH_GLDS_POL "\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glds16_run(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+    if constexpr (N >= 8) {
+        glds16_x8(sbase, voff, lds_dst);
+        glds16_run<N - 8>(sbase, voff + 8192u, lds_dst + 8192u);
+    } else if constexpr (N >= 4) {
+        glds16_x4(sbase, voff, lds_dst);
+        glds16_run<N - 4>(sbase, voff + 4096u, lds_dst + 4096u);
+    } else if constexpr (N >= 1) {
+        glds16(sbase, voff, lds_dst);
+        glds16_run<N - 1>(sbase, voff + 1024u, lds_dst + 1024u);
+    }
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -347,6 +404,13 @@ __device__ __forceinline__ v2f vmul_s(v2f a, float s) { return v2f{a.x * s, a.y 
 __device__ __forceinline__ float vmul_s(float a, float s) { return a * s; }
 __device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
 __device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+
+// (the pairs of a ragged batch in which a source is about to end: defined below, next to k_rlm_resid)
+__device__ __forceinline__ uint32_t rag_find_pairs(const Params &p, const uint32_t m_tile0, const uint32_t m_stable, const int lane, lds_u8 *lds, const uint32_t list_off);
+template <int R, int KV>
+__device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long long *const rows, const uint32_t tile, const uint32_t n_pairs, const int lane, lds_u8 *lds, const uint32_t lds0,
+                                              const uint32_t list_off, const uint32_t i_base, const uint32_t nvec, const uint32_t (&goff)[KV], const int (&offA)[R + 2], const float (&wgt)[R + 2],
+                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], v2f (&acc)[R]);
 
 // SUMF (with RAG): sum first -- the stable sources of a tile share the tile's span, taps and weights, so their spans are SUMMED as
 // they land (one FMA per float) and the lerp, the zero-state filter and everything behind it run once, on the sum (§4.6).
@@ -579,6 +643,19 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
             while (k < S && dwords[8 * (uint64_t)k + 3] < m_stable) ++k;
             return k;
         };
+        // Inside a source (no tile edge, the span fills all but the last instruction) the DMA instructions of a stage lie 1 KiB apart
+        // in memory as in the LDS: they go out as runs that share one M0 and one offset register (glds16_run) -- a tile in the middle
+        // of the batch, i.e. nearly every one.
+        constexpr int KF = KV - 1;
+        const bool lin = SUMF && !edge && nvec >= (uint32_t)(KF * 64);
+        auto stage_rag = [&](const void *data, uint32_t stage_off) {
+            if (lin) {
+                glds16_run<KF>(data, goff[0], lds0 + stage_off);
+                glds16(data, goff[KV - 1], lds0 + stage_off + (KV - 1) * 1024);
+            } else {
+                stage_source(data, stage_off);
+            }
+        };
         uint32_t q[NS + 1];
         uint32_t issued = 0, waited = 0;
         {
@@ -587,7 +664,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
             for (int d = 0; d < NS; ++d) {
                 q[d] = nxt;
                 if (nxt < S) {
-                    stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)nxt], d * kStage);
+                    stage_rag((const void *)(uintptr_t)desc[4 * (uint64_t)nxt], d * kStage);
                     ++issued;
                     nxt = next_stable(nxt + 1);
                 }
@@ -617,19 +694,29 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
             v4f accv[KV];
 #pragma unroll
             for (int k = 0; k < KV; ++k) accv[k] = v4f{0.f, 0.f, 0.f, 0.f};
+            // Descriptor words are scalar loads, and a scalar load that misses its cache is a round trip to L2 the wave sits out (the
+            // phase profile of the first version: a third of a heavy tile's time between "the stage has landed" and "the next DMA is out").
+            // So every word is asked for an iteration ahead of its use: the row of q[NS], the gain of q[1], the end of the source behind q[NS].
+            uint64_t ptr_next = q[NS] < S ? desc[4 * (uint64_t)q[NS]] : 0;
+            float g_cur = q[0] < S ? dgain[8 * (uint64_t)q[0] + 4] : 0.f;
             while (q[0] < S) {
+                const uint32_t cand = q[NS] + 1;  // almost always stable too
+                const uint32_t cand_end = cand < S ? dwords[8 * (uint64_t)cand + 3] : 0u;
+                const float g_nxt = q[1] < S ? dgain[8 * (uint64_t)q[1] + 4] : 0.f;
                 ++waited;
                 wait_groups<KV, NS>((int)(issued - waited));  // the stage of q[0] has landed
+                RH_PH(2)
                 const lds_u8 *buf = lds + st_cur;
                 v4f v[KV];
 #pragma unroll
                 for (int k = 0; k < KV; ++k) v[k] = *(const lds_f4 *)(buf + k * 1024 + lane * 16);
-                const float g = dgain[8 * (uint64_t)q[0] + 4];
+                const float g = g_cur;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the span is in registers: its stage is free
                 if (q[NS] < S) {
-                    stage_source((const void *)(uintptr_t)desc[4 * (uint64_t)q[NS]], st_cur);
+                    stage_rag((const void *)(uintptr_t)ptr_next, st_cur);
                     ++issued;
                 }
+                RH_PH(1)
 #pragma unroll
                 for (int k = 0; k < KV; ++k) {
                     accv[k].x = fma_(g, v[k].x, accv[k].x);
@@ -641,7 +728,10 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
                 if (st_cur >= NS * kStage) st_cur = 0;
 #pragma unroll
                 for (int d = 0; d < NS; ++d) q[d] = q[d + 1];
-                q[NS] = q[NS] < S ? next_stable(q[NS] + 1) : S;
+                q[NS] = cand >= S ? S : (cand_end >= m_stable ? cand : next_stable(cand + 1));
+                ptr_next = q[NS] < S ? desc[4 * (uint64_t)q[NS]] : 0;
+                g_cur = g_nxt;
+                RH_PH(4)
             }
             wait_vm<0>();
             // the summed span takes the place of a source's in stage 0: one lerp, one zero-state run
@@ -789,6 +879,19 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) CH::set(acc[r], ch, fma_(p.u.g[r][0], Q[2 * ch], fma_(p.u.g[r][1], Q[2 * ch + 1], CH::get(acc[r], ch))));
+        }
+        if constexpr (RAG && SUMF && C == 2) {
+            // The tile's own pairs in which a source is about to end, onto the mix in registers (the ring's first two stages and
+            // 128 bytes behind the ring are theirs now).  Few tiles have any, and those are the lighter ones.
+            const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
+            const uint32_t m_stable = m_far < Mout ? m_far : Mout;
+            if (p.rag_merge && live && m_stable > p.rag_pairs_from && m_tile0 < p.rag_pairs_to) {
+                RH_PH(5)
+                const uint32_t n_pairs = rag_find_pairs(p, m_tile0, m_stable, lane, lds, NS * kStage);
+                if (n_pairs)
+                    rag_run_pairs<R, KV>(p, p.gran - (uint64_t)p.n_sources * p.n_tiles * 4, tile, n_pairs, lane, lds, lds0, NS * kStage, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
+                RH_PH(3)
+            }
         }
     }
 #ifdef RH_PHASE_PROFILE
@@ -1761,10 +1864,17 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         j = j < nvec ? j : nvec - 1;  // past the end of the row: its last vector again (finite, never a tap of a stored frame)
         goff[k] = j * 16;
     }
+    // every chunk but a row's last lies whole inside the row: its DMA instructions are 1 KiB apart in memory as in the LDS and go
+    // out as one run (one M0, one offset register: glds16_run)
+    const bool lin = v0 + (uint32_t)(KV * 64) <= nvec;
     auto stage_source = [&](uint32_t s_, uint32_t stage) {
         const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+        if (lin) {
+            glds16_run<KV>(data, goff[0], lds0 + stage * kStage);
+        } else {
 #pragma unroll
-        for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+        }
     };
     if (S) stage_source(0, 0);  // the first two chunks are on their way while the lane works out its taps
     if (S > 1) stage_source(1, 1);
@@ -2097,121 +2207,87 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
 }
 
 // =================================================================================================
-// k_rlm_resid -- second half of a ragged filtered batch (behind k_rlm_fast<RAG>): the (tile, source) pairs in which
-// the source is NOT stable, i.e. ends inside the tile or within the J tiles after it.  There are at most J+2 such tiles
-// per source, so this kernel is small however large the batch: a tile finds its pairs with a ballot over the
-// descriptors and handles each one start to finish -- stage, lerp, zero-state run (masked past the end of the
-// source), scan, publish the source's own aggregate, poll the predecessors that hold one, correct frame by frame --
-// adding onto what the first half stored.  Same tile geometry, tables and aggregate rows as k_rlm_wave.
+// The (tile, source) pairs of a ragged filtered batch in which the source is NOT stable, i.e. ends inside the tile or within the J
+// tiles after it.  There are at most J+2 such tiles per source, so this part is small however large the batch: a tile finds its
+// pairs with a ballot over the descriptors (rag_find_pairs) and handles each one start to finish (rag_run_pairs) -- stage, lerp,
+// zero-state run (masked past the end of the source), scan, publish the source's own aggregate, poll the predecessors that hold
+// one, correct frame by frame -- adding onto the tile's mix of the stable sources.  Tile geometry, tables and aggregate rows are
+// those of k_rlm_wave.  Two callers: k_rlm_fast<RAG, SUMF> itself, behind its own part of the tile (Params::rag_merge: the mix is
+// still in registers, and the pairs fill in behind the stable sources of the lighter tiles); k_rlm_resid, a launch of its own
+// behind a first half that has stored its tiles (RH_RAG_TWO_KERNELS, and the per-source first half of diagnostics builds).
 // =================================================================================================
-template <int R, int KV>
-__global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    lds_u8 *const lds = (lds_u8 *)smem;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
-    const int lane = threadIdx.x;
-    // tiles are numbered in arrival order, like everywhere else: a pair polls predecessor tiles, which then hold earlier tickets
-    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
-    constexpr uint32_t L = 64u * R;
-    const uint32_t m_tile0 = tile * L;
-    const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
-    const bool first = (m0 == 0);
-    const uint32_t Mout = (uint32_t)p.out_frames;
-    const uint32_t ncol = p.n_tiles;
+// The tile's pairs: their source indices, in source order, as a list in the LDS at `list_off` (the host keeps batches with more than
+// 24 such sources in one tile on k_rlm_wave).  Returns how many.
+constexpr uint32_t kMaxPairs = 32;
+__device__ __forceinline__ uint32_t rag_find_pairs(const Params &p, const uint32_t m_tile0, const uint32_t m_stable, const int lane, lds_u8 *lds, const uint32_t list_off) {
     const uint32_t S = p.n_sources;
-    const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
-    const uint32_t m_stable = m_far < Mout ? m_far : Mout;  // sources that last as long as the mix are the first half's to the end
-    // ---- which sources are this tile's: still here, not stable ----
-    typedef __attribute__((address_space(4))) const uint32_t cu32;
-    cu32 *const desc = (cu32 *)(uintptr_t)p.srcs;
     const uint32_t *const dsrc = reinterpret_cast<const uint32_t *>(p.srcs);
-    bool any = false;
+    uint32_t n_pairs = 0;
     for (uint32_t b = 0; b < S; b += 64) {
         const uint32_t q = b + lane;
         const uint32_t ms = q < S ? dsrc[8 * (uint64_t)q + 3] : 0u;
-        any = any || __any(ms > m_tile0 && ms < m_stable);
+        const bool mine = ms > m_tile0 && ms < m_stable;  // still here, not stable
+        const unsigned long long mask = __ballot(mine);
+        const uint32_t rank = n_pairs + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (mine && rank < kMaxPairs) *(RH_LDS uint32_t *)(lds + list_off + rank * 4u) = q;
+        n_pairs += (uint32_t)__popcll(mask);
     }
-    if (!any) return;  // what k_rlm_fast<RAG> stored for this tile is final
-
-    uint32_t i_base, nvec;
-    {
-        uint64_t ib, ie;
-        uint32_t nn;
-        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
-        ib &= ~15ull;
-        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
-        ie += 1;
-        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
-        if (nv > (uint32_t)(KV * 64)) nv = KV * 64;
-        i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);
-        nvec = __builtin_amdgcn_readfirstlane(nv);
+    if (n_pairs > kMaxPairs && lane == 0) atomicOr(p.status, 1u);  // (never: the host counted them.  The status word fails the call)
+    n_pairs = __builtin_amdgcn_readfirstlane(n_pairs < kMaxPairs ? n_pairs : kMaxPairs);
+    if (n_pairs) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
-    uint32_t goff[KV];
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-        uint32_t j = lane + k * 64;
-        j = j < nvec ? j : nvec - 1;
-        goff[k] = (i_base + 2u * j) * 8u;
-    }
-    int offA[R + 2];
-    float wgt[R + 2];
-    {
-        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
-#pragma unroll
-        for (int rr = 0; rr < R + 2; ++rr) {
-            const bool dummy = first && rr < 2;
-            uint64_t i;
-            uint32_t num;
-            cursor_resolve(c, p, i, num);
-            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
-            wgt[rr] = dummy ? 0.0f : (float)num / p.Tf;
-            if (!dummy) cursor_next(c, p);
-        }
-    }
-    const Tables *__restrict__ tb = p.tabs;
-    float lM[4], b15[4], b31[4], kM[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        lM[q] = tb->laneM[lane][q];
-        b15[q] = tb->bc15M[lane][q];
-        b31[q] = tb->bc31M[lane][q];
-        kM[q] = tb->lookM[lane & (kMaxLook - 1)][q];
-    }
-    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
+    return n_pairs;
+}
+// The pairs one after the other, the span of the NEXT one already on its way (two stages of KV KiB at lds + 0 and lds + KV KiB): a
+// pair costs a memory round trip to stage and another to poll, and nothing else of this tile could hide them.  `rows`: the
+// per-source aggregate rows.  offA / wgt: taps and weights of the lane's R + 2 frames (the caller's: the tile geometry is shared).
+template <int R, int KV>
+__device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long long *const rows, const uint32_t tile, const uint32_t n_pairs, const int lane, lds_u8 *lds, const uint32_t lds0,
+                                              const uint32_t list_off, const uint32_t i_base, const uint32_t nvec, const uint32_t (&goff)[KV], const int (&offA)[R + 2], const float (&wgt)[R + 2],
+                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], v2f (&acc)[R]) {
+    constexpr uint32_t L = 64u * R, kStage = KV * 1024;
+    const uint32_t m_tile0 = tile * L, m0 = m_tile0 + (uint32_t)lane * R;
+    const bool first = (m0 == 0);
+    const uint32_t ncol = p.n_tiles;
     const uint32_t Jc = p.J < tile ? p.J : tile;
-
-    v2f acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] = v2f{0.0f, 0.0f};
-        if (m0 + r < Mout) {
-            const float2 v = *reinterpret_cast<const float2 *>(p.out + (uint64_t)(m0 + r) * 2);
-            acc[r] = v2f{v.x, v.y};
-        }
-    }
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    cu32 *const desc = (cu32 *)(uintptr_t)p.srcs;
+    const float b0 = p.u.b0, c1 = p.u.c1, c2 = p.u.c2, na1 = -p.u.a1, na2 = -p.u.a2;
     bool dead = false;
-    for (uint32_t s = 0; s < S; ++s) {
-        const uint32_t Ms = desc[8 * (uint64_t)s + 3];
-        if (!(Ms > m_tile0 && Ms < m_stable)) continue;  // uniform
+    auto stage_pair = [&](uint32_t s, uint32_t stage_off) {  // (lanes past the source's end re-fetch its last vector: finite data nothing valid reads)
         const uint64_t plo = desc[8 * (uint64_t)s], phi = desc[8 * (uint64_t)s + 1];
         const void *data = (const void *)(uintptr_t)(plo | (phi << 32));
         const uint32_t Ns = desc[8 * (uint64_t)s + 2];
-        const float g = __uint_as_float(desc[8 * (uint64_t)s + 4]);
-        // stage the tile's span of this source (lanes past its end re-fetch its last vector: finite data nothing valid reads)
         if (i_base + 2u * nvec <= Ns) {
 #pragma unroll
-            for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + k * 1024);
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
         } else {
             const uint32_t lastoff = ((Ns - 1) & ~1u) * 8u;
 #pragma unroll
-            for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + k * 1024);
+            for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + stage_off + k * 1024);
         }
-        wait_vm<0>();
+    };
+    auto pair_at = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const RH_LDS uint32_t *)(lds + list_off + i * 4u)); };
+    stage_pair(pair_at(0), 0);
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const uint32_t s = pair_at(i);
+        const lds_u8 *const buf = lds + (i & 1u) * kStage;
+        if (i + 1 < n_pairs) {
+            stage_pair(pair_at(i + 1), ((i + 1) & 1u) * kStage);
+            wait_vm<KV>();  // this pair's span has landed when only the next one's is outstanding
+        } else {
+            wait_vm<0>();
+        }
+        const uint32_t Ms = desc[8 * (uint64_t)s + 3];
+        const uint32_t Ns = desc[8 * (uint64_t)s + 2];
+        const float g = __uint_as_float(desc[8 * (uint64_t)s + 4]);
         const uint32_t dthr = Ns - 1 - i_base;  // Ms > m_tile0 => i_base <= Ns-1
         const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
         const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
         auto tap = [&](int rr) -> v2f {
-            const v2f a = *(const lds_f2 *)(lds + offA[rr]), b = *(const lds_f2 *)(lds + offA[rr] + 8);
+            const v2f a = *(const lds_f2 *)(buf + offA[rr]), b = *(const lds_f2 *)(buf + offA[rr] + 8);
             v2f x;
             x.x = fma_(b.x - a.x, wgt[rr], a.x);
             x.y = fma_(b.y - a.y, wgt[rr], a.y);
@@ -2238,7 +2314,7 @@ __global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
             x2 = x1;
             x1 = x;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free for the next pair
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free for the pair after next
         float P[4] = {0.f, 0.f, 0.f, 0.f};
         mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
         mat_acc(p.u.Tm, w1.y * g, w2.y * g, P[2], P[3]);
@@ -2266,7 +2342,7 @@ __global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
             mat_acc(b31, q0, q1, P[0], P[1]);
             mat_acc(b31, q2, q3, P[2], P[3]);
         }
-        unsigned long long *const row = p.gran + (uint64_t)s * ncol * 4;
+        unsigned long long *const row = rows + (uint64_t)s * ncol * 4;
         {  // this source's own aggregate for the tile (a later tile of it polls for it)
             const float e0 = readlane_f(P[0], 63), e1 = readlane_f(P[1], 63);
             const float e2 = readlane_f(P[2], 63), e3 = readlane_f(P[3], 63);
@@ -2332,6 +2408,82 @@ __global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
             acc[r].y += v ? hy : 0.0f;
         }
     }
+}
+
+// k_rlm_resid -- the pairs as a launch of their own, on top of what a first half has stored.
+template <int R, int KV>
+__global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    const int lane = threadIdx.x;
+    // tiles are numbered in arrival order, like everywhere else: a pair polls predecessor tiles, which then hold earlier tickets
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket, 1u) - p.ticket_base : 0u);
+    constexpr uint32_t L = 64u * R;
+    const uint32_t m_tile0 = tile * L;
+    const uint32_t m0 = m_tile0 + (uint32_t)lane * R;
+    const bool first = (m0 == 0);
+    const uint32_t Mout = (uint32_t)p.out_frames;
+    const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
+    const uint32_t m_stable = m_far < Mout ? m_far : Mout;  // sources that last as long as the mix are the first half's to the end
+    constexpr uint32_t kList = 2 * KV * 1024;
+    const uint32_t n_pairs = rag_find_pairs(p, m_tile0, m_stable, lane, lds, kList);
+    if (!n_pairs) return;  // what k_rlm_fast<RAG> stored for this tile is final
+
+    uint32_t i_base, nvec;
+    {
+        uint64_t ib, ie;
+        uint32_t nn;
+        cursor_resolve(cursor_at(m_tile0 >= 2 ? m_tile0 - 2 : 0, p), p, ib, nn);
+        ib &= ~15ull;
+        cursor_resolve(cursor_at((uint64_t)m_tile0 + L - 1, p), p, ie, nn);
+        ie += 1;
+        uint32_t nv = (uint32_t)((ie - ib + 2) / 2);
+        if (nv > (uint32_t)(KV * 64)) nv = KV * 64;
+        i_base = __builtin_amdgcn_readfirstlane((uint32_t)ib);
+        nvec = __builtin_amdgcn_readfirstlane(nv);
+    }
+    uint32_t goff[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        uint32_t j = lane + k * 64;
+        j = j < nvec ? j : nvec - 1;
+        goff[k] = (i_base + 2u * j) * 8u;
+    }
+    int offA[R + 2];
+    float wgt[R + 2];
+    {
+        Cursor c = cursor_at(first ? 0 : m0 - 2, p);
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            const bool dummy = first && rr < 2;
+            uint64_t i;
+            uint32_t num;
+            cursor_resolve(c, p, i, num);
+            offA[rr] = dummy ? 0 : (int)(((uint32_t)i - i_base) * 8u);
+            wgt[rr] = dummy ? 0.0f : (float)num / p.Tf;
+            if (!dummy) cursor_next(c, p);
+        }
+    }
+    const Tables *__restrict__ tb = p.tabs;
+    float lM[4], b15[4], b31[4], kM[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lM[q] = tb->laneM[lane][q];
+        b15[q] = tb->bc15M[lane][q];
+        b31[q] = tb->bc31M[lane][q];
+        kM[q] = tb->lookM[lane & (kMaxLook - 1)][q];
+    }
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = v2f{0.0f, 0.0f};
+        if (m0 + r < Mout) {
+            const float2 v = *reinterpret_cast<const float2 *>(p.out + (uint64_t)(m0 + r) * 2);
+            acc[r] = v2f{v.x, v.y};
+        }
+    }
+    rag_run_pairs<R, KV>(p, p.gran, tile, n_pairs, lane, lds, lds0, kList, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
     float *o = p.out + (uint64_t)m0 * 2;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -2439,13 +2591,18 @@ const Variant kWave[] = {
 // k_rlm_fast<.., RAG>: the first half of a ragged filtered batch, in the tile sizes of the general kernel (both halves
 // share the tile geometry, the tables and the aggregate rows)
 #ifdef RH_RAG_NO_SUMF  // diagnostics builds: the per-source first half
-#define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true>, &k_rlm_resid<r, kv>}
+#define RH_RAGN(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, true>, &k_rlm_resid<r, kv>}
 #else
-#define RH_RAG(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true, 2, true>, &k_rlm_resid<r, kv>}
+#define RH_RAGN(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, true, 2, true>, &k_rlm_resid<r, kv>}
 #endif
+#define RH_RAG(r, kv) RH_RAGN(r, kv, 2)
+// Deeper rings for the long runs (one wave per SIMD whatever the LDS request: four stages of 9 KiB still fit four times): the tiles of
+// a ragged batch carry unequal loads, the light ones leave early, and the heavy ones that remain are then bound by what ONE wave
+// keeps in flight.
 const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
+    RH_RAGN(14, 7, 3), RH_RAGN(14, 8, 3), RH_RAGN(18, 9, 3), RH_RAGN(18, 10, 3), RH_RAGN(14, 7, 4), RH_RAGN(14, 8, 4), RH_RAGN(18, 9, 4), RH_RAGN(18, 10, 4),
 };
 // mono (C = 1): a frame is 4 bytes, so a stage holds twice the frames per KiB
 #define RH_FAST1(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, false, 1>, &k_rlm_fast<r, kv, ns, false, false, 1>}
@@ -2463,6 +2620,7 @@ const Variant kWave1[] = {
 #undef RH_FAST1
 #undef RH_WAVE1
 #undef RH_RAG
+#undef RH_RAGN
 #undef RH_FAST
 #undef RH_WAVE
 struct VariantTab {
@@ -2541,6 +2699,7 @@ struct rh_rlm {
     Plan *plan = nullptr;   // chosen by set_sources
     uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
     uint32_t rag_frames = 0;  // pair plan: the length of the sources that last as long as the mix
+    uint32_t rag_pairs_from = 0, rag_pairs_to = 0;  // ... and the output frames between which the other sources end
     uint32_t eq_frames = 0;
     bool equal = true;
     std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
@@ -2962,13 +3121,15 @@ bool pair_ok(rh_rlm *p, const Plan &pl) {
     const uint64_t M = p->out_frames, L = 64ull * pl.v->R, J = pl.J;
     const uint64_t tiles = (M + L - 1) / L;
     if (!tiles) return false;
-    uint32_t frames_of_longest = 0, most = 0;
+    uint32_t frames_of_longest = 0, most = 0, ends_from = 0xffffffffu, ends_to = 0;
     std::vector<uint32_t> pairs((size_t)tiles, 0u);
     for (const SrcDesc &d : p->h_desc) {
         if (d.out_frames == M) {
             if (frames_of_longest && frames_of_longest != d.frames) return false;
             frames_of_longest = d.frames;
         } else if (d.out_frames > 0) {
+            ends_from = std::min(ends_from, d.out_frames);
+            ends_to = std::max(ends_to, d.out_frames);
             const uint64_t t_end = (d.out_frames - 1) / L;                                              // the tile the source ends in
             const uint64_t t_lo = (uint64_t)d.out_frames / L > J ? (uint64_t)d.out_frames / L - J : 0;  // first tile with out_frames < (t+1+J)*L
             for (uint64_t t = t_lo; t <= t_end && t < tiles; ++t) most = std::max(most, ++pairs[(size_t)t]);
@@ -2976,6 +3137,8 @@ bool pair_ok(rh_rlm *p, const Plan &pl) {
     }
     if (!frames_of_longest || most > 24) return false;
     p->rag_frames = frames_of_longest;
+    p->rag_pairs_from = ends_from;
+    p->rag_pairs_to = ends_to;
     return true;
 }
 
@@ -3099,7 +3262,19 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
         st = RH_ERR_INVALID;
     }
-    if (st == RH_OK && p->filt && !mono && make_plan(p, p->pair, tab_of(kRag), false, g, 0, 0) != RH_OK) p->pair.v = nullptr;  // optional (stereo only)
+    if (st == RH_OK && p->filt && !mono) {  // optional (stereo only).  It follows the overrides when it has that geometry; otherwise the longest runs that
+        // still give every CU three tiles (measured on 256 sources of [N/2, N] frames: 0.366 / 0.352 / 0.336 / 0.328 / 0.319 / 0.319 ms for
+        // 6 / 8 / 10 / 12 / 14 / 18 frames per lane -- the first half sums first, so a tile's fixed costs are all that is left to amortise)
+        rh_status ps = RH_ERR_UNSUPPORTED;
+        if (cfg->frames_per_lane || cfg->ring_stages) ps = make_plan(p, p->pair, tab_of(kRag), false, g, cfg->frames_per_lane, cfg->ring_stages);
+        for (uint32_t R : {18u, 14u, 12u, 10u}) {
+            if (ps == RH_OK) break;
+            const uint64_t M = g.out_frames ? g.out_frames : 1, tiles = (M + 64ull * R - 1) / (64ull * R);
+            if (tiles >= 3ull * (uint64_t)rh::g_num_cus) ps = make_plan(p, p->pair, tab_of(kRag), false, g, R, 2);
+        }
+        if (ps != RH_OK) ps = make_plan(p, p->pair, tab_of(kRag), false, g, 0, 0);
+        if (ps != RH_OK) p->pair.v = nullptr;
+    }
     hipError_t e = hipSuccess;
     if (st == RH_OK) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
@@ -3462,6 +3637,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     k.J = pl.J;
     k.ticket_base = p->ticket_base;
     k.direct = 0;
+    k.rag_merge = k.rag_pairs_from = k.rag_pairs_to = 0;
     k.prof = p->d_prof;
     k.eq_frames = p->eq_frames;
     k.batch_streams = batch_streams;
@@ -3487,11 +3663,24 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         k1.gran = p->d_gran + (uint64_t)count * p->n_tiles * 4;
         k1.eq_frames = p->rag_frames;  // the sources that last as long as the mix (one length): the end-of-source handling is theirs
         void *args1[] = {&k1};
-        hipError_t e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->filt), dim3((uint32_t)grid), dim3(64), args1, pl.lds_bytes, s);
-        if (e1 == hipSuccess) {
-            p->ticket_base += (uint32_t)grid;
+#ifdef RH_RAG_NO_SUMF
+        const bool merge = false;
+#else
+        const bool merge = !rh::knob(rh::K_RAG_TWO_KERNELS);  // the pairs inside the first kernel (Params::rag_merge)
+#endif
+        k1.rag_merge = merge ? 1u : 0u;
+        k1.rag_pairs_from = p->rag_pairs_from;
+        k1.rag_pairs_to = p->rag_pairs_to;
+        uint32_t lds1 = pl.lds_bytes + 128u;  // (the pair list behind the ring)
+        if (const char *w = rh::knob(rh::K_RAG_RESIDENT)) {  // tuning aid: at most this many tiles of the first half on a CU at once
+            const int want = atoi(w);
+            if (want >= 2 && want < 8) lds1 = std::max(lds1, (kLdsGranules / (uint32_t)want) * kLdsGranule);
+        }
+        hipError_t e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->filt), dim3((uint32_t)grid), dim3(64), args1, lds1, s);
+        if (e1 == hipSuccess) p->ticket_base += (uint32_t)grid;
+        if (e1 == hipSuccess && !merge) {
             k.ticket_base = p->ticket_base;
-            e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->plain), dim3((uint32_t)grid), dim3(64), args, (uint32_t)pl.v->KV * 1024u, s);
+            e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->plain), dim3((uint32_t)grid), dim3(64), args, 2u * (uint32_t)pl.v->KV * 1024u + 128u /* two stages + the pair list */, s);
             p->ticket_base += (uint32_t)grid;
         }
         if (e1 != hipSuccess) {
@@ -3628,7 +3817,7 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
             if (!have) p->tried.push_back(slot);
         }
         for (int R = 2; R <= kMaxR && st == RH_OK; ++R) {
-            for (int NS = 2; NS <= 3; ++NS) {
+            for (int NS = 2; NS <= (is_pair ? 4 : 3); ++NS) {
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
                 const bool mono = p->cfg.channels == 1;
@@ -3643,11 +3832,13 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
                 p->tried.push_back(cand);
                 const uint64_t tiles = (p->out_frames + 64ull * R - 1) / (64ull * R);
                 const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
-                if ((int)per_cu > cand.resident_per_cu) continue;  // would run in passes: never the fastest
+                if ((int)per_cu > cand.resident_per_cu && !is_pair) continue;  // would run in passes: never the fastest (a ragged batch's tiles are
+                                                                                // unequal: there the later ones fill in behind the heavy ones)
                 slot = cand;
                 if ((st = activate_plan(p, &slot)) != RH_OK) break;
                 float ms = 0.f;
                 if ((st = time_current(ms)) != RH_OK) break;
+                if (rh::knob(rh::K_AUTOTUNE_LOG)) std::fprintf(stderr, "rh_rlm_autotune: %d frames per lane, %d KiB x %d stages: %.4f ms (best so far %.4f)\n", R, cand.v->KV, NS, ms, best_ms);
                 if (ms < best_ms * 0.99f) {  // a candidate has to win by more than the run-to-run noise (ties keep the earlier, shallower one)
                     best_ms = ms;
                     best = cand;

@@ -233,6 +233,33 @@ int main(int argc, char **argv) {
         timeit("R10 pattern KV5", k_mimic<5, 2>, 1784, 23040, 294, 298);
         return 0;
     }
+    if (cal && argv[1][0] == 'o') {  // occupancy study: how fast does ONE wave pull its 256 x 8 KiB when fewer waves share the chip?
+        auto timeo = [&](const char *name, auto kern, uint32_t tiles, size_t lds) {
+            CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(tiles), dim3(64), lds, 0, d_in, d_out, S, stride, 1024u);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double bytes = (double)S * tiles * 8192.0;
+            printf("%-14s waves %5u (%.2f per CU) : %.3f ms  %6.0f GB/s  %5.2f GB/s per wave  %5.0f ns per 8 KiB\n", name, tiles, tiles / 256.0, best, bytes / best / 1e6, bytes / best / 1e6 / tiles,
+                   best * 1e6 / S);
+        };
+        for (uint32_t tiles : {1024u, 768u, 512u, 384u, 256u, 128u, 32u, 1u}) {
+            timeo("ring of 2", k_halo<2, 0>, tiles, 2 * 8 * 1024);
+            timeo("ring of 3", k_halo<3, 0>, tiles, 3 * 8 * 1024);
+            timeo("ring of 4", k_halo<4, 0>, tiles, 4 * 8 * 1024);
+        }
+        return 0;
+    }
     if (cal && argv[1][0] == 'm') {  // mimic: R=10 tiles of config 2 (640 out frames -> 588 in frames = 294 vectors; 298 fetched)
         const uint32_t vstride = 294, nvec = 298, tiles = 1784;
         CHECK(hipFuncSetAttribute((const void *)k_mimic<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
