@@ -356,6 +356,263 @@ __global__ __launch_bounds__(384) void k_agc_chain2(const ChainArgs a, const Cha
     else chain_body<OpA>(a, blockIdx.x >> 1);
 }
 
+// ---- the default parameters (release == 0) in ONE kernel -------------------------------------------------------------------
+// With release == 0 the peak follower is no chain (peak = |x|), and what is left -- window sum, desired gain, gain, output -- is a
+// four-stage pipeline over chunks of samples that fits one workgroup: every sample is fetched twice (as itself and, 8192 samples
+// later, as what leaves the window) and written once -- 12 bytes against the 8 of the algorithm, where the segment-by-segment form
+// above moves 60 (squares, sums, desired gains, gains: all through memory, a launch per stage and segment).
+//     wave 0 (S)           window sum of chunk t:      x, x_old  -> sum                        (SumOp: the squares ride along)
+//     waves 2 3 6 7 (D)    desired gain of chunk t-1:  sum, |x|  -> desired   (IEEE sqrt and two IEEE divides: ~48 instructions a sample)
+//     wave 1 (G)           gain of chunk t-2:          desired   -> gain      (GainOp0, its two prepared operands made in place)
+//     waves 10 11 (Y)      output of chunk t-3:        x * gain  -> memory, whole 128-byte lines
+//     waves 4 5 / 8 9      LDS-DMA of x / x_old, kFAhead chunks ahead of S, half a chunk's instructions each
+// One barrier per chunk.  The two chains keep a SIMD each to themselves and the loaders, which only issue and wait (wave w of a
+// workgroup runs on SIMD w % 4); everything with arithmetic in it runs on the other two.  What sizes the workgroup is D: a chain
+// wave walks 64 streams as fast as 16, but the desired gains of 64 streams x 32 samples are 1500 wave instructions = 6100 SIMD
+// cycles on two SIMDs, against the 1100 cycles the chains take for them (measured: 46 ns per sample with 64 streams per
+// workgroup, the chains alone 16).  So a workgroup takes 16 STREAMS and chunks of 128 samples (the same 8 KiB images; a quarter of
+// the barriers per sample): 16 of a chain wave's lanes work, and D's 3100 cycles fit the 4400 of a chunk.  The chip has the CUs:
+// 64 streams are 4 workgroups, 2048 are 128; batches of more than 16 streams per CU keep the segment-by-segment form.
+// LDS: x stays until Y has used it (kFAhead + 4 chunks), x_old until S has (kFAhead + 1), the value image -- sum, then desired,
+// then gain, in place -- 4 chunks.  Same operations in the same order as the stages above (and as k_agc_seq, up to GainOp0's tie:
+// see the header), so the same bits.
+constexpr int kFS = 16;                      // streams per workgroup
+constexpr int kFCS = 128;                    // samples per chunk and stream
+constexpr int kFV = kFCS / 4;                // 16-byte vectors per stream and chunk: 32
+constexpr int kFSub = 8;                     // vectors a chain lane holds at a time
+constexpr uint32_t kFHeadChunks = kRmsWindow / kFCS;
+constexpr int kFAhead = 3;
+constexpr int kFRX = kFAhead + 4, kFRO = kFAhead + 1, kFRA = 4;
+static_assert(kFS * kFV * 16 == (int)kSlotBytes, "a chunk image is 8 KiB");
+constexpr uint32_t kFOBase = kFRX * kSlotBytes, kFABase = kFOBase + kFRO * kSlotBytes, kFFin = kFABase + kFRA * kSlotBytes;
+constexpr size_t kFusedLds = (size_t)kFFin + kFS * 4;  // 120 KiB + 64 B
+constexpr int kFWaves = 12;
+// the image: slot o*32 + (j ^ o) holds vector j of stream o's chunk -- the 16 chain lanes, each on vector j of its own stream, then
+// hit 16 different bank groups although the rows are not padded
+__device__ __forceinline__ constexpr uint32_t fslot_of(uint32_t o, uint32_t j) { return o * kFV + (j ^ (o & (kFV - 1))); }
+struct FusedArgs {
+    const float *in;        // rows of n samples, `stride` floats apart
+    const float *in1_head;  // the carried window, [streams][8192] squares in time order; null: a fresh window (zeros)
+    float *out;
+    uint64_t n, stride, stride_out;
+    uint32_t n_streams;
+    float *state;           // per stream `state_stride` floats {sum, -, peak, gain, ...}
+    uint32_t state_stride;
+    AgcK k;
+};
+__device__ __forceinline__ float agc_desired(float sum, float p, const AgcK &k) {  // agc.rs:416-430, :169 (k_agc_desired's `one`)
+    const float rms = sqrtf(sum / (float)kRmsWindow);
+    const float rms_gain = rms > 0.0f ? k.target_level / rms : k.absolute_max_gain;
+    const float peak_gain = p > 0.0f ? fminf(k.target_level / p, k.absolute_max_gain) : k.absolute_max_gain;
+    return fmaxf(fminf(rms_gain, peak_gain), k.floor);
+}
+__global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    typedef __attribute__((address_space(3))) v4f lds_v4;
+    typedef __attribute__((address_space(3))) float lds_f;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / 64), lane = (int)threadIdx.x & 63;
+    const uint32_t g0 = blockIdx.x * (uint32_t)kFS;
+    const uint32_t live = a.n_streams - g0 < (uint32_t)kFS ? a.n_streams - g0 : (uint32_t)kFS;
+    const uint32_t nch = (uint32_t)(a.n / kFCS);  // whole chunks (host: n < 2^24); the rest is wave 0's epilogue
+    const uint32_t nsteps = nch + 3;
+    const bool chain_lane = lane < kFS;            // the lanes of S and G that walk a stream
+    const bool mine = (uint32_t)lane < live;
+    const uint32_t stream = g0 + (mine ? (uint32_t)lane : live - 1);
+    if (wave == 0) {  // ---- S: the window sum, lane = stream (agc.rs:152-163) ----
+        float *st = a.state + (uint64_t)stream * a.state_stride;
+        SumOp op;
+        op.sum = st[0];
+        auto chunk = [&](uint32_t sx, uint32_t so_, uint32_t sa, auto head_tag, auto zero_tag) {
+            constexpr bool HEAD = decltype(head_tag)::value, ZERO = decltype(zero_tag)::value;
+            const lds_u8 *inx = lds + sx * kSlotBytes, *ino = lds + kFOBase + so_ * kSlotBytes;
+            lds_u8 *img = lds + kFABase + sa * kSlotBytes;
+            for (int b = 0; b < kFV / kFSub; ++b) {
+                v4f x[kFSub], o[kFSub];
+                uint32_t sl[kFSub];
+#pragma unroll
+                for (int j = 0; j < kFSub; ++j) {
+                    sl[j] = fslot_of((uint32_t)lane & (kFS - 1), (uint32_t)(b * kFSub + j)) * 16u;
+                    x[j] = *(const lds_v4 *)(inx + sl[j]);
+                    o[j] = ZERO ? v4f{0.f, 0.f, 0.f, 0.f} : *(const lds_v4 *)(ino + sl[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < kFSub; ++j) *(lds_v4 *)(img + sl[j]) = op.template step4<HEAD>(x[j], o[j]);
+            }
+        };
+        uint32_t sx = 0, so_ = 0, sa = 0;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            if (t < nch && chain_lane) {
+                if (t < kFHeadChunks) {
+                    if (a.in1_head) chunk(sx, so_, sa, std::true_type{}, std::false_type{});
+                    else chunk(sx, so_, sa, std::true_type{}, std::true_type{});
+                } else {
+                    chunk(sx, so_, sa, std::false_type{}, std::false_type{});
+                }
+            }
+            sx = sx + 1 == (uint32_t)kFRX ? 0 : sx + 1;
+            so_ = so_ + 1 == (uint32_t)kFRO ? 0 : so_ + 1;
+            sa = (sa + 1) & (kFRA - 1);
+        }
+        barrier_lds();  // G's final gain is in the LDS
+        if (mine) {  // the last n % 128 samples: every stage, one sample at a time, straight from memory
+            const float *r0 = a.in + (uint64_t)stream * a.stride;
+            float *ro = a.out + (uint64_t)stream * a.stride_out;
+            float gain = *(const lds_f *)(lds + kFFin + lane * 4);
+            const float oma = 1.0f - a.k.attack_coeff;
+            for (uint64_t i = (uint64_t)nch * kFCS; i < a.n; ++i) {
+                const bool head = i < (uint64_t)kRmsWindow;
+                const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
+                const float xv = r0[i];
+                const float sm = op.one(xv, ov, head);
+                const float d = agc_desired(sm, fabsf(xv), a.k);
+                const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
+                gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
+                ro[i] = xv * gain;
+            }
+            st[0] = op.sum;
+            st[3] = gain;
+            if (a.n) st[2] = fabsf(r0[a.n - 1]);  // release == 0: the peak level is the last sample's magnitude
+        }
+        return;
+    }
+    if (wave == 1) {  // ---- G: the gain, lane = stream (agc.rs:486-499 with release == 0: GainOp0) ----
+        const float *st = a.state + (uint64_t)stream * a.state_stride;
+        float gain = st[3];
+        const float att = a.k.attack_coeff, oma = 1.0f - att, maxg = a.k.absolute_max_gain;
+        uint32_t sa = (0u - 2u) & (kFRA - 1);  // the image of chunk t - 2
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            if (t >= 2 && t - 2 < nch && chain_lane) {
+                lds_u8 *img = lds + kFABase + sa * kSlotBytes;
+                for (int b = 0; b < kFV / kFSub; ++b) {
+                    v4f d[kFSub];
+                    uint32_t sl[kFSub];
+#pragma unroll
+                    for (int j = 0; j < kFSub; ++j) {
+                        sl[j] = fslot_of((uint32_t)lane & (kFS - 1), (uint32_t)(b * kFSub + j)) * 16u;
+                        d[j] = *(const lds_v4 *)(img + sl[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kFSub; ++j) {
+                        // what does not wait for the gain first: clamp(desired) and desired * (1 - attack), the two operands of the chain
+                        const v4f da = d[j] * oma;
+                        v4f dc, r;
+                        dc.x = __builtin_amdgcn_fmed3f(d[j].x, 0.1f, maxg), dc.y = __builtin_amdgcn_fmed3f(d[j].y, 0.1f, maxg);
+                        dc.z = __builtin_amdgcn_fmed3f(d[j].z, 0.1f, maxg), dc.w = __builtin_amdgcn_fmed3f(d[j].w, 0.1f, maxg);
+                        gain = __builtin_amdgcn_fmed3f(gain * att + da.x, 0.1f, dc.x), r.x = gain;
+                        gain = __builtin_amdgcn_fmed3f(gain * att + da.y, 0.1f, dc.y), r.y = gain;
+                        gain = __builtin_amdgcn_fmed3f(gain * att + da.z, 0.1f, dc.z), r.z = gain;
+                        gain = __builtin_amdgcn_fmed3f(gain * att + da.w, 0.1f, dc.w), r.w = gain;
+                        *(lds_v4 *)(img + sl[j]) = r;
+                    }
+                }
+            }
+            sa = (sa + 1) & (kFRA - 1);
+        }
+        if (chain_lane) *(lds_f *)(lds + kFFin + lane * 4) = gain;
+        barrier_lds();
+        return;
+    }
+    if (wave == 2 || wave == 3 || wave == 6 || wave == 7) {  // ---- D: the desired gain of chunk t - 1, 4 samples per lane and half chunk ----
+        const uint32_t m = (uint32_t)(wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : 3);
+        const uint32_t q0 = (m * 64u + (uint32_t)lane) * 16u;  // this lane's slots: q0 and q0 + 4 KiB (the images share one layout)
+        uint32_t sx = kFRX - 1, sa = kFRA - 1;                  // ring slot and image of chunk t - 1
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            if (t >= 1 && t - 1 < nch) {
+                const lds_u8 *inx = lds + sx * kSlotBytes;
+                lds_u8 *img = lds + kFABase + sa * kSlotBytes;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v4f s4 = *(const lds_v4 *)(img + q0 + h * 4096), x4 = *(const lds_v4 *)(inx + q0 + h * 4096);
+                    v4f r;
+                    r.x = agc_desired(s4.x, fabsf(x4.x), a.k), r.y = agc_desired(s4.y, fabsf(x4.y), a.k);
+                    r.z = agc_desired(s4.z, fabsf(x4.z), a.k), r.w = agc_desired(s4.w, fabsf(x4.w), a.k);
+                    *(lds_v4 *)(img + q0 + h * 4096) = r;
+                }
+            }
+            sx = sx + 1 == (uint32_t)kFRX ? 0 : sx + 1;
+            sa = (sa + 1) & (kFRA - 1);
+        }
+        barrier_lds();
+        return;
+    }
+    // per-lane geometry of the line-wise transfers: slot q = k*64 + lane of a chunk image holds vector j = (q % 32) ^ o of stream
+    // o = q / 32, i.e. samples 4j..4j+3 of its chunk (surplus streams of the last group repeat the last live one and are never stored)
+    uint32_t so[kDma], sj[kDma];
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t q = (uint32_t)k * 64u + (uint32_t)lane;
+        so[k] = q / kFV;
+        sj[k] = (q % kFV) ^ (so[k] & (kFV - 1));
+    }
+    constexpr int kMine = kDma / 2;
+    if (wave >= 10) {  // ---- Y: chunk t - 3 leaves as x * gain (agc.rs:503), whole lines; half the lines each ----
+        const int half = wave - 10;
+        uint32_t sx = kFRX - 3, sa = kFRA - 3;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            if (t >= 3) {  // (t - 3 < nch always: nsteps = nch + 3)
+                const lds_u8 *inx = lds + sx * kSlotBytes, *img = lds + kFABase + sa * kSlotBytes;
+                float *ob = a.out + (uint64_t)g0 * a.stride_out + (uint64_t)(t - 3) * kFCS;
+#pragma unroll
+                for (int k = 0; k < kDma; ++k) {
+                    if (k / kMine != half) continue;
+                    const v4f g4 = *(const lds_v4 *)(img + (k * 64 + lane) * 16), x4 = *(const lds_v4 *)(inx + (k * 64 + lane) * 16);
+                    if (so[k] < live) __builtin_nontemporal_store(x4 * g4, reinterpret_cast<v4f *>(ob + (uint64_t)so[k] * a.stride_out + sj[k] * 4u));
+                }
+            }
+            sx = sx + 1 == (uint32_t)kFRX ? 0 : sx + 1;
+            sa = (sa + 1) & (kFRA - 1);
+        }
+        barrier_lds();
+        return;
+    }
+    // ---- the loaders (waves 4 5: x; 8 9: what leaves the window), kFAhead chunks ahead of S ----
+    const int second = wave >= 8 ? 1 : 0, half = wave & 1;
+    const uint32_t ring = second ? (uint32_t)kFRO : (uint32_t)kFRX;
+    const uint32_t lbase = (uint32_t)(uintptr_t)lds + (second ? kFOBase : 0u);
+    uint32_t voff[kDma];  // host: kFS * stride * 4 < 2^32
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t o = so[k] < live ? so[k] : live - 1;
+        voff[k] = (uint32_t)(((uint64_t)o * a.stride + sj[k] * 4u) * 4u);
+    }
+    uint32_t slot_next = 0;  // ring slot of the next chunk to issue
+    auto issue = [&](uint32_t c) {
+        const uint32_t slot = lbase + slot_next * kSlotBytes;
+        slot_next = slot_next + 1 == ring ? 0 : slot_next + 1;
+        if (second && c < kFHeadChunks && a.in1_head) {  // rows of 8192 floats: the carried window
+            const float *bh = a.in1_head + (uint64_t)g0 * kRmsWindow + (uint64_t)c * kFCS;
+#pragma unroll
+            for (int k = 0; k < kDma; ++k)
+                if (k / kMine == half) glds16(bh, (((so[k] < live ? so[k] : live - 1) * kRmsWindow + sj[k] * 4u) * 4u), slot + k * 1024);
+            return;
+        }
+        // (a fresh window -- zeros, S does not read the slot -- still fetches, x again: every chunk counts the same in vmcnt)
+        const bool self = !second || c < kFHeadChunks;
+        const float *b = a.in + (uint64_t)g0 * a.stride + (uint64_t)c * kFCS - (self ? 0 : kRmsWindow);
+#pragma unroll
+        for (int k = 0; k < kDma; ++k)
+            if (k / kMine == half) glds16(b, voff[k], slot + k * 1024);
+    };
+    for (uint32_t c = 0; c < nch && c < (uint32_t)kFAhead; ++c) issue(c);
+    for (uint32_t t = 0; t < nsteps; ++t) {
+        if (t < nch) {  // chunk t has landed when only the chunks issued after it are outstanding (vmcnt retires in order)
+            const uint32_t left = nch - 1 - t;
+            if (left >= (uint32_t)(kFAhead - 1)) wait_vm<(kFAhead - 1) * kMine>();
+            else if (left == 1) wait_vm<kMine>();
+            else wait_vm<0>();
+        }
+        barrier_lds();
+        // x: into the slot of chunk t - 4, which Y left before this barrier; x_old: into the slot of chunk t - 1, which S did
+        if (t + kFAhead < nch) issue(t + kFAhead);
+    }
+    barrier_lds();
+}
+
 // ---- everything that is not a chain: one lane per 4 samples, the whole chip.  A launch covers samples [off, off + len) of every row
 // (rows are n floats apart).
 struct SegArgs {
@@ -466,6 +723,15 @@ __global__ __launch_bounds__(256) void k_agc_window_in(float *__restrict__ state
 }
 
 template <class K>
+rh_status chain_attr_n(K kernel, const char *what, size_t lds) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, what);
+        return RH_ERR_HIP;
+    }
+    return RH_OK;
+}
+template <class K>
 rh_status chain_attr(K kernel, const char *what) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLds);
     if (e != hipSuccess) {
@@ -516,8 +782,11 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     float *scr = nullptr;
     // the `rows` region rounded up to whole 16-byte vectors: the squares behind it are written with v4f stores and fetched by 16-byte
     // LDS-DMA (one stream of an odd length -- 1 x 40 001 -- would otherwise put them 4 to 12 bytes off)
-    const size_t rows_floats = ((size_t)n_streams * n_samples + 3) & ~(size_t)3;
-    const size_t scratch_floats = fresh_floats + win_floats + rows_floats + (presq ? (size_t)n_streams * pstride : 0);
+    // release == 0 in one kernel (k_agc_fused): no rows of intermediates at all.  RH_AGC_SEGMENTS=1: the segment-by-segment form
+    // ... for batches of up to 16 streams per CU (a workgroup takes 16: see k_agc_fused)
+    const bool fused = !general && n_streams <= (uint32_t)(kFS * rh::g_num_cus) && !rh::knob(rh::K_AGC_SEGMENTS);
+    const size_t rows_floats = fused ? 0 : (((size_t)n_streams * n_samples + 3) & ~(size_t)3);
+    const size_t scratch_floats = fresh_floats + win_floats + rows_floats + (presq && !fused ? (size_t)n_streams * pstride : 0);
     // The scratch is as large as the batch (twice with the squares) and stays with the stream: a batch that would pin more than 8 GiB
     // that way, or whose scratch cannot be had at all, takes the reference-order kernels instead -- they need none (RH_ERR_UNSUPPORTED
     // is the caller's cue; a failed allocation must not fail a call that worked before the chain existed)
@@ -572,7 +841,22 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     };
     auto par_grid = [&](uint64_t len) { return dim3(rh::grid_tiles((size_t)n_streams * ((len + 3) / 4) + 1)); };
     rh_status st = RH_OK;
-    if (general) {
+    if (fused) {
+        static const rh_status attr = chain_attr_n(&k_agc_fused, "hipFuncSetAttribute(k_agc_fused)", kFusedLds);
+        if (attr != RH_OK) return attr;
+        FusedArgs f;
+        f.in = src;
+        f.in1_head = ordered;
+        f.out = dst;
+        f.n = n_samples;
+        f.stride = f.stride_out = n_samples;
+        f.n_streams = n_streams;
+        f.state = base.state;
+        f.state_stride = base.state_stride;
+        f.k = k;
+        hipLaunchKernelGGL(k_agc_fused, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWaves), kFusedLds, s, f);
+        RH_CHECK_LAUNCH();
+    } else if (general) {
         // window sum -> dst and peak follower -> rows side by side, desired gain in place, then the gain chain with both candidates
         ChainArgs a = sum_args(0), p = base;
         p.in0 = src;

@@ -1012,6 +1012,29 @@ def test_fused_ragged_filtered_batches_take_the_kernel_pair(G, O):
         assert float(np.max(np.abs(out - out2))) <= 1e-6
 
 
+def test_fused_ragged_pairs_inside_the_first_kernel_equal_the_second_launch(G, O):
+    # the pairs in which a source is about to end run inside k_rlm_fast<RAG> (Params::rag_merge), on the mix in registers;
+    # RH_RAG_TWO_KERNELS=1 keeps them in a launch of their own (k_rlm_resid) on top of the stored tiles: the same operations in the
+    # same order, so the same bits.  RH_RAG_RESIDENT limits the tiles a CU holds at once (later tiles fill in): same bits again.
+    from conftest import knobs
+
+    n = 90000
+    ns = [n] * 5 + [n - 700 * i - 13 for i in range(1, 60)] + [n // 2, n // 3, 7000]
+    xs = [rnd(5100 + i, 2 * m, 0.03) for i, m in enumerate(ns)]
+    ref = _oracle_pipeline(O, xs, 44100, 48000, None, "low_pass", 250)
+    truth = _truth_pipeline(O, xs, 44100, 48000, None, "low_pass", 250)
+    out, geo = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 250)
+    assert geo["ragged_pair"] == 1, geo
+    _check_filtered("ragged, pairs merged", out, ref, truth)
+    with knobs(RH_RAG_TWO_KERNELS="1"):
+        out2, geo2 = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 250)
+    assert geo2["ragged_pair"] == 1
+    assert np.array_equal(out, out2)
+    with knobs(RH_RAG_RESIDENT="2"):
+        out3, _ = _gpu_pipeline(G, xs, 44100, 48000, None, "low_pass", 250)
+    assert np.array_equal(out, out3)
+
+
 @pytest.mark.parametrize("general", [0, 1])
 def test_fused_same_rate_is_the_ordered_mix(G, O, general):
     # from_rate == to_rate: the converter passes through (sample_rate.rs:133-136); without a filter the fused kernel is the
