@@ -304,29 +304,34 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols(float *__restric
 }
 
 // The same walk with the NEXT U steps' loads in flight while the current U are worked on (two register sets): a lane never sits
-// between batches with nothing outstanding.
-template <int U>
+// between batches with nothing outstanding.  W: adjacent 16-byte columns per lane (a wave's access is W KiB of one row).
+template <int U, int W = 1>
 __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols_p(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain,
                                                                   const float *__restrict__ gains, size_t src_stride, size_t dst_stride, uint32_t n_streams) {
-    const size_t cols = delay / 4;
+    const size_t cols = delay / (4 * W);  // host: delay % (4 * W) == 0
     const size_t total = n + delay;
-    const size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x;  // one lane per column: the host launches exactly enough workgroups
+    const size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x;  // one lane per column group: the host launches exactly enough workgroups
     if (w >= cols * n_streams) return;
     const uint32_t stream = (uint32_t)(w / cols);
-    const size_t c = (w - (size_t)stream * cols) * 4;
+    const size_t c = (w - (size_t)stream * cols) * 4 * W;
     const float *x = src + (size_t)stream * src_stride;
     float *o = dst + (size_t)stream * dst_stride;
     const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
-    auto fetch = [&](float4 (&a4)[U], size_t i0) {
+    auto fetch = [&](float4 (&a4)[U][W], size_t i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t i = i0 + (size_t)u * delay;
-            a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n) a4[u] = rh::ld_nt(reinterpret_cast<const float4 *>(x + i));
+#pragma unroll
+            for (int v = 0; v < W; ++v) {
+                a4[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n) a4[u][v] = rh::ld_nt(reinterpret_cast<const float4 *>(x + i + 4 * v));  // (n % (4 * W) == 0: a column group is inside the row or past it)
+            }
         }
     };
-    float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 cur[U], nxt[U];
+    float4 prev[W];
+#pragma unroll
+    for (int v = 0; v < W; ++v) prev[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cur[U][W], nxt[U][W];
     fetch(cur, c);
     for (size_t i0 = c; i0 < total; i0 += (size_t)U * delay) {
         const size_t i1 = i0 + (size_t)U * delay;
@@ -335,22 +340,27 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols_p(float *__restr
         for (int u = 0; u < U; ++u) {
             const size_t i = i0 + (size_t)u * delay;
             if (i >= total) break;
-            const float4 a = cur[u];
-            float r[4];
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {prev.x, prev.y, prev.z, prev.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
-                r[k] = (i < n) ? (av[k] + s2) : s2;
+            for (int v = 0; v < W; ++v) {
+                const float4 a = cur[u][v];
+                float r[4];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {prev[v].x, prev[v].y, prev[v].z, prev[v].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float s2 = (i >= delay) ? bv[k] * gain : 0.0f;
+                    r[k] = (i < n) ? (av[k] + s2) : s2;
+                }
+                float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
+                m0 = m0 / 2.0f;
+                m1 = m1 / 2.0f;
+                rh::st_nt(reinterpret_cast<float4 *>(o + i + 4 * v), make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1));
+                prev[v] = a;
             }
-            float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
-            m0 = m0 / 2.0f;
-            m1 = m1 / 2.0f;
-            rh::st_nt(reinterpret_cast<float4 *>(o + i), make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1));
-            prev = a;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < W; ++v) cur[u][v] = nxt[u][v];
     }
 }
 
@@ -504,16 +514,20 @@ rh_status rh_reverb_spatial(float *dst, const float *src, size_t n, size_t delay
     if (vec4 && delay_samples >= 4096 && (delay_samples / 4) * n_streams >= 64u * 1024u) {
         // enough independent columns to fill the chip: every input byte once
         const size_t lanes = (delay_samples / 4) * n_streams;
-        // the walk with the next batch of loads in flight behind the current one (measured on config 3: 0.2099 -> 0.2025 ms with
-        // batches of 4 steps; 2 and 3: 0.209); RH_RS_PIPE=0: the walk without (batch size: tuning aid)
+        // the walk with the next batch of loads in flight behind the current one (measured on config 3: 0.211 -> 0.203 ms with
+        // batches of 8 steps, 0.205 / 0.209 with 6 / 4: profiles/r04_cfg3_pipe.txt); RH_RS_PIPE=0: the walk without (batch size: tuning aid)
         const char *pk = rh::knob(rh::K_RS_PIPE);
-        const int pipe = pk ? atoi(pk) : 4;
+        const int pipe = pk ? atoi(pk) : 8;
         if (pipe > 0) {
+            const int U = pipe;
             const dim3 g((unsigned)((lanes + kBlock - 1) / kBlock));
-            if (pipe == 2) hipLaunchKernelGGL(k_reverb_spatial_cols_p<2>, g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams);
-            else if (pipe == 6) hipLaunchKernelGGL(k_reverb_spatial_cols_p<6>, g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams);
-            else if (pipe == 8) hipLaunchKernelGGL(k_reverb_spatial_cols_p<8>, g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams);
-            else hipLaunchKernelGGL(k_reverb_spatial_cols_p<4>, g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams);
+#define RH_RS_LAUNCH(u, w) hipLaunchKernelGGL((k_reverb_spatial_cols_p<u, w>), g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams)
+            // (two adjacent columns per lane, W = 2, measured 0.38 ms: a wave's load then covers 2 KiB at half the lanes per line)
+            if (U == 2) RH_RS_LAUNCH(2, 1);
+            else if (U == 4) RH_RS_LAUNCH(4, 1);
+            else if (U == 6) RH_RS_LAUNCH(6, 1);
+            else RH_RS_LAUNCH(8, 1);
+#undef RH_RS_LAUNCH
             RH_CHECK_LAUNCH();
             return RH_OK;
         }

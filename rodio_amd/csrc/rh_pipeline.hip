@@ -2596,13 +2596,12 @@ const Variant kWave[] = {
 #define RH_RAGN(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, true, 2, true>, &k_rlm_resid<r, kv>}
 #endif
 #define RH_RAG(r, kv) RH_RAGN(r, kv, 2)
-// Deeper rings for the long runs (one wave per SIMD whatever the LDS request: four stages of 9 KiB still fit four times): the tiles of
-// a ragged batch carry unequal loads, the light ones leave early, and the heavy ones that remain are then bound by what ONE wave
-// keeps in flight.
+// (Rings of 3 and 4 stages for the long runs were built and measured in round 4: no change -- a heavy tile is not held back by what
+// ONE wave keeps in flight, DESIGN.md 4.4 -- and dropped again: the overrides of rh_rlm_config address the fast plan, which has no
+// such geometries.)
 const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
-    RH_RAGN(14, 7, 3), RH_RAGN(14, 8, 3), RH_RAGN(18, 9, 3), RH_RAGN(18, 10, 3), RH_RAGN(14, 7, 4), RH_RAGN(14, 8, 4), RH_RAGN(18, 9, 4), RH_RAGN(18, 10, 4),
 };
 // mono (C = 1): a frame is 4 bytes, so a stage holds twice the frames per KiB
 #define RH_FAST1(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, false, 1>, &k_rlm_fast<r, kv, ns, false, false, 1>}
@@ -3817,7 +3816,7 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
             if (!have) p->tried.push_back(slot);
         }
         for (int R = 2; R <= kMaxR && st == RH_OK; ++R) {
-            for (int NS = 2; NS <= (is_pair ? 4 : 3); ++NS) {
+            for (int NS = 2; NS <= 3; ++NS) {
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
                 const bool mono = p->cfg.channels == 1;

@@ -45,5 +45,23 @@ case "$1" in
     for nio in 0 1; do for shape in "64 1048576" "2048 32768"; do set -- $shape; echo "RH_LIMIT_NIO=$nio streams=$1 frames=$2: $(RH_LIMIT_NIO=$nio RH_BENCH_NO_PMC=1 python bench.py --config limit --sources $1 --frames $2 --steps 30 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4))")"; done; done > $E/r04_limit_io_waves.txt 2>&1
     python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -12 > $E/r04_final_gputests.txt
     ;;
+4)  # what changed after parts 1-3: the ragged pair in one kernel, the AGC in one kernel, config 3's pipelined walk
+    for u in 0 2 4 6 8; do echo "RH_RS_PIPE=$u: $(RH_RS_PIPE=$u RH_BENCH_NO_PMC=1 python bench.py --config 3 --steps 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4))")"; done > $E/r04_cfg3_pipe.txt 2>&1
+    for c in ragged agc 3; do python bench.py --config $c > $E/r04_bench_$c.json 2>/dev/null; done
+    python bench.py --config agc --sources 2048 --frames 32768 > $E/r04_bench_agc_2048.json 2>/dev/null
+    RH_AGC_SEGMENTS=1 RH_BENCH_NO_PMC=1 python bench.py --config agc --no-cpu-baseline > $E/r04_bench_agc_segments.json 2>/dev/null
+    RH_RAG_TWO_KERNELS=1 RH_BENCH_NO_PMC=1 python bench.py --config ragged --no-cpu-baseline > $E/r04_bench_ragged_two_kernels.json 2>/dev/null
+    for c in ragged 3; do
+        case $c in 3) export RH_PROF_KERNEL=reverb_spatial;; *) export RH_PROF_KERNEL=k_rlm;; esac
+        bash tools/pmc_cmd.sh r04_$c python bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+        cp gpurun_out/prof/r04_$c/summary.txt $E/r04_${c}_kernel_trace_pmc.txt
+    done
+    export RH_PROF_KERNEL=k_agc
+    bash tools/pmc_cmd.sh r04_agc python bench.py --config agc --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r04_agc/summary.txt $E/r04_agc_64x1Mi_kernel_trace_pmc.txt
+    bash tools/pmc_cmd.sh r04_agc2048 python bench.py --config agc --sources 2048 --frames 32768 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r04_agc2048/summary.txt $E/r04_agc_2048x32Ki_kernel_trace_pmc.txt
+    tools/ubench/stream_ring o > $E/r04_stream_ring_occupancy.txt 2>&1
+    ;;
 esac
 ls -la $E | tail -40
