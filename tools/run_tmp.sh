@@ -1,6 +1,4 @@
 export RH_BENCH_NO_PMC=1
-for u in 8 4 12 14 18 8 14 18; do
-  echo "RH_RS_PIPE=$u: $(RH_RS_PIPE=$u python bench.py --config 3 --steps 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4))")"
-done
-RH_RS_PIPE=14 timeout 300 python -m pytest tests -m gpu -x -q -k "reverb" 2>&1 | grep -E "passed|failed" | tail -2
-python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6
+python bench.py --config biquad --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print([(k['kernel'], round(k['kernel_ms'],4), round(k['ms_per_step'],4)) for k in d['config']['kernels']])"
+python bench.py --config biquad --steps 30 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print([(k['kernel'], round(k['kernel_ms'],4), round(k['ms_per_step'],4)) for k in d['config']['kernels']])"
+RH_PROF_KERNEL=k_b tools/kt_cmd.sh bq30 python bench.py --config biquad --steps 30 --no-cpu-baseline 2>&1 | cut -c1-200 | head -20
