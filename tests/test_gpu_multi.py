@@ -99,7 +99,7 @@ def test_bench_gpus_2_spawns_its_own_ranks_and_prints_a_complete_line(G):
     import shutil
 
     env = dict(os.environ, RH_BENCH_ONE_DEVICE="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RH_BENCH_NO_PMC"):  # (a caller's "no counter passes" is not this test's)
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--sources", "16", "--frames", "262144", "--baseline-sources", "4"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
