@@ -438,6 +438,15 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
         ticket = blockIdx.x;
         stream = 0;
         tile = ticket;
+    } else if (p.shards > 1 && p.batch_streams == 0) {
+        // one stream, tiles by ticket, eight counters (see k_rlm_chunk): workgroup b takes ticket k of counter b % 8 and works on tile
+        // b % 8 + 8 k; the grid is whole rounds of eight, workgroups past the last tile leave
+        const uint32_t x = blockIdx.x & 7u;
+        const uint32_t k_ = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket + 32u * (1u + x), 1u) - p.shard_base : 0u);
+        tile = x + 8u * k_;
+        ticket = tile;
+        stream = 0;
+        if (tile >= p.n_tiles) return;
     } else if (p.shards > 1) {
         const uint32_t x = blockIdx.x % p.shards, per = p.batch_streams / p.shards;
         ticket = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket + 32u * (1u + x), 1u) - p.shard_base : 0u);
@@ -3687,8 +3696,11 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
             const int want = atoi(w);
             if (want >= 2 && want < 8) lds1 = std::max(lds1, (kLdsGranules / (uint32_t)want) * kLdsGranule);
         }
-        hipError_t e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->filt), dim3((uint32_t)grid), dim3(64), args1, lds1, s);
-        if (e1 == hipSuccess) p->ticket_base += (uint32_t)grid;
+        const uint32_t grid8 = ((uint32_t)grid + 7u) & ~7u;  // tiles by ticket from eight counters (k_rlm_fast): whole rounds
+        k1.shards = 8;
+        k1.shard_base = p->shard_base;
+        hipError_t e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->filt), dim3(grid8), dim3(64), args1, lds1, s);
+        if (e1 == hipSuccess) p->shard_base += grid8 / 8u;
         if (e1 == hipSuccess && !merge) {
             k.ticket_base = p->ticket_base;
             e1 = hipLaunchKernel(reinterpret_cast<const void *>(pl.v->plain), dim3((uint32_t)grid), dim3(64), args, 2u * (uint32_t)pl.v->KV * 1024u + 128u /* two stages + the pair list */, s);

@@ -63,5 +63,19 @@ case "$1" in
     cp gpurun_out/prof/r04_agc2048/summary.txt $E/r04_agc_2048x32Ki_kernel_trace_pmc.txt
     tools/ubench/stream_ring o > $E/r04_stream_ring_occupancy.txt 2>&1
     ;;
+5)  # the final library: the headline again (k_rlm_chunk's DMA runs and per-XCD tickets), the ragged batch, the suite
+    python bench.py > $E/r04_bench_cfg2.json 2> $E/r04_bench_cfg2.err
+    bash tools/pmc_cmd.sh r04_cfg2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autotune --no-per-source > /dev/null 2>&1
+    cp gpurun_out/prof/r04_cfg2/summary.txt $E/r04_cfg2_kernel_trace_pmc.txt
+    RH_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 > $E/r04_bench_gpus2_one_device.json 2> $E/r04_bench_gpus2_one_device.err
+    python bench.py --shared-device --no-cpu-baseline --no-per-source > $E/r04_bench_cfg2_tiles_by_ticket.json 2>/dev/null
+    python bench.py --config 2span > $E/r04_bench_2span.json 2>/dev/null
+    python bench.py --config 2mono > $E/r04_bench_2mono.json 2>/dev/null
+    python bench.py --config ragged > $E/r04_bench_ragged.json 2>/dev/null
+    export RH_PROF_KERNEL=k_rlm
+    bash tools/pmc_cmd.sh r04_ragged python bench.py --config ragged --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r04_ragged/summary.txt $E/r04_ragged_kernel_trace_pmc.txt
+    python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -12 > $E/r04_final_gputests.txt
+    ;;
 esac
 ls -la $E | tail -40
