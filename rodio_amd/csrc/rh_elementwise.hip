@@ -304,16 +304,17 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols(float *__restric
 }
 
 // The same walk with the NEXT U steps' loads in flight while the current U are worked on (two register sets): a lane never sits
-// between batches with nothing outstanding.  W: adjacent 16-byte columns per lane (a wave's access is W KiB of one row).
+// between batches with nothing outstanding.  W: 16-byte columns per lane, 64 lanes apart -- a wave's step covers W KiB of one row
+// with W fully coalesced instructions (W = 1: a lane per column).
 template <int U, int W = 1>
 __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols_p(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain,
                                                                   const float *__restrict__ gains, size_t src_stride, size_t dst_stride, uint32_t n_streams) {
-    const size_t cols = delay / (4 * W);  // host: delay % (4 * W) == 0
+    const size_t groups = delay / (4 * 64 * W);  // wave-sized column groups per stream (host: delay % (256 * W) == 0)
     const size_t total = n + delay;
-    const size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x;  // one lane per column group: the host launches exactly enough workgroups
-    if (w >= cols * n_streams) return;
-    const uint32_t stream = (uint32_t)(w / cols);
-    const size_t c = (w - (size_t)stream * cols) * 4 * W;
+    const size_t wv = ((size_t)blockIdx.x * kBlock + threadIdx.x) / 64;  // one wave per group: the host launches exactly enough workgroups
+    if (wv >= groups * n_streams) return;
+    const uint32_t stream = (uint32_t)(wv / groups);
+    const size_t c = ((wv - (size_t)stream * groups) * W * 64 + (threadIdx.x & 63u)) * 4;  // the lane's first column; the others 256 samples apart
     const float *x = src + (size_t)stream * src_stride;
     float *o = dst + (size_t)stream * dst_stride;
     const float g0 = gains[2 * stream], g1 = gains[2 * stream + 1];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols_p(float *__restr
 #pragma unroll
             for (int v = 0; v < W; ++v) {
                 a4[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < n) a4[u][v] = rh::ld_nt(reinterpret_cast<const float4 *>(x + i + 4 * v));  // (n % (4 * W) == 0: a column group is inside the row or past it)
+                if (i < n) a4[u][v] = rh::ld_nt(reinterpret_cast<const float4 *>(x + i + 256 * v));  // (n % (256 * W) == 0: a group is inside the row or past it)
             }
         }
     };
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_reverb_spatial_cols_p(float *__restr
                 float m0 = (0.0f + r[0]) + r[1], m1 = (0.0f + r[2]) + r[3];
                 m0 = m0 / 2.0f;
                 m1 = m1 / 2.0f;
-                rh::st_nt(reinterpret_cast<float4 *>(o + i + 4 * v), make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1));
+                rh::st_nt(reinterpret_cast<float4 *>(o + i + 256 * v), make_float4(m0 * g0, m0 * g1, m1 * g0, m1 * g1));
                 prev[v] = a;
             }
         }
@@ -514,16 +515,28 @@ rh_status rh_reverb_spatial(float *dst, const float *src, size_t n, size_t delay
     if (vec4 && delay_samples >= 4096 && (delay_samples / 4) * n_streams >= 64u * 1024u) {
         // enough independent columns to fill the chip: every input byte once
         const size_t lanes = (delay_samples / 4) * n_streams;
-        // the walk with the next batch of loads in flight behind the current one (measured on config 3: 0.211 -> 0.203 ms with
-        // batches of 8 steps, 0.205 / 0.209 with 6 / 4: profiles/r04_cfg3_pipe.txt); RH_RS_PIPE=0: the walk without (batch size: tuning aid)
+        // the walk with the next batch of loads in flight behind the current one, two columns per lane (a wave's step covers 2 KiB of a
+        // row in two coalesced instructions).  Measured on config 3, same sessions: 0.2077-0.2097 ms for a lane per column and batches
+        // of 8 steps (the round's first pipelined form; without the second register set: 0.211), 0.197-0.204 for two columns and batches
+        // of 4 (default), 0.200 for four columns and 2; three columns / batches of 8: slower.  RH_RS_PIPE = 10 W + U; 0: no pipeline
         const char *pk = rh::knob(rh::K_RS_PIPE);
-        const int pipe = pk ? atoi(pk) : 8;
-        if (pipe > 0) {
-            const int U = pipe;
-            const dim3 g((unsigned)((lanes + kBlock - 1) / kBlock));
+        const int pipe = pk ? atoi(pk) : 24;
+        if (pipe > 0 && delay_samples % 256 == 0 && n % 256 == 0) {
+            // RH_RS_PIPE = 10 * W + U (W = 2 or 4 columns per lane, a wave's step then covers W KiB) or U alone (a lane per column)
+            int W = pipe >= 10 ? pipe / 10 : 1;
+            const int U = pipe % 10 ? pipe % 10 : 8;
+            if (W > 1 && (delay_samples % (256 * (size_t)W) || n % (256 * (size_t)W))) W = 1;
+            const size_t waves = lanes / 64 / (size_t)W;
+            const dim3 g((unsigned)((waves * 64 + kBlock - 1) / kBlock));
 #define RH_RS_LAUNCH(u, w) hipLaunchKernelGGL((k_reverb_spatial_cols_p<u, w>), g, dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, gains_dev, src_stride, dst_stride, n_streams)
-            // (two adjacent columns per lane, W = 2, measured 0.38 ms: a wave's load then covers 2 KiB at half the lanes per line)
-            if (U == 2) RH_RS_LAUNCH(2, 1);
+            if (W == 4 && U <= 2) RH_RS_LAUNCH(2, 4);
+            else if (W == 4) RH_RS_LAUNCH(4, 4);
+            else if (W == 2 && U <= 2) RH_RS_LAUNCH(2, 2);
+            else if (W == 2 && U <= 4) RH_RS_LAUNCH(4, 2);
+            else if (W == 2 && U <= 6) RH_RS_LAUNCH(6, 2);
+            else if (W == 2) RH_RS_LAUNCH(8, 2);
+            else if (W == 3) RH_RS_LAUNCH(4, 3);
+            else if (U == 2) RH_RS_LAUNCH(2, 1);
             else if (U == 4) RH_RS_LAUNCH(4, 1);
             else if (U == 6) RH_RS_LAUNCH(6, 1);
             else RH_RS_LAUNCH(8, 1);
