@@ -463,7 +463,7 @@ typedef struct rh_rlm_geometry_info {
     uint32_t resident_waves_per_cu;
     uint32_t n_tiles;          /* grid of the last set_sources */
     uint32_t general_kernel;   /* 1: ragged-batch kernel (per-source carries), 0: equal-length kernel */
-    uint32_t ragged_pair;      /* 1: one-shot runs of this batch take k_rlm_fast<RAG> + k_rlm_resid instead of the ragged-batch kernel */
+    uint32_t ragged_pair;      /* 1: one-shot runs of this batch take k_rlm_fast<RAG> (stable sources summed first, the pairs of ending sources behind them) instead of the ragged-batch kernel */
     uint32_t mix_first;        /* one-shot runs of this batch (filtered, equal lengths) sum the sources at the input rate first and convert + filter
                                 * that one stream: 1 = two launches (k_mix_ring or k_mix_rows, then the fused kernel on one source),
                                 * 2 = one (k_rlm_chunk: long stereo rows) */

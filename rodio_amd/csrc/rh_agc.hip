@@ -19,6 +19,9 @@
 //     k_agc_chain<GainOp0>   release == 0 (the default): the release candidate is `desired` itself; the chain is multiply, add,
 //                            max, compare, select on values the parallel pass prepared                         -> gain[n]     (in place)
 //     k_agc_apply            y = x * gain, every lane of the chip
+// and, since round 4, for the default parameters and up to 16 streams per CU:
+//     k_agc_fused            ALL of the above in one workgroup per 16 streams: the two chains on a wave each, the square roots and
+//                            divides on four more, loaders and storers around them -- nothing but x in and y out   (see there)
 // Both chains MUST round like the reference, step by step: the window sum drifts 7e-5 relative over 2 Mi samples when
 // re-associated, and the gain -- a one-pole with a 4 s time constant, 192 000 samples at 48 kHz -- integrates its own rounding
 // noise to 5e-6 relative (x gain 7 = 4e-5 on the output): a scan over composed gain maps (g -> min(H, max(L, c*g + B)) is

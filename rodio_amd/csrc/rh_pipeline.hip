@@ -367,8 +367,8 @@ __device__ __forceinline__ void wait_groups(int n) {
 // RAG: the equal-length kernel as the first half of a ragged batch (rh_rlm_run on sources of different lengths,
 // with a filter).  A tile then takes only the sources that stay whole for it and the J tiles after it ("stable":
 // nothing about them needs a per-source aggregate, see k_rlm_wave) -- for a mixer's worth of tracks that is almost
-// every (tile, source) pair -- and k_rlm_resid, launched behind it, adds the few pairs in which a source is about
-// to end.  Mix order: stable sources first (the filtered pipeline is compared at 1e-5, not bitwise).
+// every (tile, source) pair -- and the few pairs in which a source is about to end follow (rag_run_pairs: inside this kernel since
+// round 4, Params::rag_merge; k_rlm_resid, launched behind it, in the two-launch form).  Mix order: stable sources first (the filtered pipeline is compared at 1e-5, not bitwise).
 // ---- channel count as a template parameter (C = 1: mono, C = 2: stereo) -------------------------------------------------------------
 // A frame is C floats.  Everything per channel goes through these few helpers, written so that C = 2 spells out exactly the
 // operations the stereo kernels always had (component by component, same order): the stereo code objects do not change.
