@@ -77,5 +77,12 @@ case "$1" in
     cp gpurun_out/prof/r04_ragged/summary.txt $E/r04_ragged_kernel_trace_pmc.txt
     python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -12 > $E/r04_final_gputests.txt
     ;;
+6)  # the side configurations again: final library, bench.py timing a region of back-to-back launches with one pair of events
+    for c in 3 5 limit biquad agc; do python bench.py --config $c > $E/r04_bench_$c.json 2>/dev/null; done
+    for c in limit agc biquad; do python bench.py --config $c --sources 2048 --frames 32768 > $E/r04_bench_${c}_2048.json 2>/dev/null; done
+    export RH_PROF_KERNEL=reverb_spatial
+    bash tools/pmc_cmd.sh r04_3 python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r04_3/summary.txt $E/r04_3_kernel_trace_pmc.txt
+    ;;
 esac
 ls -la $E | tail -40
