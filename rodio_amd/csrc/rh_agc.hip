@@ -98,9 +98,13 @@ struct SumOp {  // CircularBuffer::push, agc.rs:152-163: sum = sum - old + new
     template <bool HEAD>
     __device__ __forceinline__ v4f step4(v4f x, v4f o) {
         v4f nw, od;
+#ifdef RH_AGC_DIAG_NOSQ  // diagnostics builds (wrong results): what do the squares cost the chain wave?
+        nw = x, od = o;
+#else
         nw.x = x.x * x.x, nw.y = x.y * x.y, nw.z = x.z * x.z, nw.w = x.w * x.w;
         if (HEAD) od = o;
         else od.x = o.x * o.x, od.y = o.y * o.y, od.z = o.z * o.z, od.w = o.w * o.w;
+#endif
         v4f r;
         sum = sum - od.x + nw.x, r.x = sum;
         sum = sum - od.y + nw.y, r.y = sum;
@@ -500,10 +504,15 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < kFSub; ++j) {
                         // what does not wait for the gain first: clamp(desired) and desired * (1 - attack), the two operands of the chain
+#ifdef RH_AGC_DIAG_G  // diagnostics builds (wrong results): what do the two prepared operands cost the gain wave?
+                        const v4f da = d[j];
+                        v4f dc = d[j], r;
+#else
                         const v4f da = d[j] * oma;
                         v4f dc, r;
                         dc.x = __builtin_amdgcn_fmed3f(d[j].x, 0.1f, maxg), dc.y = __builtin_amdgcn_fmed3f(d[j].y, 0.1f, maxg);
                         dc.z = __builtin_amdgcn_fmed3f(d[j].z, 0.1f, maxg), dc.w = __builtin_amdgcn_fmed3f(d[j].w, 0.1f, maxg);
+#endif
                         gain = __builtin_amdgcn_fmed3f(gain * att + da.x, 0.1f, dc.x), r.x = gain;
                         gain = __builtin_amdgcn_fmed3f(gain * att + da.y, 0.1f, dc.y), r.y = gain;
                         gain = __builtin_amdgcn_fmed3f(gain * att + da.z, 0.1f, dc.z), r.z = gain;
@@ -531,8 +540,12 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
                 for (int h = 0; h < 2; ++h) {
                     const v4f s4 = *(const lds_v4 *)(img + q0 + h * 4096), x4 = *(const lds_v4 *)(inx + q0 + h * 4096);
                     v4f r;
+#ifdef RH_AGC_DIAG_D  // diagnostics builds (wrong results): what do the square roots and divides cost the pipeline?
+                    r = s4 + x4;
+#else
                     r.x = agc_desired(s4.x, fabsf(x4.x), a.k), r.y = agc_desired(s4.y, fabsf(x4.y), a.k);
                     r.z = agc_desired(s4.z, fabsf(x4.z), a.k), r.w = agc_desired(s4.w, fabsf(x4.w), a.k);
+#endif
                     *(lds_v4 *)(img + q0 + h * 4096) = r;
                 }
             }
