@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void k_mimic(const float *in, float *out, uint3
 // "Mix first" inside one kernel: tile t owns the ALIGNED 8 KiB chunk t of every source (8 full instructions) and needs one
 // 128-byte line on either side of it (the neighbours' taps): a ninth instruction whose lanes 0..7 / 8..15 fetch the line
 // before / after the chunk, the other lanes clamped onto the last of them.  HALO = 0: without the ninth instruction.
-template <int NS, int HALO>
+template <int NS, int HALO, int ROT = 0>
 __global__ __launch_bounds__(64) void k_halo(const float *in, float *out, uint32_t S, uint64_t src_stride_f, uint32_t n_chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KV = 8 + HALO;
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(64) void k_halo(const float *in, float *out, uint32
         off[KV - 1] = (uint32_t)v * 4;
     }
     auto issue = [&](uint32_t s) {
-        const float *g = in + (uint64_t)s * src_stride_f;
+        // ROT: every tile starts its walk over the sources somewhere else (ROT * tile sources in): the tiles of a launch then read S
+        // different rows at a time instead of all of them the same one
+        const uint32_t sr = ROT ? (s + tile * (uint32_t)ROT) % S : s;
+        const float *g = in + (uint64_t)sr * src_stride_f;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (s % NS) * KV * 1024);
 #pragma unroll
         for (int kk = 0; kk < KV; ++kk) glds16(g + off[kk], dst + kk * 1024);
@@ -253,6 +256,11 @@ int main(int argc, char **argv) {
             printf("%-14s waves %5u (%.2f per CU) : %.3f ms  %6.0f GB/s  %5.2f GB/s per wave  %5.0f ns per 8 KiB\n", name, tiles, tiles / 256.0, best, bytes / best / 1e6, bytes / best / 1e6 / tiles,
                    best * 1e6 / S);
         };
+        timeo("ring 2, rot 1", k_halo<2, 0, 1>, 1024, 2 * 8 * 1024);
+        timeo("ring 2, rot 7", k_halo<2, 0, 7>, 1024, 2 * 8 * 1024);
+        timeo("ring 2, rot 37", k_halo<2, 0, 37>, 1024, 2 * 8 * 1024);
+        timeo("ring 2, rot 64", k_halo<2, 0, 64>, 1024, 2 * 8 * 1024);
+        timeo("ring 3, rot 37", k_halo<3, 0, 37>, 1024, 3 * 8 * 1024);
         for (uint32_t tiles : {1024u, 768u, 512u, 384u, 256u, 128u, 32u, 1u}) {
             timeo("ring of 2", k_halo<2, 0>, tiles, 2 * 8 * 1024);
             timeo("ring of 3", k_halo<3, 0>, tiles, 3 * 8 * 1024);
