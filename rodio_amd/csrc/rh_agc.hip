@@ -19,7 +19,7 @@
 //     k_agc_chain<GainOp0>   release == 0 (the default): the release candidate is `desired` itself; the chain is multiply, add,
 //                            max, compare, select on values the parallel pass prepared                         -> gain[n]     (in place)
 //     k_agc_apply            y = x * gain, every lane of the chip
-// and, since round 4, for the default parameters and up to 16 streams per CU:
+// and, since round 4, for up to 16 streams per CU (k_agc_fused<true>: any parameters, the peak follower as a third chain wave):
 //     k_agc_fused            ALL of the above in one workgroup per 16 streams: the two chains on a wave each, the square roots and
 //                            divides on four more, loaders and storers around them -- nothing but x in and y out   (see there)
 // Both chains MUST round like the reference, step by step: the window sum drifts 7e-5 relative over 2 Mi samples when
@@ -394,6 +394,13 @@ static_assert(kFS * kFV * 16 == (int)kSlotBytes, "a chunk image is 8 KiB");
 constexpr uint32_t kFOBase = kFRX * kSlotBytes, kFABase = kFOBase + kFRO * kSlotBytes, kFFin = kFABase + kFRA * kSlotBytes;
 constexpr size_t kFusedLds = (size_t)kFFin + kFS * 4;  // 120 KiB + 64 B
 constexpr int kFWaves = 12;
+// Any other parameters (release != 0): the peak follower is a third chain (wave 12, on the window sum's SIMD: two chains leave each
+// other's issue slots alone), its levels go to D through an image of their own (4 more chunks), and the gain takes both candidates
+// (GainOp).  Everything else is the same pipeline.
+constexpr uint32_t kFPBase = kFFin;                                      // the peak images (GEN only)
+constexpr uint32_t kFFinG = kFPBase + kFRA * kSlotBytes;                 // final gain [16] | final peak [16]
+constexpr size_t kFusedLdsG = (size_t)kFFinG + 2 * kFS * 4;              // 152 KiB + 128 B
+constexpr int kFWavesG = 13;
 // the image: slot o*32 + (j ^ o) holds vector j of stream o's chunk -- the 16 chain lanes, each on vector j of its own stream, then
 // hit 16 different bank groups although the rows are not padded
 __device__ __forceinline__ constexpr uint32_t fslot_of(uint32_t o, uint32_t j) { return o * kFV + (j ^ (o & (kFV - 1))); }
@@ -413,11 +420,13 @@ __device__ __forceinline__ float agc_desired(float sum, float p, const AgcK &k) 
     const float peak_gain = p > 0.0f ? fminf(k.target_level / p, k.absolute_max_gain) : k.absolute_max_gain;
     return fmaxf(fminf(rms_gain, peak_gain), k.floor);
 }
-__global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
+template <bool GEN>
+__global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lds_u8 *const lds = (lds_u8 *)smem;
     typedef __attribute__((address_space(3))) v4f lds_v4;
     typedef __attribute__((address_space(3))) float lds_f;
+    constexpr uint32_t kFin = GEN ? kFFinG : kFFin;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / 64), lane = (int)threadIdx.x & 63;
     const uint32_t g0 = blockIdx.x * (uint32_t)kFS;
     const uint32_t live = a.n_streams - g0 < (uint32_t)kFS ? a.n_streams - g0 : (uint32_t)kFS;
@@ -466,22 +475,72 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
         if (mine) {  // the last n % 128 samples: every stage, one sample at a time, straight from memory
             const float *r0 = a.in + (uint64_t)stream * a.stride;
             float *ro = a.out + (uint64_t)stream * a.stride_out;
-            float gain = *(const lds_f *)(lds + kFFin + lane * 4);
             const float oma = 1.0f - a.k.attack_coeff;
-            for (uint64_t i = (uint64_t)nch * kFCS; i < a.n; ++i) {
-                const bool head = i < (uint64_t)kRmsWindow;
-                const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
-                const float xv = r0[i];
-                const float sm = op.one(xv, ov, head);
-                const float d = agc_desired(sm, fabsf(xv), a.k);
-                const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
-                gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
-                ro[i] = xv * gain;
+            if constexpr (GEN) {
+                GainOp gop;
+                gop.att = a.k.attack_coeff, gop.rel = a.k.release_coeff, gop.oma = 1.0f - gop.att, gop.omr = 1.0f - gop.rel, gop.maxg = a.k.absolute_max_gain;
+                gop.gain = *(const lds_f *)(lds + kFin + lane * 4);
+                PeakOp pop;
+                pop.peak = *(const lds_f *)(lds + kFin + (kFS + lane) * 4);
+                pop.rel = a.k.release_coeff;
+                for (uint64_t i = (uint64_t)nch * kFCS; i < a.n; ++i) {
+                    const bool head = i < (uint64_t)kRmsWindow;
+                    const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
+                    const float xv = r0[i];
+                    const float sm = op.one(xv, ov, head);
+                    const float pk = pop.one(xv, 0.f, false);
+                    ro[i] = gop.one(xv, agc_desired(sm, pk, a.k), false);
+                }
+                st[0] = op.sum;
+                st[2] = pop.peak;
+                st[3] = gop.gain;
+            } else {
+                float gain = *(const lds_f *)(lds + kFin + lane * 4);
+                for (uint64_t i = (uint64_t)nch * kFCS; i < a.n; ++i) {
+                    const bool head = i < (uint64_t)kRmsWindow;
+                    const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
+                    const float xv = r0[i];
+                    const float sm = op.one(xv, ov, head);
+                    const float d = agc_desired(sm, fabsf(xv), a.k);
+                    const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
+                    gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
+                    ro[i] = xv * gain;
+                }
+                st[0] = op.sum;
+                st[3] = gain;
+                if (a.n) st[2] = fabsf(r0[a.n - 1]);  // release == 0: the peak level is the last sample's magnitude
             }
-            st[0] = op.sum;
-            st[3] = gain;
-            if (a.n) st[2] = fabsf(r0[a.n - 1]);  // release == 0: the peak level is the last sample's magnitude
         }
+        return;
+    }
+    if (GEN && wave == 12) {  // ---- P: the peak follower, lane = stream (agc.rs:397-407) ----
+        const float *st = a.state + (uint64_t)stream * a.state_stride;
+        PeakOp pop;
+        pop.peak = st[2];
+        pop.rel = a.k.release_coeff;
+        uint32_t sx = 0, sa = 0;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            if (t < nch && chain_lane) {
+                const lds_u8 *inx = lds + sx * kSlotBytes;
+                lds_u8 *img = lds + kFPBase + sa * kSlotBytes;
+                for (int b = 0; b < kFV / kFSub; ++b) {
+                    v4f x[kFSub];
+                    uint32_t sl[kFSub];
+#pragma unroll
+                    for (int j = 0; j < kFSub; ++j) {
+                        sl[j] = fslot_of((uint32_t)lane & (kFS - 1), (uint32_t)(b * kFSub + j)) * 16u;
+                        x[j] = *(const lds_v4 *)(inx + sl[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kFSub; ++j) *(lds_v4 *)(img + sl[j]) = pop.template step4<false>(x[j], v4f{0.f, 0.f, 0.f, 0.f});
+                }
+            }
+            sx = sx + 1 == (uint32_t)kFRX ? 0 : sx + 1;
+            sa = (sa + 1) & (kFRA - 1);
+        }
+        if (chain_lane) *(lds_f *)(lds + kFin + (kFS + lane) * 4) = pop.peak;
+        barrier_lds();
         return;
     }
     if (wave == 1) {  // ---- G: the gain, lane = stream (agc.rs:486-499 with release == 0: GainOp0) ----
@@ -503,6 +562,20 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
                     }
 #pragma unroll
                     for (int j = 0; j < kFSub; ++j) {
+                        if constexpr (GEN) {  // both candidates, select, clamp (GainOp without its output multiply: Y's)
+                            const float omr = 1.0f - a.k.release_coeff, rel = a.k.release_coeff;
+                            const v4f da = d[j] * oma, dr = d[j] * omr;
+                            v4f r;
+                            auto one = [&](float dd, float daa, float drr) {
+                                const float ca = gain * att + daa, cr = gain * rel + drr;
+                                const float g = dd > gain ? ca : cr;
+                                gain = __builtin_amdgcn_fmed3f(g, 0.1f, maxg);
+                                return gain;
+                            };
+                            r.x = one(d[j].x, da.x, dr.x), r.y = one(d[j].y, da.y, dr.y), r.z = one(d[j].z, da.z, dr.z), r.w = one(d[j].w, da.w, dr.w);
+                            *(lds_v4 *)(img + sl[j]) = r;
+                            continue;
+                        }
                         // what does not wait for the gain first: clamp(desired) and desired * (1 - attack), the two operands of the chain
 #ifdef RH_AGC_DIAG_G  // diagnostics builds (wrong results): what do the two prepared operands cost the gain wave?
                         const v4f da = d[j];
@@ -523,7 +596,7 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
             }
             sa = (sa + 1) & (kFRA - 1);
         }
-        if (chain_lane) *(lds_f *)(lds + kFFin + lane * 4) = gain;
+        if (chain_lane) *(lds_f *)(lds + kFin + lane * 4) = gain;
         barrier_lds();
         return;
     }
@@ -538,7 +611,10 @@ __global__ __launch_bounds__(64 * kFWaves) void k_agc_fused(const FusedArgs a) {
                 lds_u8 *img = lds + kFABase + sa * kSlotBytes;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const v4f s4 = *(const lds_v4 *)(img + q0 + h * 4096), x4 = *(const lds_v4 *)(inx + q0 + h * 4096);
+                    const v4f s4 = *(const lds_v4 *)(img + q0 + h * 4096);
+                    v4f x4;  // the peak level: the follower's, or with release == 0 the sample's magnitude (fabsf below is then the identity or the level)
+                    if constexpr (GEN) x4 = *(const lds_v4 *)(lds + kFPBase + sa * kSlotBytes + q0 + h * 4096);
+                    else x4 = *(const lds_v4 *)(inx + q0 + h * 4096);
                     v4f r;
 #ifdef RH_AGC_DIAG_D  // diagnostics builds (wrong results): what do the square roots and divides cost the pipeline?
                     r = s4 + x4;
@@ -800,7 +876,7 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     // LDS-DMA (one stream of an odd length -- 1 x 40 001 -- would otherwise put them 4 to 12 bytes off)
     // release == 0 in one kernel (k_agc_fused): no rows of intermediates at all.  RH_AGC_SEGMENTS=1: the segment-by-segment form
     // ... for batches of up to 16 streams per CU (a workgroup takes 16: see k_agc_fused)
-    const bool fused = !general && n_streams <= (uint32_t)(kFS * rh::g_num_cus) && !rh::knob(rh::K_AGC_SEGMENTS);
+    const bool fused = n_streams <= (uint32_t)(kFS * rh::g_num_cus) && !rh::knob(rh::K_AGC_SEGMENTS);
     const size_t rows_floats = fused ? 0 : (((size_t)n_streams * n_samples + 3) & ~(size_t)3);
     const size_t scratch_floats = fresh_floats + win_floats + rows_floats + (presq && !fused ? (size_t)n_streams * pstride : 0);
     // The scratch is as large as the batch (twice with the squares) and stays with the stream: a batch that would pin more than 8 GiB
@@ -858,8 +934,10 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     auto par_grid = [&](uint64_t len) { return dim3(rh::grid_tiles((size_t)n_streams * ((len + 3) / 4) + 1)); };
     rh_status st = RH_OK;
     if (fused) {
-        static const rh_status attr = chain_attr_n(&k_agc_fused, "hipFuncSetAttribute(k_agc_fused)", kFusedLds);
-        if (attr != RH_OK) return attr;
+        static const rh_status attr0 = chain_attr_n(&k_agc_fused<false>, "hipFuncSetAttribute(k_agc_fused)", kFusedLds);
+        static const rh_status attr1 = chain_attr_n(&k_agc_fused<true>, "hipFuncSetAttribute(k_agc_fused)", kFusedLdsG);
+        if (attr0 != RH_OK) return attr0;
+        if (attr1 != RH_OK) return attr1;
         FusedArgs f;
         f.in = src;
         f.in1_head = ordered;
@@ -870,7 +948,8 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
         f.state = base.state;
         f.state_stride = base.state_stride;
         f.k = k;
-        hipLaunchKernelGGL(k_agc_fused, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWaves), kFusedLds, s, f);
+        if (general) hipLaunchKernelGGL(k_agc_fused<true>, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWavesG), kFusedLdsG, s, f);
+        else hipLaunchKernelGGL(k_agc_fused<false>, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWaves), kFusedLds, s, f);
         RH_CHECK_LAUNCH();
     } else if (general) {
         // window sum -> dst and peak follower -> rows side by side, desired gain in place, then the gain chain with both candidates

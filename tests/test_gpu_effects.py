@@ -134,9 +134,11 @@ def test_agc_chains_equal_the_reference_order_kernel(G, O, kw):
         assert float(np.max(np.abs(a - b))) <= 1e-6
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2)])
 @pytest.mark.parametrize("S,n", [(1, 100), (3, 127), (16, 128), (17, 8192 + 300), (5, 40004), (40, 33000)])
-def test_agc_in_one_kernel_equals_the_segment_by_segment_form(G, O, S, n):
-    """k_agc_fused (round 4: the default parameters as a four-stage pipeline inside one workgroup of 16 streams, chunks of 128 samples)
+def test_agc_in_one_kernel_equals_the_segment_by_segment_form(G, O, S, n, kw):
+    """k_agc_fused (round 4: a four-stage pipeline inside one workgroup of 16 streams, chunks of 128 samples; other parameters than the
+    defaults add the peak follower as a third chain)
     against the chain kernels with the elementwise passes between them (RH_AGC_SEGMENTS=1): the same operations in the same order,
     so the same bits -- rows shorter than a chunk (everything in the epilogue), partial groups of streams, tails, and a state carried
     across blocks that are shorter and longer than the 8192-sample window."""
@@ -144,19 +146,19 @@ def test_agc_in_one_kernel_equals_the_segment_by_segment_form(G, O, S, n):
 
     xs = [_programme(700 + s, n + 8)[:n] for s in range(S)]
     x = torch.from_numpy(np.stack(xs)).cuda()
-    a = G.agc_batch(x, 48000).cpu().numpy()
+    a = G.agc_batch(x, 48000, **kw).cpu().numpy()
     with _env(RH_AGC_SEGMENTS="1"):
-        b = G.agc_batch(x, 48000).cpu().numpy()
+        b = G.agc_batch(x, 48000, **kw).cpu().numpy()
     assert np.array_equal(a, b)
     for s_ in range(min(S, 3)):
-        ref = O.TestSource(xs[s_], 1, 48000).automatic_gain_control().collect()
+        ref = O.TestSource(xs[s_], 1, 48000).automatic_gain_control(**kw).collect()
         assert float(np.max(np.abs(a[s_] - ref))) <= TOL
     # block streaming: the carried window and the four state words go in and out of the one kernel
     cuts = sorted(set([0, n] + [4 * int(c) for c in np.random.default_rng(S * 1000 + n).integers(1, max(n // 4, 2), 5) if 4 * int(c) < n]))
     st_a, st_b = G.agc_state(S), G.agc_state(S)
-    pa = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_a) for i, j in zip(cuts[:-1], cuts[1:])]
+    pa = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_a, **kw) for i, j in zip(cuts[:-1], cuts[1:])]
     with _env(RH_AGC_SEGMENTS="1"):
-        pb = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_b) for i, j in zip(cuts[:-1], cuts[1:])]
+        pb = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_b, **kw) for i, j in zip(cuts[:-1], cuts[1:])]
     whole = torch.cat(pa, dim=1).cpu().numpy()
     assert float(np.max(np.abs(whole - a))) <= 1e-6  # (a block boundary moves nothing but GainOp0's tie)
     for u, v in zip(pa, pb):
