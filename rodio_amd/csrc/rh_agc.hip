@@ -394,13 +394,14 @@ static_assert(kFS * kFV * 16 == (int)kSlotBytes, "a chunk image is 8 KiB");
 constexpr uint32_t kFOBase = kFRX * kSlotBytes, kFABase = kFOBase + kFRO * kSlotBytes, kFFin = kFABase + kFRA * kSlotBytes;
 constexpr size_t kFusedLds = (size_t)kFFin + kFS * 4;  // 120 KiB + 64 B
 constexpr int kFWaves = 12;
-// Any other parameters (release != 0): the peak follower is a third chain (wave 12, on the window sum's SIMD: two chains leave each
-// other's issue slots alone), its levels go to D through an image of their own (4 more chunks), and the gain takes both candidates
-// (GainOp).  Everything else is the same pipeline.
+// Any other parameters (release != 0): the peak follower is a third chain (wave 8, on the window sum's SIMD: two chains leave each
+// other's issue slots alone; wave 9 then loads all of x_old), its levels go to D through an image of their own (4 more chunks), and
+// the gain takes both candidates (GainOp).  Everything else is the same pipeline, in the same twelve waves (a thirteenth would cut
+// the registers of all of them to 128 a lane: spills).
 constexpr uint32_t kFPBase = kFFin;                                      // the peak images (GEN only)
 constexpr uint32_t kFFinG = kFPBase + kFRA * kSlotBytes;                 // final gain [16] | final peak [16]
 constexpr size_t kFusedLdsG = (size_t)kFFinG + 2 * kFS * 4;              // 152 KiB + 128 B
-constexpr int kFWavesG = 13;
+constexpr int kFWavesG = 12;
 // the image: slot o*32 + (j ^ o) holds vector j of stream o's chunk -- the 16 chain lanes, each on vector j of its own stream, then
 // hit 16 different bank groups although the rows are not padded
 __device__ __forceinline__ constexpr uint32_t fslot_of(uint32_t o, uint32_t j) { return o * kFV + (j ^ (o & (kFV - 1))); }
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
         }
         return;
     }
-    if (GEN && wave == 12) {  // ---- P: the peak follower, lane = stream (agc.rs:397-407) ----
+    if (GEN && wave == 8) {  // ---- P: the peak follower, lane = stream (agc.rs:397-407) ----
         const float *st = a.state + (uint64_t)stream * a.state_stride;
         PeakOp pop;
         pop.peak = st[2];
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
     }
     // ---- the loaders (waves 4 5: x; 8 9: what leaves the window), kFAhead chunks ahead of S ----
     const int second = wave >= 8 ? 1 : 0, half = wave & 1;
+    const bool all = GEN && wave == 9;  // (its partner walks the peak follower: this wave issues the whole chunk)
     const uint32_t ring = second ? (uint32_t)kFRO : (uint32_t)kFRX;
     const uint32_t lbase = (uint32_t)(uintptr_t)lds + (second ? kFOBase : 0u);
     uint32_t voff[kDma];  // host: kFS * stride * 4 < 2^32
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
             const float *bh = a.in1_head + (uint64_t)g0 * kRmsWindow + (uint64_t)c * kFCS;
 #pragma unroll
             for (int k = 0; k < kDma; ++k)
-                if (k / kMine == half) glds16(bh, (((so[k] < live ? so[k] : live - 1) * kRmsWindow + sj[k] * 4u) * 4u), slot + k * 1024);
+                if (all || k / kMine == half) glds16(bh, (((so[k] < live ? so[k] : live - 1) * kRmsWindow + sj[k] * 4u) * 4u), slot + k * 1024);
             return;
         }
         // (a fresh window -- zeros, S does not read the slot -- still fetches, x again: every chunk counts the same in vmcnt)
@@ -688,15 +690,21 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
         const float *b = a.in + (uint64_t)g0 * a.stride + (uint64_t)c * kFCS - (self ? 0 : kRmsWindow);
 #pragma unroll
         for (int k = 0; k < kDma; ++k)
-            if (k / kMine == half) glds16(b, voff[k], slot + k * 1024);
+            if (all || k / kMine == half) glds16(b, voff[k], slot + k * 1024);
     };
     for (uint32_t c = 0; c < nch && c < (uint32_t)kFAhead; ++c) issue(c);
     for (uint32_t t = 0; t < nsteps; ++t) {
         if (t < nch) {  // chunk t has landed when only the chunks issued after it are outstanding (vmcnt retires in order)
             const uint32_t left = nch - 1 - t;
-            if (left >= (uint32_t)(kFAhead - 1)) wait_vm<(kFAhead - 1) * kMine>();
-            else if (left == 1) wait_vm<kMine>();
-            else wait_vm<0>();
+            if (left >= (uint32_t)(kFAhead - 1)) {
+                if (all) wait_vm<(kFAhead - 1) * kDma>();
+                else wait_vm<(kFAhead - 1) * kMine>();
+            } else if (left == 1) {
+                if (all) wait_vm<kDma>();
+                else wait_vm<kMine>();
+            } else {
+                wait_vm<0>();
+            }
         }
         barrier_lds();
         // x: into the slot of chunk t - 4, which Y left before this barrier; x_old: into the slot of chunk t - 1, which S did
