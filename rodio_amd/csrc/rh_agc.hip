@@ -883,8 +883,8 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     // the `rows` region rounded up to whole 16-byte vectors: the squares behind it are written with v4f stores and fetched by 16-byte
     // LDS-DMA (one stream of an odd length -- 1 x 40 001 -- would otherwise put them 4 to 12 bytes off)
     // release == 0 in one kernel (k_agc_fused): no rows of intermediates at all.  RH_AGC_SEGMENTS=1: the segment-by-segment form
-    // ... for batches of up to 16 streams per CU (a workgroup takes 16: see k_agc_fused)
-    const bool fused = n_streams <= (uint32_t)(kFS * rh::g_num_cus) && !rh::knob(rh::K_AGC_SEGMENTS);
+    // (any number of streams: a workgroup takes 16, a CU one workgroup at a time)
+    const bool fused = !rh::knob(rh::K_AGC_SEGMENTS);
     const size_t rows_floats = fused ? 0 : (((size_t)n_streams * n_samples + 3) & ~(size_t)3);
     const size_t scratch_floats = fresh_floats + win_floats + rows_floats + (presq && !fused ? (size_t)n_streams * pstride : 0);
     // The scratch is as large as the batch (twice with the squares) and stays with the stream: a batch that would pin more than 8 GiB

@@ -135,7 +135,7 @@ def test_agc_chains_equal_the_reference_order_kernel(G, O, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(target_level=0.5, attack_ns=10_000_000, release_ns=5_000_000, absolute_max_gain=5.0, floor=0.2)])
-@pytest.mark.parametrize("S,n", [(1, 100), (3, 127), (16, 128), (17, 8192 + 300), (5, 40004), (40, 33000)])
+@pytest.mark.parametrize("S,n", [(1, 100), (3, 127), (16, 128), (17, 8192 + 300), (5, 40004), (40, 33000), (4200, 520)])  # (4200 streams: more workgroups than CUs)
 def test_agc_in_one_kernel_equals_the_segment_by_segment_form(G, O, S, n, kw):
     """k_agc_fused (round 4: a four-stage pipeline inside one workgroup of 16 streams, chunks of 128 samples; other parameters than the
     defaults add the peak follower as a third chain)
