@@ -407,10 +407,10 @@ __device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a :
 
 // (the pairs of a ragged batch in which a source is about to end: defined below, next to k_rlm_resid)
 __device__ __forceinline__ uint32_t rag_find_pairs(const Params &p, const uint32_t m_tile0, const uint32_t m_stable, const int lane, lds_u8 *lds, const uint32_t list_off);
-template <int R, int KV>
+template <int R, int KV, int C>
 __device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long long *const rows, const uint32_t tile, const uint32_t n_pairs, const int lane, lds_u8 *lds, const uint32_t lds0,
                                               const uint32_t list_off, const uint32_t i_base, const uint32_t nvec, const uint32_t (&goff)[KV], const int (&offA)[R + 2], const float (&wgt)[R + 2],
-                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], v2f (&acc)[R]);
+                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], typename Chan<C>::V (&acc)[R]);
 
 // SUMF (with RAG): sum first -- the stable sources of a tile share the tile's span, taps and weights, so their spans are SUMMED as
 // they land (one FMA per float) and the lerp, the zero-state filter and everything behind it run once, on the sum (§4.6).
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) CH::set(acc[r], ch, fma_(p.u.g[r][0], Q[2 * ch], fma_(p.u.g[r][1], Q[2 * ch + 1], CH::get(acc[r], ch))));
         }
-        if constexpr (RAG && SUMF && C == 2) {
+        if constexpr (RAG && SUMF) {
             // The tile's own pairs in which a source is about to end, onto the mix in registers (the ring's first two stages and
             // 128 bytes behind the ring are theirs now).  Few tiles have any, and those are the lighter ones.
             const uint32_t m_far = m_tile0 + (p.J + 1u) * L;
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(64, (R <= 4 ? (KV <= 5 ? 5 : 4) : R <= 6 ? 3 : R <=
                 RH_PH(5)
                 const uint32_t n_pairs = rag_find_pairs(p, m_tile0, m_stable, lane, lds, NS * kStage);
                 if (n_pairs)
-                    rag_run_pairs<R, KV>(p, p.gran - (uint64_t)p.n_sources * p.n_tiles * 4, tile, n_pairs, lane, lds, lds0, NS * kStage, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
+                    rag_run_pairs<R, KV, C>(p, p.gran - (uint64_t)p.n_sources * p.n_tiles * 4, tile, n_pairs, lane, lds, lds0, NS * kStage, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
                 RH_PH(3)
             }
         }
@@ -2264,10 +2264,13 @@ __device__ __forceinline__ uint32_t rag_find_pairs(const Params &p, const uint32
 // The pairs one after the other, the span of the NEXT one already on its way (two stages of KV KiB at lds + 0 and lds + KV KiB): a
 // pair costs a memory round trip to stage and another to poll, and nothing else of this tile could hide them.  `rows`: the
 // per-source aggregate rows.  offA / wgt: taps and weights of the lane's R + 2 frames (the caller's: the tile geometry is shared).
-template <int R, int KV>
+template <int R, int KV, int C>
 __device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long long *const rows, const uint32_t tile, const uint32_t n_pairs, const int lane, lds_u8 *lds, const uint32_t lds0,
                                               const uint32_t list_off, const uint32_t i_base, const uint32_t nvec, const uint32_t (&goff)[KV], const int (&offA)[R + 2], const float (&wgt)[R + 2],
-                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], v2f (&acc)[R]) {
+                                              const float (&lM)[4], const float (&b15)[4], const float (&b31)[4], const float (&kM)[4], typename Chan<C>::V (&acc)[R]) {
+    typedef Chan<C> CH;
+    typedef typename CH::V V;
+    constexpr uint32_t FB = CH::kFB, VF = CH::kVF;
     constexpr uint32_t L = 64u * R, kStage = KV * 1024;
     const uint32_t m_tile0 = tile * L, m0 = m_tile0 + (uint32_t)lane * R;
     const bool first = (m0 == 0);
@@ -2281,11 +2284,11 @@ __device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long lon
         const uint64_t plo = desc[8 * (uint64_t)s], phi = desc[8 * (uint64_t)s + 1];
         const void *data = (const void *)(uintptr_t)(plo | (phi << 32));
         const uint32_t Ns = desc[8 * (uint64_t)s + 2];
-        if (i_base + 2u * nvec <= Ns) {
+        if (i_base + VF * nvec <= Ns) {
 #pragma unroll
             for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage_off + k * 1024);
         } else {
-            const uint32_t lastoff = ((Ns - 1) & ~1u) * 8u;
+            const uint32_t lastoff = ((Ns - 1) & ~(VF - 1u)) * FB;
 #pragma unroll
             for (int k = 0; k < KV; ++k) glds16(data, goff[k] < lastoff ? goff[k] : lastoff, lds0 + stage_off + k * 1024);
         }
@@ -2305,40 +2308,44 @@ __device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long lon
         const uint32_t Ns = desc[8 * (uint64_t)s + 2];
         const float g = __uint_as_float(desc[8 * (uint64_t)s + 4]);
         const uint32_t dthr = Ns - 1 - i_base;  // Ms > m_tile0 => i_base <= Ns-1
-        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * 8u);
+        const int thr = (int)((dthr < (1u << 27) ? dthr : (1u << 27)) * FB);
         const int nvalid = Ms >= m0 + R ? R : (Ms > m0 ? (int)(Ms - m0) : 0);
-        auto tap = [&](int rr) -> v2f {
-            const v2f a = *(const lds_f2 *)(buf + offA[rr]), b = *(const lds_f2 *)(buf + offA[rr] + 8);
-            v2f x;
-            x.x = fma_(b.x - a.x, wgt[rr], a.x);
-            x.y = fma_(b.y - a.y, wgt[rr], a.y);
+        auto tap = [&](int rr) -> V {
+            const V a = CH::ld_lds(buf + offA[rr]), b = CH::ld_lds(buf + offA[rr] + FB);
             const bool last = offA[rr] >= thr;  // the source's last frame is emitted verbatim (sample_rate.rs:193-200)
-            x.x = last ? a.x : x.x;
-            x.y = last ? a.y : x.y;
+            V x;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float ac = CH::get(a, ch), bc = CH::get(b, ch);
+                const float l = fma_(bc - ac, wgt[rr], ac);
+                CH::set(x, ch, last ? ac : l);
+            }
             return x;
         };
-        v2f x2 = first ? v2f{0.f, 0.f} : tap(0);
-        v2f x1 = first ? v2f{0.f, 0.f} : tap(1);
-        v2f w1 = {0.f, 0.f}, w2 = {0.f, 0.f};
+        V x2 = first ? CH::zero() : tap(0);
+        V x1 = first ? CH::zero() : tap(1);
+        V w1 = CH::zero(), w2 = CH::zero();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const v2f x = tap(r + 2);
-            v2f w;
-            w.x = fma_(na1, w1.x, fma_(na2, w2.x, fma_(c2, x2.x, c1 * x1.x)));
-            w.y = fma_(na1, w1.y, fma_(na2, w2.y, fma_(c2, x2.y, c1 * x1.y)));
+            const V x = tap(r + 2);
+            V w;
             const bool v = r < nvalid;
-            const float yx = v ? fma_(b0, x.x, w.x) : 0.0f, yy = v ? fma_(b0, x.y, w.y) : 0.0f;
-            acc[r].x = fma_(g, yx, acc[r].x);
-            acc[r].y = fma_(g, yy, acc[r].y);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float wc = fma_(na1, CH::get(w1, ch), fma_(na2, CH::get(w2, ch), fma_(c2, CH::get(x2, ch), c1 * CH::get(x1, ch))));
+                CH::set(w, ch, wc);
+                const float y = v ? fma_(b0, CH::get(x, ch), wc) : 0.0f;
+                CH::set(acc[r], ch, fma_(g, y, CH::get(acc[r], ch)));
+            }
             w2 = w1;
             w1 = w;
             x2 = x1;
             x1 = x;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free for the pair after next
-        float P[4] = {0.f, 0.f, 0.f, 0.f};
-        mat_acc(p.u.Tm, w1.x * g, w2.x * g, P[0], P[1]);
-        mat_acc(p.u.Tm, w1.y * g, w2.y * g, P[2], P[3]);
+        float P[4] = {0.f, 0.f, 0.f, 0.f};  // (mono: the second channel's words stay zero and travel as zeros, as in k_rlm_wave)
+        mat_acc(p.u.Tm, CH::get(w1, 0) * g, CH::get(w2, 0) * g, P[0], P[1]);
+        if (C == 2) mat_acc(p.u.Tm, CH::get(w1, C - 1) * g, CH::get(w2, C - 1) * g, P[2], P[3]);
 #define RH_SCAN_STEP(K, N)                                                                          \
     {                                                                                               \
         const float q0 = dpp0<kDppRowShr + N, 0xf>(P[0]), q1 = dpp0<kDppRowShr + N, 0xf>(P[1]);     \
@@ -2425,8 +2432,8 @@ __device__ __forceinline__ void rag_run_pairs(const Params &p, unsigned long lon
         for (int r = 0; r < R; ++r) {
             const bool v = r < nvalid;
             const float hx = fma_(p.u.g[r][0], Q[0], p.u.g[r][1] * Q[1]), hy = fma_(p.u.g[r][0], Q[2], p.u.g[r][1] * Q[3]);
-            acc[r].x += v ? hx : 0.0f;
-            acc[r].y += v ? hy : 0.0f;
+            CH::set(acc[r], 0, CH::get(acc[r], 0) + (v ? hx : 0.0f));
+            if (C == 2) CH::set(acc[r], C - 1, CH::get(acc[r], C - 1) + (v ? hy : 0.0f));
         }
     }
 }
@@ -2504,7 +2511,7 @@ __global__ __launch_bounds__(64) void k_rlm_resid(const Params p) {
             acc[r] = v2f{v.x, v.y};
         }
     }
-    rag_run_pairs<R, KV>(p, p.gran, tile, n_pairs, lane, lds, lds0, kList, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
+    rag_run_pairs<R, KV, 2>(p, p.gran, tile, n_pairs, lane, lds, lds0, kList, i_base, nvec, goff, offA, wgt, lM, b15, b31, kM, acc);
     float *o = p.out + (uint64_t)m0 * 2;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -2623,6 +2630,12 @@ const Variant kWave[] = {
 const Variant kRag[] = {
     RH_RAG(6, 3), RH_RAG(6, 4), RH_RAG(6, 7), RH_RAG(6, 14), RH_RAG(8, 4), RH_RAG(8, 5), RH_RAG(8, 9), RH_RAG(9, 5), RH_RAG(10, 5), RH_RAG(10, 6), RH_RAG(12, 6), RH_RAG(12, 7),
     RH_RAG(14, 7), RH_RAG(14, 8), RH_RAG(18, 9), RH_RAG(18, 10),
+};
+// ... and for mono sources (no launch of its own for the pairs: they run inside the kernel)
+const Variant kRag1[] = {
+#define RH_RAG1(r, kv) Variant{r, kv, 2, &k_rlm_fast<r, kv, 2, true, true, 1, true>, nullptr}
+    RH_RAG1(6, 2), RH_RAG1(8, 2), RH_RAG1(8, 3), RH_RAG1(10, 3), RH_RAG1(12, 3), RH_RAG1(12, 4), RH_RAG1(16, 4), RH_RAG1(16, 5), RH_RAG1(18, 5),
+#undef RH_RAG1
 };
 // mono (C = 1): a frame is 4 bytes, so a stage holds twice the frames per KiB
 #define RH_FAST1(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true, false, 1>, &k_rlm_fast<r, kv, ns, false, false, 1>}
@@ -3282,17 +3295,17 @@ rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
     } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
         st = RH_ERR_INVALID;
     }
-    if (st == RH_OK && p->filt && !mono) {  // optional (stereo only).  It follows the overrides when it has that geometry; otherwise the longest runs that
+    if (st == RH_OK && p->filt) {  // optional.  It follows the overrides when it has that geometry; otherwise the longest runs that
         // still give every CU three tiles (measured on 256 sources of [N/2, N] frames: 0.366 / 0.352 / 0.336 / 0.328 / 0.319 / 0.319 ms for
         // 6 / 8 / 10 / 12 / 14 / 18 frames per lane -- the first half sums first, so a tile's fixed costs are all that is left to amortise)
         rh_status ps = RH_ERR_UNSUPPORTED;
-        if (cfg->frames_per_lane || cfg->ring_stages) ps = make_plan(p, p->pair, tab_of(kRag), false, g, cfg->frames_per_lane, cfg->ring_stages);
+        if (cfg->frames_per_lane || cfg->ring_stages) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, cfg->frames_per_lane, cfg->ring_stages);
         for (uint32_t R : {18u, 14u, 12u, 10u}) {
             if (ps == RH_OK) break;
             const uint64_t M = g.out_frames ? g.out_frames : 1, tiles = (M + 64ull * R - 1) / (64ull * R);
-            if (tiles >= 3ull * (uint64_t)rh::g_num_cus) ps = make_plan(p, p->pair, tab_of(kRag), false, g, R, 2);
+            if (tiles >= 3ull * (uint64_t)rh::g_num_cus) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, R, 2);
         }
-        if (ps != RH_OK) ps = make_plan(p, p->pair, tab_of(kRag), false, g, 0, 0);
+        if (ps != RH_OK) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, 0, 0);
         if (ps != RH_OK) p->pair.v = nullptr;
     }
     hipError_t e = hipSuccess;
@@ -3686,7 +3699,7 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
 #ifdef RH_RAG_NO_SUMF
         const bool merge = false;
 #else
-        const bool merge = !rh::knob(rh::K_RAG_TWO_KERNELS);  // the pairs inside the first kernel (Params::rag_merge)
+        const bool merge = !rh::knob(rh::K_RAG_TWO_KERNELS) || !pl.v->plain;  // the pairs inside the first kernel (Params::rag_merge; mono: always)
 #endif
         k1.rag_merge = merge ? 1u : 0u;
         k1.rag_pairs_from = p->rag_pairs_from;
@@ -3845,7 +3858,7 @@ rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, r
                 if (R == best.v->R && NS == best.v->NS) continue;
                 Plan cand;
                 const bool mono = p->cfg.channels == 1;
-                if ((is_pair   ? make_plan(p, cand, tab_of(kRag), false, g, (uint32_t)R, (uint32_t)NS)
+                if ((is_pair   ? make_plan(p, cand, mono ? tab_of(kRag1) : tab_of(kRag), false, g, (uint32_t)R, (uint32_t)NS)
                      : general ? make_plan(p, cand, mono ? tab_of(kWave1) : tab_of(kWave), true, g, (uint32_t)R, (uint32_t)NS)
                                : make_plan(p, cand, mono ? tab_of(kFast1) : tab_of(kFast), false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK)
                     continue;

@@ -92,6 +92,28 @@ def test_mono_ragged_batch_and_spans(G, O, filt, freq, span):
     p.close()
 
 
+def test_mono_ragged_filtered_batch_takes_the_sum_first_kernel_with_its_pairs(G, O):
+    """Mono sources of different lengths, filtered, one shot: k_rlm_fast<RAG, SUMF, C = 1> with the pairs of ending sources inside it
+    (round 4; mono batches took k_rlm_wave before).  Against the oracle and against the ragged-batch kernel on the same batch."""
+    import torch
+
+    n = 120000
+    ns = [n] * 4 + [n - 900 * i - 7 for i in range(1, 40)] + [n // 2, 9000]
+    xs = [rnd(5600 + i, m, 0.05) for i, m in enumerate(ns)]
+    ref = _oracle(O, xs, 44100, 48000, None, "low_pass", 250)
+    outs = {}
+    for general in (0, 1):
+        p = G.ResampleLowpassMix(44100, 48000, 1, None, "low_pass", 250, 0.5, max_sources=len(ns), max_in_frames=n, force_general=general)
+        p.set_sources([torch.from_numpy(x).cuda() for x in xs])
+        geo = p.geometry()
+        assert geo["general_kernel"] == 1 and geo["ragged_pair"] == (0 if general else 1), geo
+        outs[general] = p.run().cpu().numpy()
+        p.check_status()
+        p.close()
+    _check(outs[0], ref, "low_pass")
+    assert float(np.max(np.abs(outs[0] - outs[1]))) <= 1e-6
+
+
 @pytest.mark.parametrize("filt,freq", [(None, 0), ("low_pass", 200)])
 @pytest.mark.parametrize("span", [None, 32768])
 def test_mono_block_streaming(G, O, filt, freq, span):
