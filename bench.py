@@ -176,6 +176,39 @@ def cpu_baseline(x, S, N, span, freq, want_all_cores=True, ch=2):
     return res, ref
 
 
+def f64_truth(host, S, N, Cn, span, freq):
+    """The exact response of the chain in f64: the converter and the filter are linear, so the f64 sum of the sources goes through one
+    f64 lerp (sample_rate.rs:131-201 per span of min(span, 32768) samples, each span's last frame verbatim) and one f64 recurrence with
+    the coefficients rodio computes in f32 (blt.rs:502-544).  What the GPU and the oracle (rodio's own f32 recurrence) are each held against."""
+    import numpy as np
+    from scipy.signal import lfilter
+
+    from oracle import rodio_oracle as O
+
+    mix = np.zeros((N, Cn), dtype=np.float64)
+    data = host.reshape(S, N, Cn)
+    for s in range(S):
+        mix += data[s]
+    F, T = 147, 160  # 44.1 -> 48 kHz reduced (sample_rate.rs:74)
+    span_f = N if not span else min(span, 32768) // Cn
+    parts = []
+    for f0 in range(0, N, span_f):
+        xs = mix[f0:f0 + span_f]
+        n = len(xs)
+        M = (((n - 1) * T) + F - 1) // F + 1 if n > 0 else 0
+        m = np.arange(M, dtype=np.int64)
+        i = m * F // T
+        num = (m * F - i * T).astype(np.float64)
+        i1 = np.minimum(i + 1, n - 1)
+        y = xs[i] + (xs[i1] - xs[i]) * (num / T)[:, None]
+        y[i >= n - 1] = xs[n - 1]
+        parts.append(y)
+    y = np.concatenate(parts)
+    co = O.blt_coeffs("low_pass", freq, 0.5, 48000).astype(np.float64)
+    z = lfilter(co[:3], np.concatenate([[1.0], co[3:]]), y, axis=0)
+    return z.reshape(-1)
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per GPU, under
     torch.distributed.run on 127.0.0.1 (the form the driver uses for N > 1, spelled out by us when it does not).  The ranks'
@@ -248,6 +281,30 @@ def headline(args, argv):
         dist.all_reduce(t, op=op)
         return float(t.item())
 
+    # ---- which collective the timed loop runs (mixer.rs:185-198 completed across the shards) --------------------------------------
+    #   native  rh_allreduce_sum_f32 of the C ABI (rh_comm.hip: RCCL dlopen'ed, no PyTorch in the data path) -- what a Rust host calls.
+    #           The default whenever RCCL takes the ranks (N > 1 on N devices); `--collective native` at --gpus 1 runs the same code with
+    #           a communicator of one rank (the path differs from N > 1 by `nranks` only).
+    #   native-reduce  the same through rh_reduce_sum_f32 to rank 0 (north_star's "reduce": only the sink-owning rank needs the mix)
+    #   torch   torch.distributed's all_reduce (the cross-check; the only choice when the ranks time-share one device over gloo)
+    # torch.distributed stays the control plane either way: rendezvous, the 128-byte id, barriers.
+    want = args.collective
+    comm = None
+    comm_err = None
+    if want.startswith("native") or (want == "auto" and world > 1 and not one_dev):
+        try:
+            box = [D.NativeComm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            comm = D.NativeComm(rank, world, box[0])
+        except Exception as e:  # noqa: BLE001 -- RCCL not loadable / refuses the ranks: say so in the line, fall back to the cross-check path
+            comm_err = str(e)[:300]
+            if want.startswith("native") and world == 1:
+                sys.exit(f"--collective {want}: {comm_err}")
+    reduce_only = comm is not None and want == "native-reduce"
+    cstream = torch.cuda.Stream() if comm is not None else None  # the collective's stream: the all-reduce of block k runs beside the kernel of block k+1
+    done = [None, None]  # native: the event behind the collective that last used buffer i
+
     S, N, Cn = args.sources, args.frames, (1 if args.config == "2mono" else 2)
     span = 32768 if args.config == "2span" else args.span
     ragged = args.config == "ragged"
@@ -262,7 +319,7 @@ def headline(args, argv):
                                  max_in_frames=N, frames_per_lane=args.frames_per_lane, ring_stages=args.ring_stages, no_balance=args.no_balance, force_general=args.force_general)
     # N > 1: the all-reduce of block k runs on RCCL's stream beside the kernel of block k+1 -- the kernel does not have the CUs to
     # itself, so its tiles go by ticket (rodio_hip.h: rh_rlm_set_exclusive)
-    pipe.set_exclusive(world == 1 and not args.shared_device)
+    pipe.set_exclusive(world == 1 and not args.shared_device and comm is None)
     if args.per_source:
         pipe.set_mix_first(False)
     pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
@@ -275,18 +332,33 @@ def headline(args, argv):
     works = [None, None]
     lib = _lib.lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
     def step(k, ev=None, reduce=True):
         buf = outs[k & 1]
         if works[k & 1] is not None:  # the all-reduce that last used this buffer (stream-level wait)
             works[k & 1].wait()
             works[k & 1] = None
+        if done[k & 1] is not None:
+            torch.cuda.current_stream().wait_event(done[k & 1])
+            done[k & 1] = None
         if ev is not None:
             lib.rh_event_record(ev[0], stream)
         pipe.run(buf)
         if ev is not None:
             lib.rh_event_record(ev[1], stream)
-        if world > 1 and reduce:  # the mixer sum across the source shards: one RCCL all-reduce over xGMI,
+        if not reduce:
+            return
+        if comm is not None:  # the C ABI's collective on its own stream, ordered behind the kernel by an event
+            e = torch.cuda.Event()
+            e.record()
+            cstream.wait_event(e)
+            if reduce_only:
+                comm.reduce(buf, 0, stream=cstream)
+            else:
+                comm.all_reduce(buf, stream=cstream)
+            d_ = torch.cuda.Event()
+            d_.record(cstream)
+            done[k & 1] = d_
+        elif world > 1:  # the mixer sum across the source shards: one RCCL all-reduce over xGMI,
             works[k & 1] = D.all_reduce_mix(buf, async_op=True)  # rodio_amd/distributed.py; overlaps step k+1
 
     def drain():
@@ -294,6 +366,9 @@ def headline(args, argv):
             if works[i] is not None:
                 works[i].wait()
                 works[i] = None
+            if done[i] is not None:
+                torch.cuda.current_stream().wait_event(done[i])
+                done[i] = None
 
     def fence():
         if world > 1:
@@ -356,7 +431,10 @@ def headline(args, argv):
         for r_ in range(world):
             acc += parts[r_]
         exposed = max(ms_per_step - kmax, 0.0)
-        multi = {"n_ranks_seen": seen, "backend": dist.get_backend(), "kernel_ms_max_over_ranks": kmax, "kernel_ms_min_over_ranks": kmin,
+        multi = {"n_ranks_seen": seen, "backend": dist.get_backend(),
+                 "collective": {"timed": ("rh_reduce_sum_f32 to rank 0" if reduce_only else "rh_allreduce_sum_f32") + " (C ABI, rh_comm.hip over RCCL) on its own stream, block k beside the kernel of block k+1" if comm is not None
+                                else "torch.distributed all_reduce (async_op), block k beside the kernel of block k+1", "requested": want, **({"native_unavailable": comm_err} if comm_err else {})},
+                 "kernel_ms_max_over_ranks": kmax, "kernel_ms_min_over_ranks": kmin,
                  "allreduce_ms": allreduce_ms, "allreduce_bytes": int(local.numel() * 4),
                  "exposed_ms_per_step": exposed, "overlap_frac": max(0.0, min(1.0, 1.0 - exposed / allreduce_ms)) if allreduce_ms > 0 else None,
                  "reduce_check": {"samples": k, "max_abs_err_vs_rank_ordered_sum_of_partials": float((red[:k] - acc).abs().max()), "peak": float(acc.abs().max())}}
@@ -365,9 +443,10 @@ def headline(args, argv):
             multi["native_comm"] = {"skipped": "RCCL refuses two ranks on one device (RH_BENCH_ONE_DEVICE=1)"}
         else:
             try:
-                box = [D.NativeComm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = D.NativeComm(rank, world, box[0])
+                if comm is None:
+                    box = [D.NativeComm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    comm = D.NativeComm(rank, world, box[0])
                 nat = local.clone()
                 comm.all_reduce(nat)
                 torch.cuda.synchronize()
@@ -379,7 +458,6 @@ def headline(args, argv):
                 e1.record()
                 torch.cuda.synchronize()
                 multi["native_comm"] = {"allreduce_ms": e0.elapsed_time(e1) / reps, "max_abs_diff_vs_torch_distributed": diff, "entry": "rh_allreduce_sum_f32"}
-                comm.close()
             except Exception as e:  # noqa: BLE001 -- the line must still come out; the failure is in it
                 multi["native_comm"] = {"error": str(e)[:300]}
 
@@ -433,8 +511,42 @@ def headline(args, argv):
         got = mixed_last.cpu().numpy()  # the last timed launch's block
         if got.shape == ref.shape:
             d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-            parity = {"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": float(np.abs(ref).max()),
+            peak = float(np.abs(ref).max())
+            parity = {"frames_compared": int(len(ref) // Cn), "of": int(M), "max_abs_err": float(d.max()), "peak": peak, "rel_to_peak": float(d.max()) / peak if peak else None,
                       "tolerance": 1e-5, "ok": bool(d.max() <= 1e-5), "vs": "oracle (restated rodio CPU path), the timed launch's whole block"}
+            if not args.no_unscaled:
+                # the inputs are scaled by 1/S so that |mix| <= 1, which makes a bare 1e-5 abs check S times weaker.  So: the SAME workload at
+                # amplitude 1 (every source U(-1,1): the inputs multiplied by S = 2^8 in place, exact), one more launch, every frame against the oracle
+                # (whose unscaled output is S x its scaled one bit for bit: every operation of the chain is linear and S is a power of two; checked below
+                # on a prefix), and both against the exact response of the chain in f64.
+                t64 = f64_truth(host, S, N, Cn, span, args.freq)
+                sc = float(S * world)
+                data.mul_(sc)
+                pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
+                out_u = torch.empty(M * Cn, device="cuda", dtype=torch.float32)
+                pipe.run(out_u)
+                torch.cuda.synchronize()
+                pipe.check_status()
+                got_u = out_u.cpu().numpy().astype(np.float64)
+                data.mul_(1.0 / sc)
+                pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
+                ref_u = ref.astype(np.float64) * sc
+                npre = min(N, 1 << 14)
+                from oracle import rodio_oracle as O_
+                pre = O_.pipeline_resample_lowpass_mix(np.ascontiguousarray(host.reshape(S, N, Cn)[:, :npre]) * np.float32(sc), 44100, 48000, span if span else O_.SPAN_NONE, args.freq, 0.5)
+                pre_s = O_.pipeline_resample_lowpass_mix(np.ascontiguousarray(host.reshape(S, N, Cn)[:, :npre]), 44100, 48000, span if span else O_.SPAN_NONE, args.freq, 0.5)
+                if got_u.shape == ref_u.shape == t64.shape:
+                    du = np.abs(got_u - ref_u)
+                    pk = float(np.abs(ref_u).max())
+                    parity["vs_f64"] = {"gpu": float(np.abs(got.astype(np.float64) - t64).max()), "oracle": float(np.abs(ref.astype(np.float64) - t64).max()),
+                                        "what": "max abs distance from the exact (f64) response of the same chain, all frames: the GPU's time-parallel filter and rodio's own f32 recurrence side by side"}
+                    parity["unscaled"] = {"amplitude": 1.0, "frames_compared": int(len(ref) // Cn), "max_abs_err": float(du.max()), "peak": pk, "rel_to_peak": float(du.max()) / pk if pk else None,
+                                          "vs_f64": {"gpu": float(np.abs(got_u - t64 * sc).max()), "oracle": float(np.abs(ref_u - t64 * sc).max())},
+                                          "oracle_scaling_exact_on_prefix": bool(np.array_equal(pre_s.astype(np.float64) * sc, pre.astype(np.float64))),
+                                          "note": f"the same {S} sources at full scale (U(-1,1) each, inputs x {int(sc)} in place), one launch of the same plan; the 1e-5 abs tolerance of north_star is stated for |mix| <= 1 "
+                                                  "(the scaled run above); at full scale the mix peaks near 3.5 and the distance to rodio's f32 recurrence scales with it -- both sit at the same distance from the exact response"}
+                else:
+                    parity["unscaled"] = {"ok": False, "error": f"lengths {got_u.shape} / {ref_u.shape} / {t64.shape}"}
         else:
             parity = {"ok": False, "error": f"length {got.shape} vs oracle {ref.shape}"}
     elif not args.no_cpu_baseline and not ragged:
@@ -489,6 +601,9 @@ def headline(args, argv):
                 ps["parity"] = {"ok": False, "error": f"length {gotp.shape} vs oracle {cmp_ref.shape}"}
         per_source = ps
 
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -502,7 +617,7 @@ def headline(args, argv):
     child_argv = [a for a in argv]
     child_argv[child_argv.index("--frames-per-lane") + 1] = str(geo["frames_per_lane"])
     child_argv[child_argv.index("--ring-stages") + 1] = str(geo["ring_stages"])
-    if world > 1 or args.shared_device:
+    if world > 1 or args.shared_device or want.startswith("native"):
         child_argv.append("--shared-device")  # tiles by ticket, as in this run
     # (a ragged batch and a mix-first batch are two kernels per launch: the sum over both, per call)
     two = bool(geo["ragged_pair"]) or geo.get("mix_first") == 1
@@ -519,7 +634,7 @@ def headline(args, argv):
     geo["late_carries_per_launch"] = (lc & 0xffffffff) / max(args.steps + args.warmup, 1)
     if tuned:
         geo["autotuned"] = True
-    geo["tiles_by"] = "workgroup index (exclusive device)" if (world == 1 and not args.shared_device) else "ticket (the device is shared with the collective's kernels)"
+    geo["tiles_by"] = "workgroup index (exclusive device)" if (world == 1 and not args.shared_device and want == "auto") else "ticket (the device is shared with the collective's kernels)"
     kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_chunk" if geo.get("mix_first") == 2 else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
     res = {
         "metric": "Msamples/s through resample+low_pass+mix pipeline",
@@ -540,6 +655,8 @@ def headline(args, argv):
     }
     if per_source is not None:
         res["roofline"]["per_source"] = per_source
+    if world == 1 and want.startswith("native"):
+        res["config"]["collective"] = ("rh_reduce_sum_f32" if reduce_only else "rh_allreduce_sum_f32") + " (C ABI, rh_comm.hip over RCCL) with a communicator of ONE rank in the timed loop, on its own stream: the N > 1 code path, nranks = 1"
     if multi:
         one = args.one_gpu_value
         if one is None and args.one_gpu_line:  # a JSON line (or a file holding one) of the same bench at --gpus 1
@@ -764,7 +881,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-source", action="store_true", help="the headline batch on the per-source path (rh_rlm_set_mix_first(0)); the default line carries it as roofline.per_source")
     ap.add_argument("--no-per-source", action="store_true", help="skip the per-source leg of the default line")
+    ap.add_argument("--no-unscaled", action="store_true", help="skip parity.unscaled / parity.vs_f64 (the same workload at amplitude 1, and both sides against the f64 response)")
     ap.add_argument("--shared-device", action="store_true", help="tiles by ticket although one rank runs (rh_rlm_set_exclusive(0)): what the N > 1 ranks do")
+    ap.add_argument("--collective", default="auto", choices=["auto", "native", "native-reduce", "torch"],
+                    help="the collective of the timed loop: native = rh_allreduce_sum_f32 of the C ABI (default for N > 1 when RCCL takes the ranks), native-reduce = rh_reduce_sum_f32 to rank 0, torch = torch.distributed")
     ap.add_argument("--baseline-sources", type=int, default=64, help="N > 1: sources of rank 0's shard the one-thread CPU baseline times")
     ap.add_argument("--one-gpu-value", type=float, default=None, help="Msamples/s of this bench at --gpus 1: an N > 1 run then prints multi_gpu.efficiency_vs_1gpu")
     ap.add_argument("--one-gpu-line", default=None, help="... or the 1-GPU JSON line itself / a file that holds it")

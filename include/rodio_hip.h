@@ -50,6 +50,10 @@ const char *rh_last_hip_error(void);
  * 7.1): nothing reads the environment on a call's way to a launch. */
 rh_status rh_init(int32_t device);
 rh_status rh_device_name(char *buf, size_t cap);
+/* Makes the device rh_init() bound current on the CALLING thread.  HIP's current device is per thread: a helper thread of the host
+ * (the reaper that frees retired streams, the pool that pulls sources) calls this once before its first call into the library, so
+ * that what it frees, records or synchronises belongs to the right device in a multi-GPU process. */
+rh_status rh_bind_thread(void);
 /* The handle-less time-parallel kernels (rh_limit, rh_biquad mode 1) wait for hand-offs between their tiles with a bound.
  * A wait that expires (never seen on a healthy device) poisons the tile with NaN and sets a sticky word on the device:
  * RH_ERR_TIMEOUT here, once, then RH_OK again.  Covers the launches that have COMPLETED (synchronise the stream or an event

@@ -209,6 +209,7 @@ private:
         }
     }
     void loop() {
+        (void)rh_bind_thread();  // (the pulls may run GPU-backed upstreams: the thread works on the device rh_init() bound)
         std::uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
@@ -929,6 +930,11 @@ protected:
     }
     void enqueue(Slot &s) override {
         const std::size_t want = block_frames_ * up_->channels();
+        // The slot's page-locked staging block is about to be rewritten: the copy that read it two blocks ago must have run.  A host
+        // consumer has waited for that block's event already (advance()); one that takes the blocks on the device never waits on the
+        // host, so the wait is here (otherwise the refill races the asynchronous host-to-device copy of the block before).
+        // Almost always satisfied by the time the slot comes round again.
+        if (device_out_) check(rh_event_synchronize(s.done), "rh_event_synchronize");
         s.in.reset(want);
         if (up_->channels() != in_ch() || up_->sample_rate() != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
         std::size_t n = 0;
@@ -1390,7 +1396,8 @@ private:
             if (plan) (void)rh_rlm_destroy(plan);
         }
     };
-    /// Frees retired generations on a thread of its own (see enqueue()).
+    /// Frees retired generations on a thread of its own (see enqueue()).  The sources a generation owned are DESTROYED ON THAT THREAD
+    /// (rodio: `Source: Send` -- a source handed to Mixer::add may be dropped by another thread than the one that made it).
     class Reaper {
     public:
         Reaper() : th_([this] { loop(); }) {}
@@ -1412,6 +1419,7 @@ private:
 
     private:
         void loop() {
+            (void)rh_bind_thread();  // HIP's current device is per thread: what this thread frees belongs to the mixer's device
             std::unique_lock<std::mutex> lk(mu_);
             for (;;) {
                 cv_.wait(lk, [this] { return quit_ || !dead_.empty(); });

@@ -68,6 +68,7 @@ SIGNATURES = {
     "rh_async_status": (i32, []),
     "rh_init": (i32, [i32]),
     "rh_device_name": (i32, [C.c_char_p, sz]),
+    "rh_bind_thread": (i32, []),
     "rh_malloc": (i32, [C.POINTER(vp), sz]),
     "rh_free": (i32, [vp]),
     "rh_memset": (i32, [vp, i32, sz, vp]),

@@ -2777,6 +2777,7 @@ struct rh_rlm {
     // with one state per source.
     bool st_history = false;     // rh_rlm_stream_keep_history
     bool st_together = false;    // the stream still runs on the summed state
+    bool st_dirty = false;       // rh_rlm_stream_block_v has touched the stream's state in this call (an error then ends the stream)
     bool st_decided = false;     // ... or has decided not to
     std::vector<const float *> st_prev_ptrs;  // the block before: its rows,
     uint64_t st_prev_avail = 0, st_prev_g0 = 0, st_prev_m = 0, st_prev_out = 0;  // frames per row, global index of frame 0, first output frame, output frames
@@ -3448,6 +3449,8 @@ static rh_status set_sources_classes(rh_rlm *p, const float *const *srcs_host, c
     if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
     if (n_sources && (!srcs_host || !in_frames_host)) return RH_ERR_INVALID;
     for (rh_rlm::FilterClass &c : p->cls) c.members.clear();
+    p->n_sources = 0;  // (an error below leaves a handle without sources, not one whose classes and counts disagree: a run then fails cleanly)
+    p->out_frames = 0;
     const rh_rlm::FilterSpec own{p->cfg.filter_kind == 2 ? 0 : p->cfg.filter_kind, p->cfg.filter_freq, p->cfg.filter_q};
     for (uint32_t s = 0; s < n_sources; ++s) {
         const rh_rlm::FilterSpec f = s < p->filters.size() ? p->filters[s] : own;
@@ -4075,8 +4078,25 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
 // that crosses the boundary is a tile carry: k_rlm_state folds the block's aggregates into column 0 of the
 // aggregate rows, where the next launch finds it as the aggregate of a virtual predecessor tile.
 
+static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
+                                     uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream);
+
 rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
                                 uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
+    if (p) p->st_dirty = false;
+    const rh_status st = stream_block_v_impl(p, srcs_host, avail_frames_host, ended_host, n_sources, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+    // An error after the stream's state was touched (the switch from the summed state to per-source states: rows sized, the replay launched)
+    // leaves a state no later block can continue from: the stream is over, and says so (RH_ERR_INVALID on every later call) instead of
+    // wedging half-way.  Errors found while the arguments are checked leave the stream as it was.
+    if (st != RH_OK && p && p->st_dirty) {
+        p->st_done = true;
+        p->st_prev_ptrs.clear();
+    }
+    return st;
+}
+
+static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
+                                     uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames || !avail_frames_host || !ended_host) return RH_ERR_INVALID;
     if (n_sources == 0 || n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
@@ -4122,10 +4142,12 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
             p->st_prev_out = *out_frames;
             return RH_OK;
         }
+        p->st_dirty = true;
         p->st_together = false;  // a source ends or falls behind, or the block is short: one state per source from here on
     }
     const bool recover = !p->st_cols && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
     if (!p->st_cols) {  // first block of the per-source stream: size the aggregate rows once (the states live in them), zero states
+        p->st_dirty = true;
         rh::ResampleGeom g;
         rh_status st = rh::make_resample_geom(p->cfg.max_in_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &g);
         if (st != RH_OK) return st;

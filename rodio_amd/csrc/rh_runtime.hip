@@ -80,6 +80,12 @@ hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_l
     *out = e.p;
     return hipSuccess;
 }
+// A scan kernel reported a lost hand-off: whatever its launch left in the streams' hand-off tables is not to be trusted -- the next launch of
+// every stream writes its tables afresh (the "clean" shortcut of rh_limit / rh_biquad mode 1 trusts the launch before it: ADVICE r4).
+static void distrust_stream_scratch() {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto &kv : g_scratch) kv.second.aux = ScratchAux{0, 0, 0};
+}
 static void drop_stream_scratch(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     auto it = g_scratch.find(s);
@@ -180,7 +186,14 @@ rh_status rh_async_status(void) {
     RH_HIP_TRY(hipMemcpy(&v, rh::g_async_status, sizeof(v), hipMemcpyDeviceToHost));
     if (!v) return RH_OK;
     RH_HIP_TRY(rh::fill_now(rh::g_async_status, 0, sizeof(v)));
+    rh::distrust_stream_scratch();
     return RH_ERR_TIMEOUT;
+}
+
+rh_status rh_bind_thread(void) {
+    RH_REQUIRE_INIT();
+    RH_HIP_TRY(hipSetDevice(rh::g_device));
+    return RH_OK;
 }
 
 rh_status rh_device_name(char *buf, size_t cap) {

@@ -704,6 +704,9 @@ impl<I: Source> BlockSource for GpuSource<I> {
         let in_ch = self.in_ch as usize;
         let want = self.block_frames * in_ch;
         assert!(self.up.channels().get() == self.in_ch && self.up.sample_rate().get() == self.in_rate, "GpuSource: the upstream changed its format mid-stream");
+        // the slot's page-locked block is about to be rewritten: the copy that read it two blocks ago must have run (a consumer that takes the
+        // blocks on the device never waits on the host -- see GpuSource::enqueue in include/rodio_hip.hpp)
+        if self.pump.device_out { ck(unsafe { rh_event_synchronize(self.pump.slot[i].done.0) }, "rh_event_synchronize"); }
         self.pump.slot[i].stage.reserve(want);
         let (mut n, flush);
         self.pieces.clear();
@@ -879,7 +882,7 @@ struct Reaper { tx: Option<mpsc::Sender<Vec<Gen>>>, th: Option<std::thread::Join
 impl Reaper {
     fn new() -> Self {
         let (tx, rx) = mpsc::channel::<Vec<Gen>>();
-        let th = std::thread::spawn(move || { for dead in rx { drop(dead); } });   // the destructors: rh_rlm_destroy, rh_host_free, rh_free
+        let th = std::thread::spawn(move || { unsafe { rh_bind_thread(); } for dead in rx { drop(dead); } });   // (HIP's current device is per thread) the destructors: rh_rlm_destroy, rh_host_free, rh_free
         Reaper { tx: Some(tx), th: Some(th) }
     }
     fn retire(&self, g: Vec<Gen>) { let _ = self.tx.as_ref().unwrap().send(g); }

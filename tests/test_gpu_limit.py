@@ -280,6 +280,9 @@ def test_an_expired_hand_off_is_reported_and_poisons_the_output(G, O):
 
     G.async_status()  # clean slate
     x = torch.from_numpy(np.stack([_signal(70 + s, 1 << 18, 2) for s in range(64)])).cuda()
+    good = G.limit_batch(x, 2, 48000).clone()
+    good_b = G.biquad_batch(x, G.biquad_coeffs("low_pass", 200, 0.5, 48000), mode=1).clone()
+    torch.cuda.synchronize()
     with knobs(RH_SCAN_SPIN_LIMIT="0"):
         bad = 0
         for _ in range(12):  # tiles of one stream run side by side: some first looks come too early
@@ -297,7 +300,12 @@ def test_an_expired_hand_off_is_reported_and_poisons_the_output(G, O):
         G.async_status()
     assert e.value.status == 5  # RH_ERR_TIMEOUT
     G.async_status()  # sticky once, then clear
-    out = G.limit_batch(x, 2, 48000)  # and the next launch is whole again
-    torch.cuda.synchronize()
-    assert not bool(torch.isnan(out).any())
+    # ... and the next launches are whole again, bit for bit what they were before the failure: a reported failure makes every stream's
+    # next launch write its hand-off tables afresh instead of trusting what the failed launch left
+    for _ in range(3):
+        out = G.limit_batch(x, 2, 48000)
+        outb = G.biquad_batch(x, co, mode=1)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(out).any()) and torch.equal(out, good)
+        assert torch.equal(outb, good_b)
     G.async_status()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round 5 GPU calls, in parts (one gpurun call each): bash tools/r05_call.sh <part>.  Everything lands in gpurun_out/r05/.
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r05
+export TMPDIR=/tmp
+E=gpurun_out/r05
+gaps() {  # gaps <tag> <kernel> <bench args...>: timeline of back-to-back launches
+    tag=$1; kern=$2; shift 2
+    rm -rf $E/gaps_$tag; mkdir -p $E/gaps_$tag
+    (cd /tmp && RH_BENCH_NO_PMC=1 rocprofv3 --kernel-trace --hip-trace -d $GRAFT_REPO_ROOT/$E/gaps_$tag -o t -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline > $GRAFT_REPO_ROOT/$E/gaps_$tag.log 2>&1)
+    db=$(find $E/gaps_$tag -name 't_results.db' | head -1)
+    RH_PROF_KERNEL=$kern python tools/launch_gaps.py "$db" > $E/gaps_$tag.txt 2>&1
+    rm -rf $E/gaps_$tag
+    tail -30 $E/gaps_$tag.txt
+}
+case "$1" in
+1)
+    python -m pytest tests -q -m gpu -p no:cacheprovider -x 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -15 > $E/gputests_1.txt; tail -5 $E/gputests_1.txt
+    python bench.py > $E/bench_cfg2.json 2> $E/bench_cfg2.err; tail -c 1500 $E/bench_cfg2.json; tail -3 $E/bench_cfg2.err
+    python bench.py --collective native --no-per-source --no-unscaled > $E/bench_cfg2_native1.json 2> $E/bench_cfg2_native1.err; tail -c 600 $E/bench_cfg2_native1.json; tail -3 $E/bench_cfg2_native1.err
+    gaps limit k_limit_scan --config limit --steps 13 --warmup 2
+    gaps biquad k_biquad_scan --config biquad --steps 13 --warmup 2
+    ;;
+esac
