@@ -218,7 +218,18 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
  *                follows; UINT64_MAX while the span is still open (more input will come, or current_span_len() == None)
  * Output frame m reads input frames floor(m*F/T) and +1 (F/T = from/to reduced); the caller keeps the frames the next
  * segment's first tap needs (rh_uniform_first_tap).  Bit-exact with the reference (lerp as mul, IEEE divide, add).
- * Spans must hold whole frames (the trait's contract, source/mod.rs:196-200).
+ * A span that ends INSIDE a frame -- uniform.rs:56's `.min(32768)` cuts frames of 3, 5, 6, 7 channels, and a source may return None inside
+ * a frame -- is what source/mod.rs:196-200 asks sources not to produce, and rodio plays it anyway: the SampleRateConverter meets a
+ * short frame, every output frame that lerps towards it is cut to its length (zip, sample_rate.rs:174-179), the short frame itself
+ * comes out verbatim when an output lands on it (:193-200), and the ChannelCountConverter behind regroups those runs into frames of
+ * from_ch samples (channels.rs:57-85).  The TAIL of such a span is a segment of its own, marked by reserved = t (the cut frame's
+ * samples, 0 < t < from_ch):
+ *   span_frames  q, the WHOLE frames of the span
+ *   src          device pointer to input frame src_frame0 (= q - src_frames, src_frames in {0, 1}: the frame in front of the cut is
+ *                passed whenever an output frame lerps towards the cut frame), followed by the t samples of the cut frame
+ *   m0, m1       output SAMPLES [m0, m1) of the tail, 0 <= m0 <= m1 <= rh_uniform_cut_tail_samples(); dst = where sample m0 lands
+ * The whole frames in front of the tail convert as the frames of an open span (span_frames = UINT64_MAX: no verbatim last frame).
+ * What follows a cut span starts at the sample behind the cut: the caller's stream is a stream of samples, not of frames.
  * rh_uniform_span_frames: output frames computable from the first span_in_frames input frames of a span; complete != 0 adds
  * the verbatim last frame.  rh_uniform_segments validates and launches a host table (any number of segments, sources, formats
  * in one call); the _dev form takes the table from DEVICE memory unvalidated (it can travel in the caller's staging copy);
@@ -233,11 +244,14 @@ typedef struct rh_uniform_seg {
     uint32_t from_ch, to_ch;
     float gain;          /* Amplify in FRONT of the converter (mixer.add(src.amplify(g)), amplify.rs:64): both taps are scaled
                           * before the lerp, which is the reference's order of operations; 1.0 = none (x * 1.0 == x) */
-    uint32_t reserved;   /* 0 */
+    uint32_t reserved;   /* 0; t > 0 marks the tail segment of a span that ends t samples into a frame (see above) */
 } rh_uniform_seg;
 rh_status rh_uniform_span_frames(uint64_t span_in_frames, uint32_t from_rate, uint32_t to_rate, int32_t complete,
                                  uint64_t *out_frames);
 rh_status rh_uniform_first_tap(uint64_t out_frame, uint32_t from_rate, uint32_t to_rate, uint64_t *in_frame);
+/* Output samples of the tail of a span of span_whole_frames whole frames + tail_samples samples (0 < tail_samples < from_ch). */
+rh_status rh_uniform_cut_tail_samples(uint64_t span_whole_frames, uint32_t tail_samples, uint32_t from_rate, uint32_t to_rate,
+                                      uint32_t from_ch, uint32_t to_ch, uint64_t *out_samples);
 rh_status rh_uniform_segments(const rh_uniform_seg *segs_host, uint32_t n_segs, rh_stream stream);
 rh_status rh_uniform_segments_dev(const rh_uniform_seg *segs_dev, uint32_t n_segs, uint64_t max_out_frames,
                                   rh_stream stream);

@@ -281,6 +281,15 @@ struct Piece {
     std::uint32_t rate;
     std::size_t tail = 0;   // closes only: samples of a CUT last frame (uniform.rs:56: `.min(32768)` cuts frames of 3, 5, 6, 7 channels; so does a source that ends inside a frame)
     bool by_none = false;   // closes only: the span ended because the source returned None, not because its samples were counted out
+    std::optional<std::size_t> span_len = std::nullopt;  // opens only: what current_span_len() answered when the span's chain was built
+    // The SOURCE's own spans, as an adapter that merely follows them counts them (SpanTracker, span.rs:66-101: current_span_len() samples, then it
+    // looks again) -- UniformSourceIterator's chains of min(span, 32768) samples need not end where they do (a SamplesBuffer of 40 000 samples in a
+    // queue: the second chain runs on into the next sound, converting it with the first one's parameters; an adapter in FRONT of the
+    // iterator sees the new parameters at sample 40 000).  A piece never crosses either boundary.
+    std::uint16_t src_ch = 0;     // the format the source reported for these samples
+    std::uint32_t src_rate = 0;
+    bool src_opens = false;       // the first samples of a span of the source
+    std::optional<std::size_t> src_span = std::nullopt;  // src_opens only: current_span_len() at that moment
 };
 
 /// Pulls a source the way UniformSourceIterator does (uniform.rs:50-97): whenever its converter chain has run dry it asks
@@ -291,7 +300,9 @@ struct Piece {
 class SpanReader {
 public:
     static constexpr std::size_t kOpenEnded = ~std::size_t(0);
-    explicit SpanReader(Source *up = nullptr) : up_(up) {}
+    /// take_32768 = false: the spans as the source reports them, whole -- how an adapter that only FOLLOWS its input's spans meets them
+    /// (SpanTracker, span.rs:66-101: counts current_span_len() samples, then looks at the parameters again).
+    explicit SpanReader(Source *up = nullptr, bool take_32768 = true) : up_(up), clamp_(take_32768) {}
     bool ended() const { return ended_; }
     /// Format of the span the next read_piece() continues or opens (builds the next chain if none is open); false at the
     /// end of the stream.
@@ -303,23 +314,49 @@ public:
     }
     /// After peek(): the next piece is the first of its span.
     bool opens_next() const { return fresh_; }
+    /// What current_span_len() answered when the open span's chain was built.
+    std::optional<std::size_t> span_answer() const { return span_; }
     /// Frames the open span still admits (kOpenEnded: current_span_len() was None).
     std::size_t left_frames() const { return left_ == kOpenEnded ? kOpenEnded : left_ / ch_; }
     /// Up to max_frames frames of the current span into dst (dst has room for one more frame: the samples of a frame the span's end
     /// cuts come along with the last whole frames, Piece::tail); false: the stream is over and nothing was produced.
     bool read_piece(float *dst, std::size_t max_frames, Piece &out) {
         if (ended_ || (!open_ && !bootstrap())) return false;
+        if (!t_open_) {  // the source's own span opens here
+            t_span_ = up_->current_span_len();
+            t_ch_ = up_->channels();
+            t_rate_ = up_->sample_rate();
+            t_left_ = t_span_ && *t_span_ ? *t_span_ : kOpenEnded;  // (Some(0): the source is exhausted -- the read below finds that out)
+            t_open_ = t_fresh_ = true;
+        }
         std::size_t want = max_frames > kOpenEnded / ch_ ? kOpenEnded : max_frames * ch_;
         want = std::min(want, left_);
         want -= want % ch_;
         if (left_ != kOpenEnded && left_ - want < ch_) want = left_;  // the rest of the span is a cut frame: its samples belong to this span's chain
+        // the source's span ends inside the piece: the piece ends with it (where that is a frame boundary of the format the iterator converts
+        // in; a source that ENDS there -- or whose spans do not hold whole frames -- is read on: the None, or the cut, shows below)
+        bool by_span = false;
+        if (t_left_ != kOpenEnded && t_left_ < want && t_left_ % ch_ == 0 && t_left_ != 0) {
+            want = t_left_;
+            by_span = true;
+        }
         std::size_t got = want ? up_->read(dst, want) : 0;
-        const bool none = got < want;  // the source returned None inside the span
+        bool none = got < want;  // the source returned None inside the span
+        if (by_span && !none) {  // the source's span is through: a source that says it is exhausted (Some(0): buffer.rs:76-82) would return None now
+            const std::optional<std::size_t> after = up_->current_span_len();
+            none = after && *after == 0;
+        }
         if (left_ != kOpenEnded) left_ -= got;
+        const bool t_was_fresh = t_fresh_;
+        if (got) t_fresh_ = false;
+        if (t_left_ != kOpenEnded) {
+            t_left_ -= std::min(got, t_left_);
+            if (t_left_ == 0) t_open_ = false;
+        }
         const bool closes = none || left_ == 0;
         const std::size_t tail = closes ? got % ch_ : 0;  // (what becomes of it is the planner's business: it knows the target format)
         if (!closes) got -= got % ch_;
-        out = Piece{got, fresh_, closes, ch_, rate_, tail, none};
+        out = Piece{got, fresh_, closes, ch_, rate_, tail, none, fresh_ ? span_ : std::nullopt, t_ch_, t_rate_, t_was_fresh, t_was_fresh ? t_span_ : std::nullopt};
         const bool produced = got != 0 || (closes && !fresh_);  // a span that had samples before ends here: its last frame is due
         if (got) fresh_ = false;
         if (closes) open_ = false;
@@ -330,11 +367,18 @@ public:
     void restart() {
         open_ = false;
         ended_ = false;
+        t_open_ = false;
+    }
+    /// The format the SOURCE reports for the sample a read would take next, and its answer to current_span_len() there (peek() first).
+    void source_format(std::uint16_t &ch, std::uint32_t &rate, std::optional<std::size_t> &span) const {
+        if (t_open_) ch = t_ch_, rate = t_rate_, span = t_span_;
+        else ch = up_->channels(), rate = up_->sample_rate(), span = up_->current_span_len();
     }
 
 private:
     bool bootstrap() {  // uniform.rs:50-68
         const std::optional<std::size_t> span = up_->current_span_len();
+        span_ = span;
         ch_ = up_->channels();
         rate_ = up_->sample_rate();
         if (!ch_ || !rate_) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
@@ -342,7 +386,7 @@ private:
             ended_ = true;
             return false;
         }
-        left_ = span ? std::min<std::size_t>(*span, 32768) : kOpenEnded;
+        left_ = span ? (clamp_ ? std::min<std::size_t>(*span, 32768) : *span) : kOpenEnded;
         // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels: the chain rodio
         // builds for such a span ends inside a frame, and the next chain starts there -- every later span has its channels rotated.
         // The reader hands the cut frame's samples over with the span (Piece::tail) and goes on at the sample behind them, as rodio's
@@ -352,10 +396,17 @@ private:
         return true;
     }
     Source *up_;
+    bool clamp_ = true;
     bool open_ = false, fresh_ = true, ended_ = false;
     std::size_t left_ = 0;
     std::uint16_t ch_ = 0;
     std::uint32_t rate_ = 0;
+    std::optional<std::size_t> span_;
+    bool t_open_ = false, t_fresh_ = true;  // the source's own span (see Piece)
+    std::size_t t_left_ = 0;
+    std::uint16_t t_ch_ = 0;
+    std::uint32_t t_rate_ = 0;
+    std::optional<std::size_t> t_span_;
 };
 
 /// Turns the pieces of one source into the segments rh_uniform_segments converts (UniformSourceIterator::new(src, to_ch,
@@ -363,11 +414,14 @@ private:
 ///     [ the frames held() says the previous block left | the samples of this block's pieces, back to back ]
 /// (on the host or on the device), hands every piece to add() in order, and after the last one keeps the frames
 /// [keep_offset(), keep_offset() + keep_samples()) of the row for the next block.
+/// What comes out is a stream of SAMPLES, not of frames: a span that ends inside a frame (Piece::tail) makes rodio's converters
+/// emit a run of samples that need not fill an output frame (rh_uniform_cut_tail_samples), and the next span's output follows
+/// directly behind it -- out_samples() counts samples, Seg::dst_off is a sample offset.
 class UniformPlanner {
 public:
     struct Seg {
         std::size_t src_off;  // samples from the start of the row
-        std::size_t dst_off;  // output FRAMES from the first frame this block produces
+        std::size_t dst_off;  // output SAMPLES from the first sample this block produces
         rh_uniform_seg g;     // everything but the two pointers
     };
     UniformPlanner(std::uint16_t to_ch = 2, std::uint32_t to_rate = 48000) : to_ch_(to_ch), to_rate_(to_rate) {}
@@ -392,6 +446,9 @@ public:
         need = n_need > in ? n_need - in : 0;
         most = n_most > in ? n_most - in : 0;
     }
+    /// Output frames a span's end can add beyond what budget() counts: its verbatim last frame -- or, when the span ends inside a
+    /// frame, the samples rodio's converters make of the cut (at most ceil(T/F) + 1 short frames regrouped: sample_rate.rs:174-200).
+    static std::uint64_t close_slack_frames(std::uint32_t rate, std::uint32_t to_rate) { return (std::uint64_t)to_rate / rate + 3; }
     void add(const Piece &p, std::vector<Seg> &segs) {
         if (p.opens) {
             span_in_ = span_m_ = 0;
@@ -401,22 +458,16 @@ public:
         const std::uint64_t f = (p.n - p.tail) / p.ch;
         span_in_ += f;
         pos_ += p.n;
-        if (p.closes && p.tail) {
-            // A frame the span's end cuts.  At the mixer's own rate the SampleRateConverter passes through (sample_rate.rs:133-136) and the
-            // ChannelCountConverter behind it emits, for the cut frame, the output channels its samples cover (channels.rs:57-85: position k
-            // < from reads the input, the None behind the last sample ends the chain): a whole output frame when the cut frame holds at
-            // least min(from, to) samples -- one more frame for the segment, of which the kernel reads just those channels.  The next span
-            // starts at the sample behind the cut: its channels are rotated, as they are in rodio.
-            const std::size_t nc = std::min<std::size_t>(p.ch, to_ch_);
-            if (p.rate == to_rate_ && p.tail >= nc) span_in_ += 1;
-            else if (!p.by_none)  // (a cut frame in front of a real rate conversion: the converter's end game with a short frame -- runs of `tail` samples regrouped
-                                  // by the channel converter -- is not reproduced; neither is an output frame that would come out short)
-                throw Error(RH_ERR_UNSUPPORTED, "a span of a " + std::to_string(p.ch) + "-channel source ends inside a frame (" + std::to_string(p.tail) + " samples): reproduced only at the mixer's own rate" +
-                                                    (p.rate == to_rate_ ? ", and when the cut frame covers an output frame" : ""));
-            // by_none with a short tail: the source ended inside a frame; its last samples are dropped (source/mod.rs:169-178: sources end on frame boundaries)
-        }
+        const bool cut = p.closes && p.tail != 0;
+        // A span that ends inside a frame (uniform.rs:56: `.min(32768)` on 3, 5, 6, 7 channels; a source that returns None inside a frame).
+        // rodio's SampleRateConverter meets a SHORT frame: every output frame that lerps towards it is cut to its length (zip,
+        // sample_rate.rs:174-179), the short frame itself comes out verbatim when an output lands on it (:193-200), and the
+        // ChannelCountConverter behind regroups those runs into frames of `from` samples (channels.rs:57-85) -- reproduced sample for
+        // sample by a segment of its own (rh_uniform_seg::reserved = the cut frame's samples); the whole frames in front of it convert as
+        // the frames of a span that is still open (no verbatim last frame: that role went to the cut frame).  The next span starts at the
+        // sample behind the cut, its channels rotated, as in rodio.
         std::uint64_t ready = 0;
-        check(rh_uniform_span_frames(span_in_, p.rate, to_rate_, p.closes ? 1 : 0, &ready), "rh_uniform_span_frames");
+        check(rh_uniform_span_frames(span_in_, p.rate, to_rate_, (p.closes && !cut) ? 1 : 0, &ready), "rh_uniform_span_frames");
         if (ready > span_m_) {
             Seg sg;
             sg.src_off = row_off_;
@@ -426,15 +477,42 @@ public:
             sg.g.src_frames = span_in_ - row_frame0_;
             sg.g.m0 = span_m_;
             sg.g.m1 = ready;
-            sg.g.span_frames = p.closes ? span_in_ : UINT64_MAX;
+            sg.g.span_frames = (p.closes && !cut) ? span_in_ : UINT64_MAX;
             sg.g.from_rate = p.rate;
             sg.g.to_rate = to_rate_;
             sg.g.from_ch = p.ch;
             sg.g.to_ch = to_ch_;
             sg.g.gain = 1.0f;
             segs.push_back(sg);
-            out_ += ready - span_m_;
+            out_ += (std::size_t)(ready - span_m_) * to_ch_;
             span_m_ = ready;
+        }
+        if (cut) {
+            std::uint64_t tail_out = 0;
+            check(rh_uniform_cut_tail_samples(span_in_, (std::uint32_t)p.tail, p.rate, to_rate_, p.ch, to_ch_, &tail_out), "rh_uniform_cut_tail_samples");
+            if (tail_out) {
+                // the frame in front of the cut is in the row whenever an output lerps towards the cut frame: that output's first tap is
+                // this very frame, and the frames from the next output's first tap on are what a block keeps
+                const bool have_last = span_in_ >= 1 && span_in_ - 1 >= row_frame0_;
+                const std::uint64_t f0 = have_last ? span_in_ - 1 : span_in_;
+                Seg sg;
+                sg.src_off = row_off_ + (std::size_t)(f0 - row_frame0_) * p.ch;
+                sg.dst_off = out_;
+                std::memset(&sg.g, 0, sizeof sg.g);
+                sg.g.src_frame0 = f0;
+                sg.g.src_frames = span_in_ - f0;
+                sg.g.m0 = 0;
+                sg.g.m1 = tail_out;  // output SAMPLES of the tail
+                sg.g.span_frames = span_in_;
+                sg.g.from_rate = p.rate;
+                sg.g.to_rate = to_rate_;
+                sg.g.from_ch = p.ch;
+                sg.g.to_ch = to_ch_;
+                sg.g.gain = 1.0f;
+                sg.g.reserved = (std::uint32_t)p.tail;
+                segs.push_back(sg);
+                out_ += (std::size_t)tail_out;
+            }
         }
         if (p.closes) {
             held_ = 0;
@@ -457,7 +535,7 @@ public:
     }
     std::size_t keep_offset() const { return keep_off_; }
     std::size_t keep_samples() const { return keep_n_; }
-    std::uint64_t out_frames() const { return out_; }
+    std::size_t out_samples() const { return out_; }
     std::uint16_t to_channels() const { return to_ch_; }
 
 private:
@@ -466,7 +544,7 @@ private:
     std::uint64_t span_in_ = 0, span_m_ = 0;        // input frames received / output frames planned of the open span
     std::uint64_t row_frame0_ = 0, next_frame0_ = 0;  // span frame index of the first frame the row holds of the open span
     std::size_t row_off_ = 0, pos_ = 0, held_ = 0, keep_off_ = 0, keep_n_ = 0;
-    std::uint64_t out_ = 0;
+    std::size_t out_ = 0;                            // output samples planned in this block
 };
 
 /// What every GPU-backed source shares: two page-locked result blocks, one served while the other is in
@@ -561,7 +639,17 @@ public:
 
 protected:
     Timing timing_;
+    /// The format of a block's samples from offset `off` on (a source's channels(), sample_rate() and current_span_len() hold for the sample
+    /// next() returns next: source/mod.rs:196-207).
+    struct FormatMark {
+        std::size_t off = 0;
+        std::uint16_t ch = 0;
+        std::uint32_t rate = 0;
+        std::optional<std::size_t> span = std::nullopt;
+    };
     struct Slot {
+        std::vector<FormatMark> marks;  // format changes inside the block (empty: the source's format is constant)
+        FormatMark next;                // ... and the format of the sample behind the block's last one
         PinnedBuf in, out;  // staging of the pulled samples / the processed block
         std::size_t n = 0;  // samples in `out`
         bool last = false;  // upstream ended with this block
@@ -585,6 +673,7 @@ protected:
     // What a subclass needs to patch blocks that are already scheduled (GpuMixer: a source that joins a running mixer at
     // the next frame, mixer.rs:175-183): the block being served, the one in flight behind it, the read position.
     Slot &cur() { return slot_[cur_]; }
+    const Slot &cur_slot() const { return slot_[cur_]; }
     Slot &other() { return slot_[cur_ ^ 1]; }
     int slot_index(const Slot &s) const { return &s == &slot_[0] ? 0 : 1; }
     int cur_index() const { return cur_; }
@@ -669,12 +758,24 @@ public:
         if (!up_) throw std::invalid_argument("upstream");
         ch_ = up_->channels();
         rate_ = up_->sample_rate();
+        cur_in_ch_ = in_ch0_ = ch_;
+        cur_in_rate_ = in_rate0_ = rate_;
         reader_ = detail::SpanReader(up_.get());
     }
     ~GpuSource() override { (void)rh_stream_synchronize(stream_); }  // nothing of the chain may still run when its buffers go
-    // -- Source
-    std::uint16_t channels() const override { return ch_; }
-    std::uint32_t sample_rate() const override { return rate_; }
+    // -- Source.  The format is the one of the sample next() returns next: an upstream that changes its format between spans (a queue of
+    // sounds of different formats) is followed span by span -- every adapter does at the boundary what rodio's does (BltFilter: new
+    // coefficients, blt.rs:119-141; Limit: a new channel count resets its state, limit.rs:652-695; AutomaticGainControl: new coefficients
+    // and a fresh window, agc.rs:524-548) -- and the chain reports the new format from that sample on.
+    std::uint16_t channels() const override { return format_at_cursor().ch; }
+    std::uint32_t sample_rate() const override { return format_at_cursor().rate; }
+    /// What rodio's adapters answer: the input's span length behind adapters that hand on one sample per sample (amplify.rs:78-80,
+    /// blt.rs:153-155, ...), None behind Mix and the converters (mix.rs:92-94, uniform.rs:104-106).
+    std::optional<std::size_t> current_span_len() const override {
+        for (const Stage &st : stages_)
+            if (st.span_rule) return std::nullopt;  // (rule 2 -- the input's spans with another sample count -- is not mirrored: None, one continuous stream)
+        return format_at_cursor().span;
+    }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
     /// `try_seek` through the chain, adapter by adapter as rodio does it: an adapter that cannot seek (reverb = Mix,
@@ -695,11 +796,11 @@ public:
 
     // -- builder methods (source/mod.rs:255-731); call before the first next()
     GpuSource &amplify(float factor) {  // amplify.rs:64
-        return push([factor](Ctx &c) { check(rh_amplify(c.out, c.in, c.n, factor, c.stream), "rh_amplify"); return c.n; });
+        return push([factor](Ctx &c) { check(rh_amplify(c.out, c.in, c.n, factor, c.stream), "rh_amplify"); return c.n; }).any_format();
     }
     GpuSource &amplify_decibel(float db) { return amplify(rh_db_to_linear(db)); }  // amplify.rs:33-35, math.rs:51-56
     GpuSource &distortion(float gain, float threshold) {  // distortion.rs:66-72
-        return push([=](Ctx &c) { check(rh_distortion(c.out, c.in, c.n, gain, threshold, c.stream), "rh_distortion"); return c.n; });
+        return push([=](Ctx &c) { check(rh_distortion(c.out, c.in, c.n, gain, threshold, c.stream), "rh_distortion"); return c.n; }).any_format();
     }
     enum class DitherAlgorithm { GPDF = 0, HighPass = 1, RPDF = 2, TPDF = 3 };  // dither.rs:40-69
     /// dither.rs:217-242; the noise of sample k is a function of (seed, k) -- see rh_dither.
@@ -812,6 +913,12 @@ public:
         auto plan = std::make_shared<detail::UniformPlanner>(channels, sample_rate);
         auto win = std::make_shared<detail::DeviceBuf>();
         auto keep = std::make_shared<detail::DeviceBuf>();
+        // What UniformSourceIterator emits is a stream of SAMPLES: a span that ends inside a frame leaves a run that need not fill a frame of
+        // `channels`, and the next span's output follows directly behind it.  The adapters behind work on frames, so a block hands on
+        // whole frames and the samples of a frame that is not complete yet wait here for the next block (at the end of the stream they
+        // are handed on as they are: rodio's adapters take them too).
+        auto part = std::make_shared<detail::DeviceBuf>(64);
+        auto part_n = std::make_shared<std::size_t>(0);
         const std::uint16_t in_ch = ch_;
         const std::uint32_t from = rate_, to = sample_rate;
         push(
@@ -824,49 +931,79 @@ public:
                 std::vector<detail::UniformPlanner::Seg> segs;
                 for (const detail::Piece &p : pieces_) plan->add(p, segs);
                 plan->end_block();
+                const std::size_t carried = *part_n;
+                if (carried) check(rh_memcpy_d2d(c.out, part->get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
                 std::vector<rh_uniform_seg> table;
                 for (const detail::UniformPlanner::Seg &sg : segs) {
                     rh_uniform_seg g = sg.g;
                     g.src = win->get() + sg.src_off;
-                    g.dst = c.out + sg.dst_off * channels;
+                    g.dst = c.out + carried + sg.dst_off;
                     table.push_back(g);
                 }
-                if ((plan->out_frames() + 1) * channels > c.out_cap) throw Error(RH_ERR_CAPACITY, "GpuSource::uniform: block capacity");
+                const std::size_t total = carried + plan->out_samples();
+                if (total + channels > c.out_cap) throw Error(RH_ERR_CAPACITY, "GpuSource::uniform: block capacity");
                 check(rh_uniform_segments(table.data(), (std::uint32_t)table.size(), c.stream), "rh_uniform_segments");
                 if (const std::size_t kn = plan->keep_samples()) {
                     keep->reset(kn);
                     check(rh_memcpy_d2d(keep->get(), win->get() + plan->keep_offset(), kn * sizeof(float), c.stream), "rh_memcpy_d2d");
                 }
-                return (std::size_t)plan->out_frames() * channels;
+                const std::size_t rest = c.flush ? 0 : total % channels;
+                if (rest) check(rh_memcpy_d2d(part->get(), c.out + total - rest, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
+                *part_n = rest;
+                return total - rest;
             },
-            [this, in_ch, channels, from, to](std::size_t n) {  // every span may add its verbatim last frame
-                const std::uint64_t f = n / in_ch;
-                return (std::size_t)(std::max<std::uint64_t>(f, f * to / from + 2) + 2 * (pieces_.size() + 2)) * channels;
+            [this, in_ch, channels, from, to](std::size_t n) {  // every span may add its verbatim last frame, or what the converters make of a cut frame
+                // (the block's pieces may come in other formats than the chain was built for: the fewest channels and the lowest rate among them bound it)
+                const std::uint64_t ich = std::min<std::uint64_t>(in_ch, block_min_ch_ ? block_min_ch_ : in_ch), ifrom = std::min<std::uint64_t>(from, block_min_rate_ ? block_min_rate_ : from);
+                const std::uint64_t f = n / ich;
+                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * (pieces_.size() + 2) + 1) * channels;
             })
-            .on_seek([plan, channels, sample_rate](Nanos) { *plan = detail::UniformPlanner(channels, sample_rate); });  // what was pulled ahead is gone: the next span starts a fresh chain
+            .on_seek([plan, part_n, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
+                *plan = detail::UniformPlanner(channels, sample_rate);
+                *part_n = 0;
+            });
         stages_.back().span_rule = 1;
+        stages_.back().fmt = 3;  // every piece comes with its own format (uniform.rs:58-59: read at every bootstrap)
         ch_ = channels;
         rate_ = sample_rate;
         return *this;
     }
     GpuSource &limit(const rh_limit_params &settings) {  // limit.rs:94-130,853-988
-        const std::uint16_t ch = ch_;
-        const std::uint32_t rate = rate_;
-        auto st = state(2u * ch);
+        auto chp = std::make_shared<std::uint16_t>(ch_);
+        const std::uint32_t rate = rate_;  // (the coefficients belong to the rate the limiter was built for: LimitBase outlives a change of format, limit.rs:669-693)
+        auto st = state(2u * ch_);
         const rh_stream sm = stream_;
         scan_kernels_ = true;
         return push([=](Ctx &c) {
-            check(rh_limit(c.out, c.in, c.n / ch, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
-            return c.n / ch * ch;
-        }).on_seek([st, ch, sm](Nanos) { check(rh_memset(st->get(), 0, 2u * ch * sizeof(float), sm), "rh_memset"); });  // limit.rs:1139-1158
+            const std::uint16_t ch = *chp;
+            std::size_t frames = c.n / ch;
+            const std::size_t rem = c.n % ch;
+            if (rem && c.flush) {  // a stream can end inside a frame: limit.rs:927-988 still limits those samples (every channel has its own
+                                   // integrator; the zero padding only touches channels the stream no longer has)
+                check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
+                frames += 1;
+            }
+            check(rh_limit(c.out, c.in, frames, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
+            return rem && c.flush ? c.n : frames * ch;
+        }).on_seek([st, chp, sm](Nanos) { check(rh_memset(st->get(), 0, 2u * *chp * sizeof(float), sm), "rh_memset"); })  // limit.rs:1139-1158
+            .on_format([st, chp, sm](std::uint16_t ch, std::uint32_t) {  // limit.rs:652-695: another channel count rebuilds the state; another rate changes nothing
+                if (ch == *chp) return;
+                st->reset(2u * ch);
+                check(rh_memset(st->get(), 0, 2u * ch * sizeof(float), sm), "rh_memset");
+                *chp = ch;
+            });
     }
     GpuSource &automatic_gain_control(const rh_agc_params &settings) {  // agc.rs:133-171,397-504
-        const std::uint32_t rate = rate_;
+        auto ratep = std::make_shared<std::uint32_t>(rate_);
         auto st = std::make_shared<detail::DeviceBuf>(rh_agc_state_floats());
         check(rh_agc_state_init(st->get(), 1, stream_), "rh_agc_state_init");
+        const rh_stream sm = stream_;
         return push([=](Ctx &c) {
-            check(rh_agc(c.out, c.in, c.n, rate, 1, &settings, st->get(), c.stream), "rh_agc");
+            check(rh_agc(c.out, c.in, c.n, *ratep, 1, &settings, st->get(), c.stream), "rh_agc");
             return c.n;
+        }).on_format([st, ratep, sm](std::uint16_t, std::uint32_t rate) {  // agc.rs:524-548: coefficients for the new rate, a fresh window, peak 0, gain 1
+            *ratep = rate;
+            check(rh_agc_state_init(st->get(), 1, sm), "rh_agc_state_init");
         });
     }
     GpuSource &linear_gain_ramp(Nanos duration, float start_gain, float end_gain, bool clamp_end) {  // linear_ramp.rs:79-110
@@ -929,24 +1066,45 @@ protected:
         if (scan_kernels_) check(rh_async_status(), "rh_async_status");
     }
     void enqueue(Slot &s) override {
-        const std::size_t want = block_frames_ * up_->channels();
+        if (!follow_known_) {  // an upstream that reports spans may change its format between them: it is pulled span by span
+            follow_known_ = true;
+            follow_spans_ = !span_aware_ && up_->current_span_len().has_value();
+            if (follow_spans_) reader_ = detail::SpanReader(up_.get(), false);
+        }
+        const std::size_t want = block_frames_ * cur_in_ch_;
         // The slot's page-locked staging block is about to be rewritten: the copy that read it two blocks ago must have run.  A host
         // consumer has waited for that block's event already (advance()); one that takes the blocks on the device never waits on the
         // host, so the wait is here (otherwise the refill races the asynchronous host-to-device copy of the block before).
         // Almost always satisfied by the time the slot comes round again.
         if (device_out_) check(rh_event_synchronize(s.done), "rh_event_synchronize");
-        s.in.reset(want);
-        if (up_->channels() != in_ch() || up_->sample_rate() != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
+        s.in.reset(want + 64);
+        // 1. pull: runs of samples of one format (a format changes only between two spans)
+        struct Run {
+            std::size_t off, n;
+            std::uint16_t ch;
+            std::uint32_t rate;
+            std::size_t p0, p1;  // its pieces
+        };
+        std::vector<Run> runs;
+        std::vector<detail::Piece> all;
+        std::vector<std::size_t> piece_off;
         std::size_t n = 0;
         bool flush = false;
-        pieces_.clear();
-        if (span_aware_) {  // a UniformSourceIterator is in the chain: pull span by span, asking for the span where rodio asks
+        if (span_aware_ || follow_spans_) {  // span by span, asking for the span where rodio asks (UniformSourceIterator: uniform.rs:50-68; the adapters' SpanTracker: span.rs:66-101)
             while (n < want) {
+                std::uint16_t pch = 0;
+                std::uint32_t prate = 0;
+                if (!reader_.peek(pch, prate)) break;
+                const std::size_t room = (want - n) / pch;
+                if (!room) break;
                 detail::Piece pc;
-                const bool produced = reader_.read_piece(s.in.get() + n, (want - n) / in_ch(), pc);
+                const bool produced = reader_.read_piece(s.in.get() + n, room, pc);
                 if (produced) {
-                    if (pc.ch != in_ch() || pc.rate != in_rate()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream");
-                    pieces_.push_back(pc);
+                    if (runs.empty() || pc.src_ch != runs.back().ch || pc.src_rate != runs.back().rate) runs.push_back(Run{n, 0, pc.src_ch, pc.src_rate, all.size(), all.size()});
+                    runs.back().n += pc.n;
+                    runs.back().p1 = all.size() + 1;
+                    piece_off.push_back(n);
+                    all.push_back(pc);
                     n += pc.n;
                 }
                 if (reader_.ended() || !produced) break;
@@ -954,38 +1112,126 @@ protected:
             flush = reader_.ended();
         } else {
             n = up_->read(s.in.get(), want);
-            n -= n % up_->channels();  // sources end on frame boundaries (source/mod.rs:169-178)
+            n -= n % cur_in_ch_;  // sources end on frame boundaries (source/mod.rs:169-178)
             flush = n < want;
+            runs.push_back(Run{0, n, cur_in_ch_, cur_in_rate_, 0, 0});
         }
+        if (runs.empty()) runs.push_back(Run{0, 0, cur_in_ch_, cur_in_rate_, 0, 0});
         // capacity of the ping-pong buffers: the largest block any stage can emit
-        std::size_t cap = want, m = want;
+        pieces_.assign(all.begin(), all.end());
+        block_min_ch_ = 0, block_min_rate_ = 0;
+        for (const detail::Piece &pc : all) {
+            block_min_ch_ = block_min_ch_ ? std::min(block_min_ch_, pc.ch) : pc.ch;
+            block_min_rate_ = block_min_rate_ ? std::min(block_min_rate_, pc.rate) : pc.rate;
+        }
+        std::size_t cap = want + 64, m = want + 64;
         for (const Stage &st : stages_) cap = std::max(cap, m = st.bound(m));
         cap = ((cap + 3) & ~std::size_t(3)) + 64;  // + room for one padding frame
         a_.reset(cap);
         b_.reset(cap);
-        float *cur = a_.get(), *oth = b_.get();
-        if (n) check(rh_memcpy_h2d(cur, s.in.get(), n * sizeof(float), stream_), "rh_memcpy_h2d");
-        bool ends = flush;  // the upstream ended, or a stage says so: the stages behind it see the end of their input
-        for (Stage &st : stages_) {
-            Ctx c{oth, cur, n, cap, ends, stream_};
-            n = st.run(c);
-            ends = ends || c.end;
-            std::swap(cur, oth);
+        bool counted = true, fixed = false;  // every adapter hands on one sample per sample / an adapter gives one format out whatever comes in
+        for (const Stage &st : stages_) {
+            counted = counted && st.span_rule == 0;
+            fixed = fixed || st.fmt == 3;
+        }
+        if (runs.size() > 1) acc_.reset(cap * runs.size());
+        // 2. run by run through the adapters
+        s.marks.clear();
+        std::size_t total = 0;
+        float *result = a_.get();
+        bool ends = false;
+        for (std::size_t r = 0; r < runs.size(); ++r) {
+            const Run &run = runs[r];
+            if (run.ch != cur_in_ch_ || run.rate != cur_in_rate_) {  // the boundary: every adapter does what rodio's does there
+                for (Stage &st : stages_) {
+                    if (st.fmt == 3) break;  // (it meets the spans itself; what lies behind it sees one format)
+                    if (st.fmt == 2) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: the upstream changed its format mid-stream in front of an adapter that is not mirrored across such a change (convert with .uniform() first)");
+                    if (st.fmt == 1) st.on_format(run.ch, run.rate);
+                }
+                cur_in_ch_ = run.ch;
+                cur_in_rate_ = run.rate;
+            }
+            pieces_.assign(all.begin() + (std::ptrdiff_t)run.p0, all.begin() + (std::ptrdiff_t)run.p1);
+            float *cur = a_.get(), *oth = b_.get();
+            std::size_t k = run.n;
+            if (k) check(rh_memcpy_h2d(cur, s.in.get() + run.off, k * sizeof(float), stream_), "rh_memcpy_h2d");
+            bool run_ends = flush && r + 1 == runs.size();  // the upstream ended, or a stage says so: the stages behind it see the end of their input
+            for (Stage &st : stages_) {
+                Ctx c{oth, cur, k, cap, run_ends, stream_};
+                k = st.run(c);
+                run_ends = run_ends || c.end;
+                std::swap(cur, oth);
+            }
+            ends = ends || run_ends;
+            // the format of what came out: the adapters' own where one of them fixes it (or nothing changed), the run's otherwise
+            const bool as_built = fixed || (run.ch == in_ch0() && run.rate == in_rate0());
+            FormatMark mk{total, as_built ? ch_ : run.ch, as_built ? rate_ : run.rate, std::nullopt};
+            if (counted && (span_aware_ || follow_spans_)) {  // current_span_len() is the input's: a mark per span that opens in the run
+                bool first = true;
+                for (std::size_t pi = run.p0; pi < run.p1; ++pi) {
+                    if (all[pi].src_opens) open_span_ = all[pi].src_span;
+                    if (first || all[pi].src_opens) {
+                        mk.off = total + (piece_off[pi] - run.off);
+                        mk.span = open_span_;
+                        s.marks.push_back(mk);
+                    }
+                    first = false;
+                }
+                if (run.p0 == run.p1) s.marks.push_back(mk);
+            } else {
+                s.marks.push_back(mk);
+            }
+            if (runs.size() > 1) {
+                if (k) check(rh_memcpy_d2d(acc_.get() + total, cur, k * sizeof(float), stream_), "rh_memcpy_d2d");
+                result = acc_.get();
+            } else {
+                result = cur;
+            }
+            total += k;
+            if (ends) break;
+        }
+        n = total;
+        // ... and the format of the sample behind the block (the next span's, if the block ended on a boundary)
+        {
+            std::uint16_t nch = cur_in_ch_;
+            std::uint32_t nrate = cur_in_rate_;
+            std::optional<std::size_t> nspan = std::nullopt;
+            if ((span_aware_ || follow_spans_) && !ends) {
+                if (reader_.peek(nch, nrate)) reader_.source_format(nch, nrate, nspan);
+            }
+            if (ends && follow_spans_) nspan = 0;  // a source that has given everything answers Some(0) (buffer.rs:76-82)
+            const bool as_built = fixed || (nch == in_ch0() && nrate == in_rate0());
+            s.next = FormatMark{n, as_built ? ch_ : nch, as_built ? rate_ : nrate, counted ? nspan : std::nullopt};
         }
         if (device_out_) {  // the block stays on the device, in the slot's own buffer (a_ / b_ belong to the next block's stages)
-            s.dev.reset(cap);
+            s.dev.reset(std::max(cap, n + 64));
             if (s.taken_pending) {  // the consumer's copies out of this slot's previous block
                 check(rh_stream_wait_event(stream_, s.taken), "rh_stream_wait_event");
                 s.taken_pending = false;
             }
-            if (n) check(rh_memcpy_d2d(s.dev.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2d");
+            if (n) check(rh_memcpy_d2d(s.dev.get(), result, n * sizeof(float), stream_), "rh_memcpy_d2d");
         } else if (n) {
-            s.out.reset(cap);
-            check(rh_memcpy_d2h_async(s.out.get(), cur, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
+            s.out.reset(std::max(cap, n + 64));
+            check(rh_memcpy_d2h_async(s.out.get(), result, n * sizeof(float), stream_), "rh_memcpy_d2h_async");
             timing_.d2h_samples += n;
         }
         s.n = n;
         s.last = ends;
+    }
+    /// The format of the sample next() returns next.
+    FormatMark format_at_cursor() const {
+        if (!started()) {  // nothing pulled yet: the upstream's own answers
+            bool counted = true;
+            for (const Stage &st : stages_) counted = counted && st.span_rule == 0;
+            return FormatMark{0, ch_, rate_, counted ? up_->current_span_len() : std::nullopt};
+        }
+        const Slot &sl = cur_slot();
+        const std::size_t pos = position();
+        if (pos >= sl.n || sl.marks.empty()) return sl.next;
+        const FormatMark *m = &sl.marks.front();
+        for (const FormatMark &k : sl.marks)
+            if (k.off <= pos) m = &k;
+        return *m;
     }
 
 private:
@@ -1003,6 +1249,11 @@ private:
         bool seekable = true;                        // false: the adapter answers SeekError::NotSupported (mix.rs:116-120)
         std::function<void(Nanos)> on_seek = nullptr;  // what the adapter does to its own state after its input was sought
         int span_rule = 0;  // what current_span_len() is behind the adapter: 0 the input's (one sample out per sample in), 1 None (Mix, the converters), 2 the input's with another sample count
+        // The upstream's format changes between two spans.  0: the adapter does not care (amplify).  1: on_format does what rodio's adapter does at
+        // the boundary.  2: not mirrored (loud error).  3: the adapter meets the spans itself and gives one format out (UniformSourceIterator): the
+        // adapters behind it never see a change.
+        int fmt = 2;
+        std::function<void(std::uint16_t, std::uint32_t)> on_format = nullptr;
     };
     template <class T>
     struct Handle {
@@ -1014,12 +1265,21 @@ private:
     };
     template <class F>
     GpuSource &push(F run) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr, 0});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr, 0, 2, nullptr});
         return *this;
     }
     template <class F, class B>
     GpuSource &push(F run, B bound) {
-        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr, 2});
+        stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr, 2, 2, nullptr});
+        return *this;
+    }
+    GpuSource &any_format() {  // for the stage pushed last
+        stages_.back().fmt = 0;
+        return *this;
+    }
+    GpuSource &on_format(std::function<void(std::uint16_t, std::uint32_t)> f) {
+        stages_.back().fmt = 1;
+        stages_.back().on_format = std::move(f);
         return *this;
     }
     GpuSource &on_seek(std::function<void(Nanos)> f) {  // for the stage pushed last
@@ -1041,11 +1301,19 @@ private:
     }
     GpuSource &blt(int kind, std::uint32_t freq, float q) {  // blt.rs:502-544,558-560
         const std::uint16_t ch = ch_;
-        float co[5];
-        check(rh_biquad_coeffs(kind, freq, q, rate_, co), "rh_biquad_coeffs");
-        std::vector<float> coeffs(co, co + 5);
+        struct Applier {
+            float co[5];
+            bool exact;
+        };
+        const int mode = filter_mode_;
+        auto make = [kind, freq, q, mode](std::uint32_t rate) {
+            Applier a;
+            check(rh_biquad_coeffs(kind, freq, q, rate, a.co), "rh_biquad_coeffs");
+            a.exact = mode == 1 || (mode == 0 && !rh_filter_scan_ok(kind, freq, q, rate));  // the filter contract (rodio_hip.h)
+            return a;
+        };
+        auto ap = std::make_shared<Applier>(make(rate_));
         auto st = state(4u * ch);
-        const bool exact = filter_mode_ == 1 || (filter_mode_ == 0 && !rh_filter_scan_ok(kind, freq, q, rate_));  // the filter contract (rodio_hip.h)
         return push([=](Ctx &c) {
             std::size_t frames = c.n / ch;
             const std::size_t rem = c.n % ch;
@@ -1053,19 +1321,33 @@ private:
                 check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
                 frames += 1;       // the zero padding only touches channels the stream no longer has
             }
-            check(rh_biquad(c.out, c.in, frames, ch, 1, coeffs.data(), st->get(), exact ? 0 : 1, c.stream), "rh_biquad");
+            check(rh_biquad(c.out, c.in, frames, ch, 1, ap->co, st->get(), ap->exact ? 0 : 1, c.stream), "rh_biquad");
             return rem && c.flush ? c.n : frames * ch;
-        }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); });  // blt.rs:350-377
+        }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); })  // blt.rs:350-377
+            .on_format([ap, make, ch](std::uint16_t new_ch, std::uint32_t rate) {
+                // blt.rs:119-141: `recreate_applier` for the new rate; the state stays.  (A new channel COUNT: the branch that would rebuild the
+                // filter compares the count with itself, blt.rs:128, so rodio goes on filtering frames of the new layout with the state of
+                // the old one -- channels meet each other's history.  Not mirrored.)
+                if (new_ch != ch) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a filter across a change of the channel count (" + std::to_string(ch) + " -> " + std::to_string(new_ch) + ")");
+                *ap = make(rate);
+            });
     }
-    std::uint16_t in_ch() const { return in_ch_ ? in_ch_ : (in_ch_ = up_->channels()); }
-    std::uint32_t in_rate() const { return in_rate_ ? in_rate_ : (in_rate_ = up_->sample_rate()); }
 
     BoxSource up_;
     std::size_t block_frames_;
     std::uint16_t ch_ = 0;
     std::uint32_t rate_ = 0;
-    mutable std::uint16_t in_ch_ = 0;
-    mutable std::uint32_t in_rate_ = 0;
+    std::uint16_t cur_in_ch_ = 0;    // the upstream's format as of the last sample pulled
+    std::uint32_t cur_in_rate_ = 0;
+    std::uint16_t in_ch0_ = 0;       // ... and when the chain was built (ch_ / rate_ are the chain's output format for THAT input)
+    std::uint32_t in_rate0_ = 0;
+    std::uint16_t in_ch0() const { return in_ch0_; }
+    std::uint32_t in_rate0() const { return in_rate0_; }
+    std::optional<std::size_t> open_span_;  // what current_span_len() answered for the span that is open
+    std::uint16_t block_min_ch_ = 0;        // the fewest channels / the lowest rate among the pieces of the block being enqueued (0: none)
+    std::uint32_t block_min_rate_ = 0;
+    bool follow_spans_ = false, follow_known_ = false;  // the upstream reports spans: it is pulled span by span (asked once, at the first block)
+    detail::DeviceBuf acc_;          // a block whose samples have more than one format: the runs' outputs, back to back
     std::vector<Stage> stages_;
     detail::SpanReader reader_{nullptr};
     std::vector<detail::Piece> pieces_;  // the spans of the block being enqueued
@@ -1123,11 +1405,13 @@ public:
         // exact response than rodio is; at low cutoffs further than 1e-5 from rodio).
         bool reference_exact_filters = true;
     };
-    /// mixer::mixer(channels, sample_rate) (mixer.rs:25).  The sources are mixed as stereo frames; `channels` other than 2 is what
-    /// ChannelCountConverter makes of every source (channels.rs:57-85), applied ONCE, to the mixed block (the converter and the
-    /// sum commute: 1 keeps channel 0, more than 2 appends silent channels -- for that, sources must not have more than 2 channels
-    /// themselves, or their channels 2.. would be lost: such an add() is refused).
-    GpuMixer(std::uint16_t channels, std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt), out_ch_(channels) {
+    /// mixer::mixer(channels, sample_rate) (mixer.rs:25).  One and two channels: the sources are mixed as stereo frames by the fused
+    /// kernel, and a mono mixer keeps channel 0 of the mix (ChannelCountConverter(2 -> 1) commutes with the sum: channels.rs:57-85).
+    /// MORE than two channels (a 5.1 mix): every source becomes a chain of its own on the device --
+    /// [amplify] -> UniformSourceIterator(channels, rate) -> [its filter] (GpuSource, the blocks staying in device memory) -- and the
+    /// mixer adds the chains' blocks in insertion order (rh_mix_sum): rodio's Mixer::add + MixerSource::next for any layout, without the
+    /// fused kernel (whose frames are mono or stereo).
+    GpuMixer(std::uint16_t channels, std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt), out_ch_(channels), qch_(channels > 2 ? channels : 2) {
         if (!sample_rate || !channels) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         if (!opt_.block_frames) opt_.block_frames = 1;
         check(rh_stream_create(&copy_stream_), "rh_stream_create");
@@ -1153,12 +1437,26 @@ public:
         std::uint16_t ch = src->channels();
         const std::uint32_t from = src->sample_rate();
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
-        if (out_ch_ > 2 && ch > 2) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source of more than 2 channels into a mixer of more than 2 (the mix is formed in stereo)");
         if (filter.kind > 1) throw std::invalid_argument("filter kind");
-        if (filter.kind >= 0 && opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) {
+        if (wide()) {  // a mixer of more than two channels: the source's own chain, the mixer only sums
+            Src item;
+            item.up = std::move(src);
+            item.gain = gain;
+            item.ch = ch;
+            item.filt = filter;
+            make_wide(item);
+            if (running()) late_join(std::move(item));
+            else pending_.push_back(std::move(item));
+            return;
+        }
+        // A source whose spans can end inside a frame (uniform.rs:56: 32768 is no multiple of 3, 5, 6, 7 channels) may end its converted
+        // stream inside an output frame; the fused kernel filters whole frames, so such a source takes its filter along in a chain of its
+        // own, which filters exactly the samples rodio's BltFilter sees (blt.rs:431-451), and enters the mix unfiltered.
+        const bool may_cut = filter.kind >= 0 && src->current_span_len().has_value() && (32768u % ch) != 0;
+        if (filter.kind >= 0 && ((opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut)) {
             // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
             auto chain = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
-            chain->exact_filters(true);
+            if (opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) chain->exact_filters(true);
             if (gain != 1.0f) chain->amplify(gain);
             chain->uniform(2, rate_);
             if (filter.kind == 0) chain->low_pass_with_q(filter.freq, filter.q);
@@ -1182,7 +1480,21 @@ public:
     void add(std::unique_ptr<GpuSource> chain, float gain, Filter filter) {
         if (!chain) throw std::invalid_argument("source");
         GpuSource *const gs = chain.get();
-        const bool on_device = gs->channels() == 2 && !gs->started() && !fused_ratio_unsupported(gs->sample_rate(), rate_) && gs->sample_rate() != 0;
+        if (wide() && !gs->started()) {  // the chain goes on as the source's chain of a wide mixer: amplify -> uniform(channels, rate) -> filter behind what it has
+            Src item;
+            item.ch = gs->channels();
+            item.up = std::move(chain);
+            item.dev = gs;
+            item.gain = gain;
+            item.filt = filter;
+            make_wide(item);
+            if (running()) late_join(std::move(item));
+            else pending_.push_back(std::move(item));
+            return;
+        }
+        // (a chain that forwards its input's spans -- a SamplesBuffer behind amplify / a filter -- is converted span by span like any spanned
+        // source, rodio's UniformSourceIterator restarting at every span: that path pulls through the host)
+        const bool on_device = !wide() && gs->channels() == 2 && !gs->started() && !fused_ratio_unsupported(gs->sample_rate(), rate_) && gs->sample_rate() != 0 && !gs->current_span_len().has_value();
         if (!on_device) {
             add(BoxSource(std::move(chain)), gain, filter);
             return;
@@ -1246,8 +1558,8 @@ protected:
             slot_frames_[slot_index(s)] = 0;
             return;
         }
-        s.out.reset(out_cap_frames_ * 2 * std::max<std::size_t>(2, out_ch_));
-        if (debug_poison()) std::memset(s.out.get(), 0xff, out_cap_frames_ * 2 * std::max<std::size_t>(2, out_ch_) * sizeof(float));  // diagnostics: a block served before it arrived reads NaN
+        s.out.reset(out_cap_frames_ * 2 * qch_);
+        if (debug_poison()) std::memset(s.out.get(), 0xff, out_cap_frames_ * 2 * qch_ * sizeof(float));  // diagnostics: a block served before it arrived reads NaN
         // 1. every live generation converts, filters and mixes one block of its sources behind what its queue holds
         // (one that runs ahead of the slowest -- another rate, other tile boundaries -- waits with a full queue)
         for (auto &gp : gens_)
@@ -1272,17 +1584,17 @@ protected:
                 for (auto &gp : gens_) {
                     ptrs.push_back(gp->queue());
                     start.push_back(0);
-                    len.push_back(std::min(gp->fill, n) * 2);
+                    len.push_back(std::min(gp->fill, n) * qch_);
                 }
-                dmix_.reset(out_cap_frames_ * 2 * 2);
-                if (debug_poison()) check(rh_memset(dmix_.get(), 0xff, out_cap_frames_ * 2 * 2 * sizeof(float), stream_), "rh_memset");
-                check(rh_mix_sum(dmix_.get(), n * 2, ptrs.data(), start.data(), len.data(), (std::uint32_t)ptrs.size(), stream_), "rh_mix_sum");
+                dmix_.reset(out_cap_frames_ * 2 * qch_);
+                if (debug_poison()) check(rh_memset(dmix_.get(), 0xff, out_cap_frames_ * 2 * qch_ * sizeof(float), stream_), "rh_memset");
+                check(rh_mix_sum(dmix_.get(), n * qch_, ptrs.data(), start.data(), len.data(), (std::uint32_t)ptrs.size(), stream_), "rh_mix_sum");
                 mixed = dmix_.get();
             }
             send_block(s, mixed, n);
             // the block also stays on the device until it has been served: a source that joins in the middle of it is added there
-            dkeep_[slot_index(s)].reset(out_cap_frames_ * 2 * 2);
-            check(rh_memcpy_d2d(dkeep_[slot_index(s)].get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            dkeep_[slot_index(s)].reset(out_cap_frames_ * 2 * qch_);
+            check(rh_memcpy_d2d(dkeep_[slot_index(s)].get(), mixed, n * qch_ * sizeof(float), stream_), "rh_memcpy_d2d");
         }
         slot_base_[slot_index(s)] = scheduled_;
         slot_frames_[slot_index(s)] = n;
@@ -1290,7 +1602,7 @@ protected:
         for (auto &gp : gens_) {
             Gen &g = *gp;
             const std::uint64_t used = std::min(g.fill, n), rem = g.fill - used, pad = rem & 1;  // the fused kernel writes 16-byte aligned blocks behind it
-            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * 2, g.queue() + used * 2, rem * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * qch_, g.queue() + used * qch_, rem * qch_ * sizeof(float), stream_), "rh_memcpy_d2d");
             g.cur ^= 1;
             g.head = pad;
             g.fill = rem;
@@ -1300,6 +1612,18 @@ protected:
         scheduled_ += n;
         bool all_done = true;
         for (auto &gp : gens_) all_done = all_done && gp->done && gp->fill == 0;
+        std::size_t trim = 0;
+        if (all_done && out_ch_ > 1) {
+            // MixerSource::next returns None the moment no source is left (mixer.rs:120-136): when the sources that last longest end inside a
+            // frame -- the converters' output of a span that ends inside a frame need not fill one -- so does the mix.  The blocks hold whole
+            // frames (the missing samples were added as +0.0, which leaves the sums as they are); the last one is cut to what rodio returns.
+            std::uint64_t last = 0;
+            std::uint32_t valid = 0;
+            for (auto &gp : gens_) last = std::max(last, gp->join + gp->emitted);
+            for (auto &gp : gens_)
+                if (gp->join + gp->emitted == last) valid = std::max<std::uint32_t>(valid, gp->last_valid ? gp->last_valid : qch_);
+            if (n && valid && valid < qch_) trim = qch_ - valid;
+        }
         if (all_done) {
             check(rh_stream_synchronize(stream_), "rh_stream_synchronize");
             check(rh_stream_synchronize(copy_stream_), "rh_stream_synchronize");
@@ -1313,18 +1637,18 @@ protected:
             reaper_->retire(std::move(gens_));
             gens_.clear();
         }
-        s.n = (std::size_t)n * out_ch_;
+        s.n = (std::size_t)n * out_ch_ - trim;
         s.last = gens_.empty() && pending_.empty();
     }
 
 private:
     /// The mixed stereo block `mixed` (n frames, on the device) on its way to the host block of slot `s`, in the mixer's layout.
     void send_block(Slot &s, const float *mixed, std::uint64_t n) {
-        if (out_ch_ == 2) {
-            check(rh_memcpy_d2h_async(s.out.get(), mixed, n * 2 * sizeof(float), stream_), "rh_memcpy_d2h_async");
+        if (out_ch_ == qch_) {  // stereo, or a wide mix formed in the mixer's own layout
+            check(rh_memcpy_d2h_async(s.out.get(), mixed, n * qch_ * sizeof(float), stream_), "rh_memcpy_d2h_async");
             return;
         }
-        dout_.reset(out_cap_frames_ * 2 * out_ch_);  // ChannelCountConverter(2 -> channels) on the mix (channels.rs:57-85), once per block
+        dout_.reset(out_cap_frames_ * 2 * out_ch_);  // a mono mixer: ChannelCountConverter(2 -> 1) on the mix (channels.rs:57-85), once per block
         check(rh_channels_convert(dout_.get(), mixed, (std::size_t)n, 2, out_ch_, stream_), "rh_channels_convert");
         check(rh_memcpy_d2h_async(s.out.get(), dout_.get(), n * out_ch_ * sizeof(float), stream_), "rh_memcpy_d2h_async");
     }
@@ -1353,7 +1677,8 @@ private:
         // span-by-span generations: how rodio's UniformSourceIterator would pull this source, and where its converted frames wait
         detail::SpanReader reader{nullptr};
         detail::UniformPlanner plan;
-        std::uint64_t have = 0, off = 0;  // converted frames not yet mixed: `have` of them from frame `off` of the source's device row
+        std::uint64_t have_s = 0, off_s = 0;  // converted SAMPLES not yet mixed: `have_s` of them from sample `off_s` of the source's device row
+        std::uint64_t total_s = 0;            // samples of the source's stream in the mixer's layout so far (where the generation tracks them: Gen::track)
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
@@ -1386,9 +1711,26 @@ private:
         detail::DeviceBuf conv[2], dtab;     // converted rows (ping-pong: what a block leaves moves to the front of the other set); segment table
         detail::PinnedBuf tab[2];
         int ccur = 0;
-        const float *queue() const { return q[cur].get() + head * 2; }
-        float *queue_end() { return q[cur].get() + (head + fill) * 2; }
+        std::size_t qch = 2;                 // channels of the queue's frames (the mixer's, when it has more than two)
+        const float *queue() const { return q[cur].get() + head * qch; }
+        float *queue_end() { return q[cur].get() + (head + fill) * qch; }
         Filter filt;
+        // a generation of a wide mixer: every source a chain in the mixer's layout, summed by rh_mix_sum
+        bool wide = false;
+        detail::DeviceBuf drow;
+        // where the generation's stream lies in the mixer's and how it ended (enqueue(): the last block of a mix that ends inside a frame)
+        std::uint64_t join = 0, emitted = 0;  // mixer frame of its first frame; frames it has produced
+        bool track = false;                   // its sources' streams are counted in samples (Src::total_s)
+        std::uint32_t last_valid = 0;         // samples of its LAST frame that rodio's sources cover (0: the whole frame)
+        void finish() {  // (when `done` is set) the frame the longest sources end in
+            if (!track) return;
+            std::uint64_t most = 0;
+            for (const Src &x : srcs) most = std::max(most, (x.total_s + qch - 1) / qch);
+            std::uint32_t v = 0;
+            for (const Src &x : srcs)
+                if ((x.total_s + qch - 1) / qch == most) v = std::max<std::uint32_t>(v, x.total_s % qch ? (std::uint32_t)(x.total_s % qch) : (std::uint32_t)qch);
+            last_valid = v == qch ? 0 : v;
+        }
         Gen() = default;
         Gen(const Gen &) = delete;
         Gen &operator=(const Gen &) = delete;
@@ -1457,22 +1799,55 @@ private:
         x.up = std::move(conv);
         x.ch = 2;
     }
+    bool wide() const { return out_ch_ > 2; }
+    /// A source of a wide mixer: its own chain on the device, [amplify] -> UniformSourceIterator(channels, rate) -> [filter] (mixer.rs:58-66 with
+    /// rodio's adapters in rodio's order), the blocks handed over in device memory.
+    void make_wide(Src &x) {
+        GpuSource *gs = x.dev;
+        if (!gs) {
+            auto chain = std::make_unique<GpuSource>(std::move(x.up), opt_.block_frames);
+            gs = chain.get();
+            x.up = std::move(chain);
+            x.dev = gs;
+        }
+        if (x.gain != 1.0f) gs->amplify(x.gain);
+        gs->uniform(out_ch_, rate_);
+        if (x.filt.kind >= 0) {
+            if (opt_.reference_exact_filters && !rh_filter_scan_ok(x.filt.kind, x.filt.freq, x.filt.q, rate_)) gs->exact_filters(true);
+            if (x.filt.kind == 0) gs->low_pass_with_q(x.filt.freq, x.filt.q);
+            else gs->high_pass_with_q(x.filt.freq, x.filt.q);
+        }
+        gs->keep_blocks_on_device();
+        x.gain = 1.0f;
+        x.filt = Filter::none();
+        x.ch = out_ch_;
+        device_chains_ = true;
+    }
     void start_generation() {  // the sources that joined together
         std::vector<Src> all = std::move(pending_);
         pending_.clear();
+        if (wide()) {
+            start_stream_wide(std::move(all), scheduled_);
+            return;
+        }
         bool any_spans = false;
-        for (const Src &x : all) any_spans = any_spans || spanned(x);
+        for (const Src &x : all) any_spans = any_spans || (!x.dev && spanned(x));
         if (any_spans) {  // span by span, as rodio converts them: one stream per filter for all of them, in insertion order
             std::vector<Filter> fk;
             for (const Src &x : all)
-                if (std::find(fk.begin(), fk.end(), x.filt) == fk.end()) fk.push_back(x.filt);
+                if (!x.dev && std::find(fk.begin(), fk.end(), x.filt) == fk.end()) fk.push_back(x.filt);
             for (const Filter &f : fk) {
                 std::vector<Src> group;
                 for (Src &x : all)
-                    if (x.up && x.filt == f) group.push_back(std::move(x));
+                    if (x.up && !x.dev && x.filt == f) group.push_back(std::move(x));
                 start_stream(std::move(group), true);
             }
-            return;
+            // (chains that hand their blocks over on the device are continuous streams in the fused kernel's layout: streams of their own, below)
+            std::vector<Src> rest;
+            for (Src &x : all)
+                if (x.up) rest.push_back(std::move(x));
+            all = std::move(rest);
+            if (all.empty()) return;
         }
         // continuous sources: one fused stream per (input rate, filter) -- and one for its mono sources, which the kernel reads as
         // they are (4 bytes per frame) -- in order of first appearance
@@ -1495,9 +1870,26 @@ private:
             start_stream(std::move(group), false, k.mono);
         }
     }
+    void start_stream_wide(std::vector<Src> srcs, std::uint64_t join) {
+        auto gp = std::make_unique<Gen>();
+        Gen &g = *gp;
+        g.srcs = std::move(srcs);
+        g.wide = true;
+        g.track = true;
+        g.qch = qch_;
+        g.join = join;
+        // (a block takes at most block_frames frames of every chain, whatever the chains' own blocks are)
+        out_cap_frames_ = std::max<std::uint64_t>(out_cap_frames_, opt_.block_frames + 64);
+        for (auto &other : gens_)
+            for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * qch_, (other->head + other->fill) * qch_);
+        for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * qch_);
+        last_join_ = join;
+        gens_.push_back(std::move(gp));
+    }
     void start_stream(std::vector<Src> srcs, bool staged, bool mono = false) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
+        g.join = scheduled_;
         g.srcs = std::move(srcs);
         g.filt = g.srcs.front().filt;  // (one filter per stream: start_generation / late_join group by it)
         g.staged = staged;
@@ -1540,8 +1932,9 @@ private:
         check(rh_resample_out_frames(staged ? g.crow : cap_frames_, from, rate_, cfg.channels, 0, &m), "rh_resample_out_frames");
         out_cap_frames_ = std::max<std::uint64_t>(out_cap_frames_, m + 64);
         for (auto &other : gens_)  // rates differ between generations: every queue holds two of the largest blocks
-            for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * 2, (other->head + other->fill) * 2);
-        for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * 2);
+            for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * qch_, (other->head + other->fill) * qch_);
+        for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * qch_);
+        g.track = staged || from == rate_;  // the sources' streams reach the mix sample for sample: a stream that ends inside a frame is seen
         last_join_ = scheduled_;
         gens_.push_back(std::move(gp));
     }
@@ -1570,14 +1963,55 @@ private:
         g.pd_prev = g.pd_prev < 0 && g.dnext == 0 ? -1 : g.pd;
         g.pd = g.dnext;
         g.dnext = (g.dnext + 1) % 3;
-        if (g.staged) pull_block_staged(g);
+        if (g.wide) {}  // (the chains pull their own upstreams, a block ahead)
+        else if (g.staged) pull_block_staged(g);
         else pull_block_direct(g);
         g.pulled = true;
     }
     void issue_block(Gen &g) {
         g.pulled = false;
-        if (g.staged) issue_block_staged(g);
+        const std::uint64_t before = g.fill;
+        if (g.wide) issue_block_wide(g);
+        else if (g.staged) issue_block_staged(g);
         else issue_block_direct(g);
+        g.emitted += g.fill - before;
+        if (g.done) g.finish();
+    }
+    /// A block of a wide generation: up to block_frames frames of every chain, device to device into a row each, and the ordered sum
+    /// of the rows (mixer.rs:185-198) behind what the queue holds.  A chain that ends inside a frame has its last frame completed with
+    /// +0.0 (which leaves the sums as they are); Gen::finish remembers how far rodio's samples reach.
+    void issue_block_wide(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        const std::size_t want = opt_.block_frames * qch_, roww = ((want + 3) & ~std::size_t(3)) + 4 * ((qch_ + 3) / 4);
+        g.drow.reset(S * roww);
+        std::vector<const float *> ptrs(S);
+        std::vector<std::uint64_t> start(S, 0), len(S, 0);
+        std::uint64_t most = 0;
+        bool all_ended = true;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            float *row = g.drow.get() + i * roww;
+            ptrs[i] = row;
+            if (!x.ended) {
+                std::size_t got = x.dev->read_device(row, want, stream_);
+                x.total_s += got;
+                if (got < want) {
+                    x.ended = true;
+                    if (const std::size_t cut = got % qch_) {
+                        check(rh_memset(row + got, 0, (qch_ - cut) * sizeof(float), stream_), "rh_memset");
+                        got += qch_ - cut;
+                    }
+                }
+                len[i] = got;
+                most = std::max<std::uint64_t>(most, got);
+            }
+            all_ended = all_ended && x.ended;
+        }
+        const std::uint64_t out = most / qch_;
+        if (out > out_cap_frames_ * 2 - g.fill - g.head) throw Error(RH_ERR_CAPACITY, "GpuMixer: the queue of a wide generation");
+        if (out) check(rh_mix_sum(g.queue_end(), (std::size_t)out * qch_, ptrs.data(), start.data(), len.data(), (std::uint32_t)S, stream_), "rh_mix_sum");
+        g.fill += out;
+        g.done = all_ended;
     }
     template <class F>
     void pull_sources(std::size_t frames, std::size_t n, F &&fn) {
@@ -1604,7 +2038,7 @@ private:
             std::uint32_t rate = 0;
             if (!x.ended && !x.reader.peek(ch, rate)) x.ended = true;  // the chain rodio would build now is empty
             if (x.ended) continue;
-            const std::uint64_t want = g.target > x.have ? g.target - x.have : 0;
+            const std::uint64_t have = x.have_s / 2, want = g.target > have ? g.target - have : 0;
             const std::uint64_t in_frames = want * rate / rate_ + 8;
             row_cap[i] = x.plan.held_samples() + (std::size_t)in_frames * ch;
             total += (row_cap[i] + 3) & ~std::size_t(3);
@@ -1619,18 +2053,18 @@ private:
         const int oc = g.ccur, nc = g.ccur ^ 1;
         for (std::size_t i = 0; i < S; ++i) {  // what the last block left over: to the front of the other row set
             Src &x = g.srcs[i];
-            if (!x.have) continue;
+            if (!x.have_s) continue;
             rh_uniform_seg sg;
             std::memset(&sg, 0, sizeof sg);
-            sg.src = g.conv[oc].get() + i * crowf + x.off * 2;
+            sg.src = g.conv[oc].get() + i * crowf + x.off_s;  // (off_s is even: whole frames were consumed)
             sg.dst = g.conv[nc].get() + i * crowf;
-            sg.src_frames = sg.m1 = x.have;
+            sg.src_frames = sg.m1 = (x.have_s + 1) / 2;      // (an odd sample count: the sample behind the last one rides along and is overwritten)
             sg.span_frames = UINT64_MAX;
             sg.from_rate = sg.to_rate = rate_;
             sg.from_ch = sg.to_ch = 2;
             sg.gain = 1.0f;
             table.push_back(sg);
-            g.pmax_out = std::max(g.pmax_out, x.have);
+            g.pmax_out = std::max(g.pmax_out, (x.have_s + 1) / 2);
         }
         // 2. pull and plan (one source per thread at a time; the segments join the table in source order)
         std::vector<std::vector<rh_uniform_seg>> planned(S);
@@ -1649,10 +2083,11 @@ private:
                     x.ended = true;
                     break;
                 }
-                const std::uint64_t now = x.have + x.plan.out_frames();
+                const std::uint64_t now = (x.have_s + x.plan.out_samples() + 1) / 2;
                 if (now >= g.target) break;
                 std::uint64_t need = 0, most = 0;
-                x.plan.budget(rate, x.reader.opens_next(), g.target - now, g.crow - now, need, most);
+                const std::uint64_t slack = detail::UniformPlanner::close_slack_frames(rate, rate_);  // what the span's end may add
+                x.plan.budget(rate, x.reader.opens_next(), g.target - now, g.crow > now + slack ? g.crow - now - slack : 0, need, most);
                 const std::uint64_t n = std::min<std::uint64_t>(std::min(need, most), (row_cap[i] - fill) / ch);
                 if (!n) break;
                 detail::Piece pc;
@@ -1672,12 +2107,13 @@ private:
             for (const detail::UniformPlanner::Seg &sg : segs) {
                 rh_uniform_seg t = sg.g;
                 t.src = din.get() + row_off[i] + sg.src_off;
-                t.dst = g.conv[nc].get() + i * crowf + (x.have + sg.dst_off) * 2;
+                t.dst = g.conv[nc].get() + i * crowf + x.have_s + sg.dst_off;
                 t.gain = x.gain;
                 planned[i].push_back(t);
             }
-            x.have += x.plan.out_frames();
-            if (x.have > g.crow) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
+            x.have_s += x.plan.out_samples();
+            x.total_s += x.plan.out_samples();
+            if (x.have_s + 1 > g.crow * 2) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
         });
         for (std::size_t i = 0; i < S; ++i)
             for (const rh_uniform_seg &t : planned[i]) {
@@ -1712,9 +2148,16 @@ private:
         bool all_ended = true;
         for (std::size_t i = 0; i < S; ++i) {
             Src &x = g.srcs[i];
-            x.off = 0;
+            x.off_s = 0;
             ptrs[i] = g.conv[nc].get() + i * crowf;
-            avail[i] = x.have;
+            if (x.ended && (x.have_s & 1)) {
+                // the source's stream ends inside a frame: rodio's mixer adds its last sample and, at the next one, finds the source gone
+                // (mixer.rs:185-198).  Adding +0.0 for the missing sample leaves the sum as it is -- through a filter it would not.
+                if (g.filt.kind >= 0) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a filtered source of 1, 2, 4 or 8 channels whose stream ends inside a frame (its spans do not hold whole frames: source/mod.rs:196-200)");
+                check(rh_memset(g.conv[nc].get() + i * crowf + x.have_s, 0, sizeof(float), stream_), "rh_memset");
+                x.have_s += 1;
+            }
+            avail[i] = x.have_s / 2;
             ended[i] = x.ended ? 1 : 0;
             all_ended = all_ended && x.ended;
         }
@@ -1723,9 +2166,9 @@ private:
               "rh_rlm_stream_block_v");
         g.fill += out;
         for (Src &x : g.srcs) {
-            const std::uint64_t d = std::min(consumed, x.have);
-            x.off = d;
-            x.have -= d;
+            const std::uint64_t d = std::min(consumed, x.have_s / 2);
+            x.off_s = d * 2;
+            x.have_s -= d * 2;
         }
         g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }
@@ -1765,9 +2208,10 @@ private:
             if (!x.ended) {
                 const std::size_t want = opt_.block_frames * ch;
                 std::size_t got = x.up->read(row + have, want);  // straight into the staging block
+                x.ended = got < want;
                 got -= got % ch;  // sources end on frame boundaries (source/mod.rs:169-178)
                 have += got;
-                x.ended = got < want;
+                x.total_s += got / ch * 2;
             }
             g.pptrs[i] = din.get() + i * row_;
             g.pavail[i] = have / ch;
@@ -1792,9 +2236,13 @@ private:
             if (!x.ended) {
                 const std::size_t want = opt_.block_frames * 2;
                 std::size_t got = x.dev->read_device(row + have, want, copy_stream_);
-                got -= got % 2;
-                have += got;
                 x.ended = got < want;
+                x.total_s += got;
+                if (got % 2) {  // the chain's stream ends inside a frame (want is whole frames): its last sample is mixed, the missing one is +0.0
+                    check(rh_memset(row + have + got, 0, sizeof(float), copy_stream_), "rh_memset");
+                    got += 1;
+                }
+                have += got;
             }
             g.pptrs[i] = row;
             g.pavail[i] = have / 2;
@@ -1856,13 +2304,15 @@ private:
         const int li = flight ? ci ^ 1 : ci;                               // the last block that is scheduled
         const std::uint64_t sched_end = slot_base_[li] + slot_frames_[li];
         check(rh_stream_synchronize(stream_), "rh_stream_synchronize");   // the blocks about to be patched have been produced
-        const bool staged = !item.dev && spanned(item);
-        if (!staged) make_direct(item);
+        const bool staged = !wide() && !item.dev && spanned(item);
+        if (!staged && !wide()) make_direct(item);
         std::vector<Src> one;
         one.push_back(std::move(item));
-        start_stream(std::move(one), staged);
+        if (wide()) start_stream_wide(std::move(one), J);
+        else start_stream(std::move(one), staged);
         last_join_ = J;
         Gen &g = *gens_.back();
+        g.join = J;
         const std::uint64_t need = sched_end > J ? sched_end - J : 0;
         while (g.fill < need && !g.done) {
             run_block(g, cur());
@@ -1874,16 +2324,16 @@ private:
             const std::uint64_t b0 = slot_base_[si], b1 = b0 + slot_frames_[si];
             const std::uint64_t lo = std::max(J, b0), hi = std::min(b1, J + g.fill);
             if (hi <= lo) continue;
-            const float *ptrs[2] = {dkeep_[si].get(), g.queue() + (lo - J) * 2};
-            const std::uint64_t start[2] = {0, (lo - b0) * 2}, len[2] = {slot_frames_[si] * 2, (hi - lo) * 2};
-            dmix_.reset(out_cap_frames_ * 2 * 2);
-            check(rh_mix_sum(dmix_.get(), slot_frames_[si] * 2, ptrs, start, len, 2, stream_), "rh_mix_sum");
-            check(rh_memcpy_d2d(dkeep_[si].get(), dmix_.get(), slot_frames_[si] * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            const float *ptrs[2] = {dkeep_[si].get(), g.queue() + (lo - J) * qch_};
+            const std::uint64_t start[2] = {0, (lo - b0) * qch_}, len[2] = {slot_frames_[si] * qch_, (hi - lo) * qch_};
+            dmix_.reset(out_cap_frames_ * 2 * qch_);
+            check(rh_mix_sum(dmix_.get(), slot_frames_[si] * qch_, ptrs, start, len, 2, stream_), "rh_mix_sum");
+            check(rh_memcpy_d2d(dkeep_[si].get(), dmix_.get(), slot_frames_[si] * qch_ * sizeof(float), stream_), "rh_memcpy_d2d");
             send_block(sl, dkeep_[si].get(), slot_frames_[si]);
         }
         {  // the newcomer's queue moves on to the frame the next block starts at
             const std::uint64_t used = std::min(g.fill, need), rem = g.fill - used, pad = rem & 1;
-            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * 2, g.queue() + used * 2, rem * 2 * sizeof(float), stream_), "rh_memcpy_d2d");
+            if (rem) check(rh_memcpy_d2d(g.q[g.cur ^ 1].get() + pad * qch_, g.queue() + used * qch_, rem * qch_ * sizeof(float), stream_), "rh_memcpy_d2d");
             g.cur ^= 1;
             g.head = pad;
             g.fill = rem;
@@ -1905,6 +2355,7 @@ private:
     std::uint32_t rate_;
     Options opt_;
     std::uint16_t out_ch_ = 2;       // mixer::mixer(channels, ..)
+    std::size_t qch_ = 2;            // channels of the frames the mix is formed in: 2 (the fused kernel's), or the mixer's own when it has more
     bool device_chains_ = false;     // a chain hands its blocks over on the device: its scan kernels' failure word is read per block
     std::unique_ptr<Reaper> reaper_;
     ChainStats retired_chains_;

@@ -77,6 +77,74 @@ struct VecSource : Source {
     uint32_t sample_rate() const override { return rate; }
 };
 
+// A source made of PARTS, each a span with its own format (what a queue of sounds of different formats looks like to the adapters
+// behind it: src/queue.rs:140-172 forwards the current sound's span length, channels and rate).  current_span_len() = Some(len of the
+// current part); the moment a part's last sample has been taken the next part's parameters are the ones reported (source/mod.rs:196-207:
+// "the span's parameters apply to the samples next() is about to return"); Some(0) when everything has been taken (buffer.rs:76-82).
+struct SeqSource : Source {
+    struct Part {
+        std::vector<float> data;
+        uint16_t ch;
+        uint32_t rate;
+    };
+    std::vector<Part> parts;
+    size_t cur = 0, pos = 0;
+    void settle() {
+        while (cur < parts.size() && pos >= parts[cur].data.size()) {
+            if (cur + 1 == parts.size()) break;
+            ++cur;
+            pos = 0;
+        }
+    }
+    bool next(float &out) override {
+        settle();
+        if (cur >= parts.size() || pos >= parts[cur].data.size()) return false;
+        out = parts[cur].data[pos++];
+        settle();
+        return true;
+    }
+    long current_span_len() const override {
+        if (cur >= parts.size() || pos >= parts[cur].data.size()) return 0;
+        return (long)parts[cur].data.size();
+    }
+    uint16_t channels() const override { return parts.empty() ? 1 : parts[cur < parts.size() ? cur : parts.size() - 1].ch; }
+    uint32_t sample_rate() const override { return parts.empty() ? 1 : parts[cur < parts.size() ? cur : parts.size() - 1].rate; }
+};
+
+// src/source/span.rs:34-121 -- where an adapter learns that its input's parameters changed.
+struct SpanTracker {
+    size_t samples_counted = 0;
+    long cached_span_len = -1;  // None: "seek mode" -- the parameters are compared at every sample (span.rs:17-22); new() starts there (:55-62)
+    uint32_t last_rate;
+    uint16_t last_ch;
+    SpanTracker(uint32_t rate, uint16_t ch) : last_rate(rate), last_ch(ch) {}
+    struct Detection {
+        bool at_span_boundary, parameters_changed;
+    };
+    Detection advance(const Source &src) {  // span.rs:66-101
+        samples_counted += 1;
+        const long input_span_len = src.current_span_len();
+        bool parameters_changed = false, at_span_boundary = false;
+        if (input_span_len >= 0) {  // (None: parameters are stable by contract)
+            const bool counting = cached_span_len >= 0;
+            const bool known_boundary = counting && samples_counted >= (size_t)cached_span_len;
+            if (!counting || known_boundary) {
+                const uint16_t c = src.channels();
+                const uint32_t r = src.sample_rate();
+                parameters_changed = c != last_ch || r != last_rate;
+                last_ch = c;
+                last_rate = r;
+            }
+            at_span_boundary = counting ? known_boundary : parameters_changed;
+        }
+        if (at_span_boundary) {
+            samples_counted = 0;
+            cached_span_len = input_span_len;
+        }
+        return Detection{at_span_boundary, parameters_changed};
+    }
+};
+
 // src/math.rs:23-26
 inline float lerp(float first, float second, uint32_t numerator, uint32_t denominator) {
     return first + (second - first) * (float)numerator / (float)denominator;
@@ -510,15 +578,30 @@ struct TakeDuration : Source {
 // ----------------------------------------------------------- BltFilter ----
 // src/source/blt.rs:502-544 (to_applier), :558-560 (apply), :397-410/:431-451/
 // :472-492 (Mono/Stereo/Multi all reduce to per-channel state indexed by
-// position mod C).  Span-change re-coefficienting (:119-141) is not restated:
-// every source used with the oracle has constant parameters.
+// position mod C).  At a span boundary where the input's parameters changed the applier is re-made for the new sample rate
+// (:119-141: `recreate_applier`; the state and the channel layout stay -- the branch that would rebuild the filter for a new channel
+// count compares the count with itself, :128, and is never taken).
 struct BltFilter : Source {
     Source *input;
     float b0, b1, b2, a1, a2;
     std::vector<float> x1, x2, y1, y2;
     size_t position = 0;
-    BltFilter(Source *in, bool high_pass, uint32_t freq, float q) : input(in) {
-        uint32_t fs = in->sample_rate();
+    bool high_pass_;
+    uint32_t freq_;
+    float q_;
+    SpanTracker span;
+    BltFilter(Source *in, bool high_pass, uint32_t freq, float q) : input(in), high_pass_(high_pass), freq_(freq), q_(q), span(in->sample_rate(), in->channels()) {
+        to_applier(in->sample_rate());
+        size_t n = in->channels();
+        x1.assign(n, 0.f);
+        x2.assign(n, 0.f);
+        y1.assign(n, 0.f);
+        y2.assign(n, 0.f);
+    }
+    void to_applier(uint32_t fs) {  // :502-544
+        const bool high_pass = high_pass_;
+        const uint32_t freq = freq_;
+        const float q = q_;
         float w0 = 2.0f * PI_F * (float)freq / (float)fs;
         float rb0, rb1, rb2, ra0, ra1, ra2;
         if (!high_pass) {  // :504-521
@@ -544,11 +627,6 @@ struct BltFilter : Source {
         b2 = rb2 / ra0;
         a1 = ra1 / ra0;
         a2 = ra2 / ra0;
-        size_t n = in->channels();
-        x1.assign(n, 0.f);
-        x2.assign(n, 0.f);
-        y1.assign(n, 0.f);
-        y2.assign(n, 0.f);
     }
     ~BltFilter() override { delete input; }
     bool next(float &out) override {
@@ -563,6 +641,9 @@ struct BltFilter : Source {
         y1[c] = result;
         x1[c] = sample;
         out = result;
+        // :122-138 -- AFTER the sample: the tracker sees the parameters of the sample the input returns next
+        const SpanTracker::Detection d = span.advance(*input);
+        if (d.at_span_boundary && d.parameters_changed) to_applier(input->sample_rate());
         return true;
     }
     long current_span_len() const override { return input->current_span_len(); }
@@ -706,7 +787,8 @@ struct Limit : Source {
     float threshold, knee_width, inv_knee_8, attack, release;
     std::vector<float> integrators, peaks;
     size_t position = 0;
-    Limit(Source *in, float thr, float knee, uint64_t attack_ns, uint64_t release_ns) : input(in) {
+    SpanTracker span;
+    Limit(Source *in, float thr, float knee, uint64_t attack_ns, uint64_t release_ns) : input(in), span(in->sample_rate(), in->channels()) {
         uint32_t sr = in->sample_rate();
         attack = duration_to_coefficient(attack_ns, sr);
         release = duration_to_coefficient(release_ns, sr);
@@ -744,6 +826,14 @@ struct Limit : Source {
             for (float p : peaks) max_peak = fmaxf(max_peak, p);
         }
         out = sample * db_to_linear(-max_peak);
+        // limit.rs:652-695 -- after the sample: a new channel count rebuilds the limiter's state (zero integrators and peaks, position 0); the
+        // coefficients stay the ones of the rate the limiter was built for (LimitBase is carried over)
+        const SpanTracker::Detection d = span.advance(*input);
+        if (d.at_span_boundary && d.parameters_changed && input->channels() != integrators.size()) {
+            integrators.assign(input->channels(), 0.f);
+            peaks.assign(input->channels(), 0.f);
+            position = 0;
+        }
         return true;
     }
     long current_span_len() const override { return input->current_span_len(); }
@@ -763,17 +853,32 @@ struct Agc : Source {
     std::vector<float> buffer;
     float sum = 0.0f;
     size_t index = 0;
+    uint64_t attack_ns_, release_ns_;
+    SpanTracker span;
     Agc(Source *in, float target, uint64_t attack_ns, uint64_t release_ns, float max_gain, float fl)
         : input(in), target_level(target), floor_(fl), absolute_max_gain(max_gain),
-          buffer(RMS_WINDOW_SIZE, 0.0f) {
+          buffer(RMS_WINDOW_SIZE, 0.0f), span(in->sample_rate(), in->channels()) {
         const uint64_t ten_s = 10000000000ull;
         attack_ns = attack_ns < ten_s ? attack_ns : ten_s;
         release_ns = release_ns < ten_s ? release_ns : ten_s;
+        attack_ns_ = attack_ns;
+        release_ns_ = release_ns;
         attack_coeff = duration_to_coefficient(attack_ns, in->sample_rate());
         release_coeff = duration_to_coefficient(release_ns, in->sample_rate());
     }
     ~Agc() override { delete input; }
     bool next(float &out) override {
+        // agc.rs:524-548 -- BEFORE the sample: new parameters re-make the coefficients for the new rate and reset the window, the peak and the gain
+        const SpanTracker::Detection d = span.advance(*input);
+        if (d.at_span_boundary && d.parameters_changed) {
+            attack_coeff = duration_to_coefficient(attack_ns_, input->sample_rate());
+            release_coeff = duration_to_coefficient(release_ns_, input->sample_rate());
+            buffer.assign(RMS_WINDOW_SIZE, 0.0f);
+            sum = 0.0f;
+            index = 0;
+            peak_level = 0.0f;
+            current_gain = 1.0f;
+        }
         float sample;
         if (!input->next(sample)) return false;
         float sample_value = fabsf(sample);
@@ -823,6 +928,16 @@ extern "C" {
 void *orc_vec_source(const float *data, size_t n, int ch, unsigned rate, long span) {
     return new VecSource(data, n, (uint16_t)ch, rate, span);
 }
+// A source of several spans with formats of their own: orc_seq_source() then orc_seq_add() per part, in order.
+void *orc_seq_source(void) { return new SeqSource(); }
+void orc_seq_add(void *seq, const float *data, size_t n, int ch, unsigned rate) {
+    SeqSource::Part p;
+    p.data.assign(data, data + n);
+    p.ch = (uint16_t)ch;
+    p.rate = rate;
+    ((SeqSource *)seq)->parts.push_back(std::move(p));
+}
+long orc_current_span_len(void *src) { return ((Source *)src)->current_span_len(); }
 void *orc_sample_rate_converter(void *in, unsigned from, unsigned to, int ch) {
     return new SampleRateConverter((Source *)in, from, to, (uint16_t)ch, true);
 }

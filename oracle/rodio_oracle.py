@@ -35,6 +35,9 @@ def _load():
     vp, f32p = C.c_void_p, C.POINTER(C.c_float)
     sigs = {
         "orc_vec_source": (vp, [f32p, C.c_size_t, C.c_int, C.c_uint, C.c_long]),
+        "orc_seq_source": (vp, []),
+        "orc_seq_add": (None, [vp, f32p, C.c_size_t, C.c_int, C.c_uint]),
+        "orc_current_span_len": (C.c_long, [vp]),
         "orc_sample_rate_converter": (vp, [vp, C.c_uint, C.c_uint, C.c_int]),
         "orc_channel_count_converter": (vp, [vp, C.c_int, C.c_int]),
         "orc_uniform": (vp, [vp, C.c_int, C.c_uint]),
@@ -141,6 +144,10 @@ class Source:
     def sample_rate(self) -> int:
         return _lib.orc_sample_rate(self._p)
 
+    def current_span_len(self):
+        v = _lib.orc_current_span_len(self._p)
+        return None if v < 0 else v
+
     # -- rodio's builder methods (src/source/mod.rs:255-731) ------------------
     def amplify(self, factor):
         return Source(_lib.orc_amplify(self._take(), factor))
@@ -203,6 +210,16 @@ def SpanSource(samples, channels, sample_rate, span_len) -> Source:
     """A source reporting a constant current_span_len() == Some(span_len) (decoder packets)."""
     a = np.ascontiguousarray(samples, dtype=np.float32)
     return Source(_lib.orc_vec_source(_f32p(a), a.size, channels, sample_rate, int(span_len)))
+
+
+def SeqSource(parts) -> Source:
+    """A source of several spans, each with a format of its own: parts = [(samples, channels, sample_rate), ...] (what a queue of sounds
+    of different formats looks like to the adapters behind it, src/queue.rs:140-172).  current_span_len() = Some(len of the current part)."""
+    p = _lib.orc_seq_source()
+    for samples, channels, sample_rate in parts:
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        _lib.orc_seq_add(p, _f32p(a), a.size, channels, sample_rate)
+    return Source(p)
 
 
 def SampleRateConverter(inp: Source, from_rate, to_rate, channels) -> Source:

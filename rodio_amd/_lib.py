@@ -121,6 +121,7 @@ SIGNATURES = {
     "rh_resample_linear": (i32, [vp, vp, u64, u32, u32, u32, u64, vp]),
     "rh_uniform_span_frames": (i32, [u64, u32, u32, i32, C.POINTER(u64)]),
     "rh_uniform_first_tap": (i32, [u64, u32, u32, C.POINTER(u64)]),
+    "rh_uniform_cut_tail_samples": (i32, [u64, u32, u32, u32, u32, u32, C.POINTER(u64)]),
     "rh_uniform_segments": (i32, [C.POINTER(UniformSeg), u32, vp]),
     "rh_uniform_segments_dev": (i32, [vp, u32, u64, vp]),
     "rh_mix_sum": (i32, [vp, sz, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), u32, vp]),

@@ -76,6 +76,12 @@ def build_host_mirror_test(force: bool, run) -> str:
     if force or _stale(exe, deps):
         run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lrodio_hip",
              "-Wl,-rpath,$ORIGIN/../../rodio_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    # ... and the same driver over tests/cpp/fake_device.cpp (a CPU stand-in for the library: TEST INFRASTRUCTURE, it lets the host logic of the
+    # header run in the `-m "not gpu"` suite; nothing of the product links or loads it)
+    fake_src = os.path.join(root, "tests", "cpp", "fake_device.cpp")
+    fake_exe = os.path.join(root, "tests", "cpp", "host_mirror_test_fake")
+    if force or _stale(fake_exe, [src, fake_src, deps[1], deps[2]]):
+        run([shutil.which("g++") or "g++", "-std=c++17", "-O2", "-ffp-contract=off", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src, fake_src, "-o", fake_exe])
     return exe
 
 

@@ -32,19 +32,73 @@ struct SegTable {
     rh_uniform_seg s[kSegsPerLaunch];
 };
 
+// #m with floor(m*F/T) <= n-2 (both taps of the lerp exist)
+__host__ __device__ inline uint64_t lerp_ready(uint64_t n, uint64_t F, uint64_t T) {
+    if (n == 0) return 0;
+    return (uint64_t)((((unsigned __int128)(n - 1) * T) + F - 1) / F);
+}
+// The tail of a span of q whole frames that ends inside a frame (rodio_hip.h): the output frames m_first .. m_first + k - 1 have their
+// first tap on the last whole frame and lerp towards the cut frame (k may be 0: downsampling can skip that frame, and a span without
+// a whole frame has none); e = 1 when an output lands on the cut frame itself, which then comes out verbatim.
+__host__ __device__ inline void cut_counts(uint64_t q, uint64_t F, uint64_t T, uint64_t &m_first, uint64_t &k, uint64_t &e) {
+    if (F == T) {  // sample_rate.rs:133-136: the converter passes every sample through
+        m_first = q, k = 0, e = 1;
+        return;
+    }
+    m_first = lerp_ready(q, F, T);
+    k = q >= 1 ? lerp_ready(q + 1, F, T) - lerp_ready(q, F, T) : 0;
+    e = lerp_ready(q + 2, F, T) - lerp_ready(q + 1, F, T) >= 1 ? 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) {
+        const uint32_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// One output SAMPLE per lane: sample j of the tail is position j % to_ch of the (j / to_ch)-th group of from_ch converter samples
+// (channels.rs:57-85), and converter sample idx of the tail is channel idx % t of its (idx / t)-th short frame.
+__device__ __forceinline__ void convert_cut_tail(const rh_uniform_seg &g, uint32_t tile) {
+    const uint64_t j0 = g.m0 + (uint64_t)tile * kTile;
+    if (j0 >= g.m1) return;
+    const uint64_t j1 = j0 + kTile < g.m1 ? j0 + kTile : g.m1;
+    const uint32_t gc = gcd_u32(g.from_rate, g.to_rate);
+    const uint32_t F = g.from_rate / gc, T = g.to_rate / gc;
+    const uint32_t fc = g.from_ch, tc = g.to_ch, t = g.reserved;
+    uint64_t mf, k, e;
+    cut_counts(g.span_frames, F, T, mf, k, e);
+    const float *last = g.src;                         // the frame in front of the cut (read only when k > 0: then it is there)
+    const float *p = g.src + g.src_frames * fc;        // the cut frame's t samples
+    const float Tf = (float)T;
+    for (uint64_t j = j0 + threadIdx.x; j < j1; j += kBlock) {
+        const uint64_t grp = j / tc;
+        const uint32_t pos = (uint32_t)(j - grp * tc);
+        float v = 0.0f;  // channels the source does not have (a mono source cannot be cut: channels.rs:64-73's repeat never applies)
+        if (pos < fc) {
+            const uint64_t idx = grp * fc + pos, r = idx / t;
+            const uint32_t c = (uint32_t)(idx - r * t);
+            const float pv = p[c] * g.gain;
+            v = pv;
+            if (r < k) {
+                const unsigned __int128 pp = (unsigned __int128)(mf + r) * F;
+                const uint32_t num = (uint32_t)(pp % T);
+                const float av = last[c] * g.gain;
+                v = av + (pv - av) * (float)num / Tf;  // math.rs:25
+            }
+        }
+        g.dst[j - g.m0] = v;
+    }
+}
+
 __device__ __forceinline__ void convert_frames(const rh_uniform_seg &g, uint32_t tile) {
+    if (g.reserved) return convert_cut_tail(g, tile);
     const uint64_t mt0 = g.m0 + (uint64_t)tile * kTile;
     if (mt0 >= g.m1) return;
     const uint64_t mt1 = mt0 + kTile < g.m1 ? mt0 + kTile : g.m1;
-    const uint32_t gc = [&] {  // gcd of two u32 by Euclid: a handful of scalar-ish iterations, the same in every lane
-        uint32_t a = g.from_rate, b = g.to_rate;
-        while (b) {
-            const uint32_t t = a % b;
-            a = b;
-            b = t;
-        }
-        return a;
-    }();
+    const uint32_t gc = gcd_u32(g.from_rate, g.to_rate);  // a handful of scalar-ish iterations, the same in every lane
     const uint32_t F = g.from_rate / gc, T = g.to_rate / gc;
     const uint32_t fc = g.from_ch, tc = g.to_ch;
     const uint32_t nc = fc < tc ? fc : tc;  // channels that carry input
@@ -96,12 +150,6 @@ __global__ __launch_bounds__(kBlock) void k_uniform_segs_dev(const rh_uniform_se
     convert_frames(g, blockIdx.x);
 }
 
-// #m with floor(m*F/T) <= n-2 (both taps of the lerp exist)
-uint64_t lerp_ready(uint64_t n, uint64_t F, uint64_t T) {
-    if (n == 0) return 0;
-    return (uint64_t)((((unsigned __int128)(n - 1) * T) + F - 1) / F);
-}
-
 }  // namespace
 
 extern "C" {
@@ -130,10 +178,36 @@ rh_status rh_uniform_first_tap(uint64_t out_frame, uint32_t from_rate, uint32_t 
     return RH_OK;
 }
 
+rh_status rh_uniform_cut_tail_samples(uint64_t span_whole_frames, uint32_t tail_samples, uint32_t from_rate, uint32_t to_rate, uint32_t from_ch, uint32_t to_ch, uint64_t *out_samples) {
+    if (!out_samples || from_rate == 0 || to_rate == 0 || from_ch == 0 || to_ch == 0 || tail_samples == 0 || tail_samples >= from_ch) return RH_ERR_INVALID;
+    const uint32_t gc = std::gcd(from_rate, to_rate);
+    const uint64_t F = from_rate / gc, T = to_rate / gc;
+    if (F * T > 0xffffffffull) return RH_ERR_UNSUPPORTED;
+    uint64_t mf, k, e;
+    cut_counts(span_whole_frames, F, T, mf, k, e);
+    // (k + e) runs of tail_samples converter samples, regrouped by from_ch: every complete group gives an output frame, the rest
+    // the channels it covers (channels.rs:57-85: the None behind the last sample ends the chain)
+    const uint64_t u = (k + e) * tail_samples, groups = u / from_ch, rest = u % from_ch;
+    *out_samples = groups * to_ch + (rest < to_ch ? rest : to_ch);
+    return RH_OK;
+}
+
 static rh_status check_seg(const rh_uniform_seg &g) {
     if (g.from_rate == 0 || g.to_rate == 0 || g.from_ch == 0 || g.to_ch == 0) return RH_ERR_INVALID;  // NonZero in rodio
     if (g.m1 < g.m0) return RH_ERR_INVALID;
     if (g.m1 == g.m0) return RH_OK;
+    if (g.reserved) {  // the tail of a span that ends inside a frame
+        if (!g.src || !g.dst || g.reserved >= g.from_ch || g.src_frames > 1 || g.src_frames > g.span_frames || g.src_frame0 + g.src_frames != g.span_frames) return RH_ERR_INVALID;
+        uint64_t total = 0;
+        const rh_status st = rh_uniform_cut_tail_samples(g.span_frames, g.reserved, g.from_rate, g.to_rate, g.from_ch, g.to_ch, &total);
+        if (st != RH_OK) return st;
+        if (g.m1 > total) return RH_ERR_INVALID;
+        const uint32_t gc = std::gcd(g.from_rate, g.to_rate);
+        uint64_t mf, k, e;
+        cut_counts(g.span_frames, g.from_rate / gc, g.to_rate / gc, mf, k, e);
+        if (k > 0 && g.src_frames != 1) return RH_ERR_INVALID;  // an output lerps towards the cut frame: the frame in front of it must be there
+        return RH_OK;
+    }
     if (!g.src || !g.dst || g.src_frames == 0) return RH_ERR_INVALID;
     const uint32_t gc = std::gcd(g.from_rate, g.to_rate);
     const uint64_t F = g.from_rate / gc, T = g.to_rate / gc;

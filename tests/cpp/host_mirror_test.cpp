@@ -71,6 +71,53 @@ public:
 private:
     std::size_t span_;
 };
+// A source of several spans with formats of their own (the oracle's SeqSource): current_span_len() = Some(len of the current part); the moment
+// a part's last sample has been taken the next part's parameters are the ones reported; Some(0) when everything has been taken.
+class SeqSource : public rh::Source {
+public:
+    struct Part {
+        std::vector<float> data;
+        std::uint16_t ch;
+        std::uint32_t rate;
+    };
+    explicit SeqSource(std::vector<Part> parts) : parts_(std::move(parts)) { settle(); }
+    std::optional<float> next() override {
+        settle();
+        if (cur_ >= parts_.size() || pos_ >= parts_[cur_].data.size()) return std::nullopt;
+        const float v = parts_[cur_].data[pos_++];
+        settle();
+        return v;
+    }
+    std::optional<std::size_t> current_span_len() const override {
+        if (cur_ >= parts_.size() || pos_ >= parts_[cur_].data.size()) return 0;
+        return parts_[cur_].data.size();
+    }
+    std::uint16_t channels() const override { return parts_[std::min(cur_, parts_.size() - 1)].ch; }
+    std::uint32_t sample_rate() const override { return parts_[std::min(cur_, parts_.size() - 1)].rate; }
+
+private:
+    void settle() {
+        while (cur_ < parts_.size() && pos_ >= parts_[cur_].data.size()) {
+            if (cur_ + 1 == parts_.size()) break;
+            ++cur_;
+            pos_ = 0;
+        }
+    }
+    std::vector<Part> parts_;
+    std::size_t cur_ = 0, pos_ = 0;
+};
+// <dir>/seq_<index>.txt ("channels rate" per part, samples in <dir>/seq_<index>_<k>.f32) makes source <index> a SeqSource
+static rh::BoxSource make_seq_source(const std::string &dir, int index) {
+    std::FILE *f = std::fopen((dir + "/seq_" + std::to_string(index) + ".txt").c_str(), "r");
+    if (!f) return nullptr;
+    std::vector<SeqSource::Part> parts;
+    unsigned ch = 0, rate = 0;
+    for (int k = 0; std::fscanf(f, "%u %u", &ch, &rate) == 2; ++k)
+        parts.push_back(SeqSource::Part{read_f32(dir + "/seq_" + std::to_string(index) + "_" + std::to_string(k) + ".f32"), (std::uint16_t)ch, rate});
+    std::fclose(f);
+    if (parts.empty()) throw std::runtime_error("seq source without parts");
+    return std::make_unique<SeqSource>(std::move(parts));
+}
 static rh::BoxSource make_source(std::uint16_t ch, std::uint32_t rate, std::vector<float> data, int index = 0) {
     const char *e = std::getenv("RH_TEST_SOURCE");
     std::string kind = e ? e : "test";
@@ -194,22 +241,27 @@ int main(int argc, char **argv) {
                 std::vector<float> t6(40000);
                 expect(r6.read_piece(t6.data(), 100000, pc) && pc.n == 32768 && pc.tail == 2 && pc.closes && !pc.by_none && t6[32767] == 32767.0f, "the span's cut frame comes with it");
                 expect(r6.read_piece(t6.data(), 100000, pc) && pc.n == 36000 - 32768 && pc.tail == (36000 - 32768) % 6 && pc.closes && pc.by_none && t6[0] == 32768.0f, "the next span starts behind the cut");
-                // what the converters make of it: at the mixer's rate one more output frame (the channels the cut frame covers) ...
+                // what the converters make of it (sample_rate.rs:174-200, channels.rs:57-85): at the mixer's rate the whole frames pass through and the cut
+                // frame gives the output channels its samples cover -- 2 samples of a stereo frame here ...
                 rh::detail::UniformPlanner same(2, 48000);
                 std::vector<rh::detail::UniformPlanner::Seg> segs;
                 same.begin_block();
                 same.add(rh::detail::Piece{32768, true, true, 6, 48000, 2, false}, segs);
-                expect(segs.size() == 1 && segs[0].g.m1 == 5462 && segs[0].g.src_frames == 5462 && same.out_frames() == 5462, "a cut frame at the mixer's rate: one more output frame");
-                // ... and in front of a real rate conversion it is refused
-                bool threw = false;
-                try {
-                    rh::detail::UniformPlanner other(2, 44100);
-                    other.begin_block();
-                    other.add(rh::detail::Piece{32768, true, true, 6, 48000, 2, false}, segs);
-                } catch (const rh::Error &e) {
-                    threw = e.status == RH_ERR_UNSUPPORTED;
-                }
-                expect(threw, "a cut frame in front of a rate conversion is refused");
+                expect(segs.size() == 2 && segs[0].g.m1 == 5461 && segs[0].g.reserved == 0 && segs[1].g.reserved == 2 && segs[1].g.m1 == 2 && segs[1].g.span_frames == 5461 && segs[1].dst_off == 5461 * 2 &&
+                           same.out_samples() == 5461 * 2 + 2,
+                       "a cut frame at the mixer's rate: the samples it covers");
+                // ... and in front of a rate conversion the output frames that lerp towards the cut frame are cut to its length, the cut frame follows verbatim,
+                // and the channel converter regroups: 48 -> 44.1 kHz, 5461 whole frames + 2 samples: one output has its first tap on frame 5460 (2 samples),
+                // one lands on the cut frame (2 samples): 4 converter samples = an incomplete group of 6 -> the 2 output channels it covers
+                segs.clear();
+                rh::detail::UniformPlanner other(2, 44100);
+                other.begin_block();
+                other.add(rh::detail::Piece{32768, true, true, 6, 48000, 2, false}, segs);
+                uint64_t whole = 0, tail = 0;
+                expect(rh_uniform_span_frames(5461, 48000, 44100, 0, &whole) == RH_OK && rh_uniform_cut_tail_samples(5461, 2, 48000, 44100, 6, 2, &tail) == RH_OK, "span arithmetic");
+                expect(segs.size() == 2 && segs[0].g.m1 == whole && segs[0].g.span_frames == UINT64_MAX && segs[1].g.reserved == 2 && segs[1].g.m1 == tail && segs[1].g.src_frames == 1 && tail == 2 &&
+                           other.out_samples() == whole * 2 + tail,
+                       "a cut frame in front of a rate conversion");
             }
         }
         {  // NonZero channels / rate (buffer.rs:40: the types cannot hold 0)
@@ -376,6 +428,33 @@ int main(int argc, char **argv) {
                 std::fprintf(jf, "%llu\n", (unsigned long long)mixer.last_join_frame());
                 std::fclose(jf);
             }
+        } else if (mode == "latewide" && argc == 9) {
+            // host_mirror_test latewide <dir> <S0> <S1> <mixer_channels> <to_rate> <block_frames> <pull_first>: like `late`, any layouts (spec.txt: "channels rate gain"), any mixer
+            const int S0 = std::atoi(argv[3]), S1 = std::atoi(argv[4]);
+            const uint16_t mch = (uint16_t)std::atoi(argv[5]);
+            const uint32_t to = (uint32_t)std::atoll(argv[6]);
+            rh::GpuMixer::Options opt;
+            opt.block_frames = (size_t)std::atoll(argv[7]);
+            const size_t pull_first = (size_t)std::atoll(argv[8]);
+            std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
+            if (!sf) throw std::runtime_error("spec.txt");
+            rh::GpuMixer mixer(mch, to, opt);
+            auto add = [&](int i) {
+                unsigned ch = 0, rate = 0;
+                float gain = 1.0f;
+                if (std::fscanf(sf, "%u %u %f", &ch, &rate, &gain) != 3) throw std::runtime_error("spec.txt: short");
+                mixer.add(make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i), gain);
+            };
+            for (int i = 0; i < S0; ++i) add(i);
+            for (size_t k = 0; k < pull_first; ++k) {
+                const std::optional<float> v = mixer.next();
+                if (!v) break;
+                out.push_back(*v);
+            }
+            for (int i = S0; i < S0 + S1; ++i) add(i);
+            std::fclose(sf);
+            const std::vector<float> rest = drain(mixer);
+            out.insert(out.end(), rest.begin(), rest.end());
         } else if (mode == "mixer" && argc == 10) {
             const int S = std::atoi(argv[3]);
             const uint32_t from = (uint32_t)std::atoll(argv[4]), to = (uint32_t)std::atoll(argv[5]);
@@ -410,7 +489,8 @@ int main(int argc, char **argv) {
                 float gain = 1.0f;
                 char ops[1024];
                 if (std::fscanf(sf, "%u %u %f %d %u %1023s", &ch, &rate, &gain, &fkind, &ffreq, ops) != 6) throw std::runtime_error("spec.txt: short");
-                rh::BoxSource src = make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i);
+                rh::BoxSource src = make_seq_source(dir, i);
+                if (!src) src = make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i);
                 const rh::GpuMixer::Filter filt{fkind, ffreq, 0.5f};
                 if (std::string(ops) == "-") {
                     mixer.add(std::move(src), gain, filt);
@@ -442,7 +522,8 @@ int main(int argc, char **argv) {
         } else if (mode == "chain" && argc >= 6) {
             const uint16_t ch = (uint16_t)std::atoi(argv[3]);
             const uint32_t rate = (uint32_t)std::atoll(argv[4]);
-            rh::GpuSource g(make_source(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
+            rh::BoxSource seq = make_seq_source(dir, 0);
+            rh::GpuSource g(seq ? std::move(seq) : make_source(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
             for (int a = 6; a < argc; ++a) apply_op(g, argv[a]);
             std::FILE *meta = std::fopen((dir + "/format.txt").c_str(), "w");
             if (meta) {
@@ -464,7 +545,24 @@ int main(int argc, char **argv) {
                     std::fclose(sk);
                 }
             }
-            {
+            if (std::getenv("RH_TEST_TRACK_FORMAT")) {  // sample by sample, noting what the chain reports in front of every sample (test_gpu_source_follows_a_format_change)
+                std::FILE *ff = std::fopen((dir + "/formats.txt").c_str(), "w");
+                unsigned lc = 0, lr = 0;
+                long long ls = -2;
+                for (;;) {
+                    const unsigned c = g.channels(), r = g.sample_rate();
+                    const std::optional<std::size_t> sp = g.current_span_len();
+                    const long long spv = sp ? (long long)*sp : -1;
+                    if (c != lc || r != lr || spv != ls) {
+                        if (ff) std::fprintf(ff, "%zu %u %u %lld\n", out.size(), c, r, spv);
+                        lc = c, lr = r, ls = spv;
+                    }
+                    const std::optional<float> v = g.next();
+                    if (!v) break;
+                    out.push_back(*v);
+                }
+                if (ff) std::fclose(ff);
+            } else {
                 const std::vector<float> rest = drain(g);
                 out.insert(out.end(), rest.begin(), rest.end());
             }
