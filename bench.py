@@ -38,6 +38,7 @@ The other configurations (single GPU, one JSON line each; evidence for the numbe
     python bench.py --config limit      # limiter, 64 streams x 1 Mi stereo frames (and --sources 2048 --frames 32768)
     python bench.py --config agc        # automatic gain control, same shapes
     python bench.py --config biquad     # stand-alone low_pass: mode 1 (time-parallel) and mode 0 (reference order)
+    python bench.py --config stream     # the headline workload STREAMED in blocks of --block input frames (rh_rlm_stream_block_v on resident rows)
 """
 from __future__ import annotations
 
@@ -814,6 +815,57 @@ def side(args, argv):
                     "sample": f"streams 0..{rows_[-1]} of the workload ({len(rows_)} x {2 * n} samples), one thread, {dt:.2f} s; restated rodio CPU iterator path (not rustc-compiled); host has {os.cpu_count()} logical cores"}
             got = (outs_b["o"] if cfg == "biquad" else out)[rows_].cpu().numpy()
             return _parity(got, np.stack(refs), tol, f"oracle chains of streams 0..{rows_[-1]} of the timed launch"), base
+    elif cfg == "stream":
+        # BLOCK STREAMING: what a drop-in runs.  The cpal callback pulls blocks (src/stream.rs:538-545), GpuMixer answers with rh_rlm_stream_block_v per
+        # block.  Here the device side of that path alone: the headline's 256 sources RESIDENT in HBM, streamed in blocks of --block input frames
+        # through the C ABI -- every block passes `row + consumed so far` (no staging copy: *consumed_frames is a whole number of 16-byte vectors),
+        # the sources run together, so the stream carries their summed state (rh_rlm_stream_keep_history: mix first).  One "step" =
+        # one whole stream = the headline's bytes; parity = the concatenated blocks against the one-pass oracle.
+        from oracle import rodio_oracle as O
+
+        S, N, B = args.sources, args.frames, args.block
+        host = make_sources(S, N, 0, S, 2)
+        data = torch.from_numpy(host).cuda()
+        pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096)
+        pipe.set_exclusive(True)
+        mo = C.c_uint64(0)
+        _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")
+        M = mo.value
+        out = torch.empty(M * 2 + 4096, device="cuda", dtype=torch.float32)
+        nblocks = (N + B - 1) // B
+        base = [data[s_].data_ptr() for s_ in range(S)]
+        plan_cache = {}  # block index -> the ctypes arrays of the call (the stream is deterministic: the same g0 every time)
+        emitted = []
+
+        def one_stream():
+            pipe.stream_begin(keep_history=True)
+            g0 = m = 0
+            for k in range(nblocks):
+                hi = min(N, (k + 1) * B)
+                key = (k, g0)
+                if key not in plan_cache:
+                    plan_cache[key] = ((C.c_void_p * S)(*[b_ + g0 * 8 for b_ in base]), (C.c_uint64 * S)(*([hi - g0] * S)), (C.c_uint8 * S)(*([1 if hi == N else 0] * S)))
+                ptrs, avail, ended = plan_cache[key]
+                o, c = C.c_uint64(0), C.c_uint64(0)
+                _lib.check(lib.rh_rlm_stream_block_v(pipe._h, ptrs, avail, ended, S, C.c_void_p(out.data_ptr() + m * 8), M + 512 - m, C.byref(o), C.byref(c), stream), "rh_rlm_stream_block_v")
+                m += o.value
+                g0 += c.value
+            emitted.append(m)
+
+        alg = 4 * S * N * 2 + 4 * M * 2
+        kernels.append((f"stream_block_v x {nblocks}", one_stream, alg, S * N * 2))
+        workload = (f"block streaming of the headline workload: {S} resident f32 stereo sources x {N} frames in {nblocks} blocks of {B} input frames, 44.1->48 kHz + low_pass({args.freq}) + ordered "
+                    f"Mixer sum per block through rh_rlm_stream_block_v (sources that run together: the summed state, mix first); one step = one whole stream")
+        metric = "Msamples/s through the block-streamed resample+low_pass+mix pipeline"
+        like = ["%k_rlm%", "%k_mix_%"]
+        per_call = True
+
+        def checks():
+            base_, ref = cpu_baseline(host, S, N, 0, args.freq, want_all_cores=False)
+            got = out[: emitted[-1] * 2].cpu().numpy()
+            pr = _parity(got, ref, 1e-5, f"oracle (restated rodio CPU path) in ONE pass over the whole sources; the GPU output is the concatenation of {nblocks} streamed blocks")
+            pr["stream_stats"] = dict(zip(("blocks_on_the_summed_state", "blocks_with_per_source_states", "recoveries"), pipe.stream_stats()))
+            return pr, base_
     else:
         sys.exit(f"unknown --config {cfg}")
 
@@ -872,6 +924,7 @@ def main():
     ap.add_argument("--sources", type=int, default=256, help="sources per GPU (side configs: streams)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
+    ap.add_argument("--block", type=int, default=65536, help="--config stream: input frames per block")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)
     ap.add_argument("--ring-stages", type=int, default=0)
@@ -905,7 +958,7 @@ def main():
             argv.append("--per-source")
         headline(args, argv)
     else:
-        side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames)])
+        side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames), "--block", str(args.block)])
 
 
 if __name__ == "__main__":

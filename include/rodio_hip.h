@@ -422,6 +422,8 @@ rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *ds
  * in dst.  flush != 0 ends the stream (rodio's None): the remaining frames and the verbatim last frame are
  * emitted.  Across blocks the handle carries the converter's position and the summed filter state; the
  * concatenated output equals one rh_rlm_run over the whole stream to f32 rounding (<= 1e-6 in the tests).
+ * *consumed_frames is always a whole number of 16-byte vectors (a multiple of 2 stereo / 4 mono frames): a caller whose sources are
+ * RESIDENT in device memory passes `row + consumed so far` as the next block's pointer -- no staging copy at all (bench.py --config stream).
  * cfg.span_len != 0: every source reports spans of that many samples (a SamplesBuffer longer than 32 768 samples: any
  * span_len >= 32768): the converter restarts every min(span_len, 32768) samples at the same frames of every source
  * (uniform.rs:56-67), each span's last frame verbatim.  Sources with other span patterns: rh_uniform_segments in front of a

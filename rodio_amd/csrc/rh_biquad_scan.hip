@@ -64,13 +64,15 @@ struct BqArgs {
     float BL[4];              // B^L
 };
 
-__device__ __forceinline__ void mat_acc(const float *M, float x1, float x2, float &y1, float &y2) {
+template <class MP>  // (a pointer to four floats in any address space: the matrices of the argument block are read from the constant one)
+__device__ __forceinline__ void mat_acc(MP M, float x1, float x2, float &y1, float &y2) {
     y1 = fma_(M[0], x1, fma_(M[1], x2, y1));
     y2 = fma_(M[2], x1, fma_(M[3], x2, y2));
 }
 
 // Inclusive wave64 scan of 2-vectors under P_l = sum_{k<=l} B^(R*(l-k)) p_k (the fused kernel's, rh_pipeline.hip).
-__device__ __forceinline__ void scan_mat(float &P0, float &P1, const float (&sm)[4][4], const float *b15, const float *b31) {
+template <class SM>
+__device__ __forceinline__ void scan_mat(float &P0, float &P1, SM &sm, const float *b15, const float *b31) {
 #define RH_STEP(K, N)                                                                          \
     {                                                                                          \
         const float q0 = dpp0<kRowShr + N, 0xf>(P0), q1 = dpp0<kRowShr + N, 0xf>(P1);          \
@@ -91,12 +93,22 @@ __device__ __forceinline__ void scan_mat(float &P0, float &P1, const float (&sm)
     }
 }
 
+// The kernel's argument block, read where it lies: in the constant address space (the kernarg segment; it is the kernel's only argument, so it
+// sits at offset 0 of __builtin_amdgcn_kernarg_segment_ptr()).  Read through the by-value parameter, the compiler loads every scalar of it once, in
+// front of the persistent loop, and keeps them all in SGPRs -- more than the file holds beside the loop's own state: 9 % of the kernel's vector
+// instructions were v_readlane / v_writelane moving spilled scalars.  Read through a pointer that is made opaque per tile (and per phase), every
+// phase loads the constants it uses where it uses them (scalar-cache hits) and nothing outlives it.  (rh_limit.hip: the same.)
+typedef const __attribute__((address_space(4))) BqArgs *BqArgsC;
+
 template <int C, int R, int NW, bool FULL>
-__device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *halo, float (*xZ)[2 * C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
+__device__ __forceinline__ void bq_tile(BqArgsC kargs, v4f *lds, const v4f *halo, float (*xZ)[2 * C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
                                         const float (*tab)[64], const uint32_t nf, const float *next_src, v4f *next_buf, v4f *next_halo, bool &dead, const uint32_t ticket_ahead,
                                         uint32_t *ticket_slot) {
     int lane = lane_;
     asm volatile("" : "+v"(lane));  // per-tile address arithmetic is recomputed, not hoisted into registers that live for the whole kernel
+#define RH_ARGS_FRESH() asm volatile("" : "+s"(kargs))
+    RH_ARGS_FRESH();
+#define a (*kargs)
     constexpr int V = C * R / 4;
     constexpr int kPrefixUnroll = C <= 2 ? NW : 1;
     constexpr int HV = (2 * C + 3) / 4;  // vectors that hold the two frames in front of a run
@@ -202,6 +214,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     // return, instead of holding wave 0 -- and with it the workgroup at this barrier -- for a device-scope round trip
     if (threadIdx.x == 0) *ticket_slot = ticket_ahead;
     __syncthreads();  // the waves' aggregates are in LDS
+    RH_ARGS_FRESH();
     float Wp[C][2], ZT[C][2];  // state at this wave's start from the waves in front (zero tile start); the tile's aggregate
 #pragma unroll
     for (int c = 0; c < C; ++c) Wp[c][0] = Wp[c][1] = ZT[c][0] = ZT[c][1] = 0.0f;
@@ -287,7 +300,7 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     }
     // ---- the homogeneous response to the lane's true start state, the result back into the LDS slots ----------------------
     {
-        const float *wM = a.waveM[wave];
+        const auto *wM = a.waveM[wave];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float s0 = Wp[c][0], s1 = Wp[c][1];
@@ -325,10 +338,15 @@ __device__ __forceinline__ void bq_tile(const BqArgs &a, v4f *lds, const v4f *ha
     __builtin_amdgcn_wave_barrier();
     // the NEXT launch's table: this tile's record back to "not yet" (see BqArgs::gran_other)
     if (a.gran_other && wave == 0 && (uint32_t)lane < G) a.gran_other[((uint64_t)stream * a.tiles + tile) * G + lane] = __uint_as_float(kNotYet);
+#undef a
+#undef RH_ARGS_FRESH
 }
 
 template <int C, int R, int NW>
-__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_biquad_scan(const BqArgs a) {
+__global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) void k_biquad_scan(const BqArgs a_by_value) {
+    (void)a_by_value;
+    BqArgsC kargs = (BqArgsC)__builtin_amdgcn_kernarg_segment_ptr();
+#define a (*kargs)
     static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW && R >= 2, "a lane's run is whole 16-byte vectors");
     constexpr int V = C * R / 4;
     constexpr int HV = (2 * C + 3) / 4;
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
         if (nf == L) fetch(src, first, bufs[wave][0], halos[wave][0]);
     }
     while (cur < total) {
+        asm volatile("" : "+s"(kargs));  // (the arguments are re-read where they are used: see BqArgsC)
         uint32_t ticket_ahead = 0;
         if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u) - a.ticket_base;  // stored by bq_tile in front of its barrier
         uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
@@ -401,14 +420,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 4 ? (C * R <= 16 ? 4 : 2) : 1)) voi
             dma_src = nullptr;
         }
         // FULL is the TILE's property, the same for every wave of the workgroup: all of them run one instantiation, its barrier included
-        if (((uint64_t)tile + 1) * (uint64_t)(L * NW) <= a.frames) bq_tile<C, R, NW, true>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
-        else bq_tile<C, R, NW, false>(a, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
+        if (((uint64_t)tile + 1) * (uint64_t)(L * NW) <= a.frames) bq_tile<C, R, NW, true>(kargs, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
+        else bq_tile<C, R, NW, false>(kargs, bufs[wave][n & 1], halos[wave][n & 1], xZ[n & 1], lane, wave, tile, stream, tab, nf, dma_src, nb, nh, dead, ticket_ahead, ticket_slot);
         prev_full = nf == L;
         cur = nxt;
         nxt = s_ticket[(n + 2) % 3];
         ++n;
     }
     wait_vm<0>();
+#undef a
 }
 
 // ---- carried state: {x1,x2,y1,y2} per channel (blt.rs:404-407), the layout of mode 0 ----------------------------------------

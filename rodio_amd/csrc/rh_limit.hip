@@ -92,6 +92,7 @@ struct LimitArgs {
     uint64_t stride;           // floats between streams
     uint32_t n_streams, tiles; // tiles per stream
     float threshold, knee_width, inv_knee_8, attack, release;
+    float one_minus_attack, one_minus_release;  // 1.0f - attack, 1.0f - release in f32, as limit.rs:911,913 compute them (gfx950 has no scalar float ALU: a subtraction in the kernel would be a vector instruction per use)
     float rscan[4], ascan[4];  // r^(R*2^k), a^(R*2^k), k = 0..3 (row_shr 1,2,4,8)
     float rL, aL, rLW, aLW;    // r^L, a^L (one wave's share), r^LW, a^LW (one workgroup tile)
     float rwave[kMaxNW], awave[kMaxNW];  // r^(L*k), a^(L*k): k waves in front inside the workgroup tile
@@ -375,8 +376,12 @@ __device__ __forceinline__ void store_share(float *dst, const v4f *lds, const ui
 // NIO > 0: the workgroup has NIO more waves that do nothing but move samples (k_limit_scan): this function then neither fetches
 // nor stores, and its polls are the only vector-memory loads of its wave -- a poll retires when ITS data arrives, not behind
 // 16 KiB of LDS-DMA and stores in the in-order vmcnt queue.
+// The kernel's argument block, read where it lies: in the constant address space (the kernarg segment; it is the kernel's only argument, so it
+// sits at offset 0 of __builtin_amdgcn_kernarg_segment_ptr()).  See limit_tile for why the kernels do not read their by-value parameter.
+typedef const __attribute__((address_space(4))) LimitArgs *ArgsC;
+
 template <int C, int R, int NW, bool FULL, bool SKEW, int NIO = 0>
-__device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
+__device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
                                            const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
                                            const uint32_t nstream, const float *next_src, v4f *next_buf, const uint32_t ticket_ahead, uint32_t *ticket_slot RH_LP_PARAM) {
     // The lane id is made opaque per tile: everything derived from it (LDS slots, global offsets) is then recomputed here, a
@@ -384,6 +389,15 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     // whole kernel (which spilled).
     int lane = lane_;
     asm volatile("" : "+v"(lane));
+    // The same for the kernel's ARGUMENTS.  They live in the constant address space (the kernarg segment) and cost one scalar load each; read
+    // through `a_in` the compiler loads all ~50 of them once, in front of the persistent loop, and keeps them in SGPRs for the whole kernel --
+    // more than the SGPR file holds beside the loop's own state, so a tenth of the kernel's vector instructions were v_readlane / v_writelane
+    // moving spilled scalars (round 4: "9 % of VALU").  Read through a pointer that is made opaque at the top of every phase, each phase
+    // loads the few constants it uses where it uses them (scalar cache hits, under the phase's first LDS reads) and nothing outlives it.
+    // (Taking the address of the by-value parameter instead would make the compiler copy the 2 KB block to scratch.)
+#define RH_ARGS_FRESH() asm volatile("" : "+s"(kargs))
+    RH_ARGS_FRESH();
+#define a (*kargs)
     constexpr int V = C * R / 4;
     constexpr uint32_t L = 64u * R, LW = L * NW;
     typedef Rec<C> RC;
@@ -394,8 +408,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     // the loops over the waves' aggregates: where registers allow (the variants that run 2 waves per SIMD) all their LDS reads
     // leave together, one latency instead of NW
     constexpr int kPrefixUnroll = (C <= 2 && C * R > 16) ? NW : 1;
-    const float att = a.attack;
-    const T relT = splat<T>(a.release), omrT = splat<T>(1.0f - a.release), attT = splat<T>(a.attack), omaT = splat<T>(1.0f - a.attack);
+#define att (a.attack)
+#define relT splat<T>(a.release)
+#define omrT splat<T>(a.one_minus_release)
+#define attT splat<T>(a.attack)
+#define omaT splat<T>(a.one_minus_attack)
     const GainK gk{LOG10_2 * 20.0f, -a.threshold, 0.5f * a.knee_width, a.knee_width, a.inv_knee_8};
     const uint64_t f0 = (uint64_t)tile * LW + (uint64_t)wave * L;  // first frame of this wave's share; nf = valid frames in it (FULL: L)
     const uint32_t nfl = FULL ? (uint32_t)R : (nf > (uint32_t)lane * R ? (nf - lane * R < (uint32_t)R ? nf - lane * R : R) : 0u);
@@ -448,10 +465,11 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
                 B[p] = Bn;
             }
         }
+    const float rscan[4] = {a.rscan[0], a.rscan[1], a.rscan[2], a.rscan[3]};
     T Ax[N], Bx[N];  // exclusive prefixes inside the wave
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-        scan_maxaff_v<T>(A[p], B[p], a.rscan, r15, r31);
+        scan_maxaff_v<T>(A[p], B[p], rscan, r15, r31);
         Ax[p] = vdpp<kWaveShr1, 0xf>(A[p]);
         Bx[p] = vdpp<kWaveShr1, 0xf>(B[p]);
     }
@@ -462,6 +480,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     const float wI = tab[6][lane], rlane = tab[2][lane];
     RH_LP(1)
     __syncthreads();  // (1) the waves' aggregates are in LDS
+    RH_ARGS_FRESH();
     // prefix over the waves in front of this one, and the workgroup aggregate (uniform; LDS broadcast reads)
     T Ap[N], Bp[N], AT[N], BT[N];
 #pragma unroll
@@ -529,6 +548,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     }
     if (NIO == 0 && !dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(2)
+    RH_ARGS_FRESH();
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
     T I[N], Pz[N];
     const float rwave = a.rwave[wave];
@@ -543,19 +563,22 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int p = 0; p < N; ++p) {
-            const T In = vmax(g[r][p], relT * I[p] + omrT * g[r][p]);  // limit.rs:909-912, the reference's own expression
-            const T Pn = attT * Pz[p] + omaT * In;                      // limit.rs:913 from a zero state
+            // limit.rs:909-913 (P from a zero state), each recurrence step as one multiply and one FMA -- the product r*I (a*P) is not rounded on
+            // its own, which moves a value by at most one ulp where the reference rounds twice; everything around it is compared at 1e-5
+            const T In = vmax(g[r][p], vfma(relT, I[p], omrT * g[r][p]));
+            const T Pn = vfma(attT, Pz[p], omaT * In);
             if (FULL || (uint32_t)r < nfl) {
                 I[p] = In;
                 Pz[p] = Pn;
             }
             g[r][p] = Pz[p];
         }
+    const float ascan[4] = {a.ascan[0], a.ascan[1], a.ascan[2], a.ascan[3]};
     T Px[N];
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         T Pi = Pz[p];
-        scan_lin_v<T>(Pi, a.ascan, a15, a31);
+        scan_lin_v<T>(Pi, ascan, a15, a31);
         Px[p] = vdpp<kWaveShr1, 0xf>(Pi);
         if (lane == 63) {
 #pragma unroll
@@ -568,6 +591,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     if (threadIdx.x == 0) *ticket_slot = ticket_ahead;
     RH_LP(3)
     __syncthreads();  // (2) the waves' zero-state peak aggregates are in LDS
+    RH_ARGS_FRESH();
     T Pp[N], PT[N];
 #pragma unroll
     for (int p = 0; p < N; ++p) Pp[p] = PT[p] = splat<T>(0.0f);
@@ -653,6 +677,7 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
         for (int c = 0; c < C; ++c) Pin[c] = __builtin_nanf("");
     }
     RH_LP(4)
+    RH_ARGS_FRESH();
     // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----
     T Ps[N];
     float Pcur[C];
@@ -726,6 +751,13 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
     if (a.gran_other && wave == 0 && (uint32_t)lane < G) a.gran_other[((uint64_t)stream * a.tiles + tile) * G + lane] = __uint_as_float(kNotYet);
     RH_LP(6)
 }
+#undef a
+#undef att
+#undef relT
+#undef omrT
+#undef attT
+#undef omaT
+#undef RH_ARGS_FRESH
 
 // NIO = 0: every wave fetches (LDS-DMA, a tile ahead) and stores its own share.  NIO > 0: the workgroup has NIO I/O waves behind
 // its NW computing waves; they own the samples' way in and out, the computing waves touch vector memory for their hand-offs only.
@@ -742,7 +774,10 @@ __device__ __forceinline__ void limit_tile(const LimitArgs &a, v4f *lds, float (
 template <int C, int R, int NW, bool SKEW, int NIO = 0>
 // (occupancy bound: 4 workgroups per CU where the registers allow it without a spill -- 4 channels x 4 frames do not: a spill is a
 // vector-memory operation of the compiler's own inside the counted waits of the LDS-DMA; tests/test_code_objects.py checks)
-__global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a) {
+__global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C <= 3 ? 4 : 2) : 1)) void k_limit_scan(const LimitArgs a_by_value) {
+    (void)a_by_value;
+    ArgsC kargs = (ArgsC)__builtin_amdgcn_kernarg_segment_ptr();
+#define a (*kargs)
     static_assert((C * R) % 4 == 0 && R <= kMaxR && NW <= kMaxNW, "a lane's run is whole 16-byte vectors");
     static_assert(NIO == 0 || NW % NIO == 0, "every I/O wave moves the same number of shares");
     constexpr int V = C * R / 4;  // 16-byte vectors per lane; a wave's share of a tile is V KiB
@@ -841,8 +876,8 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
                 const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
                 const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
                 __syncthreads();  // B0
-                if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW, NIO>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
-                else limit_tile<C, R, NW, false, SKEW, NIO>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+                if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+                else limit_tile<C, R, NW, false, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
             }
             prev = cur;
             cur = nxt;
@@ -860,6 +895,7 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
         if (nf == L) dma_share<V>(src, bufs[wave][0], lane);
     }
     while (cur < total) {
+        asm volatile("" : "+s"(kargs));  // (the arguments are re-read where they are used: see limit_tile)
         uint32_t ticket_ahead = 0;
         if (threadIdx.x == 0) ticket_ahead = atomicAdd(a.ctl, 1u) - a.ticket_base;  // stored by limit_tile in front of its second barrier
         uint32_t *const ticket_slot = &s_ticket[(n + 2) % 3];
@@ -885,8 +921,8 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
         const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
         v4f *const buf2 = bufs[wave][(n + 1) & 1];
         // FULL is the TILE's property, the same for every wave of the workgroup: all of them run one instantiation, barriers included
-        if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
-        else limit_tile<C, R, NW, false, SKEW>(a, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        else limit_tile<C, R, NW, false, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
         prev_full = nf == L;
         cur = nxt;
         nxt = s_ticket[(n + 2) % 3];  // written before barrier (2) of the tile just done
@@ -898,6 +934,7 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_limit_prof[i], lp_acc[i]);
 #endif
+#undef a
 }
 
 // Everything the launch finds in its scratch, written by ONE kernel of this library in front of it: the control words (ticket
@@ -1025,6 +1062,8 @@ extern "C" rh_status rh_limit(float *dst, const float *src, uint64_t frames, uin
     a.inv_knee_8 = k5[2];
     a.attack = attack;
     a.release = release;
+    a.one_minus_attack = 1.0f - attack;
+    a.one_minus_release = 1.0f - release;
     // every power of the two coefficients the kernel uses (f64, rounded once): ~600 of them, the same for every block of a
     // stream -- a pull shim calls this once per block, so the last set is kept per host thread
     struct Consts {

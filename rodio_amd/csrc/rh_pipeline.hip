@@ -4067,6 +4067,7 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
         const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
         const uint64_t cons = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
         *consumed_frames = cons < avail_frames ? cons : avail_frames;
+        *consumed_frames -= *consumed_frames % (4u / p->cfg.channels);  // whole 16-byte vectors: `row + consumed` is a row the next block can take as it is
         p->st_g0 += *consumed_frames;
     }
     *out_frames = out;
@@ -4297,6 +4298,7 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         // caller drops min(consumed, what it holds) frames of every source.
         const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
         *consumed_frames = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
+        *consumed_frames -= *consumed_frames % (4u / p->cfg.channels);  // whole 16-byte vectors (see rh_rlm_stream_block)
         p->st_g0 += *consumed_frames;
     }
     *out_frames = out;

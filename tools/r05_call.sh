@@ -21,4 +21,19 @@ case "$1" in
     gaps limit k_limit_scan --config limit --steps 13 --warmup 2
     gaps biquad k_biquad_scan --config biquad --steps 13 --warmup 2
     ;;
+2)
+    python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -40 > $E/gputests_2.txt; tail -12 $E/gputests_2.txt
+    for c in limit biquad; do RH_BENCH_NO_PMC=1 python bench.py --config $c --no-cpu-baseline > $E/bench_${c}_a.json 2>/dev/null; python bench.py --config $c > $E/bench_$c.json 2>/dev/null; python bench.py --config $c --sources 2048 --frames 32768 > $E/bench_${c}_2048.json 2>/dev/null; done
+    python bench.py --config stream > $E/bench_stream.json 2> $E/bench_stream.err; tail -3 $E/bench_stream.err
+    RH_BENCH_NO_PMC=1 python bench.py --config stream --block 16384 --no-cpu-baseline > $E/bench_stream_16k.json 2>/dev/null
+    python bench.py > $E/bench_cfg2.json 2> $E/bench_cfg2.err
+    for f in bench_limit_a bench_limit bench_limit_2048 bench_biquad_a bench_biquad bench_biquad_2048 bench_stream bench_stream_16k bench_cfg2; do python - "$E/$f.json" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]
+    r=d['roofline']; print(sys.argv[1].split('/')[-1], 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), 'parity', (d.get('parity') or {}).get('ok'), (d.get('parity') or {}).get('max_abs_err'))
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+    done
+    ;;
 esac
