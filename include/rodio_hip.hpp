@@ -2056,15 +2056,16 @@ private:
             if (!x.have_s) continue;
             rh_uniform_seg sg;
             std::memset(&sg, 0, sizeof sg);
-            sg.src = g.conv[oc].get() + i * crowf + x.off_s;  // (off_s is even: whole frames were consumed)
+            sg.src = g.conv[oc].get() + i * crowf + x.off_s;
             sg.dst = g.conv[nc].get() + i * crowf;
-            sg.src_frames = sg.m1 = (x.have_s + 1) / 2;      // (an odd sample count: the sample behind the last one rides along and is overwritten)
+            sg.src_frames = sg.m1 = x.have_s;  // copied as a MONO stream, sample for sample: the count may be odd, and the sample behind the last one belongs
+                                                // to a segment of this very launch
             sg.span_frames = UINT64_MAX;
             sg.from_rate = sg.to_rate = rate_;
-            sg.from_ch = sg.to_ch = 2;
+            sg.from_ch = sg.to_ch = 1;
             sg.gain = 1.0f;
             table.push_back(sg);
-            g.pmax_out = std::max(g.pmax_out, (x.have_s + 1) / 2);
+            g.pmax_out = std::max(g.pmax_out, x.have_s);
         }
         // 2. pull and plan (one source per thread at a time; the segments join the table in source order)
         std::vector<std::vector<rh_uniform_seg>> planned(S);

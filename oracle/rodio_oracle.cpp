@@ -1088,6 +1088,11 @@ void orc_i64_to_f32(const int64_t *in, float *out, size_t n) { for (size_t i = 0
 void orc_u64_to_f32(const uint64_t *in, float *out, size_t n) {
     for (size_t i = 0; i < n; ++i) { uint64_t s = in[i]; int64_t v = s < 9223372036854775808ull ? (int64_t)s - 9223372036854775807LL - 1 : (int64_t)(s - 9223372036854775808ull); out[i] = (float)v / 9223372036854775808.0f; }
 }
+// the other reading of dasp's i64 / u64 -> f32 (through f64: two roundings); see the header of rodio_amd/csrc/rh_formats.hip
+void orc_i64_to_f32_via_f64(const int64_t *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)((double)in[i] / 9223372036854775808.0); }
+void orc_u64_to_f32_via_f64(const uint64_t *in, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { uint64_t s = in[i]; int64_t v = s < 9223372036854775808ull ? (int64_t)s - 9223372036854775807LL - 1 : (int64_t)(s - 9223372036854775808ull); out[i] = (float)((double)v / 9223372036854775808.0); }
+}
 void orc_f64_to_f32(const double *in, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (float)in[i]; }
 
 // ---- the cfg-2 pipeline as one call, for the CPU baseline of bench.py:

@@ -82,7 +82,7 @@ def _load():
     for name in ("i8_to_f32", "i16_to_f32", "u16_to_f32", "u8_to_f32", "i24_to_f32", "i32_to_f32",
                  "f32_to_i16", "f32_to_i8", "f32_to_i32", "f32_to_u16",
                  "f32_to_u8", "f32_to_i24", "f32_to_u24", "f32_to_u32", "f32_to_i64", "f32_to_u64", "f32_to_f64",
-                 "u24_to_f32", "u32_to_f32", "i64_to_f32", "u64_to_f32", "f64_to_f32"):
+                 "u24_to_f32", "u32_to_f32", "i64_to_f32", "u64_to_f32", "f64_to_f32", "i64_to_f32_via_f64", "u64_to_f32_via_f64"):
         fn = getattr(lib, "orc_" + name)
         fn.restype = None
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -302,6 +302,7 @@ def delay_samples(ns, rate, ch) -> int:
 def convert(name: str, a: np.ndarray) -> np.ndarray:
     """SampleTypeConverter restatement, e.g. convert('i16_to_f32', int16_array)."""
     src_t, dst_t = name.split("_to_")
+    dst_t = dst_t.split("_via_")[0]
     np_t = {"i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i24": np.int32, "u24": np.int32,
             "i32": np.int32, "u32": np.uint32, "i64": np.int64, "u64": np.uint64, "f32": np.float32, "f64": np.float64}
     a = np.ascontiguousarray(a, dtype=np_t[src_t])

@@ -198,7 +198,8 @@ pub struct PlannedSeg { pub src_off: usize, pub dst_off: usize, pub g: RhUniform
 pub struct UniformPlanner {
     to_ch: u16, to_rate: u32,
     span_in: u64, span_m: u64, row_frame0: u64, next_frame0: u64,
-    row_off: usize, pos: usize, held: usize, keep_off: usize, keep_n: usize, out: u64,
+    row_off: usize, pos: usize, held: usize, keep_off: usize, keep_n: usize,
+    out: usize,              // output SAMPLES planned in this block: what comes out is a stream of samples, not of frames (a span that ends inside a frame)
 }
 impl UniformPlanner {
     pub fn new(to_ch: u16, to_rate: u32) -> Self {
@@ -206,7 +207,9 @@ impl UniformPlanner {
     }
     pub fn begin_block(&mut self) { self.pos = self.held; self.row_off = 0; self.out = 0; self.keep_off = 0; self.keep_n = self.held; }
     pub fn held_samples(&self) -> usize { self.held }
-    pub fn out_frames(&self) -> u64 { self.out }
+    pub fn out_samples(&self) -> usize { self.out }
+    /// Output frames a span's end can add beyond what `budget` counts: its verbatim last frame, or what the converters make of a cut frame.
+    pub fn close_slack_frames(rate: u32, to_rate: u32) -> u64 { to_rate as u64 / rate as u64 + 3 }
     pub fn keep_offset(&self) -> usize { self.keep_off }
     pub fn keep_samples(&self) -> usize { self.keep_n }
     fn span_frames(&self, n: u64, rate: u32, complete: bool) -> u64 {
@@ -231,28 +234,35 @@ impl UniformPlanner {
         if p.opens { self.span_in = 0; self.span_m = 0; self.row_off = self.pos; self.row_frame0 = 0; }
         self.span_in += ((p.n - p.tail) / p.ch as usize) as u64;
         self.pos += p.n;
-        if p.closes && p.tail > 0 {
-            // A frame the span's end cuts.  At the mixer's own rate the SampleRateConverter passes through (sample_rate.rs:133-136) and the
-            // ChannelCountConverter behind it emits, for the cut frame, the output channels its samples cover (channels.rs:57-85): a whole
-            // output frame when the cut frame holds at least min(from, to) samples -- one more frame for the segment, of which the kernel
-            // reads just those channels.  The next span starts at the sample behind the cut: its channels are rotated, as in rodio.
-            let nc = (p.ch as usize).min(self.to_ch as usize);
-            if p.rate == self.to_rate && p.tail >= nc { self.span_in += 1; }
-            else if !p.by_none {
-                panic!("{}", RhError { status: RH_ERR_UNSUPPORTED, what: "a span ends inside a frame of a source that is also rate-converted (or whose cut frame is shorter than an output frame): reproduced only at the mixer's own rate" });
-            }
-            // by_none with a short tail: the source ended inside a frame; its last samples are dropped (source/mod.rs:169-178)
-        }
-        let ready = self.span_frames(self.span_in, p.rate, p.closes);
+        // A span that ends inside a frame (uniform.rs:56: `.min(32768)` on 3, 5, 6, 7 channels; a source that returns None inside a frame).
+        // rodio's SampleRateConverter meets a SHORT frame: every output frame that lerps towards it is cut to its length (zip,
+        // sample_rate.rs:174-179), the short frame itself comes out verbatim when an output lands on it (:193-200), and the
+        // ChannelCountConverter behind regroups those runs into frames of `from` samples (channels.rs:57-85) -- reproduced sample for sample
+        // by a segment of its own (`reserved` = the cut frame's samples); the whole frames in front of it convert as the frames of a span
+        // that is still open.  The next span starts at the sample behind the cut, its channels rotated, as in rodio.
+        let cut = p.closes && p.tail > 0;
+        let ready = self.span_frames(self.span_in, p.rate, p.closes && !cut);
+        let seg = |src_frame0: u64, src_frames: u64, m0: u64, m1: u64, span_frames: u64, reserved: u32, to_rate: u32, to_ch: u16| RhUniformSeg {
+            src: ptr::null(), dst: ptr::null_mut(), src_frame0, src_frames, m0, m1, span_frames,
+            from_rate: p.rate, to_rate, from_ch: p.ch as u32, to_ch: to_ch as u32, gain: 1.0, reserved,
+        };
         if ready > self.span_m {
-            let g = RhUniformSeg {
-                src: ptr::null(), dst: ptr::null_mut(), src_frame0: self.row_frame0, src_frames: self.span_in - self.row_frame0,
-                m0: self.span_m, m1: ready, span_frames: if p.closes { self.span_in } else { u64::MAX },
-                from_rate: p.rate, to_rate: self.to_rate, from_ch: p.ch as u32, to_ch: self.to_ch as u32, gain: 1.0, reserved: 0,
-            };
-            segs.push(PlannedSeg { src_off: self.row_off, dst_off: self.out as usize, g });
-            self.out += ready - self.span_m;
+            let g = seg(self.row_frame0, self.span_in - self.row_frame0, self.span_m, ready, if p.closes && !cut { self.span_in } else { u64::MAX }, 0, self.to_rate, self.to_ch);
+            segs.push(PlannedSeg { src_off: self.row_off, dst_off: self.out, g });
+            self.out += (ready - self.span_m) as usize * self.to_ch as usize;
             self.span_m = ready;
+        }
+        if cut {
+            let mut tail_out = 0u64;
+            ck(unsafe { rh_uniform_cut_tail_samples(self.span_in, p.tail as u32, p.rate, self.to_rate, p.ch as u32, self.to_ch as u32, &mut tail_out) }, "rh_uniform_cut_tail_samples");
+            if tail_out > 0 {
+                // the frame in front of the cut is in the row whenever an output lerps towards the cut frame (it is that output's first tap)
+                let have_last = self.span_in >= 1 && self.span_in - 1 >= self.row_frame0;
+                let f0 = if have_last { self.span_in - 1 } else { self.span_in };
+                let g = seg(f0, self.span_in - f0, 0, tail_out, self.span_in, p.tail as u32, self.to_rate, self.to_ch);
+                segs.push(PlannedSeg { src_off: self.row_off + (f0 - self.row_frame0) as usize * p.ch as usize, dst_off: self.out, g });
+                self.out += tail_out as usize;
+            }
         }
         if p.closes {
             self.held = 0; self.keep_off = 0; self.keep_n = 0;

@@ -465,7 +465,10 @@ static void convert_segment(const rh_uniform_seg &g) {
     }
 }
 rh_status rh_uniform_segments(const rh_uniform_seg *segs, uint32_t n, rh_stream) {
-    for (uint32_t k = 0; k < n; ++k) {
+    // On the device the segments of a launch run side by side: a table whose result depends on their order is a bug of the host.  Here they run
+    // LAST TO FIRST, so that a segment that overwrites what an earlier one wrote shows (round 5: the copy of a row's left-over frames took one
+    // sample too many, which belonged to the next segment -- invisible first to last).
+    for (uint32_t k = n; k-- > 0;) {
         const rh_uniform_seg &g = segs[k];
         if (!g.from_rate || !g.to_rate || !g.from_ch || !g.to_ch || g.m1 < g.m0) return RH_ERR_INVALID;
         if (g.m1 > g.m0 && (!g.src || !g.dst)) return RH_ERR_INVALID;

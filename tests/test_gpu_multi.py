@@ -182,3 +182,45 @@ def test_native_rccl_all_reduce_two_ranks():
     for p in procs:
         p.join(timeout=60)
     assert got == [(0, 3.0, 3.0), (1, 3.0, 3.0)]
+
+
+def test_native_comm_with_one_rank_is_the_identity(G):
+    """The C ABI's collective (rh_comm_*: RCCL dlopen'ed, no PyTorch in the data path -- what a Rust host calls) with a communicator of ONE
+    rank: the N > 1 code path of bench.py differs from it by `nranks` only.  All-reduce and reduce-to-root leave the block as it is; on a
+    second stream, ordered by events, like the timed loop's."""
+    import torch
+
+    from rodio_amd.distributed import NativeComm
+
+    comm = NativeComm(0, 1, NativeComm.unique_id())
+    x = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, 1 << 20).astype(np.float32)).cuda()
+    want = x.clone()
+    comm.all_reduce(x)
+    comm.reduce(x, 0)
+    side = torch.cuda.Stream()
+    e = torch.cuda.Event()
+    e.record()
+    side.wait_event(e)
+    comm.all_reduce(x, stream=side)
+    d = torch.cuda.Event()
+    d.record(side)
+    torch.cuda.current_stream().wait_event(d)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    with pytest.raises(Exception):
+        comm.reduce(x, 1)  # no such root
+    comm.close()
+
+
+def test_bench_native_collective_at_one_gpu():
+    """`bench.py --collective native` at --gpus 1: rh_allreduce_sum_f32 in the timed loop (a communicator of one rank), the line names it."""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--collective", "native", "--sources", "32", "--frames", "65536", "--steps", "3", "--warmup", "1", "--no-per-source",
+                        "--no-unscaled", "--no-autotune"], capture_output=True, text=True, timeout=600, env=dict(os.environ, RH_BENCH_NO_PMC="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # ONE JSON line on stdout (RCCL's version banner is silenced)
+    d = json.loads(lines[0])
+    assert "rh_allreduce_sum_f32" in d["config"]["collective"] and d["parity"]["ok"]

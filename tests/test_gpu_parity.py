@@ -340,6 +340,18 @@ def test_device_formats_egress_and_ingress(G, O):
     assert np.array_equal(G.SampleTypeConverter(i64, "i64", "f32"), O.convert("i64_to_f32", i64))
     u64 = i64.view(np.uint64)
     assert np.array_equal(G.SampleTypeConverter(u64, "u64", "f32"), O.convert("u64_to_f32", u64))
+    # dasp_sample is not vendored: whether its i64 -> f32 rounds once (`s as f32 / 2^63`, what ships) or twice (through f64) cannot be checked here.
+    # The two readings differ by one ulp on values such as 2^62 + 2^38 + 1; the second one sits behind RH_DASP_I64_VIA_F64=1.
+    from conftest import knobs
+
+    odd = np.int64([2 ** 62 + 2 ** 38 + 1, -(2 ** 62 + 2 ** 38 + 1), 2 ** 61 + 2 ** 37 + 1])
+    once, twice = O.convert("i64_to_f32", odd), O.convert("i64_to_f32_via_f64", odd)
+    assert not np.array_equal(once, twice)  # the doubt is real
+    assert np.array_equal(G.SampleTypeConverter(odd, "i64", "f32"), once)
+    with knobs(RH_DASP_I64_VIA_F64="1"):
+        assert np.array_equal(G.SampleTypeConverter(odd, "i64", "f32"), twice)
+        assert np.array_equal(G.SampleTypeConverter(i64, "i64", "f32"), O.convert("i64_to_f32_via_f64", i64))
+        assert np.array_equal(G.SampleTypeConverter(u64, "u64", "f32"), O.convert("u64_to_f32_via_f64", u64))
     f64 = np.concatenate([rng.uniform(-2, 2, 100003), [0.1, 1e-50, 1e50, -1e50, np.nan]])
     a, b = G.SampleTypeConverter(f64, "f64", "f32"), O.convert("f64_to_f32", f64)
     assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a[:-1], f64[:-1].astype(np.float32))
