@@ -398,7 +398,7 @@ def headline(args, argv):
 
     if child:
         if rank == 0:
-            print(json.dumps({"child": True, "kernel_ms": kernel_avg_ms, "calls": args.warmup + args.steps}), flush=True)
+            emit({"child": True, "kernel_ms": kernel_avg_ms, "calls": args.warmup + args.steps})
         return
 
     # ---- untimed diagnostics of the N > 1 path: the collective alone, the reduced block against the ranks' partials, the ranks seen --
@@ -671,7 +671,7 @@ def headline(args, argv):
         res["cpu_baseline"] = base
     if parity is not None:
         res["parity"] = parity
-    print(json.dumps(res), flush=True)
+    emit(res)
 
 
 def _timed_oracle(fn, units, what, cores=1):
@@ -902,7 +902,7 @@ def side(args, argv):
         if child:
             break  # the counter passes look at the head kernel only
     if child:
-        print(json.dumps({"child": True, "calls": calls}), flush=True)
+        emit({"child": True, "calls": calls})
         return
     rh.async_status()
     head = rows[0]
@@ -914,13 +914,23 @@ def side(args, argv):
                         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "kernel_ms": head["kernel_ms"]}}
     if not args.no_cpu_baseline and checks is not None:
         res["parity"], res["cpu_baseline"] = checks()
-    print(json.dumps(res), flush=True)
+    emit(res)
+
+
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The one JSON line, on the process's real stdout (see main())."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def main():
-    # RCCL prints a version banner on STDOUT when NCCL_DEBUG=VERSION (which this image exports): the contract is ONE JSON line there
-    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-        os.environ["NCCL_DEBUG"] = "WARN"
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -949,6 +959,12 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         self_spawn(args)  # (does not return)
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner there from C (whatever NCCL_DEBUG says on this image), and other
+    # libraries may: file descriptor 1 is pointed at stderr for the rest of the run and the line goes out through a duplicate of the real one.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     if not torch.cuda.is_available():

@@ -1578,12 +1578,21 @@ __global__ __launch_bounds__(64, (R <= 8 && KV <= 5 ? 3 : 2)) void k_rlm_wave(co
 // prices: S * N * C * 4 bytes in, N * C * 4 out.  (Without a filter the batch stays on the per-source path: that one is
 // bit-exact with rodio's ordered sum of converted samples; the filtered path is compared at 1e-5 either way.)
 // =================================================================================================
+// Short rows (a stream's block: 64 Ki frames are 128 workgroups at one vector per lane, half the chip) are cut the other way as well: gridDim.y
+// GROUPS of sources, group g summing its share of the source list into partial row g (y + g * group_stride, descriptor ydesc[g]); the fused launch
+// behind takes the partial rows as its sources and adds them in order.  One group: the whole list into one row, as before.
 template <int U>
-__global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
-                                                  const uint32_t frames, const uint32_t out_frames, const float *desc_row) {
+__global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ srcs_all, const uint32_t n_sources_all, float *__restrict__ y_all, const uint64_t n_floats, SrcDesc *__restrict__ ydesc_all,
+                                                  const uint32_t frames, const uint32_t out_frames, const float *desc_row_all, const uint64_t group_stride) {
     typedef __attribute__((address_space(4))) const uint64_t cu64;
     typedef __attribute__((address_space(4))) const float cf32;
     typedef RH_GLB const v4f glb_cf4;
+    const uint32_t per_group = (n_sources_all + gridDim.y - 1) / gridDim.y, s_first = blockIdx.y * per_group;
+    const uint32_t n_sources = s_first < n_sources_all ? (n_sources_all - s_first < per_group ? n_sources_all - s_first : per_group) : 0u;
+    const SrcDesc *const srcs = srcs_all + s_first;
+    float *const y = y_all + (uint64_t)blockIdx.y * group_stride;
+    SrcDesc *const ydesc = ydesc_all + blockIdx.y;
+    const float *const desc_row = desc_row_all + (uint64_t)blockIdx.y * group_stride;
     cu64 *const desc = (cu64 *)(uintptr_t)srcs;
     cf32 *const dgain = (cf32 *)(uintptr_t)srcs;
     const uint64_t nvec = n_floats / 4;
@@ -3760,17 +3769,8 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     if (pre || mix_first_applies(p, pl, count, sa.gran_cols != 0, batch_streams != 0)) {
         const uint64_t n_floats = (uint64_t)p->eq_frames * p->cfg.channels;
         const size_t row = (size_t)(((sa.mode ? (uint64_t)p->cfg.max_in_frames * p->cfg.channels : n_floats) + 3) & ~3ull);  // a stream: sized once, for its largest block
-        const size_t need = row * (pre ? 2 : 1) + 64;  // the mixed row (16-byte vectors) [, the filtered row], then the descriptor on its own 128 bytes
-        if (need > p->mix_floats) {
-            const rh_status w = wait_idle(p);
-            if (w != RH_OK) return w;
-            if (p->d_mix) RH_HIP_TRY(hipFree(p->d_mix));
-            p->d_mix = nullptr;
-            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_mix), need * sizeof(float)));
-            p->mix_floats = need;
-        }
-        SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32));
-        float *const frow = pre ? p->d_mix + row : p->d_mix;  // the row the fused launch reads
+        // how the row is cut: vectors per lane, workgroups, and -- short rows -- groups of sources side by side (see k_mix_rows)
+        constexpr uint32_t kMixGroups = 16;
         const uint64_t nvec = n_floats / 4;
         int U = 4;  // measured (256 x 1 Mi stereo frames): 0.410 / 0.409 / 0.342 ms for 1 / 2 / 4 vectors per lane
         // ... where the row fills the chip.  A stream's block is a short row (64 Ki frames: 128 workgroups at U = 4): fewer vectors per lane, more
@@ -3782,19 +3782,37 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         const uint64_t ring_waves = (nvec + 511) / 512;  // 8 KiB chunks
         int ring = ring_waves >= 2ull * rh::g_num_cus ? 2 : 0;  // ring depth; 0: the vector-load kernel (short rows: more, smaller pieces)
         if (const char *u = rh::knob(rh::K_MIX_U)) ring = atoi(u) >= 10 ? atoi(u) - 10 : 0;  // tuning aid: 12 / 13 = ring of 2 / 3 stages, 1 / 2 / 4 = vector loads
+        // short rows: groups of sources side by side until the launch holds two workgroups per CU (every group keeps at least 8 sources: the
+        // kernel's pipeline of descriptor fetches and loads)
+        uint32_t groups = 1;
+        if (!pre && !ring && !rh::knob(rh::K_MIX_U))
+            while (groups < kMixGroups && (uint64_t)wgs * groups < 2ull * (uint64_t)rh::g_num_cus && count / (groups * 2) >= 8) groups *= 2;
+        // the mixed row (16-byte vectors) [, the filtered row] -- or the groups' partial rows --, then the descriptors (32 bytes each) at the very end
+        const size_t rows_needed = pre ? 2 : (sa.mode ? kMixGroups : groups);  // (a stream: sized once, for whatever its blocks will need)
+        const size_t need = row * rows_needed + 64 + kMixGroups * 8;
+        if (need > p->mix_floats) {
+            const rh_status w = wait_idle(p);
+            if (w != RH_OK) return w;
+            if (p->d_mix) RH_HIP_TRY(hipFree(p->d_mix));
+            p->d_mix = nullptr;
+            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_mix), need * sizeof(float)));
+            p->mix_floats = need;
+        }
+        SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32 - kMixGroups * 8));
+        float *const frow = pre ? p->d_mix + row : p->d_mix;  // the row the fused launch reads
         const uint32_t nf = p->eq_frames, mf = (uint32_t)p->out_frames;
         if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
         else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
-        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
-        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
-        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
+        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
+        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
+        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
         RH_CHECK_LAUNCH();
         if (pre) {  // the filter of `src.low_pass(f)`, at from_rate, on the mix (time-parallel: rh_biquad mode 1, zero state)
             const rh_status fs = rh_biquad(frow, p->d_mix, p->eq_frames, p->cfg.channels, 1, p->pre_coeffs, nullptr, 1, stream);
             if (fs != RH_OK) return fs;
         }
         k.srcs = ydesc;
-        k.n_sources = 1;
+        k.n_sources = groups;  // (the partial rows, added in order by the fused launch; one row when the list was not cut)
         // every tile of the one-stream launch resident at once: no tickets (see Params::direct)
         k.direct = (p->exclusive && (uint64_t)p->n_tiles <= (uint64_t)rh::g_num_cus * (uint64_t)std::max(pl.resident_per_cu, 0)) ? 1u : 0u;
     }

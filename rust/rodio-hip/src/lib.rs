@@ -596,8 +596,14 @@ impl<I: Source> GpuSource<I> {
         let plan = std::sync::Arc::new(std::sync::Mutex::new(UniformPlanner::new(to_ch, to_rate)));
         let plan2 = plan.clone();
         let (mut win, mut keep) = (State(DeviceBuf::new()), State(DeviceBuf::new()));
+        // What UniformSourceIterator emits is a stream of SAMPLES (a span that ends inside a frame leaves a run that need not fill a frame); the
+        // adapters behind work on frames, so a block hands on whole frames and the samples of a frame that is not complete yet wait here.
+        let mut part = State(DeviceBuf::new());
+        part.0.reserve(64);
+        let part_n = std::sync::Arc::new(std::sync::Mutex::new(0usize));
+        let part_n2 = part_n.clone();
         let stage = self.push(move |c| {
-            let (win, keep) = (&mut win, &mut keep);   // (whole-struct capture)
+            let (win, keep, part) = (&mut win, &mut keep, &mut part);   // (whole-struct capture)
             let mut plan = plan.lock().unwrap();
             plan.begin_block();
             let hs = plan.held_samples();
@@ -609,25 +615,31 @@ impl<I: Source> GpuSource<I> {
             let mut segs = Vec::new();
             for p in c.pieces { plan.add(p, &mut segs); }
             plan.end_block();
+            let mut carried = part_n.lock().unwrap();
+            if *carried > 0 { ck(unsafe { rh_memcpy_d2d(c.out.cast(), part.0.p.cast(), *carried * 4, c.stream) }, "rh_memcpy_d2d"); }
             let table: Vec<RhUniformSeg> = segs.iter().map(|s| {
                 let mut g = s.g;
                 g.src = unsafe { win.0.p.add(s.src_off) };
-                g.dst = unsafe { c.out.add(s.dst_off * to_ch as usize) };
+                g.dst = unsafe { c.out.add(*carried + s.dst_off) };                 // (sample offsets)
                 g
             }).collect();
-            assert!((plan.out_frames() as usize + 1) * to_ch as usize <= c.out_cap, "GpuSource::uniform: block capacity");
+            let total = *carried + plan.out_samples();
+            assert!(total + to_ch as usize <= c.out_cap, "GpuSource::uniform: block capacity");
             ck(unsafe { rh_uniform_segments(table.as_ptr(), table.len() as u32, c.stream) }, "rh_uniform_segments");
             let kn = plan.keep_samples();
             if kn > 0 {
                 keep.0.reserve(kn);
                 ck(unsafe { rh_memcpy_d2d(keep.0.p.cast(), win.0.p.add(plan.keep_offset()).cast(), kn * 4, c.stream) }, "rh_memcpy_d2d");
             }
-            plan.out_frames() as usize * to_ch as usize
-        }, move |n, pieces| {                                                        // every span may add its verbatim last frame
+            let rest = if c.flush { 0 } else { total % to_ch as usize };          // at the end of the stream the rest of a frame is handed on as it is
+            if rest > 0 { ck(unsafe { rh_memcpy_d2d(part.0.p.cast(), c.out.add(total - rest).cast(), rest * 4, c.stream) }, "rh_memcpy_d2d"); }
+            *carried = rest;
+            total - rest
+        }, move |n, pieces| {                                                        // every span may add its verbatim last frame, or what the converters make of a cut frame
             let f = (n / in_ch) as u64;
-            (f.max(f * to_rate as u64 / from as u64 + 2) as usize + 2 * (pieces + 2)) * to_ch as usize
+            (f.max(f * to_rate as u64 / from as u64 + 2) as usize + (UniformPlanner::close_slack_frames(from, to_rate) as usize + 1) * (pieces + 2) + 1) * to_ch as usize
         }, 1);
-        stage.on_seek = Some(Box::new(move |_| *plan2.lock().unwrap() = UniformPlanner::new(to_ch, to_rate)));   // the next span starts a fresh chain
+        stage.on_seek = Some(Box::new(move |_| { *plan2.lock().unwrap() = UniformPlanner::new(to_ch, to_rate); *part_n2.lock().unwrap() = 0; }));   // the next span starts a fresh chain
         self.ch = to_ch;
         self.rate = to_rate;
         self
@@ -857,7 +869,8 @@ impl Upstream {
 struct Src {
     up: Upstream, gain: f32, filt: MixerFilter, held: Vec<f32>, ended: bool, ch: u16,
     dheld: u64, dheld_off: u64,                                                  // a device chain: frames the converter has not consumed, in the row of the block before
-    reader: SpanReader, plan: UniformPlanner, have: u64, off: u64,               // span-by-span generations
+    reader: SpanReader, plan: UniformPlanner, have_s: u64, off_s: u64,           // span-by-span generations: converted SAMPLES not yet mixed, from sample off_s of the row
+    total_s: u64,                                                                 // samples of the source's stream in the mix's layout so far (a stream that ends inside a frame: the last block is cut to what rodio returns)
 }
 unsafe impl Send for Src {}
 fn count_chain(x: &Src, st: &mut ChainStats) {
@@ -952,7 +965,7 @@ impl GpuMixer {
             return;
         }
         let item = Src { up: Upstream::Host(src), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
-                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have: 0, off: 0 };
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0 };
         if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
     }
     /// A `GpuSource` chain handed to the mixer by value, as rodio's adapters are (`mixer.add(src.reverb(..).limit(..))`, amplify.rs:19-22,
@@ -965,7 +978,7 @@ impl GpuMixer {
         let on_device = ch == 2 && !chain.started() && !fused_ratio_unsupported(rate, self.rate);
         if on_device { chain.keep_blocks_on_device(true); self.device_chains = true; }
         let item = Src { up: Upstream::Chain(chain), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
-                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have: 0, off: 0 };
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0 };
         if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
     }
     /// Everything a first `next()` would do before it can serve a sample, done NOW on the calling thread (see `BlockSource::prepare_stream`):
@@ -1268,7 +1281,7 @@ impl GpuMixer {
             match x.reader.peek(x.up.src()) {
                 None => { x.ended = true; }                                         // the chain rodio would build now is empty
                 Some((ch, r)) => {
-                    let want = g.target.saturating_sub(x.have);
+                    let want = g.target.saturating_sub(x.have_s / 2);
                     let in_frames = want * r as u64 / rate as u64 + 8;
                     row_cap[i] = x.plan.held_samples() + in_frames as usize * ch as usize;
                     total += (row_cap[i] + 3) & !3;
@@ -1281,10 +1294,11 @@ impl GpuMixer {
         g.pmax_out = 0;
         let (oc, nc) = (g.ccur, g.ccur ^ 1);
         for (i, x) in g.srcs.iter().enumerate() {                                  // what the last block left over: to the front of the other row set
-            if x.have == 0 { continue; }
-            g.ptable.push(RhUniformSeg { src: unsafe { g.conv[oc].p.add(i * crowf + x.off as usize * 2) }, dst: unsafe { g.conv[nc].p.add(i * crowf) }, src_frame0: 0, src_frames: x.have,
-                                         m0: 0, m1: x.have, span_frames: u64::MAX, from_rate: rate, to_rate: rate, from_ch: 2, to_ch: 2, gain: 1.0, reserved: 0 });
-            g.pmax_out = g.pmax_out.max(x.have);
+            if x.have_s == 0 { continue; }
+            // (copied as a MONO stream, sample for sample: the count may be odd, and the sample behind the last one belongs to a segment of this very launch)
+            g.ptable.push(RhUniformSeg { src: unsafe { g.conv[oc].p.add(i * crowf + x.off_s as usize) }, dst: unsafe { g.conv[nc].p.add(i * crowf) }, src_frame0: 0, src_frames: x.have_s,
+                                         m0: 0, m1: x.have_s, span_frames: u64::MAX, from_rate: rate, to_rate: rate, from_ch: 1, to_ch: 1, gain: 1.0, reserved: 0 });
+            g.pmax_out = g.pmax_out.max(x.have_s);
         }
         // 2. pull and plan (the spans of a source are pulled in order by one thread; the sources one after the other here -- the C++ twin
         // deals them over its pull threads the same way the direct generations do)
@@ -1299,9 +1313,10 @@ impl GpuMixer {
             let mut segs: Vec<PlannedSeg> = Vec::new();
             loop {
                 let (ch, r) = match x.reader.peek(x.up.src()) { Some(f) => f, None => { x.ended = true; break; } };
-                let now = x.have + x.plan.out_frames();
+                let now = (x.have_s + x.plan.out_samples() as u64 + 1) / 2;
                 if now >= g.target { break; }
-                let (need, most) = x.plan.budget(r, x.reader.opens_next(), g.target - now, g.crow - now);
+                let slack = UniformPlanner::close_slack_frames(r, rate);                // what the span's end may add
+                let (need, most) = x.plan.budget(r, x.reader.opens_next(), g.target - now, (g.crow - now).saturating_sub(slack));
                 let n = need.min(most).min(((row_cap[i] - fill) / ch as usize) as u64) as usize;
                 if n == 0 { break; }
                 let piece = x.reader.read_piece(x.up.src(), &mut row[fill..], n);   // straight into the staging block
@@ -1315,13 +1330,14 @@ impl GpuMixer {
             for sg in &segs {
                 let mut t = sg.g;
                 t.src = unsafe { g.din[pd].p.add(row_off[i] + sg.src_off) };
-                t.dst = unsafe { g.conv[nc].p.add(i * crowf + (x.have as usize + sg.dst_off) * 2) };
+                t.dst = unsafe { g.conv[nc].p.add(i * crowf + x.have_s as usize + sg.dst_off) };   // (sample offsets)
                 t.gain = x.gain;
                 g.pmax_out = g.pmax_out.max(t.m1 - t.m0);
                 g.ptable.push(t);
             }
-            x.have += x.plan.out_frames();
-            assert!(x.have <= g.crow, "GpuMixer: converted frames exceed the row");
+            x.have_s += x.plan.out_samples() as u64;
+            x.total_s += x.plan.out_samples() as u64;
+            assert!(x.have_s + 1 <= g.crow * 2, "GpuMixer: converted frames exceed the row");
         }
         // 3. one copy for all rows, on the copy stream: it runs beside the launches of the block before
         if total > 0 { ck(unsafe { rh_memcpy_h2d(g.din[pd].p.cast(), g.stage[slot].p.cast(), total * 4, copy_stream) }, "rh_memcpy_h2d"); }
@@ -1348,13 +1364,22 @@ impl GpuMixer {
         g.ccur = nc;
         // 4. filter + ordered sum of the converted rows
         let ptrs: Vec<*const f32> = (0..s_n).map(|i| unsafe { g.conv[nc].p.add(i * crowf) } as *const f32).collect();
-        let avail: Vec<u64> = g.srcs.iter().map(|x| x.have).collect();
+        for (i, x) in g.srcs.iter_mut().enumerate() {
+            if x.ended && x.have_s & 1 == 1 {
+                // the source's stream ends inside a frame: rodio's mixer adds its last sample and, at the next one, finds the source gone
+                // (mixer.rs:185-198).  Adding +0.0 for the missing sample leaves the sum as it is -- through a filter it would not.
+                assert!(g.filt.kind < 0, "GpuMixer: a filtered source of 1, 2, 4 or 8 channels whose stream ends inside a frame (source/mod.rs:196-200)");
+                ck(unsafe { rh_memset(g.conv[nc].p.add(i * crowf + x.have_s as usize).cast(), 0, 4, stream) }, "rh_memset");
+                x.have_s += 1;
+            }
+        }
+        let avail: Vec<u64> = g.srcs.iter().map(|x| x.have_s / 2).collect();
         let ended: Vec<u8> = g.srcs.iter().map(|x| x.ended as u8).collect();
         let (mut out, mut consumed) = (0u64, 0u64);
         ck(unsafe { rh_rlm_stream_block_v(g.plan, ptrs.as_ptr(), avail.as_ptr(), ended.as_ptr(), s_n as u32, g.queue_end(), out_cap * 2 - g.fill - g.head, &mut out, &mut consumed, stream) },
            "rh_rlm_stream_block_v");
         g.fill += out;
-        for x in &mut g.srcs { let d = consumed.min(x.have); x.off = d; x.have -= d; }
+        for x in &mut g.srcs { let d = consumed.min(x.have_s / 2); x.off_s = d * 2; x.have_s -= d * 2; }
         g.done = g.srcs.iter().all(|x| x.ended);
     }
 

@@ -57,4 +57,20 @@ PY
     done
     grep -A12 "counters" $E/r05_limit_kernel_trace_pmc.txt | head -40
     ;;
+4)
+    python -m pytest tests/test_gpu_mix_first.py tests/test_gpu_multi.py tests/test_gpu_mono.py -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -30 > $E/gputests_4.txt; tail -8 $E/gputests_4.txt
+    python bench.py --config stream > $E/bench_stream.json 2> $E/bench_stream.err; tail -3 $E/bench_stream.err
+    RH_BENCH_NO_PMC=1 python bench.py --config stream --block 16384 --no-cpu-baseline > $E/bench_stream_16k.json 2>/dev/null
+    RH_BENCH_NO_PMC=1 python bench.py --config stream --block 262144 --no-cpu-baseline > $E/bench_stream_256k.json 2>/dev/null
+    RH_PROF_KERNEL=k_ bash tools/kt_cmd.sh r05_stream python bench.py --config stream --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r05_stream/summary.txt $E/r05_stream_kernel_trace.txt; head -12 $E/r05_stream_kernel_trace.txt | cut -c1-180
+    for f in bench_stream bench_stream_16k bench_stream_256k; do python - "$E/$f.json" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]
+    r=d['roofline']; print(sys.argv[1].split('/')[-1], 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), 'parity', (d.get('parity') or {}).get('max_abs_err'))
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+    done
+    ;;
 esac
