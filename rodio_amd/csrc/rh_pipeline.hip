@@ -3785,8 +3785,9 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
         // short rows: groups of sources side by side until the launch holds two workgroups per CU (every group keeps at least 8 sources: the
         // kernel's pipeline of descriptor fetches and loads)
         uint32_t groups = 1;
+        const uint64_t per_cu = rh::knob(rh::K_MIX_GROUPS) ? (uint64_t)std::max(1, atoi(rh::knob(rh::K_MIX_GROUPS))) : 2ull;  // tuning aid: workgroups per CU the cut aims at
         if (!pre && !ring && !rh::knob(rh::K_MIX_U))
-            while (groups < kMixGroups && (uint64_t)wgs * groups < 2ull * (uint64_t)rh::g_num_cus && count / (groups * 2) >= 8) groups *= 2;
+            while (groups < kMixGroups && (uint64_t)wgs * groups < per_cu * (uint64_t)rh::g_num_cus && count / (groups * 2) >= 8) groups *= 2;
         // the mixed row (16-byte vectors) [, the filtered row] -- or the groups' partial rows --, then the descriptors (32 bytes each) at the very end
         const size_t rows_needed = pre ? 2 : (sa.mode ? kMixGroups : groups);  // (a stream: sized once, for whatever its blocks will need)
         const size_t need = row * rows_needed + 64 + kMixGroups * 8;

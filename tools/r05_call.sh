@@ -73,4 +73,22 @@ except Exception as e: print(sys.argv[1], 'ERR', e)
 PY
     done
     ;;
+5)
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4))"; }
+    {
+    for g in 1 2 4 8; do echo "stream 64Ki RH_MIX_GROUPS=$g: $(RH_MIX_GROUPS=$g RH_BENCH_NO_PMC=1 python bench.py --config stream --steps 10 --no-cpu-baseline 2>/dev/null | q)"; done
+    for g in 2 4 8; do echo "stream 16Ki RH_MIX_GROUPS=$g: $(RH_MIX_GROUPS=$g RH_BENCH_NO_PMC=1 python bench.py --config stream --block 16384 --steps 5 --no-cpu-baseline 2>/dev/null | q)"; done
+    } > $E/r05_stream_groups.txt 2>&1; cat $E/r05_stream_groups.txt
+    {
+    for shape in "64 1048576" "2048 32768"; do set -- $shape
+      for v in "16 8 0" "8 8 0" "8 16 0" "16 4 0" "8 4 0" "8 8 1" "8 4 2" "8 4 4"; do set -- $shape $v
+        env="RH_LIMIT_R=$3 RH_LIMIT_NW=$4"; [ "$5" != "0" ] && env="$env RH_LIMIT_WGS=$5"
+        echo "limit streams=$1 frames=$2 R=$3 NW=$4 WGS=$5: $(env $env RH_BENCH_NO_PMC=1 python bench.py --config limit --sources $1 --frames $2 --steps 30 --no-cpu-baseline 2>/dev/null | q)"
+      done
+    done
+    } > $E/r05_limit_geometry.txt 2>&1; cat $E/r05_limit_geometry.txt
+    ;;
+6)
+    { echo "## RH_LIMIT_PROFILE build (shader cycles per phase, summed over the tiles), k_limit_scan<2,16,8>"; for shape in "64 1048576" "2048 32768"; do echo "# streams frames = $shape"; RODIO_HIP_LIB=rodio_amd/build/librodio_hip_lprof.so python tools/prof_limit.py $shape 2>/dev/null | tail -1; done; } > $E/r05_limit_phases.txt 2>&1; cat $E/r05_limit_phases.txt
+    ;;
 esac
