@@ -428,7 +428,8 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
     // is as far ahead of the polls as a fetch can be (a.dma_top = 0, the round-2 first version, put it behind the integrator
     // look-back: that poll was then free, but the peak poll paid the whole fetch latency).
     const bool had_I = SKEW && have_I;
-    const bool dma_first = had_I || a.dma_top;
+    const uint32_t dma_where = a.dma_top;  // 1: at the top of the tile; 0: behind the integrator look-back; 2: behind the poll point (no poll of this tile ever waits for it)
+    const bool dma_first = dma_where == 1 || (had_I && dma_where != 2);
     if (NIO == 0 && dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
     // ---- the samples: whole shares were put into LDS by the DMA issued a tile ago; a short share (end of a stream) is
     //      fetched here, guarded, into the same slots.  (FULL is a property of the TILE -- every wave of the workgroup runs the same
@@ -546,7 +547,7 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
 #pragma unroll
         for (int c = 0; c < C; ++c) Iin[c] = Ao[c];
     }
-    if (NIO == 0 && !dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
+    if (NIO == 0 && !dma_first && dma_where != 2 && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(2)
     RH_ARGS_FRESH();
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
@@ -676,6 +677,7 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
 #pragma unroll
         for (int c = 0; c < C; ++c) Pin[c] = __builtin_nanf("");
     }
+    if (NIO == 0 && dma_where == 2 && next_src) dma_share<V>(next_src, next_buf, lane);
     RH_LP(4)
     RH_ARGS_FRESH();
     // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----

@@ -91,4 +91,33 @@ PY
 6)
     { echo "## RH_LIMIT_PROFILE build (shader cycles per phase, summed over the tiles), k_limit_scan<2,16,8>"; for shape in "64 1048576" "2048 32768"; do echo "# streams frames = $shape"; RODIO_HIP_LIB=rodio_amd/build/librodio_hip_lprof.so python tools/prof_limit.py $shape 2>/dev/null | tail -1; done; } > $E/r05_limit_phases.txt 2>&1; cat $E/r05_limit_phases.txt
     ;;
+7)
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4), (d.get('parity') or {}).get('max_abs_err'))"; }
+    { for rep in 1 2; do for shape in "64 1048576" "2048 32768"; do set -- $shape; for w in 1 2 0; do echo "limit streams=$1 frames=$2 RH_SCAN_DMA_TOP=$w: $(RH_SCAN_DMA_TOP=$w RH_BENCH_NO_PMC=1 python bench.py --config limit --sources $1 --frames $2 --steps 30 2>/dev/null | q)"; done; done; done; } > $E/r05_limit_dma_where.txt 2>&1; cat $E/r05_limit_dma_where.txt
+    ;;
+8)  # the round's evidence: the suite, the driver's line, its trace + counters, the side configurations, the pull path
+    python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -12 > $E/r05_final_gputests.txt; tail -4 $E/r05_final_gputests.txt
+    python bench.py > $E/r05_bench_cfg2.json 2> $E/r05_bench_cfg2.err; tail -c 400 $E/r05_bench_cfg2.json
+    RH_PROF_KERNEL=k_rlm bash tools/pmc_cmd.sh r05_cfg2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autotune --no-per-source > /dev/null 2>&1
+    cp gpurun_out/prof/r05_cfg2/summary.txt $E/r05_cfg2_kernel_trace_pmc.txt
+    for c in 3 5 ragged agc 2span 2mono; do python bench.py --config $c > $E/r05_bench_$c.json 2>/dev/null; done
+    python bench.py --collective native --no-per-source > $E/r05_bench_cfg2_native_one_rank.json 2>/dev/null
+    RH_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 > $E/r05_bench_gpus2_one_device.json 2> $E/r05_bench_gpus2_one_device.err
+    {
+        echo "## tests/cpp/host_mirror_test bench <sources> <frames> <block_frames> <host_threads>"
+        tests/cpp/host_mirror_test bench 256 4194304 65536 16
+        tests/cpp/host_mirror_test bench 256 4194304 65536 16
+        echo "## RH_TEST_SOURCE=buffer (SamplesBuffer: spans of 32768 samples, converted span by span)"
+        RH_TEST_SOURCE=buffer tests/cpp/host_mirror_test bench 256 4194304 32768 16
+    } > $E/r05_pull_path.txt 2>&1
+    for f in r05_bench_cfg2 r05_bench_3 r05_bench_5 r05_bench_ragged r05_bench_agc r05_bench_2span r05_bench_2mono r05_bench_cfg2_native_one_rank r05_bench_gpus2_one_device; do python - "$E/$f.json" <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]
+    r=d['roofline']; print(sys.argv[1].split('/')[-1], 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), 'parity', (d.get('parity') or {}).get('ok'))
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+    done
+    grep -o '"frac": [0-9.]*' $E/r05_pull_path.txt | head
+    ;;
 esac
