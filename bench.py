@@ -487,6 +487,56 @@ def headline(args, argv):
         pipe.set_mix_first(True)
         pipe.set_sources([data[s, : Cn * lens[s]] for s in range(S)])
 
+    # ---- a filter PER SOURCE in the same run: `mixer.add(a.low_pass(200)); mixer.add(b.high_pass(1000)); ...` (source/mod.rs:686-721) -- the same 256
+    # sources dealt over four filters, 64 each (rh_rlm_set_filters: one mix-first launch per class, the classes' mixes added in order of first
+    # appearance); parity against the oracle's Mixer over the per-source chains, the classes' oracle mixes computed on four host threads
+    per_class = None
+    if not ragged and not args.per_source and not args.no_per_class and world == 1 and Cn == 2 and not span and S % 4 == 0 and not child:
+        classes = [("low_pass", args.freq), ("low_pass", 1000), ("high_pass", 1000), ("low_pass", 4000)]
+        pc = rh.ResampleLowpassMix(44100, 48000, Cn, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=N)
+        pc.set_filters([classes[s_ % 4] for s_ in range(S)])
+        pc.set_sources([data[s_, : Cn * lens[s_]] for s_ in range(S)])
+        pc_out = torch.empty(M * Cn, device="cuda", dtype=torch.float32)
+        for _ in range(args.warmup):
+            pc.run(pc_out)
+        cevs = events(lib, _lib, 1)
+        torch.cuda.synchronize()
+        lib.rh_event_record(cevs[0][0], stream)
+        for k in range(args.steps):
+            pc.run(pc_out)
+        lib.rh_event_record(cevs[0][1], stream)
+        torch.cuda.synchronize()
+        pc.check_status()
+        cms = elapsed(lib, _lib, cevs)[0] / args.steps
+        alg_c = 4 * sum(lens) * Cn + 4 * M * Cn
+        per_class = {"classes": [f"{k}({f})" for k, f in classes], "sources_per_class": S // 4, "call_ms": cms, "achieved": alg_c / (cms * 1e-3) / 1e9, "frac": alg_c / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "how": "HIP events around the timed region / steps: one call = one launch per class + the sum of the classes' mixes"}
+        if not args.no_cpu_baseline:
+            from concurrent.futures import ThreadPoolExecutor
+
+            from oracle import rodio_oracle as O
+
+            def class_mix(ci):
+                m_ = O.Mixer(Cn, 48000)
+                for s_ in range(ci, S, 4):
+                    u_ = O.UniformSourceIterator(O.TestSource(host[s_], Cn, 44100), Cn, 48000)
+                    m_.add(u_.low_pass(classes[ci][1]) if classes[ci][0] == "low_pass" else u_.high_pass(classes[ci][1]))
+                return m_.collect()
+
+            with ThreadPoolExecutor(4) as ex:
+                mixes = list(ex.map(class_mix, range(4)))
+            refc = mixes[0].copy()
+            for mx_ in mixes[1:]:
+                refc = (refc + mx_).astype(np.float32)
+            gotc = pc_out.cpu().numpy()
+            if gotc.shape == refc.shape:
+                ec = float(np.abs(gotc.astype(np.float64) - refc.astype(np.float64)).max())
+                per_class["parity"] = {"max_abs_err": ec, "peak": float(np.abs(refc).max()), "tolerance": 1e-5, "ok": bool(ec <= 1e-5), "frames_compared": int(len(refc) // Cn),
+                                       "vs": "the oracle's Mixer over the 256 per-source chains (every source its own filter), the classes' mixes added in the same order"}
+            else:
+                per_class["parity"] = {"ok": False, "error": f"length {gotc.shape} vs oracle {refc.shape}"}
+        pc.close()
+
     # ---- parity and the CPU baseline ---------------------------------------------------------------------------------------
     in_samples = sum(lens) * Cn
     cores = os.cpu_count() or 1
@@ -656,6 +706,8 @@ def headline(args, argv):
     }
     if per_source is not None:
         res["roofline"]["per_source"] = per_source
+    if per_class is not None:
+        res["roofline"]["per_class"] = per_class
     if world == 1 and want.startswith("native"):
         res["config"]["collective"] = ("rh_reduce_sum_f32" if reduce_only else "rh_allreduce_sum_f32") + " (C ABI, rh_comm.hip over RCCL) with a communicator of ONE rank in the timed loop, on its own stream: the N > 1 code path, nranks = 1"
     if multi:
@@ -949,6 +1001,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-source", action="store_true", help="the headline batch on the per-source path (rh_rlm_set_mix_first(0)); the default line carries it as roofline.per_source")
     ap.add_argument("--no-per-source", action="store_true", help="skip the per-source leg of the default line")
+    ap.add_argument("--no-per-class", action="store_true", help="skip roofline.per_class (the same sources with a filter per source: four classes of 64)")
     ap.add_argument("--no-unscaled", action="store_true", help="skip parity.unscaled / parity.vs_f64 (the same workload at amplitude 1, and both sides against the f64 response)")
     ap.add_argument("--shared-device", action="store_true", help="tiles by ticket although one rank runs (rh_rlm_set_exclusive(0)): what the N > 1 ranks do")
     ap.add_argument("--collective", default="auto", choices=["auto", "native", "native-reduce", "torch"],

@@ -19,7 +19,8 @@
 //     k_agc_chain<GainOp0>   release == 0 (the default): the release candidate is `desired` itself; the chain is multiply, add,
 //                            max, compare, select on values the parallel pass prepared                         -> gain[n]     (in place)
 //     k_agc_apply            y = x * gain, every lane of the chip
-// and, since round 4, for up to 16 streams per CU (k_agc_fused<true>: any parameters, the peak follower as a third chain wave):
+// and, since round 4, for EVERY aligned out-of-place call unless RH_AGC_SEGMENTS=1 asks for the form above (k_agc_fused<true>: any parameters,
+// the peak follower as a third chain wave; more streams than the chip holds workgroups of 16 simply queue):
 //     k_agc_fused            ALL of the above in one workgroup per 16 streams: the two chains on a wave each, the square roots and
 //                            divides on four more, loaders and storers around them -- nothing but x in and y out   (see there)
 // Both chains MUST round like the reference, step by step: the window sum drifts 7e-5 relative over 2 Mi samples when
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(384) void k_agc_chain2(const ChainArgs a, const Cha
 // cycles on two SIMDs, against the 1100 cycles the chains take for them (measured: 46 ns per sample with 64 streams per
 // workgroup, the chains alone 16).  So a workgroup takes 16 STREAMS and chunks of 128 samples (the same 8 KiB images; a quarter of
 // the barriers per sample): 16 of a chain wave's lanes work, and D's 3100 cycles fit the 4400 of a chunk.  The chip has the CUs:
-// 64 streams are 4 workgroups, 2048 are 128; batches of more than 16 streams per CU keep the segment-by-segment form.
+// 64 streams are 4 workgroups, 2048 are 128; larger batches queue as further workgroups (16 384 x 32 Ki: 3.7 ms against the segment form's 10.2).
 // LDS: x stays until Y has used it (kFAhead + 4 chunks), x_old until S has (kFAhead + 1), the value image -- sum, then desired,
 // then gain, in place -- 4 chunks.  Same operations in the same order as the stages above (and as k_agc_seq, up to GainOp0's tie:
 // see the header), so the same bits.

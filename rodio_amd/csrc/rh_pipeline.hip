@@ -2824,6 +2824,11 @@ struct rh_rlm {
     std::vector<FilterClass> cls;     // classes of the sources that are set (empty: one filter, this handle runs itself)
     float *d_cls_rows = nullptr;      // [classes][row] partial mixes
     size_t cls_row_floats = 0, cls_rows = 0;
+    // RH_CLASSES_SIDE_BY_SIDE=1 (a measured alternative, slower: see run_classes): the classes' launches side by side -- class 0 on the caller's
+    // stream, the others on streams of the handle's, forked from and joined to the caller's by events
+    std::vector<hipStream_t> cls_streams;
+    std::vector<hipEvent_t> cls_done;
+    hipEvent_t cls_fork = nullptr;
 };
 
 namespace {
@@ -3370,6 +3375,12 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     for (rh_rlm::FilterClass &c : p->cls)
         if (c.h) (void)rh_rlm_destroy(c.h);
     p->cls.clear();
+    for (hipStream_t st : p->cls_streams) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
+    for (hipEvent_t e : p->cls_done) (void)hipEventDestroy(e);
+    if (p->cls_fork) (void)hipEventDestroy(p->cls_fork);
     if (p->d_cls_rows) (void)hipFree(p->d_cls_rows);
     if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
     bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
@@ -3590,14 +3601,40 @@ static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames
     }
     std::vector<const float *> ptrs;
     std::vector<uint64_t> start, len;
+    hipStream_t s0 = rh::as_stream(stream);
+    // Measured (profiles/r05_per_class.txt: 4 classes x 64 sources x 1 Mi frames): one after the other 0.368 ms, side by side 0.40-0.42 -- four
+    // launches that each want the whole chip's bandwidth get in each other's way (and their tiles go by ticket then).  So: one after the other;
+    // RH_CLASSES_SIDE_BY_SIDE=1 keeps the other form selectable.
+    const bool side_by_side = rh::knob(rh::K_CLASSES_SIDE_BY_SIDE) != nullptr;
+    if (side_by_side) {
+        while (p->cls_streams.size() + 1 < live.size()) {
+            hipStream_t ns = nullptr;
+            hipEvent_t ne = nullptr;
+            RH_HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+            p->cls_streams.push_back(ns);
+            RH_HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+            p->cls_done.push_back(ne);
+        }
+        if (!p->cls_fork) RH_HIP_TRY(hipEventCreateWithFlags(&p->cls_fork, hipEventDisableTiming));
+        RH_HIP_TRY(hipEventRecord(p->cls_fork, s0));  // what the caller queued in front (the sources' samples) is in front of every class
+    }
     for (size_t k = 0; k < live.size(); ++k) {
         float *r = p->d_cls_rows + k * p->cls_row_floats;
-        const rh_status st = rh_rlm_run(live[k]->h, r, p->cls_row_floats / C, nullptr, stream);
+        hipStream_t sk = s0;
+        if (side_by_side && k > 0) {
+            sk = p->cls_streams[k - 1];
+            RH_HIP_TRY(hipStreamWaitEvent(sk, p->cls_fork, 0));
+        }
+        if (side_by_side) live[k]->h->exclusive = false;  // other classes' kernels share the CUs: tiles by ticket (rh_rlm_set_exclusive)
+        const rh_status st = rh_rlm_run(live[k]->h, r, p->cls_row_floats / C, nullptr, reinterpret_cast<rh_stream>(sk));
         if (st != RH_OK) return st;
+        if (side_by_side && k > 0) RH_HIP_TRY(hipEventRecord(p->cls_done[k - 1], sk));
         ptrs.push_back(r);
         start.push_back(0);
         len.push_back(live[k]->out_frames * C);
     }
+    if (side_by_side)
+        for (size_t k = 1; k < live.size(); ++k) RH_HIP_TRY(hipStreamWaitEvent(s0, p->cls_done[k - 1], 0));
     const rh_status st = rh_mix_sum(dst, p->out_frames * C, ptrs.data(), start.data(), len.data(), (uint32_t)ptrs.size(), stream);
     if (st != RH_OK) return st;
     return mark_launch(p, rh::as_stream(stream));

@@ -120,4 +120,11 @@ PY
     done
     grep -o '"frac": [0-9.]*' $E/r05_pull_path.txt | head
     ;;
+9)
+    python -m pytest tests/test_gpu_mix_first.py tests/test_host_mirror.py -q -m gpu -p no:cacheprovider -k "filter or class" 2>&1 | tail -4
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; c=d['roofline']['per_class']; print('headline', round(d['roofline']['kernel_ms'],4), 'per_class', round(c['call_ms'],4), round(c['frac'],4), c.get('parity',{}).get('max_abs_err'))"; }
+    for rep in 1 2; do echo "side by side: $(python bench.py --no-per-source --no-unscaled 2>/dev/null | q)"; echo "RH_CLASSES_SERIAL=1: $(RH_CLASSES_SERIAL=1 python bench.py --no-per-source --no-unscaled 2>/dev/null | q)"; done | tee $E/r05_per_class.txt
+    RH_PROF_KERNEL=k_rlm bash tools/pmc_cmd.sh r05_cfg2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autotune --no-per-source --no-per-class > /dev/null 2>&1
+    cp gpurun_out/prof/r05_cfg2/summary.txt $E/r05_cfg2_kernel_trace_pmc.txt; head -8 $E/r05_cfg2_kernel_trace_pmc.txt | cut -c1-150
+    ;;
 esac
