@@ -84,7 +84,7 @@ struct ScratchAux {
 hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold, ScratchAux **aux = nullptr);
 // device-to-device copy as a launch on `hs` (hipMemcpyAsync DeviceToDevice makes the calling thread wait for the queue ahead of it)
 hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
-// rh_pipeline.hip: `s` has been synchronised and is about to go -- fused-pipeline handles whose launches went there are idle now
+// rh_pipeline_plan.hip: `s` has been synchronised and is about to go -- fused-pipeline handles whose launches went there are idle now
 // (they record their idle event lazily, on the stream of their last launch: never on a destroyed one).
 void rlm_stream_retired(hipStream_t s);
 

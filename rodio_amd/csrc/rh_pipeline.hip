@@ -36,114 +36,13 @@
 //     true start state S of a lane is added once, after the last source, from summed states.
 //   * tiles are numbered by an atomic ticket, so a tile only ever waits for tiles that already
 //     hold a wave slot: progress does not depend on dispatch order or residency.
-#include <algorithm>
-#include <cmath>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <numeric>
-#include <type_traits>
-#include <unordered_map>
-#include <vector>
-
-#include "rh_common.h"
-
-namespace rh {
-struct ResampleGeom {
-    uint32_t F, T;
-    uint64_t in_frames, chunk_in, chunk_out, n_chunks, last_in, out_frames;
-    int fits32;
-};
-rh_status make_resample_geom(uint64_t in_frames, uint32_t from_rate, uint32_t to_rate, uint32_t channels, uint64_t span_len, ResampleGeom *g);
-}  // namespace rh
+//
+// This unit: the kernels, their instances and the launch (rlm_launch).  The host side around it -- handles, plans and
+// tables, filter classes, the one-shot entry points (rh_pipeline_plan.hip) and block streaming (rh_pipeline_stream.hip) --
+// shares rh_pipeline_internal.h with it.
+#include "rh_pipeline_internal.h"
 
 namespace {
-
-#ifndef RH_CARRY_DEFER
-#define RH_CARRY_DEFER 2  // see DESIGN.md: slack of the tile-to-tile hand-off, in groups of 8 sources
-#endif
-constexpr int kMaxR = 20;
-constexpr int kGroupLag = RH_CARRY_DEFER;  // a source group's carries are fetched kGroupLag groups (of 8 sources) after its own
-constexpr int kMaxLook = 32;              // 2 lanes x 16 B of LDS-DMA per predecessor tile: 64 lanes
-constexpr uint32_t kSpinLimit = 1u << 22;  // x (~1 us load + s_sleep): seconds, then give up for good.  Waits end by construction (a tile only
-                                           // waits for tiles with earlier tickets); the bound must outlast a GPU that is time-sliced with other processes
-
-struct SrcDesc {          // 32 bytes, read with s_load (constant address space)
-    const float *data;
-    uint32_t frames;      // N_s   (< 2^29)
-    uint32_t out_frames;  // M_s   (< 2^31)
-    float gain;           // Amplify factor of the source (amplify.rs:64); the chain is linear, so it scales the mix term
-    uint32_t pad[3];
-};
-static_assert(sizeof(SrcDesc) == 32, "descriptor stride");
-
-// ---- the biquad as data -----------------------------------------------------------------------
-// H(z) = b0 + (c1 z^-1 + c2 z^-2)/A(z) with c1 = b1 - b0*a1, c2 = b2 - b0*a2.  The recursive
-// part w = y - b0*x is what is scanned along time: w is smooth whenever the poles sit near
-// z = 1 (also for a high-pass, whose y is not), so its zero-state run and its homogeneous
-// correction stay of the magnitude of w instead of cancelling large terms.
-//
-// The scan works on z = Tm * (w[n-1], w[n-2]) rather than on the companion state itself.  For
-// the double real pole p of rodio's default q = 0.5 (blt.rs:11-16) Tm = [[1,-p],[0,1]] turns the
-// companion matrix into [[p,0],[1,p]], whose powers [[p^n,0],[n p^(n-1),p^n]] multiply the SMALL
-// component z1 = w1 - p*w2 by the large entry; for complex poles rho*e^(+-j*theta),
-// Tm = [[1,-rho cos],[0,rho sin]] gives rho*Rotation(theta), a normal matrix.  In that basis
-// every table below is benign in f32; in the companion basis the same algebra needs f64 (measured:
-// 10-30x the reference's own f32 error).  All tables are powers of B = Tm A Tm^-1 computed on the
-// host in f64 and rounded once.
-struct Uniforms {
-    float b0, c1, c2, a1, a2;
-    float Tm[4];          // (w1,w2) -> z
-    float scanM[4][4];    // B^(R*2^k), k = 0..3   (row_shr 1,2,4,8)
-    float g[kMaxR][2];    // row 0 of A^(r+1) Tm^-1: homogeneous response of w inside a run
-};
-struct Tables {            // per-lane tables (loaded once per lane)
-    float bc15M[64][4];    // B^(R*((lane&15)+1))   (row_bcast:15 step)
-    float bc31M[64][4];    // B^(R*((lane&31)+1))   (row_bcast:31 step)
-    float laneM[64][4];    // B^(R*lane)
-    float lookM[64][4];    // B^(L*j), j < kMaxLook
-};
-
-struct Params {
-    const SrcDesc *srcs;
-    const Tables *tabs;
-    float *out;
-    unsigned long long *gran;  // [S][tiles][4] {epoch, f32 bits}
-    uint32_t *ticket;
-    uint32_t *status;
-    uint64_t out_frames;
-    uint64_t chunk_in, chunk_out;  // chunk_out == 0: unchunked
-    uint32_t n_sources, n_tiles;
-    uint32_t F, T, qF, rF;
-    float Tf, rcpT;
-    uint32_t epoch, J;
-    uint32_t ticket_base;  // value of *ticket when this launch starts (the counter is never reset)
-    uint32_t direct;       // k_rlm_fast: tile = blockIdx.x, no ticket.  Only for launches whose workgroups are all resident at once (the host
-                           // checks): then no tile can wait for one that has no slot yet.  One counter hands out ~85 tickets per microsecond,
-                           // which a one-source launch (mix first) cannot hide.
-    unsigned long long *prof;  // RH_PHASE_PROFILE builds: [tiles][8] cycles per phase
-    uint32_t eq_frames;        // k_rlm_fast: the common length of all sources
-    uint32_t batch_streams;    // k_rlm_fast: > 0 = no mixing: ticket k is tile k / batch_streams of source k % batch_streams
-    uint32_t shards;           // batch mode: > 1 = the streams are dealt over this many ticket counters (stream s -> counter s % shards)
-    uint32_t shard_base;       // ... whose common start value for this launch this is (every counter hands out n_tiles * batch_streams / shards tickets)
-    uint64_t out_stride;       // ... whose output row starts out_stride floats after the previous one
-    // k_rlm_fast, block streaming (st_mode: 0 off, 1 block of a running stream, 2 its last block):
-    uint32_t st_mode, st_active;  // st_active: output frames this block emits (a multiple of R in mode 1)
-    uint64_t st_m0, st_g0;        // global index of the block's first output frame / of input frame 0 of the buffers
-    // k_rlm_wave keeps one aggregate row per source: gran_cols columns, tile t in column t + col0.  Streaming sets
-    // col0 = 1: column 0 then holds the source's filter state at the block start, i.e. the aggregate of a virtual
-    // predecessor tile -- the look-back needs no other change.
-    uint32_t gran_cols, col0;
-    const float *st_win;          // summed filter state (scan basis) at output frame st_m0
-    float *st_wout;               // ... at st_m0 + st_active, written by the lane that would come next
-    // k_rlm_fast<RAG, SUMF>: 1 = a tile also handles its own (tile, source) pairs in which the source is about to end (rag_run_pairs),
-    // on top of its mix of the stable sources and before it stores; the per-source aggregate rows lie in front of `gran`.  Sources
-    // that are not among the longest end between output frames rag_pairs_from and rag_pairs_to: only tiles near that range look.
-    uint32_t rag_merge, rag_pairs_from, rag_pairs_to;
-    Uniforms u;
-};
 
 struct Cursor {
     uint64_t k, ml, il;
@@ -2551,51 +2450,7 @@ __global__ __launch_bounds__(64) void k_rlm_state(unsigned long long *gran, cons
     for (int q = 0; q < 4; ++q) row[q] = ((unsigned long long)next_epoch << 32) | __float_as_uint(c[q]);
 }
 
-// ------------------------------------------------------------------ host side ----
-struct M2 {
-    double a, b, c, d;
-};
-M2 mul(const M2 &x, const M2 &y) { return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; }
-M2 mpow(M2 base, uint64_t e) {
-    M2 r{1, 0, 0, 1};
-    while (e) {
-        if (e & 1) r = mul(r, base);
-        base = mul(base, base);
-        e >>= 1;
-    }
-    return r;
-}
-void put(float *dst, const M2 &m) {
-    dst[0] = (float)m.a;
-    dst[1] = (float)m.b;
-    dst[2] = (float)m.c;
-    dst[3] = (float)m.d;
-}
-double norm(const M2 &m) { return std::fabs(m.a) + std::fabs(m.b) + std::fabs(m.c) + std::fabs(m.d); }
-
-// Scan basis for the companion matrix of z^2 + a1 z + a2 (see the comment above Uniforms).
-void scan_basis(double a1, double a2, M2 &T, M2 &Tinv) {
-    const double disc = a1 * a1 - 4.0 * a2;
-    const double re = -0.5 * a1;
-    double mu, nu;
-    if (disc < 0.0 && std::sqrt(-disc) * 0.5 > 1e-3) {  // complex pair rho e^(+-j theta)
-        mu = re;                                          // rho cos(theta)
-        nu = std::sqrt(-disc) * 0.5;                      // rho sin(theta)
-    } else {  // real poles (or a numerically double one): peel off the smaller pole
-        const double sq = disc > 0.0 ? std::sqrt(disc) * 0.5 : 0.0;
-        const double l1 = re + sq, l2 = re - sq;
-        mu = std::fabs(l1) < std::fabs(l2) ? l1 : l2;
-        nu = 1.0;
-    }
-    T = {1.0, -mu, 0.0, nu};
-    Tinv = {1.0, mu / nu, 0.0, 1.0 / nu};
-}
-
-using KernelFn = void (*)(const Params);
-struct Variant {
-    int R, KV, NS;
-    KernelFn filt, plain;
-};
+// ------------------------------------------------------------------ the instances ----
 #define RH_FAST(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true>, &k_rlm_fast<r, kv, ns, false>}
 #define RH_WAVE(r, kv, ns) Variant{r, kv, ns, &k_rlm_wave<r, kv, ns, true>, &k_rlm_wave<r, kv, ns, false>}
 // KV KiB of LDS per stage must hold the input span of 64*R output frames: ~R/2 vectors per lane
@@ -2665,1016 +2520,40 @@ const Variant kWave1[] = {
 #undef RH_RAGN
 #undef RH_FAST
 #undef RH_WAVE
-struct VariantTab {
-    const Variant *v;
-    size_t n;
-};
-template <size_t N>
-constexpr VariantTab tab_of(const Variant (&t)[N]) { return VariantTab{t, N}; }
-const Variant *find_variant(VariantTab tab, int R, int kv_needed, int NS) {  // smallest KV >= kv_needed
-    const Variant *best = nullptr;
-    for (size_t i = 0; i < tab.n; ++i) {
-        const Variant &v = tab.v[i];
-        if (v.R == R && v.NS == NS && v.KV >= kv_needed && (!best || v.KV < best->KV)) best = &v;
-    }
-    return best;
-}
-// Single-wave workgroups with `lds` dynamic bytes the hardware co-schedules on one CU.
-// LDS is handed out in 1 280-byte granules (160 KiB / 128), which the occupancy query does not round to:
-// measured with tools/prof_simd.py -- a 27 136-byte request fits 5 times per CU, not 6.
-constexpr uint32_t kLdsGranule = 1280, kLdsGranules = 128;
-int blocks_per_cu(const void *fn, size_t lds) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return 0;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds) != hipSuccess) return 0;
-    const int by_lds = lds ? (int)(kLdsGranules / ((lds + kLdsGranule - 1) / kLdsGranule)) : n;
-    return n < by_lds ? n : by_lds;
-}
-// Vectors (16 B = 2 stereo or 4 mono frames) per lane a stage must hold for a tile of L output frames.
-int kv_needed(uint64_t L, uint32_t F, uint32_t T, uint32_t channels) {
-    const uint64_t fb = 4ull * channels, vf = 16 / fb;
-    const uint64_t span = ((L + 1) * F) / T + 5 + (128 / fb - 2);  // i(m0+L-1) - i(m0-2) + tap + alignment to a 128-byte line
-    const uint64_t nvec = span / vf + 2;
-    return (int)((nvec + 63) / 64);
-}
-
-// One launch plan: a kernel variant with its tables.
-// k_rlm_chunk: tables for runs of 18 frames, the tile boundaries of the batch that is set, the hand-off tables.
-struct ChunkPlan {
-    int R = 18, KV = 8;                // frames per lane; KiB per chunk (stereo: 18 / 8; mono: 18 / 4: 1024 frames per chunk either way)
-    const void *fn = nullptr;          // the instance for (R, channels, KV)
-    int tabs_R = 0;                    // the R the filter tables were built for (0: none yet)
-    bool ok = false;                   // the batch that is set can take the kernel
-    Uniforms uni;
-    Tables *d_tabs = nullptr;
-    float *d_pow = nullptr;            // [R + 1][4]
-    float *d_uni = nullptr;            // `uni` as floats, for the kernel's lanes
-    uint32_t *d_mlo = nullptr;         // [n_tiles + 1]
-    float *d_look = nullptr;           // [n_tiles][J][4]
-    unsigned long long *d_halo = nullptr;  // [n_tiles][8]
-    unsigned long long *d_gran = nullptr;  // [n_tiles][4]
-    size_t cap_tiles = 0, cap_look = 0;
-    uint32_t n_tiles = 0, J = 0, frames = 0;
-    int resident_per_cu = 0;
-    bool direct = true;
-};
-struct Plan {
-    const Variant *v = nullptr;
-    const void *kernel = nullptr;
-    bool general = false;
-    uint32_t J = 0, lds_bytes = 0;
-    int resident_per_cu = 0;
-    Uniforms uni;
-    Tables *d_tabs = nullptr;
-};
-
 }  // namespace
 
-struct rh_rlm {
-    rh_rlm_config cfg;
-    uint32_t F, T;
-    uint64_t chunk_in, chunk_out;  // chunk_out == 0: unchunked
-    bool filt;
-    float coeffs[5];
-    Plan fast, wave;        // equal-length batches / ragged batches
-    Plan pair;              // ragged filtered one-shot batches: k_rlm_fast<RAG> (v->filt) + k_rlm_resid (v->plain); v == nullptr: none
-    Plan *plan = nullptr;   // chosen by set_sources
-    uint32_t launch_lds = 0;  // lds_bytes, padded so that a CU admits exactly ceil(tiles/CUs) waves
-    uint32_t rag_frames = 0;  // pair plan: the length of the sources that last as long as the mix
-    uint32_t rag_pairs_from = 0, rag_pairs_to = 0;  // ... and the output frames between which the other sources end
-    uint32_t eq_frames = 0;
-    bool equal = true;
-    std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
-    SrcDesc *d_srcs = nullptr;
-    unsigned long long *d_gran = nullptr;
-    size_t gran_words = 0;
-    uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status, [2] late carries, [3] empty polls
-    float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
-    size_t mix_floats = 0;
-    ChunkPlan chunk;            // mix first in one kernel (k_rlm_chunk)
-    bool pre_filter = false;    // cfg.filter_first: the filter runs at from_rate in front of the converter (the fused kernels then run without one)
-    float pre_coeffs[5] = {1.f, 0.f, 0.f, 0.f, 0.f};
-    unsigned long long *d_prof = nullptr;
-    uint32_t n_sources = 0, n_tiles = 0;
-    uint64_t out_frames = 0;
-    uint32_t epoch = 0;
-    uint32_t ticket_base = 0;
-    uint32_t shard_base = 0;  // batch mode with sharded ticket counters (d_ctl + 32*(1+x)): tickets each of them has handed out
-    // block streaming (rh_rlm_stream_*)
-    bool st_on = false, st_done = false;
-    uint64_t st_g0 = 0, st_m = 0;
-    uint64_t st_chunk_in = 0, st_chunk_out = 0;  // a stream of spanned sources: input / output frames per span (0: continuous)
-    uint32_t st_nsrc = 0;
-    float *d_w[2] = {nullptr, nullptr};
-    int st_cur = 0;
-    std::vector<SrcDesc> h_desc;  // host copy of the descriptor table
-    // Block streaming uploads a descriptor table per block while earlier blocks may still be queued: the copies go through
-    // a ring of page-locked tables, and a table is rewritten only after the copy that read it has run (an asynchronous
-    // copy from pageable memory may read its source later than the call -- seen as a block mixed with the next block's
-    // descriptors when the device was busy).
-    static constexpr int kDescRing = 4;
-    SrcDesc *h_ring[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t h_ring_ev[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
-    int h_ring_next = 0;
-    std::vector<float> gains;     // per-source Amplify factors (1.0 when unset)
-    // block streaming with per-source states (rh_rlm_stream_block_v)
-    std::vector<uint64_t> st_total;  // input frames of a source that has ended (~0: still live)
-    uint32_t st_cols = 0;            // columns of an aggregate row for the stream (0: no such stream yet)
-    // rh_rlm_stream_block_v while its sources RUN TOGETHER (all live, equal frames per block): the summed state of
-    // rh_rlm_stream_block -- so the block is summed first -- until a source ends or falls behind.  Then the per-source states are
-    // recovered from the rows of the block before (rh_rlm_stream_keep_history: the caller has kept them) and the stream goes on
-    // with one state per source.
-    bool st_history = false;     // rh_rlm_stream_keep_history
-    bool st_together = false;    // the stream still runs on the summed state
-    bool st_dirty = false;       // rh_rlm_stream_block_v has touched the stream's state in this call (an error then ends the stream)
-    bool st_decided = false;     // ... or has decided not to
-    std::vector<const float *> st_prev_ptrs;  // the block before: its rows,
-    uint64_t st_prev_avail = 0, st_prev_g0 = 0, st_prev_m = 0, st_prev_out = 0;  // frames per row, global index of frame 0, first output frame, output frames
-    float *d_replay = nullptr;   // where the recovery's replay of the last tiles writes its (unused) mix
-    size_t replay_floats = 0;
-    uint32_t st_n_summed = 0, st_n_each = 0, st_n_recover = 0;  // rh_rlm_stream_stats
-    // Recorded (by wait_idle) behind what the handle has queued.  The library's streams are hipStreamNonBlocking: a null-stream
-    // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
-    // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
-    hipEvent_t idle_ev = nullptr;
-    bool launched = false;
-    hipStream_t last_stream = nullptr;  // the stream of the launches idle_ev covers
-    // rh_rlm_set_exclusive: may a launch assume that nothing else occupies CUs while it runs?  Only then does a launch whose tiles
-    // all fit at once take tile = workgroup index (Params::direct); otherwise tiles are handed out by ticket, which needs neither
-    // residency nor in-order dispatch: a tile only ever waits for tiles that already hold a wave slot.
-    bool exclusive = true;
-    bool mix_first_on = true;  // rh_rlm_set_mix_first
-    // rh_rlm_set_filters: a filter per source.  Sources of one (kind, freq, q) form a CLASS; every class is a handle of its own
-    // (`cls[c].h`, this handle's configuration with that filter) holding the class's sources in insertion order, so that each
-    // class keeps everything a one-filter batch has -- mix first where its sources share a length, the ragged pair, the ordered
-    // sum where it has no filter -- and the classes' mixes are summed in order of first appearance.
-    struct FilterSpec {
-        int32_t kind;
-        uint32_t freq;
-        float q;
-        bool operator==(const FilterSpec &o) const { return kind == o.kind && (kind < 0 || (freq == o.freq && q == o.q)); }
-    };
-    struct FilterClass {
-        FilterSpec spec;
-        rh_rlm *h = nullptr;
-        std::vector<uint32_t> members;  // indices into the parent's source list
-        uint64_t out_frames = 0;
-    };
-    std::vector<FilterSpec> filters;  // per source; empty: the handle's one filter
-    std::vector<FilterClass> cls;     // classes of the sources that are set (empty: one filter, this handle runs itself)
-    float *d_cls_rows = nullptr;      // [classes][row] partial mixes
-    size_t cls_row_floats = 0, cls_rows = 0;
-    // RH_CLASSES_SIDE_BY_SIDE=1 (a measured alternative, slower: see run_classes): the classes' launches side by side -- class 0 on the caller's
-    // stream, the others on streams of the handle's, forked from and joined to the caller's by events
-    std::vector<hipStream_t> cls_streams;
-    std::vector<hipEvent_t> cls_done;
-    hipEvent_t cls_fork = nullptr;
-};
+namespace rhp {
 
-namespace {
-
-// Every live handle, for rh::rlm_stream_retired (rh_stream_destroy / rh_stream_release_scratch call it after they have
-// synchronised the stream): a handle whose last launches went to a stream that is about to go must not record an event on it later.
-std::mutex g_handles_mu;
-std::vector<rh_rlm *> g_handles;
-
-// Block until every launch of this handle has completed.  The event is recorded HERE, behind everything the handle has queued on
-// its stream (streams run in order), not behind every launch: a launch costs no API call and no marker on the device for it.
-// The stream may be gone by now if it was a caller's own (a PyTorch stream destroyed behind the library's back; the library's
-// streams tell the handle when they go): the record then fails, and the whole device is waited for instead.  Either way the handle
-// comes out idle -- a failure here must not wedge every later set_sources / set_gains / stream_begin.
-rh_status wait_idle(rh_rlm *p) {
-    if (p->launched) {
-        hipError_t e = hipSuccess;
-        if (!p->idle_ev) e = hipEventCreateWithFlags(&p->idle_ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(p->idle_ev, p->last_stream);
-        if (e == hipSuccess) e = hipEventSynchronize(p->idle_ev);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();  // (the sticky error of the failed record)
-            e = hipDeviceSynchronize();
-        }
-        p->launched = false;
-        p->last_stream = nullptr;
-        if (e != hipSuccess) {
-            rh::set_hip_error(e, "wait_idle");
-            return RH_ERR_HIP;
-        }
+VariantTab variant_tab(TabKind kind, bool mono) {
+    switch (kind) {
+    case kTabFast: return mono ? tab_of(kFast1) : tab_of(kFast);
+    case kTabWave: return mono ? tab_of(kWave1) : tab_of(kWave);
+    default: return mono ? tab_of(kRag1) : tab_of(kRag);
     }
-    return RH_OK;
-}
-// In front of the first kernel of a launch on `s`: a handle that moves to another stream waits for what it queued on the old one
-// BEFORE anything is queued on the new one (the kernels of the two streams would otherwise share d_gran / d_ctl / d_mix).
-rh_status pre_launch(rh_rlm *p, hipStream_t s) {
-    if (p->launched && p->last_stream != s) return wait_idle(p);
-    return RH_OK;
-}
-rh_status mark_launch(rh_rlm *p, hipStream_t s) {
-    p->launched = true;
-    p->last_stream = s;
-    return RH_OK;
 }
 
-// Predecessor tiles a tile of L frames has to look back at: ||B^(L*J)|| < 2^-40 (older history is
-// below f32 resolution of the state); 0 = pole radius too close to 1 for this tile length.
-uint32_t look_tiles(const M2 &B, uint64_t L) {
-    const M2 BL = mpow(B, L);
-    M2 cur = BL;
-    for (uint32_t j = 1; j <= (uint32_t)kMaxLook; ++j) {
-        if (norm(cur) < 0x1p-40) return j;
-        cur = mul(cur, BL);
-    }
-    return 0;
-}
-size_t lds_bytes_of(const Variant &v, bool general, uint32_t J) {
-    size_t n = (size_t)v.NS * v.KV * 1024;
-    if (general) n += 128 + 32 + kMaxLook * 16 + (size_t)((J + 3) / 4) * 1024;
-    return n;
+const void *chunk_kernel(int R, uint32_t channels, int KV) {
+    if (channels == 2 && R == 9 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk<9, 2, 4>);
+    if (channels == 2 && R == 18 && KV == 8) return reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 8>);
+    if (channels == 2 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 4>);
+    if (channels == 1 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 4>);
+    if (channels == 1 && R == 18 && KV == 2) return reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 2>);
+    return nullptr;
 }
 
-// Geometry + tables of one plan.  One wave per tile of L = 64*R output frames; the cost of a geometry
-// is the most loaded SIMD: ceil(waves per CU / 4) waves, each issuing `per_frame` instructions per
-// frame + `per_source` per source one after the other; the issue interval falls with occupancy
-// (measured, tools/ubench/valu_rate.hip: 4.3 / 3.0 / 2.7 cycles per wave-instruction at 1 / 2 / 4
-// waves per SIMD).
-rh_status make_plan(rh_rlm *p, Plan &pl, VariantTab tab, bool general, const rh::ResampleGeom &g, uint32_t want_R, uint32_t want_NS) {
-    const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
-    M2 Tm, Ti;
-    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
-    const M2 B = mul(mul(Tm, A), Ti);
-    const uint64_t M = g.out_frames ? g.out_frames : 1;
-    const int cus = rh::g_num_cus;
-    const double per_frame = 19.0, per_source = general ? 170.0 : 50.0;
-    double best = 1e300;
-    const Variant *bestV = nullptr;
-    uint32_t bestJ = 0;
-    for (int R = 1; R <= kMaxR; ++R) {
-        if (want_R && (int)want_R != R) continue;
-        const uint64_t L = 64ull * R;
-        const uint32_t Jr = p->filt ? look_tiles(B, L) : 1;
-        if (Jr == 0) continue;
-        const uint64_t tiles = (M + L - 1) / L;
-        const uint64_t per_cu = (tiles + cus - 1) / cus;
-        for (int NS = 2; NS <= 4; ++NS) {
-            if (want_NS && (int)want_NS != NS) continue;
-            const Variant *v = find_variant(tab, R, kv_needed(L, g.F, g.T, p->cfg.channels), NS);
-            if (!v) continue;
-            const void *fn = reinterpret_cast<const void *>(p->filt ? v->filt : v->plain);
-            const int resident = blocks_per_cu(fn, lds_bytes_of(*v, general, Jr));
-            if (resident < 1) continue;
-            // tiles beyond the resident set only start when earlier ones finish: legal, but they
-            // run as a second pass
-            const double passes = std::ceil((double)per_cu / resident);
-            const uint64_t on_cu = std::min<uint64_t>(per_cu, resident);
-            const double w = std::ceil(on_cu / 4.0);  // waves on the most loaded SIMD
-            const double issue = 2.6 + 1.7 / std::pow(w, 1.5);
-            double cost = passes * w * (per_frame * R + per_source) * issue;
-            cost *= 1.0 + 0.01 * NS;  // among equals prefer the shallower ring (less LDS)
-            if (general && R < 8) cost *= 1.3;  // measured: the per-source scan and hand-off want the longer runs
-            if (cost < best) {
-                best = cost;
-                bestV = v;
-                bestJ = Jr;
-            }
-        }
-    }
-    if (!bestV) return RH_ERR_UNSUPPORTED;
-    pl.v = bestV;
-    pl.general = general;
-    pl.kernel = reinterpret_cast<const void *>(p->filt ? bestV->filt : bestV->plain);
-    pl.J = p->filt ? bestJ : 0;
-    pl.lds_bytes = (uint32_t)lds_bytes_of(*bestV, general, bestJ);
-    pl.resident_per_cu = blocks_per_cu(pl.kernel, pl.lds_bytes);
-    // ---- tables (all powers of B = Tm A Tm^-1 are taken in f64 on the host and rounded to f32 once)
-    Tables *h = new Tables();
-    std::memset(h, 0, sizeof(Tables));
-    Uniforms &U = pl.uni;
-    std::memset(&U, 0, sizeof(U));
-    U.b0 = p->coeffs[0];
-    U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
-    U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
-    U.a1 = p->coeffs[3];
-    U.a2 = p->coeffs[4];
-    put(U.Tm, Tm);
-    const uint64_t R = bestV->R, L = 64ull * bestV->R;
-    for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, R << k));
-    for (int r = 0; r < bestV->R; ++r) {
-        const M2 m = mul(mpow(A, r + 1), Ti);  // w[r] = row 0 of A^(r+1) applied to the companion state Ti*z
-        U.g[r][0] = (float)m.a;
-        U.g[r][1] = (float)m.b;
-    }
-    for (int l = 0; l < 64; ++l) {
-        put(h->laneM[l], mpow(B, R * l));
-        put(h->bc15M[l], mpow(B, R * ((l & 15) + 1)));
-        put(h->bc31M[l], mpow(B, R * ((l & 31) + 1)));
-    }
-    {
-        const M2 BL = mpow(B, L);
-        M2 cur{1, 0, 0, 1};
-        for (int j = 0; j < kMaxLook; ++j) {
-            put(h->lookM[j], cur);
-            cur = mul(cur, BL);
-        }
-    }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.d_tabs), sizeof(Tables));
-    if (e == hipSuccess) e = hipMemcpy(pl.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
-    delete h;
-    if (e != hipSuccess) {
-        rh::set_hip_error(e, "rh_rlm_create tables");
-        return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
-    }
-    return RH_OK;
+void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch) {
+    hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, s, gran, tabs, n_sources, cols, last_col, J, epoch, next_epoch);
 }
 
-// k_rlm_chunk for the batch that is set (equal lengths): tile boundaries, look-back weights, residency.  Leaves chunk.ok false
-// where the kernel does not apply -- the two-kernel form of mix first (or the per-source kernel) runs instead.
-rh_status build_chunk(rh_rlm *p) {
-    ChunkPlan &c = p->chunk;
-    c.ok = false;
-    constexpr uint64_t H = 4;
-    const uint32_t C = p->cfg.channels;
-    if (!p->filt || !p->equal || p->cfg.force_general || p->n_sources < 2 || rh::knob(rh::K_NO_CHUNK) || rh::knob(rh::K_NO_MIX_FIRST)) return RH_OK;
-    // The instances, in the order they are tried: chunks of 1024 frames in runs of 18 (stereo: 8 KiB, mono: 4 KiB), then chunks of
-    // 512 frames in runs of 18 for converters that make more than 1152 frames of 1024 (ratios up to 2.25: 22.05 -> 48 kHz).
-    // RH_CHUNK_HALF (a tuning aid): stereo chunks of 512 frames in runs of 9.
-    struct Inst {
-        int R, KV;
-        const void *fn;
-    };
-    std::vector<Inst> cand;
-    if (C == 2 && rh::knob(rh::K_CHUNK_HALF)) cand.push_back({9, 4, reinterpret_cast<const void *>(&k_rlm_chunk<9, 2, 4>)});
-    if (C == 2) {
-        cand.push_back({18, 8, reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 8>)});
-        cand.push_back({18, 4, reinterpret_cast<const void *>(&k_rlm_chunk<18, 2, 4>)});
-    } else {
-        cand.push_back({18, 4, reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 4>)});
-        cand.push_back({18, 2, reinterpret_cast<const void *>(&k_rlm_chunk<18, 1, 2>)});
-    }
-    const uint64_t Ns = p->eq_frames, M = p->out_frames;
-    if (Ns < 2 || (Ns * C) % 4 != 0 || M == 0) return RH_OK;  // (whole 16-byte vectors)
-    // the input frame of an output frame (cursor_at / cursor_resolve, and the verbatim last frame)
-    const uint64_t F = p->F, T = p->T, cin = p->chunk_in, cout = p->chunk_out;
-    auto in_index = [&](uint64_t m) -> uint64_t {
-        const uint64_t k = cout ? m / cout : 0, ml = m - k * cout;
-        uint64_t il = ml * F / T;
-        if (cout && il + 1 >= cin) il = cin - 1;
-        const uint64_t i = k * cin + il;
-        return i + 1 >= Ns ? Ns - 1 : i;
-    };
-    std::vector<uint32_t> mlo;
-    uint64_t tiles = 0, n_min = ~0ull;
-    int R = 0, KV = 0;
-    const void *fn = nullptr;
-    for (const Inst &in : cand) {
-        const uint64_t P = (uint64_t)in.KV * 1024 / (4 * C);
-        tiles = (Ns + P - 1) / P;
-        if (tiles < 2ull * (uint64_t)rh::g_num_cus || tiles > 0x3fffffffull) continue;  // short rows: more, smaller pieces fill the chip better
-        mlo.assign((size_t)tiles + 1, 0u);
-        for (uint64_t t = 1; t < tiles; ++t) {  // the first frame whose second tap lies in chunk t or behind it
-            uint64_t lo = mlo[(size_t)t - 1], hi = M;
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) / 2;
-                if (in_index(mid) + 1 >= t * P) hi = mid;
-                else lo = mid + 1;
-            }
-            mlo[(size_t)t] = (uint32_t)lo;
-        }
-        mlo[(size_t)tiles] = (uint32_t)M;
-        bool fits = true;
-        n_min = ~0ull;
-        for (uint64_t t = 0; t < tiles && fits; ++t) {
-            const uint64_t n = mlo[(size_t)t + 1] - mlo[(size_t)t];
-            if (n == 0 || n > 64ull * in.R) fits = false;  // a ratio that puts more frames into a chunk than 64 runs hold (or none)
-            if (t + 1 < tiles) n_min = std::min(n_min, n);
-            if (t > 0 && fits) {  // the two frames the filter looks back at, and the first tap of the first frame: in the 4 frames in front of the chunk
-                const uint64_t m = mlo[(size_t)t];
-                if (m < 2 || in_index(m - 2) + H < t * P || in_index(m) + 1 < t * P) fits = false;
-            }
-        }
-        if (fits) {
-            R = in.R, KV = in.KV, fn = in.fn;
-            break;
-        }
-    }
-    if (!fn) return RH_OK;
-    if (c.fn != fn) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0) != hipSuccess) return RH_OK;
-        c.resident_per_cu = n < 1 ? -1 : n;
-        c.fn = fn;
-        c.R = R;
-        c.KV = KV;
-    }
-    if (c.resident_per_cu < 1) return RH_OK;
-    c.direct = tiles <= (uint64_t)rh::g_num_cus * (uint64_t)c.resident_per_cu;  // every tile resident at once: no tickets
-    const M2 A{-(double)p->coeffs[3], -(double)p->coeffs[4], 1.0, 0.0};
-    M2 Tm, Ti;
-    scan_basis((double)p->coeffs[3], (double)p->coeffs[4], Tm, Ti);
-    const M2 B = mul(mul(Tm, A), Ti);
-    const uint32_t J = look_tiles(B, n_min);
-    if (J == 0 || J > 32) return RH_OK;
-    if ((uint64_t)tiles * J * 16 > (64ull << 20)) return RH_OK;  // (the per-tile look-back table: a filter that forgets slowly over very long rows)
-    {
-        const rh_status w = wait_idle(p);  // an earlier run may still read the tables
-        if (w != RH_OK) return w;
-    }
-    if (c.tabs_R != R) {
-        if (c.d_tabs) RH_HIP_TRY(hipFree(c.d_tabs));
-        if (c.d_pow) RH_HIP_TRY(hipFree(c.d_pow));
-        if (c.d_uni) RH_HIP_TRY(hipFree(c.d_uni));
-        c.d_tabs = nullptr, c.d_pow = nullptr, c.d_uni = nullptr, c.tabs_R = 0;
-        Tables *h = new Tables();
-        std::memset(h, 0, sizeof(Tables));
-        Uniforms &U = c.uni;
-        std::memset(&U, 0, sizeof(U));
-        U.b0 = p->coeffs[0];
-        U.c1 = (float)((double)p->coeffs[1] - (double)p->coeffs[0] * (double)p->coeffs[3]);
-        U.c2 = (float)((double)p->coeffs[2] - (double)p->coeffs[0] * (double)p->coeffs[4]);
-        U.a1 = p->coeffs[3];
-        U.a2 = p->coeffs[4];
-        put(U.Tm, Tm);
-        for (int k = 0; k < 4; ++k) put(U.scanM[k], mpow(B, (uint64_t)R << k));
-        for (int r = 0; r < R; ++r) {
-            const M2 m = mul(mpow(A, r + 1), Ti);
-            U.g[r][0] = (float)m.a;
-            U.g[r][1] = (float)m.b;
-        }
-        for (int l = 0; l < 64; ++l) {
-            put(h->laneM[l], mpow(B, (uint64_t)R * l));
-            put(h->bc15M[l], mpow(B, (uint64_t)R * ((l & 15) + 1)));
-            put(h->bc31M[l], mpow(B, (uint64_t)R * ((l & 31) + 1)));
-        }
-        float pw[kMaxR + 1][4];
-        std::memset(pw, 0, sizeof(pw));
-        for (int v = 0; v <= R; ++v) put(pw[v], mpow(B, (uint64_t)v));
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&c.d_tabs), sizeof(Tables));
-        if (e == hipSuccess) e = hipMemcpy(c.d_tabs, h, sizeof(Tables), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.d_pow), sizeof(pw));
-        if (e == hipSuccess) e = hipMemcpy(c.d_pow, pw, sizeof(pw), hipMemcpyHostToDevice);
-        static_assert(offsetof(Uniforms, Tm) == 20 && offsetof(Uniforms, scanM) == 36 && offsetof(Uniforms, g) == 100, "the kernel reads the Uniforms by float index");
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c.d_uni), sizeof(Uniforms));
-        if (e == hipSuccess) e = hipMemcpy(c.d_uni, &U, sizeof(Uniforms), hipMemcpyHostToDevice);
-        delete h;
-        if (e != hipSuccess) {
-            rh::set_hip_error(e, "k_rlm_chunk tables");
-            return e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
-        }
-        c.tabs_R = R;
-    }
-    if ((size_t)tiles > c.cap_tiles) {
-        if (c.d_mlo) RH_HIP_TRY(hipFree(c.d_mlo));
-        if (c.d_halo) RH_HIP_TRY(hipFree(c.d_halo));
-        if (c.d_gran) RH_HIP_TRY(hipFree(c.d_gran));
-        c.d_mlo = nullptr, c.d_halo = nullptr, c.d_gran = nullptr, c.cap_tiles = 0;
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_mlo), ((size_t)tiles + 1) * 4));
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_halo), (size_t)tiles * 64));
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_gran), (size_t)tiles * 32));
-        RH_HIP_TRY(rh::fill_now(c.d_halo, 0, (size_t)tiles * 64));  // tag 0 = never written (launch tags start at 1)
-        RH_HIP_TRY(rh::fill_now(c.d_gran, 0, (size_t)tiles * 32));
-        c.cap_tiles = (size_t)tiles;
-    }
-    const size_t look_floats = (size_t)tiles * J * 4;
-    if (look_floats > c.cap_look) {
-        if (c.d_look) RH_HIP_TRY(hipFree(c.d_look));
-        c.d_look = nullptr, c.cap_look = 0;
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_look), look_floats * 4));
-        c.cap_look = look_floats;
-    }
-    std::vector<float> look(look_floats, 0.0f);
-    {
-        // B^d for the few distances that occur (tiles of n_min or n_min + 1 frames, seams aside): memoised
-        std::unordered_map<uint64_t, M2> memo;
-        for (uint64_t t = 1; t < tiles; ++t)
-            for (uint32_t j = 0; j < J && j < t; ++j) {
-                const uint64_t d = (uint64_t)mlo[(size_t)t] - mlo[(size_t)(t - j)];
-                auto it = memo.find(d);
-                if (it == memo.end()) it = memo.emplace(d, mpow(B, d)).first;
-                put(&look[((size_t)t * J + j) * 4], it->second);
-            }
-    }
-    RH_HIP_TRY(hipMemcpy(c.d_mlo, mlo.data(), mlo.size() * 4, hipMemcpyHostToDevice));
-    RH_HIP_TRY(hipMemcpy(c.d_look, look.data(), look_floats * 4, hipMemcpyHostToDevice));
-    c.n_tiles = (uint32_t)tiles;
-    c.J = J;
-    c.frames = (uint32_t)Ns;
-    c.ok = true;
-    return RH_OK;
-}
-
-// Can the batch that is set take the kernel pair in the tile geometry of `pl`?  (1) the sources that last as long as the
-// mix share one length (the lean kernel's end-of-source handling is uniform) and (2) no tile holds many sources that are
-// about to end (k_rlm_resid takes a tile's pairs one after the other; batches whose sources all end within a few frames of
-// each other stay with k_rlm_wave).
-bool pair_ok(rh_rlm *p, const Plan &pl) {
-    if (!pl.v || !p->filt || p->equal || p->cfg.force_general || p->h_desc.size() != p->n_sources || rh::knob(rh::K_NO_HYBRID)) return false;
-    const uint64_t M = p->out_frames, L = 64ull * pl.v->R, J = pl.J;
-    const uint64_t tiles = (M + L - 1) / L;
-    if (!tiles) return false;
-    uint32_t frames_of_longest = 0, most = 0, ends_from = 0xffffffffu, ends_to = 0;
-    std::vector<uint32_t> pairs((size_t)tiles, 0u);
-    for (const SrcDesc &d : p->h_desc) {
-        if (d.out_frames == M) {
-            if (frames_of_longest && frames_of_longest != d.frames) return false;
-            frames_of_longest = d.frames;
-        } else if (d.out_frames > 0) {
-            ends_from = std::min(ends_from, d.out_frames);
-            ends_to = std::max(ends_to, d.out_frames);
-            const uint64_t t_end = (d.out_frames - 1) / L;                                              // the tile the source ends in
-            const uint64_t t_lo = (uint64_t)d.out_frames / L > J ? (uint64_t)d.out_frames / L - J : 0;  // first tile with out_frames < (t+1+J)*L
-            for (uint64_t t = t_lo; t <= t_end && t < tiles; ++t) most = std::max(most, ++pairs[(size_t)t]);
-        }
-    }
-    if (!frames_of_longest || most > 24) return false;
-    p->rag_frames = frames_of_longest;
-    p->rag_pairs_from = ends_from;
-    p->rag_pairs_to = ends_to;
-    return true;
-}
-
-// Point the handle at a plan for the current batch: grid, aggregate table, LDS request.
-rh_status activate_plan(rh_rlm *p, Plan *pl) {
-    const uint64_t M = p->out_frames;
-    const uint64_t L = 64ull * pl->v->R;
-    const uint64_t tiles = (M + L - 1) / L;
-    if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    const size_t words = (size_t)(p->n_sources + 1) * (tiles + 1) * 4;  // per (source, tile): general kernel (+ its row of summed aggregates) and batch mode; +1: streaming's end-state tile
-    if (p->filt && words > p->gran_words) {
-        {
-            const rh_status w = wait_idle(p);  // a queued launch may still read the old table
-            if (w != RH_OK) return w;
-        }
-        if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
-        p->d_gran = nullptr;
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
-        RH_HIP_TRY(rh::fill_now(p->d_gran, 0, words * 8));  // epoch 0 never matches a run
-        p->gran_words = words;
-    }
-#ifdef RH_PHASE_PROFILE
-    if (p->d_prof) RH_HIP_TRY(hipFree(p->d_prof));
-    p->d_prof = nullptr;
-    RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_prof), (tiles + 1) * 64));
-    RH_HIP_TRY(rh::fill_now(p->d_prof, 0, (tiles + 1) * 64));
-#endif
-    // The most loaded CU sets the pace: pad the LDS request until the dispatcher cannot put more
-    // than ceil(tiles/CUs) waves on any CU.
-    p->launch_lds = pl->lds_bytes;
-    if (tiles > 0 && !p->cfg.no_balance) {
-        const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
-        if ((int)per_cu <= pl->resident_per_cu) {
-            uint32_t want = (uint32_t)(kLdsGranules / per_cu) * kLdsGranule;  // whole granules: exactly per_cu fit
-            if (want > 64u * 1024u) want = 64u * 1024u;
-            while (want > pl->lds_bytes && blocks_per_cu(pl->kernel, want) < (int)per_cu) want -= kLdsGranule;
-            if (want > pl->lds_bytes) p->launch_lds = want;
-        }
-    }
-    p->plan = pl;
-    p->n_tiles = (uint32_t)tiles;
-    return RH_OK;
-}
-
-}  // namespace
-
-namespace rh {
-// `s` has been synchronised and is about to be destroyed (or its scratch released): handles whose launches went there are idle.
-void rlm_stream_retired(hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_handles_mu);
-    for (rh_rlm *p : g_handles)
-        if (p->launched && p->last_stream == s) {
-            p->launched = false;
-            p->last_stream = nullptr;
-        }
-}
-}  // namespace rh
-
-extern "C" {
-
-rh_status rh_rlm_create(rh_rlm **out, const rh_rlm_config *cfg) {
-    RH_REQUIRE_INIT();
-    if (!out || !cfg || cfg->from_rate == 0 || cfg->to_rate == 0 || cfg->channels == 0 || cfg->max_sources == 0) return RH_ERR_INVALID;
-    if (cfg->channels != 1 && cfg->channels != 2) return RH_ERR_UNSUPPORTED;  // mono and stereo frames inside the fused kernels; other layouts: rh_channels_convert / rh_uniform_segments in front
-    // from_rate == to_rate: the converter passes through (sample_rate.rs:133-136): filter + ordered mix only
-    if (cfg->max_in_frames >= (1ull << 29)) return RH_ERR_UNSUPPORTED;  // 32-bit byte offsets inside a source
-    rh::ResampleGeom g;
-    rh_status st = rh::make_resample_geom(cfg->max_in_frames, cfg->from_rate, cfg->to_rate, cfg->channels, cfg->span_len, &g);
-    if (st != RH_OK) return st;
-    if (2ull * g.F > 9ull * g.T) return RH_ERR_UNSUPPORTED;  // staging is sized for ratios <= 4.5: 192 kHz -> 44.1 kHz (the unfused ops cover the rest)
-    if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
-    rh_rlm *p = new rh_rlm();
-    p->cfg = *cfg;
-    p->F = g.F;
-    p->T = g.T;
-    p->chunk_in = g.n_chunks > 1 ? g.chunk_in : 0;
-    p->chunk_out = g.n_chunks > 1 ? g.chunk_out : 0;
-    p->filt = cfg->filter_kind >= 0;
-    if (cfg->filter_first && p->filt) {  // mixer.add(src.low_pass(f)): coefficients at the SOURCE rate; the converter behind it runs bare
-        if (cfg->filter_kind == 2) {
-            for (int k = 0; k < 5; ++k) p->pre_coeffs[k] = cfg->custom_coeffs[k];
-        } else {
-            st = rh_biquad_coeffs(cfg->filter_kind, cfg->filter_freq, cfg->filter_q, cfg->from_rate, p->pre_coeffs);
-            if (st != RH_OK) {
-                delete p;
-                return st;
-            }
-        }
-        p->pre_filter = true;
-        p->filt = false;
-    }
-    if (p->pre_filter) {
-        p->coeffs[0] = 1.f;
-        p->coeffs[1] = p->coeffs[2] = p->coeffs[3] = p->coeffs[4] = 0.f;
-    } else if (cfg->filter_kind == 2) {  // coefficients given ({b0,b1,b2,a1,a2}, already divided by a0)
-        for (int k = 0; k < 5; ++k) p->coeffs[k] = cfg->custom_coeffs[k];
-        const double a1 = p->coeffs[3], a2 = p->coeffs[4];  // stability triangle: the look-back needs a decaying filter
-        if (!(std::fabs(a2) < 1.0 && std::fabs(a1) < 1.0 + a2)) {
-            delete p;
-            return RH_ERR_UNSUPPORTED;
-        }
-    } else if (p->filt) {
-        st = rh_biquad_coeffs(cfg->filter_kind, cfg->filter_freq, cfg->filter_q, cfg->to_rate, p->coeffs);
-        if (st != RH_OK) {
-            delete p;
-            return st;
-        }
-    } else {
-        p->coeffs[0] = 1.f;
-        p->coeffs[1] = p->coeffs[2] = p->coeffs[3] = p->coeffs[4] = 0.f;
-    }
-    // two plans: equal-length batches (k_rlm_fast) and ragged ones (k_rlm_wave).  The geometry
-    // overrides of the config address the fast plan; the general plan follows them when it can.
-    const bool mono = cfg->channels == 1;
-    const VariantTab t_fast = mono ? tab_of(kFast1) : tab_of(kFast), t_wave = mono ? tab_of(kWave1) : tab_of(kWave);
-    st = make_plan(p, p->fast, t_fast, false, g, cfg->frames_per_lane, cfg->ring_stages);
-    if (st == RH_ERR_UNSUPPORTED && mono && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->fast, t_fast, false, g, 0, 0);  // (fewer mono tile sizes are built)
-    if (st == RH_OK) {
-        st = make_plan(p, p->wave, t_wave, true, g, cfg->frames_per_lane, cfg->ring_stages);
-        if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) st = make_plan(p, p->wave, t_wave, true, g, 0, 0);
-    } else if (st == RH_ERR_UNSUPPORTED && (cfg->frames_per_lane || cfg->ring_stages)) {
-        st = RH_ERR_INVALID;
-    }
-    if (st == RH_OK && p->filt) {  // optional.  It follows the overrides when it has that geometry; otherwise the longest runs that
-        // still give every CU three tiles (measured on 256 sources of [N/2, N] frames: 0.366 / 0.352 / 0.336 / 0.328 / 0.319 / 0.319 ms for
-        // 6 / 8 / 10 / 12 / 14 / 18 frames per lane -- the first half sums first, so a tile's fixed costs are all that is left to amortise)
-        rh_status ps = RH_ERR_UNSUPPORTED;
-        if (cfg->frames_per_lane || cfg->ring_stages) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, cfg->frames_per_lane, cfg->ring_stages);
-        for (uint32_t R : {18u, 14u, 12u, 10u}) {
-            if (ps == RH_OK) break;
-            const uint64_t M = g.out_frames ? g.out_frames : 1, tiles = (M + 64ull * R - 1) / (64ull * R);
-            if (tiles >= 3ull * (uint64_t)rh::g_num_cus) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, R, 2);
-        }
-        if (ps != RH_OK) ps = make_plan(p, p->pair, (mono ? tab_of(kRag1) : tab_of(kRag)), false, g, 0, 0);
-        if (ps != RH_OK) p->pair.v = nullptr;
-    }
-    hipError_t e = hipSuccess;
-    if (st == RH_OK) {
-        e = hipMalloc(reinterpret_cast<void **>(&p->d_srcs), sizeof(SrcDesc) * cfg->max_sources);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_ctl), 128 * 9);  // control words + 8 ticket counters on their own cache lines
-        if (e == hipSuccess) e = rh::fill_now(p->d_ctl, 0, 128 * 9);  // the ticket counter: a late fill would renumber tiles in mid-launch
-        if (e != hipSuccess) {
-            rh::set_hip_error(e, "rh_rlm_create");
-            st = e == hipErrorOutOfMemory ? RH_ERR_NOMEM : RH_ERR_HIP;
-        }
-    }
-    if (st != RH_OK) {
-        rh_rlm_destroy(p);
-        return st;
-    }
-    p->plan = &p->fast;
-    {
-        std::lock_guard<std::mutex> lk(g_handles_mu);
-        g_handles.push_back(p);
-    }
-    *out = p;
-    return RH_OK;
-}
-
-rh_status rh_rlm_set_exclusive(rh_rlm *p, int32_t exclusive) {
-    if (!p) return RH_ERR_INVALID;
-    p->exclusive = exclusive != 0;
-    return RH_OK;
-}
-
-rh_status rh_rlm_set_mix_first(rh_rlm *p, int32_t enable) {
-    if (!p) return RH_ERR_INVALID;
-    p->mix_first_on = enable != 0;
-    return RH_OK;
-}
-
-rh_status rh_rlm_destroy(rh_rlm *p) {
-    if (!p) return RH_OK;
-    (void)wait_idle(p);  // nothing of this handle may still run when its tables go
-    {
-        std::lock_guard<std::mutex> lk(g_handles_mu);
-        g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), p), g_handles.end());
-    }
-#if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 3
-    if (p->d_ctl && p->chunk.ok) {
-        uint32_t h[8] = {0};
-        (void)hipMemcpy(h, p->d_ctl + 8, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "chunk phases (cycles summed over tiles and launches): image+halo %u  run %u  scan+publish %u  look-back %u  correction+stores %u\n", h[0], h[1], h[2], h[3], h[4]);
-    }
-#endif
-    for (rh_rlm::FilterClass &c : p->cls)
-        if (c.h) (void)rh_rlm_destroy(c.h);
-    p->cls.clear();
-    for (hipStream_t st : p->cls_streams) {
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamDestroy(st);
-    }
-    for (hipEvent_t e : p->cls_done) (void)hipEventDestroy(e);
-    if (p->cls_fork) (void)hipEventDestroy(p->cls_fork);
-    if (p->d_cls_rows) (void)hipFree(p->d_cls_rows);
-    if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
-    bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
-    for (Plan &c : p->tried) {
-        fast_in_tried = fast_in_tried || c.d_tabs == p->fast.d_tabs;
-        wave_in_tried = wave_in_tried || c.d_tabs == p->wave.d_tabs;
-        pair_in_tried = pair_in_tried || c.d_tabs == p->pair.d_tabs;
-        if (c.d_tabs) (void)hipFree(c.d_tabs);
-    }
-    if (p->fast.d_tabs && !fast_in_tried) (void)hipFree(p->fast.d_tabs);
-    if (p->wave.d_tabs && !wave_in_tried) (void)hipFree(p->wave.d_tabs);
-    if (p->pair.d_tabs && !pair_in_tried) (void)hipFree(p->pair.d_tabs);
-    if (p->d_srcs) (void)hipFree(p->d_srcs);
-    if (p->d_gran) (void)hipFree(p->d_gran);
-    if (p->d_ctl) (void)hipFree(p->d_ctl);
-    if (p->d_mix) (void)hipFree(p->d_mix);
-    if (p->chunk.d_tabs) (void)hipFree(p->chunk.d_tabs);
-    if (p->chunk.d_pow) (void)hipFree(p->chunk.d_pow);
-    if (p->chunk.d_uni) (void)hipFree(p->chunk.d_uni);
-    if (p->chunk.d_mlo) (void)hipFree(p->chunk.d_mlo);
-    if (p->chunk.d_look) (void)hipFree(p->chunk.d_look);
-    if (p->chunk.d_halo) (void)hipFree(p->chunk.d_halo);
-    if (p->chunk.d_gran) (void)hipFree(p->chunk.d_gran);
-    if (p->d_prof) (void)hipFree(p->d_prof);
-    if (p->d_replay) (void)hipFree(p->d_replay);
-    for (int k = 0; k < 2; ++k)
-        if (p->d_w[k]) (void)hipFree(p->d_w[k]);
-    for (int k = 0; k < rh_rlm::kDescRing; ++k) {
-        if (p->h_ring_ev[k]) (void)hipEventDestroy(p->h_ring_ev[k]);
-        if (p->h_ring[k]) (void)hipHostFree(p->h_ring[k]);
-    }
-    delete p;
-    return RH_OK;
-}
-
-static rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s);
-// on_stream != nullptr: the table travels on that stream through the page-locked ring (ordered behind the launches already
-// queued there, no host synchronisation) -- what rh_biquad mode 1 does per call; nullptr: the synchronous form of the C ABI.
-static rh_status set_sources_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources, const hipStream_t *on_stream) {
-    RH_REQUIRE_INIT();
-    if (!p || (n_sources && (!srcs_host || !in_frames_host))) return RH_ERR_INVALID;
-    if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
-    std::vector<SrcDesc> &h = p->h_desc;
-    h.resize(n_sources);
-    uint64_t M = 0;
-    bool equal = true;
-    for (uint32_t s = 0; s < n_sources; ++s) {
-        if (in_frames_host[s] > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
-        if (in_frames_host[s] && (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u))) return RH_ERR_INVALID;
-        rh::ResampleGeom g;
-        rh_status st = rh::make_resample_geom(in_frames_host[s], p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
-        if (st != RH_OK) return st;
-        if (g.out_frames >= (1ull << 31)) return RH_ERR_UNSUPPORTED;  // 32-bit frame indices in the kernels
-        h[s] = SrcDesc{srcs_host[s], (uint32_t)in_frames_host[s], (uint32_t)g.out_frames, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
-        if (g.out_frames > M) M = g.out_frames;
-        equal = equal && in_frames_host[s] == in_frames_host[0];
-    }
-    if (on_stream && p->launched && p->last_stream == *on_stream) {
-        if (n_sources) {
-            const rh_status up = upload_descriptors(p, n_sources, *on_stream);
-            if (up != RH_OK) return up;
-        }
-    } else {
-        const rh_status w = wait_idle(p);  // an earlier run of this handle may still be reading the table
-        if (w != RH_OK) return w;
-        if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
-    }
-    p->equal = equal;
-    p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
-    p->n_sources = n_sources;
-    p->out_frames = M;
-    p->chunk.ok = false;
-    // equal-length batch: the merged-state kernel; otherwise the general one
-    if (equal && !p->cfg.force_general) {
-        const rh_status st = activate_plan(p, &p->fast);
-        if (st != RH_OK || on_stream) return st;
-        return build_chunk(p);
-    }
-    // different lengths + filter: almost every (tile, source) pair is "stable" and goes through the lean kernel of the pair
-    return activate_plan(p, pair_ok(p, p->pair) ? &p->pair : &p->wave);
-}
-
-// The sources dealt over the filter classes (rh_rlm_set_filters).  Classes are kept across calls (their tables and plans belong to
-// their filter); a class that has no member this time keeps its handle and is skipped by the run.
-static rh_status set_sources_classes(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
-    if (n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
-    if (n_sources && (!srcs_host || !in_frames_host)) return RH_ERR_INVALID;
-    for (rh_rlm::FilterClass &c : p->cls) c.members.clear();
-    p->n_sources = 0;  // (an error below leaves a handle without sources, not one whose classes and counts disagree: a run then fails cleanly)
-    p->out_frames = 0;
-    const rh_rlm::FilterSpec own{p->cfg.filter_kind == 2 ? 0 : p->cfg.filter_kind, p->cfg.filter_freq, p->cfg.filter_q};
-    for (uint32_t s = 0; s < n_sources; ++s) {
-        const rh_rlm::FilterSpec f = s < p->filters.size() ? p->filters[s] : own;
-        size_t k = 0;
-        while (k < p->cls.size() && !(p->cls[k].spec == f)) ++k;
-        if (k == p->cls.size()) {
-            rh_rlm::FilterClass c;
-            c.spec = f;
-            rh_rlm_config cfg = p->cfg;
-            cfg.filter_kind = f.kind < 0 ? -1 : f.kind;
-            cfg.filter_freq = f.freq;
-            cfg.filter_q = f.q;
-            const rh_status st = rh_rlm_create(&c.h, &cfg);
-            if (st != RH_OK) return st;
-            p->cls.push_back(c);
-        }
-        p->cls[k].members.push_back(s);
-    }
-    uint64_t M = 0;
-    std::vector<const float *> ptrs;
-    std::vector<uint64_t> frames;
-    std::vector<float> gains;
-    for (rh_rlm::FilterClass &c : p->cls) {
-        ptrs.clear(), frames.clear(), gains.clear();
-        for (uint32_t s : c.members) {
-            ptrs.push_back(srcs_host[s]);
-            frames.push_back(in_frames_host[s]);
-            gains.push_back(s < p->gains.size() ? p->gains[s] : 1.0f);
-        }
-        c.h->exclusive = p->exclusive;
-        c.h->mix_first_on = p->mix_first_on;
-        rh_status st = rh_rlm_set_gains(c.h, gains.data(), (uint32_t)gains.size());
-        if (st == RH_OK) st = rh_rlm_set_sources(c.h, ptrs.data(), frames.data(), (uint32_t)ptrs.size());
-        if (st != RH_OK) return st;
-        c.out_frames = c.h->out_frames;
-        if (c.out_frames > M) M = c.out_frames;
-    }
-    p->n_sources = n_sources;
-    p->out_frames = M;
-    p->chunk.ok = false;
-    return RH_OK;
-}
-
-rh_status rh_rlm_set_sources(rh_rlm *p, const float *const *srcs_host, const uint64_t *in_frames_host, uint32_t n_sources) {
-    if (p && !p->filters.empty()) {
-        RH_REQUIRE_INIT();
-        return set_sources_classes(p, srcs_host, in_frames_host, n_sources);
-    }
-    if (p && !p->cls.empty()) {  // back to the handle's one filter
-        for (rh_rlm::FilterClass &c : p->cls)
-            if (c.h) (void)rh_rlm_destroy(c.h);
-        p->cls.clear();
-    }
-    return set_sources_impl(p, srcs_host, in_frames_host, n_sources, nullptr);
-}
-
-rh_status rh_rlm_set_filters(rh_rlm *p, const int32_t *kinds_host, const uint32_t *freqs_host, const float *qs_host, uint32_t n) {
-    RH_REQUIRE_INIT();
-    if (!p || (n && (!kinds_host || !freqs_host || !qs_host)) || n > p->cfg.max_sources) return RH_ERR_INVALID;
-    if (p->pre_filter || p->st_on || p->cfg.filter_kind == 2) return RH_ERR_UNSUPPORTED;  // filter_first / custom-coefficient handles and running streams keep their one filter
-    std::vector<rh_rlm::FilterSpec> f(n);
-    for (uint32_t s = 0; s < n; ++s) {
-        if (kinds_host[s] > 1) return RH_ERR_INVALID;  // -1 none, 0 low_pass, 1 high_pass
-        f[s] = rh_rlm::FilterSpec{kinds_host[s] < 0 ? -1 : kinds_host[s], kinds_host[s] < 0 ? 0u : freqs_host[s], kinds_host[s] < 0 ? 0.f : qs_host[s]};
-        if (f[s].kind >= 0) {  // refuse here what rh_rlm_create would refuse at the next set_sources
-            float c5[5];
-            const rh_status st = rh_biquad_coeffs(f[s].kind, f[s].freq, f[s].q, p->cfg.to_rate, c5);
-            if (st != RH_OK) return st;
-        }
-    }
-    p->filters = std::move(f);
-    p->n_sources = 0;  // the sources are dealt over the classes by the next rh_rlm_set_sources
-    p->out_frames = 0;
-    return RH_OK;
-}
-
-rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
-    RH_REQUIRE_INIT();
-    if (!p || (n && !gains_host) || n > p->cfg.max_sources) return RH_ERR_INVALID;
-    p->gains.assign(gains_host, gains_host + n);
-    if (!p->cls.empty()) {  // per-source filters: every class takes the factors of its members
-        std::vector<float> g;
-        for (rh_rlm::FilterClass &c : p->cls) {
-            g.clear();
-            for (uint32_t s : c.members) g.push_back(s < n ? gains_host[s] : 1.0f);
-            const rh_status st = rh_rlm_set_gains(c.h, g.data(), (uint32_t)g.size());
-            if (st != RH_OK) return st;
-        }
-        return RH_OK;
-    }
-    if (!p->st_on && p->n_sources && p->h_desc.size() == p->n_sources) {  // sources already set: refresh their descriptors
-        for (uint32_t s = 0; s < p->n_sources; ++s) p->h_desc[s].gain = s < n ? gains_host[s] : 1.0f;
-        {
-            const rh_status w = wait_idle(p);
-            if (w != RH_OK) return w;
-        }
-        RH_HIP_TRY(hipMemcpy(p->d_srcs, p->h_desc.data(), sizeof(SrcDesc) * p->n_sources, hipMemcpyHostToDevice));
-    }
-    return RH_OK;
-}
-
-// One launch (or pair) per filter class into the class's row, then the classes' mixes summed in order of first appearance.
-static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (out_frames) *out_frames = p->out_frames;
-    if (p->out_frames == 0) return RH_OK;
-    if (!dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
-    if (out_capacity_frames < p->out_frames) return RH_ERR_CAPACITY;
-    const uint32_t C = p->cfg.channels;
-    std::vector<rh_rlm::FilterClass *> live;
-    for (rh_rlm::FilterClass &c : p->cls)
-        if (!c.members.empty() && c.out_frames) live.push_back(&c);
-    if (live.empty()) return RH_OK;
-    if (live.size() == 1) return rh_rlm_run(live[0]->h, dst, out_capacity_frames, nullptr, stream);
-    const size_t row = (size_t)((p->out_frames * C + 3) & ~3ull);
-    if (row > p->cls_row_floats || live.size() > p->cls_rows) {
-        const rh_status w = wait_idle(p);
-        if (w != RH_OK) return w;
-        for (rh_rlm::FilterClass *c : live) {  // (the rows are read by the sum behind the classes' launches: those first)
-            const rh_status wc = wait_idle(c->h);
-            if (wc != RH_OK) return wc;
-        }
-        if (p->d_cls_rows) RH_HIP_TRY(hipFree(p->d_cls_rows));
-        p->d_cls_rows = nullptr;
-        p->cls_row_floats = std::max(row, p->cls_row_floats);
-        p->cls_rows = std::max(live.size(), p->cls_rows);
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cls_rows), p->cls_row_floats * p->cls_rows * sizeof(float)));
-    }
-    std::vector<const float *> ptrs;
-    std::vector<uint64_t> start, len;
-    hipStream_t s0 = rh::as_stream(stream);
-    // Measured (profiles/r05_per_class.txt: 4 classes x 64 sources x 1 Mi frames): one after the other 0.368 ms, side by side 0.40-0.42 -- four
-    // launches that each want the whole chip's bandwidth get in each other's way (and their tiles go by ticket then).  So: one after the other;
-    // RH_CLASSES_SIDE_BY_SIDE=1 keeps the other form selectable.
-    const bool side_by_side = rh::knob(rh::K_CLASSES_SIDE_BY_SIDE) != nullptr;
-    if (side_by_side) {
-        while (p->cls_streams.size() + 1 < live.size()) {
-            hipStream_t ns = nullptr;
-            hipEvent_t ne = nullptr;
-            RH_HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-            p->cls_streams.push_back(ns);
-            RH_HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
-            p->cls_done.push_back(ne);
-        }
-        if (!p->cls_fork) RH_HIP_TRY(hipEventCreateWithFlags(&p->cls_fork, hipEventDisableTiming));
-        RH_HIP_TRY(hipEventRecord(p->cls_fork, s0));  // what the caller queued in front (the sources' samples) is in front of every class
-    }
-    for (size_t k = 0; k < live.size(); ++k) {
-        float *r = p->d_cls_rows + k * p->cls_row_floats;
-        hipStream_t sk = s0;
-        if (side_by_side && k > 0) {
-            sk = p->cls_streams[k - 1];
-            RH_HIP_TRY(hipStreamWaitEvent(sk, p->cls_fork, 0));
-        }
-        if (side_by_side) live[k]->h->exclusive = false;  // other classes' kernels share the CUs: tiles by ticket (rh_rlm_set_exclusive)
-        const rh_status st = rh_rlm_run(live[k]->h, r, p->cls_row_floats / C, nullptr, reinterpret_cast<rh_stream>(sk));
-        if (st != RH_OK) return st;
-        if (side_by_side && k > 0) RH_HIP_TRY(hipEventRecord(p->cls_done[k - 1], sk));
-        ptrs.push_back(r);
-        start.push_back(0);
-        len.push_back(live[k]->out_frames * C);
-    }
-    if (side_by_side)
-        for (size_t k = 1; k < live.size(); ++k) RH_HIP_TRY(hipStreamWaitEvent(s0, p->cls_done[k - 1], 0));
-    const rh_status st = rh_mix_sum(dst, p->out_frames * C, ptrs.data(), start.data(), len.data(), (uint32_t)ptrs.size(), stream);
-    if (st != RH_OK) return st;
-    return mark_launch(p, rh::as_stream(stream));
-}
-
-rh_status rh_rlm_run(rh_rlm *p, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
-    if (!p) return RH_ERR_INVALID;
-    if (!p->cls.empty()) return run_classes(p, dst, out_capacity_frames, out_frames, stream);
-    return rh_rlm_run_subset(p, 0, p->n_sources, dst, out_capacity_frames, out_frames, stream);
-}
-
-struct StreamArgs {
-    uint32_t mode = 0, active = 0;
-    uint64_t m0 = 0, g0 = 0;
-    const float *win = nullptr;
-    float *wout = nullptr;
-    uint32_t gran_cols = 0;  // != 0: per-source states (k_rlm_wave), aggregate rows of this many columns, tile 0 in column 1
-};
 // Mix first (k_mix_rows / k_mix_ring in front of a one-source fused launch): one-shot runs of filtered equal-length batches.
 // ... and blocks of a stream that carries ONE summed state (rh_rlm_stream_block; rh_rlm_stream_block_v while its sources run
 // together): the state of the sum is the sum of the states, so the block is summed first and the one mixed row streams through
 // the fused kernel with the stream's state words.  `per_source_states`: streams whose blocks carry a state per source.
-static bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool per_source_states, bool batch) {
+bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool per_source_states, bool batch) {
     return &pl == &p->fast && p->filt && p->mix_first_on && !per_source_states && !batch && count >= 2 && !rh::knob(rh::K_NO_MIX_FIRST);
 }
-static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
-                            const StreamArgs &sa = StreamArgs());
 
-rh_status rh_rlm_run_subset(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream) {
-    return rlm_launch(p, first, count, dst, out_capacity_frames, out_frames, stream, 0, 0);
-}
-
-rh_status rh_rlm_run_batch(rh_rlm *p, float *dst, uint64_t dst_stride_frames, uint64_t *out_frames, rh_stream stream) {
-    if (!p) return RH_ERR_INVALID;
-    if (p->plan != &p->fast || p->cfg.channels != 2) return RH_ERR_UNSUPPORTED;  // equal-length stereo sources only
-    if (p->n_sources > 1 && (dst_stride_frames < p->out_frames || (dst_stride_frames * 2) % 4 != 0)) return RH_ERR_INVALID;
-    return rlm_launch(p, 0, p->n_sources, dst, dst_stride_frames, out_frames, stream, p->n_sources, dst_stride_frames * 2);
-}
-
-static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
+rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride,
                             const StreamArgs &sa) {
     RH_REQUIRE_INIT();
     if (!p) return RH_ERR_INVALID;
@@ -3866,575 +2745,4 @@ static rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *ds
     return mark_launch(p, s);
 }
 
-rh_status rh_rlm_autotune(rh_rlm *p, float *dst, uint64_t out_capacity_frames, rh_stream stream, uint32_t *frames_per_lane, uint32_t *ring_stages) {
-    RH_REQUIRE_INIT();
-    if (!p || !dst) return RH_ERR_INVALID;
-    if (!p->cls.empty()) {  // per-source filters: every class finds its own geometry (the last one's is reported)
-        for (rh_rlm::FilterClass &c : p->cls) {
-            if (c.members.empty()) continue;
-            const rh_status st = rh_rlm_autotune(c.h, dst, out_capacity_frames, stream, frames_per_lane, ring_stages);
-            if (st != RH_OK) return st;
-        }
-        return RH_OK;
-    }
-    if (p->out_frames > 0 && out_capacity_frames >= p->out_frames) {
-        const bool general = p->plan == &p->wave, is_pair = p->plan == &p->pair;
-        Plan &slot = is_pair ? p->pair : general ? p->wave : p->fast;
-        rh::ResampleGeom g;
-        rh_status st = rh::make_resample_geom((general || is_pair) ? p->cfg.max_in_frames : p->eq_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, p->cfg.span_len, &g);
-        if (st != RH_OK) return st;
-        hipStream_t s = rh::as_stream(stream);
-        hipEvent_t e0, e1;
-        RH_HIP_TRY(hipEventCreate(&e0));
-        RH_HIP_TRY(hipEventCreate(&e1));
-        auto time_current = [&](float &ms) -> rh_status {
-            rh_status r = rh_rlm_run(p, dst, out_capacity_frames, nullptr, stream);  // warm-up
-            if (r != RH_OK) return r;
-            ms = 1e30f;
-            for (int rep = 0; rep < 3; ++rep) {
-                RH_HIP_TRY(hipEventRecord(e0, s));
-                r = rh_rlm_run(p, dst, out_capacity_frames, nullptr, stream);
-                if (r != RH_OK) return r;
-                RH_HIP_TRY(hipEventRecord(e1, s));
-                RH_HIP_TRY(hipEventSynchronize(e1));
-                float t = 0.f;
-                RH_HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-                if (t < ms) ms = t;
-            }
-            return RH_OK;
-        };
-        float best_ms = 0.f;
-        st = time_current(best_ms);
-        Plan best = slot;
-        p->tried.reserve(128);
-        {  // every table the handle ever owned is freed through `tried`
-            bool have = false;
-            for (const Plan &c : p->tried) have = have || c.d_tabs == slot.d_tabs;
-            if (!have) p->tried.push_back(slot);
-        }
-        for (int R = 2; R <= kMaxR && st == RH_OK; ++R) {
-            for (int NS = 2; NS <= 3; ++NS) {
-                if (R == best.v->R && NS == best.v->NS) continue;
-                Plan cand;
-                const bool mono = p->cfg.channels == 1;
-                if ((is_pair   ? make_plan(p, cand, mono ? tab_of(kRag1) : tab_of(kRag), false, g, (uint32_t)R, (uint32_t)NS)
-                     : general ? make_plan(p, cand, mono ? tab_of(kWave1) : tab_of(kWave), true, g, (uint32_t)R, (uint32_t)NS)
-                               : make_plan(p, cand, mono ? tab_of(kFast1) : tab_of(kFast), false, g, (uint32_t)R, (uint32_t)NS)) != RH_OK)
-                    continue;
-                if (is_pair && !pair_ok(p, cand)) {  // this tile size would put too many ending sources into one tile
-                    p->tried.push_back(cand);
-                    continue;
-                }
-                p->tried.push_back(cand);
-                const uint64_t tiles = (p->out_frames + 64ull * R - 1) / (64ull * R);
-                const uint64_t per_cu = (tiles + rh::g_num_cus - 1) / rh::g_num_cus;
-                if ((int)per_cu > cand.resident_per_cu && !is_pair) continue;  // would run in passes: never the fastest (a ragged batch's tiles are
-                                                                                // unequal: there the later ones fill in behind the heavy ones)
-                slot = cand;
-                if ((st = activate_plan(p, &slot)) != RH_OK) break;
-                float ms = 0.f;
-                if ((st = time_current(ms)) != RH_OK) break;
-                if (rh::knob(rh::K_AUTOTUNE_LOG)) std::fprintf(stderr, "rh_rlm_autotune: %d frames per lane, %d KiB x %d stages: %.4f ms (best so far %.4f)\n", R, cand.v->KV, NS, ms, best_ms);
-                if (ms < best_ms * 0.99f) {  // a candidate has to win by more than the run-to-run noise (ties keep the earlier, shallower one)
-                    best_ms = ms;
-                    best = cand;
-                }
-            }
-        }
-        slot = best;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (st != RH_OK) return st;
-        st = activate_plan(p, &slot);
-        if (st != RH_OK) return st;
-    }
-    if (frames_per_lane) *frames_per_lane = (uint32_t)p->plan->v->R;
-    if (ring_stages) *ring_stages = (uint32_t)p->plan->v->NS;
-    return RH_OK;
-}
-
-// ---- block streaming of the fused path (equal-length blocks, the same sources in every block) -------
-// What crosses a block boundary: the converter's position (st_g0: global index of frame 0 of the caller's
-// buffers; st_m: output frames emitted) and the SUM over the sources of the filter state at st_m (4 floats,
-// scan basis) -- the merged-state kernel never needs a per-source state.  A block emits whole lane runs only
-// (a multiple of R output frames), so that the state at its end is a lane's start state; the frames that are
-// left over stay with the caller: *consumed tells how many of the frames it passed are done with.
-// Upload h_desc[0..n) to d_srcs on `s` through the page-locked ring.
-static rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s) {
-    const int k = p->h_ring_next;
-    p->h_ring_next = (k + 1) % rh_rlm::kDescRing;
-    if (!p->h_ring[k]) {
-        RH_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_ring[k]), sizeof(SrcDesc) * p->cfg.max_sources, hipHostMallocDefault));
-        RH_HIP_TRY(hipEventCreateWithFlags(&p->h_ring_ev[k], hipEventDisableTiming));
-    } else {
-        RH_HIP_TRY(hipEventSynchronize(p->h_ring_ev[k]));  // the copy that last read this table has run (normally long ago)
-    }
-    std::memcpy(p->h_ring[k], p->h_desc.data(), sizeof(SrcDesc) * n);
-    RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, p->h_ring[k], sizeof(SrcDesc) * n, hipMemcpyHostToDevice, s));
-    RH_HIP_TRY(hipEventRecord(p->h_ring_ev[k], s));
-    return RH_OK;
-}
-
-// Closed forms of sample_rate.rs:131-201 for a stream whose converter restarts every `cin` input frames (`cout` output frames
-// per whole span; cin == 0: one continuous conversion).
-static uint64_t lerp_ready(uint64_t n, uint64_t F, uint64_t T) {  // #m with floor(m*F/T) <= n-2: both taps have arrived
-    return n ? (uint64_t)((((unsigned __int128)(n - 1) * T) + F - 1) / F) : 0;
-}
-static uint64_t run_total(uint64_t n, uint64_t F, uint64_t T) {  // ... plus the verbatim last frame of a run that is complete
-    const uint64_t c1 = lerp_ready(n, F, T);
-    return n && (unsigned __int128)c1 * F < (unsigned __int128)n * T ? c1 + 1 : c1;
-}
-static uint64_t stream_ready(uint64_t N, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // a source that will deliver more
-    if (!cin) return lerp_ready(N, F, T);
-    return N / cin * cout + lerp_ready(N % cin, F, T);  // whole spans are complete, verbatim frame included
-}
-static uint64_t stream_total(uint64_t N, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // a source that has ended with N frames
-    if (!cin) return run_total(N, F, T);
-    return N / cin * cout + run_total(N % cin, F, T);
-}
-static uint64_t stream_first_tap(uint64_t m, uint64_t F, uint64_t T, uint64_t cin, uint64_t cout) {  // the input frame output frame m reads first
-    if (!cin) return (uint64_t)(((unsigned __int128)m * F) / T);
-    const uint64_t k = m / cout, il = (uint64_t)(((unsigned __int128)(m % cout) * F) / T);
-    return k * cin + (il < cin - 1 ? il : cin - 1);
-}
-
-rh_status rh_rlm_stream_begin(rh_rlm *p) {
-    RH_REQUIRE_INIT();
-    if (!p) return RH_ERR_INVALID;
-    if (p->pre_filter) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs only (rodio_hip.h)
-    if (!p->filters.empty()) return RH_ERR_UNSUPPORTED;  // per-source filters: one-shot runs (a streaming host keeps one handle per filter: rodio_hip.hpp)
-    p->st_chunk_in = p->st_chunk_out = 0;
-    if (p->cfg.span_len != 0) {  // sources that report spans of span_len samples: the converter restarts every min(span_len, 32768) samples (uniform.rs:56-67)
-        const uint64_t span = p->cfg.span_len < 32768 ? p->cfg.span_len : 32768;
-        if (span % p->cfg.channels != 0) return RH_ERR_UNSUPPORTED;  // a span that splits a frame
-        p->st_chunk_in = span / p->cfg.channels;
-        const rh_status st = rh_resample_out_frames(p->st_chunk_in, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &p->st_chunk_out);
-        if (st != RH_OK) return st;
-        if (p->F == p->T) p->st_chunk_in = p->st_chunk_out = 0;  // the converter passes through: its restarts leave no trace
-    }
-    {
-        const rh_status w = wait_idle(p);  // a previous stream's last block may still read its state words
-        if (w != RH_OK) return w;
-    }
-    for (int k = 0; k < 2; ++k) {
-        if (!p->d_w[k]) RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_w[k]), 4 * sizeof(float)));
-        RH_HIP_TRY(rh::fill_now(p->d_w[k], 0, 4 * sizeof(float)));
-    }
-    p->st_on = true;
-    p->st_done = false;
-    p->st_g0 = p->st_m = 0;
-    p->st_nsrc = 0;
-    p->st_cur = 0;
-    p->st_total.clear();
-    p->st_cols = 0;
-    p->st_together = p->st_decided = false;
-    p->st_n_summed = p->st_n_each = p->st_n_recover = 0;
-    p->st_prev_ptrs.clear();
-    p->st_prev_avail = p->st_prev_g0 = p->st_prev_m = p->st_prev_out = 0;
-    return RH_OK;
-}
-
-rh_status rh_rlm_stream_stats(rh_rlm *p, uint32_t *summed_blocks, uint32_t *per_source_blocks, uint32_t *recoveries) {
-    if (!p) return RH_ERR_INVALID;
-    if (summed_blocks) *summed_blocks = p->st_n_summed;
-    if (per_source_blocks) *per_source_blocks = p->st_n_each;
-    if (recoveries) *recoveries = p->st_n_recover;
-    return RH_OK;
-}
-
-rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on) {
-    if (!p) return RH_ERR_INVALID;
-    if (p->st_on && (p->st_nsrc || p->st_decided)) return RH_ERR_INVALID;  // before the stream's first block
-    p->st_history = on != 0;
-    return RH_OK;
-}
-
-static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
-                                     uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream);
-
-rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
-                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
-    if (p->st_together || p->st_decided) return RH_ERR_INVALID;  // a stream uses one of the two block entries throughout
-    return stream_block_summed(p, srcs_host, n_sources, avail_frames, flush, dst, out_capacity_frames, out_frames, consumed_frames, stream);
-}
-
-static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
-                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
-    if (n_sources == 0 || n_sources > p->cfg.max_sources || avail_frames > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
-    if (p->st_cols || (p->st_nsrc && p->st_nsrc != n_sources)) return RH_ERR_INVALID;  // the summed state belongs to one set of sources (and one kind of stream)
-    *out_frames = 0;
-    *consumed_frames = 0;
-    const uint64_t F = p->F, T = p->T, R = p->fast.v->R, L = 64 * R;
-    const uint64_t N = p->st_g0 + avail_frames;  // input frames of the stream that exist so far
-    const uint64_t cin = p->st_chunk_in, cout = p->st_chunk_out;
-    // output frames computable from them: every m whose two taps have arrived; at the end also the verbatim last frame
-    const uint64_t m_end = flush ? stream_total(N, F, T, cin, cout) : stream_ready(N, F, T, cin, cout);
-    uint64_t out = m_end > p->st_m ? m_end - p->st_m : 0;
-    if (!flush) out = out / R * R;
-    if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
-    if (out > out_capacity_frames) return RH_ERR_CAPACITY;
-    if (out > 0 || flush) {
-        if (out > 0) {
-            if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
-            std::vector<SrcDesc> &h = p->h_desc;
-            h.resize(n_sources);
-            for (uint32_t s = 0; s < n_sources; ++s) {
-                if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
-                h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
-            }
-            {
-                const rh_status up = upload_descriptors(p, n_sources, rh::as_stream(stream));
-                if (up != RH_OK) return up;
-            }
-            p->equal = true;
-            p->eq_frames = (uint32_t)avail_frames;
-            p->n_sources = n_sources;
-            p->out_frames = out;
-            p->chunk.ok = false;  // (the tile tables of k_rlm_chunk belong to a one-shot batch)
-            rh_status st = activate_plan(p, &p->fast);
-            if (st != RH_OK) return st;
-            const uint64_t tiles = flush ? (out + L - 1) / L : out / L + 1;  // + the tile that holds the end-state lane
-            p->n_tiles = (uint32_t)tiles;
-            if (p->filt && (size_t)tiles * 4 > p->gran_words) return RH_ERR_CAPACITY;  // activate_plan sized it for ceil(out/L)+... never smaller
-            StreamArgs sa;
-            sa.mode = flush ? 2u : 1u;
-            sa.active = (uint32_t)out;
-            sa.m0 = p->st_m;
-            sa.g0 = p->st_g0;
-            sa.win = p->d_w[p->st_cur];
-            sa.wout = p->d_w[p->st_cur ^ 1];
-            st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
-            if (st != RH_OK) return st;
-            p->st_n_summed += 1;
-            if (!flush && p->filt) p->st_cur ^= 1;
-        }
-        p->st_m += out;
-        p->st_nsrc = n_sources;
-    }
-    if (flush) {
-        p->st_done = true;
-        *consumed_frames = avail_frames;
-    } else {
-        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T) (of their span)
-        const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
-        const uint64_t cons = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
-        *consumed_frames = cons < avail_frames ? cons : avail_frames;
-        *consumed_frames -= *consumed_frames % (4u / p->cfg.channels);  // whole 16-byte vectors: `row + consumed` is a row the next block can take as it is
-        p->st_g0 += *consumed_frames;
-    }
-    *out_frames = out;
-    return RH_OK;
-}
-
-// ---- block streaming with per-source filter states (ragged batches: sources of one clock that end at
-// different times) -- k_rlm_wave, whose look-back is per source anyway.  A block emits whole tiles, so the state
-// that crosses the boundary is a tile carry: k_rlm_state folds the block's aggregates into column 0 of the
-// aggregate rows, where the next launch finds it as the aggregate of a virtual predecessor tile.
-
-static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
-                                     uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream);
-
-rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
-                                uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
-    if (p) p->st_dirty = false;
-    const rh_status st = stream_block_v_impl(p, srcs_host, avail_frames_host, ended_host, n_sources, dst, out_capacity_frames, out_frames, consumed_frames, stream);
-    // An error after the stream's state was touched (the switch from the summed state to per-source states: rows sized, the replay launched)
-    // leaves a state no later block can continue from: the stream is over, and says so (RH_ERR_INVALID on every later call) instead of
-    // wedging half-way.  Errors found while the arguments are checked leave the stream as it was.
-    if (st != RH_OK && p && p->st_dirty) {
-        p->st_done = true;
-        p->st_prev_ptrs.clear();
-    }
-    return st;
-}
-
-static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, const uint64_t *avail_frames_host, const uint8_t *ended_host, uint32_t n_sources, float *dst,
-                                     uint64_t out_capacity_frames, uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
-    RH_REQUIRE_INIT();
-    if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames || !avail_frames_host || !ended_host) return RH_ERR_INVALID;
-    if (n_sources == 0 || n_sources > p->cfg.max_sources) return RH_ERR_CAPACITY;
-    if (p->st_nsrc && (p->st_nsrc != n_sources || (!p->st_cols && !p->st_together))) return RH_ERR_INVALID;  // one set of sources, one kind of stream
-    *out_frames = 0;
-    *consumed_frames = 0;
-    const uint64_t F = p->F, T = p->T, L = 64ull * p->wave.v->R;
-    const uint64_t cin = p->st_chunk_in, cout = p->st_chunk_out;
-    hipStream_t hs = rh::as_stream(stream);
-    // ---- the sources run TOGETHER (all live, the same frames each): one summed state, the block summed first -------------------
-    // What a recovery needs of the block before: K = J tiles of the per-source kernel, replayed from a zero state (the filter has
-    // forgotten what lies further back: ||B^K|| < 2^-40).  So a block stays on the summed state only if it emits at least K frames;
-    // a stream whose first block does not never starts on it.
-    const uint64_t K = (uint64_t)(p->filt ? p->wave.J : 0) * L;
-    if (!p->st_decided) {
-        p->st_decided = true;
-        p->st_together = p->st_history && p->filt && p->mix_first_on && n_sources >= 2 && K > 0 && !rh::knob(rh::K_NO_MIX_FIRST);
-    }
-    if (p->st_together) {
-        bool same = true, any_ended = false, all_ended = true;
-        for (uint32_t s = 0; s < n_sources; ++s) {
-            same = same && avail_frames_host[s] == avail_frames_host[0];
-            any_ended = any_ended || ended_host[s] != 0;
-            all_ended = all_ended && ended_host[s] != 0;
-        }
-        const uint64_t N = p->st_g0 + avail_frames_host[0];
-        const uint64_t ready = stream_ready(N, F, T, cin, cout);
-        const uint64_t Rf = p->fast.v->R;
-        const uint64_t would = ready > p->st_m ? (ready - p->st_m) / Rf * Rf : 0;
-        if (same && all_ended) {  // they end together too: the summed stream's last block
-            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 1, dst, out_capacity_frames, out_frames, consumed_frames, stream);
-            if (st == RH_OK) p->st_together = false;  // (st_done is set: nothing follows)
-            return st;
-        }
-        if (same && !any_ended && would >= K) {
-            const uint64_t g0 = p->st_g0, m0 = p->st_m;
-            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 0, dst, out_capacity_frames, out_frames, consumed_frames, stream);
-            if (st != RH_OK) return st;
-            p->st_prev_ptrs.assign(srcs_host, srcs_host + n_sources);
-            p->st_prev_avail = avail_frames_host[0];
-            p->st_prev_g0 = g0;
-            p->st_prev_m = m0;
-            p->st_prev_out = *out_frames;
-            return RH_OK;
-        }
-        p->st_dirty = true;
-        p->st_together = false;  // a source ends or falls behind, or the block is short: one state per source from here on
-    }
-    const bool recover = !p->st_cols && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
-    if (!p->st_cols) {  // first block of the per-source stream: size the aggregate rows once (the states live in them), zero states
-        p->st_dirty = true;
-        rh::ResampleGeom g;
-        rh_status st = rh::make_resample_geom(p->cfg.max_in_frames, p->cfg.from_rate, p->cfg.to_rate, p->cfg.channels, 0, &g);
-        if (st != RH_OK) return st;
-        const uint64_t span_extra = cin ? p->cfg.max_in_frames / cin + 2 : 0;  // every span a block touches adds its verbatim frame
-        const uint64_t cols = (g.out_frames + span_extra + L - 1) / L + 2;
-        if (cols > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-        const size_t words = (size_t)(p->cfg.max_sources + 1) * cols * 4;  // as activate_plan counts: one row per source + the row of summed aggregates
-        if (p->filt && words > p->gran_words) {
-            const rh_status w = wait_idle(p);
-            if (w != RH_OK) return w;
-            if (p->d_gran) RH_HIP_TRY(hipFree(p->d_gran));
-            p->d_gran = nullptr;
-            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_gran), words * 8));
-            RH_HIP_TRY(rh::fill_now(p->d_gran, 0, words * 8));
-            p->gran_words = words;
-        }
-        p->st_cols = (uint32_t)cols;
-        p->st_total.assign(n_sources, ~0ull);
-        if (p->filt && p->epoch >= 0xf0000000u) {  // keep the epoch tag from wrapping inside a stream (its states live in the table)
-            RH_HIP_TRY(hipMemsetAsync(p->d_gran, 0, p->gran_words * 8, hs));
-            p->epoch = 0;
-        }
-        if (p->filt) {
-            const rh_status pw = pre_launch(p, hs);
-            if (pw != RH_OK) return pw;
-            hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
-            RH_CHECK_LAUNCH();
-            const rh_status mk = mark_launch(p, hs);
-            if (mk != RH_OK) return mk;
-        }
-    }
-    if (recover) {
-        // The states the summed stream never kept: replay the last K output frames of the block before through the per-source kernel
-        // from a zero state (its rows are still there: rh_rlm_stream_keep_history), mix discarded, and fold the replay's aggregates
-        // into column 0 -- exactly what the end of a per-source block does.
-        const uint64_t m0 = p->st_m - K;  // >= st_prev_m: that block emitted at least K frames
-        const size_t need = (size_t)K * p->cfg.channels + 64;
-        if (need > p->replay_floats) {
-            const rh_status w = wait_idle(p);
-            if (w != RH_OK) return w;
-            if (p->d_replay) RH_HIP_TRY(hipFree(p->d_replay));
-            p->d_replay = nullptr;
-            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_replay), need * sizeof(float)));
-            p->replay_floats = need;
-        }
-        std::vector<SrcDesc> &h = p->h_desc;
-        h.resize(n_sources);
-        for (uint32_t s = 0; s < n_sources; ++s)
-            h[s] = SrcDesc{p->st_prev_ptrs[s], (uint32_t)p->st_prev_avail, (uint32_t)K, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
-        {
-            const rh_status up = upload_descriptors(p, n_sources, hs);
-            if (up != RH_OK) return up;
-        }
-        p->equal = false;
-        p->n_sources = n_sources;
-        p->out_frames = K;
-        rh_status st = activate_plan(p, &p->wave);
-        if (st != RH_OK) return st;
-        StreamArgs sa;
-        sa.mode = 1u;
-        sa.active = (uint32_t)K;
-        sa.m0 = m0;
-        sa.g0 = p->st_prev_g0;
-        sa.gran_cols = p->st_cols;
-        st = rlm_launch(p, 0, n_sources, p->d_replay, K, nullptr, stream, 0, 0, sa);
-        if (st != RH_OK) return st;
-        hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)(K / L) + 1u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
-        RH_CHECK_LAUNCH();
-        const rh_status mk = mark_launch(p, hs);
-        if (mk != RH_OK) return mk;
-        p->st_prev_ptrs.clear();
-        p->st_n_recover += 1;
-    }
-    // what every source can still give: a live one every frame whose two taps have arrived, an ended one all it has left
-    uint64_t live_min = ~0ull, ended_max = 0;
-    bool any_live = false;
-    for (uint32_t s = 0; s < n_sources; ++s) {
-        if (avail_frames_host[s] > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
-        if (p->st_total[s] == ~0ull && ended_host[s]) p->st_total[s] = p->st_g0 + avail_frames_host[s];
-        if (p->st_total[s] == ~0ull) {
-            const uint64_t N = p->st_g0 + avail_frames_host[s];
-            const uint64_t m_end = stream_ready(N, F, T, cin, cout);  // every m whose two taps have arrived
-            const uint64_t can = m_end > p->st_m ? m_end - p->st_m : 0;
-            live_min = can < live_min ? can : live_min;
-            any_live = true;
-        } else {
-            const uint64_t M = stream_total(p->st_total[s], F, T, cin, cout);
-            const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
-            ended_max = rem > ended_max ? rem : ended_max;
-        }
-    }
-    const bool final_block = !any_live;
-    const uint64_t out = final_block ? ended_max : live_min / L * L;
-    if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
-    if (out > out_capacity_frames) return RH_ERR_CAPACITY;
-    if (out > 0) {
-        if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
-        const uint64_t tiles = (out + L - 1) / L;
-        if (tiles + 1 > p->st_cols) return RH_ERR_CAPACITY;
-        std::vector<SrcDesc> &h = p->h_desc;
-        h.resize(n_sources);
-        for (uint32_t s = 0; s < n_sources; ++s) {
-            uint64_t ms = out;
-            if (p->st_total[s] != ~0ull) {
-                const uint64_t M = stream_total(p->st_total[s], F, T, cin, cout);
-                const uint64_t rem = M > p->st_m ? M - p->st_m : 0;
-                ms = rem < out ? rem : out;
-            }
-            if (ms && (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u))) return RH_ERR_INVALID;
-            h[s] = SrcDesc{ms ? srcs_host[s] : nullptr, ms ? (uint32_t)avail_frames_host[s] : 0u, (uint32_t)ms, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
-        }
-        {
-            const rh_status up = upload_descriptors(p, n_sources, hs);
-            if (up != RH_OK) return up;
-        }
-        p->equal = false;
-        p->n_sources = n_sources;
-        p->out_frames = out;
-        rh_status st = activate_plan(p, &p->wave);  // never reallocates the rows: they were sized for the largest block
-        if (st != RH_OK) return st;
-        StreamArgs sa;
-        sa.mode = final_block ? 2u : 1u;
-        sa.active = (uint32_t)out;
-        sa.m0 = p->st_m;
-        sa.g0 = p->st_g0;
-        sa.gran_cols = p->st_cols;
-        st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
-        if (st != RH_OK) return st;
-        p->st_n_each += 1;
-        if (!final_block && p->filt) {
-            hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, (uint32_t)tiles + 1u, (uint32_t)p->wave.J, p->epoch,
-                               p->epoch + 1);
-            RH_CHECK_LAUNCH();
-            const rh_status mk = mark_launch(p, hs);
-            if (mk != RH_OK) return mk;
-        }
-        p->st_m += out;
-    }
-    p->st_nsrc = n_sources;
-    if (final_block) {
-        p->st_done = true;
-        uint64_t mx = 0;
-        for (uint32_t s = 0; s < n_sources; ++s) mx = avail_frames_host[s] > mx ? avail_frames_host[s] : mx;
-        *consumed_frames = mx;
-    } else {
-        // the next block needs the taps of output frames st_m-2 onwards: input frame floor((st_m-2)*F/T).  The
-        // caller drops min(consumed, what it holds) frames of every source.
-        const uint64_t keep_from = p->st_m >= 2 ? stream_first_tap(p->st_m - 2, F, T, cin, cout) : 0;
-        *consumed_frames = keep_from > p->st_g0 ? keep_from - p->st_g0 : 0;
-        *consumed_frames -= *consumed_frames % (4u / p->cfg.channels);  // whole 16-byte vectors (see rh_rlm_stream_block)
-        p->st_g0 += *consumed_frames;
-    }
-    *out_frames = out;
-    return RH_OK;
-}
-
-rh_status rh_rlm_last_status(rh_rlm *p) {
-    RH_REQUIRE_INIT();
-    if (!p) return RH_ERR_INVALID;
-    for (rh_rlm::FilterClass &c : p->cls) {  // per-source filters: the kernels ran on the classes' handles
-        const rh_status st = rh_rlm_last_status(c.h);
-        if (st != RH_OK) return st;
-    }
-    {
-        const rh_status w = wait_idle(p);  // every launch of this handle has completed: the words below are final
-        if (w != RH_OK) return w;
-    }
-    uint32_t ctl[2] = {0, 0};
-    RH_HIP_TRY(hipMemcpy(ctl, p->d_ctl, 8, hipMemcpyDeviceToHost));
-    if (ctl[1]) {  // sticky until read
-        RH_HIP_TRY(rh::fill_now(p->d_ctl + 1, 0, 4));
-        return RH_ERR_TIMEOUT;
-    }
-    return RH_OK;
-}
-
-rh_status rh_rlm_late_carries(rh_rlm *p, uint64_t *count) {
-    RH_REQUIRE_INIT();
-    if (!p || !count) return RH_ERR_INVALID;
-    {
-        const rh_status w = wait_idle(p);
-        if (w != RH_OK) return w;
-    }
-    uint32_t v[2] = {0, 0};
-    RH_HIP_TRY(hipMemcpy(v, p->d_ctl + 2, 8, hipMemcpyDeviceToHost));
-    RH_HIP_TRY(rh::fill_now(p->d_ctl + 2, 0, 8));
-    *count = v[0] | ((uint64_t)v[1] << 32);  // high word: empty polls (RH_PHASE_PROFILE builds)
-    return RH_OK;
-}
-
-rh_status rh_rlm_phase_cycles(rh_rlm *p, double out8[8]) {
-    RH_REQUIRE_INIT();
-    if (!p || !out8) return RH_ERR_INVALID;
-    if (!p->d_prof) return RH_ERR_UNSUPPORTED;  // not an RH_PHASE_PROFILE build
-    std::vector<unsigned long long> h((size_t)p->n_tiles * 8);
-    RH_HIP_TRY(hipMemcpy(h.data(), p->d_prof, h.size() * 8, hipMemcpyDeviceToHost));
-    if (const char *path = rh::knob(rh::K_PROF_DUMP)) {  // raw [tiles][8] u64 for tools/prof_tiles.py
-        if (FILE *f = fopen(path, "wb")) {
-            fwrite(h.data(), 8, h.size(), f);
-            fclose(f);
-        }
-    }
-    for (int i = 0; i < 8; ++i) out8[i] = 0.0;
-    for (uint32_t t = 0; t < p->n_tiles; ++t)
-        for (int i = 0; i < 8; ++i) out8[i] += (double)h[(size_t)t * 8 + i];
-    for (int i = 0; i < 8; ++i) out8[i] /= p->n_tiles ? p->n_tiles : 1;
-    return RH_OK;
-}
-
-rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
-    if (!p || !info) return RH_ERR_INVALID;
-    if (!p->cls.empty()) {  // per-source filters: the geometry of the largest class
-        const rh_rlm::FilterClass *best = nullptr;
-        for (const rh_rlm::FilterClass &c : p->cls)
-            if (!best || c.members.size() > best->members.size()) best = &c;
-        return rh_rlm_geometry(best->h, info);
-    }
-    const Plan &pl = *p->plan;
-    info->threads = 64;
-    info->frames_per_lane = (uint32_t)pl.v->R;
-    info->ring_stages = (uint32_t)pl.v->NS;
-    info->stage_kib = (uint32_t)pl.v->KV;
-    info->lds_bytes = p->launch_lds ? p->launch_lds : pl.lds_bytes;
-    info->lookback_tiles = pl.J;
-    info->resident_waves_per_cu = (uint32_t)pl.resident_per_cu;
-    info->n_tiles = p->n_tiles;
-    info->general_kernel = (pl.general || p->plan == &p->pair) ? 1u : 0u;
-    info->ragged_pair = p->plan == &p->pair ? 1u : 0u;
-    info->mix_first = (p->pre_filter && p->plan == &p->fast) ? 1u : mix_first_applies(p, pl, p->n_sources, false, false) ? (p->chunk.ok ? 2u : 1u) : 0u;
-    return RH_OK;
-}
-
-}  // extern "C"
+}  // namespace rhp
