@@ -23,6 +23,8 @@
 // the peak follower as a third chain wave; more streams than the chip holds workgroups of 16 simply queue):
 //     k_agc_fused            ALL of the above in one workgroup per 16 streams: the two chains on a wave each, the square roots and
 //                            divides on four more, loaders and storers around them -- nothing but x in and y out   (see there)
+//     k_agc_fused0           round 5, the default parameters (release == 0): the same pipeline with everything that is not a chain
+//                            operation taken off the two chain waves (a wave's time is its instruction count x 6-7 cycles)   (see there)
 // Both chains MUST round like the reference, step by step: the window sum drifts 7e-5 relative over 2 Mi samples when
 // re-associated, and the gain -- a one-pole with a 4 s time constant, 192 000 samples at 48 kHz -- integrates its own rounding
 // noise to 5e-6 relative (x gain 7 = 4e-5 on the output): a scan over composed gain maps (g -> min(H, max(L, c*g + B)) is
@@ -422,6 +424,16 @@ __device__ __forceinline__ float agc_desired(float sum, float p, const AgcK &k) 
     const float peak_gain = p > 0.0f ? fminf(k.target_level / p, k.absolute_max_gain) : k.absolute_max_gain;
     return fmaxf(fminf(rms_gain, peak_gain), k.floor);
 }
+// The same value with ONE division: a correctly rounded quotient is monotonic in its divisor, so of target / rms and target / p the
+// smaller is the one by the larger divisor -- min(target / rms, min(target / p, max)) == min(target / max(rms, p), max) bit for bit -- and
+// a level that is zero (or a NaN: the square root of a window sum that rounding drove below zero; `rms > 0` is false for it and the
+// reference takes `max`) drops out of both forms: v_max_f32 returns the other operand.  k_agc_fused0's D waves: 11 instructions of 48 less.
+__device__ __forceinline__ float agc_desired1(float sum, float p, const AgcK &k) {
+    const float rms = sqrtf(sum / (float)kRmsWindow);
+    const float m = fmaxf(rms, p);
+    const float g = m > 0.0f ? fminf(k.target_level / m, k.absolute_max_gain) : k.absolute_max_gain;
+    return fmaxf(g, k.floor);
+}
 template <bool GEN>
 __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -714,6 +726,403 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
     barrier_lds();
 }
 
+// ---- round 5: the default parameters again, the chain waves carrying nothing but their chains -------------------------------
+// Every wave of this kernel issues ONE instruction every 6-7 cycles, whatever the instruction and whether or not it depends on
+// the one before (RH_AGC_PROFILE builds print the time each role spends between two barriers: profiles/r05_agc_roles.txt), so a
+// chain wave's time is its instruction COUNT.  k_agc_fused<false> above spends 5.5 instructions a sample on each: the window sum
+// squares both its inputs (2 multiplies beside the 2 dependent adds), the gain makes its two operands (a multiply and a median
+// beside the 3 dependent operations), both add a ring base to every address and wait before every first use of a vector.  Here the
+// waves that only move data or work in parallel take that over, one pipeline stage earlier:
+//     role 4 5 (X, Q)      LDS-DMA of x, 3 chunks ahead; chunk t: x*x of the vectors the wave fetched itself -> the value image
+//     role 0 (S)           window sum of chunk t-1:    x*x (image), x_old -> sum        (1 multiply, 2 dependent adds)
+//     role 2 3 6 7 (D)     operands of chunk t-2:      sum, |x| -> desired * (1 - attack) (image), clamp(desired) (a ring of its own);
+//                          `desired` with ONE division (agc_desired1)
+//     role 1 (G)           gain of chunk t-3:          the two operands -> gain          (3 dependent operations, nothing else)
+//     role 10 11 (Y)       output of chunk t-4:        x * gain -> memory
+//     role 8 9             LDS-DMA of x_old, as before
+// and the chain waves take their vectors in batches of four behind ONE wait each.  Per chunk of 128 samples: S 530 instructions
+// (384 arithmetic, 96 LDS, 32 address adds, 18 waits and scalar), G 528 -- 4.1 a sample against 5.5 -- in 3300 cycles.
+// Same operations on the same operands in the same order as k_agc_fused<false> -- who computes a square or a clamp does not change
+// its bits (tests: equal to RH_AGC_FUSED_R4=1, to the segment form and to the reference-order kernel).
+// LDS: x 8 chunks (3 in flight, Q, S's step, D, G's step, Y), x_old 4, the value image 5, clamp(desired) 2: 152 KiB.
+constexpr int kQRX = 8, kQRO = 4, kQRA = 5, kQRC = 2;
+constexpr uint32_t kQOBase = kQRX * kSlotBytes, kQABase = kQOBase + kQRO * kSlotBytes, kQCBase = kQABase + kQRA * kSlotBytes, kQFin = kQCBase + kQRC * kSlotBytes;
+constexpr size_t kFused0Lds = (size_t)kQFin + kFS * 4;  // 152 KiB + 64 B
+__device__ __forceinline__ void ring_next(uint32_t &s, uint32_t n) { s = s + 1 == n ? 0 : s + 1; }
+#ifdef RH_AGC_PROFILE  // diagnostics builds: per role, the time between leaving a barrier and reaching the next (s_memtime), printed by workgroup 0
+#define RH_AP_DECL unsigned long long ap_busy = 0, ap_t0 = 0; const unsigned long long ap_start = __builtin_readcyclecounter(), ap_rt0 = __builtin_amdgcn_s_memrealtime();
+#define RH_AP_BEGIN ap_t0 = __builtin_readcyclecounter();
+#define RH_AP_END ap_busy += __builtin_readcyclecounter() - ap_t0;
+#define RH_AP_REPORT(name)                                                                                                                      \
+    if (blockIdx.x == 0 && lane == 0)                                                                                                           \
+        printf("agc hw wave %2d role %2d %s: busy %llu of %llu memtime ticks, %llu realtime ticks, %u steps\n", wave_hw, wave, name, ap_busy,   \
+               __builtin_readcyclecounter() - ap_start, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ap_rt0), nsteps);
+#else
+#define RH_AP_DECL
+#define RH_AP_BEGIN
+#define RH_AP_END
+#define RH_AP_REPORT(name)
+#endif
+#ifndef RH_AGC_ND
+#define RH_AGC_ND 4  // D waves: 4 (8 samples a lane and chunk) or 8 (4 samples)
+#endif
+constexpr int kQND = RH_AGC_ND, kQWaves = 8 + kQND;
+__global__ __launch_bounds__(64 * kQWaves) void k_agc_fused0(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    typedef __attribute__((address_space(3))) v4f lds_v4;
+    typedef __attribute__((address_space(3))) float lds_f;
+    // Which role runs where (hardware wave w of a workgroup sits on SIMD w % 4) moves the time by 20 %: a chain wave issues FASTER the
+    // busier the waves beside it are (6.1 cycles an instruction with two D waves beside it, 6.3 with one, 6.9 with two loaders) -- but
+    // a D wave beside a chain takes 3200 cycles for its chunk instead of 2200, two of them 4000, more than the chain.  Measured
+    // (profiles/r05_agc_placement_*.txt, 64 x 1 Mi frames): S G | D D | X X | O O | Y Y in hardware order 27.8 -> 25.0 ms with the
+    // batched waits; both D pairs on the chains' SIMDs 27.4; one D beside each chain and Y behind it (below) 23.0; sixteen waves with
+    // eight D waves (RH_AGC_ND=8) 26.3-27.1; s_setprio for the chains: nothing.  RH_AGC_ROLE_MAP (builds): the role of each hardware wave.
+#ifndef RH_AGC_ROLE_MAP
+#if RH_AGC_ND == 8
+#define RH_AGC_ROLE_MAP 0, 1, 12, 14, 2, 6, 13, 15, 3, 7, 4, 5, 10, 11, 8, 9
+#else
+#define RH_AGC_ROLE_MAP 0, 1, 2, 3, 6, 7, 4, 5, 10, 11, 8, 9
+#endif
+#endif
+    const int wave_hw = __builtin_amdgcn_readfirstlane((int)threadIdx.x / 64), lane = (int)threadIdx.x & 63;
+    constexpr int kRoleMap[kQWaves] = {RH_AGC_ROLE_MAP};
+    int wave = 0;
+#pragma unroll
+    for (int w = 0; w < kQWaves; ++w) wave = wave_hw == w ? kRoleMap[w] : wave;
+    const uint32_t g0 = blockIdx.x * (uint32_t)kFS;
+    const uint32_t live = a.n_streams - g0 < (uint32_t)kFS ? a.n_streams - g0 : (uint32_t)kFS;
+    const uint32_t nch = (uint32_t)(a.n / kFCS);  // whole chunks (host: n < 2^24); the rest is wave 0's epilogue
+    const uint32_t nsteps = nch + 4;              // step t: Q on chunk t, S on t - 1, D on t - 2, G on t - 3, Y on t - 4
+    const bool chain_lane = lane < kFS;
+    const bool mine = (uint32_t)lane < live;
+    const uint32_t stream = g0 + (mine ? (uint32_t)lane : live - 1);
+    RH_AP_DECL
+    if (wave == 0 || wave == 1) {
+        // a chain lane's 32 vectors of a chunk image: vector 16 h + l of stream o lies at pre[l] + 256 h (fslot_of: (16 h + l) ^ o = 16 h + (l ^ o), o < 16)
+        const uint32_t o = (uint32_t)lane & (kFS - 1);
+        uint32_t pre[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) pre[l] = fslot_of(o, (uint32_t)l) * 16u;
+        if (wave == 0) {  // ---- S: the window sum of chunk t - 1 (agc.rs:152-163), in place over the squares Q left in the image ----
+            float *st = a.state + (uint64_t)stream * a.state_stride;
+            SumOp op;
+            op.sum = st[0];
+            auto chunk = [&](uint32_t so_, uint32_t sa, auto head_tag, auto zero_tag) {
+                constexpr bool HEAD = decltype(head_tag)::value, ZERO = decltype(zero_tag)::value;
+                const lds_u8 *ino = lds + kQOBase + so_ * kSlotBytes;
+                lds_u8 *img = lds + kQABase + sa * kSlotBytes;
+                // (batches of 4 vectors, one wait per batch, the next batch's reads issued in the middle of this one's chain: see G)
+                constexpr int kB = 4, kNB = kFV / kB;
+                v4f nw[2][kB], od[2][kB], r[kB];
+                auto slot_of = [&](int v) { return pre[v & 15] + (uint32_t)(v >> 4) * 256u; };
+                auto fetch = [&](int b) {
+#pragma unroll
+                    for (int j = 0; j < kB; ++j) {
+                        nw[b & 1][j] = *(const lds_v4 *)(img + slot_of(b * kB + j));
+                        if (!ZERO) od[b & 1][j] = *(const lds_v4 *)(ino + slot_of(b * kB + j));
+                    }
+                };
+                auto run = [&](int b, int j) {
+                    v4f q = ZERO ? v4f{0.f, 0.f, 0.f, 0.f} : od[b & 1][j];
+                    const v4f &n4 = nw[b & 1][j];
+#ifndef RH_AGC_DIAG_NOSQ  // (diagnostics builds, wrong results: what does the remaining multiply cost the chain wave?)
+                    if (!HEAD) q.x = q.x * q.x, q.y = q.y * q.y, q.z = q.z * q.z, q.w = q.w * q.w;  // (HEAD: the carried window holds squares)
+#endif
+                    op.sum = op.sum - q.x + n4.x, r[j].x = op.sum;
+                    op.sum = op.sum - q.y + n4.y, r[j].y = op.sum;
+                    op.sum = op.sum - q.z + n4.z, r[j].z = op.sum;
+                    op.sum = op.sum - q.w + n4.w, r[j].w = op.sum;
+                };
+                fetch(0);
+#pragma unroll
+                for (int b = 0; b < kNB; ++b) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b > 0) {
+                        *(lds_v4 *)(img + slot_of((b - 1) * kB + 2)) = r[2];
+                        *(lds_v4 *)(img + slot_of((b - 1) * kB + 3)) = r[3];
+                    }
+                    run(b, 0), run(b, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b + 1 < kNB) fetch(b + 1);
+                    *(lds_v4 *)(img + slot_of(b * kB + 0)) = r[0];
+                    *(lds_v4 *)(img + slot_of(b * kB + 1)) = r[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    run(b, 2), run(b, 3);
+                }
+                *(lds_v4 *)(img + slot_of(kFV - 2)) = r[2];
+                *(lds_v4 *)(img + slot_of(kFV - 1)) = r[3];
+            };
+            uint32_t so_ = kQRO - 1, sa = kQRA - 1;  // the slots of chunk t - 1
+            for (uint32_t t = 0; t < nsteps; ++t) {
+                barrier_lds();
+                RH_AP_BEGIN
+                if (t >= 1 && t - 1 < nch && chain_lane) {
+                    if (t - 1 < kFHeadChunks) {
+                        if (a.in1_head) chunk(so_, sa, std::true_type{}, std::false_type{});
+                        else chunk(so_, sa, std::true_type{}, std::true_type{});
+                    } else {
+                        chunk(so_, sa, std::false_type{}, std::false_type{});
+                    }
+                }
+                ring_next(so_, kQRO);
+                ring_next(sa, kQRA);
+                RH_AP_END
+            }
+            RH_AP_REPORT("S (window sum)")
+            barrier_lds();  // G's final gain is in the LDS
+            if (mine) {  // the last n % 128 samples: every stage, one sample at a time, straight from memory
+                const float *r0 = a.in + (uint64_t)stream * a.stride;
+                float *ro = a.out + (uint64_t)stream * a.stride_out;
+                const float oma = 1.0f - a.k.attack_coeff;
+                float gain = *(const lds_f *)(lds + kQFin + lane * 4);
+                for (uint64_t i = (uint64_t)nch * kFCS; i < a.n; ++i) {
+                    const bool head = i < (uint64_t)kRmsWindow;
+                    const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
+                    const float xv = r0[i];
+                    const float sm = op.one(xv, ov, head);
+                    const float d = agc_desired(sm, fabsf(xv), a.k);
+                    const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
+                    gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
+                    ro[i] = xv * gain;
+                }
+                st[0] = op.sum;
+                st[3] = gain;
+                if (a.n) st[2] = fabsf(r0[a.n - 1]);  // release == 0: the peak level is the last sample's magnitude
+            }
+            return;
+        }
+        // ---- G: the gain of chunk t - 3 (agc.rs:486-499 with release == 0: GainOp0), in place over desired * (1 - attack) ----
+        const float *st = a.state + (uint64_t)stream * a.state_stride;
+        float gain = st[3];
+        const float att = a.k.attack_coeff;
+        uint32_t sa = kQRA - 3, sc = (0u - 3u) & (kQRC - 1);  // the slots of chunk t - 3
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            RH_AP_BEGIN
+            if (t >= 3 && t - 3 < nch && chain_lane) {
+                lds_u8 *img = lds + kQABase + sa * kSlotBytes;
+                const lds_u8 *clp = lds + kQCBase + sc * kSlotBytes;
+                // Batches of 4 vectors, the next batch's reads issued in the middle of this one's chain and ONE wait per batch (the compiler's
+                // own schedule waits before every first use, 63 times a chunk -- and every instruction of a lone wave costs its 6 cycles); a
+                // batch's last two results are written behind the next batch's wait, so that no wait ever stands behind a fresh LDS write.
+                constexpr int kB = 4, kNB = kFV / kB;
+                v4f da[2][kB], dc[2][kB], r[kB];
+                auto slot_of = [&](int v) { return pre[v & 15] + (uint32_t)(v >> 4) * 256u; };
+                auto fetch = [&](int b) {
+#pragma unroll
+                    for (int j = 0; j < kB; ++j) {
+                        da[b & 1][j] = *(const lds_v4 *)(img + slot_of(b * kB + j));
+                        dc[b & 1][j] = *(const lds_v4 *)(clp + slot_of(b * kB + j));
+                    }
+                };
+                auto run = [&](int b, int j) {
+                    const v4f &A = da[b & 1][j], &C = dc[b & 1][j];
+#ifdef RH_AGC_DIAG_G  // diagnostics builds (wrong results): the chain with two dependent operations a sample instead of three
+                    gain = gain * att + A.x, r[j].x = gain;
+                    gain = gain * att + A.y, r[j].y = gain;
+                    gain = gain * att + A.z, r[j].z = gain;
+                    gain = gain * att + A.w + C.w, r[j].w = gain;
+#else
+                    gain = __builtin_amdgcn_fmed3f(gain * att + A.x, 0.1f, C.x), r[j].x = gain;
+                    gain = __builtin_amdgcn_fmed3f(gain * att + A.y, 0.1f, C.y), r[j].y = gain;
+                    gain = __builtin_amdgcn_fmed3f(gain * att + A.z, 0.1f, C.z), r[j].z = gain;
+                    gain = __builtin_amdgcn_fmed3f(gain * att + A.w, 0.1f, C.w), r[j].w = gain;
+#endif
+                };
+                fetch(0);
+#pragma unroll
+                for (int b = 0; b < kNB; ++b) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b > 0) {
+                        *(lds_v4 *)(img + slot_of((b - 1) * kB + 2)) = r[2];
+                        *(lds_v4 *)(img + slot_of((b - 1) * kB + 3)) = r[3];
+                    }
+                    run(b, 0), run(b, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b + 1 < kNB) fetch(b + 1);
+                    *(lds_v4 *)(img + slot_of(b * kB + 0)) = r[0];
+                    *(lds_v4 *)(img + slot_of(b * kB + 1)) = r[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    run(b, 2), run(b, 3);
+                }
+                *(lds_v4 *)(img + slot_of(kFV - 2)) = r[2];
+                *(lds_v4 *)(img + slot_of(kFV - 1)) = r[3];
+            }
+            ring_next(sa, kQRA);
+            sc = (sc + 1) & (kQRC - 1);
+            RH_AP_END
+        }
+        RH_AP_REPORT("G (gain)")
+        if (chain_lane) *(lds_f *)(lds + kQFin + lane * 4) = gain;
+        barrier_lds();
+        return;
+    }
+    if (wave == 2 || wave == 3 || wave == 6 || wave == 7 || wave >= 12) {  // ---- D: the gain's two operands for chunk t - 2, 4 samples per lane and part of a chunk ----
+        const uint32_t m = (uint32_t)(wave >= 12 ? wave - 8 : wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : 3);
+        constexpr int kParts = 8 / kQND;                        // 16-byte vectors per lane and chunk
+        constexpr uint32_t kPart = kSlotBytes / kParts;
+        const uint32_t q0 = (m * 64u + (uint32_t)lane) * 16u;  // this lane's slots: q0 (and q0 + 4 KiB: the images share one layout)
+        const float oma = 1.0f - a.k.attack_coeff, maxg = a.k.absolute_max_gain;
+        uint32_t sx = kQRX - 2, sa = kQRA - 2, sc = 0;  // the slots of chunk t - 2
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            RH_AP_BEGIN
+            if (t >= 2 && t - 2 < nch) {
+                const lds_u8 *inx = lds + sx * kSlotBytes;
+                lds_u8 *img = lds + kQABase + sa * kSlotBytes, *clp = lds + kQCBase + sc * kSlotBytes;
+#pragma unroll
+                for (int h = 0; h < kParts; ++h) {
+                    const v4f s4 = *(const lds_v4 *)(img + q0 + h * kPart), x4 = *(const lds_v4 *)(inx + q0 + h * kPart);
+                    v4f d, dc;
+#ifdef RH_AGC_DIAG_D  // diagnostics builds (wrong results): what do the square roots and divides cost the pipeline?
+                    d = s4 + x4;
+#elif defined(RH_AGC_TWO_DIVISIONS)
+                    d.x = agc_desired(s4.x, fabsf(x4.x), a.k), d.y = agc_desired(s4.y, fabsf(x4.y), a.k);
+                    d.z = agc_desired(s4.z, fabsf(x4.z), a.k), d.w = agc_desired(s4.w, fabsf(x4.w), a.k);
+#else
+                    d.x = agc_desired1(s4.x, fabsf(x4.x), a.k), d.y = agc_desired1(s4.y, fabsf(x4.y), a.k);
+                    d.z = agc_desired1(s4.z, fabsf(x4.z), a.k), d.w = agc_desired1(s4.w, fabsf(x4.w), a.k);
+#endif
+                    // what does not wait for the gain: clamp(desired) and desired * (1 - attack), the two operands of the chain
+                    dc.x = __builtin_amdgcn_fmed3f(d.x, 0.1f, maxg), dc.y = __builtin_amdgcn_fmed3f(d.y, 0.1f, maxg);
+                    dc.z = __builtin_amdgcn_fmed3f(d.z, 0.1f, maxg), dc.w = __builtin_amdgcn_fmed3f(d.w, 0.1f, maxg);
+                    *(lds_v4 *)(img + q0 + h * kPart) = d * oma;
+                    *(lds_v4 *)(clp + q0 + h * kPart) = dc;
+                }
+            }
+            ring_next(sx, kQRX);
+            ring_next(sa, kQRA);
+            sc = (sc + 1) & (kQRC - 1);
+            RH_AP_END
+        }
+        RH_AP_REPORT("D (desired gain)")
+        barrier_lds();
+        return;
+    }
+    // per-lane geometry of the line-wise transfers (as in k_agc_fused)
+    uint32_t so[kDma], sj[kDma];
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t q = (uint32_t)k * 64u + (uint32_t)lane;
+        so[k] = q / kFV;
+        sj[k] = (q % kFV) ^ (so[k] & (kFV - 1));
+    }
+    constexpr int kMine = kDma / 2;
+    if (wave >= 10) {  // ---- Y: chunk t - 4 leaves as x * gain (agc.rs:503), whole lines; half the lines each ----
+        const int half = wave - 10;
+        uint32_t sx = kQRX - 4, sa = kQRA - 4;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            RH_AP_BEGIN
+            if (t >= 4) {  // (t - 4 < nch always: nsteps = nch + 4)
+                const lds_u8 *inx = lds + sx * kSlotBytes, *img = lds + kQABase + sa * kSlotBytes;
+                float *ob = a.out + (uint64_t)g0 * a.stride_out + (uint64_t)(t - 4) * kFCS;
+#pragma unroll
+                for (int k = 0; k < kDma; ++k) {
+                    if (k / kMine != half) continue;
+                    const v4f g4 = *(const lds_v4 *)(img + (k * 64 + lane) * 16), x4 = *(const lds_v4 *)(inx + (k * 64 + lane) * 16);
+                    if (so[k] < live) __builtin_nontemporal_store(x4 * g4, reinterpret_cast<v4f *>(ob + (uint64_t)so[k] * a.stride_out + sj[k] * 4u));
+                }
+            }
+            ring_next(sx, kQRX);
+            ring_next(sa, kQRA);
+            RH_AP_END
+        }
+        RH_AP_REPORT("Y (output)")
+        barrier_lds();
+        return;
+    }
+    const int second = wave >= 8 ? 1 : 0, half = wave & 1;
+    uint32_t voff[kDma];  // host: kFS * stride * 4 < 2^32
+#pragma unroll
+    for (int k = 0; k < kDma; ++k) {
+        const uint32_t o = so[k] < live ? so[k] : live - 1;
+        voff[k] = (uint32_t)(((uint64_t)o * a.stride + sj[k] * 4u) * 4u);
+    }
+    if (!second) {  // ---- X, Q (waves 4 5): x, three chunks ahead of its squares; chunk t's squares go to the value image ----
+        const uint32_t lbase = (uint32_t)(uintptr_t)lds;
+        uint32_t slot_next = 0;
+        auto issue = [&](uint32_t c) {
+            const uint32_t slot = lbase + slot_next * kSlotBytes;
+            ring_next(slot_next, kQRX);
+            const float *b = a.in + (uint64_t)g0 * a.stride + (uint64_t)c * kFCS;
+#pragma unroll
+            for (int k = 0; k < kDma; ++k)
+                if (k / kMine == half) glds16(b, voff[k], slot + k * 1024);
+        };
+        for (uint32_t c = 0; c < nch && c < 3u; ++c) issue(c);
+        uint32_t sx = 0, sa = 0;
+        for (uint32_t t = 0; t < nsteps; ++t) {
+            barrier_lds();
+            RH_AP_BEGIN
+            // into the slot of chunk t - 5, which Y left before this barrier
+            if (t + 3 < nch) issue(t + 3);
+            if (t < nch) {  // chunk t has landed when only the chunks issued after it are outstanding (vmcnt retires in order)
+                const uint32_t left = nch - 1 - t;
+                if (left >= 3) wait_vm<3 * kMine>();
+                else if (left == 2) wait_vm<2 * kMine>();
+                else if (left == 1) wait_vm<kMine>();
+                else wait_vm<0>();
+                const lds_u8 *inx = lds + sx * kSlotBytes;
+                lds_u8 *img = lds + kQABase + sa * kSlotBytes;
+#pragma unroll
+                for (int k = 0; k < kDma; ++k) {
+                    if (k / kMine != half) continue;  // (the vectors this wave fetched itself: its own vmcnt covers them)
+                    const v4f x4 = *(const lds_v4 *)(inx + (k * 64 + lane) * 16);
+                    v4f q;
+                    q.x = x4.x * x4.x, q.y = x4.y * x4.y, q.z = x4.z * x4.z, q.w = x4.w * x4.w;  // |x| * |x| (agc.rs:414) == x * x
+                    *(lds_v4 *)(img + (k * 64 + lane) * 16) = q;
+                }
+            }
+            ring_next(sx, kQRX);
+            ring_next(sa, kQRA);
+            RH_AP_END
+        }
+        RH_AP_REPORT("X, Q (x and its squares)")
+        barrier_lds();
+        return;
+    }
+    // ---- waves 8 9: what leaves the window (x 8192 samples back, or the carried window), landed before S's step ----
+    const uint32_t lbase = (uint32_t)(uintptr_t)lds + kQOBase;
+    uint32_t slot_next = 0;
+    auto issue = [&](uint32_t c) {
+        const uint32_t slot = lbase + slot_next * kSlotBytes;
+        ring_next(slot_next, kQRO);
+        if (c < kFHeadChunks && a.in1_head) {  // rows of 8192 floats: the carried window
+            const float *bh = a.in1_head + (uint64_t)g0 * kRmsWindow + (uint64_t)c * kFCS;
+#pragma unroll
+            for (int k = 0; k < kDma; ++k)
+                if (k / kMine == half) glds16(bh, (((so[k] < live ? so[k] : live - 1) * kRmsWindow + sj[k] * 4u) * 4u), slot + k * 1024);
+            return;
+        }
+        // (a fresh window -- zeros, S does not read the slot -- still fetches, x again: every chunk counts the same in vmcnt)
+        const float *b = a.in + (uint64_t)g0 * a.stride + (uint64_t)c * kFCS - (c < kFHeadChunks ? 0 : kRmsWindow);
+#pragma unroll
+        for (int k = 0; k < kDma; ++k)
+            if (k / kMine == half) glds16(b, voff[k], slot + k * 1024);
+    };
+    for (uint32_t c = 0; c < nch && c < 2u; ++c) issue(c);
+    for (uint32_t t = 0; t < nsteps; ++t) {
+        RH_AP_BEGIN
+        if (t >= 1 && t - 1 < nch) {  // S takes chunk t - 1 behind this barrier
+            const uint32_t left = nch - t;  // chunks behind it
+            if (left >= 2) wait_vm<2 * kMine>();
+            else if (left == 1) wait_vm<kMine>();
+            else wait_vm<0>();
+        }
+        RH_AP_END
+        barrier_lds();
+        if (t + 2 < nch) issue(t + 2);  // into the slot of chunk t - 2, which S left before this barrier
+    }
+    RH_AP_REPORT("x_old (its wait only)")
+    barrier_lds();
+}
+
 // ---- everything that is not a chain: one lane per 4 samples, the whole chip.  A launch covers samples [off, off + len) of every row
 // (rows are n floats apart).
 struct SegArgs {
@@ -945,8 +1354,10 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
     if (fused) {
         static const rh_status attr0 = chain_attr_n(&k_agc_fused<false>, "hipFuncSetAttribute(k_agc_fused)", kFusedLds);
         static const rh_status attr1 = chain_attr_n(&k_agc_fused<true>, "hipFuncSetAttribute(k_agc_fused)", kFusedLdsG);
+        static const rh_status attr2 = chain_attr_n(&k_agc_fused0, "hipFuncSetAttribute(k_agc_fused0)", kFused0Lds);
         if (attr0 != RH_OK) return attr0;
         if (attr1 != RH_OK) return attr1;
+        if (attr2 != RH_OK) return attr2;
         FusedArgs f;
         f.in = src;
         f.in1_head = ordered;
@@ -958,7 +1369,8 @@ rh_status agc_chain_launch(float *dst, const float *src, uint64_t n_samples, uin
         f.state_stride = base.state_stride;
         f.k = k;
         if (general) hipLaunchKernelGGL(k_agc_fused<true>, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWavesG), kFusedLdsG, s, f);
-        else hipLaunchKernelGGL(k_agc_fused<false>, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWaves), kFusedLds, s, f);
+        else if (rh::knob(rh::K_AGC_FUSED_R4)) hipLaunchKernelGGL(k_agc_fused<false>, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kFWaves), kFusedLds, s, f);
+        else hipLaunchKernelGGL(k_agc_fused0, dim3((n_streams + kFS - 1) / kFS), dim3(64 * kQWaves), kFused0Lds, s, f);
         RH_CHECK_LAUNCH();
     } else if (general) {
         // window sum -> dst and peak follower -> rows side by side, desired gain in place, then the gain chain with both candidates

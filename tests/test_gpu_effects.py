@@ -166,6 +166,29 @@ def test_agc_in_one_kernel_equals_the_segment_by_segment_form(G, O, S, n, kw):
     assert torch.equal(st_a, st_b)
 
 
+@pytest.mark.parametrize("S,n", [(3, 127), (16, 128), (17, 8192 + 300), (5, 40004), (40, 33000), (300, 1500)])
+def test_agc_round_5_kernel_equals_round_4s(G, O, S, n):
+    """k_agc_fused0 (round 5: the squares, the clamp and desired * (1 - attack) made by the waves around the two chain waves, the desired gain
+    with one division, one wait per four vectors) against k_agc_fused<false> (RH_AGC_FUSED_R4=1): who computes an operand does not change
+    its bits -- fresh windows, carried windows across uneven blocks, partial groups of streams, tails shorter than a chunk."""
+    import torch
+
+    xs = [_programme(900 + s, n + 8)[:n] for s in range(S)]
+    x = torch.from_numpy(np.stack(xs)).cuda()
+    a = G.agc_batch(x, 48000)
+    with _env(RH_AGC_FUSED_R4="1"):
+        b = G.agc_batch(x, 48000)
+    assert torch.equal(a, b)
+    cuts = sorted(set([0, n] + [4 * int(c) for c in np.random.default_rng(S * 77 + n).integers(1, max(n // 4, 2), 4) if 4 * int(c) < n]))
+    st_a, st_b = G.agc_state(S), G.agc_state(S)
+    pa = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_a) for i, j in zip(cuts[:-1], cuts[1:])]
+    with _env(RH_AGC_FUSED_R4="1"):
+        pb = [G.agc_batch(x[:, i:j].contiguous(), 48000, state=st_b) for i, j in zip(cuts[:-1], cuts[1:])]
+    for u, v in zip(pa, pb):
+        assert torch.equal(u, v)
+    assert torch.equal(st_a, st_b)
+
+
 @pytest.mark.parametrize("S,n", [(1, 40001), (1, 32770), (3, 40003), (2, 65537)])
 def test_agc_one_stream_of_an_odd_length_above_the_square_pass_threshold(G, O, S, n):
     """rows of n >= 32 768 samples take the parallel square pass, whose rows sit BEHIND the per-stream rows in the scratch:

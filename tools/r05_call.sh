@@ -127,4 +127,40 @@ PY
     RH_PROF_KERNEL=k_rlm bash tools/pmc_cmd.sh r05_cfg2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-autotune --no-per-source --no-per-class > /dev/null 2>&1
     cp gpurun_out/prof/r05_cfg2/summary.txt $E/r05_cfg2_kernel_trace_pmc.txt; head -8 $E/r05_cfg2_kernel_trace_pmc.txt | cut -c1-150
     ;;
+10)  # the AGC's chain waves with nothing but their chains (k_agc_fused0) against round 4's kernel
+    python -m pytest tests/test_gpu_effects.py -q -m gpu -p no:cacheprovider -k agc 2>&1 | tail -4
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['ms_per_step'],4), round(d['roofline']['kernel_ms'],4), (d.get('parity') or {}).get('max_abs_err'))"; }
+    { for rep in 1; do for shape in "64 1048576" "2048 32768"; do set -- $shape; for w in 0 1; do v=""; [ $w = 1 ] && v="RH_AGC_FUSED_R4=1"; echo "agc streams=$1 frames=$2 $v: $(env $v RH_BENCH_NO_PMC=1 python bench.py --config agc --sources $1 --frames $2 --steps 5 2>/dev/null | q)"; done; done; done; } > $E/r05_agc_fused0.txt 2>&1; cat $E/r05_agc_fused0.txt
+    ;;
+11)  # k_agc_fused0: which stage sets a chunk's time?  diagnostics builds (wrong results) beside the product
+    python -m pytest tests/test_gpu_effects.py -q -m gpu -p no:cacheprovider -k agc 2>&1 | tail -3
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['ms_per_step'],4), round(d['roofline']['kernel_ms'],4), (d.get('parity') or {}).get('max_abs_err'))"; }
+    { for shape in "64 1048576" "2048 32768"; do set -- $shape; for v in "" twodiv diagD diagG nosq; do l=""; [ -n "$v" ] && l="RODIO_HIP_LIB=variants/librodio_hip_agc_$v.so"; echo "agc streams=$1 frames=$2 $v: $(env $l RH_BENCH_NO_PMC=1 python bench.py --config agc --sources $1 --frames $2 --steps 5 2>/dev/null | q)"; done; done; } > $E/r05_agc_stages.txt 2>&1; cat $E/r05_agc_stages.txt
+    ;;
+12)  # k_agc_fused0 by role (RH_AGC_PROFILE builds), and how far repeated runs of one build lie apart
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['ms_per_step'],4), (d.get('parity') or {}).get('max_abs_err'))"; }
+    {
+        for v in prof prof2 profD; do echo "## variants/librodio_hip_agc_$v.so, 64 streams x 1 Mi frames"; RODIO_HIP_LIB=variants/librodio_hip_agc_$v.so RH_BENCH_NO_PMC=1 python bench.py --config agc --sources 64 --frames 1048576 --steps 2 --warmup 1 2>&1 | grep "agc role" | tail -6; done
+        for rep in 1 2 3; do for v in "" twodiv diagD; do l=""; [ -n "$v" ] && l="RODIO_HIP_LIB=variants/librodio_hip_agc_$v.so"; echo "agc 64 x 1 Mi $v: $(env $l RH_BENCH_NO_PMC=1 python bench.py --config agc --sources 64 --frames 1048576 --steps 5 2>/dev/null | q)"; done; done
+    } > $E/r05_agc_roles.txt 2>&1; cat $E/r05_agc_roles.txt
+    ;;
+13)  # k_agc_fused0: wave priorities and which roles share the chains' SIMDs
+    q() { python -c "import sys,json; d=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print(round(d['ms_per_step'],4), (d.get('parity') or {}).get('max_abs_err'))"; }
+    { for shape in "64 1048576" "2048 32768"; do set -- $shape; for v in "" $VARIANTS; do l=""; [ -n "$v" ] && l="RODIO_HIP_LIB=variants/librodio_hip_agc_$v.so"; echo "agc streams=$1 frames=$2 $v: $(env $l RH_BENCH_NO_PMC=1 python bench.py --config agc --sources $1 --frames $2 --steps 5 2>/dev/null | q)"; done; done; } > $E/r05_agc_placement_$TAG.txt 2>&1; cat $E/r05_agc_placement_$TAG.txt
+    ;;
+14)  # the AGC's evidence: tests, both shapes through bench.py, kernel trace + counters, time per role
+    python -m pytest tests/test_gpu_effects.py -q -m gpu -p no:cacheprovider -k agc 2>&1 | tail -2
+    python bench.py --config agc > $E/r05_bench_agc.json 2>/dev/null; python bench.py --config agc --sources 2048 --frames 32768 > $E/r05_bench_agc_2048.json 2>/dev/null
+    RH_AGC_FUSED_R4=1 RH_BENCH_NO_PMC=1 python bench.py --config agc > $E/r05_bench_agc_round4_kernel.json 2>/dev/null
+    RH_PROF_KERNEL=k_agc bash tools/pmc_cmd.sh r05_agc python bench.py --config agc --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    cp gpurun_out/prof/r05_agc/summary.txt $E/r05_agc_64x1Mi_kernel_trace_pmc.txt
+    { echo "## RH_AGC_PROFILE build, 64 streams x 1 Mi frames, workgroup 0: s_memtime ticks between leaving a barrier and reaching the next, per wave, summed over the steps"; RODIO_HIP_LIB=variants/librodio_hip_agc_prof.so RH_BENCH_NO_PMC=1 python bench.py --config agc --steps 2 --warmup 1 2>&1 | grep "agc hw" | tail -12 | sort; } > $E/r05_agc_roles_final.txt
+    for f in r05_bench_agc r05_bench_agc_2048 r05_bench_agc_round4_kernel; do python - "$E/$f.json" <<'PY'
+import json,sys
+d=[json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')][-1]
+r=d['roofline']; print(sys.argv[1].split('/')[-1], 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), 'parity', (d.get('parity') or {}).get('max_abs_err'))
+PY
+    done
+    cat $E/r05_agc_roles_final.txt; head -12 $E/r05_agc_64x1Mi_kernel_trace_pmc.txt | cut -c1-160
+    ;;
 esac
