@@ -333,10 +333,11 @@ public:
         want = std::min(want, left_);
         want -= want % ch_;
         if (left_ != kOpenEnded && left_ - want < ch_) want = left_;  // the rest of the span is a cut frame: its samples belong to this span's chain
-        // the source's span ends inside the piece: the piece ends with it (where that is a frame boundary of the format the iterator converts
-        // in; a source that ENDS there -- or whose spans do not hold whole frames -- is read on: the None, or the cut, shows below)
+        // the source's span ends inside the piece: the piece ends with it -- also inside a frame of the format the iterator converts in (the
+        // adapters in front of the iterator re-make their state at that very sample: GpuSource splits its runs there; the planner counts the
+        // open span in samples, so a piece may stop anywhere).  A source that ENDS there is read on: the None shows below.
         bool by_span = false;
-        if (t_left_ != kOpenEnded && t_left_ < want && t_left_ % ch_ == 0 && t_left_ != 0) {
+        if (t_left_ != kOpenEnded && t_left_ < want && t_left_ != 0) {
             want = t_left_;
             by_span = true;
         }
@@ -347,6 +348,7 @@ public:
             none = after && *after == 0;
         }
         if (left_ != kOpenEnded) left_ -= got;
+        span_got_ += got;
         const bool t_was_fresh = t_fresh_;
         if (got) t_fresh_ = false;
         if (t_left_ != kOpenEnded) {
@@ -354,8 +356,7 @@ public:
             if (t_left_ == 0) t_open_ = false;
         }
         const bool closes = none || left_ == 0;
-        const std::size_t tail = closes ? got % ch_ : 0;  // (what becomes of it is the planner's business: it knows the target format)
-        if (!closes) got -= got % ch_;
+        const std::size_t tail = closes ? span_got_ % ch_ : 0;  // the samples of the frame the span's end cuts, over all its pieces (what becomes of them is the planner's business: it knows the target format)
         out = Piece{got, fresh_, closes, ch_, rate_, tail, none, fresh_ ? span_ : std::nullopt, t_ch_, t_rate_, t_was_fresh, t_was_fresh ? t_span_ : std::nullopt};
         const bool produced = got != 0 || (closes && !fresh_);  // a span that had samples before ends here: its last frame is due
         if (got) fresh_ = false;
@@ -393,12 +394,13 @@ private:
         // source does; what the converters make of a cut frame is UniformPlanner::add's business.
         open_ = true;
         fresh_ = true;
+        span_got_ = 0;
         return true;
     }
     Source *up_;
     bool clamp_ = true;
     bool open_ = false, fresh_ = true, ended_ = false;
-    std::size_t left_ = 0;
+    std::size_t left_ = 0, span_got_ = 0;  // samples the open span still admits / has delivered
     std::uint16_t ch_ = 0;
     std::uint32_t rate_ = 0;
     std::optional<std::size_t> span_;
@@ -451,14 +453,19 @@ public:
     static std::uint64_t close_slack_frames(std::uint32_t rate, std::uint32_t to_rate) { return (std::uint64_t)to_rate / rate + 3; }
     void add(const Piece &p, std::vector<Seg> &segs) {
         if (p.opens) {
-            span_in_ = span_m_ = 0;
+            span_in_ = span_m_ = span_samples_ = 0;
             row_off_ = pos_;  // the span's frame 0 sits here
             row_frame0_ = 0;
         }
-        const std::uint64_t f = (p.n - p.tail) / p.ch;
-        span_in_ += f;
+        // (a piece may stop inside a frame where the source's own span does: the open span is counted in samples, the samples of a frame
+        // that is not whole yet lie behind the whole frames in the row and are kept with them)
+        const std::uint64_t span_total = span_samples_ + p.n;
+        const std::size_t tail = p.closes ? (std::size_t)(span_total % p.ch) : 0;  // the samples of the frame the span's end cuts (they may have come with earlier pieces)
+        span_samples_ = span_total - tail;
+        span_in_ = span_samples_ / p.ch;
+        const std::size_t partial = (std::size_t)(span_samples_ % p.ch);
         pos_ += p.n;
-        const bool cut = p.closes && p.tail != 0;
+        const bool cut = tail != 0;
         // A span that ends inside a frame (uniform.rs:56: `.min(32768)` on 3, 5, 6, 7 channels; a source that returns None inside a frame).
         // rodio's SampleRateConverter meets a SHORT frame: every output frame that lerps towards it is cut to its length (zip,
         // sample_rate.rs:174-179), the short frame itself comes out verbatim when an output lands on it (:193-200), and the
@@ -489,7 +496,7 @@ public:
         }
         if (cut) {
             std::uint64_t tail_out = 0;
-            check(rh_uniform_cut_tail_samples(span_in_, (std::uint32_t)p.tail, p.rate, to_rate_, p.ch, to_ch_, &tail_out), "rh_uniform_cut_tail_samples");
+            check(rh_uniform_cut_tail_samples(span_in_, (std::uint32_t)tail, p.rate, to_rate_, p.ch, to_ch_, &tail_out), "rh_uniform_cut_tail_samples");
             if (tail_out) {
                 // the frame in front of the cut is in the row whenever an output lerps towards the cut frame: that output's first tap is
                 // this very frame, and the frames from the next output's first tap on are what a block keeps
@@ -509,7 +516,7 @@ public:
                 sg.g.from_ch = p.ch;
                 sg.g.to_ch = to_ch_;
                 sg.g.gain = 1.0f;
-                sg.g.reserved = (std::uint32_t)p.tail;
+                sg.g.reserved = (std::uint32_t)tail;
                 segs.push_back(sg);
                 out_ += (std::size_t)tail_out;
             }
@@ -523,7 +530,7 @@ public:
             first = std::max(first, row_frame0_);
             first = std::min(first, span_in_);
             keep_off_ = row_off_ + (std::size_t)(first - row_frame0_) * p.ch;
-            keep_n_ = (std::size_t)(span_in_ - first) * p.ch;
+            keep_n_ = (std::size_t)(span_in_ - first) * p.ch + partial;
             held_ = keep_n_;
             next_frame0_ = first;
         }
@@ -542,6 +549,7 @@ private:
     std::uint16_t to_ch_;
     std::uint32_t to_rate_;
     std::uint64_t span_in_ = 0, span_m_ = 0;        // input frames received / output frames planned of the open span
+    std::uint64_t span_samples_ = 0;                // ... and its samples (whole frames + the frame that is not whole yet)
     std::uint64_t row_frame0_ = 0, next_frame0_ = 0;  // span frame index of the first frame the row holds of the open span
     std::size_t row_off_ = 0, pos_ = 0, held_ = 0, keep_off_ = 0, keep_n_ = 0;
     std::size_t out_ = 0;                            // output samples planned in this block
@@ -902,14 +910,12 @@ public:
         for (const Stage &st : stages_)
             if (st.span_rule) rule = st.span_rule;
         if (rule == 2 && up_->current_span_len()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::uniform behind take_duration / delay / channel_volume on a source that reports spans");
-        if (rule != 0) {  // continuous from here on: ChannelCountConverter(SampleRateConverter(..)) once (uniform.rs:62-67)
-            const std::uint16_t from_ch = ch_;
-            convert_sample_rate(sample_rate);
-            if (channels != from_ch) convert_channels(channels);
-            stages_.back().span_rule = 1;
-            return *this;
-        }
-        span_aware_ = true;
+        // (rule != 0: the input is continuous from here on -- current_span_len() is None behind a converter or a Mix -- so the iterator builds
+        // ChannelCountConverter(SampleRateConverter(..)) once, uniform.rs:62-67: ONE span that opens with the first sample and closes with the
+        // stream, through the same planner, which also knows what rodio's converters make of a stream that ends inside a frame)
+        const bool one_span = rule != 0;
+        if (!one_span) span_aware_ = true;
+        auto started = std::make_shared<bool>(false);
         auto plan = std::make_shared<detail::UniformPlanner>(channels, sample_rate);
         auto win = std::make_shared<detail::DeviceBuf>();
         auto keep = std::make_shared<detail::DeviceBuf>();
@@ -929,7 +935,15 @@ public:
                 if (hs) check(rh_memcpy_d2d(win->get(), keep->get(), hs * sizeof(float), c.stream), "rh_memcpy_d2d");
                 if (c.n) check(rh_memcpy_d2d(win->get() + hs, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
                 std::vector<detail::UniformPlanner::Seg> segs;
-                for (const detail::Piece &p : pieces_) plan->add(p, segs);
+                if (one_span) {
+                    if (c.n || (c.flush && *started)) {
+                        detail::Piece p{c.n, !*started, c.flush, in_ch, from, 0, c.flush, std::nullopt, in_ch, from, !*started, std::nullopt};
+                        *started = true;
+                        plan->add(p, segs);
+                    }
+                } else {
+                    for (const detail::Piece &p : pieces_) plan->add(p, segs);
+                }
                 plan->end_block();
                 const std::size_t carried = *part_n;
                 if (carried) check(rh_memcpy_d2d(c.out, part->get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
@@ -952,18 +966,19 @@ public:
                 *part_n = rest;
                 return total - rest;
             },
-            [this, in_ch, channels, from, to](std::size_t n) {  // every span may add its verbatim last frame, or what the converters make of a cut frame
+            [this, in_ch, channels, from, to, one_span](std::size_t n) {  // every span may add its verbatim last frame, or what the converters make of a cut frame
                 // (the block's pieces may come in other formats than the chain was built for: the fewest channels and the lowest rate among them bound it)
-                const std::uint64_t ich = std::min<std::uint64_t>(in_ch, block_min_ch_ ? block_min_ch_ : in_ch), ifrom = std::min<std::uint64_t>(from, block_min_rate_ ? block_min_rate_ : from);
-                const std::uint64_t f = n / ich;
-                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * (pieces_.size() + 2) + 1) * channels;
+                const std::uint64_t ich = one_span ? in_ch : std::min<std::uint64_t>(in_ch, block_min_ch_ ? block_min_ch_ : in_ch), ifrom = one_span ? from : std::min<std::uint64_t>(from, block_min_rate_ ? block_min_rate_ : from);
+                const std::uint64_t f = n / ich + 1;
+                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((one_span ? 1 : pieces_.size()) + 2) + 1) * channels;
             })
-            .on_seek([plan, part_n, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
+            .on_seek([plan, part_n, started, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
                 *plan = detail::UniformPlanner(channels, sample_rate);
                 *part_n = 0;
+                *started = false;
             });
         stages_.back().span_rule = 1;
-        stages_.back().fmt = 3;  // every piece comes with its own format (uniform.rs:58-59: read at every bootstrap)
+        stages_.back().fmt = one_span ? 0 : 3;  // every piece comes with its own format (uniform.rs:58-59: read at every bootstrap); behind another converter nothing changes any more
         ch_ = channels;
         rate_ = sample_rate;
         return *this;
@@ -974,23 +989,21 @@ public:
         auto st = state(2u * ch_);
         const rh_stream sm = stream_;
         scan_kernels_ = true;
+        auto fc = std::make_shared<FrameCarry>();
         return push([=](Ctx &c) {
             const std::uint16_t ch = *chp;
-            std::size_t frames = c.n / ch;
-            const std::size_t rem = c.n % ch;
-            if (rem && c.flush) {  // a stream can end inside a frame: limit.rs:927-988 still limits those samples (every channel has its own
-                                   // integrator; the zero padding only touches channels the stream no longer has)
-                check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
-                frames += 1;
-            }
-            check(rh_limit(c.out, c.in, frames, ch, rate, 1, &settings, st->get(), c.stream), "rh_limit");
-            return rem && c.flush ? c.n : frames * ch;
-        }).on_seek([st, chp, sm](Nanos) { check(rh_memset(st->get(), 0, 2u * *chp * sizeof(float), sm), "rh_memset"); })  // limit.rs:1139-1158
-            .on_format([st, chp, sm](std::uint16_t ch, std::uint32_t) {  // limit.rs:652-695: another channel count rebuilds the state; another rate changes nothing
+            return run_framewise(c, ch, *fc, st->get(), 2u * ch, [&](float *out, const float *in, std::size_t frames, float *state) {
+                check(rh_limit(out, in, frames, ch, rate, 1, &settings, state, c.stream), "rh_limit");
+            });
+        }).on_seek([st, chp, fc, sm](Nanos) {  // limit.rs:1139-1158
+            check(rh_memset(st->get(), 0, 2u * *chp * sizeof(float), sm), "rh_memset");
+            fc->n = 0;
+        }).on_format([st, chp, fc, sm](std::uint16_t ch, std::uint32_t) {  // limit.rs:652-695: another channel count rebuilds the state (and the channel position); another rate changes nothing
                 if (ch == *chp) return;
                 st->reset(2u * ch);
                 check(rh_memset(st->get(), 0, 2u * ch * sizeof(float), sm), "rh_memset");
                 *chp = ch;
+                fc->n = 0;
             });
     }
     GpuSource &automatic_gain_control(const rh_agc_params &settings) {  // agc.rs:133-171,397-504
@@ -1294,6 +1307,48 @@ private:
         stages_.back().span_rule = rule;
         return *this;
     }
+    // Adapters that work on whole frames and carry state (BltFilter, Limit) over an input that may break off inside a frame: at the end of a
+    // span (rodio's adapters run sample by sample -- blt.rs:431-451, limit.rs:927-988 -- and their channel position simply goes on into the
+    // next span) or of the stream.  `kernel(out, in, frames, state)` runs whole frames from `state`.  The samples of a broken frame are
+    // EMITTED AT ONCE, from a copy of the state with the frame completed by zeros (what follows a sample in time does not reach back to
+    // it) -- one sample out per sample in, so the format marks of the block stay where rodio reports them -- and KEPT, so that the real
+    // state meets them again in front of the samples that complete the frame; on_format / on_seek drop them where rodio starts afresh.
+    struct FrameCarry {
+        detail::DeviceBuf part, pad, st2, tin, tout;
+        std::size_t n = 0;  // samples of an open frame, already emitted
+    };
+    template <class K>
+    static std::size_t run_framewise(Ctx &c, std::uint16_t ch, FrameCarry &fc, float *state, std::size_t state_floats, K kernel) {
+        const std::size_t carried = fc.n, total = carried + c.n, frames = total / ch, rem = total % ch;
+        const float *in = c.in;
+        float *out = c.out;
+        if (carried) {  // (rare: once behind every span that ends inside a frame)
+            fc.tin.reset(total + ch);
+            fc.tout.reset(total + ch);
+            check(rh_memcpy_d2d(fc.tin.get(), fc.part.get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
+            if (c.n) check(rh_memcpy_d2d(fc.tin.get() + carried, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
+            in = fc.tin.get();
+            out = fc.tout.get();
+        }
+        if (frames) kernel(out, in, frames, state);
+        if (carried && frames * ch > carried) check(rh_memcpy_d2d(c.out, out + carried, (frames * ch - carried) * sizeof(float), c.stream), "rh_memcpy_d2d");
+        if (rem) {
+            const std::size_t before = frames ? 0 : carried;  // of the open frame's samples: emitted by an earlier call
+            if (rem > before) {
+                fc.pad.reset(2u * ch);
+                fc.st2.reset(state_floats);
+                check(rh_memset(fc.pad.get(), 0, ch * sizeof(float), c.stream), "rh_memset");
+                check(rh_memcpy_d2d(fc.pad.get(), in + frames * ch, rem * sizeof(float), c.stream), "rh_memcpy_d2d");
+                check(rh_memcpy_d2d(fc.st2.get(), state, state_floats * sizeof(float), c.stream), "rh_memcpy_d2d");
+                kernel(fc.pad.get() + ch, fc.pad.get(), 1, fc.st2.get());
+                check(rh_memcpy_d2d(c.out + (frames * ch + before - carried), fc.pad.get() + ch + before, (rem - before) * sizeof(float), c.stream), "rh_memcpy_d2d");
+                fc.part.reset(ch);
+                check(rh_memcpy_d2d(fc.part.get(), in + frames * ch, rem * sizeof(float), c.stream), "rh_memcpy_d2d");
+            }
+        }
+        fc.n = rem;
+        return c.n;
+    }
     std::shared_ptr<detail::DeviceBuf> state(std::size_t floats) {
         auto st = std::make_shared<detail::DeviceBuf>(floats);
         check(rh_memset(st->get(), 0, floats * sizeof(float), stream_), "rh_memset");
@@ -1314,21 +1369,24 @@ private:
         };
         auto ap = std::make_shared<Applier>(make(rate_));
         auto st = state(4u * ch);
+        auto fc = std::make_shared<FrameCarry>();
         return push([=](Ctx &c) {
-            std::size_t frames = c.n / ch;
-            const std::size_t rem = c.n % ch;
-            if (rem && c.flush) {  // a stream can end inside a frame (reverb with an odd delay): blt.rs:431-451 still filters those samples
-                check(rh_memset(const_cast<float *>(c.in) + c.n, 0, (ch - rem) * sizeof(float), c.stream), "rh_memset");
-                frames += 1;       // the zero padding only touches channels the stream no longer has
-            }
-            check(rh_biquad(c.out, c.in, frames, ch, 1, ap->co, st->get(), ap->exact ? 0 : 1, c.stream), "rh_biquad");
-            return rem && c.flush ? c.n : frames * ch;
-        }).on_seek([st, ch, sm = stream_](Nanos) { check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset"); })  // blt.rs:350-377
-            .on_format([ap, make, ch](std::uint16_t new_ch, std::uint32_t rate) {
+            return run_framewise(c, ch, *fc, st->get(), 4u * ch, [&](float *out, const float *in, std::size_t frames, float *state) {
+                check(rh_biquad(out, in, frames, ch, 1, ap->co, state, ap->exact ? 0 : 1, c.stream), "rh_biquad");
+            });
+        }).on_seek([st, ch, fc, sm = stream_](Nanos) {  // blt.rs:350-377
+            check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset");
+            fc->n = 0;
+        })
+            .on_format([ap, make, ch, fc](std::uint16_t new_ch, std::uint32_t rate) {
                 // blt.rs:119-141: `recreate_applier` for the new rate; the state stays.  (A new channel COUNT: the branch that would rebuild the
                 // filter compares the count with itself, blt.rs:128, so rodio goes on filtering frames of the new layout with the state of
                 // the old one -- channels meet each other's history.  Not mirrored.)
                 if (new_ch != ch) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a filter across a change of the channel count (" + std::to_string(ch) + " -> " + std::to_string(new_ch) + ")");
+                // The span in front of the change ended inside a frame (source/mod.rs:169-178 asks sources for whole frames): rodio's filter goes on
+                // at the next channel with the new coefficients, the channels in front of it have met the old ones -- a frame with two sets of
+                // coefficients, which the frame-wise kernel does not run.  Loud, not wrong.
+                if (fc->n) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a filter's coefficients change inside a frame (the span in front of the new sample rate ended inside one)");
                 *ap = make(rate);
             });
     }

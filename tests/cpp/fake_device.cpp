@@ -431,8 +431,8 @@ static void convert_segment(const rh_uniform_seg &g) {
         const uint64_t q = g.span_frames;
         uint64_t mf, k, e;
         cut_counts(q, r.F, r.T, mf, k, e);
-        const float *last = g.src;                          // frame q-1 (if q >= 1)
-        const float *p = g.src + (q >= 1 ? fc : 0);         // the cut frame's t samples
+        const float *last = g.src;                          // the frame in front of the cut (read only when k > 0: then the host put it there)
+        const float *p = g.src + g.src_frames * fc;         // the cut frame's t samples (src_frames: 0 or 1, as rh_uniform.hip reads it)
         for (uint64_t j = g.m0; j < g.m1; ++j) {
             const uint64_t grp = j / tc, pos = j % tc;
             float v = 0.0f;

@@ -1,0 +1,224 @@
+"""Seeded random chains through the C++ host mirror on the CPU stand-in (tests/cpp/fake_device.cpp: test infrastructure) against the oracle:
+sources of one or several spans with formats of their own (whole frames or a cut last frame), span kinds, random adapter chains and random
+block sizes.  What the fixed cases of tests/test_host_mirror.py pin one by one, in combinations nobody wrote down: span readers, the planner
+of `uniform` (sample carries, cut tails), format marks through the block pump, adapters that re-make their state at a span boundary.
+No GPU: the fake device runs the C ABI's operations in the oracle's order, so the host side is all that is under test here."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import test_host_mirror as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "cpp", "host_mirror_test_fake")
+TOL = 1e-5
+RATES = [8000, 22050, 44100, 48000, 96000]
+
+
+def _ops_any_format(rng, n_ops, channel_counts):
+    """Adapters whose chains follow an upstream that changes its format (include/rodio_hip.hpp: Stage::fmt != 2).  A filter in front of a
+    change of the channel COUNT is refused (blt.rs:128), so filters only go behind a `uniform` when the parts differ in channels."""
+    ops, fixed = [], len(set(channel_counts)) == 1
+    for _ in range(n_ops):
+        kind = rng.choice(["amplify", "filter", "limit", "agc", "uniform", "uniform"])
+        if kind == "amplify":
+            ops.append(f"amplify:{rng.choice([0.5, 0.7, 1.25])}")
+        elif kind == "filter":
+            if fixed:
+                ops.append(f"{rng.choice(['low_pass', 'high_pass'])}:{rng.choice([800, 1000, 3000])}")
+        elif kind == "limit":
+            ops.append("limit")
+        elif kind == "agc":
+            if "agc" not in ops:
+                ops.append("agc")
+        else:
+            ops.append(f"uniform:{rng.choice([1, 2, 3, 6])}:{rng.choice(RATES)}")
+            fixed = True
+    return ops or ["amplify:0.5"]
+
+
+def _oracle_chain(O, src, ops):
+    for op in ops:
+        t = op.split(":")
+        if t[0] == "amplify":
+            src = src.amplify(float(np.float32(float(t[1]))))
+        elif t[0] == "low_pass":
+            src = src.low_pass(int(t[1]))
+        elif t[0] == "high_pass":
+            src = src.high_pass(int(t[1]))
+        elif t[0] == "limit":
+            src = src.limit()
+        elif t[0] == "agc":
+            src = src.automatic_gain_control()
+        elif t[0] == "uniform":
+            src = O.UniformSourceIterator(src, int(t[1]), int(t[2]))
+        else:
+            raise AssertionError(op)
+    return src
+
+
+def _tolerance(ops, ref):
+    inexact = [op for op in ops if op.startswith(("low_pass", "high_pass", "limit", "agc"))]
+    if not inexact:
+        return None
+    tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref))) if len(ref) else 1.0)
+    if "agc" in ops and len(inexact) > 1:
+        tol *= 8  # (the AGC's gain -- up to 7 -- multiplies what a filter or the limiter in front of it left)
+    return tol
+
+
+def _sequence_case(O, tmp_path, seed, exe):
+    rng = np.random.default_rng(77000 + seed)
+    n_parts = int(rng.integers(1, 4))
+    parts = []
+    for k in range(n_parts):
+        ch = int(rng.choice([1, 2, 2, 2, 3, 6]))
+        rate = int(rng.choice(RATES))
+        frames = int(rng.integers(1, 9000))
+        cut = int(rng.integers(0, ch)) if rng.random() < 0.3 else 0  # a part that ends inside a frame
+        parts.append((M.rnd(77000 + 100 * seed + k, frames * ch + cut, 0.5), ch, rate))
+    ops = _ops_any_format(rng, int(rng.integers(1, 4)), [p[1] for p in parts])
+    block = int(rng.choice([64, 777, 4096, 16384]))
+    M._write_seq(tmp_path, 0, parts)
+    r = subprocess.run([exe, "chain", str(tmp_path), str(parts[0][1]), str(parts[0][2]), str(block)] + ops, capture_output=True, text=True, timeout=300)
+    what = (seed, [(len(x), c, rt) for x, c, rt in parts], ops, block)
+    if seed in REFUSED:  # loud refusals are part of the contract -- where they are expected
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower() and REFUSED[seed] in r.stderr, (what, r.stderr)
+        return
+    assert r.returncode == 0, (what, r.stderr)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    ref = _oracle_chain(O, O.SeqSource(parts), ops).collect()
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    tol = _tolerance(ops, ref)
+    if tol is None:
+        assert np.array_equal(got, ref), (what, int(np.argmax(got != ref)))
+    else:
+        assert float(np.max(np.abs(got - ref))) <= tol if len(ref) else True, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+def _one_source_case(O, tmp_path, seed, exe):
+    rng = np.random.default_rng(88000 + seed)
+    ch = int(rng.choice([1, 2, 2, 3, 5, 6]))
+    rate = int(rng.choice(RATES))
+    n = int(rng.integers(1, 30000))
+    kind = str(rng.choice(["test", "buffer", f"spans:{int(rng.choice([37, 1000, 2304, 32768]))}"]))
+    if kind in ("test", "buffer") or rng.random() < 0.5:
+        # a Source MUST end on a frame (source/mod.rs:169-178; the mirror drops what a continuous source emits beyond its last whole frame);
+        # spans that cut frames are what `.min(32768)` and queues of sounds make, so half of the spanned cases keep their odd lengths
+        n -= n % ch
+        n = max(n, ch)
+    x = M.rnd(88000 + seed, n, 0.5)
+    ops = _ops_any_format(rng, int(rng.integers(1, 4)), [ch])
+    block = int(rng.choice([64, 777, 4096, 16384]))
+    x.tofile(tmp_path / "src_0.f32")
+    r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300, env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, (n, ch, rate, kind), ops, block)
+    assert r.returncode == 0, (what, r.stderr)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    ref = _oracle_chain(O, M._span_source(O, kind, x, ch, rate), ops).collect()
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    tol = _tolerance(ops, ref)
+    if tol is None:
+        assert np.array_equal(got, ref), (what, int(np.argmax(got != ref)))
+    else:
+        assert (float(np.max(np.abs(got - ref))) <= tol) if len(ref) else True, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+# seeds 0..: the suite's; the ones behind them: cases that failed while this file was written (a cut frame in a middle span in front of the
+# limiter / a filter; the source's span ending inside a frame of the iterator's chain, with an AGC in front of it; two `uniform`s in one chain;
+# a new sample rate inside a frame in front of a filter -- refused)
+SEQ_SEEDS = list(range(48)) + [162, 248, 477]
+# a span ends inside a frame and the next one brings another sample rate, in front of a filter: a frame with two sets of coefficients
+REFUSED = {162: "inside a frame", 248: "inside a frame", 477: "inside a frame"}
+ONE_SEEDS = list(range(32))
+
+
+@pytest.mark.parametrize("seed", SEQ_SEEDS)
+def test_random_chain_over_a_sequence_of_formats(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _sequence_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.parametrize("seed", ONE_SEEDS)
+def test_random_chain_over_one_source_of_any_span_kind(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _one_source_case(O, tmp_path, seed, FAKE)
+
+
+# ... and the same cases through the real library (the kernels under the host logic): a third of them, the GPU suite has its budget
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEQ_SEEDS[::3] + [162, 248, 477])
+def test_gpu_random_chain_over_a_sequence_of_formats(O, tmp_path, seed):
+    _sequence_case(O, tmp_path, seed, M.EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", ONE_SEEDS[::3])
+def test_gpu_random_chain_over_one_source_of_any_span_kind(O, tmp_path, seed):
+    _one_source_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and into a GpuMixer ----
+def _mixer_case(O, tmp_path, seed, exe):
+    """`mixer.add(chain(source))` for a handful of random sources -- plain ones of any span kind, queues of sounds of different formats, with and
+    without adapter chains, chains handed over on the device or through the host -- into mixers of 1, 2 and 6 channels: the samples of rodio's
+    Mixer over UniformSourceIterator(chain(source).amplify(gain))."""
+    rng = np.random.default_rng(99000 + seed)
+    S = int(rng.integers(1, 6))
+    mixer_ch = int(rng.choice([1, 2, 2, 6]))
+    to_rate = int(rng.choice([22050, 44100, 48000]))
+    block = int(rng.choice([777, 4096, 20000]))
+    on_device = bool(rng.integers(0, 2))
+    kind = str(rng.choice(["test", "buffer", "mixed", "spans:2304", "spans:1000"]))
+    lines, adds = [], []
+    for i in range(S):
+        gain = float(np.float32(rng.choice([0.5, 0.8, 1.0, 1.2])))
+        seq = rng.random() < 0.4
+        if seq:
+            parts = []
+            for k in range(int(rng.integers(1, 4))):
+                ch = int(rng.choice([1, 2, 2, 6]))
+                parts.append((M.rnd(99000 + 1000 * seed + 10 * i + k, int(rng.integers(1, 6000)) * ch, 0.2), ch, int(rng.choice(RATES))))
+            M._write_seq(tmp_path, i, parts)
+            ch0, rate0, chans = parts[0][1], parts[0][2], [p[1] for p in parts]
+            make = lambda parts=parts: O.SeqSource(parts)
+        else:
+            ch0, rate0 = int(rng.choice([1, 2, 2, 6])), int(rng.choice(RATES))
+            x = M.rnd(99000 + 1000 * seed + 10 * i, int(rng.integers(1, 15000)) * ch0, 0.2)
+            x.tofile(tmp_path / f"src_{i}.f32")
+            chans = [ch0]
+            make = lambda x=x, ch0=ch0, rate0=rate0, i=i: M._span_source(O, kind, x, ch0, rate0, i)
+        ops = _ops_any_format(rng, int(rng.integers(1, 3)), chans) if rng.random() < 0.5 else []
+        lines.append(f"{ch0} {rate0} {gain} -1 0 {','.join(ops) if ops else '-'}\n")
+        adds.append((make, ops, gain))
+    (tmp_path / "spec.txt").write_text("".join(lines))
+    r = subprocess.run([exe, "chainmix", str(tmp_path), str(S), str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S, mixer_ch, to_rate, block, on_device, kind, lines)
+    assert r.returncode == 0, (what, r.stderr)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    m = O.Mixer(mixer_ch, to_rate)
+    for make, ops, gain in adds:
+        m.add(O.UniformSourceIterator(_oracle_chain(O, make(), ops).amplify(gain), mixer_ch, to_rate))
+    ref = m.collect()
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any("agc" in l for l in lines) else 1)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+MIX_SEEDS = list(range(40))
+
+
+@pytest.mark.parametrize("seed", MIX_SEEDS)
+def test_random_sources_into_a_mixer(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _mixer_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", MIX_SEEDS[::3])
+def test_gpu_random_sources_into_a_mixer(O, tmp_path, seed):
+    _mixer_case(O, tmp_path, seed, M.EXE)
