@@ -222,3 +222,120 @@ def test_random_sources_into_a_mixer(O, tmp_path, seed):
 @pytest.mark.parametrize("seed", MIX_SEEDS[::3])
 def test_gpu_random_sources_into_a_mixer(O, tmp_path, seed):
     _mixer_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and every adapter of the mirror over a continuous source ----
+def _full_ops(rng, ch, n_ops):
+    """The whole vocabulary of the test driver (tests/cpp/host_mirror_test.cpp: apply_op) in random order; the channel count is tracked
+    because channel_volume / channels / spatial / uniform change it."""
+    ops = []
+    for _ in range(n_ops):
+        kind = str(rng.choice(["amplify", "filter", "limit", "agc", "uniform", "reverb", "take", "delay", "fade_in", "fade_out", "distortion", "channel_volume", "channels", "dither", "spatial"]))
+        if kind == "amplify":
+            ops.append(f"amplify:{rng.choice([0.5, 0.7, 1.25])}")
+        elif kind == "filter":
+            ops.append(f"{rng.choice(['low_pass', 'high_pass'])}:{rng.choice([800, 1000, 3000])}")
+        elif kind in ("limit", "agc"):
+            if kind not in ops:
+                ops.append(kind)
+        elif kind == "uniform":
+            ch = int(rng.choice([1, 2, 3, 6]))
+            ops.append(f"uniform:{ch}:{rng.choice(RATES)}")
+        elif kind == "reverb":
+            ops.append(f"reverb:{int(rng.choice([1000000, 20833333, 150000000]))}:{rng.choice([0.3, 0.5])}")
+        elif kind == "take":
+            ops.append(f"take:{int(rng.choice([1000000, 50000000, 300000007]))}:{int(rng.integers(0, 2))}")
+        elif kind == "delay":
+            ops.append(f"delay:{int(rng.choice([1000000, 10000000, 300000000]))}")
+        elif kind in ("fade_in", "fade_out"):
+            ops.append(f"{kind}:{int(rng.choice([1000000, 100000000]))}")
+        elif kind == "distortion":
+            ops.append(f"distortion:{rng.choice([2.0, 4.0])}:{rng.choice([0.3, 0.6])}")
+        elif kind == "channel_volume":
+            to = int(rng.choice([1, 2, 4]))
+            ops.append("channel_volume:" + ",".join(str(v) for v in rng.choice([0.25, 0.5, 1.0, 0.75], to)))
+            ch = to
+        elif kind == "channels":
+            ch = int(rng.choice([1, 2, 3, 6]))
+            ops.append(f"channels:{ch}")
+        elif kind == "dither":
+            ops.append(f"dither:{int(rng.choice([16, 24]))}:{int(rng.integers(0, 4))}:{int(rng.integers(0, 100))}")
+        elif kind == "spatial" and ch == 1:  # (rodio's Spatial takes a mono source, spatial.rs:19-24 ... the driver's op is channel_volume with the two ear gains)
+            ops.append("spatial")
+            ch = 2
+    return ops or ["amplify:0.5"]
+
+
+def _oracle_full(O, src, ops):
+    algos = ["GPDF", "HighPass", "RPDF", "TPDF"]
+    for op in ops:
+        t = op.split(":")
+        if t[0] in ("amplify", "low_pass", "high_pass", "limit", "agc", "uniform"):
+            src = _oracle_chain(O, src, [op])
+        elif t[0] == "reverb":
+            src = src.reverb(int(t[1]), float(t[2]))
+        elif t[0] == "take":
+            src = src.take_duration(int(t[1]), t[2] == "1")
+        elif t[0] == "delay":
+            src = src.delay(int(t[1]))
+        elif t[0] == "fade_in":
+            src = src.fade_in(int(t[1]))
+        elif t[0] == "fade_out":
+            src = src.fade_out(int(t[1]))
+        elif t[0] == "distortion":
+            src = src.distortion(float(t[1]), float(t[2]))
+        elif t[0] == "channel_volume":
+            src = O.ChannelVolume(src, [float(v) for v in t[1].split(",")])
+        elif t[0] == "channels":
+            src = O.ChannelCountConverter(src, src.channels(), int(t[1]))
+        elif t[0] == "dither":
+            src = src.dither(int(t[1]), algos[int(t[2])], int(t[3]))
+        elif t[0] == "spatial":
+            src = O.Spatial(src, [0.5, 0.0, 1.0], [-1.0, 0.0, 0.0], [1.0, 0.0, 0.0])
+        else:
+            raise AssertionError(op)
+    return src
+
+
+def _full_case(O, tmp_path, seed, exe):
+    rng = np.random.default_rng(66000 + seed)
+    ch = int(rng.choice([1, 1, 2, 2, 3, 6]))
+    rate = int(rng.choice(RATES))
+    n = int(rng.integers(1, 12000)) * ch
+    x = M.rnd(66000 + seed, n, 0.5)
+    ops = _full_ops(rng, ch, int(rng.integers(1, 5)))
+    block = int(rng.choice([64, 777, 4096, 16384]))
+    x.tofile(tmp_path / "src_0.f32")
+    r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
+    what = (seed, (n, ch, rate), ops, block)
+    assert r.returncode == 0, (what, r.stderr)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    ref_src = _oracle_full(O, O.TestSource(x, ch, rate), ops)
+    ref = ref_src.collect()
+    fmt = (tmp_path / "format.txt").read_text().split()
+    assert (int(fmt[0]), int(fmt[1])) == (ref_src.channels(), ref_src.sample_rate()), what
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    tol = _tolerance(ops, ref)
+    gpdf = [i for i, op in enumerate(ops) if op.startswith("dither:") and op.split(":")[2] == "0"]
+    if tol is None and gpdf:  # Gaussian dither: logf / cosf differ in the last bit between the device and the host (tests/test_gpu_parity.py: 1e-7) ...
+        amp = 1.0
+        for op in ops[gpdf[0] + 1:]:  # ... times what stands behind it
+            amp *= float(op.split(":")[1]) if op.startswith(("amplify", "distortion")) else 1.0
+        tol = 1e-7 * max(1.0, amp) * len(gpdf)
+    if tol is None:
+        assert np.array_equal(got, ref), (what, int(np.argmax(got != ref)))
+    elif len(ref):
+        if any(op.startswith("distortion") for op in ops):
+            tol *= 8  # (its gain of 2 or 4 in front of the clip)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+# (the stand-in device answers RH_ERR_UNSUPPORTED for the adapters without host logic of their own -- ramps, dither, distortion, take_duration,
+# spatial: fake_device.cpp -- so these chains run through the real library only)
+FULL_SEEDS = list(range(int(os.environ.get("RH_FUZZ_FULL", "40"))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", FULL_SEEDS)
+def test_gpu_random_chain_of_any_adapters(O, tmp_path, seed):
+    _full_case(O, tmp_path, seed, M.EXE)
