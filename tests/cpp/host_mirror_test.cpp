@@ -453,8 +453,20 @@ int main(int argc, char **argv) {
             }
             for (int i = S0; i < S0 + S1; ++i) add(i);
             std::fclose(sf);
-            const std::vector<float> rest = drain(mixer);
-            out.insert(out.end(), rest.begin(), rest.end());
+            // (as in `late`: an ended mixer that was given a new source answers None until its channel position is back at 0, mixer.rs:120-136)
+            int nones = 0;
+            std::optional<float> v;
+            while (nones < 16 && !(v = mixer.next())) ++nones;
+            if (v) out.push_back(*v);
+            if (v) {
+                const std::vector<float> rest = drain(mixer);
+                out.insert(out.end(), rest.begin(), rest.end());
+            }
+            std::FILE *nf = std::fopen((dir + "/nones.txt").c_str(), "w");
+            if (nf) {
+                std::fprintf(nf, "%d\n", nones);
+                std::fclose(nf);
+            }
         } else if (mode == "mixer" && argc == 10) {
             const int S = std::atoi(argv[3]);
             const uint32_t from = (uint32_t)std::atoll(argv[4]), to = (uint32_t)std::atoll(argv[5]);

@@ -339,3 +339,83 @@ FULL_SEEDS = list(range(int(os.environ.get("RH_FUZZ_FULL", "40"))))
 @pytest.mark.parametrize("seed", FULL_SEEDS)
 def test_gpu_random_chain_of_any_adapters(O, tmp_path, seed):
     _full_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and sources that join a mixer that is already running ----
+def _late_case(O, tmp_path, seed, exe):
+    """`Mixer::add` on a mixer whose consumer has pulled `pull_first` samples (mixer.rs:175-183: the new source starts at the next frame
+    boundary of the mix): sources of any layout and span kind, mixers of 1 / 2 / 6 channels, joins in the first block, deep into the
+    stream, and behind its end."""
+    rng = np.random.default_rng(55000 + seed)
+    S0, S1 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    mixer_ch = int(rng.choice([1, 2, 2, 6]))
+    to_rate = int(rng.choice([22050, 44100, 48000]))
+    block = int(rng.choice([777, 4096, 7000]))
+    kind = str(rng.choice(["test", "buffer", "mixed", "spans:2304"]))
+    spec, xs = [], []
+    for i in range(S0 + S1):
+        ch, rate = int(rng.choice([1, 2, 2, 6])), int(rng.choice(RATES))
+        gain = float(np.float32(rng.choice([0.5, 0.8, 1.0])))
+        x = M.rnd(55000 + 100 * seed + i, int(rng.integers(1, 12000)) * ch, 0.2)
+        x.tofile(tmp_path / f"src_{i}.f32")
+        spec.append((ch, rate, gain))
+        xs.append(x)
+    (tmp_path / "spec.txt").write_text("".join(f"{c} {r} {g}\n" for c, r, g in spec))
+    chain = lambda i: O.UniformSourceIterator(M._span_source(O, kind, xs[i], spec[i][0], spec[i][1], i).amplify(spec[i][2]), mixer_ch, to_rate)
+    m = O.Mixer(mixer_ch, to_rate)
+    for i in range(S0):
+        m.add(chain(i))
+    # how long the first sources play decides where a join can land: inside the stream, or behind its end
+    total0 = len(O_collect_copy(O, kind, xs, spec, S0, mixer_ch, to_rate))
+    pull_first = int(rng.integers(0, max(1, int(total0 * 1.2)) + 1))
+    ref = []
+    for _ in range(pull_first):
+        v = m.next()
+        if v is None:
+            break
+        ref.append(v)
+    for i in range(S0, S0 + S1):
+        m.add(chain(i))
+    # an ended mixer that was given a new source answers None until its channel position is back at 0 (mixer.rs:120-136): the consumer keeps asking
+    nones, v = 0, None
+    while nones < 16:
+        v = m.next()
+        if v is not None:
+            break
+        nones += 1
+    if v is not None:
+        ref = np.concatenate([np.asarray(ref + [v], dtype=np.float32), m.collect()])
+    else:
+        ref = np.asarray(ref, dtype=np.float32)
+    r = subprocess.run([exe, "latewide", str(tmp_path), str(S0), str(S1), str(mixer_ch), str(to_rate), str(block), str(pull_first)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S0, S1, mixer_ch, to_rate, block, kind, pull_first, total0, spec, [len(x) for x in xs])
+    assert r.returncode == 0, (what, r.stderr)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    # (sources of one input rate share a fused handle, so three sources of two rates are summed as s0 + (s1 + s2) where rodio's Mixer folds
+    # ((s0 + s1) + s2), mixer.rs:185-198: an ulp, inside north_star's 1e-5 for the mix)
+    assert float(np.max(np.abs(got - ref))) <= TOL if len(ref) else True, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+    assert int((tmp_path / "nones.txt").read_text()) == nones, what
+
+
+def O_collect_copy(O, kind, xs, spec, S0, mixer_ch, to_rate):
+    m = O.Mixer(mixer_ch, to_rate)
+    for i in range(S0):
+        m.add(O.UniformSourceIterator(M._span_source(O, kind, xs[i], spec[i][0], spec[i][1], i).amplify(spec[i][2]), mixer_ch, to_rate))
+    return m.collect()
+
+
+LATE_SEEDS = list(range(40))
+
+
+@pytest.mark.parametrize("seed", LATE_SEEDS)
+def test_random_late_joins(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _late_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", LATE_SEEDS[::3])
+def test_gpu_random_late_joins(O, tmp_path, seed):
+    _late_case(O, tmp_path, seed, M.EXE)
