@@ -293,15 +293,32 @@ def headline(args, argv):
     comm = None
     comm_err = None
     if want.startswith("native") or (want == "auto" and world > 1 and not one_dev):
-        try:
-            box = [D.NativeComm.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            comm = D.NativeComm(rank, world, box[0])
-        except Exception as e:  # noqa: BLE001 -- RCCL not loadable / refuses the ranks: say so in the line, fall back to the cross-check path
-            comm_err = str(e)[:300]
-            if want.startswith("native") and world == 1:
-                sys.exit(f"--collective {want}: {comm_err}")
+        # Every rank takes the same path: rank 0's failure to make the id travels WITH the broadcast (an exception in front of it would leave the
+        # others waiting there), and the ranks agree on the outcome before the first launch -- RCCL not loadable / refusing the ranks on any
+        # of them sends all of them to the cross-check path, and the line says so.
+        uid = None
+        if rank == 0:
+            try:
+                uid = D.NativeComm.unique_id()
+            except Exception as e:  # noqa: BLE001
+                comm_err = str(e)[:300]
+        box = [(uid, comm_err)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        uid, comm_err = box[0]
+        if uid is not None:
+            try:
+                comm = D.NativeComm(rank, world, uid)
+            except Exception as e:  # noqa: BLE001
+                comm_err = str(e)[:300]
+        if world > 1:
+            agreed = torch.tensor([1 if comm is not None else 0], device=cdev, dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0 and comm is not None:
+                comm = None
+                comm_err = comm_err or "another rank could not join the communicator"
+        if comm is None and want.startswith("native") and world == 1:
+            sys.exit(f"--collective {want}: {comm_err}")
     reduce_only = comm is not None and want == "native-reduce"
     cstream = torch.cuda.Stream() if comm is not None else None  # the collective's stream: the all-reduce of block k runs beside the kernel of block k+1
     done = [None, None]  # native: the event behind the collective that last used buffer i
