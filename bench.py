@@ -895,9 +895,9 @@ def side(args, argv):
         S, N, B = args.sources, args.frames, args.block
         host = make_sources(S, N, 0, S, 2)
         data = torch.from_numpy(host).cuda()
-        # (18 frames per lane: what the one-shot autotune keeps on this workload -- and an even number: a block's frames are a multiple of it, so every
-        # block's output starts on a 16-byte boundary of the stream's buffer)
-        pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=args.frames_per_lane or 18)
+        # (frames per lane: the library's choice for a handle of this block size, as GpuMixer leaves it -- short runs: a block's one mixed row is a
+        # latency chain of a few dozen tiles, profiles/r05_stream_frames_per_lane.txt; a block emits whole 16-byte vectors whatever the run length)
+        pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=args.frames_per_lane or 0)
         pipe.set_exclusive(True)
         mo = C.c_uint64(0)
         _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")

@@ -1482,7 +1482,9 @@ __global__ __launch_bounds__(64, (R <= 8 && KV <= 5 ? 3 : 2)) void k_rlm_wave(co
 // behind takes the partial rows as its sources and adds them in order.  One group: the whole list into one row, as before.
 template <int U>
 __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ srcs_all, const uint32_t n_sources_all, float *__restrict__ y_all, const uint64_t n_floats, SrcDesc *__restrict__ ydesc_all,
-                                                  const uint32_t frames, const uint32_t out_frames, const float *desc_row_all, const uint64_t group_stride) {
+                                                  const uint32_t frames, const uint32_t out_frames, const float *desc_row_all, const uint64_t group_stride, const uint64_t src_off) {
+    // (src_off: bytes added to every source pointer of the table -- a stream whose sources all moved on by the same amount since the table was
+    // uploaded passes the distance instead of uploading it again: rh_pipeline_stream.hip)
     typedef __attribute__((address_space(4))) const uint64_t cu64;
     typedef __attribute__((address_space(4))) const float cf32;
     typedef RH_GLB const v4f glb_cf4;
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
         auto fetch_desc = [&](uint32_t j) {
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
-                pN[k] = desc[4 * (uint64_t)(j * SB + k)];
+                pN[k] = desc[4 * (uint64_t)(j * SB + k)] + src_off;
                 gN[k] = dgain[8 * (uint64_t)(j * SB + k) + 4];
             }
         };
@@ -1560,7 +1562,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
             }
         }
         for (uint32_t s = steps * SB; s < n_sources; ++s) {
-            glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)desc[4 * (uint64_t)s];
+            glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)(desc[4 * (uint64_t)s] + src_off);
             const float g = dgain[8 * (uint64_t)s + 4];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1579,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
             if (i >= nvec) break;
             v4f a = v4f{0.f, 0.f, 0.f, 0.f};
             for (uint32_t s = 0; s < n_sources; ++s) {
-                glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)desc[4 * (uint64_t)s];
+                glb_cf4 *const ptr = (glb_cf4 *)(uintptr_t)(desc[4 * (uint64_t)s] + src_off);
                 const float g = dgain[8 * (uint64_t)s + 4];
                 const v4f v = ptr[i];
                 a.x = fma_(g, v.x, a.x), a.y = fma_(g, v.y, a.y), a.z = fma_(g, v.z, a.z), a.w = fma_(g, v.w, a.w);
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
         const uint64_t t = nvec * 4 + threadIdx.x;  // the floats behind the last whole vector (a mono batch of a length not divisible by 4)
         if (t < n_floats) {
             float a = 0.f;
-            for (uint32_t s = 0; s < n_sources; ++s) a = fma_(dgain[8 * (uint64_t)s + 4], ((glb_cf32 *)(uintptr_t)desc[4 * (uint64_t)s])[t], a);
+            for (uint32_t s = 0; s < n_sources; ++s) a = fma_(dgain[8 * (uint64_t)s + 4], ((glb_cf32 *)(uintptr_t)(desc[4 * (uint64_t)s] + src_off))[t], a);
             y[t] = a;
         }
         if (threadIdx.x == 0) {  // the one-entry descriptor table the fused launch behind this one reads
@@ -1610,7 +1612,7 @@ __global__ __launch_bounds__(256) void k_mix_rows(const SrcDesc *__restrict__ sr
 // and accumulates.  A row of n_floats gives ceil(n_floats / 2048) waves: for rows that fill the chip (the host decides).
 template <int NS>
 __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ srcs, const uint32_t n_sources, float *__restrict__ y, const uint64_t n_floats, SrcDesc *__restrict__ ydesc,
-                                                 const uint32_t frames, const uint32_t out_frames, const float *desc_row) {
+                                                 const uint32_t frames, const uint32_t out_frames, const float *desc_row, const uint64_t src_off) {
     constexpr int KV = 8;
     constexpr uint32_t kStage = KV * 1024;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * kStage];
@@ -1632,7 +1634,7 @@ __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ src
         goff[k] = (uint32_t)(j * 16);  // rows are < 2^32 bytes (frames < 2^29)
     }
     auto stage_source = [&](uint32_t s_, uint32_t stage) {
-        const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+        const void *data = (const void *)(uintptr_t)(desc[4 * (uint64_t)s_] + src_off);
 #pragma unroll
         for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
     };
@@ -1683,7 +1685,7 @@ __global__ __launch_bounds__(64) void k_mix_ring(const SrcDesc *__restrict__ src
         const uint64_t t = nvec * 4 + lane;  // the floats behind the last whole vector
         if (t < n_floats) {
             float a = 0.f;
-            for (uint32_t s_ = 0; s_ < n_sources; ++s_) a = fma_(dgain[8 * (uint64_t)s_ + 4], ((glb_cf32 *)(uintptr_t)desc[4 * (uint64_t)s_])[t], a);
+            for (uint32_t s_ = 0; s_ < n_sources; ++s_) a = fma_(dgain[8 * (uint64_t)s_ + 4], ((glb_cf32 *)(uintptr_t)(desc[4 * (uint64_t)s_] + src_off))[t], a);
             y[t] = a;
         }
         if (lane == 0) {
@@ -2718,11 +2720,11 @@ rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint
         SrcDesc *const ydesc = reinterpret_cast<SrcDesc *>(p->d_mix + (p->mix_floats - 32 - kMixGroups * 8));
         float *const frow = pre ? p->d_mix + row : p->d_mix;  // the row the fused launch reads
         const uint32_t nf = p->eq_frames, mf = (uint32_t)p->out_frames;
-        if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
-        else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow);
-        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
-        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
-        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row);
+        if (ring >= 3) hipLaunchKernelGGL(k_mix_ring<3>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, sa.src_off);
+        else if (ring == 2) hipLaunchKernelGGL(k_mix_ring<2>, dim3((uint32_t)ring_waves), dim3(64), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, sa.src_off);
+        else if (U == 1) hipLaunchKernelGGL(k_mix_rows<1>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row, sa.src_off);
+        else if (U == 2) hipLaunchKernelGGL(k_mix_rows<2>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row, sa.src_off);
+        else hipLaunchKernelGGL(k_mix_rows<4>, dim3(wgs, groups), dim3(256), 0, s, k.srcs, count, p->d_mix, n_floats, ydesc, nf, mf, frow, (uint64_t)row, sa.src_off);
         RH_CHECK_LAUNCH();
         if (pre) {  // the filter of `src.low_pass(f)`, at from_rate, on the mix (time-parallel: rh_biquad mode 1, zero state)
             const rh_status fs = rh_biquad(frow, p->d_mix, p->eq_frames, p->cfg.channels, 1, p->pre_coeffs, nullptr, 1, stream);

@@ -225,6 +225,7 @@ struct StreamArgs {
     const float *win = nullptr;
     float *wout = nullptr;
     uint32_t gran_cols = 0;  // != 0: per-source states (k_rlm_wave), aggregate rows of this many columns, tile 0 in column 1
+    uint64_t src_off = 0;    // mix first: bytes added to every source pointer of the table on the device (a stream that did not upload it again)
 };
 }  // namespace rhp
 using namespace rhp;  // (an internal header: see the top)
@@ -245,6 +246,9 @@ struct rh_rlm {
     bool equal = true;
     std::vector<Plan> tried;  // autotune candidates (their tables are freed with the handle)
     SrcDesc *d_srcs = nullptr;
+    uint64_t srcs_version = 0;  // counts the uploads of the table (whoever makes them): a stream that reuses the table checks it is still its own
+    std::vector<const float *> st_tab_ptrs;  // a stream's summed blocks: the pointers of the table it uploaded last ...
+    uint64_t st_tab_version = ~0ull;         // ... and srcs_version right after that upload
     unsigned long long *d_gran = nullptr;
     size_t gran_words = 0;
     uint32_t *d_ctl = nullptr;  // [0] ticket, [1] status, [2] late carries, [3] empty polls

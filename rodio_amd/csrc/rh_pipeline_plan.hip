@@ -418,6 +418,7 @@ rh_status upload_descriptors(rh_rlm *p, uint32_t n, hipStream_t s) {
     }
     std::memcpy(p->h_ring[k], p->h_desc.data(), sizeof(SrcDesc) * n);
     RH_HIP_TRY(hipMemcpyAsync(p->d_srcs, p->h_ring[k], sizeof(SrcDesc) * n, hipMemcpyHostToDevice, s));
+    p->srcs_version += 1;
     RH_HIP_TRY(hipEventRecord(p->h_ring_ev[k], s));
     return RH_OK;
 }
@@ -637,6 +638,7 @@ static rh_status set_sources_impl(rh_rlm *p, const float *const *srcs_host, cons
         const rh_status w = wait_idle(p);  // an earlier run of this handle may still be reading the table
         if (w != RH_OK) return w;
         if (n_sources) RH_HIP_TRY(hipMemcpy(p->d_srcs, h.data(), sizeof(SrcDesc) * n_sources, hipMemcpyHostToDevice));
+        p->srcs_version += 1;
     }
     p->equal = equal;
     p->eq_frames = n_sources ? (uint32_t)in_frames_host[0] : 0;
@@ -741,6 +743,7 @@ rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
     RH_REQUIRE_INIT();
     if (!p || (n && !gains_host) || n > p->cfg.max_sources) return RH_ERR_INVALID;
     p->gains.assign(gains_host, gains_host + n);
+    p->srcs_version += 1;  // (a stream that reuses its table on the device uploads it again: the gains travel in it)
     if (!p->cls.empty()) {  // per-source filters: every class takes the factors of its members
         std::vector<float> g;
         for (rh_rlm::FilterClass &c : p->cls) {
@@ -758,6 +761,7 @@ rh_status rh_rlm_set_gains(rh_rlm *p, const float *gains_host, uint32_t n) {
             if (w != RH_OK) return w;
         }
         RH_HIP_TRY(hipMemcpy(p->d_srcs, p->h_desc.data(), sizeof(SrcDesc) * p->n_sources, hipMemcpyHostToDevice));
+        p->srcs_version += 1;
     }
     return RH_OK;
 }

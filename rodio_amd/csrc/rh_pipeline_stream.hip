@@ -38,6 +38,7 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     if (!p) return RH_ERR_INVALID;
     if (p->pre_filter) return RH_ERR_UNSUPPORTED;  // filter_first: one-shot runs only (rodio_hip.h)
     if (!p->filters.empty()) return RH_ERR_UNSUPPORTED;  // per-source filters: one-shot runs (a streaming host keeps one handle per filter: rodio_hip.hpp)
+    p->st_tab_version = ~0ull;  // (the first summed block uploads its table)
     p->st_chunk_in = p->st_chunk_out = 0;
     if (p->cfg.span_len != 0) {  // sources that report spans of span_len samples: the converter restarts every min(span_len, 32768) samples (uniform.rs:56-67)
         const uint64_t span = p->cfg.span_len < 32768 ? p->cfg.span_len : 32768;
@@ -109,21 +110,44 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
     // output frames computable from them: every m whose two taps have arrived; at the end also the verbatim last frame
     const uint64_t m_end = flush ? stream_total(N, F, T, cin, cout) : stream_ready(N, F, T, cin, cout);
     uint64_t out = m_end > p->st_m ? m_end - p->st_m : 0;
-    if (!flush) out = out / R * R;
+    if (!flush) {
+        // whole lane runs (the state at the block's end is a lane's start state) that are whole 16-byte vectors too: a caller that writes
+        // the blocks one behind the other (`dst + emitted so far`) stays aligned whatever R the plan took (odd R: pairs of runs)
+        const uint64_t vec = 4u / p->cfg.channels;  // frames per 16 bytes: 2 (stereo), 4 (mono)
+        const uint64_t unit = R / std::gcd(R, vec) * vec;
+        out = out / unit * unit;
+    }
     if (out >= (1ull << 31)) return RH_ERR_UNSUPPORTED;
     if (out > out_capacity_frames) return RH_ERR_CAPACITY;
     if (out > 0 || flush) {
         if (out > 0) {
             if (!srcs_host || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return RH_ERR_INVALID;
             std::vector<SrcDesc> &h = p->h_desc;
-            h.resize(n_sources);
-            for (uint32_t s = 0; s < n_sources; ++s) {
-                if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
-                h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+            // A block that is summed first reads nothing of the table but the pointers and the gains (k_mix_rows / k_mix_ring; the frame
+            // counts travel as kernel arguments), and they take a common offset: when every source has moved on by the same number of
+            // bytes since the table was uploaded -- rows of one staging block, resident rows read at `row + consumed` -- the table stays
+            // where it is and the distance goes with the launch.  One copy kernel and two dependent boundaries less per block
+            // (4 + ~3 us of the 49 us a 64 Ki-frame block of 256 sources takes: profiles/r05_stream_kernel_trace.txt).
+            const bool sum_first = mix_first_applies(p, p->fast, n_sources, false, false);
+            uint64_t src_off = 0;
+            bool reuse = sum_first && p->st_tab_version == p->srcs_version && p->st_tab_ptrs.size() == n_sources && !rh::knob(rh::K_STREAM_UPLOAD_ALWAYS);
+            if (reuse) {
+                src_off = (uint64_t)(reinterpret_cast<uintptr_t>(srcs_host[0]) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[0]));
+                for (uint32_t s = 0; s < n_sources && reuse; ++s)
+                    reuse = srcs_host[s] && !(reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u) &&
+                            (uint64_t)(reinterpret_cast<uintptr_t>(srcs_host[s]) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[s])) == src_off;
             }
-            {
+            if (!reuse) {
+                src_off = 0;
+                h.resize(n_sources);
+                for (uint32_t s = 0; s < n_sources; ++s) {
+                    if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
+                    h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+                }
                 const rh_status up = upload_descriptors(p, n_sources, rh::as_stream(stream));
                 if (up != RH_OK) return up;
+                p->st_tab_ptrs.assign(srcs_host, srcs_host + n_sources);
+                p->st_tab_version = p->srcs_version;
             }
             p->equal = true;
             p->eq_frames = (uint32_t)avail_frames;
@@ -142,6 +166,7 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
             sa.g0 = p->st_g0;
             sa.win = p->d_w[p->st_cur];
             sa.wout = p->d_w[p->st_cur ^ 1];
+            sa.src_off = src_off;
             st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
             if (st != RH_OK) return st;
             p->st_n_summed += 1;

@@ -380,6 +380,69 @@ def test_a_filter_per_source_in_the_fused_mixer(G, O, n_equal):
     p.close()
 
 
+def test_block_streaming_keeps_its_table_while_the_sources_move_together(G, O):
+    """A block that is summed first reads only pointers and gains of the source table, and they take a common offset: resident rows read at
+    `row + consumed` (every source moves on by the same bytes) stream without uploading the table again (rh_pipeline_stream.hip).  The same
+    stream with RH_STREAM_UPLOAD_ALWAYS=1: the same bits.  In the middle of the stream one source moves to another buffer (its distance
+    differs: the table is uploaded again) and the gains change (they travel in the table): still the bits of the stream that uploads every time,
+    and -- up to the frame where the gains changed -- the oracle's samples."""
+    import ctypes as C
+
+    import torch
+    from conftest import knobs
+    from rodio_amd import _lib
+
+    lib = _lib.lib
+    S, N, B = 6, 300_000, 40_000
+    xs = [rnd(8800 + s, 2 * N, 0.15) for s in range(S)]
+    g1, g2 = np.linspace(0.5, 1.2, S).astype(np.float32), np.linspace(1.1, 0.4, S).astype(np.float32)
+    data = torch.from_numpy(np.stack(xs)).cuda()
+    moved = data[2].clone()  # the third source's samples once more, somewhere else
+    mo = C.c_uint64(0)
+    _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")
+    M = mo.value
+
+    def run():
+        p = G.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", 1000, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=18)
+        p.set_gains(g1)
+        p.stream_begin(keep_history=True)
+        out = torch.zeros(2 * M + 4096, device="cuda", dtype=torch.float32)
+        g0 = m = k = 0
+        switch_at = None
+        while True:
+            hi = min(N, (k + 1) * B)
+            base = [data[s_].data_ptr() for s_ in range(S)]
+            if k >= 3:
+                base[2] = moved.data_ptr()
+            if k == 5:
+                p.set_gains(g2)
+                switch_at = m
+            ptrs = (C.c_void_p * S)(*[b_ + g0 * 8 for b_ in base])
+            avail = (C.c_uint64 * S)(*([hi - g0] * S))
+            ended = (C.c_uint8 * S)(*([1 if hi == N else 0] * S))
+            o, c = C.c_uint64(0), C.c_uint64(0)
+            _lib.check(lib.rh_rlm_stream_block_v(p._h, ptrs, avail, ended, S, C.c_void_p(out.data_ptr() + m * 8), M + 512 - m, C.byref(o), C.byref(c), None), "rh_rlm_stream_block_v")
+            m += o.value
+            g0 += c.value
+            k += 1
+            if hi == N:
+                break
+        p.check_status()
+        stats = p.stream_stats()
+        res = out[: 2 * m].cpu().numpy()
+        p.close()
+        return res, switch_at, stats
+
+    a, sw_a, st_a = run()
+    with knobs(RH_STREAM_UPLOAD_ALWAYS="1"):
+        b, sw_b, st_b = run()
+    assert st_a == st_b and st_a[0] >= 7 and st_a[1] == 0, (st_a, st_b)  # every block on the summed state
+    assert sw_a == sw_b and np.array_equal(a, b)
+    ref1 = _oracle(O, xs, 44100, 48000, None, "low_pass", 1000, g1, 2)
+    assert len(a) == len(ref1)
+    assert float(np.max(np.abs(a[: 2 * sw_a] - ref1[: 2 * sw_a]))) <= TOL
+
+
 @pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
 @pytest.mark.parametrize("case", ["end together", "end apart", "short first block", "short block in the middle", "one falls behind"])
 def test_block_streaming_of_sources_that_run_together(G, O, filt, freq, case):
