@@ -908,6 +908,11 @@ def side(args, argv):
         plan_cache = {}  # block index -> the ctypes arrays of the call (the stream is deterministic: the same g0 every time)
         emitted = []
 
+        # --short-source F: source 0 has only F x N frames -- the stream leaves the summed state when it ends (a state per source, recovered from
+        # the block before) and returns to it once that source has given everything (rh_pipeline_stream.hip); RH_STREAM_NO_REJOIN=1: a state per
+        # source from there to the end, as before round 5.  No parity in this mode (tests/test_gpu_mix_first.py has the oracle's comparison).
+        N0 = max(4, int(N * args.short_source) // 4 * 4) if args.short_source else N
+
         def one_stream():
             pipe.stream_begin(keep_history=True)
             g0 = m = 0
@@ -915,7 +920,8 @@ def side(args, argv):
                 hi = min(N, (k + 1) * B)
                 key = (k, g0)
                 if key not in plan_cache:
-                    plan_cache[key] = ((C.c_void_p * S)(*[b_ + g0 * 8 for b_ in base]), (C.c_uint64 * S)(*([hi - g0] * S)), (C.c_uint8 * S)(*([1 if hi == N else 0] * S)))
+                    av = [max(0, min(hi, N0 if s_ == 0 else N) - g0) for s_ in range(S)]
+                    plan_cache[key] = ((C.c_void_p * S)(*[b_ + g0 * 8 for b_ in base]), (C.c_uint64 * S)(*av), (C.c_uint8 * S)(*[1 if hi >= (N0 if s_ == 0 else N) else 0 for s_ in range(S)]))
                 ptrs, avail, ended = plan_cache[key]
                 o, c = C.c_uint64(0), C.c_uint64(0)
                 _lib.check(lib.rh_rlm_stream_block_v(pipe._h, ptrs, avail, ended, S, C.c_void_p(out.data_ptr() + m * 8), M + 512 - m, C.byref(o), C.byref(c), stream), "rh_rlm_stream_block_v")
@@ -932,6 +938,8 @@ def side(args, argv):
         per_call = True
 
         def checks():
+            if args.short_source:
+                return {"ok": None, "note": "--short-source: timing only", "stream_stats": dict(zip(("blocks_on_the_summed_state", "blocks_with_per_source_states", "recoveries"), pipe.stream_stats()))}, None
             base_, ref = cpu_baseline(host, S, N, 0, args.freq, want_all_cores=False)
             got = out[: emitted[-1] * 2].cpu().numpy()
             pr = _parity(got, ref, 1e-5, f"oracle (restated rodio CPU path) in ONE pass over the whole sources; the GPU output is the concatenation of {nblocks} streamed blocks")
@@ -1009,6 +1017,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
     ap.add_argument("--block", type=int, default=65536, help="--config stream: input frames per block")
+    ap.add_argument("--short-source", type=float, default=0.0, help="--config stream: source 0 ends after this fraction of the frames (timing only)")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)
     ap.add_argument("--ring-stages", type=int, default=0)
@@ -1049,7 +1058,7 @@ def main():
             argv.append("--per-source")
         headline(args, argv)
     else:
-        side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames), "--block", str(args.block)])
+        side(args, ["--config", args.config, "--sources", str(args.sources), "--frames", str(args.frames), "--block", str(args.block), "--short-source", str(args.short_source)])
 
 
 if __name__ == "__main__":

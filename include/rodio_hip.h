@@ -451,7 +451,11 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
  * carries their SUM (as rh_rlm_stream_block does) and every block is summed at the input rate first and converted and filtered once
  * (DESIGN.md 4.6).  When a source ends or falls behind, the states of the others are recovered from the rows of the block BEFORE
  * (a replay of its last few tiles through the per-source kernel: a stable filter has forgotten what lies further back) and the stream
- * goes on with one state per source.  The caller opts in by promising what the recovery needs: on != 0 = "the rows I pass to a block
+ * goes on with one state per source -- until its sources run together AGAIN: every source either gone (ended, and everything it had
+ * emitted) or live with the same frames as the other live ones.  Then the sum of the live states becomes the stream's summed state and
+ * the blocks are summed first once more (a block with a state per source costs a wave per tile walking every source: ~360 us for 256
+ * sources whatever the block's length; a mixer whose sounds end one after the other would otherwise spend its life there).
+ * The caller opts in by promising what the recovery needs: on != 0 = "the rows I pass to a block
  * stay valid and unchanged until the work of the NEXT block call has run" (three row sets in rotation do: include/rodio_hip.hpp).
  * Between rh_rlm_stream_begin and the stream's first block.  Without it -- the default -- every block takes the per-source kernel. */
 rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on);

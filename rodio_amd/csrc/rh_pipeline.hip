@@ -2452,6 +2452,30 @@ __global__ __launch_bounds__(64) void k_rlm_state(unsigned long long *gran, cons
     for (int q = 0; q < 4; ++q) row[q] = ((unsigned long long)next_epoch << 32) | __float_as_uint(c[q]);
 }
 
+// A stream with a state per source whose live sources run together again (the others have ended and given everything): the summed
+// state the fused kernel streams on is the sum of the live sources' states -- column 0 of their rows, which k_rlm_state has just written
+// (tagged `tag`).  A source the table marks with gain 0 is gone (or mute: its state is zero then) and stays out.  One workgroup.
+__global__ __launch_bounds__(256) void k_rlm_state_sum(const unsigned long long *__restrict__ gran, const SrcDesc *__restrict__ srcs, uint32_t n_sources, uint32_t ncol, uint32_t tag,
+                                                      float *__restrict__ w_out) {
+    __shared__ float part[4][256];
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t s = threadIdx.x; s < n_sources; s += 256u) {
+        if (srcs[s].gain == 0.0f) continue;
+        const unsigned long long *row = gran + (uint64_t)s * ncol * 4;
+        const unsigned long long g0 = row[0], g1 = row[1], g2 = row[2], g3 = row[3];
+        if ((uint32_t)(g0 >> 32) != tag || (uint32_t)(g1 >> 32) != tag || (uint32_t)(g2 >> 32) != tag || (uint32_t)(g3 >> 32) != tag) continue;
+        c[0] += __uint_as_float((uint32_t)g0), c[1] += __uint_as_float((uint32_t)g1), c[2] += __uint_as_float((uint32_t)g2), c[3] += __uint_as_float((uint32_t)g3);
+    }
+    for (int q = 0; q < 4; ++q) part[q][threadIdx.x] = c[q];
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w)
+            for (int q = 0; q < 4; ++q) part[q][threadIdx.x] += part[q][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) w_out[threadIdx.x] = part[threadIdx.x][0];
+}
+
 // ------------------------------------------------------------------ the instances ----
 #define RH_FAST(r, kv, ns) Variant{r, kv, ns, &k_rlm_fast<r, kv, ns, true>, &k_rlm_fast<r, kv, ns, false>}
 #define RH_WAVE(r, kv, ns) Variant{r, kv, ns, &k_rlm_wave<r, kv, ns, true>, &k_rlm_wave<r, kv, ns, false>}
@@ -2545,6 +2569,10 @@ const void *chunk_kernel(int R, uint32_t channels, int KV) {
 
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch) {
     hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, s, gran, tabs, n_sources, cols, last_col, J, epoch, next_epoch);
+}
+
+void launch_state_sum(hipStream_t s, const unsigned long long *gran, const SrcDesc *srcs, uint32_t n_sources, uint32_t cols, uint32_t tag, float *w_out) {
+    hipLaunchKernelGGL(k_rlm_state_sum, dim3(1), dim3(256), 0, s, gran, srcs, n_sources, cols, tag, w_out);
 }
 
 // Mix first (k_mix_rows / k_mix_ring in front of a one-source fused launch): one-shot runs of filtered equal-length batches.

@@ -296,6 +296,8 @@ struct rh_rlm {
     float *d_replay = nullptr;   // where the recovery's replay of the last tiles writes its (unused) mix
     size_t replay_floats = 0;
     uint32_t st_n_summed = 0, st_n_each = 0, st_n_recover = 0;  // rh_rlm_stream_stats
+    uint32_t st_n_rejoin = 0;                 // times the stream went back to the summed state
+    std::vector<uint8_t> st_gone, st_prev_gone;  // sources that have given everything (the summed blocks behind a return; the block before, for a recovery)
     // Recorded (by wait_idle) behind what the handle has queued.  The library's streams are hipStreamNonBlocking: a null-stream
     // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
     // kernel may still read (descriptors, control words, aggregate table, stream states) waits for this event first.
@@ -341,6 +343,8 @@ VariantTab variant_tab(TabKind kind, bool mono);             // the instances of
 const void *chunk_kernel(int R, uint32_t channels, int KV);  // the instance of k_rlm_chunk, or nullptr
 // k_rlm_state on `s`: folds a block's aggregates into column 0 of the per-source rows (see rh_pipeline_stream.hip)
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch);
+// k_rlm_state_sum on `s`: the sum of the live sources' states (column 0 of their rows, tagged `tag`) -> the 4 words of a summed state
+void launch_state_sum(hipStream_t s, const unsigned long long *gran, const SrcDesc *srcs, uint32_t n_sources, uint32_t cols, uint32_t tag, float *w_out);
 bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool per_source_states, bool batch);
 rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride_floats,
                      const StreamArgs &sa = StreamArgs());

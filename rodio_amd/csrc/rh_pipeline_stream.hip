@@ -64,8 +64,10 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     p->st_total.clear();
     p->st_cols = 0;
     p->st_together = p->st_decided = false;
-    p->st_n_summed = p->st_n_each = p->st_n_recover = 0;
+    p->st_n_summed = p->st_n_each = p->st_n_recover = p->st_n_rejoin = 0;
     p->st_prev_ptrs.clear();
+    p->st_gone.clear();
+    p->st_prev_gone.clear();
     p->st_prev_avail = p->st_prev_g0 = p->st_prev_m = p->st_prev_out = 0;
     return RH_OK;
 }
@@ -86,7 +88,7 @@ rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on) {
 }
 
 static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
-                                     uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream);
+                                     uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream, const std::vector<uint8_t> *gone = nullptr);
 
 rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
                               uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
@@ -96,12 +98,15 @@ rh_status rh_rlm_stream_block(rh_rlm *p, const float *const *srcs_host, uint32_t
     return stream_block_summed(p, srcs_host, n_sources, avail_frames, flush, dst, out_capacity_frames, out_frames, consumed_frames, stream);
 }
 
+// `gone` (rh_rlm_stream_block_v, a stream back on the summed state after sources have ended): sources that have given everything.  Their table
+// entries point at a live source's row with gain 0 -- exact zeros in the sum, the row count of the launch unchanged, and the entries move on
+// with the live rows (the table stays on the device).
 static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, uint32_t n_sources, uint64_t avail_frames, int32_t flush, float *dst, uint64_t out_capacity_frames,
-                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream) {
+                              uint64_t *out_frames, uint64_t *consumed_frames, rh_stream stream, const std::vector<uint8_t> *gone) {
     RH_REQUIRE_INIT();
     if (!p || !p->st_on || p->st_done || !out_frames || !consumed_frames) return RH_ERR_INVALID;
     if (n_sources == 0 || n_sources > p->cfg.max_sources || avail_frames > p->cfg.max_in_frames) return RH_ERR_CAPACITY;
-    if (p->st_cols || (p->st_nsrc && p->st_nsrc != n_sources)) return RH_ERR_INVALID;  // the summed state belongs to one set of sources (and one kind of stream)
+    if ((p->st_cols && !gone) || (p->st_nsrc && p->st_nsrc != n_sources)) return RH_ERR_INVALID;  // the summed state belongs to one set of sources (and one kind of stream)
     *out_frames = 0;
     *consumed_frames = 0;
     const uint64_t F = p->F, T = p->T, R = p->fast.v->R, L = 64 * R;
@@ -131,22 +136,28 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
             const bool sum_first = mix_first_applies(p, p->fast, n_sources, false, false);
             uint64_t src_off = 0;
             bool reuse = sum_first && p->st_tab_version == p->srcs_version && p->st_tab_ptrs.size() == n_sources && !rh::knob(rh::K_STREAM_UPLOAD_ALWAYS);
+            uint32_t lead = 0;  // the first source that is still there
+            while (gone && lead + 1 < n_sources && (*gone)[lead]) ++lead;
+            auto row_of = [&](uint32_t s) { return gone && (*gone)[s] ? srcs_host[lead] : srcs_host[s]; };
             if (reuse) {
-                src_off = (uint64_t)(reinterpret_cast<uintptr_t>(srcs_host[0]) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[0]));
+                src_off = (uint64_t)(reinterpret_cast<uintptr_t>(row_of(0)) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[0]));
                 for (uint32_t s = 0; s < n_sources && reuse; ++s)
-                    reuse = srcs_host[s] && !(reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u) &&
-                            (uint64_t)(reinterpret_cast<uintptr_t>(srcs_host[s]) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[s])) == src_off;
+                    reuse = row_of(s) && !(reinterpret_cast<uintptr_t>(row_of(s)) & 15u) &&
+                            (uint64_t)(reinterpret_cast<uintptr_t>(row_of(s)) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[s])) == src_off;
             }
             if (!reuse) {
                 src_off = 0;
                 h.resize(n_sources);
+                p->st_tab_ptrs.resize(n_sources);
                 for (uint32_t s = 0; s < n_sources; ++s) {
-                    if (!srcs_host[s] || (reinterpret_cast<uintptr_t>(srcs_host[s]) & 15u)) return RH_ERR_INVALID;
-                    h[s] = SrcDesc{srcs_host[s], (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+                    const float *row = row_of(s);
+                    if (!row || (reinterpret_cast<uintptr_t>(row) & 15u)) return RH_ERR_INVALID;
+                    const bool is_gone = gone && (*gone)[s];
+                    h[s] = SrcDesc{row, (uint32_t)avail_frames, (uint32_t)out, is_gone ? 0.0f : (s < p->gains.size() ? p->gains[s] : 1.0f), {0, 0, 0}};
+                    p->st_tab_ptrs[s] = row;
                 }
                 const rh_status up = upload_descriptors(p, n_sources, rh::as_stream(stream));
                 if (up != RH_OK) return up;
-                p->st_tab_ptrs.assign(srcs_host, srcs_host + n_sources);
                 p->st_tab_version = p->srcs_version;
             }
             p->equal = true;
@@ -232,28 +243,91 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         p->st_decided = true;
         p->st_together = p->st_history && p->filt && p->mix_first_on && n_sources >= 2 && K > 0 && !rh::knob(rh::K_NO_MIX_FIRST);
     }
+    const uint64_t Rf = p->fast.v->R;
+    auto would_emit = [&](uint64_t avail) {  // output frames a summed block of `avail` frames per source would emit
+        const uint64_t ready = stream_ready(p->st_g0 + avail, F, T, cin, cout);
+        return ready > p->st_m ? (ready - p->st_m) / Rf * Rf : 0;
+    };
+    // ---- ... and TOGETHER AGAIN: a stream with a state per source whose sources have either given everything or still run, the running ones
+    // with the same frames.  The summed state is the sum of their states (column 0 of their rows: k_rlm_state_sum); the ones that are gone
+    // stay in the table with gain 0 (stream_block_summed).  From there the stream is what it was before the first source ended -- one summed
+    // launch per block instead of a wave per tile walking every source (~360 us per block of 256 sources whatever its length) -- until the
+    // next source ends.  RH_STREAM_NO_REJOIN=1: a state per source to the end, as before round 5.
+    bool leaving = false;
+    if (!p->st_together && p->st_cols && p->st_history && p->filt && p->mix_first_on && K > 0 && !p->st_total.empty() && !rh::knob(rh::K_NO_MIX_FIRST) && !rh::knob(rh::K_STREAM_NO_REJOIN)) {
+        bool ok = true;
+        uint32_t live = 0;
+        uint64_t av = 0;
+        std::vector<uint8_t> gone(n_sources, 0);
+        for (uint32_t s = 0; s < n_sources && ok; ++s) {
+            if (p->st_total[s] != ~0ull) {  // it has ended: gone only when it has given everything
+                const uint64_t M = stream_total(p->st_total[s], F, T, cin, cout);
+                ok = M <= p->st_m;
+                gone[s] = 1;
+                continue;
+            }
+            ok = !ended_host[s] && (live == 0 || avail_frames_host[s] == av);
+            av = avail_frames_host[s];
+            live += 1;
+        }
+        if (ok && live >= 2 && would_emit(av) >= K) {
+            p->st_dirty = true;
+            // the table of the summed blocks first (the sum reads who is gone from it), then the sum of the live states into the summed state's words
+            std::vector<SrcDesc> &h = p->h_desc;
+            h.resize(n_sources);
+            uint32_t lead = 0;
+            while (lead + 1 < n_sources && gone[lead]) ++lead;
+            p->st_tab_ptrs.resize(n_sources);
+            for (uint32_t s = 0; s < n_sources; ++s) {
+                const float *row = gone[s] ? srcs_host[lead] : srcs_host[s];
+                if (!row || (reinterpret_cast<uintptr_t>(row) & 15u)) return RH_ERR_INVALID;
+                h[s] = SrcDesc{row, (uint32_t)av, 0u, gone[s] ? 0.0f : (s < p->gains.size() ? p->gains[s] : 1.0f), {0, 0, 0}};
+                p->st_tab_ptrs[s] = row;
+            }
+            {
+                const rh_status up = upload_descriptors(p, n_sources, hs);
+                if (up != RH_OK) return up;
+            }
+            p->st_tab_version = p->srcs_version;
+            {
+                const rh_status pw = pre_launch(p, hs);
+                if (pw != RH_OK) return pw;
+            }
+            launch_state_sum(hs, p->d_gran, p->d_srcs, n_sources, p->st_cols, p->epoch + 1, p->d_w[p->st_cur]);  // (column 0 carries the tag of the launch that would have read it)
+            RH_CHECK_LAUNCH();
+            p->epoch += 1;  // ... a tag the summed launch that comes next must not share: its tiles' words lie in the same table
+            {
+                const rh_status mk = mark_launch(p, hs);
+                if (mk != RH_OK) return mk;
+            }
+            p->st_gone.swap(gone);
+            p->st_together = true;
+            p->st_n_rejoin += 1;
+        }
+    }
     if (p->st_together) {
+        const std::vector<uint8_t> *gone = p->st_gone.empty() ? nullptr : &p->st_gone;
         bool same = true, any_ended = false, all_ended = true;
+        uint32_t lead = 0;
+        while (gone && lead + 1 < n_sources && (*gone)[lead]) ++lead;
         for (uint32_t s = 0; s < n_sources; ++s) {
-            same = same && avail_frames_host[s] == avail_frames_host[0];
+            if (gone && (*gone)[s]) continue;
+            same = same && avail_frames_host[s] == avail_frames_host[lead];
             any_ended = any_ended || ended_host[s] != 0;
             all_ended = all_ended && ended_host[s] != 0;
         }
-        const uint64_t N = p->st_g0 + avail_frames_host[0];
-        const uint64_t ready = stream_ready(N, F, T, cin, cout);
-        const uint64_t Rf = p->fast.v->R;
-        const uint64_t would = ready > p->st_m ? (ready - p->st_m) / Rf * Rf : 0;
         if (same && all_ended) {  // they end together too: the summed stream's last block
-            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 1, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[lead], 1, dst, out_capacity_frames, out_frames, consumed_frames, stream, gone);
             if (st == RH_OK) p->st_together = false;  // (st_done is set: nothing follows)
             return st;
         }
-        if (same && !any_ended && would >= K) {
+        if (same && !any_ended && would_emit(avail_frames_host[lead]) >= K) {
             const uint64_t g0 = p->st_g0, m0 = p->st_m;
-            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[0], 0, dst, out_capacity_frames, out_frames, consumed_frames, stream);
+            const rh_status st = stream_block_summed(p, srcs_host, n_sources, avail_frames_host[lead], 0, dst, out_capacity_frames, out_frames, consumed_frames, stream, gone);
             if (st != RH_OK) return st;
             p->st_prev_ptrs.assign(srcs_host, srcs_host + n_sources);
-            p->st_prev_avail = avail_frames_host[0];
+            p->st_prev_gone = p->st_gone;
+            p->st_prev_avail = avail_frames_host[lead];
             p->st_prev_g0 = g0;
             p->st_prev_m = m0;
             p->st_prev_out = *out_frames;
@@ -261,8 +335,10 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         }
         p->st_dirty = true;
         p->st_together = false;  // a source ends or falls behind, or the block is short: one state per source from here on
+        leaving = true;
     }
-    const bool recover = !p->st_cols && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
+    const bool recover = (leaving || !p->st_cols) && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
+    const bool rows_exist = p->st_cols != 0;  // (the stream has had a state per source before: its rows are sized, their column 0 carries old tags)
     if (!p->st_cols) {  // first block of the per-source stream: size the aggregate rows once (the states live in them), zero states
         p->st_dirty = true;
         rh::ResampleGeom g;
@@ -301,6 +377,14 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         // from a zero state (its rows are still there: rh_rlm_stream_keep_history), mix discarded, and fold the replay's aggregates
         // into column 0 -- exactly what the end of a per-source block does.
         const uint64_t m0 = p->st_m - K;  // >= st_prev_m: that block emitted at least K frames
+        if (rows_exist) {  // zero states tagged for the replay (the first time round, the sizing above has just written them)
+            const rh_status pw = pre_launch(p, hs);
+            if (pw != RH_OK) return pw;
+            launch_state(hs, p->d_gran, p->wave.d_tabs, n_sources, p->st_cols, 0u, (uint32_t)p->wave.J, p->epoch, p->epoch + 1);
+            RH_CHECK_LAUNCH();
+            const rh_status mk = mark_launch(p, hs);
+            if (mk != RH_OK) return mk;
+        }
         const size_t need = (size_t)K * p->cfg.channels + 64;
         if (need > p->replay_floats) {
             const rh_status w = wait_idle(p);
@@ -312,8 +396,10 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         }
         std::vector<SrcDesc> &h = p->h_desc;
         h.resize(n_sources);
-        for (uint32_t s = 0; s < n_sources; ++s)
-            h[s] = SrcDesc{p->st_prev_ptrs[s], (uint32_t)p->st_prev_avail, (uint32_t)K, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+        for (uint32_t s = 0; s < n_sources; ++s) {
+            const bool was_gone = s < p->st_prev_gone.size() && p->st_prev_gone[s];  // (it had given everything before that block: nothing to replay, no state)
+            h[s] = SrcDesc{was_gone ? nullptr : p->st_prev_ptrs[s], was_gone ? 0u : (uint32_t)p->st_prev_avail, was_gone ? 0u : (uint32_t)K, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+        }
         {
             const rh_status up = upload_descriptors(p, n_sources, hs);
             if (up != RH_OK) return up;

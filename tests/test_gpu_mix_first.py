@@ -444,7 +444,7 @@ def test_block_streaming_keeps_its_table_while_the_sources_move_together(G, O):
 
 
 @pytest.mark.parametrize("filt,freq", [("low_pass", 200), ("high_pass", 300)])
-@pytest.mark.parametrize("case", ["end together", "end apart", "short first block", "short block in the middle", "one falls behind"])
+@pytest.mark.parametrize("case", ["end together", "end apart", "short first block", "short block in the middle", "one falls behind", "end apart, together again"])
 def test_block_streaming_of_sources_that_run_together(G, O, filt, freq, case):
     """rh_rlm_stream_block_v + rh_rlm_stream_keep_history (VERDICT r03 missing #5): what a mixer's sources do from the moment they are
     added until the first of them ends -- all live, the same frames per block -- runs on the SUMMED state, every block summed first.
@@ -455,9 +455,10 @@ def test_block_streaming_of_sources_that_run_together(G, O, filt, freq, case):
 
     S = 6
     ns = {"end together": [90000] * S, "end apart": [90000, 61000, 90000, 45000, 90000, 40000], "short first block": [90000, 61000, 90000, 90000, 90000, 90000],
-          "short block in the middle": [90000] * S, "one falls behind": [90000] * S}[case]
+          "short block in the middle": [90000] * S, "one falls behind": [90000] * S, "end apart, together again": [200000, 60000, 200000, 130000, 200000, 200000]}[case]
     cuts = {"end together": [0, 25000, 50000, 75000, 90000], "end apart": [0, 25000, 50000, 75000, 90000], "short first block": [0, 700, 30000, 60000, 90000],
-            "short block in the middle": [0, 30000, 30300, 60000, 90000], "one falls behind": [0, 25000, 50000, 75000, 90000]}[case]
+            "short block in the middle": [0, 30000, 30300, 60000, 90000], "one falls behind": [0, 25000, 50000, 75000, 90000],
+            "end apart, together again": list(range(0, 200001, 25000))}[case]
     gains = np.linspace(0.5, 1.3, S).astype(np.float32)
     xs = [rnd(7100 + i, 2 * n, 0.15) for i, n in enumerate(ns)]
     m = O.Mixer(2, 48000)
@@ -497,7 +498,10 @@ def test_block_streaming_of_sources_that_run_together(G, O, filt, freq, case):
         if not hist:
             assert summed == 0 and rec == 0 and each >= 4
         else:  # which blocks ran how: the cases are what their names say
-            want = {"end together": (4, 0, 0), "end apart": (1, 3, 1), "short first block": (0, 4, 0), "short block in the middle": (1, 2, 1), "one falls behind": (1, 3, 1)}[case]
+            # (round 5: a stream with a state per source goes back to the summed state once its sources have either given everything or run
+            # together again -- the block behind a short one, the blocks between two sources' ends)
+            want = {"end together": (4, 0, 0), "end apart": (1, 3, 1), "short first block": (2, 2, 1), "short block in the middle": (3, 0, 1), "one falls behind": (3, 1, 1),
+                    "end apart, together again": (6, 2, 2)}[case]
             assert (summed, each, rec) == want, (case, summed, each, rec)
         p.close()
     assert len(got[True]) == len(ref) == len(got[False]), (len(got[True]), len(got[False]), len(ref))
