@@ -191,8 +191,11 @@ def _mixer_case(O, tmp_path, seed, exe):
             chans = [ch0]
             make = lambda x=x, ch0=ch0, rate0=rate0, i=i: M._span_source(O, kind, x, ch0, rate0, i)
         ops = _ops_any_format(rng, int(rng.integers(1, 3)), chans) if rng.random() < 0.5 else []
-        lines.append(f"{ch0} {rate0} {gain} -1 0 {','.join(ops) if ops else '-'}\n")
-        adds.append((make, ops, gain))
+        # `mixer.add(source.low_pass(f))` with the filter given to the mixer (GpuMixer::add(src, gain, filter): the fused path's filter classes);
+        # mixers of one and two channels only (a wide mixer takes chains)
+        fk, ff = (int(rng.integers(0, 2)), int(rng.choice([300, 1000, 3000]))) if (mixer_ch <= 2 and rng.random() < 0.4) else (-1, 0)
+        lines.append(f"{ch0} {rate0} {gain} {fk} {ff} {','.join(ops) if ops else '-'}\n")
+        adds.append((make, ops, gain, fk, ff))
     (tmp_path / "spec.txt").write_text("".join(lines))
     r = subprocess.run([exe, "chainmix", str(tmp_path), str(S), str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, RH_TEST_SOURCE=kind))
@@ -200,8 +203,9 @@ def _mixer_case(O, tmp_path, seed, exe):
     assert r.returncode == 0, (what, r.stderr)
     got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
     m = O.Mixer(mixer_ch, to_rate)
-    for make, ops, gain in adds:
-        m.add(O.UniformSourceIterator(_oracle_chain(O, make(), ops).amplify(gain), mixer_ch, to_rate))
+    for make, ops, gain, fk, ff in adds:
+        u = O.UniformSourceIterator(_oracle_chain(O, make(), ops).amplify(gain), mixer_ch, to_rate)
+        m.add(u.low_pass(ff) if fk == 0 else u.high_pass(ff) if fk == 1 else u)
     ref = m.collect()
     assert len(got) == len(ref), (what, len(got), len(ref))
     if len(ref):
