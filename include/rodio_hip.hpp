@@ -997,13 +997,13 @@ public:
             });
         }).on_seek([st, chp, fc, sm](Nanos) {  // limit.rs:1139-1158
             check(rh_memset(st->get(), 0, 2u * *chp * sizeof(float), sm), "rh_memset");
-            fc->n = 0;
+            fc->n = fc->lead = 0;
         }).on_format([st, chp, fc, sm](std::uint16_t ch, std::uint32_t) {  // limit.rs:652-695: another channel count rebuilds the state (and the channel position); another rate changes nothing
                 if (ch == *chp) return;
                 st->reset(2u * ch);
                 check(rh_memset(st->get(), 0, 2u * ch * sizeof(float), sm), "rh_memset");
                 *chp = ch;
-                fc->n = 0;
+                fc->n = fc->lead = 0;
             });
     }
     GpuSource &automatic_gain_control(const rh_agc_params &settings) {  // agc.rs:133-171,397-504
@@ -1315,33 +1315,70 @@ private:
     // state meets them again in front of the samples that complete the frame; on_format / on_seek drop them where rodio starts afresh.
     struct FrameCarry {
         detail::DeviceBuf part, pad, st2, tin, tout;
-        std::size_t n = 0;  // samples of an open frame, already emitted
+        std::size_t n = 0;     // samples of an open frame, already emitted from a copy of the state and kept for the real one
+        std::size_t lead = 0;  // channels of the open frame that are done for good (commit_open_frame): the next samples go on at this channel
     };
+    // One frame of which only the channels [c0, c0 + k) are real (the others zeros), through a copy of the state; the outputs of those channels
+    // go to `out`, and -- `keep` -- their state entries (per_ch floats a channel, one channel after the other: rh_biquad's layout) back into the
+    // real state.  The channels are independent in the filters; the limiter never needs `keep` (its coefficients do not change with the rate).
+    template <class K>
+    static void run_part_of_a_frame(FrameCarry &fc, std::uint16_t ch, std::size_t c0, std::size_t k, const float *in, float *out, float *state, std::size_t state_floats, bool keep, rh_stream s,
+                                    K kernel) {
+        fc.pad.reset(2u * ch);
+        fc.st2.reset(state_floats);
+        check(rh_memset(fc.pad.get(), 0, ch * sizeof(float), s), "rh_memset");
+        check(rh_memcpy_d2d(fc.pad.get() + c0, in, k * sizeof(float), s), "rh_memcpy_d2d");
+        check(rh_memcpy_d2d(fc.st2.get(), state, state_floats * sizeof(float), s), "rh_memcpy_d2d");
+        kernel(fc.pad.get() + ch, fc.pad.get(), 1, fc.st2.get());
+        if (out) check(rh_memcpy_d2d(out, fc.pad.get() + ch + c0, k * sizeof(float), s), "rh_memcpy_d2d");
+        if (keep) {
+            const std::size_t per_ch = state_floats / ch;
+            check(rh_memcpy_d2d(state + per_ch * c0, fc.st2.get() + per_ch * c0, per_ch * k * sizeof(float), s), "rh_memcpy_d2d");
+        }
+    }
+    // The adapter's parameters are about to change (a filter's coefficients at a new sample rate) while a frame is open: the samples that were
+    // emitted from a copy of the state meet the OLD parameters for good -- their channels' state entries go into the real state -- and the
+    // frame goes on at the next channel with the new ones (rodio's filter runs sample by sample: blt.rs:431-451; the recreated applier,
+    // blt.rs:119-141, simply meets the next sample).
+    template <class K>
+    static void commit_open_frame(FrameCarry &fc, std::uint16_t ch, float *state, std::size_t state_floats, rh_stream s, K kernel) {
+        if (!fc.n) return;
+        run_part_of_a_frame(fc, ch, fc.lead, fc.n, fc.part.get(), nullptr, state, state_floats, true, s, kernel);
+        fc.lead += fc.n;  // (< ch: an open frame is never whole)
+        fc.n = 0;
+    }
     template <class K>
     static std::size_t run_framewise(Ctx &c, std::uint16_t ch, FrameCarry &fc, float *state, std::size_t state_floats, K kernel) {
-        const std::size_t carried = fc.n, total = carried + c.n, frames = total / ch, rem = total % ch;
-        const float *in = c.in;
-        float *out = c.out;
+        const float *cin = c.in;
+        float *cout = c.out;
+        std::size_t cn = c.n;
+        if (fc.lead) {  // a frame whose first channels are done (see commit_open_frame): its next samples one part at a time, straight into the state
+            const std::size_t k = std::min<std::size_t>(ch - fc.lead, cn);
+            if (k) run_part_of_a_frame(fc, ch, fc.lead, k, cin, cout, state, state_floats, true, c.stream, kernel);
+            fc.lead = fc.lead + k == ch ? 0 : fc.lead + k;
+            cin += k, cout += k, cn -= k;
+            if (fc.lead) return c.n;  // (the block ended inside that frame)
+        }
+        const std::size_t carried = fc.n, total = carried + cn, frames = total / ch, rem = total % ch;
+        const float *in = cin;
+        float *out = cout;
         if (carried) {  // (rare: once behind every span that ends inside a frame)
             fc.tin.reset(total + ch);
             fc.tout.reset(total + ch);
             check(rh_memcpy_d2d(fc.tin.get(), fc.part.get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
-            if (c.n) check(rh_memcpy_d2d(fc.tin.get() + carried, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
+            if (cn) check(rh_memcpy_d2d(fc.tin.get() + carried, cin, cn * sizeof(float), c.stream), "rh_memcpy_d2d");
             in = fc.tin.get();
             out = fc.tout.get();
         }
         if (frames) kernel(out, in, frames, state);
-        if (carried && frames * ch > carried) check(rh_memcpy_d2d(c.out, out + carried, (frames * ch - carried) * sizeof(float), c.stream), "rh_memcpy_d2d");
+        if (carried && frames * ch > carried) check(rh_memcpy_d2d(cout, out + carried, (frames * ch - carried) * sizeof(float), c.stream), "rh_memcpy_d2d");
         if (rem) {
             const std::size_t before = frames ? 0 : carried;  // of the open frame's samples: emitted by an earlier call
             if (rem > before) {
+                // (all of the open frame's samples through the copy again: the ones emitted before give the same outputs, only the new ones are taken)
                 fc.pad.reset(2u * ch);
-                fc.st2.reset(state_floats);
-                check(rh_memset(fc.pad.get(), 0, ch * sizeof(float), c.stream), "rh_memset");
-                check(rh_memcpy_d2d(fc.pad.get(), in + frames * ch, rem * sizeof(float), c.stream), "rh_memcpy_d2d");
-                check(rh_memcpy_d2d(fc.st2.get(), state, state_floats * sizeof(float), c.stream), "rh_memcpy_d2d");
-                kernel(fc.pad.get() + ch, fc.pad.get(), 1, fc.st2.get());
-                check(rh_memcpy_d2d(c.out + (frames * ch + before - carried), fc.pad.get() + ch + before, (rem - before) * sizeof(float), c.stream), "rh_memcpy_d2d");
+                run_part_of_a_frame(fc, ch, 0, rem, in + frames * ch, nullptr, state, state_floats, false, c.stream, kernel);
+                check(rh_memcpy_d2d(cout + (frames * ch + before - carried), fc.pad.get() + ch + before, (rem - before) * sizeof(float), c.stream), "rh_memcpy_d2d");
                 fc.part.reset(ch);
                 check(rh_memcpy_d2d(fc.part.get(), in + frames * ch, rem * sizeof(float), c.stream), "rh_memcpy_d2d");
             }
@@ -1376,17 +1413,19 @@ private:
             });
         }).on_seek([st, ch, fc, sm = stream_](Nanos) {  // blt.rs:350-377
             check(rh_memset(st->get(), 0, 4u * ch * sizeof(float), sm), "rh_memset");
-            fc->n = 0;
+            fc->n = fc->lead = 0;
         })
-            .on_format([ap, make, ch, fc](std::uint16_t new_ch, std::uint32_t rate) {
+            .on_format([ap, make, ch, fc, st, sm = stream_](std::uint16_t new_ch, std::uint32_t rate) {
                 // blt.rs:119-141: `recreate_applier` for the new rate; the state stays.  (A new channel COUNT: the branch that would rebuild the
                 // filter compares the count with itself, blt.rs:128, so rodio goes on filtering frames of the new layout with the state of
                 // the old one -- channels meet each other's history.  Not mirrored.)
                 if (new_ch != ch) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a filter across a change of the channel count (" + std::to_string(ch) + " -> " + std::to_string(new_ch) + ")");
-                // The span in front of the change ended inside a frame (source/mod.rs:169-178 asks sources for whole frames): rodio's filter goes on
-                // at the next channel with the new coefficients, the channels in front of it have met the old ones -- a frame with two sets of
-                // coefficients, which the frame-wise kernel does not run.  Loud, not wrong.
-                if (fc->n) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a filter's coefficients change inside a frame (the span in front of the new sample rate ended inside one)");
+                // The span in front of the change may have ended inside a frame (source/mod.rs:169-178 asks sources for whole frames; queues of
+                // odd sounds exist): rodio's filter goes on at the next channel with the new coefficients, the channels in front of it have met
+                // the old ones -- commit_open_frame.
+                commit_open_frame(*fc, ch, st->get(), 4u * ch, sm, [&](float *out, const float *in, std::size_t frames, float *state) {
+                    check(rh_biquad(out, in, frames, ch, 1, ap->co, state, ap->exact ? 0 : 1, sm), "rh_biquad");
+                });
                 *ap = make(rate);
             });
     }
