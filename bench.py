@@ -309,8 +309,16 @@ def headline(args, argv):
         if uid is not None:
             try:
                 comm = D.NativeComm(rank, world, uid)
+                # ... and one small all-reduce through it before anything is timed: a communicator that initialises but cannot reduce (a
+                # transport RCCL picks and the box refuses) shows here, where the ranks can still agree to take the other path
+                probe = torch.full((1024,), float(rank + 1), device="cuda", dtype=torch.float32)
+                comm.all_reduce(probe)
+                torch.cuda.synchronize()
+                if abs(float(probe[0].item()) - world * (world + 1) / 2.0) > 1e-3:
+                    raise RuntimeError(f"rh_allreduce_sum_f32 probe: {float(probe[0].item())} on rank {rank} of {world}")
             except Exception as e:  # noqa: BLE001
                 comm_err = str(e)[:300]
+                comm = None
         if world > 1:
             agreed = torch.tensor([1 if comm is not None else 0], device=cdev, dtype=torch.int32)
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
