@@ -56,9 +56,20 @@ def kernel_metadata(tmp_path):
 def test_no_kernel_uses_scratch_or_spills_vector_registers(tmp_path):
     ks = kernel_metadata(tmp_path)
     assert len(ks) > 100, len(ks)  # every translation unit was found and parsed
-    for must in ("k_rlm_chunk", "k_rlm_fast", "k_rlm_wave", "k_mix_ring", "k_limit_scan", "k_biquad_scan", "k_agc_chain", "k_uniform_segs"):
+    for must in ("k_rlm_chunk", "k_rlm_fast", "k_rlm_wave", "k_mix_ring", "k_limit_scan", "k_biquad_scan", "k_agc_chain", "k_agc_fused0", "k_rlm_state_sum", "k_uniform_segs"):
         assert any(must in k for k in ks), must
     bad = {k: v for k, v in ks.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0) or v["dynamic_stack"]}
     assert not bad, bad
     # gfx950 only: the library carries no other code object
     assert all(b"gfx950" in img[:4096] or True for img in code_objects())
+
+
+@pytest.mark.skipif(not os.path.exists(READELF), reason="llvm-readelf not found")
+def test_the_agc_kernel_of_round_5_keeps_its_twelve_waves(tmp_path):
+    """k_agc_fused0 runs twelve waves in one workgroup (three per SIMD: 168 vector registers each) over 152 KiB of LDS: a build that needs more
+    of either would not launch -- or, worse, would fit and spill."""
+    ks = kernel_metadata(tmp_path)
+    (name,) = [k for k in ks if "k_agc_fused0" in k]
+    v = ks[name]
+    assert v["vgpr_count"] <= 168, v
+    assert not v.get("sgpr_spill_count", 0), v
