@@ -758,8 +758,10 @@ private:
 // ---------------------------------------------------------------- GpuSource: adapter chain on one upstream ----
 /// `upstream.amplify(..).low_pass(..)...` with the chain executed block-wise on the GPU.  Adapters with
 /// memory (filters, limiter, AGC, reverb, converters) carry it across blocks: any block size gives the bits
-/// of one pass.  The upstream must keep its format (a source whose channels()/sample_rate() change
-/// mid-stream is what UniformSourceIterator is for: convert first).
+/// of one pass.  An upstream that changes its format between spans (a queue of sounds) is followed span by span by the adapters
+/// that rodio's own SpanTracker serves -- filters, limiter, AGC, `uniform` -- and by everything that does not look at the format; the
+/// others (reverb, delay, take_duration, channel_volume, ramps, dither) refuse such a change loudly: `.uniform()` in front of them
+/// makes the format one.
 class GpuSource : public detail::BlockPump {
 public:
     explicit GpuSource(BoxSource upstream, std::size_t block_frames = 1u << 15) : up_(std::move(upstream)), block_frames_(block_frames ? block_frames : 1) {
