@@ -877,8 +877,13 @@ public:
         push([from, to](Ctx &c) {
             const std::size_t frames = c.n / from;
             check(rh_channels_convert(c.out, c.in, frames, from, to, c.stream), "rh_channels_convert");
-            return frames * to;
-        }, [from, to](std::size_t n) { return n / from * to; }).spans(1);  // a bare converter is an iterator, not a Source: what wraps it sees no spans
+            // A stream that ends inside a frame (reverb with a delay that is no whole number of frames: delay.rs:14 counts samples): the
+            // converter hands on the samples of the open frame as far as both layouts go -- positions below `from` are plain input.next()
+            // (channels.rs:57-67), a None ends the stream -- so min(rest, to) samples follow the whole frames.
+            const std::size_t rest = c.flush ? std::min<std::size_t>(c.n % from, to) : 0;
+            if (rest) check(rh_memcpy_d2d(c.out + frames * to, c.in + frames * from, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
+            return frames * to + rest;
+        }, [from, to](std::size_t n) { return n / from * to + to; }).spans(1);  // a bare converter is an iterator, not a Source: what wraps it sees no spans
         ch_ = to;
         return *this;
     }
@@ -1059,18 +1064,35 @@ public:
     /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
     GpuSource &delay(Nanos duration) {
         const std::uint64_t d = rh_delay_samples((std::uint64_t)duration.count(), rate_, ch_);
+        const std::uint16_t ch = ch_;
         auto first = std::make_shared<bool>(true);
+        // The silence counts SAMPLES (delay.rs:14): one that is no whole number of frames shifts the stream inside its frames.  The adapters
+        // behind work on frames, so a block hands on whole frames and the samples of the frame that is not complete yet wait here for the next
+        // block (as behind `uniform`); the end of the stream hands them on as they are.
+        auto part = std::make_shared<detail::DeviceBuf>(64);
+        auto part_n = std::make_shared<std::size_t>(0);
         return push(
                    [=](Ctx &c) {
+                       std::size_t k;
                        if (*first) {
                            *first = false;
                            check(rh_delay(c.out, c.in, c.n, d, c.stream), "rh_delay");
-                           return c.n + (std::size_t)d;
+                           k = c.n + (std::size_t)d;
+                       } else {
+                           const std::size_t carried = *part_n;
+                           if (carried) check(rh_memcpy_d2d(c.out, part->get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
+                           check(rh_amplify(c.out + carried, c.in, c.n, 1.0f, c.stream), "rh_amplify");  // x * 1.0 == x: a copy into the other buffer
+                           k = carried + c.n;
                        }
-                       check(rh_amplify(c.out, c.in, c.n, 1.0f, c.stream), "rh_amplify");  // x * 1.0 == x: a copy into the other buffer
-                       return c.n;
+                       const std::size_t rest = c.flush ? 0 : k % ch;
+                       if (rest) {
+                           part->reset(ch);
+                           check(rh_memcpy_d2d(part->get(), c.out + k - rest, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
+                       }
+                       *part_n = rest;
+                       return k - rest;
                    },
-                   [d](std::size_t n) { return n + (std::size_t)d; })
+                   [d, ch](std::size_t n) { return n + (std::size_t)d + ch; })
             .not_seekable();
     }
     GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13

@@ -9,7 +9,7 @@
 // ("device memory" is host memory, streams and events are no-ops), with the arithmetic of the reference restated in the
 // reference's order (like oracle/rodio_oracle.cpp, whose iterator classes it does not use: the C ABI works on blocks with
 // carried state, so the loops are written block-wise here).  Entry points the host mirror does not call are absent, and the
-// ones it rarely calls answer RH_ERR_UNSUPPORTED.  The fused stream (rh_rlm_stream_block_v) is emulated by its CONTRACT (whole
+// ones without host logic of their own (rh_dither) answer RH_ERR_UNSUPPORTED.  The fused stream (rh_rlm_stream_block_v) is emulated by its CONTRACT (whole
 // tiles while sources are live, everything once all have ended, one common *consumed_frames), not by its kernels.
 //
 // Build: g++ -std=c++17 -O2 -ffp-contract=off -I include tests/cpp/host_mirror_test.cpp tests/cpp/fake_device.cpp -o tests/cpp/host_mirror_test_fake
@@ -118,7 +118,17 @@ float rh_db_to_linear(float db) { return powf(2.0f, db * 0.05f * LOG2_10); }
 float rh_linear_to_db(float lin) { return log2f(lin) * LOG10_2 * 20.0f; }
 float rh_duration_to_coefficient(uint64_t ns, uint32_t rate) { return expf(-1.0f / (duration_to_float(ns) * (float)rate)); }
 uint64_t rh_delay_samples(uint64_t ns, uint32_t rate, uint32_t ch) { return (uint64_t)((unsigned __int128)ns * ch * rate / 1000000000ull); }
-rh_status rh_spatial_gains(const float[3], const float[3], const float[3], float[2]) { return RH_ERR_UNSUPPORTED; }  // (host arithmetic, no host logic: tested on the real library)
+rh_status rh_spatial_gains(const float emitter[3], const float left[3], const float right[3], float out[2]) {  // spatial.rs:19-24, :48-69
+    auto dist_sq = [](const float *a, const float *b) {
+        float s = 0.0f;
+        for (int k = 0; k < 3; ++k) s += (a[k] - b[k]) * (a[k] - b[k]);
+        return s;
+    };
+    const float lsq = dist_sq(left, emitter), rsq = dist_sq(right, emitter), max_diff = std::sqrt(dist_sq(left, right)), ld = std::sqrt(lsq), rd = std::sqrt(rsq);
+    out[0] = std::fmin(((ld - rd) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f) * std::fmin(1.0f / lsq, 1.0f);
+    out[1] = std::fmin(((rd - ld) / max_diff + 1.0f) / 4.0f + 0.5f, 1.0f) * std::fmin(1.0f / rsq, 1.0f);
+    return RH_OK;
+}
 
 // ---------------------------------------------------------------- elementwise ----
 rh_status rh_amplify(float *dst, const float *src, size_t n, float f, rh_stream) {
@@ -149,11 +159,68 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs, const
     }
     return RH_OK;
 }
-rh_status rh_distortion(float *, const float *, size_t, float, float, rh_stream) { return RH_ERR_UNSUPPORTED; }
-rh_status rh_dither(float *, const float *, size_t, uint64_t, uint32_t, uint32_t, int32_t, uint64_t, rh_stream) { return RH_ERR_UNSUPPORTED; }
-rh_status rh_linear_gain_ramp(float *, const float *, size_t, uint64_t, uint32_t, uint32_t, uint64_t, float, float, int32_t, rh_stream) { return RH_ERR_UNSUPPORTED; }
-rh_status rh_delay(float *, const float *, uint64_t, uint64_t, rh_stream) { return RH_ERR_UNSUPPORTED; }
-rh_status rh_take_duration(float *, const float *, uint64_t, uint64_t, uint32_t, uint32_t, uint64_t, int32_t, uint64_t *, int32_t *, rh_stream) { return RH_ERR_UNSUPPORTED; }
+rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, float threshold, rh_stream) {  // distortion.rs:66-72
+    if (!(threshold >= 0.0f)) return RH_ERR_INVALID;  // (f32::clamp panics on min > max and on NaN)
+    for (size_t i = 0; i < n; ++i) {
+        float v = src[i] * gain;
+        if (v < -threshold) v = -threshold;
+        if (v > threshold) v = threshold;
+        dst[i] = v;
+    }
+    return RH_OK;
+}
+rh_status rh_dither(float *, const float *, size_t, uint64_t, uint32_t, uint32_t, int32_t, uint64_t, rh_stream) { return RH_ERR_UNSUPPORTED; }  // (no host logic beyond a sample counter: tested on the real library)
+// linear_ramp.rs:79-110, sample by sample from the start of the stream (the entry point is stateless: sample_offset says where the block lies;
+// a test's streams are short enough to walk)
+rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, float start_gain, float end_gain,
+                              int32_t clamp_end, rh_stream) {
+    if (!channels || !sample_rate) return RH_ERR_INVALID;
+    uint64_t elapsed = 0, sample_idx = 0;
+    const uint64_t dt = 1000000000ull / sample_rate;
+    for (uint64_t k = 0; k < sample_offset + n; ++k) {
+        float factor;
+        if (elapsed >= duration_ns) {
+            factor = clamp_end ? end_gain : 1.0f;
+        } else {
+            sample_idx += 1;
+            const float p = duration_to_float(elapsed) / duration_to_float(duration_ns);
+            factor = start_gain * (1.0f - p) + end_gain * p;
+        }
+        if (sample_idx % channels == 0) elapsed += dt;
+        if (k >= sample_offset) dst[k - sample_offset] = src[k - sample_offset] * factor;
+    }
+    return RH_OK;
+}
+rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samples, rh_stream) {  // delay.rs:68-75: the silence, then the input
+    for (uint64_t i = 0; i < delay_samples; ++i) dst[i] = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) dst[delay_samples + i] = src[i];
+    return RH_OK;
+}
+// take.rs:96-148: samples while remaining >= duration_per_sample, the fade-out filter before the decrement, the cut frame completed with silence
+rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out, uint64_t *out_samples,
+                           int32_t *ended, rh_stream) {
+    if (!channels || !sample_rate || !out_samples) return RH_ERR_INVALID;
+    const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);
+    if (!dps) return RH_ERR_UNSUPPORTED;
+    uint64_t remaining = duration_ns - std::min(duration_ns, sample_offset * dps), m = 0;
+    bool expired = false;
+    for (uint64_t i = 0;; ++i) {
+        if (remaining < dps) {  // (also right behind the block's last sample: rodio's next call would answer None without pulling)
+            expired = true;
+            const uint64_t in_frame = (sample_offset + i) % channels;
+            for (uint64_t z = in_frame ? channels - in_frame : 0; z > 0; --z) dst[m++] = 0.0f;
+            break;
+        }
+        if (i == n) break;
+        float v = src[i];
+        if (fade_out) v = v * (float)(remaining / 1000000ull) / (float)(duration_ns / 1000000ull);
+        remaining -= dps;
+        dst[m++] = v;
+    }
+    *out_samples = m;
+    if (ended) *ended = expired ? 1 : 0;
+    return RH_OK;
+}
 
 // ---------------------------------------------------------------- BltFilter ----
 rh_status rh_biquad_coeffs(int32_t kind, uint32_t freq, float q, uint32_t fs, float out[5]) {  // blt.rs:502-544

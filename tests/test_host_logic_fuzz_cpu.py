@@ -230,12 +230,12 @@ def test_gpu_random_sources_into_a_mixer(O, tmp_path, seed):
 
 
 # ------------------------------------------------------------------ ... and every adapter of the mirror over a continuous source ----
-def _full_ops(rng, ch, n_ops):
+def _full_ops(rng, ch, n_ops, dither=True):
     """The whole vocabulary of the test driver (tests/cpp/host_mirror_test.cpp: apply_op) in random order; the channel count is tracked
     because channel_volume / channels / spatial / uniform change it."""
     ops = []
     for _ in range(n_ops):
-        kind = str(rng.choice(["amplify", "filter", "limit", "agc", "uniform", "reverb", "take", "delay", "fade_in", "fade_out", "distortion", "channel_volume", "channels", "dither", "spatial"]))
+        kind = str(rng.choice(["amplify", "filter", "limit", "agc", "uniform", "reverb", "take", "delay", "fade_in", "fade_out", "distortion", "channel_volume", "channels", "spatial"] + (["dither"] if dither else [])))
         if kind == "amplify":
             ops.append(f"amplify:{rng.choice([0.5, 0.7, 1.25])}")
         elif kind == "filter":
@@ -302,13 +302,13 @@ def _oracle_full(O, src, ops):
     return src
 
 
-def _full_case(O, tmp_path, seed, exe):
+def _full_case(O, tmp_path, seed, exe, dither=True):
     rng = np.random.default_rng(66000 + seed)
     ch = int(rng.choice([1, 1, 2, 2, 3, 6]))
     rate = int(rng.choice(RATES))
     n = int(rng.integers(1, 12000)) * ch
     x = M.rnd(66000 + seed, n, 0.5)
-    ops = _full_ops(rng, ch, int(rng.integers(1, 5)))
+    ops = _full_ops(rng, ch, int(rng.integers(1, 5)), dither)
     block = int(rng.choice([64, 777, 4096, 16384]))
     x.tofile(tmp_path / "src_0.f32")
     r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
@@ -335,9 +335,15 @@ def _full_case(O, tmp_path, seed, exe):
         assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
 
 
-# (the stand-in device answers RH_ERR_UNSUPPORTED for the adapters without host logic of their own -- ramps, dither, distortion, take_duration,
-# spatial: fake_device.cpp -- so these chains run through the real library only)
+# (the stand-in device has every adapter but `dither` -- no host logic beyond a sample counter, and its noise is the library's contract, not
+# rodio's: fake_device.cpp -- so the chains with it run through the real library only)
 FULL_SEEDS = list(range(int(os.environ.get("RH_FUZZ_FULL", "40"))))
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_chain_of_any_adapters(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _full_case(O, tmp_path, seed, FAKE, dither=False)
 
 
 @pytest.mark.gpu
