@@ -858,11 +858,14 @@ public:
         const std::uint16_t in_ch = ch_;
         const std::uint16_t out_ch = (std::uint16_t)gains.size();
         if (!out_ch) throw std::invalid_argument("channel_volume: no output channels");
-        push([gains, in_ch, out_ch](Ctx &c) {
-            const std::size_t frames = c.n / in_ch;
-            check(rh_channel_volume(c.out, c.in, frames, in_ch, gains.data(), out_ch, c.stream), "rh_channel_volume");
-            return frames * out_ch;
-        }, [in_ch, out_ch](std::size_t n) { return n / in_ch * out_ch; });
+        auto rg = std::make_shared<Regroup>();
+        push([gains, in_ch, out_ch, rg](Ctx &c) {
+            return run_grouped(c, in_ch, *rg, [&](const float *in, std::size_t n) {
+                const std::size_t frames = n / in_ch;  // (a frame the stream ends in is dropped: `input.next()?`, channel_volume.rs:71-79)
+                check(rh_channel_volume(c.out, in, frames, in_ch, gains.data(), out_ch, c.stream), "rh_channel_volume");
+                return frames * out_ch;
+            });
+        }, [in_ch, out_ch](std::size_t n) { return (n / in_ch + 1) * out_ch; }).on_seek([rg](Nanos) { rg->n = 0; });
         ch_ = out_ch;
         return *this;
     }
@@ -874,16 +877,19 @@ public:
     GpuSource &convert_channels(std::uint16_t to) {  // ChannelCountConverter, channels.rs:57-85
         const std::uint16_t from = ch_;
         if (!to) throw std::invalid_argument("channels are NonZero in rodio");
-        push([from, to](Ctx &c) {
-            const std::size_t frames = c.n / from;
-            check(rh_channels_convert(c.out, c.in, frames, from, to, c.stream), "rh_channels_convert");
-            // A stream that ends inside a frame (reverb with a delay that is no whole number of frames: delay.rs:14 counts samples): the
-            // converter hands on the samples of the open frame as far as both layouts go -- positions below `from` are plain input.next()
-            // (channels.rs:57-67), a None ends the stream -- so min(rest, to) samples follow the whole frames.
-            const std::size_t rest = c.flush ? std::min<std::size_t>(c.n % from, to) : 0;
-            if (rest) check(rh_memcpy_d2d(c.out + frames * to, c.in + frames * from, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
-            return frames * to + rest;
-        }, [from, to](std::size_t n) { return n / from * to + to; }).spans(1);  // a bare converter is an iterator, not a Source: what wraps it sees no spans
+        auto rg = std::make_shared<Regroup>();
+        push([from, to, rg](Ctx &c) {
+            return run_grouped(c, from, *rg, [&](const float *in, std::size_t n) {
+                const std::size_t frames = n / from;
+                check(rh_channels_convert(c.out, in, frames, from, to, c.stream), "rh_channels_convert");
+                // A stream that ends inside a frame (reverb with a delay that is no whole number of frames: delay.rs:14 counts samples): the
+                // converter hands on the samples of the open frame as far as both layouts go -- positions below `from` are plain input.next()
+                // (channels.rs:57-67), a None ends the stream -- so min(rest, to) samples follow the whole frames.
+                const std::size_t rest = std::min<std::size_t>(n % from, to);
+                if (rest) check(rh_memcpy_d2d(c.out + frames * to, in + frames * from, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
+                return frames * to + rest;
+            });
+        }, [from, to](std::size_t n) { return (n / from + 1) * to + to; }).spans(1).on_seek([rg](Nanos) { rg->n = 0; });  // a bare converter is an iterator, not a Source: what wraps it sees no spans
         ch_ = to;
         return *this;
     }
@@ -895,11 +901,14 @@ public:
         auto h = std::make_shared<Handle<rh_resampler>>();
         check(rh_resampler_create(&h->p, from, to, ch), "rh_resampler_create");
         h->destroy = [](rh_resampler *r) { (void)rh_resampler_destroy(r); };
-        push([h, ch](Ctx &c) {
-            std::uint64_t m = 0;
-            check(rh_resampler_process(h->p, c.out, c.out_cap / ch, c.in, c.n / ch, c.flush ? 1 : 0, &m, c.stream), "rh_resampler_process");
-            return (std::size_t)m * ch;
-        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 2) * to / from + 2) * ch; }).spans(1);
+        auto rg = std::make_shared<Regroup>();
+        push([h, ch, rg](Ctx &c) {
+            return run_grouped(c, ch, *rg, [&](const float *in, std::size_t n) {
+                std::uint64_t m = 0;  // (a frame the stream ends in is not converted here: `uniform` is the adapter that knows what rodio's converter makes of it)
+                check(rh_resampler_process(h->p, c.out, c.out_cap / ch, in, n / ch, c.flush ? 1 : 0, &m, c.stream), "rh_resampler_process");
+                return (std::size_t)m * ch;
+            });
+        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 3) * to / from + 2) * ch; }).spans(1);
         rate_ = to;
         return *this;
     }
@@ -1337,6 +1346,33 @@ private:
     // EMITTED AT ONCE, from a copy of the state with the frame completed by zeros (what follows a sample in time does not reach back to
     // it) -- one sample out per sample in, so the format marks of the block stay where rodio reports them -- and KEPT, so that the real
     // state meets them again in front of the samples that complete the frame; on_format / on_seek drop them where rodio starts afresh.
+    // Adapters that regroup the flat stream into frames of `from` samples and keep no state between them (ChannelCountConverter,
+    // ChannelVolume, the bare SampleRateConverter): a block may stop inside a frame -- a spanned upstream whose spans do, adapters in
+    // front that emit an open frame's samples at once -- and rodio's iterators simply go on with the next sample.  Here the samples of the
+    // open frame wait for the next block; the end of the stream hands them to `fn` as they are.  fn(in, n) -> samples written to c.out.
+    struct Regroup {
+        detail::DeviceBuf part, tin;
+        std::size_t n = 0;
+    };
+    template <class F>
+    static std::size_t run_grouped(Ctx &c, std::uint16_t from, Regroup &rg, F fn) {
+        const std::size_t carried = rg.n, total = carried + c.n;
+        const float *in = c.in;
+        if (carried) {
+            rg.tin.reset(total + from);
+            check(rh_memcpy_d2d(rg.tin.get(), rg.part.get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
+            if (c.n) check(rh_memcpy_d2d(rg.tin.get() + carried, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
+            in = rg.tin.get();
+        }
+        const std::size_t rest = c.flush ? 0 : total % from;
+        const std::size_t k = fn(in, total - rest);
+        if (rest) {
+            rg.part.reset(from);
+            check(rh_memcpy_d2d(rg.part.get(), in + total - rest, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
+        }
+        rg.n = rest;
+        return k;
+    }
     struct FrameCarry {
         detail::DeviceBuf part, pad, st2, tin, tout;
         std::size_t n = 0;     // samples of an open frame, already emitted from a copy of the state and kept for the real one
