@@ -782,9 +782,19 @@ public:
     /// What rodio's adapters answer: the input's span length behind adapters that hand on one sample per sample (amplify.rs:78-80,
     /// blt.rs:153-155, ...), None behind Mix and the converters (mix.rs:92-94, uniform.rs:104-106).
     std::optional<std::size_t> current_span_len() const override {
+        int rule = 0;  // of the last adapter that does anything to the spans
         for (const Stage &st : stages_)
-            if (st.span_rule) return std::nullopt;  // (rule 2 -- the input's spans with another sample count -- is not mirrored: None, one continuous stream)
-        return format_at_cursor().span;
+            if (st.span_rule) rule = st.span_rule;
+        if (rule == 0) return format_at_cursor().span;
+        // Rule 1: None whatever comes in (Mix, the converters).  Rule 2: rodio's adapter answers with span arithmetic of its own -- Delay adds the
+        // silence it still owes (delay.rs:88-92), TakeDuration cuts at what it still admits (take.rs:158-178), ChannelVolume hands on the
+        // input's number although it changes the sample count (channel_volume.rs:97-99) -- which is not mirrored: over an upstream that
+        // reports None the answer is None and right; over one that reports spans a consumer that ASKS (a mixer, UniformSourceIterator) would
+        // convert differently from rodio, so it is told so instead of being told None.
+        if (rule == 2 && up_->current_span_len().has_value())
+            throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
+                                            "(put .uniform() in front of them, or hand the consumer the plain source)");
+        return std::nullopt;
     }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
