@@ -470,3 +470,49 @@ def _full_span_case(O, tmp_path, seed, exe):
 def test_random_chain_of_any_adapters_over_spans_that_cut_frames(O, tmp_path, seed):
     assert os.path.exists(FAKE), "run python rodio_amd/build.py"
     _full_span_case(O, tmp_path, seed, FAKE)
+
+
+# ------------------------------------------------------------------ ... and try_seek in the middle of a chain's stream ----
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_seek_through_a_chain(O, tmp_path, seed):
+    """try_seek through chains of seekable adapters whose state starts afresh behind a seek (amplify, filters, distortion, the limiter:
+    blt.rs:350-377, limit.rs:1139-1158) over a SamplesBuffer, after any number of samples (also in the middle of a frame), to any position:
+    what was pulled before the seek, then the chain applied afresh from the frame SamplesBuffer::try_seek lands on (buffer.rs:99-121: the float
+    position, the next multiple of the channel count), resumed at the consumer's channel (tests/test_host_mirror.py::test_gpu_source_try_seek)."""
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    rng = np.random.default_rng(22000 + seed)
+    ch, rate, n = int(rng.choice([1, 2, 2, 3, 6])), int(rng.choice(RATES)), int(rng.integers(100, 20000))
+    x = M.rnd(22000 + seed, ch * n, 0.5)
+    ops = []
+    for _ in range(int(rng.integers(1, 4))):
+        k = str(rng.choice(["amplify", "filter", "distortion", "limit"]))
+        if k == "amplify":
+            ops.append(f"amplify:{rng.choice([0.5, 0.8, 1.25])}")
+        elif k == "filter":
+            ops.append(f"{rng.choice(['low_pass', 'high_pass'])}:{rng.choice([800, 1000, 3000])}")
+        elif k == "distortion":
+            ops.append(f"distortion:{rng.choice([2.0, 4.0])}:{rng.choice([0.3, 0.6])}")
+        elif "limit" not in ops:
+            ops.append("limit")
+    ops = ops or ["amplify:0.5"]
+    block = int(rng.choice([64, 777, 4096, 16384]))
+    pulled, seek_frame = int(rng.integers(0, ch * n)), int(rng.integers(0, n))
+    ns = seek_frame * 1_000_000_000 // rate
+    x.tofile(tmp_path / "src_0.f32")
+    env = dict(os.environ, RH_TEST_SEEK_AFTER=str(pulled), RH_TEST_SEEK_NS=str(ns), RH_TEST_SOURCE="buffer")
+    r = subprocess.run([FAKE, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300, env=env)
+    what = (seed, (n, ch, rate), ops, block, pulled, seek_frame)
+    assert r.returncode == 0, (what, r.stderr)
+    ok, k = (int(v) for v in (tmp_path / "seek.txt").read_text().split())
+    assert ok == 1, what
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    secs = np.float32(ns // 1_000_000_000) + np.float32(ns % 1_000_000_000) / np.float32(1e9)  # math.rs:118-122
+    npos = min(int(np.float32(np.float32(secs * np.float32(rate)) * np.float32(ch))), n * ch)
+    frame = (npos + ch - 1) // ch
+    before = _oracle_full(O, O.TestSource(x, ch, rate), ops).collect()[:k]
+    after = _oracle_full(O, O.TestSource(x[frame * ch:], ch, rate), ops).collect()[k % ch:]
+    ref = np.concatenate([before, after])
+    assert len(got) == len(ref), (what, len(got), len(ref), k, frame)
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any(op.startswith("distortion") for op in ops) else 1)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
