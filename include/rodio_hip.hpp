@@ -798,6 +798,10 @@ public:
     }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
+    /// The chain's stream can end inside a frame although its upstream keeps `Source`'s contract: reverb and delay count their
+    /// silence in SAMPLES (delay.rs:14: every second stereo reverb ends inside a frame), and `uniform` over spans that cut frames hands
+    /// on what rodio's converters make of the cut.  A consumer that works on whole frames (GpuMixer's fused streams) asks.
+    bool may_end_inside_a_frame() const { return may_cut_; }
     /// `try_seek` through the chain, adapter by adapter as rodio does it: an adapter that cannot seek (reverb = Mix,
     /// mix.rs:116-120) fails the call before anything moved; otherwise the upstream seeks, what was pulled and processed
     /// ahead is dropped, and every adapter does to its state what its `try_seek` does -- filters and the limiter start
@@ -850,6 +854,7 @@ public:
     GpuSource &high_pass_with_q(std::uint32_t freq, float q) { return blt(1, freq, q); }
     GpuSource &reverb(Nanos duration, float amplitude) {  // source/mod.rs:628-634
         const std::uint64_t d = rh_delay_samples((std::uint64_t)duration.count(), rate_, ch_);
+        may_cut_ = may_cut_ || d % ch_ != 0;
         auto h = std::make_shared<Handle<rh_echo>>();
         check(rh_echo_create(&h->p, d, amplitude), "rh_echo_create");
         h->destroy = [](rh_echo *e) { (void)rh_echo_destroy(e); };
@@ -877,6 +882,7 @@ public:
             });
         }, [in_ch, out_ch](std::size_t n) { return (n / in_ch + 1) * out_ch; }).on_seek([rg](Nanos) { rg->n = 0; });
         ch_ = out_ch;
+        may_cut_ = false;  // (an open last frame is dropped: `input.next()?`)
         return *this;
     }
     GpuSource &spatial(const float emitter[3], const float left_ear[3], const float right_ear[3]) {  // spatial.rs:19-24,48-69
@@ -941,6 +947,7 @@ public:
         // stream, through the same planner, which also knows what rodio's converters make of a stream that ends inside a frame)
         const bool one_span = rule != 0;
         if (!one_span) span_aware_ = true;
+        may_cut_ = may_cut_ || (!one_span && ch_ > 1 && up_->current_span_len().has_value());  // (a span that cuts a frame leaves a run of samples that need not fill an output frame)
         auto started = std::make_shared<bool>(false);
         auto plan = std::make_shared<detail::UniformPlanner>(channels, sample_rate);
         auto win = std::make_shared<detail::DeviceBuf>();
@@ -1083,6 +1090,7 @@ public:
     /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
     GpuSource &delay(Nanos duration) {
         const std::uint64_t d = rh_delay_samples((std::uint64_t)duration.count(), rate_, ch_);
+        may_cut_ = may_cut_ || d % ch_ != 0;
         const std::uint16_t ch = ch_;
         auto first = std::make_shared<bool>(true);
         // The silence counts SAMPLES (delay.rs:14): one that is no whole number of frames shifts the stream inside its frames.  The adapters
@@ -1522,6 +1530,7 @@ private:
     int filter_mode_ = 0;  // 0: by the filter contract, per filter; 1: reference order throughout; 2: time-parallel throughout
     detail::DeviceBuf a_, b_;
     bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
+    bool may_cut_ = false;       // an adapter of the chain can make the stream end inside a frame (may_end_inside_a_frame())
 };
 
 // ---------------------------------------------------------------- GpuMixer: the fused mixer path ----
@@ -1619,6 +1628,11 @@ public:
         // A source whose spans can end inside a frame (uniform.rs:56: 32768 is no multiple of 3, 5, 6, 7 channels) may end its converted
         // stream inside an output frame; the fused kernel filters whole frames, so such a source takes its filter along in a chain of its
         // own, which filters exactly the samples rodio's BltFilter sees (blt.rs:431-451), and enters the mix unfiltered.
+        if (GpuSource *gs = dynamic_cast<GpuSource *>(src.get()); gs && completes_with_uniform(*gs, gain, filter)) {  // (see add(chain): the same, whoever owns the chain)
+            src.release();
+            add(std::unique_ptr<GpuSource>(gs), gain, filter);
+            return;
+        }
         const bool may_cut = filter.kind >= 0 && src->current_span_len().has_value() && (32768u % ch) != 0;
         if (filter.kind >= 0 && ((opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut)) {
             // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
@@ -1639,6 +1653,13 @@ public:
         if (running()) late_join(std::move(item));  // mixer.rs:175-183: admitted at the next frame
         else pending_.push_back(std::move(item));    // starts with the stream (or resumes an ended one)
     }
+private:
+    // A chain whose stream can end inside a frame and is not yet what Mixer::add would make of it (see add(chain))
+    bool completes_with_uniform(const GpuSource &gs, float gain, const Filter &filter) const {
+        return !wide() && !gs.started() && gs.may_end_inside_a_frame() && !(gs.channels() == out_ch_ && gs.sample_rate() == rate_ && gain == 1.0f && filter.kind < 0);
+    }
+
+public:
     /// A GpuSource chain handed to the mixer by value, as rodio's adapters are (`mixer.add(src.reverb(..).limit(..))`, amplify.rs:19-22,
     /// mixer.rs:58-72): its blocks stay in device memory and the mixer takes them device-to-device -- the chain's output never
     /// crosses to the host and back.  (A chain that is not stereo at a rate the fused converter takes, or one that has already
@@ -1647,6 +1668,18 @@ public:
     void add(std::unique_ptr<GpuSource> chain, float gain, Filter filter) {
         if (!chain) throw std::invalid_argument("source");
         GpuSource *const gs = chain.get();
+        if (completes_with_uniform(*gs, gain, filter)) {
+            // The fused streams convert whole frames; what rodio's UniformSourceIterator makes of a stream that ends inside one (the cut
+            // tail of sample_rate.rs:174-200 / channels.rs:57-85) is what `uniform` makes of it: the chain is completed to
+            // `chain.amplify(gain) -> UniformSourceIterator(channels, rate) [-> filter]` -- Mixer::add's own wrapping, mixer.rs:58-66 -- and
+            // enters the mix as it is, sample for sample (a stream at the mixer's rate is tracked to its last sample: Gen::track).
+            if (gain != 1.0f) chain->amplify(gain);
+            chain->uniform(out_ch_, rate_);
+            if (filter.kind == 0) chain->low_pass_with_q(filter.freq, filter.q);
+            else if (filter.kind == 1) chain->high_pass_with_q(filter.freq, filter.q);
+            add(std::move(chain), 1.0f, Filter::none());
+            return;
+        }
         if (wide() && !gs->started()) {  // the chain goes on as the source's chain of a wide mixer: amplify -> uniform(channels, rate) -> filter behind what it has
             Src item;
             item.ch = gs->channels();

@@ -437,6 +437,7 @@ unsafe impl<T> Sync for Handle<T> {}
 pub struct GpuSource<I: Source> {
     up: I, block_frames: usize, ch: u16, rate: u32, in_ch: u16, in_rate: u32,
     stages: Vec<Stage>, reader: SpanReader, pieces: Vec<Piece>, span_aware: bool, scan_kernels: bool,
+    may_cut: bool,     // an adapter of the chain can make the stream end inside a frame (may_end_inside_a_frame)
     filter_mode: u8,   // 0: by the filter contract, per filter (rh_filter_scan_ok); 1: reference order throughout; 2: time-parallel throughout
     a: DeviceBuf, b: DeviceBuf, pump: Pump,
 }
@@ -446,11 +447,15 @@ impl<I: Source> GpuSource<I> {
     pub fn new(upstream: I, block_frames: usize) -> Self {
         let (ch, rate) = (upstream.channels().get(), upstream.sample_rate().get());
         GpuSource { up: upstream, block_frames: block_frames.max(1), ch, rate, in_ch: ch, in_rate: rate, stages: Vec::new(), reader: SpanReader::new(),
-                    pieces: Vec::new(), span_aware: false, scan_kernels: false, filter_mode: 0, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new() }
+                    pieces: Vec::new(), span_aware: false, scan_kernels: false, may_cut: false, filter_mode: 0, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new() }
     }
     pub fn inner(&self) -> &I { &self.up }
     pub fn inner_mut(&mut self) -> &mut I { &mut self.up }
     pub fn into_inner(self) -> I where I: Clone { self.up.clone() }
+    /// The chain's stream can end inside a frame although its upstream keeps `Source`'s contract: reverb and delay count their silence in
+    /// SAMPLES (delay.rs:14), `uniform` over spans that cut frames hands on what rodio's converters make of the cut.  (The C++ twin's GpuMixer
+    /// completes such a chain to `amplify -> UniformSourceIterator -> filter` before it enters a fused stream: not ported, INTEGRATION.md.)
+    pub fn may_end_inside_a_frame(&self) -> bool { self.may_cut }
     fn push(&mut self, run: impl FnMut(&mut Ctx) -> usize + Send + 'static, bound: impl Fn(usize, usize) -> usize + Send + 'static, span_rule: u8) -> &mut Stage {
         self.stages.push(Stage { run: Box::new(run), bound: Box::new(bound), seekable: true, on_seek: None, span_rule });
         self.stages.last_mut().unwrap()
@@ -513,6 +518,7 @@ impl<I: Source> GpuSource<I> {
     }
     pub fn reverb(mut self, duration: Duration, amplitude: f32) -> Self {         // source/mod.rs:628-634
         let d = unsafe { rh_delay_samples(duration.as_nanos() as u64, self.rate, self.ch as u32) };
+        self.may_cut = self.may_cut || d % self.ch as u64 != 0;
         let mut e: *mut RhEcho = ptr::null_mut();
         ck(unsafe { rh_echo_create(&mut e, d, amplitude) }, "rh_echo_create");
         let h = Handle { p: e, destroy: rh_echo_destroy };
@@ -584,6 +590,7 @@ impl<I: Source> GpuSource<I> {
     pub fn uniform(mut self, channels: ChannelCount, sample_rate: SampleRate) -> Self {
         let rule = self.stages.iter().rev().map(|s| s.span_rule).find(|&r| r != 0).unwrap_or(0);
         assert!(!(rule == 2 && self.up.current_span_len().is_some()), "GpuSource::uniform behind take_duration / delay / channel_volume on a source that reports spans");
+        self.may_cut = self.may_cut || (rule == 0 && self.ch > 1 && self.up.current_span_len().is_some());
         if rule != 0 {                                                              // continuous from here on
             let from_ch = self.ch;
             let mut s = self.convert_sample_rate(sample_rate);
@@ -702,6 +709,7 @@ impl<I: Source> GpuSource<I> {
     /// `delay(d)` (delay.rs:8-16,68-75): `rh_delay_samples()` zeros in front of the stream.  Not seekable here.
     pub fn delay(mut self, duration: Duration) -> Self {
         let d = unsafe { rh_delay_samples(duration.as_nanos() as u64, self.rate, self.ch as u32) };
+        self.may_cut = self.may_cut || d % self.ch as u64 != 0;
         let mut first = true;
         let stage = self.push(move |c| {
             if first {

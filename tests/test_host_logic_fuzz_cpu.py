@@ -516,3 +516,46 @@ def test_random_seek_through_a_chain(O, tmp_path, seed):
     if len(ref):
         tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any(op.startswith("distortion") for op in ops) else 1)
         assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+# ------------------------------------------------------------------ ... and chains of any adapters handed to a mixer ----
+def _mixer_chains_case(O, tmp_path, seed, exe):
+    """`mixer.add(source.reverb(..).limit())` and the like: chains of the whole vocabulary (without dither; channel_volume's list of gains collides
+    with the spec file's separator) over plain and spanned sources, handed over on the device or pulled through the host, into mixers of 1, 2
+    and 6 channels -- against rodio's Mixer over UniformSourceIterator(chain.amplify(gain)).  Chains whose stream ends inside a frame (every
+    second stereo reverb) included: GpuMixer completes them with their own `uniform`.  Combinations the mirror does not take are refused loudly."""
+    rng = np.random.default_rng(33000 + seed)
+    S, mixer_ch, to_rate = int(rng.integers(1, 5)), int(rng.choice([1, 2, 2, 6])), int(rng.choice([22050, 44100, 48000]))
+    block, on_device = int(rng.choice([777, 4096, 20000])), bool(rng.integers(0, 2))
+    kind = str(rng.choice(["test", "buffer", "mixed", "spans:2304", "spans:1000"]))
+    lines, adds = [], []
+    for i in range(S):
+        gain = float(np.float32(rng.choice([0.5, 0.8, 1.0])))
+        ch0, rate0 = int(rng.choice([1, 2, 2, 6])), int(rng.choice(RATES))
+        x = M.rnd(33000 + 1000 * seed + 10 * i, int(rng.integers(1, 9000)) * ch0, 0.2)
+        x.tofile(tmp_path / f"src_{i}.f32")
+        ops = [o for o in _full_ops(rng, ch0, int(rng.integers(1, 3)), False) if not o.startswith("channel_volume")] if rng.random() < 0.6 else []
+        lines.append(f"{ch0} {rate0} {gain} -1 0 {','.join(ops) if ops else '-'}\n")
+        adds.append((x, ch0, rate0, i, ops, gain))
+    (tmp_path / "spec.txt").write_text("".join(lines))
+    r = subprocess.run([exe, "chainmix", str(tmp_path), str(S), str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S, mixer_ch, to_rate, block, on_device, kind, lines)
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    m = O.Mixer(mixer_ch, to_rate)
+    for x, ch0, rate0, i, ops, gain in adds:
+        m.add(O.UniformSourceIterator(_oracle_full(O, M._span_source(O, kind, x, ch0, rate0, i), ops).amplify(gain), mixer_ch, to_rate))
+    ref = m.collect()
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any("agc" in l or "distortion" in l for l in lines) else 1)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_chains_of_any_adapters_into_a_mixer(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _mixer_chains_case(O, tmp_path, seed, FAKE)
