@@ -124,3 +124,18 @@ def test_refusals_across_a_format_change(tmp_path, fake):
 @pytest.mark.parametrize("mixer_ch,block", [(2, 4096), (6, 20000)])
 def test_mixer_takes_sources_that_change_their_format(O, tmp_path, fake, mixer_ch, block):
     M.test_gpu_mixer_takes_sources_that_change_their_format(O, tmp_path, mixer_ch, block)
+
+
+def test_every_case_of_the_gpu_suite_of_the_host_mirror_on_the_stand_in_device():
+    """tests/test_host_mirror.py's `-m gpu` cases -- all of them, not the selection above -- with the driver that is linked against
+    tests/cpp/fake_device.cpp (RH_HOST_MIRROR_EXE): the host logic they exercise runs here without a GPU.  The four cases that need
+    rh_dither (no host logic of its own: the stand-in does not have it) are left to the GPU."""
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    import sys
+
+    dither = [f"tests/test_host_mirror.py::test_gpu_source_chain_pull_is_bit_exact[{b}-{c}]" for b in (777, 16384) for c in (8, 9)]
+    cmd = [sys.executable, "-m", "pytest", "tests/test_host_mirror.py", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"] + [a for d in dither for a in ("--deselect", d)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1200, env=dict(os.environ, RH_HOST_MIRROR_EXE=FAKE))
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, r.stdout[-3000:]
+    assert int(tail.split(" passed")[0].split()[-1]) >= 260, tail
