@@ -1176,7 +1176,10 @@ protected:
             flush = reader_.ended();
         } else {
             n = up_->read(s.in.get(), want);
-            n -= n % cur_in_ch_;  // sources end on frame boundaries (source/mod.rs:169-178)
+            // sources end on frame boundaries (source/mod.rs:169-178).  One that reports no spans and ends inside a frame all the same is
+            // refused: rodio would play the cut frame's samples, this path converts whole frames only (a source that REPORTS its spans may
+            // end anywhere: the branch above)
+            if (n % cur_in_ch_) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
             flush = n < want;
             runs.push_back(Run{0, n, cur_in_ch_, cur_in_rate_, 0, 0});
         }
@@ -1633,7 +1636,9 @@ public:
             add(std::unique_ptr<GpuSource>(gs), gain, filter);
             return;
         }
-        const bool may_cut = filter.kind >= 0 && src->current_span_len().has_value() && (32768u % ch) != 0;
+        // (... and one whose span at hand does not hold whole frames -- a SamplesBuffer of an odd number of stereo samples, packets of 37)
+        const std::optional<std::size_t> span_now = src->current_span_len();
+        const bool may_cut = filter.kind >= 0 && span_now.has_value() && ((32768u % ch) != 0 || (*span_now % ch) != 0);
         if (filter.kind >= 0 && ((opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut)) {
             // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
             auto chain = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
@@ -2240,7 +2245,7 @@ private:
             if (x.ended) continue;
             const std::uint64_t have = x.have_s / 2, want = g.target > have ? g.target - have : 0;
             const std::uint64_t in_frames = want * rate / rate_ + 8;
-            row_cap[i] = x.plan.held_samples() + (std::size_t)in_frames * ch;
+            row_cap[i] = x.plan.held_samples() + (std::size_t)(in_frames + 1) * ch;  // (+ a frame: read_piece brings a cut frame's samples along with the last whole ones)
             total += (row_cap[i] + 3) & ~std::size_t(3);
         }
         stage.reset(total ? total : 4);
@@ -2289,7 +2294,10 @@ private:
                 std::uint64_t need = 0, most = 0;
                 const std::uint64_t slack = detail::UniformPlanner::close_slack_frames(rate, rate_);  // what the span's end may add
                 x.plan.budget(rate, x.reader.opens_next(), g.target - now, g.crow > now + slack ? g.crow - now - slack : 0, need, most);
-                const std::uint64_t n = std::min<std::uint64_t>(std::min(need, most), (row_cap[i] - fill) / ch);
+                // (whole frames that fit the row AND leave room for the up to ch - 1 samples of a frame the span's end cuts: spans of 37 samples
+                // end inside a frame every time, and a row that was filled to its last frame took the cut samples into the next row)
+                const std::uint64_t room = row_cap[i] - fill >= ch ? (row_cap[i] - fill - (ch - 1)) / ch : 0;
+                const std::uint64_t n = std::min<std::uint64_t>(std::min(need, most), room);
                 if (!n) break;
                 detail::Piece pc;
                 const bool produced = x.reader.read_piece(row + fill, (std::size_t)n, pc);  // straight into the staging block
@@ -2410,7 +2418,9 @@ private:
                 const std::size_t want = opt_.block_frames * ch;
                 std::size_t got = x.up->read(row + have, want);  // straight into the staging block
                 x.ended = got < want;
-                got -= got % ch;  // sources end on frame boundaries (source/mod.rs:169-178)
+                // sources end on frame boundaries (source/mod.rs:169-178); one that reports no spans and ends inside a frame all the same is
+                // refused rather than shortened (rodio would convert the cut frame's samples; span-reporting sources take the staged path, which does)
+                if (got % ch) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
                 have += got;
                 x.total_s += got / ch * 2;
             }

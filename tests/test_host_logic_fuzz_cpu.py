@@ -559,3 +559,55 @@ def _mixer_chains_case(O, tmp_path, seed, exe):
 def test_random_chains_of_any_adapters_into_a_mixer(O, tmp_path, seed):
     assert os.path.exists(FAKE), "run python rodio_amd/build.py"
     _mixer_chains_case(O, tmp_path, seed, FAKE)
+
+
+# ------------------------------------------------------------------ ... and plain sources of any layout and span length into the fused stereo mixer ----
+def _mixer_plain_case(O, tmp_path, seed, exe):
+    """`mixer.add(source)` for one to eight plain sources of 1, 2, 3 or 6 channels at any rate into the stereo mixer, with and without the
+    mixer's own filter: the fused path and its staging in front of it (one row per source, span by span).  The sources report no spans, one
+    span (SamplesBuffer) or packets of 37, 1000, 2304, 32768 samples -- packets of 37 cut a stereo frame every time, and a fifth of the spanned
+    sources END inside a frame.  Found here: a staging row filled to its last whole frame took a cut frame's samples into the next source's
+    row (or past the block: seed 275, heap corruption)."""
+    rng = np.random.default_rng(11000 + seed)
+    S, to_rate = int(rng.integers(1, 9)), int(rng.choice([22050, 44100, 48000]))
+    filt, freq = (int(rng.integers(0, 2)), int(rng.choice([200, 1000, 3000]))) if rng.random() < 0.5 else (-1, 0)
+    block, lane = int(rng.choice([777, 4096, 16384, 30000])), int(rng.choice([3, 4, 8]))
+    kind = str(rng.choice(["test", "buffer", "mixed", "spans:2304", "spans:1000", "spans:37", "spans:32768"]))
+    kinds = [kind if kind != "mixed" else ["test", "buffer", "spans:4096"][i % 3] for i in range(S)]
+    spec, xs = [], []
+    for i in range(S):
+        ch, rate, g = int(rng.choice([1, 2, 2, 2, 3, 6])), int(rng.choice(RATES)), float(np.float32(rng.choice([0.5, 0.8, 1.0, 1.2])))
+        n = int(rng.integers(0, 20000)) * ch
+        if kinds[i] != "test" and rng.random() < 0.2:  # (a source that reports no spans ends on a frame boundary: source/mod.rs:169-178)
+            n += int(rng.integers(0, ch))
+        spec.append((ch, rate, g, n))
+        xs.append(M.rnd(11000 + 100 * seed + i, n, 0.15))
+        xs[-1].tofile(tmp_path / f"src_{i}.f32")
+    (tmp_path / "spec.txt").write_text("".join(f"{c} {r} {g}\n" for c, r, g, _ in spec))
+    r = subprocess.run([exe, "mixany", str(tmp_path), str(S), str(to_rate), str(filt), str(freq), str(block), str(lane)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S, to_rate, filt, freq, block, lane, kind, spec)
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    ref = M._mix_oracle(O, spec, xs, kinds, 2, to_rate, filt, freq)
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref))))
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+PLAIN_SEEDS = list(range(40)) + [45, 83, 275, 284]
+
+
+@pytest.mark.parametrize("seed", PLAIN_SEEDS)
+def test_random_plain_sources_into_the_stereo_mixer(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _mixer_plain_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", PLAIN_SEEDS[::4] + [275])
+def test_gpu_random_plain_sources_into_the_stereo_mixer(O, tmp_path, seed):
+    _mixer_plain_case(O, tmp_path, seed, M.EXE)
