@@ -1636,17 +1636,21 @@ public:
             add(std::unique_ptr<GpuSource>(gs), gain, filter);
             return;
         }
-        // (... and one whose span at hand does not hold whole frames -- a SamplesBuffer of an odd number of stereo samples, packets of 37)
+        // (... and one whose span at hand does not hold whole frames -- a SamplesBuffer of an odd number of stereo samples, packets of 37.)
+        // A MONO mixer forms its mix in stereo and takes channel 0 of it, which is rodio's UniformSourceIterator(src, 1, rate) per source as
+        // long as every source's stereo stream keeps to whole frames; a span that ends inside a frame gives ONE sample either way
+        // (channels.rs:57-67) and what follows would sit in the wrong channel -- such a source is converted to mono by a chain of its own.
         const std::optional<std::size_t> span_now = src->current_span_len();
-        const bool may_cut = filter.kind >= 0 && span_now.has_value() && ((32768u % ch) != 0 || (*span_now % ch) != 0);
-        if (filter.kind >= 0 && ((opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut)) {
+        const bool cuts = span_now.has_value() && ((32768u % ch) != 0 || (*span_now % ch) != 0);
+        const bool may_cut = cuts && (filter.kind >= 0 || out_ch_ == 1);
+        if ((filter.kind >= 0 && opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut) {
             // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
             auto chain = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
-            if (opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) chain->exact_filters(true);
+            if (filter.kind >= 0 && opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) chain->exact_filters(true);
             if (gain != 1.0f) chain->amplify(gain);
-            chain->uniform(2, rate_);
+            chain->uniform(out_ch_, rate_);
             if (filter.kind == 0) chain->low_pass_with_q(filter.freq, filter.q);
-            else chain->high_pass_with_q(filter.freq, filter.q);
+            else if (filter.kind == 1) chain->high_pass_with_q(filter.freq, filter.q);
             add(std::move(chain), 1.0f, Filter::none());
             return;
         }
@@ -1884,6 +1888,7 @@ private:
         detail::UniformPlanner plan;
         std::uint64_t have_s = 0, off_s = 0;  // converted SAMPLES not yet mixed: `have_s` of them from sample `off_s` of the source's device row
         std::uint64_t total_s = 0;            // samples of the source's stream in the mixer's layout so far (where the generation tracks them: Gen::track)
+        bool odd_close = false;               // ... a span has closed on an odd count of them (a mono mixer cannot go on behind that: pull_block_staged)
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
@@ -2304,6 +2309,10 @@ private:
                 if (produced) {
                     fill += pc.n;
                     x.plan.add(pc, segs);
+                    if (out_ch_ == 1) {  // (see add(): the stereo stream of a mono mixer's source keeps to whole frames, or ends)
+                        if (x.odd_close && pc.n) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a mono mixer over a source whose span ended inside a frame after spans of whole frames (source/mod.rs:196-200)");
+                        if (pc.closes) x.odd_close = ((x.total_s + x.plan.out_samples()) & 1) != 0;
+                    }
                 }
                 if (x.reader.ended()) {
                     x.ended = true;

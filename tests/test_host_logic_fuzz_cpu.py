@@ -611,3 +611,61 @@ def test_random_plain_sources_into_the_stereo_mixer(O, tmp_path, seed):
 @pytest.mark.parametrize("seed", PLAIN_SEEDS[::4] + [275])
 def test_gpu_random_plain_sources_into_the_stereo_mixer(O, tmp_path, seed):
     _mixer_plain_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and sources whose spans cut frames into mixers of 1, 2, 3, 6 channels ----
+def _mixer_cut_case(O, tmp_path, seed, exe):
+    """`_mixer_case` where it hurts: sources of 1, 2, 3, 5, 6 channels as SamplesBuffers or in packets of 5, 37, 1000, 2304 samples (spans that end
+    inside a frame all the time), three in ten ending inside a frame, with and without short adapter chains and per-source filters, into mixers
+    of 1, 2, 3 and 6 channels.  Found here: a MONO mixer formed its mix in stereo and took channel 0 -- behind a span that gave the stereo
+    stream an odd number of samples that was the wrong channel (a 7-channel SamplesBuffer; stereo packets of 37)."""
+    rng = np.random.default_rng(77000 + seed)
+    S, mixer_ch, to_rate = int(rng.integers(1, 6)), int(rng.choice([1, 2, 2, 6, 3])), int(rng.choice([22050, 44100, 48000]))
+    block, on_device = int(rng.choice([777, 4096, 20000])), bool(rng.integers(0, 2))
+    kind = str(rng.choice(["buffer", "mixed", "spans:2304", "spans:1000", "spans:37", "spans:5"]))
+    kinds = [kind if kind != "mixed" else ["test", "buffer", "spans:4096"][i % 3] for i in range(S)]
+    lines, adds = [], []
+    for i in range(S):
+        gain = float(np.float32(rng.choice([0.5, 0.8, 1.0, 1.2])))
+        ch0, rate0 = int(rng.choice([1, 2, 2, 6, 3, 5])), int(rng.choice(RATES))
+        n = int(rng.integers(1, 9000)) * ch0
+        if kinds[i] != "test" and rng.random() < 0.3:
+            n += int(rng.integers(0, ch0))
+        x = M.rnd(77000 + 1000 * seed + 10 * i, n, 0.2)
+        x.tofile(tmp_path / f"src_{i}.f32")
+        ops = _ops_any_format(rng, int(rng.integers(1, 3)), [ch0]) if rng.random() < 0.4 else []
+        fk, ff = (int(rng.integers(0, 2)), int(rng.choice([300, 1000, 3000]))) if (mixer_ch <= 2 and rng.random() < 0.4) else (-1, 0)
+        lines.append(f"{ch0} {rate0} {gain} {fk} {ff} {','.join(ops) if ops else '-'}\n")
+        adds.append((x, ch0, rate0, i, ops, gain, fk, ff))
+    (tmp_path / "spec.txt").write_text("".join(lines))
+    r = subprocess.run([exe, "chainmix", str(tmp_path), str(S), str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S, mixer_ch, to_rate, block, on_device, kind, lines)
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    m = O.Mixer(mixer_ch, to_rate)
+    for x, ch0, rate0, i, ops, gain, fk, ff in adds:
+        u = O.UniformSourceIterator(_oracle_chain(O, M._span_source(O, kind, x, ch0, rate0, i), ops).amplify(gain), mixer_ch, to_rate)
+        m.add(u.low_pass(ff) if fk == 0 else u.high_pass(ff) if fk == 1 else u)
+    ref = m.collect()
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any("agc" in l for l in lines) else 1)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+CUT_SEEDS = list(range(40)) + [71, 110, 128, 130, 157, 171, 183]
+
+
+@pytest.mark.parametrize("seed", CUT_SEEDS)
+def test_random_sources_whose_spans_cut_frames_into_a_mixer(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _mixer_cut_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", CUT_SEEDS[::4] + [130])
+def test_gpu_random_sources_whose_spans_cut_frames_into_a_mixer(O, tmp_path, seed):
+    _mixer_cut_case(O, tmp_path, seed, M.EXE)
