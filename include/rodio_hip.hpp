@@ -1624,7 +1624,7 @@ public:
             item.ch = ch;
             item.filt = filter;
             make_wide(item);
-            if (running()) late_join(std::move(item));
+            if (joins_a_running_mix()) late_join(std::move(item));
             else pending_.push_back(std::move(item));
             return;
         }
@@ -1659,7 +1659,7 @@ public:
         item.gain = gain;
         item.ch = ch;
         item.filt = filter;
-        if (running()) late_join(std::move(item));  // mixer.rs:175-183: admitted at the next frame
+        if (joins_a_running_mix()) late_join(std::move(item));  // mixer.rs:175-183: admitted at the next frame
         else pending_.push_back(std::move(item));    // starts with the stream (or resumes an ended one)
     }
 private:
@@ -1697,7 +1697,7 @@ public:
             item.gain = gain;
             item.filt = filter;
             make_wide(item);
-            if (running()) late_join(std::move(item));
+            if (joins_a_running_mix()) late_join(std::move(item));
             else pending_.push_back(std::move(item));
             return;
         }
@@ -1716,7 +1716,7 @@ public:
         item.ch = 2;
         item.filt = filter;
         device_chains_ = true;
-        if (running()) late_join(std::move(item));
+        if (joins_a_running_mix()) late_join(std::move(item));
         else pending_.push_back(std::move(item));
     }
     // MixerSource::next advances its channel position on every call, also on the ones that return None (mixer.rs:120-136),
@@ -2516,6 +2516,20 @@ private:
     /// covers them, added onto their device copies at its offset (rh_mix_sum: old mix first, the newcomer last = insertion
     /// order, bit for bit without a filter) and the blocks travel to the host again.  From the next block on it is one more
     /// generation.
+    // Mixer::add on a running mixer admits the source at the next frame of the mix (late_join) -- unless the mix is about to END inside a
+    // frame (its last block is cut to what rodio's sources cover) and the consumer is already in that frame: rodio's mixer then answers None
+    // for the rest of it (no source is left, and a pending one only starts on a frame boundary: mixer.rs:120-136,175-183) and goes on
+    // with the new source afterwards.  That is what an ENDED mixer does with a pending source (can_resume()), so the source waits for that.
+    bool joins_a_running_mix() {
+        if (!running()) return false;
+        const int ci = cur_index();
+        const bool flight = other_in_flight();
+        const int li = flight ? ci ^ 1 : ci;
+        const Slot &ls = flight ? other() : cur();
+        if (!ls.last || ls.n == (std::size_t)slot_frames_[li] * out_ch_) return true;
+        const std::uint64_t consumed = slot_base_[ci] * out_ch_ + position();
+        return (consumed + out_ch_ - 1) / out_ch_ < slot_base_[li] + slot_frames_[li];
+    }
     void late_join(Src item) {
         const int ci = cur_index();
         const std::uint64_t consumed = slot_base_[ci] * out_ch_ + position();  // samples already handed out
@@ -2534,6 +2548,13 @@ private:
         Gen &g = *gens_.back();
         g.join = J;
         const std::uint64_t need = sched_end > J ? sched_end - J : 0;
+        if (need + 64 > out_cap_frames_) {
+            // the newcomer catches up with everything that is scheduled -- up to two blocks, and a block of a generation that ran behind a
+            // full queue can hold nearly two of the newcomer's own -- and its last block of that may reach a block beyond: the queues grow
+            out_cap_frames_ = need + 64;
+            for (auto &other : gens_)
+                for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * qch_, (other->head + other->fill) * qch_);
+        }
         while (g.fill < need && !g.done) {
             run_block(g, cur());
             check(rh_stream_synchronize(stream_), "rh_stream_synchronize");  // the staging blocks alternate: never more than one copy in flight here
@@ -2563,7 +2584,15 @@ private:
         // a mixer that was about to end goes on: the block that carried the end mark loses it, and if nothing was in flight the
         // next block is requested now
         Slot &last_slot = flight ? other() : cur();
-        if (last_slot.last && !(g.done && g.fill == 0)) {
+        const bool plays_on = !(g.done && g.fill == 0);
+        if (last_slot.last && last_slot.n < (std::size_t)slot_frames_[li] * out_ch_) {
+            // ... and a mix that was about to end INSIDE its last frame (the block was cut to the samples rodio's sources cover; the device copy
+            // holds the whole frame, +0.0 where nothing played) has that frame completed by a newcomer that plays beyond it, or that ends in it
+            const std::size_t whole = (std::size_t)slot_frames_[li] * out_ch_;
+            if (plays_on) last_slot.n = whole;
+            else if (J + g.emitted == sched_end) last_slot.n = std::max(last_slot.n, whole - (g.last_valid ? qch_ - g.last_valid : 0));
+        }
+        if (last_slot.last && plays_on) {
             last_slot.last = false;
             if (!flight) submit(other());
         }

@@ -669,3 +669,110 @@ def test_random_sources_whose_spans_cut_frames_into_a_mixer(O, tmp_path, seed):
 @pytest.mark.parametrize("seed", CUT_SEEDS[::4] + [130])
 def test_gpu_random_sources_whose_spans_cut_frames_into_a_mixer(O, tmp_path, seed):
     _mixer_cut_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and late joins around mixes that end inside a frame ----
+def _late_run(O, tmp_path, exe, spec, xs, kind, S0, mixer_ch, to_rate, block, pull_first):
+    """`S0` sources, `pull_first` samples taken one by one, the rest of the sources added, everything else taken (the consumer keeps asking
+    through up to 16 Nones, then until the first None): what rodio's mixer returns, what the mirror returns, and the Nones in between."""
+    for i, x in enumerate(xs):
+        x.tofile(tmp_path / f"src_{i}.f32")
+    (tmp_path / "spec.txt").write_text("".join(f"{c} {r} {g}\n" for c, r, g in spec))
+    chain = lambda i: O.UniformSourceIterator(M._span_source(O, kind, xs[i], spec[i][0], spec[i][1], i).amplify(spec[i][2]), mixer_ch, to_rate)
+    m = O.Mixer(mixer_ch, to_rate)
+    for i in range(S0):
+        m.add(chain(i))
+    ref = []
+    for _ in range(pull_first):
+        v = m.next()
+        if v is None:
+            break
+        ref.append(v)
+    for i in range(S0, len(xs)):
+        m.add(chain(i))
+    nones, v = 0, None
+    while nones < 16:
+        v = m.next()
+        if v is not None:
+            break
+        nones += 1
+    ref = np.concatenate([np.asarray(ref + [v], dtype=np.float32), m.collect()]) if v is not None else np.asarray(ref, dtype=np.float32)
+    r = subprocess.run([exe, "latewide", str(tmp_path), str(S0), str(len(xs) - S0), str(mixer_ch), str(to_rate), str(block), str(pull_first)], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, RH_TEST_SOURCE=kind))
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), r.stderr
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    return np.fromfile(tmp_path / "out.f32", dtype=np.float32), ref, int((tmp_path / "nones.txt").read_text()), nones
+
+
+def _late_cut_case(O, tmp_path, seed, exe):
+    """`_late_case` over sources whose spans cut frames (SamplesBuffers of 3, 5, 6 channels, packets of 5, 37, 1000, 2304 samples), three in ten
+    ending inside a frame, into mixers of 1, 2, 3 and 6 channels.  Found here: a mix that was about to END inside a frame -- its last block
+    already cut to the samples rodio's sources cover, one block ahead of the consumer -- stayed cut when a source joined in front of that
+    frame (a sample of the newcomer missing, up to five in a 6-channel mixer); and a newcomer that had two scheduled blocks of a generation
+    behind a full queue to catch up with overran its own queue."""
+    rng = np.random.default_rng(56000 + seed)
+    S0, S1 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    mixer_ch, to_rate, block = int(rng.choice([1, 2, 2, 6, 3])), int(rng.choice([22050, 44100, 48000])), int(rng.choice([777, 4096, 7000]))
+    kind = str(rng.choice(["buffer", "mixed", "spans:2304", "spans:37", "spans:1000", "spans:5"]))
+    kinds = [kind if kind != "mixed" else ["test", "buffer", "spans:4096"][i % 3] for i in range(S0 + S1)]
+    spec, xs = [], []
+    for i in range(S0 + S1):
+        ch, rate, gain = int(rng.choice([1, 2, 2, 6, 3, 5])), int(rng.choice(RATES)), float(np.float32(rng.choice([0.5, 0.8, 1.0])))
+        n = int(rng.integers(1, 12000)) * ch
+        if kinds[i] != "test" and rng.random() < 0.3:
+            n += int(rng.integers(0, ch))
+        spec.append((ch, rate, gain))
+        xs.append(M.rnd(56000 + 100 * seed + i, n, 0.2))
+    total0 = len(O_collect_copy(O, kind, xs, spec, S0, mixer_ch, to_rate))
+    pull_first = int(rng.integers(0, max(1, int(total0 * 1.2)) + 1))
+    got, ref, nones_got, nones = _late_run(O, tmp_path, exe, spec, xs, kind, S0, mixer_ch, to_rate, block, pull_first)
+    what = (seed, S0, S1, mixer_ch, to_rate, block, kind, pull_first, total0, spec, [len(x) for x in xs])
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    assert float(np.max(np.abs(got - ref))) <= TOL if len(ref) else True, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+    assert nones_got == nones, what
+
+
+LATE_CUT_SEEDS = list(range(40)) + [50, 54, 58, 78, 88, 89, 109, 136, 161, 169, 191, 194]
+
+
+@pytest.mark.parametrize("seed", LATE_CUT_SEEDS)
+def test_random_late_joins_of_sources_whose_spans_cut_frames(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _late_cut_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", LATE_CUT_SEEDS[::4] + [161, 194])
+def test_gpu_random_late_joins_of_sources_whose_spans_cut_frames(O, tmp_path, seed):
+    _late_cut_case(O, tmp_path, seed, M.EXE)
+
+
+LATE_EDGES = [  # (specs, samples, mixer channels, pull_first): a first source that ends inside a frame, a second one added around that frame
+    ([(2, 48000, 1.0), (2, 48000, 0.5)], [2001, 3000], 2, pf) for pf in (1990, 1999, 2000, 2001, 2002)
+] + [([(6, 48000, 1.0), (6, 48000, 0.5)], [603, 3000], 6, pf) for pf in (600, 601, 602, 603, 604, 605, 606)] + [([(6, 48000, 1.0), (2, 44100, 0.5)], [603, 300], 6, pf) for pf in (601, 603)]
+
+
+def _late_edge(O, tmp_path, exe, case):
+    spec, ns, mixer_ch, pull_first = case
+    xs = [M.rnd(900 + i, n, 0.2) for i, n in enumerate(ns)]
+    got, ref, nones_got, nones = _late_run(O, tmp_path, exe, spec, xs, "buffer", 1, mixer_ch, 48000, 777, pull_first)
+    assert len(got) == len(ref), (case, len(got), len(ref))
+    assert np.array_equal(got, ref), (case, int(np.argmax(got != ref)))
+    assert nones_got == nones, (case, nones_got, nones)
+
+
+@pytest.mark.parametrize("case", LATE_EDGES)
+def test_late_join_around_a_mix_that_ends_inside_a_frame(O, tmp_path, case):
+    """The first source's stream ends inside a frame, and the consumer is one block behind the mixer, which has cut its last block to rodio's
+    samples.  A source that joins IN FRONT of that frame completes it (the block gets its whole length back); one that joins while the
+    consumer is INSIDE it waits: rodio's mixer has no source left for the rest of the frame -- None, once per missing sample -- and starts
+    the pending one at the next frame (mixer.rs:120-136,175-183).  Bit for bit, and the same number of Nones."""
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _late_edge(O, tmp_path, FAKE, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", LATE_EDGES[::2])
+def test_gpu_late_join_around_a_mix_that_ends_inside_a_frame(O, tmp_path, case):
+    _late_edge(O, tmp_path, M.EXE, case)
