@@ -688,6 +688,7 @@ protected:
     bool running() const { return primed_ && !ended_; }
     bool other_in_flight() const { return primed_ && !ended_ && !slot_[cur_].last; }
     std::size_t position() const { return pos_; }
+    std::uint64_t handed_out() const { return handed_out_; }  // samples served so far
     void submit(Slot &s) {
         const auto t0 = std::chrono::steady_clock::now();
         enqueue(s);
@@ -786,15 +787,9 @@ public:
         for (const Stage &st : stages_)
             if (st.span_rule) rule = st.span_rule;
         if (rule == 0) return format_at_cursor().span;
-        // Rule 1: None whatever comes in (Mix, the converters).  Rule 2: rodio's adapter answers with span arithmetic of its own -- Delay adds the
-        // silence it still owes (delay.rs:88-92), TakeDuration cuts at what it still admits (take.rs:158-178), ChannelVolume hands on the
-        // input's number although it changes the sample count (channel_volume.rs:97-99) -- which is not mirrored: over an upstream that
-        // reports None the answer is None and right; over one that reports spans a consumer that ASKS (a mixer, UniformSourceIterator) would
-        // convert differently from rodio, so it is told so instead of being told None.
-        if (rule == 2 && up_->current_span_len().has_value())
-            throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
-                                            "(put .uniform() in front of them, or hand the consumer the plain source)");
-        return std::nullopt;
+        // Rule 1: None whatever comes in (Mix, the converters).  Rule 2: rodio's adapter answers with span arithmetic of its own (span_behind()).
+        if (rule == 1) return std::nullopt;
+        return span_behind(stages_.size(), handed_out());
     }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
@@ -934,21 +929,35 @@ public:
     /// SamplesBuffer or a decoder (which report spans) and a generator (None: one continuous conversion) each come out as
     /// they do in rodio.  Spans travel through the adapters in front that keep the sample count (amplify, filters, limiter,
     /// ...: they forward current_span_len()); behind reverb (Mix: None, mix.rs:92-94) or a bare converter the stream is
-    /// continuous.  Behind take_duration / delay / channel_volume a spanned upstream is refused (their span arithmetic is
-    /// not mirrored).
+    /// continuous.  Behind take_duration / delay over a continuous upstream the spans are the ones rodio's adapters report
+    /// there (TakeDuration: Some(what it still admits), so chains of 32768 samples, and Some(0) in front of the silence that
+    /// completes a cut frame: span_behind()); behind them over an upstream that itself reports spans the iterator is refused.
     GpuSource &uniform(std::uint16_t channels, std::uint32_t sample_rate) {
         if (!channels || !sample_rate) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         int rule = 0;
         for (const Stage &st : stages_)
             if (st.span_rule) rule = st.span_rule;
         if (rule == 2 && up_->current_span_len()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::uniform behind take_duration / delay / channel_volume on a source that reports spans");
+        // (rule 2 over a continuous upstream: the spans are the ones rodio's adapters report there -- TakeDuration's Some(what it still admits),
+        // in chains of 32768 samples, ending with Some(0) in front of the silence that completes a cut frame -- computed at every bootstrap from
+        // the adapters' sample counts: span_behind())
+        const bool computed = rule == 2;
+        const std::size_t upto = stages_.size();
+        if (computed) (void)span_behind(upto, 0);  // (combinations the counts do not cover are refused here, not at the first block)
         // (rule != 0: the input is continuous from here on -- current_span_len() is None behind a converter or a Mix -- so the iterator builds
         // ChannelCountConverter(SampleRateConverter(..)) once, uniform.rs:62-67: ONE span that opens with the first sample and closes with the
         // stream, through the same planner, which also knows what rodio's converters make of a stream that ends inside a frame)
         const bool one_span = rule != 0;
         if (!one_span) span_aware_ = true;
         may_cut_ = may_cut_ || (!one_span && ch_ > 1 && up_->current_span_len().has_value());  // (a span that cuts a frame leaves a run of samples that need not fill an output frame)
+        may_cut_ = may_cut_ || (computed && ch_ > 1);
         auto started = std::make_shared<bool>(false);
+        struct Computed {  // the open span of the computed mode
+            std::uint64_t taken = 0;  // samples of the input consumed so far
+            std::size_t left = 0;     // samples the open span still admits (SpanReader::kOpenEnded: the answer was None)
+            bool open = false, fresh = true, ended = false;
+        };
+        auto cs = std::make_shared<Computed>();
         auto plan = std::make_shared<detail::UniformPlanner>(channels, sample_rate);
         auto win = std::make_shared<detail::DeviceBuf>();
         auto keep = std::make_shared<detail::DeviceBuf>();
@@ -968,7 +977,35 @@ public:
                 if (hs) check(rh_memcpy_d2d(win->get(), keep->get(), hs * sizeof(float), c.stream), "rh_memcpy_d2d");
                 if (c.n) check(rh_memcpy_d2d(win->get() + hs, c.in, c.n * sizeof(float), c.stream), "rh_memcpy_d2d");
                 std::vector<detail::UniformPlanner::Seg> segs;
-                if (one_span) {
+                if (computed) {
+                    std::size_t off = 0;
+                    while (!cs->ended && (off < c.n || (c.flush && cs->open))) {
+                        std::optional<std::size_t> answer;
+                        if (!cs->open) {  // uniform.rs:50-68: bootstrap
+                            answer = span_behind(upto, cs->taken);
+                            if (answer && *answer == 0) {  // Take{n: 0}: the chain is empty, next() is None -- whatever the input still holds
+                                cs->ended = true;
+                                break;
+                            }
+                            cs->left = answer ? std::min<std::size_t>(*answer, 32768) : detail::SpanReader::kOpenEnded;
+                            cs->open = cs->fresh = true;
+                        }
+                        const std::size_t take = std::min(cs->left, c.n - off);
+                        if (cs->left != detail::SpanReader::kOpenEnded) cs->left -= take;
+                        const bool last = c.flush && off + take == c.n;  // the input returned None inside the span
+                        const bool closes = cs->left == 0 || last;
+                        if (take || (closes && !cs->fresh)) {
+                            detail::Piece p{take, cs->fresh, closes, in_ch, from, 0, last && cs->left != 0, cs->fresh ? answer : std::nullopt, in_ch, from, cs->fresh, std::nullopt};
+                            plan->add(p, segs);
+                        }
+                        if (take) cs->fresh = false;
+                        off += take;
+                        cs->taken += take;
+                        if (closes) cs->open = false;
+                        if (last) cs->ended = true;
+                    }
+                    if (cs->ended) c.end = true;  // the iterator has returned None: the stream ends here although the input may have more
+                } else if (one_span) {
                     if (c.n || (c.flush && *started)) {
                         detail::Piece p{c.n, !*started, c.flush, in_ch, from, 0, c.flush, std::nullopt, in_ch, from, !*started, std::nullopt};
                         *started = true;
@@ -999,16 +1036,17 @@ public:
                 *part_n = rest;
                 return total - rest;
             },
-            [this, in_ch, channels, from, to, one_span](std::size_t n) {  // every span may add its verbatim last frame, or what the converters make of a cut frame
+            [this, in_ch, channels, from, to, one_span, computed](std::size_t n) {  // every span may add its verbatim last frame, or what the converters make of a cut frame
                 // (the block's pieces may come in other formats than the chain was built for: the fewest channels and the lowest rate among them bound it)
                 const std::uint64_t ich = one_span ? in_ch : std::min<std::uint64_t>(in_ch, block_min_ch_ ? block_min_ch_ : in_ch), ifrom = one_span ? from : std::min<std::uint64_t>(from, block_min_rate_ ? block_min_rate_ : from);
                 const std::uint64_t f = n / ich + 1;
-                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((one_span ? 1 : pieces_.size()) + 2) + 1) * channels;
+                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((computed ? n / 32768 + 2 : one_span ? 1 : pieces_.size()) + 2) + 1) * channels;
             })
-            .on_seek([plan, part_n, started, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
+            .on_seek([plan, part_n, started, cs, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
                 *plan = detail::UniformPlanner(channels, sample_rate);
                 *part_n = 0;
                 *started = false;
+                cs->open = false;
             });
         stages_.back().span_rule = 1;
         stages_.back().fmt = one_span ? 0 : 3;  // every piece comes with its own format (uniform.rs:58-59: read at every bootstrap); behind another converter nothing changes any more
@@ -1072,6 +1110,9 @@ public:
         const std::uint32_t rate = rate_;
         auto pos = std::make_shared<std::uint64_t>(0);
         auto done = std::make_shared<bool>(false);
+        // the samples the duration admits: one per duration_per_sample = 1e9 / (rate * channels) ns, integer (take.rs:21-24,124-131)
+        const std::uint64_t per_sample = 1000000000ull / ((std::uint64_t)rate * ch);
+        const std::uint64_t admits = per_sample ? (std::uint64_t)duration.count() / per_sample : 0;
         return push(
             [=](Ctx &c) {
                 c.end = true;
@@ -1084,7 +1125,14 @@ public:
                 c.end = *done;
                 return (std::size_t)m;
             },
-            [ch](std::size_t n) { return n + ch; });
+            [ch](std::size_t n) { return n + ch; })
+            .span_arithmetic(
+                [admits](std::optional<std::size_t> in, std::uint64_t emitted) -> std::optional<std::size_t> {  // take.rs:176-195
+                    const std::uint64_t rem = admits > emitted ? admits - emitted : 0;
+                    if (rem == 0) return std::size_t(0);
+                    return in && *in < rem ? in : std::optional<std::size_t>((std::size_t)rem);
+                },
+                [admits](std::uint64_t emitted) { return std::min(emitted, admits); });  // (behind them: the silence that completes a cut frame)
     }
     /// `delay(d)` (delay.rs:8-16,68-75): rh_delay_samples() zeros in front of the stream.  Not seekable here (rodio's Delay
     /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
@@ -1120,7 +1168,13 @@ public:
                        return k - rest;
                    },
                    [d, ch](std::size_t n) { return n + (std::size_t)d + ch; })
-            .not_seekable();
+            .not_seekable()
+            .span_arithmetic(
+                [d](std::optional<std::size_t> in, std::uint64_t emitted) -> std::optional<std::size_t> {  // delay.rs:94-98: the input's answer + the silence still owed
+                    if (!in) return std::nullopt;
+                    return *in + (std::size_t)(d > emitted ? d - emitted : 0);
+                },
+                [d](std::uint64_t emitted) { return emitted > d ? emitted - d : 0; });
     }
     GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13
     GpuSource &fade_out(Nanos duration) { return linear_gain_ramp(duration, 1.0f, 0.0f, true); }  // fadeout.rs:13
@@ -1321,6 +1375,10 @@ private:
         // adapters behind it never see a change.
         int fmt = 2;
         std::function<void(std::uint16_t, std::uint32_t)> on_format = nullptr;
+        // span_rule 2, where the arithmetic is mirrored (take_duration, delay): rodio's answer behind the adapter from its input's answer and
+        // the number of samples the adapter has emitted; and how many of its input's samples it has taken by then (span_behind())
+        std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> span_fn = nullptr;
+        std::function<std::uint64_t(std::uint64_t)> span_in_pos = nullptr;
     };
     template <class T>
     struct Handle {
@@ -1360,6 +1418,45 @@ private:
     GpuSource &spans(int rule) {
         stages_.back().span_rule = rule;
         return *this;
+    }
+    GpuSource &span_arithmetic(std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> fn, std::function<std::uint64_t(std::uint64_t)> in_pos) {
+        stages_.back().span_fn = std::move(fn);
+        stages_.back().span_in_pos = std::move(in_pos);
+        return *this;
+    }
+    /// rodio's answer to current_span_len() behind the first `upto` adapters at sample `pos` of their output, where the last of them that
+    /// does anything to the spans is a take_duration / delay / channel_volume.  TakeDuration answers with what its duration still admits
+    /// unless its input's span is shorter -- Some(..) over an input that says None too, and Some(0) once it is spent (take.rs:176-195);
+    /// Delay adds the silence it still owes to its input's answer (delay.rs:94-98); ChannelVolume hands its input's answer on
+    /// (channel_volume.rs:103-105).  Computed from the adapters' sample counts, so only over an input that answers None whatever the
+    /// position (a generator, or what comes out of a Mix or a converter): over an upstream that reports spans the answer would depend
+    /// on where in ITS span the consumer asks -- refused, loudly, like every combination the counts do not cover.
+    std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos) const {
+        std::size_t first = 0;
+        for (std::size_t k = 0; k < upto; ++k)
+            if (stages_[k].span_rule == 1) first = k + 1;
+        if (first == 0 && up_->current_span_len().has_value())
+            throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
+                                            "(put .uniform() in front of them, or hand the consumer the plain source)");
+        std::vector<std::uint64_t> at(upto + 1, 0);  // at[k + 1]: samples adapter k has emitted when the chain has emitted `pos`
+        at[upto] = pos;
+        bool counts = false;
+        for (std::size_t k = first; k < upto; ++k) counts = counts || stages_[k].span_fn;
+        for (std::size_t k = upto; k-- > first;) {
+            const Stage &st = stages_[k];
+            if (st.span_rule == 2 && !st.span_fn) {  // ChannelVolume: another sample count, the input's answer
+                bool counted_in_front = false;
+                for (std::size_t j = first; j < k; ++j) counted_in_front = counted_in_front || stages_[j].span_fn;
+                if (counted_in_front) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len: channel_volume behind take_duration / delay (the span arithmetic across its change of the sample count is not mirrored)");
+                break;  // nothing in front of it counts: the answer there is None wherever the consumer asks
+            }
+            at[k] = st.span_in_pos ? st.span_in_pos(at[k + 1]) : at[k + 1];
+        }
+        std::optional<std::size_t> ans;
+        if (!counts) return ans;
+        for (std::size_t k = first; k < upto; ++k)
+            if (stages_[k].span_fn) ans = stages_[k].span_fn(ans, at[k + 1]);
+        return ans;
     }
     // Adapters that work on whole frames and carry state (BltFilter, Limit) over an input that may break off inside a frame: at the end of a
     // span (rodio's adapters run sample by sample -- blt.rs:431-451, limit.rs:927-988 -- and their channel position simply goes on into the

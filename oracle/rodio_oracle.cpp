@@ -570,7 +570,15 @@ struct TakeDuration : Source {
             return true;
         }
     }
-    long current_span_len() const override { return input->current_span_len(); }
+    // take.rs:176-195: what the duration still admits, unless the input's span is shorter -- Some(..) over an input that reports None too,
+    // so a UniformSourceIterator behind it converts in chains of 32768 samples, and Some(0) once the duration is spent: the silence that
+    // completes a cut frame (:107-115) lies behind that and never reaches an iterator that asks.
+    long current_span_len() const override {
+        if (dps_ns == 0 || remaining_ns == 0) return 0;
+        const long remaining_samples = (long)(remaining_ns / dps_ns);
+        const long in = input->current_span_len();
+        return in >= 0 && in < remaining_samples ? in : remaining_samples;
+    }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
 };

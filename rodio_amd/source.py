@@ -127,12 +127,20 @@ class GpuSource:
         return GpuSource(out, self._channels, self._sample_rate, None if self.span_len is None else self.span_len + d)
 
     def take_duration(self, duration_ns: int, fade_out: bool = False) -> "GpuSource":
+        """src/source/take.rs:96-148.  current_span_len() behind it is what the duration still admits unless the input's span is
+        shorter -- Some(..) over an input that says None too, Some(0) once it is spent (take.rs:176-195): a UniformSourceIterator
+        behind it converts in chains of 32768 samples and ends in front of the silence that completes a cut frame (`_admits`)."""
         _ensure()
         out = _dev_empty(len(self) + self._channels)
         m, ended = C.c_uint64(0), C.c_int32(0)
         check(lib.rh_take_duration(_ptr(out), _ptr(self.samples), len(self), 0, self._channels, self._sample_rate, duration_ns,
                                    int(fade_out), C.byref(m), C.byref(ended), _stream()), "rh_take_duration")
-        return GpuSource(out[: m.value], self._channels, self._sample_rate, self.span_len)
+        per_sample = 1_000_000_000 // (self._sample_rate * self._channels)
+        admits = duration_ns // per_sample if per_sample else 0
+        span = self.span_len if (self.span_len is not None and self.span_len < admits) else admits
+        res = GpuSource(out[: m.value], self._channels, self._sample_rate, span)
+        res._admits = min(admits, m.value)
+        return res
 
     def distortion(self, gain: float, threshold: float) -> "GpuSource":
         _ensure()
@@ -288,6 +296,11 @@ def UniformSourceIterator(inp: GpuSource, channels: int, sample_rate: int) -> Gp
     """src/source/uniform.rs:50-97: ChannelCountConverter<SampleRateConverter<Take<I>>> restarted
     every min(current_span_len, 32768) samples."""
     span = inp.current_span_len() or 0
+    admits = getattr(inp, "_admits", None)
+    if admits is not None and admits < len(inp):  # (a TakeDuration answers Some(0) there: the iterator never asks for the frame's padding)
+        inp = GpuSource(inp.samples[:admits], inp.channels(), inp.sample_rate(), inp.span_len)
+    if min(span, 32768) >= len(inp):  # one chain for everything: the same as a continuous stream (and the form that knows a cut last frame)
+        span = 0
     r = SampleRateConverter(inp, inp.sample_rate(), sample_rate, inp.channels(), span)
     return ChannelCountConverter(r, inp.channels(), channels)
 

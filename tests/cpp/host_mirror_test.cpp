@@ -46,6 +46,11 @@ static void write_f32(const std::string &path, const std::vector<float> &v) {
     if (!v.empty()) std::fwrite(v.data(), 4, v.size(), f);
     std::fclose(f);
 }
+// the block size of a run; RH_TEST_BLOCK overrides what the command line says (tools/fuzz_mixer_chains.py: the same cases in blocks of 64 or 100 000 frames)
+static size_t block_arg(const char *a) {
+    const char *e = std::getenv("RH_TEST_BLOCK");
+    return (size_t)std::atoll(e && *e ? e : a);
+}
 static std::vector<std::string> split(const std::string &s, char sep) {
     std::vector<std::string> out;
     std::stringstream ss(s);
@@ -314,7 +319,7 @@ int main(int argc, char **argv) {
             rh::GpuMixer::Options opt;
             opt.filter_kind = 0;
             opt.filter_freq = 200;
-            opt.block_frames = (size_t)std::atoll(argv[4]);
+            opt.block_frames = block_arg(argv[4]);
             opt.host_threads = argc == 6 ? (unsigned)std::atoi(argv[5]) : 0;
             rh::GpuMixer mixer(48000, opt);
             uint32_t lcg = 12345u;
@@ -377,7 +382,7 @@ int main(int argc, char **argv) {
             rh::GpuMixer::Options opt;
             opt.filter_kind = std::atoi(argv[5]);
             opt.filter_freq = (uint32_t)std::atoll(argv[6]);
-            opt.block_frames = (size_t)std::atoll(argv[7]);
+            opt.block_frames = block_arg(argv[7]);
             opt.frames_per_lane = (uint32_t)std::atoll(argv[8]);
             std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
             if (!sf) throw std::runtime_error("spec.txt");
@@ -397,7 +402,7 @@ int main(int argc, char **argv) {
             rh::GpuMixer::Options opt;
             opt.filter_kind = std::atoi(argv[7]);
             opt.filter_freq = (uint32_t)std::atoll(argv[8]);
-            opt.block_frames = (size_t)std::atoll(argv[9]);
+            opt.block_frames = block_arg(argv[9]);
             opt.frames_per_lane = (uint32_t)std::atoll(argv[10]);
             const size_t pull_first = (size_t)std::atoll(argv[11]);
             const std::vector<float> gains = read_f32(dir + "/gains.f32");
@@ -434,7 +439,7 @@ int main(int argc, char **argv) {
             const uint16_t mch = (uint16_t)std::atoi(argv[5]);
             const uint32_t to = (uint32_t)std::atoll(argv[6]);
             rh::GpuMixer::Options opt;
-            opt.block_frames = (size_t)std::atoll(argv[7]);
+            opt.block_frames = block_arg(argv[7]);
             const size_t pull_first = (size_t)std::atoll(argv[8]);
             std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
             if (!sf) throw std::runtime_error("spec.txt");
@@ -473,7 +478,7 @@ int main(int argc, char **argv) {
             rh::GpuMixer::Options opt;
             opt.filter_kind = std::atoi(argv[6]);
             opt.filter_freq = (uint32_t)std::atoll(argv[7]);
-            opt.block_frames = (size_t)std::atoll(argv[8]);
+            opt.block_frames = block_arg(argv[8]);
             opt.frames_per_lane = (uint32_t)std::atoll(argv[9]);
             const std::vector<float> gains = read_f32(dir + "/gains.f32");
             rh::GpuMixer mixer(to, opt);
@@ -490,7 +495,7 @@ int main(int argc, char **argv) {
             const uint16_t mch = (uint16_t)std::atoi(argv[4]);
             const uint32_t to = (uint32_t)std::atoll(argv[5]);
             rh::GpuMixer::Options opt;
-            opt.block_frames = (size_t)std::atoll(argv[6]);
+            opt.block_frames = block_arg(argv[6]);
             const bool on_device = std::atoi(argv[7]) != 0;
             std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
             if (!sf) throw std::runtime_error("spec.txt");
@@ -535,7 +540,7 @@ int main(int argc, char **argv) {
             const uint16_t ch = (uint16_t)std::atoi(argv[3]);
             const uint32_t rate = (uint32_t)std::atoll(argv[4]);
             rh::BoxSource seq = make_seq_source(dir, 0);
-            rh::GpuSource g(seq ? std::move(seq) : make_source(ch, rate, read_f32(dir + "/src_0.f32")), (size_t)std::atoll(argv[5]));
+            rh::GpuSource g(seq ? std::move(seq) : make_source(ch, rate, read_f32(dir + "/src_0.f32")), block_arg(argv[5]));
             for (int a = 6; a < argc; ++a) apply_op(g, argv[a]);
             std::FILE *meta = std::fopen((dir + "/format.txt").c_str(), "w");
             if (meta) {

@@ -380,6 +380,18 @@ def test_take_duration_golden_and_bit_exact(G, O):
         assert np.array_equal(got, ref), (ch, rate, ns, fade, len(got), len(ref))
 
 
+def test_take_duration_in_front_of_a_uniform_source_iterator(G, O):
+    # take.rs:176-195: TakeDuration answers Some(what it still admits) over a generator that says None, so the iterator behind it converts in
+    # chains of 32768 samples (88 206 samples: three chains) -- or in one, when the duration admits less than that
+    x = rnd(36, 2 * 60000)
+    for ch, rate, ns in [(2, 44100, 1_000_000_000), (2, 44100, 300_000_000), (1, 8000, 2_000_000_000), (2, 48000, 5_000_000_000)]:
+        xs = x[: (len(x) // ch) * ch]
+        assert G.TestSource(xs, ch, rate).take_duration(ns).current_span_len() == O.TestSource(xs, ch, rate).take_duration(ns).current_span_len()
+        ref = O.UniformSourceIterator(O.TestSource(xs, ch, rate).take_duration(ns), 2, 44100 if rate == 48000 else 48000).collect()
+        got = G.UniformSourceIterator(G.TestSource(xs, ch, rate).take_duration(ns), 2, 44100 if rate == 48000 else 48000).collect()
+        assert len(got) == len(ref) and np.array_equal(got, ref), (ch, rate, ns, len(got), len(ref))
+
+
 def test_config1_sine_resample_amplify_bit_exact(G, O):
     # BASELINE configs[0]: 1 x SineWave at 44.1 kHz -> SampleRateConverter to 48 kHz -> amplify(0.8), 10 s
     from conftest import sine_generator

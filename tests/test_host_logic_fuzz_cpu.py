@@ -776,3 +776,72 @@ def test_late_join_around_a_mix_that_ends_inside_a_frame(O, tmp_path, case):
 @pytest.mark.parametrize("case", LATE_EDGES[::2])
 def test_gpu_late_join_around_a_mix_that_ends_inside_a_frame(O, tmp_path, case):
     _late_edge(O, tmp_path, M.EXE, case)
+
+
+# ------------------------------------------------------------------ ... and the span arithmetic of take_duration / delay in front of an iterator that asks ----
+def _span_arithmetic_case(O, tmp_path, seed, exe):
+    """`TakeDuration::current_span_len()` answers Some(what the duration still admits) -- over a generator that says None too, and Some(0) once
+    it is spent (take.rs:176-195); `Delay` adds the silence it still owes (delay.rs:94-98).  A UniformSourceIterator behind them (the chain's own
+    `.uniform()`, or the mixer's) therefore converts in chains of 32768 samples where it would convert a bare generator in one, and ends in
+    front of the silence that completes a frame the duration cut.  Continuous sources of up to 60 000 frames, takes that end before and behind
+    the source's end, inside and between frames; as a chain of its own (half of them) and into mixers of 1, 2, 6 channels.  (Until round 5
+    the oracle handed the input's answer through -- as did the mirror.  Both follow take.rs now.)"""
+    rng = np.random.default_rng(88000 + seed)
+    ch, rate = int(rng.choice([1, 2, 2, 3, 6])), int(rng.choice(RATES))
+    frames = int(rng.integers(100, 60000))
+    x = M.rnd(88000 + seed, frames * ch, 0.4)
+    x.tofile(tmp_path / "src_0.f32")
+    dur = lambda f: int(f * 1e9 / rate) + int(rng.integers(0, 30000))  # nanoseconds for about f frames
+    ops = []
+    for _ in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(0, 6))
+        if k == 0 or not ops:
+            ops.append(f"take:{dur(rng.integers(1, int(frames * 1.3) + 2))}:{int(rng.integers(0, 2))}")
+        elif k == 1:
+            ops.append(f"delay:{dur(rng.integers(0, 3000))}")
+        elif k == 2:
+            ops.append(f"amplify:{float(np.float32(rng.choice([0.5, 0.8, 1.2])))}")
+        elif k == 3:
+            ops.append(f"low_pass:{int(rng.choice([300, 1000, 3000]))}")
+        elif k == 4:
+            ops.append("limit")
+        else:
+            ops.append(f"fade_in:{dur(rng.integers(1, 2000))}")
+    block = int(rng.choice([777, 4096, 40000]))
+    if rng.random() < 0.5:  # the chain's own iterator
+        ops = ops + [f"uniform:{int(rng.choice([1, 2, 6]))}:{int(rng.choice([22050, 44100, 48000]))}"] + (["amplify:0.5"] if rng.random() < 0.5 else [])
+        r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
+        what = (seed, (frames, ch, rate), ops, block)
+        ref = _oracle_full(O, O.TestSource(x, ch, rate), ops).collect()
+    else:  # the mixer's
+        mixer_ch, to_rate, on_device = int(rng.choice([1, 2, 2, 6])), int(rng.choice([22050, 44100, 48000])), bool(rng.integers(0, 2))
+        gain = float(np.float32(rng.choice([0.5, 1.0])))
+        (tmp_path / "spec.txt").write_text(f"{ch} {rate} {gain} -1 0 {','.join(ops)}\n2 44100 0.5 -1 0 -\n")
+        y = M.rnd(88500 + seed, 2 * 3000, 0.2)
+        y.tofile(tmp_path / "src_1.f32")
+        r = subprocess.run([exe, "chainmix", str(tmp_path), "2", str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300)
+        what = (seed, (frames, ch, rate), ops, block, mixer_ch, to_rate, on_device)
+        m = O.Mixer(mixer_ch, to_rate)
+        m.add(O.UniformSourceIterator(_oracle_full(O, O.TestSource(x, ch, rate), ops).amplify(gain), mixer_ch, to_rate))
+        m.add(O.UniformSourceIterator(O.TestSource(y, 2, 44100).amplify(0.5), mixer_ch, to_rate))
+        ref = m.collect()
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref))))
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_random_takes_and_delays_in_front_of_an_iterator_that_asks_for_spans(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _span_arithmetic_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(0, 60, 3)))
+def test_gpu_random_takes_and_delays_in_front_of_an_iterator_that_asks_for_spans(O, tmp_path, seed):
+    _span_arithmetic_case(O, tmp_path, seed, M.EXE)

@@ -340,6 +340,34 @@ def test_take_duration_golden(O):
     assert len(O.TestSource(x, 1, 48000).take_duration(0).collect()) == 0
 
 
+def test_take_duration_and_delay_answer_current_span_len_as_the_reference_does(O):
+    """take.rs:176-195 and delay.rs:94-98, by hand (the reference has no test for them): TakeDuration answers what its duration still admits
+    unless the input's span is shorter -- over an input that says None too -- and Some(0) once it is spent (the silence that completes a cut
+    frame lies behind that); Delay adds the silence it still owes to its input's answer, and hands None on.  A UniformSourceIterator
+    behind a take therefore stops in front of that silence."""
+    nps = 1_000_000_000 // (44100 * 2)
+    t = O.TestSource(np.ones(100, np.float32), 2, 44100).take_duration(nps * 5)  # admits 5 samples: cuts the third frame
+    answers = []
+    while True:
+        answers.append(t.current_span_len())
+        if not len(t.pull(1)):
+            break
+    assert answers == [5, 4, 3, 2, 1, 0, 0]  # five samples, the sixth is the frame's silence: Some(0) in front of it, and behind
+    assert O.SamplesBuffer(2, 44100, np.ones(4, np.float32)).take_duration(nps * 10).current_span_len() == 4  # the input's span is shorter (:192-194)
+    assert O.SamplesBuffer(2, 44100, np.ones(40, np.float32)).take_duration(nps * 10).current_span_len() == 10
+    assert O.TestSource(np.ones(8, np.float32), 2, 44100).take_duration(0).current_span_len() == 0  # remaining_nanos == 0 (:185-187)
+    d = O.TestSource(np.ones(8, np.float32), 2, 44100).delay(1_000_000_000)
+    assert d.current_span_len() is None
+    d = O.SamplesBuffer(1, 1000, np.ones(8, np.float32)).delay(3_000_000)  # three samples of silence
+    answers = []
+    for _ in range(5):
+        answers.append(d.current_span_len())
+        d.pull(1)
+    assert answers == [11, 10, 9, 8, 8]
+    u = O.UniformSourceIterator(O.TestSource(np.ones(100, np.float32), 2, 44100).take_duration(nps * 5), 2, 44100)
+    assert u.collect().tolist() == [1.0] * 5  # (the bare adapter returns six samples: test_take_duration_golden)
+
+
 def test_sine_generator_restatement_matches_the_reference_vector():
     # signal_generator.rs:227-238 (TEST_EPSILON = 1e-6): the input of BASELINE config 1
     from conftest import sine_generator
