@@ -789,7 +789,7 @@ public:
         if (rule == 0) return format_at_cursor().span;
         // Rule 1: None whatever comes in (Mix, the converters).  Rule 2: rodio's adapter answers with span arithmetic of its own (span_behind()).
         if (rule == 1) return std::nullopt;
-        return span_behind(stages_.size(), handed_out());
+        return span_behind(stages_.size(), handed_out(), true);
     }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
@@ -1132,7 +1132,8 @@ public:
                     if (rem == 0) return std::size_t(0);
                     return in && *in < rem ? in : std::optional<std::size_t>((std::size_t)rem);
                 },
-                [admits](std::uint64_t emitted) { return std::min(emitted, admits); });  // (behind them: the silence that completes a cut frame)
+                [admits](std::uint64_t emitted) { return std::min(emitted, admits); })  // (behind them: the silence that completes a cut frame)
+            .keeps_the_sample_count();
     }
     /// `delay(d)` (delay.rs:8-16,68-75): rh_delay_samples() zeros in front of the stream.  Not seekable here (rodio's Delay
     /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
@@ -1250,11 +1251,8 @@ protected:
         cap = ((cap + 3) & ~std::size_t(3)) + 64;  // + room for one padding frame
         a_.reset(cap);
         b_.reset(cap);
-        bool counted = true, fixed = false;  // every adapter hands on one sample per sample / an adapter gives one format out whatever comes in
-        for (const Stage &st : stages_) {
-            counted = counted && st.span_rule == 0;
-            fixed = fixed || st.fmt == 3;
-        }
+        bool counted = spans_stay_in_place(), fixed = false;  // every adapter hands on one sample per sample / an adapter gives one format out whatever comes in
+        for (const Stage &st : stages_) fixed = fixed || st.fmt == 3;
         if (runs.size() > 1) acc_.reset(cap * runs.size());
         // 2. run by run through the adapters
         s.marks.clear();
@@ -1342,9 +1340,7 @@ protected:
     /// The format of the sample next() returns next.
     FormatMark format_at_cursor() const {
         if (!started()) {  // nothing pulled yet: the upstream's own answers
-            bool counted = true;
-            for (const Stage &st : stages_) counted = counted && st.span_rule == 0;
-            return FormatMark{0, ch_, rate_, counted ? up_->current_span_len() : std::nullopt};
+            return FormatMark{0, ch_, rate_, spans_stay_in_place() ? up_->current_span_len() : std::nullopt};
         }
         const Slot &sl = cur_slot();
         const std::size_t pos = position();
@@ -1379,6 +1375,7 @@ private:
         // the number of samples the adapter has emitted; and how many of its input's samples it has taken by then (span_behind())
         std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> span_fn = nullptr;
         std::function<std::uint64_t(std::uint64_t)> span_in_pos = nullptr;
+        bool span_keeps_count = false;  // ... and it hands on one sample per sample until it ends the stream (take_duration): the input's spans lie where they lay
     };
     template <class T>
     struct Handle {
@@ -1419,6 +1416,16 @@ private:
         stages_.back().span_rule = rule;
         return *this;
     }
+    // every adapter hands on one sample per sample (until one of them ends the stream): the spans of the input lie at the same samples of the output
+    bool spans_stay_in_place() const {
+        for (const Stage &st : stages_)
+            if (st.span_rule != 0 && !st.span_keeps_count) return false;
+        return true;
+    }
+    GpuSource &keeps_the_sample_count() {
+        stages_.back().span_keeps_count = true;
+        return *this;
+    }
     GpuSource &span_arithmetic(std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> fn, std::function<std::uint64_t(std::uint64_t)> in_pos) {
         stages_.back().span_fn = std::move(fn);
         stages_.back().span_in_pos = std::move(in_pos);
@@ -1431,13 +1438,21 @@ private:
     /// (channel_volume.rs:103-105).  Computed from the adapters' sample counts, so only over an input that answers None whatever the
     /// position (a generator, or what comes out of a Mix or a converter): over an upstream that reports spans the answer would depend
     /// on where in ITS span the consumer asks -- refused, loudly, like every combination the counts do not cover.
-    std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos) const {
+    std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos, bool at_cursor = false) const {
         std::size_t first = 0;
         for (std::size_t k = 0; k < upto; ++k)
             if (stages_[k].span_rule == 1) first = k + 1;
-        if (first == 0 && up_->current_span_len().has_value())
-            throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
-                                            "(put .uniform() in front of them, or hand the consumer the plain source)");
+        std::optional<std::size_t> ans;  // the answer in front of adapter `first`
+        if (first == 0 && up_->current_span_len().has_value()) {
+            // Over an upstream that reports spans the adapters ask IT, wherever the consumer asks them.  Where every adapter hands on one
+            // sample per sample (take_duration among amplify, the filters, ...) the chain knows the upstream's answer for the sample at
+            // its cursor (the block's marks: the answer the upstream gave when the span opened -- a SamplesBuffer, a decoder's packets:
+            // sources whose answer holds for the whole span); behind a delay or a channel_volume it does not.
+            if (!(at_cursor && spans_stay_in_place()))
+                throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
+                                                "(put .uniform() in front of them, or hand the consumer the plain source)");
+            ans = format_at_cursor().span;
+        }
         std::vector<std::uint64_t> at(upto + 1, 0);  // at[k + 1]: samples adapter k has emitted when the chain has emitted `pos`
         at[upto] = pos;
         bool counts = false;
@@ -1452,7 +1467,6 @@ private:
             }
             at[k] = st.span_in_pos ? st.span_in_pos(at[k + 1]) : at[k + 1];
         }
-        std::optional<std::size_t> ans;
         if (!counts) return ans;
         for (std::size_t k = first; k < upto; ++k)
             if (stages_[k].span_fn) ans = stages_[k].span_fn(ans, at[k + 1]);
