@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <exception>
 #include <memory>
@@ -781,7 +782,8 @@ public:
     std::uint16_t channels() const override { return format_at_cursor().ch; }
     std::uint32_t sample_rate() const override { return format_at_cursor().rate; }
     /// What rodio's adapters answer: the input's span length behind adapters that hand on one sample per sample (amplify.rs:78-80,
-    /// blt.rs:153-155, ...), None behind Mix and the converters (mix.rs:92-94, uniform.rs:104-106).
+    /// blt.rs:153-155, ...), None behind Mix and the converters (mix.rs:92-94, uniform.rs:104-106), and the adapters' own arithmetic
+    /// behind take_duration / delay / channel_volume (span_behind()).
     std::optional<std::size_t> current_span_len() const override {
         int rule = 0;  // of the last adapter that does anything to the spans
         for (const Stage &st : stages_)
@@ -789,7 +791,7 @@ public:
         if (rule == 0) return format_at_cursor().span;
         // Rule 1: None whatever comes in (Mix, the converters).  Rule 2: rodio's adapter answers with span arithmetic of its own (span_behind()).
         if (rule == 1) return std::nullopt;
-        return span_behind(stages_.size(), handed_out(), true);
+        return span_behind(stages_.size(), handed_out());
     }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
@@ -810,6 +812,14 @@ public:
         restart(ch_);
         for (Stage &st : stages_)
             if (st.on_seek) st.on_seek(pos);
+        if (span_log_on_) {  // what was pulled ahead is gone: the next sample pulled is the one the consumer's cursor reaches
+            std::uint64_t q = handed_out();
+            for (std::size_t k = stages_.size(); k-- > 0;)
+                if (stages_[k].span_in_pos) q = stages_[k].span_in_pos(q);
+            in_total_ = q;
+            span_log_.clear();
+            up_ended_ = false;
+        }
         return true;
     }
 
@@ -875,7 +885,10 @@ public:
                 check(rh_channel_volume(c.out, in, frames, in_ch, gains.data(), out_ch, c.stream), "rh_channel_volume");
                 return frames * out_ch;
             });
-        }, [in_ch, out_ch](std::size_t n) { return (n / in_ch + 1) * out_ch; }).on_seek([rg](Nanos) { rg->n = 0; });
+        }, [in_ch, out_ch](std::size_t n) { return (n / in_ch + 1) * out_ch; }).on_seek([rg](Nanos) { rg->n = 0; })
+            .span_arithmetic(  // channel_volume.rs:103-105: the input's answer as it is -- counted in ITS samples, of which a frame has been taken whenever an output frame begins (:71-79)
+                [](std::optional<std::size_t> in, std::uint64_t) { return in; },
+                [in_ch, out_ch](std::uint64_t emitted) { return (emitted + out_ch - 1) / out_ch * in_ch; });
         ch_ = out_ch;
         may_cut_ = false;  // (an open last frame is dropped: `input.next()?`)
         return *this;
@@ -929,15 +942,15 @@ public:
     /// SamplesBuffer or a decoder (which report spans) and a generator (None: one continuous conversion) each come out as
     /// they do in rodio.  Spans travel through the adapters in front that keep the sample count (amplify, filters, limiter,
     /// ...: they forward current_span_len()); behind reverb (Mix: None, mix.rs:92-94) or a bare converter the stream is
-    /// continuous.  Behind take_duration / delay over a continuous upstream the spans are the ones rodio's adapters report
-    /// there (TakeDuration: Some(what it still admits), so chains of 32768 samples, and Some(0) in front of the silence that
-    /// completes a cut frame: span_behind()); behind them over an upstream that itself reports spans the iterator is refused.
+    /// continuous.  Behind take_duration / delay the spans are the ones rodio's adapters report there (TakeDuration:
+    /// Some(what it still admits) unless the input's span is shorter -- so chains of 32768 samples over a generator -- and
+    /// Some(0) in front of the silence that completes a cut frame; Delay: the input's answer plus the silence it still owes:
+    /// span_behind()); behind channel_volume over an upstream that reports spans the iterator is refused.
     GpuSource &uniform(std::uint16_t channels, std::uint32_t sample_rate) {
         if (!channels || !sample_rate) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         int rule = 0;
         for (const Stage &st : stages_)
             if (st.span_rule) rule = st.span_rule;
-        if (rule == 2 && up_->current_span_len()) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::uniform behind take_duration / delay / channel_volume on a source that reports spans");
         // (rule 2 over a continuous upstream: the spans are the ones rodio's adapters report there -- TakeDuration's Some(what it still admits),
         // in chains of 32768 samples, ending with Some(0) in front of the silence that completes a cut frame -- computed at every bootstrap from
         // the adapters' sample counts: span_behind())
@@ -1189,6 +1202,7 @@ protected:
             follow_known_ = true;
             follow_spans_ = !span_aware_ && up_->current_span_len().has_value();
             if (follow_spans_) reader_ = detail::SpanReader(up_.get(), false);
+            for (const Stage &st : stages_) span_log_on_ = span_log_on_ || st.span_fn;
         }
         const std::size_t want = block_frames_ * cur_in_ch_;
         // The slot's page-locked staging block is about to be rewritten: the copy that read it two blocks ago must have run.  A host
@@ -1224,6 +1238,7 @@ protected:
                     runs.back().p1 = all.size() + 1;
                     piece_off.push_back(n);
                     all.push_back(pc);
+                    if (span_log_on_ && pc.src_opens) span_log_.emplace_back(in_total_ + n, pc.src_span);
                     n += pc.n;
                 }
                 if (reader_.ended() || !produced) break;
@@ -1238,6 +1253,8 @@ protected:
             flush = n < want;
             runs.push_back(Run{0, n, cur_in_ch_, cur_in_rate_, 0, 0});
         }
+        in_total_ += n;
+        up_ended_ = up_ended_ || flush;
         if (runs.empty()) runs.push_back(Run{0, 0, cur_in_ch_, cur_in_rate_, 0, 0});
         // capacity of the ping-pong buffers: the largest block any stage can emit
         pieces_.assign(all.begin(), all.end());
@@ -1435,25 +1452,15 @@ private:
     /// does anything to the spans is a take_duration / delay / channel_volume.  TakeDuration answers with what its duration still admits
     /// unless its input's span is shorter -- Some(..) over an input that says None too, and Some(0) once it is spent (take.rs:176-195);
     /// Delay adds the silence it still owes to its input's answer (delay.rs:94-98); ChannelVolume hands its input's answer on
-    /// (channel_volume.rs:103-105).  Computed from the adapters' sample counts, so only over an input that answers None whatever the
-    /// position (a generator, or what comes out of a Mix or a converter): over an upstream that reports spans the answer would depend
-    /// on where in ITS span the consumer asks -- refused, loudly, like every combination the counts do not cover.
-    std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos, bool at_cursor = false) const {
+    /// (channel_volume.rs:103-105).  Computed from the adapters' sample counts: every adapter maps the samples it has emitted to the
+    /// samples it has taken, down to the sample of the upstream the question reaches.  Combinations the counts do not cover
+    /// (ChannelVolume's change of the sample count between them, or over an upstream that reports spans) are refused, loudly.
+    std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos) const {
         std::size_t first = 0;
         for (std::size_t k = 0; k < upto; ++k)
             if (stages_[k].span_rule == 1) first = k + 1;
-        std::optional<std::size_t> ans;  // the answer in front of adapter `first`
-        if (first == 0 && up_->current_span_len().has_value()) {
-            // Over an upstream that reports spans the adapters ask IT, wherever the consumer asks them.  Where every adapter hands on one
-            // sample per sample (take_duration among amplify, the filters, ...) the chain knows the upstream's answer for the sample at
-            // its cursor (the block's marks: the answer the upstream gave when the span opened -- a SamplesBuffer, a decoder's packets:
-            // sources whose answer holds for the whole span); behind a delay or a channel_volume it does not.
-            if (!(at_cursor && spans_stay_in_place()))
-                throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind take_duration / delay / channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
-                                                "(put .uniform() in front of them, or hand the consumer the plain source)");
-            ans = format_at_cursor().span;
-        }
-        std::vector<std::uint64_t> at(upto + 1, 0);  // at[k + 1]: samples adapter k has emitted when the chain has emitted `pos`
+        const bool upstream_asked = first == 0 && up_->current_span_len().has_value();  // the adapters' questions reach an upstream that reports spans
+        std::vector<std::uint64_t> at(upto + 1, 0);  // at[k + 1]: samples adapter k has emitted when the chain has emitted `pos`; at[first]: samples taken from what lies in front
         at[upto] = pos;
         bool counts = false;
         for (std::size_t k = first; k < upto; ++k) counts = counts || stages_[k].span_fn;
@@ -1463,14 +1470,29 @@ private:
                 bool counted_in_front = false;
                 for (std::size_t j = first; j < k; ++j) counted_in_front = counted_in_front || stages_[j].span_fn;
                 if (counted_in_front) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len: channel_volume behind take_duration / delay (the span arithmetic across its change of the sample count is not mirrored)");
-                break;  // nothing in front of it counts: the answer there is None wherever the consumer asks
+                if (upstream_asked)
+                    throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
+                                                    "(put .uniform() in front of it, or hand the consumer the plain source)");
+                return std::nullopt;  // nothing in front of it counts: the answer there is None wherever the consumer asks
             }
             at[k] = st.span_in_pos ? st.span_in_pos(at[k + 1]) : at[k + 1];
         }
+        // Over an upstream that reports spans the adapters ask IT, wherever the consumer asks them: the chain keeps the upstream's answers
+        // by sample position (span_log_: what it answered when each of its spans opened -- a SamplesBuffer, a decoder's packets: sources
+        // whose answer holds for the whole span), and at[0] is the upstream sample the question reaches.
+        std::optional<std::size_t> ans = upstream_asked ? upstream_answer_at(at[0]) : std::nullopt;
         if (!counts) return ans;
         for (std::size_t k = first; k < upto; ++k)
             if (stages_[k].span_fn) ans = stages_[k].span_fn(ans, at[k + 1]);
         return ans;
+    }
+    std::optional<std::size_t> upstream_answer_at(std::uint64_t q) const {
+        if (span_log_.empty()) return up_->current_span_len();  // nothing pulled yet: the upstream itself
+        if (up_ended_ && q >= in_total_) return std::size_t(0);  // it has given everything (buffer.rs:76-82)
+        std::size_t i = 0;
+        while (i + 1 < span_log_.size() && span_log_[i + 1].first <= q) ++i;
+        span_log_.erase(span_log_.begin(), span_log_.begin() + (std::ptrdiff_t)i);  // (the questions only move forward)
+        return span_log_.front().second;
     }
     // Adapters that work on whole frames and carry state (BltFilter, Limit) over an input that may break off inside a frame: at the end of a
     // span (rodio's adapters run sample by sample -- blt.rs:431-451, limit.rs:927-988 -- and their channel position simply goes on into the
@@ -1633,6 +1655,11 @@ private:
     std::uint16_t in_ch0() const { return in_ch0_; }
     std::uint32_t in_rate0() const { return in_rate0_; }
     std::optional<std::size_t> open_span_;  // what current_span_len() answered for the span that is open
+    // (chains with take_duration / delay over an upstream that reports spans: span_behind()) the upstream's answers by the sample at which each
+    // of its spans opened, the samples pulled from it so far, and whether it has ended
+    mutable std::deque<std::pair<std::uint64_t, std::optional<std::size_t>>> span_log_;
+    std::uint64_t in_total_ = 0;
+    bool up_ended_ = false, span_log_on_ = false;
     std::uint16_t block_min_ch_ = 0;        // the fewest channels / the lowest rate among the pieces of the block being enqueued (0: none)
     std::uint32_t block_min_rate_ = 0;
     bool follow_spans_ = false, follow_known_ = false;  // the upstream reports spans: it is pulled span by span (asked once, at the first block)

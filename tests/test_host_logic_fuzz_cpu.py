@@ -789,8 +789,15 @@ def _span_arithmetic_case(O, tmp_path, seed, exe):
     rng = np.random.default_rng(88000 + seed)
     ch, rate = int(rng.choice([1, 2, 2, 3, 6])), int(rng.choice(RATES))
     frames = int(rng.integers(100, 60000))
-    x = M.rnd(88000 + seed, frames * ch, 0.4)
+    # ... and over sources that report spans themselves: the adapters ask THEM wherever the consumer asks the adapters (`min(the input's span,
+    # what the duration admits)`, `the input's span + the silence owed`), which the chain answers from the upstream's answers by sample position
+    kind = str(rng.choice(["test", "test", "buffer", "spans:1000", "spans:37", "spans:40000"]))
+    # (a SamplesBuffer may end inside a frame; the packet sources of this harness keep answering Some(packet) when they are exhausted, and what
+    # rodio's ChannelVolume returns when it is asked AGAIN after the None of a cut frame -- the stale sum, channel_volume.rs:71-88 -- is theirs alone)
+    x = M.rnd(88000 + seed, frames * ch + (int(rng.integers(0, ch)) if kind == "buffer" and rng.random() < 0.3 else 0), 0.4)
     x.tofile(tmp_path / "src_0.f32")
+    env = dict(os.environ, RH_TEST_SOURCE=kind)
+    in_chain = rng.random() < 0.5
     dur = lambda f: int(f * 1e9 / rate) + int(rng.integers(0, 30000))  # nanoseconds for about f frames
     ops = []
     for _ in range(int(rng.integers(1, 4))):
@@ -807,29 +814,35 @@ def _span_arithmetic_case(O, tmp_path, seed, exe):
             ops.append("limit")
         else:
             ops.append(f"fade_in:{dur(rng.integers(1, 2000))}")
+    if in_chain and rng.random() < 0.3:  # ChannelVolume hands its input's answer on although it changes the sample count (channel_volume.rs:103-105)
+        ops.insert(int(rng.integers(0, len(ops) + 1)), "channel_volume:" + ",".join(str(float(np.float32(g))) for g in rng.choice([0.25, 0.5, 1.0], int(rng.integers(1, 4)))))
     block = int(rng.choice([777, 4096, 40000]))
-    if rng.random() < 0.5:  # the chain's own iterator
+    if in_chain:  # the chain's own iterator
         ops = ops + [f"uniform:{int(rng.choice([1, 2, 6]))}:{int(rng.choice([22050, 44100, 48000]))}"] + (["amplify:0.5"] if rng.random() < 0.5 else [])
-        r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
-        what = (seed, (frames, ch, rate), ops, block)
-        ref = _oracle_full(O, O.TestSource(x, ch, rate), ops).collect()
+        r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300, env=env)
+        what = (seed, (frames, ch, rate), kind, ops, block)
+        ref = _oracle_full(O, M._span_source(O, kind, x, ch, rate, 0), ops).collect()
     else:  # the mixer's
         mixer_ch, to_rate, on_device = int(rng.choice([1, 2, 2, 6])), int(rng.choice([22050, 44100, 48000])), bool(rng.integers(0, 2))
         gain = float(np.float32(rng.choice([0.5, 1.0])))
         (tmp_path / "spec.txt").write_text(f"{ch} {rate} {gain} -1 0 {','.join(ops)}\n2 44100 0.5 -1 0 -\n")
         y = M.rnd(88500 + seed, 2 * 3000, 0.2)
         y.tofile(tmp_path / "src_1.f32")
-        r = subprocess.run([exe, "chainmix", str(tmp_path), "2", str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300)
-        what = (seed, (frames, ch, rate), ops, block, mixer_ch, to_rate, on_device)
+        r = subprocess.run([exe, "chainmix", str(tmp_path), "2", str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0"], capture_output=True, text=True, timeout=300, env=env)
+        what = (seed, (frames, ch, rate), kind, ops, block, mixer_ch, to_rate, on_device)
         m = O.Mixer(mixer_ch, to_rate)
-        m.add(O.UniformSourceIterator(_oracle_full(O, O.TestSource(x, ch, rate), ops).amplify(gain), mixer_ch, to_rate))
-        m.add(O.UniformSourceIterator(O.TestSource(y, 2, 44100).amplify(0.5), mixer_ch, to_rate))
+        m.add(O.UniformSourceIterator(_oracle_full(O, M._span_source(O, kind, x, ch, rate, 0), ops).amplify(gain), mixer_ch, to_rate))
+        m.add(O.UniformSourceIterator(M._span_source(O, kind, y, 2, 44100, 1).amplify(0.5), mixer_ch, to_rate))
         ref = m.collect()
     if r.returncode != 0:
         assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
         pytest.skip(f"refused: {r.stderr.strip()[:160]}")
     got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
     assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        nan = np.isnan(ref)  # (a fade-out over less than a millisecond is 0 / 0 in rodio: take.rs:33-38)
+        assert np.array_equal(np.isnan(got), nan), what
+        got, ref = got[~nan], ref[~nan]
     if len(ref):
         tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref))))
         assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
