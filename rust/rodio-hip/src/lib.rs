@@ -1291,7 +1291,7 @@ impl GpuMixer {
                 Some((ch, r)) => {
                     let want = g.target.saturating_sub(x.have_s / 2);
                     let in_frames = want * r as u64 / rate as u64 + 8;
-                    row_cap[i] = x.plan.held_samples() + in_frames as usize * ch as usize;
+                    row_cap[i] = x.plan.held_samples() + (in_frames as usize + 1) * ch as usize;   // (+ a frame: read_piece brings a cut frame's samples along with the last whole ones)
                     total += (row_cap[i] + 3) & !3;
                 }
             }
@@ -1325,7 +1325,9 @@ impl GpuMixer {
                 if now >= g.target { break; }
                 let slack = UniformPlanner::close_slack_frames(r, rate);                // what the span's end may add
                 let (need, most) = x.plan.budget(r, x.reader.opens_next(), g.target - now, (g.crow - now).saturating_sub(slack));
-                let n = need.min(most).min(((row_cap[i] - fill) / ch as usize) as u64) as usize;
+                // (whole frames that fit the row AND leave room for the up to ch - 1 samples of a frame the span's end cuts)
+                let room = if row_cap[i] - fill >= ch as usize { (row_cap[i] - fill - (ch as usize - 1)) / ch as usize } else { 0 };
+                let n = need.min(most).min(room as u64) as usize;
                 if n == 0 { break; }
                 let piece = x.reader.read_piece(x.up.src(), &mut row[fill..], n);   // straight into the staging block
                 if let Some(pc) = piece { fill += pc.n; x.plan.add(&pc, &mut segs); }
