@@ -1775,12 +1775,9 @@ public:
             return;
         }
         // (... and one whose span at hand does not hold whole frames -- a SamplesBuffer of an odd number of stereo samples, packets of 37.)
-        // A MONO mixer forms its mix in stereo and takes channel 0 of it, which is rodio's UniformSourceIterator(src, 1, rate) per source as
-        // long as every source's stereo stream keeps to whole frames; a span that ends inside a frame gives ONE sample either way
-        // (channels.rs:57-67) and what follows would sit in the wrong channel -- such a source is converted to mono by a chain of its own.
         const std::optional<std::size_t> span_now = src->current_span_len();
         const bool cuts = span_now.has_value() && ((32768u % ch) != 0 || (*span_now % ch) != 0);
-        const bool may_cut = cuts && (filter.kind >= 0 || out_ch_ == 1);
+        const bool may_cut = cuts && filter.kind >= 0;
         if ((filter.kind >= 0 && opt_.reference_exact_filters && !rh_filter_scan_ok(filter.kind, filter.freq, filter.q, rate_)) || may_cut) {
             // outside the filter contract: the source's own chain, the filter in the reference's order, the mixer only sums
             auto chain = std::make_unique<GpuSource>(std::move(src), opt_.block_frames);
@@ -2026,7 +2023,6 @@ private:
         detail::UniformPlanner plan;
         std::uint64_t have_s = 0, off_s = 0;  // converted SAMPLES not yet mixed: `have_s` of them from sample `off_s` of the source's device row
         std::uint64_t total_s = 0;            // samples of the source's stream in the mixer's layout so far (where the generation tracks them: Gen::track)
-        bool odd_close = false;               // ... a span has closed on an odd count of them (a mono mixer cannot go on behind that: pull_block_staged)
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
@@ -2055,6 +2051,8 @@ private:
         detail::DeviceBuf qm;              // ... which ChannelCountConverter(1 -> 2) (channels.rs:64-73) turns into the stereo queue, once per block
         // span-by-span generations (`staged`): the sources are converted to the mixer's format first, row by row
         bool staged = false;
+        std::size_t sch = 2;                 // ... in frames of this many channels: 2, or 1 for a mono mixer (UniformSourceIterator(src, 1, rate) per source: a span that ends
+                                             // inside a frame gives one sample either way, channels.rs:57-67, so the mono stream cannot be had from a stereo one)
         std::uint64_t target = 0, crow = 0;  // converted frames a block tops every row up to; capacity of a row (frames)
         detail::DeviceBuf conv[2], dtab;     // converted rows (ping-pong: what a block leaves moves to the front of the other set); segment table
         detail::PinnedBuf tab[2];
@@ -2241,7 +2239,8 @@ private:
         g.srcs = std::move(srcs);
         g.filt = g.srcs.front().filt;  // (one filter per stream: start_generation / late_join group by it)
         g.staged = staged;
-        g.mono = mono && !staged;
+        g.sch = staged && out_ch_ == 1 ? 1 : 2;
+        g.mono = staged ? g.sch == 1 : mono;
         const std::uint32_t from = staged ? rate_ : g.srcs.front().up->sample_rate();  // staged: the fused kernel sees converted rows
         rh_rlm_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
@@ -2259,7 +2258,7 @@ private:
             g.crow = g.target + 64;
             for (Src &x : g.srcs) {
                 x.reader = detail::SpanReader(x.up.get());
-                x.plan = detail::UniformPlanner(2, rate_);
+                x.plan = detail::UniformPlanner((std::uint16_t)g.sch, rate_);
             }
             const std::size_t crowf = ((std::size_t)g.crow * 2 + 3) & ~std::size_t(3);
             for (auto &b : g.conv) b.reset(g.srcs.size() * crowf);
@@ -2432,7 +2431,7 @@ private:
                     x.ended = true;
                     break;
                 }
-                const std::uint64_t now = (x.have_s + x.plan.out_samples() + 1) / 2;
+                const std::uint64_t now = (x.have_s + x.plan.out_samples() + g.sch - 1) / g.sch;
                 if (now >= g.target) break;
                 std::uint64_t need = 0, most = 0;
                 const std::uint64_t slack = detail::UniformPlanner::close_slack_frames(rate, rate_);  // what the span's end may add
@@ -2447,10 +2446,6 @@ private:
                 if (produced) {
                     fill += pc.n;
                     x.plan.add(pc, segs);
-                    if (out_ch_ == 1) {  // (see add(): the stereo stream of a mono mixer's source keeps to whole frames, or ends)
-                        if (x.odd_close && pc.n) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a mono mixer over a source whose span ended inside a frame after spans of whole frames (source/mod.rs:196-200)");
-                        if (pc.closes) x.odd_close = ((x.total_s + x.plan.out_samples()) & 1) != 0;
-                    }
                 }
                 if (x.reader.ended()) {
                     x.ended = true;
@@ -2469,7 +2464,7 @@ private:
             }
             x.have_s += x.plan.out_samples();
             x.total_s += x.plan.out_samples();
-            if (x.have_s + 1 > g.crow * 2) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
+            if (x.have_s + g.sch - 1 > g.crow * g.sch) throw Error(RH_ERR_CAPACITY, "GpuMixer: converted frames exceed the row");
         });
         for (std::size_t i = 0; i < S; ++i)
             for (const rh_uniform_seg &t : planned[i]) {
@@ -2506,25 +2501,32 @@ private:
             Src &x = g.srcs[i];
             x.off_s = 0;
             ptrs[i] = g.conv[nc].get() + i * crowf;
-            if (x.ended && (x.have_s & 1)) {
+            if (g.sch == 2 && x.ended && (x.have_s & 1)) {
                 // the source's stream ends inside a frame: rodio's mixer adds its last sample and, at the next one, finds the source gone
                 // (mixer.rs:185-198).  Adding +0.0 for the missing sample leaves the sum as it is -- through a filter it would not.
                 if (g.filt.kind >= 0) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a filtered source of 1, 2, 4 or 8 channels whose stream ends inside a frame (its spans do not hold whole frames: source/mod.rs:196-200)");
                 check(rh_memset(g.conv[nc].get() + i * crowf + x.have_s, 0, sizeof(float), stream_), "rh_memset");
                 x.have_s += 1;
             }
-            avail[i] = x.have_s / 2;
+            avail[i] = x.have_s / g.sch;
             ended[i] = x.ended ? 1 : 0;
             all_ended = all_ended && x.ended;
         }
         std::uint64_t out = 0, consumed = 0;
-        check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
-              "rh_rlm_stream_block_v");
+        if (g.mono) {  // the mono mix of the block, then ChannelCountConverter(1 -> 2) behind the stereo queue (send_block takes channel 0 of it again)
+            g.qm.reset(out_cap_frames_ * 2);
+            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.qm.get(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+                  "rh_rlm_stream_block_v");
+            if (out) check(rh_channels_convert(g.queue_end(), g.qm.get(), (std::size_t)out, 1, 2, stream_), "rh_channels_convert");
+        } else {
+            check(rh_rlm_stream_block_v(g.plan, ptrs.data(), avail.data(), ended.data(), (std::uint32_t)S, g.queue_end(), out_cap_frames_ * 2 - g.fill - g.head, &out, &consumed, stream_),
+                  "rh_rlm_stream_block_v");
+        }
         g.fill += out;
         for (Src &x : g.srcs) {
-            const std::uint64_t d = std::min(consumed, x.have_s / 2);
-            x.off_s = d * 2;
-            x.have_s -= d * 2;
+            const std::uint64_t d = std::min(consumed, x.have_s / g.sch);
+            x.off_s = d * g.sch;
+            x.have_s -= d * g.sch;
         }
         g.done = all_ended;  // the call that saw every source ended emitted everything that was left
     }

@@ -486,6 +486,57 @@ int main(int argc, char **argv) {
                 mixer.add(make_source(2, from, read_f32(dir + "/src_" + std::to_string(i) + ".f32")), gains.at((size_t)i));
             if (mixer.channels() != 2 || mixer.sample_rate() != to) throw std::runtime_error("format");
             out = drain(mixer);
+        } else if (mode == "latechain" && argc == 10) {
+            // host_mirror_test latechain <dir> <S0> <S1> <mixer_channels> <to_rate> <block_frames> <on_device 0|1> <pull_first>: `chainmix`'s sources
+            // (spec.txt: "channels rate gain filter_kind filter_freq op,op,..."), the last S1 of them added to the RUNNING mixer as `latewide` does
+            const int S0 = std::atoi(argv[3]), S1 = std::atoi(argv[4]);
+            const uint16_t mch = (uint16_t)std::atoi(argv[5]);
+            const uint32_t to = (uint32_t)std::atoll(argv[6]);
+            rh::GpuMixer::Options opt;
+            opt.block_frames = block_arg(argv[7]);
+            const bool on_device = std::atoi(argv[8]) != 0;
+            const size_t pull_first = (size_t)std::atoll(argv[9]);
+            std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
+            if (!sf) throw std::runtime_error("spec.txt");
+            rh::GpuMixer mixer(mch, to, opt);
+            auto add = [&](int i) {
+                unsigned ch = 0, rate = 0, ffreq = 0;
+                int fkind = -1;
+                float gain = 1.0f;
+                char ops[1024];
+                if (std::fscanf(sf, "%u %u %f %d %u %1023s", &ch, &rate, &gain, &fkind, &ffreq, ops) != 6) throw std::runtime_error("spec.txt: short");
+                rh::BoxSource src = make_source((uint16_t)ch, rate, read_f32(dir + "/src_" + std::to_string(i) + ".f32"), i);
+                const rh::GpuMixer::Filter filt{fkind, ffreq, 0.5f};
+                if (std::string(ops) == "-") {
+                    mixer.add(std::move(src), gain, filt);
+                } else {
+                    auto g = std::make_unique<rh::GpuSource>(std::move(src), opt.block_frames);
+                    for (const std::string &o : split(ops, ',')) apply_op(*g, o);
+                    if (on_device) mixer.add(std::move(g), gain, filt);
+                    else mixer.add(rh::BoxSource(std::move(g)), gain, filt);
+                }
+            };
+            for (int i = 0; i < S0; ++i) add(i);
+            for (size_t k = 0; k < pull_first; ++k) {
+                const std::optional<float> v = mixer.next();
+                if (!v) break;
+                out.push_back(*v);
+            }
+            for (int i = S0; i < S0 + S1; ++i) add(i);
+            std::fclose(sf);
+            int nones = 0;
+            std::optional<float> v;
+            while (nones < 16 && !(v = mixer.next())) ++nones;
+            if (v) {
+                out.push_back(*v);
+                const std::vector<float> rest = drain(mixer);
+                out.insert(out.end(), rest.begin(), rest.end());
+            }
+            std::FILE *nf = std::fopen((dir + "/nones.txt").c_str(), "w");
+            if (nf) {
+                std::fprintf(nf, "%d\n", nones);
+                std::fclose(nf);
+            }
         } else if (mode == "chainmix" && argc == 8) {
             // host_mirror_test chainmix <dir> <S> <mixer_channels> <to_rate> <block_frames> <on_device 0|1>
             //   <dir>/spec.txt, one line per source: "channels rate gain filter_kind filter_freq op,op,..." ("-" = no adapters: the source

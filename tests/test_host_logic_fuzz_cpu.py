@@ -858,3 +858,82 @@ def test_random_takes_and_delays_in_front_of_an_iterator_that_asks_for_spans(O, 
 @pytest.mark.parametrize("seed", list(range(0, 60, 3)))
 def test_gpu_random_takes_and_delays_in_front_of_an_iterator_that_asks_for_spans(O, tmp_path, seed):
     _span_arithmetic_case(O, tmp_path, seed, M.EXE)
+
+
+# ------------------------------------------------------------------ ... and chains and filtered sources added to a RUNNING mixer ----
+def _late_chains_case(O, tmp_path, seed, exe):
+    """`_mixer_chains_case` + `_late_case`: one to three sources -- plain, with a filter of their own, or chains of the whole vocabulary, handed over
+    on the device or through the host -- play in a mixer of 1, 2 or 6 channels; after `pull_first` samples one or two more are added
+    (mixer.rs:175-183: admitted at the next frame), sources of any span kind.  Samples and the Nones in between as rodio's mixer returns them."""
+    rng = np.random.default_rng(58000 + seed)
+    S0, S1 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    mixer_ch, to_rate = int(rng.choice([1, 2, 2, 6])), int(rng.choice([22050, 44100, 48000]))
+    block, on_device = int(rng.choice([777, 4096, 7000])), bool(rng.integers(0, 2))
+    kind = str(rng.choice(["test", "buffer", "mixed", "spans:1000", "spans:37"]))
+    lines, adds = [], []
+    for i in range(S0 + S1):
+        ch0, rate0, gain = int(rng.choice([1, 2, 2, 6])), int(rng.choice(RATES)), float(np.float32(rng.choice([0.5, 0.8, 1.0])))
+        x = M.rnd(58000 + 100 * seed + i, int(rng.integers(1, 9000)) * ch0, 0.2)
+        x.tofile(tmp_path / f"src_{i}.f32")
+        ops = [o for o in _full_ops(rng, ch0, int(rng.integers(1, 3)), False) if not o.startswith("channel_volume")] if rng.random() < 0.6 else []
+        fk, ff = (int(rng.integers(0, 2)), int(rng.choice([300, 1000, 3000]))) if (mixer_ch <= 2 and rng.random() < 0.3) else (-1, 0)
+        lines.append(f"{ch0} {rate0} {gain} {fk} {ff} {','.join(ops) if ops else '-'}\n")
+        adds.append((x, ch0, rate0, i, ops, gain, fk, ff))
+    (tmp_path / "spec.txt").write_text("".join(lines))
+
+    def chain(a):
+        x, ch0, rate0, i, ops, gain, fk, ff = a
+        u = O.UniformSourceIterator(_oracle_full(O, M._span_source(O, kind, x, ch0, rate0, i), ops).amplify(gain), mixer_ch, to_rate)
+        return u.low_pass(ff) if fk == 0 else u.high_pass(ff) if fk == 1 else u
+
+    m0 = O.Mixer(mixer_ch, to_rate)
+    for a in adds[:S0]:
+        m0.add(chain(a))
+    total0 = len(m0.collect())
+    pull_first = int(rng.integers(0, max(1, int(total0 * 1.2)) + 1))
+    m = O.Mixer(mixer_ch, to_rate)
+    for a in adds[:S0]:
+        m.add(chain(a))
+    ref = []
+    for _ in range(pull_first):
+        v = m.next()
+        if v is None:
+            break
+        ref.append(v)
+    for a in adds[S0:]:
+        m.add(chain(a))
+    nones, v = 0, None
+    while nones < 16:
+        v = m.next()
+        if v is not None:
+            break
+        nones += 1
+    ref = np.concatenate([np.asarray(ref + [v], dtype=np.float32), m.collect()]) if v is not None else np.asarray(ref, dtype=np.float32)
+    r = subprocess.run([exe, "latechain", str(tmp_path), str(S0), str(S1), str(mixer_ch), str(to_rate), str(block), "1" if on_device else "0", str(pull_first)], capture_output=True,
+                       text=True, timeout=300, env=dict(os.environ, RH_TEST_SOURCE=kind))
+    what = (seed, S0, S1, mixer_ch, to_rate, block, on_device, kind, pull_first, total0, lines)
+    if r.returncode != 0:
+        assert r.returncode == 1 and "unsupported" in r.stderr.lower(), (what, r.stderr)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    assert len(got) == len(ref), (what, len(got), len(ref))
+    if len(ref):
+        nan = np.isnan(ref)  # (a fade-out over less than a millisecond is 0 / 0 in rodio: take.rs:33-38)
+        assert np.array_equal(np.isnan(got), nan), what
+        got, ref = got[~nan], ref[~nan]
+    if len(ref):
+        tol = 2 * TOL * max(1.0, float(np.max(np.abs(ref)))) * (8 if any("agc" in l or "distortion" in l for l in lines) else 1)
+        assert float(np.max(np.abs(got - ref))) <= tol, (what, float(np.max(np.abs(got - ref))), int(np.argmax(np.abs(got - ref))))
+    assert int((tmp_path / "nones.txt").read_text()) == nones, what
+
+
+@pytest.mark.parametrize("seed", list(range(48)) + [611])
+def test_random_chains_and_filtered_sources_join_a_running_mixer(O, tmp_path, seed):
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _late_chains_case(O, tmp_path, seed, FAKE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(0, 48, 4)) + [611])
+def test_gpu_random_chains_and_filtered_sources_join_a_running_mixer(O, tmp_path, seed):
+    _late_chains_case(O, tmp_path, seed, M.EXE)
