@@ -879,10 +879,23 @@ public:
         const std::uint16_t out_ch = (std::uint16_t)gains.size();
         if (!out_ch) throw std::invalid_argument("channel_volume: no output channels");
         auto rg = std::make_shared<Regroup>();
-        push([gains, in_ch, out_ch, rg](Ctx &c) {
+        auto emitted = std::make_shared<std::uint64_t>(0);
+        const std::size_t self = stages_.size();
+        push([this, gains, in_ch, out_ch, rg, emitted, self](Ctx &c) {
             return run_grouped(c, in_ch, *rg, [&](const float *in, std::size_t n) {
                 const std::size_t frames = n / in_ch;  // (a frame the stream ends in is dropped: `input.next()?`, channel_volume.rs:71-79)
                 check(rh_channel_volume(c.out, in, frames, in_ch, gains.data(), out_ch, c.stream), "rh_channel_volume");
+                *emitted += frames * out_ch;
+                if (n % in_ch) {
+                    // ... and rodio's ChannelVolume is left with its channel position at 0 and the sum of the samples it did get: asked AGAIN
+                    // after that None -- a UniformSourceIterator does ask, once, unless the adapter says Some(0) -- it returns one more frame
+                    // made of that stale sum (:71-88).  Where the answer there is Some(0) (a SamplesBuffer that has given everything)
+                    // nobody asks; where it is not, the drop-in does not guess who is listening.
+                    const std::optional<std::size_t> after = span_behind(self + 1, *emitted + 1);  // (the frame it began: its input has given everything)
+                    if (!(after && *after == 0))
+                        throw Error(RH_ERR_UNSUPPORTED, "GpuSource::channel_volume: its input ends inside a frame and its current_span_len() there is not Some(0): what rodio's ChannelVolume "
+                                                        "returns next depends on whether its consumer asks again (channel_volume.rs:71-88)");
+                }
                 return frames * out_ch;
             });
         }, [in_ch, out_ch](std::size_t n) { return (n / in_ch + 1) * out_ch; }).on_seek([rg](Nanos) { rg->n = 0; })
@@ -1246,10 +1259,8 @@ protected:
             flush = reader_.ended();
         } else {
             n = up_->read(s.in.get(), want);
-            // sources end on frame boundaries (source/mod.rs:169-178).  One that reports no spans and ends inside a frame all the same is
-            // refused: rodio would play the cut frame's samples, this path converts whole frames only (a source that REPORTS its spans may
-            // end anywhere: the branch above)
-            if (n % cur_in_ch_) throw Error(RH_ERR_UNSUPPORTED, "GpuSource: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
+            // (sources end on frame boundaries, source/mod.rs:169-178; one that does not hands its cut frame to the adapters as a spanned one
+            // does: they carry open frames anyway)
             flush = n < want;
             runs.push_back(Run{0, n, cur_in_ch_, cur_in_rate_, 0, 0});
         }

@@ -302,17 +302,19 @@ def _oracle_full(O, src, ops):
     return src
 
 
-def _full_case(O, tmp_path, seed, exe, dither=True):
+def _full_case(O, tmp_path, seed, exe, dither=True, partial=False):
     rng = np.random.default_rng(66000 + seed)
-    ch = int(rng.choice([1, 1, 2, 2, 3, 6]))
+    ch = int(rng.choice([1, 1, 2, 2, 3, 6]) if not partial else rng.choice([2, 2, 3, 6]))
     rate = int(rng.choice(RATES))
-    n = int(rng.integers(1, 12000)) * ch
+    n = int(rng.integers(1, 12000)) * ch + (int(rng.integers(1, ch)) if partial else 0)
     x = M.rnd(66000 + seed, n, 0.5)
     ops = _full_ops(rng, ch, int(rng.integers(1, 5)), dither)
     block = int(rng.choice([64, 777, 4096, 16384]))
     x.tofile(tmp_path / "src_0.f32")
     r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
     what = (seed, (n, ch, rate), ops, block)
+    if partial and r.returncode == 1 and "channel_volume" in r.stderr and "unsupported" in r.stderr.lower():
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")  # (what ChannelVolume returns after the None of a cut frame depends on who asks again)
     assert r.returncode == 0, (what, r.stderr)
     got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
     ref_src = _oracle_full(O, O.TestSource(x, ch, rate), ops)
@@ -344,6 +346,14 @@ FULL_SEEDS = list(range(int(os.environ.get("RH_FUZZ_FULL", "40"))))
 def test_random_chain_of_any_adapters(O, tmp_path, seed):
     assert os.path.exists(FAKE), "run python rodio_amd/build.py"
     _full_case(O, tmp_path, seed, FAKE, dither=False)
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_chain_over_a_continuous_source_that_ends_inside_a_frame(O, tmp_path, seed):
+    """A source that reports no spans and ends inside a frame all the same (source/mod.rs:169-178 asks for whole frames; a truncated file
+    decodes to one): the adapters carry the open frame as they do for a span that ends inside one.  Was: refused."""
+    assert os.path.exists(FAKE), "run python rodio_amd/build.py"
+    _full_case(O, tmp_path, seed, FAKE, dither=False, partial=True)
 
 
 @pytest.mark.gpu
