@@ -1066,7 +1066,7 @@ public:
                 // (the block's pieces may come in other formats than the chain was built for: the fewest channels and the lowest rate among them bound it)
                 const std::uint64_t ich = one_span ? in_ch : std::min<std::uint64_t>(in_ch, block_min_ch_ ? block_min_ch_ : in_ch), ifrom = one_span ? from : std::min<std::uint64_t>(from, block_min_rate_ ? block_min_rate_ : from);
                 const std::uint64_t f = n / ich + 1;
-                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((computed ? n / 32768 + 2 : one_span ? 1 : pieces_.size()) + 2) + 1) * channels;
+                return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((computed ? pieces_.size() * ((in_ch + in_ch0() - 1) / in_ch0()) + n / 32768 + 4 : one_span ? 1 : pieces_.size()) + 2) + 1) * channels;  // (computed: a span of the upstream per piece -- more where a channel_volume in between made more samples of them --, the cuts at 32768, a take's end)
             })
             .on_seek([plan, part_n, started, cs, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
                 *plan = detail::UniformPlanner(channels, sample_rate);
@@ -1266,6 +1266,14 @@ protected:
         }
         in_total_ += n;
         up_ended_ = up_ended_ || flush;
+        if (span_log_.size() > 4096) {  // nobody has asked for a while: what lies in front of the sample the consumer's cursor reaches is not asked for any more
+            std::uint64_t q = handed_out();
+            for (std::size_t k = stages_.size(); k-- > 0;)
+                if (stages_[k].span_in_pos) q = stages_[k].span_in_pos(q);
+            std::size_t i = 0;
+            while (i + 1 < span_log_.size() && span_log_[i + 1].first <= q) ++i;
+            span_log_.erase(span_log_.begin(), span_log_.begin() + (std::ptrdiff_t)i);
+        }
         if (runs.empty()) runs.push_back(Run{0, 0, cur_in_ch_, cur_in_rate_, 0, 0});
         // capacity of the ping-pong buffers: the largest block any stage can emit
         pieces_.assign(all.begin(), all.end());
