@@ -1354,7 +1354,7 @@ protected:
             if ((span_aware_ || follow_spans_) && !ends) {
                 if (reader_.peek(nch, nrate)) reader_.source_format(nch, nrate, nspan);
             }
-            if (ends && follow_spans_) nspan = 0;  // a source that has given everything answers Some(0) (buffer.rs:76-82)
+            if (ends && follow_spans_) nspan = reader_.ended() ? up_->current_span_len() : std::optional<std::size_t>(0);  // a source that has given everything stands where the question reaches it: Some(0) from a SamplesBuffer (buffer.rs:76-82)
             const bool as_built = fixed || (nch == in_ch0() && nrate == in_rate0());
             s.next = FormatMark{n, as_built ? ch_ : nch, as_built ? rate_ : nrate, counted ? nspan : std::nullopt};
         }
@@ -1507,7 +1507,7 @@ private:
     }
     std::optional<std::size_t> upstream_answer_at(std::uint64_t q) const {
         if (span_log_.empty()) return up_->current_span_len();  // nothing pulled yet: the upstream itself
-        if (up_ended_ && q >= in_total_) return std::size_t(0);  // it has given everything (buffer.rs:76-82)
+        if (up_ended_ && q >= in_total_) return up_->current_span_len();  // it has given everything, and stands where the question reaches it: Some(0) from a SamplesBuffer (buffer.rs:76-82)
         std::size_t i = 0;
         while (i + 1 < span_log_.size() && span_log_[i + 1].first <= q) ++i;
         span_log_.erase(span_log_.begin(), span_log_.begin() + (std::ptrdiff_t)i);  // (the questions only move forward)

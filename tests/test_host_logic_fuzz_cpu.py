@@ -801,7 +801,7 @@ def _span_arithmetic_case(O, tmp_path, seed, exe):
     frames = int(rng.integers(100, 60000))
     # ... and over sources that report spans themselves: the adapters ask THEM wherever the consumer asks the adapters (`min(the input's span,
     # what the duration admits)`, `the input's span + the silence owed`), which the chain answers from the upstream's answers by sample position
-    kind = str(rng.choice(["test", "test", "buffer", "spans:1000", "spans:37", "spans:40000"]))
+    kind = str(rng.choice(["test", "test", "buffer", "spans:1000", "spans:37", "spans:40000", "spans:5"]))
     # (a SamplesBuffer may end inside a frame; the packet sources of this harness keep answering Some(packet) when they are exhausted, and what
     # rodio's ChannelVolume returns when it is asked AGAIN after the None of a cut frame -- the stale sum, channel_volume.rs:71-88 -- is theirs alone)
     x = M.rnd(88000 + seed, frames * ch + (int(rng.integers(0, ch)) if kind == "buffer" and rng.random() < 0.3 else 0), 0.4)
