@@ -19,7 +19,11 @@
 // (it has no numeric tests for them): biquad, AGC, reverb, spatial gains,
 // amplify, limiter (range tests only), sample-type conversion (dasp_sample
 // 0.11.0, an un-vendored dependency: formulas restated from the published
-// crate).  Those rows are "parity unpinned" -- see DESIGN.md.
+// crate).  Those rows are "parity unpinned" -- see DESIGN.md.  So are the adapters' answers to
+// current_span_len() (TakeDuration: take.rs:176-195, Delay: delay.rs:94-98, ChannelVolume:
+// channel_volume.rs:103-105): the reference has no test for them, the cases in
+// tests/test_oracle_golden.py are derived by hand from those lines (round 5 found TakeDuration's
+// restated wrongly -- the input's answer handed through -- by reading them again).
 //
 // Citations are file:line under /root/reference.
 
