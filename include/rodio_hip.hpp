@@ -958,7 +958,7 @@ public:
     /// continuous.  Behind take_duration / delay the spans are the ones rodio's adapters report there (TakeDuration:
     /// Some(what it still admits) unless the input's span is shorter -- so chains of 32768 samples over a generator -- and
     /// Some(0) in front of the silence that completes a cut frame; Delay: the input's answer plus the silence it still owes:
-    /// span_behind()); behind channel_volume over an upstream that reports spans the iterator is refused.
+    /// span_behind(); ChannelVolume: its input's answer, counted in the input's samples).
     GpuSource &uniform(std::uint16_t channels, std::uint32_t sample_rate) {
         if (!channels || !sample_rate) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         int rule = 0;
@@ -1472,8 +1472,8 @@ private:
     /// unless its input's span is shorter -- Some(..) over an input that says None too, and Some(0) once it is spent (take.rs:176-195);
     /// Delay adds the silence it still owes to its input's answer (delay.rs:94-98); ChannelVolume hands its input's answer on
     /// (channel_volume.rs:103-105).  Computed from the adapters' sample counts: every adapter maps the samples it has emitted to the
-    /// samples it has taken, down to the sample of the upstream the question reaches.  Combinations the counts do not cover
-    /// (ChannelVolume's change of the sample count between them, or over an upstream that reports spans) are refused, loudly.
+    /// samples it has taken, down to the sample of the upstream the question reaches (whose answers the chain keeps by sample
+    /// position: span_log_).  An adapter with rule 2 and no such mapping would be refused, loudly (there is none at present).
     std::optional<std::size_t> span_behind(std::size_t upto, std::uint64_t pos) const {
         std::size_t first = 0;
         for (std::size_t k = 0; k < upto; ++k)
@@ -1485,15 +1485,8 @@ private:
         for (std::size_t k = first; k < upto; ++k) counts = counts || stages_[k].span_fn;
         for (std::size_t k = upto; k-- > first;) {
             const Stage &st = stages_[k];
-            if (st.span_rule == 2 && !st.span_fn) {  // ChannelVolume: another sample count, the input's answer
-                bool counted_in_front = false;
-                for (std::size_t j = first; j < k; ++j) counted_in_front = counted_in_front || stages_[j].span_fn;
-                if (counted_in_front) throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len: channel_volume behind take_duration / delay (the span arithmetic across its change of the sample count is not mirrored)");
-                if (upstream_asked)
-                    throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind channel_volume on a source that reports spans: rodio's span arithmetic there is not mirrored "
-                                                    "(put .uniform() in front of it, or hand the consumer the plain source)");
-                return std::nullopt;  // nothing in front of it counts: the answer there is None wherever the consumer asks
-            }
+            if (st.span_rule == 2 && !st.span_fn)  // (an adapter that changes the sample count and says nothing about how: none at present)
+                throw Error(RH_ERR_UNSUPPORTED, "GpuSource::current_span_len behind an adapter whose span arithmetic is not mirrored");
             at[k] = st.span_in_pos ? st.span_in_pos(at[k + 1]) : at[k + 1];
         }
         // Over an upstream that reports spans the adapters ask IT, wherever the consumer asks them: the chain keeps the upstream's answers
