@@ -9,7 +9,7 @@
 // ("device memory" is host memory, streams and events are no-ops), with the arithmetic of the reference restated in the
 // reference's order (like oracle/rodio_oracle.cpp, whose iterator classes it does not use: the C ABI works on blocks with
 // carried state, so the loops are written block-wise here).  Entry points the host mirror does not call are absent, and the
-// ones without host logic of their own (rh_dither) answer RH_ERR_UNSUPPORTED.  The fused stream (rh_rlm_stream_block_v) is emulated by its CONTRACT (whole
+// every adapter of the mirror has its entry point here (rh_dither with the counter-based noise the header states).  The fused stream (rh_rlm_stream_block_v) is emulated by its CONTRACT (whole
 // tiles while sources are live, everything once all have ended, one common *consumed_frames), not by its kernels.
 //
 // Build: g++ -std=c++17 -O2 -ffp-contract=off -I include tests/cpp/host_mirror_test.cpp tests/cpp/fake_device.cpp -o tests/cpp/host_mirror_test_fake
@@ -169,7 +169,38 @@ rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, floa
     }
     return RH_OK;
 }
-rh_status rh_dither(float *, const float *, size_t, uint64_t, uint32_t, uint32_t, int32_t, uint64_t, rh_stream) { return RH_ERR_UNSUPPORTED; }  // (no host logic beyond a sample counter: tested on the real library)
+// dither.rs:217-242 with the counter-based noise rodio_hip.h states for rh_dither (the noise of sample k = sample_offset + i is a function of (seed, k))
+static uint64_t dither_mix(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+rh_status rh_dither(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels, uint32_t target_bits, int32_t algorithm, uint64_t seed, rh_stream) {
+    if (!channels || target_bits < 1 || target_bits > 32 || algorithm < 0 || algorithm > 3) return RH_ERR_INVALID;
+    const float lsb = (float)(1.0 / (double)(1ull << (target_bits - 1)));
+    auto bits_at = [seed](uint64_t k) { return dither_mix(seed ^ dither_mix(k + 1)); };
+    auto u1 = [](uint64_t h) { return (float)((int32_t)(h >> 40) - 8388608) * 1.1920928955078125e-07f; };
+    auto u2 = [](uint64_t h) { return (float)((int32_t)((h >> 16) & 0xffffffu) - 8388608) * 1.1920928955078125e-07f; };
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t k = sample_offset + i, h = bits_at(k);
+        float noise;
+        if (algorithm == 3) {
+            noise = (u1(h) + u2(h)) * 0.5f;
+        } else if (algorithm == 2) {
+            noise = u1(h);
+        } else if (algorithm == 1) {
+            noise = u1(h) - (k >= channels ? u1(bits_at(k - channels)) : 0.0f);
+        } else {
+            const float a = (float)((uint32_t)(h >> 40) + 1u) * 5.9604644775390625e-08f, b = (float)((uint32_t)(h >> 16) & 0xffffffu) * 5.9604644775390625e-08f;
+            noise = std::sqrt(-2.0f * std::log(a)) * std::cos(6.2831853071795864769f * b) * 0.6f;
+        }
+        dst[i] = src[i] - noise * lsb;
+    }
+    return RH_OK;
+}
 // linear_ramp.rs:79-110, sample by sample from the start of the stream (the entry point is stateless: sample_offset says where the block lies;
 // a test's streams are short enough to walk)
 rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, float start_gain, float end_gain,
