@@ -799,6 +799,14 @@ public:
     /// silence in SAMPLES (delay.rs:14: every second stereo reverb ends inside a frame), and `uniform` over spans that cut frames hands
     /// on what rodio's converters make of the cut.  A consumer that works on whole frames (GpuMixer's fused streams) asks.
     bool may_end_inside_a_frame() const { return may_cut_; }
+    /// The chain's current_span_len() comes from an adapter's own arithmetic (take_duration, delay, channel_volume: span_behind()): a consumer
+    /// that asks -- a UniformSourceIterator, a mixer -- converts it in the chains those answers make, and stops where they say Some(0).
+    bool answers_with_adapter_spans() const {
+        int rule = 0;
+        for (const Stage &st : stages_)
+            if (st.span_rule) rule = st.span_rule;
+        return rule == 2;
+    }
     /// `try_seek` through the chain, adapter by adapter as rodio does it: an adapter that cannot seek (reverb = Mix,
     /// mix.rs:116-120) fails the call before anything moved; otherwise the upstream seeks, what was pulled and processed
     /// ahead is dropped, and every adapter does to its state what its `try_seek` does -- filters and the limiter start
@@ -1812,7 +1820,12 @@ public:
 private:
     // A chain whose stream can end inside a frame and is not yet what Mixer::add would make of it (see add(chain))
     bool completes_with_uniform(const GpuSource &gs, float gain, const Filter &filter) const {
-        return !wide() && !gs.started() && gs.may_end_inside_a_frame() && !(gs.channels() == out_ch_ && gs.sample_rate() == rate_ && gain == 1.0f && filter.kind < 0);
+        // (... or whose spans are an adapter's own -- take_duration's Some(what it still admits), Some(0) in front of the silence that completes a cut
+        // frame --: its own `uniform` computes them where rodio's iterator asks, and the result stays on the device; pulled through the host the
+        // mixer's reader would ask the same questions)
+        if (wide() || gs.started()) return false;
+        if (gs.answers_with_adapter_spans()) return true;
+        return gs.may_end_inside_a_frame() && !(gs.channels() == out_ch_ && gs.sample_rate() == rate_ && gain == 1.0f && filter.kind < 0);
     }
 
 public:
