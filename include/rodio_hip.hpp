@@ -799,6 +799,10 @@ public:
     /// silence in SAMPLES (delay.rs:14: every second stereo reverb ends inside a frame), and `uniform` over spans that cut frames hands
     /// on what rodio's converters make of the cut.  A consumer that works on whole frames (GpuMixer's fused streams) asks.
     bool may_end_inside_a_frame() const { return may_cut_; }
+    /// The stream has ended where rodio's ChannelVolume would return one more frame -- made of a stale sum -- to a consumer that asks again after
+    /// its None (channel_volume.rs:71-88: its input ended inside a frame).  A consumer that stops at None has everything; one that would ask
+    /// again (UniformSourceIterator does, once: a mixer) refuses the chain.
+    bool ended_with_a_stale_frame() const { return stale_frame_; }
     /// The chain's current_span_len() comes from an adapter's own arithmetic (take_duration, delay, channel_volume: span_behind()): a consumer
     /// that asks -- a UniformSourceIterator, a mixer -- converts it in the chains those answers make, and stops where they say Some(0).
     bool answers_with_adapter_spans() const {
@@ -899,10 +903,16 @@ public:
                     // after that None -- a UniformSourceIterator does ask, once, unless the adapter says Some(0) -- it returns one more frame
                     // made of that stale sum (:71-88).  Where the answer there is Some(0) (a SamplesBuffer that has given everything)
                     // nobody asks; where it is not, the drop-in does not guess who is listening.
+                    // Adapters that pass samples on one by one end with it; an iterator or a Mix behind it in the chain asks again (refused), and so
+                    // does a mixer the chain was handed to (which looks at ended_with_a_stale_frame()).
                     const std::optional<std::size_t> after = span_behind(self + 1, *emitted + 1);  // (the frame it began: its input has given everything)
-                    if (!(after && *after == 0))
-                        throw Error(RH_ERR_UNSUPPORTED, "GpuSource::channel_volume: its input ends inside a frame and its current_span_len() there is not Some(0): what rodio's ChannelVolume "
-                                                        "returns next depends on whether its consumer asks again (channel_volume.rs:71-88)");
+                    if (!(after && *after == 0)) {
+                        for (std::size_t k = self + 1; k < stages_.size(); ++k)
+                            if (stages_[k].span_rule == 1)
+                                throw Error(RH_ERR_UNSUPPORTED, "GpuSource::channel_volume: its input ends inside a frame and its current_span_len() there is not Some(0): what rodio's "
+                                                                "ChannelVolume returns to the adapter behind it, which asks again, is a frame of its stale sum (channel_volume.rs:71-88)");
+                        stale_frame_ = true;
+                    }
                 }
                 return frames * out_ch;
             });
@@ -1691,6 +1701,7 @@ private:
     int filter_mode_ = 0;  // 0: by the filter contract, per filter; 1: reference order throughout; 2: time-parallel throughout
     detail::DeviceBuf a_, b_;
     bool scan_kernels_ = false;  // the chain launches handle-less scan kernels: their failure word is read per block
+    bool stale_frame_ = false;   // ended_with_a_stale_frame()
     bool may_cut_ = false;       // an adapter of the chain can make the stream end inside a frame (may_end_inside_a_frame())
 };
 
@@ -2347,6 +2358,11 @@ private:
         else if (g.staged) issue_block_staged(g);
         else issue_block_direct(g);
         g.emitted += g.fill - before;
+        for (const Src &x : g.srcs)  // (rodio's UniformSourceIterator asks a source again, once, after its None)
+            if (x.ended)
+                if (const GpuSource *gs = x.up ? dynamic_cast<const GpuSource *>(x.up.get()) : nullptr; gs && gs->ended_with_a_stale_frame())
+                    throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a chain ended inside a frame of its channel_volume's input: asked again, as rodio's mixer asks, ChannelVolume returns a frame of its "
+                                                    "stale sum (channel_volume.rs:71-88)");
         if (g.done) g.finish();
     }
     /// A block of a wide generation: up to block_frames frames of every chain, device to device into a row each, and the ordered sum

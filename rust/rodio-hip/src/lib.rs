@@ -456,6 +456,8 @@ impl<I: Source> GpuSource<I> {
     /// SAMPLES (delay.rs:14), `uniform` over spans that cut frames hands on what rodio's converters make of the cut.  (The C++ twin's GpuMixer
     /// completes such a chain to `amplify -> UniformSourceIterator -> filter` before it enters a fused stream: not ported, INTEGRATION.md.)
     pub fn may_end_inside_a_frame(&self) -> bool { self.may_cut }
+    /// The stream ended where rodio's ChannelVolume would return one more frame of its stale sum to a consumer that asks again (C++ twin only so far: always false here).
+    pub fn ended_with_a_stale_frame(&self) -> bool { false }
     /// The chain's `current_span_len()` comes from an adapter's own arithmetic (take_duration, delay, channel_volume): see the C++ twin's `span_behind`.
     pub fn answers_with_adapter_spans(&self) -> bool { self.stages.iter().rev().map(|s| s.span_rule).find(|&r| r != 0).unwrap_or(0) == 2 }
     fn push(&mut self, run: impl FnMut(&mut Ctx) -> usize + Send + 'static, bound: impl Fn(usize, usize) -> usize + Send + 'static, span_rule: u8) -> &mut Stage {
