@@ -900,19 +900,15 @@ public:
                 *emitted += frames * out_ch;
                 if (n % in_ch) {
                     // ... and rodio's ChannelVolume is left with its channel position at 0 and the sum of the samples it did get: asked AGAIN
-                    // after that None -- a UniformSourceIterator does ask, once, unless the adapter says Some(0) -- it returns one more frame
-                    // made of that stale sum (:71-88).  Where the answer there is Some(0) (a SamplesBuffer that has given everything)
-                    // nobody asks; where it is not, the drop-in does not guess who is listening.
-                    // Adapters that pass samples on one by one end with it; an iterator or a Mix behind it in the chain asks again (refused), and so
+                    // after that None it returns one more frame made of that stale sum (:71-88).  Adapters that pass samples on one by one end
+                    // with the None; a converter behind it polls its input again while it drains (sample_rate.rs:110-122), a
+                    // UniformSourceIterator once more when its chain has ended (uniform.rs:76-97), a Mix through both (refused); and so
                     // does a mixer the chain was handed to (which looks at ended_with_a_stale_frame()).
-                    const std::optional<std::size_t> after = span_behind(self + 1, *emitted + 1);  // (the frame it began: its input has given everything)
-                    if (!(after && *after == 0)) {
-                        for (std::size_t k = self + 1; k < stages_.size(); ++k)
-                            if (stages_[k].span_rule == 1)
-                                throw Error(RH_ERR_UNSUPPORTED, "GpuSource::channel_volume: its input ends inside a frame and its current_span_len() there is not Some(0): what rodio's "
-                                                                "ChannelVolume returns to the adapter behind it, which asks again, is a frame of its stale sum (channel_volume.rs:71-88)");
-                        stale_frame_ = true;
-                    }
+                    for (std::size_t k = self + 1; k < stages_.size(); ++k)
+                        if (stages_[k].span_rule == 1)
+                            throw Error(RH_ERR_UNSUPPORTED, "GpuSource::channel_volume: its input ends inside a frame: what rodio's ChannelVolume returns to the converter behind it, "
+                                                            "which polls it again, is a frame of its stale sum (channel_volume.rs:71-88)");
+                    stale_frame_ = true;
                 }
                 return frames * out_ch;
             });
