@@ -54,6 +54,16 @@ struct Source {
     virtual long current_span_len() const = 0;
     virtual uint16_t channels() const = 0;
     virtual uint32_t sample_rate() const = 0;
+    // Iterator::size_hint(): (lower, upper) with `bounded == false` for an upper bound of None.  The default is the
+    // trait's own `(0, None)` (what benches/shared.rs:14-21 `TestSource` answers: it only implements next()).
+    struct Hint {
+        size_t lo;
+        bool bounded;
+        size_t hi;
+    };
+    virtual Hint size_hint() const { return Hint{0, false, 0}; }
+    // total_duration() in nanoseconds; -1 encodes None (source/mod.rs:209-213).
+    virtual long long total_duration_ns() const { return -1; }
 };
 
 // A plain sample iterator (what `Vec<f32>::into_iter()` is in the reference's
@@ -66,8 +76,22 @@ struct VecSource : Source {
     uint16_t ch;
     uint32_t rate;
     long span;  // -1: None (TestSource); -2: SamplesBuffer rule; k>=0: constant Some(k)
+    // size_hint(): a SamplesBuffer counts its remaining samples (buffer.rs:134-137), and so does a plain `Vec::into_iter()` (the role this
+    // type plays in the reference's converter tests: channels.rs:146-161 relies on it); benches/shared.rs `TestSource` implements only
+    // next(), so it answers the trait's default (0, None).  total_duration(): SamplesBuffer computes it (buffer.rs:45-51); TestSource is
+    // GIVEN one by whoever builds it (shared.rs:11,47-49) -- orc_vec_set_total_duration.
+    bool exact_hint;
+    long long total_ns = -1;
     VecSource(const float *d, size_t n, uint16_t c, uint32_t r, long sp)
-        : data(d, d + n), ch(c), rate(r), span(sp) {}
+        : data(d, d + n), ch(c), rate(r), span(sp), exact_hint(sp == -2) {
+        if (sp == -2) total_ns = (long long)(1000000000ull * (uint64_t)n / r / c);  // buffer.rs:45-51
+    }
+    Hint size_hint() const override {
+        if (!exact_hint) return Hint{0, false, 0};
+        const size_t remaining = data.size() - pos;
+        return Hint{remaining, true, remaining};
+    }
+    long long total_duration_ns() const override { return total_ns; }
     bool next(float &out) override {
         if (pos >= data.size()) return false;
         out = data[pos++];
@@ -113,6 +137,11 @@ struct SeqSource : Source {
     }
     uint16_t channels() const override { return parts.empty() ? 1 : parts[cur < parts.size() ? cur : parts.size() - 1].ch; }
     uint32_t sample_rate() const override { return parts.empty() ? 1 : parts[cur < parts.size() ? cur : parts.size() - 1].rate; }
+    // queue.rs:245-247: (the current sound's lower bound, None) -- every part is a SamplesBuffer (buffer.rs:134-137); queue.rs:195-197: None
+    Hint size_hint() const override {
+        const size_t lo = cur < parts.size() && pos < parts[cur].data.size() ? parts[cur].data.size() - pos : 0;
+        return Hint{lo, false, 0};
+    }
 };
 
 // src/source/span.rs:34-121 -- where an adapter learns that its input's parameters changed.
@@ -259,6 +288,22 @@ struct SampleRateConverter : Source {
     long current_span_len() const override { return -1; }
     uint16_t channels() const override { return ch; }
     uint32_t sample_rate() const override { return out_rate; }
+    // sample_rate.rs:204-238 (its own comment: "this is wrong here": restated as it stands, usize / u32 arithmetic as written)
+    size_t apply_hint(size_t samples) const {
+        size_t samples_after_chunk = samples;
+        if (current_span_pos_in_chunk == from - 1) samples_after_chunk += next_frame.size();                    // :210-214
+        const uint32_t a = current_span_pos_in_chunk + 2;                                                        // :216-219
+        const size_t unread = (size_t)(from > a ? from - a : 0) * (size_t)ch;
+        samples_after_chunk = samples_after_chunk > unread ? samples_after_chunk - unread : 0;
+        samples_after_chunk = samples_after_chunk * (size_t)to / (size_t)from;                                  // :222
+        const size_t samples_current_chunk = (size_t)(to - next_output_span_pos_in_chunk) * (size_t)ch;        // :226-227
+        return samples_current_chunk + samples_after_chunk + output_buffer.size();                             // :229
+    }
+    Hint size_hint() const override {
+        const Hint in = input->size_hint();
+        if (from == to) return in;  // :232-233
+        return Hint{apply_hint(in.lo), in.bounded, in.bounded ? apply_hint(in.hi) : 0};
+    }
 };
 
 // ------------------------------------------------ ChannelCountConverter ----
@@ -305,6 +350,16 @@ struct ChannelCountConverter : Source {
     long current_span_len() const override { return -1; }
     uint16_t channels() const override { return to; }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    // channels.rs:88-102
+    Hint size_hint() const override {
+        const Hint in = input->size_hint();
+        const size_t consumed = std::min<size_t>(from, next_output_sample_pos);
+        auto f = [&](size_t v) {
+            const size_t x = (v + consumed) / from * to;
+            return x > next_output_sample_pos ? x - next_output_sample_pos : 0;
+        };
+        return Hint{f(in.lo), in.bounded, in.bounded ? f(in.hi) : 0};
+    }
 };
 
 // src/source/uniform.rs:148-178 (private `Take`)
@@ -326,6 +381,12 @@ struct Take : Source {
     long current_span_len() const override { return -1; }
     uint16_t channels() const override { return iter->channels(); }
     uint32_t sample_rate() const override { return iter->sample_rate(); }
+    // uniform.rs:181-196
+    Hint size_hint() const override {
+        const Hint in = iter->size_hint();
+        if (!limited) return in;
+        return Hint{std::min(in.lo, n), true, in.bounded && in.hi < n ? in.hi : n};
+    }
 };
 
 // ------------------------------------------------ UniformSourceIterator ----
@@ -338,8 +399,12 @@ struct UniformSourceIterator : Source {
     std::unique_ptr<Take> take;
     std::unique_ptr<SampleRateConverter> src;
     std::unique_ptr<ChannelCountConverter> ccc;
+    long long total_ns;  // uniform.rs:37: asked once, when the iterator is built
     UniformSourceIterator(Source *in, uint16_t ch, uint32_t rate)
-        : input(in), target_channels(ch), target_rate(rate) {}
+        : input(in), target_channels(ch), target_rate(rate), total_ns(in->total_duration_ns()) {}
+    // uniform.rs:100-108: the lower bound of the chain that is open (of the input while none has been built), and no upper bound
+    Hint size_hint() const override { return Hint{ccc ? ccc->size_hint().lo : input->size_hint().lo, false, 0}; }
+    long long total_duration_ns() const override { return total_ns; }  // :131-133
     ~UniformSourceIterator() override { delete input; }
     void bootstrap() {  // :50-68
         long span = input->current_span_len();
@@ -407,6 +472,19 @@ struct MixerSource : Source {
     long current_span_len() const override { return -1; }
     uint16_t channels() const override { return ch; }
     uint32_t sample_rate() const override { return rate; }
+    // mixer.rs:139-166: nothing while no source plays; otherwise the LONGEST source bounds the mix, and one unbounded source unbounds it.
+    // (Sources still waiting in `still_pending` / the channel do not count.)  total_duration: None (:104-106) -- the trait default.
+    Hint size_hint() const override {
+        if (current_sources.empty()) return Hint{0, true, 0};
+        Hint h{0, true, 0};
+        for (const Source *s : current_sources) {
+            const Hint x = s->size_hint();
+            h.lo = std::max(h.lo, x.lo);
+            if (h.bounded && x.bounded) h.hi = std::max(h.hi, x.hi);
+            else h.bounded = false;
+        }
+        return h;
+    }
 };
 
 // ------------------------------------------------------------- Amplify ----
@@ -425,6 +503,8 @@ struct Amplify : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // amplify.rs:68-70
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // amplify.rs:95-97
 };
 
 // ---------------------------------------------------------- Distortion ----
@@ -447,6 +527,8 @@ struct Distortion : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // distortion.rs:75-77
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // distortion.rs:102-104
 };
 
 // ---------------------------------------------------------------- Dither ----
@@ -498,6 +580,8 @@ struct Dither : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // dither.rs:245-247
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // dither.rs:272-274
 };
 
 // ------------------------------------------------------- LinearGainRamp ----
@@ -531,6 +615,8 @@ struct LinearGainRamp : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // linear_ramp.rs:109-111 (fadein.rs:58-60, fadeout.rs:58-60)
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // linear_ramp.rs:136-138 (fadein.rs:85-87, fadeout.rs:85-87)
 };
 
 // -------------------------------------------------------- TakeDuration ----
@@ -585,6 +671,20 @@ struct TakeDuration : Source {
     }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    // take.rs:151-171: what the remaining duration admits (whole nanoseconds / duration_per_sample), cut to the input's bounds -- and an upper
+    // bound even over an input that has none.  (The silence that completes a cut frame, :107-115, is not counted: restated as written.)
+    Hint size_hint() const override {
+        if (dps_ns == 0 || remaining_ns == 0) return Hint{0, true, 0};
+        const size_t remaining_samples = (size_t)(remaining_ns / dps_ns);
+        const Hint in = input->size_hint();
+        return Hint{std::min(in.lo, remaining_samples), true, in.bounded ? std::min(in.hi, remaining_samples) : remaining_samples};
+    }
+    // take.rs:209-219: the shorter of the input's duration and the requested one; None over an input that has none
+    long long total_duration_ns() const override {
+        const long long d = input->total_duration_ns();
+        if (d < 0) return -1;
+        return (uint64_t)d < requested_ns ? d : (long long)requested_ns;
+    }
 };
 
 // ----------------------------------------------------------- BltFilter ----
@@ -661,6 +761,8 @@ struct BltFilter : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // blt.rs:144-146,320-322
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // blt.rs:171-173,345-347
 };
 
 // --------------------------------------------------------------- Delay ----
@@ -668,7 +770,8 @@ struct BltFilter : Source {
 struct Delay : Source {
     Source *input;
     size_t remaining_samples;
-    Delay(Source *in, uint64_t ns) : input(in) {
+    uint64_t requested_ns;
+    Delay(Source *in, uint64_t ns) : input(in), requested_ns(ns) {
         unsigned __int128 s = (unsigned __int128)ns * in->channels() * in->sample_rate() /
                               1000000000ull;
         remaining_samples = (size_t)s;
@@ -688,6 +791,16 @@ struct Delay : Source {
     }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    // delay.rs:78-84: the input's bounds plus the silence still owed
+    Hint size_hint() const override {
+        const Hint in = input->size_hint();
+        return Hint{in.lo + remaining_samples, in.bounded, in.bounded ? in.hi + remaining_samples : 0};
+    }
+    // delay.rs:111-115: the input's duration plus the REQUESTED delay (not the rounded silence)
+    long long total_duration_ns() const override {
+        const long long d = input->total_duration_ns();
+        return d < 0 ? -1 : d + (long long)requested_ns;
+    }
 };
 
 // --------------------------------------------------------------- Speed ----
@@ -704,6 +817,31 @@ struct Speed : Source {
         float r = (float)input->sample_rate() * factor;
         if (!(r > 1.0f)) r = 1.0f;
         return sat_cast_u32(r);
+    }
+    Hint size_hint() const override { return input->size_hint(); }  // speed.rs:108-110
+    // speed.rs:136-138: `d.div_f32(factor)` = Duration::from_secs_f32(d.as_secs_f32() / factor).  from_secs_f32 is exact on the f32 it is given,
+    // rounding to the nearest nanosecond, ties to even (core::time, Rust >= 1.63) -- restated from the standard library's documentation, unpinned.
+    long long total_duration_ns() const override {
+        const long long d = input->total_duration_ns();
+        if (d < 0) return -1;
+        const float v = duration_to_float((uint64_t)d) / factor;
+        if (!(v >= 0.0f) || v >= 1.8446744e19f) return -1;  // (from_secs_f32 panics there; never reached by the tests)
+        int e = 0;
+        const float m = std::frexp(v, &e);                  // v = m * 2^e, m in [0.5, 1)
+        const unsigned __int128 mant = (unsigned __int128)(uint64_t)std::ldexp((double)m, 24);  // 24-bit integer mantissa
+        const int sh = e - 24;                              // v = mant * 2^sh
+        unsigned __int128 ns;
+        if (sh >= 0) {
+            ns = (mant << sh) * 1000000000ull;
+        } else {
+            const unsigned __int128 num = mant * 1000000000ull;
+            const int k = -sh;
+            if (k >= 120) return 0;
+            ns = num >> k;
+            const unsigned __int128 rem = num - (ns << k), half = (unsigned __int128)1 << (k - 1);
+            if (rem > half || (rem == half && (ns & 1))) ns += 1;
+        }
+        return (long long)ns;
     }
 };
 
@@ -735,6 +873,62 @@ struct Mix : Source {
     long current_span_len() const override { return -1; }
     uint16_t channels() const override { return in1->channels(); }
     uint32_t sample_rate() const override { return in1->sample_rate(); }
+    // mix.rs:56-67: the longer input bounds the mix
+    Hint size_hint() const override {
+        const Hint a = in1->size_hint(), b = in2->size_hint();
+        return Hint{std::max(a.lo, b.lo), a.bounded && b.bounded, a.bounded && b.bounded ? std::max(a.hi, b.hi) : 0};
+    }
+    // mix.rs:104-112
+    long long total_duration_ns() const override {
+        const long long a = in1->total_duration_ns(), b = in2->total_duration_ns();
+        return a < 0 || b < 0 ? -1 : std::max(a, b);
+    }
+};
+
+// ------------------------------------------------------------ Buffered ----
+// src/source/buffered.rs:11-24 (total_duration asked once), :97-126 (`extract`: a span = the input's current span, or 32768 samples of an
+// input that reports none, with the format the input had when the span was cut), :159-196 (next; size_hint is `(0, None)`: its own TODO),
+// :206-237.  Clones share the spans (Arc): the oracle extracts them all when the source is built and hands every clone the list.
+struct Buffered : Source {
+    struct Span {
+        std::vector<float> data;
+        uint16_t ch;
+        uint32_t rate;
+    };
+    std::shared_ptr<const std::vector<Span>> spans;
+    size_t cur = 0, pos = 0;
+    long long total_ns;
+    static std::shared_ptr<const std::vector<Span>> extract_all(Source *in) {  // :97-126, span after span
+        auto v = std::make_shared<std::vector<Span>>();
+        for (;;) {
+            const long span_len = in->current_span_len();
+            if (span_len == 0) break;
+            Span s;
+            s.ch = in->channels();
+            s.rate = in->sample_rate();
+            const size_t max_samples = span_len < 0 ? 32768 : (size_t)span_len;
+            float x;
+            while (s.data.size() < max_samples && in->next(x)) s.data.push_back(x);
+            if (s.data.empty()) break;
+            v->push_back(std::move(s));
+        }
+        return v;
+    }
+    Buffered(std::shared_ptr<const std::vector<Span>> sp, long long total) : spans(std::move(sp)), total_ns(total) {}
+    bool next(float &out) override {  // :166-189
+        if (cur >= spans->size()) return false;
+        out = (*spans)[cur].data[pos++];
+        if (pos >= (*spans)[cur].data.size()) {
+            ++cur;
+            pos = 0;
+        }
+        return true;
+    }
+    long current_span_len() const override { return cur < spans->size() ? (long)(*spans)[cur].data.size() : 0; }  // :208-215
+    uint16_t channels() const override { return cur < spans->size() ? (*spans)[cur].ch : 1; }                    // :218-224
+    uint32_t sample_rate() const override { return cur < spans->size() ? (*spans)[cur].rate : 44100; }           // :227-233
+    Hint size_hint() const override { return Hint{0, false, 0}; }                                                // :192-195
+    long long total_duration_ns() const override { return total_ns; }                                            // :235-237
 };
 
 // -------------------------------------------------------- ChannelVolume ----
@@ -769,6 +963,8 @@ struct ChannelVolume : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return (uint16_t)channel_volumes.size(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // channel_volume.rs:91-93 (spatial.rs:84-86): the INPUT's answer, whatever the two layouts are
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // channel_volume.rs:119-121 (spatial.rs:111-113)
 };
 
 // src/source/spatial.rs:19-24 (dist_sq), :48-69 (set_positions)
@@ -851,6 +1047,8 @@ struct Limit : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // limit.rs:705-707,1083-1085
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // limit.rs:592-594,1121-1123
 };
 
 // ----------------------------------------------------------------- AGC ----
@@ -919,6 +1117,8 @@ struct Agc : Source {
     long current_span_len() const override { return input->current_span_len(); }
     uint16_t channels() const override { return input->channels(); }
     uint32_t sample_rate() const override { return input->sample_rate(); }
+    Hint size_hint() const override { return input->size_hint(); }                        // agc.rs:561-563
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // agc.rs:588-590
 };
 
 // Rust `as` casts saturate and map NaN to 0.
@@ -950,6 +1150,18 @@ void orc_seq_add(void *seq, const float *data, size_t n, int ch, unsigned rate) 
     ((SeqSource *)seq)->parts.push_back(std::move(p));
 }
 long orc_current_span_len(void *src) { return ((Source *)src)->current_span_len(); }
+// Iterator::size_hint(): *lo, *hi and 1, or *lo and 0 for an upper bound of None
+int orc_size_hint(void *src, unsigned long long *lo, unsigned long long *hi) {
+    const Source::Hint h = ((Source *)src)->size_hint();
+    *lo = h.lo;
+    *hi = h.bounded ? h.hi : 0;
+    return h.bounded ? 1 : 0;
+}
+// Source::total_duration() in nanoseconds, -1 for None
+long long orc_total_duration_ns(void *src) { return ((Source *)src)->total_duration_ns(); }
+// a TestSource is given its duration (benches/shared.rs:11,47-49); a plain Vec::into_iter() counts its samples (exact = 1)
+void orc_vec_set_total_duration(void *src, long long ns) { ((VecSource *)src)->total_ns = ns; }
+void orc_vec_set_exact_hint(void *src, int exact) { ((VecSource *)src)->exact_hint = exact != 0; }
 void *orc_sample_rate_converter(void *in, unsigned from, unsigned to, int ch) {
     return new SampleRateConverter((Source *)in, from, to, (uint16_t)ch, true);
 }
@@ -973,15 +1185,26 @@ void *orc_speed(void *in, float factor) { return new Speed((Source *)in, factor)
 // materialises the input once and builds both branches from it.
 void *orc_reverb(void *in, unsigned long long ns, float amplitude) {
     Source *s = (Source *)in;
-    std::vector<float> all;
-    float v;
-    while (s->next(v)) all.push_back(v);
-    uint16_t ch = s->channels();
-    uint32_t rate = s->sample_rate();
+    const long long total = s->total_duration_ns();  // buffered.rs:16
+    const uint16_t ch = s->channels();
+    const uint32_t rate = s->sample_rate();
+    auto spans = Buffered::extract_all(s);
     delete s;
-    Source *a = new VecSource(all.data(), all.size(), ch, rate, -1);
-    Source *b = new Delay(new Amplify(new VecSource(all.data(), all.size(), ch, rate, -1), amplitude), ns);
+    if (spans->empty()) {  // (an empty input: Span::End reports 1 channel at 44100 Hz, buffered.rs:218-233; the chains built on it keep the input's format as before)
+        Source *a = new VecSource(nullptr, 0, ch, rate, -1);
+        Source *b = new Delay(new Amplify(new VecSource(nullptr, 0, ch, rate, -1), amplitude), ns);
+        return new Mix(a, b);
+    }
+    Source *a = new Buffered(spans, total);
+    Source *b = new Delay(new Amplify(new Buffered(spans, total), amplitude), ns);
     return new Mix(a, b);
+}
+void *orc_buffered(void *in) {
+    Source *s = (Source *)in;
+    const long long total = s->total_duration_ns();
+    auto spans = Buffered::extract_all(s);
+    delete s;
+    return new Buffered(spans, total);
 }
 void *orc_channel_volume(void *in, const float *gains, int n) {
     return new ChannelVolume((Source *)in, gains, (size_t)n);

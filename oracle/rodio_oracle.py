@@ -38,6 +38,11 @@ def _load():
         "orc_seq_source": (vp, []),
         "orc_seq_add": (None, [vp, f32p, C.c_size_t, C.c_int, C.c_uint]),
         "orc_current_span_len": (C.c_long, [vp]),
+        "orc_size_hint": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+        "orc_total_duration_ns": (C.c_longlong, [vp]),
+        "orc_vec_set_total_duration": (None, [vp, C.c_longlong]),
+        "orc_vec_set_exact_hint": (None, [vp, C.c_int]),
+        "orc_buffered": (vp, [vp]),
         "orc_sample_rate_converter": (vp, [vp, C.c_uint, C.c_uint, C.c_int]),
         "orc_channel_count_converter": (vp, [vp, C.c_int, C.c_int]),
         "orc_uniform": (vp, [vp, C.c_int, C.c_uint]),
@@ -148,6 +153,20 @@ class Source:
         v = _lib.orc_current_span_len(self._p)
         return None if v < 0 else v
 
+    def size_hint(self):
+        """Iterator::size_hint(): (lower, upper) with upper None for "no upper bound"."""
+        lo, hi = C.c_ulonglong(0), C.c_ulonglong(0)
+        bounded = _lib.orc_size_hint(self._p, C.byref(lo), C.byref(hi))
+        return int(lo.value), (int(hi.value) if bounded else None)
+
+    def total_duration(self):
+        """Source::total_duration() in nanoseconds, or None (source/mod.rs:209-213)."""
+        v = _lib.orc_total_duration_ns(self._p)
+        return None if v < 0 else int(v)
+
+    def buffered(self):  # buffered.rs:11-24
+        return Source(_lib.orc_buffered(self._take()))
+
     # -- rodio's builder methods (src/source/mod.rs:255-731) ------------------
     def amplify(self, factor):
         return Source(_lib.orc_amplify(self._take(), factor))
@@ -194,10 +213,17 @@ class Source:
                                    absolute_max_gain, floor))
 
 
-def TestSource(samples, channels, sample_rate) -> Source:
-    """benches/shared.rs:6-46, src/source/mod.rs:865-930: current_span_len() == None."""
+def TestSource(samples, channels, sample_rate, total_duration=None, exact_size_hint=False) -> Source:
+    """benches/shared.rs:6-46, src/source/mod.rs:865-930: current_span_len() == None.  The benches' TestSource is GIVEN its
+    total_duration (shared.rs:11,47-49: nanoseconds here) and answers the trait's default size_hint() (0, None) (it implements only
+    next()); exact_size_hint=True makes it the plain `Vec::into_iter()` of the reference's converter tests, which counts its samples."""
     a = np.ascontiguousarray(samples, dtype=np.float32)
-    return Source(_lib.orc_vec_source(_f32p(a), a.size, channels, sample_rate, SPAN_NONE))
+    p = _lib.orc_vec_source(_f32p(a), a.size, channels, sample_rate, SPAN_NONE)
+    if total_duration is not None:
+        _lib.orc_vec_set_total_duration(p, int(total_duration))
+    if exact_size_hint:
+        _lib.orc_vec_set_exact_hint(p, 1)
+    return Source(p)
 
 
 def SamplesBuffer(channels, sample_rate, samples) -> Source:
