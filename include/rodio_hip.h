@@ -169,6 +169,13 @@ rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samp
 rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels,
                            uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out,
                            uint64_t *out_samples, int32_t *ended, rh_stream stream);
+/* ... the same from ANY state of the adapter (after `try_seek`, take.rs:222-231: remaining = requested.saturating_sub(pos), the frame
+ * position 0): remaining_ns = what is left of the duration at src[0], requested_ns = the adapter's whole duration (the fade-out
+ * filter's denominator, :33-38), frame_phase = samples of the current frame already emitted (decides the silence that completes
+ * a cut frame, :107-115).  *remaining_after_ns (may be NULL) = what is left behind the samples taken. */
+rh_status rh_take_duration_from(float *dst, const float *src, uint64_t n, uint64_t remaining_ns, uint64_t requested_ns,
+                                uint32_t frame_phase, uint32_t channels, uint32_t sample_rate, int32_t fade_out,
+                                uint64_t *out_samples, int32_t *ended, uint64_t *remaining_after_ns, rh_stream stream);
 
 /* ---- ChannelVolume / Spatial: src/source/channel_volume.rs:71-88, src/source/spatial.rs:48-69.
  * gains_host has out_ch entries (out_ch <= 16).  dst holds frames*out_ch samples. */

@@ -58,6 +58,12 @@ inline void check(rh_status st, const char *what) {
 inline void init(int device = 0) { check(rh_init(device), "rh_init"); }
 
 using Nanos = std::chrono::nanoseconds;
+/// `Iterator::size_hint()`: (lower, upper), upper == nullopt for "no upper bound".
+struct SizeHint {
+    std::size_t lower = 0;
+    std::optional<std::size_t> upper = std::nullopt;
+    bool operator==(const SizeHint &o) const { return lower == o.lower && upper == o.upper; }
+};
 
 // ---------------------------------------------------------------- trait Source (source/mod.rs:179-218) ----
 class Source {
@@ -69,6 +75,8 @@ public:
     virtual std::uint16_t channels() const = 0;
     virtual std::uint32_t sample_rate() const = 0;
     virtual std::optional<Nanos> total_duration() const { return std::nullopt; }
+    /// `Iterator::size_hint`: the trait's default is (0, None) -- what a source that only implements next() answers (benches/shared.rs:14-21).
+    virtual SizeHint size_hint() const { return SizeHint{}; }
     /// `try_seek`: false == SeekError::NotSupported (source/mod.rs:766-787).
     virtual bool try_seek(Nanos) { return false; }
     /// Bulk form of next() that block adapters pull with; the default is the per-sample loop.
@@ -103,6 +111,10 @@ public:
     std::uint32_t sample_rate() const override { return rate_; }
     std::optional<Nanos> total_duration() const override {  // buffer.rs:45-51
         return Nanos((std::int64_t)(1000000000ull * (std::uint64_t)data_.size() / rate_ / ch_));
+    }
+    SizeHint size_hint() const override {  // buffer.rs:134-137
+        const std::size_t remaining = data_.size() - pos_;
+        return SizeHint{remaining, remaining};
     }
     /// buffer.rs:99-121: jump to the sample for `pos`, saturating at the end, keeping the channel the consumer is at.
     bool try_seek(Nanos pos) override {
@@ -556,6 +568,252 @@ private:
     std::size_t out_ = 0;                            // output samples planned in this block
 };
 
+/// What a source answered to size_hint() at the positions it was asked (the adapters read a block ahead of the consumer; rodio's adapters ask
+/// their input where THEY stand).  at(q): the answer at sample q of the source -- the last answer recorded at or before q, less the samples taken
+/// since (exact for a source that counts its samples down, buffer.rs:134-137, and for one that answers the trait's default (0, None); a valid
+/// bound for any other).
+class HintLog {
+public:
+    void note(std::uint64_t pos, const SizeHint &h) {
+        if (!log_.empty() && log_.back().first == pos) log_.back().second = h;
+        else log_.emplace_back(pos, h);
+        if (log_.size() > 256) log_.pop_front();  // (nobody has asked for a long while: a question that old is answered from the oldest answer kept)
+    }
+    bool empty() const { return log_.empty(); }
+    void clear() { log_.clear(); }
+    SizeHint at(std::uint64_t q) const {
+        std::size_t i = 0;
+        while (i + 1 < log_.size() && log_[i + 1].first <= q) ++i;
+        if (i) log_.erase(log_.begin(), log_.begin() + (std::ptrdiff_t)i);  // (the questions only move forward)
+        const std::uint64_t since = q > log_.front().first ? q - log_.front().first : 0;
+        SizeHint h = log_.front().second;
+        h.lower = h.lower > since ? h.lower - (std::size_t)since : 0;
+        if (h.upper) h.upper = *h.upper > since ? *h.upper - (std::size_t)since : 0;
+        return h;
+    }
+
+private:
+    mutable std::deque<std::pair<std::uint64_t, SizeHint>> log_;
+};
+
+/// UniformSourceIterator::size_hint() (uniform.rs:100-108): the lower bound of the converter chain that is open -- ChannelCountConverter
+/// (channels.rs:88-102) over SampleRateConverter (sample_rate.rs:204-238) over Take (uniform.rs:181-196) -- and no upper bound.  Those bounds are
+/// functions of the converters' COUNTERS (position in the chunk, samples waiting in the output buffer, the length of the frame read ahead,
+/// what Take still admits); the samples themselves are converted on the device, so this class runs the three iterators' state machines over
+/// counts only, fed with the spans the samples were pulled in (Piece), lazily: nothing happens until somebody asks.
+class UniformCounter {
+public:
+    /// bare_converter: a SampleRateConverter on its own (no Take in front, no ChannelCountConverter behind): both of ITS bounds.
+    UniformCounter(std::uint16_t to_ch = 2, std::uint32_t to_rate = 48000, bool bare_converter = false) : to_ch_(to_ch), to_rate_(to_rate), bare_(bare_converter) {}
+    /// A piece of the input, in pull order; `up_pos`: samples taken from the iterator's input in front of it.
+    void feed(const Piece &p, std::uint64_t up_pos) {
+        if (p.opens || spans_.empty() || spans_.back().closed) {
+            compact();
+            Span sp;
+            sp.ch = p.ch, sp.rate = p.rate, sp.up_pos = up_pos;
+            sp.limited = p.span_len.has_value();
+            sp.take_n = sp.limited ? std::min<std::size_t>(*p.span_len, 32768) : 0;  // uniform.rs:56
+            spans_.push_back(sp);
+        }
+        spans_.back().got += p.n;
+        if (p.closes) spans_.back().closed = true;
+    }
+    void input_ended() {
+        ended_ = true;
+        if (!spans_.empty()) spans_.back().closed = true;
+    }
+    /// size_hint() once the iterator has returned `e` samples; nullopt: it returned None before that (its stream is shorter than e).
+    /// `in_hint(q)`: the input's size_hint() at sample q of the input.
+    std::optional<SizeHint> hint_at(std::uint64_t e, const std::function<SizeHint(std::uint64_t)> &in_hint) {
+        while (done_ < e)
+            if (!step()) return std::nullopt;
+        if (bare_ && !started_ && !spans_.empty()) (void)bootstrap();  // SampleRateConverter::new reads its first two frames (sample_rate.rs:58-71)
+        if (!started_) return SizeHint{in_hint(taken_total()).lower, std::nullopt};  // uniform.rs:105: no chain has been built yet -- the pending input itself
+        if (!open_) return SizeHint{0, std::nullopt};  // (every chain has run dry and no span was pulled for another one)
+        // Take (uniform.rs:181-196)
+        SizeHint h = in_hint(taken_total());
+        if (cur().limited) {
+            h.lower = std::min(h.lower, left_);
+            h.upper = h.upper && *h.upper < left_ ? *h.upper : left_;
+        }
+        // SampleRateConverter (sample_rate.rs:204-238; usize / u32 arithmetic as written there)
+        auto apply = [&](std::size_t samples) {
+            std::size_t after = samples;
+            if (pos_in_chunk_ == from_ - 1) after += next_len_;
+            const std::uint32_t a = pos_in_chunk_ + 2;
+            const std::size_t unread = (std::size_t)(from_ > a ? from_ - a : 0) * cur().ch;
+            after = after > unread ? after - unread : 0;
+            after = after * (std::size_t)to_ / (std::size_t)from_;
+            return (std::size_t)(to_ - out_pos_) * cur().ch + after + buf_len_;
+        };
+        if (from_ != to_) {
+            h.lower = apply(h.lower);
+            if (h.upper) h.upper = apply(*h.upper);
+        }
+        if (bare_) return h;
+        // ChannelCountConverter (channels.rs:88-102); UniformSourceIterator keeps the lower bound (uniform.rs:100-108)
+        const std::size_t consumed = std::min<std::size_t>(cur().ch, ccc_pos_);
+        const std::size_t x = (h.lower + consumed) / cur().ch * to_ch_;
+        return SizeHint{x > ccc_pos_ ? x - ccc_pos_ : 0, std::nullopt};
+    }
+
+private:
+    struct Span {
+        std::uint16_t ch = 0;
+        std::uint32_t rate = 0;
+        std::uint64_t up_pos = 0;
+        bool limited = false, closed = false;
+        std::size_t take_n = 0;
+        std::uint64_t got = 0;   // samples the span's chain took from the input
+        std::uint64_t reps = 1;  // ... that many spans like this one, back to back (a SamplesBuffer comes in spans of 32768: uniform.rs:56)
+    };
+    void compact() {  // the spans nobody has asked about yet, run-length encoded
+        if (spans_.size() < 2) return;
+        Span &a = spans_[spans_.size() - 2];
+        const Span &b = spans_.back();
+        if (a.closed && b.closed && a.ch == b.ch && a.rate == b.rate && a.limited == b.limited && a.take_n == b.take_n && a.got == b.got && b.reps == 1) {
+            a.reps += 1;
+            spans_.pop_back();
+        }
+    }
+    const Span &cur() const { return spans_.front(); }
+    std::uint64_t taken_total() const { return open_ ? cur().up_pos + used_ : (spans_.empty() ? 0 : spans_.front().up_pos); }
+    // Take::next over the counts (uniform.rs:160-177)
+    bool take_next() {
+        if (cur().limited) {
+            if (left_ == 0) return false;
+            left_ -= 1;
+        }
+        if (used_ < cur().got) {
+            used_ += 1;
+            return true;
+        }
+        if (cur().closed) return false;  // the input returned None here
+        used_ += 1;  // (asked beyond what has been pulled: the source has not said None, the sample is taken to exist)
+        return true;
+    }
+    std::size_t take_frame() {  // sample_rate.rs:58-71,113-121: up to `channels` samples
+        std::size_t k = 0;
+        while (k < cur().ch && take_next()) ++k;
+        return k;
+    }
+    void next_input_span() {  // sample_rate.rs:110-122
+        pos_in_chunk_ += 1;
+        cur_len_ = next_len_;
+        next_len_ = take_frame();
+    }
+    bool src_next() {  // sample_rate.rs:131-201
+        if (from_ == to_) return take_next();
+        if (buf_len_) {
+            buf_len_ -= 1;
+            return true;
+        }
+        if (out_pos_ == to_) {
+            out_pos_ = 0;
+            next_input_span();
+            while (pos_in_chunk_ != from_) next_input_span();
+            pos_in_chunk_ = 0;
+        } else {
+            const std::uint32_t req = (from_ * out_pos_ / to_) % from_;
+            while (pos_in_chunk_ != req) next_input_span();
+        }
+        const std::size_t n = std::min(cur_len_, next_len_);  // zip
+        out_pos_ += 1;
+        if (n) {
+            buf_len_ = n - 1;
+            return true;
+        }
+        if (!cur_len_) return false;  // :193-200 draining `current_span`
+        buf_len_ = cur_len_ - 1;
+        cur_len_ = 0;
+        return true;
+    }
+    bool ccc_next() {  // channels.rs:57-85
+        const std::uint16_t from = cur().ch, to = to_ch_;
+        bool some;
+        if (ccc_pos_ == 0) {
+            some = src_next();
+            have_repeat_ = some;
+        } else if (ccc_pos_ < from) {
+            some = src_next();
+        } else if (ccc_pos_ == 1) {
+            some = have_repeat_;
+        } else {
+            some = true;
+        }
+        if (some) ccc_pos_ += 1;
+        if (ccc_pos_ == to) {
+            ccc_pos_ = 0;
+            for (std::uint16_t k = to; k < from; ++k) (void)src_next();
+        }
+        return some;
+    }
+    bool bootstrap() {  // uniform.rs:50-68,82-92: the next span's chain
+        if (open_) {
+            if (spans_.front().reps > 1) {
+                spans_.front().reps -= 1;
+                spans_.front().up_pos += spans_.front().got;
+            } else {
+                spans_.pop_front();
+            }
+        }
+        started_ = true;
+        if (spans_.empty()) {
+            open_ = false;
+            return false;  // nothing was pulled for another chain: the one rodio builds here is empty
+        }
+        open_ = true;
+        used_ = 0;
+        left_ = cur().take_n;
+        std::uint64_t a = cur().rate, b = to_rate_;
+        while (b) {
+            const std::uint64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        from_ = (std::uint32_t)(cur().rate / a);
+        to_ = (std::uint32_t)(to_rate_ / a);
+        pos_in_chunk_ = out_pos_ = 0;
+        buf_len_ = 0;
+        ccc_pos_ = 0;
+        have_repeat_ = false;
+        cur_len_ = next_len_ = 0;
+        if (from_ != to_) {
+            cur_len_ = take_frame();
+            next_len_ = take_frame();
+        }
+        return true;
+    }
+    bool step() {  // UniformSourceIterator::next (uniform.rs:76-97)
+        if (bare_) {  // the converter alone: one chain, built when the adapter is
+            if (!started_ && !bootstrap()) return false;
+            if (!open_ || !src_next()) return false;
+            done_ += 1;
+            return true;
+        }
+        if (open_ && ccc_next()) {
+            done_ += 1;
+            return true;
+        }
+        if (!bootstrap()) return false;
+        if (!ccc_next()) return false;
+        done_ += 1;
+        return true;
+    }
+    std::uint16_t to_ch_;
+    std::uint32_t to_rate_;
+    bool bare_ = false;
+    std::deque<Span> spans_;  // front(): the span of the open chain
+    bool open_ = false, started_ = false, ended_ = false;
+    std::uint64_t done_ = 0;   // samples the iterator has returned in the simulation
+    std::uint64_t used_ = 0;   // samples the open chain has taken from the input
+    std::size_t left_ = 0;     // Take::n
+    std::uint32_t from_ = 1, to_ = 1, pos_in_chunk_ = 0, out_pos_ = 0;
+    std::size_t cur_len_ = 0, next_len_ = 0, buf_len_ = 0;
+    std::uint16_t ccc_pos_ = 0;
+    bool have_repeat_ = false;
+};
+
 /// What every GPU-backed source shares: two page-locked result blocks, one served while the other is in
 /// flight.  A subclass implements enqueue(): pull upstream, copy in, launch, copy out -- all asynchronous on
 /// `stream_`; the sizes are known on the host when it returns.
@@ -793,6 +1051,28 @@ public:
         if (rule == 1) return std::nullopt;
         return span_behind(stages_.size(), handed_out());
     }
+    /// What rodio's adapters answer, adapter by adapter: the input's duration behind the ones that keep it (amplify.rs:95-97, blt.rs:171-173,
+    /// limit.rs:592-594, agc.rs:588-590, channel_volume.rs:119-121, ...), plus the delay behind `delay` (delay.rs:111-115), the shorter of the
+    /// two behind `take_duration` (take.rs:209-219), the longer behind `reverb` (mix.rs:104-112 over delay.rs:111-115), and -- behind `reverb`
+    /// and `uniform` -- the value the input gave when the adapter was BUILT (buffered.rs:16, uniform.rs:37).
+    std::optional<Nanos> total_duration() const override {
+        std::optional<Nanos> d = up_->total_duration();
+        for (const Stage &st : stages_)
+            if (st.dur_fn) d = st.dur_fn(d);
+        return d;
+    }
+    /// `Iterator::size_hint()` as rodio's adapter chain would answer it where the CONSUMER stands (the chain itself reads a block ahead):
+    /// every adapter's own arithmetic (delay.rs:78-84, take.rs:151-171, mix.rs:56-67, channels.rs:88-102, sample_rate.rs:204-238,
+    /// uniform.rs:100-108; the input's answer behind the adapters that hand it on: amplify.rs:68-70, blt.rs:144-146, ...) over the upstream's
+    /// answer at the sample the question reaches (detail::HintLog).
+    SizeHint size_hint() const override { return size_hint_at(handed_out()); }
+    /// ... once `emitted` samples of the chain's stream have been served (a consumer that takes the blocks ahead of ITS consumer: GpuMixer).
+    SizeHint size_hint_at(std::uint64_t emitted) const {
+        if (hint_->log.empty()) hint_->before = up_->size_hint();  // nothing pulled (since the last seek): the upstream stands where the question reaches it
+        return hint_->at(emitted);
+    }
+    /// The last adapter of the chain is a `uniform` (what Mixer::add would wrap the chain in is already there).
+    bool ends_with_uniform() const { return last_kind_ == 1; }
     Source &inner() { return *up_; }
     BoxSource into_inner() { return std::move(up_); }
     /// The chain's stream can end inside a frame although its upstream keeps `Source`'s contract: reverb and delay count their
@@ -824,6 +1104,12 @@ public:
         restart(ch_);
         for (Stage &st : stages_)
             if (st.on_seek) st.on_seek(pos);
+        // (the adapters' counts start over: what the chain emits from here on is the stream behind the new position, less the samples that keep
+        // the consumer's channel -- restart())
+        hint_->log.clear();
+        hint_->out_base = handed_out();
+        hint_->skip = handed_out() % ch_;
+        hint_->in_base = pulled_total_;
         if (span_log_on_) {  // what was pulled ahead is gone: the next sample pulled is the one the consumer's cursor reaches
             std::uint64_t q = handed_out();
             for (std::size_t k = stages_.size(); k-- > 0;)
@@ -875,8 +1161,26 @@ public:
         auto h = std::make_shared<Handle<rh_echo>>();
         check(rh_echo_create(&h->p, d, amplitude), "rh_echo_create");
         h->destroy = [](rh_echo *e) { (void)rh_echo_destroy(e); };
+        struct Seen {
+            std::uint64_t n = 0;  // samples of the input so far
+            bool all = false;     // ... and that is all of it
+        };
+        auto seen = std::make_shared<Seen>();
+        // (size_hint) Once the plain branch has found its Buffered source at its end, its iterator builds a chain on `Span::End` at every call --
+        // ONE channel at 44100 Hz (buffered.rs:218-233), whatever the source was -- and an empty SampleRateConverter 44100 -> rate answers a whole
+        // chunk of `to` samples less the one its failed next() counted (sample_rate.rs:190,226-229: the chunk it believes it is in), which the
+        // ChannelCountConverter 1 -> channels behind it multiplies (channels.rs:93): rodio's lower bound while only the echo plays.  Restated, not judged.
+        std::uint64_t g44 = 44100, gb = rate_;
+        while (gb) {
+            const std::uint64_t t = g44 % gb;
+            g44 = gb;
+            gb = t;
+        }
+        const std::size_t end_chunk = rate_ == 44100 ? 0 : (std::size_t)(rate_ / g44 - 1) * ch_;
         return push(
-            [h, d](Ctx &c) {
+            [h, d, seen](Ctx &c) {
+                seen->n += c.n;
+                seen->all = seen->all || c.flush;
                 if (c.n) check(rh_echo_process(h->p, c.out, c.in, c.n, c.stream), "rh_echo_process");
                 if (!c.flush) return c.n;
                 if (d) check(rh_echo_flush(h->p, c.out + c.n, c.stream), "rh_echo_flush");  // the delayed clone outlives the source
@@ -884,7 +1188,29 @@ public:
             },
             [d](std::size_t n) { return n + (std::size_t)d; })
             .not_seekable()
-            .spans(1);  // Mix::current_span_len() is None (mix.rs:92-94)
+            .spans(1)  // Mix::current_span_len() is None (mix.rs:92-94)
+            .duration([captured = total_duration(), duration](std::optional<Nanos>) -> std::optional<Nanos> {  // mix.rs:104-112: max(f1, f1 + d), f1 asked when the source was buffered (buffered.rs:16)
+                return captured ? std::optional<Nanos>(*captured + duration) : std::nullopt;
+            })
+            // mix.rs:56-67 over two UniformSourceIterators (mix.rs:10-22) at the source's own format: (the larger lower bound, None).  The plain
+            // branch reads a Buffered source, whose bounds are (0, None) (buffered.rs:192-195): 0.  The echo -- Delay over Amplify over the clone --
+            // owes d - e samples of silence (delay.rs:78-84), of which its iterator's open chain admits what Take has left (uniform.rs:56,181-196:
+            // chains of min(the buffered span + the silence owed, 32768) samples), counted in whole frames from where the chain stands
+            // (channels.rs:88-102); before the first sample no chain exists and the iterator answers with Delay's own bound (uniform.rs:105).
+            .hints([d, ch = ch_, s0 = current_span_len().value_or(32768), seen, end_chunk](const HintAt &, std::uint64_t e) {
+                if (e == 0) return SizeHint{(std::size_t)d, std::nullopt};
+                const std::size_t plain = seen->all && e > seen->n ? end_chunk : 0;  // (the plain branch has returned None: see above)
+                if (e >= d) return SizeHint{plain, std::nullopt};
+                std::uint64_t start = 0, n = std::min<std::uint64_t>(s0 + d, 32768);
+                while (n && start + n <= e) {  // the chains that have run dry (the silence comes first: the buffered span stays where it is)
+                    start += n;
+                    n = std::min<std::uint64_t>(s0 + (d - start), 32768);
+                }
+                const std::uint64_t in_chain = e - start, pos = in_chain % ch;
+                const std::uint64_t lo = std::min<std::uint64_t>(d - e, n > in_chain ? n - in_chain : 0);
+                const std::uint64_t x = (lo + pos) / ch * ch;
+                return SizeHint{std::max(plain, (std::size_t)(x > pos ? x - pos : 0)), std::nullopt};
+            });
     }
     GpuSource &channel_volume(std::vector<float> gains) {  // channel_volume.rs:71-88
         const std::uint16_t in_ch = ch_;
@@ -940,7 +1266,18 @@ public:
                 if (rest) check(rh_memcpy_d2d(c.out + frames * to, in + frames * from, rest * sizeof(float), c.stream), "rh_memcpy_d2d");
                 return frames * to + rest;
             });
-        }, [from, to](std::size_t n) { return (n / from + 1) * to + to; }).spans(1).on_seek([rg](Nanos) { rg->n = 0; });  // a bare converter is an iterator, not a Source: what wraps it sees no spans
+        }, [from, to](std::size_t n) { return (n / from + 1) * to + to; }).spans(1).on_seek([rg](Nanos) { rg->n = 0; })  // a bare converter is an iterator, not a Source: what wraps it sees no spans
+            // channels.rs:88-102: whole frames of what the input still holds, from where the converter stands -- it has taken min(pos, from) samples of
+            // the frame it is in (the surplus channels go when the frame is complete, :77-81)
+            .hints([from, to](const HintAt &in, std::uint64_t e) {
+                const std::uint64_t pos = e % to, consumed = std::min<std::uint64_t>(from, pos);
+                const SizeHint h = in(e / to * from + consumed);
+                auto f = [&](std::size_t v) {
+                    const std::uint64_t x = (v + consumed) / from * to;
+                    return (std::size_t)(x > pos ? x - pos : 0);
+                };
+                return SizeHint{f(h.lower), h.upper ? std::optional<std::size_t>(f(*h.upper)) : std::nullopt};
+            });
         ch_ = to;
         return *this;
     }
@@ -953,13 +1290,25 @@ public:
         check(rh_resampler_create(&h->p, from, to, ch), "rh_resampler_create");
         h->destroy = [](rh_resampler *r) { (void)rh_resampler_destroy(r); };
         auto rg = std::make_shared<Regroup>();
-        push([h, ch, rg](Ctx &c) {
+        // sample_rate.rs:204-238: the converter's bounds are functions of its counters; they run here, over counts (detail::UniformCounter)
+        auto cnt = std::make_shared<detail::UniformCounter>(ch, to, true);
+        auto fed = std::make_shared<std::uint64_t>(0);
+        cnt->feed(detail::Piece{0, true, false, ch, from, 0, false, std::nullopt, ch, from, true, std::nullopt}, 0);
+        push([h, ch, rg, cnt, fed, from](Ctx &c) {
+            cnt->feed(detail::Piece{c.n, false, c.flush, ch, from, 0, c.flush, std::nullopt, ch, from, false, std::nullopt}, *fed);
+            *fed += c.n;
             return run_grouped(c, ch, *rg, [&](const float *in, std::size_t n) {
                 std::uint64_t m = 0;  // (a frame the stream ends in is not converted here: `uniform` is the adapter that knows what rodio's converter makes of it)
                 check(rh_resampler_process(h->p, c.out, c.out_cap / ch, in, n / ch, c.flush ? 1 : 0, &m, c.stream), "rh_resampler_process");
                 return (std::size_t)m * ch;
             });
-        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 3) * to / from + 2) * ch; }).spans(1);
+        }, [from, to, ch](std::size_t n) { return (std::size_t)((std::uint64_t)(n / ch + 3) * to / from + 2) * ch; }).spans(1)
+            .hints([cnt](const HintAt &in, std::uint64_t e) { return cnt->hint_at(e, in).value_or(SizeHint{0, std::size_t(0)}); })
+            .on_seek([cnt, fed, ch, from, to](Nanos) {  // (the counts start over with the stream behind the new position)
+                *cnt = detail::UniformCounter(ch, to, true);
+                cnt->feed(detail::Piece{0, true, false, ch, from, 0, false, std::nullopt, ch, from, true, std::nullopt}, 0);
+                *fed = 0;
+            });
         rate_ = to;
         return *this;
     }
@@ -1005,10 +1354,19 @@ public:
         // `channels`, and the next span's output follows directly behind it.  The adapters behind work on frames, so a block hands on
         // whole frames and the samples of a frame that is not complete yet wait here for the next block (at the end of the stream they
         // are handed on as they are: rodio's adapters take them too).
-        auto part = std::make_shared<detail::DeviceBuf>(64);
+        auto part = std::make_shared<detail::DeviceBuf>(std::max<std::size_t>(64, channels));
         auto part_n = std::make_shared<std::size_t>(0);
         const std::uint16_t in_ch = ch_;
         const std::uint32_t from = rate_, to = sample_rate;
+        // uniform.rs:100-108: the bounds of the converter chain that is open are functions of the converters' counters: they run here, over
+        // counts, fed with the same pieces as the planner (detail::UniformCounter)
+        auto cnt = std::make_shared<detail::UniformCounter>(channels, sample_rate);
+        auto fed = std::make_shared<std::uint64_t>(0);
+        const std::optional<Nanos> captured = total_duration();  // uniform.rs:37: asked once, when the iterator is built
+        auto feed = [cnt, fed](const detail::Piece &p) {
+            cnt->feed(p, *fed);
+            *fed += p.n;
+        };
         push(
             [=](Ctx &c) {
                 plan->begin_block();
@@ -1037,6 +1395,7 @@ public:
                         if (take || (closes && !cs->fresh)) {
                             detail::Piece p{take, cs->fresh, closes, in_ch, from, 0, last && cs->left != 0, cs->fresh ? answer : std::nullopt, in_ch, from, cs->fresh, std::nullopt};
                             plan->add(p, segs);
+                            feed(p);
                         }
                         if (take) cs->fresh = false;
                         off += take;
@@ -1050,10 +1409,15 @@ public:
                         detail::Piece p{c.n, !*started, c.flush, in_ch, from, 0, c.flush, std::nullopt, in_ch, from, !*started, std::nullopt};
                         *started = true;
                         plan->add(p, segs);
+                        feed(p);
                     }
                 } else {
-                    for (const detail::Piece &p : pieces_) plan->add(p, segs);
+                    for (const detail::Piece &p : pieces_) {
+                        plan->add(p, segs);
+                        feed(p);
+                    }
                 }
+                if (c.flush || c.end) cnt->input_ended();
                 plan->end_block();
                 const std::size_t carried = *part_n;
                 if (carried) check(rh_memcpy_d2d(c.out, part->get(), carried * sizeof(float), c.stream), "rh_memcpy_d2d");
@@ -1082,13 +1446,18 @@ public:
                 const std::uint64_t f = n / ich + 1;
                 return (std::size_t)(std::max<std::uint64_t>(f, f * to / ifrom + 2) + (detail::UniformPlanner::close_slack_frames((std::uint32_t)ifrom, to) + 1) * ((computed ? pieces_.size() * ((in_ch + in_ch0() - 1) / in_ch0()) + n / 32768 + 4 : one_span ? 1 : pieces_.size()) + 2) + 1) * channels;  // (computed: a span of the upstream per piece -- more where a channel_volume in between made more samples of them --, the cuts at 32768, a take's end)
             })
-            .on_seek([plan, part_n, started, cs, channels, sample_rate](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
+            .on_seek([plan, part_n, started, cs, channels, sample_rate, cnt, fed](Nanos) {  // what was pulled ahead is gone: the next span starts a fresh chain
                 *plan = detail::UniformPlanner(channels, sample_rate);
                 *part_n = 0;
                 *started = false;
                 cs->open = false;
-            });
+                *cnt = detail::UniformCounter(channels, sample_rate);
+                *fed = 0;
+            })
+            .duration([captured](std::optional<Nanos>) { return captured; })  // uniform.rs:131-133
+            .hints([cnt](const HintAt &in, std::uint64_t e) { return cnt->hint_at(e, in).value_or(SizeHint{0, std::nullopt}); });
         stages_.back().span_rule = 1;
+        last_kind_ = 1;
         stages_.back().fmt = one_span ? 0 : 3;  // every piece comes with its own format (uniform.rs:58-59: read at every bootstrap); behind another converter nothing changes any more
         ch_ = channels;
         rate_ = sample_rate;
@@ -1144,25 +1513,34 @@ public:
         });
     }
     /// `take_duration(d)`, with `set_filter_fadeout()` when `fade_out` (take.rs:96-148): the samples the duration admits, a cut
-    /// frame completed with zeros, then the end of the stream.  Seeking moves the upstream only (take.rs forwards try_seek).
+    /// frame completed with zeros, then the end of the stream.  `try_seek` moves the upstream and starts the duration over from
+    /// the new position: what is left is the requested duration less `pos` (take.rs:222-231).
     GpuSource &take_duration(Nanos duration, bool fade_out = false) {
         const std::uint16_t ch = ch_;
         const std::uint32_t rate = rate_;
-        auto pos = std::make_shared<std::uint64_t>(0);
-        auto done = std::make_shared<bool>(false);
+        const std::uint64_t requested = (std::uint64_t)duration.count();
+        struct Took {
+            std::uint64_t remaining;     // of the duration, at the next sample the adapter takes
+            std::uint32_t phase = 0;     // samples of the current frame already emitted (take.rs:124-131)
+            bool done = false;
+            std::uint64_t since = 0;     // what was left of the duration at the start of the stream / behind the last seek (size_hint counts from there)
+        };
+        auto tk = std::make_shared<Took>();
+        tk->remaining = tk->since = requested;
         // the samples the duration admits: one per duration_per_sample = 1e9 / (rate * channels) ns, integer (take.rs:21-24,124-131)
         const std::uint64_t per_sample = 1000000000ull / ((std::uint64_t)rate * ch);
-        const std::uint64_t admits = per_sample ? (std::uint64_t)duration.count() / per_sample : 0;
+        const std::uint64_t admits = per_sample ? requested / per_sample : 0;
         return push(
             [=](Ctx &c) {
                 c.end = true;
-                if (*done) return std::size_t(0);
-                std::uint64_t m = 0;
+                if (tk->done) return std::size_t(0);
+                std::uint64_t m = 0, after = 0;
                 std::int32_t ended = 0;
-                check(rh_take_duration(c.out, c.in, c.n, *pos, ch, rate, (std::uint64_t)duration.count(), fade_out ? 1 : 0, &m, &ended, c.stream), "rh_take_duration");
-                *pos += c.n;
-                *done = ended != 0;
-                c.end = *done;
+                check(rh_take_duration_from(c.out, c.in, c.n, tk->remaining, requested, tk->phase, ch, rate, fade_out ? 1 : 0, &m, &ended, &after, c.stream), "rh_take_duration_from");
+                if (per_sample) tk->phase = (std::uint32_t)((tk->phase + (tk->remaining - after) / per_sample) % ch);
+                tk->remaining = after;
+                tk->done = ended != 0;
+                c.end = tk->done;
                 return (std::size_t)m;
             },
             [ch](std::size_t n) { return n + ch; })
@@ -1173,7 +1551,26 @@ public:
                     return in && *in < rem ? in : std::optional<std::size_t>((std::size_t)rem);
                 },
                 [admits](std::uint64_t emitted) { return std::min(emitted, admits); })  // (behind them: the silence that completes a cut frame)
-            .keeps_the_sample_count();
+            .keeps_the_sample_count()
+            .on_seek([tk, requested](Nanos pos) {  // take.rs:222-231
+                const std::uint64_t p = (std::uint64_t)pos.count();
+                tk->remaining = tk->since = requested > p ? requested - p : 0;
+                tk->phase = 0;
+                tk->done = false;
+            })
+            .duration([duration](std::optional<Nanos> in) -> std::optional<Nanos> {  // take.rs:209-219
+                if (!in) return std::nullopt;
+                return *in < duration ? *in : duration;
+            })
+            // take.rs:151-171: what the remaining duration admits, cut to the input's bounds -- an upper bound even over an input that has none
+            .hints([tk, per_sample](const HintAt &in, std::uint64_t e) {
+                const std::uint64_t can = per_sample ? tk->since / per_sample : 0, took = std::min(e, can);
+                const std::uint64_t remaining = tk->since - took * per_sample;
+                if (!per_sample || remaining == 0) return SizeHint{0, std::size_t(0)};
+                const std::size_t rs = (std::size_t)(remaining / per_sample);
+                const SizeHint h = in(took);
+                return SizeHint{std::min(h.lower, rs), h.upper ? std::min(*h.upper, rs) : rs};
+            });
     }
     /// `delay(d)` (delay.rs:8-16,68-75): rh_delay_samples() zeros in front of the stream.  Not seekable here (rodio's Delay
     /// splits the position between the silence and the input; the shim's seek hands every adapter the same position).
@@ -1215,7 +1612,15 @@ public:
                     if (!in) return std::nullopt;
                     return *in + (std::size_t)(d > emitted ? d - emitted : 0);
                 },
-                [d](std::uint64_t emitted) { return emitted > d ? emitted - d : 0; });
+                [d](std::uint64_t emitted) { return emitted > d ? emitted - d : 0; })
+            .duration([duration](std::optional<Nanos> in) { return in ? std::optional<Nanos>(*in + duration) : std::nullopt; })  // delay.rs:111-115: + the REQUESTED delay
+            .hints([d](const HintAt &in, std::uint64_t e) {  // delay.rs:78-84: the input's bounds plus the silence still owed
+                const std::size_t owed = (std::size_t)(d > e ? d - e : 0);
+                SizeHint h = in(e > d ? e - d : 0);
+                h.lower += owed;
+                if (h.upper) h.upper = *h.upper + owed;
+                return h;
+            });
     }
     GpuSource &fade_in(Nanos duration) { return linear_gain_ramp(duration, 0.0f, 1.0f, false); }  // fadein.rs:11-13
     GpuSource &fade_out(Nanos duration) { return linear_gain_ramp(duration, 1.0f, 0.0f, true); }  // fadeout.rs:13
@@ -1232,12 +1637,13 @@ protected:
             for (const Stage &st : stages_) span_log_on_ = span_log_on_ || st.span_fn;
         }
         const std::size_t want = block_frames_ * cur_in_ch_;
+        hint_->log.note(pulled_total_, up_->size_hint());  // (size_hint(): what the upstream answers where this block's first sample is pulled)
         // The slot's page-locked staging block is about to be rewritten: the copy that read it two blocks ago must have run.  A host
         // consumer has waited for that block's event already (advance()); one that takes the blocks on the device never waits on the
         // host, so the wait is here (otherwise the refill races the asynchronous host-to-device copy of the block before).
         // Almost always satisfied by the time the slot comes round again.
         if (device_out_) check(rh_event_synchronize(s.done), "rh_event_synchronize");
-        s.in.reset(want + 64);
+        s.in.reset(want + std::max<std::size_t>(64, cur_in_ch_));  // (+ room for a cut frame of any layout)
         // 1. pull: runs of samples of one format (a format changes only between two spans)
         struct Run {
             std::size_t off, n;
@@ -1279,6 +1685,7 @@ protected:
             runs.push_back(Run{0, n, cur_in_ch_, cur_in_rate_, 0, 0});
         }
         in_total_ += n;
+        pulled_total_ += n;
         up_ended_ = up_ended_ || flush;
         if (span_log_.size() > 4096) {  // nobody has asked for a while: what lies in front of the sample the consumer's cursor reaches is not asked for any more
             std::uint64_t q = handed_out();
@@ -1426,6 +1833,31 @@ private:
         std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> span_fn = nullptr;
         std::function<std::uint64_t(std::uint64_t)> span_in_pos = nullptr;
         bool span_keeps_count = false;  // ... and it hands on one sample per sample until it ends the stream (take_duration): the input's spans lie where they lay
+        // total_duration() behind the adapter from its input's (null: the input's, amplify.rs:95-97 and the like)
+        std::function<std::optional<Nanos>(std::optional<Nanos>)> dur_fn = nullptr;
+    };
+    // size_hint(): what every adapter makes of its input's answer.  `in(q)`: the input's size_hint() once q of ITS samples have been taken;
+    // `emitted`: samples the adapter has emitted (both counted from the start of the stream, or from the last seek).  The state lives apart from
+    // the chain (shared): a consumer that keeps asking after the chain has been retired (GpuMixer) holds on to it.
+    using HintAt = std::function<SizeHint(std::uint64_t)>;
+    struct HintStage {
+        std::function<SizeHint(const HintAt &in, std::uint64_t emitted)> fn = nullptr;  // null: in(in_pos(emitted))
+        std::function<std::uint64_t(std::uint64_t)> in_pos = nullptr;                   // null: one sample in per sample out
+    };
+    struct HintState {
+        std::vector<HintStage> stages;
+        detail::HintLog log;         // the upstream's answers, by the sample at which it was asked
+        SizeHint before;             // ... and its answer while nothing has been pulled
+        std::uint64_t out_base = 0, in_base = 0, skip = 0;  // (after a seek) samples the chain had served / the upstream had given by then; samples dropped to keep the consumer's channel
+        SizeHint at(std::uint64_t emitted) const {
+            const std::uint64_t rel = (emitted > out_base ? emitted - out_base : 0) + skip;
+            HintAt h = [this](std::uint64_t q) { return log.empty() ? before : log.at(in_base + q); };
+            for (const HintStage &st : stages) {
+                if (st.fn) h = [prev = std::move(h), &st](std::uint64_t x) { return st.fn(prev, x); };
+                else if (st.in_pos) h = [prev = std::move(h), &st](std::uint64_t x) { return prev(st.in_pos(x)); };
+            }
+            return h(rel);
+        }
     };
     template <class T>
     struct Handle {
@@ -1438,11 +1870,23 @@ private:
     template <class F>
     GpuSource &push(F run) {
         stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), [](std::size_t n) { return n; }, true, nullptr, 0, 2, nullptr});
+        hint_->stages.emplace_back();
+        last_kind_ = 0;
         return *this;
     }
     template <class F, class B>
     GpuSource &push(F run, B bound) {
         stages_.push_back(Stage{std::function<std::size_t(Ctx &)>(run), std::function<std::size_t(std::size_t)>(bound), true, nullptr, 2, 2, nullptr});
+        hint_->stages.emplace_back();
+        last_kind_ = 0;
+        return *this;
+    }
+    GpuSource &duration(std::function<std::optional<Nanos>(std::optional<Nanos>)> f) {  // for the stage pushed last
+        stages_.back().dur_fn = std::move(f);
+        return *this;
+    }
+    GpuSource &hints(std::function<SizeHint(const HintAt &, std::uint64_t)> f) {  // for the stage pushed last
+        hint_->stages.back().fn = std::move(f);
         return *this;
     }
     GpuSource &any_format() {  // for the stage pushed last
@@ -1454,7 +1898,13 @@ private:
         stages_.back().on_format = std::move(f);
         return *this;
     }
-    GpuSource &on_seek(std::function<void(Nanos)> f) {  // for the stage pushed last
+    GpuSource &on_seek(std::function<void(Nanos)> f) {  // for the stage pushed last (a second call adds to the first)
+        if (stages_.back().on_seek) {
+            f = [a = std::move(stages_.back().on_seek), b = std::move(f)](Nanos p) {
+                a(p);
+                b(p);
+            };
+        }
         stages_.back().on_seek = std::move(f);
         return *this;
     }
@@ -1478,6 +1928,7 @@ private:
     }
     GpuSource &span_arithmetic(std::function<std::optional<std::size_t>(std::optional<std::size_t>, std::uint64_t)> fn, std::function<std::uint64_t(std::uint64_t)> in_pos) {
         stages_.back().span_fn = std::move(fn);
+        hint_->stages.back().in_pos = in_pos;
         stages_.back().span_in_pos = std::move(in_pos);
         return *this;
     }
@@ -1647,6 +2098,12 @@ private:
         auto ap = std::make_shared<Applier>(make(rate_));
         auto st = state(4u * ch);
         auto fc = std::make_shared<FrameCarry>();
+        const bool behind_uniform = last_kind_ == 1;
+        struct Mark {  // (runs when the builder expression is complete: the adapter pushed last is this filter)
+            GpuSource *g;
+            bool on;
+            ~Mark() { g->last_kind_ = on ? 2 : 0; }
+        } mark{this, behind_uniform};
         return push([=](Ctx &c) {
             return run_framewise(c, ch, *fc, st->get(), 4u * ch, [&](float *out, const float *in, std::size_t frames, float *state) {
                 check(rh_biquad(out, in, frames, ch, 1, ap->co, state, ap->exact ? 0 : 1, c.stream), "rh_biquad");
@@ -1686,6 +2143,10 @@ private:
     mutable std::deque<std::pair<std::uint64_t, std::optional<std::size_t>>> span_log_;
     std::uint64_t in_total_ = 0;
     bool up_ended_ = false, span_log_on_ = false;
+    std::shared_ptr<HintState> hint_ = std::make_shared<HintState>();  // size_hint(): see HintState
+    int last_kind_ = 0;  // the adapter pushed last: 1 a `uniform`, 2 a filter right behind a `uniform`, 0 anything else
+    friend class GpuMixer;
+    std::uint64_t pulled_total_ = 0;                                   // samples pulled from the upstream, whatever was sought in between
     std::uint16_t block_min_ch_ = 0;        // the fewest channels / the lowest rate among the pieces of the block being enqueued (0: none)
     std::uint32_t block_min_rate_ = 0;
     bool follow_spans_ = false, follow_known_ = false;  // the upstream reports spans: it is pulled span by span (asked once, at the first block)
@@ -1902,6 +2363,34 @@ public:
     }
     std::uint16_t channels() const override { return out_ch_; }
     std::uint32_t sample_rate() const override { return rate_; }
+    /// mixer.rs:104-106: a mixer has no duration.
+    std::optional<Nanos> total_duration() const override { return std::nullopt; }
+    /// mixer.rs:139-166: (0, Some(0)) while no source plays -- sources that wait for the next frame do not count --; otherwise the largest lower
+    /// bound among the sources that play where the CONSUMER stands, and no upper bound (every source sits in a UniformSourceIterator,
+    /// mixer.rs:58-66, whose upper bound is None: uniform.rs:100-108).  A source plays from the call that admitted it to the call in which it
+    /// returns None (mixer.rs:185-198).  Which adapters rodio's spelling of add(src, gain, filter) has: see HintTrack.
+    SizeHint size_hint() const override {
+        const std::uint64_t consumed = started() ? slot_base_[cur_index()] * out_ch_ + position() : 0;
+        bool any = false;
+        std::size_t lower = 0;
+        for (std::size_t i = 0; i < hints_.size();) {
+            HintTrack &t = *hints_[i];
+            const std::uint64_t first = t.join_frame * out_ch_;
+            if (consumed <= first) {
+                ++i;
+                continue;  // admitted by a call still to come
+            }
+            const std::optional<std::size_t> lo = t.lower_at(consumed - first, out_ch_);
+            if (!lo) {  // it has returned None in front of the consumer: gone for good
+                hints_.erase(hints_.begin() + (std::ptrdiff_t)i);
+                continue;
+            }
+            any = true;
+            lower = std::max(lower, *lo);
+            ++i;
+        }
+        return any ? SizeHint{lower, std::nullopt} : SizeHint{0, std::size_t(0)};
+    }
     /// What became of the GpuSource chains handed to add(): how many there were, how many delivered their blocks on the device, and
     /// the samples of chain output that crossed to the host (0 when every chain stayed on the device) / went device-to-device.
     struct ChainStats {
@@ -2030,6 +2519,63 @@ private:
     }
     struct Src;
     struct Gen;
+    /// size_hint() of ONE source of the mix, where the mixer's consumer stands.  rodio's spelling of add(src, gain, filter):
+    ///     mixer.add(src)                                                          gain 1, no filter
+    ///     mixer.add(src.amplify(g))                                               a gain (amplify.rs:68-70 hands the bounds on)
+    ///     mixer.add(UniformSourceIterator::new(src.amplify(g), ch, rate).low_pass(f))   a filter: it runs at the mixer's rate, behind a converter of its own
+    /// and Mixer::add wraps what it gets in a UniformSourceIterator (mixer.rs:58-66).  So the bounds are those of ONE iterator over the source
+    /// (`counter`: the mixer itself converts; or the chain's own last `uniform`), and behind a filter of one more -- a pass-through at the
+    /// mixer's own format, whose ChannelCountConverter still counts in whole frames from where it stands (channels.rs:88-102).
+    struct HintTrack {
+        std::uint64_t join_frame = 0;                     // the mixer frame of the source's first frame
+        std::shared_ptr<detail::UniformCounter> counter;  // the iterator the mixer stands for (null: the chain ends with its own)
+        detail::HintLog log;                              // a plain source's answers by the sample at which it was asked
+        std::shared_ptr<GpuSource::HintState> chain;      // a GpuSource chain: its own arithmetic (kept alive beyond the chain)
+        std::uint64_t pulled = 0;                         // samples taken from the source
+        bool wrapped_again = false;                       // a filter sits behind the iterator: Mixer::add's own iterator comes on top
+        bool total_known = false;                         // a chain that ends with its own iterator: the length of its stream, once it has ended
+        std::uint64_t total = 0;
+        SizeHint source_at(std::uint64_t q) const { return chain ? chain->at(q) : log.empty() ? SizeHint{} : log.at(q); }
+        std::optional<std::size_t> lower_at(std::uint64_t e, std::uint16_t ch) {
+            std::size_t lo;
+            if (counter) {
+                const std::optional<SizeHint> h = counter->hint_at(e, [this](std::uint64_t q) { return source_at(q); });
+                if (!h) return std::nullopt;
+                lo = h->lower;
+            } else {
+                if (total_known && e > total) return std::nullopt;
+                lo = source_at(e).lower;
+            }
+            if (!wrapped_again) return lo;
+            const std::uint64_t pos = e % ch;  // channels.rs:88-102 with from == to: ((lower + pos) / ch * ch) - pos
+            const std::uint64_t x = (lo + pos) / ch * ch;
+            return (std::size_t)(x > pos ? x - pos : 0);
+        }
+    };
+    mutable std::vector<std::shared_ptr<HintTrack>> hints_;
+    void track(Gen &g) {  // (start_stream / start_stream_wide: the generation's sources start playing)
+        for (Src &x : g.srcs) {
+            auto t = std::make_shared<HintTrack>();
+            t->join_frame = g.join;
+            const GpuSource *gs = x.up ? dynamic_cast<const GpuSource *>(x.up.get()) : nullptr;
+            if (gs) t->chain = gs->hint_;
+            if (gs && gs->hint_->log.empty()) gs->hint_->before = gs->up_->size_hint();
+            const bool own = gs && gs->ends_with_uniform() && gs->channels() == out_ch_ && gs->sample_rate() == rate_ && x.gain == 1.0f && x.filt.kind < 0;
+            const bool own_filtered = gs && !own && chain_ends_with_uniform_and_filter(*gs) && x.gain == 1.0f && x.filt.kind < 0;
+            if (own || own_filtered) {
+                t->wrapped_again = own_filtered;
+            } else {
+                t->counter = std::make_shared<detail::UniformCounter>(out_ch_, rate_);
+                t->wrapped_again = x.filt.kind >= 0;
+            }
+            x.hint = t;
+            hints_.push_back(std::move(t));
+        }
+    }
+    // (make_wide / add(chain) complete a chain to `.. -> uniform(channels, rate) -> filter`: the iterator is the last adapter but one)
+    static bool chain_ends_with_uniform_and_filter(const GpuSource &gs) {
+        return gs.last_kind_ == 2;
+    }
     static void count_chain(const Src &x, ChainStats &st) {
         const GpuSource *g = x.up ? dynamic_cast<const GpuSource *>(x.up.get()) : nullptr;
         if (!g) return;
@@ -2055,6 +2601,18 @@ private:
         detail::UniformPlanner plan;
         std::uint64_t have_s = 0, off_s = 0;  // converted SAMPLES not yet mixed: `have_s` of them from sample `off_s` of the source's device row
         std::uint64_t total_s = 0;            // samples of the source's stream in the mixer's layout so far (where the generation tracks them: Gen::track)
+        std::shared_ptr<HintTrack> hint;      // size_hint(): see HintTrack
+        // a pull of `got` samples (ONE continuous span: the source reports none); `ended`: it returned None behind them
+        void note_pull(std::size_t got, bool ended_now) {
+            if (!hint) return;
+            if (hint->counter) {
+                detail::Piece p{got, hint->pulled == 0, ended_now, ch, 0, 0, ended_now, std::nullopt, ch, 0, hint->pulled == 0, std::nullopt};
+                p.rate = p.src_rate = up->sample_rate();
+                if (got || ended_now) hint->counter->feed(p, hint->pulled);
+                if (ended_now) hint->counter->input_ended();
+            }
+            hint->pulled += got;
+        }
     };
     struct Gen {  // sources that joined together: one clock, one fused stream
         std::vector<Src> srcs;
@@ -2262,6 +2820,7 @@ private:
             for (auto &b : other->q) grow_keep(b, out_cap_frames_ * 2 * qch_, (other->head + other->fill) * qch_);
         for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * qch_);
         last_join_ = join;
+        track(g);
         gens_.push_back(std::move(gp));
     }
     void start_stream(std::vector<Src> srcs, bool staged, bool mono = false) {
@@ -2315,6 +2874,7 @@ private:
         for (auto &b : g.q) b.reset(out_cap_frames_ * 2 * qch_);
         g.track = staged || from == rate_;  // the sources' streams reach the mix sample for sample: a stream that ends inside a frame is seen
         last_join_ = scheduled_;
+        track(g);
         gens_.push_back(std::move(gp));
     }
     void grow_keep(detail::DeviceBuf &b, std::size_t floats, std::size_t keep) {
@@ -2379,8 +2939,10 @@ private:
             if (!x.ended) {
                 std::size_t got = x.dev->read_device(row, want, stream_);
                 x.total_s += got;
+                x.note_pull(got, got < want);
                 if (got < want) {
                     x.ended = true;
+                    if (x.hint) x.hint->total_known = true, x.hint->total = x.total_s;
                     if (const std::size_t cut = got % qch_) {
                         check(rh_memset(row + got, 0, (qch_ - cut) * sizeof(float), stream_), "rh_memset");
                         got += qch_ - cut;
@@ -2479,13 +3041,17 @@ private:
                 const std::uint64_t n = std::min<std::uint64_t>(std::min(need, most), room);
                 if (!n) break;
                 detail::Piece pc;
+                if (x.hint && !x.hint->chain) x.hint->log.note(x.hint->pulled, x.up->size_hint());
                 const bool produced = x.reader.read_piece(row + fill, (std::size_t)n, pc);  // straight into the staging block
                 if (produced) {
                     fill += pc.n;
                     x.plan.add(pc, segs);
+                    if (x.hint && x.hint->counter) x.hint->counter->feed(pc, x.hint->pulled);
+                    if (x.hint) x.hint->pulled += pc.n;
                 }
                 if (x.reader.ended()) {
                     x.ended = true;
+                    if (x.hint && x.hint->counter) x.hint->counter->input_ended();
                     break;
                 }
                 if (!produced) break;
@@ -2602,8 +3168,10 @@ private:
             if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
             if (!x.ended) {
                 const std::size_t want = opt_.block_frames * ch;
+                if (x.hint && !x.hint->chain) x.hint->log.note(x.hint->pulled, x.up->size_hint());
                 std::size_t got = x.up->read(row + have, want);  // straight into the staging block
                 x.ended = got < want;
+                x.note_pull(got, x.ended);
                 // sources end on frame boundaries (source/mod.rs:169-178); one that reports no spans and ends inside a frame all the same is
                 // refused rather than shortened (rodio would convert the cut frame's samples; span-reporting sources take the staged path, which does)
                 if (got % ch) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
@@ -2635,6 +3203,8 @@ private:
                 std::size_t got = x.dev->read_device(row + have, want, copy_stream_);
                 x.ended = got < want;
                 x.total_s += got;
+                x.note_pull(got, x.ended);
+                if (x.ended && x.hint) x.hint->total_known = true, x.hint->total = x.total_s;
                 if (got % 2) {  // the chain's stream ends inside a frame (want is whole frames): its last sample is mixed, the missing one is +0.0
                     check(rh_memset(row + have + got, 0, sizeof(float), copy_stream_), "rh_memset");
                     got += 1;
@@ -2724,6 +3294,8 @@ private:
         last_join_ = J;
         Gen &g = *gens_.back();
         g.join = J;
+        for (Src &x : g.srcs)
+            if (x.hint) x.hint->join_frame = J;
         const std::uint64_t need = sched_end > J ? sched_end - J : 0;
         if (need + 64 > out_cap_frames_) {
             // the newcomer catches up with everything that is scheduled -- up to two blocks, and a block of a generation that ran behind a

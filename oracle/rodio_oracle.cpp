@@ -83,8 +83,8 @@ struct VecSource : Source {
     bool exact_hint;
     long long total_ns = -1;
     VecSource(const float *d, size_t n, uint16_t c, uint32_t r, long sp)
-        : data(d, d + n), ch(c), rate(r), span(sp), exact_hint(sp == -2) {
-        if (sp == -2) total_ns = (long long)(1000000000ull * (uint64_t)n / r / c);  // buffer.rs:45-51
+        : data(d, d + n), ch(c), rate(r), span(sp), exact_hint(sp != -1) {  // (a source of constant spans -- packets -- is a SamplesBuffer that answers current_span_len() differently)
+        if (sp != -1) total_ns = (long long)(1000000000ull * (uint64_t)n / r / c);  // buffer.rs:45-51
     }
     Hint size_hint() const override {
         if (!exact_hint) return Hint{0, false, 0};
@@ -304,6 +304,8 @@ struct SampleRateConverter : Source {
         if (from == to) return in;  // :232-233
         return Hint{apply_hint(in.lo), in.bounded, in.bounded ? apply_hint(in.hi) : 0};
     }
+    // (the converters are plain iterators in rodio, not Sources: what wraps them in the oracle's plumbing sees the input's duration)
+    long long total_duration_ns() const override { return input->total_duration_ns(); }
 };
 
 // ------------------------------------------------ ChannelCountConverter ----
@@ -360,6 +362,7 @@ struct ChannelCountConverter : Source {
         };
         return Hint{f(in.lo), in.bounded, in.bounded ? f(in.hi) : 0};
     }
+    long long total_duration_ns() const override { return input->total_duration_ns(); }  // (see SampleRateConverter)
 };
 
 // src/source/uniform.rs:148-178 (private `Take`)
@@ -1173,6 +1176,12 @@ void *orc_uniform(void *in, int ch, unsigned rate) {
 }
 void *orc_amplify(void *in, float factor) { return new Amplify((Source *)in, factor); }
 void *orc_take_duration(void *in, unsigned long long ns, int fade_out) { return new TakeDuration((Source *)in, ns, fade_out != 0); }
+// ... in the state `try_seek(pos)` leaves it in (take.rs:222-231): remaining = requested.saturating_sub(pos), the frame position 0
+void *orc_take_duration_sought(void *in, unsigned long long requested_ns, unsigned long long pos_ns, int fade_out) {
+    TakeDuration *t = new TakeDuration((Source *)in, requested_ns, fade_out != 0);
+    t->remaining_ns = requested_ns > pos_ns ? requested_ns - pos_ns : 0;
+    return t;
+}
 void *orc_dither(void *in, unsigned bits, int algorithm, unsigned long long seed) { return new Dither((Source *)in, bits, algorithm, seed); }
 void *orc_distortion(void *in, float gain, float threshold) { return new Distortion((Source *)in, gain, threshold); }
 void *orc_linear_gain_ramp(void *in, unsigned long long ns, float a, float b, int clamp_end) { return new LinearGainRamp((Source *)in, ns, a, b, clamp_end != 0); }

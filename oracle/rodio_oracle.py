@@ -50,6 +50,7 @@ def _load():
         "orc_distortion": (vp, [vp, C.c_float, C.c_float]),
         "orc_dither": (vp, [vp, C.c_uint, C.c_int, C.c_ulonglong]),
         "orc_take_duration": (vp, [vp, C.c_ulonglong, C.c_int]),
+        "orc_take_duration_sought": (vp, [vp, C.c_ulonglong, C.c_ulonglong, C.c_int]),
         "orc_linear_gain_ramp": (vp, [vp, C.c_ulonglong, C.c_float, C.c_float, C.c_int]),
         "orc_low_pass": (vp, [vp, C.c_uint, C.c_float]),
         "orc_high_pass": (vp, [vp, C.c_uint, C.c_float]),
@@ -173,6 +174,9 @@ class Source:
 
     def take_duration(self, duration_ns, fade_out=False):  # take.rs; fade_out = set_filter_fadeout()
         return Source(_lib.orc_take_duration(self._take(), duration_ns, int(fade_out)))
+
+    def take_duration_sought(self, duration_ns, pos_ns, fade_out=False):  # take.rs:222-231: the adapter as try_seek(pos) leaves it
+        return Source(_lib.orc_take_duration_sought(self._take(), duration_ns, pos_ns, int(fade_out)))
 
     def dither(self, target_bits, algorithm="TPDF", seed=0):  # dither.rs:217-242 with the counter-based noise contract
         return Source(_lib.orc_dither(self._take(), target_bits, {"GPDF": 0, "HighPass": 1, "RPDF": 2, "TPDF": 3}[algorithm], seed))

@@ -146,6 +146,7 @@ SIGNATURES = {
     "rh_wav_header_f32_host": (sz, [vp, sz, u32, u32, u64]),
     "rh_delay": (i32, [vp, vp, u64, u64, vp]),
     "rh_take_duration": (i32, [vp, vp, u64, u64, u32, u32, u64, i32, C.POINTER(u64), C.POINTER(i32), vp]),
+    "rh_take_duration_from": (i32, [vp, vp, u64, u64, u64, u32, u32, u32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64), vp]),
     "rh_distortion": (i32, [vp, vp, sz, f32, f32, vp]),
     "rh_db_to_linear": (f32, [f32]),
     "rh_linear_to_db": (f32, [f32]),

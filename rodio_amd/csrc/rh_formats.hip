@@ -128,16 +128,16 @@ __global__ __launch_bounds__(kBlock) void k_delay(float *__restrict__ dst, const
 }
 // TakeDuration: src/source/take.rs:96-148.  out[i] = x[i] (optionally * remaining_ms / total_ms, the
 // fade-out filter of :33-38) for the `take` samples the duration admits, then `pad` zeros that complete
-// the frame.  remaining at sample k of the stream = duration - k * (1e9 / (rate*channels)).
-__global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ dst, const float *__restrict__ src, uint64_t take, uint64_t pad, uint64_t k0, uint64_t dps_ns,
-                                                          uint64_t duration_ns, int fade) {
+// the frame.  remaining at sample i of the block = rem0 - i * (1e9 / (rate*channels)).
+__global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ dst, const float *__restrict__ src, uint64_t take, uint64_t pad, uint64_t rem0_ns, uint64_t dps_ns,
+                                                          uint64_t requested_ns, int fade) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const float total = (float)(duration_ns / 1000000ull);
+    const float total = (float)(requested_ns / 1000000ull);
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < take + pad; i += stride) {
         float v = 0.0f;
         if (i < take) {
             v = src[i];
-            if (fade) v = v * (float)((duration_ns - (k0 + i) * dps_ns) / 1000000ull) / total;
+            if (fade) v = v * (float)((rem0_ns - i * dps_ns) / 1000000ull) / total;
         }
         dst[i] = v;
     }
@@ -201,24 +201,37 @@ rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samp
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
-rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out,
-                           uint64_t *out_samples, int32_t *ended, rh_stream stream) {
+rh_status rh_take_duration_from(float *dst, const float *src, uint64_t n, uint64_t remaining_ns, uint64_t requested_ns, uint32_t frame_phase, uint32_t channels, uint32_t sample_rate,
+                                int32_t fade_out, uint64_t *out_samples, int32_t *ended, uint64_t *remaining_after_ns, rh_stream stream) {
     RH_REQUIRE_INIT();
-    if (channels == 0 || sample_rate == 0 || !out_samples) return RH_ERR_INVALID;
+    if (channels == 0 || sample_rate == 0 || !out_samples || frame_phase >= channels) return RH_ERR_INVALID;
     const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);  // take.rs:63-67
     if (dps == 0) return RH_ERR_UNSUPPORTED;  // above 1 GHz*channel the reference never expires
-    const uint64_t K = duration_ns / dps;  // samples of the stream the duration admits
-    const uint64_t left = K > sample_offset ? K - sample_offset : 0;
+    const uint64_t left = remaining_ns / dps;  // samples the remaining duration admits (:107: `remaining < duration_per_sample` ends it)
     const uint64_t take = n < left ? n : left;
-    const bool expires_here = left <= n;                       // the duration runs out inside this block (or exactly at its end)
-    const uint64_t pad = expires_here && K % channels ? channels - K % channels : 0;
+    const bool expires_here = left <= n;       // the duration runs out inside this block (or exactly at its end)
+    const uint64_t phase_end = (frame_phase + take) % channels;
+    const uint64_t pad = expires_here && phase_end ? channels - phase_end : 0;  // :107-115
     *out_samples = take + pad;
     if (ended) *ended = expires_here ? 1 : 0;
+    if (remaining_after_ns) *remaining_after_ns = remaining_ns - take * dps;
     if (take + pad == 0) return RH_OK;
     if (!dst || (take && !src)) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_for(take + pad)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, sample_offset, dps, duration_ns, fade_out ? 1 : 0);
+    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_for(take + pad)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, remaining_ns, dps, requested_ns, fade_out ? 1 : 0);
     RH_CHECK_LAUNCH();
     return RH_OK;
+}
+rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out,
+                           uint64_t *out_samples, int32_t *ended, rh_stream stream) {
+    if (channels == 0 || sample_rate == 0) return RH_ERR_INVALID;
+    const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);
+    if (dps == 0) {
+        RH_REQUIRE_INIT();
+        return RH_ERR_UNSUPPORTED;
+    }
+    const uint64_t K = duration_ns / dps;  // samples of the stream the duration admits
+    const uint64_t done = sample_offset < K ? sample_offset : K;
+    return rh_take_duration_from(dst, src, n, duration_ns - done * dps, duration_ns, (uint32_t)(done % channels), channels, sample_rate, fade_out, out_samples, ended, nullptr, stream);
 }
 rh_status rh_convert_f32_to_u8(uint8_t *dst, const float *src, size_t n, rh_stream s) { return launch<F32ToU8>(dst, src, n, s); }
 rh_status rh_convert_f32_to_i24(int32_t *dst, const float *src, size_t n, rh_stream s) { return launch<F32ToI24>(dst, src, n, s); }

@@ -133,6 +133,7 @@ pub struct Piece {
     pub opens: bool, pub closes: bool, pub ch: u16, pub rate: u32,
     pub tail: usize,         // closes only: samples of a CUT last frame (uniform.rs:56: `.min(32768)` cuts frames of 3, 5, 6, 7 channels)
     pub by_none: bool,       // closes only: the span ended because the source returned None, not because its samples were counted out
+    pub limit: Option<usize>,  // opens only: what `Take` admits to the span's chain, min(current_span_len(), 32768) (uniform.rs:56); None: the source reports no spans
 }
 
 /// Pulls a source the way `UniformSourceIterator` does (`uniform.rs:50-97`): whenever its converter chain has run dry it asks
@@ -140,7 +141,7 @@ pub struct Piece {
 /// `min(span, 32768)` samples (`Take`, `uniform.rs:56,148-178`) to the chain it builds for them.  A span ends when that many
 /// samples were taken or when the source returns `None`; the stream ends when a fresh chain yields nothing.
 #[derive(Default)]
-pub struct SpanReader { open: bool, fresh: bool, ended: bool, left: usize, ch: u16, rate: u32 }
+pub struct SpanReader { open: bool, fresh: bool, ended: bool, left: usize, ch: u16, rate: u32, limit: Option<usize> }
 const OPEN_ENDED: usize = usize::MAX;
 impl SpanReader {
     pub fn new() -> Self { SpanReader { fresh: true, ..Default::default() } }
@@ -157,6 +158,7 @@ impl SpanReader {
         self.rate = up.sample_rate().get();
         if span == Some(0) { self.ended = true; return false; }                  // Take{n: 0}: the chain is empty, next() is None
         self.left = span.map(|s| s.min(32768)).unwrap_or(OPEN_ENDED);
+        self.limit = span.map(|s| s.min(32768));
         // source/mod.rs:196-200 asks for spans of whole frames; `.min(32768)` breaks that for 3, 5, 6, 7 ... channels: the chain rodio
         // builds for such a span ends inside a frame and the next one starts there -- every later span has its channels rotated.  The
         // reader hands the cut frame's samples over with the span (`Piece::tail`) and goes on at the sample behind them, as rodio's
@@ -178,7 +180,7 @@ impl SpanReader {
         let closes = none || self.left == 0;
         let tail = if closes { got % ch } else { 0 };                             // (what becomes of it is the planner's business: it knows the target format)
         if !closes { got -= got % ch; }
-        let piece = Piece { n: got, opens: self.fresh, closes, ch: self.ch, rate: self.rate, tail, by_none: none };
+        let piece = Piece { n: got, opens: self.fresh, closes, ch: self.ch, rate: self.rate, tail, by_none: none, limit: if self.fresh { self.limit } else { None } };
         let produced = got != 0 || (closes && !self.fresh);                       // a span that had samples before ends here: its last frame is due
         if got != 0 { self.fresh = false; }
         if closes { self.open = false; }
@@ -416,6 +418,202 @@ trait BlockSource {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ size_hint ----
+/// `Iterator::size_hint()`: (lower, upper).
+pub type SizeHint = (usize, Option<usize>);
+
+/// What a source answered to `size_hint()` at the positions it was asked (the adapters read a block ahead of the consumer; rodio's adapters
+/// ask their input where THEY stand).  `at(q)`: the last answer recorded at or before sample q, less the samples taken since -- exact for a
+/// source that counts its samples down (buffer.rs:134-137) and for one that answers the trait's default (0, None); a valid bound otherwise.
+#[derive(Default)]
+pub struct HintLog { log: std::collections::VecDeque<(u64, SizeHint)> }
+impl HintLog {
+    pub fn note(&mut self, pos: u64, h: SizeHint) {
+        match self.log.back_mut() { Some(b) if b.0 == pos => b.1 = h, _ => self.log.push_back((pos, h)) }
+        if self.log.len() > 256 { self.log.pop_front(); }
+    }
+    pub fn is_empty(&self) -> bool { self.log.is_empty() }
+    pub fn clear(&mut self) { self.log.clear(); }
+    pub fn at(&mut self, q: u64) -> SizeHint {
+        while self.log.len() > 1 && self.log[1].0 <= q { self.log.pop_front(); }     // (the questions only move forward)
+        let (p, h) = self.log[0];
+        let since = q.saturating_sub(p) as usize;
+        (h.0.saturating_sub(since), h.1.map(|u| u.saturating_sub(since)))
+    }
+}
+
+/// `UniformSourceIterator::size_hint()` (uniform.rs:100-108): the lower bound of the converter chain that is open -- ChannelCountConverter
+/// (channels.rs:88-102) over SampleRateConverter (sample_rate.rs:204-238) over Take (uniform.rs:181-196) -- and no upper bound.  Those bounds
+/// are functions of the converters' COUNTERS; the samples are converted on the device, so this runs the three iterators' state machines
+/// over counts only, fed with the spans the samples were pulled in, lazily.  The twin of `detail::UniformCounter` (include/rodio_hip.hpp).
+pub struct UniformCounter {
+    to_ch: u16, to_rate: u32, bare: bool,
+    spans: std::collections::VecDeque<CountSpan>,                                 // front: the span of the open chain
+    open: bool, started: bool, done: u64, used: u64, left: usize,
+    from: u32, to: u32, pos_in_chunk: u32, out_pos: u32, cur_len: usize, next_len: usize, buf_len: usize, ccc_pos: u16, have_repeat: bool,
+}
+#[derive(Clone, Copy)]
+struct CountSpan { ch: u16, rate: u32, up_pos: u64, limited: bool, closed: bool, take_n: usize, got: u64, reps: u64 }
+impl UniformCounter {
+    /// `bare`: a SampleRateConverter on its own (no Take in front, no ChannelCountConverter behind): both of ITS bounds.
+    pub fn new(to_ch: u16, to_rate: u32, bare: bool) -> Self {
+        UniformCounter { to_ch, to_rate, bare, spans: Default::default(), open: false, started: false, done: 0, used: 0, left: 0, from: 1, to: 1, pos_in_chunk: 0, out_pos: 0,
+                         cur_len: 0, next_len: 0, buf_len: 0, ccc_pos: 0, have_repeat: false }
+    }
+    /// A piece of the input, in pull order; `up_pos`: samples taken from the iterator's input in front of it.
+    pub fn feed(&mut self, p: &Piece, up_pos: u64) {
+        if p.opens || self.spans.back().map_or(true, |b| b.closed) {
+            self.compact();
+            self.spans.push_back(CountSpan { ch: p.ch, rate: p.rate, up_pos, limited: p.limit.is_some(), closed: false, take_n: p.limit.unwrap_or(0), got: 0, reps: 1 });
+        }
+        let b = self.spans.back_mut().unwrap();
+        b.got += p.n as u64;
+        if p.closes { b.closed = true; }
+    }
+    pub fn input_ended(&mut self) { if let Some(b) = self.spans.back_mut() { b.closed = true; } }
+    fn compact(&mut self) {                                                       // the spans nobody has asked about yet, run-length encoded
+        let n = self.spans.len();
+        if n < 2 { return; }
+        let (a, b) = (self.spans[n - 2], self.spans[n - 1]);
+        if a.closed && b.closed && a.ch == b.ch && a.rate == b.rate && a.limited == b.limited && a.take_n == b.take_n && a.got == b.got && b.reps == 1 {
+            self.spans[n - 2].reps += 1;
+            self.spans.pop_back();
+        }
+    }
+    fn cur(&self) -> CountSpan { self.spans[0] }
+    fn taken_total(&self) -> u64 { if self.open { self.cur().up_pos + self.used } else { self.spans.front().map_or(0, |s| s.up_pos) } }
+    fn take_next(&mut self) -> bool {                                             // Take::next over the counts (uniform.rs:160-177)
+        let c = self.cur();
+        if c.limited { if self.left == 0 { return false; } self.left -= 1; }
+        if self.used < c.got { self.used += 1; return true; }
+        if c.closed { return false; }                                             // the input returned None here
+        self.used += 1;                                                           // (asked beyond what has been pulled: the sample is taken to exist)
+        true
+    }
+    fn take_frame(&mut self) -> usize { let ch = self.cur().ch as usize; let mut k = 0; while k < ch && self.take_next() { k += 1; } k }   // sample_rate.rs:58-71,113-121
+    fn next_input_span(&mut self) { self.pos_in_chunk += 1; self.cur_len = self.next_len; self.next_len = self.take_frame(); }               // sample_rate.rs:110-122
+    fn src_next(&mut self) -> bool {                                              // sample_rate.rs:131-201
+        if self.from == self.to { return self.take_next(); }
+        if self.buf_len > 0 { self.buf_len -= 1; return true; }
+        if self.out_pos == self.to {
+            self.out_pos = 0;
+            self.next_input_span();
+            while self.pos_in_chunk != self.from { self.next_input_span(); }
+            self.pos_in_chunk = 0;
+        } else {
+            let req = (self.from.wrapping_mul(self.out_pos) / self.to) % self.from;
+            while self.pos_in_chunk != req { self.next_input_span(); }
+        }
+        let n = self.cur_len.min(self.next_len);                                  // zip
+        self.out_pos += 1;
+        if n > 0 { self.buf_len = n - 1; return true; }
+        if self.cur_len == 0 { return false; }                                    // :193-200 draining `current_span`
+        self.buf_len = self.cur_len - 1;
+        self.cur_len = 0;
+        true
+    }
+    fn ccc_next(&mut self) -> bool {                                              // channels.rs:57-85
+        let (from, to) = (self.cur().ch, self.to_ch);
+        let some;
+        if self.ccc_pos == 0 { some = self.src_next(); self.have_repeat = some; }
+        else if self.ccc_pos < from { some = self.src_next(); }
+        else if self.ccc_pos == 1 { some = self.have_repeat; }
+        else { some = true; }
+        if some { self.ccc_pos += 1; }
+        if self.ccc_pos == to {
+            self.ccc_pos = 0;
+            for _ in to..from { let _ = self.src_next(); }
+        }
+        some
+    }
+    fn bootstrap(&mut self) -> bool {                                             // uniform.rs:50-68,82-92: the next span's chain
+        if self.open {
+            if self.spans[0].reps > 1 { self.spans[0].reps -= 1; self.spans[0].up_pos += self.spans[0].got; } else { self.spans.pop_front(); }
+        }
+        self.started = true;
+        if self.spans.is_empty() { self.open = false; return false; }             // nothing was pulled for another chain: the one rodio builds here is empty
+        self.open = true;
+        self.used = 0;
+        let c = self.cur();
+        self.left = c.take_n;
+        let (mut a, mut b) = (c.rate as u64, self.to_rate as u64);
+        while b != 0 { let t = a % b; a = b; b = t; }
+        self.from = (c.rate as u64 / a) as u32;
+        self.to = (self.to_rate as u64 / a) as u32;
+        self.pos_in_chunk = 0; self.out_pos = 0; self.buf_len = 0; self.ccc_pos = 0; self.have_repeat = false; self.cur_len = 0; self.next_len = 0;
+        if self.from != self.to { self.cur_len = self.take_frame(); self.next_len = self.take_frame(); }
+        true
+    }
+    fn step(&mut self) -> bool {                                                  // UniformSourceIterator::next (uniform.rs:76-97)
+        if self.bare {
+            if !self.started && !self.bootstrap() { return false; }
+            if !self.open || !self.src_next() { return false; }
+            self.done += 1;
+            return true;
+        }
+        if self.open && self.ccc_next() { self.done += 1; return true; }
+        if !self.bootstrap() || !self.ccc_next() { return false; }
+        self.done += 1;
+        true
+    }
+    /// `size_hint()` once the iterator has returned `e` samples; `None`: it returned None before that.  `in_hint(q)`: the input's
+    /// `size_hint()` at sample q of the input.
+    pub fn hint_at(&mut self, e: u64, in_hint: &mut dyn FnMut(u64) -> SizeHint) -> Option<SizeHint> {
+        while self.done < e { if !self.step() { return None; } }
+        if self.bare && !self.started && !self.spans.is_empty() { let _ = self.bootstrap(); }   // SampleRateConverter::new reads its first two frames (sample_rate.rs:58-71)
+        if !self.started { return Some((in_hint(self.taken_total()).0, None)); }    // uniform.rs:105: no chain has been built yet -- the pending input itself
+        if !self.open { return Some((0, None)); }
+        let c = self.cur();
+        let mut h = in_hint(self.taken_total());                                    // Take (uniform.rs:181-196)
+        if c.limited { h = (h.0.min(self.left), Some(h.1.map_or(self.left, |u| u.min(self.left)))); }
+        let (from, to, pos, out_pos, next_len, buf_len, ch) = (self.from, self.to, self.pos_in_chunk, self.out_pos, self.next_len, self.buf_len, c.ch as usize);
+        let apply = |samples: usize| -> usize {                                     // sample_rate.rs:204-238, usize / u32 arithmetic as written there
+            let mut after = samples;
+            if pos == from - 1 { after += next_len; }
+            let unread = from.saturating_sub(pos + 2) as usize * ch;
+            after = after.saturating_sub(unread);
+            after = after * to as usize / from as usize;
+            (to - out_pos) as usize * ch + after + buf_len
+        };
+        if from != to { h = (apply(h.0), h.1.map(apply)); }
+        if self.bare { return Some(h); }
+        let p = self.ccc_pos as usize;                                              // channels.rs:88-102; the iterator keeps the lower bound (uniform.rs:100-108)
+        let consumed = ch.min(p);
+        Some((((h.0 + consumed) / ch * self.to_ch as usize).saturating_sub(p), None))
+    }
+}
+
+/// What every adapter of a chain makes of its input's `size_hint()`.  `fun(in, emitted)`: `in(q)` = the input's answer once q of ITS samples
+/// have been taken, `emitted` = samples the adapter has emitted (both from the start of the stream, or from the last seek).  Shared (Arc):
+/// a consumer that keeps asking after the chain has been retired (GpuMixer) holds on to it.  The twin of `GpuSource::HintState`.
+pub struct HintStage {
+    pub fun: Option<Box<dyn FnMut(&mut dyn FnMut(u64) -> SizeHint, u64) -> SizeHint + Send>>,   // None: in(in_pos(emitted))
+    pub in_pos: Option<Box<dyn Fn(u64) -> u64 + Send>>,                                          // None: one sample in per sample out
+}
+#[derive(Default)]
+pub struct HintState { pub stages: Vec<HintStage>, pub log: HintLog, pub before: SizeHint, pub out_base: u64, pub in_base: u64, pub skip: u64 }
+impl HintState {
+    pub fn at(&mut self, emitted: u64) -> SizeHint {
+        let rel = emitted.saturating_sub(self.out_base) + self.skip;
+        let HintState { stages, log, before, in_base, .. } = self;
+        fn through(stages: &mut [HintStage], x: u64, base: &mut dyn FnMut(u64) -> SizeHint) -> SizeHint {
+            match stages.split_last_mut() {
+                None => base(x),
+                Some((st, front)) => {
+                    let mut input = |q: u64| through(front, q, base);
+                    match (&mut st.fun, &st.in_pos) {
+                        (Some(f), _) => f(&mut input, x),
+                        (None, Some(p)) => input(p(x)),
+                        (None, None) => input(x),
+                    }
+                }
+            }
+        }
+        let (b, ib) = (*before, *in_base);
+        through(stages, rel, &mut |q| if log.is_empty() { b } else { log.at(ib + q) })
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GpuSource ----
 struct Ctx<'a> { out: *mut f32, inp: *const f32, n: usize, out_cap: usize, flush: bool, stream: RhStream, pieces: &'a [Piece], end: bool }
 struct Stage {
@@ -440,15 +638,43 @@ pub struct GpuSource<I: Source> {
     may_cut: bool,     // an adapter of the chain can make the stream end inside a frame (may_end_inside_a_frame)
     filter_mode: u8,   // 0: by the filter contract, per filter (rh_filter_scan_ok); 1: reference order throughout; 2: time-parallel throughout
     a: DeviceBuf, b: DeviceBuf, pump: Pump,
+    hint: Arc<Mutex<HintState>>,   // size_hint(): see HintState
+    durs: Vec<Option<Box<dyn Fn(Option<Duration>) -> Option<Duration> + Send>>>,   // total_duration() behind every adapter from its input's (None: the input's, amplify.rs:95-97 and the like)
+    pulled_total: u64,             // samples pulled from the upstream, whatever was sought in between
+    last_kind: u8,                 // the adapter pushed last: 1 a `uniform`, 2 a filter right behind a `uniform`, 0 anything else
 }
+type Arc<T> = std::sync::Arc<T>;
+type Mutex<T> = std::sync::Mutex<T>;
 unsafe impl<I: Source + Send> Send for GpuSource<I> {}
 
 impl<I: Source> GpuSource<I> {
     pub fn new(upstream: I, block_frames: usize) -> Self {
         let (ch, rate) = (upstream.channels().get(), upstream.sample_rate().get());
         GpuSource { up: upstream, block_frames: block_frames.max(1), ch, rate, in_ch: ch, in_rate: rate, stages: Vec::new(), reader: SpanReader::new(),
-                    pieces: Vec::new(), span_aware: false, scan_kernels: false, may_cut: false, filter_mode: 0, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new() }
+                    pieces: Vec::new(), span_aware: false, scan_kernels: false, may_cut: false, filter_mode: 0, a: DeviceBuf::new(), b: DeviceBuf::new(), pump: Pump::new(),
+                    hint: Arc::new(Mutex::new(HintState::default())), durs: Vec::new(), pulled_total: 0, last_kind: 0 }
     }
+    /// `total_duration()` as rodio's adapters answer it, adapter by adapter: the input's behind the ones that keep it (amplify.rs:95-97,
+    /// blt.rs:171-173, limit.rs:592-594, agc.rs:588-590, channel_volume.rs:119-121), plus the delay behind `delay` (delay.rs:111-115), the
+    /// shorter of the two behind `take_duration` (take.rs:209-219), the longer behind `reverb` (mix.rs:104-112), and -- behind `reverb` and
+    /// `uniform` -- the value the input gave when the adapter was BUILT (buffered.rs:16, uniform.rs:37).
+    fn duration_through(&self) -> Option<Duration> {
+        let mut d = self.up.total_duration();
+        for f in self.durs.iter().flatten() { d = f(d); }
+        d
+    }
+    /// `size_hint()` once `emitted` samples of the chain's stream have been served (a consumer that takes the blocks ahead of ITS consumer:
+    /// GpuMixer); `size_hint()` itself asks for the consumer's own position.
+    pub fn size_hint_at(&self, emitted: u64) -> SizeHint {
+        let mut h = self.hint.lock().unwrap();
+        if h.log.is_empty() { h.before = self.up.size_hint(); }                     // nothing pulled (since the last seek): the upstream stands where the question reaches it
+        h.at(emitted)
+    }
+    /// The last adapter of the chain is a `uniform` (what Mixer::add would wrap the chain in is already there).
+    pub fn ends_with_uniform(&self) -> bool { self.last_kind == 1 }
+    fn set_hints(&mut self, f: impl FnMut(&mut dyn FnMut(u64) -> SizeHint, u64) -> SizeHint + Send + 'static) { self.hint.lock().unwrap().stages.last_mut().unwrap().fun = Some(Box::new(f)); }
+    fn set_in_pos(&mut self, f: impl Fn(u64) -> u64 + Send + 'static) { self.hint.lock().unwrap().stages.last_mut().unwrap().in_pos = Some(Box::new(f)); }
+    fn set_duration(&mut self, f: impl Fn(Option<Duration>) -> Option<Duration> + Send + 'static) { *self.durs.last_mut().unwrap() = Some(Box::new(f)); }
     pub fn inner(&self) -> &I { &self.up }
     pub fn inner_mut(&mut self) -> &mut I { &mut self.up }
     pub fn into_inner(self) -> I where I: Clone { self.up.clone() }
@@ -462,6 +688,9 @@ impl<I: Source> GpuSource<I> {
     pub fn answers_with_adapter_spans(&self) -> bool { self.stages.iter().rev().map(|s| s.span_rule).find(|&r| r != 0).unwrap_or(0) == 2 }
     fn push(&mut self, run: impl FnMut(&mut Ctx) -> usize + Send + 'static, bound: impl Fn(usize, usize) -> usize + Send + 'static, span_rule: u8) -> &mut Stage {
         self.stages.push(Stage { run: Box::new(run), bound: Box::new(bound), seekable: true, on_seek: None, span_rule });
+        self.hint.lock().unwrap().stages.push(HintStage { fun: None, in_pos: None });
+        self.durs.push(None);
+        self.last_kind = 0;
         self.stages.last_mut().unwrap()
     }
     fn state(&self, floats: usize) -> std::sync::Arc<State> {
@@ -512,12 +741,14 @@ impl<I: Source> GpuSource<I> {
         let st = self.state(4 * ch as usize);
         let exact = self.filter_mode == 1 || (self.filter_mode == 0 && unsafe { rh_filter_scan_ok(kind, freq, q, self.rate) } == 0);   // the filter contract (rodio_hip.h)
         let (st2, sm, mode) = (st.clone(), self.pump.stream as usize, if exact { 0 } else { 1 });
+        let behind_uniform = self.last_kind == 1;
         let stage = self.push(move |c| {
             let frames = c.n / ch as usize;
             ck(unsafe { rh_biquad(c.out, c.inp, frames as u64, ch, 1, co.as_ptr(), st.0.p, mode, c.stream) }, "rh_biquad");
             frames * ch as usize
         }, |n, _| n, 0);
         stage.on_seek = Some(Box::new(move |_| ck(unsafe { rh_memset(st2.0.p.cast(), 0, 4 * ch as usize * 4, sm as RhStream) }, "rh_memset")));   // blt.rs:350-377
+        self.last_kind = if behind_uniform { 2 } else { 0 };
         self
     }
     pub fn reverb(mut self, duration: Duration, amplitude: f32) -> Self {         // source/mod.rs:628-634
@@ -526,14 +757,40 @@ impl<I: Source> GpuSource<I> {
         let mut e: *mut RhEcho = ptr::null_mut();
         ck(unsafe { rh_echo_create(&mut e, d, amplitude) }, "rh_echo_create");
         let h = Handle { p: e, destroy: rh_echo_destroy };
+        let captured = self.duration_through();                                       // buffered.rs:16: asked when the source is buffered
+        let s0 = self.current_span_len().unwrap_or(32768) as u64;
+        let (chn, rate_now) = (self.ch as u64, self.rate as u64);
+        let seen = Arc::new(Mutex::new((0u64, false)));                               // samples of the input so far / that is all of it
+        let seen2 = seen.clone();
         let stage = self.push(move |c| {
             let h = &h;   // (the whole handle moves into the closure -- it is Send and dropped with the stage -- not just its raw pointer field)
+            { let mut sn = seen.lock().unwrap(); sn.0 += c.n as u64; sn.1 = sn.1 || c.flush; }
             if c.n > 0 { ck(unsafe { rh_echo_process(h.p, c.out, c.inp, c.n as u64, c.stream) }, "rh_echo_process"); }
             if !c.flush { return c.n; }
             if d > 0 { ck(unsafe { rh_echo_flush(h.p, c.out.add(c.n), c.stream) }, "rh_echo_flush"); }                 // the delayed clone outlives the source
             c.n + d as usize
         }, move |n, _| n + d as usize, 1);                                           // Mix::current_span_len() is None (mix.rs:92-94)
         stage.seekable = false;                                                        // mix.rs:116-120
+        self.set_duration(move |_| captured.map(|f1| f1 + duration));                 // mix.rs:104-112: max(f1, f1 + d)
+        // mix.rs:56-67 over two UniformSourceIterators (mix.rs:10-22): (the larger lower bound, None) -- see GpuSource::reverb in include/rodio_hip.hpp
+        // for the derivation (the echo's silence through Take's chains of min(span + silence, 32768) samples in whole frames; the plain branch at
+        // its Buffered source's end: an empty 44100 -> rate converter on ONE channel, buffered.rs:218-233, sample_rate.rs:190,226-229).
+        let (mut g44, mut gb) = (44100u64, rate_now);
+        while gb != 0 { let t = g44 % gb; g44 = gb; gb = t; }
+        let end_chunk = if rate_now == 44100 { 0 } else { (rate_now / g44 - 1) * chn };
+        self.set_hints(move |_, e| {
+            if e == 0 { return (d as usize, None); }
+            let sn = *seen2.lock().unwrap();
+            let plain = if sn.1 && e > sn.0 { end_chunk } else { 0 };
+            if e >= d { return (plain as usize, None); }
+            let (mut start, mut n) = (0u64, (s0 + d).min(32768));
+            while n > 0 && start + n <= e { start += n; n = (s0 + (d - start)).min(32768); }
+            let in_chain = e - start;
+            let pos = in_chain % chn;
+            let lo = (d - e).min(n.saturating_sub(in_chain));
+            let x = (lo + pos) / chn * chn;
+            (plain.max(x.saturating_sub(pos)) as usize, None)
+        });
         self
     }
     pub fn channel_volume(mut self, gains: Vec<f32>) -> Self {                    // channel_volume.rs:71-88
@@ -544,6 +801,7 @@ impl<I: Source> GpuSource<I> {
             ck(unsafe { rh_channel_volume(c.out, c.inp, frames, in_ch as u32, gains.as_ptr(), out_ch as u32, c.stream) }, "rh_channel_volume");
             frames * out_ch
         }, move |n, _| n / in_ch * out_ch, 2);
+        self.set_in_pos(move |e| (e + out_ch as u64 - 1) / out_ch as u64 * in_ch as u64);   // channel_volume.rs:91-93: the INPUT's answer; a frame of it has been taken whenever an output frame begins (:71-79)
         self.ch = out_ch as u16;
         self
     }
@@ -572,6 +830,12 @@ impl<I: Source> GpuSource<I> {
             ck(unsafe { rh_channels_convert(c.out, c.inp, frames, from as u32, to as u32, c.stream) }, "rh_channels_convert");
             frames * to
         }, move |n, _| n / from * to, 1);
+        self.set_hints(move |inp, e| {                                              // channels.rs:88-102
+            let (pos, consumed) = (e % to as u64, (from as u64).min(e % to as u64));
+            let h = inp(e / to as u64 * from as u64 + consumed);
+            let f = |v: usize| ((v as u64 + consumed) / from as u64 * to as u64).saturating_sub(pos) as usize;
+            (f(h.0), h.1.map(f))
+        });
         self.ch = to as u16;
         self
     }
@@ -581,12 +845,22 @@ impl<I: Source> GpuSource<I> {
         let mut r: *mut RhResampler = ptr::null_mut();
         ck(unsafe { rh_resampler_create(&mut r, from, to, ch as u32) }, "rh_resampler_create");
         let h = Handle { p: r, destroy: rh_resampler_destroy };
-        self.push(move |c| {
+        let cnt = Arc::new(Mutex::new((UniformCounter::new(ch as u16, to, true), 0u64)));   // sample_rate.rs:204-238 over counts; samples fed so far
+        cnt.lock().unwrap().0.feed(&Piece { n: 0, opens: true, closes: false, ch: ch as u16, rate: from, tail: 0, by_none: false, limit: None }, 0);
+        let (cnt2, cnt3) = (cnt.clone(), cnt.clone());
+        let stage = self.push(move |c| {
             let h = &h;   // (whole-struct capture: see reverb)
+            { let mut k = cnt.lock().unwrap(); let at = k.1; k.0.feed(&Piece { n: c.n, opens: false, closes: c.flush, ch: ch as u16, rate: from, tail: 0, by_none: c.flush, limit: None }, at); k.1 += c.n as u64; }
             let mut m = 0u64;
             ck(unsafe { rh_resampler_process(h.p, c.out, (c.out_cap / ch) as u64, c.inp, (c.n / ch) as u64, c.flush as i32, &mut m, c.stream) }, "rh_resampler_process");
             m as usize * ch
         }, move |n, _| (((n / ch + 2) as u64 * to as u64 / from as u64) as usize + 2) * ch, 1);
+        stage.on_seek = Some(Box::new(move |_| {                                    // (the counts start over with the stream behind the new position)
+            let mut k = cnt3.lock().unwrap();
+            *k = (UniformCounter::new(ch as u16, to, true), 0);
+            k.0.feed(&Piece { n: 0, opens: true, closes: false, ch: ch as u16, rate: from, tail: 0, by_none: false, limit: None }, 0);
+        }));
+        self.set_hints(move |inp, e| cnt2.lock().unwrap().0.hint_at(e, inp).unwrap_or((0, Some(0))));
         self.rate = to;
         self
     }
@@ -600,6 +874,12 @@ impl<I: Source> GpuSource<I> {
             let mut s = self.convert_sample_rate(sample_rate);
             if channels.get() != from_ch { s = s.convert_channels(channels); }
             if let Some(st) = s.stages.last_mut() { st.span_rule = 1; }
+            // (uniform.rs:37,100-108: the duration the input gave when the iterator was built; the lower bound only -- the arithmetic of the two
+            // bare converters above is that of the iterator's one continuous chain)
+            let captured = s.duration_through();
+            s.set_duration(move |_| captured);
+            { let mut hs = s.hint.lock().unwrap(); if let Some(f) = hs.stages.last_mut().and_then(|st| st.fun.take()) { let mut f = f; hs.stages.last_mut().unwrap().fun = Some(Box::new(move |i, e| (f(i, e).0, None))); } }
+            s.last_kind = 1;
             return s;
         }
         self.span_aware = true;
@@ -610,11 +890,15 @@ impl<I: Source> GpuSource<I> {
         // What UniformSourceIterator emits is a stream of SAMPLES (a span that ends inside a frame leaves a run that need not fill a frame); the
         // adapters behind work on frames, so a block hands on whole frames and the samples of a frame that is not complete yet wait here.
         let mut part = State(DeviceBuf::new());
-        part.0.reserve(64);
+        part.0.reserve(64.max(to_ch as usize));
         let part_n = std::sync::Arc::new(std::sync::Mutex::new(0usize));
         let part_n2 = part_n.clone();
+        let captured = self.duration_through();                                       // uniform.rs:37
+        let cnt = Arc::new(Mutex::new((UniformCounter::new(to_ch, to_rate, false), 0u64)));   // uniform.rs:100-108 over counts, fed with the planner's pieces
+        let (cnt2, cnt3) = (cnt.clone(), cnt.clone());
         let stage = self.push(move |c| {
             let (win, keep, part) = (&mut win, &mut keep, &mut part);   // (whole-struct capture)
+            { let mut k = cnt.lock().unwrap(); for p in c.pieces { let at = k.1; k.0.feed(p, at); k.1 += p.n as u64; } if c.flush { k.0.input_ended(); } }
             let mut plan = plan.lock().unwrap();
             plan.begin_block();
             let hs = plan.held_samples();
@@ -650,7 +934,14 @@ impl<I: Source> GpuSource<I> {
             let f = (n / in_ch) as u64;
             (f.max(f * to_rate as u64 / from as u64 + 2) as usize + (UniformPlanner::close_slack_frames(from, to_rate) as usize + 1) * (pieces + 2) + 1) * to_ch as usize
         }, 1);
-        stage.on_seek = Some(Box::new(move |_| { *plan2.lock().unwrap() = UniformPlanner::new(to_ch, to_rate); *part_n2.lock().unwrap() = 0; }));   // the next span starts a fresh chain
+        stage.on_seek = Some(Box::new(move |_| {   // the next span starts a fresh chain
+            *plan2.lock().unwrap() = UniformPlanner::new(to_ch, to_rate);
+            *part_n2.lock().unwrap() = 0;
+            *cnt3.lock().unwrap() = (UniformCounter::new(to_ch, to_rate, false), 0);
+        }));
+        self.set_duration(move |_| captured);                                         // uniform.rs:131-133
+        self.set_hints(move |inp, e| cnt2.lock().unwrap().0.hint_at(e, inp).unwrap_or((0, None)));
+        self.last_kind = 1;
         self.ch = to_ch;
         self.rate = to_rate;
         self
@@ -694,20 +985,42 @@ impl<I: Source> GpuSource<I> {
     }
     pub fn fade_in(self, duration: Duration) -> Self { self.linear_gain_ramp(duration, 0.0, 1.0, false) }   // fadein.rs:11-13
     pub fn fade_out(self, duration: Duration) -> Self { self.linear_gain_ramp(duration, 1.0, 0.0, true) }    // fadeout.rs:13
-    /// `take_duration(d)`, with `set_filter_fadeout()` when `fade_out` (take.rs:96-148).
+    /// `take_duration(d)`, with `set_filter_fadeout()` when `fade_out` (take.rs:96-148).  `try_seek` starts the duration over from the new
+    /// position: what is left is the requested duration less `pos` (take.rs:222-231).
     pub fn take_duration(mut self, duration: Duration, fade_out: bool) -> Self {
         let (ch, rate, ns) = (self.ch as u32, self.rate, duration.as_nanos() as u64);
-        let (mut pos, mut done) = (0u64, false);
-        self.push(move |c| {
+        // (remaining of the duration at the next sample, samples of the current frame already emitted, done, what was left at the start / behind the last seek)
+        let tk = Arc::new(Mutex::new((ns, 0u32, false, ns)));
+        let (tk2, tk3) = (tk.clone(), tk.clone());
+        let per_sample = 1_000_000_000u64 / (rate as u64 * ch as u64);
+        let stage = self.push(move |c| {
+            let mut t = tk.lock().unwrap();
             c.end = true;
-            if done { return 0; }
-            let (mut m, mut ended) = (0u64, 0i32);
-            ck(unsafe { rh_take_duration(c.out, c.inp, c.n as u64, pos, ch, rate, ns, fade_out as i32, &mut m, &mut ended, c.stream) }, "rh_take_duration");
-            pos += c.n as u64;
-            done = ended != 0;
-            c.end = done;
+            if t.2 { return 0; }
+            let (mut m, mut ended, mut after) = (0u64, 0i32, 0u64);
+            ck(unsafe { rh_take_duration_from(c.out, c.inp, c.n as u64, t.0, ns, t.1, ch, rate, fade_out as i32, &mut m, &mut ended, &mut after, c.stream) }, "rh_take_duration_from");
+            if per_sample > 0 { t.1 = ((t.1 as u64 + (t.0 - after) / per_sample) % ch as u64) as u32; }
+            t.0 = after;
+            t.2 = ended != 0;
+            c.end = t.2;
             m as usize
         }, move |n, _| n + ch as usize, 2);
+        stage.on_seek = Some(Box::new(move |pos: Duration| {                         // take.rs:222-231
+            let mut t = tk2.lock().unwrap();
+            let left = ns.saturating_sub(pos.as_nanos() as u64);
+            *t = (left, 0, false, left);
+        }));
+        self.set_duration(move |inp| inp.map(|d| d.min(duration)));                   // take.rs:209-219
+        self.set_hints(move |inp, e| {                                                // take.rs:151-171
+            let since = tk3.lock().unwrap().3;
+            if per_sample == 0 { return (0, Some(0)); }
+            let took = e.min(since / per_sample);
+            let remaining = since - took * per_sample;
+            if remaining == 0 { return (0, Some(0)); }
+            let rs = (remaining / per_sample) as usize;
+            let h = inp(took);
+            (h.0.min(rs), Some(h.1.map_or(rs, |u| u.min(rs))))
+        });
         self
     }
     /// `delay(d)` (delay.rs:8-16,68-75): `rh_delay_samples()` zeros in front of the stream.  Not seekable here.
@@ -725,6 +1038,12 @@ impl<I: Source> GpuSource<I> {
             c.n
         }, move |n, _| n + d as usize, 2);
         stage.seekable = false;
+        self.set_duration(move |inp| inp.map(|v| v + duration));                      // delay.rs:111-115: + the REQUESTED delay
+        self.set_hints(move |inp, e| {                                                // delay.rs:78-84: the input's bounds plus the silence still owed
+            let owed = d.saturating_sub(e) as usize;
+            let h = inp(e.saturating_sub(d));
+            (h.0 + owed, h.1.map(|u| u + owed))
+        });
         self
     }
 }
@@ -742,6 +1061,7 @@ impl<I: Source> BlockSource for GpuSource<I> {
         // blocks on the device never waits on the host -- see GpuSource::enqueue in include/rodio_hip.hpp)
         if self.pump.device_out { ck(unsafe { rh_event_synchronize(self.pump.slot[i].done.0) }, "rh_event_synchronize"); }
         self.pump.slot[i].stage.reserve(want);
+        { let h = self.up.size_hint(); self.hint.lock().unwrap().log.note(self.pulled_total, h); }   // (size_hint(): what the upstream answers where this block's first sample is pulled)
         let (mut n, flush);
         self.pieces.clear();
         {
@@ -762,6 +1082,7 @@ impl<I: Source> BlockSource for GpuSource<I> {
                 flush = n < want;
             }
         }
+        self.pulled_total += n as u64;
         // capacity of the ping-pong buffers: the largest block any stage can emit
         let (mut cap, mut m) = (want, want);
         for st in &self.stages { m = (st.bound)(m, self.pieces.len()); cap = cap.max(m); }
@@ -801,6 +1122,10 @@ pub trait DeviceChain: Send {
     fn started(&self) -> bool;
     fn read_device(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize;
     fn timing(&self) -> Timing;
+    /// size_hint(): the chain's own arithmetic (kept alive beyond the chain), primed with the upstream's answer while nothing has been pulled; and
+    /// whether the chain ends with a `uniform` (1), with a filter right behind one (2), or with anything else (0).
+    fn hint_state(&self) -> std::sync::Arc<std::sync::Mutex<HintState>>;
+    fn last_kind(&self) -> u8;
 }
 impl<I: Source + Send> DeviceChain for GpuSource<I> {
     fn as_source(&mut self) -> &mut dyn Source { self }
@@ -810,16 +1135,25 @@ impl<I: Source + Send> DeviceChain for GpuSource<I> {
     fn started(&self) -> bool { GpuSource::started(self) }
     fn read_device(&mut self, ddst: *mut f32, n: usize, consumer: RhStream) -> usize { GpuSource::read_device(self, ddst, n, consumer) }
     fn timing(&self) -> Timing { GpuSource::timing(self) }
+    fn hint_state(&self) -> std::sync::Arc<std::sync::Mutex<HintState>> {
+        { let mut h = self.hint.lock().unwrap(); if h.log.is_empty() { h.before = self.up.size_hint(); } }
+        self.hint.clone()
+    }
+    fn last_kind(&self) -> u8 { self.last_kind }
 }
 impl<I: Source> Iterator for GpuSource<I> {
     type Item = f32;
     fn next(&mut self) -> Option<f32> { self.next_sample() }
+    /// As rodio's adapter chain would answer where the CONSUMER stands (the chain itself reads a block ahead): every adapter's own arithmetic
+    /// (delay.rs:78-84, take.rs:151-171, mix.rs:56-67, channels.rs:88-102, sample_rate.rs:204-238, uniform.rs:100-108; the input's answer behind
+    /// the adapters that hand it on: amplify.rs:68-70, blt.rs:144-146, ...) over the upstream's answer at the sample the question reaches.
+    fn size_hint(&self) -> (usize, Option<usize>) { self.size_hint_at(self.pump.handed_out) }
 }
 impl<I: Source> Source for GpuSource<I> {
     fn current_span_len(&self) -> Option<usize> { None }
     fn channels(&self) -> ChannelCount { ChannelCount::new(self.ch).unwrap() }
     fn sample_rate(&self) -> SampleRate { SampleRate::new(self.rate).unwrap() }
-    fn total_duration(&self) -> Option<Duration> { None }
+    fn total_duration(&self) -> Option<Duration> { self.duration_through() }
     /// `try_seek` through the chain, adapter by adapter as rodio does it: an adapter that cannot seek (reverb = Mix, mix.rs:116-120)
     /// fails the call before anything moved; otherwise the upstream seeks, what was pulled and processed ahead is dropped, and
     /// every adapter does to its state what its `try_seek` does (blt.rs:350-377, limit.rs:1139-1158, linear_ramp.rs:141-146).
@@ -830,6 +1164,13 @@ impl<I: Source> Source for GpuSource<I> {
         let ch = self.ch as usize;
         self.pump.restart(ch);
         for st in &mut self.stages { if let Some(f) = st.on_seek.as_mut() { f(pos); } }
+        {   // (the adapters' counts start over: what the chain emits from here on is the stream behind the new position, less the samples that keep the consumer's channel)
+            let mut h = self.hint.lock().unwrap();
+            h.log.clear();
+            h.out_base = self.pump.handed_out;
+            h.skip = self.pump.handed_out % ch as u64;
+            h.in_base = self.pulled_total;
+        }
         Ok(())
     }
 }
@@ -883,8 +1224,52 @@ struct Src {
     dheld: u64, dheld_off: u64,                                                  // a device chain: frames the converter has not consumed, in the row of the block before
     reader: SpanReader, plan: UniformPlanner, have_s: u64, off_s: u64,           // span-by-span generations: converted SAMPLES not yet mixed, from sample off_s of the row
     total_s: u64,                                                                 // samples of the source's stream in the mix's layout so far (a stream that ends inside a frame: the last block is cut to what rodio returns)
+    hint: Option<std::sync::Arc<std::sync::Mutex<HintTrack>>>,                   // size_hint(): see HintTrack
 }
 unsafe impl Send for Src {}
+impl Src {
+    /// A pull of `got` samples of ONE continuous span (the source reports none); `ended`: it returned None behind them.
+    fn note_pull(&mut self, got: usize, ended: bool) {
+        let Some(h) = &self.hint else { return };
+        let mut t = h.lock().unwrap();
+        let (first, rate, at) = (t.pulled == 0, self.up.src_ref().sample_rate().get(), t.pulled);
+        if let Some(c) = t.counter.as_mut() {
+            if got > 0 || ended { c.feed(&Piece { n: got, opens: first, closes: ended, ch: self.ch, rate, tail: 0, by_none: ended, limit: None }, at); }
+            if ended { c.input_ended(); }
+        }
+        t.pulled += got as u64;
+    }
+    fn note_hint(&mut self) {   // (before a pull of a plain source: what it answers where the pull starts)
+        let Some(h) = &self.hint else { return };
+        let mut t = h.lock().unwrap();
+        if t.chain.is_none() { let (at, ans) = (t.pulled, self.up.src_ref().size_hint()); t.log.note(at, ans); }
+    }
+}
+/// `size_hint()` of ONE source of the mix, where the mixer's consumer stands.  rodio's spelling of `add(src, gain, filter)`:
+///     mixer.add(src)                                                                gain 1, no filter
+///     mixer.add(src.amplify(g))                                                     a gain (amplify.rs:68-70 hands the bounds on)
+///     mixer.add(UniformSourceIterator::new(src.amplify(g), ch, rate).low_pass(f))   a filter: it runs at the mixer's rate, behind a converter of its own
+/// and Mixer::add wraps what it gets in a UniformSourceIterator (mixer.rs:58-66).  So the bounds are those of ONE iterator over the source
+/// (`counter`: the mixer itself converts; or the chain's own last `uniform`), and behind a filter of one more -- a pass-through at the mixer's
+/// own format, whose ChannelCountConverter still counts in whole frames from where it stands (channels.rs:88-102).  The twin of
+/// `GpuMixer::HintTrack` (include/rodio_hip.hpp).
+pub struct HintTrack {
+    join_frame: u64, counter: Option<UniformCounter>, log: HintLog, chain: Option<std::sync::Arc<std::sync::Mutex<HintState>>>, pulled: u64,
+    wrapped_again: bool, total_known: bool, total: u64,
+}
+impl HintTrack {
+    fn lower_at(&mut self, e: u64, ch: u16) -> Option<usize> {
+        let HintTrack { counter, log, chain, .. } = self;
+        let mut source_at = |q: u64| -> SizeHint { match chain { Some(c) => c.lock().unwrap().at(q), None => if log.is_empty() { (0, None) } else { log.at(q) } } };
+        let lo = match counter {
+            Some(c) => c.hint_at(e, &mut source_at)?.0,
+            None => { if self.total_known && e > self.total { return None; } source_at(e).0 }
+        };
+        if !self.wrapped_again { return Some(lo); }
+        let pos = (e % ch as u64) as usize;                                         // channels.rs:88-102 with from == to
+        Some(((lo + pos) / ch as usize * ch as usize).saturating_sub(pos))
+    }
+}
 fn count_chain(x: &Src, st: &mut ChainStats) {
     if let Upstream::Chain(c) = &x.up {
         st.chains += 1;
@@ -933,6 +1318,7 @@ pub struct GpuMixer {
     copy_stream: RhStream,              // host-to-device copies of the staged rows: the link stays busy while the pump's stream runs the block before
     device_chains: bool, retired_chains: ChainStats, reaper: Option<Reaper>,
     pump: Pump,
+    hints: Mutex<Vec<Arc<Mutex<HintTrack>>>>,   // size_hint(): the sources that play, or are about to (outlive their generation: the last blocks are served after it is retired)
 }
 unsafe impl Send for GpuMixer {}
 
@@ -956,7 +1342,7 @@ impl GpuMixer {
         ck(unsafe { rh_stream_create(&mut copy_stream) }, "rh_stream_create");
         GpuMixer { rate: sample_rate.get(), out_ch: channels.get(), opt, pending: Vec::new(), gens: Vec::new(), cap_frames: 0, row: 0, out_cap_frames: 0, scheduled: 0, last_join: 0,
                    dmix: DeviceBuf::new(), dout: DeviceBuf::new(), dkeep: [DeviceBuf::new(), DeviceBuf::new()], slot_base: [0; 2], slot_frames: [0; 2], calls: 0, resume_ok: true,
-                   copy_stream, device_chains: false, retired_chains: ChainStats::default(), reaper: None, pump: Pump::new() }
+                   copy_stream, device_chains: false, retired_chains: ChainStats::default(), reaper: None, pump: Pump::new(), hints: Mutex::new(Vec::new()) }
     }
     fn default_filter(&self) -> MixerFilter { MixerFilter { kind: self.opt.filter_kind, freq: self.opt.filter_freq, q: self.opt.filter_q } }
     /// `Mixer::add` (mixer.rs:58-66), with the source's volume (`mixer.add(src.amplify(gain))`).  May be called at any time.
@@ -977,7 +1363,7 @@ impl GpuMixer {
             return;
         }
         let item = Src { up: Upstream::Host(src), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
-                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0 };
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0, hint: None };
         if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
     }
     /// A `GpuSource` chain handed to the mixer by value, as rodio's adapters are (`mixer.add(src.reverb(..).limit(..))`, amplify.rs:19-22,
@@ -990,7 +1376,7 @@ impl GpuMixer {
         let on_device = ch == 2 && !chain.started() && !fused_ratio_unsupported(rate, self.rate);
         if on_device { chain.keep_blocks_on_device(true); self.device_chains = true; }
         let item = Src { up: Upstream::Chain(chain), gain, filt: filter, held: Vec::new(), ended: false, ch, dheld: 0, dheld_off: 0,
-                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0 };
+                         reader: SpanReader::new(), plan: UniformPlanner::new(2, self.rate), have_s: 0, off_s: 0, total_s: 0, hint: None };
         if self.pump.running() { self.late_join(item); } else { self.pending.push(item); }
     }
     /// Everything a first `next()` would do before it can serve a sample, done NOW on the calling thread (see `BlockSource::prepare_stream`):
@@ -1100,6 +1486,17 @@ impl GpuMixer {
         }
         for b in &mut g.q { b.reserve(self.out_cap_frames as usize * 4); }
         self.last_join = self.scheduled;
+        for x in &mut g.srcs {   // size_hint(): the generation's sources start playing (late_join moves join_frame to the frame they join at)
+            let (chain, kind) = match &x.up { Upstream::Chain(c) => (Some(c.hint_state()), c.last_kind()), Upstream::Host(_) => (None, 0) };
+            let (sch, srate) = (x.up.src_ref().channels().get(), x.up.src_ref().sample_rate().get());
+            let same = sch == self.out_ch && srate == self.rate && x.gain == 1.0 && x.filt.kind < 0;
+            let own = chain.is_some() && same && (kind == 1 || kind == 2);           // the chain ends with its own iterator (and a filter behind it): nothing for the mixer's to do
+            let t = HintTrack { join_frame: self.scheduled, counter: if own { None } else { Some(UniformCounter::new(self.out_ch, self.rate, false)) }, log: HintLog::default(), chain,
+                                pulled: 0, wrapped_again: if own { kind == 2 } else { x.filt.kind >= 0 }, total_known: false, total: 0 };
+            let t = Arc::new(Mutex::new(t));
+            x.hint = Some(t.clone());
+            self.hints.lock().unwrap().push(t);
+        }
         self.gens.push(g);
     }
 
@@ -1167,10 +1564,12 @@ impl GpuMixer {
                 row[..have].copy_from_slice(&x.held);
                 if !x.ended {
                     let want = block_frames * ch;
+                    x.note_hint();
                     let mut got = read_into(x.up.src(), &mut row[have..have + want]);   // straight into the staging block
                     got -= got % ch;                                                // sources end on frame boundaries (source/mod.rs:169-178)
                     have += got;
                     x.ended = got < want;
+                    x.note_pull(got, x.ended);
                 }
                 *res = ((have / ch) as u64, x.ended as u8);
             };
@@ -1215,6 +1614,8 @@ impl GpuMixer {
                 got -= got % 2;
                 have += got;
                 x.ended = got < want;
+                x.note_pull(got, x.ended);
+                if x.ended { if let Some(h) = &x.hint { let mut t = h.lock().unwrap(); t.total_known = true; t.total = t.pulled; } }
             }
             g.pptrs[i] = row as *const f32;
             g.pavail[i] = (have / 2) as u64;
@@ -1333,9 +1734,18 @@ impl GpuMixer {
                 let room = if row_cap[i] - fill >= ch as usize { (row_cap[i] - fill - (ch as usize - 1)) / ch as usize } else { 0 };
                 let n = need.min(most).min(room as u64) as usize;
                 if n == 0 { break; }
+                x.note_hint();
                 let piece = x.reader.read_piece(x.up.src(), &mut row[fill..], n);   // straight into the staging block
-                if let Some(pc) = piece { fill += pc.n; x.plan.add(&pc, &mut segs); }
-                if x.reader.ended() { x.ended = true; break; }
+                if let Some(pc) = piece {
+                    fill += pc.n;
+                    x.plan.add(&pc, &mut segs);
+                    if let Some(h) = &x.hint { let mut t = h.lock().unwrap(); let at = t.pulled; if let Some(c) = t.counter.as_mut() { c.feed(&pc, at); } t.pulled += pc.n as u64; }
+                }
+                if x.reader.ended() {
+                    x.ended = true;
+                    if let Some(h) = &x.hint { if let Some(c) = h.lock().unwrap().counter.as_mut() { c.input_ended(); } }
+                    break;
+                }
                 if piece.is_none() { break; }
             }
             x.plan.end_block();
@@ -1432,6 +1842,7 @@ impl GpuMixer {
         self.start_stream(vec![item], staged, mono);
         self.last_join = j;
         let gi = self.gens.len() - 1;
+        for x in &self.gens[gi].srcs { if let Some(h) = &x.hint { h.lock().unwrap().join_frame = j; } }
         let need = sched_end.saturating_sub(j);
         while self.gens[gi].fill < need && !self.gens[gi].done {
             self.run_block(gi);
@@ -1562,6 +1973,26 @@ impl Iterator for GpuMixer {
         self.resume_ok = self.calls % self.out_ch as u64 == 0;
         self.calls += 1;
         self.next_sample()
+    }
+    /// mixer.rs:139-166: (0, Some(0)) while no source plays -- sources that wait for the next frame do not count --; otherwise the largest lower
+    /// bound among the sources that play where the CONSUMER stands, and no upper bound (every source sits in a UniformSourceIterator,
+    /// mixer.rs:58-66, whose upper bound is None: uniform.rs:100-108).  A source plays from the call that admitted it to the call in which it
+    /// returns None (mixer.rs:185-198).
+    fn size_hint(&self) -> (usize, Option<usize>) {
+        let oc = self.out_ch as u64;
+        let consumed = if self.pump.primed { self.slot_base[self.pump.cur] * oc + self.pump.pos as u64 } else { 0 };
+        let mut hints = self.hints.lock().unwrap();
+        let (mut any, mut lower) = (false, 0usize);
+        hints.retain(|t| {
+            let mut t = t.lock().unwrap();
+            let first = t.join_frame * oc;
+            if consumed <= first { return true; }                                   // admitted by a call still to come
+            match t.lower_at(consumed - first, self.out_ch) {
+                None => false,                                                      // it has returned None in front of the consumer: gone for good
+                Some(lo) => { any = true; lower = lower.max(lo); true }
+            }
+        });
+        if any { (lower, None) } else { (0, Some(0)) }
     }
 }
 impl Source for GpuMixer {

@@ -228,29 +228,38 @@ rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samp
     return RH_OK;
 }
 // take.rs:96-148: samples while remaining >= duration_per_sample, the fade-out filter before the decrement, the cut frame completed with silence
-rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out, uint64_t *out_samples,
-                           int32_t *ended, rh_stream) {
-    if (!channels || !sample_rate || !out_samples) return RH_ERR_INVALID;
+rh_status rh_take_duration_from(float *dst, const float *src, uint64_t n, uint64_t remaining_ns, uint64_t requested_ns, uint32_t frame_phase, uint32_t channels, uint32_t sample_rate, int32_t fade_out,
+                                uint64_t *out_samples, int32_t *ended, uint64_t *remaining_after_ns, rh_stream) {
+    if (!channels || !sample_rate || !out_samples || frame_phase >= channels) return RH_ERR_INVALID;
     const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);
     if (!dps) return RH_ERR_UNSUPPORTED;
-    uint64_t remaining = duration_ns - std::min(duration_ns, sample_offset * dps), m = 0;
+    uint64_t remaining = remaining_ns, m = 0;
     bool expired = false;
     for (uint64_t i = 0;; ++i) {
         if (remaining < dps) {  // (also right behind the block's last sample: rodio's next call would answer None without pulling)
             expired = true;
-            const uint64_t in_frame = (sample_offset + i) % channels;
+            const uint64_t in_frame = (frame_phase + i) % channels;
             for (uint64_t z = in_frame ? channels - in_frame : 0; z > 0; --z) dst[m++] = 0.0f;
             break;
         }
         if (i == n) break;
         float v = src[i];
-        if (fade_out) v = v * (float)(remaining / 1000000ull) / (float)(duration_ns / 1000000ull);
+        if (fade_out) v = v * (float)(remaining / 1000000ull) / (float)(requested_ns / 1000000ull);
         remaining -= dps;
         dst[m++] = v;
     }
     *out_samples = m;
     if (ended) *ended = expired ? 1 : 0;
+    if (remaining_after_ns) *remaining_after_ns = remaining;
     return RH_OK;
+}
+rh_status rh_take_duration(float *dst, const float *src, uint64_t n, uint64_t sample_offset, uint32_t channels, uint32_t sample_rate, uint64_t duration_ns, int32_t fade_out, uint64_t *out_samples,
+                           int32_t *ended, rh_stream s) {
+    if (!channels || !sample_rate || !out_samples) return RH_ERR_INVALID;
+    const uint64_t dps = 1000000000ull / ((uint64_t)sample_rate * channels);
+    if (!dps) return RH_ERR_UNSUPPORTED;
+    const uint64_t done = std::min(sample_offset, duration_ns / dps);
+    return rh_take_duration_from(dst, src, n, duration_ns - done * dps, duration_ns, (uint32_t)(done % channels), channels, sample_rate, fade_out, out_samples, ended, nullptr, s);
 }
 
 // ---------------------------------------------------------------- BltFilter ----

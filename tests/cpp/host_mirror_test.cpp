@@ -67,6 +67,7 @@ class TestSource : public rh::SamplesBuffer {
 public:
     using rh::SamplesBuffer::SamplesBuffer;
     std::optional<std::size_t> current_span_len() const override { return std::nullopt; }
+    rh::SizeHint size_hint() const override { return rh::SizeHint{}; }  // benches/shared.rs:14-21 implements only next(): the trait's default (0, None); its total_duration is GIVEN (:47-49; here: the buffer's)
 };
 class SpanSource : public rh::SamplesBuffer {
 public:
@@ -133,8 +134,25 @@ static rh::BoxSource make_source(std::uint16_t ch, std::uint32_t rate, std::vect
     return std::make_unique<TestSource>(ch, rate, std::move(data));
 }
 // the consumer: like the cpal callback, it takes samples one at a time; every so often in bulk, as wav_to_writer would
+// RH_TEST_TRACK_HINTS (the mixer modes): size_hint() in front of every sample drain() takes and behind the last (written to hints.i64 as
+// lower, upper or -1 at exit; `late` / `latewide`: the samples pulled before the late add are not tracked, the file starts at the join)
+static std::vector<long long> g_hints;
+static void note_hint(const rh::Source &src) {
+    const rh::SizeHint h = src.size_hint();
+    g_hints.push_back((long long)h.lower);
+    g_hints.push_back(h.upper ? (long long)*h.upper : -1);
+}
 static std::vector<float> drain(rh::Source &src) {
     std::vector<float> out;
+    if (std::getenv("RH_TEST_TRACK_HINTS")) {
+        for (;;) {
+            note_hint(src);
+            const std::optional<float> v = src.next();
+            if (!v) break;
+            out.push_back(*v);
+        }
+        return out;
+    }
     float chunk[777];
     for (int round = 0;; ++round) {
         if (round % 3 == 2) {
@@ -613,7 +631,32 @@ int main(int argc, char **argv) {
                     std::fclose(sk);
                 }
             }
-            if (std::getenv("RH_TEST_TRACK_FORMAT")) {  // sample by sample, noting what the chain reports in front of every sample (test_gpu_source_follows_a_format_change)
+            if (std::getenv("RH_TEST_TRACK_HINTS")) {  // sample by sample: size_hint() in front of every sample and behind the last (hints.i64: lower, upper or -1), total_duration() (duration.txt: ns or -1)
+                std::vector<long long> hints;
+                auto note = [&]() {
+                    const rh::SizeHint h = g.size_hint();
+                    hints.push_back((long long)h.lower);
+                    hints.push_back(h.upper ? (long long)*h.upper : -1);
+                };
+                const std::optional<rh::Nanos> d0 = g.total_duration();
+                for (;;) {
+                    note();
+                    const std::optional<float> v = g.next();
+                    if (!v) break;
+                    out.push_back(*v);
+                }
+                const std::optional<rh::Nanos> d1 = g.total_duration();
+                std::FILE *hf = std::fopen((dir + "/hints.i64").c_str(), "wb");
+                if (hf) {
+                    if (!hints.empty()) std::fwrite(hints.data(), sizeof(long long), hints.size(), hf);
+                    std::fclose(hf);
+                }
+                std::FILE *df = std::fopen((dir + "/duration.txt").c_str(), "w");
+                if (df) {
+                    std::fprintf(df, "%lld %lld\n", d0 ? (long long)d0->count() : -1, d1 ? (long long)d1->count() : -1);
+                    std::fclose(df);
+                }
+            } else if (std::getenv("RH_TEST_TRACK_FORMAT")) {  // sample by sample, noting what the chain reports in front of every sample (test_gpu_source_follows_a_format_change)
                 std::FILE *ff = std::fopen((dir + "/formats.txt").c_str(), "w");
                 unsigned lc = 0, lr = 0;
                 long long ls = -2;
@@ -639,6 +682,13 @@ int main(int argc, char **argv) {
             return 2;
         }
         write_f32(dir + "/out.f32", out);
+        if (!g_hints.empty()) {
+            std::FILE *hf = std::fopen((dir + "/hints.i64").c_str(), "wb");
+            if (hf) {
+                std::fwrite(g_hints.data(), sizeof(long long), g_hints.size(), hf);
+                std::fclose(hf);
+            }
+        }
         std::printf("%zu samples\n", out.size());
         return 0;
     } catch (const std::exception &e) {

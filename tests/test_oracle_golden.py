@@ -451,3 +451,94 @@ def test_dither_reference_test_properties(O):
     for bits2 in (8, 16, 24, 32):
         y = O.TestSource(z[:4096], 1, sr).dither(bits2, "RPDF", 5).collect()
         assert 0 < np.max(np.abs(y)) <= 1.0 / (1 << (bits2 - 1))
+
+
+# ------------------------------------------------------------------ total_duration() and size_hint() (the rest of the trait) ----
+def test_total_duration_and_size_hint_derived_by_hand(O):
+    """The reference has one numeric test here (channels.rs:146-161, below); every other expectation is DERIVED BY HAND from the cited lines --
+    none of these numbers was produced by running the oracle."""
+    z = np.zeros(9600, np.float32)  # 4800 stereo frames at 48 kHz = 100 ms (buffer.rs:45-51: 1e9 * 9600 / 48000 / 2)
+    buf = lambda: O.SamplesBuffer(2, 48000, z)  # noqa: E731
+    # buffer.rs:134-137 counts the remaining samples; :95-97 the duration
+    s = buf()
+    assert s.size_hint() == (9600, 9600) and s.total_duration() == 100_000_000
+    s.pull(3)
+    assert s.size_hint() == (9597, 9597) and s.total_duration() == 100_000_000
+    # benches/shared.rs:14-21: TestSource implements only next() -> the trait's default (0, None); :47-49: it is GIVEN its duration
+    t = O.TestSource(z, 2, 48000, total_duration=5)
+    assert t.size_hint() == (0, None) and t.total_duration() == 5 and O.TestSource(z, 2, 48000).total_duration() is None
+    # the adapters that hand both on: amplify.rs:68-70,95-97, blt.rs:144-146,171-173, limit.rs:705-707,592-594, agc.rs:561-563,588-590,
+    # distortion.rs:75-77,102-104, linear_ramp.rs:109-111,136-138, channel_volume.rs:91-93,119-121 (the INPUT's count, whatever the layouts)
+    for wrap in (lambda s: s.amplify(0.5), lambda s: s.low_pass(200), lambda s: s.high_pass(300), lambda s: s.limit(), lambda s: s.automatic_gain_control(),
+                 lambda s: s.distortion(2.0, 0.5), lambda s: s.fade_in(10_000_000), lambda s: O.ChannelVolume(s, [1.0, 0.5, 0.25])):
+        a = wrap(buf())
+        assert a.size_hint() == (9600, 9600) and a.total_duration() == 100_000_000
+        a.pull(1)
+    assert O.ChannelVolume(buf(), [1.0, 0.5, 0.25]).pull(1) is not None
+    cv = O.ChannelVolume(buf(), [1.0, 0.5, 0.25])
+    cv.pull(1)  # channel_volume.rs:71-79: the first output sample takes a whole input frame
+    assert cv.size_hint() == (9598, 9598)
+    # delay.rs:8-16: 10 000 001 ns * 2 * 48000 / 1e9 = 960.000096 -> 960 samples of silence; :78-84 adds what is still owed; :111-115 adds the
+    # REQUESTED duration (not the rounded silence)
+    d = buf().delay(10_000_001)
+    assert d.size_hint() == (10560, 10560) and d.total_duration() == 110_000_001
+    d.pull(100)
+    assert d.size_hint() == (10460, 10460)
+    d.pull(900)  # 1000 taken: the silence is through, 40 samples of the buffer gone
+    assert d.size_hint() == (9560, 9560)
+    assert O.TestSource(z, 2, 48000).delay(10_000_001).size_hint() == (960, None)
+    # take.rs:63-67: duration_per_sample = 1e9 / (48000 * 2) = 10416 ns; :151-171: 50 ms / 10416 = 4800.3 -> 4800 samples, cut to the input's
+    # bounds, an upper bound even over an input without one; :209-219: the shorter duration
+    tk = buf().take_duration(50_000_000)
+    assert tk.size_hint() == (4800, 4800) and tk.total_duration() == 50_000_000
+    tk.pull(10)  # remaining = 50 000 000 - 10 * 10416 = 49 895 840 -> 4790 samples
+    assert tk.size_hint() == (4790, 4790)
+    assert O.TestSource(z, 2, 48000).take_duration(50_000_000).size_hint() == (0, 4800)
+    assert buf().take_duration(500_000_000).total_duration() == 100_000_000 and buf().take_duration(500_000_000).size_hint() == (9600, 9600)
+    assert O.TestSource(z, 2, 48000).take_duration(50_000_000).total_duration() is None
+    whole = buf().take_duration(50_000_000)
+    assert len(whole.collect()) == 4800 and whole.size_hint() == (0, 0)  # remaining 3200 ns < 10416: 0 samples
+    # uniform.rs:37,131-133: the duration the input gave when the iterator was built; :100-108: (lower, None) -- of the pending input while no
+    # chain exists (:105), of ChannelCountConverter(SampleRateConverter(Take(..))) afterwards
+    u = O.UniformSourceIterator(O.SamplesBuffer(2, 44100, np.zeros(2000, np.float32)), 2, 48000)
+    assert u.size_hint() == (2000, None) and u.total_duration() == 1_000_000_000 * 2000 // 44100 // 2
+    u.pull(1)
+    # Take admits min(2000, 32768) = 2000; SampleRateConverter::new took two frames (sample_rate.rs:58-71): 1996 left in Take and in the buffer ->
+    # Take (uniform.rs:181-196): (1996, Some(1996)).  sample_rate.rs:204-238 with from = 147, to = 160, pos_in_chunk 0, out_pos 1, one sample in
+    # the output buffer: 1996 - (147 - 2) * 2 = 1706; 1706 * 160 / 147 = 1856; + (160 - 1) * 2 + 1 = 2175.  channels.rs:88-102 with from = to = 2,
+    # position 1: (2175 + 1) / 2 * 2 - 1 = 2175.
+    assert u.size_hint() == (2175, None)
+    # mixer.rs:139-166: nothing plays before the first call admits the sources; then the longest lower bound, and None since one source's is
+    m = O.Mixer(2, 48000)
+    assert m.rx.size_hint() == (0, 0) and m.rx.total_duration() is None  # :104-106
+    m.add(O.SamplesBuffer(2, 44100, np.zeros(2000, np.float32)))
+    m.add(O.SamplesBuffer(2, 48000, np.zeros(100, np.float32)))
+    assert m.rx.size_hint() == (0, 0)  # (still pending)
+    m.next()
+    # the second source at the mixer's own format: Take 100 -> after one sample 99; the converter passes through (sample_rate.rs:232-233);
+    # channels.rs:88-102: (99 + 1) / 2 * 2 - 1 = 99.  The first: 2175 as above.
+    assert m.rx.size_hint() == (2175, None)
+    # mix.rs:56-67,104-112 over buffered.rs:16,192-195 and delay.rs:78-84,111-115: reverb = Mix(Buffered, Delay(Amplify(Buffered))):
+    # total = max(f1, f1 + d); lower = max(0, the silence the echo owes) before the first sample (uniform.rs:105 on both branches)
+    r = buf().reverb(10_000_000, 0.5)  # delay.rs:8-16: 960 samples
+    assert r.size_hint() == (960, None) and r.total_duration() == 110_000_000
+    r.pull(2)  # the echo's chain: Take min(9600 + 960, 32768) - 2 left, 958 owed; channels.rs:88-102 at position 0: 958 / 2 * 2 = 958
+    assert r.size_hint() == (958, None)
+    r.pull(1)  # 957 owed, position 1: (957 + 1) / 2 * 2 - 1 = 957
+    assert r.size_hint() == (957, None)
+    assert O.TestSource(z, 2, 48000).reverb(10_000_000, 0.5).total_duration() is None
+
+
+def test_channels_size_hint_reference_test(O):
+    """channels.rs:146-161 `size_hint`: the converter over a plain Vec::into_iter() counts its remaining output exactly, down to (0, Some(0))."""
+    def check(inp, f, t):
+        count = len(O.ChannelCountConverter(O.TestSource(inp, 1, 1, exact_size_hint=True), f, t).collect())
+        c = O.ChannelCountConverter(O.TestSource(inp, 1, 1, exact_size_hint=True), f, t)
+        for left in range(count, -1, -1):
+            assert c.size_hint() == (left, left), (f, t, left, c.size_hint())
+            c.pull(1)
+        assert c.size_hint() == (0, 0)
+
+    check([1.0, 2.0, 3.0], 1, 2)
+    check([1.0, 2.0, 3.0, 4.0], 2, 4)
+    check([1.0, 2.0, 3.0, 4.0], 4, 2)
