@@ -15,15 +15,22 @@
 //
 // Pinned against the reference's own golden vectors by tests/test_oracle_golden.py
 // (sample_rate.rs:356-387, channels.rs:114-177, mixer.rs:208-341,
-// channel_volume.rs:135-166, math.rs:238-339).  Unpinned by the reference
-// (it has no numeric tests for them): biquad, AGC, reverb, spatial gains,
-// amplify, limiter (range tests only), sample-type conversion (dasp_sample
-// 0.11.0, an un-vendored dependency: formulas restated from the published
-// crate).  Those rows are "parity unpinned" -- see DESIGN.md.  So are the adapters' answers to
-// current_span_len() (TakeDuration: take.rs:176-195, Delay: delay.rs:94-98, ChannelVolume:
-// channel_volume.rs:103-105): the reference has no test for them, the cases in
-// tests/test_oracle_golden.py are derived by hand from those lines (round 5 found TakeDuration's
-// restated wrongly -- the input's answer handed through -- by reading them again).
+// channel_volume.rs:135-166, math.rs:238-339).  The rows the reference has no
+// numeric test for -- biquad, AGC, reverb, amplify, limiter (range tests only),
+// sample-type conversion (dasp_sample 0.11.0, an un-vendored dependency: formulas
+// restated from the published crate) -- are held against a SECOND DERIVATION that
+// shares no code and no language with this file: tests/golden/derive_traces.py
+// (plain Python over numpy f32 scalars, written from the cited lines; its output is
+// the committed tests/golden/traces.npz; tests/test_oracle_traces.py compares bit
+// for bit where every step is IEEE-exact, the limiter to 2e-6).  Two restatements
+// that agree are not the reference itself: DESIGN.md says "pinned by a second
+// derivation" for these rows, not "pinned by the reference".  The adapters' answers
+// to current_span_len(), size_hint() and total_duration() (take.rs:151-195,209-219,
+// delay.rs:78-98,111-115, channel_volume.rs:91-105, mix.rs:56-67,104-112,
+// uniform.rs:100-108, mixer.rs:139-166 ...) have no reference test either apart from
+// channels.rs:146-161: the cases in tests/test_oracle_golden.py are derived by hand
+// from those lines (round 5 found TakeDuration's current_span_len restated wrongly
+// -- the input's answer handed through -- by reading them again).
 //
 // Citations are file:line under /root/reference.
 
