@@ -345,8 +345,8 @@ rh_status rh_limit(float *dst, const float *src, uint64_t frames, uint32_t chann
 
 /* ---- AutomaticGainControl: src/source/agc.rs:133-171,397-504.  One state for all interleaved
  * channels of a stream.  state (optional): rh_agc_state_floats() floats per stream.
- * NaN / Inf input: with release == 0 (the default) the gain update is a median of three (v_med3_f32), which recovers once the input is finite
- * again; the reference's f32::clamp stays poisoned (a NaN gain is NaN forever).  For finite input the two are the same operations in the same order. */
+ * NaN / Inf input: as the reference (agc.rs:150,406,422-426,453-457, derived in tests/golden/derive_traces.py): the sample comes out NaN, the
+ * window sum and the peak level stay NaN, both `> 0.0` tests fail from then on and the gain climbs to absolute_max_gain and stays there. */
 typedef struct rh_agc_params {
     float target_level;      /* default 1.0 */
     uint64_t attack_ns;      /* default 4 s; clamped to 10 s like source/mod.rs:432-433 */

@@ -33,9 +33,11 @@
 // rh_recurrence.hip, which stays for unaligned rows and in-place calls); the default-parameter path (GainOp0, release == 0) folds
 // the select and the clamp into one median and is bit-identical EXCEPT where the attack candidate and `desired` lie within a rounding
 // of each other, where it differs by that rounding (one ulp, not accumulating: the recurrence contracts) -- measured 0.0 on every
-// test signal, compared at 2e-7.  Non-finite samples: agc.rs's f32::clamp propagates a NaN into current_gain for good; v_med3_f32
-// returns the median of the finite operands, so after a NaN / Inf sample this path recovers where the reference (and k_agc_seq) stay
-// poisoned.  Audio does not carry NaNs; a caller that must reproduce the poisoning uses RH_AGC_SEQ.
+// test signal, compared at 2e-7.  Non-finite samples (round 6, derived from agc.rs in tests/golden/derive_traces.py): the reference's GAIN
+// never becomes NaN -- a NaN sample poisons the window sum and the peak level for good, both `> 0.0` tests fail from then on, `desired` is
+// absolute_max_gain and the gain climbs to the ceiling and stays there (the NaN sample itself comes out NaN).  The kernels do the same: the sums
+// run in the reference's order (NaN stays), and the default-parameter paths, which take |x| for the peak level, poison it with the sum
+// (agc_peak0); test_gpu_agc_after_a_nan holds them against the derived trace.
 //
 // What a chain costs: ONE wave walks time for 64 streams, and a lone wave issues one instruction every 5-7 cycles whatever its
 // kind (measured: SQ_WAVE_CYCLES / instructions), so the chain wave carries nothing but the chain -- wave 0 issues LDS reads,
@@ -418,6 +420,12 @@ struct FusedArgs {
     uint32_t state_stride;
     AgcK k;
 };
+// release == 0: the peak follower peak * c + |x| * (1 - c) with c = 0 either way (agc.rs:397-407) IS |x| -- for numbers.  A NaN sample makes the
+// reference's peak level NaN for good (NaN * 0 + v), an infinite one from the sample after it (inf * 0); from then on `peak_level > 0.0` is false
+// and the peak gain is absolute_max_gain (:421-427).  The window sum tells: it is NaN exactly when the peak level is (sum - old + NaN; inf - inf
+// when the infinite square leaves the window: the peak has been NaN since the sample after it, and while the sum is still +inf the rms gain 0
+// decides whatever the peak says).  So: the peak level of the default parameters, poisoned where the reference's is.
+__device__ __forceinline__ float agc_peak0(float sum, float x) { return sum != sum ? sum : fabsf(x); }
 __device__ __forceinline__ float agc_desired(float sum, float p, const AgcK &k) {  // agc.rs:416-430, :169 (k_agc_desired's `one`)
     const float rms = sqrtf(sum / (float)kRmsWindow);
     const float rms_gain = rms > 0.0f ? k.target_level / rms : k.absolute_max_gain;
@@ -430,7 +438,7 @@ __device__ __forceinline__ float agc_desired(float sum, float p, const AgcK &k) 
 // reference takes `max`) drops out of both forms: v_max_f32 returns the other operand.  k_agc_fused0's D waves: 11 instructions of 48 less.
 __device__ __forceinline__ float agc_desired1(float sum, float p, const AgcK &k) {
     const float rms = sqrtf(sum / (float)kRmsWindow);
-    const float m = fmaxf(rms, p);
+    const float m = fmaxf(rms, p);  // (p = agc_peak0(): NaN with the sum, and then so is m)
     const float g = m > 0.0f ? fminf(k.target_level / m, k.absolute_max_gain) : k.absolute_max_gain;
     return fmaxf(g, k.floor);
 }
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
                     const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
                     const float xv = r0[i];
                     const float sm = op.one(xv, ov, head);
-                    const float d = agc_desired(sm, fabsf(xv), a.k);
+                    const float d = agc_desired(sm, agc_peak0(sm, xv), a.k);
                     const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
                     gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
                     ro[i] = xv * gain;
@@ -633,8 +641,8 @@ __global__ __launch_bounds__(64 * (GEN ? kFWavesG : kFWaves)) void k_agc_fused(c
 #ifdef RH_AGC_DIAG_D  // diagnostics builds (wrong results): what do the square roots and divides cost the pipeline?
                     r = s4 + x4;
 #else
-                    r.x = agc_desired(s4.x, fabsf(x4.x), a.k), r.y = agc_desired(s4.y, fabsf(x4.y), a.k);
-                    r.z = agc_desired(s4.z, fabsf(x4.z), a.k), r.w = agc_desired(s4.w, fabsf(x4.w), a.k);
+                    r.x = agc_desired(s4.x, agc_peak0(s4.x, x4.x), a.k), r.y = agc_desired(s4.y, agc_peak0(s4.y, x4.y), a.k);
+                    r.z = agc_desired(s4.z, agc_peak0(s4.z, x4.z), a.k), r.w = agc_desired(s4.w, agc_peak0(s4.w, x4.w), a.k);
 #endif
                     *(lds_v4 *)(img + q0 + h * 4096) = r;
                 }
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(64 * kQWaves) void k_agc_fused0(const FusedArgs a) 
                     const float ov = head ? (a.in1_head ? a.in1_head[(uint64_t)stream * kRmsWindow + i] : 0.0f) : r0[i - kRmsWindow];
                     const float xv = r0[i];
                     const float sm = op.one(xv, ov, head);
-                    const float d = agc_desired(sm, fabsf(xv), a.k);
+                    const float d = agc_desired(sm, agc_peak0(sm, xv), a.k);
                     const float dc = __builtin_amdgcn_fmed3f(d, 0.1f, a.k.absolute_max_gain), da = d * oma;
                     gain = __builtin_amdgcn_fmed3f(gain * a.k.attack_coeff + da, 0.1f, dc);
                     ro[i] = xv * gain;
@@ -982,11 +990,11 @@ __global__ __launch_bounds__(64 * kQWaves) void k_agc_fused0(const FusedArgs a) 
 #ifdef RH_AGC_DIAG_D  // diagnostics builds (wrong results): what do the square roots and divides cost the pipeline?
                     d = s4 + x4;
 #elif defined(RH_AGC_TWO_DIVISIONS)
-                    d.x = agc_desired(s4.x, fabsf(x4.x), a.k), d.y = agc_desired(s4.y, fabsf(x4.y), a.k);
-                    d.z = agc_desired(s4.z, fabsf(x4.z), a.k), d.w = agc_desired(s4.w, fabsf(x4.w), a.k);
+                    d.x = agc_desired(s4.x, agc_peak0(s4.x, x4.x), a.k), d.y = agc_desired(s4.y, agc_peak0(s4.y, x4.y), a.k);
+                    d.z = agc_desired(s4.z, agc_peak0(s4.z, x4.z), a.k), d.w = agc_desired(s4.w, agc_peak0(s4.w, x4.w), a.k);
 #else
-                    d.x = agc_desired1(s4.x, fabsf(x4.x), a.k), d.y = agc_desired1(s4.y, fabsf(x4.y), a.k);
-                    d.z = agc_desired1(s4.z, fabsf(x4.z), a.k), d.w = agc_desired1(s4.w, fabsf(x4.w), a.k);
+                    d.x = agc_desired1(s4.x, agc_peak0(s4.x, x4.x), a.k), d.y = agc_desired1(s4.y, agc_peak0(s4.y, x4.y), a.k);
+                    d.z = agc_desired1(s4.z, agc_peak0(s4.z, x4.z), a.k), d.w = agc_desired1(s4.w, agc_peak0(s4.w, x4.w), a.k);
 #endif
                     // what does not wait for the gain: clamp(desired) and desired * (1 - attack), the two operands of the chain
                     dc.x = __builtin_amdgcn_fmed3f(d.x, 0.1f, maxg), dc.y = __builtin_amdgcn_fmed3f(d.y, 0.1f, maxg);
@@ -1150,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_agc_desired(float *__restrict__ d, cons
             const v4f x4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(x + at));
             v4f p4;
             if (peak) p4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(peak + at));
-            else p4 = v4f{fabsf(x4.x), fabsf(x4.y), fabsf(x4.z), fabsf(x4.w)};
+            else p4 = v4f{agc_peak0(s4.x, x4.x), agc_peak0(s4.y, x4.y), agc_peak0(s4.z, x4.z), agc_peak0(s4.w, x4.w)};
             v4f r;
             r.x = one(s4.x, p4.x), r.y = one(s4.y, p4.y), r.z = one(s4.z, p4.z), r.w = one(s4.w, p4.w);
             if (da) {
@@ -1161,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_agc_desired(float *__restrict__ d, cons
         } else {
             for (uint64_t i = col; i < g.len; ++i) {
                 const uint64_t q = row * g.n + g.off + i;
-                const float r = one(d[q], peak ? peak[q] : fabsf(x[q]));
+                const float r = one(d[q], peak ? peak[q] : agc_peak0(d[q], x[q]));
                 if (da) da[q] = r * oma;
                 d[q] = da ? clampg(r) : r;
             }
