@@ -907,6 +907,9 @@ def side(args, argv):
         # latency chain of a few dozen tiles, profiles/r05_stream_frames_per_lane.txt; a block emits whole 16-byte vectors whatever the run length)
         pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=args.frames_per_lane or 0)
         pipe.set_exclusive(True)
+        # the rows are resident and complete before the first call: the promise rh_rlm_stream_overlap asks for -- consecutive blocks run side by
+        # side on two streams of the handle's (RH_SBLK_NO_OVERLAP=1 / --no-overlap: one after the other on the caller's stream)
+        _lib.check(lib.rh_rlm_stream_overlap(pipe._h, 0 if args.no_overlap else 1), "rh_rlm_stream_overlap")
         mo = C.c_uint64(0)
         _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")
         M = mo.value
@@ -952,6 +955,10 @@ def side(args, argv):
             got = out[: emitted[-1] * 2].cpu().numpy()
             pr = _parity(got, ref, 1e-5, f"oracle (restated rodio CPU path) in ONE pass over the whole sources; the GPU output is the concatenation of {nblocks} streamed blocks")
             pr["stream_stats"] = dict(zip(("blocks_on_the_summed_state", "blocks_with_per_source_states", "recoveries"), pipe.stream_stats()))
+            ol = C.c_uint32(0)
+            _lib.check(lib.rh_rlm_stream_one_launch_blocks(pipe._h, C.byref(ol)), "rh_rlm_stream_one_launch_blocks")
+            pr["stream_stats"]["blocks_in_one_launch"] = ol.value
+            pr["stream_stats"]["blocks_side_by_side"] = not args.no_overlap and not os.environ.get("RH_SBLK_NO_OVERLAP")
             return pr, base_
     else:
         sys.exit(f"unknown --config {cfg}")
@@ -1025,6 +1032,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
     ap.add_argument("--block", type=int, default=65536, help="--config stream: input frames per block")
+    ap.add_argument("--no-overlap", action="store_true", help="--config stream: every block on the caller's stream (no rh_rlm_stream_overlap)")
     ap.add_argument("--short-source", type=float, default=0.0, help="--config stream: source 0 ends after this fraction of the frames (timing only)")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)

@@ -466,6 +466,17 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
  * stay valid and unchanged until the work of the NEXT block call has run" (three row sets in rotation do: include/rodio_hip.hpp).
  * Between rh_rlm_stream_begin and the stream's first block.  Without it -- the default -- every block takes the per-source kernel. */
 rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on);
+/* Blocks side by side.  A block of a stream on the summed state is ONE launch where the library can make it one (k_rlm_sblk: the sum over
+ * the sources, the conversion and the filter in one kernel), and a short kernel spends a third of its life filling and draining the chip.
+ * on != 0 = "the rows I pass to a block call are COMPLETE in device memory when I make the call" (decoded assets resident in HBM; a caller
+ * that has synchronised its producer) -- the library then need not order a block's reads behind the caller's stream, and runs consecutive
+ * blocks on two streams of its own: a block starts while the one in front still runs and takes the stream's state from it through tagged
+ * words.  Nothing changes for the output: a block's dst is complete in the order of the stream passed to its call.  Without the promise
+ * (the default: rows that a copy on the caller's stream is still filling) every block runs on the caller's stream.  rh_rlm_set_exclusive(0)
+ * switches it off (two blocks' workgroups must fit the chip together). */
+rh_status rh_rlm_stream_overlap(rh_rlm *p, int32_t on);
+/* Diagnostics: blocks of the current stream that ran as one launch. */
+rh_status rh_rlm_stream_one_launch_blocks(rh_rlm *p, uint32_t *blocks);
 /* Diagnostics: blocks of the current stream that ran on the summed state / on one state per source, and recoveries in between. */
 rh_status rh_rlm_stream_stats(rh_rlm *p, uint32_t *summed_blocks, uint32_t *per_source_blocks, uint32_t *recoveries);
 /* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels

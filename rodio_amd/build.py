@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librodio_hip.so")
-SOURCES = ["rh_runtime.hip", "rh_elementwise.hip", "rh_resample.hip", "rh_recurrence.hip", "rh_limit.hip", "rh_agc.hip", "rh_biquad_scan.hip", "rh_stream.hip", "rh_uniform.hip", "rh_formats.hip", "rh_wav.hip", "rh_comm.hip", "rh_pipeline.hip", "rh_pipeline_plan.hip", "rh_pipeline_stream.hip"]
+SOURCES = ["rh_runtime.hip", "rh_elementwise.hip", "rh_resample.hip", "rh_recurrence.hip", "rh_limit.hip", "rh_agc.hip", "rh_biquad_scan.hip", "rh_stream.hip", "rh_uniform.hip", "rh_formats.hip", "rh_wav.hip", "rh_comm.hip", "rh_pipeline.hip", "rh_pipeline_plan.hip", "rh_pipeline_stream.hip", "rh_pipeline_sblk.hip"]
 # -ffp-contract=off: the reference's f32 expressions (lerp, biquad, mixer sum) must not be
 # fused; kernels that want an FMA spell it __builtin_fmaf.
 # -fno-slp-vectorize: hipcc's SLP pass pairs the two stereo channels into v_pk_*_f32; on gfx950
@@ -42,7 +42,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "rh_common.h"), os.path.join(CSRC, "rh_scan_common.h"), os.path.join(CSRC, "rh_pipeline_internal.h"), os.path.join(HERE, "..", "include", "rodio_hip.h")]
+    headers = [os.path.join(CSRC, "rh_common.h"), os.path.join(CSRC, "rh_scan_common.h"), os.path.join(CSRC, "rh_pipeline_internal.h"), os.path.join(CSRC, "rh_pipeline_dev.h"), os.path.join(HERE, "..", "include", "rodio_hip.h")]
     cc = hipcc()
     jobs = []
     objs = []

@@ -255,6 +255,7 @@ struct rh_rlm {
     float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
     size_t mix_floats = 0;
     ChunkPlan chunk;            // mix first in one kernel (k_rlm_chunk)
+    void *sblk = nullptr;       // a stream's summed blocks in one kernel (k_rlm_sblk: rh_pipeline_sblk.hip owns the type)
     bool pre_filter = false;    // cfg.filter_first: the filter runs at from_rate in front of the converter (the fused kernels then run without one)
     float pre_coeffs[5] = {1.f, 0.f, 0.f, 0.f, 0.f};
     unsigned long long *d_prof = nullptr;
@@ -297,6 +298,8 @@ struct rh_rlm {
     size_t replay_floats = 0;
     uint32_t st_n_summed = 0, st_n_each = 0, st_n_recover = 0;  // rh_rlm_stream_stats
     uint32_t st_n_rejoin = 0;                 // times the stream went back to the summed state
+    uint32_t st_n_sblk = 0;                   // summed blocks that ran as ONE launch (k_rlm_sblk)
+    bool st_overlap = false;                  // rh_rlm_stream_overlap: consecutive one-launch blocks run side by side (rows resident)
     std::vector<uint8_t> st_gone, st_prev_gone;  // sources that have given everything (the summed blocks behind a return; the block before, for a recovery)
     // Recorded (by wait_idle) behind what the handle has queued.  The library's streams are hipStreamNonBlocking: a null-stream
     // hipMemcpy / hipMemset does NOT wait for them, so everything on the host side that rewrites device state a queued
@@ -348,6 +351,10 @@ void launch_state_sum(hipStream_t s, const unsigned long long *gran, const SrcDe
 bool mix_first_applies(const rh_rlm *p, const Plan &pl, uint32_t count, bool per_source_states, bool batch);
 rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint64_t out_capacity_frames, uint64_t *out_frames, rh_stream stream, uint32_t batch_streams, uint64_t out_stride_floats,
                      const StreamArgs &sa = StreamArgs());
+// rh_pipeline_sblk.hip: a block of a stream on the summed state in ONE launch (k_rlm_sblk); *taken = false: not this kernel's block
+rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail_frames, uint64_t out_frames, float *dst, const StreamArgs &sa, hipStream_t s, bool *taken);
+void sblk_free(rh_rlm *p);
+void sblk_other_block(rh_rlm *p);  // a block of the stream ran elsewhere (or the stream begins)
 // rh_pipeline_plan.hip
 rh_status wait_idle(rh_rlm *p);
 rh_status pre_launch(rh_rlm *p, hipStream_t s);

@@ -574,6 +574,7 @@ rh_status rh_rlm_destroy(rh_rlm *p) {
     for (hipEvent_t e : p->cls_done) (void)hipEventDestroy(e);
     if (p->cls_fork) (void)hipEventDestroy(p->cls_fork);
     if (p->d_cls_rows) (void)hipFree(p->d_cls_rows);
+    sblk_free(p);
     if (p->idle_ev) (void)hipEventDestroy(p->idle_ev);
     bool fast_in_tried = false, wave_in_tried = false, pair_in_tried = false;
     for (Plan &c : p->tried) {

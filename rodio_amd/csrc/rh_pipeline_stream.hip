@@ -64,11 +64,24 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     p->st_total.clear();
     p->st_cols = 0;
     p->st_together = p->st_decided = false;
-    p->st_n_summed = p->st_n_each = p->st_n_recover = p->st_n_rejoin = 0;
+    p->st_n_summed = p->st_n_each = p->st_n_recover = p->st_n_rejoin = p->st_n_sblk = 0;
     p->st_prev_ptrs.clear();
     p->st_gone.clear();
     p->st_prev_gone.clear();
     p->st_prev_avail = p->st_prev_g0 = p->st_prev_m = p->st_prev_out = 0;
+    sblk_other_block(p);
+    return RH_OK;
+}
+
+rh_status rh_rlm_stream_overlap(rh_rlm *p, int32_t on) {
+    if (!p) return RH_ERR_INVALID;
+    p->st_overlap = on != 0;
+    return RH_OK;
+}
+
+rh_status rh_rlm_stream_one_launch_blocks(rh_rlm *p, uint32_t *blocks) {
+    if (!p || !blocks) return RH_ERR_INVALID;
+    *blocks = p->st_n_sblk;
     return RH_OK;
 }
 
@@ -165,21 +178,40 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
             p->n_sources = n_sources;
             p->out_frames = out;
             p->chunk.ok = false;  // (the tile tables of k_rlm_chunk belong to a one-shot batch)
-            rh_status st = activate_plan(p, &p->fast);
-            if (st != RH_OK) return st;
-            const uint64_t tiles = flush ? (out + L - 1) / L : out / L + 1;  // + the tile that holds the end-state lane
-            p->n_tiles = (uint32_t)tiles;
-            if (p->filt && (size_t)tiles * 4 > p->gran_words) return RH_ERR_CAPACITY;  // activate_plan sized it for ceil(out/L)+... never smaller
-            StreamArgs sa;
-            sa.mode = flush ? 2u : 1u;
-            sa.active = (uint32_t)out;
-            sa.m0 = p->st_m;
-            sa.g0 = p->st_g0;
-            sa.win = p->d_w[p->st_cur];
-            sa.wout = p->d_w[p->st_cur ^ 1];
-            sa.src_off = src_off;
-            st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
-            if (st != RH_OK) return st;
+            // ONE launch per block where the block is k_rlm_sblk's (rh_pipeline_sblk.hip): the sum, the conversion and the filter in one kernel
+            bool taken = false;
+            if (sum_first) {
+                StreamArgs sb;
+                sb.mode = flush ? 2u : 1u;
+                sb.active = (uint32_t)out;
+                sb.m0 = p->st_m;
+                sb.g0 = p->st_g0;
+                sb.win = p->d_w[p->st_cur];
+                sb.wout = p->d_w[p->st_cur ^ 1];
+                sb.src_off = src_off;
+                const rh_status sk = sblk_try(p, n_sources, avail_frames, out, dst, sb, rh::as_stream(stream), &taken);
+                if (sk != RH_OK) return sk;
+            }
+            if (taken) {
+                p->st_n_sblk += 1;
+            } else {
+                sblk_other_block(p);
+                rh_status st = activate_plan(p, &p->fast);
+                if (st != RH_OK) return st;
+                const uint64_t tiles = flush ? (out + L - 1) / L : out / L + 1;  // + the tile that holds the end-state lane
+                p->n_tiles = (uint32_t)tiles;
+                if (p->filt && (size_t)tiles * 4 > p->gran_words) return RH_ERR_CAPACITY;  // activate_plan sized it for ceil(out/L)+... never smaller
+                StreamArgs sa;
+                sa.mode = flush ? 2u : 1u;
+                sa.active = (uint32_t)out;
+                sa.m0 = p->st_m;
+                sa.g0 = p->st_g0;
+                sa.win = p->d_w[p->st_cur];
+                sa.wout = p->d_w[p->st_cur ^ 1];
+                sa.src_off = src_off;
+                st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
+                if (st != RH_OK) return st;
+            }
             p->st_n_summed += 1;
             if (!flush && p->filt) p->st_cur ^= 1;
         }
@@ -244,9 +276,10 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         p->st_together = p->st_history && p->filt && p->mix_first_on && n_sources >= 2 && K > 0 && !rh::knob(rh::K_NO_MIX_FIRST);
     }
     const uint64_t Rf = p->fast.v->R;
-    auto would_emit = [&](uint64_t avail) {  // output frames a summed block of `avail` frames per source would emit
+    auto would_emit = [&](uint64_t avail) {  // output frames a summed block of `avail` frames per source would emit: stream_block_summed's own rounding
         const uint64_t ready = stream_ready(p->st_g0 + avail, F, T, cin, cout);
-        return ready > p->st_m ? (ready - p->st_m) / Rf * Rf : 0;
+        const uint64_t vec = 4u / p->cfg.channels, unit = Rf / std::gcd(Rf, vec) * vec;  // (whole lane runs that are whole 16-byte vectors: ADVICE r5 -- rounding to R alone let a
+        return ready > p->st_m ? (ready - p->st_m) / unit * unit : 0;                     // block pass the K test and then emit fewer than K frames, which a later recovery relies on)
     };
     // ---- ... and TOGETHER AGAIN: a stream with a state per source whose sources have either given everything or still run, the running ones
     // with the same frames.  The summed state is the sum of their states (column 0 of their rows: k_rlm_state_sum); the ones that are gone
@@ -337,6 +370,7 @@ static rh_status stream_block_v_impl(rh_rlm *p, const float *const *srcs_host, c
         p->st_together = false;  // a source ends or falls behind, or the block is short: one state per source from here on
         leaving = true;
     }
+    sblk_other_block(p);  // (a block with a state per source: the summed state, if it comes back, comes back in the plain words)
     const bool recover = (leaving || !p->st_cols) && p->st_prev_out >= K && K > 0 && !p->st_prev_ptrs.empty();
     const bool rows_exist = p->st_cols != 0;  // (the stream has had a state per source before: its rows are sized, their column 0 carries old tags)
     if (!p->st_cols) {  // first block of the per-source stream: size the aggregate rows once (the states live in them), zero states

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/kt_cmd.sh <tag> <command...>   (GPU box) kernel trace only -> gpurun_out/prof/<tag>/summary.txt
+# usage: kt.sh <tag> <command...>: kernel trace only
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/prof/$tag
@@ -7,5 +7,5 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $R
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- "$@" > $out/kt.log 2>&1
-python tools/prof_summary.py $out/kt/kt_results.db | cut -c1-220 > $out/summary.txt
+python tools/prof_summary.py $out/kt/kt_results.db | cut -c1-200 > $out/summary.txt
 cat $out/summary.txt
