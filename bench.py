@@ -907,9 +907,11 @@ def side(args, argv):
         # latency chain of a few dozen tiles, profiles/r05_stream_frames_per_lane.txt; a block emits whole 16-byte vectors whatever the run length)
         pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=args.frames_per_lane or 0)
         pipe.set_exclusive(True)
-        # the rows are resident and complete before the first call: the promise rh_rlm_stream_overlap asks for -- consecutive blocks run side by
-        # side on two streams of the handle's (RH_SBLK_NO_OVERLAP=1 / --no-overlap: one after the other on the caller's stream)
-        _lib.check(lib.rh_rlm_stream_overlap(pipe._h, 0 if args.no_overlap else 1), "rh_rlm_stream_overlap")
+        # --overlap: rh_rlm_stream_overlap (the rows are resident and complete before the first call: the promise it asks for) -- consecutive blocks side
+        # by side on two streams of the handle's, every block from a zero filter state with the true state added by a small kernel behind it.
+        # Measured SLOWER than one block after the other (profiles/r06_stream_overlap.txt: seven stream / event calls a block make the host the
+        # bound), so the default is the plain form: ONE launch per block on the caller's stream.
+        _lib.check(lib.rh_rlm_stream_overlap(pipe._h, 1 if args.overlap else 0), "rh_rlm_stream_overlap")
         mo = C.c_uint64(0)
         _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")
         M = mo.value
@@ -958,7 +960,7 @@ def side(args, argv):
             ol = C.c_uint32(0)
             _lib.check(lib.rh_rlm_stream_one_launch_blocks(pipe._h, C.byref(ol)), "rh_rlm_stream_one_launch_blocks")
             pr["stream_stats"]["blocks_in_one_launch"] = ol.value
-            pr["stream_stats"]["blocks_side_by_side"] = not args.no_overlap and not os.environ.get("RH_SBLK_NO_OVERLAP")
+            pr["stream_stats"]["blocks_side_by_side"] = bool(args.overlap) and not os.environ.get("RH_SBLK_NO_OVERLAP")
             return pr, base_
     else:
         sys.exit(f"unknown --config {cfg}")
@@ -1032,7 +1034,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
     ap.add_argument("--block", type=int, default=65536, help="--config stream: input frames per block")
-    ap.add_argument("--no-overlap", action="store_true", help="--config stream: every block on the caller's stream (no rh_rlm_stream_overlap)")
+    ap.add_argument("--overlap", action="store_true", help="--config stream: rh_rlm_stream_overlap (consecutive blocks side by side; measured slower: host-bound)")
     ap.add_argument("--short-source", type=float, default=0.0, help="--config stream: source 0 ends after this fraction of the frames (timing only)")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)

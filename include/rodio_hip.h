@@ -470,8 +470,8 @@ rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on);
  * the sources, the conversion and the filter in one kernel), and a short kernel spends a third of its life filling and draining the chip.
  * on != 0 = "the rows I pass to a block call are COMPLETE in device memory when I make the call" (decoded assets resident in HBM; a caller
  * that has synchronised its producer) -- the library then need not order a block's reads behind the caller's stream, and runs consecutive
- * blocks on two streams of its own: a block starts while the one in front still runs and takes the stream's state from it through tagged
- * words.  Nothing changes for the output: a block's dst is complete in the order of the stream passed to its call.  Without the promise
+ * blocks on two streams of its own: a block starts while the one in front still runs -- from a zero filter state; what the stream's true
+ * state at its first frame adds (a few hundred frames: the filter forgets) follows in a small kernel ordered behind both by events.  Nothing changes for the output: a block's dst is complete in the order of the stream passed to its call.  Without the promise
  * (the default: rows that a copy on the caller's stream is still filling) every block runs on the caller's stream.  rh_rlm_set_exclusive(0)
  * switches it off (two blocks' workgroups must fit the chip together). */
 rh_status rh_rlm_stream_overlap(rh_rlm *p, int32_t on);

@@ -39,11 +39,6 @@ struct SblkArgs {
     // from frame mb = m0 - mb_off (mb_off = 2: the two frames the filter looks back at; less at the very start of a stream), whose first tap is
     // frame ib of the rows with numerator rb:  frame mb + u reads row frame ib + (rb + u F) / T, numerator (rb + u F) mod T.
     uint32_t ib, rb, mb_off;
-    // Blocks that overlap (rh_rlm_stream_overlap): the stream's state as tagged words {tag, f32 bits}, polled by the tiles it reaches and written
-    // by the last tile -- the block in front may still be running on the handle's other stream.  Null: the plain floats of Params::st_win / st_wout.
-    const unsigned long long *win_t;
-    unsigned long long *wout_t;
-    uint32_t tag_in, tag_out;
 };
 
 template <int N>
@@ -196,7 +191,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
         const bool far = dj > q.Dmax;  // (forgotten: weight 0)
         const float *kp = q.powD + 4 * (uint64_t)(far ? 0u : dj);
         const uint32_t dW = u_lo - q.mb_off;
-        win_on = (p.st_win != nullptr || q.win_t != nullptr) && dW <= q.Dmax;
+        win_on = p.st_win != nullptr && dW <= q.Dmax;
         const float *wp = q.powD + 4 * (uint64_t)(win_on ? dW : 0u);
         const float *ep = q.powD + 4 * (uint64_t)(n_t <= q.Dmax ? n_t : q.Dmax);
         const float *pw = q.powD + 4 * v;
@@ -210,7 +205,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
             eM[k] = n_t <= q.Dmax ? ep[k] : 0.f;
             pwv[k] = pw[k];
         }
-        if (win_on && !q.win_t) {
+        if (win_on) {
 #pragma unroll
             for (int k = 0; k < 2 * C; ++k) win[k] = p.st_win[k];
         }
@@ -440,28 +435,6 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
             c[k] = readlane_f(c[k], 15) + readlane_f(c[k], 31);
         }
     }
-    if (win_on && q.win_t) {  // the block in front may still run (on the handle's other stream): its last tile tags the state it leaves
-        const bool want = lane < 2 * C;
-        unsigned long long wv = 0;
-        bool ok = false;
-        uint32_t spins = 0;
-        while (true) {
-            if (want && !ok) {
-                wv = __hip_atomic_load(q.win_t + (want ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (uint32_t)(wv >> 32) == q.tag_in;
-            }
-            if (__all(ok || !want)) break;
-            if (++spins > kSpinLimit) {
-                if (lane == 0) atomicOr(p.status, 1u);
-                dead = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const float wl = __uint_as_float((uint32_t)wv);
-#pragma unroll
-        for (int k = 0; k < 2 * C; ++k) win[k] = readlane_f(wl, k);
-    }
     if (win_on) {  // + B^(m_lo - m0) * (the stream's state at m0)
         const float M[4] = {readfirstlane_f(wM[0]), readfirstlane_f(wM[1]), readfirstlane_f(wM[2]), readfirstlane_f(wM[3])};
 #pragma unroll
@@ -471,7 +444,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
 #pragma unroll
         for (int k = 0; k < 2 * C; ++k) c[k] = __builtin_nanf("");
     }
-    if (last_tile && p.st_mode == 1 && (p.st_wout || q.wout_t) && lane < 2 * C) {  // the stream's state at the block's end: A + B^(n_t) * carry
+    if (last_tile && p.st_mode == 1 && p.st_wout && lane < 2 * C) {  // the stream's state at the block's end: A + B^(n_t) * carry
         const float M[4] = {readfirstlane_f(eM[0]), readfirstlane_f(eM[1]), readfirstlane_f(eM[2]), readfirstlane_f(eM[3])};
         float e[2 * C];
 #pragma unroll
@@ -481,8 +454,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
         float ev = e[0];
 #pragma unroll
         for (int k = 1; k < 2 * C; ++k) ev = lane == k ? e[k] : ev;
-        if (p.st_wout) p.st_wout[lane] = ev;
-        if (q.wout_t) __hip_atomic_store(q.wout_t + lane, ((unsigned long long)q.tag_out << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.st_wout[lane] = ev;
     }
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);  // start state of the lane's run = Q + B^(R*lane) * carry
@@ -513,6 +485,40 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
                 }
             }
         }
+    }
+}
+
+// Blocks side by side (rh_rlm_stream_overlap).  A block that starts while the block in front still runs cannot have the stream's state at its
+// first frame -- and must not wait for it inside the kernel (two streams are two hardware queues: a kernel that spins for one that sits
+// undispatched in another queue waits for the scheduler's time slice, tens of milliseconds; measured).  The filter is linear: the block runs
+// from a ZERO state (k_rlm_sblk with no st_win; its last tile leaves the zero-state end state e0), and this kernel, ordered behind it and
+// behind the fix-up of the block in front by stream events alone, adds what the true state S at the block's first frame contributes:
+//     y[m0 + d] += g_d . S   (g_d = row 0 of A^(d+1) Tm^-1, d = 0 .. Dmax: beyond that the filter has forgotten S to 2^-40),
+//     state at the block's end = e0 + B^(frames) S.
+// A few hundred frames and eight floats: microseconds, off the blocks' critical path.
+template <int C>
+__global__ __launch_bounds__(256) void k_sblk_fix(float *__restrict__ out, const uint32_t frames, const float *__restrict__ G, const float *__restrict__ powD, const uint32_t Dmax,
+                                                  const float *__restrict__ s_in, const float *__restrict__ e0, float *__restrict__ s_out) {
+    float S[2 * C];
+#pragma unroll
+    for (int k = 0; k < 2 * C; ++k) S[k] = s_in[k];
+    const uint32_t n = frames < Dmax + 1u ? frames : Dmax + 1u;
+    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) {
+        const float g0 = G[2 * d], g1 = G[2 * d + 1];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) out[(uint64_t)d * C + ch] = fma_(g0, S[2 * ch], fma_(g1, S[2 * ch + 1], out[(uint64_t)d * C + ch]));
+    }
+    if (s_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        float e[2 * C];
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) e[k] = e0[k];
+        if (frames <= Dmax) {
+            const float *M = powD + 4 * (uint64_t)frames;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(M, S[2 * ch], S[2 * ch + 1], e[2 * ch], e[2 * ch + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) s_out[k] = e[k];
     }
 }
 
@@ -550,10 +556,11 @@ struct SblkPlan {
     // rh_rlm_stream_overlap: consecutive blocks on two streams of the handle's
     hipStream_t ovl_stream[2] = {nullptr, nullptr};
     hipEvent_t ovl_done[2] = {nullptr, nullptr}, ovl_pre = nullptr;
-    hipEvent_t ovl_go[2] = {nullptr, nullptr};  // recorded on a block's stream right in front of its kernel: the block behind it is launched behind this
-    unsigned long long *d_wt = nullptr;    // [2][4] tagged state words
+    hipStream_t fix_stream = nullptr;           // the fix-ups, one behind the other
+    hipEvent_t fix_done[2] = {nullptr, nullptr};
+    float *d_e0 = nullptr;                      // [2][4]: a block's zero-state end state
+    float *d_G = nullptr;                       // [Dmax + 1][2]: row 0 of A^(d+1) Tm^-1
     uint32_t blk = 0;                      // blocks of the current stream that this kernel ran
-    uint32_t tag_ctr = 0;                  // the tag of the state words written last (never reused)
     bool prev_sblk = false;                // ... and the block before this one was one of them
     uint64_t seen_version = ~0ull;         // the table upload the handle's streams have been ordered behind
 };
@@ -570,11 +577,13 @@ void sblk_free(rh_rlm *p) {
     if (s->d_uni) (void)hipFree(s->d_uni);
     if (s->d_pow) (void)hipFree(s->d_pow);
     if (s->d_gran) (void)hipFree(s->d_gran);
-    if (s->d_wt) (void)hipFree(s->d_wt);
+    if (s->d_e0) (void)hipFree(s->d_e0);
+    if (s->d_G) (void)hipFree(s->d_G);
+    if (s->fix_stream) (void)hipStreamDestroy(s->fix_stream);
     for (int k = 0; k < 2; ++k) {
         if (s->ovl_stream[k]) (void)hipStreamDestroy(s->ovl_stream[k]);
         if (s->ovl_done[k]) (void)hipEventDestroy(s->ovl_done[k]);
-        if (s->ovl_go[k]) (void)hipEventDestroy(s->ovl_go[k]);
+        if (s->fix_done[k]) (void)hipEventDestroy(s->fix_done[k]);
     }
     if (s->ovl_pre) (void)hipEventDestroy(s->ovl_pre);
     delete s;
@@ -609,6 +618,16 @@ static rh_status sblk_tables(rh_rlm *p, SblkPlan &s, int R) {
         RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_pow), pw.size() * 4));
         RH_HIP_TRY(hipMemcpy(s.d_pow, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
         s.Dmax = d;
+        std::vector<float> gt((size_t)(d + 1) * 2);  // what a state at a block's first frame adds to frame d: row 0 of A^(d+1) Tm^-1 (k_sblk_fix)
+        M2 ap = A;
+        for (uint32_t k = 0; k <= d; ++k) {
+            const M2 m = mul(ap, Ti);
+            gt[(size_t)k * 2] = (float)m.a;
+            gt[(size_t)k * 2 + 1] = (float)m.b;
+            ap = mul(ap, A);
+        }
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_G), gt.size() * 4));
+        RH_HIP_TRY(hipMemcpy(s.d_G, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
     }
     Tables *h = new Tables();
     std::memset(h, 0, sizeof(Tables));
@@ -717,32 +736,27 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     }
     hipStream_t ls = hs;  // the stream of the launch
     const int par = (int)(s.blk & 1u);
+    bool pre_recorded = false;
     if (ovl) {
         for (int k = 0; k < 2; ++k) {
             if (!s.ovl_stream[k]) RH_HIP_TRY(hipStreamCreateWithFlags(&s.ovl_stream[k], hipStreamNonBlocking));
             if (!s.ovl_done[k]) RH_HIP_TRY(hipEventCreateWithFlags(&s.ovl_done[k], hipEventDisableTiming));
-            if (!s.ovl_go[k]) RH_HIP_TRY(hipEventCreateWithFlags(&s.ovl_go[k], hipEventDisableTiming));
+            if (!s.fix_done[k]) RH_HIP_TRY(hipEventCreateWithFlags(&s.fix_done[k], hipEventDisableTiming));
         }
+        if (!s.fix_stream) RH_HIP_TRY(hipStreamCreateWithFlags(&s.fix_stream, hipStreamNonBlocking));
         if (!s.ovl_pre) RH_HIP_TRY(hipEventCreateWithFlags(&s.ovl_pre, hipEventDisableTiming));
-        if (!s.d_wt) {
-            RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_wt), 2 * 4 * 8));
-            RH_HIP_TRY(rh::fill_now(s.d_wt, 0, 2 * 4 * 8));
-        }
+        if (!s.d_e0) RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_e0), 2 * 4 * sizeof(float)));
         ls = s.ovl_stream[par];
-        // What this block needs of the caller's stream: the source table (when it was uploaded since the handle's streams last looked) and a state
-        // that another kernel wrote there.  The ROWS are not ordered behind the caller's stream: they are complete when the call is made (the
-        // contract of rh_rlm_stream_overlap) -- that is what lets this block start while the one in front still runs.
+        // What this block needs of the caller's stream: the source table (when it was uploaded since the handle's streams last looked) and -- its
+        // fix-up -- a state that another kernel wrote there.  The ROWS are not ordered behind the caller's stream: they are complete when the
+        // call is made (the contract of rh_rlm_stream_overlap) -- that is what lets this block start while the one in front still runs.
         if (!s.prev_sblk || s.seen_version != p->srcs_version) {
             RH_HIP_TRY(hipEventRecord(s.ovl_pre, hs));
             RH_HIP_TRY(hipStreamWaitEvent(ls, s.ovl_pre, 0));
             s.seen_version = p->srcs_version;
+            pre_recorded = true;
         }
-        // A block polls the state the block in front leaves: that block's kernel must be DISPATCHED first (the two streams are two hardware
-        // queues; a queue whose kernel spins for a kernel that sits undispatched in another queue of the same pipe waits for the scheduler's
-        // time slice: tens of milliseconds a block, measured).  So a block's kernel is launched behind an event that the block in front
-        // recorded on ITS stream right in front of its own kernel.
-        if (s.prev_sblk) RH_HIP_TRY(hipStreamWaitEvent(ls, s.ovl_go[par ^ 1], 0));
-        RH_HIP_TRY(hipEventRecord(s.ovl_go[par], ls));
+        if (s.blk >= 2) RH_HIP_TRY(hipStreamWaitEvent(ls, s.fix_done[par], 0));  // (the zero-state end state of the block two in front has been read)
     }
     {
         const rh_status w = pre_launch(p, hs);
@@ -781,8 +795,8 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     k.st_active = (uint32_t)out;
     k.st_m0 = sa.m0;
     k.st_g0 = sa.g0;
-    k.st_win = sa.win;
-    k.st_wout = sa.wout;
+    k.st_win = ovl ? nullptr : sa.win;                                  // side by side: from a zero state, the true one added behind it (k_sblk_fix)
+    k.st_wout = ovl ? (sa.mode == 1 ? s.d_e0 + 4 * par : nullptr) : sa.wout;
     k.u = s.uni;
     SblkArgs q;
     {
@@ -797,12 +811,6 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     q.uni = s.d_uni;
     q.powD = s.d_pow;
     q.gran = s.d_gran + (size_t)par * s.cap_tiles * 4;
-    q.win_t = (ovl && s.prev_sblk) ? s.d_wt + (size_t)par * 4 : nullptr;
-    q.tag_in = s.tag_ctr;
-    q.wout_t = ovl ? s.d_wt + (size_t)(par ^ 1) * 4 : nullptr;
-    s.tag_ctr += 1;
-    if (s.tag_ctr == 0) s.tag_ctr = 1;
-    q.tag_out = s.tag_ctr;
     q.src_off = sa.src_off;
     q.Dmax = s.Dmax;
     q.P = (uint32_t)P;
@@ -813,9 +821,22 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
         rh::set_hip_error(e, "k_rlm_sblk");
         return RH_ERR_HIP;
     }
-    if (ovl) {  // the block's output is complete in the CALLER's stream order, as ever
+    if (ovl) {
         RH_HIP_TRY(hipEventRecord(s.ovl_done[par], ls));
-        RH_HIP_TRY(hipStreamWaitEvent(hs, s.ovl_done[par], 0));
+        // the fix-up: behind this block's kernel, behind the fix-up of the block in front (the stream's order), behind whoever else wrote the state
+        if (!s.prev_sblk) {
+            if (!pre_recorded) RH_HIP_TRY(hipEventRecord(s.ovl_pre, hs));
+            RH_HIP_TRY(hipStreamWaitEvent(s.fix_stream, s.ovl_pre, 0));
+        }
+        RH_HIP_TRY(hipStreamWaitEvent(s.fix_stream, s.ovl_done[par], 0));
+        const uint32_t nfix = (uint32_t)(out < (uint64_t)s.Dmax + 1 ? out : (uint64_t)s.Dmax + 1);
+        const dim3 fg((nfix + 255u) / 256u ? (nfix + 255u) / 256u : 1u);
+        float *const s_out = sa.mode == 1 ? sa.wout : nullptr;
+        if (C == 2) hipLaunchKernelGGL(k_sblk_fix<2>, fg, dim3(256), 0, s.fix_stream, dst, (uint32_t)out, s.d_G, s.d_pow, s.Dmax, sa.win, s.d_e0 + 4 * par, s_out);
+        else hipLaunchKernelGGL(k_sblk_fix<1>, fg, dim3(256), 0, s.fix_stream, dst, (uint32_t)out, s.d_G, s.d_pow, s.Dmax, sa.win, s.d_e0 + 4 * par, s_out);
+        RH_CHECK_LAUNCH();
+        RH_HIP_TRY(hipEventRecord(s.fix_done[par], s.fix_stream));
+        RH_HIP_TRY(hipStreamWaitEvent(hs, s.fix_done[par], 0));  // the block's output is complete in the CALLER's stream order, as ever
     }
     s.prev_sblk = true;
     s.blk += 1;

@@ -537,3 +537,66 @@ def test_the_filter_contract(G, fs):
     if fs == 48000:
         assert G.filter_scan_ok("low_pass", 100, 0.5, fs) and not G.filter_scan_ok("low_pass", 50, 0.5, fs)
         assert G.filter_scan_ok("high_pass", 600, 0.5, fs) and not G.filter_scan_ok("high_pass", 500, 0.5, fs)
+
+
+@pytest.mark.parametrize("ch,filt,freq,frm,B", [(2, "low_pass", 200, 44100, 40_000), (2, "high_pass", 1000, 48000, 9_000), (1, "low_pass", 1000, 44100, 70_000), (2, "low_pass", 200, 48000, 3_000),
+                                                (2, "low_pass", 4000, 50000, 20_000)])
+def test_a_block_of_a_summed_stream_in_one_launch(G, O, ch, filt, freq, frm, B):
+    """Round 6: a block of a stream on the summed state is ONE kernel (k_rlm_sblk, rh_pipeline_sblk.hip) -- the sum over the
+    sources, the conversion and the filter -- with nothing from the host per block but its arguments.  Resident rows read at `row + consumed`,
+    blocks of B input frames (tile windows of 1, 2 or 3 KiB by the block's length; a last block that is shorter; the verbatim last frame): the
+    oracle's one-pass samples; the same stream with RH_NO_SBLK=1 (two launches per block, as until round 5) within 2e-6; and side by side
+    (rh_rlm_stream_overlap: every block from a zero state, the true state added behind it by k_sblk_fix) the same again."""
+    import ctypes as C
+
+    import torch
+    from conftest import knobs
+    from rodio_amd import _lib
+
+    lib = _lib.lib
+    S, N = 7, 200_000
+    xs = [rnd(9900 + s, ch * N, 0.15) for s in range(S)]
+    gains = np.linspace(0.4, 1.3, S).astype(np.float32)
+    data = torch.from_numpy(np.stack(xs)).cuda()
+    mo = C.c_uint64(0)
+    _lib.check(lib.rh_resample_out_frames(N, frm, 48000, ch, 0, C.byref(mo)), "rh_resample_out_frames")
+    M = mo.value
+
+    def run(overlap):
+        p = G.ResampleLowpassMix(frm, 48000, ch, None, filt, freq, 0.5, max_sources=S, max_in_frames=B + 4096)
+        p.set_gains(gains)
+        p.stream_begin(keep_history=True)
+        _lib.check(lib.rh_rlm_stream_overlap(p._h, 1 if overlap else 0), "rh_rlm_stream_overlap")
+        out = torch.zeros(ch * M + 4096, device="cuda", dtype=torch.float32)
+        g0 = m = k = 0
+        while True:
+            hi = min(N, (k + 1) * B)
+            ptrs = (C.c_void_p * S)(*[data[s_].data_ptr() + g0 * 4 * ch for s_ in range(S)])
+            avail = (C.c_uint64 * S)(*([hi - g0] * S))
+            ended = (C.c_uint8 * S)(*([1 if hi == N else 0] * S))
+            o, c = C.c_uint64(0), C.c_uint64(0)
+            _lib.check(lib.rh_rlm_stream_block_v(p._h, ptrs, avail, ended, S, C.c_void_p(out.data_ptr() + m * 4 * ch), M + 512 - m, C.byref(o), C.byref(c), None), "rh_rlm_stream_block_v")
+            m += o.value
+            g0 += c.value
+            k += 1
+            if hi == N:
+                break
+        p.check_status()
+        one = C.c_uint32(0)
+        _lib.check(lib.rh_rlm_stream_one_launch_blocks(p._h, C.byref(one)), "rh_rlm_stream_one_launch_blocks")
+        res = out[: ch * m].cpu().numpy()
+        stats = p.stream_stats()
+        p.close()
+        return res, one.value, stats, k
+
+    a, one_a, st_a, nb = run(False)
+    b, one_b, st_b, _ = run(True)
+    with knobs(RH_NO_SBLK="1"):
+        c_, one_c, st_c, _ = run(False)
+    ref = _oracle(O, xs, frm, 48000, None, filt, freq, gains, ch)
+    assert len(a) == len(b) == len(c_) == len(ref), (len(a), len(b), len(c_), len(ref))
+    assert one_a == nb and one_b == nb and one_c == 0, (one_a, one_b, one_c, nb)  # every block of the stream, the last (flush) one included
+    assert st_a[0] == nb and st_a[1] == 0
+    e = [float(np.max(np.abs(v - ref))) for v in (a, b, c_)]
+    assert max(e) <= TOL, e
+    assert float(np.max(np.abs(a - c_))) <= 2e-6 and float(np.max(np.abs(a - b))) <= 2e-6
