@@ -711,6 +711,74 @@ def headline(args, argv):
     if tuned:
         geo["autotuned"] = True
     geo["tiles_by"] = "workgroup index (exclusive device)" if (world == 1 and not args.shared_device and want == "auto") else "ticket (the device is shared with the collective's kernels)"
+    # ---- roofline.side: BASELINE's other single-GPU configurations in the driver's line: config 3 (reverb + spatial),
+    # config 5 (i16 -> f32 + 6 -> 2 channels on music.wav) and the headline workload STREAMED in blocks (what GpuMixer runs), each with its
+    # time per call, fraction of the 8 TB/s roofline and parity; bounded (a few seconds each; python bench.py --config {3,5,stream} are the
+    # full lines with cpu_baseline and counter traffic).
+    side_legs = None
+    if world == 1 and args.config == "2" and not child and not args.per_source and not args.no_side and not ragged:
+        import copy
+
+        side_legs = {}
+        t_side = time.perf_counter()
+        try:
+            # the stream: the very rows of the headline launch, resident, in blocks of B input frames through rh_rlm_stream_block_v; parity against the
+            # oracle's ONE-pass block of the headline's parity leg (`ref`), or -- without it -- against the one-shot launch's block
+            for B in (65536, 16384):
+                sp = rh.ResampleLowpassMix(44100, 48000, Cn, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096)
+                sp.set_exclusive(True)
+                so = torch.empty(M * Cn + 4096, device="cuda", dtype=torch.float32)
+                nb = (N + B - 1) // B
+                basep = [data[s_].data_ptr() for s_ in range(S)]
+                cache = {}
+                got_m = [0]
+
+                def one_stream():
+                    sp.stream_begin(keep_history=True)
+                    g0 = m_ = 0
+                    for k_ in range(nb):
+                        hi = min(N, (k_ + 1) * B)
+                        if (k_, g0) not in cache:
+                            cache[(k_, g0)] = ((C.c_void_p * S)(*[b_ + g0 * 4 * Cn for b_ in basep]), (C.c_uint64 * S)(*([hi - g0] * S)), (C.c_uint8 * S)(*([1 if hi >= N else 0] * S)))
+                        ptrs, avail, ended = cache[(k_, g0)]
+                        o_, c_ = C.c_uint64(0), C.c_uint64(0)
+                        _lib.check(lib.rh_rlm_stream_block_v(sp._h, ptrs, avail, ended, S, C.c_void_p(so.data_ptr() + m_ * 4 * Cn), M + 512 - m_, C.byref(o_), C.byref(c_), stream), "rh_rlm_stream_block_v")
+                        m_ += o_.value
+                        g0 += c_.value
+                    got_m[0] = m_
+
+                one_stream()
+                one_stream()
+                torch.cuda.synchronize()
+                evs_ = events(lib, _lib, 1)
+                reps = 5
+                lib.rh_event_record(evs_[0][0], stream)
+                for _ in range(reps):
+                    one_stream()
+                lib.rh_event_record(evs_[0][1], stream)
+                torch.cuda.synchronize()
+                sms = elapsed(lib, _lib, evs_)[0] / reps
+                sp.check_status()
+                one_l = C.c_uint32(0)
+                _lib.check(lib.rh_rlm_stream_one_launch_blocks(sp._h, C.byref(one_l)), "rh_rlm_stream_one_launch_blocks")
+                gs = so[: got_m[0] * Cn].cpu().numpy()
+                against = ref if ref is not None else mixed_last.cpu().numpy()
+                ok_len = gs.shape == against.shape
+                es = float(np.abs(gs.astype(np.float64) - against.astype(np.float64)).max()) if ok_len else float("inf")
+                side_legs["stream" if B == 65536 else f"stream_{B}"] = {
+                    "ms": sms, "frac": alg_bytes / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, "block_frames": B, "blocks": nb, "blocks_in_one_launch": one_l.value, "max_abs_err": es, "parity_ok": bool(es <= 1e-5),
+                    "vs": "the oracle's one-pass block (the headline's parity reference)" if ref is not None else "the one-shot launch's block",
+                    "what": f"the headline's {S} resident sources through rh_rlm_stream_block_v in blocks of {B} input frames; one call = one whole stream = the headline's bytes"}
+                sp.close()
+                del so
+            for cfg_ in ("3", "5"):
+                a2 = copy.copy(args)
+                a2.config, a2.steps, a2.warmup, a2.no_cpu_baseline = cfg_, 10, 2, False
+                side_legs[cfg_] = side(a2, [], lite=True)
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001  (a side leg never takes the headline line down)
+            side_legs["error"] = str(e)[:300]
+        side_legs["seconds"] = time.perf_counter() - t_side
     kern = "k_rlm_fast+k_rlm_resid" if geo["ragged_pair"] else ("k_rlm_wave" if geo["general_kernel"] else "k_rlm_chunk" if geo.get("mix_first") == 2 else "k_mix_ring+k_rlm_fast" if geo.get("mix_first") else "k_rlm_fast")
     res = {
         "metric": "Msamples/s through resample+low_pass+mix pipeline",
@@ -733,6 +801,8 @@ def headline(args, argv):
         res["roofline"]["per_source"] = per_source
     if per_class is not None:
         res["roofline"]["per_class"] = per_class
+    if side_legs:
+        res["roofline"]["side"] = side_legs
     if world == 1 and want.startswith("native"):
         res["config"]["collective"] = ("rh_reduce_sum_f32" if reduce_only else "rh_allreduce_sum_f32") + " (C ABI, rh_comm.hip over RCCL) with a communicator of ONE rank in the timed loop, on its own stream: the N > 1 code path, nranks = 1"
     if multi:
@@ -771,7 +841,7 @@ def _parity(got, ref, tol, what):
             "ok": bool(d.size == 0 or d.max() <= tol), "vs": what}
 
 
-def side(args, argv):
+def side(args, argv, lite=False):
     """Single-GPU configurations other than the headline: one JSON line with the same fields -- `parity` against the oracle,
     `cpu_baseline` (the oracle timed on a bounded sample of the same workload) and live `roofline.traffic` included."""
     import numpy as np
@@ -1000,6 +1070,16 @@ def side(args, argv):
         return
     rh.async_status()
     head = rows[0]
+    if lite:  # a leg of the default line (roofline.side): the timing and the parity, no counter passes, nothing printed
+        out_ = {"ms": head["kernel_ms"], "frac": head["frac"], "kernels": [{"kernel": r_["kernel"], "ms": r_["kernel_ms"], "frac": r_["frac"]} for r_ in rows], "workload": workload}
+        if checks is not None:
+            pr_, _ = checks()
+            out_["parity_ok"] = bool(pr_.get("ok"))
+            if "max_abs_err" in pr_:
+                out_["max_abs_err"] = pr_["max_abs_err"]
+            if pr_.get("bit_exact") is not None or "i16_to_f32" in pr_:
+                out_["bit_exact"] = bool(pr_.get("ok"))
+        return out_
     traffic, traffic_how = pmc_traffic(argv, like, per_call)
     res = {"metric": metric, "value": head["Msamples_per_s"], "unit": "Msamples/s", "n_gpus": 1, "steps": head["steps"], "warmup": args.warmup,
            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i16->f32" if cfg == "5" else "f32", "data": "synthetic" if cfg != "5" else "the reference's assets/music.wav, tiled",
@@ -1046,6 +1126,7 @@ def main():
     ap.add_argument("--per-source", action="store_true", help="the headline batch on the per-source path (rh_rlm_set_mix_first(0)); the default line carries it as roofline.per_source")
     ap.add_argument("--no-per-source", action="store_true", help="skip the per-source leg of the default line")
     ap.add_argument("--no-per-class", action="store_true", help="skip roofline.per_class (the same sources with a filter per source: four classes of 64)")
+    ap.add_argument("--no-side", action="store_true", help="skip roofline.side (configs 3, 5 and the block-streamed headline workload in the default line)")
     ap.add_argument("--no-unscaled", action="store_true", help="skip parity.unscaled / parity.vs_f64 (the same workload at amplitude 1, and both sides against the f64 response)")
     ap.add_argument("--shared-device", action="store_true", help="tiles by ticket although one rank runs (rh_rlm_set_exclusive(0)): what the N > 1 ranks do")
     ap.add_argument("--collective", default="auto", choices=["auto", "native", "native-reduce", "torch"],
