@@ -332,7 +332,10 @@ float rh_duration_to_coefficient(uint64_t duration_ns, uint32_t sample_rate);
 
 /* ---- Limit: src/source/limit.rs:94-130,853-988.  state: 2*channels floats
  * {integrator, peak} per channel (optional).  Works in place (dst == src).  A hand-off that expires inside the
- * kernel poisons the output with NaN and is reported by rh_async_status(). */
+ * kernel poisons the output with NaN and is reported by rh_async_status().
+ * Parity is by TOLERANCE only (<= 1e-5 abs, tested): the time-parallel kernel evaluates log2 / exp2 with the device's instructions, composes the
+ * integrator and peak recurrences as max-affine maps and, inside a run, spells them mul + FMA where limit.rs:909-913 has mul, mul, add (one
+ * rounding fewer per step).  RH_LIMIT_SEQ=1 takes the one-lane-per-stream kernel in the reference's operation order throughout. */
 typedef struct rh_limit_params {
     float threshold_db; /* LimitSettings::threshold  (default -1) */
     float knee_width_db;/* LimitSettings::knee_width (default 4)  */

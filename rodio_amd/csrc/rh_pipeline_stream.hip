@@ -146,36 +146,42 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
             // bytes since the table was uploaded -- rows of one staging block, resident rows read at `row + consumed` -- the table stays
             // where it is and the distance goes with the launch.  One copy kernel and two dependent boundaries less per block
             // (4 + ~3 us of the 49 us a 64 Ki-frame block of 256 sources takes: profiles/r05_stream_kernel_trace.txt).
-            const bool sum_first = mix_first_applies(p, p->fast, n_sources, false, false);
+            // Sources that are gone (a stream back on the summed state) are not in the table at all: it holds the live ones, in order (an
+            // entry with gain 0 that points at a live row turns that row's Inf into NaN -- rodio's mixer has no contribution there at all -- and
+            // reads the row once more).
+            std::vector<uint32_t> live;
+            for (uint32_t s = 0; s < n_sources; ++s)
+                if (!(gone && (*gone)[s])) live.push_back(s);
+            const uint32_t nl = (uint32_t)live.size();
+            if (nl == 0) return RH_ERR_INVALID;
+            const bool sum_first = mix_first_applies(p, p->fast, nl, false, false);
             uint64_t src_off = 0;
-            bool reuse = sum_first && p->st_tab_version == p->srcs_version && p->st_tab_ptrs.size() == n_sources && !rh::knob(rh::K_STREAM_UPLOAD_ALWAYS);
-            uint32_t lead = 0;  // the first source that is still there
-            while (gone && lead + 1 < n_sources && (*gone)[lead]) ++lead;
-            auto row_of = [&](uint32_t s) { return gone && (*gone)[s] ? srcs_host[lead] : srcs_host[s]; };
+            bool reuse = sum_first && p->st_tab_version == p->srcs_version && p->st_tab_ptrs.size() == nl && !rh::knob(rh::K_STREAM_UPLOAD_ALWAYS);
+            auto row_of = [&](uint32_t k) { return srcs_host[live[k]]; };
             if (reuse) {
                 src_off = (uint64_t)(reinterpret_cast<uintptr_t>(row_of(0)) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[0]));
-                for (uint32_t s = 0; s < n_sources && reuse; ++s)
-                    reuse = row_of(s) && !(reinterpret_cast<uintptr_t>(row_of(s)) & 15u) &&
-                            (uint64_t)(reinterpret_cast<uintptr_t>(row_of(s)) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[s])) == src_off;
+                for (uint32_t k = 0; k < nl && reuse; ++k)
+                    reuse = row_of(k) && !(reinterpret_cast<uintptr_t>(row_of(k)) & 15u) &&
+                            (uint64_t)(reinterpret_cast<uintptr_t>(row_of(k)) - reinterpret_cast<uintptr_t>(p->st_tab_ptrs[k])) == src_off;
             }
             if (!reuse) {
                 src_off = 0;
-                h.resize(n_sources);
-                p->st_tab_ptrs.resize(n_sources);
-                for (uint32_t s = 0; s < n_sources; ++s) {
-                    const float *row = row_of(s);
+                h.resize(nl);
+                p->st_tab_ptrs.resize(nl);
+                for (uint32_t k = 0; k < nl; ++k) {
+                    const float *row = row_of(k);
                     if (!row || (reinterpret_cast<uintptr_t>(row) & 15u)) return RH_ERR_INVALID;
-                    const bool is_gone = gone && (*gone)[s];
-                    h[s] = SrcDesc{row, (uint32_t)avail_frames, (uint32_t)out, is_gone ? 0.0f : (s < p->gains.size() ? p->gains[s] : 1.0f), {0, 0, 0}};
-                    p->st_tab_ptrs[s] = row;
+                    const uint32_t s = live[k];
+                    h[k] = SrcDesc{row, (uint32_t)avail_frames, (uint32_t)out, s < p->gains.size() ? p->gains[s] : 1.0f, {0, 0, 0}};
+                    p->st_tab_ptrs[k] = row;
                 }
-                const rh_status up = upload_descriptors(p, n_sources, rh::as_stream(stream));
+                const rh_status up = upload_descriptors(p, nl, rh::as_stream(stream));
                 if (up != RH_OK) return up;
                 p->st_tab_version = p->srcs_version;
             }
             p->equal = true;
             p->eq_frames = (uint32_t)avail_frames;
-            p->n_sources = n_sources;
+            p->n_sources = nl;
             p->out_frames = out;
             p->chunk.ok = false;  // (the tile tables of k_rlm_chunk belong to a one-shot batch)
             // ONE launch per block where the block is k_rlm_sblk's (rh_pipeline_sblk.hip): the sum, the conversion and the filter in one kernel
@@ -189,7 +195,7 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
                 sb.win = p->d_w[p->st_cur];
                 sb.wout = p->d_w[p->st_cur ^ 1];
                 sb.src_off = src_off;
-                const rh_status sk = sblk_try(p, n_sources, avail_frames, out, dst, sb, rh::as_stream(stream), &taken);
+                const rh_status sk = sblk_try(p, nl, avail_frames, out, dst, sb, rh::as_stream(stream), &taken);
                 if (sk != RH_OK) return sk;
             }
             if (taken) {
@@ -209,7 +215,7 @@ static rh_status stream_block_summed(rh_rlm *p, const float *const *srcs_host, u
                 sa.win = p->d_w[p->st_cur];
                 sa.wout = p->d_w[p->st_cur ^ 1];
                 sa.src_off = src_off;
-                st = rlm_launch(p, 0, n_sources, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
+                st = rlm_launch(p, 0, nl, dst, out_capacity_frames, nullptr, stream, 0, 0, sa);
                 if (st != RH_OK) return st;
             }
             p->st_n_summed += 1;

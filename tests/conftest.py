@@ -18,14 +18,17 @@ def pytest_sessionstart(session):
     own "run python rodio_amd/build.py"."""
     need = [os.path.join(ROOT, "rodio_amd", "librodio_hip.so"), os.path.join(ROOT, "oracle", "librodio_oracle.so"),
             os.path.join(ROOT, "tests", "cpp", "host_mirror_test"), os.path.join(ROOT, "tests", "cpp", "host_mirror_test_fake")]
-    if all(os.path.exists(p) for p in need) or os.path.exists("/dev/kfd"):  # (the GPU box gets the prebuilt files with the snapshot)
+    if all(os.path.exists(p) for p in need):
         return
     import subprocess
 
+    # (ADVICE r5: a failed build used to surface as hundreds of "run python rodio_amd/build.py" failures with the compiler's output thrown away)
     try:
-        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, timeout=3000, check=False, capture_output=True)
-    except Exception:
-        pass
+        r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, timeout=3000, check=False, capture_output=True, text=True)
+    except Exception as e:  # noqa: BLE001
+        pytest.exit(f"building the library / oracle / test drivers failed: {e}", returncode=3)
+    if r.returncode != 0:
+        pytest.exit("building the library / oracle / test drivers failed (python -c 'import __graft_entry__ as g; g.build()'):\n" + (r.stderr or r.stdout)[-4000:], returncode=3)
 
 
 @pytest.fixture(scope="session")
