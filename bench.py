@@ -977,10 +977,9 @@ def side(args, argv, lite=False):
         # latency chain of a few dozen tiles, profiles/r05_stream_frames_per_lane.txt; a block emits whole 16-byte vectors whatever the run length)
         pipe = rh.ResampleLowpassMix(44100, 48000, 2, None, "low_pass", args.freq, 0.5, max_sources=S, max_in_frames=B + 4096, frames_per_lane=args.frames_per_lane or 0)
         pipe.set_exclusive(True)
-        # --overlap: rh_rlm_stream_overlap (the rows are resident and complete before the first call: the promise it asks for) -- consecutive blocks side
-        # by side on two streams of the handle's, every block from a zero filter state with the true state added by a small kernel behind it.
-        # Measured SLOWER than one block after the other (profiles/r06_stream_overlap.txt: seven stream / event calls a block make the host the
-        # bound), so the default is the plain form: ONE launch per block on the caller's stream.
+        # --overlap: rh_rlm_stream_overlap (the rows are resident and complete before the first call: the promise it asks for) -- a block is launched
+        # on the same stream WITHOUT a barrier behind the block in front (hipExtAnyOrderLaunch) and waits for the filter state inside the kernel.
+        # Bit-identical, +1-3 % (profiles/r06_bench_stream_*_overlap.json); opt-in because of the promise: the default is one block after the other.
         _lib.check(lib.rh_rlm_stream_overlap(pipe._h, 1 if args.overlap else 0), "rh_rlm_stream_overlap")
         mo = C.c_uint64(0)
         _lib.check(lib.rh_resample_out_frames(N, 44100, 48000, 2, 0, C.byref(mo)), "rh_resample_out_frames")
@@ -1114,7 +1113,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per source")
     ap.add_argument("--span", type=int, default=0, help="current_span_len of the sources (0 = None)")
     ap.add_argument("--block", type=int, default=65536, help="--config stream: input frames per block")
-    ap.add_argument("--overlap", action="store_true", help="--config stream: rh_rlm_stream_overlap (consecutive blocks side by side; measured slower: host-bound)")
+    ap.add_argument("--overlap", action="store_true", help="--config stream: rh_rlm_stream_overlap (a block launched without a barrier behind the block in front; +1-3 %%)")
     ap.add_argument("--short-source", type=float, default=0.0, help="--config stream: source 0 ends after this fraction of the frames (timing only)")
     ap.add_argument("--freq", type=int, default=200)
     ap.add_argument("--frames-per-lane", type=int, default=0)

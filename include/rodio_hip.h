@@ -471,15 +471,19 @@ rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs_host, const 
 rh_status rh_rlm_stream_keep_history(rh_rlm *p, int32_t on);
 /* Blocks side by side.  A block of a stream on the summed state is ONE launch where the library can make it one (k_rlm_sblk: the sum over
  * the sources, the conversion and the filter in one kernel), and a short kernel spends a third of its life filling and draining the chip.
- * on != 0 = "the rows I pass to a block call are COMPLETE in device memory when I make the call" (decoded assets resident in HBM; a caller
- * that has synchronised its producer) -- the library then need not order a block's reads behind the caller's stream, and runs consecutive
- * blocks on two streams of its own: a block starts while the one in front still runs -- from a zero filter state; what the stream's true
- * state at its first frame adds (a few hundred frames: the filter forgets) follows in a small kernel ordered behind both by events.  Nothing changes for the output: a block's dst is complete in the order of the stream passed to its call.  Without the promise
- * (the default: rows that a copy on the caller's stream is still filling) every block runs on the caller's stream.  rh_rlm_set_exclusive(0)
- * switches it off (two blocks' workgroups must fit the chip together). */
+ * on != 0 = "the rows I pass to a block call are COMPLETE in device memory when I make the call, and nothing I queued on `stream` since the
+ * block in front is something this block has to wait for" (decoded assets resident in HBM; a caller that has synchronised its producer).
+ * The library then launches a block WITHOUT a barrier behind the block in front, on the same stream (hipExtAnyOrderLaunch): its workgroups
+ * start on every XCD that has finished the block in front while the others still work on it, and the few tiles the stream's filter state
+ * still reaches wait for it inside the kernel (tagged words, left by the last tile of the block in front).  Nothing changes for the output:
+ * a block's dst is complete in the order of the stream for every later launch that carries a barrier -- every launch but these.  Off (the
+ * default: rows that a copy on the caller's stream is still filling) every block starts behind everything in front of it.
+ * rh_rlm_set_exclusive(0) switches it off (the blocks' workgroups must fit the chip at once). */
 rh_status rh_rlm_stream_overlap(rh_rlm *p, int32_t on);
 /* Diagnostics: blocks of the current stream that ran as one launch. */
 rh_status rh_rlm_stream_one_launch_blocks(rh_rlm *p, uint32_t *blocks);
+/* Diagnostics: ... and how many of those started while the block in front still ran (rh_rlm_stream_overlap). */
+rh_status rh_rlm_stream_overlapped_blocks(rh_rlm *p, uint32_t *blocks);
 /* Diagnostics: blocks of the current stream that ran on the summed state / on one state per source, and recoveries in between. */
 rh_status rh_rlm_stream_stats(rh_rlm *p, uint32_t *summed_blocks, uint32_t *per_source_blocks, uint32_t *recoveries);
 /* No mixer: every source is converted and filtered into its own row, dst + s*dst_stride_frames*channels
@@ -513,7 +517,8 @@ typedef struct rh_rlm_geometry_info {
     uint32_t ragged_pair;      /* 1: one-shot runs of this batch take k_rlm_fast<RAG> (stable sources summed first, the pairs of ending sources behind them) instead of the ragged-batch kernel */
     uint32_t mix_first;        /* one-shot runs of this batch (filtered, equal lengths) sum the sources at the input rate first and convert + filter
                                 * that one stream: 1 = two launches (k_mix_ring or k_mix_rows, then the fused kernel on one source),
-                                * 2 = one (k_rlm_chunk: long stereo rows) */
+                                * 2 = one (k_rlm_chunk: long stereo rows); 3 = a handle with a filter per source (rh_rlm_set_filters) whose classes all take
+                                * k_rlm_chunk and whose LAST run walked them in one launch (k_rlm_chunk_multi), the classes' mixes added behind it */
 } rh_rlm_geometry_info;
 rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info);
 

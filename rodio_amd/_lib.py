@@ -169,6 +169,7 @@ SIGNATURES = {
     "rh_rlm_stream_keep_history": (i32, [vp, i32]),
     "rh_rlm_stream_overlap": (i32, [vp, i32]),
     "rh_rlm_stream_one_launch_blocks": (i32, [vp, C.POINTER(u32)]),
+    "rh_rlm_stream_overlapped_blocks": (i32, [vp, C.POINTER(u32)]),
     "rh_rlm_stream_stats": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
     "rh_rlm_set_exclusive": (i32, [vp, i32]),
     "rh_rlm_set_mix_first": (i32, [vp, i32]),

@@ -227,66 +227,92 @@ __device__ __forceinline__ uint32_t poll_window(const float *gran_stream, int64_
     }
 }
 
-// The poll point of a tile (see limit_tile): the first window of the peak look-back of THIS tile and the first window of the
-// integrator look-back of the workgroup's NEXT tile, fetched together -- one round trip to L2 instead of one per look-back.
+// The look-ahead poll of a tile (see limit_tile; more streams than workgroups): the first windows of BOTH look-backs of the workgroup's
+// NEXT tile -- its predecessors hold older tickets and their zero-state aggregates depend on nothing this workgroup still owes --
+// requested behind this tile's last publish and collected behind its output pass: one round trip to L2 for both, and no tile waits
+// for it (the pass hides it).  issue() puts the loads on the wire; complete() is the poll loop entered with its first loads in flight.
 template <int C>
 struct PollPair {
+    typedef Rec<C> RC;
     float Z[C], E[C], AB[2 * C], Ij[C];
     uint32_t jstarP, jstarI;
+    float gz[C], ga[2 * C];  // in flight between issue() and complete(): nothing may read them before complete()'s wait
+    bool haveP, haveI;
+    // (the addresses are worked out again where a poll has to be repeated: kept across the tile they cost the widest instance its last registers)
+    static __device__ __forceinline__ void where(const float *gs, int64_t base, uint32_t reachP, uint32_t reachI, int lane, const float *&pP, const float *&pI, bool &realP, bool &realI) {
+        constexpr uint32_t G = RC::stride;
+        const int64_t idx = base - lane;
+        realP = idx >= 0 && (uint32_t)lane < reachP, realI = idx >= 0 && (uint32_t)lane < reachI;
+        pP = gs + (realP ? (uint64_t)idx : 0) * G + RC::oZ, pI = gs + (realI ? (uint64_t)idx : 0) * G + RC::oA;
+    }
+    __device__ __forceinline__ void issue(const float *gs, int64_t base, uint32_t reachP, uint32_t reachI, int lane) {
+        const float *pP, *pI;
+        bool realP, realI;
+        where(gs, base, reachP, reachI, lane, pP, pI, realP, realI);
+        if (realP) load_words<C, RC::wS>(pP, gz);
+        if (realI) load_words<2 * C, RC::wA>(pI, ga);
+    }
+    // YOUNGER: vector-memory instructions this wave has certainly issued behind issue() (the LDS-DMA of the next tile's samples, or 0).
+    // vmcnt retires in order: waiting for "at most YOUNGER outstanding" collects the poll and leaves those fetches in flight.
+    template <int YOUNGER>
+    __device__ __forceinline__ bool complete(const bool younger_there, const float *gs, int64_t base, uint32_t reachP, uint32_t reachI, const float *init, int lane,
+                                             const uint32_t spin_limit) {  // false: a hand-off never arrived
+        // (everything but the words in flight is worked out here, not kept across the tile: the widest instance has no registers to spare)
+        const float *pP, *pI;
+        bool realP, realI;
+        where(gs, base, reachP, reachI, lane, pP, pI, realP, realI);
+        const int64_t idx = base - lane;
+        haveP = !realP, haveI = !realI;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            Z[c] = 0.0f, AB[c] = AB[C + c] = 0.0f;
+            E[c] = (idx == -1 && init) ? init[2 * c + 1] : 0.0f;
+            Ij[c] = (idx == -1 && init) ? init[2 * c] : 0.0f;
+        }
+        const unsigned long long virtP = __ballot(!realP), virtI = __ballot(!realI);
+        jstarP = virtP ? (uint32_t)__builtin_ctzll(virtP) : 64u;
+        jstarI = virtI ? (uint32_t)__builtin_ctzll(virtI) : 64u;
+        uint32_t spins = 0;
+        bool first = true;
+        while (true) {
+            if (!first) {
+                if (!haveP) load_words<C, RC::wS>(pP, gz);
+                if (!haveI) load_words<2 * C, RC::wA>(pI, ga);
+            }
+            if (first && younger_there) {
+                wait_loads_behind<YOUNGER>(gz);  // (both are waited for whether or not this lane fetched: the registers are only read if it did)
+                wait_loads_behind<YOUNGER>(ga);
+            } else {
+                wait_loads(gz);
+                wait_loads(ga);
+            }
+            first = false;
+            if (!haveP) {
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < C; ++c) ok = ok && word_ok(gz[c]);
+                if (ok) {
+                    haveP = true;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) Z[c] = gz[c];
+                }
+            }
+            if (!haveI) {
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 2 * C; ++c) ok = ok && word_ok(ga[c]);
+                if (ok) {
+                    haveI = true;
+#pragma unroll
+                    for (int c = 0; c < 2 * C; ++c) AB[c] = ga[c];
+                }
+            }
+            if (__all((haveP || (uint32_t)lane > jstarP) && (haveI || (uint32_t)lane > jstarI))) return true;
+            if (++spins > spin_limit) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
 };
-template <int C>
-__device__ __forceinline__ void poll_pair(const float *gsP, int64_t baseP, uint32_t reachP, const float *initP, const float *gsI, int64_t baseI, uint32_t reachI,
-                                          const float *initI, bool wantI, int lane, PollPair<C> &o, bool &dead, const uint32_t spin_limit) {
-    typedef Rec<C> RC;
-    constexpr uint32_t G = RC::stride;
-    const int64_t idxP = baseP - lane, idxI = baseI - lane;
-    const bool realP = idxP >= 0 && (uint32_t)lane < reachP, realI = wantI && idxI >= 0 && (uint32_t)lane < reachI;
-    const float *pP = gsP + (realP ? (uint64_t)idxP : 0) * G + RC::oZ, *pI = gsI + (realI ? (uint64_t)idxI : 0) * G + RC::oA;
-    bool haveP = !realP, haveI = !realI;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        o.Z[c] = 0.0f, o.AB[c] = o.AB[C + c] = 0.0f;
-        o.E[c] = (idxP == -1 && initP) ? initP[2 * c] : 0.0f;
-        o.Ij[c] = (idxI == -1 && initI) ? initI[2 * c] : 0.0f;
-    }
-    const unsigned long long virtP = __ballot(!realP), virtI = __ballot(!realI);
-    o.jstarP = virtP ? (uint32_t)__builtin_ctzll(virtP) : 64u;
-    o.jstarI = virtI ? (uint32_t)__builtin_ctzll(virtI) : 64u;
-    uint32_t spins = 0;
-    while (true) {
-        float gz[C], ga[2 * C];
-        if (!haveP) load_words<C, RC::wS>(pP, gz);
-        if (!haveI) load_words<2 * C, RC::wA>(pI, ga);
-        if (!haveP) wait_loads(gz);
-        if (!haveI) wait_loads(ga);
-        if (!haveP) {
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < C; ++c) ok = ok && word_ok(gz[c]);
-            if (ok) {
-                haveP = true;
-#pragma unroll
-                for (int c = 0; c < C; ++c) o.Z[c] = gz[c];
-            }
-        }
-        if (!haveI) {
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < 2 * C; ++c) ok = ok && word_ok(ga[c]);
-            if (ok) {
-                haveI = true;
-#pragma unroll
-                for (int c = 0; c < 2 * C; ++c) o.AB[c] = ga[c];
-            }
-        }
-        if (__all((haveP || (uint32_t)lane > o.jstarP) && (haveI || (uint32_t)lane > o.jstarI))) return;
-        if (++spins > spin_limit) {
-            dead = true;
-            return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
 
 // (two channels per instruction: f2, Pk<C>, splat / vfma / vmax / comp / pair_of / vdpp / vsel -- rh_scan_common.h)
 // limit.rs:853-873 for one sample or a pair (see gain_computer above: the same expression, with the lower knee branch
@@ -379,10 +405,15 @@ __device__ __forceinline__ void store_share(float *dst, const v4f *lds, const ui
 // The kernel's argument block, read where it lies: in the constant address space (the kernarg segment; it is the kernel's only argument, so it
 // sits at offset 0 of __builtin_amdgcn_kernarg_segment_ptr()).  See limit_tile for why the kernels do not read their by-value parameter.
 typedef const __attribute__((address_space(4))) LimitArgs *ArgsC;
+#if defined(RH_LIMIT_NO_ARITH) && RH_LIMIT_NO_ARITH
+#define RH_LIMIT_NO_ARITH_ 1
+#else
+#define RH_LIMIT_NO_ARITH_ 0
+#endif
 
 template <int C, int R, int NW, bool FULL, bool SKEW, int NIO = 0>
 __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 * C], float (*xP)[C], const int lane_, const int wave, const uint32_t tile, const uint32_t stream,
-                                           const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
+                                           const float (*tab)[64], const uint32_t nf, float (&Icarry)[C], float (&Pcarry)[C], bool &have_I, const bool has_next, const uint32_t ntile,
                                            const uint32_t nstream, const float *next_src, v4f *next_buf, const uint32_t ticket_ahead, uint32_t *ticket_slot RH_LP_PARAM) {
     // The lane id is made opaque per tile: everything derived from it (LDS slots, global offsets) is then recomputed here, a
     // few VALU operations, instead of being hoisted out of the persistent loop into registers that stay occupied for the
@@ -428,6 +459,20 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
     // is as far ahead of the polls as a fetch can be (a.dma_top = 0, the round-2 first version, put it behind the integrator
     // look-back: that poll was then free, but the peak poll paid the whole fetch latency).
     const bool had_I = SKEW && have_I;
+#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK
+    constexpr bool kLookback = false;
+#else
+    constexpr bool kLookback = true;
+#endif
+    // ---- the look-ahead poll (SKEW: more streams than workgroups): the first windows of both look-backs of the workgroup's NEXT tile leave
+    //      here, in front of every other fetch of this tile, and are collected behind its output pass.  Ticket order: that tile's
+    //      predecessors hold tickets a whole round of the streams older -- they published long ago, as a rule -- and what they publish
+    //      depends on nothing this workgroup still owes (waits go to strictly smaller tickets: no cycle).  In FRONT of the DMA because
+    //      vmcnt retires in order: a poll behind it comes home when the 8 KiB in front of it have, and on a chip that is busy moving
+    //      samples that is a tile's time later (measured: the polls cost 0.04 ms of 0.26 wherever they stood behind the DMA) ---------
+    const bool ahead = kLookback && SKEW && has_next;
+    PollPair<C> q;
+    if (ahead) q.issue(a.gran + (uint64_t)nstream * a.tiles * G, (int64_t)ntile - 1, a.jP, a.jI, lane);
     const uint32_t dma_where = a.dma_top;  // 1: at the top of the tile; 0: behind the integrator look-back; 2: behind the poll point (no poll of this tile ever waits for it)
     const bool dma_first = dma_where == 1 || (had_I && dma_where != 2);
     if (NIO == 0 && dma_first && next_src) dma_share<V>(next_src, next_buf, lane);
@@ -450,13 +495,17 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
 #pragma unroll
         for (int i = 0; i < 4; i += W) {
             const int r = (4 * j + i) / C, p = ((4 * j + i) % C) / W;
+#if defined(RH_LIMIT_NO_ARITH) && RH_LIMIT_NO_ARITH  // timing experiment only (wrong results): the tile's skeleton without its per-sample arithmetic
+            T gv = pair_of(e + i, T());
+#else
             T gv = gain_computer_v<T>(pair_of(e + i, T()), gk);
+#endif
             if (!FULL) gv = vsel((uint32_t)r < nfl, gv, splat<T>(0.0f));
             g[r][p] = gv;
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < (RH_LIMIT_NO_ARITH_ ? 1 : R); ++r)
 #pragma unroll
         for (int p = 0; p < N; ++p) {
             const T bn = omrT * g[r][p];
@@ -552,7 +601,7 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
     RH_ARGS_FRESH();
     // ---- true integrator per sample, zero-state attack run (g becomes the zero-state peak) ----------------------------------
     T I[N], Pz[N];
-    const float rwave = a.rwave[wave];
+    const float rwave = a.rwave[__builtin_amdgcn_readfirstlane(wave)];
     const float a15 = tab[3][lane], a31 = tab[4][lane];
 #pragma unroll
     for (int p = 0; p < N; ++p) {
@@ -561,7 +610,7 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
         Pz[p] = splat<T>(0.0f);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < (RH_LIMIT_NO_ARITH_ ? 1 : R); ++r)
 #pragma unroll
         for (int p = 0; p < N; ++p) {
             // limit.rs:909-913 (P from a zero state), each recurrence step as one multiply and one FMA -- the product r*I (a*P) is not rounded on
@@ -611,67 +660,35 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
         for (int c = 0; c < C; ++c) v = lane == c ? comp(PT[c / W], c % W) : v;
         word_store(rec + RC::oZ + lane, v);
     }
-    // ---- the poll point: look-back for the peak of this tile, P_in = sum_{j<j*} a^(LW*j) Pz_{t-1-j} + a^(LW*j*) Pend_j*, and the
-    //      integrator look-back of the workgroup's next tile (ticket order: its predecessors run or are done, and their
-    //      zero-state aggregates depend on nothing) -- both first windows in one round trip ----------------------------------
+    // ---- look-back for the peak of this tile, P_in = sum_{j<j*} a^(LW*j) Pz_{t-1-j} + a^(LW*j*) Pend_j*.  More streams than workgroups
+    //      (SKEW): it was walked a tile ago, with the integrator's, by the look-ahead poll below; a workgroup's first tile and the
+    //      other shapes walk it here ------------------------------------------------------------------------------------------------
     float Pin[C];
-    {
-        float Co = 1.0f;
+    auto fold_P = [&](float (&Po)[C], float &Co, const float (&Zj)[C], const float (&Ej)[C], uint32_t jstar) {
+        const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
 #pragma unroll
-        for (int c = 0; c < C; ++c) Pin[c] = 0.0f;
-        auto fold_P = [&](const float (&Zj)[C], const float (&Ej)[C], uint32_t jstar) {
-            const bool front = (uint32_t)lane < jstar, star = (uint32_t)lane == jstar;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float tot;
-                (void)wave_excl_sum(front ? wP * Zj[c] : (star ? wP * Ej[c] : 0.0f), tot);
-                Pin[c] = fma_(Co, tot, Pin[c]);
-            }
-            if (jstar < 64) return true;
-            Co *= a.aL64;
-            return Co < kNegligible;
-        };
-        const float *const gnext = a.gran + (uint64_t)nstream * a.tiles * G;
-        const float *const ninit = a.state_in ? a.state_in + (uint64_t)nstream * C * 2 : nullptr;
-        float Ao[C], Bo[C], CoI = 1.0f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = 0.0f;
-        bool doneP = dead, doneI = dead || !SKEW || !has_next;
-#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK
-        doneP = doneI = true;
-        dead = true;  // (skips the poll pair below; un-poisoned again right after)
-#endif
-        int64_t baseP = (int64_t)tile - 1, baseI = (int64_t)ntile - 1;
-        if (SKEW && !dead) {
-            PollPair<C> q;
-            poll_pair<C>(gstream, baseP, a.jP, init ? init + 1 : nullptr, gnext, baseI, a.jI, ninit, has_next, lane, q, dead, a.spin);
-            if (!dead) {
-                doneP = fold_P(q.Z, q.E, q.jstarP);
-                if (has_next) doneI = fold_I(Ao, Bo, CoI, q.AB, q.Ij, q.jstarI);
-                baseP -= 64, baseI -= 64;
-            }
+        for (int c = 0; c < C; ++c) {
+            float tot;
+            (void)wave_excl_sum(front ? wP * Zj[c] : (star ? wP * Ej[c] : 0.0f), tot);
+            Po[c] = fma_(Co, tot, Po[c]);
         }
-        while (!doneP && !dead) {  // (further windows: coefficients that do not forget within 64 tiles)
+        if (jstar < 64) return true;
+        Co *= a.aL64;
+        return Co < kNegligible;
+    };
+#pragma unroll
+    for (int c = 0; c < C; ++c) Pin[c] = had_I ? Pcarry[c] : 0.0f;
+    if (kLookback && !had_I && !dead) {
+        float Co = 1.0f;
+        int64_t baseP = (int64_t)tile - 1;
+        while (true) {
             float Zj[C], Ej[C];
             const uint32_t jstar = poll_window<C, C, RC::wS>(gstream, baseP, lane, a.jP, G, RC::oZ, init ? init + 1 : nullptr, Zj, Ej, dead, a.spin);
             if (dead) break;
-            doneP = fold_P(Zj, Ej, jstar);
+            if (fold_P(Pin, Co, Zj, Ej, jstar)) break;
             baseP -= 64;
         }
-        while (!doneI && !dead) {
-            float AB[2 * C], Ij[C];
-            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gnext, baseI, lane, a.jI, G, RC::oA, ninit, AB, Ij, dead, a.spin);
-            if (dead) break;
-            doneI = fold_I(Ao, Bo, CoI, AB, Ij, jstar);
-            baseI -= 64;
-        }
-        have_I = SKEW && has_next && !dead;
-#pragma unroll
-        for (int c = 0; c < C; ++c) Icarry[c] = Ao[c];
     }
-#if defined(RH_LIMIT_NO_LOOKBACK) && RH_LIMIT_NO_LOOKBACK
-    dead = false;
-#endif
     if (dead) {  // a hand-off never arrived: fail the call (status word) and poison the tile
         if (lane == 0) atomicOr(a.status, 1u);
 #pragma unroll
@@ -683,7 +700,7 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
     // ---- per-sample peak, gain coupled over the channels (limit.rs:946-960, :983-986); the result goes back to the LDS row ----
     T Ps[N];
     float Pcur[C];
-    const float awave = a.awave[wave];
+    const float awave = a.awave[__builtin_amdgcn_readfirstlane(wave)];  // (a scalar load: a vector one would wait behind the look-ahead poll)
 #pragma unroll
     for (int p = 0; p < N; ++p) {
         const T Pw = vfma(splat<T>(awave), pair_of(Pin + p * W, T()), Pp[p]);  // this wave's start state
@@ -702,6 +719,14 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
         for (int i = 0; i < 4; i += W) {
             const int r = (4 * j + i) / C, c0 = (4 * j + i) % C, p = c0 / W;
             if (c0 == 0) ap *= att;  // a^(r+1)
+#if defined(RH_LIMIT_NO_ARITH) && RH_LIMIT_NO_ARITH
+            if (r != 0) {
+                const T out = pair_of(e + i, T()) * Ps[p];
+#pragma unroll
+                for (int w = 0; w < W; ++w) e[i + w] = comp(out, w);
+                continue;
+            }
+#endif
             const T Pnew = vfma(splat<T>(ap), Ps[p], g[r][p]);
             // the reference advances one sample at a time: the gain of channel c sees this frame's peaks of the channels up to
             // c and the previous frame's of the others
@@ -741,6 +766,39 @@ __device__ __forceinline__ void limit_tile(ArgsC kargs, v4f *lds, float (*xI)[2 
         }
     }
     RH_LP(5)
+    // ---- the look-ahead poll comes home (it had the whole output pass to do so); further windows -- coefficients that do not forget
+    //      within 64 tiles -- are walked here.  A hand-off that never arrives is left to the next tile, which then walks in place
+    //      and fails the call ---------------------------------------------------------------------------------------------------------
+    have_I = false;
+    RH_ARGS_FRESH();
+    const float *const gnext = a.gran + (uint64_t)nstream * a.tiles * G;
+    const float *const ninit = a.state_in ? a.state_in + (uint64_t)nstream * C * 2 : nullptr;
+    if (ahead && q.template complete<V>(NIO == 0 && next_src != nullptr, gnext, (int64_t)ntile - 1, a.jP, a.jI, ninit, lane, a.spin) && !dead) {
+        float Ao[C], Bo[C], Pn[C], CoI = 1.0f, CoP = 1.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) Ao[c] = Bo[c] = Pn[c] = 0.0f;
+        bool doneP = fold_P(Pn, CoP, q.Z, q.E, q.jstarP), doneI = fold_I(Ao, Bo, CoI, q.AB, q.Ij, q.jstarI), lost = false;
+        int64_t baseP = (int64_t)ntile - 1 - 64, baseI = baseP;
+        while (!doneP && !lost) {
+            float Zj[C], Ej[C];
+            const uint32_t jstar = poll_window<C, C, RC::wS>(gnext, baseP, lane, a.jP, G, RC::oZ, ninit ? ninit + 1 : nullptr, Zj, Ej, lost, a.spin);
+            if (lost) break;
+            doneP = fold_P(Pn, CoP, Zj, Ej, jstar);
+            baseP -= 64;
+        }
+        while (!doneI && !lost) {
+            float AB[2 * C], Ij[C];
+            const uint32_t jstar = poll_window<C, 2 * C, RC::wA>(gnext, baseI, lane, a.jI, G, RC::oA, ninit, AB, Ij, lost, a.spin);
+            if (lost) break;
+            doneI = fold_I(Ao, Bo, CoI, AB, Ij, jstar);
+            baseI -= 64;
+        }
+        if (!lost) {
+            have_I = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) Icarry[c] = Ao[c], Pcarry[c] = Pn[c];
+        }
+    }
     // ---- LDS rows -> coalesced store -----------------------------------------------------------------------------------
     __builtin_amdgcn_wave_barrier();
     if (NIO == 0) {
@@ -822,9 +880,9 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
     uint32_t cur = s_ticket[0], nxt = s_ticket[1];
     uint32_t n = 0;
     bool prev_full = false, have_I = false;
-    float Icarry[C];
+    float Icarry[C], Pcarry[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) Icarry[c] = 0.0f;
+    for (int c = 0; c < C; ++c) Icarry[c] = Pcarry[c] = 0.0f;
     if constexpr (NIO > 0) {
         constexpr int PER = NW / NIO;  // shares per I/O wave
         const bool io = wave >= NW;
@@ -878,8 +936,8 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
                 const bool has_next = SKEW && nxt < total && nxt - cur < a.n_streams;
                 const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
                 __syncthreads();  // B0
-                if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
-                else limit_tile<C, R, NW, false, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+                if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, Pcarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
+                else limit_tile<C, R, NW, false, SKEW, NIO>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, Pcarry, have_I, has_next, ntile, nstream, nullptr, nullptr, ticket_ahead, ticket_slot RH_LP_ARG);
             }
             prev = cur;
             cur = nxt;
@@ -923,8 +981,8 @@ __global__ __launch_bounds__(64 * (NW + NIO), (NW + NIO >= 4 ? (C * R <= 16 && C
         const uint32_t ntile = has_next ? nxt / a.n_streams : 0u, nstream = has_next ? nxt - ntile * a.n_streams : 0u;
         v4f *const buf2 = bufs[wave][(n + 1) & 1];
         // FULL is the TILE's property, the same for every wave of the workgroup: all of them run one instantiation, barriers included
-        if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
-        else limit_tile<C, R, NW, false, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        if (tile_full(cur)) limit_tile<C, R, NW, true, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, Pcarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
+        else limit_tile<C, R, NW, false, SKEW>(kargs, bufs[wave][n & 1], xI, xP, lane, wave, tile, stream, tab, nf, Icarry, Pcarry, have_I, has_next, ntile, nstream, src2, buf2, ticket_ahead, ticket_slot RH_LP_ARG);
         prev_full = nf == L;
         cur = nxt;
         nxt = s_ticket[(n + 2) % 3];  // written before barrier (2) of the tile just done

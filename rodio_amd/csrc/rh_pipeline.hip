@@ -1461,6 +1461,17 @@ struct ChunkArgs {
     const float *powM;         // [R + 1][4]: B^v
     const float *uni;          // the plan's Uniforms as an array of floats in device memory (Params::u holds the same values)
 };
+constexpr uint32_t kChunkMultiMax = 7;  // classes in one launch (k_rlm_chunk_multi): what fits the 4 KiB kernarg segment
+struct ChunkMulti {
+    struct Entry {
+        Params p;
+        ChunkArgs q;
+    };
+    uint32_t n;                          // classes in this launch
+    uint32_t first[kChunkMultiMax + 1];  // first workgroup of every class (multiples of 8: a workgroup's XCD is its class-relative index's too); [n] = the grid
+    Entry e[kChunkMultiMax];
+};
+static_assert(sizeof(ChunkMulti) <= 4096, "the kernarg segment");
 #if defined(RH_CHUNK_DIAG) && RH_CHUNK_DIAG == 3  // diagnostics builds: shader cycles per phase behind the source loop, summed over the tiles into ctl[8..15]
 #define RH_CPH(i) { const unsigned long long cph_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(p.ticket + 8 + (i), (uint32_t)(cph_now - cph_last)); cph_last = cph_now; }
 #define RH_CPH_DECL unsigned long long cph_last = __builtin_readcyclecounter();
@@ -1470,7 +1481,7 @@ struct ChunkArgs {
 #endif
 // C: channels of a frame; KV: KiB of a chunk (8 for stereo: 1024 frames; 4 for mono: 1024 frames too -- the tile stays at 64 runs of 18).
 template <int R, int C, int KV>
-__global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const ChunkArgs q) {
+__device__ __forceinline__ void rlm_chunk_tile(const Params &p, const ChunkArgs &q, const uint32_t block) {
     typedef Chan<C> CH;
     typedef typename CH::V V;
     constexpr int NS = 2, H = 4;
@@ -1488,7 +1499,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
     const int lane = threadIdx.x;
     // Every tile resident at once (the host knows): tile = workgroup.  More tiles than slots: tiles are handed out by a ticket, so
     // that a tile only ever waits for tiles that already run or have finished (its waits go to earlier tiles only).
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = block;
     if (!p.direct) {
         // One device-scope counter hands out ~85 tickets per microsecond: 12 us for the 1024 tiles of the benchmark batch, 4 % of
         // the launch.  So the tickets come from EIGHT counters on separate cache lines, one per XCD: workgroup b takes ticket k of
@@ -1497,7 +1508,7 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         // for tiles that hold a slot or are done: the lowest unfinished tile of a counter is held by a workgroup that runs, or all
         // earlier workgroups of that XCD have finished and the next one starts.  (The grid is rounded up to whole rounds of eight, so
         // that every counter advances by the same amount per launch: workgroups past the last tile leave.)
-        const uint32_t x = blockIdx.x & 7u;
+        const uint32_t x = block & 7u;
         const uint32_t k = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(p.ticket + 32u * (1u + x), 1u) - p.shard_base : 0u);
         tile = x + 8u * k;
         if (tile >= p.n_tiles) return;
@@ -1876,6 +1887,40 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const Chunk
         }
     }
     RH_CPH(4)  // correction + stores (issue)
+}
+template <int R, int C, int KV>
+__global__ __launch_bounds__(64, 2) void k_rlm_chunk(const Params p, const ChunkArgs q) {
+    rlm_chunk_tile<R, C, KV>(p, q, blockIdx.x);
+}
+// Several batches in ONE launch (the filter classes of a mixer, rh_rlm_set_filters): workgroups first[k] .. first[k+1]-1 are class k's launch of
+// k_rlm_chunk, with that class's arguments -- its own sources, tables, hand-off words, ticket counters and output row.  Nothing crosses
+// between classes; what the one launch saves is the drain and the ramp between launches that each want the whole chip (four classes of the
+// benchmark batch: 0.368 ms as four launches).  The arguments are read where they lie, in the kernarg segment: a class index that is not a
+// constant would otherwise make the compiler copy the whole block to scratch.
+template <int R, int C, int KV>
+__global__ __launch_bounds__(64, 2) void k_rlm_chunk_multi(const ChunkMulti m) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < kChunkMultiMax; ++i) k += (i < m.n && blockIdx.x >= m.first[i]) ? 1u : 0u;
+    uint32_t b0 = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < kChunkMultiMax; ++i) b0 = (i == k) ? m.first[i] : b0;
+    k = __builtin_amdgcn_readfirstlane(k);
+    typedef const __attribute__((address_space(4))) unsigned char *cbytes;
+    cbytes e = (cbytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChunkMulti, e) + (size_t)k * sizeof(ChunkMulti::Entry);
+    Params p;
+    ChunkArgs q;
+    typedef const __attribute__((address_space(4))) uint32_t *cwords;
+    static_assert(sizeof(Params) % 4 == 0 && sizeof(ChunkArgs) % 4 == 0 && offsetof(ChunkMulti::Entry, q) % 4 == 0, "copied word by word");
+    {
+        cwords wp = (cwords)(e + offsetof(ChunkMulti::Entry, p)), wq = (cwords)(e + offsetof(ChunkMulti::Entry, q));
+        uint32_t *dp = reinterpret_cast<uint32_t *>(&p), *dq = reinterpret_cast<uint32_t *>(&q);
+#pragma unroll
+        for (uint32_t i = 0; i < sizeof(Params) / 4; ++i) dp[i] = wp[i];  // (what the tile does not read is never loaded: the copy dissolves into scalar loads)
+#pragma unroll
+        for (uint32_t i = 0; i < sizeof(ChunkArgs) / 4; ++i) dq[i] = wq[i];
+    }
+    rlm_chunk_tile<R, C, KV>(p, q, blockIdx.x - b0);
 }
 
 // =================================================================================================
@@ -2308,6 +2353,49 @@ const void *chunk_kernel(int R, uint32_t channels, int KV) {
     return nullptr;
 }
 
+static const void *chunk_multi_kernel(int R, uint32_t channels, int KV) {
+    if (channels == 2 && R == 9 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk_multi<9, 2, 4>);
+    if (channels == 2 && R == 18 && KV == 8) return reinterpret_cast<const void *>(&k_rlm_chunk_multi<18, 2, 8>);
+    if (channels == 2 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk_multi<18, 2, 4>);
+    if (channels == 1 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk_multi<18, 1, 4>);
+    if (channels == 1 && R == 18 && KV == 2) return reinterpret_cast<const void *>(&k_rlm_chunk_multi<18, 1, 2>);
+    return nullptr;
+}
+
+rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, rh_stream stream, bool *taken) {
+    *taken = false;
+    if (n < 2 || n > kChunkMultiMax || rh::knob(rh::K_CLASSES_ONE_BY_ONE)) return RH_OK;
+    const void *fn = nullptr;
+    for (uint32_t k = 0; k < n; ++k) {
+        const rh_rlm *h = classes[k];
+        if (!h || !h->cls.empty() || !h->plan || h->out_frames == 0 || row_capacity_frames < h->out_frames) return RH_OK;
+        if (!h->chunk.ok || !mix_first_applies(h, *h->plan, h->n_sources, false, false)) return RH_OK;
+        const void *f = chunk_multi_kernel(h->chunk.R, h->cfg.channels, h->chunk.KV);
+        if (!f || (fn && f != fn)) return RH_OK;
+        fn = f;
+    }
+    ChunkMulti m;
+    memset(&m, 0, sizeof m);
+    for (uint32_t k = 0; k < n; ++k) {
+        rh_rlm *h = classes[k];
+        h->collect = &m;
+        const rh_status st = rlm_launch(h, 0, h->n_sources, rows[k], row_capacity_frames, nullptr, stream, 0, 0, StreamArgs{});
+        h->collect = nullptr;
+        if (st != RH_OK) return st;
+        if (m.n != k + 1) return RH_ERR_UNSUPPORTED;  // (the class took another path after all: its launch is queued, the others' tickets are not)
+    }
+    void *args[] = {&m};
+    hipStream_t s = rh::as_stream(stream);
+    const hipError_t e = hipLaunchKernel(fn, dim3(m.first[m.n]), dim3(64), args, 0, s);
+    if (e != hipSuccess) {
+        rh::set_hip_error(e, "k_rlm_chunk_multi launch");
+        return RH_ERR_HIP;
+    }
+    for (uint32_t k = 0; k < n; ++k) mark_launch(classes[k], s);
+    *taken = true;
+    return RH_OK;
+}
+
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch) {
     hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, s, gran, tabs, n_sources, cols, last_col, J, epoch, next_epoch);
 }
@@ -2441,6 +2529,18 @@ rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint
         ca.powM = c.d_pow;
         ca.uni = c.d_uni;
         k.direct = (c.direct && p->exclusive) ? 1u : 0u;
+        if (p->collect) {  // one launch for several classes (chunk_launch_classes): this one's arguments behind the others', tiles by ticket
+            ChunkMulti &m = *static_cast<ChunkMulti *>(p->collect);
+            if (m.n >= kChunkMultiMax) return RH_ERR_UNSUPPORTED;
+            k.direct = 0;
+            const uint32_t g8 = (c.n_tiles + 7u) & ~7u;
+            m.e[m.n].p = k;
+            m.e[m.n].q = ca;
+            m.first[m.n + 1] = m.first[m.n] + g8;
+            m.n += 1;
+            p->shard_base += g8 / 8u;
+            return RH_OK;
+        }
         const uint32_t cgrid = k.direct ? c.n_tiles : (c.n_tiles + 7u) & ~7u;  // by ticket: whole rounds of the eight counters (k_rlm_chunk)
         void *cargs[] = {&k, &ca};
         const hipError_t ce = hipLaunchKernel(c.fn, dim3(cgrid), dim3(64), cargs, 0, s);

@@ -255,6 +255,8 @@ struct rh_rlm {
     float *d_mix = nullptr;     // mix first (k_mix_rows): the batch summed at the input rate, and behind it its one-entry descriptor table
     size_t mix_floats = 0;
     ChunkPlan chunk;            // mix first in one kernel (k_rlm_chunk)
+    bool cls_one_launch = false;  // per-source filters: the last run walked the classes in one launch (k_rlm_chunk_multi)
+    void *collect = nullptr;    // chunk_launch_classes: the launch being put together (rlm_launch then adds this handle's arguments to it instead of launching)
     void *sblk = nullptr;       // a stream's summed blocks in one kernel (k_rlm_sblk: rh_pipeline_sblk.hip owns the type)
     bool pre_filter = false;    // cfg.filter_first: the filter runs at from_rate in front of the converter (the fused kernels then run without one)
     float pre_coeffs[5] = {1.f, 0.f, 0.f, 0.f, 0.f};
@@ -344,6 +346,9 @@ namespace rhp {
 enum TabKind { kTabFast, kTabWave, kTabRag };
 VariantTab variant_tab(TabKind kind, bool mono);             // the instances of k_rlm_fast / k_rlm_wave / k_rlm_fast<RAG> + k_rlm_resid
 const void *chunk_kernel(int R, uint32_t channels, int KV);  // the instance of k_rlm_chunk, or nullptr
+// The classes of a mixer with per-source filters as ONE launch of k_rlm_chunk_multi (class k's mix into rows[k]): *taken = false and nothing
+// done when a class does not take the k_rlm_chunk path, the classes' instances differ, or there are more than fit one kernarg segment
+rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, rh_stream stream, bool *taken);
 // k_rlm_state on `s`: folds a block's aggregates into column 0 of the per-source rows (see rh_pipeline_stream.hip)
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch);
 // k_rlm_state_sum on `s`: the sum of the live sources' states (column 0 of their rows, tagged `tag`) -> the 4 words of a summed state
@@ -354,7 +359,8 @@ rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint
 // rh_pipeline_sblk.hip: a block of a stream on the summed state in ONE launch (k_rlm_sblk); *taken = false: not this kernel's block
 rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail_frames, uint64_t out_frames, float *dst, const StreamArgs &sa, hipStream_t s, bool *taken);
 void sblk_free(rh_rlm *p);
-void sblk_other_block(rh_rlm *p);  // a block of the stream ran elsewhere (or the stream begins)
+void sblk_other_block(rh_rlm *p, bool stream_begins = false);
+uint32_t sblk_chained_blocks(const rh_rlm *p);  // blocks of the current stream launched without a barrier behind the block in front  // a block of the stream ran elsewhere (or the stream begins)
 // rh_pipeline_plan.hip
 rh_status wait_idle(rh_rlm *p);
 rh_status pre_launch(rh_rlm *p, hipStream_t s);

@@ -779,6 +779,7 @@ static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames
     for (rh_rlm::FilterClass &c : p->cls)
         if (!c.members.empty() && c.out_frames) live.push_back(&c);
     if (live.empty()) return RH_OK;
+    p->cls_one_launch = false;
     if (live.size() == 1) return rh_rlm_run(live[0]->h, dst, out_capacity_frames, nullptr, stream);
     const size_t row = (size_t)((p->out_frames * C + 3) & ~3ull);
     if (row > p->cls_row_floats || live.size() > p->cls_rows) {
@@ -801,6 +802,31 @@ static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames
     // launches that each want the whole chip's bandwidth get in each other's way (and their tiles go by ticket then).  So: one after the other;
     // RH_CLASSES_SIDE_BY_SIDE=1 keeps the other form selectable.
     const bool side_by_side = rh::knob(rh::K_CLASSES_SIDE_BY_SIDE) != nullptr;
+    // Round 6: ONE launch that walks the classes (k_rlm_chunk_multi: class k's workgroups behind class k-1's, every class with its own arguments,
+    // tables and tickets) where every class takes the k_rlm_chunk path: what four launches lose between them -- each drains the chip and ramps
+    // up again -- stays inside one grid.  RH_CLASSES_ONE_BY_ONE=1: the launches of round 5.
+    if (!side_by_side) {
+        std::vector<rh_rlm *> hs;
+        std::vector<float *> rows;
+        for (size_t k = 0; k < live.size(); ++k) {
+            hs.push_back(live[k]->h);
+            rows.push_back(p->d_cls_rows + k * p->cls_row_floats);
+        }
+        bool taken = false;
+        const rh_status st = chunk_launch_classes(hs.data(), rows.data(), p->cls_row_floats / C, (uint32_t)hs.size(), stream, &taken);
+        if (st != RH_OK) return st;
+        p->cls_one_launch = taken;
+        if (taken) {
+            for (size_t k = 0; k < live.size(); ++k) {
+                ptrs.push_back(rows[k]);
+                start.push_back(0);
+                len.push_back(live[k]->out_frames * C);
+            }
+            const rh_status sm = rh_mix_sum(dst, p->out_frames * C, ptrs.data(), start.data(), len.data(), (uint32_t)ptrs.size(), stream);
+            if (sm != RH_OK) return sm;
+            return mark_launch(p, rh::as_stream(stream));
+        }
+    }
     if (side_by_side) {
         while (p->cls_streams.size() + 1 < live.size()) {
             hipStream_t ns = nullptr;
@@ -998,7 +1024,9 @@ rh_status rh_rlm_geometry(rh_rlm *p, rh_rlm_geometry_info *info) {
         const rh_rlm::FilterClass *best = nullptr;
         for (const rh_rlm::FilterClass &c : p->cls)
             if (!best || c.members.size() > best->members.size()) best = &c;
-        return rh_rlm_geometry(best->h, info);
+        const rh_status st = rh_rlm_geometry(best->h, info);
+        if (st == RH_OK && p->cls_one_launch) info->mix_first = 3u;
+        return st;
     }
     const Plan &pl = *p->plan;
     info->threads = 64;

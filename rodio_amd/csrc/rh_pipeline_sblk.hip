@@ -24,6 +24,7 @@
 //
 // Blocks the kernel does not take (spans that restart the converter, ratios that put more than 64 R frames into a window, more tiles than
 // fit the chip at once under rh_rlm_set_exclusive(0), a filter that forgets too slowly) run as before.  RH_NO_SBLK=1 is the A/B.
+#include <hip/hip_ext.h>
 #include "rh_pipeline_dev.h"
 
 namespace {
@@ -39,6 +40,12 @@ struct SblkArgs {
     // from frame mb = m0 - mb_off (mb_off = 2: the two frames the filter looks back at; less at the very start of a stream), whose first tap is
     // frame ib of the rows with numerator rb:  frame mb + u reads row frame ib + (rb + u F) / T, numerator (rb + u F) mod T.
     uint32_t ib, rb, mb_off;
+    // rh_rlm_stream_overlap: the stream's state between two blocks that are in flight together, as tagged words {tag, f32 bits} beside the plain
+    // ones.  hand_in != nullptr: this block was launched WITHOUT a barrier behind the block in front (hipExtAnyOrderLaunch, the same queue):
+    // its tiles that the state still reaches wait for the words tagged hand_tag.  hand_out != nullptr: the last tile leaves them, tagged p.epoch.
+    const unsigned long long *hand_in;
+    unsigned long long *hand_out;
+    uint32_t hand_tag;
 };
 
 template <int N>
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
             eM[k] = n_t <= q.Dmax ? ep[k] : 0.f;
             pwv[k] = pw[k];
         }
-        if (win_on) {
+        if (win_on && !q.hand_in) {
 #pragma unroll
             for (int k = 0; k < 2 * C; ++k) win[k] = p.st_win[k];
         }
@@ -435,6 +442,27 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
             c[k] = readlane_f(c[k], 15) + readlane_f(c[k], 31);
         }
     }
+    if (win_on && q.hand_in) {  // the block in front still runs: its last tile leaves the state as tagged words (it holds a slot or is done: see sblk_try)
+        unsigned long long hv[2 * C];
+        uint32_t spins = 0;
+        while (true) {
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) {
+                hv[k] = __hip_atomic_load(q.hand_in + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && ((uint32_t)(hv[k] >> 32) == q.hand_tag);
+            }
+            if (all) break;
+            if (++spins > kSpinLimit) {
+                if (lane == 0) atomicOr(p.status, 1u);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * C; ++k) win[k] = __uint_as_float((uint32_t)hv[k]);
+    }
     if (win_on) {  // + B^(m_lo - m0) * (the stream's state at m0)
         const float M[4] = {readfirstlane_f(wM[0]), readfirstlane_f(wM[1]), readfirstlane_f(wM[2]), readfirstlane_f(wM[3])};
 #pragma unroll
@@ -455,6 +483,7 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
 #pragma unroll
         for (int k = 1; k < 2 * C; ++k) ev = lane == k ? e[k] : ev;
         p.st_wout[lane] = ev;
+        if (q.hand_out) __hip_atomic_store(q.hand_out + lane, ((unsigned long long)p.epoch << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);  // start state of the lane's run = Q + B^(R*lane) * carry
@@ -488,40 +517,6 @@ __global__ __launch_bounds__(64 * (kSblkWaves + 1), (NS * KV <= 8 ? 5 : 3)) void
     }
 }
 
-// Blocks side by side (rh_rlm_stream_overlap).  A block that starts while the block in front still runs cannot have the stream's state at its
-// first frame -- and must not wait for it inside the kernel (two streams are two hardware queues: a kernel that spins for one that sits
-// undispatched in another queue waits for the scheduler's time slice, tens of milliseconds; measured).  The filter is linear: the block runs
-// from a ZERO state (k_rlm_sblk with no st_win; its last tile leaves the zero-state end state e0), and this kernel, ordered behind it and
-// behind the fix-up of the block in front by stream events alone, adds what the true state S at the block's first frame contributes:
-//     y[m0 + d] += g_d . S   (g_d = row 0 of A^(d+1) Tm^-1, d = 0 .. Dmax: beyond that the filter has forgotten S to 2^-40),
-//     state at the block's end = e0 + B^(frames) S.
-// A few hundred frames and eight floats: microseconds, off the blocks' critical path.
-template <int C>
-__global__ __launch_bounds__(256) void k_sblk_fix(float *__restrict__ out, const uint32_t frames, const float *__restrict__ G, const float *__restrict__ powD, const uint32_t Dmax,
-                                                  const float *__restrict__ s_in, const float *__restrict__ e0, float *__restrict__ s_out) {
-    float S[2 * C];
-#pragma unroll
-    for (int k = 0; k < 2 * C; ++k) S[k] = s_in[k];
-    const uint32_t n = frames < Dmax + 1u ? frames : Dmax + 1u;
-    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) {
-        const float g0 = G[2 * d], g1 = G[2 * d + 1];
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) out[(uint64_t)d * C + ch] = fma_(g0, S[2 * ch], fma_(g1, S[2 * ch + 1], out[(uint64_t)d * C + ch]));
-    }
-    if (s_out && blockIdx.x == 0 && threadIdx.x == 0) {
-        float e[2 * C];
-#pragma unroll
-        for (int k = 0; k < 2 * C; ++k) e[k] = e0[k];
-        if (frames <= Dmax) {
-            const float *M = powD + 4 * (uint64_t)frames;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) mat_acc(M, S[2 * ch], S[2 * ch + 1], e[2 * ch], e[2 * ch + 1]);
-        }
-#pragma unroll
-        for (int k = 0; k < 2 * C; ++k) s_out[k] = e[k];
-    }
-}
-
 struct Inst {
     int R, C, KV, NS;
     const void *fn;
@@ -531,11 +526,6 @@ struct Inst {
 const Inst kInst[] = {
     RH_SBLK(3, 2, 1, 12), RH_SBLK(5, 2, 2, 6), RH_SBLK(7, 2, 3, 4), RH_SBLK(9, 2, 4, 3),
     RH_SBLK(5, 1, 1, 12), RH_SBLK(9, 1, 2, 6),
-};
-// ... with rings of at most 64 KiB a workgroup: two blocks' workgroups share a CU (rh_rlm_stream_overlap)
-const Inst kInstHalf[] = {
-    RH_SBLK(3, 2, 1, 8), RH_SBLK(5, 2, 2, 4), RH_SBLK(7, 2, 3, 2),
-    RH_SBLK(5, 1, 1, 8), RH_SBLK(9, 1, 2, 4),
 };
 #undef RH_SBLK
 
@@ -550,24 +540,31 @@ struct SblkPlan {
     Tables *d_tabs = nullptr;
     float *d_uni = nullptr, *d_pow = nullptr;
     uint32_t Dmax = 0;
-    unsigned long long *d_gran = nullptr;  // [2][cap_tiles][4]: the tiles' aggregates, one set per block in flight
+    unsigned long long *d_gran = nullptr;  // [3][cap_tiles][4]: the tiles' aggregates, one set per block in flight and one spare
     size_t cap_tiles = 0;
     bool unusable = false;     // the filter forgets too slowly for a table of powers
-    // rh_rlm_stream_overlap: consecutive blocks on two streams of the handle's
-    hipStream_t ovl_stream[2] = {nullptr, nullptr};
-    hipEvent_t ovl_done[2] = {nullptr, nullptr}, ovl_pre = nullptr;
-    hipStream_t fix_stream = nullptr;           // the fix-ups, one behind the other
-    hipEvent_t fix_done[2] = {nullptr, nullptr};
-    float *d_e0 = nullptr;                      // [2][4]: a block's zero-state end state
-    float *d_G = nullptr;                       // [Dmax + 1][2]: row 0 of A^(d+1) Tm^-1
+    // rh_rlm_stream_overlap: the stream's state as tagged words, one set per block in flight (and one spare)
+    unsigned long long *d_hand = nullptr;  // [3][4]
+    uint32_t last_tag = 0;                 // the tag the block in front leaves there (its epoch), in set last_set
+    int last_set = 0;
+    bool last_handed = false;              // ... if it leaves one (a block of a running stream under rh_rlm_stream_overlap)
+    hipStream_t last_stream = nullptr;     // the stream the block in front was launched on
+    uint32_t n_chained = 0;                // blocks launched without a barrier behind the block in front (diagnostics)
     uint32_t blk = 0;                      // blocks of the current stream that this kernel ran
     bool prev_sblk = false;                // ... and the block before this one was one of them
-    uint64_t seen_version = ~0ull;         // the table upload the handle's streams have been ordered behind
+    uint64_t seen_version = ~0ull;         // the source table the block in front read (a block behind a new upload starts behind a barrier)
 };
 
-void sblk_other_block(rh_rlm *p) {  // a block of the stream ran elsewhere (or the stream begins): the state lives in the plain words again
+void sblk_other_block(rh_rlm *p, bool stream_begins) {  // a block of the stream ran elsewhere (or the stream begins): the state lives in the plain words again
     SblkPlan *s = static_cast<SblkPlan *>(p->sblk);
-    if (s) s->prev_sblk = false;
+    if (!s) return;
+    s->prev_sblk = false;
+    if (stream_begins) s->n_chained = 0;
+}
+
+uint32_t sblk_chained_blocks(const rh_rlm *p) {
+    const SblkPlan *s = static_cast<const SblkPlan *>(p->sblk);
+    return s ? s->n_chained : 0u;
 }
 
 void sblk_free(rh_rlm *p) {
@@ -577,15 +574,7 @@ void sblk_free(rh_rlm *p) {
     if (s->d_uni) (void)hipFree(s->d_uni);
     if (s->d_pow) (void)hipFree(s->d_pow);
     if (s->d_gran) (void)hipFree(s->d_gran);
-    if (s->d_e0) (void)hipFree(s->d_e0);
-    if (s->d_G) (void)hipFree(s->d_G);
-    if (s->fix_stream) (void)hipStreamDestroy(s->fix_stream);
-    for (int k = 0; k < 2; ++k) {
-        if (s->ovl_stream[k]) (void)hipStreamDestroy(s->ovl_stream[k]);
-        if (s->ovl_done[k]) (void)hipEventDestroy(s->ovl_done[k]);
-        if (s->fix_done[k]) (void)hipEventDestroy(s->fix_done[k]);
-    }
-    if (s->ovl_pre) (void)hipEventDestroy(s->ovl_pre);
+    if (s->d_hand) (void)hipFree(s->d_hand);
     delete s;
     p->sblk = nullptr;
 }
@@ -618,16 +607,6 @@ static rh_status sblk_tables(rh_rlm *p, SblkPlan &s, int R) {
         RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_pow), pw.size() * 4));
         RH_HIP_TRY(hipMemcpy(s.d_pow, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
         s.Dmax = d;
-        std::vector<float> gt((size_t)(d + 1) * 2);  // what a state at a block's first frame adds to frame d: row 0 of A^(d+1) Tm^-1 (k_sblk_fix)
-        M2 ap = A;
-        for (uint32_t k = 0; k <= d; ++k) {
-            const M2 m = mul(ap, Ti);
-            gt[(size_t)k * 2] = (float)m.a;
-            gt[(size_t)k * 2 + 1] = (float)m.b;
-            ap = mul(ap, A);
-        }
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_G), gt.size() * 4));
-        RH_HIP_TRY(hipMemcpy(s.d_G, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
     }
     Tables *h = new Tables();
     std::memset(h, 0, sizeof(Tables));
@@ -684,13 +663,12 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     if (s.unusable) return RH_OK;
     // the instance: the smallest window whose tiles fit the chip one per CU (more, smaller tiles would queue behind each other; fewer, larger
     // ones leave CUs idle); RH_SBLK_KV pins it
-    // rh_rlm_stream_overlap: this block beside the one in front, on the handle's other stream (rows resident: the caller's promise)
-    const bool ovl = p->st_overlap && p->exclusive && !rh::knob(rh::K_SBLK_NO_OVERLAP);
+    const bool ovl = p->st_overlap && p->exclusive && !rh::knob(rh::K_SBLK_NO_OVERLAP);  // rh_rlm_stream_overlap (rows resident: the caller's promise)
     const Inst *pick = nullptr;
     uint64_t tiles = 0, P = 0;
     const char *pin = rh::knob(rh::K_SBLK_KV);
-    const Inst *const tab = ovl ? kInstHalf : kInst;
-    const size_t n_tab = ovl ? sizeof(kInstHalf) / sizeof(kInstHalf[0]) : sizeof(kInst) / sizeof(kInst[0]);
+    const Inst *const tab = kInst;
+    const size_t n_tab = sizeof(kInst) / sizeof(kInst[0]);
     for (size_t ii = 0; ii < n_tab; ++ii) {
         const Inst &in = tab[ii];
         if ((uint32_t)in.C != C) continue;
@@ -721,8 +699,7 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     if (J == 0 || J > 32) return RH_OK;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick->fn, 64 * (kSblkWaves + 1), 0) != hipSuccess || per_cu < 1) return RH_OK;
-    if (ovl && (per_cu < 2 || tiles > (uint64_t)rh::g_num_cus)) return RH_OK;  // (two blocks' workgroups must fit the chip together: one per CU each)
-    const bool direct = p->exclusive && tiles <= (uint64_t)rh::g_num_cus * (uint64_t)(ovl ? 1 : per_cu);
+    const bool direct = p->exclusive && tiles <= (uint64_t)rh::g_num_cus * (uint64_t)per_cu;
     if (!direct && tiles > 8ull * (uint64_t)rh::g_num_cus * (uint64_t)per_cu) return RH_OK;  // (long blocks: the two-launch form reaches the chip's rate there)
     if ((size_t)tiles > s.cap_tiles) {
         const rh_status w = wait_idle(p);
@@ -730,34 +707,28 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
         if (s.d_gran) RH_HIP_TRY(hipFree(s.d_gran));
         s.d_gran = nullptr, s.cap_tiles = 0;
         const size_t cap = (size_t)tiles + 64;
-        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_gran), 2 * cap * 32));
-        RH_HIP_TRY(rh::fill_now(s.d_gran, 0, 2 * cap * 32));  // tag 0 = never written (launch tags start at 1)
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_gran), 3 * cap * 32));
+        RH_HIP_TRY(rh::fill_now(s.d_gran, 0, 3 * cap * 32));  // tag 0 = never written (launch tags start at 1)
         s.cap_tiles = cap;
     }
-    hipStream_t ls = hs;  // the stream of the launch
-    const int par = (int)(s.blk & 1u);
-    bool pre_recorded = false;
-    if (ovl) {
-        for (int k = 0; k < 2; ++k) {
-            if (!s.ovl_stream[k]) RH_HIP_TRY(hipStreamCreateWithFlags(&s.ovl_stream[k], hipStreamNonBlocking));
-            if (!s.ovl_done[k]) RH_HIP_TRY(hipEventCreateWithFlags(&s.ovl_done[k], hipEventDisableTiming));
-            if (!s.fix_done[k]) RH_HIP_TRY(hipEventCreateWithFlags(&s.fix_done[k], hipEventDisableTiming));
-        }
-        if (!s.fix_stream) RH_HIP_TRY(hipStreamCreateWithFlags(&s.fix_stream, hipStreamNonBlocking));
-        if (!s.ovl_pre) RH_HIP_TRY(hipEventCreateWithFlags(&s.ovl_pre, hipEventDisableTiming));
-        if (!s.d_e0) RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_e0), 2 * 4 * sizeof(float)));
-        ls = s.ovl_stream[par];
-        // What this block needs of the caller's stream: the source table (when it was uploaded since the handle's streams last looked) and -- its
-        // fix-up -- a state that another kernel wrote there.  The ROWS are not ordered behind the caller's stream: they are complete when the
-        // call is made (the contract of rh_rlm_stream_overlap) -- that is what lets this block start while the one in front still runs.
-        if (!s.prev_sblk || s.seen_version != p->srcs_version) {
-            RH_HIP_TRY(hipEventRecord(s.ovl_pre, hs));
-            RH_HIP_TRY(hipStreamWaitEvent(ls, s.ovl_pre, 0));
-            s.seen_version = p->srcs_version;
-            pre_recorded = true;
-        }
-        if (s.blk >= 2) RH_HIP_TRY(hipStreamWaitEvent(ls, s.fix_done[par], 0));  // (the zero-state end state of the block two in front has been read)
+    // rh_rlm_stream_overlap -- a block that starts while the block in front still runs.  Two streams are two hardware queues, and a kernel that
+    // waits for one that sits undispatched in ANOTHER queue waits for the scheduler's time slice (measured: 28-65 ms a block), so both blocks go
+    // to the caller's stream, this one WITHOUT the barrier a launch normally carries (hipExtAnyOrderLaunch).  What that does on this part
+    // (tools/ubench/any_order.hip, profiles/r06_any_order_ubench.txt): every XCD takes the queue's kernels in order on its own -- this block's
+    // workgroups start on an XCD as soon as that XCD has finished its share of the block in front, while the other XCDs still work on theirs.
+    // So the tail of one block and the ramp of the next overlap across XCDs, the block in front has all its workgroups on the chip when this
+    // one's first workgroup starts (they fit it at once: `direct`), and the only thing this block needs of it -- the stream's state -- is
+    // waited for inside the kernel by the few tiles it still reaches (tagged words, SblkArgs::hand_in).  The next launch WITH a barrier --
+    // anything else on the stream -- waits for both.  Conditions: the block in front was one of these, on this stream, reading the same source
+    // table (nothing of ours was queued in between), and left the tagged state.  Three sets of hand-off tables in rotation: block k + 2 starts
+    // on an XCD only when block k + 1 is done there, and block k + 1's tiles there looked back at tiles of the other XCDs, which started behind
+    // block k's (tiles >= 16: every XCD holds a tile that looks back across all eight) -- the third set is slack on top of that argument.
+    const int set = (int)(s.blk % 3u);
+    if (ovl && !s.d_hand) {
+        RH_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s.d_hand), 3 * 4 * sizeof(unsigned long long)));
+        RH_HIP_TRY(rh::fill_now(s.d_hand, 0, 3 * 4 * sizeof(unsigned long long)));  // tag 0 = never written
     }
+    bool chained = ovl && s.prev_sblk && s.last_handed && s.last_stream == hs && s.seen_version == p->srcs_version && direct && tiles >= 16 && sa.win != nullptr;
     {
         const rh_status w = pre_launch(p, hs);
         if (w != RH_OK) return w;
@@ -765,7 +736,9 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     p->epoch += 1;
     if (p->epoch == 0) {  // tag wrap: start over from clean tables
         if (p->d_gran) RH_HIP_TRY(hipMemsetAsync(p->d_gran, 0, p->gran_words * 8, hs));
-        RH_HIP_TRY(hipMemsetAsync(s.d_gran, 0, s.cap_tiles * 32, hs));
+        RH_HIP_TRY(hipMemsetAsync(s.d_gran, 0, 3 * s.cap_tiles * 32, hs));
+        if (s.d_hand) RH_HIP_TRY(hipMemsetAsync(s.d_hand, 0, 3 * 4 * sizeof(unsigned long long), hs));
+        chained = false;  // (behind the fills, and no tag of the old count is waited for)
         p->epoch = 1;
     }
     Params k;
@@ -795,8 +768,8 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     k.st_active = (uint32_t)out;
     k.st_m0 = sa.m0;
     k.st_g0 = sa.g0;
-    k.st_win = ovl ? nullptr : sa.win;                                  // side by side: from a zero state, the true one added behind it (k_sblk_fix)
-    k.st_wout = ovl ? (sa.mode == 1 ? s.d_e0 + 4 * par : nullptr) : sa.wout;
+    k.st_win = sa.win;
+    k.st_wout = sa.wout;
     k.u = s.uni;
     SblkArgs q;
     {
@@ -810,34 +783,28 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     }
     q.uni = s.d_uni;
     q.powD = s.d_pow;
-    q.gran = s.d_gran + (size_t)par * s.cap_tiles * 4;
+    q.gran = s.d_gran + (size_t)set * s.cap_tiles * 4;
     q.src_off = sa.src_off;
     q.Dmax = s.Dmax;
     q.P = (uint32_t)P;
+    const bool hands = ovl && sa.mode == 1 && sa.wout != nullptr && direct;
+    q.hand_in = chained ? s.d_hand + (size_t)s.last_set * 4 : nullptr;
+    q.hand_tag = s.last_tag;
+    q.hand_out = hands ? s.d_hand + (size_t)set * 4 : nullptr;
     void *args[] = {&k, &q};
     const uint32_t grid = direct ? (uint32_t)tiles : (((uint32_t)tiles + 7u) & ~7u);
-    const hipError_t e = hipLaunchKernel(pick->fn, dim3(grid), dim3(64 * (kSblkWaves + 1)), args, 0, ls);
+    const hipError_t e = chained ? hipExtLaunchKernel(pick->fn, dim3(grid), dim3(64 * (kSblkWaves + 1)), args, 0, hs, nullptr, nullptr, hipExtAnyOrderLaunch)
+                                 : hipLaunchKernel(pick->fn, dim3(grid), dim3(64 * (kSblkWaves + 1)), args, 0, hs);
     if (e != hipSuccess) {
         rh::set_hip_error(e, "k_rlm_sblk");
         return RH_ERR_HIP;
     }
-    if (ovl) {
-        RH_HIP_TRY(hipEventRecord(s.ovl_done[par], ls));
-        // the fix-up: behind this block's kernel, behind the fix-up of the block in front (the stream's order), behind whoever else wrote the state
-        if (!s.prev_sblk) {
-            if (!pre_recorded) RH_HIP_TRY(hipEventRecord(s.ovl_pre, hs));
-            RH_HIP_TRY(hipStreamWaitEvent(s.fix_stream, s.ovl_pre, 0));
-        }
-        RH_HIP_TRY(hipStreamWaitEvent(s.fix_stream, s.ovl_done[par], 0));
-        const uint32_t nfix = (uint32_t)(out < (uint64_t)s.Dmax + 1 ? out : (uint64_t)s.Dmax + 1);
-        const dim3 fg((nfix + 255u) / 256u ? (nfix + 255u) / 256u : 1u);
-        float *const s_out = sa.mode == 1 ? sa.wout : nullptr;
-        if (C == 2) hipLaunchKernelGGL(k_sblk_fix<2>, fg, dim3(256), 0, s.fix_stream, dst, (uint32_t)out, s.d_G, s.d_pow, s.Dmax, sa.win, s.d_e0 + 4 * par, s_out);
-        else hipLaunchKernelGGL(k_sblk_fix<1>, fg, dim3(256), 0, s.fix_stream, dst, (uint32_t)out, s.d_G, s.d_pow, s.Dmax, sa.win, s.d_e0 + 4 * par, s_out);
-        RH_CHECK_LAUNCH();
-        RH_HIP_TRY(hipEventRecord(s.fix_done[par], s.fix_stream));
-        RH_HIP_TRY(hipStreamWaitEvent(hs, s.fix_done[par], 0));  // the block's output is complete in the CALLER's stream order, as ever
-    }
+    s.last_handed = hands;
+    s.last_tag = p->epoch;
+    s.last_set = set;
+    s.last_stream = hs;
+    s.seen_version = p->srcs_version;
+    if (chained) s.n_chained += 1;
     s.prev_sblk = true;
     s.blk += 1;
     if (!direct) p->shard_base += grid / 8u;

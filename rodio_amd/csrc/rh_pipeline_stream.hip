@@ -69,7 +69,7 @@ rh_status rh_rlm_stream_begin(rh_rlm *p) {
     p->st_gone.clear();
     p->st_prev_gone.clear();
     p->st_prev_avail = p->st_prev_g0 = p->st_prev_m = p->st_prev_out = 0;
-    sblk_other_block(p);
+    sblk_other_block(p, true);
     return RH_OK;
 }
 
@@ -82,6 +82,12 @@ rh_status rh_rlm_stream_overlap(rh_rlm *p, int32_t on) {
 rh_status rh_rlm_stream_one_launch_blocks(rh_rlm *p, uint32_t *blocks) {
     if (!p || !blocks) return RH_ERR_INVALID;
     *blocks = p->st_n_sblk;
+    return RH_OK;
+}
+
+rh_status rh_rlm_stream_overlapped_blocks(rh_rlm *p, uint32_t *blocks) {
+    if (!p || !blocks) return RH_ERR_INVALID;
+    *blocks = sblk_chained_blocks(p);
     return RH_OK;
 }
 

@@ -119,6 +119,17 @@ __device__ __forceinline__ void wait_loads(float (&v)[N]) {  // the values are o
     for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
 }
 
+// ... with at most YOUNGER vector-memory instructions of this wave still in flight: vmcnt retires in order, so loads that were issued in FRONT of
+// YOUNGER others have arrived when the count is down to YOUNGER.  (The caller knows that at least that many were issued behind them.)
+template <int YOUNGER, int N>
+__device__ __forceinline__ void wait_loads_behind(float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // ---- the tile's samples in LDS -------------------------------------------------------------------------------------------

@@ -626,6 +626,10 @@ rh_status rh_rlm_stream_one_launch_blocks(rh_rlm *, uint32_t *blocks) {
     if (blocks) *blocks = 0;
     return RH_OK;
 }
+rh_status rh_rlm_stream_overlapped_blocks(rh_rlm *, uint32_t *blocks) {
+    if (blocks) *blocks = 0;
+    return RH_OK;
+}
 rh_status rh_rlm_last_status(rh_rlm *) { return RH_OK; }
 rh_status rh_rlm_stream_block_v(rh_rlm *p, const float *const *srcs, const uint64_t *avail, const uint8_t *ended, uint32_t S, float *dst, uint64_t cap, uint64_t *out_frames, uint64_t *consumed, rh_stream) {
     if (!p || !p->on || p->done || !out_frames || !consumed) return RH_ERR_INVALID;

@@ -380,6 +380,50 @@ def test_a_filter_per_source_in_the_fused_mixer(G, O, n_equal):
     p.close()
 
 
+@pytest.mark.parametrize("ch,n", [(2, 300_000), (1, 280_004)])
+def test_filter_classes_walked_in_one_launch(G, O, ch, n):
+    """Round 6 (VERDICT r05 next #5a): a mixer whose sources carry different filters (`mixer.add(a.low_pass(200)); mixer.add(b.high_pass(300))`,
+    source/mod.rs:686-721, mixer.rs:58-66) where every class is long enough for k_rlm_chunk: ONE launch walks the classes (k_rlm_chunk_multi --
+    class k's workgroups behind class k-1's, each with its own arguments, tables and tickets), the classes' mixes are added behind it.  The
+    oracle's Mixer over the per-source chains; the same bits as one launch per class (RH_CLASSES_ONE_BY_ONE=1: the tile code is the same);
+    geometry().mix_first says which form ran."""
+    import torch
+    from conftest import knobs
+
+    filters = [("low_pass", 200), ("high_pass", 300), ("low_pass", 1000), ("high_pass", 300), ("low_pass", 200), ("low_pass", 1000), ("low_pass", 200)]
+    S = len(filters)
+    gains = np.linspace(0.5, 1.2, S).astype(np.float32)
+    xs = [rnd(7300 + i, ch * n, 0.1) for i in range(S)]
+    m = O.Mixer(ch, 48000)
+    for x, f, g in zip(xs, filters, gains):
+        u = O.UniformSourceIterator(O.TestSource(x, ch, 44100).amplify(float(g)), ch, 48000)
+        m.add(u.low_pass(f[1]) if f[0] == "low_pass" else u.high_pass(f[1]))
+    ref = m.collect()
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+
+    def run():
+        p = G.ResampleLowpassMix(44100, 48000, ch, None, "low_pass", 200, 0.5, max_sources=S, max_in_frames=n)
+        p.set_filters(filters)
+        p.set_gains(gains)
+        p.set_sources(xd)
+        got = p.run().cpu().numpy()
+        again = p.run().cpu().numpy()
+        p.check_status()
+        how = p.geometry()["mix_first"]
+        p.close()
+        assert np.array_equal(got, again)
+        return got, how
+
+    one, how_one = run()
+    with knobs(RH_CLASSES_ONE_BY_ONE="1"):
+        each, how_each = run()
+    assert how_one == 3 and how_each == 2, (how_one, how_each)
+    assert len(one) == len(ref) == len(each)
+    e = float(np.max(np.abs(one - ref)))
+    print(f"[filter classes in one launch, {ch} ch] |gpu - oracle| = {e:.2e}")
+    assert e <= TOL and np.array_equal(one, each)
+
+
 def test_block_streaming_keeps_its_table_while_the_sources_move_together(G, O):
     """A block that is summed first reads only pointers and gains of the source table, and they take a common offset: resident rows read at
     `row + consumed` (every source moves on by the same bytes) stream without uploading the table again (rh_pipeline_stream.hip).  The same
@@ -546,7 +590,7 @@ def test_a_block_of_a_summed_stream_in_one_launch(G, O, ch, filt, freq, frm, B):
     sources, the conversion and the filter -- with nothing from the host per block but its arguments.  Resident rows read at `row + consumed`,
     blocks of B input frames (tile windows of 1, 2 or 3 KiB by the block's length; a last block that is shorter; the verbatim last frame): the
     oracle's one-pass samples; the same stream with RH_NO_SBLK=1 (two launches per block, as until round 5) within 2e-6; and side by side
-    (rh_rlm_stream_overlap: every block from a zero state, the true state added behind it by k_sblk_fix) the same again."""
+    (rh_rlm_stream_overlap: a block launched without a barrier behind the block in front, the state waited for inside the kernel) bit for bit."""
     import ctypes as C
 
     import torch
@@ -584,19 +628,24 @@ def test_a_block_of_a_summed_stream_in_one_launch(G, O, ch, filt, freq, frm, B):
         p.check_status()
         one = C.c_uint32(0)
         _lib.check(lib.rh_rlm_stream_one_launch_blocks(p._h, C.byref(one)), "rh_rlm_stream_one_launch_blocks")
+        ovl = C.c_uint32(0)
+        _lib.check(lib.rh_rlm_stream_overlapped_blocks(p._h, C.byref(ovl)), "rh_rlm_stream_overlapped_blocks")
         res = out[: ch * m].cpu().numpy()
         stats = p.stream_stats()
         p.close()
-        return res, one.value, stats, k
+        return res, one.value, stats, k, ovl.value
 
-    a, one_a, st_a, nb = run(False)
-    b, one_b, st_b, _ = run(True)
+    a, one_a, st_a, nb, ovl_a = run(False)
+    b, one_b, st_b, _, ovl_b = run(True)
     with knobs(RH_NO_SBLK="1"):
-        c_, one_c, st_c, _ = run(False)
+        c_, one_c, st_c, _, _ = run(False)
     ref = _oracle(O, xs, frm, 48000, None, filt, freq, gains, ch)
     assert len(a) == len(b) == len(c_) == len(ref), (len(a), len(b), len(c_), len(ref))
     assert one_a == nb and one_b == nb and one_c == 0, (one_a, one_b, one_c, nb)  # every block of the stream, the last (flush) one included
     assert st_a[0] == nb and st_a[1] == 0
     e = [float(np.max(np.abs(v - ref))) for v in (a, b, c_)]
     assert max(e) <= TOL, e
-    assert float(np.max(np.abs(a - c_))) <= 2e-6 and float(np.max(np.abs(a - b))) <= 2e-6
+    assert float(np.max(np.abs(a - c_))) <= 2e-6
+    # side by side: the same kernel with the same state words, waited for inside it -- the same bits; every block but the stream's first (no state
+    # to wait for) and a last one of a few frames started without a barrier behind the block in front
+    assert np.array_equal(a, b) and ovl_a == 0 and nb - 3 <= ovl_b <= nb - 1, (ovl_a, ovl_b, nb)
