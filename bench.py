@@ -535,7 +535,7 @@ def headline(args, argv):
         cms = elapsed(lib, _lib, cevs)[0] / args.steps
         alg_c = 4 * sum(lens) * Cn + 4 * M * Cn
         per_class = {"classes": [f"{k}({f})" for k, f in classes], "sources_per_class": S // 4, "call_ms": cms, "achieved": alg_c / (cms * 1e-3) / 1e9, "frac": alg_c / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "how": "HIP events around the timed region / steps: one call = one launch per class + the sum of the classes' mixes"}
+                     "how": "HIP events around the timed region / steps: one call = ONE launch that walks the classes and adds their mixes (k_rlm_chunk_classes; RH_CLASSES_ONE_BY_ONE=1: a launch per class + rh_mix_sum)"}
         if not args.no_cpu_baseline:
             from concurrent.futures import ThreadPoolExecutor
 

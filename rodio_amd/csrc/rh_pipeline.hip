@@ -1469,6 +1469,7 @@ struct ChunkMulti {
     };
     uint32_t n;                          // classes in this launch
     uint32_t first[kChunkMultiMax + 1];  // first workgroup of every class (multiples of 8: a workgroup's XCD is its class-relative index's too); [n] = the grid
+    float *sum_out;                      // k_rlm_chunk_classes: where the SUM of the classes' mixes goes (the classes' own rows stay unwritten)
     Entry e[kChunkMultiMax];
 };
 static_assert(sizeof(ChunkMulti) <= 4096, "the kernarg segment");
@@ -1923,6 +1924,477 @@ __global__ __launch_bounds__(64, 2) void k_rlm_chunk_multi(const ChunkMulti m) {
     rlm_chunk_tile<R, C, KV>(p, q, blockIdx.x - b0);
 }
 
+// The classes of a mixer in one launch, TWO waves a tile, ONE output (round 6).  A class of 64 sources is a quarter of the headline's bytes, and
+// every way of running four of them measured the same 0.36-0.37 ms against the headline's 0.31 for the same bytes: a launch per class,
+// the launches lined up in one grid (k_rlm_chunk_multi), a wave that loads while another converts and filters.  The loaders alone take
+// 0.308 ms; stamps per tile and class (tools/cls_stamps.py) showed where the rest goes: each class's mix was STORED -- 36 MB of writes in
+// all, interleaved with 2 GiB of reads, took 40-55 us of the launch (a run's stores: 55 us a class while the loaders run, 1.5 us once they
+// are done) -- and then read again by rh_mix_sum.  So: a workgroup owns chunk `tile` of EVERY class.  Wave 0 only ever loads: it sums the
+// chunk over class k's sources through its ring -- the ring does not know about classes, the source after next goes out across a class's
+// end -- and leaves the mixed chunk in one of two LDS images (two counters in the LDS, no barrier: it may be two classes ahead).  Wave 1
+// converts and filters class k's chunk exactly as k_rlm_chunk's lone wave does (the same operations in the same order) and ADDS the result
+// to a run of registers, 0.0 + class 0 + class 1 + ... -- rh_mix_sum's order, the same bits -- which leaves once, as whole lines, when the
+// last class is done and the loaders have nothing left to read.  0.317 ms: the classes cost what the headline costs.  For classes of one
+// geometry (equal lengths, one rate pair: one table of tile bounds) whose tiles are all resident at once (the host checks: tile =
+// workgroup, no ticket); anything else takes k_rlm_chunk_multi and the classes' rows.
+#if defined(RH_CLS_DIAG) && RH_CLS_DIAG == 9  // diagnostics builds: wall-clock stamps per (tile, class): loader {sum done, image written}, wave 1 {image seen, halo there, look-back there, done}
+__device__ unsigned long long g_cls_stamp[2048 * 8 * 8];
+#define RH_CLS_STAMP(i) { if (lane == 0 && tile < 2048 && k < 8) g_cls_stamp[((uint64_t)tile * 8 + k) * 8 + (i)] = wall_clock64(); }
+#else
+#define RH_CLS_STAMP(i)
+#endif
+#define RH_PARG(T, e, f) (*(const __attribute__((address_space(4))) T *)((e) + offsetof(ChunkMulti::Entry, p) + offsetof(Params, f)))
+#define RH_QARG(T, e, f) (*(const __attribute__((address_space(4))) T *)((e) + offsetof(ChunkMulti::Entry, q) + offsetof(ChunkArgs, f)))
+template <int R, int C, int KV>
+__global__ __launch_bounds__(128, 2) void k_rlm_chunk_classes(const ChunkMulti m) {
+    typedef Chan<C> CH;
+    typedef typename CH::V V;
+    constexpr int NS = 2, H = 4;
+    constexpr uint32_t FB = CH::kFB;
+    constexpr uint32_t kStage = KV * 1024, P = kStage / FB;
+    // LDS: the loader's ring | two words the waves meet at | TWO images of a mixed chunk, [64 bytes: the 4 frames in front | the chunk | 64 bytes].
+    // Two images and counters instead of barriers: the loader may be two classes ahead of wave 1 -- a tile's wave 1 waits for its NEIGHBOURS'
+    // loaders (the frames in front of its chunk, their aggregates), and with one image and a barrier a class every loader was tied to within
+    // a class of the slowest loader near it: measured 0.361 ms against 0.308 for the loaders alone.
+    constexpr uint32_t kCtl = NS * kStage;
+    constexpr uint32_t kImg = kStage + 128;
+    constexpr uint32_t MB0 = kCtl + 64 + 64;         // the chunk of image 0 (its 4 frames in front at MB0 - H * FB)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kCtl + 64 + 2 * kImg];
+    lds_u8 *const lds = (lds_u8 *)smem;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    typedef __attribute__((address_space(4))) const uint64_t cu64;
+    typedef __attribute__((address_space(4))) const float cf32;
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    typedef const __attribute__((address_space(4))) unsigned char *cbytes;
+    const cbytes kseg = (cbytes)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_cls = m.n;
+    const Params &p0 = m.e[0].p;  // the geometry the classes share
+    const uint32_t tile = blockIdx.x;
+    const uint32_t Ns = p0.eq_frames;
+    auto entry = [&](uint32_t k) -> cbytes { return kseg + offsetof(ChunkMulti, e) + (size_t)k * sizeof(ChunkMulti::Entry); };
+    // the two counters: classes handed over by the loader / finished by wave 1 (LDS words; a wave's LDS operations complete in order)
+    auto ctl_read = [&](uint32_t which) -> uint32_t {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds0 + kCtl + which * 4) : "memory");
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    auto ctl_write = [&](uint32_t which, uint32_t v) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *(RH_LDS uint32_t *)(lds + kCtl + which * 4) = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (wave == 0) {
+        if (lane < 2) *(RH_LDS uint32_t *)(lds + kCtl + lane * 4) = 0u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave == 0) {
+        // ---- the loader: the sum of chunk `tile` over every class's sources, class after class (k_rlm_chunk's source loop) ----
+        const uint32_t nvec = Ns * C / 4;
+        const uint32_t v0 = tile * (KV * 64);
+        uint32_t goff[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            uint32_t j = v0 + (uint32_t)k * 64 + lane;
+            j = j < nvec ? j : nvec - 1;
+            goff[k] = j * 16;
+        }
+        const bool lin = v0 + (uint32_t)(KV * 64) <= nvec;
+        auto stage_source = [&](cu64 *desc, uint32_t s_, uint32_t stage) {
+            const void *data = (const void *)(uintptr_t)desc[4 * (uint64_t)s_];
+            if (lin) {
+                glds16_run<KV>(data, goff[0], lds0 + stage * kStage);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KV; ++k) glds16(data, goff[k], lds0 + stage * kStage + k * 1024);
+            }
+        };
+        constexpr int NHV = H * FB / 16;
+        // The ring does not know about classes: the source after next goes out as soon as a stage is free, across a class's end too (its last
+        // two sources are summed while the next class's first two are on their way) -- only the hand-over of the mixed chunk happens per class.
+        __builtin_amdgcn_s_setprio(3);  // (this wave's few instructions are the memory side's pace: in front of wave 1's arithmetic on the same SIMD)
+        uint32_t kc = 0, sc = 0;        // the next source to request: source sc of class kc
+        cu64 *ndesc = (cu64 *)(uintptr_t)RH_PARG(uint64_t, entry(0), srcs);
+        uint32_t nS = RH_PARG(uint32_t, entry(0), n_sources);
+        uint32_t nstage = 0;
+        auto request_next = [&]() {  // (classes without sources are the host's to leave out)
+            if (kc >= n_cls) return false;
+            stage_source(ndesc, sc, nstage);
+            nstage ^= 1u;
+            if (++sc == nS) {
+                sc = 0;
+                if (++kc < n_cls) {
+                    ndesc = (cu64 *)(uintptr_t)RH_PARG(uint64_t, entry(kc), srcs);
+                    nS = RH_PARG(uint32_t, entry(kc), n_sources);
+                }
+            }
+            return true;
+        };
+        uint32_t ahead = 0;  // groups of KV fetches in flight
+        if (request_next()) ++ahead;
+        if (request_next()) ++ahead;
+        uint32_t st = 0;
+        for (uint32_t k = 0; k < n_cls; ++k) {
+            const cbytes e = entry(k);
+            cf32 *const dgain = (cf32 *)(uintptr_t)RH_PARG(uint64_t, e, srcs);
+            const uint32_t S = RH_PARG(uint32_t, e, n_sources);
+            v4f acc[KV];
+#pragma unroll
+            for (int i = 0; i < KV; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            float g_next = S ? dgain[4] : 0.f;
+            for (uint32_t s_ = 0; s_ < S; ++s_) {
+                const float g = g_next;
+                g_next = s_ + 1 < S ? dgain[8 * (uint64_t)(s_ + 1) + 4] : 0.f;
+                // this source has landed when at most the group behind it is outstanding (the few stores of a hand-over in between only make
+                // the wait stricter)
+                if (ahead > 1) wait_vm<KV>();
+                else wait_vm<0>();
+                --ahead;
+                const lds_u8 *buf = lds + st * kStage;
+                v4f v[KV];
+#pragma unroll
+                for (int i = 0; i < KV; ++i) v[i] = *(const lds_f4 *)(buf + i * 1024 + lane * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the chunk is in registers: its stage is free ...
+                if (request_next()) ++ahead;                        // ... for the source after next, of this class or the next one
+#pragma unroll
+                for (int i = 0; i < KV; ++i) {
+                    acc[i].x = fma_(g, v[i].x, acc[i].x);
+                    acc[i].y = fma_(g, v[i].y, acc[i].y);
+                    acc[i].z = fma_(g, v[i].z, acc[i].z);
+                    acc[i].w = fma_(g, v[i].w, acc[i].w);
+                }
+                st ^= 1u;
+            }
+            RH_CLS_STAMP(0)
+            // the chunk's last 4 mixed frames to the tile behind (first: its wave 1 is waiting for them) ...
+            if (lane >= 64 - NHV) {
+                unsigned long long *hp = (unsigned long long *)(uintptr_t)RH_QARG(uint64_t, e, halo) + (uint64_t)tile * 8 + (uint32_t)(lane - (64 - NHV)) * 4;
+                const uint32_t epoch = RH_PARG(uint32_t, e, epoch);
+                const float ev[4] = {acc[KV - 1].x, acc[KV - 1].y, acc[KV - 1].z, acc[KV - 1].w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) __hip_atomic_store(hp + w, ((unsigned long long)epoch << 32) | __float_as_uint(ev[w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ... and the mixed chunk into the image wave 1 is not reading: it has finished class k - 2 (it may still be on class k - 1)
+            if (k >= 2) {
+                uint32_t spins = 0;
+                while (ctl_read(1) + 2 <= k) {
+                    if (++spins > kSpinLimit) break;  // (wave 1 reports what it waits for)
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            {
+                lds_u8 *img = lds + MB0 + (k & 1u) * kImg;
+#pragma unroll
+                for (int i = 0; i < KV; ++i) *(lds_f4 *)(img + (uint32_t)(i * 64 + lane) * 16) = acc[i];
+                if (lane == 0) *(lds_f4 *)(img + kStage) = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            ctl_write(0, k + 1);
+            RH_CLS_STAMP(1)
+        }
+        return;
+    }
+    // ---- wave 1: what k_rlm_chunk does behind its source loop, for every class in turn ----
+    const ChunkArgs &q0 = m.e[0].q;
+    const uint32_t m_lo = ((cu32 *)(uintptr_t)q0.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q0.m_lo)[tile + 1];
+    const uint32_t m0 = m_lo + (uint32_t)lane * R;
+    const uint32_t n_t = m_hi - m_lo;  // <= 64 * R (host)
+    const int nfl = (int)n_t - lane * R < 0 ? 0 : ((int)n_t - lane * R > R ? R : (int)n_t - lane * R);
+    const uint32_t nl0 = (n_t + R - 1) / R;
+    const uint32_t vlast = nl0 ? n_t - (nl0 - 1) * R : 0;  // frames of the last lane's run, 1 .. R
+    const bool first = (m0 == 0);
+    int offA[R + 2];
+    float wgt[R + 2];
+    {
+        const int64_t fbase = (int64_t)tile * P;
+        Cursor c = cursor_at(first ? 0 : m0 - 2, p0);
+#pragma unroll
+        for (int rr = 0; rr < R + 2; ++rr) {
+            const bool dummy = first && rr < 2;
+            uint64_t i;
+            uint32_t num;
+            cursor_resolve(c, p0, i, num);
+            if (i + 1 >= Ns) {
+                i = Ns - 1;
+                num = 0;
+            }
+            int64_t f = (int64_t)i - fbase;
+            f = f < -H ? -H : (f > (int64_t)P - 1 ? (int64_t)P - 1 : f);
+            offA[rr] = dummy ? 0 : (int)f * (int)FB;  // (relative to the chunk in its image)
+            wgt[rr] = dummy ? 0.0f : (float)num / p0.Tf;
+            if (!dummy) cursor_next(c, p0);
+        }
+    }
+    // The classes' mixes are ADDED here, in registers, in the classes' order (0.0 + class 0 + class 1 + ...: rh_mix_sum's order over the classes'
+    // rows, bit for bit) and leave once, behind the last class -- when the loaders are done.  Measured with a row per class (tools/cls_stamps.py):
+    // 36 MB of output stores interleaved with the 2 GiB of reads cost 40-55 us of a 310 us launch; written at the end, like k_rlm_chunk's, nothing.
+    V ytot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ytot[r] = CH::zero();
+    for (uint32_t k = 0; k < n_cls; ++k) {
+        const cbytes e = entry(k);
+        // the class's tables and addresses: fetched here, a class's loads away from their use
+        const Tables *__restrict__ tb = (const Tables *)(uintptr_t)RH_PARG(uint64_t, e, tabs);
+        const uint32_t J = RH_PARG(uint32_t, e, J), epoch = RH_PARG(uint32_t, e, epoch);
+        const uint32_t Jc = J < tile ? J : tile;
+        const bool want_look = (uint32_t)lane < Jc;
+        unsigned long long *const halo = (unsigned long long *)(uintptr_t)RH_QARG(uint64_t, e, halo);
+        unsigned long long *const gran = (unsigned long long *)(uintptr_t)RH_PARG(uint64_t, e, gran);
+        uint32_t *const status = (uint32_t *)(uintptr_t)RH_PARG(uint64_t, e, status);
+        const float U = ((const float *)(uintptr_t)RH_QARG(uint64_t, e, uni))[lane < 61 ? lane : 60];
+        float lM[4], b15[4], b31[4], kM[4], pwv[4];
+        {
+            const float *kp = (const float *)(uintptr_t)RH_QARG(uint64_t, e, lookT) + ((uint64_t)tile * J + (want_look ? lane : 0)) * 4;
+            const float *pw = (const float *)(uintptr_t)RH_QARG(uint64_t, e, powM) + 4 * vlast;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lM[i] = tb->laneM[lane][i];
+                b15[i] = tb->bc15M[lane][i];
+                b31[i] = tb->bc31M[lane][i];
+                kM[i] = kp[i];
+                pwv[i] = pw[i];
+            }
+        }
+        lds_u8 *const img = lds + MB0 + (k & 1u) * kImg;  // the class's mixed chunk, when the loader says so
+        {
+            uint32_t spins = 0;
+            while (ctl_read(0) <= k) {
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicOr(status, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+#if defined(RH_CLS_DIAG) && RH_CLS_DIAG == 1  // diagnostics builds (wrong results): the loader's pace with nothing behind the hand-over
+        CH::set(ytot[0], 0, CH::get(ytot[0], 0) + lM[0] + b15[0] + b31[0] + kM[0] + pwv[0] + U + (float)offA[0] + wgt[1] + (float)nfl + (want_look ? 1.f : 0.f) + (float)(uintptr_t)halo + (float)(uintptr_t)gran + (float)(uintptr_t)status + (float)epoch);
+        ctl_write(1, k + 1);
+        continue;
+#endif
+        RH_CLS_STAMP(2)
+        // ---- the last 4 frames of the tile in front ----
+        bool dead = false;
+        if (tile == 0) {
+            if (lane < H * C) *(RH_LDS float *)(img - H * FB + lane * 4) = 0.0f;
+        } else {
+            const bool want = lane < H * C;
+            const unsigned long long *hp = halo + (uint64_t)(tile - 1) * 8 + (want ? lane : 0);
+            unsigned long long hv = 0;
+            bool ok = false;
+            uint32_t spins = 0;
+            while (true) {
+                if (want && !ok) {
+                    hv = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (uint32_t)(hv >> 32) == epoch;
+                }
+                if (__all(ok || !want)) break;
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicOr(status, 1u);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (want) *(RH_LDS float *)(img - H * FB + lane * 4) = dead ? __builtin_nanf("") : __uint_as_float((uint32_t)hv);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        RH_CLS_STAMP(3)
+        // ---- the lane's run of the mixed stream: lerp, zero-state biquad; the run-end state after nfl frames ----
+        const float b0 = readlane_f(U, 0), c1 = readlane_f(U, 1), c2 = readlane_f(U, 2), na1 = -readlane_f(U, 3), na2 = -readlane_f(U, 4);
+        V out[R];
+        V E1 = CH::zero(), E2 = CH::zero();
+        {
+            V ta[R + 2], tb2[R + 2];
+#pragma unroll
+            for (int rr = 0; rr < R + 2; ++rr) {
+                ta[rr] = CH::ld_lds(img + offA[rr]);
+                tb2[rr] = CH::ld_lds(img + offA[rr] + FB);
+            }
+            auto tap = [&](int rr) -> V {
+                V x;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) CH::set(x, ch, fma_(CH::get(tb2[rr], ch) - CH::get(ta[rr], ch), wgt[rr], CH::get(ta[rr], ch)));
+                return x;
+            };
+            V x2 = first ? CH::zero() : tap(0);
+            V x1 = first ? CH::zero() : tap(1);
+            V w1 = CH::zero(), w2 = CH::zero();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const V x = tap(r + 2);
+                V w;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const float wc = fma_(na1, CH::get(w1, ch), fma_(na2, CH::get(w2, ch), fma_(c2, CH::get(x2, ch), c1 * CH::get(x1, ch))));
+                    CH::set(w, ch, wc);
+                    CH::set(out[r], ch, fma_(b0, CH::get(x, ch), wc));
+                }
+                w2 = w1;
+                w1 = w;
+                x2 = x1;
+                x1 = x;
+                E1 = vsel(r + 1 == nfl, w1, E1);
+                E2 = vsel(r + 1 == nfl, w2, E2);
+            }
+        }
+        // ---- scan of the run-end states (scan basis) ----
+        float Pq[2 * C];
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) Pq[i] = 0.f;
+        {
+            const float Tm[4] = {readlane_f(U, 5), readlane_f(U, 6), readlane_f(U, 7), readlane_f(U, 8)};
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(Tm, CH::get(E1, ch), CH::get(E2, ch), Pq[2 * ch], Pq[2 * ch + 1]);
+        }
+        float own[2 * C];
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) own[i] = Pq[i];
+#define RH_CSCAN(K, N)                                                                             \
+    {                                                                                              \
+        float sq[2 * C];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2 * C; ++i) sq[i] = dpp0<kDppRowShr + N, 0xf>(Pq[i]); \
+        const float sM[4] = {readlane_f(U, 9 + 4 * K), readlane_f(U, 10 + 4 * K), readlane_f(U, 11 + 4 * K), readlane_f(U, 12 + 4 * K)}; \
+        _Pragma("unroll") for (int ch = 0; ch < C; ++ch) mat_acc(sM, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]); \
+    }
+        RH_CSCAN(0, 1)
+        RH_CSCAN(1, 2)
+        RH_CSCAN(2, 4)
+        RH_CSCAN(3, 8)
+#undef RH_CSCAN
+        {
+            float sq[2 * C];
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) sq[i] = dpp0<kDppBcast15, 0xa>(Pq[i]);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(b15, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]);
+        }
+        {
+            float sq[2 * C];
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) sq[i] = dpp0<kDppBcast31, 0xc>(Pq[i]);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) mat_acc(b31, sq[2 * ch], sq[2 * ch + 1], Pq[2 * ch], Pq[2 * ch + 1]);
+        }
+        {  // the tile aggregate: the short last run on top of the inclusive prefix of the lane before it
+            const int nl = (int)nl0;
+            float A[2 * C];
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) A[i] = 0.f;
+            if (nl >= 1) {
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) A[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own[i]), nl - 1));
+            }
+            if (nl >= 2) {
+                const float M[4] = {readfirstlane_f(pwv[0]), readfirstlane_f(pwv[1]), readfirstlane_f(pwv[2]), readfirstlane_f(pwv[3])};  // B^v
+                float xp[2 * C];
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) xp[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pq[i]), nl - 2));
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) mat_acc(M, xp[2 * ch], xp[2 * ch + 1], A[2 * ch], A[2 * ch + 1]);
+            }
+            if (lane < 2 * C) {
+                float ev = A[0];
+#pragma unroll
+                for (int i = 1; i < 2 * C; ++i) ev = lane == i ? A[i] : ev;
+                __hip_atomic_store(gran + (uint64_t)tile * 4 + (uint32_t)lane, ((unsigned long long)epoch << 32) | __float_as_uint(ev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        float Q[2 * C];
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) Q[i] = dpp0<kDppWaveShr1, 0xf>(Pq[i]);
+        // ---- the tile carry: lane j < J polls tile-1-j, weights it with B^(m_lo[tile] - m_lo[tile-j]) ----
+        float c[2 * C];
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) c[i] = 0.f;
+        if (tile > 0) {
+            const unsigned long long *gp = gran + (uint64_t)(tile - 1 - (want_look ? (uint32_t)lane : 0u)) * 4;
+            unsigned long long gv[2 * C];
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) gv[i] = 0;
+            bool ok = false;
+            uint32_t spins = 0;
+            while (true) {
+                if (want_look && !ok) {
+                    bool all = true;
+#pragma unroll
+                    for (int i = 0; i < 2 * C; ++i) {
+                        gv[i] = __hip_atomic_load(gp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        all = all && ((uint32_t)(gv[i] >> 32) == epoch);
+                    }
+                    ok = all;
+                }
+                if (__all(ok || !want_look)) break;
+                if (++spins > kSpinLimit) {
+                    if (lane == 0) atomicOr(status, 1u);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (lane == 0 && spins) atomicAdd(status + 1, spins);
+            if (want_look && ok && !dead) {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) mat_acc(kM, __uint_as_float((uint32_t)gv[2 * ch]), __uint_as_float((uint32_t)gv[2 * ch + 1]), c[2 * ch], c[2 * ch + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) {  // sum over lanes 0..31 -> uniform
+                c[i] += dpp0<kDppRowShr + 1, 0xf>(c[i]);
+                c[i] += dpp0<kDppRowShr + 2, 0xf>(c[i]);
+                c[i] += dpp0<kDppRowShr + 4, 0xf>(c[i]);
+                c[i] += dpp0<kDppRowShr + 8, 0xf>(c[i]);
+                c[i] = readlane_f(c[i], 15) + readlane_f(c[i], 31);
+            }
+        }
+        if (dead) {
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) c[i] = __builtin_nanf("");
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mat_acc(lM, c[2 * ch], c[2 * ch + 1], Q[2 * ch], Q[2 * ch + 1]);
+        RH_CLS_STAMP(4)
+        // the taps are in registers: the image is the loader's again
+        ctl_write(1, k + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float y = fma_(readlane_f(U, 25 + 2 * r), Q[2 * ch], fma_(readlane_f(U, 26 + 2 * r), Q[2 * ch + 1], CH::get(out[r], ch)));
+                CH::set(ytot[r], ch, CH::get(ytot[r], ch) + y);
+            }
+        }
+        RH_CLS_STAMP(5)
+    }
+    // ---- the sum leaves as whole lines through the ring (the loader has summed its last chunk: nothing is in flight into it) ----
+    {
+        constexpr uint32_t kRow = (R + 1) * FB;
+        static_assert(64 * kRow <= kCtl + 64 + 2 * kImg, "the rows fit the LDS (the ring, and behind it the images: everything is free now)");
+        lds_u8 *row = lds + (uint32_t)lane * kRow;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (C == 2) *(lds_f2 *)(row + r * FB) = v2f{CH::get(ytot[r], 0), CH::get(ytot[r], C - 1)};
+            else *(RH_LDS float *)(row + r * FB) = CH::get(ytot[r], 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float *ot = m.sum_out + ((uint64_t)m_lo + (uint32_t)lane) * C;  // this lane's frame of every group of 64
+        for (uint32_t f0 = 0; f0 < n_t; f0 += 64) {
+            const uint32_t f = f0 + (uint32_t)lane;
+            if (f < n_t) {
+                const lds_u8 *src2 = lds + (f / R) * kRow + (f % R) * FB;
+                if (C == 2) {
+                    const v2f a = *(const lds_f2 *)src2;
+                    *reinterpret_cast<float2 *>(ot + (uint64_t)f0 * 2) = make_float2(a.x, a.y);
+                } else {
+                    ot[f0] = *(const RH_LDS float *)src2;
+                }
+            }
+        }
+    }
+}
+#undef RH_PARG
+#undef RH_QARG
+
 // =================================================================================================
 // The (tile, source) pairs of a ragged filtered batch in which the source is NOT stable, i.e. ends inside the tile or within the J
 // tiles after it.  There are at most J+2 such tiles per source, so this part is small however large the batch: a tile finds its
@@ -2362,8 +2834,17 @@ static const void *chunk_multi_kernel(int R, uint32_t channels, int KV) {
     return nullptr;
 }
 
-rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, rh_stream stream, bool *taken) {
+static const void *chunk_classes_kernel(int R, uint32_t channels, int KV) {
+    if (channels == 2 && R == 18 && KV == 8) return reinterpret_cast<const void *>(&k_rlm_chunk_classes<18, 2, 8>);
+    if (channels == 2 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk_classes<18, 2, 4>);
+    if (channels == 1 && R == 18 && KV == 4) return reinterpret_cast<const void *>(&k_rlm_chunk_classes<18, 1, 4>);
+    if (channels == 1 && R == 18 && KV == 2) return reinterpret_cast<const void *>(&k_rlm_chunk_classes<18, 1, 2>);
+    return nullptr;
+}
+
+rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, float *dst_sum, rh_stream stream, bool *taken, bool *summed) {
     *taken = false;
+    *summed = false;
     if (n < 2 || n > kChunkMultiMax || rh::knob(rh::K_CLASSES_ONE_BY_ONE)) return RH_OK;
     const void *fn = nullptr;
     for (uint32_t k = 0; k < n; ++k) {
@@ -2386,9 +2867,32 @@ rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint6
     }
     void *args[] = {&m};
     hipStream_t s = rh::as_stream(stream);
-    const hipError_t e = hipLaunchKernel(fn, dim3(m.first[m.n]), dim3(64), args, 0, s);
+    // Classes of ONE geometry (equal lengths, one rate pair, one chunk size: one table of tile bounds) whose tiles fit the chip at once: a
+    // workgroup of two waves per tile walks the classes itself -- one wave loads, the other converts and filters (k_rlm_chunk_classes)
+    const void *fn2 = rh::knob(rh::K_CLASSES_ONE_WAVE) ? nullptr : chunk_classes_kernel(classes[0]->chunk.R, classes[0]->cfg.channels, classes[0]->chunk.KV);
+    bool same = fn2 != nullptr;
+    for (uint32_t k = 0; k < n && same; ++k) {
+        const rh_rlm *h = classes[k], *h0 = classes[0];
+        same = h->exclusive && h->eq_frames == h0->eq_frames && h->out_frames == h0->out_frames && h->F == h0->F && h->T == h0->T && h->chunk_in == h0->chunk_in &&
+               h->chunk_out == h0->chunk_out && h->chunk.n_tiles == h0->chunk.n_tiles && h->chunk.R == h0->chunk.R && h->chunk.KV == h0->chunk.KV && h->n_sources >= 1;
+    }
+    if (same) {
+        int per_cu = 0;
+        same = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn2, 128, 0) == hipSuccess && per_cu >= 1 &&
+               (uint64_t)classes[0]->chunk.n_tiles <= (uint64_t)per_cu * (uint64_t)rh::g_num_cus;
+    }
+    hipError_t e;
+    if (same) {
+        m.sum_out = dst_sum;
+        e = hipLaunchKernel(fn2, dim3(classes[0]->chunk.n_tiles), dim3(128), args, 0, s);
+        *summed = e == hipSuccess;
+    } else {
+        e = hipLaunchKernel(fn, dim3(m.first[m.n]), dim3(64), args, 0, s);
+        if (e == hipSuccess)
+            for (uint32_t k = 0; k < n; ++k) classes[k]->shard_base += (m.first[k + 1] - m.first[k]) / 8u;  // every counter of a class has handed out this many tickets
+    }
     if (e != hipSuccess) {
-        rh::set_hip_error(e, "k_rlm_chunk_multi launch");
+        rh::set_hip_error(e, "k_rlm_chunk_multi / k_rlm_chunk_classes launch");
         return RH_ERR_HIP;
     }
     for (uint32_t k = 0; k < n; ++k) mark_launch(classes[k], s);
@@ -2396,6 +2900,11 @@ rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint6
     return RH_OK;
 }
 
+#if defined(RH_CLS_DIAG) && RH_CLS_DIAG == 9
+extern "C" int rh_debug_cls_stamps(unsigned long long *dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cls_stamp), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch) {
     hipLaunchKernelGGL(k_rlm_state, dim3((n_sources + 63) / 64), dim3(64), 0, s, gran, tabs, n_sources, cols, last_col, J, epoch, next_epoch);
 }
@@ -2538,8 +3047,7 @@ rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint
             m.e[m.n].q = ca;
             m.first[m.n + 1] = m.first[m.n] + g8;
             m.n += 1;
-            p->shard_base += g8 / 8u;
-            return RH_OK;
+            return RH_OK;  // (the ticket counters advance in chunk_launch_classes, if the launch it decides on takes tickets)
         }
         const uint32_t cgrid = k.direct ? c.n_tiles : (c.n_tiles + 7u) & ~7u;  // by ticket: whole rounds of the eight counters (k_rlm_chunk)
         void *cargs[] = {&k, &ca};

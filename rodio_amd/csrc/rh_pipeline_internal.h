@@ -348,7 +348,8 @@ VariantTab variant_tab(TabKind kind, bool mono);             // the instances of
 const void *chunk_kernel(int R, uint32_t channels, int KV);  // the instance of k_rlm_chunk, or nullptr
 // The classes of a mixer with per-source filters as ONE launch of k_rlm_chunk_multi (class k's mix into rows[k]): *taken = false and nothing
 // done when a class does not take the k_rlm_chunk path, the classes' instances differ, or there are more than fit one kernarg segment
-rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, rh_stream stream, bool *taken);
+// (*summed: the launch added the classes' mixes itself, into dst_sum -- k_rlm_chunk_classes; the rows are then unwritten)
+rh_status chunk_launch_classes(rh_rlm *const *classes, float *const *rows, uint64_t row_capacity_frames, uint32_t n, float *dst_sum, rh_stream stream, bool *taken, bool *summed);
 // k_rlm_state on `s`: folds a block's aggregates into column 0 of the per-source rows (see rh_pipeline_stream.hip)
 void launch_state(hipStream_t s, unsigned long long *gran, const Tables *tabs, uint32_t n_sources, uint32_t cols, uint32_t last_col, uint32_t J, uint32_t epoch, uint32_t next_epoch);
 // k_rlm_state_sum on `s`: the sum of the live sources' states (column 0 of their rows, tagged `tag`) -> the 4 words of a summed state

@@ -812,10 +812,11 @@ static rh_status run_classes(rh_rlm *p, float *dst, uint64_t out_capacity_frames
             hs.push_back(live[k]->h);
             rows.push_back(p->d_cls_rows + k * p->cls_row_floats);
         }
-        bool taken = false;
-        const rh_status st = chunk_launch_classes(hs.data(), rows.data(), p->cls_row_floats / C, (uint32_t)hs.size(), stream, &taken);
+        bool taken = false, summed = false;
+        const rh_status st = chunk_launch_classes(hs.data(), rows.data(), p->cls_row_floats / C, (uint32_t)hs.size(), dst, stream, &taken, &summed);
         if (st != RH_OK) return st;
         p->cls_one_launch = taken;
+        if (summed) return mark_launch(p, rh::as_stream(stream));  // (the launch added the classes' mixes itself)
         if (taken) {
             for (size_t k = 0; k < live.size(); ++k) {
                 ptrs.push_back(rows[k]);

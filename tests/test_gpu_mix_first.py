@@ -380,17 +380,22 @@ def test_a_filter_per_source_in_the_fused_mixer(G, O, n_equal):
     p.close()
 
 
-@pytest.mark.parametrize("ch,n", [(2, 300_000), (1, 280_004)])
-def test_filter_classes_walked_in_one_launch(G, O, ch, n):
+@pytest.mark.parametrize("ch,n,many", [(2, 300_000, False), (1, 280_004, False), (2, 270_000, True)])
+def test_filter_classes_walked_in_one_launch(G, O, ch, n, many):
     """Round 6 (VERDICT r05 next #5a): a mixer whose sources carry different filters (`mixer.add(a.low_pass(200)); mixer.add(b.high_pass(300))`,
-    source/mod.rs:686-721, mixer.rs:58-66) where every class is long enough for k_rlm_chunk: ONE launch walks the classes (k_rlm_chunk_multi --
-    class k's workgroups behind class k-1's, each with its own arguments, tables and tickets), the classes' mixes are added behind it.  The
+    source/mod.rs:686-721, mixer.rs:58-66) where every class is long enough for k_rlm_chunk: ONE launch walks the classes (k_rlm_chunk_classes:
+    a workgroup of two waves per tile, one summing the tile's chunk class after class, the other converting and filtering behind it; or, for
+    classes of different geometry and under RH_CLASSES_ONE_WAVE=1, k_rlm_chunk_multi -- class k's workgroups behind class k-1's, each with its
+    own arguments, tables and tickets), the classes' mixes are added behind it.  The
     oracle's Mixer over the per-source chains; the same bits as one launch per class (RH_CLASSES_ONE_BY_ONE=1: the tile code is the same);
     geometry().mix_first says which form ran."""
     import torch
     from conftest import knobs
 
     filters = [("low_pass", 200), ("high_pass", 300), ("low_pass", 1000), ("high_pass", 300), ("low_pass", 200), ("low_pass", 1000), ("low_pass", 200)]
+    if many:  # seven classes (what one launch takes), two sources each, in mixed order
+        kinds = [("low_pass", 200), ("high_pass", 700), ("low_pass", 1000), ("high_pass", 2000), ("low_pass", 4000), ("low_pass", 500), ("high_pass", 1200)]
+        filters = kinds + kinds[::-1]
     S = len(filters)
     gains = np.linspace(0.5, 1.2, S).astype(np.float32)
     xs = [rnd(7300 + i, ch * n, 0.1) for i in range(S)]
@@ -414,14 +419,16 @@ def test_filter_classes_walked_in_one_launch(G, O, ch, n):
         assert np.array_equal(got, again)
         return got, how
 
-    one, how_one = run()
+    one, how_one = run()  # two waves a tile: one loads class after class, the other converts, filters and ADDS the classes' mixes (k_rlm_chunk_classes)
+    with knobs(RH_CLASSES_ONE_WAVE="1"):
+        lined, how_lined = run()  # the classes' launches lined up in one grid (k_rlm_chunk_multi)
     with knobs(RH_CLASSES_ONE_BY_ONE="1"):
         each, how_each = run()
-    assert how_one == 3 and how_each == 2, (how_one, how_each)
-    assert len(one) == len(ref) == len(each)
+    assert how_one == 3 and how_lined == 3 and how_each == 2, (how_one, how_lined, how_each)
+    assert len(one) == len(ref) == len(each) == len(lined)
     e = float(np.max(np.abs(one - ref)))
     print(f"[filter classes in one launch, {ch} ch] |gpu - oracle| = {e:.2e}")
-    assert e <= TOL and np.array_equal(one, each)
+    assert e <= TOL and np.array_equal(one, each) and np.array_equal(lined, each)
 
 
 def test_block_streaming_keeps_its_table_while_the_sources_move_together(G, O):
