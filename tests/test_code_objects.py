@@ -73,3 +73,27 @@ def test_the_agc_kernel_of_round_5_keeps_its_twelve_waves(tmp_path):
     v = ks[name]
     assert v["vgpr_count"] <= 168, v
     assert not v.get("sgpr_spill_count", 0), v
+
+
+OBJDUMP = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not found")
+def test_the_limiters_look_ahead_polls_are_not_read_before_their_wait(tmp_path):
+    """k_limit_scan requests the next tile's look-backs in front of the tile's DMA and collects them a tile's work later (rh_limit.hip, PollPair).
+    The loads are inline asm: the compiler does not know they are in flight, and a register copy or a spill of their destinations in front of
+    the counted wait would read what has not arrived (seen in a build that held them in vector types: scratch_store right behind the load)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from check_held_loads import check_text
+    for n, img in enumerate(code_objects()):
+        if b"k_limit_scan" not in img:
+            continue
+        f = tmp_path / f"co_{n}.elf"
+        f.write_bytes(img)
+        dis = subprocess.run([OBJDUMP, "-d", str(f)], capture_output=True, text=True, check=True).stdout
+        seen, loads, bad = check_text(dis, ["k_limit_scan"])
+        assert seen >= 16 and loads >= 100, (seen, loads)
+        assert not bad, bad[:3]
+        return
+    raise AssertionError("no code object holds k_limit_scan")
