@@ -1514,7 +1514,12 @@ __device__ __forceinline__ void rlm_chunk_tile(const Params &p, const ChunkArgs 
         tile = x + 8u * k;
         if (tile >= p.n_tiles) return;
     }
+#ifdef RH_CHUNK_RAGSIM  // diagnostics builds: the load profile of a ragged batch (lengths uniform in [N/2, N]) on the equal batch's data -- timing only
+    const uint32_t Ns = p.eq_frames;
+    const uint32_t S = 2u * tile < p.n_tiles ? p.n_sources : (uint32_t)(((uint64_t)p.n_sources * 2u * (p.n_tiles - tile)) / p.n_tiles);
+#else
     const uint32_t Ns = p.eq_frames, S = p.n_sources;
+#endif
     const uint32_t m_lo = ((cu32 *)(uintptr_t)q.m_lo)[tile], m_hi = ((cu32 *)(uintptr_t)q.m_lo)[tile + 1];
     const uint32_t m0 = m_lo + (uint32_t)lane * R;
     int nfl;  // frames of this lane's run
