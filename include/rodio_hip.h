@@ -298,6 +298,32 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host,
                      const uint64_t *start_host, const uint64_t *len_host, uint32_t n_sources,
                      rh_stream stream);
 
+/* ---- A block of a mixer of ANY channel count in ONE launch (mixer::mixer(nz!(6), rate): src/mixer.rs:25,185-198), for continuous
+ * sources (current_span_len() == None) of any rate and layout: per source Amplify (amplify.rs:64) -> SampleRateConverter
+ * (sample_rate.rs:131-201) -> ChannelCountConverter (channels.rs:57-85), i.e. UniformSourceIterator (uniform.rs:58-67), and the
+ * ordered sum.  Bit-identical to the chain of stand-alone calls (rh_amplify, rh_resample_linear / rh_uniform_segments,
+ * rh_channels_convert, rh_mix_sum) it replaces.  dst receives out_frames frames of `channels` floats: the frames m0 .. m0+out_frames-1
+ * of the mix, whatever m0 is -- the caller describes, per source, where those frames lie in what it holds:
+ *   data      device pointer to the source frame that holds the FIRST tap of output frame m0: frame floor(m0 F / T) of the source's
+ *             stream (F / T = from_rate / to_rate reduced), `channels` interleaved floats a frame
+ *   phase     (m0 F) mod T: where frame m0 lies between its taps
+ *   frames    output frames of this block the source reaches (<= out_frames): it is silent behind them (it has ended).  Both taps of
+ *             every one of them -- frames floor((phase + j F) / T) and the next, counted from data -- must be readable, except
+ *   last      ... that a source which has ENDED passes the index (counted from data) of its LAST frame: an output frame whose first
+ *             tap is that frame is emitted verbatim (sample_rate.rs:193-200) and its second tap is not read.  Live: UINT32_MAX.
+ * 4-byte alignment is all the rows need.  srcs_host is a host array, read before the call returns.  include/rodio_hip.hpp
+ * (GpuMixer, mixers of more than two channels) plans the blocks. */
+typedef struct rh_wide_src {
+    const float *data;
+    uint32_t channels, from_rate;
+    uint32_t phase;
+    uint64_t frames;
+    uint32_t last;
+    float gain;
+} rh_wide_src;
+rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uint64_t out_frames,
+                            const rh_wide_src *srcs_host, uint32_t n_sources, rh_stream stream);
+
 /* ---- BltFilter (low_pass / high_pass): src/source/blt.rs:502-544,558-560,397-492.
  * kind: 0 = low_pass, 1 = high_pass.  coeffs5 = {b0,b1,b2,a1,a2} (already divided by a0).
  * state (optional device pointer, 4*channels floats {x1,x2,y1,y2} per channel) carries the

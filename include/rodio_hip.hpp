@@ -32,6 +32,7 @@
 #include <exception>
 #include <memory>
 #include <mutex>
+#include <numeric>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -2209,13 +2210,18 @@ public:
         // device: rodio's samples, at the price of per-source launches.  false: every filter stays in the fused kernel (closer to the
         // exact response than rodio is; at low cutoffs further than 1e-5 from rodio).
         bool reference_exact_filters = true;
+        // Mixers of more than two channels: true = every source a chain of its own, whatever it is (the form of rounds 5; a comparison aid).
+        // false (default): a generation of plain continuous sources without filters converts and sums a block in one launch (rh_wide_mix_block)
+        bool wide_chains = false;
     };
     /// mixer::mixer(channels, sample_rate) (mixer.rs:25).  One and two channels: the sources are mixed as stereo frames by the fused
     /// kernel, and a mono mixer keeps channel 0 of the mix (ChannelCountConverter(2 -> 1) commutes with the sum: channels.rs:57-85).
-    /// MORE than two channels (a 5.1 mix): every source becomes a chain of its own on the device --
-    /// [amplify] -> UniformSourceIterator(channels, rate) -> [its filter] (GpuSource, the blocks staying in device memory) -- and the
-    /// mixer adds the chains' blocks in insertion order (rh_mix_sum): rodio's Mixer::add + MixerSource::next for any layout, without the
-    /// fused kernel (whose frames are mono or stereo).
+    /// MORE than two channels (a 5.1 mix): sources that join together and are all plain continuous ones without a filter (decoded assets,
+    /// generators: current_span_len() == None) are converted and summed a block at a time in ONE launch (rh_wide_mix_block: Amplify ->
+    /// SampleRateConverter -> ChannelCountConverter per source and the ordered sum, any rates and layouts side by side).  Anything else --
+    /// a filter, spans, a GpuSource chain -- becomes a chain of its own on the device, [amplify] -> UniformSourceIterator(channels, rate)
+    /// -> [its filter] (GpuSource, the blocks staying in device memory), and the mixer adds the chains' blocks in insertion order
+    /// (rh_mix_sum): rodio's Mixer::add + MixerSource::next for any layout, bit for bit either way.
     GpuMixer(std::uint16_t channels, std::uint32_t sample_rate, Options opt) : rate_(sample_rate), opt_(opt), out_ch_(channels), qch_(channels > 2 ? channels : 2) {
         if (!sample_rate || !channels) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         if (!opt_.block_frames) opt_.block_frames = 1;
@@ -2243,13 +2249,16 @@ public:
         const std::uint32_t from = src->sample_rate();
         if (!ch || !from) throw std::invalid_argument("channels and sample_rate are NonZero in rodio");
         if (filter.kind > 1) throw std::invalid_argument("filter kind");
-        if (wide()) {  // a mixer of more than two channels: the source's own chain, the mixer only sums
+        if (wide()) {  // a mixer of more than two channels: the source's own chain, the mixer only sums --
             Src item;
             item.up = std::move(src);
             item.gain = gain;
             item.ch = ch;
             item.filt = filter;
-            make_wide(item);
+            // ... unless the source is a plain continuous one without a filter: those stay as they are, and a generation of such sources
+            // converts and sums a block in ONE launch (rh_wide_mix_block; start_stream_wide decides)
+            item.fusew = !opt_.wide_chains && filter.kind < 0 && !dynamic_cast<GpuSource *>(item.up.get()) && !item.up->current_span_len().has_value() && !ratio_beyond_u32(from, rate_);
+            if (!item.fusew) make_wide(item);
             if (joins_a_running_mix()) late_join(std::move(item));
             else pending_.push_back(std::move(item));
             return;
@@ -2402,6 +2411,8 @@ public:
         for (const Src &x : pending_) count_chain(x, st);
         return st;
     }
+    /// Blocks of wide generations that ran as one launch (rh_wide_mix_block).
+    std::uint64_t wide_fused_blocks() const { return wide_fused_blocks_; }
     /// Output frame (of this mixer) at which the most recently started generation joined.
     std::uint64_t last_join_frame() const { return last_join_; }
     /// Threads that have pulled sources so far (1 until a block was large enough for the pool).
@@ -2601,6 +2612,10 @@ private:
         detail::UniformPlanner plan;
         std::uint64_t have_s = 0, off_s = 0;  // converted SAMPLES not yet mixed: `have_s` of them from sample `off_s` of the source's device row
         std::uint64_t total_s = 0;            // samples of the source's stream in the mixer's layout so far (where the generation tracks them: Gen::track)
+        // a wide mixer's plain sources (Gen::widefused): `held` starts at frame `wpos` of the source's stream; its reduced rates
+        bool fusew = false;
+        std::uint64_t wpos = 0;
+        std::uint32_t wF = 1, wT = 1;
         std::shared_ptr<HintTrack> hint;      // size_hint(): see HintTrack
         // a pull of `got` samples (ONE continuous span: the source reports none); `ended`: it returned None behind them
         void note_pull(std::size_t got, bool ended_now) {
@@ -2654,6 +2669,13 @@ private:
         // a generation of a wide mixer: every source a chain in the mixer's layout, summed by rh_mix_sum
         bool wide = false;
         detail::DeviceBuf drow;
+        // ... or, where every source is a plain continuous one (Src::fusew), ONE launch a block that converts and sums them (rh_wide_mix_block)
+        bool widefused = false;
+        std::uint64_t wm = 0, wend = 0;  // output frames planned so far; (once every source has ended) where the longest stream ends
+        std::size_t wrow = 0;            // floats per staged row
+        std::vector<rh_wide_src> wtab;   // the block that has been pulled: its sources as the launch sees them,
+        std::uint64_t wout = 0;          // its output frames,
+        bool wlast = false;              // and whether it is the generation's last
         // where the generation's stream lies in the mixer's and how it ended (enqueue(): the last block of a mix that ends inside a frame)
         std::uint64_t join = 0, emitted = 0;  // mixer frame of its first frame; frames it has produced
         bool track = false;                   // its sources' streams are counted in samples (Src::total_s)
@@ -2809,8 +2831,19 @@ private:
     void start_stream_wide(std::vector<Src> srcs, std::uint64_t join) {
         auto gp = std::make_unique<Gen>();
         Gen &g = *gp;
+        bool fused = !srcs.empty();
+        for (const Src &x : srcs) fused = fused && x.fusew;
+        for (Src &x : srcs) {
+            if (!fused && x.fusew) make_wide(x);  // (one chain among them: the rows of all are summed in insertion order by rh_mix_sum)
+            x.fusew = fused;
+            if (fused) {
+                const std::uint32_t from = x.up->sample_rate(), gc = std::gcd(from, rate_);
+                x.wF = from / gc, x.wT = rate_ / gc;
+            }
+        }
         g.srcs = std::move(srcs);
         g.wide = true;
+        g.widefused = fused;
         g.track = true;
         g.qch = qch_;
         g.join = join;
@@ -2902,7 +2935,9 @@ private:
         g.pd_prev = g.pd_prev < 0 && g.dnext == 0 ? -1 : g.pd;
         g.pd = g.dnext;
         g.dnext = (g.dnext + 1) % 3;
-        if (g.wide) {}  // (the chains pull their own upstreams, a block ahead)
+        if (g.wide) {  // (chains pull their own upstreams, a block ahead)
+            if (g.widefused) pull_block_widefused(g);
+        }
         else if (g.staged) pull_block_staged(g);
         else pull_block_direct(g);
         g.pulled = true;
@@ -2910,7 +2945,8 @@ private:
     void issue_block(Gen &g) {
         g.pulled = false;
         const std::uint64_t before = g.fill;
-        if (g.wide) issue_block_wide(g);
+        if (g.widefused) issue_block_widefused(g);
+        else if (g.wide) issue_block_wide(g);
         else if (g.staged) issue_block_staged(g);
         else issue_block_direct(g);
         g.emitted += g.fill - before;
@@ -2920,6 +2956,117 @@ private:
                     throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a chain ended inside a frame of its channel_volume's input: asked again, as rodio's mixer asks, ChannelVolume returns a frame of its "
                                                     "stale sum (channel_volume.rs:71-88)");
         if (g.done) g.finish();
+    }
+    /// A block of a wide generation of PLAIN sources (continuous, no filter: Src::fusew), host half.  Output frames g.wm .. of the mix are
+    /// planned here: every live source is pulled until both taps of frame g.wm + block_frames - 1 are there (sources of different rates
+    /// give different numbers of frames), the block emits what every live source can give -- everything once all have ended -- and one
+    /// pitched copy brings the rows `[what the block before left | the new frames]`, each in its source's own layout, to the device.
+    // (64-bit arithmetic throughout: m F is split at T, so nothing overflows however long the mixer has played)
+    static std::uint64_t wide_first_tap(std::uint64_t m, std::uint32_t F, std::uint32_t T) { return m / T * F + m % T * F / T; }  // floor(m F / T)
+    static std::uint64_t wide_ready(std::uint64_t n, std::uint32_t F, std::uint32_t T) {  // output frames a stream of n frames (so far) can give: both taps there
+        if (F == T || n == 0) return n;
+        const std::uint64_t a = n - 1;  // ceil(a T / F): the frames m with floor(m F / T) <= n - 2
+        return a / F * T + (a % F * T + F - 1) / F;
+    }
+    static std::uint64_t wide_total(std::uint64_t n, std::uint32_t F, std::uint32_t T) {  // ... of an ended one: + the verbatim last frame (sample_rate.rs:193-200)
+        if (F == T || n == 0) return n;
+        const std::uint64_t c1 = wide_ready(n, F, T);
+        return c1 + (wide_first_tap(c1, F, T) < n ? 1 : 0);  // (the next frame's first tap is the last frame: it lands on it)
+    }
+    static bool ratio_beyond_u32(std::uint32_t from, std::uint32_t to) {  // the reference multiplies in u32 (sample_rate.rs:157,173)
+        const std::uint32_t gc = std::gcd(from, to);
+        return (std::uint64_t)(from / gc) * (to / gc) > 0xffffffffull;
+    }
+    void pull_block_widefused(Gen &g) {
+        const std::size_t S = g.srcs.size();
+        const std::uint64_t m0 = g.wm, target = m0 + opt_.block_frames;
+        // frames every live source must hold for the block, and the row that fits them all
+        std::vector<std::uint64_t> need(S, 0);
+        std::size_t roww = 4;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            const std::uint64_t have = x.held.size() / x.ch;
+            need[i] = x.ended ? x.wpos + have : (x.wF == x.wT ? target : wide_first_tap(target - 1, x.wF, x.wT) + 2);
+            const std::uint64_t fr = std::max(need[i], x.wpos + have) - x.wpos;
+            roww = std::max<std::size_t>(roww, ((std::size_t)fr * x.ch + 3) & ~std::size_t(3));
+        }
+        g.wrow = roww;
+        detail::PinnedBuf &stage = g.stage[g.pslot];
+        stage.reset(S * roww);
+        detail::DeviceBuf &din = g.din[g.pd];
+        din.reset(S * roww);
+        pull_sources(S * opt_.block_frames, S, [&](std::size_t i) {
+            Src &x = g.srcs[i];
+            const std::size_t ch = x.ch;
+            float *row = stage.get() + i * roww;
+            std::size_t have = x.held.size();
+            if (have) std::memcpy(row, x.held.data(), have * sizeof(float));
+            if (!x.ended && need[i] > x.wpos + have / ch) {
+                const std::size_t want = (std::size_t)(need[i] - x.wpos - have / ch) * ch;
+                if (x.hint && !x.hint->chain) x.hint->log.note(x.hint->pulled, x.up->size_hint());
+                const std::size_t got = x.up->read(row + have, want);
+                x.ended = got < want;
+                x.note_pull(got, x.ended);
+                if (got % ch) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
+                have += got;
+            }
+            x.held.assign(row, row + have);  // (what the block does not consume stays; dropped below, once the block is planned)
+        });
+        // what the block emits
+        bool any_live = false;
+        std::uint64_t m_end = target, longest = 0;
+        for (const Src &x : g.srcs) {
+            const std::uint64_t n = x.wpos + x.held.size() / x.ch;
+            if (x.ended) longest = std::max(longest, wide_total(n, x.wF, x.wT));
+            else any_live = true, m_end = std::min(m_end, wide_ready(n, x.wF, x.wT));
+        }
+        if (!any_live) m_end = std::min(target, longest);
+        if (m_end < m0) m_end = m0;
+        const std::uint64_t out = m_end - m0;
+        g.wout = out;
+        g.wlast = !any_live && m_end >= longest;
+        g.wend = longest;
+        g.wtab.assign(S, rh_wide_src{});
+        std::size_t width = 0;
+        for (std::size_t i = 0; i < S; ++i) {
+            Src &x = g.srcs[i];
+            const std::uint64_t have = x.held.size() / x.ch, n = x.wpos + have;
+            const std::uint64_t i0 = wide_first_tap(m0, x.wF, x.wT);
+            rh_wide_src &d = g.wtab[i];
+            const std::uint64_t end = x.ended ? wide_total(n, x.wF, x.wT) : m_end;
+            d.frames = std::min(end, m_end) > m0 ? std::min(end, m_end) - m0 : 0;
+            d.data = d.frames ? din.get() + i * roww + (std::size_t)(i0 - x.wpos) * x.ch : nullptr;  // (i0 >= wpos: the block before dropped up to its own i(m_end) only)
+            d.channels = x.ch;
+            d.from_rate = x.up->sample_rate();
+            d.phase = (std::uint32_t)(m0 % x.wT * x.wF % x.wT);
+            d.last = x.ended ? (std::uint32_t)(n ? n - 1 - std::min(i0, n - 1) : 0) : 0xffffffffu;
+            d.gain = x.gain;
+            if (d.frames) width = std::max<std::size_t>(width, (std::size_t)have * x.ch);
+            if (x.ended && g.wlast) x.total_s = wide_total(n, x.wF, x.wT) * qch_;
+            // the frames in front of the next block's first tap are done with
+            const std::uint64_t keep_from = std::min(wide_first_tap(m_end, x.wF, x.wT), n);
+            if (keep_from > x.wpos) {
+                x.held.erase(x.held.begin(), x.held.begin() + (std::ptrdiff_t)((keep_from - x.wpos) * x.ch));
+                x.wpos = keep_from;
+            }
+            if (x.ended && x.hint && (!d.frames || std::min(end, m_end) == end)) x.hint->total_known = true, x.hint->total = wide_total(n, x.wF, x.wT) * qch_;
+        }
+        g.wm = m_end;
+        if (width) check(rh_memcpy_h2d_rows(din.get(), stage.get(), roww * sizeof(float), width * sizeof(float), S, copy_stream_), "rh_memcpy_h2d_rows");
+        check(rh_event_record(g.copied[g.pslot].get(), copy_stream_), "rh_event_record");
+    }
+    /// ... and its device half: the one launch (per source Amplify -> SampleRateConverter -> ChannelCountConverter, and the ordered sum)
+    /// behind what the queue holds.
+    void issue_block_widefused(Gen &g) {
+        check(rh_stream_wait_event(stream_, g.copied[g.pslot].get()), "rh_stream_wait_event");
+        const std::uint64_t out = g.wout;
+        if (out > out_cap_frames_ * 2 - g.fill - g.head) throw Error(RH_ERR_CAPACITY, "GpuMixer: the queue of a wide generation");
+        if (out) {
+            check(rh_wide_mix_block(g.queue_end(), (std::uint32_t)qch_, rate_, out, g.wtab.data(), (std::uint32_t)g.wtab.size(), stream_), "rh_wide_mix_block");
+            ++wide_fused_blocks_;
+        }
+        g.fill += out;
+        g.done = g.wlast;
     }
     /// A block of a wide generation: up to block_frames frames of every chain, device to device into a row each, and the ordered sum
     /// of the rows (mixer.rs:185-198) behind what the queue holds.  A chain that ends inside a frame has its last frame completed with
@@ -3357,6 +3504,7 @@ private:
     bool device_chains_ = false;     // a chain hands its blocks over on the device: its scan kernels' failure word is read per block
     std::unique_ptr<Reaper> reaper_;
     ChainStats retired_chains_;
+    std::uint64_t wide_fused_blocks_ = 0;
     detail::DeviceBuf dout_;         // the mixed block in the mixer's channel layout (channels != 2)
     std::vector<Src> pending_;
     std::vector<std::unique_ptr<Gen>> gens_;

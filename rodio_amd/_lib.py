@@ -44,6 +44,10 @@ class UniformSeg(C.Structure):
                 ("span_frames", C.c_uint64), ("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("from_ch", C.c_uint32), ("to_ch", C.c_uint32), ("gain", C.c_float), ("reserved", C.c_uint32)]
 
 
+class WideSrc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("channels", C.c_uint32), ("from_rate", C.c_uint32), ("phase", C.c_uint32), ("frames", C.c_uint64), ("last", C.c_uint32), ("gain", C.c_float)]
+
+
 class RlmConfig(C.Structure):
     _fields_ = [("from_rate", C.c_uint32), ("to_rate", C.c_uint32), ("channels", C.c_uint32),
                 ("span_len", C.c_uint64), ("filter_kind", C.c_int32), ("filter_freq", C.c_uint32),
@@ -125,6 +129,7 @@ SIGNATURES = {
     "rh_uniform_segments": (i32, [C.POINTER(UniformSeg), u32, vp]),
     "rh_uniform_segments_dev": (i32, [vp, u32, u64, vp]),
     "rh_mix_sum": (i32, [vp, sz, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), u32, vp]),
+    "rh_wide_mix_block": (i32, [vp, u32, u32, u64, C.POINTER(WideSrc), u32, vp]),
     "rh_biquad_coeffs": (i32, [i32, u32, f32, u32, f32p]),
     "rh_biquad": (i32, [vp, vp, u64, u32, u32, f32p, vp, i32, vp]),
     "rh_limit": (i32, [vp, vp, u64, u32, u32, u32, C.POINTER(LimitParams), vp, vp]),

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librodio_hip.so")
-SOURCES = ["rh_runtime.hip", "rh_elementwise.hip", "rh_resample.hip", "rh_recurrence.hip", "rh_limit.hip", "rh_agc.hip", "rh_biquad_scan.hip", "rh_stream.hip", "rh_uniform.hip", "rh_formats.hip", "rh_wav.hip", "rh_comm.hip", "rh_pipeline.hip", "rh_pipeline_plan.hip", "rh_pipeline_stream.hip", "rh_pipeline_sblk.hip"]
+SOURCES = ["rh_runtime.hip", "rh_elementwise.hip", "rh_resample.hip", "rh_recurrence.hip", "rh_limit.hip", "rh_agc.hip", "rh_biquad_scan.hip", "rh_stream.hip", "rh_uniform.hip", "rh_widemix.hip", "rh_formats.hip", "rh_wav.hip", "rh_comm.hip", "rh_pipeline.hip", "rh_pipeline_plan.hip", "rh_pipeline_stream.hip", "rh_pipeline_sblk.hip"]
 # -ffp-contract=off: the reference's f32 expressions (lerp, biquad, mixer sum) must not be
 # fused; kernels that want an FMA spell it __builtin_fmaf.
 # -fno-slp-vectorize: hipcc's SLP pass pairs the two stereo channels into v_pk_*_f32; on gfx950

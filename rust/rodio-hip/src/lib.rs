@@ -1390,6 +1390,11 @@ impl GpuMixer {
         st
     }
     /// Output frame (of this mixer) at which the most recently started generation joined.
+    /// Blocks of generations of MORE than two channels that ran as one launch (`rh_wide_mix_block`, declared in [`ffi`]: Amplify ->
+    /// SampleRateConverter -> ChannelCountConverter per source and the ordered sum, any layouts side by side).  The C++ mirror plans such
+    /// blocks (`GpuMixer::pull_block_widefused` of include/rodio_hip.hpp); this twin still forms every mix in stereo and widens it once
+    /// (see `with_channels`), so it never issues one: always 0 here.  INTEGRATION.md section 1 lists the difference.
+    pub fn wide_fused_blocks(&self) -> u64 { 0 }
     pub fn last_join_frame(&self) -> u64 { self.last_join }
     /// Threads that pull a block's sources.
     pub fn pull_threads(&self) -> u32 {

@@ -159,6 +159,41 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs, const
     }
     return RH_OK;
 }
+rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uint64_t out_frames, const rh_wide_src *srcs, uint32_t n, rh_stream) {  // amplify.rs:64, sample_rate.rs:131-201, channels.rs:57-85, mixer.rs:185-198
+    if (out_frames == 0) return RH_OK;
+    if (!dst || !channels || !to_rate || (n && !srcs)) return RH_ERR_INVALID;
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!srcs[s].frames) continue;
+        if (!srcs[s].data || !srcs[s].channels || !srcs[s].from_rate || srcs[s].frames > out_frames) return RH_ERR_INVALID;
+        const uint32_t g = std::gcd(srcs[s].from_rate, to_rate);
+        if ((uint64_t)(srcs[s].from_rate / g) * (to_rate / g) > 0xffffffffull) return RH_ERR_UNSUPPORTED;
+        if (srcs[s].phase >= to_rate / g) return RH_ERR_INVALID;
+    }
+    for (uint64_t j = 0; j < out_frames; ++j)
+        for (uint32_t c = 0; c < channels; ++c) {
+            float sum = 0.0f;
+            for (uint32_t s = 0; s < n; ++s) {
+                const rh_wide_src &x = srcs[s];
+                if (j >= x.frames) continue;
+                const uint32_t g = std::gcd(x.from_rate, to_rate), F = x.from_rate / g, T = to_rate / g;
+                const uint64_t p = (uint64_t)x.phase + j * F, i = p / T;
+                const uint32_t num = (uint32_t)(p - i * T);
+                float v = 0.0f;
+                if (c < x.channels || (c == 1 && x.channels == 1)) {
+                    const uint32_t k = c < x.channels ? c : 0;
+                    const float a = x.data[i * x.channels + k] * x.gain;
+                    v = a;
+                    if (F != T && i < x.last) {
+                        const float b = x.data[(i + 1) * x.channels + k] * x.gain;
+                        v = a + (b - a) * (float)num / (float)T;
+                    }
+                }
+                sum += v;
+            }
+            dst[j * channels + c] = sum;
+        }
+    return RH_OK;
+}
 rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, float threshold, rh_stream) {  // distortion.rs:66-72
     if (!(threshold >= 0.0f)) return RH_ERR_INVALID;  // (f32::clamp panics on min > max and on NaN)
     for (size_t i = 0; i < n; ++i) {

@@ -565,6 +565,7 @@ int main(int argc, char **argv) {
             const uint32_t to = (uint32_t)std::atoll(argv[5]);
             rh::GpuMixer::Options opt;
             opt.block_frames = block_arg(argv[6]);
+            opt.wide_chains = std::getenv("RH_TEST_WIDE_CHAINS") != nullptr;  // (a comparison aid: every source of a wide mixer a chain of its own)
             const bool on_device = std::atoi(argv[7]) != 0;
             std::FILE *sf = std::fopen((dir + "/spec.txt").c_str(), "r");
             if (!sf) throw std::runtime_error("spec.txt");
@@ -600,9 +601,10 @@ int main(int argc, char **argv) {
             const rh::GpuMixer::ChainStats cs = mixer.chain_stats();  // (the chains themselves are gone with their generation)
             std::FILE *st = std::fopen((dir + "/stats.txt").c_str(), "w");
             if (st) {
-                std::fprintf(st, "{\"chains\": %llu, \"chains_on_device\": %llu, \"chain_d2h_samples\": %llu, \"chain_device_samples\": %llu, \"first_read_seconds\": %.6f, \"prepare_seconds\": %.6f}\n",
+                std::fprintf(st, "{\"chains\": %llu, \"chains_on_device\": %llu, \"chain_d2h_samples\": %llu, \"chain_device_samples\": %llu, \"first_read_seconds\": %.6f, \"prepare_seconds\": %.6f, "
+                                 "\"wide_fused_blocks\": %llu}\n",
                              (unsigned long long)cs.chains, (unsigned long long)cs.on_device, (unsigned long long)cs.d2h_samples, (unsigned long long)cs.device_samples, first_read,
-                             mixer.timing().first_advance_s);
+                             mixer.timing().first_advance_s, (unsigned long long)mixer.wide_fused_blocks());
                 std::fclose(st);
             }
         } else if (mode == "chain" && argc >= 6) {

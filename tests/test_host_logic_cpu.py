@@ -97,6 +97,15 @@ def test_mixers_of_more_than_two_channels(O, tmp_path, fake, mixer_ch, block, ki
     M.test_gpu_mixer_of_more_than_two_channels(O, tmp_path, mixer_ch, block, kind)
 
 
+@pytest.mark.parametrize("mixer_ch,block", [(6, 4096), (8, 1000), (3, 65536)])
+def test_wide_generation_in_one_launch_a_block(O, tmp_path, fake, mixer_ch, block):
+    M.test_gpu_mixer_wide_generation_in_one_launch_a_block(O, tmp_path, mixer_ch, block)
+
+
+def test_wide_generation_with_one_chain_among_the_plain_sources(O, tmp_path, fake):
+    M.test_gpu_mixer_wide_generation_with_one_chain_among_the_plain_sources(O, tmp_path)
+
+
 @pytest.mark.parametrize("on_device", [True, False])
 def test_six_channels_filters_and_chains(O, tmp_path, fake, on_device):
     M.test_gpu_mixer_of_six_channels_filters_and_chains(O, tmp_path, on_device)

@@ -14,7 +14,7 @@ SCALARS = {
     "core::ffi::c_char": "char", "RhStatus": "rh_status", "RhStream": "rh_stream", "RhEvent": "rh_event",
 }
 STRUCTS = {"RhRlm": "rh_rlm", "RhRlmConfig": "rh_rlm_config", "RhEcho": "rh_echo", "RhResampler": "rh_resampler", "RhLimitParams": "rh_limit_params",
-           "RhAgcParams": "rh_agc_params", "RhComm": "rh_comm", "RhWavInfo": "rh_wav_info", "RhRlmGeometryInfo": "rh_rlm_geometry_info", "RhUniformSeg": "rh_uniform_seg"}
+           "RhAgcParams": "rh_agc_params", "RhComm": "rh_comm", "RhWavInfo": "rh_wav_info", "RhRlmGeometryInfo": "rh_rlm_geometry_info", "RhUniformSeg": "rh_uniform_seg", "RhWideSrc": "rh_wide_src"}
 CRATE = os.path.join(ROOT, "rust", "rodio-hip")
 
 
