@@ -771,6 +771,17 @@ def headline(args, argv):
                     "what": f"the headline's {S} resident sources through rh_rlm_stream_block_v in blocks of {B} input frames; one call = one whole stream = the headline's bytes"}
                 sp.close()
                 del so
+            try:  # a block of a 5.1 mixer in one launch (rh_wide_mix_block) beside the chain of stand-alone launches it replaces
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import bench_wide
+
+                wm = bench_wide.measure(16, 16384, 6, 44100, 48000, 30)
+                side_legs["wide"] = {"ms": wm["new"], "ms_chain_of_launches": wm["old"], "frac": wm["algorithmic_bytes"] / (wm["new"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "bit_identical_to_chain": wm["bit_identical_to_chain"], "parity_ok": bool(wm["oracle_ok"]) and wm["bit_identical_to_chain"],
+                                     "vs": "the oracle's mixer on the block's first 2048 frames, bit for bit; the whole block against the chain of stand-alone launches",
+                                     "what": "one block of mixer::mixer(6, 48 kHz): 16 resident 5.1 sources at 44.1 kHz, amplify -> convert -> ordered sum, 16384 frames (a short launch-bound kernel: see ms)"}
+            except Exception as e:  # noqa: BLE001
+                side_legs["wide"] = {"error": str(e)[:200]}
             for cfg_ in ("3", "5"):
                 a2 = copy.copy(args)
                 a2.config, a2.steps, a2.warmup, a2.no_cpu_baseline = cfg_, 10, 2, False

@@ -23,6 +23,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kWideChunk = 32;  // sources a launch
+constexpr int kWideGroup = 4;        // ... walked in groups of this many, whose tap loads leave together
 constexpr uint32_t kWideRates = 4;   // ... of at most this many different (rate, phase) pairs: the position of an output frame between its taps is worked out once per pair
 
 struct WideRate {
@@ -37,20 +38,33 @@ struct WideDesc {
     uint32_t last;      // ended sources: index (relative to data) of the LAST frame; live ones: 0xffffffff
     uint32_t rate;      // index into WideTable::r
     float gain;
-    uint32_t pad;
+    float Tf;           // T of its rate as a float; 0: the converter passes through (F == T, sample_rate.rs:133-136)
 };
 struct WideTable {
     WideRate r[kWideRates];
     WideDesc d[kWideChunk];
 };
 
-// The sources are walked in groups of four whose loads leave together: a lane's additions stay in insertion order (the reference's rounding
+// The sources are walked in groups of kWideGroup whose loads leave together: a lane's additions stay in insertion order (the reference's rounding
 // sequence), but nothing about one source's taps depends on the sum so far.  A source that does not reach the sample -- it has ended, or the
 // channel is one it does not have -- reads its own first float and adds +0.0, which leaves a sum that started at +0.0 as it is.
 template <bool CONT>
 __global__ __launch_bounds__(kBlock) void k_wide_mix(float *__restrict__ dst, uint32_t to_ch, uint32_t out_frames, const WideTable tbl, uint32_t n_sources) {
     const uint64_t total = (uint64_t)out_frames * to_ch;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    {
+        // The table lies in the kernel-argument segment and is read through the scalar cache, descriptor after descriptor: the first wave of
+        // a CU would miss on every line of it in turn (measured: 0.39 us per source, 12.5 us for a table of 32 -- whatever the block's length).
+        // One word of every line is asked for HERE, all requests in flight at once: one round trip, and the walk below hits.
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&tbl);
+        constexpr uint32_t kLines = (sizeof(WideTable) + 63) / 64;
+        uint32_t t[kLines], touch = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kLines; ++q) t[q] = w[q * 16u];
+#pragma unroll
+        for (uint32_t q = 0; q < kLines; ++q) touch |= t[q];
+        asm volatile("" ::"s"(touch));
+    }
     for (uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += stride) {
         const uint32_t j = (uint32_t)(o / to_ch);
         const uint32_t c = (uint32_t)(o - (uint64_t)j * to_ch);
@@ -63,27 +77,28 @@ __global__ __launch_bounds__(kBlock) void k_wide_mix(float *__restrict__ dst, ui
             w[q] = (float)(p - il[q] * tbl.r[q].T);
         }
         float acc = CONT ? dst[o] : 0.0f;
-        for (uint32_t s0 = 0; s0 < n_sources; s0 += 4) {  // (host: n_sources is a multiple of 4)
-            float a[4], b[4], wv[4], Tf[4], g[4];
-            bool on[4], lerp[4];
+        // (two groups in flight -- the taps of the group behind requested before the group in front is added -- and groups of eight were
+        //  measured: no faster.  At block sizes a launch is a few waves per CU walking the table; 0.27 us per source is their instruction stream.)
+        for (uint32_t s0 = 0; s0 < n_sources; s0 += kWideGroup) {  // (host: n_sources is a whole number of groups)
+            float a[kWideGroup], b[kWideGroup], wv[kWideGroup], Tf[kWideGroup], g[kWideGroup];
+            bool on[kWideGroup], lerp[kWideGroup];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kWideGroup; ++u) {
                 const WideDesc d = tbl.d[s0 + u];
                 const uint32_t q = d.rate;
                 const uint32_t i = q == 0 ? il[0] : (q == 1 ? il[1] : (q == 2 ? il[2] : il[3]));
                 wv[u] = q == 0 ? w[0] : (q == 1 ? w[1] : (q == 2 ? w[2] : w[3]));
-                const WideRate r = tbl.r[q];
-                Tf[u] = r.Tf;
+                Tf[u] = d.Tf;
                 g[u] = d.gain;
                 const uint32_t k = c < d.ch ? c : 0u;                         // channels.rs:59-70: k < from: the input channel; k == 1 of a mono source: its only one;
                 on[u] = j < d.frames && (c < d.ch || (c == 1u && d.ch == 1u));  // otherwise 0.0
-                lerp[u] = on[u] && r.F != r.T && i < d.last;
+                lerp[u] = on[u] && d.Tf != 0.0f && i < d.last;
                 const float *pa = d.data + (on[u] ? (uint64_t)i * d.ch + k : 0ull);
                 a[u] = *pa;
                 b[u] = pa[lerp[u] ? d.ch : 0u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kWideGroup; ++u) {
                 const float x = a[u] * g[u];  // Amplify (amplify.rs:64) in front of the converter
                 float v = x;
                 if (lerp[u]) {
@@ -132,9 +147,9 @@ rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uin
         };
         clear_rates();
         auto launch = [&]() {
-            while (k % 4) {  // whole groups of four: slots that reach no frame (and point at something readable: the first source's first tap)
+            while (k % kWideGroup) {  // whole groups: slots that reach no frame (and point at something readable: the first source's first tap)
                 WideDesc &d = tbl.d[k++];
-                d = WideDesc{tbl.d[0].data, 1u, 0u, 0u, 0u, 0.0f, 0u};
+                d = WideDesc{tbl.d[0].data, 1u, 0u, 0u, 0u, 0.0f, 0.0f};
             }
             const uint64_t total = (uint64_t)nf * channels;
             const dim3 grid(rh::grid_for((size_t)total, kBlock, 256u * 16u));
@@ -165,7 +180,7 @@ rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uin
             d.last = x.last == 0xffffffffu ? 0xffffffffu : (x.last >= i0 ? (uint32_t)(x.last - i0) : 0u);
             d.rate = q;
             d.gain = x.gain;
-            d.pad = 0;
+            d.Tf = red[s].F == red[s].T ? 0.0f : (float)red[s].T;
             if (k == kWideChunk) launch();
         }
         if (k || !cont) launch();  // (no source reaches these frames: the mix is +0.0 there)
