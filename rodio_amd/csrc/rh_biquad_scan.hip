@@ -184,8 +184,13 @@ __device__ __forceinline__ void bq_tile(BqArgsC kargs, v4f *lds, const v4f *halo
         for (int i = 0; i < 4; ++i) {
             const int r = (4 * j + i) / C, c = (4 * j + i) % C;
             const float x = e[i];
+#ifdef RH_BQ_NO_ARITH  // diagnostics builds (tools/build_scan_variant.sh; wrong results, timing only): the per-sample recurrence, the scans and the correction deleted
+            const float w = x1[c];
+            yz[r][c] = x;
+#else
             const float w = fma_(a.na1, w1[c], fma_(a.na2, w2[c], fma_(a.c2, x2[c], a.c1 * x1[c])));
             yz[r][c] = fma_(a.b0, x, w);
+#endif
             if (FULL || (uint32_t)r < nfl) {
                 w2[c] = w1[c];
                 w1[c] = w;
@@ -204,7 +209,9 @@ __device__ __forceinline__ void bq_tile(BqArgsC kargs, v4f *lds, const v4f *halo
         for (int c = 0; c < C; ++c) {
             P[c][0] = P[c][1] = 0.0f;
             mat_acc(a.Tm, w1[c], w2[c], P[c][0], P[c][1]);
+#ifndef RH_BQ_NO_ARITH
             scan_mat(P[c][0], P[c][1], a.scanM, b15, b31);
+#endif
             Q[c][0] = dpp0<kWaveShr1, 0xf>(P[c][0]);  // exclusive: lane 0 gets 0
             Q[c][1] = dpp0<kWaveShr1, 0xf>(P[c][1]);
             if (lane == 63) xZ[wave][2 * c] = P[c][0], xZ[wave][2 * c + 1] = P[c][1];
@@ -260,7 +267,11 @@ __device__ __forceinline__ void bq_tile(BqArgsC kargs, v4f *lds, const v4f *halo
             }
         }
         const float *pr = gstream + (real ? (uint64_t)idx : 0) * G;
+#ifdef RH_BQ_NO_LOOKBACK  // diagnostics builds: no tile looks at the tiles in front of it
+        bool have = true;
+#else
         bool have = !real;
+#endif
         uint32_t spins = 0;
         while (true) {
             if (!have) {
@@ -316,7 +327,11 @@ __device__ __forceinline__ void bq_tile(BqArgsC kargs, v4f *lds, const v4f *halo
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (4 * j + i) / C, c = (4 * j + i) % C;
+#ifdef RH_BQ_NO_ARITH
+            e[i] = yz[r][c] + Q[c][0];
+#else
             e[i] = fma_(a.g[r][0], Q[c][0], fma_(a.g[r][1], Q[c][1], yz[r][c]));
+#endif
         }
         v.x = e[0], v.y = e[1], v.z = e[2], v.w = e[3];
         lds[slot_of<V>(lane, j)] = v;

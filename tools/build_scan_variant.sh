@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function"
 objs=""
-for f in rh_runtime rh_elementwise rh_resample rh_recurrence rh_stream rh_uniform rh_formats rh_wav rh_comm rh_pipeline rh_pipeline_plan rh_pipeline_stream; do objs="$objs rodio_amd/build/$f.o"; done
+for f in rh_runtime rh_elementwise rh_resample rh_recurrence rh_stream rh_uniform rh_widemix rh_formats rh_wav rh_comm rh_pipeline rh_pipeline_plan rh_pipeline_stream rh_pipeline_sblk; do objs="$objs rodio_amd/build/$f.o"; done
 for f in rh_limit rh_biquad_scan rh_agc; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c rodio_amd/csrc/$f.hip -o variants/obj_$name/$f.o &
   objs="$objs variants/obj_$name/$f.o"
