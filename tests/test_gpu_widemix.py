@@ -163,3 +163,72 @@ def test_wide_mix_arguments(rh):
     assert f(C.c_void_p(d.data_ptr()), 6, 48000, 4, s, 1, None) == 1
     s[0].phase, s[0].from_rate = 0, 4294967291  # F * T beyond u32 (sample_rate.rs:157)
     assert f(C.c_void_p(d.data_ptr()), 6, 48000, 4, s, 1, None) == 3  # RH_ERR_UNSUPPORTED
+
+
+def _one_shot(rh, srcs, to_ch, to_rate):
+    """Every source whole and ended: ONE call of rh_wide_mix_block gives the whole mix."""
+    rng = np.random.default_rng(0)
+    return _run(rh, srcs, to_ch, to_rate, rng, feed=1 << 20)
+
+
+def test_wide_mix_replays_the_references_own_vectors(rh):
+    """The numbers rodio's tests hold for the three iterators this kernel folds into one -- through the kernel, not through the oracle:
+    src/mixer.rs:208-256 (basic, channels_conv, rate_conv), src/conversions/sample_rate.rs:356-387, src/conversions/channels.rs:114-143
+    (a SamplesBuffer of a few samples is one span: the same stream as a continuous source)."""
+    f = np.float32
+    a, b = f([10.0, -10.0, 10.0, -10.0]), f([5.0, 5.0, 5.0, 5.0])
+    assert _one_shot(rh, [(a, 1, 48000, 1.0), (b, 1, 48000, 1.0)], 1, 48000).tolist() == [15.0, -5.0, 15.0, -5.0]                               # mixer.rs:208-222
+    assert _one_shot(rh, [(a, 1, 48000, 1.0), (b, 1, 48000, 1.0)], 2, 48000).tolist() == [15.0, 15.0, -5.0, -5.0, 15.0, 15.0, -5.0, -5.0]       # :224-242
+    assert _one_shot(rh, [(a, 1, 48000, 1.0), (b, 1, 48000, 1.0)], 1, 96000).tolist() == [15.0, 5.0, -5.0, 5.0, 15.0, 5.0, -5.0]                 # :244-256
+    out = _one_shot(rh, [(f([2.0, 16.0, 4.0, 18.0, 6.0, 20.0, 8.0, 22.0]), 2, 2000, 1.0)], 2, 3000)                                               # sample_rate.rs:356-366
+    assert np.trunc(out).tolist() == [2.0, 16.0, 3.0, 17.0, 4.0, 18.0, 6.0, 20.0, 7.0, 21.0, 8.0, 22.0]
+    assert np.trunc(_one_shot(rh, [(f([1.0, 14.0]), 1, 1000, 1.0)], 1, 7000)).tolist() == [1.0, 2.0, 4.0, 6.0, 8.0, 10.0, 12.0, 14.0]             # :368-376
+    assert _one_shot(rh, [(np.arange(17, dtype=f), 1, 12000, 1.0)], 1, 2400).tolist() == [0.0, 5.0, 10.0, 15.0]                                   # :378-387
+    assert _one_shot(rh, [(f([1, 2, 3, 4, 5, 6]), 3, 1, 1.0)], 2, 1).tolist() == [1, 2, 4, 5]                                                     # channels.rs:114-143
+    assert _one_shot(rh, [(f([1, 2, 3, 4, 5, 6, 7, 8]), 4, 1, 1.0)], 1, 1).tolist() == [1, 5]
+    assert _one_shot(rh, [(f([1, 2, 3, 4]), 1, 1, 1.0)], 2, 1).tolist() == [1, 1, 2, 2, 3, 3, 4, 4]
+    assert _one_shot(rh, [(f([1, 2]), 1, 1, 1.0)], 4, 1).tolist() == [1, 1, 0, 0, 2, 2, 0, 0]
+    assert _one_shot(rh, [(f([1, 2, 3, 4]), 2, 1, 1.0)], 4, 1).tolist() == [1, 2, 0, 0, 3, 4, 0, 0]
+
+
+def test_wide_mix_properties_at_full_block_sizes(rh):
+    """Size-independent properties at a block the oracle would need minutes for (64 sources x 256 Ki frames of 5.1): from == to is the identity
+    (sample_rate.rs:254-270), up by k then every k-th frame is the input (:318-334), the mix is linear in the gains -- and the order of the
+    additions is the insertion order (a permutation of the sources changes the bits of a sum of many, the same order never does)."""
+    import torch
+
+    from rodio_amd import _lib, source
+
+    source._ensure()
+    rng = np.random.default_rng(9)
+    S, M, Cc = 64, 1 << 18, 6
+    rows = [torch.from_numpy(rng.uniform(-1, 1, (M + 2) * Cc).astype(np.float32)).cuda() for _ in range(S)]
+
+    def mix(order, gains, rate, to_rate, frames):
+        arr = (_lib.WideSrc * len(order))()
+        for k, s in enumerate(order):
+            arr[k].data, arr[k].channels, arr[k].from_rate, arr[k].phase, arr[k].frames, arr[k].last, arr[k].gain = rows[s].data_ptr(), Cc, rate, 0, frames, 0xFFFFFFFF, gains[k]
+        dst = torch.empty(frames * Cc, device="cuda")
+        _lib.check(_lib.lib.rh_wide_mix_block(C.c_void_p(dst.data_ptr()), Cc, to_rate, frames, arr, len(order), source._stream()), "rh_wide_mix_block")
+        return dst
+
+    one = mix([3], [1.0], 48000, 48000, M)
+    assert torch.equal(one, rows[3][: M * Cc])
+    up = mix([5], [1.0], 16000, 48000, 3 * (M // 4))
+    assert torch.equal(up.view(-1, Cc)[::3], rows[5][: (M // 4) * Cc].view(-1, Cc))
+    order = list(range(S))
+    g = [0.5] * S
+    m1 = mix(order, g, 44100, 48000, M)
+    assert torch.equal(m1, mix(order, g, 44100, 48000, M))                       # run after run: the same bits
+    m2 = mix(order, [1.0] * S, 44100, 48000, M)
+    assert torch.equal(m1 * 2, m2)                                               # a power of two scales every term and every partial sum exactly
+    rev = mix(order[::-1], g, 44100, 48000, M)
+    assert not torch.equal(rev, m1) and float((rev - m1).abs().max()) < 1e-4     # another order: other roundings of the same sum
+    # ... and against the f64 sum of the same taps: the ordered f32 sum stays within S ulps of a sum of 64 terms of size < 1
+    i = (torch.arange(M, device="cuda", dtype=torch.int64) * 147) // 160
+    w = ((torch.arange(M, device="cuda", dtype=torch.int64) * 147) % 160).to(torch.float64) / 160.0
+    ref = torch.zeros(M, Cc, dtype=torch.float64, device="cuda")
+    for s in order:
+        x = rows[s].view(-1, Cc).to(torch.float64)
+        ref += 0.5 * (x[i] + (x[i + 1] - x[i]) * w[:, None])
+    assert float((m1.view(-1, Cc).to(torch.float64) - ref).abs().max()) < 64 * 4e-6
