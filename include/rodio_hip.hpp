@@ -2995,6 +2995,7 @@ private:
         stage.reset(S * roww);
         detail::DeviceBuf &din = g.din[g.pd];
         din.reset(S * roww);
+        std::vector<std::size_t> haves(S, 0);  // samples in every row: [what the block before left | the new ones]
         pull_sources(S * opt_.block_frames, S, [&](std::size_t i) {
             Src &x = g.srcs[i];
             const std::size_t ch = x.ch;
@@ -3010,13 +3011,14 @@ private:
                 if (got % ch) throw Error(RH_ERR_UNSUPPORTED, "GpuMixer: a source whose current_span_len() is None ended inside a frame (source/mod.rs:169-178 asks for whole frames)");
                 have += got;
             }
-            x.held.assign(row, row + have);  // (what the block does not consume stays; dropped below, once the block is planned)
+            haves[i] = have;
         });
         // what the block emits
         bool any_live = false;
         std::uint64_t m_end = target, longest = 0;
-        for (const Src &x : g.srcs) {
-            const std::uint64_t n = x.wpos + x.held.size() / x.ch;
+        for (std::size_t i = 0; i < S; ++i) {
+            const Src &x = g.srcs[i];
+            const std::uint64_t n = x.wpos + haves[i] / x.ch;
             if (x.ended) longest = std::max(longest, wide_total(n, x.wF, x.wT));
             else any_live = true, m_end = std::min(m_end, wide_ready(n, x.wF, x.wT));
         }
@@ -3030,7 +3032,7 @@ private:
         std::size_t width = 0;
         for (std::size_t i = 0; i < S; ++i) {
             Src &x = g.srcs[i];
-            const std::uint64_t have = x.held.size() / x.ch, n = x.wpos + have;
+            const std::uint64_t have = haves[i] / x.ch, n = x.wpos + have;
             const std::uint64_t i0 = wide_first_tap(m0, x.wF, x.wT);
             rh_wide_src &d = g.wtab[i];
             const std::uint64_t end = x.ended ? wide_total(n, x.wF, x.wT) : m_end;
@@ -3041,14 +3043,13 @@ private:
             d.phase = (std::uint32_t)(m0 % x.wT * x.wF % x.wT);
             d.last = x.ended ? (std::uint32_t)(n ? n - 1 - std::min(i0, n - 1) : 0) : 0xffffffffu;
             d.gain = x.gain;
-            if (d.frames) width = std::max<std::size_t>(width, (std::size_t)have * x.ch);
+            if (d.frames) width = std::max<std::size_t>(width, haves[i]);
             if (x.ended && g.wlast) x.total_s = wide_total(n, x.wF, x.wT) * qch_;
-            // the frames in front of the next block's first tap are done with
+            // the frames from the next block's first tap on are kept for it (a few: the block consumes what it was pulled for)
             const std::uint64_t keep_from = std::min(wide_first_tap(m_end, x.wF, x.wT), n);
-            if (keep_from > x.wpos) {
-                x.held.erase(x.held.begin(), x.held.begin() + (std::ptrdiff_t)((keep_from - x.wpos) * x.ch));
-                x.wpos = keep_from;
-            }
+            const float *row = stage.get() + i * roww;
+            x.held.assign(row + (std::size_t)(keep_from - x.wpos) * x.ch, row + haves[i]);
+            x.wpos = keep_from;
             if (x.ended && x.hint && (!d.frames || std::min(end, m_end) == end)) x.hint->total_known = true, x.hint->total = wide_total(n, x.wF, x.wT) * qch_;
         }
         g.wm = m_end;
