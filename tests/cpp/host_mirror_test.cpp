@@ -394,6 +394,44 @@ int main(int argc, char **argv) {
                         mixer.timing().wait_s, (unsigned long long)mixer.timing().blocks, prep_s, start_s, last_read, slowest_read, e2e, e2e / 63.0, e2e_prep, e2e_prep / 63.0);
             return 0;
         }
+        if (mode == "benchwide" && argc == 6) {
+            // host_mirror_test benchwide <S> <frames> <block_frames> <mixer_channels>: S continuous 5.1-style sources at 44.1 kHz (host memory) into
+            // mixer::mixer(channels, 48 kHz), pulled to the end; RH_TEST_WIDE_CHAINS=1: every source a chain of its own (the form of round 5)
+            const int S = std::atoi(argv[2]);
+            const size_t frames = (size_t)std::atoll(argv[3]);
+            const uint16_t mch = (uint16_t)std::atoi(argv[5]);
+            rh::GpuMixer::Options opt;
+            opt.block_frames = block_arg(argv[4]);
+            opt.wide_chains = std::getenv("RH_TEST_WIDE_CHAINS") != nullptr;
+            rh::GpuMixer mixer(mch, 48000, opt);
+            uint32_t lcg = 12345u;
+            for (int i = 0; i < S; ++i) {
+                std::vector<float> x(frames * mch);
+                for (float &v : x) {
+                    lcg = lcg * 1664525u + 1013904223u;
+                    v = ((float)(lcg >> 8) / 8388608.0f - 1.0f) / (float)S;
+                }
+                mixer.add(make_source(mch, 44100, std::move(x)), 0.5f + 0.01f * (float)i);
+            }
+            std::vector<float> chunk(1u << 16);
+            mixer.prepare();
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t total = 0;
+            double sum = 0;
+            for (;;) {
+                const size_t k = mixer.read(chunk.data(), chunk.size());
+                total += k;
+                for (size_t q = 0; q < k; q += 4097) sum += chunk[q];
+                if (k < chunk.size()) break;
+            }
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double in_bytes = (double)S * (double)frames * mch * 4.0;
+            std::printf("{\"mode\": \"%s\", \"sources\": %d, \"channels\": %u, \"frames\": %zu, \"block_frames\": %zu, \"out_samples\": %zu, \"seconds\": %.4f, \"Msamples_per_s_in\": %.1f, "
+                        "\"host_link_GBps\": %.2f, \"host_link_frac_of_63\": %.3f, \"wide_fused_blocks\": %llu, \"blocks\": %llu, \"checksum\": %.9g}\n",
+                        opt.wide_chains ? "a chain per source" : "one launch a block", S, (unsigned)mch, frames, opt.block_frames, total, sec, in_bytes / 4.0 / sec / 1e6, in_bytes / sec / 1e9,
+                        in_bytes / sec / 1e9 / 63.0, (unsigned long long)mixer.wide_fused_blocks(), (unsigned long long)mixer.timing().blocks, sum);
+            return 0;
+        }
         if (mode == "mixany" && argc == 9) {
             const int S = std::atoi(argv[3]);
             const uint32_t to = (uint32_t)std::atoll(argv[4]);
