@@ -2990,6 +2990,9 @@ private:
             const std::uint64_t fr = std::max(need[i], x.wpos + have) - x.wpos;
             roww = std::max<std::size_t>(roww, ((std::size_t)fr * x.ch + 3) & ~std::size_t(3));
         }
+        // (rows a little longer than this block needs, and never shorter than the block before: the page-locked block and the device rows are
+        //  allocated once -- a block whose rows come out a frame longer must not allocate 50 MB of page-locked memory again)
+        roww = std::max(g.wrow, (roww + 64 * qch_ + 1023) & ~std::size_t(1023));
         g.wrow = roww;
         detail::PinnedBuf &stage = g.stage[g.pslot];
         stage.reset(S * roww);

@@ -427,9 +427,11 @@ int main(int argc, char **argv) {
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const double in_bytes = (double)S * (double)frames * mch * 4.0;
             std::printf("{\"mode\": \"%s\", \"sources\": %d, \"channels\": %u, \"frames\": %zu, \"block_frames\": %zu, \"out_samples\": %zu, \"seconds\": %.4f, \"Msamples_per_s_in\": %.1f, "
-                        "\"host_link_GBps\": %.2f, \"host_link_frac_of_63\": %.3f, \"wide_fused_blocks\": %llu, \"blocks\": %llu, \"checksum\": %.9g}\n",
+                        "\"host_link_GBps\": %.2f, \"host_link_frac_of_63\": %.3f, \"wide_fused_blocks\": %llu, \"blocks\": %llu, \"checksum\": %.9g, "
+                        "\"host_seconds\": {\"pull\": %.4f, \"prefetch\": %.4f, \"submit\": %.4f, \"wait\": %.4f}}\n",
                         opt.wide_chains ? "a chain per source" : "one launch a block", S, (unsigned)mch, frames, opt.block_frames, total, sec, in_bytes / 4.0 / sec / 1e6, in_bytes / sec / 1e9,
-                        in_bytes / sec / 1e9 / 63.0, (unsigned long long)mixer.wide_fused_blocks(), (unsigned long long)mixer.timing().blocks, sum);
+                        in_bytes / sec / 1e9 / 63.0, (unsigned long long)mixer.wide_fused_blocks(), (unsigned long long)mixer.timing().blocks, sum, mixer.timing().pull_s, mixer.timing().prefetch_s,
+                        mixer.timing().submit_s, mixer.timing().wait_s);
             return 0;
         }
         if (mode == "mixany" && argc == 9) {
