@@ -919,6 +919,11 @@ def side(args, argv, lite=False):
         m = C.c_uint64(0)
         kernels.append(("wav_decode_i16_to_f32", lambda: _lib.check(lib.rh_wav_decode(C.c_void_p(f32.data_ptr()), C.c_void_p(d_raw.data_ptr()), n, 2, 16, 0, C.byref(m), stream), "rh_wav_decode"), 6 * n, n))
         kernels.append(("channels_6_to_2", lambda: _lib.check(lib.rh_channels_convert(C.c_void_p(out2.data_ptr()), C.c_void_p(f32.data_ptr()), frames6, 6, 2, stream), "rh_channels_convert"), 32 * frames6, frames6 * 6))
+        # ... and both in ONE launch (round 6: rh_wav_decode_channels): the decoded block in between -- 4 B a sample written and read again -- never exists
+        out2f = torch.empty(frames6 * 2 + 4, device="cuda", dtype=torch.float32)
+        mf = C.c_uint64(0)
+        kernels.append(("wav_decode_and_channels_6_to_2_one_launch", lambda: _lib.check(lib.rh_wav_decode_channels(C.c_void_p(out2f.data_ptr()), C.c_void_p(d_raw.data_ptr()), frames6 * 6, 6, 16, 0, 2, C.byref(mf), stream),
+                                                                                     "rh_wav_decode_channels"), 12 * frames6 + 8 * frames6, frames6 * 6))
         workload = (f"assets/music.wav data chunk ({info['samples']} PCM16 samples, RIFF probed by rh_wav_probe_host) tiled x{tile} = {n} samples: i16 -> f32 on the device "
                     f"(rh_wav_decode), then the f32 stream re-framed as {frames6} frames x 6 ch -> ChannelCountConverter(6 -> 2) (BASELINE config 5)")
         metric = "Msamples/s through i16->f32 DataConverter"
@@ -934,7 +939,8 @@ def side(args, argv, lite=False):
             p1 = _parity(got1, ref1, 0, "oracle i16 -> f32 (dasp_sample 0.11.0 restated), the whole data chunk")
             p2 = _parity(got2, ref2, 0, "oracle ChannelCountConverter(6 -> 2), 149 109 frames")
             whole = bool(torch.equal(f32[: ns_ * tile].view(tile, ns_), f32[:ns_].expand(tile, ns_)))  # every tile decoded alike
-            return {"ok": p1["ok"] and p2["ok"] and whole, "i16_to_f32": p1, "channels_6_to_2": p2, "all_tiles_equal": whole}, base
+            fused_same = bool(mf.value == frames6 * 2 and torch.equal(out2f[: frames6 * 2].view(torch.int32), out2.view(torch.int32)))  # the one-launch form: the same bits, all of them
+            return {"ok": p1["ok"] and p2["ok"] and whole and fused_same, "i16_to_f32": p1, "channels_6_to_2": p2, "all_tiles_equal": whole, "one_launch_bit_identical": fused_same}, base
     elif cfg in ("limit", "agc", "biquad"):
         from oracle import rodio_oracle as O
 

@@ -132,6 +132,13 @@ typedef struct rh_wav_info {
 rh_status rh_wav_probe_host(const uint8_t *bytes, size_t size, rh_wav_info *info);
 rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uint32_t channels,
                         uint32_t bits_per_sample, int32_t is_float, uint64_t *out_samples, rh_stream stream);
+/* rh_wav_decode and ChannelCountConverter(channels -> to_channels) (src/conversions/channels.rs:57-85) in ONE pass: what
+ * `UniformSourceIterator::new(decoder, to_channels, same rate)` makes of the file (uniform.rs:58-67 -- BASELINE config 5's chain).  dst
+ * receives *out_samples = ceil(n_samples / channels) * to_channels samples, bit-identical to rh_wav_decode followed by
+ * rh_channels_convert; the decoded block in between (4 bytes a sample written and read again) never exists. */
+rh_status rh_wav_decode_channels(float *dst, const uint8_t *data, uint64_t n_samples, uint32_t channels,
+                                 uint32_t bits_per_sample, int32_t is_float, uint32_t to_channels,
+                                 uint64_t *out_samples, rh_stream stream);
 size_t rh_wav_header_f32_host(uint8_t *out, size_t cap, uint32_t channels, uint32_t sample_rate, uint64_t n_samples);
 
 /* ---- ChannelCountConverter: src/conversions/channels.rs:57-85.  Bit-exact.

@@ -24,6 +24,7 @@ from .source import (  # noqa: F401
     TestSource,
     UniformSourceIterator,
     WavDecoder,
+    WavDecoderChannels,
     agc_batch,
     async_status,
     agc_state,

@@ -148,6 +148,7 @@ SIGNATURES = {
     "rh_echo_flush": (i32, [vp, vp, vp]),
     "rh_wav_probe_host": (i32, [vp, sz, C.POINTER(WavInfo)]),
     "rh_wav_decode": (i32, [vp, vp, u64, u32, u32, i32, C.POINTER(u64), vp]),
+    "rh_wav_decode_channels": (i32, [vp, vp, u64, u32, u32, i32, u32, C.POINTER(u64), vp]),
     "rh_wav_header_f32_host": (sz, [vp, sz, u32, u32, u64]),
     "rh_delay": (i32, [vp, vp, u64, u64, vp]),
     "rh_take_duration": (i32, [vp, vp, u64, u64, u32, u32, u64, i32, C.POINTER(u64), C.POINTER(i32), vp]),

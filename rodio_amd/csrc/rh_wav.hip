@@ -29,6 +29,49 @@ __global__ __launch_bounds__(kBlock) void k_fill_zero(float *__restrict__ dst, s
     if (i < to) dst[i] = 0.0f;
 }
 
+// ---- decode AND ChannelCountConverter in one pass (BASELINE config 5: the decoded block goes straight into the converter) -------------
+// out[f][k] = k < from ? sample(f, k) : (k == 1 && from == 1 ? sample(f, 0) : 0.0)   (channels.rs:59-70), sample = hound's to_sample::<f32>()
+// of the file's bytes (wav.rs:107-151), 0.0 where the data chunk ends inside the last frame (wav.rs:161-169).  The two-launch form writes
+// the decoded f32 block (4 B a sample) and reads it again; here a 6-channel PCM16 frame costs 12 B in + 4 * to B out instead of 36 + 24 + 4 * to.
+// A lane produces four consecutive output samples (one 16-byte store); its few loads hit lines its neighbours touch too.
+template <int FMT>  // 0: u8, 1: i16, 2: packed i24, 3: i32, 4: f32 (all little-endian, as the file holds them)
+__device__ __forceinline__ float pcm_sample(const uint8_t *__restrict__ src, uint64_t i) {
+    if (FMT == 0) return (float)((int)src[i] - 128) / 128.0f;
+    if (FMT == 1) return (float)reinterpret_cast<const int16_t *>(src)[i] / 32768.0f;
+    if (FMT == 2) {
+        const uint8_t *b = src + 3 * i;
+        const int32_t v = (int32_t)b[0] | ((int32_t)b[1] << 8) | ((int32_t)(int8_t)b[2] << 16);
+        return (float)v / 8388608.0f;
+    }
+    if (FMT == 3) return (float)reinterpret_cast<const int32_t *>(src)[i] / 2147483648.0f;
+    return reinterpret_cast<const float *>(src)[i];
+}
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void k_pcm_to_channels(float *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n_samples, uint64_t frames, uint32_t from, uint32_t to, int vec_ok) {
+    const uint64_t total = frames * to, nvec = (total + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const uint64_t o0 = 4 * v;
+        uint64_t f = o0 / to;
+        uint32_t k = (uint32_t)(o0 - f * to);
+        float e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool has = k < from || (k == 1u && from == 1u);
+            const uint64_t idx = f * from + (k < from ? k : 0u);
+            e[i] = (has && o0 + i < total && idx < n_samples) ? pcm_sample<FMT>(src, idx) : 0.0f;
+            if (++k == to) k = 0, ++f;
+        }
+        if (vec_ok && o0 + 4 <= total) {
+            rh::st_nt(reinterpret_cast<float4 *>(dst + o0), make_float4(e[0], e[1], e[2], e[3]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (o0 + i < total) dst[o0 + i] = e[i];
+        }
+    }
+}
+
 uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 void wr32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
@@ -107,6 +150,39 @@ rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uin
         hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((total - n_samples + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, dst, (size_t)n_samples, (size_t)total);  // up to channels - 1 samples: a header may say 65 535 channels
         RH_CHECK_LAUNCH();
     }
+    return RH_OK;
+}
+
+rh_status rh_wav_decode_channels(float *dst, const uint8_t *data, uint64_t n_samples, uint32_t channels, uint32_t bits_per_sample, int32_t is_float, uint32_t to_channels,
+                                 uint64_t *out_samples, rh_stream stream) {
+    RH_REQUIRE_INIT();
+    if (channels == 0 || to_channels == 0 || !out_samples) return RH_ERR_INVALID;
+    const uint64_t frames = (n_samples + channels - 1) / channels;  // a cut last frame is completed with silence (wav.rs:161-169) and converted like the others
+    *out_samples = frames * to_channels;
+    if (frames == 0) return RH_OK;
+    if (!dst || !data) return RH_ERR_INVALID;
+    int fmt;
+    if (is_float) {
+        if (bits_per_sample != 32) return RH_ERR_UNSUPPORTED;  // wav.rs:107-117
+        fmt = 4;
+    } else if (bits_per_sample == 8) fmt = 0;
+    else if (bits_per_sample == 16) fmt = 1;
+    else if (bits_per_sample == 24) fmt = 2;
+    else if (bits_per_sample == 32) fmt = 3;
+    else return RH_ERR_UNSUPPORTED;  // "unofficial" depths (wav.rs:137-151)
+    const uintptr_t align = fmt == 1 ? 1u : (fmt >= 3 ? 3u : 0u);
+    if (reinterpret_cast<uintptr_t>(data) & align) return RH_ERR_INVALID;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+    const dim3 grid(rh::grid_tiles((size_t)((frames * to_channels + 3) / 4)));
+    hipStream_t s = rh::as_stream(stream);
+#define RH_PCM(F) hipLaunchKernelGGL(k_pcm_to_channels<F>, grid, dim3(kBlock), 0, s, dst, data, n_samples, frames, channels, to_channels, vec_ok)
+    if (fmt == 0) RH_PCM(0);
+    else if (fmt == 1) RH_PCM(1);
+    else if (fmt == 2) RH_PCM(2);
+    else if (fmt == 3) RH_PCM(3);
+    else RH_PCM(4);
+#undef RH_PCM
+    RH_CHECK_LAUNCH();
     return RH_OK;
 }
 

@@ -369,6 +369,22 @@ def WavDecoder(file_bytes: bytes) -> "GpuSource":
     return GpuSource(out[: m.value], w["channels"], w["sample_rate"], None)
 
 
+def WavDecoderChannels(file_bytes: bytes, to_channels: int) -> "GpuSource":
+    """`UniformSourceIterator::new(decoder, to_channels, the file's rate)`: src/decoder/wav.rs + src/conversions/channels.rs:57-85 in ONE
+    launch (rh_wav_decode_channels) -- the decoded block in the file's own layout never exists."""
+    _ensure()
+    torch = _t()
+    w = wav_probe(file_bytes)
+    raw = np.frombuffer(file_bytes, dtype=np.uint8, count=w["data_bytes"], offset=w["data_offset"])
+    d_in = torch.from_numpy(raw.copy()).to("cuda") if raw.size else torch.empty(1, dtype=torch.uint8, device="cuda")
+    frames = (w["samples"] + w["channels"] - 1) // w["channels"]
+    out = _dev_empty(frames * to_channels + 4)
+    m = C.c_uint64(0)
+    check(lib.rh_wav_decode_channels(_ptr(out), _ptr(d_in), w["samples"], w["channels"], w["bits_per_sample"], w["is_float"], to_channels, C.byref(m), _stream()),
+          "rh_wav_decode_channels")
+    return GpuSource(out[: m.value], to_channels, w["sample_rate"], None)
+
+
 def wav_to_bytes(source: "GpuSource") -> bytes:
     """src/wav_output.rs:62-96: 32-bit float WAVE of the source's whole frames."""
     n = len(source)

@@ -296,6 +296,58 @@ def test_wav_ingest_and_egress(G, O):
     assert np.array_equal(np.frombuffer(out[44:], "<f4"), O.convert("i16_to_f32", i16[:30000]) * np.float32(0.5))
 
 
+def test_wav_decode_and_channel_conversion_in_one_launch(G, O):
+    """BASELINE config 5 as ONE launch (rh_wav_decode_channels): `UniformSourceIterator::new(decoder, to_ch, rate)` = wav.rs:94-172 then
+    channels.rs:57-85.  Every sample format x down / up / mono -> n / same, a data chunk that ends inside its last frame (the silence that
+    completes it is converted like a frame), bit-identical to the two launches and to the oracle's ChannelCountConverter over the decoded stream;
+    the committed excerpt of the reference's music.wav against its golden 6 -> 2 vector."""
+    import os
+    import struct
+
+    from test_host_logic import _wav_bytes
+
+    rng = np.random.default_rng(57)
+    cases = [(6, 16, 2), (6, 16, 8), (1, 16, 4), (2, 8, 1), (3, 24, 2), (5, 32, 5), (2, "f32", 6), (1, 8, 1), (7, 16, 3)]
+    for ch, bits, to in cases:
+        n = int(rng.integers(1000, 40000))
+        n -= 1 if n % ch == 0 else 0  # (ends inside a frame wherever ch > 1)
+        if bits == "f32":
+            x = rnd(58, n)
+            wav = _wav_bytes(ch, 48000, 32, x.astype("<f4").tobytes(), fmt_tag=3)
+        elif bits == 8:
+            wav = _wav_bytes(ch, 48000, 8, rng.integers(0, 256, n, dtype=np.int64).astype(np.uint8).tobytes())
+        elif bits == 16:
+            wav = _wav_bytes(ch, 48000, 16, rng.integers(-32768, 32768, n, dtype=np.int64).astype("<i2").tobytes())
+        elif bits == 24:
+            wav = _wav_bytes(ch, 48000, 24, b"".join(struct.pack("<i", int(v))[:3] for v in rng.integers(-2 ** 23, 2 ** 23, n, dtype=np.int64)), extensible=True)
+        else:
+            wav = _wav_bytes(ch, 48000, 32, rng.integers(-2 ** 31, 2 ** 31, n, dtype=np.int64).astype("<i4").tobytes())
+        two = G.WavDecoder(wav)
+        decoded = two.collect()
+        assert len(decoded) % ch == 0
+        want = O.ChannelCountConverter(O.TestSource(decoded, ch, 48000), ch, to).collect()
+        two_launches = G.ChannelCountConverter(G.TestSource(decoded, ch, 48000), ch, to).collect()
+        one = G.WavDecoderChannels(wav, to)
+        assert (one.channels(), one.sample_rate()) == (to, 48000)
+        got = one.collect()
+        assert got.shape == want.shape, (ch, bits, to)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got.view(np.uint32), two_launches.view(np.uint32)), (ch, bits, to)
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    i16 = np.load(os.path.join(gdir, "music_excerpt_i16.npy"))
+    i16 = i16[: (len(i16) // 6) * 6]
+    got = G.WavDecoderChannels(_wav_bytes(6, 44100, 16, i16.astype("<i2").tobytes()), 2).collect()
+    assert np.array_equal(got, np.load(os.path.join(gdir, "music_excerpt_6to2.npy")))
+    # arguments
+    import ctypes as C
+
+    from rodio_amd import _lib
+
+    m = C.c_uint64(7)
+    assert _lib.lib.rh_wav_decode_channels(None, None, 0, 2, 16, 0, 2, C.byref(m), None) == 0 and m.value == 0  # nothing to do
+    assert _lib.lib.rh_wav_decode_channels(None, None, 4, 2, 16, 0, 0, C.byref(m), None) == 1                  # to_channels is NonZero
+    assert _lib.lib.rh_wav_decode_channels(None, None, 4, 2, 12, 0, 2, C.byref(m), None) in (1, 3)             # null pointers / an unofficial depth
+
+
 def test_golden_music_excerpt_config5(G):
     # BASELINE config 5 on the committed excerpt of the reference's assets/music.wav
     # (tests/golden/make_golden.py): i16 -> f32 and ChannelCountConverter 6 -> 2, bit-exact
