@@ -1095,6 +1095,9 @@ def side(args, argv, lite=False):
                 out_["max_abs_err"] = pr_["max_abs_err"]
             if pr_.get("bit_exact") is not None or "i16_to_f32" in pr_:
                 out_["bit_exact"] = bool(pr_.get("ok"))
+        if cfg == "5" and len(rows) >= 3:  # the config is a CHAIN (decode, then 6 -> 2): its time as two launches and as the one launch of round 6
+            out_["chain_ms_two_launches"] = rows[0]["kernel_ms"] + rows[1]["kernel_ms"]
+            out_["chain_ms_one_launch"] = rows[2]["kernel_ms"]
         return out_
     traffic, traffic_how = pmc_traffic(argv, like, per_call)
     res = {"metric": metric, "value": head["Msamples_per_s"], "unit": "Msamples/s", "n_gpus": 1, "steps": head["steps"], "warmup": args.warmup,
