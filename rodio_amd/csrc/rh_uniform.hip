@@ -25,7 +25,9 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kTile = 2048;        // output frames per workgroup
+constexpr uint32_t kTile = 2048;        // output frames per workgroup of a large launch;
+constexpr uint32_t kTileSmall = 256;    // ... of a small one (a chain's block: a frame per lane, eight times the workgroups -- 8 workgroups walking 2048 frames each took 20 us)
+inline uint32_t tile_for(uint64_t most, uint32_t n_segs) { return ((most + kTile - 1) / kTile) * n_segs >= 1024 ? kTile : kTileSmall; }
 constexpr uint32_t kSegsPerLaunch = 48; // by-value table: 48 x 80 B of kernel arguments
 
 struct SegTable {
@@ -61,7 +63,7 @@ __device__ __forceinline__ uint32_t gcd_u32(uint32_t a, uint32_t b) {
 
 // One output SAMPLE per lane: sample j of the tail is position j % to_ch of the (j / to_ch)-th group of from_ch converter samples
 // (channels.rs:57-85), and converter sample idx of the tail is channel idx % t of its (idx / t)-th short frame.
-__device__ __forceinline__ void convert_cut_tail(const rh_uniform_seg &g, uint32_t tile) {
+__device__ __forceinline__ void convert_cut_tail(const rh_uniform_seg &g, uint32_t tile, const uint32_t kTile) {  // (the launch's tile length shadows the constant)
     const uint64_t j0 = g.m0 + (uint64_t)tile * kTile;
     if (j0 >= g.m1) return;
     const uint64_t j1 = j0 + kTile < g.m1 ? j0 + kTile : g.m1;
@@ -93,8 +95,8 @@ __device__ __forceinline__ void convert_cut_tail(const rh_uniform_seg &g, uint32
     }
 }
 
-__device__ __forceinline__ void convert_frames(const rh_uniform_seg &g, uint32_t tile) {
-    if (g.reserved) return convert_cut_tail(g, tile);
+__device__ __forceinline__ void convert_frames(const rh_uniform_seg &g, uint32_t tile, const uint32_t kTile) {  // (the launch's tile length shadows the constant)
+    if (g.reserved) return convert_cut_tail(g, tile, kTile);
     const uint64_t mt0 = g.m0 + (uint64_t)tile * kTile;
     if (mt0 >= g.m1) return;
     const uint64_t mt1 = mt0 + kTile < g.m1 ? mt0 + kTile : g.m1;
@@ -139,15 +141,15 @@ __device__ __forceinline__ void convert_frames(const rh_uniform_seg &g, uint32_t
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_uniform_segs_val(const SegTable tbl, uint32_t n) {
-    if (blockIdx.y < n) convert_frames(tbl.s[blockIdx.y], blockIdx.x);
+__global__ __launch_bounds__(kBlock) void k_uniform_segs_val(const SegTable tbl, uint32_t n, uint32_t tile_frames) {
+    if (blockIdx.y < n) convert_frames(tbl.s[blockIdx.y], blockIdx.x, tile_frames);
 }
-__global__ __launch_bounds__(kBlock) void k_uniform_segs_dev(const rh_uniform_seg *__restrict__ segs, uint32_t n) {
+__global__ __launch_bounds__(kBlock) void k_uniform_segs_dev(const rh_uniform_seg *__restrict__ segs, uint32_t n, uint32_t tile_frames) {
     if (blockIdx.y >= n) return;
     __shared__ rh_uniform_seg g;
     if (threadIdx.x < sizeof(rh_uniform_seg) / 8) reinterpret_cast<uint64_t *>(&g)[threadIdx.x] = reinterpret_cast<const uint64_t *>(segs + blockIdx.y)[threadIdx.x];
     __syncthreads();
-    convert_frames(g, blockIdx.x);
+    convert_frames(g, blockIdx.x, tile_frames);
 }
 
 }  // namespace
@@ -244,9 +246,10 @@ rh_status rh_uniform_segments(const rh_uniform_seg *segs_host, uint32_t n_segs, 
             most = std::max<uint64_t>(most, t.s[k].m1 - t.s[k].m0);
         }
         if (!most) continue;
-        const uint64_t tiles = (most + kTile - 1) / kTile;
+        const uint32_t tf = tile_for(most, n);
+        const uint64_t tiles = (most + tf - 1) / tf;
         if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(k_uniform_segs_val, dim3((uint32_t)tiles, n), dim3(kBlock), 0, s, t, n);
+        hipLaunchKernelGGL(k_uniform_segs_val, dim3((uint32_t)tiles, n), dim3(kBlock), 0, s, t, n, tf);
         RH_CHECK_LAUNCH();
     }
     return RH_OK;
@@ -256,9 +259,10 @@ rh_status rh_uniform_segments_dev(const rh_uniform_seg *segs_dev, uint32_t n_seg
     RH_REQUIRE_INIT();
     if (!n_segs || !max_out_frames) return RH_OK;
     if (!segs_dev || n_segs > 65535u) return RH_ERR_INVALID;
-    const uint64_t tiles = (max_out_frames + kTile - 1) / kTile;
+    const uint32_t tf = tile_for(max_out_frames, n_segs);
+    const uint64_t tiles = (max_out_frames + tf - 1) / tf;
     if (tiles > 0x7fffffffull) return RH_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_uniform_segs_dev, dim3((uint32_t)tiles, n_segs), dim3(kBlock), 0, rh::as_stream(stream), segs_dev, n_segs);
+    hipLaunchKernelGGL(k_uniform_segs_dev, dim3((uint32_t)tiles, n_segs), dim3(kBlock), 0, rh::as_stream(stream), segs_dev, n_segs, tf);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
