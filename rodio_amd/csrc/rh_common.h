@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what);
 // process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
 enum Knob {
     K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
-    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_COUNT
+    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_WIDE_GENERAL, K_COUNT
 };
 const char *knob(Knob k);
 void load_knobs();

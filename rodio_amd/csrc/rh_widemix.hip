@@ -112,6 +112,61 @@ __global__ __launch_bounds__(kBlock) void k_wide_mix(float *__restrict__ dst, ui
     }
 }
 
+// ---- the uniform case: every source of the launch has the mixer's channel count and ONE rate, and reaches every frame of the launch with both
+// taps (no source ends inside it).  Then the tap offset and the weight are the lane's own, once, and a source costs two loads, the lerp and
+// the add: what a mixer of many alike sources runs (k_wide_mix spends ~35 vector instructions per source and sample on the cases it must
+// tell apart, which is what bounds it at scale: 0.41 of the roofline for 256 stereo sources).  The same operations in the same order.
+struct WideUniSrc {
+    const float *data;
+    float gain;
+    uint32_t pad;
+};
+struct WideUniTable {
+    uint32_t F, T, r0, ch;
+    float Tf;
+    uint32_t pad[3];
+    WideUniSrc d[kWideChunk];
+};
+constexpr int kUniGroup = 8;  // sources whose taps are in flight together (sixteen loads a lane; four: 0.44 of the roofline at 64 x 64 Ki frames of 5.1, eight: see profiles/r06_bench_wide.txt)
+template <bool CONT, bool LERP>
+__global__ __launch_bounds__(kBlock) void k_wide_mix_uniform(float *__restrict__ dst, uint32_t out_frames, const WideUniTable tbl, uint32_t n_sources) {
+    const uint32_t ch = tbl.ch;
+    const uint64_t total = (uint64_t)out_frames * ch;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t o = (uint64_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += stride) {
+        const uint32_t j = (uint32_t)(o / ch);
+        const uint32_t c = (uint32_t)(o - (uint64_t)j * ch);
+        const uint32_t p = tbl.r0 + j * tbl.F;
+        const uint32_t il = LERP ? p / tbl.T : j;
+        const float w = LERP ? (float)(p - il * tbl.T) : 0.0f;
+        const uint64_t off = (uint64_t)il * ch + c;
+        float acc = CONT ? dst[o] : 0.0f;
+        uint32_t nv = n_sources;
+        asm volatile("" : "+v"(nv));  // (a vector register: "is this slot a source" below is a select, not a branch that would split the group's loads)
+        for (uint32_t s0 = 0; s0 < n_sources; s0 += kUniGroup) {  // (the slots behind the last source of a short last group repeat the first source: read, not added)
+            float a[kUniGroup], b[kUniGroup], g[kUniGroup];
+#pragma unroll
+            for (int u = 0; u < kUniGroup; ++u) {
+                const WideUniSrc d = tbl.d[s0 + u];
+                g[u] = d.gain;
+                a[u] = d.data[off];
+                b[u] = LERP ? d.data[off + ch] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kUniGroup; ++u) {
+                const float x = a[u] * g[u];
+                float v = x;
+                if (LERP) {
+                    const float y = b[u] * g[u];
+                    v = x + (y - x) * w / tbl.Tf;
+                }
+                acc += s0 + u < nv ? v : 0.0f;  // (+ 0.0 leaves a sum that started at + 0.0 as it is)
+            }
+        }
+        dst[o] = acc;
+    }
+}
+
 }  // namespace
 
 rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uint64_t out_frames, const rh_wide_src *srcs_host, uint32_t n_sources, rh_stream stream) {
@@ -136,8 +191,31 @@ rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uin
         if (fit < step) step = fit;
     }
     if (step == 0) return RH_ERR_UNSUPPORTED;
-    for (uint64_t j0 = 0; j0 < out_frames; j0 += step) {
-        const uint32_t nf = (uint32_t)(out_frames - j0 < step ? out_frames - j0 : step);
+    // Alike sources (one rate and phase, the mixer's layout): the frames in front of the first one that ends -- or whose last frame a tap reaches --
+    // go to the uniform kernel as a launch of their own, the rest to the general one.
+    uint64_t j_uni = 0;
+    {
+        bool alike = true;
+        int first = -1;
+        uint64_t upto = out_frames;
+        for (uint32_t s = 0; s < n_sources && alike; ++s) {
+            const rh_wide_src &x = srcs_host[s];
+            if (x.frames == 0) continue;
+            if (first < 0) first = (int)s;
+            alike = x.channels == channels && red[s].F == red[(size_t)first].F && red[s].T == red[(size_t)first].T && x.phase == srcs_host[first].phase;
+            uint64_t u = x.frames;
+            if (x.last != 0xffffffffu && red[s].F != red[s].T) {  // il(j) >= last  <=>  phase + j F >= last T
+                const uint64_t need = (uint64_t)x.last * red[s].T;
+                const uint64_t jl = need > x.phase ? (need - x.phase + red[s].F - 1) / red[s].F : 0;
+                if (jl < u) u = jl;
+            }
+            if (u < upto) upto = u;
+        }
+        if (alike && first >= 0 && upto >= 1024 && upto < out_frames) j_uni = upto;
+    }
+    for (uint64_t j0 = 0; j0 < out_frames;) {
+        const uint64_t seg_end = j0 < j_uni ? j_uni : out_frames;
+        const uint32_t nf = (uint32_t)(seg_end - j0 < step ? seg_end - j0 : step);
         WideTable tbl;
         uint32_t k = 0, nr = 0;
         bool cont = false;
@@ -147,6 +225,30 @@ rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uin
         };
         clear_rates();
         auto launch = [&]() {
+            {  // the uniform case (k_wide_mix_uniform): one rate, the mixer's layout, no source that ends inside the launch
+                bool uni = k > 0 && nr == 1;
+                const uint64_t il_max = ((uint64_t)tbl.r[0].r0 + (uint64_t)(nf - 1) * tbl.r[0].F) / tbl.r[0].T;
+                const bool lerp = tbl.r[0].F != tbl.r[0].T;
+                for (uint32_t q = 0; q < k && uni; ++q) uni = tbl.d[q].ch == channels && tbl.d[q].frames == nf && (!lerp || il_max < tbl.d[q].last);
+                if (uni && !rh::knob(rh::K_WIDE_GENERAL)) {
+                    WideUniTable u;
+                    u.F = tbl.r[0].F, u.T = tbl.r[0].T, u.r0 = tbl.r[0].r0, u.ch = channels, u.Tf = tbl.r[0].Tf;
+                    u.pad[0] = u.pad[1] = u.pad[2] = 0;
+                    for (uint32_t q = 0; q < kWideChunk; ++q) u.d[q] = WideUniSrc{tbl.d[q < k ? q : 0].data, q < k ? tbl.d[q].gain : 0.0f, 0u};
+                    const uint64_t total = (uint64_t)nf * channels;
+                    const dim3 grid(rh::grid_for((size_t)total, kBlock, 256u * 16u));
+                    float *d = dst + j0 * channels;
+                    hipStream_t st = rh::as_stream(stream);
+                    if (cont && lerp) hipLaunchKernelGGL((k_wide_mix_uniform<true, true>), grid, dim3(kBlock), 0, st, d, nf, u, k);
+                    else if (cont) hipLaunchKernelGGL((k_wide_mix_uniform<true, false>), grid, dim3(kBlock), 0, st, d, nf, u, k);
+                    else if (lerp) hipLaunchKernelGGL((k_wide_mix_uniform<false, true>), grid, dim3(kBlock), 0, st, d, nf, u, k);
+                    else hipLaunchKernelGGL((k_wide_mix_uniform<false, false>), grid, dim3(kBlock), 0, st, d, nf, u, k);
+                    cont = true;
+                    k = 0;
+                    clear_rates();
+                    return;
+                }
+            }
             while (k % kWideGroup) {  // whole groups: slots that reach no frame (and point at something readable: the first source's first tap)
                 WideDesc &d = tbl.d[k++];
                 d = WideDesc{tbl.d[0].data, 1u, 0u, 0u, 0u, 0.0f, 0.0f};
@@ -185,6 +287,7 @@ rh_status rh_wide_mix_block(float *dst, uint32_t channels, uint32_t to_rate, uin
         }
         if (k || !cont) launch();  // (no source reaches these frames: the mix is +0.0 there)
         RH_CHECK_LAUNCH();
+        j0 += nf;
     }
     return RH_OK;
 }

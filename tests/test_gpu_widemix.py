@@ -232,3 +232,16 @@ def test_wide_mix_properties_at_full_block_sizes(rh):
         x = rows[s].view(-1, Cc).to(torch.float64)
         ref += 0.5 * (x[i] + (x[i + 1] - x[i]) * w[:, None])
     assert float((m1.view(-1, Cc).to(torch.float64) - ref).abs().max()) < 64 * 4e-6
+
+
+@pytest.mark.parametrize("ch,rate,to_rate", [(6, 44100, 48000), (2, 44100, 48000), (6, 48000, 48000), (4, 96000, 44100), (1, 22050, 48000)])
+def test_wide_mix_alike_sources_take_the_uniform_kernel(rh, ch, rate, to_rate):
+    """Sources of the mixer's own layout and one rate: while all of them are live a block is k_wide_mix_uniform's (tap offset and weight worked out
+    once per lane); the blocks in which one of them ends go back to the general kernel.  40 sources (two launches a block), different lengths
+    and gains: the oracle's mixer, bit for bit."""
+    rng = np.random.default_rng(800 + ch)
+    srcs = [(rng.uniform(-1, 1, int(rng.integers(9000, 30000)) * ch).astype(np.float32), ch, rate, float(np.float32(rng.uniform(0.2, 1.5)))) for _ in range(40)]
+    want = _oracle(srcs, ch, to_rate)
+    got = _run(rh, srcs, ch, to_rate, rng, feed=3000)
+    assert got.shape == want.shape
+    assert np.array_equal(_bits(got), _bits(want))
