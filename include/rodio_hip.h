@@ -120,7 +120,9 @@ rh_status rh_convert_f64_to_f32(float *dst, const double *src, size_t n, rh_stre
 
 /* ---- WAV / PCM either side of the path (src/decoder/wav.rs:94-172 ingest, src/wav_output.rs:62-96 egress).
  * probe (host, no GPU): walks the RIFF chunks of a file image.  decode: `data` is a DEVICE copy of the data
- * chunk (8-bit unsigned, 16/24/32-bit signed LE or 32-bit float); dst receives *out_samples f32 samples --
+ * chunk (8-bit unsigned, 16/24/32-bit signed LE or 32-bit float) AT ANY BYTE ADDRESS -- `file + data_offset` of an uploaded file image
+ * is fine: the chunks in front of `data` decide where it starts (the reference's own assets/audacity32bit_int.wav: 32-bit samples at
+ * offset 102; tests/wav_test.rs) and hound reads a byte stream; dst receives *out_samples f32 samples --
  * n_samples plus the silence that completes a cut frame (wav.rs:161-169).  header (host): the 44-byte
  * 32-bit-float header wav_to_writer produces, for the whole frames of n_samples (wav_output.rs:98-140);
  * the payload is the f32 block itself.  Returns the bytes written (0 = does not fit). */

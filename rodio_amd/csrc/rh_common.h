@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what);
 // process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
 enum Knob {
     K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
-    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_WIDE_GENERAL, K_COUNT
+    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_WIDE_GENERAL, K_PCM_NO_TILE, K_PCM_TILE_KB, K_COUNT
 };
 const char *knob(Knob k);
 void load_knobs();
@@ -84,6 +84,8 @@ struct ScratchAux {
 hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold, ScratchAux **aux = nullptr);
 // device-to-device copy as a launch on `hs` (hipMemcpyAsync DeviceToDevice makes the calling thread wait for the queue ahead of it)
 hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
+// rh_wav.hip: ChannelCountConverter straight from sample bytes (PCM or f32 frames), a tile of frames per workgroup; false = not launched
+bool pcm_tile_try(float *dst, const uint8_t *data, uint64_t n_samples, uint64_t frames, uint32_t channels, uint32_t to_channels, int fmt, hipStream_t s);
 // rh_pipeline_plan.hip: `s` has been synchronised and is about to go -- fused-pipeline handles whose launches went there are idle now
 // (they record their idle event lazily, on the stream of their last launch: never on a destroyed one).
 void rlm_stream_retired(hipStream_t s);

@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what) {
 namespace {
 const char *const kKnobNames[K_COUNT] = {"RH_AGC_SEQ", "RH_AGC_VEC", "RH_BIQUAD_NO_FALLBACK", "RH_BIQUAD_SEQ", "RH_BIQUAD_R", "RH_BIQUAD_NW", "RH_BIQUAD_WGS", "RH_LIMIT_SEQ",
                                          "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_LIMIT_NIO", "RH_LIMIT_INIT", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
-                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC", "RH_NO_MIX_FIRST", "RH_MIX_U", "RH_NO_CHUNK", "RH_CHUNK_HALF", "RH_AUTOTUNE_LOG", "RH_RAG_RESIDENT", "RH_RAG_TWO_KERNELS", "RH_AGC_SEGMENTS", "RH_RS_PIPE", "RH_DASP_I64_VIA_F64", "RH_MIX_GROUPS", "RH_CLASSES_SIDE_BY_SIDE", "RH_AGC_FUSED_R4", "RH_STREAM_UPLOAD_ALWAYS", "RH_STREAM_NO_REJOIN", "RH_NO_SBLK", "RH_SBLK_KV", "RH_SBLK_NO_OVERLAP", "RH_CLASSES_ONE_BY_ONE", "RH_CLASSES_ONE_WAVE", "RH_WIDE_GENERAL"};
+                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC", "RH_NO_MIX_FIRST", "RH_MIX_U", "RH_NO_CHUNK", "RH_CHUNK_HALF", "RH_AUTOTUNE_LOG", "RH_RAG_RESIDENT", "RH_RAG_TWO_KERNELS", "RH_AGC_SEGMENTS", "RH_RS_PIPE", "RH_DASP_I64_VIA_F64", "RH_MIX_GROUPS", "RH_CLASSES_SIDE_BY_SIDE", "RH_AGC_FUSED_R4", "RH_STREAM_UPLOAD_ALWAYS", "RH_STREAM_NO_REJOIN", "RH_NO_SBLK", "RH_SBLK_KV", "RH_SBLK_NO_OVERLAP", "RH_CLASSES_ONE_BY_ONE", "RH_CLASSES_ONE_WAVE", "RH_WIDE_GENERAL", "RH_PCM_NO_TILE", "RH_PCM_TILE_KB"};
 std::string g_knob_val[K_COUNT];
 bool g_knob_set[K_COUNT];
 }  // namespace

@@ -355,13 +355,26 @@ def wav_probe(file_bytes: bytes):
     return {n: getattr(info, n) for n, _ in _lib.WavInfo._fields_}
 
 
-def WavDecoder(file_bytes: bytes) -> "GpuSource":
+def _wav_data_on_device(file_bytes: bytes, w, image: bool):
+    """The data chunk on the device: a copy of its own, or (image=True) the whole file uploaded as it is and the chunk taken where it lies
+    -- `file + data_offset`, whatever byte address that is."""
+    torch = _t()
+    if image and w["data_bytes"]:
+        whole = torch.from_numpy(np.frombuffer(file_bytes, dtype=np.uint8).copy()).to("cuda")
+        return whole[w["data_offset"]: w["data_offset"] + w["data_bytes"]]
+    raw = np.frombuffer(file_bytes, dtype=np.uint8, count=w["data_bytes"], offset=w["data_offset"])
+    return torch.from_numpy(raw.copy()).to("cuda") if raw.size else None
+
+
+def WavDecoder(file_bytes: bytes, image: bool = False) -> "GpuSource":
     """src/decoder/wav.rs: the data chunk goes to the device as bytes and is converted there."""
     _ensure()
     torch = _t()
     w = wav_probe(file_bytes)
-    raw = np.frombuffer(file_bytes, dtype=np.uint8, count=w["data_bytes"], offset=w["data_offset"])
-    d_in = torch.from_numpy(raw.copy()).to("cuda") if raw.size else torch.empty(0, dtype=torch.uint8, device="cuda")
+    d_in = _wav_data_on_device(file_bytes, w, image)
+    raw = np.empty(0 if d_in is None else 1, np.uint8)
+    if d_in is None:
+        d_in = torch.empty(0, dtype=torch.uint8, device="cuda")
     out = _dev_empty(w["samples"] + w["channels"])
     m = C.c_uint64(0)
     check(lib.rh_wav_decode(_ptr(out), _ptr(d_in) if raw.size else None, w["samples"], w["channels"], w["bits_per_sample"],
@@ -369,14 +382,15 @@ def WavDecoder(file_bytes: bytes) -> "GpuSource":
     return GpuSource(out[: m.value], w["channels"], w["sample_rate"], None)
 
 
-def WavDecoderChannels(file_bytes: bytes, to_channels: int) -> "GpuSource":
+def WavDecoderChannels(file_bytes: bytes, to_channels: int, image: bool = False) -> "GpuSource":
     """`UniformSourceIterator::new(decoder, to_channels, the file's rate)`: src/decoder/wav.rs + src/conversions/channels.rs:57-85 in ONE
     launch (rh_wav_decode_channels) -- the decoded block in the file's own layout never exists."""
     _ensure()
     torch = _t()
     w = wav_probe(file_bytes)
-    raw = np.frombuffer(file_bytes, dtype=np.uint8, count=w["data_bytes"], offset=w["data_offset"])
-    d_in = torch.from_numpy(raw.copy()).to("cuda") if raw.size else torch.empty(1, dtype=torch.uint8, device="cuda")
+    d_in = _wav_data_on_device(file_bytes, w, image)
+    if d_in is None:
+        d_in = torch.empty(1, dtype=torch.uint8, device="cuda")
     frames = (w["samples"] + w["channels"] - 1) // w["channels"]
     out = _dev_empty(frames * to_channels + 4)
     m = C.c_uint64(0)
