@@ -190,6 +190,48 @@ __global__ __launch_bounds__(kBlock) void k_channel_volume(float *__restrict__ d
         for (uint32_t k = 0; k < out_ch; ++k) dst[f * out_ch + k] = m * gains.g[k];
     }
 }
+// The same, a TILE of frames per workgroup (round 6; rh_wav.hip's k_pcm_to_channels_tile is the shape): the tile's samples come in once as
+// aligned 16-byte vectors and are parked in LDS, a lane per frame takes the mean there (the reference's order: from 0.0, channel after
+// channel, then / C_in), and a lane per four output SAMPLES multiplies by the channel's gain and stores 16 bytes.  A lane per frame that
+// loops over both layouts measured 0.48 (6 -> 2) and 0.39 (2 -> 6) of 8 TB/s.
+__global__ __launch_bounds__(kBlock) void k_channel_volume_tile(float *__restrict__ dst, const float *__restrict__ src, size_t frames, uint32_t in_ch, Gains gains, uint32_t out_ch,
+                                                                 uint32_t tile_frames, uint32_t in_floats, int vec_ok) {
+    extern __shared__ uint4 cv_tile[];
+    float *lds = reinterpret_cast<float *>(cv_tile);
+    float *means = lds + in_floats, *g = means + tile_frames;
+    const size_t f0 = (size_t)blockIdx.x * tile_frames;  // (a multiple of 4 frames: the tile's first output sample starts a 16-byte vector)
+    const uint32_t nf = (uint32_t)(frames - f0 < tile_frames ? frames - f0 : tile_frames);
+    const uintptr_t p0 = reinterpret_cast<uintptr_t>(src + f0 * in_ch), a0 = p0 & ~(uintptr_t)15;
+    const uint32_t shift = (uint32_t)(p0 - a0) / 4u, nvec = (shift + nf * in_ch + 3u) / 4u;
+    for (uint32_t v = threadIdx.x; v < nvec; v += kBlock) cv_tile[v] = rh::ld_nt(reinterpret_cast<const uint4 *>(a0) + v);
+    if (threadIdx.x < out_ch) g[threadIdx.x] = gains.g[threadIdx.x];
+    __syncthreads();
+    for (uint32_t f = threadIdx.x; f < nf; f += kBlock) {
+        const float *x = lds + shift + f * in_ch;
+        float m = 0.0f;
+        for (uint32_t c = 0; c < in_ch; ++c) m = m + x[c];
+        means[f] = m / (float)in_ch;
+    }
+    __syncthreads();
+    const uint32_t total = nf * out_ch, nv = (total + 3u) / 4u;
+    float *out = dst + f0 * out_ch;
+    for (uint32_t v = threadIdx.x; v < nv; v += kBlock) {
+        const uint32_t o0 = 4u * v;
+        uint32_t f = o0 / out_ch, k = o0 - f * out_ch;
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = o0 + j < total ? means[f] * g[k] : 0.0f;
+            if (++k == out_ch) k = 0, ++f;
+        }
+        if (vec_ok && o0 + 4u <= total) {
+            rh::st_nt(reinterpret_cast<float4 *>(out + o0), make_float4(e[0], e[1], e[2], e[3]));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (o0 + j < total) out[o0 + j] = e[j];
+        }
+    }
+}
 // Stereo in / stereo out (Spatial): one float2 load + one float2 store per lane.
 __global__ __launch_bounds__(kBlock) void k_channel_volume_2x2(float2 *__restrict__ dst, const float2 *__restrict__ src, size_t frames, float g0, float g1) {
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -205,12 +247,26 @@ __global__ __launch_bounds__(kBlock) void k_channel_volume_2x2(float2 *__restric
 // y[n] = x[n] + 0.0 (n < D); x[n] + a*x[n-D] (D <= n < L); a*x[n-D] (L <= n < L+D); when D > L
 // the gap [L, D) is Delay's zeros alone.  The second tap is 4*D bytes behind the first, i.e.
 // an L2 / Infinity-Cache hit for any realistic D, so HBM sees one read and one write.
-__global__ __launch_bounds__(kBlock) void k_echo_mix(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain) {
-    const size_t total = n + delay;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
-        const float s2 = (i < delay) ? 0.0f : src[i - delay] * gain;  // Delay(Amplify(x))
-        dst[i] = (i < n) ? (src[i] + s2) : s2;                          // mix.rs:47-52
+__global__ __launch_bounds__(kBlock) void k_echo_mix(float *__restrict__ dst, const float *__restrict__ src, size_t n, size_t delay, float gain, int vec_ok) {
+    // four consecutive samples a lane (round 6: a sample a lane measured 0.37 of 8 TB/s, tools/bench_rows.py); the operations per sample are
+    // the reference's: Delay(Amplify(x)) = x[i - D] * gain, or Delay's 0.0; mix.rs:47-52 adds where the input still runs
+    const size_t total = n + delay, nvec = (total + 3) / 4, stride = (size_t)gridDim.x * kBlock;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const size_t i = 4 * v;
+        const float4 xv = rh::ld4_at(src, (int64_t)i, n), dv = rh::ld4_at(src, (int64_t)i - (int64_t)delay, n);
+        const float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s2 = (i + j < delay) ? 0.0f : d[j] * gain;
+            e[j] = (i + j < n) ? (x[j] + s2) : s2;
+        }
+        if (vec_ok && i + 4 <= total) {
+            rh::st_nt(reinterpret_cast<float4 *>(dst) + v, make_float4(e[0], e[1], e[2], e[3]));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < total) dst[i + j] = e[j];
+        }
     }
 }
 
@@ -465,7 +521,16 @@ rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_
     } else {
         Gains g{};
         for (uint32_t k = 0; k < out_ch; ++k) g.g[k] = gains_host[k];
-        hipLaunchKernelGGL(k_channel_volume, dim3(rh::grid_for(frames)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, in_ch, g, out_ch);
+        // ~10 KiB in + out a tile (rh_wav.hip's measurement of this shape); frames of hundreds of channels keep the lane per frame
+        const uint64_t tf = (10240ull / (4ull * (in_ch + out_ch))) & ~3ull;
+        if (tf >= 8 && !rh::knob(rh::K_PCM_NO_TILE) && (frames + tf - 1) / tf <= 0x7fffffffull) {
+            const uint32_t in_floats = (uint32_t)((tf * in_ch + 4 + 3) & ~3ull);
+            const size_t lds = ((size_t)in_floats + tf + 16) * 4;
+            hipLaunchKernelGGL(k_channel_volume_tile, dim3((unsigned)((frames + tf - 1) / tf)), dim3(kBlock), lds, rh::as_stream(stream), dst, src, frames, in_ch, g, out_ch, (uint32_t)tf, in_floats,
+                               (int)aligned16(dst));
+        } else {
+            hipLaunchKernelGGL(k_channel_volume, dim3(rh::grid_for(frames)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, in_ch, g, out_ch);
+        }
     }
     RH_CHECK_LAUNCH();
     return RH_OK;
@@ -559,7 +624,7 @@ rh_status rh_echo_mix(float *dst, const float *src, size_t n, size_t delay_sampl
     RH_REQUIRE_INIT();
     if (n + delay_samples == 0) return RH_OK;
     if (!dst || (!src && n)) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_echo_mix, dim3(rh::grid_for(n + delay_samples)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain);
+    hipLaunchKernelGGL(k_echo_mix, dim3(rh::grid_tiles((n + delay_samples + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, gain, (int)aligned16(dst));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -53,14 +53,13 @@ struct U64ToF32ViaF64 { typedef uint64_t In; typedef float Out; static __device_
 struct F64ToF32 { typedef double In; typedef float Out; static __device__ __forceinline__ Out cvt(In s) { return (float)s; } };
 
 // Distortion: src/source/distortion.rs:66-72  (v = x*gain; v.clamp(-t, t); NaN stays NaN)
-__global__ __launch_bounds__(kBlock) void k_distortion(float *__restrict__ dst, const float *__restrict__ src, size_t n, float gain, float threshold) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        float v = src[i] * gain;
+__global__ __launch_bounds__(kBlock) void k_distortion(float *__restrict__ dst, const float *__restrict__ src, size_t n, float gain, float threshold, int vec_ok) {
+    rh::map4<kBlock>(dst, src, n, vec_ok, [=](size_t, float x) {
+        float v = x * gain;
         v = v < -threshold ? -threshold : v;
         v = v > threshold ? threshold : v;
-        dst[i] = v;
-    }
+        return v;
+    });
 }
 // Dither: src/source/dither.rs:217-242  out = x - noise * lsb, lsb = 1 / 2^(bits-1).  The reference draws the
 // noise from a SmallRng seeded from system entropy (noise.rs:137,198,378,554), so no two runs of it agree; the
@@ -80,9 +79,8 @@ __device__ __forceinline__ uint64_t dither_bits(uint64_t seed, uint64_t k) {
 }
 __device__ __forceinline__ float dither_u1(uint64_t h) { return (float)((int32_t)(h >> 40) - 8388608) * 1.1920928955078125e-07f; }              // 24 bits -> [-1, 1)
 __device__ __forceinline__ float dither_u2(uint64_t h) { return (float)((int32_t)((h >> 16) & 0xffffffu) - 8388608) * 1.1920928955078125e-07f; }
-__global__ __launch_bounds__(kBlock) void k_dither(float *__restrict__ dst, const float *__restrict__ src, size_t n, uint64_t k0, uint32_t channels, float lsb, int32_t algorithm, uint64_t seed) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+__global__ __launch_bounds__(kBlock) void k_dither(float *__restrict__ dst, const float *__restrict__ src, size_t n, uint64_t k0, uint32_t channels, float lsb, int32_t algorithm, uint64_t seed, int vec_ok) {
+    rh::map4<kBlock>(dst, src, n, vec_ok, [=](size_t i, float x) {
         const uint64_t k = k0 + i;
         const uint64_t h = dither_bits(seed, k);
         float noise;
@@ -98,49 +96,80 @@ __global__ __launch_bounds__(kBlock) void k_dither(float *__restrict__ dst, cons
             const float b = (float)((uint32_t)(h >> 16) & 0xffffffu) * 5.9604644775390625e-08f;  // [0, 1)
             noise = sqrtf(-2.0f * logf(a)) * cosf(6.2831853071795864769f * b) * 0.6f;
         }
-        dst[i] = src[i] - noise * lsb;
-    }
+        return x - noise * lsb;
+    });
 }
 // LinearGainRamp (fade_in / fade_out): src/source/linear_ramp.rs:79-110.  The iterator's `elapsed` is a
 // pure function of the frame index while the ramp runs (f * (1e9 / rate) ns), so the op is stateless:
 // sample k0+i of the stream is in frame (k0+i)/channels.
 __device__ __forceinline__ float secs_f32(uint64_t ns) { return (float)(ns / 1000000000ull) + (float)(uint32_t)(ns % 1000000000ull) / 1000000000.0f; }
+// (a lane's four samples: ONE 64-bit division finds the first one's frame, the others follow by counting channels)
 __global__ __launch_bounds__(kBlock) void k_linear_gain_ramp(float *__restrict__ dst, const float *__restrict__ src, size_t n, uint64_t k0, uint32_t channels, uint64_t step_ns,
-                                                             uint64_t total_ns, float total_s, float start_gain, float end_gain, float after) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint64_t frame = (k0 + i) / channels;
-        // elapsed >= total  <=>  frame >= ceil(total / step); guard the product against wrap-around
-        const bool done = step_ns != 0 && frame >= (total_ns + step_ns - 1) / step_ns;
-        float factor = after;
-        if (!done) {
-            const float p = secs_f32(frame * step_ns) / total_s;
-            factor = start_gain * (1.0f - p) + end_gain * p;
+                                                             uint64_t done_frame, float total_s, float start_gain, float end_gain, float after, int vec_ok) {
+    const size_t nvec = (n + 3) / 4, stride = (size_t)gridDim.x * kBlock;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const size_t i = 4 * v;
+        uint64_t frame = (k0 + i) / channels;
+        uint32_t c = (uint32_t)((k0 + i) - frame * channels);
+        auto factor_of = [&](uint64_t fr) {
+            // elapsed >= total  <=>  frame >= ceil(total / step) (done_frame; never when the step is 0)
+            if (step_ns != 0 && fr >= done_frame) return after;
+            const float p = secs_f32(fr * step_ns) / total_s;
+            return start_gain * (1.0f - p) + end_gain * p;
+        };
+        float factor = factor_of(frame);
+        float x[4], y[4];
+        const bool vec = vec_ok && i + 4 <= n;
+        if (vec) {
+            const float4 t = rh::ld_nt(reinterpret_cast<const float4 *>(src) + v);
+            x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
+        } else {
+            for (int j = 0; j < 4; ++j) x[j] = i + j < n ? src[i + j] : 0.0f;
         }
-        dst[i] = src[i] * factor;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = x[j] * factor;
+            if (++c == channels) c = 0, factor = factor_of(++frame);
+        }
+        if (vec) {
+            rh::st_nt(reinterpret_cast<float4 *>(dst) + v, make_float4(y[0], y[1], y[2], y[3]));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) dst[i + j] = y[j];
+        }
     }
 }
 
 // Delay: src/source/delay.rs:68-75 -- `delay` samples of silence, then the input.
-__global__ __launch_bounds__(kBlock) void k_delay(float *__restrict__ dst, const float *__restrict__ src, uint64_t n, uint64_t delay) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n + delay; i += stride) dst[i] = i < delay ? 0.0f : src[i - delay];
+__global__ __launch_bounds__(kBlock) void k_delay(float *__restrict__ dst, const float *__restrict__ src, uint64_t n, uint64_t delay, int vec_ok) {
+    const uint64_t total = n + delay, nvec = (total + 3) / 4, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const uint64_t i = 4 * v;
+        const float4 x = rh::ld4_at(src, (int64_t)i - (int64_t)delay, n);  // 0.0 in front of the row: Delay's silence
+        if (vec_ok && i + 4 <= total) {
+            rh::st_nt(reinterpret_cast<float4 *>(dst) + v, x);
+        } else {
+            const float e[4] = {x.x, x.y, x.z, x.w};
+            for (int j = 0; j < 4; ++j)
+                if (i + j < total) dst[i + j] = e[j];
+        }
+    }
 }
 // TakeDuration: src/source/take.rs:96-148.  out[i] = x[i] (optionally * remaining_ms / total_ms, the
 // fade-out filter of :33-38) for the `take` samples the duration admits, then `pad` zeros that complete
 // the frame.  remaining at sample i of the block = rem0 - i * (1e9 / (rate*channels)).
 __global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ dst, const float *__restrict__ src, uint64_t take, uint64_t pad, uint64_t rem0_ns, uint64_t dps_ns,
-                                                          uint64_t requested_ns, int fade) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+                                                          uint64_t requested_ns, int fade, int vec_ok) {
     const float total = (float)(requested_ns / 1000000ull);
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < take + pad; i += stride) {
-        float v = 0.0f;
-        if (i < take) {
-            v = src[i];
-            if (fade) v = v * (float)((rem0_ns - i * dps_ns) / 1000000ull) / total;
-        }
-        dst[i] = v;
-    }
+    auto one = [=](size_t i, float x) {
+        float v = x;
+        if (fade) v = v * (float)((rem0_ns - i * dps_ns) / 1000000ull) / total;
+        return v;
+    };
+    rh::map4<kBlock>(dst, src, (size_t)take, vec_ok, one);
+    if (pad && blockIdx.x == 0 && threadIdx.x < pad) dst[take + threadIdx.x] = 0.0f;  // the zeros that complete a cut frame (fewer than `channels`)
+    if (pad > kBlock && blockIdx.x == 0)
+        for (uint64_t i = kBlock + threadIdx.x; i < pad; i += kBlock) dst[take + i] = 0.0f;
 }
 
 template <typename Op>
@@ -158,6 +187,8 @@ rh_status launch(typename Op::Out *dst, const typename Op::In *src, size_t n, rh
     return RH_OK;
 }
 
+inline int rows_vec_ok(const void *dst, const void *src) { return ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0; }
+
 }  // namespace
 
 extern "C" {
@@ -166,7 +197,7 @@ rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, floa
     if (!(threshold >= 0.0f)) return RH_ERR_INVALID;  // f32::clamp panics when min > max or NaN
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_distortion, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold);
+    hipLaunchKernelGGL(k_distortion, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold, rows_vec_ok(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -176,7 +207,7 @@ rh_status rh_dither(float *dst, const float *src, size_t n, uint64_t sample_offs
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
     const float lsb = (float)(1.0 / (double)(1ull << (target_bits - 1)));  // dither.rs:180
-    hipLaunchKernelGGL(k_dither, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, lsb, algorithm, seed);
+    hipLaunchKernelGGL(k_dither, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, lsb, algorithm, seed, rows_vec_ok(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -188,8 +219,9 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
     if (!dst || !src) return RH_ERR_INVALID;
     const uint64_t step_ns = 1000000000ull / sample_rate;  // linear_ramp.rs:98-100 (0 above 1 GHz: the ramp never advances)
     const float total_s = (float)(duration_ns / 1000000000ull) + (float)(uint32_t)(duration_ns % 1000000000ull) / 1000000000.0f;
-    hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, duration_ns, total_s, start_gain,
-                       end_gain, clamp_end ? end_gain : 1.0f);
+    const uint64_t done_frame = step_ns ? (duration_ns + step_ns - 1) / step_ns : 0;  // elapsed >= total from this frame on
+    hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, done_frame, total_s, start_gain,
+                       end_gain, clamp_end ? end_gain : 1.0f, rows_vec_ok(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -197,7 +229,7 @@ rh_status rh_delay(float *dst, const float *src, uint64_t n, uint64_t delay_samp
     RH_REQUIRE_INIT();
     if (n + delay_samples == 0) return RH_OK;
     if (!dst || (n && !src)) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_delay, dim3(rh::grid_for(n + delay_samples)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples);
+    hipLaunchKernelGGL(k_delay, dim3(rh::grid_tiles((n + delay_samples + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, delay_samples, (int)((reinterpret_cast<uintptr_t>(dst) & 15u) == 0));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -217,7 +249,7 @@ rh_status rh_take_duration_from(float *dst, const float *src, uint64_t n, uint64
     if (remaining_after_ns) *remaining_after_ns = remaining_ns - take * dps;
     if (take + pad == 0) return RH_OK;
     if (!dst || (take && !src)) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_for(take + pad)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, remaining_ns, dps, requested_ns, fade_out ? 1 : 0);
+    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_tiles((take + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, remaining_ns, dps, requested_ns, fade_out ? 1 : 0, rows_vec_ok(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

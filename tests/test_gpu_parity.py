@@ -154,6 +154,24 @@ def test_resample_bit_exact(G, O, frm, to, ch, n):
 
 
 @pytest.mark.parametrize("frm,to,ch,n,span", [
+    (44100, 48000, 1, 31_000_001, 0),   # longer than 2^32 / F frames: the position no longer fits 32 bits (sample_rate.rs keeps it per span; one span here)
+    (44101, 48000, 2, 9_000_001, 0),    # F = 44101, T = 48000: a tile's remainder times its index passes 2^32 (the 64-bit branch of the tile's base)
+    (48000, 44100, 2, 2_000_001, 0), (44100, 48000, 6, 700_001, 0), (44100, 48000, 2, 3_000_000, 32768), (44100, 48000, 2, 400_001, 96), (8000, 48000, 1, 300_001, 40),
+])
+def test_resample_tiles_long_rows_bit_exact(G, O, frm, to, ch, n, span):
+    """rh_resample_linear's tile kernel (k_resample_tile): rows of many tiles, positions beyond 32 bits, spans shorter than a tile (a tile across
+    several chunk boundaries: the frame-by-frame branch, and runs that do not fit the tile's LDS) -- against the oracle's pull loop, bit for bit."""
+    x = rnd(n + 7, n * ch)
+    if span:
+        ref = O.UniformSourceIterator(O.SpanSource(x, ch, frm, span), ch, to).collect()
+        out = G.UniformSourceIterator(G.SpanSource(x, ch, frm, span), ch, to).collect()
+    else:
+        ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+        out = G.SampleRateConverter(G.TestSource(x, ch, frm), frm, to, ch).collect()
+    assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("frm,to,ch,n,span", [
     (44100, 48000, 2, 100000, 32768), (44100, 48000, 2, 16384 * 3, 32768), (44100, 48000, 2, 16384 * 3 + 1, 32768),
     (48000, 44100, 2, 70001, 32768), (44100, 48000, 1, 5000, 300), (8000, 48000, 2, 999, 64),
     (48000, 8000, 2, 5003, 1000), (44100, 48000, 2, 100000, 1 << 22),
@@ -667,9 +685,9 @@ def test_agc(G, O):
     assert np.max(np.abs(out - ref)) <= TOL
 
 
-def test_mixer_random_ordered_sum_bit_exact(G, O):
+@pytest.mark.parametrize("S,n", [(37, 20001), (150, 6001)])  # 150: more sources than one launch's table holds (128) -- the sum continues from the stored partial
+def test_mixer_random_ordered_sum_bit_exact(G, O, S, n):
     # full-scale sources: only the reference's own summation order reproduces these bits
-    S, n = 37, 20001
     mo, mg = O.Mixer(2, 48000), G.Mixer(2, 48000)
     for s in range(S):
         x = rnd(100 + s, 2 * (n - 13 * s))
