@@ -172,17 +172,38 @@ __global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ ds
         for (uint64_t i = kBlock + threadIdx.x; i < pad; i += kBlock) dst[take + i] = 0.0f;
 }
 
+// Four consecutive samples a lane, one load and one store of four (16 bytes for the 4-byte formats, 2 x 16 for i64 / u64 / f64) where both rows
+// start on such a boundary; a vector a lane (rh::grid_tiles).  A sample a lane under the capped grid-stride loop was 0.3-0.6 of 8 TB/s.
+template <typename T>
+struct alignas(4 * sizeof(T)) Quad {
+    T e[4];
+};
 template <typename Op>
-__global__ __launch_bounds__(kBlock) void k_convert(typename Op::Out *__restrict__ dst, const typename Op::In *__restrict__ src, size_t n) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = Op::cvt(src[i]);
+__global__ __launch_bounds__(kBlock) void k_convert(typename Op::Out *__restrict__ dst, const typename Op::In *__restrict__ src, size_t n, int vec_ok) {
+    typedef Quad<typename Op::In> QI;
+    typedef Quad<typename Op::Out> QO;
+    const size_t nvec = (n + 3) / 4, stride = (size_t)gridDim.x * kBlock;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const size_t i = 4 * v;
+        if (vec_ok && i + 4 <= n) {
+            const QI x = reinterpret_cast<const QI *>(src)[v];
+            QO y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y.e[j] = Op::cvt(x.e[j]);
+            reinterpret_cast<QO *>(dst)[v] = y;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) dst[i + j] = Op::cvt(src[i + j]);
+        }
+    }
 }
 template <typename Op>
 rh_status launch(typename Op::Out *dst, const typename Op::In *src, size_t n, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_convert<Op>, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
+    const int vec_ok = reinterpret_cast<uintptr_t>(dst) % sizeof(Quad<typename Op::Out>) == 0 && reinterpret_cast<uintptr_t>(src) % sizeof(Quad<typename Op::In>) == 0;
+    hipLaunchKernelGGL(k_convert<Op>, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

@@ -5,7 +5,8 @@
 // The RIFF chunk walk and the header are host work (rh_wav_probe_host / rh_wav_header_f32_host: plain C,
 // no GPU); the sample conversion runs on the device straight from the file bytes, so a file -> file job
 // never does the int -> float pass on the CPU.  hound is an un-vendored dependency (Cargo.lock): its
-// byte-level behaviour is restated from the WAVE specification -- parity unpinned.
+// byte-level behaviour is restated from the WAVE specification and pinned by the six files the reference's own test decodes
+// (tests/wav_test.rs:1-33; tests/golden/wav/) against scipy.io.wavfile, bit for bit (tests/test_wav_assets.py).
 #include <cstdlib>
 #include <cstring>
 
