@@ -782,6 +782,26 @@ def headline(args, argv):
                                      "what": "one block of mixer::mixer(6, 48 kHz): 16 resident 5.1 sources at 44.1 kHz, amplify -> convert -> ordered sum, 16384 frames (a short launch-bound kernel: see ms)"}
             except Exception as e:  # noqa: BLE001
                 side_legs["wide"] = {"error": str(e)[:200]}
+            try:  # the one-row launches a chain falls back to (SURVEY 8(a) row by row), at a quarter of tools/bench_rows.py's size; the resampler against the oracle
+                import bench_rows
+                import numpy as np
+
+                names = ["resample_linear ch=2 44100->48000", "resample_linear ch=1 44100->48000", "resample_linear ch=6 44100->48000", "mix_sum S=32", "amplify", "echo_mix D=65536",
+                         "channel_volume 2->6", "i16_to_f32", "linear_gain_ramp", "delay D=65536"]
+                rr = bench_rows.measure(128, 5, names)
+                xs = (np.random.default_rng(77).uniform(-1, 1, 2 * 300_001)).astype(np.float32)
+                import rodio_amd as rh_
+                from oracle import rodio_oracle as O_
+
+                got_ = rh_.SampleRateConverter(rh_.TestSource(xs, 2, 44100), 44100, 48000, 2).collect()
+                ref_ = O_.SampleRateConverter(O_.TestSource(xs, 2, 44100), 44100, 48000, 2).collect()
+                side_legs["rows"] = {"frac": {r["row"]: r["frac"] for r in rr}, "ms": {r["row"]: r["ms"] for r in rr},
+                                     "parity_ok": bool(got_.shape == ref_.shape and np.array_equal(got_.view(np.uint32), ref_.view(np.uint32))),
+                                     "vs": "the oracle's SampleRateConverter on 300 001 stereo frames, bit for bit (the other rows: pytest -m gpu)",
+                                     "what": "stand-alone C-ABI entries on 128 MiB of f32 input, HIP events, fraction of 8 TB/s on algorithmic bytes (tools/bench_rows.py; 512 MiB: profiles/r06_rows.txt)"}
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                side_legs["rows"] = {"error": str(e)[:200]}
             for cfg_ in ("3", "5"):
                 a2 = copy.copy(args)
                 a2.config, a2.steps, a2.warmup, a2.no_cpu_baseline = cfg_, 10, 2, False

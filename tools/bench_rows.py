@@ -29,13 +29,11 @@ def timed(fn, steps):
     return e0.elapsed_time(e1) / steps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mib", type=int, default=512)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--only", default="")
-    a = ap.parse_args()
-    only = set(x for x in a.only.split(",") if x)
+def measure(mib=512, steps=10, only=(), emit=None):
+    """The rows as a list of dicts (bench.py's `roofline.side.rows` calls this with a smaller size and a few rows)."""
+    a = argparse.Namespace(mib=mib, steps=steps)
+    only = set(only)
+    rows = []
     source._ensure()
     lib, st = _lib.lib, source._stream()
     n = (a.mib << 20) // 4  # f32 samples of input
@@ -50,7 +48,9 @@ def main():
         d = {"row": name, "ms": round(ms, 4), "GBps": round(alg / ms / 1e6, 1), "frac": round(alg / ms / 1e6 / 8000, 3)}
         if extra:
             d.update(extra)
-        print(json.dumps(d), flush=True)
+        rows.append(d)
+        if emit:
+            emit(d)
 
     # a1/a2 SampleRateConverter, stand-alone: 44.1 -> 48 kHz (and down), stereo / mono / 5.1
     for ch, fr, to in [(2, 44100, 48000), (1, 44100, 48000), (6, 44100, 48000), (2, 48000, 44100), (2, 8000, 48000)]:
@@ -87,6 +87,16 @@ def main():
     i16 = torch.empty(n, dtype=torch.int16, device="cuda")
     row("f32_to_i16", lambda: ck(lib.rh_convert_f32_to_i16(P(i16), P(x), n, st), "cv"), 6 * n)
     row("i16_to_f32", lambda: ck(lib.rh_convert_i16_to_f32(P(dst), P(i16), n, st), "cv"), 6 * n)
+    i32 = torch.empty(n, dtype=torch.int32, device="cuda")
+    row("f32_to_i32", lambda: ck(lib.rh_convert_f32_to_i32(P(i32), P(x), n, st), "cv"), 8 * n)
+    row("f32_to_u32", lambda: ck(lib.rh_convert_f32_to_u32(P(i32), P(x), n, st), "cv"), 8 * n)
+    row("u32_to_f32", lambda: ck(lib.rh_convert_u32_to_f32(P(dst), P(i32), n, st), "cv"), 8 * n)
+    u8 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    row("f32_to_u8", lambda: ck(lib.rh_convert_f32_to_u8(P(u8), P(x), n, st), "cv"), 5 * n)
+    f64 = torch.empty(n // 2, dtype=torch.float64, device="cuda")
+    row("f32_to_f64", lambda: ck(lib.rh_convert_f32_to_f64(P(f64), P(x), n // 2, st), "cv"), 12 * (n // 2))
+    row("f64_to_f32", lambda: ck(lib.rh_convert_f64_to_f32(P(dst), P(f64), n // 2, st), "cv"), 12 * (n // 2))
+    del i32, u8, f64
     # (f)3 elementwise adapters
     row("distortion", lambda: ck(lib.rh_distortion(P(dst), P(x), n, 2.0, 0.8, st), "rh_distortion"), 8 * n)
     row("delay D=65536", lambda: ck(lib.rh_delay(P(dst), P(x), n, D, st), "rh_delay"), 4 * n + 4 * (n + D))
@@ -97,6 +107,16 @@ def main():
     ck(lib.rh_biquad_coeffs(0, 200, 0.5, 48000, co), "coeffs")
     S = 64
     row("biquad 64 streams (mode 1)", lambda: ck(lib.rh_biquad(P(dst), P(x), n // S // 2, 2, S, co, None, 1, st), "rh_biquad"), 8 * (n // S // 2) * 2 * S)
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mib", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    measure(a.mib, a.steps, [x for x in a.only.split(",") if x], emit=lambda d: print(json.dumps(d), flush=True))
 
 
 if __name__ == "__main__":
