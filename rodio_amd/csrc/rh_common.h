@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what);
 // process that changes one afterwards calls rh_init() again.  knob() returns the value or nullptr.
 enum Knob {
     K_AGC_SEQ, K_AGC_VEC, K_BIQUAD_NO_FALLBACK, K_BIQUAD_SEQ, K_BIQUAD_R, K_BIQUAD_NW, K_BIQUAD_WGS, K_LIMIT_SEQ, K_LIMIT_R, K_LIMIT_NW, K_LIMIT_WGS, K_LIMIT_GRID,
-    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_WIDE_GENERAL, K_PCM_NO_TILE, K_PCM_TILE_KB, K_COUNT
+    K_LIMIT_SKEW, K_LIMIT_NIO, K_LIMIT_INIT, K_SCAN_DMA_TOP, K_SCAN_SPIN_LIMIT, K_NO_HYBRID, K_NO_TICKET_SHARDS, K_PROF_DUMP, K_HOST_ALLOC, K_NO_MIX_FIRST, K_MIX_U, K_NO_CHUNK, K_CHUNK_HALF, K_AUTOTUNE_LOG, K_RAG_RESIDENT, K_RAG_TWO_KERNELS, K_AGC_SEGMENTS, K_RS_PIPE, K_DASP_I64_VIA_F64, K_MIX_GROUPS, K_CLASSES_SIDE_BY_SIDE, K_AGC_FUSED_R4, K_STREAM_UPLOAD_ALWAYS, K_STREAM_NO_REJOIN, K_NO_SBLK, K_SBLK_KV, K_SBLK_NO_OVERLAP, K_CLASSES_ONE_BY_ONE, K_CLASSES_ONE_WAVE, K_WIDE_GENERAL, K_PCM_NO_TILE, K_PCM_TILE_KB, K_LERP_IEEE_DIV, K_COUNT
 };
 const char *knob(Knob k);
 void load_knobs();
@@ -84,6 +84,19 @@ struct ScratchAux {
 hipError_t stream_scratch(hipStream_t s, size_t bytes, void **out, std::unique_lock<std::mutex> &hold, ScratchAux **aux = nullptr);
 // device-to-device copy as a launch on `hs` (hipMemcpyAsync DeviceToDevice makes the calling thread wait for the queue ahead of it)
 hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
+// The lerp's division `(b - a) * num / T` (math.rs:25) in three instructions instead of the IEEE sequence's ten -- q0 = t * r, rem = fma(-q0, T, t),
+// q = fma(rem, r, q0) with r = RN(1 / T) from the host (Markstein) -- is NOT the IEEE quotient for every t: tools/ubench/div_check.hip runs all 2^32
+// bit patterns of t (profiles/r06_div_check.txt).  For T = 160 it differs for t = -0 (it returns +0; and t is a zero on every frame that lands on
+// a tap), for +-Inf (NaN), and for 1.7 M values below 2^-120 where the residual underflows; whether it is exact on the rest depends on T.
+// What the FUSED converter without a filter does (div_lerp below; the only kernel family that needs the short form -- the stand-alone converter
+// measured the same with the IEEE division and simply divides): (i) lerp_div_fast_ok(T) CHECKS the T of a plan once per process -- every mantissa,
+// both signs, three binades (the quotient scales with t as long as nothing underflows) against the IEEE division on the device -- and caches the
+// answer; a T that fails gets r = 0: the IEEE division; (ii) zeros and infinities take q0, which is the IEEE answer for them; (iii) nonzero
+// |t| < 2^-120 -- 1e-36, the last samples of a tail that decays into subnormals -- may come out one unit of THEIR last place off (1e-45 absolute):
+// the one place where the unfiltered fused mix is not the reference's bits (a guard per sample cost the kernel a quarter of its rate, 0.78 -> 0.57
+// of the roofline; tests/test_gpu_parity.py::test_lerp_division_*).  RH_LERP_IEEE_DIV=1: the IEEE division everywhere.
+bool lerp_div_fast_ok(uint32_t T);
+inline float lerp_rcp(uint32_t T) { return lerp_div_fast_ok(T) ? 1.0f / (float)T : 0.0f; }
 // rh_wav.hip: ChannelCountConverter straight from sample bytes (PCM or f32 frames), a tile of frames per workgroup; false = not launched
 bool pcm_tile_try(float *dst, const uint8_t *data, uint64_t n_samples, uint64_t frames, uint32_t channels, uint32_t to_channels, int fmt, hipStream_t s);
 // rh_pipeline_plan.hip: `s` has been synchronised and is about to go -- fused-pipeline handles whose launches went there are idle now
@@ -128,6 +141,14 @@ __device__ __forceinline__ void st_nt(float4 *p, float4 v) {
 }
 __device__ __forceinline__ void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
 
+// t / Tf as the fused converter takes it (see lerp_div_fast_ok above); rcpT = rh::lerp_rcp(T), the same in every lane
+__device__ __forceinline__ float div_lerp(float t, float Tf, float rcpT) {
+    if (rcpT == 0.0f) return t / Tf;
+    const float q0 = t * rcpT;
+    const float rem = __builtin_fmaf(-q0, Tf, t);
+    const float q = __builtin_fmaf(rem, rcpT, q0);
+    return __builtin_amdgcn_classf(t, 0x264) ? q0 : q;  // +-0 and +-Inf: q0 is the quotient (the residual would make +0 of -0 and NaN of Inf)
+}
 // dst[i] = f(i, src[i]) for i < n, FOUR consecutive samples a lane (one 16-byte load, one 16-byte store where both rows start on 16-byte
 // boundaries), a vector a lane and a grid of rh::grid_tiles((n + 3) / 4): the shape tools/bench_rows.py measured at 0.79-0.82 of 8 TB/s
 // (amplify, f32 -> i16) against 0.26-0.61 for a sample a lane under a capped grid-stride loop.  Works in place.

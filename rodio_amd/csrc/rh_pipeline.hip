@@ -2966,7 +2966,7 @@ rh_status rlm_launch(rh_rlm *p, uint32_t first, uint32_t count, float *dst, uint
     k.qF = p->F / p->T;
     k.rF = p->F % p->T;
     k.Tf = (float)p->T;
-    k.rcpT = 1.0f / (float)p->T;
+    k.rcpT = rh::lerp_rcp(p->T);  // 0: this T did not pass the exhaustive check of the short division (rh_common.h)
     k.epoch = p->epoch;
     k.J = pl.J;
     k.ticket_base = p->ticket_base;

@@ -55,13 +55,10 @@ __device__ __forceinline__ void cursor_resolve(const Cursor &c, const Params &p,
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// Correctly rounded t / T with a host-side correctly rounded reciprocal (Markstein): q0 within
-// 1 ulp, exact residual by FMA, one correction.  Same value as the IEEE divide in math.rs:25.
-__device__ __forceinline__ float div_T(float t, float Tf, float rcpT) {
-    const float q0 = t * rcpT;
-    const float rem = fma_(-q0, Tf, t);
-    return fma_(rem, rcpT, q0);
-}
+// t / T of math.rs:25: rh::div_lerp (rh_common.h) -- three instructions and a select where that is the IEEE quotient (rcpT = rh::lerp_rcp(T): this
+// T checked exhaustively; zeros and infinities handled), the IEEE sequence for a T that failed the check.  Until round 6's last session this was
+// the bare three instructions: +0 for t = -0 (every frame that lands on a tap), NaN for t = Inf.  Nonzero |t| < 2^-120 may still be an ulp off.
+__device__ __forceinline__ float div_T(float t, float Tf, float rcpT) { return rh::div_lerp(t, Tf, rcpT); }
 
 // y += M * x for a row-major 2x2
 __device__ __forceinline__ void mat_acc(const float *M, float x1, float x2, float &y1, float &y2) {

@@ -758,7 +758,7 @@ rh_status sblk_try(rh_rlm *p, uint32_t n_sources, uint64_t avail, uint64_t out, 
     k.qF = p->F / p->T;
     k.rF = p->F % p->T;
     k.Tf = (float)p->T;
-    k.rcpT = 1.0f / (float)p->T;
+    k.rcpT = rh::lerp_rcp(p->T);  // 0: this T did not pass the exhaustive check of the short division (rh_common.h)
     k.epoch = p->epoch;
     k.J = (uint32_t)J;
     k.direct = direct ? 1u : 0u;

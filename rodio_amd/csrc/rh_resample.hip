@@ -245,8 +245,8 @@ __device__ __forceinline__ void resample_tile_out(const rh::ResampleGeom &g, Tap
 // and walks to its next frames by adding F mod T / F div T -- the per-frame 64-bit division of the kernel above was what bound it, and a
 // 32-bit division a frame still left this one at 0.40 of the roofline.  CH: 1 / 2 known at compile time, 0 = any.
 template <int CH, typename TapPtr>
-__device__ __forceinline__ void resample_tile_out_fast(TapPtr taps, float *__restrict__ out, uint32_t num0, uint32_t dv, uint32_t nf, uint32_t chr, uint32_t F, uint32_t T, float invT, uint32_t qF,
-                                                       uint32_t rF, int vec_ok) {
+__device__ __forceinline__ void resample_tile_out_fast(TapPtr taps, float *__restrict__ out, uint32_t num0, uint32_t dv, uint32_t nf, uint32_t chr, uint32_t F, uint32_t T, float invT,
+                                                       uint32_t qF, uint32_t rF, int vec_ok) {
     const uint32_t ch = CH ? (uint32_t)CH : chr;
     const float Tf = (float)T, inv_ch = 1.0f / (float)ch;
     const uint32_t total = nf * ch, nv = (total + 3u) / 4u;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void resample_tile_out_fast(TapPtr taps, float *__res
                 o = a;
                 if (!vb) {
                     const float b = taps[t + ch];
-                    o = a + (b - a) * (float)num / Tf;
+                    o = a + (b - a) * (float)num / Tf;  // math.rs:25 (the IEEE division: a shortened one measured no faster here, and is not exact everywhere -- rh_common.h)
                 }
             }
             e[j] = o;
@@ -458,7 +458,7 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
             const dim3 tgrid((unsigned)((g.out_frames + tf - 1) / tf));
             const uint32_t lds_floats = (uint32_t)((in_floats + 3) & ~3ull);
             const int vec_ok = reinterpret_cast<uintptr_t>(dst) % 16 == 0;
-            const float invT = 1.0f / (float)g.T;
+            const float invT = 1.0f / (float)g.T;       // for the position estimate (corrected by one)
             const uint32_t qF = g.F / g.T, rF = g.F % g.T;
 #define RH_RST(P, CH) hipLaunchKernelGGL((k_resample_tile<P, CH>), tgrid, dim3(kBlock), lds_floats * 4, s, dst, src, g, channels, (uint32_t)tf, lds_floats, qA, rA, invT, qF, rF, small_out, vec_ok)
             if (g.fits32) {

@@ -21,7 +21,7 @@ void set_hip_error(hipError_t e, const char *what) {
 namespace {
 const char *const kKnobNames[K_COUNT] = {"RH_AGC_SEQ", "RH_AGC_VEC", "RH_BIQUAD_NO_FALLBACK", "RH_BIQUAD_SEQ", "RH_BIQUAD_R", "RH_BIQUAD_NW", "RH_BIQUAD_WGS", "RH_LIMIT_SEQ",
                                          "RH_LIMIT_R", "RH_LIMIT_NW", "RH_LIMIT_WGS", "RH_LIMIT_GRID", "RH_LIMIT_SKEW", "RH_LIMIT_NIO", "RH_LIMIT_INIT", "RH_SCAN_DMA_TOP", "RH_SCAN_SPIN_LIMIT", "RH_NO_HYBRID",
-                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC", "RH_NO_MIX_FIRST", "RH_MIX_U", "RH_NO_CHUNK", "RH_CHUNK_HALF", "RH_AUTOTUNE_LOG", "RH_RAG_RESIDENT", "RH_RAG_TWO_KERNELS", "RH_AGC_SEGMENTS", "RH_RS_PIPE", "RH_DASP_I64_VIA_F64", "RH_MIX_GROUPS", "RH_CLASSES_SIDE_BY_SIDE", "RH_AGC_FUSED_R4", "RH_STREAM_UPLOAD_ALWAYS", "RH_STREAM_NO_REJOIN", "RH_NO_SBLK", "RH_SBLK_KV", "RH_SBLK_NO_OVERLAP", "RH_CLASSES_ONE_BY_ONE", "RH_CLASSES_ONE_WAVE", "RH_WIDE_GENERAL", "RH_PCM_NO_TILE", "RH_PCM_TILE_KB"};
+                                         "RH_NO_TICKET_SHARDS", "RH_PROF_DUMP", "RH_HOST_ALLOC", "RH_NO_MIX_FIRST", "RH_MIX_U", "RH_NO_CHUNK", "RH_CHUNK_HALF", "RH_AUTOTUNE_LOG", "RH_RAG_RESIDENT", "RH_RAG_TWO_KERNELS", "RH_AGC_SEGMENTS", "RH_RS_PIPE", "RH_DASP_I64_VIA_F64", "RH_MIX_GROUPS", "RH_CLASSES_SIDE_BY_SIDE", "RH_AGC_FUSED_R4", "RH_STREAM_UPLOAD_ALWAYS", "RH_STREAM_NO_REJOIN", "RH_NO_SBLK", "RH_SBLK_KV", "RH_SBLK_NO_OVERLAP", "RH_CLASSES_ONE_BY_ONE", "RH_CLASSES_ONE_WAVE", "RH_WIDE_GENERAL", "RH_PCM_NO_TILE", "RH_PCM_TILE_KB", "RH_LERP_IEEE_DIV"};
 std::string g_knob_val[K_COUNT];
 bool g_knob_set[K_COUNT];
 }  // namespace
@@ -45,6 +45,44 @@ __global__ void k_fill(unsigned char *p, uint32_t word, size_t n) {
     if (i0 < n - tail0) p[tail0 + i0] = (unsigned char)word;
 }
 }  // namespace
+namespace {
+// every mantissa, both signs, three binades inside div_exact's short-path domain: the short path against the IEEE division
+__global__ void k_lerp_div_check(float Tf, float rcpT, uint32_t *bad) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 2^23 mantissas
+    const uint32_t exps[3] = {32u, 127u, 231u};
+    uint32_t miss = 0;
+    for (int k = 0; k < 3; ++k)
+        for (uint32_t sgn = 0; sgn < 2; ++sgn) {
+            const float t = __uint_as_float((sgn << 31) | (exps[k] << 23) | m);
+            const float q0 = t * rcpT;
+            const float rem = __builtin_fmaf(-q0, Tf, t);
+            const float q = __builtin_fmaf(rem, rcpT, q0);
+            miss |= __float_as_uint(q) != __float_as_uint(t / Tf);
+        }
+    if (miss) atomicOr(bad, 1u);
+}
+std::mutex g_div_mu;
+std::unordered_map<uint32_t, bool> g_div_ok;
+uint32_t *g_div_flag = nullptr;
+}  // namespace
+bool lerp_div_fast_ok(uint32_t T) {
+    if (T == 0 || knob(K_LERP_IEEE_DIV) || !g_initialized) return false;
+    std::lock_guard<std::mutex> hold(g_div_mu);
+    auto it = g_div_ok.find(T);
+    if (it != g_div_ok.end()) return it->second;
+    bool ok = false;
+    do {  // (any HIP failure: not verified, the IEEE division)
+        if (!g_div_flag && hipMalloc(reinterpret_cast<void **>(&g_div_flag), 4) != hipSuccess) break;
+        if (fill_now(g_div_flag, 0, 4) != hipSuccess) break;
+        const float Tf = (float)T;
+        hipLaunchKernelGGL(k_lerp_div_check, dim3((1u << 23) / 256), dim3(256), 0, nullptr, Tf, 1.0f / Tf, g_div_flag);
+        uint32_t bad = 1;
+        if (hipMemcpy(&bad, g_div_flag, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        ok = bad == 0;
+    } while (false);
+    g_div_ok[T] = ok;
+    return ok;
+}
 namespace {
 struct Scratch {
     void *p = nullptr;

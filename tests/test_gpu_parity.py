@@ -784,6 +784,55 @@ def test_fused_other_ratios_bit_exact(G, O, frm, to):
     assert np.array_equal(out, ref)
 
 
+def _same_bits(out, ref):
+    """Bit for bit, the sign of a zero included; NaNs where the reference has NaNs (payloads are not compared)."""
+    if out.shape != ref.shape:
+        return False
+    nan = np.isnan(ref)
+    return bool(np.array_equal(np.isnan(out), nan) and np.array_equal(out.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]))
+
+
+def _specials(seed, n, tiny=True):
+    """Samples among which the lerp's `(b - a) * num / T` meets what a shortened division gets wrong: -0.0 (a fall to silence on an exact frame),
+    values below 2^-120 (the end of a decaying tail; tiny=False leaves them out), and a burst of Inf / NaN (a broken decoder)."""
+    rng = np.random.default_rng(seed)
+    x = rnd(seed, n)
+    k = rng.integers(0, n, n // 3)
+    pool = [0.0, -0.0, 1e-33, 6e-30, -7e-25] + ([1e-40, -1e-40, 3e-39, -2.5e-38, 1.1754944e-38, -1e-36] if tiny else [])
+    x[k] = rng.choice(np.array(pool, np.float32), k.size)
+    x[n // 2: n // 2 + 400] = -0.0  # frames that start on a tap exactly (num == 0) with a negative slope towards them: t = -0.0
+    x[n // 2 - 7] = -0.25
+    j = n - n // 5
+    x[j: j + 6] = np.array([np.inf, 1.0, -np.inf, np.nan, 0.5, np.inf], np.float32)
+    return x
+
+
+@pytest.mark.parametrize("frm,to", [(44100, 48000), (48000, 44100), (8000, 48000), (44100, 96000), (44101, 48000)])
+def test_lerp_division_is_the_ieee_quotient(G, O, frm, to):
+    """math.rs:25 divides by `denominator as f32`; a kernel may take three instructions for it only where that is the IEEE quotient
+    (rh_common.h: div_lerp / lerp_div_fast_ok; tools/ubench/div_check.hip is the exhaustive run).  The stand-alone converter (mono / stereo / 5.1:
+    it divides) on samples with zeros of both signs, subnormals, Inf and NaN -- the oracle's bits, the sign of every zero included; the fused
+    converter + ordered sum without a filter the same on zeros, Inf and NaN, and within 1e-44 where nonzero |t| < 2^-120 meets the short division
+    (the documented exception: one unit of a subnormal's last place)."""
+    for ch, n in [(1, 30011), (2, 30011), (6, 5003)]:
+        x = _specials(frm + ch, n * ch)
+        ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+        out = G.SampleRateConverter(G.TestSource(x, ch, frm), frm, to, ch).collect()
+        assert _same_bits(out, ref), (ch, frm, to)
+    xs = [_specials(900 + s, 2 * 20011, tiny=False) for s in range(3)]
+    for general in (0, 1):
+        ref = _oracle_pipeline(O, xs, frm, to, None, None, 0)
+        out, _ = _gpu_pipeline(G, xs, frm, to, None, None, 0, force_general=general)
+        assert _same_bits(out, ref), (frm, to, general)
+    x1 = [_specials(950, 2 * 20011, tiny=True)]  # one source: the sum does not hide anything
+    ref = _oracle_pipeline(O, x1, frm, to, None, None, 0)
+    out, _ = _gpu_pipeline(G, x1, frm, to, None, None, 0)
+    ok = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(out), ~ok) and np.array_equal(np.isinf(out), np.isinf(ref))
+    fin = ok & ~np.isinf(ref)
+    assert np.max(np.abs(out[fin].astype(np.float64) - ref[fin].astype(np.float64))) <= 1e-44
+
+
 def test_fused_ragged_lengths_bit_exact(G, O):
     ns = [40000, 1, 0, 2, 39999, 12345, 147, 148]
     xs = [rnd(500 + i, 2 * n) for i, n in enumerate(ns)]
