@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void k_resample_linear(float *__restrict__ 
             il = p / g.T;
             num = (uint32_t)(p - il * g.T);
         }
-        const uint64_t nc = (k == g.n_chunks - 1) ? g.last_in : g.chunk_in;
+        const uint64_t nc = g.chunk_in + (k == g.n_chunks - 1 ? g.last_in - g.chunk_in : 0);  // (as a sum: the select between two kernel arguments became an indexed read of a scratch copy)
         const bool verbatim = il + 1 >= nc;  // i == nc-1: the drained last frame
         const uint64_t i = k * g.chunk_in + (verbatim ? nc - 1 : il);
         const float numf = (float)num;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void resample_pos(const rh::ResampleGeom &g, uint64_t
         il = p / g.T;
         num = (uint32_t)(p - il * g.T);
     }
-    const uint64_t nc = (k == g.n_chunks - 1) ? g.last_in : g.chunk_in;
+    const uint64_t nc = g.chunk_in + (k == g.n_chunks - 1 ? g.last_in - g.chunk_in : 0);  // (as a sum: the select between two kernel arguments became an indexed read of a scratch copy)
     verbatim = il + 1 >= nc;  // i == nc-1: the drained last frame
     i = k * g.chunk_in + (verbatim ? nc - 1 : il);
 }
@@ -179,7 +179,8 @@ __device__ __forceinline__ TilePos resample_tile_pos(const rh::ResampleGeom &g, 
         t.k = 0;
         const uint64_t br = (uint64_t)tile * rA;
         uint64_t d;
-        if ((br >> 32) == 0) d = (uint32_t)br / g.T, t.num0 = (uint32_t)br - (uint32_t)d * g.T;
+        if (rA == 0) d = 0, t.num0 = 0;  // tiles of whole periods (the launcher's choice wherever a period fits a tile)
+        else if ((br >> 32) == 0) d = (uint32_t)br / g.T, t.num0 = (uint32_t)br - (uint32_t)d * g.T;
         else d = br / g.T, t.num0 = (uint32_t)(br - d * g.T);
         t.il0 = (uint64_t)tile * qA + d;
         t.nc = g.last_in;
@@ -198,7 +199,7 @@ __device__ __forceinline__ TilePos resample_tile_pos(const rh::ResampleGeom &g, 
         t.il0 = p / g.T, t.num0 = (uint32_t)(p - t.il0 * g.T);
     }
     t.k = k;
-    t.nc = (k == g.n_chunks - 1) ? g.last_in : g.chunk_in;
+    t.nc = g.chunk_in + (k == g.n_chunks - 1 ? g.last_in - g.chunk_in : 0);
     t.one_chunk = k == g.n_chunks - 1 || ml + nf <= g.chunk_out;
     return t;
 }
@@ -449,7 +450,12 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
         if (const char *k = rh::knob(rh::K_PCM_TILE_KB)) kb = (uint32_t)std::atoi(k);
         if (kb < 1 || kb > 48) kb = 32;
         const double per_frame = 4.0 * channels * (1.0 + (double)g.F / (double)g.T);
-        const uint64_t tf = (uint64_t)(kb * 1024.0 / per_frame) & ~3ull;
+        uint64_t tf = (uint64_t)(kb * 1024.0 / per_frame) & ~3ull;
+        {   // whole periods of the converter where they fit: a tile that starts on a tap (tile_frames a multiple of T) finds its place in the row
+            // by one multiplication (rA == 0 below) instead of a division every lane repeats
+            const uint64_t period = std::lcm<uint64_t>(g.T, 4);
+            if (g.n_chunks <= 1 && tf >= period) tf -= tf % period;
+        }
         const uint64_t in_floats = ((uint64_t)((double)tf * g.F / g.T) + 8) * channels + 8;  // the run of a tile inside one chunk, with room for a few chunk boundaries
         const uint64_t A = tf * g.F;  // input positions a tile advances, in units of 1 / T of an input frame
         if (tf >= 16 && in_floats * 4 <= 56 * 1024 && (g.out_frames + tf - 1) / tf <= 0x7fffffffull && (uint64_t)tf * channels < (1ull << 30) && A + g.T < (1ull << 32) && g.T < (1u << 30)) {
