@@ -171,6 +171,34 @@ def test_resample_tiles_long_rows_bit_exact(G, O, frm, to, ch, n, span):
     assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_resample_tiles_random_geometries_bit_exact(G, O, seed):
+    """Seeded random rates (small and large reduced denominators, up- and down-sampling by up to 8), layouts, lengths and spans through
+    rh_resample_linear: tiles of whole converter periods and not, rows shorter than a tile, spans shorter than a tile, a last chunk of one frame."""
+    rng = np.random.default_rng(4242 + seed)
+    rates = [8000, 11025, 16000, 22050, 32000, 44100, 44101, 48000, 88200, 96000, 47999, 12345, 7, 3, 1000, 999, 192000]
+    for _ in range(20):
+        frm, to = (int(v) for v in rng.choice(rates, 2, replace=False))
+        gq = int(np.gcd(frm, to))
+        if max(frm, to) > 8 * min(frm, to) or (frm // gq) * (to // gq) > 0xffffffff:  # (the reference multiplies the reduced rates in u32, sample_rate.rs:157,173: refused)
+            continue
+        ch = int(rng.integers(1, 9))
+        n = int(rng.choice([1, 2, 3, int(rng.integers(4, 400)), int(rng.integers(400, 30000)), int(rng.integers(30000, 250000))]))
+        span = 0
+        if rng.random() < 0.5:
+            span = ch * int(rng.choice([1, 2, int(rng.integers(3, 60)), int(rng.integers(60, 5000)), 32768 // ch, 40000]))
+            if span > 32768 and 32768 % ch:
+                span = 0  # (uniform.rs:56 caps a span at 32768 samples: a cap that splits a frame is a case of its own, refused by the stand-alone entry)
+        x = rnd(n + seed, n * ch)
+        if span:
+            ref = O.UniformSourceIterator(O.SpanSource(x, ch, frm, span), ch, to).collect()
+            out = G.UniformSourceIterator(G.SpanSource(x, ch, frm, span), ch, to).collect()
+        else:
+            ref = O.SampleRateConverter(O.TestSource(x, ch, frm), frm, to, ch).collect()
+            out = G.SampleRateConverter(G.TestSource(x, ch, frm), frm, to, ch).collect()
+        assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (frm, to, ch, n, span)
+
+
 @pytest.mark.parametrize("frm,to,ch,n,span", [
     (44100, 48000, 2, 100000, 32768), (44100, 48000, 2, 16384 * 3, 32768), (44100, 48000, 2, 16384 * 3 + 1, 32768),
     (48000, 44100, 2, 70001, 32768), (44100, 48000, 1, 5000, 300), (8000, 48000, 2, 999, 64),
