@@ -415,6 +415,89 @@ __global__ __launch_bounds__(kBlock) void k_mix_sum_v4(float *__restrict__ dst, 
         }
     }
 }
+// The same for SHORT rows of many sources (a block of a wide mixer: 256 rows of 2 MiB are 512 workgroups): the loop above keeps a load or two a
+// lane in flight, which is enough -- and kinder to DRAM pages -- when the launch has thousands of workgroups (32 rows of 16 MiB: 0.78 of 8 TB/s,
+// against 0.51-0.66 for any grouped form), and not when it has two a CU (0.39-0.44): there a lane asks for eight sources at once, the next
+// eight before it adds these (0.63).  The additions stay in insertion order; a group any lane of the wave cannot take whole goes source by source.
+template <bool CONT, uint32_t kGroup>
+__global__ __launch_bounds__(kBlock) void k_mix_sum_v4_grp(float *__restrict__ dst, uint64_t out_len, const MixTable tbl, uint32_t n_sources) {
+    const uint64_t nvec = (out_len + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    //                                 sources whose loads leave together  // sources whose loads leave together (round 6, last session: one source after the other, each behind its own
+                                    // bounds branch, kept ONE load a lane in flight -- 256 rows of 2 MiB: 0.39 of 8 TB/s)
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const uint64_t o = v * 4;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (CONT) {
+            for (int k = 0; k < 4; ++k)
+                if (o + k < out_len) acc[k] = dst[o + k];
+        }
+        auto one = [&](const MixDesc d) {  // a source that may start late, end inside the vector or not reach it
+            const uint64_t rel = o - d.start;  // wraps to huge when o < start
+            if (rel < d.len) {
+                if (rel + 4 <= d.len) {
+                    const float4 x = *reinterpret_cast<const float4 *>(d.data + rel);
+                    acc[0] += x.x;
+                    acc[1] += x.y;
+                    acc[2] += x.z;
+                    acc[3] += x.w;
+                } else {
+                    for (int k = 0; k < 4; ++k)
+                        if (rel + k < d.len) acc[k] += d.data[rel + k];
+                }
+            }
+        };
+        // group g + 1's loads leave BEFORE group g's are added (two groups a lane in flight; waiting for a group with nothing behind it measured
+        // 0.53 of 8 TB/s at 32 rows where the old loop had 0.78)
+        auto is_full = [&](uint32_t s0) {  // every source of the group holds the whole vector -- in every lane of the wave, or the group goes source by source
+            bool full = true;
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) {
+                const uint64_t rel = o - tbl.d[s0 + u].start;
+                full = full && rel < tbl.d[s0 + u].len && rel + 4 <= tbl.d[s0 + u].len;
+            }
+            return __builtin_amdgcn_ballot_w64(!full) == 0;
+        };
+        uint32_t s = 0;
+        float4 cur[kGroup], nxt[kGroup];
+        bool cur_ok = false, nxt_ok = false;
+        if (kGroup <= n_sources) {
+            cur_ok = is_full(0);
+            if (cur_ok) {
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u) cur[u] = *reinterpret_cast<const float4 *>(tbl.d[u].data + (o - tbl.d[u].start));
+            }
+        }
+        for (; s + kGroup <= n_sources; s += kGroup) {
+            nxt_ok = s + 2 * kGroup <= n_sources && is_full(s + kGroup);
+            if (nxt_ok) {
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u) nxt[u] = *reinterpret_cast<const float4 *>(tbl.d[s + kGroup + u].data + (o - tbl.d[s + kGroup + u].start));
+            }
+            if (cur_ok) {
+#pragma unroll
+                for (uint32_t u = 0; u < kGroup; ++u) {  // the additions in insertion order (mixer.rs:185-198)
+                    acc[0] += cur[u].x;
+                    acc[1] += cur[u].y;
+                    acc[2] += cur[u].z;
+                    acc[3] += cur[u].w;
+                }
+            } else {
+                for (uint32_t u = 0; u < kGroup; ++u) one(tbl.d[s + u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kGroup; ++u) cur[u] = nxt[u];
+            cur_ok = nxt_ok;
+        }
+        for (; s < n_sources; ++s) one(tbl.d[s]);
+        if (o + 4 <= out_len) {
+            *reinterpret_cast<float4 *>(dst + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (o + k < out_len) dst[o + k] = acc[k];
+        }
+    }
+}
 
 }  // namespace
 
@@ -517,8 +600,15 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host, 
         std::memset(&t, 0, sizeof(t));
         for (uint32_t i = 0; i < n; ++i) t.d[i] = MixDesc{srcs_host[first + i], start_host[first + i], len_host[first + i]};
         if (vec_ok) {
-            if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, dim3(rh::grid_tiles((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
-            else hipLaunchKernelGGL(k_mix_sum_v4<false>, dim3(rh::grid_tiles((out_len + 3) / 4)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            const dim3 grid(rh::grid_tiles((out_len + 3) / 4));
+            const bool grouped = rh::knob(rh::K_MIX_GROUPS) ? std::atoi(rh::knob(rh::K_MIX_GROUPS)) > 1 : (grid.x < 8u * (unsigned)rh::g_num_cus && n >= 16);
+            if (grouped) {
+                if (first) hipLaunchKernelGGL((k_mix_sum_v4_grp<true, 8>), grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+                else hipLaunchKernelGGL((k_mix_sum_v4_grp<false, 8>), grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            } else {
+                if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+                else hipLaunchKernelGGL(k_mix_sum_v4<false>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
+            }
         } else {
             if (first) hipLaunchKernelGGL(k_mix_sum<true>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
             else hipLaunchKernelGGL(k_mix_sum<false>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
