@@ -233,13 +233,24 @@ __global__ __launch_bounds__(kBlock) void k_channel_volume_tile(float *__restric
     }
 }
 // Stereo in / stereo out (Spatial): one float2 load + one float2 store per lane.
-__global__ __launch_bounds__(kBlock) void k_channel_volume_2x2(float2 *__restrict__ dst, const float2 *__restrict__ src, size_t frames, float g0, float g1) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t f = (size_t)blockIdx.x * kBlock + threadIdx.x; f < frames; f += stride) {
-        float2 x = src[f];
-        float m = (0.0f + x.x) + x.y;
+__global__ __launch_bounds__(kBlock) void k_channel_volume_2x2(float *__restrict__ dst, const float *__restrict__ src, size_t frames, float g0, float g1, int vec_ok) {
+    // two frames a lane (one 16-byte load, one 16-byte store), a vector a lane
+    const size_t nvec = (frames + 1) / 2, stride = (size_t)gridDim.x * kBlock;
+    auto one = [=](float l, float r, float &ol, float &orr) {
+        float m = (0.0f + l) + r;
         m = m / 2.0f;
-        dst[f] = make_float2(m * g0, m * g1);
+        ol = m * g0, orr = m * g1;
+    };
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        if (vec_ok && 2 * v + 2 <= frames) {
+            const float4 x = rh::ld_nt(reinterpret_cast<const float4 *>(src) + v);
+            float4 y;
+            one(x.x, x.y, y.x, y.y);
+            one(x.z, x.w, y.z, y.w);
+            rh::st_nt(reinterpret_cast<float4 *>(dst) + v, y);
+        } else {
+            for (size_t f = 2 * v; f < 2 * v + 2 && f < frames; ++f) one(src[2 * f], src[2 * f + 1], dst[2 * f], dst[2 * f + 1]);
+        }
     }
 }
 
@@ -516,8 +527,9 @@ rh_status rh_channel_volume(float *dst, const float *src, size_t frames, uint32_
     if (out_ch > 16) return RH_ERR_UNSUPPORTED;
     if (frames == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    if (in_ch == 2 && out_ch == 2 && (reinterpret_cast<uintptr_t>(dst) % 8 == 0) && (reinterpret_cast<uintptr_t>(src) % 8 == 0)) {
-        hipLaunchKernelGGL(k_channel_volume_2x2, dim3(rh::grid_for(frames)), dim3(kBlock), 0, rh::as_stream(stream), reinterpret_cast<float2 *>(dst), reinterpret_cast<const float2 *>(src), frames, gains_host[0], gains_host[1]);
+    if (in_ch == 2 && out_ch == 2) {
+        hipLaunchKernelGGL(k_channel_volume_2x2, dim3(rh::grid_tiles((frames + 1) / 2)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, frames, gains_host[0], gains_host[1],
+                           (int)(aligned16(dst) && aligned16(src)));
     } else {
         Gains g{};
         for (uint32_t k = 0; k < out_ch; ++k) g.g[k] = gains_host[k];
