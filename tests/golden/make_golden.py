@@ -10,6 +10,10 @@ keep a 32 768-sample excerpt that contains both quiet and loud passages, and wri
   music.wav                  the asset itself (1.8 MB, cc-by-sa: /root/reference/assets/README.md), byte for byte: BASELINE config 5
                              at full size feeds the real RIFF image through rh_wav_probe_host / rh_wav_decode
 The expected arrays are computed here with numpy from the cited formulas, independently of oracle/.
+
+tests/golden/wav/ (since round 6): the six files the reference's tests/wav_test.rs decodes (assets/audacity16bit.wav, lmms16bit.wav, lmms24bit.wav,
+audacity32bit.wav, lmms32bit.wav, audacity32bit_int.wav), copied byte for byte -- `cp /root/reference/assets/<name> tests/golden/wav/` -- as INPUT data of
+tests/test_wav_assets.py; nothing is derived from them here (the expected samples come from scipy.io.wavfile at test time).
 """
 import os
 import struct
