@@ -93,3 +93,30 @@ def test_egress_read_back_by_scipy(rh):
     out = rh.wav_to_bytes(rh.TestSource(x[:-1], 2, 48000))  # 8 001 samples: the half frame is dropped (wav_output.rs:98-140)
     rate, d = wavfile.read(io.BytesIO(out))
     assert rate == 48000 and d.dtype == np.float32 and d.shape == (4000, 2) and np.array_equal(d.reshape(-1), x[:8000])
+
+
+@pytest.mark.gpu
+def test_wav_to_file_as_the_reference_tests_it(rh):
+    """src/wav_output.rs:144-181 `test_wav_to_file`: SineWave::new(745.0).amplify(0.1).take_duration(1 s) written by wav_to_file and read back
+    (the reference reads with hound; here with scipy, and with this library's own decoder): the source's rate and channel count, as many
+    samples as the source yields, the same samples.  SineWave is 48 kHz mono, sample n = sin(TAU * phase_n), phase stepping by f / rate
+    (signal_generator.rs:51-53,130-135; sine.rs:51-58) -- built on the host here: the test is about the file, not about the sine."""
+    from oracle import rodio_oracle as O
+    from scipy.io import wavfile
+
+    rh.init(0)
+    rate, f = 48000, np.float32(745.0)
+    phase, step, xs = np.float32(0.0), np.float32(f / np.float32(rate)), []
+    for _ in range(rate + 1000):  # (a little more than the second take_duration keeps)
+        xs.append(np.sin(np.float32(6.2831855) * phase, dtype=np.float32))
+        phase = np.float32((phase + step) % np.float32(1.0))
+    x = np.array(xs, np.float32)
+    make = lambda M: M.TestSource(x, 1, rate).amplify(0.1).take_duration(1_000_000_000)  # noqa: E731
+    out = rh.wav_to_bytes(make(rh))
+    expected = make(O).collect()
+    assert len(expected) == rate  # one second of a mono source: 1e9 / (1e9 / 48000) samples (take.rs:63-67)
+    r, d = wavfile.read(io.BytesIO(out))
+    assert r == rate and d.ndim == 1 and d.dtype == np.float32          # reference.sample_rate(), reference.channels(), f32 samples
+    assert len(d) == len(expected) and np.array_equal(d.view(np.uint32), expected.view(np.uint32))
+    back = rh.WavDecoder(out)
+    assert (back.channels(), back.sample_rate()) == (1, rate) and np.array_equal(back.collect().view(np.uint32), expected.view(np.uint32))
