@@ -8,6 +8,8 @@
 // grid-stride over <= 2048 workgroups of 256 threads (4 waves of 64).
 #include <cmath>
 
+#include <cstdlib>
+
 #include "rh_common.h"
 
 namespace {
@@ -62,6 +64,35 @@ __global__ __launch_bounds__(kBlock) void k_int_to_f32(float *__restrict__ dst, 
     }
     if (v < nvec) emit(v, rh::ld_nt(src4 + v));
     for (size_t i = nvec * VEC + tid; i < n; i += stride) dst[i] = ToF32<T>::cvt(src[i]);
+}
+
+// 1- and 2-byte samples, the form whose STORES are whole lines: a lane takes four samples (4 or 8 bytes in, one 16-byte store), twice, 256
+// vectors apart -- every store instruction of a wave writes 1 KiB in a row.  The kernel above gives a lane 16 bytes in and 32 (64) out: each of
+// its stores fills half (a quarter) of every line it touches -- i16 -> f32 on 512 MiB: 0.73-0.75 of 8 TB/s against 0.805 (tools/bench_rows.py),
+// which is BASELINE config 5's first step.  A workgroup owns 512 output vectors.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_int_to_f32_lines(float *__restrict__ dst, const T *__restrict__ src, size_t n) {
+    static_assert(sizeof(T) <= 2, "one- and two-byte samples");
+    typedef unsigned raw_t __attribute__((ext_vector_type(sizeof(T) == 2 ? 2 : 1)));
+    const size_t nq = n / 4;  // groups of four samples
+    const raw_t *s4 = reinterpret_cast<const raw_t *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    const size_t stride = (size_t)gridDim.x * (2 * kBlock);
+    for (size_t base = (size_t)blockIdx.x * (2 * kBlock); base < nq; base += stride) {
+        const size_t q0 = base + threadIdx.x, q1 = q0 + kBlock;
+        raw_t r0 = {}, r1 = {};
+        if (q0 < nq) r0 = __builtin_nontemporal_load(s4 + q0);
+        if (q1 < nq) r1 = __builtin_nontemporal_load(s4 + q1);
+        auto emit = [&](size_t q, raw_t raw) {
+            T v[4];
+            __builtin_memcpy(v, &raw, 4 * sizeof(T));
+            rh::st_nt(d4 + q, make_float4(ToF32<T>::cvt(v[0]), ToF32<T>::cvt(v[1]), ToF32<T>::cvt(v[2]), ToF32<T>::cvt(v[3])));
+        };
+        if (q0 < nq) emit(q0, r0);
+        if (q1 < nq) emit(q1, r1);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = nq * 4 + threadIdx.x; i < n; i += kBlock) dst[i] = ToF32<T>::cvt(src[i]);
 }
 
 template <typename T>
@@ -284,12 +315,18 @@ __global__ __launch_bounds__(kBlock) void k_echo_mix(float *__restrict__ dst, co
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
+void launch_lines(float *dst, const T *src, size_t n, hipStream_t s) {
+    if constexpr (sizeof(T) <= 2) hipLaunchKernelGGL(k_int_to_f32_lines<T>, dim3(rh::grid_tiles((n / 4 + 1) / 2 + 1)), dim3(kBlock), 0, s, dst, src, n);
+}
+template <typename T>
 rh_status launch_int_to_f32(float *dst, const T *src, size_t n, rh_stream stream) {
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
     constexpr int VEC = 16 / sizeof(T);
-    if (aligned16(dst) && aligned16(src)) {
+    if (sizeof(T) <= 2 && aligned16(dst) && (reinterpret_cast<uintptr_t>(src) & (4 * sizeof(T) - 1)) == 0 && !rh::knob(rh::K_PCM_NO_TILE)) {
+        launch_lines(dst, src, n, rh::as_stream(stream));
+    } else if (aligned16(dst) && aligned16(src)) {
         hipLaunchKernelGGL(k_int_to_f32<T>, dim3(rh::grid_tiles(n / VEC + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
     } else {
         hipLaunchKernelGGL(k_int_to_f32_scalar<T>, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);

@@ -172,27 +172,29 @@ __global__ __launch_bounds__(kBlock) void k_take_duration(float *__restrict__ ds
         for (uint64_t i = kBlock + threadIdx.x; i < pad; i += kBlock) dst[take + i] = 0.0f;
 }
 
-// Four consecutive samples a lane, one load and one store of four (16 bytes for the 4-byte formats, 2 x 16 for i64 / u64 / f64) where both rows
-// start on such a boundary; a vector a lane (rh::grid_tiles).  A sample a lane under the capped grid-stride loop was 0.3-0.6 of 8 TB/s.
-template <typename T>
-struct alignas(4 * sizeof(T)) Quad {
-    T e[4];
+// E consecutive samples a lane, one load and one store, E such that the WIDER side is 16 bytes (four for the 4-byte formats, two where i64 / u64 /
+// f64 are involved: a lane that stores 32 bytes fills half of every line a store instruction touches -- i16 -> f32, rh_elementwise.hip); a
+// vector a lane (rh::grid_tiles).  A sample a lane under the capped grid-stride loop was 0.3-0.6 of 8 TB/s.
+template <typename T, int E>
+struct alignas(E * sizeof(T)) Pack {
+    T e[E];
 };
 template <typename Op>
 __global__ __launch_bounds__(kBlock) void k_convert(typename Op::Out *__restrict__ dst, const typename Op::In *__restrict__ src, size_t n, int vec_ok) {
-    typedef Quad<typename Op::In> QI;
-    typedef Quad<typename Op::Out> QO;
-    const size_t nvec = (n + 3) / 4, stride = (size_t)gridDim.x * kBlock;
+    constexpr int E = 16 / (sizeof(typename Op::In) > sizeof(typename Op::Out) ? sizeof(typename Op::In) : sizeof(typename Op::Out));
+    typedef Pack<typename Op::In, E> QI;
+    typedef Pack<typename Op::Out, E> QO;
+    const size_t nvec = (n + E - 1) / E, stride = (size_t)gridDim.x * kBlock;
     for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
-        const size_t i = 4 * v;
-        if (vec_ok && i + 4 <= n) {
+        const size_t i = E * v;
+        if (vec_ok && i + E <= n) {
             const QI x = reinterpret_cast<const QI *>(src)[v];
             QO y;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y.e[j] = Op::cvt(x.e[j]);
+            for (int j = 0; j < E; ++j) y.e[j] = Op::cvt(x.e[j]);
             reinterpret_cast<QO *>(dst)[v] = y;
         } else {
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < E; ++j)
                 if (i + j < n) dst[i + j] = Op::cvt(src[i + j]);
         }
     }
@@ -202,8 +204,9 @@ rh_status launch(typename Op::Out *dst, const typename Op::In *src, size_t n, rh
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    const int vec_ok = reinterpret_cast<uintptr_t>(dst) % sizeof(Quad<typename Op::Out>) == 0 && reinterpret_cast<uintptr_t>(src) % sizeof(Quad<typename Op::In>) == 0;
-    hipLaunchKernelGGL(k_convert<Op>, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
+    constexpr int E = 16 / (sizeof(typename Op::In) > sizeof(typename Op::Out) ? sizeof(typename Op::In) : sizeof(typename Op::Out));
+    const int vec_ok = reinterpret_cast<uintptr_t>(dst) % sizeof(Pack<typename Op::Out, E>) == 0 && reinterpret_cast<uintptr_t>(src) % sizeof(Pack<typename Op::In, E>) == 0;
+    hipLaunchKernelGGL(k_convert<Op>, dim3(rh::grid_tiles((n + E - 1) / E)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, vec_ok);
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
