@@ -231,11 +231,21 @@ rh_status rh_wav_decode(float *dst, const uint8_t *data, uint64_t n_samples, uin
     if (!dst || (n_samples && !data)) return RH_ERR_INVALID;
     hipStream_t s = rh::as_stream(stream);
     rh_status st = RH_OK;
-    {   // samples that do not sit on their own size's boundary (a data chunk behind odd-sized chunks: file + data_offset): put together from
-        // their bytes by the one-launch kernel with the layout kept (from == to: every frame verbatim, the cut one completed with silence)
+    {   // `file + data_offset`: the canonical header is 44 bytes, so the samples of an uploaded file image start 4 bytes off a 16-byte boundary (and
+        // anywhere behind odd-sized chunks).  The converters below want rows on vector boundaries and fall back to a sample a lane otherwise; the
+        // tile kernel reads aligned vectors AROUND the row and does not care, at the same rate (from == to: every frame verbatim, the cut one
+        // completed with silence).  Samples off their OWN size's boundary always go there (put together from their bytes).
         const uintptr_t a = reinterpret_cast<uintptr_t>(data);
-        if ((bits_per_sample == 16 && (a & 1u)) || (bits_per_sample == 32 && (a & 3u)))
-            return rh_wav_decode_channels(dst, data, n_samples, channels, bits_per_sample, is_float, channels, out_samples, stream);
+        const bool off_size = (bits_per_sample == 16 && (a & 1u)) || (bits_per_sample == 32 && (a & 3u));
+        const bool off_vector = (bits_per_sample == 16 && (a & 7u)) || (bits_per_sample == 8 && (a & 3u)) || (bits_per_sample == 32 && !is_float && (a & 15u));
+        if (off_size) return rh_wav_decode_channels(dst, data, n_samples, channels, bits_per_sample, is_float, channels, out_samples, stream);
+        if (off_vector && !is_float) {
+            const int fmt = bits_per_sample == 8 ? 0 : bits_per_sample == 16 ? 1 : 3;
+            if (rh::pcm_tile_try(dst, data, n_samples, total / channels, channels, channels, fmt, s)) {
+                RH_CHECK_LAUNCH();
+                return RH_OK;
+            }
+        }
     }
     if (is_float) {
         if (bits_per_sample != 32) return RH_ERR_UNSUPPORTED;  // wav.rs:107-117
