@@ -149,23 +149,6 @@ __device__ __forceinline__ float div_lerp(float t, float Tf, float rcpT) {
     const float q = __builtin_fmaf(rem, rcpT, q0);
     return __builtin_amdgcn_classf(t, 0x264) ? q0 : q;  // +-0 and +-Inf: q0 is the quotient (the residual would make +0 of -0 and NaN of Inf)
 }
-// dst[i] = f(i, src[i]) for i < n, FOUR consecutive samples a lane (one 16-byte load, one 16-byte store where both rows start on 16-byte
-// boundaries), a vector a lane and a grid of rh::grid_tiles((n + 3) / 4): the shape tools/bench_rows.py measured at 0.79-0.82 of 8 TB/s
-// (amplify, f32 -> i16) against 0.26-0.61 for a sample a lane under a capped grid-stride loop.  Works in place.
-template <int BLOCK, typename F>
-__device__ __forceinline__ void map4(float *__restrict__ dst, const float *__restrict__ src, size_t n, int vec_ok, F f) {
-    const size_t nvec = (n + 3) / 4, stride = (size_t)gridDim.x * BLOCK;
-    for (size_t v = (size_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
-        const size_t i = 4 * v;
-        if (vec_ok && i + 4 <= n) {
-            const float4 x = ld_nt(reinterpret_cast<const float4 *>(src) + v);
-            st_nt(reinterpret_cast<float4 *>(dst) + v, make_float4(f(i, x.x), f(i + 1, x.y), f(i + 2, x.z), f(i + 3, x.w)));
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (i + j < n) dst[i + j] = f(i + j, src[i + j]);
-        }
-    }
-}
 // src[q .. q+3] for a row of n samples, q of any sign and alignment; 0.0 where q + j is outside [0, n).  Inside, two aligned 16-byte loads
 // (the second one is the next lane's first: an L1 hit) and a pick by the address' residue -- the same for every lane of a launch.  The
 // aligned vectors reach up to 12 bytes outside the row, inside the 16 bytes that hold a sample of it.
@@ -184,6 +167,32 @@ __device__ __forceinline__ float4 ld4_at(const float *__restrict__ src, int64_t 
     float e[4];
     for (int j = 0; j < 4; ++j) e[j] = (q + j >= 0 && (uint64_t)(q + j) < n) ? src[q + j] : 0.0f;
     return make_float4(e[0], e[1], e[2], e[3]);
+}
+// dst[i] = f(i, src[i]) for i < n, FOUR consecutive samples a lane (one 16-byte load, one 16-byte store), a vector a lane and a grid of
+// rh::grid_tiles((n + 3) / 4): the shape tools/bench_rows.py measured at 0.79-0.82 of 8 TB/s (amplify, f32 -> i16) against 0.26-0.61 for a
+// sample a lane under a capped grid-stride loop.  vec: bit 0 = src starts on a 16-byte boundary, bit 1 = dst does (rows_vec_bits) -- a src that
+// does not is read through ld4_at (aligned vectors around the row), a dst that does not is stored sample by sample.  Works in place.
+template <int BLOCK, typename F>
+__device__ __forceinline__ void map4(float *__restrict__ dst, const float *__restrict__ src, size_t n, int vec, F f) {
+    const size_t nvec = (n + 3) / 4, stride = (size_t)gridDim.x * BLOCK;
+    for (size_t v = (size_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        const size_t i = 4 * v;
+        if (i + 4 <= n) {
+            const float4 x = (vec & 1) ? ld_nt(reinterpret_cast<const float4 *>(src) + v) : ld4_at(src, (int64_t)i, n);
+            const float4 y = make_float4(f(i, x.x), f(i + 1, x.y), f(i + 2, x.z), f(i + 3, x.w));
+            if (vec & 2) {
+                st_nt(reinterpret_cast<float4 *>(dst) + v, y);
+            } else {
+                dst[i] = y.x, dst[i + 1] = y.y, dst[i + 2] = y.z, dst[i + 3] = y.w;
+            }
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) dst[i + j] = f(i + j, src[i + j]);
+        }
+    }
+}
+inline int rows_vec_bits(const void *dst, const void *src) {
+    return ((reinterpret_cast<uintptr_t>(src) & 15u) == 0 ? 1 : 0) | ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0 ? 2 : 0);
 }
 #endif
 

@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rh_common.h"
 
@@ -190,21 +191,8 @@ __global__ __launch_bounds__(kBlock) void k_channels_convert(float *__restrict__
 // coalesced and its reads hit each input line once.
 
 // --------------------------------------------------------------- Amplify ----
-__global__ __launch_bounds__(kBlock) void k_amplify(float *__restrict__ dst, const float *__restrict__ src, size_t n, float factor, int vec_ok) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    size_t done = 0;
-    if (vec_ok) {
-        const size_t nvec = n / 4;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (size_t v = tid; v < nvec; v += stride) {
-            float4 r = rh::ld_nt(s4 + v);
-            rh::st_nt(d4 + v, make_float4(r.x * factor, r.y * factor, r.z * factor, r.w * factor));
-        }
-        done = nvec * 4;
-    }
-    for (size_t i = done + tid; i < n; i += stride) dst[i] = src[i] * factor;
+__global__ __launch_bounds__(kBlock) void k_amplify(float *__restrict__ dst, const float *__restrict__ src, size_t n, float factor, int vec) {
+    rh::map4<kBlock>(dst, src, n, vec, [=](size_t, float x) { return x * factor; });
 }
 
 // ---------------------------------------------------------- ChannelVolume ----
@@ -328,6 +316,9 @@ rh_status launch_int_to_f32(float *dst, const T *src, size_t n, rh_stream stream
         launch_lines(dst, src, n, rh::as_stream(stream));
     } else if (aligned16(dst) && aligned16(src)) {
         hipLaunchKernelGGL(k_int_to_f32<T>, dim3(rh::grid_tiles(n / VEC + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
+    } else if ((std::is_same<T, int16_t>::value || std::is_same<T, uint8_t>::value) && (reinterpret_cast<uintptr_t>(src) & (sizeof(T) - 1)) == 0 &&
+               rh::pcm_tile_try(dst, reinterpret_cast<const uint8_t *>(src), n, n, 1, 1, std::is_same<T, int16_t>::value ? 1 : 0, rh::as_stream(stream))) {
+        // a row that starts off a vector boundary (inside a larger buffer): rh_wav.hip's tile kernel, PCM16 / unsigned 8-bit are two of its formats
     } else {
         hipLaunchKernelGGL(k_int_to_f32_scalar<T>, dim3(rh::grid_for(n)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n);
     }
@@ -553,7 +544,7 @@ rh_status rh_amplify(float *dst, const float *src, size_t n, float factor, rh_st
     RH_REQUIRE_INIT();
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_amplify, dim3(rh::grid_tiles(n / 4 + 1)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, factor, (int)(aligned16(dst) && aligned16(src)));
+    hipLaunchKernelGGL(k_amplify, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, factor, rh::rows_vec_bits(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

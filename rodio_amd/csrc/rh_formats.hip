@@ -119,9 +119,9 @@ __global__ __launch_bounds__(kBlock) void k_linear_gain_ramp(float *__restrict__
         };
         float factor = factor_of(frame);
         float x[4], y[4];
-        const bool vec = vec_ok && i + 4 <= n;
-        if (vec) {
-            const float4 t = rh::ld_nt(reinterpret_cast<const float4 *>(src) + v);
+        const bool whole = i + 4 <= n, vec = (vec_ok & 2) && whole;  // (vec_ok: rh::rows_vec_bits)
+        if (whole) {
+            const float4 t = (vec_ok & 1) ? rh::ld_nt(reinterpret_cast<const float4 *>(src) + v) : rh::ld4_at(src, (int64_t)i, n);
             x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
         } else {
             for (int j = 0; j < 4; ++j) x[j] = i + j < n ? src[i + j] : 0.0f;
@@ -211,8 +211,6 @@ rh_status launch(typename Op::Out *dst, const typename Op::In *src, size_t n, rh
     return RH_OK;
 }
 
-inline int rows_vec_ok(const void *dst, const void *src) { return ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0; }
-
 }  // namespace
 
 extern "C" {
@@ -221,7 +219,7 @@ rh_status rh_distortion(float *dst, const float *src, size_t n, float gain, floa
     if (!(threshold >= 0.0f)) return RH_ERR_INVALID;  // f32::clamp panics when min > max or NaN
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_distortion, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold, rows_vec_ok(dst, src));
+    hipLaunchKernelGGL(k_distortion, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, gain, threshold, rh::rows_vec_bits(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -231,7 +229,7 @@ rh_status rh_dither(float *dst, const float *src, size_t n, uint64_t sample_offs
     if (n == 0) return RH_OK;
     if (!dst || !src) return RH_ERR_INVALID;
     const float lsb = (float)(1.0 / (double)(1ull << (target_bits - 1)));  // dither.rs:180
-    hipLaunchKernelGGL(k_dither, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, lsb, algorithm, seed, rows_vec_ok(dst, src));
+    hipLaunchKernelGGL(k_dither, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, lsb, algorithm, seed, rh::rows_vec_bits(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -245,7 +243,7 @@ rh_status rh_linear_gain_ramp(float *dst, const float *src, size_t n, uint64_t s
     const float total_s = (float)(duration_ns / 1000000000ull) + (float)(uint32_t)(duration_ns % 1000000000ull) / 1000000000.0f;
     const uint64_t done_frame = step_ns ? (duration_ns + step_ns - 1) / step_ns : 0;  // elapsed >= total from this frame on
     hipLaunchKernelGGL(k_linear_gain_ramp, dim3(rh::grid_tiles((n + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, n, sample_offset, channels, step_ns, done_frame, total_s, start_gain,
-                       end_gain, clamp_end ? end_gain : 1.0f, rows_vec_ok(dst, src));
+                       end_gain, clamp_end ? end_gain : 1.0f, rh::rows_vec_bits(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }
@@ -273,7 +271,7 @@ rh_status rh_take_duration_from(float *dst, const float *src, uint64_t n, uint64
     if (remaining_after_ns) *remaining_after_ns = remaining_ns - take * dps;
     if (take + pad == 0) return RH_OK;
     if (!dst || (take && !src)) return RH_ERR_INVALID;
-    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_tiles((take + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, remaining_ns, dps, requested_ns, fade_out ? 1 : 0, rows_vec_ok(dst, src));
+    hipLaunchKernelGGL(k_take_duration, dim3(rh::grid_tiles((take + 3) / 4)), dim3(kBlock), 0, rh::as_stream(stream), dst, src, take, pad, remaining_ns, dps, requested_ns, fade_out ? 1 : 0, rh::rows_vec_bits(dst, src));
     RH_CHECK_LAUNCH();
     return RH_OK;
 }

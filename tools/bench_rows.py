@@ -81,6 +81,8 @@ def measure(mib=512, steps=10, only=(), emit=None):
     dst = torch.empty(n + 1 + (1 << 17), device="cuda")
     # a7 Amplify
     row("amplify", lambda: ck(lib.rh_amplify(P(dst), P(x), n, 0.5, st), "rh_amplify"), 8 * n)
+    xo = x[1:]  # a row that starts 4 bytes off a vector boundary (a row inside a larger buffer)
+    row("amplify src+4B", lambda: ck(lib.rh_amplify(P(dst), P(xo), n - 1, 0.5, st), "rh_amplify"), 8 * (n - 1))
     # a9 reverb stand-alone (echo mix), delay 65 536 samples
     D = 65536
     row("echo_mix D=65536", lambda: ck(lib.rh_echo_mix(P(dst), P(x), n, D, 0.7, st), "rh_echo_mix"), 4 * n + 4 * (n + D))
@@ -96,6 +98,8 @@ def measure(mib=512, steps=10, only=(), emit=None):
     i16 = torch.empty(n, dtype=torch.int16, device="cuda")
     row("f32_to_i16", lambda: ck(lib.rh_convert_f32_to_i16(P(i16), P(x), n, st), "cv"), 6 * n)
     row("i16_to_f32", lambda: ck(lib.rh_convert_i16_to_f32(P(dst), P(i16), n, st), "cv"), 6 * n)
+    i16o = i16[2:]
+    row("i16_to_f32 src+4B", lambda: ck(lib.rh_convert_i16_to_f32(P(dst), P(i16o), n - 2, st), "cv"), 6 * (n - 2))
     i32 = torch.empty(n, dtype=torch.int32, device="cuda")
     row("f32_to_i32", lambda: ck(lib.rh_convert_f32_to_i32(P(i32), P(x), n, st), "cv"), 8 * n)
     row("f32_to_u32", lambda: ck(lib.rh_convert_f32_to_u32(P(i32), P(x), n, st), "cv"), 8 * n)
