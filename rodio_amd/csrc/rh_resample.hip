@@ -415,6 +415,39 @@ __global__ __launch_bounds__(kBlock) void k_mix_sum_v4(float *__restrict__ dst, 
         }
     }
 }
+// The same for rows that start ANYWHERE (a late join two samples into a vector, a row inside a larger buffer): every source through
+// rh::ld4_at -- aligned vectors around the samples, 0.0 where the source does not reach (an addition of +0.0 leaves a sum that started at +0.0
+// as it is: the sum is never -0.0).  The sample-a-lane kernel it replaces there ran at a fraction of this one's rate.
+template <bool CONT>
+__global__ __launch_bounds__(kBlock) void k_mix_sum_any(float *__restrict__ dst, uint64_t out_len, const MixTable tbl, uint32_t n_sources, int dst_vec) {
+    const uint64_t nvec = (out_len + 3) / 4;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const uint64_t o = v * 4;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (CONT) {
+            for (int k = 0; k < 4; ++k)
+                if (o + k < out_len) acc[k] = dst[o + k];
+        }
+        for (uint32_t s = 0; s < n_sources; ++s) {
+            const MixDesc d = tbl.d[s];
+            const int64_t rel = (int64_t)o - (int64_t)d.start;
+            if (rel > -4 && rel < (int64_t)d.len) {  // (uniform nowhere, cheap everywhere: the sources a vector does not touch are skipped)
+                const float4 x = rh::ld4_at(d.data, rel, d.len);
+                acc[0] += x.x;
+                acc[1] += x.y;
+                acc[2] += x.z;
+                acc[3] += x.w;
+            }
+        }
+        if (dst_vec && o + 4 <= out_len) {
+            *reinterpret_cast<float4 *>(dst + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (o + k < out_len) dst[o + k] = acc[k];
+        }
+    }
+}
 // The same for SHORT rows of many sources (a block of a wide mixer: 256 rows of 2 MiB are 512 workgroups): the loop above keeps a load or two a
 // lane in flight, which is enough -- and kinder to DRAM pages -- when the launch has thousands of workgroups (32 rows of 16 MiB: 0.78 of 8 TB/s,
 // against 0.51-0.66 for any grouped form), and not when it has two a CU (0.39-0.44): there a lane asks for eight sources at once, the next
@@ -609,6 +642,11 @@ rh_status rh_mix_sum(float *dst, size_t out_len, const float *const *srcs_host, 
                 if (first) hipLaunchKernelGGL(k_mix_sum_v4<true>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
                 else hipLaunchKernelGGL(k_mix_sum_v4<false>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
             }
+        } else if (!rh::knob(rh::K_PCM_NO_TILE)) {
+            const dim3 grid(rh::grid_tiles((out_len + 3) / 4));
+            const int dst_vec = reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+            if (first) hipLaunchKernelGGL(k_mix_sum_any<true>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n, dst_vec);
+            else hipLaunchKernelGGL(k_mix_sum_any<false>, grid, dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n, dst_vec);
         } else {
             if (first) hipLaunchKernelGGL(k_mix_sum<true>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);
             else hipLaunchKernelGGL(k_mix_sum<false>, dim3(rh::grid_for(out_len)), dim3(kBlock), 0, s, dst, (uint64_t)out_len, t, n);

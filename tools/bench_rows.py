@@ -78,6 +78,14 @@ def measure(mib=512, steps=10, only=(), emit=None):
         dst = torch.empty(L + 8, device="cuda")
         row(f"mix_sum S={S} odd pitch", lambda: ck(lib.rh_mix_sum(P(dst), L, ptrs, starts, lens, S, st), "rh_mix_sum"), 4 * L * S + 4 * L)
         del dst
+    for S in (4, 32):  # late joins: every source starts two samples after the one in front (rows off the vector boundary)
+        L = n // S // 4 * 4 - 256
+        ptrs = (C.c_void_p * S)(*[x.data_ptr() + 4 * (L + 256) * s0 for s0 in range(S)])
+        starts = (C.c_uint64 * S)(*[2 * s0 for s0 in range(S)])
+        lens = (C.c_uint64 * S)(*([L] * S))
+        dst = torch.empty(L + 2 * S + 8, device="cuda")
+        row(f"mix_sum S={S} late joins", lambda: ck(lib.rh_mix_sum(P(dst), L + 2 * S, ptrs, starts, lens, S, st), "rh_mix_sum"), 4 * L * S + 4 * L)
+        del dst
     dst = torch.empty(n + 1 + (1 << 17), device="cuda")
     # a7 Amplify
     row("amplify", lambda: ck(lib.rh_amplify(P(dst), P(x), n, 0.5, st), "rh_amplify"), 8 * n)
