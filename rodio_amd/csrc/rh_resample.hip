@@ -565,6 +565,9 @@ rh_status rh_resample_linear(float *dst, const float *src, uint64_t in_frames, u
         uint32_t kb = 32;
         if (const char *k = rh::knob(rh::K_PCM_TILE_KB)) kb = (uint32_t)std::atoi(k);
         if (kb < 1 || kb > 48) kb = 32;
+        const double per_frame0 = 4.0 * channels * (1.0 + (double)g.F / (double)g.T);
+        if (!rh::knob(rh::K_PCM_TILE_KB))  // a short row (a chain's block): smaller tiles, so that the launch is more than a handful of workgroups
+            while (kb > 8 && (double)g.out_frames * per_frame0 < 128.0 * kb * 1024.0) kb /= 2;
         const double per_frame = 4.0 * channels * (1.0 + (double)g.F / (double)g.T);
         uint64_t tf = (uint64_t)(kb * 1024.0 / per_frame) & ~3ull;
         {   // whole periods of the converter where they fit: a tile that starts on a tap (tile_frames a multiple of T) finds its place in the row
