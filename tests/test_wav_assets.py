@@ -55,6 +55,31 @@ def test_probe_walks_the_reference_assets(rh, name, ch, bits, is_float, offset):
     assert (d.ndim == 1) == (ch == 1) and (ch == 1 or d.shape[1] == ch)
 
 
+def test_probe_survives_damaged_files(rh):
+    """The RIFF walk on the host (rh_wav_probe_host) over what real files look like after an accident: the six assets cut at random places and with
+    random bytes of their chunk headers overwritten -- it refuses or it answers, and what it answers lies inside the bytes it was given (no read
+    past the end: the image is handed over in a buffer of exactly its size)."""
+    rng = np.random.default_rng(2024)
+    n_ok = n_refused = 0
+    for name, *_ in FILES:
+        b = open(os.path.join(WAVS, name), "rb").read()
+        head = min(len(b), 256)
+        for _ in range(300):
+            img = bytearray(b[: int(rng.integers(0, len(b) + 1))] if rng.random() < 0.5 else b)
+            for _ in range(int(rng.integers(0, 4))):
+                if len(img):
+                    img[int(rng.integers(0, min(head, len(img))))] = int(rng.integers(0, 256))
+            try:
+                w = rh.wav_probe(bytes(img))
+            except rh.RhError:
+                n_refused += 1
+                continue
+            n_ok += 1
+            assert w["data_offset"] + w["data_bytes"] <= len(img) and w["channels"] >= 1 and w["sample_rate"] >= 1
+            assert w["samples"] * ((w["bits_per_sample"] + 7) // 8) <= w["data_bytes"]
+    assert n_ok > 100 and n_refused > 100
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,ch,bits,is_float,offset", FILES)
 def test_decode_of_the_reference_assets(rh, name, ch, bits, is_float, offset):
