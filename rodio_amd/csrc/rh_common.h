@@ -91,7 +91,8 @@ hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t hs);
 // What the FUSED converter without a filter does (div_lerp below; the only kernel family that needs the short form -- the stand-alone converter
 // measured the same with the IEEE division and simply divides): (i) lerp_div_fast_ok(T) CHECKS the T of a plan once per process -- every mantissa,
 // both signs, three binades (the quotient scales with t as long as nothing underflows) against the IEEE division on the device -- and caches the
-// answer; a T that fails gets r = 0: the IEEE division; (ii) zeros and infinities take q0, which is the IEEE answer for them; (iii) nonzero
+// answer; a T that fails gets r = 0: the IEEE division; (ii) zeros and infinities are put right by v_div_fixup_f32 (forms 1 and 2 of div_check.hip: no
+// mismatch left above 2^-119 for any T tried); (iii) nonzero
 // |t| < 2^-120 -- 1e-36, the last samples of a tail that decays into subnormals -- may come out one unit of THEIR last place off (1e-45 absolute):
 // the one place where the unfiltered fused mix is not the reference's bits (a guard per sample cost the kernel a quarter of its rate, 0.78 -> 0.57
 // of the roofline; tests/test_gpu_parity.py::test_lerp_division_*).  RH_LERP_IEEE_DIV=1: the IEEE division everywhere.
@@ -147,7 +148,8 @@ __device__ __forceinline__ float div_lerp(float t, float Tf, float rcpT) {
     const float q0 = t * rcpT;
     const float rem = __builtin_fmaf(-q0, Tf, t);
     const float q = __builtin_fmaf(rem, rcpT, q0);
-    return __builtin_amdgcn_classf(t, 0x264) ? q0 : q;  // +-0 and +-Inf: q0 is the quotient (the residual would make +0 of -0 and NaN of Inf)
+    return __builtin_amdgcn_div_fixupf(q, Tf, t);  // v_div_fixup_f32, the instruction the IEEE sequence itself ends with: -0 for t = -0, Inf for Inf (the residual
+                                                   // makes +0 and NaN of them), q otherwise -- the same values as a class test and a select of q0, one instruction less
 }
 // src[q .. q+3] for a row of n samples, q of any sign and alignment; 0.0 where q + j is outside [0, n).  Inside, two aligned 16-byte loads
 // (the second one is the next lane's first: an L1 hit) and a pick by the address' residue -- the same for every lane of a launch.  The

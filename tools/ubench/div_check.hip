@@ -8,13 +8,18 @@
 #include <cstdio>
 #include <cstdlib>
 
+// FORM 0: the bare three instructions; 1: + a class test and a select (zeros and infinities take q0: what rh_common.h's div_lerp ships);
+// 2: + v_div_fixup_f32, the instruction the IEEE sequence itself ends with
+template <int FORM>
 __global__ void k_check(float Tf, float rcpT, unsigned long long *bad_by_exp, unsigned long long *bad_zero_sign) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
         const float t = __uint_as_float((uint32_t)b);
         const float q0 = t * rcpT;
         const float rem = __builtin_fmaf(-q0, Tf, t);
-        const float q = __builtin_fmaf(rem, rcpT, q0);
+        float q = __builtin_fmaf(rem, rcpT, q0);
+        if (FORM == 1) q = __builtin_amdgcn_classf(t, 0x264) ? q0 : q;
+        if (FORM == 2) q = __builtin_amdgcn_div_fixupf(q, Tf, t);
         const float ref = t / Tf;
         const bool both_nan = (q != q) && (ref != ref);
         if (!both_nan && __float_as_uint(q) != __float_as_uint(ref)) {
@@ -30,8 +35,11 @@ int main(int argc, char **argv) {
     for (int a = 1; a < argc; ++a) {
         const uint32_t T = (uint32_t)std::strtoul(argv[a], nullptr, 10);
         const float Tf = (float)T, rcpT = 1.0f / Tf;
+      for (int form = 0; form < 3; ++form) {
         hipMemset(d, 0, 257 * 8);
-        hipLaunchKernelGGL(k_check, dim3(256 * 32), dim3(256), 0, 0, Tf, rcpT, d, d + 256);
+        if (form == 0) hipLaunchKernelGGL(k_check<0>, dim3(256 * 32), dim3(256), 0, 0, Tf, rcpT, d, d + 256);
+        else if (form == 1) hipLaunchKernelGGL(k_check<1>, dim3(256 * 32), dim3(256), 0, 0, Tf, rcpT, d, d + 256);
+        else hipLaunchKernelGGL(k_check<2>, dim3(256 * 32), dim3(256), 0, 0, Tf, rcpT, d, d + 256);
         unsigned long long h[257];
         hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
         unsigned long long total = 0;
@@ -42,13 +50,14 @@ int main(int argc, char **argv) {
                 if (lo < 0) lo = e;
                 hi = e;
             }
-        std::printf("T = %u: %llu mismatching values of t (biased exponents %d .. %d), %llu that differ in the sign of a zero\n", T, total, lo, hi, h[256]);
+        std::printf("T = %u, form %d: %llu mismatching values of t (biased exponents %d .. %d), %llu that differ in the sign of a zero\n", T, form, total, lo, hi, h[256]);
         if (total) {
             std::printf("   by biased exponent:");
             for (int e = 0; e < 256; ++e)
                 if (h[e]) std::printf(" %d:%llu", e, h[e]);
             std::printf("\n");
         }
+      }
     }
     return 0;
 }
